@@ -1,0 +1,191 @@
+/*
+ * pdmp_mi355.h -- C ABI of libpdmp_mi355.so, the MI355X (gfx950) ensemble engine for the PDMP event loop.
+ *
+ * The reference (ZigZagBoomerang.jl @ v0.13.2) has no FFI: its boundary is the Julia method signatures
+ *     spdmp(∇ϕ, t0, x0, θ0, T, c, [G,] F::ZigZag, args...; factor, adapt, seed) -> Ξ,(t,x,θ),(acc,num),c
+ *                                                               (src/sfact.jl:162-163,211,214)
+ *     pdmp (∇ϕ, ...same...)                = spdmp(..., All(), ...)   (src/sfact.jl:236)
+ *     pdmp (∇ϕ!, t0,x0,θ0,T,c, B::BouncyParticle; ...)               (src/not_fact_samplers.jl:117,395)
+ *     sspdmp(∇ϕ, t0,x0,θ0,T,c, [G,] F::ZigZag, κ, args...; ...)       (src/ss_fact.jl:159-160,217)
+ * Each entry point below names the reference lines it replaces.  A Julia `ccall` shim that keeps those
+ * signatures is shown in INTEGRATION.md; the Python mirror lives in zigzagboomerang.jl_amd/samplers.py.
+ *
+ * Conventions
+ *   - plain C, caller-owned HOST pointers unless a name ends in `_dev`; the library never frees caller
+ *     memory and never keeps a caller pointer after the call returns;
+ *   - coordinates are 0-based (the Julia shim adds 1); matrices are CSC with int64 colptr/rowval,
+ *     rows ascending inside a column (SparseArrays layout, src/common.jl:17-20);
+ *   - return codes, never exceptions; per-chain status words replace the reference's `error(...)`
+ *     (src/sfact.jl:124): one diverged chain never aborts the ensemble;
+ *   - one ensemble is bound to one HIP device; calls on one ensemble must be serialised by the caller,
+ *     different ensembles are independent (no globals except the thread-local error string);
+ *   - a user gradient closure cannot cross a C ABI: targets are an enumerated set (Gaussian CSC now).
+ *   - randomness: chain k draws from Philox4x32-10 keyed by seeds[k]; draw order is the reference's
+ *     `rand(rng)` call order (include/pdmp_detmath.h, oracle/pdmp_oracle.h).
+ */
+#ifndef PDMP_MI355_H
+#define PDMP_MI355_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDMP_ABI_VERSION 1
+
+typedef enum {
+    PDMP_OK = 0,
+    PDMP_ERR_INVALID = 1,     /* bad argument / call order */
+    PDMP_ERR_NO_DEVICE = 2,   /* no gfx950 HIP device: the engine has NO CPU fallback */
+    PDMP_ERR_HIP = 3,         /* a HIP runtime call failed; see pdmp_last_error() */
+    PDMP_ERR_UNSUPPORTED = 4, /* configuration outside what the kernels implement */
+    PDMP_ERR_NOMEM = 5
+} pdmp_status;
+
+/* sampler = which reference driver the ensemble reproduces */
+#define PDMP_SAMPLER_ZIGZAG_LOCAL 0 /* spdmp, G = Matched()      src/sfact.jl:73-145,214 */
+#define PDMP_SAMPLER_ZIGZAG_ALL 1   /* pdmp,  G = All()          src/sfact.jl:236        */
+#define PDMP_SAMPLER_BPS 2          /* pdmp,  BouncyParticle     src/not_fact_samplers.jl:52-147 */
+#define PDMP_SAMPLER_STICKY_ZIGZAG 3 /* sspdmp                   src/ss_fact.jl:78-215   */
+
+/* per-chain status words */
+#define PDMP_CHAIN_OK 0
+#define PDMP_CHAIN_BOUND_VIOLATED 1 /* l >= lb with adapt = false (reference: error, src/sfact.jl:124) */
+#define PDMP_CHAIN_STALLED 2        /* queue minimum is +Inf */
+#define PDMP_CHAIN_TRACE_FULL 3     /* trace buffer full: drain with pdmp_ensemble_trace_* and run again */
+
+/* run flags */
+#define PDMP_RUN_REFERENCE_TAIL 0 /* `while t′ < T` (src/sfact.jl:199): the last event has t′ >= T        */
+#define PDMP_RUN_STOP_BEFORE 1    /* pause BEFORE popping a key >= T (slice boundary; resumable, exact)  */
+
+typedef struct pdmp_ensemble pdmp_ensemble;
+
+typedef struct {
+    uint32_t struct_size; /* sizeof(pdmp_config), for ABI growth */
+    int32_t device;       /* HIP device ordinal */
+    int32_t sampler;      /* PDMP_SAMPLER_* */
+    int32_t adapt;        /* kwarg adapt  (src/sfact.jl:163) */
+    double factor;        /* kwarg factor (src/sfact.jl:163: 1.8; BPS 2.0; sticky 1.5) */
+    int64_t nchains;      /* ensemble width on THIS device */
+    int64_t d;            /* dimension */
+    int64_t trace_capacity; /* events kept per chain (0: count only, no trace) */
+} pdmp_config;
+
+/* One FactTrace event (t[i], i, x[i], θ[i]) after the flip: src/sfact.jl:50-52, src/trace.jl:38. 32 bytes. */
+typedef struct {
+    double t;
+    int64_t i; /* 0-based */
+    double x;
+    double theta;
+} pdmp_event;
+
+/* Per-chain counters (the reference returns (acc, num); src/sfact.jl:211). */
+typedef struct {
+    double t_last;      /* t′ of the last processed event/proposal */
+    uint64_t num;       /* proposals                (num, src/sfact.jl:120) */
+    uint64_t nacc;      /* accepted reflections     (sum(acc), :122)        */
+    uint64_t nrefresh;  /* refresh events           (:78-114)               */
+    uint64_t ntrace;    /* events currently in the trace buffer             */
+    uint64_t nevents;   /* events emitted since set_state (never reset)     */
+    uint64_t ndraw_main;
+    uint64_t ndraw_global;
+    uint32_t status;    /* PDMP_CHAIN_* */
+    uint32_t reserved;
+} pdmp_chain_counters;
+
+const char* pdmp_last_error(void);
+int pdmp_abi_version(void);
+/* number of usable gfx950 devices (0 if none / HIP not initialisable) */
+int pdmp_device_count(void);
+
+/*
+ * Test hook: evaluate the shared numerical contract (include/pdmp_detmath.h) on the device for draws
+ * k = 0..n-1 of `seed`; out is [6 x n] row-major: u01, pdmp_log(u), a/b, sqrt, poisson_time, pdmp_randn.
+ * A host evaluation of the same expressions must agree bit-for-bit (tests/test_gpu_detmath.py).
+ */
+pdmp_status pdmp_debug_math_probe(int device, uint64_t seed, int64_t n, double* out);
+
+pdmp_status pdmp_ensemble_create(const pdmp_config* cfg, pdmp_ensemble** out);
+void pdmp_ensemble_destroy(pdmp_ensemble* ens);
+
+/*
+ * Flow Z = ZigZag(Γ, μ, σ; λref, ρ) (src/types.jl:19-27).  Γ is the BOUNDING precision used by ab()
+ * (src/fact_samplers.jl:50-54); its column pattern defines G1 (src/sfact.jl:170) and G2 (:178).
+ * sigma may be NULL (ones).  lambda_ref > 0 enables the refresh clock (src/sfact.jl:78-114,188-190).
+ */
+pdmp_status pdmp_ensemble_set_flow_zigzag(pdmp_ensemble* ens, const int64_t* colptr, const int64_t* rowval,
+                                          const double* nzval, const double* mu, const double* sigma,
+                                          double lambda_ref, double rho);
+
+/*
+ * Target ∇ϕ(x, i) = Γt[:,i]·x  [ − Γt[:,i]·μt ]  (idot, src/common.jl:16-24; closure of
+ * scripts/gaussianrandomfield.jl:25, test/maintest.jl:9).  The pattern of Γt must be contained in the
+ * flow's Γ pattern (the reference reads only x[j], j in G[i]: src/sfact.jl:116).  mu may be NULL.
+ * Must be called after set_flow_zigzag.
+ */
+pdmp_status pdmp_ensemble_set_target_gaussian_csc(pdmp_ensemble* ens, const int64_t* colptr,
+                                                  const int64_t* rowval, const double* nzval,
+                                                  const double* mu);
+
+/*
+ * Initial state (src/sfact.jl:164-190): x0, theta0 are [nchains x d] row-major; c is [d] (copied; with
+ * adapt each chain gets its own copy, returned by final_state -- no hidden mutation of caller memory,
+ * unlike src/fact_samplers.jl:68); seeds is [nchains].  Computes b[i] = ab(...) and the initial queue
+ * Q[i] = poisson_time(b[i], rand(rng)) ON THE DEVICE, drawing the first d uniforms of each chain in
+ * order i = 0..d-1 (:184-187; like the reference, t0 is not added to the initial keys).
+ */
+pdmp_status pdmp_ensemble_set_state(pdmp_ensemble* ens, double t0, const double* x0, const double* theta0,
+                                    const double* c, const uint64_t* seeds);
+
+/*
+ * Synthetic initial state generated on the device (benchmarks): seeds[k] = seed0 + k,
+ * x0[k][i] = randn (Philox stream PDMP_STREAM_INIT, draw i), theta0[k][i] = ±1 (draw d+i)
+ * -- the shape of scripts/gaussianrandomfield.jl:29-30.
+ */
+pdmp_status pdmp_ensemble_set_state_synthetic(pdmp_ensemble* ens, double t0, const double* c, uint64_t seed0);
+
+/*
+ * Advance every chain to time T (the `while t′ < T` driver loop, src/sfact.jl:199-208, around
+ * spdmp_inner!, :73-145).  Asynchronous on `stream` (a hipStream_t, NULL = the ensemble's own stream);
+ * re-entrant: calling run again with a larger T continues the same event sequence.
+ */
+pdmp_status pdmp_ensemble_run(pdmp_ensemble* ens, double T, int flags, void* stream);
+pdmp_status pdmp_ensemble_sync(pdmp_ensemble* ens);
+/* duration of the most recent run's event-loop kernel, from HIP events recorded on its stream (syncs) */
+pdmp_status pdmp_ensemble_last_run_ms(pdmp_ensemble* ens, float* ms);
+
+pdmp_status pdmp_ensemble_counters(pdmp_ensemble* ens, pdmp_chain_counters* out /* [nchains] */);
+/* sum over chains of num / nacc / nevents, reduced on the host from the counters */
+pdmp_status pdmp_ensemble_totals(pdmp_ensemble* ens, uint64_t* num, uint64_t* nacc, uint64_t* nevents);
+
+/* trace access (FactTrace.events, src/trace.jl:7-13): copy events [first, first+count) of one chain */
+pdmp_status pdmp_ensemble_trace_copy(pdmp_ensemble* ens, int64_t chain, int64_t first, int64_t count,
+                                     pdmp_event* out);
+/* forget buffered events (after draining them); clears PDMP_CHAIN_TRACE_FULL */
+pdmp_status pdmp_ensemble_trace_reset(pdmp_ensemble* ens);
+
+/*
+ * Final state of chains [chain_first, chain_first+n): per-coordinate clocks t, positions x, velocities θ
+ * (NOT advanced to T, src/sfact.jl:210-211), accept counts acc (int64, :182) and bounds c.  Any output
+ * pointer may be NULL.  All arrays are [n x d] row-major.
+ */
+pdmp_status pdmp_ensemble_final_state(pdmp_ensemble* ens, int64_t chain_first, int64_t n, double* t, double* x,
+                                      double* theta, int64_t* acc, double* c);
+
+/*
+ * Path integrals for ESS / moments (no counterpart in the reference; the integrand is the one of
+ * mean(trace), src/trace.jl:182-200).  Requires all chains paused with PDMP_RUN_STOP_BEFORE at time T.
+ * Adds, for this batch [T_prev, T], Y = (1/ΔT) ∫ x_i dt per chain and accumulates over chains:
+ *   sum_y[i] += Y, sum_y2[i] += Y*Y   (device reduction; outputs are host [d] arrays, may be NULL)
+ */
+pdmp_status pdmp_ensemble_batch_means(pdmp_ensemble* ens, double T_prev, double T, double* sum_y, double* sum_y2);
+
+/* raw device pointers for zero-copy consumers (e.g. an RCCL gather of trace segments) */
+pdmp_status pdmp_ensemble_trace_dev(pdmp_ensemble* ens, void** events_dev, int64_t* capacity);
+pdmp_status pdmp_ensemble_counters_dev(pdmp_ensemble* ens, void** counters_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDMP_MI355_H */

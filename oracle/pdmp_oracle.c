@@ -1,0 +1,960 @@
+/*
+ * pdmp_oracle.c -- CPU ORACLE (test infrastructure only; see pdmp_oracle.h for the parity status).
+ *
+ * Every function cites the reference lines (relative to /root/reference) it restates.  The arithmetic
+ * is written operation by operation in the order Julia evaluates it; the file is compiled with
+ * -ffp-contract=off so that no a*b+c is fused.
+ */
+#include "pdmp_oracle.h"
+#include "../include/pdmp_detmath.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+/* ------------------------------------------------------------------ small helpers */
+
+/* pos(x) = max(zero(x), x), src/common.jl:8 */
+static inline double pos(double x) {
+    return (x > 0.0) ? x : ((x != x) ? x : 0.0);
+}
+
+void orc_trace_init(orc_trace* tr) {
+    tr->ev = NULL;
+    tr->n = 0;
+    tr->cap = 0;
+}
+void orc_trace_free(orc_trace* tr) {
+    free(tr->ev);
+    tr->ev = NULL;
+    tr->n = tr->cap = 0;
+}
+static void trace_push(orc_trace* tr, double t, int64_t i, double x, double th) {
+    if (!tr) return;
+    if (tr->n == tr->cap) {
+        tr->cap = tr->cap ? 2 * tr->cap : 1024;
+        tr->ev = (orc_event*)realloc(tr->ev, (size_t)tr->cap * sizeof(orc_event));
+    }
+    tr->ev[tr->n].t = t;
+    tr->ev[tr->n].i = i;
+    tr->ev[tr->n].x = x;
+    tr->ev[tr->n].theta = th;
+    tr->n++;
+}
+
+/* ------------------------------------------------------------------ src/poissontime.jl */
+
+/* poisson_time(a, b, u), src/poissontime.jl:8-30 */
+double orc_poisson_time(double a, double b, double u) {
+    if (b > 0) {
+        if (a < 0) {
+            return sqrt(-pdmp_log(u) * 2.0 / b) - a / b; /* :11 */
+        } else {
+            return sqrt((a / b) * (a / b) - pdmp_log(u) * 2.0 / b) - a / b; /* :13 */
+        }
+    } else if (b == 0) {
+        if (a > 0) {
+            return -pdmp_log(u) / a; /* :17 */
+        } else {
+            return INFINITY; /* :19 */
+        }
+    } else {
+        if (a <= 0) {
+            return INFINITY; /* :23 */
+        } else if (-pdmp_log(u) <= -(a * a) / b + (a * a) / (2 * b)) { /* :24 */
+            return -sqrt((a / b) * (a / b) - pdmp_log(u) * 2.0 / b) - a / b; /* :25 */
+        } else {
+            return INFINITY; /* :27 */
+        }
+    }
+}
+
+/* poisson_time((a,b,c), u), src/poissontime.jl:39-65 : rate c + (a + b t)^+ */
+double orc_poisson_time3(double a, double b, double c, double u) {
+    double lu = pdmp_log(u);
+    if (b > 0) {
+        if (a < 0) {
+            if (-c * a / b + lu < 0.0) {
+                return sqrt(-2 * b * lu + c * c + 2 * a * c) / b - (a + c) / b; /* :43 */
+            } else {
+                return -lu / c; /* :45 */
+            }
+        } else {
+            return sqrt(-lu * 2.0 * b + (a + c) * (a + c)) / b - (a + c) / b; /* :48 */
+        }
+    } else if (b == 0) {
+        if (a > 0) {
+            return -lu / (a + c); /* :52 */
+        } else {
+            return -lu / c; /* :54 */
+        }
+    } else {
+        if (a <= 0.0) {
+            return -lu / c; /* :58 */
+        } else if (-c * a / b - (a * a) / (2 * b) + lu > 0.0) {
+            return +sqrt((a + c) * (a + c) - 2.0 * lu * b) / b - (a + c) / b; /* :60 */
+        } else {
+            return (-lu + (a * a) / (2 * b)) / c; /* :62 */
+        }
+    }
+}
+
+/* idot(A::SparseMatrixCSC, j, x), src/common.jl:16-24 : sequential sum in CSC (ascending row) order */
+double orc_idot(const orc_csc* A, int64_t j, const double* x) {
+    double s = 0.0;
+    for (int64_t p = A->colptr[j]; p < A->colptr[j + 1]; ++p) {
+        s += A->nzval[p] * x[A->rowval[p]];
+    }
+    return s;
+}
+
+/* ------------------------------------------------------------------ src/priorityqueue.jl */
+
+struct orc_pq {
+    int64_t len, cap;
+    int64_t* xs_key; /* 1-based heap positions, xs[k] = key => val */
+    double* xs_val;
+    int64_t* index;  /* key -> heap position */
+};
+
+/* isless on Float64 (Base): NaN sorts last, -0.0 < 0.0 */
+static inline int f_isless(double a, double b) {
+    if (a != a) return 0;
+    if (b != b) return 1;
+    if (a < b) return 1;
+    if (a == b) return signbit(a) && !signbit(b);
+    return 0;
+}
+
+orc_pq* orc_pq_new(int64_t capacity) {
+    orc_pq* q = (orc_pq*)calloc(1, sizeof(orc_pq));
+    q->cap = capacity;
+    q->xs_key = (int64_t*)malloc((size_t)(capacity + 1) * sizeof(int64_t));
+    q->xs_val = (double*)malloc((size_t)(capacity + 1) * sizeof(double));
+    q->index = (int64_t*)malloc((size_t)(capacity + 1) * sizeof(int64_t));
+    return q;
+}
+void orc_pq_free(orc_pq* q) {
+    if (!q) return;
+    free(q->xs_key);
+    free(q->xs_val);
+    free(q->index);
+    free(q);
+}
+int64_t orc_pq_len(const orc_pq* q) {
+    return q->len;
+}
+
+/* percolate_down!, src/priorityqueue.jl:46-61 (on equal children the RIGHT child is taken, :50) */
+static void pq_down(orc_pq* q, int64_t i) {
+    int64_t xk = q->xs_key[i];
+    double xv = q->xs_val[i];
+    int64_t l;
+    while ((l = 2 * i) <= q->len) {
+        int64_t r = 2 * i + 1;
+        int64_t j = (r > q->len || f_isless(q->xs_val[l], q->xs_val[r])) ? l : r;
+        if (f_isless(q->xs_val[j], xv)) {
+            q->index[q->xs_key[j]] = i;
+            q->xs_key[i] = q->xs_key[j];
+            q->xs_val[i] = q->xs_val[j];
+            i = j;
+        } else {
+            break;
+        }
+    }
+    q->index[xk] = i;
+    q->xs_key[i] = xk;
+    q->xs_val[i] = xv;
+}
+/* percolate_up!, src/priorityqueue.jl:63-77 */
+static void pq_up(orc_pq* q, int64_t i) {
+    int64_t xk = q->xs_key[i];
+    double xv = q->xs_val[i];
+    while (i > 1) {
+        int64_t j = i / 2;
+        if (f_isless(xv, q->xs_val[j])) {
+            q->index[q->xs_key[j]] = i;
+            q->xs_key[i] = q->xs_key[j];
+            q->xs_val[i] = q->xs_val[j];
+            i = j;
+        } else {
+            break;
+        }
+    }
+    q->index[xk] = i;
+    q->xs_key[i] = xk;
+    q->xs_val[i] = xv;
+}
+/* enqueue!, src/priorityqueue.jl:107-117 (keys must arrive in order) */
+void orc_pq_enqueue(orc_pq* q, int64_t key, double val) {
+    if (q->len != key || q->len >= q->cap) abort(); /* "Elements must be enqueue! in order" */
+    q->len++;
+    q->xs_key[q->len] = key;
+    q->xs_val[q->len] = val;
+    q->index[key] = q->len;
+    pq_up(q, q->len);
+}
+/* setindex!, src/priorityqueue.jl:95-105 */
+void orc_pq_set(orc_pq* q, int64_t key, double val) {
+    int64_t i = q->index[key];
+    double old = q->xs_val[i];
+    q->xs_val[i] = val;
+    if (f_isless(old, val)) {
+        pq_down(q, i);
+    } else {
+        pq_up(q, i);
+    }
+}
+double orc_pq_get(const orc_pq* q, int64_t key) {
+    return q->xs_val[q->index[key]];
+}
+/* peek, src/priorityqueue.jl:44 */
+void orc_pq_peek(const orc_pq* q, int64_t* key, double* val) {
+    *key = q->xs_key[1];
+    *val = q->xs_val[1];
+}
+int orc_pq_check(const orc_pq* q) {
+    for (int64_t i = 1; i <= q->len; ++i) {
+        if (q->index[q->xs_key[i]] != i) return 0;
+        if (i > 1 && f_isless(q->xs_val[i], q->xs_val[i / 2])) return 0;
+    }
+    return 1;
+}
+
+/* ------------------------------------------------------------------ neighbourhood graphs */
+
+typedef struct {
+    int64_t* ptr; /* d+1 */
+    int64_t* idx;
+} nbr_graph;
+
+static void graph_free(nbr_graph* g) {
+    free(g->ptr);
+    free(g->idx);
+    g->ptr = g->idx = NULL;
+}
+
+/* G1[i] = rowvals(F.Γ)[nzrange(F.Γ, i)], src/sfact.jl:170 */
+static nbr_graph graph_g1(const orc_csc* A) {
+    nbr_graph g;
+    int64_t d = A->n;
+    g.ptr = (int64_t*)malloc((size_t)(d + 1) * sizeof(int64_t));
+    g.idx = (int64_t*)malloc((size_t)A->colptr[d] * sizeof(int64_t) + 8);
+    memcpy(g.ptr, A->colptr, (size_t)(d + 1) * sizeof(int64_t));
+    memcpy(g.idx, A->rowval, (size_t)A->colptr[d] * sizeof(int64_t));
+    return g;
+}
+
+static int cmp_i64(const void* a, const void* b) {
+    int64_t x = *(const int64_t*)a, y = *(const int64_t*)b;
+    return (x > y) - (x < y);
+}
+
+/* G2[i] = setdiff(union(G1[j] for j in G1[i]), G[i]), src/sfact.jl:178 (stored ascending; the order of
+ * a neighbourhood only fixes the order of independent per-coordinate moves) */
+static nbr_graph graph_g2(const nbr_graph* g1, int64_t d) {
+    nbr_graph g;
+    g.ptr = (int64_t*)malloc((size_t)(d + 1) * sizeof(int64_t));
+    int64_t cap = 16 * d + 16, n = 0;
+    g.idx = (int64_t*)malloc((size_t)cap * sizeof(int64_t));
+    int64_t* tmp = NULL;
+    int64_t tmpcap = 0;
+    for (int64_t i = 0; i < d; ++i) {
+        g.ptr[i] = n;
+        int64_t m = 0;
+        for (int64_t p = g1->ptr[i]; p < g1->ptr[i + 1]; ++p) {
+            int64_t j = g1->idx[p];
+            m += g1->ptr[j + 1] - g1->ptr[j];
+        }
+        if (m > tmpcap) {
+            tmpcap = 2 * m;
+            tmp = (int64_t*)realloc(tmp, (size_t)tmpcap * sizeof(int64_t));
+        }
+        m = 0;
+        for (int64_t p = g1->ptr[i]; p < g1->ptr[i + 1]; ++p) {
+            int64_t j = g1->idx[p];
+            for (int64_t q = g1->ptr[j]; q < g1->ptr[j + 1]; ++q) tmp[m++] = g1->idx[q];
+        }
+        qsort(tmp, (size_t)m, sizeof(int64_t), cmp_i64);
+        int64_t last = -1;
+        for (int64_t k = 0; k < m; ++k) {
+            int64_t v = tmp[k];
+            if (v == last) continue;
+            last = v;
+            /* setdiff with G[i] = G1[i] (Matched) */
+            int in_g = 0;
+            for (int64_t p = g1->ptr[i]; p < g1->ptr[i + 1]; ++p) {
+                if (g1->idx[p] == v) {
+                    in_g = 1;
+                    break;
+                }
+            }
+            if (in_g) continue;
+            if (n == cap) {
+                cap *= 2;
+                g.idx = (int64_t*)realloc(g.idx, (size_t)cap * sizeof(int64_t));
+            }
+            g.idx[n++] = v;
+        }
+    }
+    g.ptr[d] = n;
+    free(tmp);
+    return g;
+}
+
+/* ------------------------------------------------------------------ local ZigZag: src/sfact.jl */
+
+typedef struct {
+    int64_t d;
+    const orc_zz_params* p;
+    nbr_graph g1, g2;
+    double* gmu_bound;  /* idot(Z.Γ, i, Z.μ), src/fact_samplers.jl:51 */
+    double* gmu_target; /* idot(Γt, i, μt) or NULL */
+} zz_ctx;
+
+/* smove_forward!(i::Int, ...), src/sfact.jl:13-16 */
+static inline void move1(int64_t j, double* t, double* x, const double* th, double tp) {
+    x[j] = x[j] + th[j] * (tp - t[j]);
+    t[j] = tp;
+}
+/* smove_forward!(G, i, ...), src/sfact.jl:6-12 */
+static inline void move_nbrs(const nbr_graph* g, int64_t i, double* t, double* x, const double* th, double tp) {
+    for (int64_t p = g->ptr[i]; p < g->ptr[i + 1]; ++p) move1(g->idx[p], t, x, th, tp);
+}
+/* smove_forward!(t, x, θ, t′, Z), src/sfact.jl:23-28 */
+static inline void move_all(int64_t d, double* t, double* x, const double* th, double tp) {
+    for (int64_t j = 0; j < d; ++j) move1(j, t, x, th, tp);
+}
+
+/* ab(G, i, x, θ, c, Z::ZigZag), src/fact_samplers.jl:50-54 with loosen(c,x) = c + x (:41) */
+static inline void zz_ab(const orc_csc* G, const double* gmu, int64_t i, const double* x, const double* th,
+                         const double* c, double* a, double* b) {
+    *a = c[i] + (orc_idot(G, i, x) - gmu[i]) * th[i];
+    *b = c[i] / 100 + th[i] * orc_idot(G, i, th);
+}
+
+/* ∇ϕ(x, i, Γ) = idot(Γ, i, x), scripts/gaussianrandomfield.jl:25, test/maintest.jl:9 */
+static inline double zz_grad(const zz_ctx* cx, int64_t i, const double* x) {
+    double g = orc_idot(cx->p->target_gamma, i, x);
+    if (cx->gmu_target) g = g - cx->gmu_target[i];
+    return g;
+}
+
+int orc_spdmp_zigzag(int64_t d, const orc_zz_params* p, double t0, double T, double* x, double* th,
+                     double* c, double* t, int64_t* acc, orc_trace* tr, orc_zz_result* res) {
+    zz_ctx cx;
+    cx.d = d;
+    cx.p = p;
+    cx.g1 = graph_g1(p->bound_gamma);
+    if (!p->move_all) {
+        cx.g2 = graph_g2(&cx.g1, d); /* src/sfact.jl:178 */
+    } else {
+        cx.g2.ptr = cx.g2.idx = NULL; /* G2 = nothing, src/sfact.jl:175 */
+    }
+    cx.gmu_bound = (double*)malloc((size_t)d * sizeof(double));
+    for (int64_t i = 0; i < d; ++i) cx.gmu_bound[i] = orc_idot(p->bound_gamma, i, p->bound_mu);
+    cx.gmu_target = NULL;
+    if (p->target_mu) {
+        cx.gmu_target = (double*)malloc((size_t)d * sizeof(double));
+        for (int64_t i = 0; i < d; ++i) cx.gmu_target[i] = orc_idot(p->target_gamma, i, p->target_mu);
+    }
+    const int hasrefresh = p->lambda_ref > 0; /* src/fact_samplers.jl:19 */
+    const uint64_t seed = p->seed;
+    uint64_t nm = 0, ng = 0; /* draw counters: main stream, "global rng" stream */
+
+    double* t_old = (double*)malloc((size_t)d * sizeof(double));
+    double* ba = (double*)malloc((size_t)d * sizeof(double));
+    double* bb = (double*)malloc((size_t)d * sizeof(double));
+    for (int64_t i = 0; i < d; ++i) {
+        t[i] = t0; /* src/sfact.jl:168 */
+        t_old[i] = t0;
+        acc[i] = 0;
+    }
+    orc_pq* Q = orc_pq_new(d + 1);
+    for (int64_t i = 0; i < d; ++i) zz_ab(p->bound_gamma, cx.gmu_bound, i, x, th, c, &ba[i], &bb[i]); /* :184 */
+    for (int64_t i = 0; i < d; ++i) {
+        /* :186  enqueue!(Q, i => poisson_time(b[i], rand(rng)))   (t0 is NOT added in the reference) */
+        orc_pq_enqueue(Q, i, orc_poisson_time(ba[i], bb[i], pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)));
+    }
+    if (hasrefresh) {
+        /* :189  waiting_time_ref(rng, F) = randexp(rng)/λref, src/dynamics.jl:100 */
+        orc_pq_enqueue(Q, d, -pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)) / p->lambda_ref);
+    }
+
+    int64_t num = 0, nacc = 0, nrefresh = 0;
+    int status = ORC_OK;
+    double tp = t0; /* t′ */
+    int done = 0;
+    /* driver loop `while t′ < T`, src/sfact.jl:199-208, around spdmp_inner!, :73-145 */
+    while (!done && tp < T) {
+        for (;;) { /* spdmp_inner!: while true */
+            int64_t i;
+            double tq;
+            orc_pq_peek(Q, &i, &tq); /* :77 */
+            if (p->stop_before_T && !(tq < T)) {
+                done = 1;
+                break;
+            }
+            if (tq == INFINITY) {
+                status = ORC_STALLED;
+                done = 1;
+                break;
+            }
+            tp = tq;
+            int refresh = i >= d; /* :78 */
+            if (refresh) i = (int64_t)pdmp_randint(seed, PDMP_STREAM_GLOBAL, ng++, (uint32_t)d); /* :80 */
+            if (p->move_all) {
+                move_all(d, t, x, th, tp); /* :19 */
+            } else {
+                move_nbrs(&cx.g1, i, t, x, th, tp); /* :82 (G = G1, Matched) */
+            }
+            if (refresh) {
+                i = (int64_t)pdmp_randint(seed, PDMP_STREAM_GLOBAL, ng++, (uint32_t)d); /* :84 */
+                if (!p->move_all) move_nbrs(&cx.g2, i, t, x, th, tp);                    /* :85 */
+                /* :100-101  θ[i] = F.σ[i]*rand(rng, (-1,1)) */
+                double u = pdmp_u01(seed, PDMP_STREAM_MAIN, nm++);
+                th[i] = p->sigma[i] * ((u < 0.5) ? -1.0 : 1.0);
+                /* :108  Q[n+1] = t′ + waiting_time_ref(F)  (global rng) */
+                orc_pq_set(Q, d, tp + (-pdmp_log(pdmp_u01(seed, PDMP_STREAM_GLOBAL, ng++)) / p->lambda_ref));
+                for (int64_t q = cx.g1.ptr[i]; q < cx.g1.ptr[i + 1]; ++q) { /* :110-114 */
+                    int64_t j = cx.g1.idx[q];
+                    zz_ab(p->bound_gamma, cx.gmu_bound, j, x, th, c, &ba[j], &bb[j]);
+                    t_old[j] = t[j];
+                    orc_pq_set(Q, j, t[j] + orc_poisson_time(ba[j], bb[j], pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)));
+                }
+                nrefresh++;
+                trace_push(tr, t[i], i, x[i], th[i]); /* :143 */
+                break;
+            }
+            double gi = zz_grad(&cx, i, x);                     /* :118 */
+            double l = pos(gi * th[i]);                         /* :119, src/fact_samplers.jl:28-30 */
+            double lb = pos(ba[i] + bb[i] * (t[i] - t_old[i])); /* :119, src/sfact.jl:70 */
+            num += 1;                                           /* :120 */
+            if (pdmp_u01(seed, PDMP_STREAM_MAIN, nm++) * lb < l) { /* :121 */
+                acc[i] += 1;
+                nacc += 1;
+                if (l >= lb) { /* :123 */
+                    if (!p->adapt) {
+                        status = ORC_BOUND_VIOLATED; /* :124 error(...) */
+                        done = 1;
+                        break;
+                    }
+                    c[i] *= p->factor; /* :127, src/fact_samplers.jl:67-70 */
+                }
+                if (!p->move_all) move_nbrs(&cx.g2, i, t, x, th, tp); /* :129 */
+                th[i] = -th[i];                                        /* :130, src/dynamics.jl:46-49 */
+                for (int64_t q = cx.g1.ptr[i]; q < cx.g1.ptr[i + 1]; ++q) { /* :131-135 */
+                    int64_t j = cx.g1.idx[q];
+                    zz_ab(p->bound_gamma, cx.gmu_bound, j, x, th, c, &ba[j], &bb[j]);
+                    t_old[j] = t[j];
+                    orc_pq_set(Q, j, t[j] + orc_poisson_time(ba[j], bb[j], pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)));
+                }
+                trace_push(tr, t[i], i, x[i], th[i]); /* :143 with event() :50-52 */
+                break;
+            } else { /* :136-140 */
+                zz_ab(p->bound_gamma, cx.gmu_bound, i, x, th, c, &ba[i], &bb[i]);
+                t_old[i] = t[i];
+                orc_pq_set(Q, i, t[i] + orc_poisson_time(ba[i], bb[i], pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)));
+                continue;
+            }
+        }
+        if (p->max_events > 0 && (nacc + nrefresh) >= p->max_events && !done) {
+            status = ORC_TRACE_LIMIT;
+            done = 1;
+        }
+    }
+    if (res) {
+        res->num = num;
+        res->nacc = nacc;
+        res->nrefresh = nrefresh;
+        res->ndraw_main = nm;
+        res->ndraw_global = ng;
+        res->t_last = tp;
+        res->status = status;
+    }
+    orc_pq_free(Q);
+    free(t_old);
+    free(ba);
+    free(bb);
+    free(cx.gmu_bound);
+    free(cx.gmu_target);
+    graph_free(&cx.g1);
+    if (cx.g2.ptr) graph_free(&cx.g2);
+    return status;
+}
+
+/* ------------------------------------------------------------------ 1-d ZigZag: src/zigzagboom1d.jl */
+
+int64_t orc_pdmp_zigzag1d(double mu, double sigma2, double x, double th, double T, double c, int adapt,
+                          double factor, uint64_t seed, orc_event1d* out, int64_t cap, int64_t* acc_out,
+                          int64_t* num_out) {
+    uint64_t nm = 0;
+    double t = 0.0; /* :35 */
+    int64_t n = 0;
+    if (n < cap) {
+        out[n].t = t;
+        out[n].x = x;
+        out[n].theta = th;
+    }
+    n++; /* :36 */
+    /* t_ref = t + waiting_time_ref(ZigZag1d) = Inf, :19,37 -> the refresh branch :42-46 never fires */
+    int64_t num = 0, acc = 0;
+    double a = c + th * x, b = th * th; /* ab, :15 */
+    double tp = t + orc_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)); /* :40 */
+    while (t < T) {                                                                    /* :41 */
+        double tau = tp - t;                                                           /* :48 */
+        t = tau + t;                                                                   /* move_forward, src/dynamics.jl:66-68 */
+        x = x + th * tau;
+        double gx = (x - mu) / sigma2;  /* ∇ϕ(x), test/test1d.jl:9 */
+        double l = pos(th * gx);        /* λ, :5 */
+        double lb = pos(a + b * tau);   /* λ_bar, :9,50 */
+        num += 1;
+        if (pdmp_u01(seed, PDMP_STREAM_MAIN, nm++) * lb < l) { /* :52 */
+            acc += 1;
+            if (l >= lb) { /* :54 */
+                if (!adapt) return -1;
+                c *= factor;
+            }
+            th = -th; /* :58 */
+            if (n < cap) {
+                out[n].t = t;
+                out[n].x = x;
+                out[n].theta = th;
+            }
+            n++; /* :60 */
+        }
+        a = c + th * x; /* :63 */
+        b = th * th;
+        tp = t + orc_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)); /* :64 */
+    }
+    *acc_out = acc;
+    *num_out = num;
+    return n;
+}
+
+/* ------------------------------------------------------------------ BPS: src/not_fact_samplers.jl */
+
+/*
+ * dot(a, b) over d elements.  The reference calls BLAS ddot (summation order unspecified); the order is
+ * FIXED here to the one a 64-lane wavefront uses: lane l sums elements l, l+64, l+128, ... in order,
+ * then lanes are combined by the xor-butterfly 32,16,8,4,2,1.
+ */
+static double dot_wave64(const double* a, const double* b, int64_t d) {
+    double part[64];
+    for (int l = 0; l < 64; ++l) {
+        double s = 0.0;
+        for (int64_t k = l; k < d; k += 64) s += a[k] * b[k];
+        part[l] = s;
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        double nxt[64];
+        for (int l = 0; l < 64; ++l) nxt[l] = part[l] + part[l ^ off];
+        memcpy(part, nxt, sizeof part);
+    }
+    return part[0];
+}
+
+/* y = Γ (x - μ): Wrapper(∇ϕ!) with ∇ϕ!(y,x) = mul!(y, Γ, x) (test/maintest.jl:163), Γ symmetric so the
+ * CSC column gather equals the row product; per output the sum runs in ascending index order. */
+static void bps_grad(const orc_csc* G, const double* mu, const double* x, double* tmp, double* y, int64_t d) {
+    for (int64_t k = 0; k < d; ++k) tmp[k] = x[k] - mu[k];
+    for (int64_t r = 0; r < d; ++r) y[r] = orc_idot(G, r, tmp);
+}
+
+int orc_pdmp_bps(int64_t d, const orc_bps_params* p, double t0, double T, double* x, double* th, double* t_ev,
+                 double* x_ev, double* th_ev, int64_t ev_cap, orc_bps_result* res) {
+    const uint64_t seed = p->seed;
+    uint64_t nm = 0;
+    double* g = (double*)malloc((size_t)d * sizeof(double));
+    double* tmp = (double*)malloc((size_t)d * sizeof(double));
+    double* gth = (double*)malloc((size_t)d * sizeof(double));
+    double t = t0;
+    double c = p->c;
+    int64_t num = 0, acc = 0, nrefresh = 0, nev = 0;
+    int status = ORC_OK;
+    const double rho = p->rho, rhobar = sqrt(1 - rho * rho); /* src/dynamics.jl:113 */
+
+    double tau_ref = -pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)) / p->lambda_ref; /* :121 */
+    bps_grad(p->gamma, p->mu, x, tmp, g, d);                                             /* :122-123 */
+    /* ab(x, θ, C::GlobalBound, ...) = (C.c + θ'(Γ(x-μ)), θ'(Γθ), Inf), :26-28 */
+    double a = c + dot_wave64(th, g, d);
+    for (int64_t r = 0; r < d; ++r) gth[r] = orc_idot(p->gamma, r, th);
+    double b = dot_wave64(th, gth, d);
+    double tp = t + orc_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)); /* next_time :43-50, :135 */
+
+    while (t < T) { /* :136 */
+        for (;;) {  /* pdmp_inner!, :52-97 */
+            if (tau_ref < tp) { /* :55 refresh */
+                double tau = tau_ref - t;
+                t += tau; /* move_forward!, src/dynamics.jl:11-15 */
+                for (int64_t k = 0; k < d; ++k) x[k] += th[k] * tau;
+                /* refresh!, src/dynamics.jl:112-118 with L = I:  θ .*= ρ; θ .+= ρ̄*randn(rng,d) */
+                for (int64_t k = 0; k < d; ++k) th[k] *= rho;
+                for (int64_t k = 0; k < d; ++k) th[k] += rhobar * pdmp_randn(seed, PDMP_STREAM_MAIN, nm++);
+                bps_grad(p->gamma, p->mu, x, tmp, g, d);                                      /* :58-59 */
+                tau_ref = t + (-pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)) / p->lambda_ref); /* :61 */
+                a = c + dot_wave64(th, g, d);                                                 /* :62 */
+                for (int64_t r = 0; r < d; ++r) gth[r] = orc_idot(p->gamma, r, th);
+                b = dot_wave64(th, gth, d);
+                tp = t + orc_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)); /* :63 */
+                nrefresh++;
+                break; /* :64 return */
+            }
+            /* renew branch :65-71 is unreachable with GlobalBound (abc[3] = Inf) */
+            double tau = tp - t; /* :73 */
+            t += tau;
+            for (int64_t k = 0; k < d; ++k) x[k] += th[k] * tau; /* :74 */
+            bps_grad(p->gamma, p->mu, x, tmp, g, d);              /* :75-76 */
+            double gt = dot_wave64(g, th, d);
+            double l = pos(gt);            /* λ, :14 */
+            double lb = pos(a + b * tau);  /* :77 */
+            num += 1;
+            if (pdmp_u01(seed, PDMP_STREAM_MAIN, nm++) * lb <= l) { /* :79 */
+                acc += 1;
+                if (l > lb) { /* :81 */
+                    if (!p->adapt) {
+                        status = ORC_BOUND_VIOLATED;
+                        goto finish;
+                    }
+                    c *= p->factor; /* :83 */
+                }
+                /* reflect!, src/dynamics.jl:90-93 with L = I: θ .-= (2 dot(∇ϕx,θ)/normsq(∇ϕx)) ∇ϕx */
+                double nrm = dot_wave64(g, g, d);
+                double coef = 2 * gt / nrm;
+                for (int64_t k = 0; k < d; ++k) th[k] -= coef * g[k];
+                /* :86-87 gradient again (x unchanged) */
+                a = c + dot_wave64(th, g, d); /* :88 */
+                for (int64_t r = 0; r < d; ++r) gth[r] = orc_idot(p->gamma, r, th);
+                b = dot_wave64(th, gth, d);
+                tp = t + orc_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)); /* :89 */
+                break;                                                                    /* :90 */
+            } else {
+                a = c + dot_wave64(th, g, d); /* :92 */
+                /* b = θ'Γθ unchanged in value, recomputed by the reference; recompute for bit parity */
+                for (int64_t r = 0; r < d; ++r) gth[r] = orc_idot(p->gamma, r, th);
+                b = dot_wave64(th, gth, d);
+                tp = t + orc_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)); /* :93 */
+            }
+        }
+        /* push!(Ξ, event(t, x, θ, Flow)) = (t, copy(x), copy(θ), nothing), :138, :39-41 */
+        if (nev < ev_cap) {
+            if (t_ev) t_ev[nev] = t;
+            if (x_ev) memcpy(x_ev + nev * d, x, (size_t)d * sizeof(double));
+            if (th_ev) memcpy(th_ev + nev * d, th, (size_t)d * sizeof(double));
+        }
+        nev++;
+        if (p->max_events > 0 && nev >= p->max_events) {
+            status = ORC_TRACE_LIMIT;
+            break;
+        }
+    }
+finish:
+    if (res) {
+        res->num = num;
+        res->nacc = acc;
+        res->nrefresh = nrefresh;
+        res->nevents = nev;
+        res->ndraw_main = nm;
+        res->t_last = t;
+        res->c_out = c;
+        res->status = status;
+    }
+    free(g);
+    free(tmp);
+    free(gth);
+    return status;
+}
+
+/* ------------------------------------------------------------------ sticky ZigZag: src/ss_fact.jl */
+
+/* freezing_time, src/ss_fact.jl:10-16 */
+static inline double freezing_time(double x, double th) {
+    if (th * x >= 0) return INFINITY;
+    return -x / th;
+}
+/* ssmove_forward!(G, i, ...), src/ss_fact.jl:38-45 */
+static inline void ssmove_nbrs(const nbr_graph* g, int64_t i, double* t, double* x, const double* th, double tp) {
+    for (int64_t p = g->ptr[i]; p < g->ptr[i + 1]; ++p) {
+        int64_t j = g->idx[p];
+        if (th[j] != 0.0) move1(j, t, x, th, tp);
+    }
+}
+/* queue_time!, src/ss_fact.jl:54-65 */
+static inline void queue_time(orc_pq* Q, const double* t, const double* x, const double* th, int64_t i,
+                              const double* ba, const double* bb, unsigned char* f, uint64_t seed, uint64_t* nm) {
+    double trefl = orc_poisson_time(ba[i], bb[i], pdmp_u01(seed, PDMP_STREAM_MAIN, (*nm)++));
+    double tfreeze = freezing_time(x[i], th[i]);
+    if (tfreeze <= trefl) {
+        f[i] = 1;
+        orc_pq_set(Q, i, t[i] + tfreeze);
+    } else {
+        f[i] = 0;
+        orc_pq_set(Q, i, t[i] + trefl);
+    }
+}
+
+int orc_sspdmp_zigzag(int64_t d, const orc_sticky_params* p, double t0, double T, double* x, double* th,
+                      double* c, double* t, orc_trace* tr, orc_zz_result* res) {
+    nbr_graph g1 = graph_g1(p->bound_gamma);
+    nbr_graph g2 = graph_g2(&g1, d); /* :172 */
+    double* gmu = (double*)malloc((size_t)d * sizeof(double));
+    double* gmt = NULL;
+    for (int64_t i = 0; i < d; ++i) gmu[i] = orc_idot(p->bound_gamma, i, p->bound_mu);
+    if (p->target_mu) {
+        gmt = (double*)malloc((size_t)d * sizeof(double));
+        for (int64_t i = 0; i < d; ++i) gmt[i] = orc_idot(p->target_gamma, i, p->target_mu);
+    }
+    const uint64_t seed = p->seed;
+    uint64_t nm = 0;
+    double* t_old = (double*)malloc((size_t)d * sizeof(double));
+    double* ba = (double*)malloc((size_t)d * sizeof(double));
+    double* bb = (double*)malloc((size_t)d * sizeof(double));
+    double* thf = (double*)calloc((size_t)d, sizeof(double));        /* θf, :174 */
+    unsigned char* f = (unsigned char*)calloc((size_t)d, 1);         /* :165 */
+    for (int64_t i = 0; i < d; ++i) t[i] = t_old[i] = t0;            /* :163-164 */
+    orc_pq* Q = orc_pq_new(d + 1);
+    for (int64_t i = 0; i < d; ++i) zz_ab(p->bound_gamma, gmu, i, x, th, c, &ba[i], &bb[i]); /* :177 */
+    for (int64_t i = 0; i < d; ++i) {                                                          /* :178-188 */
+        double trefl = orc_poisson_time(ba[i], bb[i], pdmp_u01(seed, PDMP_STREAM_MAIN, nm++));
+        double tfreez = freezing_time(x[i], th[i]);
+        if (trefl > tfreez) {
+            f[i] = 1;
+            orc_pq_enqueue(Q, i, t0 + tfreez);
+        } else {
+            f[i] = 0;
+            orc_pq_enqueue(Q, i, t0 + trefl);
+        }
+    }
+    int64_t num = 0, acc = 0, nev = 0;
+    int status = ORC_OK;
+    double tp = t0;
+    while (tp < T) { /* :202 */
+        for (;;) {   /* sspdmp_inner!, :78-157 */
+            int64_t i;
+            double tq;
+            orc_pq_peek(Q, &i, &tq); /* :83 */
+            if (tq == INFINITY) {
+                status = ORC_STALLED;
+                goto finish;
+            }
+            tp = tq;
+            if (f[i]) { /* :87 case 1: to be frozen */
+                move1(i, t, x, th, tp); /* :88 */
+                if (fabs(x[i]) > 1e-8) {  /* :89-91 */
+                    status = ORC_BOUND_VIOLATED;
+                    goto finish;
+                }
+                x[i] = 0.0 * th[i]; /* :92  x[i] = -0*θ[i]  (Int -0 == 0, so the sign is θ's) */
+                thf[i] = th[i];
+                th[i] = 0.0; /* :93 */
+                t_old[i] = t[i];
+                f[i] = 0;
+                orc_pq_set(Q, i, t[i] - pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)) / p->kappa[i]); /* :96 */
+                if (!p->strong_upperbounds) { /* :97-107 */
+                    ssmove_nbrs(&g1, i, t, x, th, tp);
+                    ssmove_nbrs(&g2, i, t, x, th, tp);
+                    for (int64_t q = g1.ptr[i]; q < g1.ptr[i + 1]; ++q) {
+                        int64_t j = g1.idx[q];
+                        if (th[j] != 0) {
+                            zz_ab(p->bound_gamma, gmu, j, x, th, c, &ba[j], &bb[j]);
+                            t_old[j] = t[j];
+                            queue_time(Q, t, x, th, j, ba, bb, f, seed, &nm);
+                        }
+                    }
+                }
+            } else if (x[i] == 0 && th[i] == 0) { /* :108 case 2: was frozen */
+                t[i] = tp;                         /* :109 */
+                th[i] = thf[i];
+                thf[i] = 0.0; /* :110 */
+                if (p->reversible) { /* :111-113 */
+                    double u = pdmp_u01(seed, PDMP_STREAM_MAIN, nm++);
+                    th[i] *= (u < 0.5) ? -1.0 : 1.0;
+                }
+                t_old[i] = t[i];
+                ssmove_nbrs(&g1, i, t, x, th, tp); /* :115 */
+                ssmove_nbrs(&g2, i, t, x, th, tp); /* :116 */
+                for (int64_t q = g1.ptr[i]; q < g1.ptr[i + 1]; ++q) { /* :117-123 */
+                    int64_t j = g1.idx[q];
+                    if (th[j] != 0) {
+                        zz_ab(p->bound_gamma, gmu, j, x, th, c, &ba[j], &bb[j]);
+                        t_old[j] = t[j];
+                        queue_time(Q, t, x, th, j, ba, bb, f, seed, &nm);
+                    }
+                }
+            } else { /* :124 reflection proposal */
+                ssmove_nbrs(&g1, i, t, x, th, tp); /* :125 */
+                double gi = orc_idot(p->target_gamma, i, x);
+                if (gmt) gi = gi - gmt[i];
+                double l = pos(gi * th[i]);
+                double lb = pos(ba[i] + bb[i] * (t[i] - t_old[i])); /* :128 */
+                num += 1;
+                if (pdmp_u01(seed, PDMP_STREAM_MAIN, nm++) * lb < l) { /* :130 */
+                    acc += 1;
+                    if (l > lb) { /* :132 */
+                        if (!p->adapt) {
+                            status = ORC_BOUND_VIOLATED;
+                            goto finish;
+                        }
+                        acc = num = 0; /* :134 */
+                        c[i] *= p->factor;
+                    }
+                    ssmove_nbrs(&g2, i, t, x, th, tp); /* :138 */
+                    th[i] = -th[i];                    /* :139 */
+                    for (int64_t q = g1.ptr[i]; q < g1.ptr[i + 1]; ++q) { /* :140-146 */
+                        int64_t j = g1.idx[q];
+                        if (th[j] != 0) {
+                            zz_ab(p->bound_gamma, gmu, j, x, th, c, &ba[j], &bb[j]);
+                            t_old[j] = t[j];
+                            queue_time(Q, t, x, th, j, ba, bb, f, seed, &nm);
+                        }
+                    }
+                } else { /* :147-151 */
+                    zz_ab(p->bound_gamma, gmu, i, x, th, c, &ba[i], &bb[i]);
+                    t_old[i] = t[i];
+                    queue_time(Q, t, x, th, i, ba, bb, f, seed, &nm);
+                    continue;
+                }
+            }
+            trace_push(tr, t[i], i, x[i], th[i]); /* :154 */
+            nev++;
+            break; /* :155 */
+        }
+        if (p->max_events > 0 && nev >= p->max_events) {
+            status = ORC_TRACE_LIMIT;
+            break;
+        }
+    }
+finish:
+    if (res) {
+        res->num = num;
+        res->nacc = acc;
+        res->nrefresh = 0;
+        res->ndraw_main = nm;
+        res->ndraw_global = 0;
+        res->t_last = tp;
+        res->status = status;
+    }
+    orc_pq_free(Q);
+    free(t_old);
+    free(ba);
+    free(bb);
+    free(thf);
+    free(f);
+    free(gmu);
+    free(gmt);
+    graph_free(&g1);
+    graph_free(&g2);
+    return status;
+}
+
+/* ------------------------------------------------------------------ CPU baseline ensemble driver */
+
+typedef struct {
+    int64_t d;
+    const orc_zz_params* p;
+    double t0, T;
+    int64_t nchains;
+    const double *x0, *th0, *c;
+    uint64_t seed0;
+    int64_t next; /* atomic work counter */
+    int64_t num, acc;
+    pthread_mutex_t mu;
+} ens_job;
+
+static void* ens_worker(void* arg) {
+    ens_job* job = (ens_job*)arg;
+    int64_t d = job->d;
+    double* x = (double*)malloc((size_t)d * sizeof(double));
+    double* th = (double*)malloc((size_t)d * sizeof(double));
+    double* c = (double*)malloc((size_t)d * sizeof(double));
+    double* t = (double*)malloc((size_t)d * sizeof(double));
+    int64_t* acc = (int64_t*)malloc((size_t)d * sizeof(int64_t));
+    int64_t mynum = 0, myacc = 0;
+    for (;;) {
+        int64_t k = __atomic_fetch_add(&job->next, 1, __ATOMIC_RELAXED);
+        if (k >= job->nchains) break;
+        memcpy(x, job->x0 + k * d, (size_t)d * sizeof(double));
+        memcpy(th, job->th0 + k * d, (size_t)d * sizeof(double));
+        memcpy(c, job->c, (size_t)d * sizeof(double));
+        orc_zz_params p = *job->p;
+        p.seed = job->seed0 + (uint64_t)k;
+        orc_zz_result r;
+        orc_spdmp_zigzag(d, &p, job->t0, job->T, x, th, c, t, acc, NULL, &r);
+        mynum += r.num;
+        myacc += r.nacc;
+    }
+    pthread_mutex_lock(&job->mu);
+    job->num += mynum;
+    job->acc += myacc;
+    pthread_mutex_unlock(&job->mu);
+    free(x);
+    free(th);
+    free(c);
+    free(t);
+    free(acc);
+    return NULL;
+}
+
+double orc_spdmp_zigzag_ensemble(int64_t d, const orc_zz_params* p, double t0, double T, int64_t nchains,
+                                 const double* x0, const double* th0, const double* c, uint64_t seed0,
+                                 int nthreads, int64_t* num_total, int64_t* acc_total) {
+    ens_job job;
+    memset(&job, 0, sizeof job);
+    job.d = d;
+    job.p = p;
+    job.t0 = t0;
+    job.T = T;
+    job.nchains = nchains;
+    job.x0 = x0;
+    job.th0 = th0;
+    job.c = c;
+    job.seed0 = seed0;
+    pthread_mutex_init(&job.mu, NULL);
+    if (nthreads < 1) nthreads = 1;
+    pthread_t* th = (pthread_t*)malloc((size_t)nthreads * sizeof(pthread_t));
+    struct timespec ts0, ts1;
+    clock_gettime(CLOCK_MONOTONIC, &ts0);
+    for (int k = 0; k < nthreads; ++k) pthread_create(&th[k], NULL, ens_worker, &job);
+    for (int k = 0; k < nthreads; ++k) pthread_join(th[k], NULL);
+    clock_gettime(CLOCK_MONOTONIC, &ts1);
+    free(th);
+    pthread_mutex_destroy(&job.mu);
+    *num_total = job.num;
+    *acc_total = job.acc;
+    return (double)(ts1.tv_sec - ts0.tv_sec) + 1e-9 * (double)(ts1.tv_nsec - ts0.tv_nsec);
+}
+
+/* ------------------------------------------------------------------ host side of the device math probe */
+/* Same expressions as math_probe_kernel (zigzagboomerang.jl_amd/csrc/pdmp_kernels.hip), evaluated with the
+ * oracle's own poisson_time and libm sqrt: out is [6 x n] row-major. */
+void orc_math_probe(uint64_t seed, int64_t n, double* out) {
+    for (int64_t k = 0; k < n; ++k) {
+        const double u = pdmp_u01(seed, 0u, (uint64_t)k);
+        const double v = pdmp_u01(seed, 1u, (uint64_t)k);
+        const double w = pdmp_u01(seed, 2u, (uint64_t)k);
+        const double a = (u - 0.5) * 8.0;
+        const double b = ((k % 7) == 0) ? 0.0 : (v - 0.5) * 4.0;
+        out[0 * n + k] = u;
+        out[1 * n + k] = pdmp_log(u);
+        out[2 * n + k] = a / ((v - 0.5) * 4.0);
+        out[3 * n + k] = sqrt(u * 1000.0 + v);
+        out[4 * n + k] = orc_poisson_time(a, b, w);
+        out[5 * n + k] = pdmp_randn(seed, 3u, (uint64_t)k);
+    }
+}
+double orc_log(double x) { return pdmp_log(x); }
+double orc_u01(uint64_t seed, uint32_t stream, uint64_t n) { return pdmp_u01(seed, stream, n); }
+double orc_randn(uint64_t seed, uint32_t stream, uint64_t n) { return pdmp_randn(seed, stream, n); }
+void orc_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    pdmp_u32x4 r = pdmp_philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
+    for (int k = 0; k < 4; ++k) out[k] = r.v[k];
+}
+/* synthetic initial state of pdmp_ensemble_set_state_synthetic (include/pdmp_mi355.h) */
+void orc_synthetic_state(uint64_t seed, int64_t d, double* x0, double* theta0) {
+    for (int64_t i = 0; i < d; ++i) {
+        x0[i] = pdmp_randn(seed, PDMP_STREAM_INIT, (uint64_t)i);
+        theta0[i] = (pdmp_u01(seed, PDMP_STREAM_INIT, (uint64_t)(d + i)) < 0.5) ? -1.0 : 1.0;
+    }
+}

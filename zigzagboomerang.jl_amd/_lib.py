@@ -1,0 +1,110 @@
+"""ctypes binding of libpdmp_mi355.so (C ABI: include/pdmp_mi355.h).
+
+Loading never falls back to a CPU implementation: if the shared object is missing or no gfx950 device is
+visible, the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+PDMP_OK = 0
+ERR_NAMES = {0: "PDMP_OK", 1: "PDMP_ERR_INVALID", 2: "PDMP_ERR_NO_DEVICE", 3: "PDMP_ERR_HIP",
+             4: "PDMP_ERR_UNSUPPORTED", 5: "PDMP_ERR_NOMEM"}
+
+SAMPLER_ZIGZAG_LOCAL, SAMPLER_ZIGZAG_ALL, SAMPLER_BPS, SAMPLER_STICKY_ZIGZAG = 0, 1, 2, 3
+CHAIN_OK, CHAIN_BOUND_VIOLATED, CHAIN_STALLED, CHAIN_TRACE_FULL = 0, 1, 2, 3
+RUN_REFERENCE_TAIL, RUN_STOP_BEFORE = 0, 1
+
+EVENT_DTYPE = np.dtype([("t", "<f8"), ("i", "<i8"), ("x", "<f8"), ("theta", "<f8")])
+COUNTERS_DTYPE = np.dtype([("t_last", "<f8"), ("num", "<u8"), ("nacc", "<u8"), ("nrefresh", "<u8"),
+                           ("ntrace", "<u8"), ("nevents", "<u8"), ("ndraw_main", "<u8"),
+                           ("ndraw_global", "<u8"), ("status", "<u4"), ("reserved", "<u4")])
+assert EVENT_DTYPE.itemsize == 32 and COUNTERS_DTYPE.itemsize == 72
+
+# every symbol include/pdmp_mi355.h declares (tests check that the library exports all of them)
+EXPORTED_SYMBOLS = [
+    "pdmp_last_error", "pdmp_abi_version", "pdmp_device_count", "pdmp_ensemble_create",
+    "pdmp_ensemble_destroy", "pdmp_ensemble_set_flow_zigzag", "pdmp_ensemble_set_target_gaussian_csc",
+    "pdmp_ensemble_set_state", "pdmp_ensemble_set_state_synthetic", "pdmp_ensemble_run", "pdmp_ensemble_sync",
+    "pdmp_ensemble_last_run_ms", "pdmp_ensemble_counters", "pdmp_ensemble_totals", "pdmp_ensemble_trace_copy",
+    "pdmp_ensemble_trace_reset", "pdmp_ensemble_final_state", "pdmp_ensemble_batch_means",
+    "pdmp_ensemble_trace_dev", "pdmp_ensemble_counters_dev", "pdmp_debug_math_probe",
+]
+
+
+class PdmpConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("sampler", C.c_int32), ("adapt", C.c_int32),
+                ("factor", C.c_double), ("nchains", C.c_int64), ("d", C.c_int64), ("trace_capacity", C.c_int64)]
+
+
+class PdmpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{ERR_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB_PATH
+
+
+def load():
+    """Load libpdmp_mi355.so; raise if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+            f"{path} is missing: run `python zigzagboomerang.jl_amd/build.py` (hipcc, gfx950). "
+            "There is no CPU fallback for the engine.")
+    L = C.CDLL(path)
+    vp, i64, f64 = C.c_void_p, C.c_int64, C.c_double
+    L.pdmp_last_error.restype = C.c_char_p
+    L.pdmp_abi_version.restype = C.c_int
+    L.pdmp_device_count.restype = C.c_int
+    L.pdmp_ensemble_create.argtypes = [C.POINTER(PdmpConfig), C.POINTER(vp)]
+    L.pdmp_ensemble_destroy.argtypes = [vp]
+    L.pdmp_ensemble_destroy.restype = None
+    L.pdmp_ensemble_set_flow_zigzag.argtypes = [vp, vp, vp, vp, vp, vp, f64, f64]
+    L.pdmp_ensemble_set_target_gaussian_csc.argtypes = [vp, vp, vp, vp, vp]
+    L.pdmp_ensemble_set_state.argtypes = [vp, f64, vp, vp, vp, vp]
+    L.pdmp_ensemble_set_state_synthetic.argtypes = [vp, f64, vp, C.c_uint64]
+    L.pdmp_ensemble_run.argtypes = [vp, f64, C.c_int, vp]
+    L.pdmp_ensemble_sync.argtypes = [vp]
+    L.pdmp_ensemble_last_run_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.pdmp_ensemble_counters.argtypes = [vp, vp]
+    L.pdmp_ensemble_totals.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.pdmp_ensemble_trace_copy.argtypes = [vp, i64, i64, i64, vp]
+    L.pdmp_ensemble_trace_reset.argtypes = [vp]
+    L.pdmp_ensemble_final_state.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp]
+    L.pdmp_ensemble_batch_means.argtypes = [vp, f64, f64, vp, vp]
+    L.pdmp_ensemble_trace_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
+    L.pdmp_ensemble_counters_dev.argtypes = [vp, C.POINTER(vp)]
+    L.pdmp_debug_math_probe.argtypes = [C.c_int, C.c_uint64, i64, vp]
+    for name in EXPORTED_SYMBOLS:
+        fn = getattr(L, name)
+        if name not in ("pdmp_last_error", "pdmp_abi_version", "pdmp_device_count", "pdmp_ensemble_destroy"):
+            fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(code):
+    if code != PDMP_OK:
+        raise PdmpError(code, load().pdmp_last_error().decode("utf-8", "replace"))
+
+
+def math_probe(seed, n, device=0):
+    out = np.empty((6, n))
+    check(load().pdmp_debug_math_probe(int(device), int(seed), int(n), out.ctypes.data))
+    return out
+
+
+def device_count():
+    return load().pdmp_device_count()

@@ -1,0 +1,53 @@
+"""Build recipe of libpdmp_mi355.so (hipcc, gfx950 only) -- used by __graft_entry__.build() and by hand.
+
+    python zigzagboomerang.jl_amd/build.py
+
+The shared object is written in-tree (lib/libpdmp_mi355.so) so that it travels to the GPU box with the
+repository snapshot; it is git-ignored.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_DIR = os.path.join(PKG_DIR, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libpdmp_mi355.so")
+SOURCES = ["pdmp_capi.hip", "pdmp_kernels.hip"]
+HEADERS = [os.path.join(CSRC, "pdmp_engine.hpp"),
+           os.path.join(PKG_DIR, "..", "include", "pdmp_mi355.h"),
+           os.path.join(PKG_DIR, "..", "include", "pdmp_detmath.h")]
+
+# -ffp-contract=off: the kernels must round exactly like the CPU oracle (no fused multiply-add).
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
+               "-shared", "-Wall", "-Wno-unused-function"]
+
+
+def find_hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libpdmp_mi355.so cannot be built (there is no CPU fallback)")
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    return os.path.getmtime(LIB_PATH) < max(os.path.getmtime(p) for p in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [find_hipcc()] + HIPCC_FLAGS + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,602 @@
+// pdmp_capi.hip -- implementation of the C ABI declared in include/pdmp_mi355.h.
+//
+// Host-side work only: argument checking, building the read-only "neighbourhood program" tables from the
+// flow's CSC pattern (G1, G2 of src/sfact.jl:170-179), HBM allocation, kernel launches.  There is NO CPU
+// fallback: without a gfx950 device every entry point that needs one fails with PDMP_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pdmp_engine.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+pdmp_status fail(pdmp_status st, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return st;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return fail(PDMP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    pdmp_status alloc(size_t count) {
+        release();
+        if (count == 0) return PDMP_OK;
+        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(PDMP_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+        }
+        n = count;
+        return PDMP_OK;
+    }
+    pdmp_status upload(const std::vector<T>& h) {
+        pdmp_status st = alloc(h.size());
+        if (st != PDMP_OK) return st;
+        if (!h.empty()) HIP_TRY(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+        return PDMP_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~DevBuf() { release(); }
+};
+
+}  // namespace
+
+struct pdmp_ensemble {
+    pdmp_config cfg{};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    bool has_flow = false, has_target = false, has_state = false;
+
+    // host copies of the flow (needed to align the target and to rebuild tables)
+    std::vector<uint32_t> colptr, rowval;
+    std::vector<double> bval, mu, sigma;
+    double lambda_ref = 0.0, rho = 0.0;
+    int64_t nnz = 0;
+    uint32_t nblk = 0, nblk_pad = 0;
+    int64_t dk = 0;
+    bool has_tmu = false;
+
+    // device tables
+    DevBuf<uint32_t> d_colptr, d_rowval, d_sptr, d_sidx, d_qptr;
+    DevBuf<uint8_t> d_pos, d_selfpos;
+    DevBuf<double> d_bval, d_tval, d_gmu_b, d_gmu_t, d_c, d_sigma;
+    // device state
+    DevBuf<pdmp::ZzRec> d_rec;
+    DevBuf<double> d_keys, d_c_chain, d_jprev, d_sum;
+    DevBuf<pdmp::DevChain> d_hdr;
+    DevBuf<pdmp_event> d_ev;
+
+    pdmp::ZzTables tables() const {
+        pdmp::ZzTables tb{};
+        tb.colptr = d_colptr.p;
+        tb.rowval = d_rowval.p;
+        tb.bval = d_bval.p;
+        tb.tval = d_tval.p;
+        tb.gmu_b = d_gmu_b.p;
+        tb.gmu_t = has_tmu ? d_gmu_t.p : nullptr;
+        tb.sptr = d_sptr.p;
+        tb.sidx = d_sidx.p;
+        tb.qptr = d_qptr.p;
+        tb.pos = d_pos.p;
+        tb.selfpos = d_selfpos.p;
+        tb.c_shared = d_c.p;
+        tb.sigma = d_sigma.p;
+        return tb;
+    }
+};
+
+extern "C" {
+
+const char* pdmp_last_error(void) {
+    return g_err.c_str();
+}
+
+int pdmp_abi_version(void) {
+    return PDMP_ABI_VERSION;
+}
+
+int pdmp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int k = 0; k < n; ++k) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, k) != hipSuccess) continue;
+        if (strncmp(prop.gcnArchName, "gfx950", 6) == 0) ok++;
+    }
+    return ok;
+}
+
+pdmp_status pdmp_debug_math_probe(int device, uint64_t seed, int64_t n, double* out) {
+    if (!out || n <= 0) return fail(PDMP_ERR_INVALID, "bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(PDMP_ERR_NO_DEVICE, "no HIP device visible");
+    HIP_TRY(hipSetDevice(device));
+    DevBuf<double> buf;
+    pdmp_status st = buf.alloc((size_t)(6 * n));
+    if (st != PDMP_OK) return st;
+    int rc = pdmp::launch_math_probe(seed, n, buf.p, nullptr);
+    if (rc != 0) return fail(PDMP_ERR_HIP, "math probe launch failed: %s", hipGetErrorString((hipError_t)rc));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, buf.p, (size_t)(6 * n) * sizeof(double), hipMemcpyDeviceToHost));
+    return PDMP_OK;
+}
+
+pdmp_status pdmp_ensemble_create(const pdmp_config* cfg, pdmp_ensemble** out) {
+    if (!cfg || !out) return fail(PDMP_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(pdmp_config))
+        return fail(PDMP_ERR_INVALID, "pdmp_config.struct_size %u != %zu", cfg->struct_size, sizeof(pdmp_config));
+    if (cfg->nchains <= 0 || cfg->d <= 0) return fail(PDMP_ERR_INVALID, "nchains and d must be positive");
+    if (cfg->d >= (int64_t)1 << 31) return fail(PDMP_ERR_UNSUPPORTED, "d must be < 2^31");
+    if (cfg->sampler != PDMP_SAMPLER_ZIGZAG_LOCAL)
+        return fail(PDMP_ERR_UNSUPPORTED, "sampler %d: only PDMP_SAMPLER_ZIGZAG_LOCAL has a device kernel so far",
+                    cfg->sampler);
+    if (cfg->trace_capacity < 0) return fail(PDMP_ERR_INVALID, "trace_capacity < 0");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(PDMP_ERR_NO_DEVICE, "no HIP device visible: libpdmp_mi355 has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(PDMP_ERR_INVALID, "device %d out of range", cfg->device);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(PDMP_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", cfg->device,
+                    prop.gcnArchName);
+    HIP_TRY(hipSetDevice(cfg->device));
+    pdmp_ensemble* e = new pdmp_ensemble();
+    e->cfg = *cfg;
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&e->ev0) != hipSuccess || hipEventCreate(&e->ev1) != hipSuccess) {
+        delete e;
+        return fail(PDMP_ERR_HIP, "stream/event creation failed");
+    }
+    *out = e;
+    return PDMP_OK;
+}
+
+void pdmp_ensemble_destroy(pdmp_ensemble* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->cfg.device);
+    (void)hipDeviceSynchronize();
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+pdmp_status pdmp_ensemble_set_flow_zigzag(pdmp_ensemble* e, const int64_t* colptr, const int64_t* rowval,
+                                          const double* nzval, const double* mu, const double* sigma,
+                                          double lambda_ref, double rho) {
+    if (!e || !colptr || !rowval || !nzval) return fail(PDMP_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const int64_t d = e->cfg.d;
+    if (colptr[0] != 0) return fail(PDMP_ERR_INVALID, "colptr[0] must be 0 (0-based CSC)");
+    const int64_t nnz = colptr[d];
+    if (nnz <= 0 || nnz >= (int64_t)1 << 31) return fail(PDMP_ERR_INVALID, "bad nnz %lld", (long long)nnz);
+    if (lambda_ref < 0) return fail(PDMP_ERR_INVALID, "lambda_ref < 0");
+    if (lambda_ref > 0)
+        return fail(PDMP_ERR_UNSUPPORTED, "refresh clock (lambda_ref > 0, src/sfact.jl:78-114) has no device path yet");
+    e->colptr.assign(d + 1, 0);
+    e->rowval.assign(nnz, 0);
+    e->bval.assign(nzval, nzval + nnz);
+    for (int64_t i = 0; i <= d; ++i) {
+        if (colptr[i] < 0 || colptr[i] > nnz || (i > 0 && colptr[i] < colptr[i - 1]))
+            return fail(PDMP_ERR_INVALID, "colptr not monotone at %lld", (long long)i);
+        e->colptr[i] = (uint32_t)colptr[i];
+    }
+    std::vector<uint8_t> selfpos(d, 0);
+    for (int64_t i = 0; i < d; ++i) {
+        const int64_t k = colptr[i + 1] - colptr[i];
+        if (k > 64) return fail(PDMP_ERR_UNSUPPORTED, "column %lld has %lld > 64 non-zeros", (long long)i, (long long)k);
+        bool has_diag = false;
+        for (int64_t p = colptr[i]; p < colptr[i + 1]; ++p) {
+            const int64_t r = rowval[p];
+            if (r < 0 || r >= d) return fail(PDMP_ERR_INVALID, "row index out of range in column %lld", (long long)i);
+            if (p > colptr[i] && rowval[p - 1] >= r)
+                return fail(PDMP_ERR_INVALID, "rows of column %lld are not strictly ascending", (long long)i);
+            if (r == i) {
+                has_diag = true;
+                selfpos[i] = (uint8_t)(p - colptr[i]);
+            }
+            e->rowval[p] = (uint32_t)r;
+        }
+        if (!has_diag)
+            return fail(PDMP_ERR_UNSUPPORTED, "Γ[%lld,%lld] is structurally zero: i must belong to G1[i]", (long long)i,
+                        (long long)i);
+    }
+    e->nnz = nnz;
+    e->mu.assign(d, 0.0);
+    if (mu) e->mu.assign(mu, mu + d);
+    e->sigma.assign(d, 1.0);
+    if (sigma) e->sigma.assign(sigma, sigma + d);
+    e->lambda_ref = lambda_ref;
+    e->rho = rho;
+
+    // gmu_b[i] = idot(Γ, i, μ) (src/fact_samplers.jl:51), summed in CSC order like idot (src/common.jl:16-24)
+    std::vector<double> gmu(d, 0.0);
+    for (int64_t i = 0; i < d; ++i) {
+        double s = 0.0;
+        for (uint32_t p = e->colptr[i]; p < e->colptr[i + 1]; ++p) s += e->bval[p] * e->mu[e->rowval[p]];
+        gmu[i] = s;
+    }
+
+    // S[i] = G1[i] ++ G2[i], G2[i] = (∪_{j∈G1[i]} G1[j]) \ G1[i]  (src/sfact.jl:178), both ascending
+    std::vector<uint32_t> sptr(d + 1, 0), sidx;
+    sidx.reserve((size_t)nnz * 3);
+    std::vector<uint32_t> qptr(nnz + 1, 0);
+    std::vector<uint8_t> pos;
+    pos.reserve((size_t)nnz * 5);
+    std::vector<uint32_t> tmp;
+    for (int64_t i = 0; i < d; ++i) {
+        const uint32_t c0 = e->colptr[i], c1 = e->colptr[i + 1];
+        tmp.clear();
+        for (uint32_t p = c0; p < c1; ++p) {
+            const uint32_t j = e->rowval[p];
+            for (uint32_t q = e->colptr[j]; q < e->colptr[j + 1]; ++q) tmp.push_back(e->rowval[q]);
+        }
+        std::sort(tmp.begin(), tmp.end());
+        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+        const size_t s0 = sidx.size();
+        for (uint32_t p = c0; p < c1; ++p) sidx.push_back(e->rowval[p]);
+        for (uint32_t v : tmp) {
+            if (!std::binary_search(e->rowval.begin() + c0, e->rowval.begin() + c1, v)) sidx.push_back(v);
+        }
+        const size_t m = sidx.size() - s0;
+        if (m > 64)
+            return fail(PDMP_ERR_UNSUPPORTED, "two-hop neighbourhood of coordinate %lld has %zu > 64 members",
+                        (long long)i, m);
+        sptr[i + 1] = (uint32_t)sidx.size();
+        // positions inside S[i] of the members of G1[j], j = G1[i][jj]
+        for (uint32_t p = c0; p < c1; ++p) {
+            const uint32_t j = e->rowval[p];
+            qptr[p] = (uint32_t)pos.size();
+            for (uint32_t q = e->colptr[j]; q < e->colptr[j + 1]; ++q) {
+                const uint32_t r = e->rowval[q];
+                size_t where = m;
+                for (size_t w = 0; w < m; ++w) {
+                    if (sidx[s0 + w] == r) {
+                        where = w;
+                        break;
+                    }
+                }
+                if (where == m)
+                    return fail(PDMP_ERR_UNSUPPORTED,
+                                "pattern of Γ is not symmetric: row %u of column %u is not reachable from %lld", r, j,
+                                (long long)i);
+                pos.push_back((uint8_t)where);
+            }
+        }
+    }
+    qptr[nnz] = (uint32_t)pos.size();
+    if (pos.empty()) pos.push_back(0);
+
+    pdmp_status st;
+    if ((st = e->d_colptr.upload(e->colptr)) != PDMP_OK) return st;
+    if ((st = e->d_rowval.upload(e->rowval)) != PDMP_OK) return st;
+    if ((st = e->d_bval.upload(e->bval)) != PDMP_OK) return st;
+    if ((st = e->d_gmu_b.upload(gmu)) != PDMP_OK) return st;
+    if ((st = e->d_sptr.upload(sptr)) != PDMP_OK) return st;
+    if ((st = e->d_sidx.upload(sidx)) != PDMP_OK) return st;
+    if ((st = e->d_qptr.upload(qptr)) != PDMP_OK) return st;
+    if ((st = e->d_pos.upload(pos)) != PDMP_OK) return st;
+    if ((st = e->d_selfpos.upload(selfpos)) != PDMP_OK) return st;
+    if ((st = e->d_sigma.upload(e->sigma)) != PDMP_OK) return st;
+
+    const int64_t nkeys = d + 1;  // slot d is the refresh clock (+Inf when λref = 0)
+    e->nblk = (uint32_t)((nkeys + 63) / 64);
+    e->nblk_pad = (e->nblk + 1u) & ~1u;
+    e->dk = (int64_t)e->nblk * 64;
+    if (pdmp::zz_local_lds_bytes(e->nblk_pad) > 160 * 1024)
+        return fail(PDMP_ERR_UNSUPPORTED, "d = %lld needs %zu bytes of LDS for the queue's level 1 (> 160 KiB)",
+                    (long long)d, pdmp::zz_local_lds_bytes(e->nblk_pad));
+    e->has_flow = true;
+    e->has_target = false;
+    e->has_state = false;
+    return PDMP_OK;
+}
+
+pdmp_status pdmp_ensemble_set_target_gaussian_csc(pdmp_ensemble* e, const int64_t* colptr, const int64_t* rowval,
+                                                  const double* nzval, const double* mu) {
+    if (!e || !colptr || !rowval || !nzval) return fail(PDMP_ERR_INVALID, "null argument");
+    if (!e->has_flow) return fail(PDMP_ERR_INVALID, "set_flow_zigzag must be called first");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const int64_t d = e->cfg.d;
+    if (colptr[0] != 0) return fail(PDMP_ERR_INVALID, "colptr[0] must be 0 (0-based CSC)");
+    // align Γt to the flow's pattern: slots absent from Γt carry 0.0 (s + 0.0*x == s bit-for-bit)
+    std::vector<double> tval(e->nnz, 0.0), gmu_t(d, 0.0);
+    for (int64_t i = 0; i < d; ++i) {
+        uint32_t q = e->colptr[i];
+        const uint32_t q1 = e->colptr[i + 1];
+        double s = 0.0;
+        for (int64_t p = colptr[i]; p < colptr[i + 1]; ++p) {
+            const int64_t r = rowval[p];
+            if (p > colptr[i] && rowval[p - 1] >= r)
+                return fail(PDMP_ERR_INVALID, "rows of target column %lld are not strictly ascending", (long long)i);
+            while (q < q1 && (int64_t)e->rowval[q] < r) ++q;
+            if (q == q1 || (int64_t)e->rowval[q] != r)
+                return fail(PDMP_ERR_UNSUPPORTED,
+                            "target Γt[%lld,%lld] lies outside the flow's pattern G[%lld] (src/sfact.jl:116)",
+                            (long long)r, (long long)i, (long long)i);
+            tval[q] = nzval[p];
+            if (mu) s += nzval[p] * mu[r];
+        }
+        gmu_t[i] = s;
+    }
+    e->has_tmu = (mu != nullptr);
+    pdmp_status st;
+    if ((st = e->d_tval.upload(tval)) != PDMP_OK) return st;
+    if ((st = e->d_gmu_t.upload(gmu_t)) != PDMP_OK) return st;
+    e->has_target = true;
+    e->has_state = false;
+    return PDMP_OK;
+}
+
+static pdmp_status alloc_state(pdmp_ensemble* e) {
+    const int64_t d = e->cfg.d, n = e->cfg.nchains;
+    pdmp_status st;
+    if (e->d_rec.n != (size_t)(n * d) && (st = e->d_rec.alloc((size_t)(n * d))) != PDMP_OK) return st;
+    if (e->d_keys.n != (size_t)(n * e->dk) && (st = e->d_keys.alloc((size_t)(n * e->dk))) != PDMP_OK) return st;
+    if (e->d_hdr.n != (size_t)n && (st = e->d_hdr.alloc((size_t)n)) != PDMP_OK) return st;
+    if (e->cfg.adapt && e->d_c_chain.n != (size_t)(n * d) && (st = e->d_c_chain.alloc((size_t)(n * d))) != PDMP_OK)
+        return st;
+    if (e->cfg.trace_capacity > 0 && e->d_ev.n != (size_t)(n * e->cfg.trace_capacity) &&
+        (st = e->d_ev.alloc((size_t)(n * e->cfg.trace_capacity))) != PDMP_OK)
+        return st;
+    e->d_jprev.release();
+    return PDMP_OK;
+}
+
+static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, const double* th0, const double* c,
+                              const uint64_t* seeds, uint64_t seed0) {
+    if (!e->has_flow || !e->has_target) return fail(PDMP_ERR_INVALID, "flow and target must be set before the state");
+    if (!c) return fail(PDMP_ERR_INVALID, "c is required");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const int64_t d = e->cfg.d, n = e->cfg.nchains;
+    pdmp_status st = alloc_state(e);
+    if (st != PDMP_OK) return st;
+    std::vector<double> cv(c, c + d);
+    if ((st = e->d_c.upload(cv)) != PDMP_OK) return st;
+    DevBuf<double> sx, sth;
+    DevBuf<uint64_t> sseed;
+    if (x0) {
+        if ((st = sx.alloc((size_t)(n * d))) != PDMP_OK) return st;
+        if ((st = sth.alloc((size_t)(n * d))) != PDMP_OK) return st;
+        HIP_TRY(hipMemcpy(sx.p, x0, (size_t)(n * d) * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(sth.p, th0, (size_t)(n * d) * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (seeds) {
+        if ((st = sseed.alloc((size_t)n)) != PDMP_OK) return st;
+        HIP_TRY(hipMemcpy(sseed.p, seeds, (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice));
+    }
+    pdmp::ZzInitParams P{};
+    P.tb = e->tables();
+    P.rec = e->d_rec.p;
+    P.keys = e->d_keys.p;
+    P.hdr = e->d_hdr.p;
+    P.c_chain = e->cfg.adapt ? e->d_c_chain.p : nullptr;
+    P.x0 = x0 ? sx.p : nullptr;
+    P.th0 = x0 ? sth.p : nullptr;
+    P.seeds = seeds ? sseed.p : nullptr;
+    P.seed0 = seed0;
+    P.d = d;
+    P.dk = e->dk;
+    P.nchains = n;
+    P.t0 = t0;
+    P.lambda_ref = e->lambda_ref;
+    P.has_refresh = e->lambda_ref > 0;
+    int rc = pdmp::launch_zz_init(P, e->stream);
+    if (rc != 0) return fail(PDMP_ERR_HIP, "zz_init launch failed: %s", hipGetErrorString((hipError_t)rc));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->has_state = true;
+    e->timed = false;
+    return PDMP_OK;
+}
+
+pdmp_status pdmp_ensemble_set_state(pdmp_ensemble* e, double t0, const double* x0, const double* theta0,
+                                    const double* c, const uint64_t* seeds) {
+    if (!e || !x0 || !theta0 || !seeds) return fail(PDMP_ERR_INVALID, "null argument");
+    return init_state(e, t0, x0, theta0, c, seeds, 0);
+}
+
+pdmp_status pdmp_ensemble_set_state_synthetic(pdmp_ensemble* e, double t0, const double* c, uint64_t seed0) {
+    if (!e) return fail(PDMP_ERR_INVALID, "null argument");
+    return init_state(e, t0, nullptr, nullptr, c, nullptr, seed0);
+}
+
+pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* stream) {
+    if (!e) return fail(PDMP_ERR_INVALID, "null argument");
+    if (!e->has_state) return fail(PDMP_ERR_INVALID, "set_state must be called before run");
+    if (flags != PDMP_RUN_REFERENCE_TAIL && flags != PDMP_RUN_STOP_BEFORE) return fail(PDMP_ERR_INVALID, "bad flags");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    pdmp::ZzRunParams P{};
+    P.tb = e->tables();
+    P.rec = e->d_rec.p;
+    P.keys = e->d_keys.p;
+    P.hdr = e->d_hdr.p;
+    P.ev = e->cfg.trace_capacity > 0 ? e->d_ev.p : nullptr;
+    P.c_chain = e->cfg.adapt ? e->d_c_chain.p : nullptr;
+    P.d = e->cfg.d;
+    P.dk = e->dk;
+    P.trace_cap = e->cfg.trace_capacity;
+    P.nblk = e->nblk;
+    P.nblk_pad = e->nblk_pad;
+    P.T = T;
+    P.factor = e->cfg.factor;
+    P.lambda_ref = e->lambda_ref;
+    P.flags = flags;
+    P.adapt = e->cfg.adapt;
+    P.has_refresh = e->lambda_ref > 0;
+    HIP_TRY(hipEventRecord(e->ev0, s));
+    int rc = pdmp::launch_zz_local_run(P, e->cfg.nchains, s);
+    if (rc != 0) return fail(PDMP_ERR_HIP, "zz_local_run launch failed: %s", hipGetErrorString((hipError_t)rc));
+    HIP_TRY(hipEventRecord(e->ev1, s));
+    e->timed = true;
+    return PDMP_OK;
+}
+
+pdmp_status pdmp_ensemble_sync(pdmp_ensemble* e) {
+    if (!e) return fail(PDMP_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    return PDMP_OK;
+}
+
+pdmp_status pdmp_ensemble_last_run_ms(pdmp_ensemble* e, float* ms) {
+    if (!e || !ms) return fail(PDMP_ERR_INVALID, "null argument");
+    if (!e->timed) return fail(PDMP_ERR_INVALID, "no run has been launched");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipEventSynchronize(e->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, e->ev0, e->ev1));
+    return PDMP_OK;
+}
+
+pdmp_status pdmp_ensemble_counters(pdmp_ensemble* e, pdmp_chain_counters* out) {
+    if (!e || !out) return fail(PDMP_ERR_INVALID, "null argument");
+    if (!e->has_state) return fail(PDMP_ERR_INVALID, "no state");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<pdmp::DevChain> h((size_t)e->cfg.nchains);
+    HIP_TRY(hipMemcpy(h.data(), e->d_hdr.p, h.size() * sizeof(pdmp::DevChain), hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < h.size(); ++k) out[k] = h[k].c;
+    return PDMP_OK;
+}
+
+pdmp_status pdmp_ensemble_totals(pdmp_ensemble* e, uint64_t* num, uint64_t* nacc, uint64_t* nevents) {
+    if (!e) return fail(PDMP_ERR_INVALID, "null argument");
+    std::vector<pdmp_chain_counters> c((size_t)e->cfg.nchains);
+    pdmp_status st = pdmp_ensemble_counters(e, c.data());
+    if (st != PDMP_OK) return st;
+    uint64_t a = 0, b = 0, n = 0;
+    for (auto& k : c) {
+        n += k.num;
+        a += k.nacc;
+        b += k.nevents;
+    }
+    if (num) *num = n;
+    if (nacc) *nacc = a;
+    if (nevents) *nevents = b;
+    return PDMP_OK;
+}
+
+pdmp_status pdmp_ensemble_trace_copy(pdmp_ensemble* e, int64_t chain, int64_t first, int64_t count, pdmp_event* out) {
+    if (!e || !out) return fail(PDMP_ERR_INVALID, "null argument");
+    if (e->cfg.trace_capacity <= 0) return fail(PDMP_ERR_INVALID, "ensemble was created with trace_capacity = 0");
+    if (chain < 0 || chain >= e->cfg.nchains || first < 0 || count < 0 || first + count > e->cfg.trace_capacity)
+        return fail(PDMP_ERR_INVALID, "trace range out of bounds");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (count)
+        HIP_TRY(hipMemcpy(out, e->d_ev.p + chain * e->cfg.trace_capacity + first, (size_t)count * sizeof(pdmp_event),
+                          hipMemcpyDeviceToHost));
+    return PDMP_OK;
+}
+
+pdmp_status pdmp_ensemble_trace_reset(pdmp_ensemble* e) {
+    if (!e) return fail(PDMP_ERR_INVALID, "null argument");
+    if (!e->has_state) return fail(PDMP_ERR_INVALID, "no state");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    // ntrace lives at a fixed offset inside each 128-byte header: zero it with a strided 2-D memset
+    const size_t off = offsetof(pdmp::DevChain, c) + offsetof(pdmp_chain_counters, ntrace);
+    HIP_TRY(hipMemset2D(reinterpret_cast<char*>(e->d_hdr.p) + off, sizeof(pdmp::DevChain), 0, sizeof(uint64_t),
+                        (size_t)e->cfg.nchains));
+    // status TRACE_FULL -> OK is handled by the kernel at entry (only BOUND_VIOLATED / STALLED are sticky)
+    return PDMP_OK;
+}
+
+pdmp_status pdmp_ensemble_final_state(pdmp_ensemble* e, int64_t chain_first, int64_t n, double* t, double* x,
+                                      double* theta, int64_t* acc, double* c) {
+    if (!e) return fail(PDMP_ERR_INVALID, "null argument");
+    if (!e->has_state) return fail(PDMP_ERR_INVALID, "no state");
+    if (chain_first < 0 || n < 0 || chain_first + n > e->cfg.nchains) return fail(PDMP_ERR_INVALID, "chain range");
+    if (n == 0) return PDMP_OK;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    const int64_t d = e->cfg.d;
+    const size_t cnt = (size_t)(n * d);
+    DevBuf<double> bt, bx, bth, bc;
+    DevBuf<int64_t> bacc;
+    pdmp_status st;
+    if (t && (st = bt.alloc(cnt)) != PDMP_OK) return st;
+    if (x && (st = bx.alloc(cnt)) != PDMP_OK) return st;
+    if (theta && (st = bth.alloc(cnt)) != PDMP_OK) return st;
+    if (acc && (st = bacc.alloc(cnt)) != PDMP_OK) return st;
+    if (c && (st = bc.alloc(cnt)) != PDMP_OK) return st;
+    const double* c_src = e->cfg.adapt ? e->d_c_chain.p : e->d_c.p;
+    const int64_t c_stride = e->cfg.adapt ? d : 0;
+    int rc = pdmp::launch_zz_unpack(e->d_rec.p, c_src, c_stride, d, chain_first, n, bt.p, bx.p, bth.p, bacc.p, bc.p,
+                                    e->stream);
+    if (rc != 0) return fail(PDMP_ERR_HIP, "unpack launch failed: %s", hipGetErrorString((hipError_t)rc));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (t) HIP_TRY(hipMemcpy(t, bt.p, cnt * sizeof(double), hipMemcpyDeviceToHost));
+    if (x) HIP_TRY(hipMemcpy(x, bx.p, cnt * sizeof(double), hipMemcpyDeviceToHost));
+    if (theta) HIP_TRY(hipMemcpy(theta, bth.p, cnt * sizeof(double), hipMemcpyDeviceToHost));
+    if (acc) HIP_TRY(hipMemcpy(acc, bacc.p, cnt * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (c) HIP_TRY(hipMemcpy(c, bc.p, cnt * sizeof(double), hipMemcpyDeviceToHost));
+    return PDMP_OK;
+}
+
+pdmp_status pdmp_ensemble_batch_means(pdmp_ensemble* e, double T_prev, double T, double* sum_y, double* sum_y2) {
+    if (!e) return fail(PDMP_ERR_INVALID, "null argument");
+    if (!e->has_state) return fail(PDMP_ERR_INVALID, "no state");
+    if (!(T > T_prev)) return fail(PDMP_ERR_INVALID, "T must exceed T_prev");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    const int64_t d = e->cfg.d, n = e->cfg.nchains;
+    pdmp_status st;
+    if (e->d_jprev.n != (size_t)(n * d)) {
+        if ((st = e->d_jprev.alloc((size_t)(n * d))) != PDMP_OK) return st;
+        HIP_TRY(hipMemset(e->d_jprev.p, 0, (size_t)(n * d) * sizeof(double)));
+    }
+    if (e->d_sum.n != (size_t)(2 * d) && (st = e->d_sum.alloc((size_t)(2 * d))) != PDMP_OK) return st;
+    HIP_TRY(hipMemset(e->d_sum.p, 0, (size_t)(2 * d) * sizeof(double)));
+    int rc = pdmp::launch_zz_batch_means(e->d_rec.p, e->d_jprev.p, d, n, T_prev, T, e->d_sum.p, e->d_sum.p + d,
+                                         e->stream);
+    if (rc != 0) return fail(PDMP_ERR_HIP, "batch_means launch failed: %s", hipGetErrorString((hipError_t)rc));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (sum_y) HIP_TRY(hipMemcpy(sum_y, e->d_sum.p, (size_t)d * sizeof(double), hipMemcpyDeviceToHost));
+    if (sum_y2) HIP_TRY(hipMemcpy(sum_y2, e->d_sum.p + d, (size_t)d * sizeof(double), hipMemcpyDeviceToHost));
+    return PDMP_OK;
+}
+
+pdmp_status pdmp_ensemble_trace_dev(pdmp_ensemble* e, void** events_dev, int64_t* capacity) {
+    if (!e || !events_dev || !capacity) return fail(PDMP_ERR_INVALID, "null argument");
+    *events_dev = e->d_ev.p;
+    *capacity = e->cfg.trace_capacity;
+    return PDMP_OK;
+}
+
+pdmp_status pdmp_ensemble_counters_dev(pdmp_ensemble* e, void** counters_dev) {
+    if (!e || !counters_dev) return fail(PDMP_ERR_INVALID, "null argument");
+    *counters_dev = e->d_hdr.p;
+    return PDMP_OK;
+}
+
+}  // extern "C"

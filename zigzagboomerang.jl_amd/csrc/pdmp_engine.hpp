@@ -1,0 +1,114 @@
+// pdmp_engine.hpp -- internal data layout of libpdmp_mi355.so (not part of the C ABI).
+//
+// HBM layout (all per-ensemble, one ensemble per device):
+//
+//   shared, read-only, L2/MALL resident (built once from the flow + target, "neighbourhood program"):
+//     colptr[d+1] u32, rowval[nnz] u32      G1[i] = rows of column i of the bounding Γ   (src/sfact.jl:170)
+//     bval[nnz] f64, tval[nnz] f64          bounding Γ values; target Γ values aligned to the same slots
+//     gmu_b[d], gmu_t[d] f64                idot(Γ,i,μ) constants of ab() / of the target
+//     sptr[d+1], sidx[...] u32              S[i] = G1[i] (ascending) followed by G2[i] (ascending, :178)
+//     qptr[nnz+1] u32, pos[...] u8          for slot (i,jj): positions inside S[i] of the members of G1[j]
+//     selfpos[d] u8                         position of i inside G1[i]
+//     c[d], sigma[d] f64
+//
+//   per chain (chain-major, nothing shared between chains):
+//     rec[d]  64-byte records {x, θ, t, I, t_old, a, b, acc}: ONE 64 B sector per touched coordinate
+//     keys[dk] f64, dk = 64*nblk            event-time queue level 0 (padded with +Inf; key d = refresh)
+//     hdr      128 B                        counters, RNG draw indices, status
+//     ev[cap]  32-byte events               FactTrace segment
+//
+//   LDS (per wavefront = per chain): level-1 of the queue: (min key, argmin) of every 64-key block,
+//   plus a 64-slot (x,θ) scratch for the neighbourhood being re-bounded.
+#pragma once
+#include <cstdint>
+
+#include "../../include/pdmp_mi355.h"
+
+namespace pdmp {
+
+struct alignas(64) ZzRec {
+    double x;      // position at the coordinate's own clock t          (src/sfact.jl:168,180)
+    double th;     // velocity θ
+    double t;      // per-coordinate clock
+    double I;      // ∫ x dt accumulated up to t (engine-only, for batch means)
+    double t_old;  // time the bound (a,b) was computed                  (src/sfact.jl:169)
+    double a, b;   // affine bound a + b (t - t_old)                     (src/fact_samplers.jl:50-54)
+    uint64_t acc;  // accepted reflections of this coordinate            (src/sfact.jl:182)
+};
+static_assert(sizeof(ZzRec) == 64, "record must be one 64-byte sector");
+
+struct alignas(128) DevChain {
+    pdmp_chain_counters c;  // 72 bytes, copied out verbatim by pdmp_ensemble_counters
+    uint64_t seed;
+    double t0;
+    double t_event;  // t′ of the last RETURNED event: the loop variable of `while t′ < T` (src/sfact.jl:199)
+    uint64_t pad[4];
+};
+static_assert(sizeof(DevChain) == 128, "chain header is 128 bytes");
+
+// Read-only tables of the local ZigZag kernels (device pointers).
+struct ZzTables {
+    const uint32_t* __restrict__ colptr;
+    const uint32_t* __restrict__ rowval;
+    const double* __restrict__ bval;
+    const double* __restrict__ tval;
+    const double* __restrict__ gmu_b;
+    const double* __restrict__ gmu_t;  // nullptr: target has no mean shift
+    const uint32_t* __restrict__ sptr;
+    const uint32_t* __restrict__ sidx;
+    const uint32_t* __restrict__ qptr;
+    const uint8_t* __restrict__ pos;
+    const uint8_t* __restrict__ selfpos;
+    const double* __restrict__ c_shared;
+    const double* __restrict__ sigma;
+};
+
+struct ZzRunParams {
+    ZzTables tb;
+    ZzRec* rec;
+    double* keys;
+    DevChain* hdr;
+    pdmp_event* ev;
+    double* c_chain;  // per-chain bounds when adapt, else nullptr
+    int64_t d;
+    int64_t dk;        // padded key count per chain (multiple of 64)
+    int64_t trace_cap;
+    uint32_t nblk;
+    uint32_t nblk_pad;  // nblk rounded up to even (keeps LDS sub-arrays 16-byte aligned)
+    double T;
+    double factor;
+    double lambda_ref;
+    int32_t flags;
+    int32_t adapt;
+    int32_t has_refresh;
+};
+
+struct ZzInitParams {
+    ZzTables tb;
+    ZzRec* rec;
+    double* keys;
+    DevChain* hdr;
+    double* c_chain;
+    const double* x0;  // [nchains x d] staging (nullptr: synthetic)
+    const double* th0;
+    const uint64_t* seeds;  // [nchains] (nullptr: seed0 + chain)
+    uint64_t seed0;
+    int64_t d;
+    int64_t dk;
+    int64_t nchains;
+    double t0;
+    double lambda_ref;
+    int32_t has_refresh;
+};
+
+// launch wrappers implemented in pdmp_kernels.hip (hipStream_t passed as void*)
+int launch_zz_init(const ZzInitParams& p, void* stream);
+int launch_zz_local_run(const ZzRunParams& p, int64_t nchains, void* stream);
+int launch_zz_unpack(const ZzRec* rec, const double* c_src, int64_t c_stride, int64_t d, int64_t chain_first,
+                     int64_t n, double* t, double* x, double* th, int64_t* acc, double* c, void* stream);
+int launch_zz_batch_means(const ZzRec* rec, double* jprev, int64_t d, int64_t nchains, double T_prev, double T,
+                          double* sum_y, double* sum_y2, void* stream);
+size_t zz_local_lds_bytes(uint32_t nblk_pad);
+int launch_math_probe(uint64_t seed, int64_t n, double* out, void* stream);
+
+}  // namespace pdmp

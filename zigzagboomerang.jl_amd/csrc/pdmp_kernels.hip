@@ -1,0 +1,575 @@
+// pdmp_kernels.hip -- gfx950 (CDNA4) kernels of the PDMP ensemble engine.
+//
+// Mapping: ONE CHAIN PER WAVEFRONT (64 lanes), one wavefront per workgroup, persistent over a time slice.
+// Chains are independent, so there is no inter-workgroup communication at all; the read-only
+// "neighbourhood program" tables are shared through L2 / Infinity Cache.
+//
+// The event-time queue (reference: binary heap SPriorityQueue, src/priorityqueue.jl) is a two-level
+// 64-ary tournament matched to the wave width:
+//   level 0: d keys in HBM (one coalesced 512-byte block = 64 keys = one load instruction),
+//   level 1: (min, argmin) of each block in LDS; peek = 64-lane strided scan + DPP min-reduction.
+// change-key of the popped coordinate = patch its (prefetched) block in registers and re-reduce; a
+// neighbour's new key either lowers its block minimum (LDS write only) or, rarely, forces a block rescan.
+//
+// Arithmetic is written operation-by-operation in the reference's order (no FMA contraction: the file is
+// compiled with -ffp-contract=off), so that event sequences are bit-identical to oracle/pdmp_oracle.c.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+#include "../../include/pdmp_detmath.h"
+#include "pdmp_engine.hpp"
+
+namespace pdmp {
+
+#define PDMP_INF __builtin_inf()
+
+// ------------------------------------------------------------------------------------------ lane helpers
+
+__device__ __forceinline__ double readlane_f64(double v, int srclane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int srclane) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, srclane);
+}
+__device__ __forceinline__ uint32_t uniform_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ double uniform_f64(double v) {
+    int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double min_f64(double a, double b) {
+    return (b < a) ? b : a;
+}
+
+// Minimum over the 64 lanes, returned wave-uniform.  4 DPP steps inside each row of 16 lanes
+// (quad xor-1, quad xor-2, half-row mirror, row mirror), then the 4 row minima through SGPRs.
+__device__ __forceinline__ double wave_min_f64(double v) {
+    v = min_f64(v, dpp_f64<0xB1>(v));   // quad_perm [1,0,3,2]
+    v = min_f64(v, dpp_f64<0x4E>(v));   // quad_perm [2,3,0,1]
+    v = min_f64(v, dpp_f64<0x141>(v));  // row_half_mirror
+    v = min_f64(v, dpp_f64<0x140>(v));  // row_mirror
+    double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16), r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
+    return min_f64(min_f64(r0, r1), min_f64(r2, r3));
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    for (int off = 32; off >= 1; off >>= 1) {
+        uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
+        v = (o < v) ? o : v;
+    }
+    return uniform_u32(v);
+}
+
+// pos(x) = max(zero(x), x), src/common.jl:8
+__device__ __forceinline__ double pos_part(double x) {
+    return (x > 0.0) ? x : ((x != x) ? x : 0.0);
+}
+
+// poisson_time(a, b, u), src/poissontime.jl:8-30 (device restatement; the oracle has its own)
+__device__ __forceinline__ double dev_poisson_time(double a, double b, double u) {
+    const double L = pdmp_log(u);
+    if (b > 0) {
+        const double r = a / b;
+        if (a < 0) {
+            return sqrt(-L * 2.0 / b) - r;
+        } else {
+            return sqrt(r * r - L * 2.0 / b) - r;
+        }
+    } else if (b == 0) {
+        if (a > 0) {
+            return -L / a;
+        } else {
+            return PDMP_INF;
+        }
+    } else {
+        if (a <= 0) {
+            return PDMP_INF;
+        } else if (-L <= -(a * a) / b + (a * a) / (2 * b)) {
+            const double r = a / b;
+            return -sqrt(r * r - L * 2.0 / b) - r;
+        } else {
+            return PDMP_INF;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ init kernel
+//
+// src/sfact.jl:164-190: t = fill(t0), t_old = copy(t), b[i] = ab(G1,i,x,θ,c,F), Q[i] = poisson_time(b[i], rand(rng))
+// with the d uniforms drawn in order i = 0..d-1 (draw index = i), then the refresh clock (draw index d).
+// One thread per (chain, coordinate).
+__global__ __launch_bounds__(256) void zz_init_kernel(ZzInitParams P) {
+    const int64_t chain = blockIdx.x;
+    const int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x;
+    const int64_t d = P.d;
+    const uint64_t seed = P.seeds ? P.seeds[chain] : (P.seed0 + (uint64_t)chain);
+    ZzRec* rec = P.rec + chain * d;
+    double* keys = P.keys + chain * P.dk;
+
+    if (i < d) {
+        auto x_of = [&](int64_t r) -> double {
+            return P.x0 ? P.x0[chain * d + r] : pdmp_randn(seed, PDMP_STREAM_INIT, (uint64_t)r);
+        };
+        auto th_of = [&](int64_t r) -> double {
+            return P.th0 ? P.th0[chain * d + r]
+                         : ((pdmp_u01(seed, PDMP_STREAM_INIT, (uint64_t)(d + r)) < 0.5) ? -1.0 : 1.0);
+        };
+        const double xi = x_of(i), thi = th_of(i);
+        double gx = 0.0, gt = 0.0;  // idot(Γ,i,x), idot(Γ,i,θ): src/common.jl:16-24
+        for (uint32_t p = P.tb.colptr[i]; p < P.tb.colptr[i + 1]; ++p) {
+            const uint32_t r = P.tb.rowval[p];
+            const double v = P.tb.bval[p];
+            gx += v * x_of(r);
+            gt += v * th_of(r);
+        }
+        const double ci = P.tb.c_shared[i];
+        if (P.c_chain) P.c_chain[chain * d + i] = ci;
+        const double a = ci + (gx - P.tb.gmu_b[i]) * thi;  // src/fact_samplers.jl:51
+        const double b = ci / 100 + thi * gt;             // :52
+        const double key = dev_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, (uint64_t)i));  // :186
+        ZzRec r;
+        r.x = xi;
+        r.th = thi;
+        r.t = P.t0;
+        r.I = 0.0;
+        r.t_old = P.t0;
+        r.a = a;
+        r.b = b;
+        r.acc = 0;
+        rec[i] = r;
+        keys[i] = key;
+    } else if (i < P.dk) {
+        double key = PDMP_INF;
+        if (i == d && P.has_refresh) {
+            // src/sfact.jl:189: enqueue!(Q, n+1 => waiting_time_ref(rng, F)) = randexp(rng)/λref
+            key = -pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, (uint64_t)d)) / P.lambda_ref;
+        }
+        keys[i] = key;
+    }
+    if (i == 0) {
+        DevChain h;
+        h.c.t_last = P.t0;
+        h.c.num = 0;
+        h.c.nacc = 0;
+        h.c.nrefresh = 0;
+        h.c.ntrace = 0;
+        h.c.nevents = 0;
+        h.c.ndraw_main = (uint64_t)d + (P.has_refresh ? 1u : 0u);
+        h.c.ndraw_global = 0;
+        h.c.status = PDMP_CHAIN_OK;
+        h.c.reserved = 0;
+        h.seed = seed;
+        h.t0 = P.t0;
+        h.t_event = P.t0;
+        for (int k = 0; k < 4; ++k) h.pad[k] = 0;
+        P.hdr[chain] = h;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ event loop
+//
+// spdmp_inner! (src/sfact.jl:73-145) under the driver loop `while t′ < T` (:199-208), G = Matched().
+
+size_t zz_local_lds_bytes(uint32_t nblk_pad) {
+    return (size_t)nblk_pad * 8 + 3 * 64 * 8 + (size_t)nblk_pad * 4;
+}
+
+__global__ __launch_bounds__(64) void zz_local_run_kernel(ZzRunParams P) {
+    const int lane = threadIdx.x;
+    const int64_t chain = blockIdx.x;
+    const int64_t d = P.d;
+    const uint32_t nblk = P.nblk;
+
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* bk = reinterpret_cast<double*>(smem);  // [nblk_pad] block minima
+    double* sx = bk + P.nblk_pad;                  // [64] x of S[i] after the move
+    double* sth = sx + 64;                         // [64] θ of S[i]
+    double* pk = sth + 64;                         // [64] patched copy of the popped key block
+    uint32_t* bi = reinterpret_cast<uint32_t*>(pk + 64);  // [nblk_pad] block argmin (coordinate id)
+
+    ZzRec* rec = P.rec + chain * d;
+    double* keys = P.keys + chain * P.dk;
+    DevChain* hdr = P.hdr + chain;
+    pdmp_event* ev = P.ev ? P.ev + chain * P.trace_cap : nullptr;
+    const double* cvec = P.c_chain ? (P.c_chain + chain * d) : P.tb.c_shared;
+    double* cmut = P.c_chain ? (P.c_chain + chain * d) : nullptr;
+
+    uint32_t status = hdr->c.status;
+    if (status == PDMP_CHAIN_BOUND_VIOLATED || status == PDMP_CHAIN_STALLED) return;
+    const uint64_t seed = hdr->seed;
+    uint64_t nm = hdr->c.ndraw_main;
+    uint64_t num = hdr->c.num, nacc = hdr->c.nacc, ntrace = hdr->c.ntrace, nevents = hdr->c.nevents;
+    double t_last = hdr->c.t_last;
+    double t_event = hdr->t_event;
+    status = PDMP_CHAIN_OK;
+
+    const double T = P.T;
+    const bool stop_before = (P.flags & PDMP_RUN_STOP_BEFORE) != 0;
+    const bool adapt = P.adapt != 0;
+
+    // ---- rebuild level 1 of the queue from the keys in HBM (each lane scans whole blocks)
+    for (uint32_t b = lane; b < nblk; b += 64) {
+        const double* kp = keys + (size_t)b * 64;
+        double mk = kp[0];
+        uint32_t mi = 0;
+#pragma unroll 8
+        for (int q = 1; q < 64; ++q) {
+            const double v = kp[q];
+            if (v < mk) {
+                mk = v;
+                mi = q;
+            }
+        }
+        bk[b] = mk;
+        bi[b] = b * 64 + mi;
+    }
+    __syncthreads();
+
+    bool running = stop_before || (t_event < T);  // `while t′ < T`, src/sfact.jl:199
+    while (running) {
+        if (P.trace_cap > 0 && ntrace >= (uint64_t)P.trace_cap) {
+            status = PDMP_CHAIN_TRACE_FULL;
+            break;
+        }
+        // ---------------- peek(Q), src/sfact.jl:77
+        double mk = PDMP_INF;
+        uint32_t mb = 0xffffffffu;
+        for (uint32_t b = lane; b < nblk; b += 64) {
+            const double v = bk[b];
+            if (v < mk) {
+                mk = v;
+                mb = b;
+            }
+        }
+        const double tp = wave_min_f64(mk);
+        if (!(tp < PDMP_INF)) {  // +Inf (or NaN): nothing can happen any more
+            status = PDMP_CHAIN_STALLED;
+            break;
+        }
+        if (stop_before && !(tp < T)) break;
+        const uint64_t ball = __ballot(mk == tp);
+        uint32_t blk;
+        if (__popcll(ball) == 1) {
+            blk = readlane_u32(mb, __ffsll((unsigned long long)ball) - 1);
+        } else {  // exact tie between blocks: lowest coordinate wins
+            blk = wave_min_u32((mk == tp) ? mb : 0xffffffffu);
+        }
+        const uint32_t i = uniform_u32(bi[blk]);
+        t_last = tp;
+
+        // ---------------- neighbourhood program of coordinate i
+        const uint32_t cp0 = P.tb.colptr[i];
+        const int k = (int)(P.tb.colptr[i + 1] - cp0);
+        const uint32_t sp0 = P.tb.sptr[i];
+        const int m = (int)(P.tb.sptr[i + 1] - sp0);
+        const int self = (int)P.tb.selfpos[i];
+        const uint32_t s = (lane < m) ? P.tb.sidx[sp0 + lane] : i;
+        ZzRec* rs = rec + s;
+        const ZzRec* ri = rec + i;
+
+        // ---------------- loads: G[i] positions, bound of i, own key block
+        double x = 0.0, th = 0.0, t = 0.0, I = 0.0;
+        if (lane < k) {
+            x = rs->x;
+            th = rs->th;
+            t = rs->t;
+            I = rs->I;
+        }
+        const double told_i = ri->t_old, a_i = ri->a, b_i = ri->b;
+        const uint64_t acc_i = ri->acc;
+        const double kb0 = keys[(size_t)blk * 64 + lane];
+        const double tv = (lane < k) ? P.tb.tval[cp0 + lane] : 0.0;
+
+        // ---------------- smove_forward!(G, i, t, x, θ, t′, F), src/sfact.jl:6-12,82
+        if (lane < k) {
+            const double dt = tp - t;
+            const double xn = x + th * dt;
+            I = I + dt * ((x + xn) * 0.5);
+            x = xn;
+            t = tp;
+        }
+        // ---------------- ∇ϕ(x, i) = idot(Γt, i, x) sequentially in ascending row order, src/common.jl:16-24
+        double g = 0.0;
+        for (int p = 0; p < k; ++p) g += readlane_f64(tv, p) * readlane_f64(x, p);
+        if (P.tb.gmu_t) g = g - P.tb.gmu_t[i];
+        const double th_i = readlane_f64(th, self);
+        const double l = pos_part(g * th_i);                       // sλ, src/sfact.jl:69,119
+        const double lb = pos_part(a_i + b_i * (tp - told_i));     // sλ̄, :70,119 (t[i] == t′ after the move)
+        num += 1;                                                  // :120
+        const double ucoin = pdmp_u01(seed, PDMP_STREAM_MAIN, nm); // :121
+        nm += 1;
+        const bool accept = (ucoin * lb < l);
+        bool violated = false;
+        int nmoved = k;
+        if (accept) {
+            nacc += 1;  // acc[i] += 1, :122
+            violated = (l >= lb);  // :123
+            if (violated && !adapt) {
+                // reference: error("Tuning parameter `c` too small."), :124 -> per-chain status word
+                status = PDMP_CHAIN_BOUND_VIOLATED;
+                if (lane < k) {
+                    rs->x = x;
+                    rs->t = t;
+                    rs->I = I;
+                }
+                break;
+            }
+            // smove_forward!(G2, i, ...), :129
+            if (lane >= k && lane < m) {
+                x = rs->x;
+                th = rs->th;
+                t = rs->t;
+                I = rs->I;
+                const double dt = tp - t;
+                const double xn = x + th * dt;
+                I = I + dt * ((x + xn) * 0.5);
+                x = xn;
+                t = tp;
+            }
+            nmoved = m;
+            if (lane == self) th = -th;  // reflect!, src/dynamics.jl:46-49, :130
+        }
+        // ---------------- stage (x, θ) of the moved neighbourhood for the re-bounding lanes
+        if (lane < nmoved) {
+            sx[lane] = x;
+            sth[lane] = th;
+        }
+        pk[lane] = kb0;
+        __syncthreads();
+
+        // ---------------- ab + new event time for j in G1[i] (accept, :131-135) or for i alone (reject, :137-139)
+        const bool active = accept ? (lane < k) : (lane == self);
+        double key = PDMP_INF;
+        if (active) {
+            const uint32_t j = s;
+            const uint32_t cj0 = P.tb.colptr[j];
+            const int kj = (int)(P.tb.colptr[j + 1] - cj0);
+            const uint32_t q0 = P.tb.qptr[cp0 + lane];
+            double gx = 0.0, gt = 0.0;
+            for (int pp = 0; pp < kj; ++pp) {
+                const double v = P.tb.bval[cj0 + pp];
+                const int ps = (int)P.tb.pos[q0 + pp];
+                gx += v * sx[ps];
+                gt += v * sth[ps];
+            }
+            double cj = cvec[j];
+            if (violated && lane == self) {  // adapt!(c, i, factor), src/fact_samplers.jl:67-70, :127
+                cj *= P.factor;
+                cmut[j] = cj;
+            }
+            const double a = cj + (gx - P.tb.gmu_b[j]) * th;  // src/fact_samplers.jl:51
+            const double b = cj / 100 + th * gt;             // :52
+            const uint64_t di = accept ? (nm + (uint64_t)lane) : nm;
+            const double uu = pdmp_u01(seed, PDMP_STREAM_MAIN, di);
+            key = t + dev_poisson_time(a, b, uu);  // Q[j] = t[j] + poisson_time(b[j], rand(rng))
+            rs->t_old = t;                         // t_old[j] = t[j]
+            rs->a = a;
+            rs->b = b;
+            keys[j] = key;
+            if ((j >> 6) == blk) pk[j & 63] = key;
+        }
+        nm += accept ? (uint64_t)k : 1u;
+
+        // ---------------- write back the moved coordinates
+        if (lane < nmoved) {
+            rs->x = x;
+            rs->th = th;
+            rs->t = t;
+            rs->I = I;
+        }
+        if (accept && lane == self) rs->acc = acc_i + 1;
+
+        // ---------------- queue: re-reduce the popped block from the patched register copy
+        __syncthreads();
+        {
+            const double kb = pk[lane];
+            const double mn = wave_min_f64(kb);
+            const uint64_t bl = __ballot(kb == mn);
+            const int arg = bl ? (__ffsll((unsigned long long)bl) - 1) : 0;
+            if (lane == 0) {
+                bk[blk] = mn;
+                bi[blk] = blk * 64 + (uint32_t)arg;
+            }
+        }
+        // ---------------- queue: neighbours that live in other blocks
+        if (accept) {
+            for (int jj = 0; jj < k; ++jj) {
+                const uint32_t j = readlane_u32(s, jj);
+                const uint32_t bj = j >> 6;
+                if (bj == blk) continue;
+                const double kj = readlane_f64(key, jj);
+                __syncthreads();
+                const double cur = bk[bj];
+                const uint32_t ci = bi[bj];
+                if (kj < cur || (kj == cur && j < ci)) {
+                    if (lane == 0) {
+                        bk[bj] = kj;
+                        bi[bj] = j;
+                    }
+                } else if (ci == j) {
+                    // j was its block's minimum and moved later: rescan that block (keys[] already updated)
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                    const double kv = __hip_atomic_load(keys + (size_t)bj * 64 + lane, __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT);
+                    const double mn = wave_min_f64(kv);
+                    const uint64_t bl = __ballot(kv == mn);
+                    const int arg = bl ? (__ffsll((unsigned long long)bl) - 1) : 0;
+                    if (lane == 0) {
+                        bk[bj] = mn;
+                        bi[bj] = bj * 64 + (uint32_t)arg;
+                    }
+                }
+            }
+            // ---------------- event(i, t, x, θ, F) = (t[i], i, x[i], θ[i]), src/sfact.jl:50-52,143
+            const double x_i = readlane_f64(x, self);
+            const double thn_i = readlane_f64(th, self);
+            if (ev && lane == 0) {
+                pdmp_event e;
+                e.t = tp;
+                e.i = (int64_t)i;
+                e.x = x_i;
+                e.theta = thn_i;
+                ev[ntrace] = e;
+            }
+            ntrace += 1;
+            nevents += 1;
+            t_event = tp;
+            if (!stop_before && !(tp < T)) running = false;  // `while t′ < T`
+        }
+        __syncthreads();
+    }
+
+    if (lane == 0) {
+        hdr->c.t_last = t_last;
+        hdr->t_event = t_event;
+        hdr->c.num = num;
+        hdr->c.nacc = nacc;
+        hdr->c.ntrace = ntrace;
+        hdr->c.nevents = nevents;
+        hdr->c.ndraw_main = nm;
+        hdr->c.status = status;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ unpack / moments
+
+// final state (t, x, θ), acc, c of chains [chain_first, chain_first + n): src/sfact.jl:211
+__global__ __launch_bounds__(256) void zz_unpack_kernel(const ZzRec* rec, const double* c_src, int64_t c_stride,
+                                                        int64_t d, int64_t chain_first, double* t, double* x,
+                                                        double* th, int64_t* acc, double* c) {
+    const int64_t n = blockIdx.x;
+    const int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x;
+    if (i >= d) return;
+    const ZzRec r = rec[(chain_first + n) * d + i];
+    const int64_t o = n * d + i;
+    if (t) t[o] = r.t;
+    if (x) x[o] = r.x;
+    if (th) th[o] = r.th;
+    if (acc) acc[o] = (int64_t)r.acc;
+    if (c) c[o] = c_src[(chain_first + n) * c_stride + i];
+}
+
+// Batch means of the exact path integral: J = I + ∫_t^T (x + θ(s-t)) ds, Y = (J - Jprev)/ΔT per chain,
+// ΣY and ΣY² over chains.  Threads own a coordinate and walk a group of chains (records are 64 B, so a
+// warp of consecutive coordinates reads consecutive sectors).
+__global__ __launch_bounds__(256) void zz_batch_means_kernel(const ZzRec* rec, double* jprev, int64_t d,
+                                                             int64_t nchains, int64_t chains_per_group,
+                                                             double T_prev, double T, double* sum_y, double* sum_y2) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= d) return;
+    const int64_t c0 = (int64_t)blockIdx.y * chains_per_group;
+    const int64_t c1 = (c0 + chains_per_group < nchains) ? (c0 + chains_per_group) : nchains;
+    const double inv = 1.0 / (T - T_prev);
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t ch = c0; ch < c1; ++ch) {
+        const ZzRec* r = rec + ch * d + i;
+        const double dt = T - r->t;
+        const double J = r->I + dt * (r->x + r->th * (dt * 0.5));
+        const double y = (J - jprev[ch * d + i]) * inv;
+        jprev[ch * d + i] = J;
+        s1 += y;
+        s2 += y * y;
+    }
+    atomicAdd(sum_y + i, s1);
+    atomicAdd(sum_y2 + i, s2);
+}
+
+// ------------------------------------------------------------------------------------------ math probe
+//
+// Evaluates the shared numerical contract on the device so that a test can compare it bit-for-bit with
+// the host: row 0 u01, 1 pdmp_log(u), 2 a/b, 3 sqrt, 4 poisson_time(a,b,w), 5 pdmp_randn.
+__global__ __launch_bounds__(256) void math_probe_kernel(uint64_t seed, int64_t n, double* out) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const double u = pdmp_u01(seed, 0u, (uint64_t)k);
+    const double v = pdmp_u01(seed, 1u, (uint64_t)k);
+    const double w = pdmp_u01(seed, 2u, (uint64_t)k);
+    const double a = (u - 0.5) * 8.0;
+    const double b = ((k % 7) == 0) ? 0.0 : (v - 0.5) * 4.0;
+    out[0 * n + k] = u;
+    out[1 * n + k] = pdmp_log(u);
+    out[2 * n + k] = a / ((v - 0.5) * 4.0);
+    out[3 * n + k] = sqrt(u * 1000.0 + v);
+    out[4 * n + k] = dev_poisson_time(a, b, w);
+    out[5 * n + k] = pdmp_randn(seed, 3u, (uint64_t)k);
+}
+
+int launch_math_probe(uint64_t seed, int64_t n, double* out, void* stream) {
+    hipLaunchKernelGGL(math_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed,
+                       n, out);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ launchers
+
+int launch_zz_init(const ZzInitParams& p, void* stream) {
+    dim3 grid((unsigned)p.nchains, (unsigned)((p.dk + 255) / 256));
+    hipLaunchKernelGGL(zz_init_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}
+
+int launch_zz_local_run(const ZzRunParams& p, int64_t nchains, void* stream) {
+    const size_t lds = zz_local_lds_bytes(p.nblk_pad);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(zz_local_run_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(zz_local_run_kernel, dim3((unsigned)nchains), dim3(64), lds, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}
+
+int launch_zz_unpack(const ZzRec* rec, const double* c_src, int64_t c_stride, int64_t d, int64_t chain_first,
+                     int64_t n, double* t, double* x, double* th, int64_t* acc, double* c, void* stream) {
+    dim3 grid((unsigned)n, (unsigned)((d + 255) / 256));
+    hipLaunchKernelGGL(zz_unpack_kernel, grid, dim3(256), 0, (hipStream_t)stream, rec, c_src, c_stride, d,
+                       chain_first, t, x, th, acc, c);
+    return (int)hipGetLastError();
+}
+
+int launch_zz_batch_means(const ZzRec* rec, double* jprev, int64_t d, int64_t nchains, double T_prev, double T,
+                          double* sum_y, double* sum_y2, void* stream) {
+    const int64_t groups = (nchains < 64) ? 1 : 64;
+    const int64_t per = (nchains + groups - 1) / groups;
+    dim3 grid((unsigned)((d + 255) / 256), (unsigned)groups);
+    hipLaunchKernelGGL(zz_batch_means_kernel, grid, dim3(256), 0, (hipStream_t)stream, rec, jprev, d, nchains, per,
+                       T_prev, T, sum_y, sum_y2);
+    return (int)hipGetLastError();
+}
+
+}  // namespace pdmp

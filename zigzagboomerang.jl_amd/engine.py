@@ -1,0 +1,150 @@
+"""Ensemble: thin object wrapper over the C ABI handle `pdmp_ensemble*` (include/pdmp_mi355.h).
+
+All compute happens inside libpdmp_mi355.so on the gfx950 device; this file only marshals numpy arrays.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .types import GaussianTarget, ZigZag
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+class Ensemble:
+    """An ensemble of independent chains on one MI355X, one chain per wavefront."""
+
+    def __init__(self, nchains, d, *, sampler=_lib.SAMPLER_ZIGZAG_LOCAL, adapt=False, factor=1.8, device=0,
+                 trace_capacity=0):
+        self._L = _lib.load()
+        self.nchains, self.d = int(nchains), int(d)
+        self.trace_capacity = int(trace_capacity)
+        self.adapt = bool(adapt)
+        cfg = _lib.PdmpConfig(C.sizeof(_lib.PdmpConfig), int(device), int(sampler), int(bool(adapt)), float(factor),
+                              self.nchains, self.d, self.trace_capacity)
+        h = C.c_void_p()
+        _lib.check(self._L.pdmp_ensemble_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pdmp_ensemble_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- configuration
+    def set_flow(self, F: ZigZag):
+        G = F.Γ
+        if G.shape != (self.d, self.d):
+            raise ValueError("flow Γ has the wrong shape")
+        cp, rv, nz = _i64(G.indptr), _i64(G.indices), _f64(G.data)
+        mu, sg = _f64(F.μ), _f64(F.σ)
+        _lib.check(self._L.pdmp_ensemble_set_flow_zigzag(self._h, _ptr(cp), _ptr(rv), _ptr(nz), _ptr(mu), _ptr(sg),
+                                                        float(F.λref), float(F.ρ)))
+
+    def set_target(self, target: GaussianTarget):
+        G = target.Γ
+        if G.shape != (self.d, self.d):
+            raise ValueError("target Γ has the wrong shape")
+        cp, rv, nz = _i64(G.indptr), _i64(G.indices), _f64(G.data)
+        mu = None if target.μ is None else _f64(target.μ)
+        _lib.check(self._L.pdmp_ensemble_set_target_gaussian_csc(self._h, _ptr(cp), _ptr(rv), _ptr(nz), _ptr(mu)))
+
+    def set_state(self, t0, x0, theta0, c, seeds):
+        x0 = _f64(x0).reshape(self.nchains, self.d)
+        theta0 = _f64(theta0).reshape(self.nchains, self.d)
+        c = _f64(c).reshape(self.d)
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64).reshape(self.nchains)
+        _lib.check(self._L.pdmp_ensemble_set_state(self._h, float(t0), _ptr(x0), _ptr(theta0), _ptr(c), _ptr(seeds)))
+
+    def set_state_synthetic(self, t0, c, seed0):
+        c = _f64(c).reshape(self.d)
+        _lib.check(self._L.pdmp_ensemble_set_state_synthetic(self._h, float(t0), _ptr(c), int(seed0)))
+
+    # ---- running
+    def run(self, T, flags=_lib.RUN_REFERENCE_TAIL, stream=None, sync=True):
+        _lib.check(self._L.pdmp_ensemble_run(self._h, float(T), int(flags), stream))
+        if sync:
+            self.sync()
+
+    def sync(self):
+        _lib.check(self._L.pdmp_ensemble_sync(self._h))
+
+    def last_run_ms(self):
+        ms = C.c_float()
+        _lib.check(self._L.pdmp_ensemble_last_run_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    # ---- results
+    def counters(self):
+        out = np.empty(self.nchains, dtype=_lib.COUNTERS_DTYPE)
+        _lib.check(self._L.pdmp_ensemble_counters(self._h, _ptr(out)))
+        return out
+
+    def totals(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _lib.check(self._L.pdmp_ensemble_totals(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(num=a.value, nacc=b.value, nevents=c.value)
+
+    def trace(self, chain, first=0, count=None, counters=None):
+        if counters is None:
+            counters = self.counters()
+        n = int(counters["ntrace"][chain])
+        if count is None:
+            count = n - first
+        out = np.empty(count, dtype=_lib.EVENT_DTYPE)
+        _lib.check(self._L.pdmp_ensemble_trace_copy(self._h, int(chain), int(first), int(count), _ptr(out)))
+        return out
+
+    def trace_reset(self):
+        _lib.check(self._L.pdmp_ensemble_trace_reset(self._h))
+
+    def final_state(self, chain_first=0, n=None, want_c=True):
+        if n is None:
+            n = self.nchains - chain_first
+        t = np.empty((n, self.d))
+        x = np.empty((n, self.d))
+        th = np.empty((n, self.d))
+        acc = np.empty((n, self.d), dtype=np.int64)
+        c = np.empty((n, self.d)) if want_c else None
+        _lib.check(self._L.pdmp_ensemble_final_state(self._h, int(chain_first), int(n), _ptr(t), _ptr(x), _ptr(th),
+                                                    _ptr(acc), _ptr(c)))
+        return dict(t=t, x=x, theta=th, acc=acc, c=c)
+
+    def batch_means(self, T_prev, T):
+        s1 = np.empty(self.d)
+        s2 = np.empty(self.d)
+        _lib.check(self._L.pdmp_ensemble_batch_means(self._h, float(T_prev), float(T), _ptr(s1), _ptr(s2)))
+        return s1, s2
+
+    def trace_dev(self):
+        p, cap = C.c_void_p(), C.c_int64()
+        _lib.check(self._L.pdmp_ensemble_trace_dev(self._h, C.byref(p), C.byref(cap)))
+        return p.value, cap.value
+
+    def counters_dev(self):
+        p = C.c_void_p()
+        _lib.check(self._L.pdmp_ensemble_counters_dev(self._h, C.byref(p)))
+        return p.value

@@ -1,0 +1,76 @@
+"""Host-side mirror of the reference's sampler entry points for the device-resident hot path.
+
+    spdmp(∇ϕ, t0, x0, θ0, T, c, F::ZigZag, args...; factor=1.8, adapt=false, seed) = Ξ, (t, x, θ), (acc, num), c
+                                                                        (src/sfact.jl:162-163,211,214)
+
+Differences forced by the C ABI: `∇ϕ, args...` is replaced by an enumerated `target` (GaussianTarget);
+coordinates are 0-based; x0/θ0 may be [nchains, d] to run an ensemble (outputs then carry a leading chain
+axis).  Everything else -- argument order, keyword names, the 4-tuple returned, the error raised when the
+bound `c` is too small with adapt=false -- follows the reference.
+"""
+import numpy as np
+
+from . import _lib
+from .engine import Ensemble
+from .types import FactTrace, GaussianTarget, ZigZag
+
+DEFAULT_SEED = 0x5EED0000
+
+
+def _drain(ens, events):
+    cnt = ens.counters()
+    for k in range(ens.nchains):
+        n = int(cnt["ntrace"][k])
+        if n:
+            events[k].append(ens.trace(k, 0, n, counters=cnt))
+    ens.trace_reset()
+
+
+def spdmp(target, t0, x0, θ0, T, c, F, *, factor=1.8, adapt=False, seed=DEFAULT_SEED, device=0,
+          trace_capacity=None, trace=True):
+    """Local ZigZag (spdmp with G = Matched()).  Returns Ξ, (t, x, θ), (acc, num), c like the reference."""
+    if not isinstance(F, ZigZag):
+        raise TypeError("spdmp on the device supports F::ZigZag")
+    if not isinstance(target, GaussianTarget):
+        raise TypeError("target must be one of the device-resident families (GaussianTarget)")
+    x0 = np.asarray(x0, dtype=np.float64)
+    θ0 = np.asarray(θ0, dtype=np.float64)
+    single = x0.ndim == 1
+    X0 = np.atleast_2d(x0)
+    TH0 = np.atleast_2d(θ0)
+    nch, d = X0.shape
+    c = np.asarray(c, dtype=np.float64)
+    seeds = (np.uint64(seed) + np.arange(nch, dtype=np.uint64)) if np.isscalar(seed) else np.asarray(seed, np.uint64)
+    if trace_capacity is None:
+        # ~0.8 reflections per coordinate per unit time on the GMRF; generous first guess, refilled on demand
+        trace_capacity = int(min(max(1024, 2.0 * d * max(T - t0, 1.0)), 1 << 22))
+    cap = trace_capacity if trace else 0
+    ens = Ensemble(nch, d, sampler=_lib.SAMPLER_ZIGZAG_LOCAL, adapt=adapt, factor=factor, device=device,
+                   trace_capacity=cap)
+    try:
+        ens.set_flow(F)
+        ens.set_target(target)
+        ens.set_state(t0, X0, TH0, c, seeds)
+        events = [[] for _ in range(nch)]
+        while True:
+            ens.run(T, _lib.RUN_REFERENCE_TAIL)
+            cnt = ens.counters()
+            if np.any(cnt["status"] == _lib.CHAIN_BOUND_VIOLATED):
+                raise RuntimeError("Tuning parameter `c` too small.")  # src/sfact.jl:124
+            if trace:
+                _drain(ens, events)
+            if not np.any(cnt["status"] == _lib.CHAIN_TRACE_FULL):
+                break
+        fs = ens.final_state()
+        cnt = ens.counters()
+    finally:
+        ens.close()
+    traces = []
+    for k in range(nch):
+        ev = np.concatenate(events[k]) if events[k] else np.empty(0, dtype=_lib.EVENT_DTYPE)
+        traces.append(FactTrace(F, t0, X0[k].copy(), TH0[k].copy(), ev))
+    num = cnt["num"].astype(np.int64)
+    c_out = fs["c"] if adapt else np.broadcast_to(c, (nch, d)).copy()
+    if single:
+        return traces[0], (fs["t"][0], fs["x"][0], fs["theta"][0]), (fs["acc"][0], int(num[0])), c_out[0]
+    return traces, (fs["t"], fs["x"], fs["theta"]), (fs["acc"], num), c_out

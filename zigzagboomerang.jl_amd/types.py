@@ -1,0 +1,82 @@
+"""Parameter carriers mirroring the reference's dynamics descriptors (src/types.jl).
+
+The reference passes a gradient closure ∇ϕ; a closure cannot cross the C ABI, so targets are an
+enumerated set of device-resident families (GaussianTarget so far: the closure of
+scripts/gaussianrandomfield.jl:25 and test/maintest.jl:9).
+"""
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+import scipy.sparse as sp
+
+
+def _csc(A):
+    A = sp.csc_matrix(A, dtype=np.float64)
+    A.sort_indices()
+    A.sum_duplicates()
+    return A
+
+
+@dataclass
+class ZigZag:
+    """ZigZag(Γ, μ, σ=diag(Γ).^(-0.5); λref=0.0, ρ=0.0)  -- src/types.jl:19-27.
+
+    Γ is the sparse precision used for the affine bounds (and whose column pattern defines the local
+    neighbourhoods G1/G2, src/sfact.jl:170-179); μ the approximate target mean.
+    """
+    Γ: sp.csc_matrix
+    μ: np.ndarray
+    σ: Optional[np.ndarray] = None
+    λref: float = 0.0
+    ρ: float = 0.0
+
+    def __post_init__(self):
+        self.Γ = _csc(self.Γ)
+        self.μ = np.ascontiguousarray(self.μ, dtype=np.float64)
+        if self.σ is None:
+            self.σ = np.asarray(self.Γ.diagonal(), dtype=np.float64) ** (-0.5)
+        self.σ = np.ascontiguousarray(self.σ, dtype=np.float64)
+
+    @property
+    def ρ̄(self):
+        return float(np.sqrt(1 - self.ρ ** 2))
+
+
+@dataclass
+class BouncyParticle:
+    """BouncyParticle(Γ, μ, λ; ρ=0.0) -- src/types.jl:35-45 (mass L = cholesky(Symmetric(Γ)).L)."""
+    Γ: sp.csc_matrix
+    μ: np.ndarray
+    λref: float
+    ρ: float = 0.0
+
+    def __post_init__(self):
+        self.Γ = _csc(self.Γ)
+        self.μ = np.ascontiguousarray(self.μ, dtype=np.float64)
+
+
+@dataclass
+class GaussianTarget:
+    """∇ϕ(x, i) = Γ[:, i]·x  [− Γ[:, i]·μ]  (idot, src/common.jl:16-24): the device-resident stand-in
+    for the reference's `∇ϕ(x, i, Γ) = idot(Γ, i, x)` closure + its `args... = (Γ,)`."""
+    Γ: sp.csc_matrix
+    μ: Optional[np.ndarray] = None
+
+    def __post_init__(self):
+        self.Γ = _csc(self.Γ)
+        if self.μ is not None:
+            self.μ = np.ascontiguousarray(self.μ, dtype=np.float64)
+
+
+@dataclass
+class FactTrace:
+    """FactTrace(F, t0, x0, θ0, events) -- src/trace.jl:7-13; events are (t, i, x_i, θ_i), i 0-based."""
+    F: object
+    t0: float
+    x0: np.ndarray
+    θ0: np.ndarray
+    events: np.ndarray = field(default_factory=lambda: np.empty(0))
+
+    def __len__(self):  # Base.length(FT::Trace) = 1 + length(FT.events), src/trace.jl:42
+        return 1 + len(self.events)
