@@ -1,0 +1,227 @@
+#!/usr/bin/env python
+"""bench.py -- reflection events/s (+ ESS/s) of the local-ZigZag hot path on config C3.
+
+Workload (BASELINE.json configs[2], the one `metric` is quoted on):
+    Γ = 0.01 I + gridlaplacian(128,128)  (scripts/gridlaplace.jl:4-21, scripts/gaussianrandomfield.jl:15), d = 16384,
+    ∇ϕ(x,i) = Γ[:,i]·x, Z = ZigZag(Γ, 0), c[i] = ‖Γ[:,i]‖₂, x0 ~ N(0,I), θ0 ∈ {±1}, t0 = 0, adapt = false,
+    4096 chains PER GPU (weak scaling: chains are independent, no data-path collective), Philox seeds 0x5EED0000 + chain.
+A "step" advances every chain by ΔT = 1.0 time units through pdmp_ensemble_run (one persistent kernel launch);
+the initial state is generated on the device, so inputs are resident in HBM when the timed region starts.
+Traces ARE written (32 B/event into a per-chain HBM segment, part of the algorithmic bytes) and recycled every step.
+
+    python bench.py --gpus 1 --steps 20 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and, at N=1, `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+GRID = 128
+CHAINS_PER_GPU = 4096
+DT_STEP = 1.0
+SEED0 = 0x5EED0000
+
+
+def algorithmic_bytes(num, nacc):
+    """224 B per proposal + 48 B per rejection + 616 B per accepted reflection."""
+    return 224.0 * num + 48.0 * (num - nacc) + 616.0 * nacc
+
+
+def cpu_baseline(pkg, G, c, budget_s=15.0):
+    """The CPU oracle (a C port of the reference algorithm, kind="port") on the host cores, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    d = G.shape[0]
+    ncores = os.cpu_count() or 1
+    # calibrate on one short chain, then size the sample to ~budget_s of wall time on all cores
+    x0, th0 = O.synthetic_state(SEED0, d)
+    s1, n1, a1 = O.spdmp_zigzag_ensemble(G, None, G, x0[None], th0[None], c, 1.0, seed0=SEED0, nthreads=1)
+    per_chain_per_T = max(s1, 1e-3)
+    nch = ncores * 2
+    T = float(np.clip(budget_s / (2 * per_chain_per_T), 1.0, 20.0))
+    X0 = np.stack([O.synthetic_state(SEED0 + k, d)[0] for k in range(nch)])
+    TH0 = np.stack([O.synthetic_state(SEED0 + k, d)[1] for k in range(nch)])
+    secs, num, acc = O.spdmp_zigzag_ensemble(G, None, G, X0, TH0, c, T, seed0=SEED0, nthreads=ncores)
+    s_single, n_single, a_single = O.spdmp_zigzag_ensemble(G, None, G, X0[:1], TH0[:1], c, min(T, 4.0), seed0=SEED0, nthreads=1)
+    return {"value": acc / secs, "unit": "reflection events/s", "cores": ncores, "kind": "port",
+            "sample": f"{nch} chains of config C3 (d=16384) to T={T:.2f} on {ncores} threads, chain-parallel; "
+                      f"same algorithm/seeds/event sequence as the GPU chains",
+            "proposals_per_s": num / secs, "single_thread_events_per_s": a_single / s_single,
+            "acceptance": acc / max(num, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--chains", type=int, default=CHAINS_PER_GPU, help="chains per GPU")
+    ap.add_argument("--grid", type=int, default=GRID)
+    ap.add_argument("--dt", type=float, default=DT_STEP)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-trace", action="store_true", help="count events only (diagnostic; not the headline mode)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+
+    pkg = load_package()
+    pkg.build.build()
+    if pkg._lib.device_count() < 1:
+        raise SystemExit("bench.py: no gfx950 device visible; the engine has no CPU fallback")
+    G = pkg.problems.gmrf_precision(args.grid)
+    d = G.shape[0]
+    c = pkg.problems.column_norms(G)
+    nch = args.chains
+    # events per chain per unit time ~0.8 d; 2x head-room, recycled every step
+    cap = 0 if args.no_trace else int(2.0 * d * args.dt) + 1024
+    ens = pkg.Ensemble(nch, d, device=local_rank, trace_capacity=cap)
+    ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
+    ens.set_target(pkg.GaussianTarget(G))
+    ens.set_state_synthetic(0.0, c, SEED0 + rank * nch)
+
+    def barrier():
+        ens.sync()
+        if dist is not None:
+            dist.barrier()
+            import torch
+            torch.cuda.synchronize()
+
+    def step(k):
+        T = (k + 1) * args.dt
+        ens.run(T, pkg._lib.RUN_STOP_BEFORE, sync=False)
+        ms = ens.last_run_ms()  # HIP events on the launch stream; also waits for the kernel
+        if cap:
+            ens.trace_reset()
+        return ms
+
+    tot_prev = None
+    for k in range(args.warmup):
+        step(k)
+    barrier()
+    tot0 = ens.totals()
+    kernel_ms = []
+    sum_y = np.zeros(d)
+    sum_y2 = np.zeros(d)
+    t_start = time.perf_counter()
+    for k in range(args.warmup, args.warmup + args.steps):
+        kernel_ms.append(step(k))
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    tot1 = ens.totals()
+    cnt = ens.counters()
+    bad = int(np.count_nonzero(cnt["status"] != pkg._lib.CHAIN_OK))
+
+    num = tot1["num"] - tot0["num"]
+    nacc = tot1["nacc"] - tot0["nacc"]
+    nev = tot1["nevents"] - tot0["nevents"]
+
+    # ESS/s: batch means of the exact path integral, one batch per extra slice AFTER the timed region
+    ess = None
+    if rank == 0 and world == 1 and not args.no_trace and args.steps >= 4:
+        B = 8
+        T0 = (args.warmup + args.steps) * args.dt
+        s1 = np.zeros(d)
+        s2 = np.zeros(d)
+        t_ess = time.perf_counter()
+        ens.batch_means(0.0, T0)  # sets the baseline J(T0); its Y over [0,T0] is discarded (burn-in)
+        for b in range(B):
+            Tb = T0 + (b + 1) * args.dt
+            ens.run(Tb, pkg._lib.RUN_STOP_BEFORE)
+            ens.trace_reset()
+            a, q = ens.batch_means(Tb - args.dt, Tb)
+            s1 += a
+            s2 += q
+        t_ess = time.perf_counter() - t_ess
+        n = B * nch
+        var_y = (s2 - s1 * s1 / n) / (n - 1)
+        import scipy.sparse.linalg as spla
+        lu = spla.splu(G.tocsc())
+        probes = np.linspace(0, d - 1, 32).astype(int)
+        var_pi = np.array([lu.solve(np.eye(1, d, p).ravel())[p] for p in probes])
+        ess_i = n * var_pi / np.maximum(var_y[probes], 1e-300)  # ESS over all chains and batches, per coordinate
+        ess = {"definition": "batch means of exact path integrals, B=8 batches x all chains, 32 probe coordinates, "
+                             "Var_pi = exact diag(inv(Gamma))",
+               "ess_min_per_s": float(ess_i.min() / t_ess), "ess_median_per_s": float(np.median(ess_i) / t_ess),
+               "seconds": t_ess}
+
+    # aggregate over ranks: max time, summed work
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ww = torch.tensor([float(num), float(nacc), float(nev), float(bad)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(ww, op=dist.ReduceOp.SUM)
+        elapsed = float(tt.item())
+        num_all, nacc_all, nev_all, bad_all = [float(v) for v in ww.tolist()]
+    else:
+        num_all, nacc_all, nev_all, bad_all = float(num), float(nacc), float(nev), float(bad)
+
+    if rank == 0:
+        k_ms = float(np.mean(kernel_ms))
+        bytes_launch = algorithmic_bytes(num, nacc) / args.steps
+        achieved = bytes_launch / (k_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_per_proposal.json")
+        if os.path.exists(tpath):
+            tp = json.load(open(tpath))
+            traffic = tp["hbm_bytes_per_proposal"] * (num / args.steps)
+        out = {
+            "metric": "reflection events/sec, d=16384 local ZigZag (spdmp), ensemble of independent chains",
+            "value": nev_all / elapsed,
+            "unit": "reflection events/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"C3: local ZigZag spdmp on Gamma=0.01I+gridlaplacian({args.grid},{args.grid}), d={d}, "
+                                   f"{nch} chains/GPU, step = advance all chains by dT={args.dt}, traces "
+                                   f"{'off' if args.no_trace else 'on (32 B/event)'}",
+                       "chains_per_gpu": nch, "d": d, "dT": args.dt, "parallelism": f"chains sharded x{world}, no collective in the run"},
+            "proposals_per_s": num_all / elapsed,
+            "acceptance": nacc_all / max(num_all, 1.0),
+            "unhealthy_chains": bad_all,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "zz_local_run_kernel", "kernel_ms_avg": k_ms,
+                         "algorithmic_bytes_per_launch": bytes_launch,
+                         "model": "224*num + 48*(num-nacc) + 616*nacc bytes (SURVEY 8d3)"},
+        }
+        if ess is not None:
+            out["ess"] = ess
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pkg, G, c)
+        print(json.dumps(out), flush=True)
+    ens.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

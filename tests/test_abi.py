@@ -1,0 +1,51 @@
+"""The C-ABI library loads (no GPU needed) and exports exactly what include/pdmp_mi355.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "pdmp_mi355.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pdmp_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree(pkg):
+    assert declared_functions() == sorted(pkg._lib.EXPORTED_SYMBOLS)
+
+
+def test_library_loads_and_exports_every_symbol(pkg):
+    pkg.build.build()
+    L = ctypes.CDLL(pkg._lib.lib_path())
+    for name in declared_functions():
+        assert hasattr(L, name), name
+    assert pkg._lib.load().pdmp_abi_version() == 1
+
+
+def test_struct_sizes(pkg):
+    assert ctypes.sizeof(pkg._lib.PdmpConfig) == 48
+    assert pkg._lib.EVENT_DTYPE.itemsize == 32 and pkg._lib.COUNTERS_DTYPE.itemsize == 72
+
+
+def test_no_cpu_fallback_without_device(pkg):
+    """On a box without a GPU, creating an ensemble must fail loudly (PDMP_ERR_NO_DEVICE), never emulate."""
+    if pkg._lib.device_count() > 0:
+        pytest.skip("a gfx950 device is present")
+    with pytest.raises(pkg._lib.PdmpError) as ei:
+        pkg.Ensemble(1, 4)
+    assert ei.value.code == 2
+
+
+def test_product_never_imports_the_oracle():
+    pkg_dir = os.path.join(ROOT, "zigzagboomerang.jl_amd")
+    for dp, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                txt = open(os.path.join(dp, f), errors="replace").read()
+                assert "oracle_lib" not in txt and "liboracle" not in txt, (dp, f)
+                assert not re.search(r'#include\s*[<"][^>"]*oracle', txt), (dp, f)
+                assert not re.search(r'^\s*(from|import)\s+\S*oracle', txt, flags=re.M), (dp, f)

@@ -1,0 +1,199 @@
+"""The oracle's samplers against the reference's STATISTICAL acceptance tests (the only pins that exist:
+the reference holds no golden event sequences) and against the committed golden fixtures."""
+import hashlib
+import math
+
+import numpy as np
+import scipy.sparse as sp
+
+import oracle_lib as O
+
+
+def test_zigzag1d_statistics():
+    """test/test1d.jl:13-27: ZigZag1d on N(π/3, 1.3), T=8000, c=10."""
+    mu, s2, T = math.pi / 3, 1.3, 8000.0
+    ev, acc, num = O.pdmp_zigzag1d(mu, s2, 1.01, -1.5, T, 10.0, seed=3)
+    N = len(ev)
+    assert T / 10 < N < T * 10
+    t, x = ev["t"], ev["x"]
+    est = np.sum((x[:-1] + x[1:]) / 2 * np.diff(t)) / T
+    assert abs(est - mu) < 2 / math.sqrt(N)
+    xa, xb, dt = x[:-1], x[1:], np.diff(t)
+    m2 = np.sum(dt * (xa * xa + xa * xb + xb * xb) / 3) / t[-1]
+    assert abs((m2 - est ** 2) - s2) < 2.5 / math.sqrt(N) + 0.05
+    assert 0 < acc / num < 1
+
+
+def test_golden_c1_chain(golden):
+    ev, acc, num = O.pdmp_zigzag1d(0.0, 1.0, 1.01, -1.5, 1000.0, 10.0, seed=0x5EED0000)
+    got = np.stack([ev["t"], ev["x"], ev["theta"]], axis=1)
+    assert np.array_equal(got, golden["c1_events"])
+    assert [acc, num] == golden["c1_acc_num"].tolist()
+    assert ev["t"][-2] < 1000.0  # `while t < T` counts proposals, so the last recorded flip may precede T
+
+
+def _zz_case(pkg, golden, name, scale):
+    G = pkg.problems.maintest_precision(8) if name == "d8" else pkg.problems.gmrf_precision(8)
+    return G, scale * G, golden[f"{name}_x0"], golden[f"{name}_th0"], golden[f"{name}_c"]
+
+
+def test_golden_local_zigzag_chains(pkg, golden):
+    for name, scale in (("d8", 0.9), ("grid8", 1.0)):
+        G, Gb, x0, th0, c = _zz_case(pkg, golden, name, scale)
+        r = O.spdmp_zigzag(Gb, None, G, x0, th0, c, 50.0, seed=1234)
+        ev, want = r["events"], golden[f"{name}_events"]
+        assert len(ev) == len(want)
+        for f in ("t", "i", "x", "theta"):
+            assert np.array_equal(ev[f], want[f]), (name, f)
+        assert np.array_equal(r["acc"], golden[f"{name}_acc"]) and r["num"] == golden[f"{name}_num"][0]
+        assert np.array_equal(np.stack([r["t"], r["x"], r["theta"]]), golden[f"{name}_final"])
+        # structure of a FactTrace: times non-decreasing, event = state after the flip, last event beyond T
+        assert np.all(np.diff(ev["t"]) >= 0) and ev["t"][-1] >= 50.0 > ev["t"][-2]
+        assert r["acc"].sum() == len(ev)
+
+
+def test_golden_c3_first_events(pkg, golden):
+    G = pkg.problems.gmrf_precision(128)
+    c = pkg.problems.column_norms(G)
+    for k in range(2):
+        seed = 0x5EED0000 + k
+        x0, th0 = O.synthetic_state(seed, G.shape[0])
+        r = O.spdmp_zigzag(G, None, G, x0, th0, c, 1e9, seed=seed, max_events=10000)
+        ev = r["events"][:10000]
+        assert np.array_equal(ev["i"].astype(np.uint16), golden[f"c3_chain{k}_idx"])
+        h = hashlib.sha256()
+        for f in ("t", "x", "theta"):
+            h.update(np.ascontiguousarray(ev[f]).tobytes())
+        assert h.hexdigest() == str(golden[f"c3_chain{k}_hash"][0])
+
+
+def test_local_zigzag_statistics_d8(pkg):
+    """test/maintest.jl:37-61 (SZigZag): Γ = S S', Z = ZigZag(0.9Γ, 0), T = 1000, discretize dt = 0.5."""
+    G = pkg.problems.maintest_precision(8)
+    d, T = 8, 1000.0
+    rng = np.random.default_rng(2)
+    x0 = rng.random(d)
+    th0 = rng.choice([-1.0, -0.5, 0.5, 1.0], d)
+    c = 0.7 * pkg.problems.column_norms(G)
+    r = O.spdmp_zigzag(0.9 * G, None, G, x0, th0, c, T, seed=21, adapt=True, factor=1.8)
+    assert r["status"] == 0
+    tr = pkg.FactTrace(None, 0.0, x0, th0, r["events"])
+    ts, xs = pkg.trace.discretize(tr, 0.5)
+    assert np.allclose(np.diff(ts), 0.5)
+    S = np.linalg.inv(G.toarray())
+    assert np.mean(np.abs(xs.mean(axis=0))) < 2 / math.sqrt(T) * np.sqrt(np.diag(S)).max() * 2
+    assert np.mean(np.abs(np.cov(xs.T) - S)) < 2.5 / math.sqrt(T)
+    # pdmp (G = All()) gives the same chain up to rounding of the lazy clocks (src/sfact.jl:236)
+    r2 = O.spdmp_zigzag(0.9 * G, None, G, x0, th0, c, 20.0, seed=21, adapt=True, factor=1.8, move_all=True)
+    r1 = O.spdmp_zigzag(0.9 * G, None, G, x0, th0, c, 20.0, seed=21, adapt=True, factor=1.8)
+    assert np.array_equal(r1["events"]["i"], r2["events"]["i"])
+    assert np.allclose(r1["events"]["t"], r2["events"]["t"], rtol=1e-9)
+    # subtrace consistency, test/maintest.jl:53-58
+    J = np.arange(0, d, 2)
+    ts2, xs2 = pkg.trace.discretize(pkg.trace.subtrace(tr, J), 0.5)
+    assert np.allclose(ts2, ts[:len(ts2)]) and np.allclose(xs2, xs[:len(ts2)][:, J])
+
+
+def test_bound_violation_is_reported(pkg):
+    """adapt=false and c too small: the reference throws (src/sfact.jl:124); the oracle reports the status."""
+    G = pkg.problems.gmrf_precision(4)
+    d = 16
+    rng = np.random.default_rng(0)
+    # the bound uses 0.3Γ while the target is Γ: with a tiny c the affine bound is below the true rate
+    x0, th0 = rng.standard_normal(d) * 5, rng.choice([-1.0, 1.0], d)
+    r = O.spdmp_zigzag(0.3 * G, None, G, x0, th0, np.full(d, 1e-6), 50.0, seed=1)
+    assert r["status"] == O.ORC_BOUND_VIOLATED
+    r = O.spdmp_zigzag(0.3 * G, None, G, x0, th0, np.full(d, 1e-6), 50.0, seed=1, adapt=True)
+    assert r["status"] == 0 and r["c"].max() > 1e-6
+
+
+def test_refresh_branch_runs(pkg):
+    """λref > 0 (src/sfact.jl:78-114,188-190): refresh events are recorded, keep |θ_i| = σ_i."""
+    G = pkg.problems.gmrf_precision(4)
+    d = 16
+    rng = np.random.default_rng(1)
+    sig = np.full(d, 0.5)
+    r = O.spdmp_zigzag(G, None, G, rng.standard_normal(d), sig * rng.choice([-1.0, 1.0], d), 2 * pkg.problems.column_norms(G),
+                       100.0, seed=4, lambda_ref=0.3, sigma=sig)
+    assert r["status"] == 0 and r["nrefresh"] > 10
+    assert len(r["events"]) == r["nacc"] + r["nrefresh"]
+    assert np.all(np.abs(r["theta"]) == 0.5) and r["ndraw_global"] == 3 * r["nrefresh"]
+
+
+def _bps_discretize(t0, x0, th0, t_ev, x_ev, dt):
+    ts = np.arange(t0, t_ev[-1], dt)
+    tt = np.concatenate([[t0], t_ev])
+    xx = np.vstack([x0, x_ev])
+    out = np.empty((len(ts), x0.size))
+    for j in range(x0.size):
+        out[:, j] = np.interp(ts, tt, xx[:, j])
+    return ts, out
+
+
+def test_bps_statistics_d8(pkg):
+    """test/maintest.jl:156-172: BouncyParticle(Γ, 0, 0.5), c = 1.1, T = 300 (mass L = I here)."""
+    G = pkg.problems.maintest_precision(8)
+    d, T = 8, 300.0
+    rng = np.random.default_rng(3)
+    x0, th0 = rng.standard_normal(d), rng.standard_normal(d)
+    r = O.pdmp_bps(G, None, x0, th0, 1.1, T, lambda_ref=0.5, seed=8, ev_cap=100000)
+    assert r["status"] == 0 and r["nevents"] == len(r["t_ev"]) and r["nrefresh"] > 50
+    assert np.all(np.diff(r["t_ev"]) > 0) and r["t_ev"][-1] >= T
+    ts, xs = _bps_discretize(0.0, x0, th0, r["t_ev"], r["x_ev"], 0.1)
+    S = np.linalg.inv(G.toarray())
+    assert np.mean(np.abs(xs.mean(axis=0))) < 2 / math.sqrt(T) * 1.5
+    assert np.mean(np.abs(np.cov(xs.T) - S)) < 2 / math.sqrt(T) * 1.5
+
+
+def test_golden_bps16(golden):
+    d = 16
+    r = O.pdmp_bps(sp.identity(d, format="csc"), None, golden["bps16_x0"], golden["bps16_th0"], 1e-3, 1e9, lambda_ref=1.0,
+                   seed=99, max_events=200, ev_cap=200)
+    assert np.array_equal(r["t_ev"], golden["bps16_t"])
+    assert np.array_equal(r["x_ev"][-1], golden["bps16_x_last"]) and np.array_equal(r["theta_ev"][-1], golden["bps16_th_last"])
+    assert [r["num"], r["nacc"], r["nrefresh"]] == golden["bps16_counts"].tolist()
+
+
+def test_sticky_1d_statistics(pkg):
+    """test/sticky.jl:7-36: P(X≠0) = w, E X = wμ, E X² = w(σ²+μ²) with the closed-form w (:30)."""
+    sig2, mu, kappa, T = 0.5, 0.9, 1.5, 2000.0
+    Gf = sp.csc_matrix(np.array([[1.0]]))
+    Gt = sp.csc_matrix(np.array([[1 / sig2]]))
+    r = O.sspdmp_zigzag(Gf, np.array([0.0]), Gt, np.array([1.0]), np.array([0.8]), np.array([20.0]), np.array([kappa]), T,
+                        target_mu=np.array([mu]), seed=1)
+    assert r["status"] == 0
+    tr = pkg.FactTrace(None, 0.0, np.array([1.0]), np.array([0.8]), r["events"])
+    ts, xs = pkg.trace.discretize(tr, 0.2)
+    x = xs[:, 0]
+    sig = math.sqrt(sig2)
+    w = math.sqrt(2 * math.pi) * sig / (math.sqrt(2 * math.pi) * sig + math.exp(-0.5 * mu ** 2 / sig2) / kappa)
+    assert abs(np.mean(x != 0) - w) < 2.5 / math.sqrt(T)
+    assert abs(np.mean(x) - w * mu) < 5.0 / math.sqrt(T)
+    assert abs(np.mean(x ** 2) - w * (sig2 + mu ** 2)) < 5.0 / math.sqrt(T)
+
+
+def test_golden_sticky1d(golden):
+    Gf = sp.csc_matrix(np.array([[1.0]]))
+    Gt = sp.csc_matrix(np.array([[2.0]]))
+    r = O.sspdmp_zigzag(Gf, np.array([0.0]), Gt, np.array([1.0]), np.array([0.8]), np.array([20.0]), np.array([1.5]), 200.0,
+                        target_mu=np.array([0.9]), seed=5)
+    for f in ("t", "i", "x", "theta"):
+        assert np.array_equal(r["events"][f], golden["sticky1d_events"][f])
+    assert [r["num"], r["nacc"]] == golden["sticky1d_counts"].tolist()
+
+
+def test_sticky_d8_no_sticking(pkg):
+    """test/sticky.jl:39-65: κ = 1000 ("dont stop, actually") reproduces the Gaussian moments."""
+    G = pkg.problems.maintest_precision(8)
+    d, T = 8, 1000.0
+    rng = np.random.default_rng(1)
+    x0 = rng.random(d)
+    th0 = rng.choice([-1.0, -0.5, 0.5, 1.0], d)
+    c = 0.7 * pkg.problems.column_norms(G)
+    r = O.sspdmp_zigzag(0.9 * G, None, G, x0, th0, c, np.full(d, 1000.0), T, seed=12, adapt=True)
+    assert r["status"] == 0
+    tr = pkg.FactTrace(None, 0.0, x0, th0, r["events"])
+    ts, xs = pkg.trace.discretize(tr, 0.5)
+    S = np.linalg.inv(G.toarray())
+    assert np.mean(np.abs(xs.mean(axis=0))) < 2 / math.sqrt(T) * 1.5
+    assert np.mean(np.abs(np.cov(xs.T) - S)) < 2.5 / math.sqrt(T)

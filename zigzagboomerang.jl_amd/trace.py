@@ -1,0 +1,131 @@
+"""Trace consumers, mirroring src/trace.jl for FactTrace (what every caller of spdmp does next with Ξ).
+
+Events are structured arrays (t, i, x, theta) with 0-based i.  Vectorised numpy, host side only: these
+are the callers' post-processing, not part of the device hot path.
+"""
+import numpy as np
+
+from .types import FactTrace
+
+
+def collect(tr: FactTrace):
+    """collect(Ξ): list of (t, x) at event times -- Base.iterate(FT::FactTrace), src/trace.jl:44-63.
+
+    Like the reference, the LAST event is not applied (:56)."""
+    t, x, th = tr.t0, tr.x0.copy(), tr.θ0.copy()
+    ts, xs = [t], [x.copy()]
+    ev = tr.events
+    for k in range(len(ev) - 1):
+        t2, i, xi, thi = ev[k]
+        x += th * (t2 - t)  # move_forward!, src/dynamics.jl:11-15
+        t = t2
+        x[i] = xi
+        th[i] = thi
+        ts.append(t)
+        xs.append(x.copy())
+    return np.array(ts), np.array(xs)
+
+
+def discretize(tr: FactTrace, dt):
+    """collect(discretize(Ξ, dt)): positions on the grid t0, t0+dt, ... -- src/trace.jl:94-125."""
+    ev = tr.events
+    t, x, th = tr.t0, tr.x0.copy(), tr.θ0.copy()
+    ts, xs = [t], [x.copy()]
+    k = 0
+    n = len(ev)
+    while True:
+        step = dt
+        done = False
+        while True:
+            if k >= n:
+                done = True
+                break
+            ti = ev["t"][k]
+            if t + step < ti:
+                x += th * step
+                t += step
+                break
+            d_t = ti - t
+            step -= d_t
+            x += th * d_t
+            t = ti
+            i = ev["i"][k]
+            x[i] = ev["x"][k]
+            th[i] = ev["theta"][k]
+            k += 1
+        if done:
+            break
+        ts.append(t)
+        xs.append(x.copy())
+    return np.array(ts), np.array(xs)
+
+
+def mean(tr: FactTrace):
+    """mean(Ξ): time average of the piecewise-linear path per coordinate -- src/trace.jl:182-200."""
+    ev = tr.events
+    x = tr.x0.copy()
+    y = np.zeros_like(x)
+    T = ev["t"][-1]
+    t = np.full(x.shape, tr.t0)
+    scale = 1 / (2 * T)
+    for t2, i, xi, _ in ev:
+        y[i] += (x[i] + xi) * (t2 - t[i]) * scale
+        t[i] = t2
+        x[i] = xi
+    return y
+
+
+def moments(tr: FactTrace, T_end=None):
+    """Exact time averages of x_i and x_i² over [t0, T_end] (segments of coordinate i between ITS events);
+    the tail after a coordinate's last event is extrapolated with its last velocity.  Used by the tests."""
+    ev = tr.events
+    d = tr.x0.size
+    if T_end is None:
+        T_end = ev["t"][-1]
+    s1 = np.zeros(d)
+    s2 = np.zeros(d)
+    x = tr.x0.copy()
+    th = tr.θ0.copy()
+    t = np.full(d, tr.t0)
+    for t2, i, xi, thi in ev:
+        if t2 > T_end:
+            continue
+        dt = t2 - t[i]
+        xa, xb = x[i], x[i] + th[i] * dt
+        s1[i] += dt * (xa + xb) / 2
+        s2[i] += dt * (xa * xa + xa * xb + xb * xb) / 3
+        t[i], x[i], th[i] = t2, xi, thi
+    dt = T_end - t
+    xb = x + th * dt
+    s1 += dt * (x + xb) / 2
+    s2 += dt * (x * x + x * xb + xb * xb) / 3
+    L = T_end - tr.t0
+    m = s1 / L
+    return m, s2 / L - m * m
+
+
+def subtrace(tr: FactTrace, J):
+    """subtrace(Ξ, J): trace of the subvector x[J] -- src/trace.jl:275-290."""
+    J = np.asarray(J)
+    assert np.all(np.diff(J) > 0)
+    ev = tr.events
+    loc = np.searchsorted(J, ev["i"])
+    loc_c = np.minimum(loc, len(J) - 1)
+    keep = J[loc_c] == ev["i"]
+    sub = ev[keep].copy()
+    sub["i"] = loc_c[keep]
+    return FactTrace(tr.F, tr.t0, tr.x0[J].copy(), tr.θ0[J].copy(), sub)
+
+
+def inclusion_prob(tr: FactTrace):
+    """inclusion_prob(Ξ): fraction of time each coordinate is non-zero -- src/trace.jl:161-178."""
+    ev = tr.events
+    x = tr.x0.copy()
+    y = np.zeros_like(x)
+    T = ev["t"][-1]
+    t = np.full(x.shape, tr.t0)
+    for t2, i, xi, _ in ev:
+        y[i] += ((x[i] != 0) | (xi != 0)) * (t2 - t[i]) / T
+        t[i] = t2
+        x[i] = xi
+    return y
