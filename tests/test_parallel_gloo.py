@@ -1,0 +1,98 @@
+"""N>1 path on CPU: world_size-2 gloo run of the sharding + post-run gather/reduce (no GPU, no data-path collective)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch
+    import torch.distributed as dist
+    import oracle_lib as O
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    par = pkg.parallel
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        nch_total = 5
+        first, n = par.shard_range(nch_total, rank, world)
+        G = pkg.problems.gmrf_precision(4)
+        d = 16
+        c = pkg.problems.column_norms(G)
+        # each rank simulates ITS chains (the oracle stands in for the device engine on this CPU-only box)
+        evs, ys = [], []
+        for k in range(first, first + n):
+            x0, th0 = O.synthetic_state(1000 + k, d)
+            r = O.spdmp_zigzag(G, None, G, x0, th0, c, 5.0, seed=1000 + k)
+            evs.append(r["events"])
+            ys.append(pkg.trace.moments(pkg.FactTrace(None, 0.0, x0, th0, r["events"]), 5.0)[0])
+        counts = torch.tensor([len(e) for e in evs], dtype=torch.int64)
+        all_counts = par.all_gather_counts(counts)
+        seg = par.events_to_tensor(np.concatenate(evs)) if evs else torch.empty((0, 4), dtype=torch.float64)
+        gathered = par.gatherv_events(seg, all_counts, dst=0)
+        sy = torch.from_numpy(np.sum(ys, axis=0))
+        sy2 = torch.from_numpy(np.sum(np.square(ys), axis=0))
+        par.reduce_moments(sy, sy2, dst=0)
+        if rank == 0:
+            out = []
+            for r_, t in enumerate(gathered):
+                ev = par.tensor_to_events(t, O.EVENT_DTYPE)
+                off = 0
+                for cnt in all_counts[r_].tolist():
+                    out.append(ev[off:off + cnt].copy())
+                    off += cnt
+            q.put(("ok", [o.tobytes() for o in out], sy.numpy(), sy2.numpy()))
+        else:
+            q.put(("ok", None, None, None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_range_partitions_exactly(pkg):
+    for total in (1, 5, 4096, 65536):
+        for world in (1, 2, 3, 8):
+            spans = [pkg.parallel.shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and sum(n for _, n in spans) == total
+            for (f0, n0), (f1, _) in zip(spans, spans[1:]):
+                assert f1 == f0 + n0
+            assert max(n for _, n in spans) - min(n for _, n in spans) <= 1
+
+
+def test_world2_gather_and_reduce_match_single_process(pkg):
+    import torch.multiprocessing as mp
+    import oracle_lib as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    root = [r for r in res if r[1] is not None][0]
+    G = pkg.problems.gmrf_precision(4)
+    c = pkg.problems.column_norms(G)
+    ys = []
+    for k in range(5):
+        x0, th0 = O.synthetic_state(1000 + k, 16)
+        r = O.spdmp_zigzag(G, None, G, x0, th0, c, 5.0, seed=1000 + k)
+        assert root[1][k] == r["events"].tobytes()
+        ys.append(pkg.trace.moments(pkg.FactTrace(None, 0.0, x0, th0, r["events"]), 5.0)[0])
+    assert np.allclose(root[2], np.sum(ys, axis=0)) and np.allclose(root[3], np.sum(np.square(ys), axis=0))
