@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -81,6 +82,13 @@ struct pdmp_ensemble {
     uint32_t nblk = 0, nblk_pad = 0;
     int64_t dk = 0;
     bool has_tmu = false;
+
+    // host copies of the derived tables (inputs of the per-coordinate blob)
+    std::vector<double> h_gmu_b, h_tval;
+    std::vector<uint32_t> h_sptr, h_sidx, h_qptr;
+    std::vector<uint8_t> h_pos, h_selfpos;
+    uint32_t blob_w = 0, blob_w_pad = 0, blob_sw = 0, blob_pw = 0, blob_kmax = 0;
+    DevBuf<uint64_t> d_blob;
 
     // device tables
     DevBuf<uint32_t> d_colptr, d_rowval, d_sptr, d_sidx, d_qptr;
@@ -296,6 +304,13 @@ pdmp_status pdmp_ensemble_set_flow_zigzag(pdmp_ensemble* e, const int64_t* colpt
     qptr[nnz] = (uint32_t)pos.size();
     if (pos.empty()) pos.push_back(0);
 
+    e->h_gmu_b = gmu;
+    e->h_sptr = sptr;
+    e->h_sidx = sidx;
+    e->h_qptr = qptr;
+    e->h_pos = pos;
+    e->h_selfpos = selfpos;
+
     pdmp_status st;
     if ((st = e->d_colptr.upload(e->colptr)) != PDMP_OK) return st;
     if ((st = e->d_rowval.upload(e->rowval)) != PDMP_OK) return st;
@@ -312,9 +327,6 @@ pdmp_status pdmp_ensemble_set_flow_zigzag(pdmp_ensemble* e, const int64_t* colpt
     e->nblk = (uint32_t)((nkeys + 63) / 64);
     e->nblk_pad = (e->nblk + 1u) & ~1u;
     e->dk = (int64_t)e->nblk * 64;
-    if (pdmp::zz_local_lds_bytes(e->nblk_pad) > 160 * 1024)
-        return fail(PDMP_ERR_UNSUPPORTED, "d = %lld needs %zu bytes of LDS for the queue's level 1 (> 160 KiB)",
-                    (long long)d, pdmp::zz_local_lds_bytes(e->nblk_pad));
     e->has_flow = true;
     e->has_target = false;
     e->has_state = false;
@@ -349,12 +361,77 @@ pdmp_status pdmp_ensemble_set_target_gaussian_csc(pdmp_ensemble* e, const int64_
         gmu_t[i] = s;
     }
     e->has_tmu = (mu != nullptr);
+    e->h_tval = tval;
     pdmp_status st;
     if ((st = e->d_tval.upload(tval)) != PDMP_OK) return st;
     if ((st = e->d_gmu_t.upload(gmu_t)) != PDMP_OK) return st;
     e->has_target = true;
     e->has_state = false;
     return PDMP_OK;
+}
+
+// Per-coordinate "neighbourhood program": everything a proposal at coordinate i needs that depends on i alone,
+// packed in 64-bit words so that ONE coalesced wave load brings it on chip (kernel: zz_local_run_kernel).
+//   [0]                 k | m<<8 | selfpos<<16 | kjmax<<24          (kjmax = max_j |G1[j]|, j in G1[i])
+//   [1 .. 1+SW)         S[i] = G1[i] ++ G2[i], two u32 ids per word                (SW = ceil(MMAX/2))
+//   then k sub-records of R = 4 + PW + KMAX words, one per j = G1[i][jj]:
+//     [0] Γt[j,i] (target)   [1] Γ[:,j]·μ   [2] c[j]   [3] |G1[j]|
+//     [4 .. 4+PW)        positions inside S[i] of the members of G1[j], 8 bytes per word (PW = ceil(KMAX/8))
+//     [4+PW .. +KMAX)    Γ[G1[j], j] (bounding precision values, CSC order)
+static pdmp_status build_blob(pdmp_ensemble* e, const double* c) {
+    const int64_t d = e->cfg.d;
+    uint32_t kmax = 0, mmax = 0;
+    for (int64_t i = 0; i < d; ++i) {
+        kmax = std::max(kmax, e->colptr[i + 1] - e->colptr[i]);
+        mmax = std::max(mmax, e->h_sptr[i + 1] - e->h_sptr[i]);
+    }
+    const uint32_t SW = (mmax + 1) / 2, PW = (kmax + 7) / 8, R = 4 + PW + kmax;
+    const uint32_t W = 1 + SW + kmax * R;
+    const uint32_t Wpad = (W + 1u) & ~1u;
+    if ((double)W * 8.0 * (double)d > 4.0e9)
+        return fail(PDMP_ERR_UNSUPPORTED, "neighbourhood programs would take %.1f GB (d=%lld, max column nnz %u)",
+                    (double)W * 8.0 * (double)d / 1e9, (long long)d, kmax);
+    if (pdmp::zz_local_lds_bytes(e->nblk_pad, Wpad) > 160 * 1024)
+        return fail(PDMP_ERR_UNSUPPORTED, "d = %lld / max column nnz %u need %zu bytes of LDS per chain (> 160 KiB)",
+                    (long long)d, kmax, pdmp::zz_local_lds_bytes(e->nblk_pad, Wpad));
+    std::vector<uint64_t> blob((size_t)W * (size_t)d, 0);
+    auto bits = [](double v) {
+        uint64_t u;
+        memcpy(&u, &v, sizeof u);
+        return u;
+    };
+    for (int64_t i = 0; i < d; ++i) {
+        uint64_t* B = blob.data() + (size_t)i * W;
+        const uint32_t c0 = e->colptr[i], k = e->colptr[i + 1] - c0;
+        const uint32_t s0 = e->h_sptr[i], m = e->h_sptr[i + 1] - s0;
+        uint32_t kjmax = 0;
+        for (uint32_t w = 0; w < m; ++w) {
+            const uint64_t id = e->h_sidx[s0 + w];
+            B[1 + (w >> 1)] |= (w & 1) ? (id << 32) : id;
+        }
+        for (uint32_t jj = 0; jj < k; ++jj) {
+            const uint32_t j = e->rowval[c0 + jj];
+            const uint32_t cj0 = e->colptr[j], kj = e->colptr[j + 1] - cj0;
+            kjmax = std::max(kjmax, kj);
+            uint64_t* S = B + 1 + SW + (size_t)jj * R;
+            S[0] = bits(e->h_tval[c0 + jj]);
+            S[1] = bits(e->h_gmu_b[j]);
+            S[2] = bits(c[j]);
+            S[3] = kj;
+            const uint32_t q0 = e->h_qptr[c0 + jj];
+            for (uint32_t pp = 0; pp < kj; ++pp) {
+                S[4 + (pp >> 3)] |= (uint64_t)e->h_pos[q0 + pp] << (8 * (pp & 7));
+                S[4 + PW + pp] = bits(e->bval[cj0 + pp]);
+            }
+        }
+        B[0] = (uint64_t)k | ((uint64_t)m << 8) | ((uint64_t)e->h_selfpos[i] << 16) | ((uint64_t)kjmax << 24);
+    }
+    e->blob_w = W;
+    e->blob_w_pad = Wpad;
+    e->blob_sw = SW;
+    e->blob_pw = PW;
+    e->blob_kmax = kmax;
+    return e->d_blob.upload(blob);
 }
 
 static pdmp_status alloc_state(pdmp_ensemble* e) {
@@ -382,6 +459,7 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
     if (st != PDMP_OK) return st;
     std::vector<double> cv(c, c + d);
     if ((st = e->d_c.upload(cv)) != PDMP_OK) return st;
+    if ((st = build_blob(e, c)) != PDMP_OK) return st;
     DevBuf<double> sx, sth;
     DevBuf<uint64_t> sseed;
     if (x0) {
@@ -442,6 +520,22 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
     P.hdr = e->d_hdr.p;
     P.ev = e->cfg.trace_capacity > 0 ? e->d_ev.p : nullptr;
     P.c_chain = e->cfg.adapt ? e->d_c_chain.p : nullptr;
+    P.blob = e->d_blob.p;
+    DevBuf<double> dbgbuf;
+    const char* dbgenv = getenv("PDMP_DEBUG");
+    const int64_t dbg_cap = dbgenv ? atoll(dbgenv) : 0;
+    if (dbg_cap > 0) {
+        pdmp_status st2 = dbgbuf.alloc((size_t)dbg_cap * 16);
+        if (st2 != PDMP_OK) return st2;
+        HIP_TRY(hipMemset(dbgbuf.p, 0, (size_t)dbg_cap * 16 * sizeof(double)));
+        P.dbg = dbgbuf.p;
+        P.dbg_cap = dbg_cap;
+    }
+    P.blob_w = e->blob_w;
+    P.blob_w_pad = e->blob_w_pad;
+    P.blob_sw = e->blob_sw;
+    P.blob_pw = e->blob_pw;
+    P.blob_kmax = e->blob_kmax;
     P.d = e->cfg.d;
     P.dk = e->dk;
     P.trace_cap = e->cfg.trace_capacity;
@@ -458,6 +552,16 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
     if (rc != 0) return fail(PDMP_ERR_HIP, "zz_local_run launch failed: %s", hipGetErrorString((hipError_t)rc));
     HIP_TRY(hipEventRecord(e->ev1, s));
     e->timed = true;
+    if (dbg_cap > 0) {
+        HIP_TRY(hipDeviceSynchronize());
+        std::vector<double> hd((size_t)dbg_cap * 16);
+        HIP_TRY(hipMemcpy(hd.data(), dbgbuf.p, hd.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int64_t r = 0; r < dbg_cap; ++r) {
+            const double* D = hd.data() + r * 16;
+            fprintf(stderr, "DBG %3lld tp=%.6f i=%g acc=%g k=%g m=%g self=%g l=%.6g lb=%.6g u=%.6f key=%.6f t=%.6f L=%.6f g=%.6g a_i=%.6g x0=%.6g cj=%.6g\n",
+                    (long long)r, D[0], D[1], D[2], D[3], D[4], D[5], D[6], D[7], D[8], D[9], D[10], D[11], D[12], D[13], D[14], D[15]);
+        }
+    }
     return PDMP_OK;
 }
 

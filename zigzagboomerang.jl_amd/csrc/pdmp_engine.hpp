@@ -70,6 +70,10 @@ struct ZzRunParams {
     DevChain* hdr;
     pdmp_event* ev;
     double* c_chain;  // per-chain bounds when adapt, else nullptr
+    double* dbg;  // optional [dbg_cap x 16] per-proposal diagnostics of chain 0 (PDMP_DEBUG env), else nullptr
+    int64_t dbg_cap;
+    const uint64_t* __restrict__ blob;  // [d x blob_w] neighbourhood programs (layout: pdmp_capi.hip build_blob)
+    uint32_t blob_w, blob_w_pad, blob_sw, blob_pw, blob_kmax;
     int64_t d;
     int64_t dk;        // padded key count per chain (multiple of 64)
     int64_t trace_cap;
@@ -108,7 +112,7 @@ int launch_zz_unpack(const ZzRec* rec, const double* c_src, int64_t c_stride, in
                      int64_t n, double* t, double* x, double* th, int64_t* acc, double* c, void* stream);
 int launch_zz_batch_means(const ZzRec* rec, double* jprev, int64_t d, int64_t nchains, double T_prev, double T,
                           double* sum_y, double* sum_y2, void* stream);
-size_t zz_local_lds_bytes(uint32_t nblk_pad);
+size_t zz_local_lds_bytes(uint32_t nblk_pad, uint32_t blob_w_pad);
 int launch_math_probe(uint64_t seed, int64_t n, double* out, void* stream);
 
 }  // namespace pdmp

@@ -184,29 +184,73 @@ __global__ __launch_bounds__(256) void zz_init_kernel(ZzInitParams P) {
 // ------------------------------------------------------------------------------------------ event loop
 //
 // spdmp_inner! (src/sfact.jl:73-145) under the driver loop `while t′ < T` (:199-208), G = Matched().
+//
+// Dependent memory levels per proposal: LDS peek -> {neighbourhood blob (L2/MALL), rec[i], popped key block}
+// -> neighbour records (HBM).  Everything a proposal needs that is a function of i alone lives in ONE
+// contiguous blob (built on the host, pdmp_capi.hip: build_blob) fetched with a single coalesced wave load.
+// A workgroup is one wavefront, so no s_barrier / vmcnt(0) fence is ever needed: DS operations of a wave
+// execute in order, and stores are fire-and-forget.
 
-size_t zz_local_lds_bytes(uint32_t nblk_pad) {
-    return (size_t)nblk_pad * 8 + 3 * 64 * 8 + (size_t)nblk_pad * 4;
+size_t zz_local_lds_bytes(uint32_t nblk_pad, uint32_t blob_w_pad) {
+    return (size_t)nblk_pad * 8 + 3 * 64 * 8 + (size_t)blob_w_pad * 8 + (size_t)nblk_pad * 4;
 }
+
+// poisson_time(a, b, u) with L = log(u) supplied (src/poissontime.jl:8-30)
+__device__ __forceinline__ double dev_poisson_time_L(double a, double b, double L) {
+    if (b > 0) {
+        const double r = a / b;
+        if (a < 0) {
+            return sqrt(-L * 2.0 / b) - r;
+        } else {
+            return sqrt(r * r - L * 2.0 / b) - r;
+        }
+    } else if (b == 0) {
+        if (a > 0) {
+            return -L / a;
+        } else {
+            return PDMP_INF;
+        }
+    } else {
+        if (a <= 0) {
+            return PDMP_INF;
+        } else if (-L <= -(a * a) / b + (a * a) / (2 * b)) {
+            const double r = a / b;
+            return -sqrt(r * r - L * 2.0 / b) - r;
+        } else {
+            return PDMP_INF;
+        }
+    }
+}
+
+// Cross-lane hand-off through LDS inside ONE wavefront: DS operations execute in issue order, so no s_barrier
+// and no s_waitcnt vmcnt(0) is needed -- but the COMPILER must be told that memory changed behind the thread's
+// back (otherwise it may forward a lane's own earlier store to its later load of the same slot).
+#define LDS_ORDER()                      \
+    do {                                 \
+        __builtin_amdgcn_wave_barrier(); \
+        asm volatile("" ::: "memory");   \
+    } while (0)
 
 __global__ __launch_bounds__(64) void zz_local_run_kernel(ZzRunParams P) {
     const int lane = threadIdx.x;
     const int64_t chain = blockIdx.x;
     const int64_t d = P.d;
     const uint32_t nblk = P.nblk;
+    const uint32_t W = P.blob_w, SW = P.blob_sw, PW = P.blob_pw, KMAX = P.blob_kmax;
+    const uint32_t R = 4 + PW + KMAX;
 
     extern __shared__ __align__(16) unsigned char smem[];
     double* bk = reinterpret_cast<double*>(smem);  // [nblk_pad] block minima
     double* sx = bk + P.nblk_pad;                  // [64] x of S[i] after the move
     double* sth = sx + 64;                         // [64] θ of S[i]
     double* pk = sth + 64;                         // [64] patched copy of the popped key block
-    uint32_t* bi = reinterpret_cast<uint32_t*>(pk + 64);  // [nblk_pad] block argmin (coordinate id)
+    uint64_t* lb = reinterpret_cast<uint64_t*>(pk + 64);               // [blob_w_pad] neighbourhood blob of i
+    uint32_t* bi = reinterpret_cast<uint32_t*>(lb + P.blob_w_pad);     // [nblk_pad] block argmin (coordinate id)
 
     ZzRec* rec = P.rec + chain * d;
     double* keys = P.keys + chain * P.dk;
     DevChain* hdr = P.hdr + chain;
     pdmp_event* ev = P.ev ? P.ev + chain * P.trace_cap : nullptr;
-    const double* cvec = P.c_chain ? (P.c_chain + chain * d) : P.tb.c_shared;
     double* cmut = P.c_chain ? (P.c_chain + chain * d) : nullptr;
 
     uint32_t status = hdr->c.status;
@@ -238,7 +282,7 @@ __global__ __launch_bounds__(64) void zz_local_run_kernel(ZzRunParams P) {
         bk[b] = mk;
         bi[b] = b * 64 + mi;
     }
-    __syncthreads();
+    LDS_ORDER();
 
     bool running = stop_before || (t_event < T);  // `while t′ < T`, src/sfact.jl:199
     while (running) {
@@ -272,28 +316,60 @@ __global__ __launch_bounds__(64) void zz_local_run_kernel(ZzRunParams P) {
         const uint32_t i = uniform_u32(bi[blk]);
         t_last = tp;
 
-        // ---------------- neighbourhood program of coordinate i
-        const uint32_t cp0 = P.tb.colptr[i];
-        const int k = (int)(P.tb.colptr[i + 1] - cp0);
-        const uint32_t sp0 = P.tb.sptr[i];
-        const int m = (int)(P.tb.sptr[i + 1] - sp0);
-        const int self = (int)P.tb.selfpos[i];
-        const uint32_t s = (lane < m) ? P.tb.sidx[sp0 + lane] : i;
-        ZzRec* rs = rec + s;
+        // ---------------- level-1 loads: everything that is a function of i alone
+        {
+            const uint64_t* bsrc = P.blob + (size_t)i * W;
+            for (uint32_t w = lane; w < W; w += 64) lb[w] = bsrc[w];
+        }
         const ZzRec* ri = rec + i;
+        const double told_i = ri->t_old, a_i = ri->a, b_i = ri->b;
+        const uint64_t acc_i = ri->acc;
+        const double kb0 = keys[(size_t)blk * 64 + lane];
 
-        // ---------------- loads: G[i] positions, bound of i, own key block
+        // ---------------- random numbers of this proposal, computed under the memory latency.
+        // draw nm is the thinning coin (:121); draw nm+1+jj re-bounds the jj-th member of G1[i] on accept (:134),
+        // draw nm+1 re-bounds i on reject (:139).  Lane 63 evaluates the coin, lane jj its own re-bound draw.
+        double ucoin, Llane;
+        if (KMAX < 64) {
+            const uint64_t idx = (lane == 63) ? nm : (nm + 1 + (uint64_t)lane);
+            const double u = pdmp_u01(seed, PDMP_STREAM_MAIN, idx);
+            ucoin = readlane_f64(u, 63);
+            Llane = pdmp_log(u);
+        } else {
+            ucoin = pdmp_u01(seed, PDMP_STREAM_MAIN, nm);
+            Llane = pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm + 1 + (uint64_t)lane));
+        }
+        // read lane 0's draw HERE, in wave-uniform control flow: inside the divergent re-bound block below lane 0
+        // may be inactive, and the compiler is free to sink the computation of Llane into that block.
+        const double L_reject = readlane_f64(Llane, 0);
+
+        // ---------------- neighbourhood header and member list from the blob (now in LDS)
+        LDS_ORDER();
+        const uint64_t hw = lb[0];
+        const int k = (int)uniform_u32((uint32_t)(hw & 0xff));
+        const int m = (int)uniform_u32((uint32_t)((hw >> 8) & 0xff));
+        const int self = (int)uniform_u32((uint32_t)((hw >> 16) & 0xff));
+        const int kjmax = (int)uniform_u32((uint32_t)((hw >> 24) & 0xff));
+        uint32_t s = i;
+        if (lane < m) {
+            const uint64_t sw = lb[1 + (lane >> 1)];
+            s = (lane & 1) ? (uint32_t)(sw >> 32) : (uint32_t)sw;
+        }
+        ZzRec* rs = rec + s;
+        // ---------------- level-2 loads: positions of G[i] and (speculatively) of G2[i]
         double x = 0.0, th = 0.0, t = 0.0, I = 0.0;
-        if (lane < k) {
+        if (lane < m) {
             x = rs->x;
             th = rs->th;
             t = rs->t;
             I = rs->I;
         }
-        const double told_i = ri->t_old, a_i = ri->a, b_i = ri->b;
-        const uint64_t acc_i = ri->acc;
-        const double kb0 = keys[(size_t)blk * 64 + lane];
-        const double tv = (lane < k) ? P.tb.tval[cp0 + lane] : 0.0;
+        const uint32_t sub = 1 + SW + (uint32_t)lane * R;  // this lane's sub-record (valid for lane < k)
+        double tv = 0.0, cj = 0.0;
+        if (lane < k) {
+            tv = __longlong_as_double((long long)lb[sub + 0]);
+            cj = cmut ? cmut[s] : __longlong_as_double((long long)lb[sub + 2]);
+        }
 
         // ---------------- smove_forward!(G, i, t, x, θ, t′, F), src/sfact.jl:6-12,82
         if (lane < k) {
@@ -308,17 +384,15 @@ __global__ __launch_bounds__(64) void zz_local_run_kernel(ZzRunParams P) {
         for (int p = 0; p < k; ++p) g += readlane_f64(tv, p) * readlane_f64(x, p);
         if (P.tb.gmu_t) g = g - P.tb.gmu_t[i];
         const double th_i = readlane_f64(th, self);
-        const double l = pos_part(g * th_i);                       // sλ, src/sfact.jl:69,119
-        const double lb = pos_part(a_i + b_i * (tp - told_i));     // sλ̄, :70,119 (t[i] == t′ after the move)
-        num += 1;                                                  // :120
-        const double ucoin = pdmp_u01(seed, PDMP_STREAM_MAIN, nm); // :121
-        nm += 1;
-        const bool accept = (ucoin * lb < l);
+        const double l = pos_part(g * th_i);                    // sλ, src/sfact.jl:69,119
+        const double lbound = pos_part(a_i + b_i * (tp - told_i));  // sλ̄, :70,119 (t[i] == t′ after the move)
+        num += 1;                                               // :120
+        const bool accept = (ucoin * lbound < l);               // :121
         bool violated = false;
         int nmoved = k;
         if (accept) {
-            nacc += 1;  // acc[i] += 1, :122
-            violated = (l >= lb);  // :123
+            nacc += 1;               // acc[i] += 1, :122
+            violated = (l >= lbound);  // :123
             if (violated && !adapt) {
                 // reference: error("Tuning parameter `c` too small."), :124 -> per-chain status word
                 status = PDMP_CHAIN_BOUND_VIOLATED;
@@ -327,14 +401,11 @@ __global__ __launch_bounds__(64) void zz_local_run_kernel(ZzRunParams P) {
                     rs->t = t;
                     rs->I = I;
                 }
+                nm += 1;
                 break;
             }
             // smove_forward!(G2, i, ...), :129
             if (lane >= k && lane < m) {
-                x = rs->x;
-                th = rs->th;
-                t = rs->t;
-                I = rs->I;
                 const double dt = tp - t;
                 const double xn = x + th * dt;
                 I = I + dt * ((x + xn) * 0.5);
@@ -350,40 +421,53 @@ __global__ __launch_bounds__(64) void zz_local_run_kernel(ZzRunParams P) {
             sth[lane] = th;
         }
         pk[lane] = kb0;
-        __syncthreads();
+        LDS_ORDER();
 
         // ---------------- ab + new event time for j in G1[i] (accept, :131-135) or for i alone (reject, :137-139)
         const bool active = accept ? (lane < k) : (lane == self);
         double key = PDMP_INF;
         if (active) {
-            const uint32_t j = s;
-            const uint32_t cj0 = P.tb.colptr[j];
-            const int kj = (int)(P.tb.colptr[j + 1] - cj0);
-            const uint32_t q0 = P.tb.qptr[cp0 + lane];
+            const double gmu = __longlong_as_double((long long)lb[sub + 1]);
+            const int kj = (int)(lb[sub + 3] & 0xff);
             double gx = 0.0, gt = 0.0;
-            for (int pp = 0; pp < kj; ++pp) {
-                const double v = P.tb.bval[cj0 + pp];
-                const int ps = (int)P.tb.pos[q0 + pp];
-                gx += v * sx[ps];
-                gt += v * sth[ps];
+            for (int base = 0; base < kjmax; base += 8) {
+                const uint64_t pw = lb[sub + 4 + (base >> 3)];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int pp = base + q;
+                    if (pp < kj) {
+                        const double v = __longlong_as_double((long long)lb[sub + 4 + PW + pp]);
+                        const int ps = (int)((pw >> (8 * q)) & 0xff);
+                        gx += v * sx[ps];
+                        gt += v * sth[ps];
+                    }
+                }
             }
-            double cj = cvec[j];
             if (violated && lane == self) {  // adapt!(c, i, factor), src/fact_samplers.jl:67-70, :127
                 cj *= P.factor;
-                cmut[j] = cj;
+                cmut[s] = cj;
             }
-            const double a = cj + (gx - P.tb.gmu_b[j]) * th;  // src/fact_samplers.jl:51
-            const double b = cj / 100 + th * gt;             // :52
-            const uint64_t di = accept ? (nm + (uint64_t)lane) : nm;
-            const double uu = pdmp_u01(seed, PDMP_STREAM_MAIN, di);
-            key = t + dev_poisson_time(a, b, uu);  // Q[j] = t[j] + poisson_time(b[j], rand(rng))
-            rs->t_old = t;                         // t_old[j] = t[j]
+            const double a = cj + (gx - gmu) * th;  // src/fact_samplers.jl:51
+            const double b = cj / 100 + th * gt;   // :52
+            const double L = accept ? Llane : L_reject;
+            key = t + dev_poisson_time_L(a, b, L);  // Q[j] = t[j] + poisson_time(b[j], rand(rng))
+            rs->t_old = t;                          // t_old[j] = t[j]
             rs->a = a;
             rs->b = b;
-            keys[j] = key;
-            if ((j >> 6) == blk) pk[j & 63] = key;
+            keys[s] = key;
+            if ((s >> 6) == blk) pk[s & 63] = key;
         }
-        nm += accept ? (uint64_t)k : 1u;
+        if (P.dbg && chain == 0 && (int64_t)(num - 1) < P.dbg_cap) {
+            double* D = P.dbg + (num - 1) * 16;
+            const double ks = readlane_f64(key, self), ts = readlane_f64(t, self), Ls = readlane_f64(Llane, self);
+            const double xs0 = readlane_f64(x, 0), cjs = readlane_f64(cj, self);
+            if (lane == 0) {
+                D[0] = tp; D[1] = (double)i; D[2] = accept ? 1.0 : 0.0; D[3] = (double)k; D[4] = (double)m;
+                D[5] = (double)self; D[6] = l; D[7] = lbound; D[8] = ucoin; D[9] = ks; D[10] = ts; D[11] = Ls;
+                D[12] = g; D[13] = a_i; D[14] = xs0; D[15] = cjs;
+            }
+        }
+        nm += accept ? (uint64_t)(1 + k) : 2u;
 
         // ---------------- write back the moved coordinates
         if (lane < nmoved) {
@@ -394,8 +478,8 @@ __global__ __launch_bounds__(64) void zz_local_run_kernel(ZzRunParams P) {
         }
         if (accept && lane == self) rs->acc = acc_i + 1;
 
-        // ---------------- queue: re-reduce the popped block from the patched register copy
-        __syncthreads();
+        // ---------------- queue: re-reduce the popped block from the patched copy
+        LDS_ORDER();
         {
             const double kb = pk[lane];
             const double mn = wave_min_f64(kb);
@@ -413,7 +497,7 @@ __global__ __launch_bounds__(64) void zz_local_run_kernel(ZzRunParams P) {
                 const uint32_t bj = j >> 6;
                 if (bj == blk) continue;
                 const double kj = readlane_f64(key, jj);
-                __syncthreads();
+                LDS_ORDER();
                 const double cur = bk[bj];
                 const uint32_t ci = bi[bj];
                 if (kj < cur || (kj == cur && j < ci)) {
@@ -422,8 +506,8 @@ __global__ __launch_bounds__(64) void zz_local_run_kernel(ZzRunParams P) {
                         bi[bj] = j;
                     }
                 } else if (ci == j) {
-                    // j was its block's minimum and moved later: rescan that block (keys[] already updated)
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                    // j was its block's minimum and moved later: rescan that block (keys[] already updated;
+                    // same-wave store -> load to one address is ordered by the memory pipeline)
                     const double kv = __hip_atomic_load(keys + (size_t)bj * 64 + lane, __ATOMIC_RELAXED,
                                                         __HIP_MEMORY_SCOPE_AGENT);
                     const double mn = wave_min_f64(kv);
@@ -451,7 +535,7 @@ __global__ __launch_bounds__(64) void zz_local_run_kernel(ZzRunParams P) {
             t_event = tp;
             if (!stop_before && !(tp < T)) running = false;  // `while t′ < T`
         }
-        __syncthreads();
+        LDS_ORDER();
     }
 
     if (lane == 0) {
@@ -544,7 +628,7 @@ int launch_zz_init(const ZzInitParams& p, void* stream) {
 }
 
 int launch_zz_local_run(const ZzRunParams& p, int64_t nchains, void* stream) {
-    const size_t lds = zz_local_lds_bytes(p.nblk_pad);
+    const size_t lds = zz_local_lds_bytes(p.nblk_pad, p.blob_w_pad);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(zz_local_run_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .types import GaussianTarget, ZigZag
+from .flows import GaussianTarget, ZigZag
 
 
 def _i64(a):

@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _lib
 from .engine import Ensemble
-from .types import FactTrace, GaussianTarget, ZigZag
+from .flows import FactTrace, GaussianTarget, ZigZag
 
 DEFAULT_SEED = 0x5EED0000
 

@@ -5,7 +5,7 @@ are the callers' post-processing, not part of the device hot pat
 """
 import numpy as np
 
-from .types import FactTrace
+from .flows import FactTrace
 
 
 def collect(tr: FactTrace):
