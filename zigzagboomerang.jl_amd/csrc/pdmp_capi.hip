@@ -87,7 +87,8 @@ struct pdmp_ensemble {
     std::vector<double> h_gmu_b, h_tval;
     std::vector<uint32_t> h_sptr, h_sidx, h_qptr;
     std::vector<uint8_t> h_pos, h_selfpos;
-    uint32_t blob_w = 0, blob_w_pad = 0, blob_sw = 0, blob_pw = 0, blob_kmax = 0;
+    uint32_t blob_w = 0, blob_w_pad = 0, blob_sw = 0, blob_pw = 0, blob_kmax = 0, blob_mmax = 0;
+    bool use_spec = false;  // speculative 4-events-per-iteration kernel (zz_local_spec_kernel)
     DevBuf<uint64_t> d_blob;
 
     // device tables
@@ -394,14 +395,14 @@ static pdmp_status build_blob(pdmp_ensemble* e, const double* c) {
     if (pdmp::zz_local_lds_bytes(e->nblk_pad, Wpad) > 160 * 1024)
         return fail(PDMP_ERR_UNSUPPORTED, "d = %lld / max column nnz %u need %zu bytes of LDS per chain (> 160 KiB)",
                     (long long)d, kmax, pdmp::zz_local_lds_bytes(e->nblk_pad, Wpad));
-    std::vector<uint64_t> blob((size_t)W * (size_t)d, 0);
+    std::vector<uint64_t> blob((size_t)Wpad * (size_t)d, 0);
     auto bits = [](double v) {
         uint64_t u;
         memcpy(&u, &v, sizeof u);
         return u;
     };
     for (int64_t i = 0; i < d; ++i) {
-        uint64_t* B = blob.data() + (size_t)i * W;
+        uint64_t* B = blob.data() + (size_t)i * Wpad;
         const uint32_t c0 = e->colptr[i], k = e->colptr[i + 1] - c0;
         const uint32_t s0 = e->h_sptr[i], m = e->h_sptr[i + 1] - s0;
         uint32_t kjmax = 0;
@@ -431,6 +432,10 @@ static pdmp_status build_blob(pdmp_ensemble* e, const double* c) {
     e->blob_sw = SW;
     e->blob_pw = PW;
     e->blob_kmax = kmax;
+    e->blob_mmax = mmax;
+    const char* force = getenv("PDMP_KERNEL");  // "seq" forces the one-event-per-iteration kernel (A/B runs, tests)
+    e->use_spec = pdmp::zz_spec_supported(e->nblk, mmax, kmax) && !(force && strcmp(force, "seq") == 0) &&
+                  pdmp::zz_spec_lds_bytes(e->nblk_pad, Wpad) <= 64 * 1024;
     return e->d_blob.upload(blob);
 }
 
@@ -548,7 +553,8 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
     P.adapt = e->cfg.adapt;
     P.has_refresh = e->lambda_ref > 0;
     HIP_TRY(hipEventRecord(e->ev0, s));
-    int rc = pdmp::launch_zz_local_run(P, e->cfg.nchains, s);
+    int rc = (e->use_spec && dbg_cap == 0) ? pdmp::launch_zz_local_spec(P, e->cfg.nchains, s)
+                                           : pdmp::launch_zz_local_run(P, e->cfg.nchains, s);
     if (rc != 0) return fail(PDMP_ERR_HIP, "zz_local_run launch failed: %s", hipGetErrorString((hipError_t)rc));
     HIP_TRY(hipEventRecord(e->ev1, s));
     e->timed = true;

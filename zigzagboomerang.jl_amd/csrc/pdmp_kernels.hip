@@ -318,7 +318,7 @@ __global__ __launch_bounds__(64) void zz_local_run_kernel(ZzRunParams P) {
 
         // ---------------- level-1 loads: everything that is a function of i alone
         {
-            const uint64_t* bsrc = P.blob + (size_t)i * W;
+            const uint64_t* bsrc = P.blob + (size_t)i * P.blob_w_pad;
             for (uint32_t w = lane; w < W; w += 64) lb[w] = bsrc[w];
         }
         const ZzRec* ri = rec + i;
@@ -550,6 +550,503 @@ __global__ __launch_bounds__(64) void zz_local_run_kernel(ZzRunParams P) {
     }
 }
 
+// ------------------------------------------------------------------------------------------ speculative event loop
+//
+// Same chain semantics as zz_local_run_kernel, but up to E = 4 events of the chain are processed per iteration, one per
+// 16-lane group (a DPP row), and committed only as far as they are PROVABLY what sequential processing would do:
+//
+//   select   the E smallest block minima of the queue (distinct blocks), in time order t_0 <= t_1 <= ...
+//   execute  every event on the state as it is (loads, move, gradient, re-bound) WITHOUT storing anything
+//   resolve  the accept chain in time order: event r's thinning coin is draw nm + off_r of the chain's stream, where
+//            off_r counts the draws events 0..r-1 consume (2 on reject, 1 + k on accept) -- one wave-wide Philox call
+//            produces all 64 candidate draws of the iteration
+//   validate event r >= 1 is committed iff all earlier ones are, its two-hop zone S[i_r] is disjoint from theirs (so
+//            nothing it read was written by them) and every key they produce or expose -- the re-reduced minimum of
+//            their popped block and all their new keys -- is > t_r (so it really is the next event of the chain)
+//   commit   the valid prefix: stores, level-1 updates, event records; the rest is discarded and re-selected.
+//
+// Zone-disjoint events with that key condition commute exactly, so the committed sequence (indices, accept/reject,
+// times, positions, RNG draws) is bit-identical to the sequential kernel and to the oracle.  The gain: 4x the
+// memory-level parallelism per wavefront and one instruction stream for 4 events.
+// Requirements: |S[i]| <= 16, max column nnz <= 15, d + 1 <= 64 * 8 * 64; otherwise zz_local_run_kernel is used.
+
+size_t zz_spec_lds_bytes(uint32_t nblk_pad, uint32_t blob_w_pad) {
+    // bk | U | LU | SX | STH | PK[4][64] | LB[4][Wpad] | Lr,LBr,Mr (4 each, padded to 16) | bi | Z[64] | Kr[4]
+    return (size_t)nblk_pad * 8 + (size_t)(64 * 4 + 4 * 64) * 8 + (size_t)4 * blob_w_pad * 8 + 16 * 8 +
+           (size_t)nblk_pad * 4 + 64 * 4 + 16 * 4;
+}
+
+// minimum over the 16 lanes of a DPP row, returned in every lane of the row
+__device__ __forceinline__ double row_min_f64(double v) {
+    v = min_f64(v, dpp_f64<0xB1>(v));
+    v = min_f64(v, dpp_f64<0x4E>(v));
+    v = min_f64(v, dpp_f64<0x141>(v));
+    v = min_f64(v, dpp_f64<0x140>(v));
+    return v;
+}
+
+template <int NE>
+__global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
+    constexpr int E = 4;
+    const int lane = threadIdx.x;
+    const int g = lane >> 4;   // group = DPP row = event slot
+    const int gl = lane & 15;  // lane inside the group
+    const int64_t chain = blockIdx.x;
+    const int64_t d = P.d;
+    const uint32_t nblk = P.nblk;
+    const uint32_t W2 = P.blob_w_pad >> 1, SW = P.blob_sw, PW = P.blob_pw, KMAX = P.blob_kmax;
+    const uint32_t R_ = 4 + PW + KMAX;
+
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* bk = reinterpret_cast<double*>(smem);          // [nblk_pad]
+    double* U = bk + P.nblk_pad;                           // [64] uniforms nm + lane
+    double* LU = U + 64;                                   // [64] their logs
+    double* SX = LU + 64;                                  // [4][16]
+    double* STH = SX + 64;                                 // [4][16]
+    double* PK = STH + 64;                                 // [4][64]
+    uint64_t* LB = reinterpret_cast<uint64_t*>(PK + 256);  // [4][Wpad]
+    double* Lr = reinterpret_cast<double*>(LB + 4 * P.blob_w_pad);  // [4] true rates
+    double* LBr = Lr + 4;                                  // [4] bounds
+    double* Mr = LBr + 4;                                  // [4] validation minima (+4 spare)
+    uint32_t* bi = reinterpret_cast<uint32_t*>(Mr + 8);    // [nblk_pad]
+    uint32_t* Z = bi + P.nblk_pad;                         // [64] zone ids
+    uint32_t* Kr = Z + 64;                                 // [4] k per event
+
+    double* sx = SX + g * 16;
+    double* sth = STH + g * 16;
+    double* pk = PK + g * 64;
+    uint64_t* lb = LB + (size_t)g * P.blob_w_pad;
+
+    ZzRec* rec = P.rec + chain * d;
+    double* keys = P.keys + chain * P.dk;
+    DevChain* hdr = P.hdr + chain;
+    pdmp_event* ev = P.ev ? P.ev + chain * P.trace_cap : nullptr;
+    double* cmut = P.c_chain ? (P.c_chain + chain * d) : nullptr;
+
+    uint32_t status = hdr->c.status;
+    if (status == PDMP_CHAIN_BOUND_VIOLATED || status == PDMP_CHAIN_STALLED) return;
+    const uint64_t seed = hdr->seed;
+    uint64_t nm = hdr->c.ndraw_main;
+    uint64_t num = hdr->c.num, nacc = hdr->c.nacc, ntrace = hdr->c.ntrace, nevents = hdr->c.nevents;
+    double t_last = hdr->c.t_last;
+    double t_event = hdr->t_event;
+    status = PDMP_CHAIN_OK;
+
+    const double T = P.T;
+    const bool stop_before = (P.flags & PDMP_RUN_STOP_BEFORE) != 0;
+    const bool adapt = P.adapt != 0;
+
+    for (uint32_t b = lane; b < nblk; b += 64) {
+        const double* kp = keys + (size_t)b * 64;
+        double mk = kp[0];
+        uint32_t mi = 0;
+#pragma unroll 8
+        for (int q = 1; q < 64; ++q) {
+            const double v = kp[q];
+            if (v < mk) {
+                mk = v;
+                mi = q;
+            }
+        }
+        bk[b] = mk;
+        bi[b] = b * 64 + mi;
+    }
+    LDS_ORDER();
+
+    bool running = stop_before || (t_event < T);
+    while (running) {
+        if (P.trace_cap > 0 && ntrace >= (uint64_t)P.trace_cap) {
+            status = PDMP_CHAIN_TRACE_FULL;
+            break;
+        }
+        // ---------------- select the E smallest block minima (exact: every lane keeps its <= NE entries in registers)
+        double ent[NE];
+#pragma unroll
+        for (int q = 0; q < NE; ++q) {
+            const uint32_t b = (uint32_t)lane + 64u * q;
+            ent[q] = (b < nblk) ? bk[b] : PDMP_INF;
+        }
+        double tpr[E];
+        uint32_t blkr[E];
+        int Esel = 0;
+        bool first_inf = false;
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            tpr[r] = PDMP_INF;
+            blkr[r] = 0;
+            if (Esel == r) {
+                double mv = ent[0];
+                int mq = 0;
+#pragma unroll
+                for (int q = 1; q < NE; ++q) {
+                    if (ent[q] < mv) {
+                        mv = ent[q];
+                        mq = q;
+                    }
+                }
+                const double tp = wave_min_f64(mv);
+                if (!(tp < PDMP_INF)) {
+                    if (r == 0) first_inf = true;
+                } else if (!(stop_before && !(tp < T))) {
+                    const uint64_t ball = __ballot(mv == tp);
+                    const int wl = __ffsll((unsigned long long)ball) - 1;
+                    const uint32_t qw = readlane_u32((uint32_t)mq, wl);
+                    if (lane == wl) {
+#pragma unroll
+                        for (int q = 0; q < NE; ++q) {
+                            if (q == mq) ent[q] = PDMP_INF;
+                        }
+                    }
+                    tpr[r] = tp;
+                    blkr[r] = qw * 64u + (uint32_t)wl;
+                    Esel = r + 1;
+                }
+            }
+        }
+        if (Esel == 0) {
+            if (first_inf) status = PDMP_CHAIN_STALLED;
+            break;
+        }
+        const bool gvalid = g < Esel;
+        const double tp = (g == 0) ? tpr[0] : (g == 1) ? tpr[1] : (g == 2) ? tpr[2] : tpr[3];
+        const uint32_t blk = (g == 0) ? blkr[0] : (g == 1) ? blkr[1] : (g == 2) ? blkr[2] : blkr[3];
+        const uint32_t i = gvalid ? bi[blk] : 0u;
+
+        // ---------------- level-1 loads (functions of i alone), per group
+        {
+            const ulonglong2* bsrc = reinterpret_cast<const ulonglong2*>(P.blob + (size_t)i * P.blob_w_pad);
+            ulonglong2* bdst = reinterpret_cast<ulonglong2*>(lb);
+            if (gvalid) {
+                for (uint32_t w = gl; w < W2; w += 16) bdst[w] = bsrc[w];
+            }
+        }
+        const ZzRec* ri = rec + i;
+        double told_i = 0.0, a_i = 0.0, b_i = 0.0;
+        uint64_t acc_i = 0;
+        double kq[4] = {PDMP_INF, PDMP_INF, PDMP_INF, PDMP_INF};
+        if (gvalid) {
+            told_i = ri->t_old;
+            a_i = ri->a;
+            b_i = ri->b;
+            acc_i = ri->acc;
+            const double2* kp = reinterpret_cast<const double2*>(keys + (size_t)blk * 64 + gl * 4);
+            const double2 k01 = kp[0], k23 = kp[1];
+            kq[0] = k01.x;
+            kq[1] = k01.y;
+            kq[2] = k23.x;
+            kq[3] = k23.y;
+        }
+        // ---------------- the 64 candidate draws of this iteration: draw nm + lane and its log
+        {
+            const double u = pdmp_u01(seed, PDMP_STREAM_MAIN, nm + (uint64_t)lane);
+            U[lane] = u;
+            LU[lane] = pdmp_log(u);
+        }
+        LDS_ORDER();
+        // ---------------- neighbourhood header and member list
+        int k = 0, m = 0, self = 0, kjmax = 0;
+        uint32_t s = 0xffffff00u + (uint32_t)lane;
+        if (gvalid) {
+            const uint64_t hw = lb[0];
+            k = (int)(hw & 0xff);
+            m = (int)((hw >> 8) & 0xff);
+            self = (int)((hw >> 16) & 0xff);
+            kjmax = (int)((hw >> 24) & 0xff);
+            if (gl < m) {
+                const uint64_t sw = lb[1 + (gl >> 1)];
+                s = (gl & 1) ? (uint32_t)(sw >> 32) : (uint32_t)sw;
+            }
+        }
+        const bool member = gvalid && gl < m;
+        ZzRec* rs = rec + (member ? s : i);
+        double x = 0.0, th = 0.0, t = 0.0, I = 0.0;
+        if (member) {
+            x = rs->x;
+            th = rs->th;
+            t = rs->t;
+            I = rs->I;
+        }
+        Z[lane] = s;
+        const uint32_t sub = 1 + SW + (uint32_t)gl * R_;
+        double cj = 0.0;
+        if (gvalid && gl < k) cj = cmut ? cmut[s] : __longlong_as_double((long long)lb[sub + 2]);
+
+        // ---------------- zone conflicts with earlier groups (exact: compare member ids)
+        LDS_ORDER();
+        bool myconf = false;
+#pragma unroll
+        for (int q = 0; q < E - 1; ++q) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t zz = Z[q * 16 + j];
+                myconf = myconf || ((q < g) && member && (zz == s));
+            }
+        }
+        const uint64_t confball = __ballot(myconf);
+
+        // ---------------- smove_forward!(G, i, ...), gradient, rates
+        if (gvalid && gl < k) {
+            const double dt = tp - t;
+            const double xn = x + th * dt;
+            I = I + dt * ((x + xn) * 0.5);
+            x = xn;
+            t = tp;
+        }
+        if (member) {
+            sx[gl] = x;
+            sth[gl] = th;
+        }
+        LDS_ORDER();
+        {
+            double gr = 0.0;
+            for (uint32_t p = 0; p < KMAX; ++p) {
+                if ((int)p < k) gr += __longlong_as_double((long long)lb[1 + SW + p * R_]) * sx[p];
+            }
+            if (gvalid) {
+                if (P.tb.gmu_t) gr = gr - P.tb.gmu_t[i];
+                const double th_i = sth[self];
+                const double l = pos_part(gr * th_i);
+                const double lbound = pos_part(a_i + b_i * (tp - told_i));
+                if (gl == 0) {
+                    Lr[g] = l;
+                    LBr[g] = lbound;
+                    Kr[g] = (uint32_t)k;
+                }
+            }
+        }
+        LDS_ORDER();
+        // ---------------- accept chain in time order (wave-uniform, every lane computes it)
+        bool accr[E], violr[E];
+        uint32_t offr[E + 1];
+        offr[0] = 0;
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            accr[r] = false;
+            violr[r] = false;
+            offr[r + 1] = offr[r];
+            if (r < Esel) {
+                const double coin = U[offr[r]];
+                const double l = Lr[r], lbound = LBr[r];
+                accr[r] = (coin * lbound < l);             // :121
+                violr[r] = accr[r] && (l >= lbound);       // :123
+                offr[r + 1] = offr[r] + (accr[r] ? (1u + Kr[r]) : 2u);
+            }
+        }
+        const bool accept = (g == 0) ? accr[0] : (g == 1) ? accr[1] : (g == 2) ? accr[2] : accr[3];
+        const bool violated = (g == 0) ? violr[0] : (g == 1) ? violr[1] : (g == 2) ? violr[2] : violr[3];
+        const uint32_t myoff = (g == 0) ? offr[0] : (g == 1) ? offr[1] : (g == 2) ? offr[2] : offr[3];
+
+        int nmoved = k;
+        if (gvalid && accept) {
+            if (gl >= k && gl < m) {  // smove_forward!(G2, i, ...), :129
+                const double dt = tp - t;
+                const double xn = x + th * dt;
+                I = I + dt * ((x + xn) * 0.5);
+                x = xn;
+                t = tp;
+            }
+            nmoved = m;
+            if (gl == self) th = -th;  // reflect!, :130
+        }
+        if (gvalid && gl < nmoved) {
+            sx[gl] = x;
+            sth[gl] = th;
+        }
+        {
+            double2* pk2 = reinterpret_cast<double2*>(pk + gl * 4);
+            pk2[0] = make_double2(kq[0], kq[1]);
+            pk2[1] = make_double2(kq[2], kq[3]);
+        }
+        LDS_ORDER();
+        // ---------------- re-bound (ab + poisson_time) -- results stay in registers until the commit
+        const bool active = gvalid && (accept ? (gl < k) : (gl == self));
+        double key = PDMP_INF, a = 0.0, b = 0.0;
+        if (active) {
+            const double gmu = __longlong_as_double((long long)lb[sub + 1]);
+            const int kj = (int)(lb[sub + 3] & 0xff);
+            double gx = 0.0, gt = 0.0;
+            for (int base = 0; base < kjmax; base += 8) {
+                const uint64_t pw = lb[sub + 4 + (base >> 3)];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int pp = base + q;
+                    if (pp < kj) {
+                        const double v = __longlong_as_double((long long)lb[sub + 4 + PW + pp]);
+                        const int ps = (int)((pw >> (8 * q)) & 0xff);
+                        gx += v * sx[ps];
+                        gt += v * sth[ps];
+                    }
+                }
+            }
+            if (violated && gl == self) cj *= P.factor;  // adapt!(c, i, factor), :127 (stored at commit)
+            a = cj + (gx - gmu) * th;
+            b = cj / 100 + th * gt;
+            const double L = LU[myoff + 1 + (accept ? (uint32_t)gl : 0u)];
+            key = t + dev_poisson_time_L(a, b, L);
+            if ((s >> 6) == blk) pk[s & 63] = key;
+        }
+        LDS_ORDER();
+        // ---------------- patched minimum of the popped block, and everything this event could expose
+        double rowmin, candmin;
+        uint32_t cand;
+        {
+            const double2* pk2 = reinterpret_cast<const double2*>(pk + gl * 4);
+            const double2 p01 = pk2[0], p23 = pk2[1];
+            double lm = p01.x;
+            uint32_t li = 0;
+            if (p01.y < lm) {
+                lm = p01.y;
+                li = 1;
+            }
+            if (p23.x < lm) {
+                lm = p23.x;
+                li = 2;
+            }
+            if (p23.y < lm) {
+                lm = p23.y;
+                li = 3;
+            }
+            candmin = lm;
+            cand = blk * 64u + (uint32_t)gl * 4u + li;
+            rowmin = row_min_f64(lm);
+        }
+        const uint64_t winball = __ballot(gvalid && candmin == rowmin);
+        const int wl = __ffs((unsigned)((winball >> (16 * g)) & 0xffffu)) - 1;
+        const double keymin = row_min_f64(key);
+        const double Mg = min_f64(rowmin, keymin);
+        double Mv[E];
+#pragma unroll
+        for (int r = 0; r < E; ++r) Mv[r] = readlane_f64(Mg, 16 * r);
+
+        // ---------------- validate: longest prefix that equals sequential processing
+        int Rc = 0;            // committed events
+        uint32_t nacc_c = 0;   // accepted among them
+        double prefM = PDMP_INF;
+        bool stop_chain = false;
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            if (r < Esel && Rc == r && !stop_chain) {
+                const bool conf = ((confball >> (16 * r)) & 0xffffull) != 0;
+                const bool ok = (r == 0) || (!conf && prefM > tpr[r]);
+                if (ok) {
+                    if (violr[r] && !adapt) {
+                        status = PDMP_CHAIN_BOUND_VIOLATED;  // reference: error(...), :124
+                        stop_chain = true;
+                    } else {
+                        Rc = r + 1;
+                        prefM = min_f64(prefM, Mv[r]);
+                        if (accr[r]) {
+                            nacc_c += 1;
+                            if (P.trace_cap > 0 && ntrace + nacc_c >= (uint64_t)P.trace_cap) {
+                                status = PDMP_CHAIN_TRACE_FULL;
+                                stop_chain = true;
+                            }
+                            if (!stop_before && !(tpr[r] < T)) {  // `while t′ < T`
+                                running = false;
+                                stop_chain = true;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        Rc = (int)uniform_u32((uint32_t)Rc);
+
+        // ---------------- commit the valid prefix
+        const bool commit = gvalid && g < Rc;
+        if (commit) {
+            if (gl < nmoved) {
+                rs->x = x;
+                rs->th = th;
+                rs->t = t;
+                rs->I = I;
+            }
+            if (active) {
+                rs->t_old = t;
+                rs->a = a;
+                rs->b = b;
+                keys[s] = key;
+                if (violated && gl == self) cmut[s] = cj;
+            }
+            if (accept && gl == self) rs->acc = acc_i + 1;
+            if (gl == wl) {
+                bk[blk] = rowmin;
+                bi[blk] = cand;
+            }
+            if (accept && gl == self && ev) {
+                uint32_t rank = 0;
+#pragma unroll
+                for (int r = 0; r < E; ++r) rank += (r < g && accr[r]) ? 1u : 0u;
+                pdmp_event e;
+                e.t = tp;
+                e.i = (int64_t)i;
+                e.x = x;
+                e.theta = th;
+                ev[ntrace + rank] = e;
+            }
+        }
+        LDS_ORDER();
+        // ---------------- level-1 updates for re-bounded neighbours living in other blocks, in event order
+        for (int r = 0; r < Rc; ++r) {
+            const bool acc_r = (r == 0) ? accr[0] : (r == 1) ? accr[1] : (r == 2) ? accr[2] : accr[3];
+            if (!acc_r) continue;
+            const uint32_t own = (r == 0) ? blkr[0] : (r == 1) ? blkr[1] : (r == 2) ? blkr[2] : blkr[3];
+            const int kr = (int)uniform_u32(Kr[r]);
+            for (int jj = 0; jj < kr; ++jj) {
+                const uint32_t j = readlane_u32(s, 16 * r + jj);
+                const uint32_t bj = j >> 6;
+                if (bj == own) continue;
+                const double kj = readlane_f64(key, 16 * r + jj);
+                LDS_ORDER();
+                const double cur = bk[bj];
+                const uint32_t ci = bi[bj];
+                if (kj < cur || (kj == cur && j < ci)) {
+                    if (lane == 0) {
+                        bk[bj] = kj;
+                        bi[bj] = j;
+                    }
+                } else if (ci == j) {
+                    const double kv = __hip_atomic_load(keys + (size_t)bj * 64 + lane, __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT);
+                    const double mn = wave_min_f64(kv);
+                    const uint64_t bl = __ballot(kv == mn);
+                    const int arg = bl ? (__ffsll((unsigned long long)bl) - 1) : 0;
+                    if (lane == 0) {
+                        bk[bj] = mn;
+                        bi[bj] = bj * 64 + (uint32_t)arg;
+                    }
+                }
+            }
+        }
+        // ---------------- counters
+        if (Rc > 0) {
+            num += (uint64_t)Rc;
+            nacc += nacc_c;
+            ntrace += nacc_c;
+            nevents += nacc_c;
+            nm += (Rc == 1) ? offr[1] : (Rc == 2) ? offr[2] : (Rc == 3) ? offr[3] : offr[4];
+            t_last = (Rc == 1) ? tpr[0] : (Rc == 2) ? tpr[1] : (Rc == 3) ? tpr[2] : tpr[3];
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                if (r < Rc && accr[r]) t_event = tpr[r];
+            }
+        }
+        if (status != PDMP_CHAIN_OK) break;
+        LDS_ORDER();
+    }
+
+    if (lane == 0) {
+        hdr->c.t_last = t_last;
+        hdr->t_event = t_event;
+        hdr->c.num = num;
+        hdr->c.nacc = nacc;
+        hdr->c.ntrace = ntrace;
+        hdr->c.nevents = nevents;
+        hdr->c.ndraw_main = nm;
+        hdr->c.status = status;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ unpack / moments
 
 // final state (t, x, θ), acc, c of chains [chain_first, chain_first + n): src/sfact.jl:211
@@ -624,6 +1121,26 @@ int launch_math_probe(uint64_t seed, int64_t n, double* out, void* stream) {
 int launch_zz_init(const ZzInitParams& p, void* stream) {
     dim3 grid((unsigned)p.nchains, (unsigned)((p.dk + 255) / 256));
     hipLaunchKernelGGL(zz_init_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}
+
+bool zz_spec_supported(uint32_t nblk, uint32_t mmax, uint32_t kmax) {
+    return mmax <= 16 && kmax <= 15 && nblk <= 64 * 8;
+}
+
+int launch_zz_local_spec(const ZzRunParams& p, int64_t nchains, void* stream) {
+    const size_t lds = zz_spec_lds_bytes(p.nblk_pad, p.blob_w_pad);
+    const int ne = (int)((p.nblk + 63) / 64);
+    dim3 grid((unsigned)nchains), block(64);
+    if (ne <= 1) {
+        hipLaunchKernelGGL(zz_local_spec_kernel<1>, grid, block, lds, (hipStream_t)stream, p);
+    } else if (ne <= 2) {
+        hipLaunchKernelGGL(zz_local_spec_kernel<2>, grid, block, lds, (hipStream_t)stream, p);
+    } else if (ne <= 5) {
+        hipLaunchKernelGGL(zz_local_spec_kernel<5>, grid, block, lds, (hipStream_t)stream, p);
+    } else {
+        hipLaunchKernelGGL(zz_local_spec_kernel<8>, grid, block, lds, (hipStream_t)stream, p);
+    }
     return (int)hipGetLastError();
 }
 
