@@ -53,7 +53,7 @@ __device__ __forceinline__ double dpp_f64(double v) {
 }
 
 __device__ __forceinline__ double min_f64(double a, double b) {
-    return (b < a) ? b : a;
+    return __builtin_fmin(a, b);  // v_min_f64; keys are never NaN unless a chain has diverged (NaN loses: treated as +Inf)
 }
 
 // Minimum over the 64 lanes, returned wave-uniform.  4 DPP steps inside each row of 16 lanes
@@ -659,46 +659,41 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
             status = PDMP_CHAIN_TRACE_FULL;
             break;
         }
-        // ---------------- select the E smallest block minima (exact: every lane keeps its <= NE entries in registers)
-        double ent[NE];
+        // ---------------- select E candidate events: lane l owns the level-1 entries l, l+64, ...; it offers its best
+        // entry and remembers its second best.  A lane offers only ONE entry per iteration, so the candidates are the E
+        // smallest entries only if no lane holds two of them -- the lane's second best therefore enters the validation
+        // bound of every later event (hid[r]), which keeps the commit rule exact.
+        double best = PDMP_INF, second = PDMP_INF;
+        uint32_t bestb = 0;
 #pragma unroll
         for (int q = 0; q < NE; ++q) {
             const uint32_t b = (uint32_t)lane + 64u * q;
-            ent[q] = (b < nblk) ? bk[b] : PDMP_INF;
+            const double v = (b < nblk) ? bk[b] : PDMP_INF;
+            const bool lt = v < best;
+            second = min_f64(second, lt ? best : v);
+            bestb = lt ? b : bestb;
+            best = lt ? v : best;
         }
-        double tpr[E];
+        double tpr[E], hid[E];
         uint32_t blkr[E];
         int Esel = 0;
         bool first_inf = false;
 #pragma unroll
         for (int r = 0; r < E; ++r) {
             tpr[r] = PDMP_INF;
+            hid[r] = PDMP_INF;
             blkr[r] = 0;
             if (Esel == r) {
-                double mv = ent[0];
-                int mq = 0;
-#pragma unroll
-                for (int q = 1; q < NE; ++q) {
-                    if (ent[q] < mv) {
-                        mv = ent[q];
-                        mq = q;
-                    }
-                }
-                const double tp = wave_min_f64(mv);
+                const double tp = wave_min_f64(best);
                 if (!(tp < PDMP_INF)) {
                     if (r == 0) first_inf = true;
                 } else if (!(stop_before && !(tp < T))) {
-                    const uint64_t ball = __ballot(mv == tp);
+                    const uint64_t ball = __ballot(best == tp);
                     const int wl = __ffsll((unsigned long long)ball) - 1;
-                    const uint32_t qw = readlane_u32((uint32_t)mq, wl);
-                    if (lane == wl) {
-#pragma unroll
-                        for (int q = 0; q < NE; ++q) {
-                            if (q == mq) ent[q] = PDMP_INF;
-                        }
-                    }
+                    blkr[r] = readlane_u32(bestb, wl);
+                    hid[r] = readlane_f64(second, wl);
+                    if (lane == wl) best = PDMP_INF;
                     tpr[r] = tp;
-                    blkr[r] = qw * 64u + (uint32_t)wl;
                     Esel = r + 1;
                 }
             }
@@ -774,13 +769,19 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
         // ---------------- zone conflicts with earlier groups (exact: compare member ids)
         LDS_ORDER();
         bool myconf = false;
+        {
+            const uint2* Z2 = reinterpret_cast<const uint2*>(Z);
 #pragma unroll
-        for (int q = 0; q < E - 1; ++q) {
+            for (int q = 0; q < E - 1; ++q) {
+                bool hit = false;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const uint32_t zz = Z[q * 16 + j];
-                myconf = myconf || ((q < g) && member && (zz == s));
+                for (int j = 0; j < 8; ++j) {
+                    const uint2 zz = Z2[q * 8 + j];
+                    hit = hit || (zz.x == s) || (zz.y == s);
+                }
+                myconf = myconf || (hit && (q < g));
             }
+            myconf = myconf && member;
         }
         const uint64_t confball = __ballot(myconf);
 
@@ -934,7 +935,7 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
                         stop_chain = true;
                     } else {
                         Rc = r + 1;
-                        prefM = min_f64(prefM, Mv[r]);
+                        prefM = min_f64(prefM, min_f64(Mv[r], hid[r]));
                         if (accr[r]) {
                             nacc_c += 1;
                             if (P.trace_cap > 0 && ntrace + nacc_c >= (uint64_t)P.trace_cap) {
