@@ -191,3 +191,49 @@ def test_count_only_mode_matches_traced_mode(gpu_pkg):
     x0, th0 = O.synthetic_state(42 + 3, d)
     r = O.spdmp_zigzag(G, None, G, x0, th0, c, 5.0, seed=45)
     assert np.array_equal(res[0][1]["x"][3], r["x"]) and int(res[0][0]["num"][3]) == r["num"]
+
+
+def test_refresh_clock_matches_oracle(gpu_pkg):
+    """λref > 0: src/sfact.jl:78-114,188-190 (two global-rng coordinate draws, σ_i·(±1) refresh, stale-clock re-bound)."""
+    pkg = gpu_pkg
+    for n, lam in ((4, 0.7), (8, 0.3)):
+        G = pkg.problems.gmrf_precision(n)
+        d = n * n
+        rng = np.random.default_rng(n)
+        sig = 0.5 + rng.random(d)
+        x0 = rng.standard_normal((3, d))
+        th0 = sig * rng.choice([-1.0, 1.0], (3, d))
+        c = 2.0 * pkg.problems.column_norms(G)
+        Z = pkg.ZigZag(G, np.zeros(d), sig, λref=lam)
+        tr, fs, (acc, num), _ = pkg.spdmp(pkg.GaussianTarget(G), 0.0, x0, th0, 30.0, c, Z, seed=61)
+        for k in range(3):
+            r = O.spdmp_zigzag(G, None, G, x0[k], th0[k], c, 30.0, seed=61 + k, lambda_ref=lam, sigma=sig)
+            assert r["nrefresh"] > 3
+            assert_chain_equal(tr[k].events, fs, k, num[k], r, f"refresh n={n} chain {k}")
+            assert np.array_equal(acc[k], r["acc"])
+
+
+def test_pdmp_all_matches_oracle(gpu_pkg):
+    """pdmp = spdmp with G = All() (src/sfact.jl:236): all coordinates move at every proposal."""
+    pkg = gpu_pkg
+    G = pkg.problems.maintest_precision(8)
+    rng = np.random.default_rng(8)
+    x0 = rng.random((4, 8))
+    th0 = rng.choice([-1.0, 1.0], (4, 8))
+    c = 0.7 * pkg.problems.column_norms(G)
+    Z = pkg.ZigZag(0.9 * G, np.zeros(8))
+    tr, fs, (acc, num), cout = pkg.pdmp(pkg.GaussianTarget(G), 0.0, x0, th0, 100.0, c, Z, seed=5, adapt=True)
+    for k in range(4):
+        r = O.spdmp_zigzag(0.9 * G, None, G, x0[k], th0[k], c, 100.0, seed=5 + k, adapt=True, move_all=True)
+        assert_chain_equal(tr[k].events, fs, k, num[k], r, f"pdmp chain {k}")
+        assert np.array_equal(cout[k], r["c"])
+        assert np.all(fs[0][k] == fs[0][k][0])  # every clock sits at the last proposal time
+    G = pkg.problems.gmrf_precision(8)
+    x0 = rng.standard_normal((2, 64))
+    th0 = rng.choice([-1.0, 1.0], (2, 64))
+    c = pkg.problems.column_norms(G)
+    tr, fs, (acc, num), _ = pkg.pdmp(pkg.GaussianTarget(G), 0.0, x0, th0, 10.0, c, pkg.ZigZag(G, np.zeros(64), λref=0.5), seed=15)
+    for k in range(2):
+        r = O.spdmp_zigzag(G, None, G, x0[k], th0[k], c, 10.0, seed=15 + k, move_all=True, lambda_ref=0.5,
+                           sigma=np.asarray(G.diagonal()) ** -0.5)
+        assert_chain_equal(tr[k].events, fs, k, num[k], r, f"pdmp+refresh chain {k}")

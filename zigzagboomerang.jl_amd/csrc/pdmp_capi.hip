@@ -164,9 +164,8 @@ pdmp_status pdmp_ensemble_create(const pdmp_config* cfg, pdmp_ensemble** out) {
         return fail(PDMP_ERR_INVALID, "pdmp_config.struct_size %u != %zu", cfg->struct_size, sizeof(pdmp_config));
     if (cfg->nchains <= 0 || cfg->d <= 0) return fail(PDMP_ERR_INVALID, "nchains and d must be positive");
     if (cfg->d >= (int64_t)1 << 31) return fail(PDMP_ERR_UNSUPPORTED, "d must be < 2^31");
-    if (cfg->sampler != PDMP_SAMPLER_ZIGZAG_LOCAL)
-        return fail(PDMP_ERR_UNSUPPORTED, "sampler %d: only PDMP_SAMPLER_ZIGZAG_LOCAL has a device kernel so far",
-                    cfg->sampler);
+    if (cfg->sampler != PDMP_SAMPLER_ZIGZAG_LOCAL && cfg->sampler != PDMP_SAMPLER_ZIGZAG_ALL)
+        return fail(PDMP_ERR_UNSUPPORTED, "sampler %d has no device kernel yet (ZIGZAG_LOCAL and ZIGZAG_ALL do)", cfg->sampler);
     if (cfg->trace_capacity < 0) return fail(PDMP_ERR_INVALID, "trace_capacity < 0");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -209,8 +208,6 @@ pdmp_status pdmp_ensemble_set_flow_zigzag(pdmp_ensemble* e, const int64_t* colpt
     const int64_t nnz = colptr[d];
     if (nnz <= 0 || nnz >= (int64_t)1 << 31) return fail(PDMP_ERR_INVALID, "bad nnz %lld", (long long)nnz);
     if (lambda_ref < 0) return fail(PDMP_ERR_INVALID, "lambda_ref < 0");
-    if (lambda_ref > 0)
-        return fail(PDMP_ERR_UNSUPPORTED, "refresh clock (lambda_ref > 0, src/sfact.jl:78-114) has no device path yet");
     e->colptr.assign(d + 1, 0);
     e->rowval.assign(nnz, 0);
     e->bval.assign(nzval, nzval + nnz);
@@ -552,8 +549,10 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
     P.flags = flags;
     P.adapt = e->cfg.adapt;
     P.has_refresh = e->lambda_ref > 0;
+    P.move_all = e->cfg.sampler == PDMP_SAMPLER_ZIGZAG_ALL;
     HIP_TRY(hipEventRecord(e->ev0, s));
-    int rc = (e->use_spec && dbg_cap == 0) ? pdmp::launch_zz_local_spec(P, e->cfg.nchains, s)
+    const bool spec_ok = e->use_spec && dbg_cap == 0 && !P.has_refresh && !P.move_all;
+    int rc = spec_ok ? pdmp::launch_zz_local_spec(P, e->cfg.nchains, s)
                                            : pdmp::launch_zz_local_run(P, e->cfg.nchains, s);
     if (rc != 0) return fail(PDMP_ERR_HIP, "zz_local_run launch failed: %s", hipGetErrorString((hipError_t)rc));
     HIP_TRY(hipEventRecord(e->ev1, s));

@@ -85,6 +85,7 @@ struct ZzRunParams {
     int32_t flags;
     int32_t adapt;
     int32_t has_refresh;
+    int32_t move_all;  // G = All(): the `pdmp` driver for ZigZag (src/sfact.jl:236)
 };
 
 struct ZzInitParams {

@@ -256,8 +256,9 @@ __global__ __launch_bounds__(64) void zz_local_run_kernel(ZzRunParams P) {
     uint32_t status = hdr->c.status;
     if (status == PDMP_CHAIN_BOUND_VIOLATED || status == PDMP_CHAIN_STALLED) return;
     const uint64_t seed = hdr->seed;
-    uint64_t nm = hdr->c.ndraw_main;
+    uint64_t nm = hdr->c.ndraw_main, ng = hdr->c.ndraw_global;
     uint64_t num = hdr->c.num, nacc = hdr->c.nacc, ntrace = hdr->c.ntrace, nevents = hdr->c.nevents;
+    uint64_t nrefresh = hdr->c.nrefresh;
     double t_last = hdr->c.t_last;
     double t_event = hdr->t_event;
     status = PDMP_CHAIN_OK;
@@ -265,6 +266,44 @@ __global__ __launch_bounds__(64) void zz_local_run_kernel(ZzRunParams P) {
     const double T = P.T;
     const bool stop_before = (P.flags & PDMP_RUN_STOP_BEFORE) != 0;
     const bool adapt = P.adapt != 0;
+    const bool has_refresh = P.has_refresh != 0;
+    const bool move_all = P.move_all != 0;
+
+    // smove_forward!(::All, ...) = move every coordinate (src/sfact.jl:19,23-28): the `pdmp` driver, G = All()
+    auto sweep_all = [&](double tnew) {
+        for (int64_t q = lane; q < d; q += 64) {
+            ZzRec* r = rec + q;
+            const double x0 = r->x, th0 = r->th, t0 = r->t, I0 = r->I;
+            const double dt = tnew - t0;
+            const double xn = x0 + th0 * dt;
+            r->x = xn;
+            r->t = tnew;
+            r->I = I0 + dt * ((x0 + xn) * 0.5);
+        }
+    };
+    // generic level-1 update for one changed key (j, kj) whose new value is already stored in keys[]
+    auto queue_update = [&](uint32_t j, double kj) {
+        const uint32_t bj = j >> 6;
+        LDS_ORDER();
+        const double cur = bk[bj];
+        const uint32_t ci = bi[bj];
+        if (kj < cur || (kj == cur && j < ci)) {
+            if (lane == 0) {
+                bk[bj] = kj;
+                bi[bj] = j;
+            }
+        } else if (ci == j) {
+            const double kv = __hip_atomic_load(keys + (size_t)bj * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double mn = wave_min_f64(kv);
+            const uint64_t bl = __ballot(kv == mn);
+            const int arg = bl ? (__ffsll((unsigned long long)bl) - 1) : 0;
+            if (lane == 0) {
+                bk[bj] = mn;
+                bi[bj] = bj * 64 + (uint32_t)arg;
+            }
+        }
+        LDS_ORDER();
+    };
 
     // ---- rebuild level 1 of the queue from the keys in HBM (each lane scans whole blocks)
     for (uint32_t b = lane; b < nblk; b += 64) {
@@ -315,6 +354,135 @@ __global__ __launch_bounds__(64) void zz_local_run_kernel(ZzRunParams P) {
         }
         const uint32_t i = uniform_u32(bi[blk]);
         t_last = tp;
+
+        if (has_refresh && i == (uint32_t)d) {
+            // ---------------- refresh clock popped: src/sfact.jl:78-114 (restated with its quirks: the coordinate whose
+            // neighbourhood is moved (:80) and the coordinate that is refreshed (:84) are two independent draws from the
+            // "global rng" stream, and G1[i] is re-bounded at the coordinates' own, possibly stale, clocks)
+            const uint32_t i1 = pdmp_randint(seed, PDMP_STREAM_GLOBAL, ng, (uint32_t)d);
+            ng += 1;
+            if (move_all) {
+                sweep_all(tp);
+            } else {
+                const uint64_t* bsrc = P.blob + (size_t)i1 * P.blob_w_pad;
+                for (uint32_t w = lane; w < W; w += 64) lb[w] = bsrc[w];
+                LDS_ORDER();
+                const int k1 = (int)uniform_u32((uint32_t)(lb[0] & 0xff));
+                if (lane < k1) {
+                    const uint64_t sw = lb[1 + (lane >> 1)];
+                    const uint32_t s1 = (lane & 1) ? (uint32_t)(sw >> 32) : (uint32_t)sw;
+                    ZzRec* r1 = rec + s1;
+                    const double x0 = r1->x, th0 = r1->th, t0 = r1->t, I0 = r1->I;
+                    const double dt = tp - t0;
+                    const double xn = x0 + th0 * dt;
+                    r1->x = xn;
+                    r1->t = tp;
+                    r1->I = I0 + dt * ((x0 + xn) * 0.5);
+                }
+                LDS_ORDER();
+            }
+            const uint32_t i2 = pdmp_randint(seed, PDMP_STREAM_GLOBAL, ng, (uint32_t)d);
+            ng += 1;
+            {
+                const uint64_t* bsrc = P.blob + (size_t)i2 * P.blob_w_pad;
+                for (uint32_t w = lane; w < W; w += 64) lb[w] = bsrc[w];
+            }
+            LDS_ORDER();
+            const uint64_t hw = lb[0];
+            const int k = (int)uniform_u32((uint32_t)(hw & 0xff));
+            const int m = (int)uniform_u32((uint32_t)((hw >> 8) & 0xff));
+            const int self = (int)uniform_u32((uint32_t)((hw >> 16) & 0xff));
+            const int kjmax = (int)uniform_u32((uint32_t)((hw >> 24) & 0xff));
+            uint32_t s = i2;
+            if (lane < m) {
+                const uint64_t sw = lb[1 + (lane >> 1)];
+                s = (lane & 1) ? (uint32_t)(sw >> 32) : (uint32_t)sw;
+            }
+            ZzRec* rs = rec + s;
+            double x = 0.0, th = 0.0, t = 0.0, I = 0.0;
+            if (lane < m) {
+                x = rs->x;
+                th = rs->th;
+                t = rs->t;
+                I = rs->I;
+            }
+            if (!move_all && lane >= k && lane < m) {  // smove_forward!(G2, i, ...), :85
+                const double dt = tp - t;
+                const double xn = x + th * dt;
+                I = I + dt * ((x + xn) * 0.5);
+                x = xn;
+                t = tp;
+            }
+            const double usign = pdmp_u01(seed, PDMP_STREAM_MAIN, nm);  // θ[i] = σ[i]*rand(rng, (-1,1)), :100-101
+            nm += 1;
+            if (lane == self) th = P.tb.sigma[i2] * ((usign < 0.5) ? -1.0 : 1.0);
+            // Q[n+1] = t′ + waiting_time_ref(F) = t′ + randexp()/λref from the global rng, :108
+            const double newref = tp + (-pdmp_log(pdmp_u01(seed, PDMP_STREAM_GLOBAL, ng))) / P.lambda_ref;
+            ng += 1;
+            if (lane < m) {
+                sx[lane] = x;
+                sth[lane] = th;
+            }
+            LDS_ORDER();
+            const uint32_t sub = 1 + SW + (uint32_t)lane * R;
+            double key = PDMP_INF;
+            if (lane < k) {  // :110-114
+                const double gmu = __longlong_as_double((long long)lb[sub + 1]);
+                const double cj = cmut ? cmut[s] : __longlong_as_double((long long)lb[sub + 2]);
+                const int kj = (int)(lb[sub + 3] & 0xff);
+                double gx = 0.0, gt = 0.0;
+                for (int base = 0; base < kjmax; base += 8) {
+                    const uint64_t pw = lb[sub + 4 + (base >> 3)];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int pp = base + q;
+                        if (pp < kj) {
+                            const double v = __longlong_as_double((long long)lb[sub + 4 + PW + pp]);
+                            const int ps = (int)((pw >> (8 * q)) & 0xff);
+                            gx += v * sx[ps];
+                            gt += v * sth[ps];
+                        }
+                    }
+                }
+                const double a = cj + (gx - gmu) * th;
+                const double b = cj / 100 + th * gt;
+                const double L = pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm + (uint64_t)lane));
+                key = t + dev_poisson_time_L(a, b, L);  // Q[j] = t[j] + poisson_time(...): t[j] is j's OWN clock here
+                rs->t_old = t;
+                rs->a = a;
+                rs->b = b;
+                keys[s] = key;
+            }
+            nm += (uint64_t)k;
+            if (lane < m) {
+                rs->x = x;
+                rs->th = th;
+                rs->t = t;
+                rs->I = I;
+            }
+            if (lane == 0) keys[d] = newref;
+            for (int jj = 0; jj <= k; ++jj) {
+                const uint32_t j = (jj < k) ? readlane_u32(s, jj) : (uint32_t)d;
+                const double kj = (jj < k) ? readlane_f64(key, jj < k ? jj : 0) : newref;
+                queue_update(j, kj);
+            }
+            const double t_i = readlane_f64(t, self), x_i = readlane_f64(x, self), th_i2 = readlane_f64(th, self);
+            if (ev && lane == 0) {  // event(i, t, x, θ, F) = (t[i], i, x[i], θ[i]), :143
+                pdmp_event e;
+                e.t = t_i;
+                e.i = (int64_t)i2;
+                e.x = x_i;
+                e.theta = th_i2;
+                ev[ntrace] = e;
+            }
+            nrefresh += 1;
+            ntrace += 1;
+            nevents += 1;
+            t_event = tp;
+            if (!stop_before && !(tp < T)) running = false;
+            continue;
+        }
+        if (move_all) sweep_all(tp);
 
         // ---------------- level-1 loads: everything that is a function of i alone
         {
@@ -546,6 +714,8 @@ __global__ __launch_bounds__(64) void zz_local_run_kernel(ZzRunParams P) {
         hdr->c.ntrace = ntrace;
         hdr->c.nevents = nevents;
         hdr->c.ndraw_main = nm;
+        hdr->c.ndraw_global = ng;
+        hdr->c.nrefresh = nrefresh;
         hdr->c.status = status;
     }
 }

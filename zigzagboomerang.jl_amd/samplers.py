@@ -28,9 +28,21 @@ def _drain(ens, events):
 
 def spdmp(target, t0, x0, θ0, T, c, F, *, factor=1.8, adapt=False, seed=DEFAULT_SEED, device=0,
           trace_capacity=None, trace=True):
-    """Local ZigZag (spdmp with G = Matched()).  Returns Ξ, (t, x, θ), (acc, num), c like the reference."""
+    """Local ZigZag: spdmp(∇ϕ, t0, x0, θ0, T, c, F::ZigZag, args...) with G = Matched() (src/sfact.jl:214).
+    Returns Ξ, (t, x, θ), (acc, num), c like the reference (:211)."""
+    return _zigzag(_lib.SAMPLER_ZIGZAG_LOCAL, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, trace_capacity, trace)
+
+
+def pdmp(target, t0, x0, θ0, T, c, F, *, factor=1.8, adapt=False, seed=DEFAULT_SEED, device=0,
+         trace_capacity=None, trace=True):
+    """pdmp(∇ϕ, t0, x0, θ0, T, c, F::ZigZag, args...) = spdmp(..., All(), ...) (src/sfact.jl:236): every proposal moves
+    ALL coordinates (no sparsity assumption on ∇ϕ); same return value as spdmp."""
+    return _zigzag(_lib.SAMPLER_ZIGZAG_ALL, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, trace_capacity, trace)
+
+
+def _zigzag(sampler, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, trace_capacity, trace):
     if not isinstance(F, ZigZag):
-        raise TypeError("spdmp on the device supports F::ZigZag")
+        raise TypeError("the device path supports F::ZigZag")
     if not isinstance(target, GaussianTarget):
         raise TypeError("target must be one of the device-resident families (GaussianTarget)")
     x0 = np.asarray(x0, dtype=np.float64)
@@ -45,7 +57,7 @@ def spdmp(target, t0, x0, θ0, T, c, F, *, factor=1.8, adapt=False, seed=DEFAULT
         # ~0.8 reflections per coordinate per unit time on the GMRF; generous first guess, refilled on demand
         trace_capacity = int(min(max(1024, 2.0 * d * max(T - t0, 1.0)), 1 << 22))
     cap = trace_capacity if trace else 0
-    ens = Ensemble(nch, d, sampler=_lib.SAMPLER_ZIGZAG_LOCAL, adapt=adapt, factor=factor, device=device,
+    ens = Ensemble(nch, d, sampler=sampler, adapt=adapt, factor=factor, device=device,
                    trace_capacity=cap)
     try:
         ens.set_flow(F)
