@@ -181,6 +181,25 @@ pdmp_status pdmp_ensemble_final_state(pdmp_ensemble* ens, int64_t chain_first, i
  */
 pdmp_status pdmp_ensemble_batch_means(pdmp_ensemble* ens, double T_prev, double T, double* sum_y, double* sum_y2);
 
+/* ------------------------------------------------------------------ Bouncy particle sampler (PDMP_SAMPLER_BPS)
+ *
+ * pdmp(∇ϕ!, t0, x0, θ0, T, c, B::BouncyParticle; adapt, factor=2.0) -> Ξ::PDMPTrace, (t, x, θ), (acc, num), c
+ * (src/not_fact_samplers.jl:117-147,395-396) with GlobalBound(c) and the Gaussian target ∇ϕ!(y, x) = Γ(x − μ)
+ * (test/maintest.jl:163).  Mass matrix L = I (config C2: Γ = I); a general cholesky(Γ).L is not implemented.
+ * Events are (t, copy(x), copy(θ)) (:39-41); dot products use the fixed summation order stated in oracle/pdmp_oracle.c.
+ */
+pdmp_status pdmp_ensemble_set_flow_bps(pdmp_ensemble* ens, const int64_t* colptr, const int64_t* rowval,
+                                       const double* nzval, const double* mu, double lambda_ref, double rho);
+/* x0, theta0: [nchains x d]; c: the scalar bound constant (GlobalBound(c)); seeds: [nchains] */
+pdmp_status pdmp_ensemble_set_state_bps(pdmp_ensemble* ens, double t0, const double* x0, const double* theta0, double c,
+                                        const uint64_t* seeds);
+/* events [first, first+count) of one chain: t [count], x and theta [count x d] (any may be NULL) */
+pdmp_status pdmp_ensemble_bps_trace_copy(pdmp_ensemble* ens, int64_t chain, int64_t first, int64_t count, double* t,
+                                         double* x, double* theta);
+/* final (t, x, θ) and adapted c of chains [chain_first, chain_first+n): t, c are [n]; x, theta are [n x d] */
+pdmp_status pdmp_ensemble_bps_final_state(pdmp_ensemble* ens, int64_t chain_first, int64_t n, double* t, double* x,
+                                          double* theta, double* c);
+
 /* raw device pointers for zero-copy consumers (e.g. an RCCL gather of trace segments) */
 pdmp_status pdmp_ensemble_trace_dev(pdmp_ensemble* ens, void** events_dev, int64_t* capacity);
 pdmp_status pdmp_ensemble_counters_dev(pdmp_ensemble* ens, void** counters_dev);

@@ -539,7 +539,8 @@ int64_t orc_pdmp_zigzag1d(double mu, double sigma2, double x, double th, double 
 /*
  * dot(a, b) over d elements.  The reference calls BLAS ddot (summation order unspecified); the order is
  * FIXED here to the one a 64-lane wavefront uses: lane l sums elements l, l+64, l+128, ... in order,
- * then lanes are combined by the xor-butterfly 32,16,8,4,2,1.
+ * then lanes are combined by the xor-butterfly 1,2,4,8,16,32 (quads, rows of 16, then the four rows: the order the
+ * gfx950 DPP reduction takes).
  */
 static double dot_wave64(const double* a, const double* b, int64_t d) {
     double part[64];
@@ -548,7 +549,7 @@ static double dot_wave64(const double* a, const double* b, int64_t d) {
         for (int64_t k = l; k < d; k += 64) s += a[k] * b[k];
         part[l] = s;
     }
-    for (int off = 32; off >= 1; off >>= 1) {
+    for (int off = 1; off <= 32; off <<= 1) {
         double nxt[64];
         for (int l = 0; l < 64; ++l) nxt[l] = part[l] + part[l ^ off];
         memcpy(part, nxt, sizeof part);

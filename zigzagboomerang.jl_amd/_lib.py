@@ -32,6 +32,8 @@ EXPORTED_SYMBOLS = [
     "pdmp_ensemble_last_run_ms", "pdmp_ensemble_counters", "pdmp_ensemble_totals", "pdmp_ensemble_trace_copy",
     "pdmp_ensemble_trace_reset", "pdmp_ensemble_final_state", "pdmp_ensemble_batch_means",
     "pdmp_ensemble_trace_dev", "pdmp_ensemble_counters_dev", "pdmp_debug_math_probe",
+    "pdmp_ensemble_set_flow_bps", "pdmp_ensemble_set_state_bps", "pdmp_ensemble_bps_trace_copy",
+    "pdmp_ensemble_bps_final_state",
 ]
 
 
@@ -87,6 +89,10 @@ def load():
     L.pdmp_ensemble_trace_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
     L.pdmp_ensemble_counters_dev.argtypes = [vp, C.POINTER(vp)]
     L.pdmp_debug_math_probe.argtypes = [C.c_int, C.c_uint64, i64, vp]
+    L.pdmp_ensemble_set_flow_bps.argtypes = [vp, vp, vp, vp, vp, f64, f64]
+    L.pdmp_ensemble_set_state_bps.argtypes = [vp, f64, vp, vp, f64, vp]
+    L.pdmp_ensemble_bps_trace_copy.argtypes = [vp, i64, i64, i64, vp, vp, vp]
+    L.pdmp_ensemble_bps_final_state.argtypes = [vp, i64, i64, vp, vp, vp, vp]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(L, name)
         if name not in ("pdmp_last_error", "pdmp_abi_version", "pdmp_device_count", "pdmp_ensemble_destroy"):

@@ -1,0 +1,376 @@
+// pdmp_bps.hip -- Bouncy Particle Sampler ensemble on gfx950: pdmp_inner! (src/not_fact_samplers.jl:52-97) under the
+// driver loop `while t < T` (:136-144), GlobalBound(c), Gaussian target ∇ϕ!(y,x) = Γ(x-μ), mass L = I.
+//
+// One chain per wavefront.  The d-vectors x, θ, ∇ϕ live in REGISTERS (element e = slot*64 + lane, NS slots per lane), so a
+// proposal touches HBM only to emit an event: (t, copy(x), copy(θ)) = 8(2d+1) bytes, written fully coalesced
+// (src/not_fact_samplers.jl:39-41).  That write stream is the roofline of this kernel.
+// Dot products use ONE fixed summation order, the one oracle/pdmp_oracle.c restates (dot_wave64): per-lane partial sums
+// over the slots in order, then the xor-butterfly 1,2,4,8 inside each DPP row and the four row sums ((r0+r1)+(r2+r3)).
+// A general CSC Γ is applied by staging the operand vector in LDS and gathering (idot order, src/common.jl:16-24); a diagonal
+// Γ (config C2: Γ = I) takes a register-only path.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+#include "../../include/pdmp_detmath.h"
+#include "pdmp_engine.hpp"
+
+namespace pdmp {
+
+#define BPS_INF __builtin_inf()
+
+__device__ __forceinline__ double b_readlane(double v, int srclane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ double b_dpp(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// all-lanes sum in the oracle's order: xor 1, 2 (quads), 4, 8 (row of 16), then (r0+r1)+(r2+r3)
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    v = v + b_dpp<0xB1>(v);   // lane ^ 1
+    v = v + b_dpp<0x4E>(v);   // lane ^ 2
+    v = v + b_dpp<0x141>(v);  // other quad of the half row (same value in every lane of a quad: == lane ^ 4)
+    v = v + b_dpp<0x140>(v);  // other half row (== lane ^ 8)
+    const double r0 = b_readlane(v, 0), r1 = b_readlane(v, 16), r2 = b_readlane(v, 32), r3 = b_readlane(v, 48);
+    return (r0 + r1) + (r2 + r3);  // lane ^ 16, then lane ^ 32
+}
+
+__device__ __forceinline__ double bps_pos(double x) {
+    return (x > 0.0) ? x : ((x != x) ? x : 0.0);
+}
+
+// poisson_time(a, b, u), src/poissontime.jl:8-30
+__device__ __forceinline__ double bps_poisson_time(double a, double b, double u) {
+    const double L = pdmp_log(u);
+    if (b > 0) {
+        const double r = a / b;
+        if (a < 0) return sqrt(-L * 2.0 / b) - r;
+        return sqrt(r * r - L * 2.0 / b) - r;
+    } else if (b == 0) {
+        return (a > 0) ? (-L / a) : BPS_INF;
+    } else {
+        if (a <= 0) return BPS_INF;
+        if (-L <= -(a * a) / b + (a * a) / (2 * b)) {
+            const double r = a / b;
+            return -sqrt(r * r - L * 2.0 / b) - r;
+        }
+        return BPS_INF;
+    }
+}
+
+template <int NS, bool DIAG>
+__global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
+    const int lane = threadIdx.x;
+    const int64_t chain = blockIdx.x;
+    const int64_t d = P.d;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* tmp = reinterpret_cast<double*>(smem);  // [d] operand of the CSC gather (general Γ only)
+
+    double* gx = P.x + chain * d;
+    double* gth = P.th + chain * d;
+    double* sc = P.scal + chain * 8;  // {t, a, b, tp, tau_ref, c}
+    DevChain* hdr = P.hdr + chain;
+
+    uint32_t status = hdr->c.status;
+    if (status == PDMP_CHAIN_BOUND_VIOLATED || status == PDMP_CHAIN_STALLED) return;
+    status = PDMP_CHAIN_OK;
+    const uint64_t seed = hdr->seed;
+    uint64_t nm = hdr->c.ndraw_main;
+    uint64_t num = hdr->c.num, nacc = hdr->c.nacc, nrefresh = hdr->c.nrefresh, ntrace = hdr->c.ntrace,
+             nevents = hdr->c.nevents;
+    double t = sc[0], a = sc[1], b = sc[2], tp = sc[3], tau_ref = sc[4], c = sc[5];
+
+    double x[NS], th[NS], g[NS], mu[NS], dg[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int64_t e = (int64_t)s * 64 + lane;
+        const bool in = e < d;
+        x[s] = in ? gx[e] : 0.0;
+        th[s] = in ? gth[e] : 0.0;
+        mu[s] = in ? P.mu[e] : 0.0;
+        dg[s] = (DIAG && in) ? P.nzval[e] : 0.0;
+        g[s] = 0.0;
+    }
+    const double rho = P.rho, rhobar = sqrt(1 - rho * rho);  // src/dynamics.jl:113
+    const double T = P.T;
+    const bool stop_before = (P.flags & PDMP_RUN_STOP_BEFORE) != 0;
+
+    // y = Γ v  with v = in[] (-mu if sub): idot per output element, ascending row order
+    auto apply_gamma = [&](const double (&in)[NS], bool sub_mu, double (&out)[NS]) {
+        if (DIAG) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const double v = sub_mu ? (in[s] - mu[s]) : in[s];
+                out[s] = 0.0 + dg[s] * v;
+            }
+        } else {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int64_t e = (int64_t)s * 64 + lane;
+                if (e < d) tmp[e] = sub_mu ? (in[s] - mu[s]) : in[s];
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int64_t e = (int64_t)s * 64 + lane;
+                double y = 0.0;
+                if (e < d) {
+                    for (int64_t p = P.colptr[e]; p < P.colptr[e + 1]; ++p) y += P.nzval[p] * tmp[P.rowval[p]];
+                }
+                out[s] = y;
+            }
+        }
+    };
+    auto dot = [&](const double (&u)[NS], const double (&v)[NS]) -> double {
+        double part = 0.0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int64_t e = (int64_t)s * 64 + lane;
+            if (e < d) part += u[s] * v[s];
+        }
+        return wave_sum_f64(part);
+    };
+    // ab(x, θ, C::GlobalBound, ...) = (c + θ'(Γ(x-μ)), θ'(Γθ), Inf), src/not_fact_samplers.jl:26-28, and next_time :43-50
+    auto rebound = [&]() {
+        a = c + dot(th, g);
+        double gt[NS];
+        apply_gamma(th, false, gt);
+        b = dot(th, gt);
+        tp = t + bps_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, nm));
+        nm += 1;
+    };
+
+    bool running = stop_before || (t < T);  // `while t < T`, :136
+    while (running) {
+        if (P.trace_cap > 0 && ntrace >= (uint64_t)P.trace_cap) {
+            status = PDMP_CHAIN_TRACE_FULL;
+            break;
+        }
+        const bool is_ref = tau_ref < tp;  // :55
+        const double tnext = is_ref ? tau_ref : tp;
+        if (!(tnext < BPS_INF)) {
+            status = PDMP_CHAIN_STALLED;
+            break;
+        }
+        if (stop_before && !(tnext < T)) break;
+        const double tau = tnext - t;  // :56 / :73
+        t += tau;                      // move_forward!, src/dynamics.jl:11-15
+#pragma unroll
+        for (int s = 0; s < NS; ++s) x[s] += th[s] * tau;
+        bool emit = false;
+        if (is_ref) {
+            // refresh!, src/dynamics.jl:112-118 with L = I: θ .*= ρ; θ .+= ρ̄ randn(rng, d)  (draw nm + e for element e)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int64_t e = (int64_t)s * 64 + lane;
+                th[s] *= rho;
+                if (e < d) th[s] += rhobar * pdmp_randn(seed, PDMP_STREAM_MAIN, nm + (uint64_t)e);
+            }
+            nm += (uint64_t)d;
+            apply_gamma(x, true, g);                                                                       // :58-59
+            tau_ref = t + (-pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm)) / P.lambda_ref);                  // :61
+            nm += 1;
+            rebound();  // :62-63
+            nrefresh += 1;
+            emit = true;  // :64
+        } else {
+            apply_gamma(x, true, g);  // :75-76
+            const double gt = dot(g, th);
+            const double l = bps_pos(gt);            // λ, :14
+            const double lb = bps_pos(a + b * tau);  // :77
+            num += 1;
+            const double coin = pdmp_u01(seed, PDMP_STREAM_MAIN, nm);
+            nm += 1;
+            if (coin * lb <= l) {  // :79
+                nacc += 1;
+                if (l > lb) {  // :81
+                    if (!P.adapt) {
+                        status = PDMP_CHAIN_BOUND_VIOLATED;  // reference: error(...), :82
+                        break;
+                    }
+                    c *= P.factor;  // :83
+                }
+                // reflect!, src/dynamics.jl:90-93 with L = I: θ .-= (2 dot(∇ϕx,θ)/normsq(∇ϕx)) ∇ϕx
+                const double nrm = dot(g, g);
+                const double coef = 2 * gt / nrm;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) th[s] -= coef * g[s];
+                rebound();  // :86-89
+                emit = true;  // :90
+            } else {
+                a = c + gt;  // :92 (θ'g == g'θ bit for bit; b = θ'Γθ is unchanged because θ is)
+                tp = t + bps_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, nm));  // :93
+                nm += 1;
+            }
+        }
+        if (emit) {
+            // push!(Ξ, (t, copy(x), copy(θ), nothing)), :138, :39-41 -- coalesced 8(2d+1)-byte record
+            if (P.trace_cap > 0) {
+                const int64_t slot = chain * P.trace_cap + (int64_t)ntrace;
+                if (lane == 0) P.ev_t[slot] = t;
+                double* ex = P.ev_x + slot * d;
+                double* eth = P.ev_th + slot * d;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const int64_t e = (int64_t)s * 64 + lane;
+                    if (e < d) {
+                        ex[e] = x[s];
+                        eth[e] = th[s];
+                    }
+                }
+            }
+            ntrace += 1;
+            nevents += 1;
+            if (!stop_before && !(t < T)) running = false;
+        }
+    }
+
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int64_t e = (int64_t)s * 64 + lane;
+        if (e < d) {
+            gx[e] = x[s];
+            gth[e] = th[s];
+        }
+    }
+    if (lane == 0) {
+        sc[0] = t;
+        sc[1] = a;
+        sc[2] = b;
+        sc[3] = tp;
+        sc[4] = tau_ref;
+        sc[5] = c;
+        hdr->c.t_last = t;
+        hdr->t_event = t;
+        hdr->c.num = num;
+        hdr->c.nacc = nacc;
+        hdr->c.nrefresh = nrefresh;
+        hdr->c.ntrace = ntrace;
+        hdr->c.nevents = nevents;
+        hdr->c.ndraw_main = nm;
+        hdr->c.status = status;
+    }
+}
+
+// Initial state, src/not_fact_samplers.jl:117-135: τref = randexp(rng)/λref (draw 0), ∇ϕx, abc = ab(...), t′ = next_time (draw 1).
+template <int NS, bool DIAG>
+__global__ __launch_bounds__(64) void bps_init_kernel(BpsRunParams P, const uint64_t* seeds, double t0, double c0) {
+    const int lane = threadIdx.x;
+    const int64_t chain = blockIdx.x;
+    const int64_t d = P.d;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* tmp = reinterpret_cast<double*>(smem);
+    const double* gx = P.x + chain * d;
+    const double* gth = P.th + chain * d;
+    const uint64_t seed = seeds[chain];
+    double x[NS], th[NS], g[NS], gt[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int64_t e = (int64_t)s * 64 + lane;
+        x[s] = (e < d) ? gx[e] : 0.0;
+        th[s] = (e < d) ? gth[e] : 0.0;
+    }
+    auto apply_gamma = [&](const double (&in)[NS], bool sub_mu, double (&out)[NS]) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int64_t e = (int64_t)s * 64 + lane;
+            if (e < d) tmp[e] = sub_mu ? (in[s] - P.mu[e]) : in[s];
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int64_t e = (int64_t)s * 64 + lane;
+            double y = 0.0;
+            if (e < d) {
+                for (int64_t p = P.colptr[e]; p < P.colptr[e + 1]; ++p) y += P.nzval[p] * tmp[P.rowval[p]];
+            }
+            out[s] = y;
+        }
+    };
+    auto dot = [&](const double (&u)[NS], const double (&v)[NS]) -> double {
+        double part = 0.0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int64_t e = (int64_t)s * 64 + lane;
+            if (e < d) part += u[s] * v[s];
+        }
+        return wave_sum_f64(part);
+    };
+    const double tau_ref = -pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, 0)) / P.lambda_ref;  // :121
+    apply_gamma(x, true, g);                                                               // :122-123
+    const double a = c0 + dot(th, g);                                                      // :126
+    apply_gamma(th, false, gt);
+    const double b = dot(th, gt);
+    const double tp = t0 + bps_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, 1));    // :135
+    if (lane == 0) {
+        double* sc = P.scal + chain * 8;
+        sc[0] = t0;
+        sc[1] = a;
+        sc[2] = b;
+        sc[3] = tp;
+        sc[4] = tau_ref;
+        sc[5] = c0;
+        sc[6] = 0.0;
+        sc[7] = 0.0;
+        DevChain h;
+        h.c.t_last = t0;
+        h.c.num = 0;
+        h.c.nacc = 0;
+        h.c.nrefresh = 0;
+        h.c.ntrace = 0;
+        h.c.nevents = 0;
+        h.c.ndraw_main = 2;
+        h.c.ndraw_global = 0;
+        h.c.status = PDMP_CHAIN_OK;
+        h.c.reserved = 0;
+        h.seed = seed;
+        h.t0 = t0;
+        h.t_event = t0;
+        for (int k = 0; k < 4; ++k) h.pad[k] = 0;
+        P.hdr[chain] = h;
+    }
+}
+
+template <int NS>
+static int launch_ns(const BpsRunParams& p, int64_t nchains, bool diag, bool init, const uint64_t* seeds, double t0,
+                     double c0, void* stream) {
+    const size_t lds = (size_t)p.d * 8;
+    dim3 grid((unsigned)nchains), block(64);
+    if (init) {
+        hipLaunchKernelGGL((bps_init_kernel<NS, false>), grid, block, lds, (hipStream_t)stream, p, seeds, t0, c0);
+    } else if (diag) {
+        hipLaunchKernelGGL((bps_run_kernel<NS, true>), grid, block, 0, (hipStream_t)stream, p);
+    } else {
+        hipLaunchKernelGGL((bps_run_kernel<NS, false>), grid, block, lds, (hipStream_t)stream, p);
+    }
+    return (int)hipGetLastError();
+}
+
+static int dispatch(const BpsRunParams& p, int64_t nchains, bool diag, bool init, const uint64_t* seeds, double t0,
+                    double c0, void* stream) {
+    const int64_t ns = (p.d + 63) / 64;
+    if (ns <= 1) return launch_ns<1>(p, nchains, diag, init, seeds, t0, c0, stream);
+    if (ns <= 2) return launch_ns<2>(p, nchains, diag, init, seeds, t0, c0, stream);
+    if (ns <= 4) return launch_ns<4>(p, nchains, diag, init, seeds, t0, c0, stream);
+    if (ns <= 8) return launch_ns<8>(p, nchains, diag, init, seeds, t0, c0, stream);
+    if (ns <= 16) return launch_ns<16>(p, nchains, diag, init, seeds, t0, c0, stream);
+    return -1;
+}
+
+int launch_bps_init(const BpsRunParams& p, int64_t nchains, const uint64_t* seeds, double t0, double c0, void* stream) {
+    return dispatch(p, nchains, false, true, seeds, t0, c0, stream);
+}
+int launch_bps_run(const BpsRunParams& p, int64_t nchains, bool diag, void* stream) {
+    return dispatch(p, nchains, diag, false, nullptr, 0.0, 0.0, stream);
+}
+
+}  // namespace pdmp

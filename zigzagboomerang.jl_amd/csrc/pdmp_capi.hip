@@ -100,6 +100,11 @@ struct pdmp_ensemble {
     DevBuf<double> d_keys, d_c_chain, d_jprev, d_sum;
     DevBuf<pdmp::DevChain> d_hdr;
     DevBuf<pdmp_event> d_ev;
+    // BPS
+    DevBuf<int64_t> b_colptr, b_rowval;
+    DevBuf<double> b_nzval, b_mu, b_x, b_th, b_scal, b_ev_t, b_ev_x, b_ev_th;
+    bool bps_diag = false;
+    double bps_lambda = 0.0, bps_rho = 0.0;
 
     pdmp::ZzTables tables() const {
         pdmp::ZzTables tb{};
@@ -164,8 +169,11 @@ pdmp_status pdmp_ensemble_create(const pdmp_config* cfg, pdmp_ensemble** out) {
         return fail(PDMP_ERR_INVALID, "pdmp_config.struct_size %u != %zu", cfg->struct_size, sizeof(pdmp_config));
     if (cfg->nchains <= 0 || cfg->d <= 0) return fail(PDMP_ERR_INVALID, "nchains and d must be positive");
     if (cfg->d >= (int64_t)1 << 31) return fail(PDMP_ERR_UNSUPPORTED, "d must be < 2^31");
-    if (cfg->sampler != PDMP_SAMPLER_ZIGZAG_LOCAL && cfg->sampler != PDMP_SAMPLER_ZIGZAG_ALL)
-        return fail(PDMP_ERR_UNSUPPORTED, "sampler %d has no device kernel yet (ZIGZAG_LOCAL and ZIGZAG_ALL do)", cfg->sampler);
+    if (cfg->sampler != PDMP_SAMPLER_ZIGZAG_LOCAL && cfg->sampler != PDMP_SAMPLER_ZIGZAG_ALL &&
+        cfg->sampler != PDMP_SAMPLER_BPS)
+        return fail(PDMP_ERR_UNSUPPORTED, "sampler %d has no device kernel yet", cfg->sampler);
+    if (cfg->sampler == PDMP_SAMPLER_BPS && cfg->d > 1024)
+        return fail(PDMP_ERR_UNSUPPORTED, "BPS keeps x, θ, ∇ϕ in registers: d <= 1024 (got %lld)", (long long)cfg->d);
     if (cfg->trace_capacity < 0) return fail(PDMP_ERR_INVALID, "trace_capacity < 0");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -515,6 +523,34 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
     if (flags != PDMP_RUN_REFERENCE_TAIL && flags != PDMP_RUN_STOP_BEFORE) return fail(PDMP_ERR_INVALID, "bad flags");
     HIP_TRY(hipSetDevice(e->cfg.device));
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    if (e->cfg.sampler == PDMP_SAMPLER_BPS) {
+        pdmp::BpsRunParams B{};
+        B.colptr = e->b_colptr.p;
+        B.rowval = e->b_rowval.p;
+        B.nzval = e->b_nzval.p;
+        B.mu = e->b_mu.p;
+        B.x = e->b_x.p;
+        B.th = e->b_th.p;
+        B.scal = e->b_scal.p;
+        B.hdr = e->d_hdr.p;
+        B.ev_t = e->b_ev_t.p;
+        B.ev_x = e->b_ev_x.p;
+        B.ev_th = e->b_ev_th.p;
+        B.d = e->cfg.d;
+        B.trace_cap = e->cfg.trace_capacity;
+        B.T = T;
+        B.factor = e->cfg.factor;
+        B.lambda_ref = e->bps_lambda;
+        B.rho = e->bps_rho;
+        B.flags = flags;
+        B.adapt = e->cfg.adapt;
+        HIP_TRY(hipEventRecord(e->ev0, s));
+        int rcb = pdmp::launch_bps_run(B, e->cfg.nchains, e->bps_diag, s);
+        if (rcb != 0) return fail(PDMP_ERR_HIP, "bps_run launch failed (%d)", rcb);
+        HIP_TRY(hipEventRecord(e->ev1, s));
+        e->timed = true;
+        return PDMP_OK;
+    }
     pdmp::ZzRunParams P{};
     P.tb = e->tables();
     P.rec = e->d_rec.p;
@@ -692,6 +728,122 @@ pdmp_status pdmp_ensemble_batch_means(pdmp_ensemble* e, double T_prev, double T,
     HIP_TRY(hipStreamSynchronize(e->stream));
     if (sum_y) HIP_TRY(hipMemcpy(sum_y, e->d_sum.p, (size_t)d * sizeof(double), hipMemcpyDeviceToHost));
     if (sum_y2) HIP_TRY(hipMemcpy(sum_y2, e->d_sum.p + d, (size_t)d * sizeof(double), hipMemcpyDeviceToHost));
+    return PDMP_OK;
+}
+
+pdmp_status pdmp_ensemble_set_flow_bps(pdmp_ensemble* e, const int64_t* colptr, const int64_t* rowval, const double* nzval,
+                                       const double* mu, double lambda_ref, double rho) {
+    if (!e || !colptr || !rowval || !nzval) return fail(PDMP_ERR_INVALID, "null argument");
+    if (e->cfg.sampler != PDMP_SAMPLER_BPS) return fail(PDMP_ERR_INVALID, "ensemble was not created with PDMP_SAMPLER_BPS");
+    if (!(lambda_ref > 0)) return fail(PDMP_ERR_INVALID, "BouncyParticle needs a strictly positive refreshment rate");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const int64_t d = e->cfg.d;
+    if (colptr[0] != 0) return fail(PDMP_ERR_INVALID, "colptr[0] must be 0 (0-based CSC)");
+    const int64_t nnz = colptr[d];
+    bool diag = (nnz == d);
+    for (int64_t i = 0; i < d; ++i) {
+        if (colptr[i + 1] < colptr[i]) return fail(PDMP_ERR_INVALID, "colptr not monotone");
+        for (int64_t p = colptr[i]; p < colptr[i + 1]; ++p) {
+            if (rowval[p] < 0 || rowval[p] >= d) return fail(PDMP_ERR_INVALID, "row index out of range");
+            if (p > colptr[i] && rowval[p - 1] >= rowval[p]) return fail(PDMP_ERR_INVALID, "rows not ascending");
+        }
+        if (diag && !(colptr[i + 1] - colptr[i] == 1 && rowval[colptr[i]] == i)) diag = false;
+    }
+    e->bps_diag = diag;
+    e->bps_lambda = lambda_ref;
+    e->bps_rho = rho;
+    pdmp_status st;
+    if ((st = e->b_colptr.upload(std::vector<int64_t>(colptr, colptr + d + 1))) != PDMP_OK) return st;
+    if ((st = e->b_rowval.upload(std::vector<int64_t>(rowval, rowval + nnz))) != PDMP_OK) return st;
+    if ((st = e->b_nzval.upload(std::vector<double>(nzval, nzval + nnz))) != PDMP_OK) return st;
+    std::vector<double> muv(d, 0.0);
+    if (mu) muv.assign(mu, mu + d);
+    if ((st = e->b_mu.upload(muv)) != PDMP_OK) return st;
+    e->has_flow = true;
+    e->has_target = true;
+    e->has_state = false;
+    return PDMP_OK;
+}
+
+pdmp_status pdmp_ensemble_set_state_bps(pdmp_ensemble* e, double t0, const double* x0, const double* theta0, double c,
+                                        const uint64_t* seeds) {
+    if (!e || !x0 || !theta0 || !seeds) return fail(PDMP_ERR_INVALID, "null argument");
+    if (e->cfg.sampler != PDMP_SAMPLER_BPS || !e->has_flow) return fail(PDMP_ERR_INVALID, "set_flow_bps first");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const int64_t d = e->cfg.d, n = e->cfg.nchains, cap = e->cfg.trace_capacity;
+    pdmp_status st;
+    if ((st = e->b_x.alloc((size_t)(n * d))) != PDMP_OK) return st;
+    if ((st = e->b_th.alloc((size_t)(n * d))) != PDMP_OK) return st;
+    if ((st = e->b_scal.alloc((size_t)(n * 8))) != PDMP_OK) return st;
+    if ((st = e->d_hdr.alloc((size_t)n)) != PDMP_OK) return st;
+    if (cap > 0) {
+        if ((st = e->b_ev_t.alloc((size_t)(n * cap))) != PDMP_OK) return st;
+        if ((st = e->b_ev_x.alloc((size_t)(n * cap * d))) != PDMP_OK) return st;
+        if ((st = e->b_ev_th.alloc((size_t)(n * cap * d))) != PDMP_OK) return st;
+    }
+    HIP_TRY(hipMemcpy(e->b_x.p, x0, (size_t)(n * d) * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->b_th.p, theta0, (size_t)(n * d) * sizeof(double), hipMemcpyHostToDevice));
+    DevBuf<uint64_t> sseed;
+    if ((st = sseed.alloc((size_t)n)) != PDMP_OK) return st;
+    HIP_TRY(hipMemcpy(sseed.p, seeds, (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice));
+    pdmp::BpsRunParams B{};
+    B.colptr = e->b_colptr.p;
+    B.rowval = e->b_rowval.p;
+    B.nzval = e->b_nzval.p;
+    B.mu = e->b_mu.p;
+    B.x = e->b_x.p;
+    B.th = e->b_th.p;
+    B.scal = e->b_scal.p;
+    B.hdr = e->d_hdr.p;
+    B.d = d;
+    B.lambda_ref = e->bps_lambda;
+    B.rho = e->bps_rho;
+    int rc = pdmp::launch_bps_init(B, n, sseed.p, t0, c, e->stream);
+    if (rc != 0) return fail(PDMP_ERR_HIP, "bps_init launch failed (%d)", rc);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->has_state = true;
+    e->timed = false;
+    return PDMP_OK;
+}
+
+pdmp_status pdmp_ensemble_bps_trace_copy(pdmp_ensemble* e, int64_t chain, int64_t first, int64_t count, double* t, double* x,
+                                         double* theta) {
+    if (!e) return fail(PDMP_ERR_INVALID, "null argument");
+    const int64_t cap = e->cfg.trace_capacity, d = e->cfg.d;
+    if (e->cfg.sampler != PDMP_SAMPLER_BPS || cap <= 0) return fail(PDMP_ERR_INVALID, "no BPS trace buffer");
+    if (chain < 0 || chain >= e->cfg.nchains || first < 0 || count < 0 || first + count > cap)
+        return fail(PDMP_ERR_INVALID, "trace range out of bounds");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (count == 0) return PDMP_OK;
+    const int64_t slot = chain * cap + first;
+    if (t) HIP_TRY(hipMemcpy(t, e->b_ev_t.p + slot, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+    if (x) HIP_TRY(hipMemcpy(x, e->b_ev_x.p + slot * d, (size_t)(count * d) * sizeof(double), hipMemcpyDeviceToHost));
+    if (theta)
+        HIP_TRY(hipMemcpy(theta, e->b_ev_th.p + slot * d, (size_t)(count * d) * sizeof(double), hipMemcpyDeviceToHost));
+    return PDMP_OK;
+}
+
+pdmp_status pdmp_ensemble_bps_final_state(pdmp_ensemble* e, int64_t chain_first, int64_t n, double* t, double* x,
+                                          double* theta, double* c) {
+    if (!e) return fail(PDMP_ERR_INVALID, "null argument");
+    if (e->cfg.sampler != PDMP_SAMPLER_BPS || !e->has_state) return fail(PDMP_ERR_INVALID, "no BPS state");
+    if (chain_first < 0 || n < 0 || chain_first + n > e->cfg.nchains) return fail(PDMP_ERR_INVALID, "chain range");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    const int64_t d = e->cfg.d;
+    if (n == 0) return PDMP_OK;
+    if (x) HIP_TRY(hipMemcpy(x, e->b_x.p + chain_first * d, (size_t)(n * d) * sizeof(double), hipMemcpyDeviceToHost));
+    if (theta)
+        HIP_TRY(hipMemcpy(theta, e->b_th.p + chain_first * d, (size_t)(n * d) * sizeof(double), hipMemcpyDeviceToHost));
+    if (t || c) {
+        std::vector<double> sc((size_t)n * 8);
+        HIP_TRY(hipMemcpy(sc.data(), e->b_scal.p + chain_first * 8, sc.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int64_t k = 0; k < n; ++k) {
+            if (t) t[k] = sc[k * 8 + 0];
+            if (c) c[k] = sc[k * 8 + 5];
+        }
+    }
     return PDMP_OK;
 }
 

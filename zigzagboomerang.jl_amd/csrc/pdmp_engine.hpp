@@ -106,6 +106,27 @@ struct ZzInitParams {
     int32_t has_refresh;
 };
 
+// Bouncy particle sampler (pdmp_bps.hip): per chain x[d], θ[d] (SoA), 8 scalars {t, a, b, t′, τref, c, -, -}
+struct BpsRunParams {
+    const int64_t* __restrict__ colptr;
+    const int64_t* __restrict__ rowval;
+    const double* __restrict__ nzval;
+    const double* __restrict__ mu;
+    double* x;
+    double* th;
+    double* scal;
+    DevChain* hdr;
+    double* ev_t;   // [nchains x cap]
+    double* ev_x;   // [nchains x cap x d]
+    double* ev_th;  // [nchains x cap x d]
+    int64_t d;
+    int64_t trace_cap;
+    double T, factor, lambda_ref, rho;
+    int32_t flags, adapt;
+};
+int launch_bps_init(const BpsRunParams& p, int64_t nchains, const uint64_t* seeds, double t0, double c0, void* stream);
+int launch_bps_run(const BpsRunParams& p, int64_t nchains, bool diag, void* stream);
+
 // launch wrappers implemented in pdmp_kernels.hip (hipStream_t passed as void*)
 int launch_zz_init(const ZzInitParams& p, void* stream);
 int launch_zz_local_run(const ZzRunParams& p, int64_t nchains, void* stream);

@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .flows import GaussianTarget, ZigZag
+from .flows import BouncyParticle, GaussianTarget, ZigZag
 
 
 def _i64(a):
@@ -63,6 +63,41 @@ class Ensemble:
         mu, sg = _f64(F.μ), _f64(F.σ)
         _lib.check(self._L.pdmp_ensemble_set_flow_zigzag(self._h, _ptr(cp), _ptr(rv), _ptr(nz), _ptr(mu), _ptr(sg),
                                                         float(F.λref), float(F.ρ)))
+
+    def set_flow_bps(self, B: BouncyParticle):
+        G = B.Γ
+        if G.shape != (self.d, self.d):
+            raise ValueError("flow Γ has the wrong shape")
+        cp, rv, nz, mu = _i64(G.indptr), _i64(G.indices), _f64(G.data), _f64(B.μ)
+        _lib.check(self._L.pdmp_ensemble_set_flow_bps(self._h, _ptr(cp), _ptr(rv), _ptr(nz), _ptr(mu), float(B.λref),
+                                                     float(B.ρ)))
+
+    def set_state_bps(self, t0, x0, theta0, c, seeds):
+        x0 = _f64(x0).reshape(self.nchains, self.d)
+        theta0 = _f64(theta0).reshape(self.nchains, self.d)
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64).reshape(self.nchains)
+        _lib.check(self._L.pdmp_ensemble_set_state_bps(self._h, float(t0), _ptr(x0), _ptr(theta0), float(c), _ptr(seeds)))
+
+    def bps_trace(self, chain, first=0, count=None, counters=None):
+        if counters is None:
+            counters = self.counters()
+        if count is None:
+            count = int(counters["ntrace"][chain]) - first
+        t = np.empty(count)
+        x = np.empty((count, self.d))
+        th = np.empty((count, self.d))
+        _lib.check(self._L.pdmp_ensemble_bps_trace_copy(self._h, int(chain), int(first), int(count), _ptr(t), _ptr(x), _ptr(th)))
+        return t, x, th
+
+    def bps_final_state(self, chain_first=0, n=None):
+        if n is None:
+            n = self.nchains - chain_first
+        t = np.empty(n)
+        c = np.empty(n)
+        x = np.empty((n, self.d))
+        th = np.empty((n, self.d))
+        _lib.check(self._L.pdmp_ensemble_bps_final_state(self._h, int(chain_first), int(n), _ptr(t), _ptr(x), _ptr(th), _ptr(c)))
+        return dict(t=t, x=x, theta=th, c=c)
 
     def set_target(self, target: GaussianTarget):
         G = target.Γ

@@ -80,3 +80,18 @@ class FactTrace:
 
     def __len__(self):  # Base.length(FT::Trace) = 1 + length(FT.events), src/trace.jl:42
         return 1 + len(self.events)
+
+
+@dataclass
+class PDMPTrace:
+    """PDMPTrace(F, t0, x0, θ0, events) -- src/trace.jl:20-27; events are (t, copy(x), copy(θ)) (src/not_fact_samplers.jl:39-41)."""
+    F: object
+    t0: float
+    x0: np.ndarray
+    θ0: np.ndarray
+    t: np.ndarray = field(default_factory=lambda: np.empty(0))
+    x: np.ndarray = field(default_factory=lambda: np.empty((0, 0)))
+    θ: np.ndarray = field(default_factory=lambda: np.empty((0, 0)))
+
+    def __len__(self):
+        return 1 + len(self.t)

@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _lib
 from .engine import Ensemble
-from .flows import FactTrace, GaussianTarget, ZigZag
+from .flows import BouncyParticle, FactTrace, GaussianTarget, PDMPTrace, ZigZag
 
 DEFAULT_SEED = 0x5EED0000
 
@@ -36,7 +36,13 @@ def spdmp(target, t0, x0, θ0, T, c, F, *, factor=1.8, adapt=False, seed=DEFAULT
 def pdmp(target, t0, x0, θ0, T, c, F, *, factor=1.8, adapt=False, seed=DEFAULT_SEED, device=0,
          trace_capacity=None, trace=True):
     """pdmp(∇ϕ, t0, x0, θ0, T, c, F::ZigZag, args...) = spdmp(..., All(), ...) (src/sfact.jl:236): every proposal moves
-    ALL coordinates (no sparsity assumption on ∇ϕ); same return value as spdmp."""
+    ALL coordinates (no sparsity assumption on ∇ϕ); same return value as spdmp.
+
+    pdmp(∇ϕ!, t0, x0, θ0, T, c, B::BouncyParticle; adapt, factor=2.0) (src/not_fact_samplers.jl:117,395-396) when F is a
+    BouncyParticle: the target is ∇ϕ!(y, x) = B.Γ(x − B.μ) (pass target=None), c is the scalar of GlobalBound(c);
+    returns Ξ::PDMPTrace, (t, x, θ), (acc, num), c."""
+    if isinstance(F, BouncyParticle):
+        return _bps(t0, x0, θ0, T, c, F, 2.0 if factor == 1.8 else factor, adapt, seed, device, trace_capacity, trace)
     return _zigzag(_lib.SAMPLER_ZIGZAG_ALL, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, trace_capacity, trace)
 
 
@@ -86,3 +92,52 @@ def _zigzag(sampler, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, 
     if single:
         return traces[0], (fs["t"][0], fs["x"][0], fs["theta"][0]), (fs["acc"][0], int(num[0])), c_out[0]
     return traces, (fs["t"], fs["x"], fs["theta"]), (fs["acc"], num), c_out
+
+
+def _bps(t0, x0, θ0, T, c, B, factor, adapt, seed, device, trace_capacity, trace):
+    x0 = np.asarray(x0, dtype=np.float64)
+    θ0 = np.asarray(θ0, dtype=np.float64)
+    single = x0.ndim == 1
+    X0, TH0 = np.atleast_2d(x0), np.atleast_2d(θ0)
+    nch, d = X0.shape
+    seeds = (np.uint64(seed) + np.arange(nch, dtype=np.uint64)) if np.isscalar(seed) else np.asarray(seed, np.uint64)
+    if trace_capacity is None:
+        trace_capacity = int(min(max(256, 64 * max(T - t0, 1.0)), (1 << 28) // max(2 * d, 1)))
+    cap = trace_capacity if trace else 0
+    ens = Ensemble(nch, d, sampler=_lib.SAMPLER_BPS, adapt=adapt, factor=factor, device=device, trace_capacity=cap)
+    try:
+        ens.set_flow_bps(B)
+        ens.set_state_bps(t0, X0, TH0, float(c), seeds)
+        ts = [[] for _ in range(nch)]
+        xs = [[] for _ in range(nch)]
+        ths = [[] for _ in range(nch)]
+        while True:
+            ens.run(T, _lib.RUN_REFERENCE_TAIL)
+            cnt = ens.counters()
+            if np.any(cnt["status"] == _lib.CHAIN_BOUND_VIOLATED):
+                raise RuntimeError("Tuning parameter `c` too small.")  # src/not_fact_samplers.jl:82
+            if trace:
+                for k in range(nch):
+                    if cnt["ntrace"][k]:
+                        a, b_, c_ = ens.bps_trace(k, counters=cnt)
+                        ts[k].append(a)
+                        xs[k].append(b_)
+                        ths[k].append(c_)
+                ens.trace_reset()
+            if not np.any(cnt["status"] == _lib.CHAIN_TRACE_FULL):
+                break
+        fs = ens.bps_final_state()
+        cnt = ens.counters()
+    finally:
+        ens.close()
+    traces = []
+    for k in range(nch):
+        if ts[k]:
+            traces.append(PDMPTrace(B, t0, X0[k].copy(), TH0[k].copy(), np.concatenate(ts[k]), np.concatenate(xs[k]),
+                                    np.concatenate(ths[k])))
+        else:
+            traces.append(PDMPTrace(B, t0, X0[k].copy(), TH0[k].copy(), np.empty(0), np.empty((0, d)), np.empty((0, d))))
+    acc, num = cnt["nacc"].astype(np.int64), cnt["num"].astype(np.int64)
+    if single:
+        return traces[0], (fs["t"][0], fs["x"][0], fs["theta"][0]), (int(acc[0]), int(num[0])), fs["c"][0]
+    return traces, (fs["t"], fs["x"], fs["theta"]), (acc, num), fs["c"]
