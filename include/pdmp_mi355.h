@@ -181,6 +181,15 @@ pdmp_status pdmp_ensemble_final_state(pdmp_ensemble* ens, int64_t chain_first, i
  */
 pdmp_status pdmp_ensemble_batch_means(pdmp_ensemble* ens, double T_prev, double T, double* sum_y, double* sum_y2);
 
+/* ------------------------------------------------------------------ sticky ZigZag (PDMP_SAMPLER_STICKY_ZIGZAG)
+ *
+ * sspdmp(∇ϕ, t0, x0, θ0, T, c, F::ZigZag, κ, args...; reversible=false, strong_upperbounds=false, factor=1.5, adapt)
+ * (src/ss_fact.jl:159-160,217).  Call after set_flow_zigzag / set_target_gaussian_csc and before set_state: kappa is the
+ * [d] vector of thaw rates.  Events are FactTrace events (freeze, thaw and reflection alike, :154); the counters' nacc/num
+ * are the reference's scalar (acc, num) (:175,214).  The refresh clock is not implemented by the reference (:86).
+ */
+pdmp_status pdmp_ensemble_set_sticky(pdmp_ensemble* ens, const double* kappa, int reversible, int strong_upperbounds);
+
 /* ------------------------------------------------------------------ Bouncy particle sampler (PDMP_SAMPLER_BPS)
  *
  * pdmp(∇ϕ!, t0, x0, θ0, T, c, B::BouncyParticle; adapt, factor=2.0) -> Ξ::PDMPTrace, (t, x, θ), (acc, num), c

@@ -1,0 +1,75 @@
+"""Sticky ZigZag (sspdmp, src/ss_fact.jl) on gfx950 vs the CPU oracle, through the C ABI (-m gpu)."""
+import math
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def check(pkg, Gb, G, mu_t, x0, th0, c, kappa, T, seed, adapt=False, reversible=False, strong=False, mu_b=None):
+    d = G.shape[0]
+    Z = pkg.ZigZag(Gb, np.zeros(d) if mu_b is None else mu_b)
+    tr, (t, x, th), (acc, num), cout = pkg.sspdmp(pkg.GaussianTarget(G, mu_t), 0.0, x0, th0, T, c, Z, kappa, seed=seed,
+                                                  adapt=adapt, reversible=reversible, strong_upperbounds=strong)
+    for k in range(x0.shape[0]):
+        r = O.sspdmp_zigzag(Gb, mu_b, G, x0[k], th0[k], c, kappa, T, target_mu=mu_t, seed=seed + k, adapt=adapt,
+                            reversible=reversible, strong_upperbounds=strong)
+        assert r["status"] == 0
+        ev, oe = tr[k].events, r["events"]
+        assert len(ev) == len(oe), (k, len(ev), len(oe))
+        for f in ("i", "t", "x", "theta"):
+            assert np.array_equal(ev[f], oe[f]), (k, f)
+        assert (int(acc[k]), int(num[k])) == (r["nacc"], r["num"])
+        assert np.array_equal(t[k], r["t"]) and np.array_equal(x[k], r["x"]) and np.array_equal(th[k], r["theta"])
+        assert np.array_equal(cout[k], r["c"])
+    return tr
+
+
+def test_sticky_1d_reference_parameters_and_statistics(gpu_pkg):
+    """test/sticky.jl:7-36: σ² = 0.5, μ = 0.9, flow Γ = [1], c = 20, κ = 1.5, T = 2000; closed-form weight w (:30)."""
+    pkg = gpu_pkg
+    Gf = sp.csc_matrix(np.array([[1.0]]))
+    Gt = sp.csc_matrix(np.array([[2.0]]))
+    x0, th0 = np.array([[1.0], [1.0]]), np.array([[0.8], [0.8]])
+    T = 2000.0
+    tr = check(pkg, Gf, Gt, np.array([0.9]), x0, th0, np.array([20.0]), np.array([1.5]), T, seed=1)
+    ts, xs = pkg.trace.discretize(tr[0], 0.2)
+    x = xs[:, 0]
+    w = math.sqrt(2 * math.pi * 0.5) / (math.sqrt(2 * math.pi * 0.5) + math.exp(-0.5 * 0.81 / 0.5) / 1.5)
+    assert abs(np.mean(x != 0) - w) < 2.5 / math.sqrt(T)
+    assert abs(np.mean(x) - w * 0.9) < 5.0 / math.sqrt(T)
+
+
+def test_sticky_d8_and_grid(gpu_pkg):
+    pkg = gpu_pkg
+    G = pkg.problems.maintest_precision(8)
+    rng = np.random.default_rng(1)
+    x0 = rng.random((4, 8))
+    th0 = rng.choice([-1.0, -0.5, 0.5, 1.0], (4, 8))
+    c = 0.7 * pkg.problems.column_norms(G)
+    check(pkg, 0.9 * G, G, None, x0, th0, c, np.full(8, 1000.0), 200.0, seed=12, adapt=True)  # test/sticky.jl:39-65
+    check(pkg, 0.9 * G, G, None, x0, th0, c, np.full(8, 0.5), 200.0, seed=13, adapt=True)     # real sticking
+    check(pkg, 0.9 * G, G, None, x0, th0, c, np.full(8, 0.5), 100.0, seed=14, adapt=True, reversible=True)
+    check(pkg, 0.9 * G, G, None, x0, th0, c, np.full(8, 0.5), 100.0, seed=15, adapt=True, strong=True)
+    G2 = pkg.problems.gmrf_precision(12)  # d = 144: three key blocks
+    d = 144
+    x0 = rng.standard_normal((3, d))
+    th0 = rng.choice([-1.0, 1.0], (3, d))
+    check(pkg, G2, G2, None, x0, th0, pkg.problems.column_norms(G2), 0.3 + rng.random(d), 25.0, seed=16)
+    mu = 0.3 * rng.standard_normal(d)
+    check(pkg, G2, G2, mu, x0, th0, pkg.problems.column_norms(G2), np.full(d, 1.0), 15.0, seed=17, mu_b=mu)
+
+
+def test_golden_sticky1d(gpu_pkg, golden):
+    pkg = gpu_pkg
+    Gf = sp.csc_matrix(np.array([[1.0]]))
+    Gt = sp.csc_matrix(np.array([[2.0]]))
+    tr, _, (acc, num), _ = pkg.sspdmp(pkg.GaussianTarget(Gt, np.array([0.9])), 0.0, np.array([1.0]), np.array([0.8]), 200.0,
+                                       np.array([20.0]), pkg.ZigZag(Gf, np.zeros(1)), np.array([1.5]), seed=5)
+    for f in ("t", "i", "x", "theta"):
+        assert np.array_equal(tr.events[f], golden["sticky1d_events"][f])
+    assert [int(num), int(acc)] == golden["sticky1d_counts"].tolist()

@@ -100,6 +100,10 @@ struct pdmp_ensemble {
     DevBuf<double> d_keys, d_c_chain, d_jprev, d_sum;
     DevBuf<pdmp::DevChain> d_hdr;
     DevBuf<pdmp_event> d_ev;
+    // sticky ZigZag
+    DevBuf<double> d_kappa, d_thf;
+    bool has_kappa = false;
+    int reversible = 0, strong_upperbounds = 0;
     // BPS
     DevBuf<int64_t> b_colptr, b_rowval;
     DevBuf<double> b_nzval, b_mu, b_x, b_th, b_scal, b_ev_t, b_ev_x, b_ev_th;
@@ -170,7 +174,7 @@ pdmp_status pdmp_ensemble_create(const pdmp_config* cfg, pdmp_ensemble** out) {
     if (cfg->nchains <= 0 || cfg->d <= 0) return fail(PDMP_ERR_INVALID, "nchains and d must be positive");
     if (cfg->d >= (int64_t)1 << 31) return fail(PDMP_ERR_UNSUPPORTED, "d must be < 2^31");
     if (cfg->sampler != PDMP_SAMPLER_ZIGZAG_LOCAL && cfg->sampler != PDMP_SAMPLER_ZIGZAG_ALL &&
-        cfg->sampler != PDMP_SAMPLER_BPS)
+        cfg->sampler != PDMP_SAMPLER_BPS && cfg->sampler != PDMP_SAMPLER_STICKY_ZIGZAG)
         return fail(PDMP_ERR_UNSUPPORTED, "sampler %d has no device kernel yet", cfg->sampler);
     if (cfg->sampler == PDMP_SAMPLER_BPS && cfg->d > 1024)
         return fail(PDMP_ERR_UNSUPPORTED, "BPS keeps x, θ, ∇ϕ in registers: d <= 1024 (got %lld)", (long long)cfg->d);
@@ -462,6 +466,8 @@ static pdmp_status alloc_state(pdmp_ensemble* e) {
 static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, const double* th0, const double* c,
                               const uint64_t* seeds, uint64_t seed0) {
     if (!e->has_flow || !e->has_target) return fail(PDMP_ERR_INVALID, "flow and target must be set before the state");
+    const bool sticky = e->cfg.sampler == PDMP_SAMPLER_STICKY_ZIGZAG;
+    if (sticky && !e->has_kappa) return fail(PDMP_ERR_INVALID, "pdmp_ensemble_set_sticky must be called before the state");
     if (!c) return fail(PDMP_ERR_INVALID, "c is required");
     HIP_TRY(hipSetDevice(e->cfg.device));
     const int64_t d = e->cfg.d, n = e->cfg.nchains;
@@ -498,6 +504,11 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
     P.t0 = t0;
     P.lambda_ref = e->lambda_ref;
     P.has_refresh = e->lambda_ref > 0;
+    P.sticky = sticky ? 1 : 0;
+    if (sticky) {
+        if (e->d_thf.n != (size_t)(n * d) && (st = e->d_thf.alloc((size_t)(n * d))) != PDMP_OK) return st;
+        P.thf = e->d_thf.p;
+    }
     int rc = pdmp::launch_zz_init(P, e->stream);
     if (rc != 0) return fail(PDMP_ERR_HIP, "zz_init launch failed: %s", hipGetErrorString((hipError_t)rc));
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -587,8 +598,13 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
     P.has_refresh = e->lambda_ref > 0;
     P.move_all = e->cfg.sampler == PDMP_SAMPLER_ZIGZAG_ALL;
     HIP_TRY(hipEventRecord(e->ev0, s));
-    const bool spec_ok = e->use_spec && dbg_cap == 0 && !P.has_refresh && !P.move_all;
-    int rc = spec_ok ? pdmp::launch_zz_local_spec(P, e->cfg.nchains, s)
+    const bool sticky = e->cfg.sampler == PDMP_SAMPLER_STICKY_ZIGZAG;
+    P.kappa = e->d_kappa.p;
+    P.thf = e->d_thf.p;
+    P.reversible = e->reversible;
+    P.strong_upperbounds = e->strong_upperbounds;
+    const bool spec_ok = e->use_spec && dbg_cap == 0 && !P.has_refresh && !P.move_all && !sticky;
+    int rc = sticky ? pdmp::launch_zz_sticky_run(P, e->cfg.nchains, s) : spec_ok ? pdmp::launch_zz_local_spec(P, e->cfg.nchains, s)
                                            : pdmp::launch_zz_local_run(P, e->cfg.nchains, s);
     if (rc != 0) return fail(PDMP_ERR_HIP, "zz_local_run launch failed: %s", hipGetErrorString((hipError_t)rc));
     HIP_TRY(hipEventRecord(e->ev1, s));
@@ -728,6 +744,21 @@ pdmp_status pdmp_ensemble_batch_means(pdmp_ensemble* e, double T_prev, double T,
     HIP_TRY(hipStreamSynchronize(e->stream));
     if (sum_y) HIP_TRY(hipMemcpy(sum_y, e->d_sum.p, (size_t)d * sizeof(double), hipMemcpyDeviceToHost));
     if (sum_y2) HIP_TRY(hipMemcpy(sum_y2, e->d_sum.p + d, (size_t)d * sizeof(double), hipMemcpyDeviceToHost));
+    return PDMP_OK;
+}
+
+pdmp_status pdmp_ensemble_set_sticky(pdmp_ensemble* e, const double* kappa, int reversible, int strong_upperbounds) {
+    if (!e || !kappa) return fail(PDMP_ERR_INVALID, "null argument");
+    if (e->cfg.sampler != PDMP_SAMPLER_STICKY_ZIGZAG) return fail(PDMP_ERR_INVALID, "ensemble is not a sticky ZigZag");
+    if (!e->has_flow) return fail(PDMP_ERR_INVALID, "set_flow_zigzag must be called first");
+    if (e->lambda_ref > 0) return fail(PDMP_ERR_UNSUPPORTED, "refreshment not implemented (src/ss_fact.jl:86)");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    pdmp_status st = e->d_kappa.upload(std::vector<double>(kappa, kappa + e->cfg.d));
+    if (st != PDMP_OK) return st;
+    e->reversible = reversible;
+    e->strong_upperbounds = strong_upperbounds;
+    e->has_kappa = true;
+    e->has_state = false;
     return PDMP_OK;
 }
 

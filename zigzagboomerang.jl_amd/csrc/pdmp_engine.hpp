@@ -86,6 +86,10 @@ struct ZzRunParams {
     int32_t adapt;
     int32_t has_refresh;
     int32_t move_all;  // G = All(): the `pdmp` driver for ZigZag (src/sfact.jl:236)
+    // sticky ZigZag (src/ss_fact.jl)
+    const double* __restrict__ kappa;  // [d] thaw rates
+    double* thf;                       // [nchains x d] saved speeds θf
+    int32_t reversible, strong_upperbounds;
 };
 
 struct ZzInitParams {
@@ -104,6 +108,8 @@ struct ZzInitParams {
     double t0;
     double lambda_ref;
     int32_t has_refresh;
+    int32_t sticky;  // src/ss_fact.jl:178-188: initial key = min(reflection proposal, hitting time of 0), flag f[i]
+    double* thf;
 };
 
 // Bouncy particle sampler (pdmp_bps.hip): per chain x[d], θ[d] (SoA), 8 scalars {t, a, b, t′, τref, c, -, -}
@@ -131,6 +137,7 @@ int launch_bps_run(const BpsRunParams& p, int64_t nchains, bool diag, void* stre
 int launch_zz_init(const ZzInitParams& p, void* stream);
 int launch_zz_local_run(const ZzRunParams& p, int64_t nchains, void* stream);
 int launch_zz_local_spec(const ZzRunParams& p, int64_t nchains, void* stream);
+int launch_zz_sticky_run(const ZzRunParams& p, int64_t nchains, void* stream);
 bool zz_spec_supported(uint32_t nblk, uint32_t mmax, uint32_t kmax);
 size_t zz_spec_lds_bytes(uint32_t nblk_pad, uint32_t blob_w_pad);
 int launch_zz_unpack(const ZzRec* rec, const double* c_src, int64_t c_stride, int64_t d, int64_t chain_first,

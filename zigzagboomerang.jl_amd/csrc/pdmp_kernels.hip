@@ -141,7 +141,19 @@ __global__ __launch_bounds__(256) void zz_init_kernel(ZzInitParams P) {
         if (P.c_chain) P.c_chain[chain * d + i] = ci;
         const double a = ci + (gx - P.tb.gmu_b[i]) * thi;  // src/fact_samplers.jl:51
         const double b = ci / 100 + thi * gt;             // :52
-        const double key = dev_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, (uint64_t)i));  // :186
+        double key = dev_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, (uint64_t)i));  // :186
+        uint64_t fflag = 0;
+        if (P.sticky) {
+            // src/ss_fact.jl:178-188: the first event of i is the earlier of its reflection proposal and its hitting time of 0
+            const double tfreez = (thi * xi >= 0) ? PDMP_INF : (-xi / thi);  // freezing_time, :10-16
+            if (key > tfreez) {
+                fflag = 1;
+                key = P.t0 + tfreez;
+            } else {
+                key = P.t0 + key;
+            }
+            if (P.thf) P.thf[chain * d + i] = 0.0;
+        }
         ZzRec r;
         r.x = xi;
         r.th = thi;
@@ -150,7 +162,7 @@ __global__ __launch_bounds__(256) void zz_init_kernel(ZzInitParams P) {
         r.t_old = P.t0;
         r.a = a;
         r.b = b;
-        r.acc = 0;
+        r.acc = fflag;  // sticky: f[i] ("the next event of i is a freeze"), src/ss_fact.jl:165; otherwise acc[i] = 0
         rec[i] = r;
         keys[i] = key;
     } else if (i < P.dk) {
@@ -716,6 +728,345 @@ __global__ __launch_bounds__(64) void zz_local_run_kernel(ZzRunParams P) {
         hdr->c.ndraw_main = nm;
         hdr->c.ndraw_global = ng;
         hdr->c.nrefresh = nrefresh;
+        hdr->c.status = status;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ sticky ZigZag
+//
+// sspdmp_inner! (src/ss_fact.jl:78-157) under the driver loop `while t′ < T` (:202-211): three kinds of popped key --
+// freeze (f[i]: x_i hits 0, the coordinate sticks, its thaw clock −log(rand())/κ_i is queued), thaw (x_i == 0 && θ_i == 0:
+// the saved speed θf[i] is restored) and reflection proposal (as spdmp_inner!, but frozen coordinates neither move nor get
+// re-bounded).  One event per iteration; the record's `acc` word holds f[i], θf lives in its own per-chain array.
+// Draws (the reference uses the global rng for all of them): draw nm is the thaw time / reversible sign / thinning coin,
+// then one draw per re-bounded (non-frozen) coordinate in ascending order.
+
+size_t zz_sticky_lds_bytes(uint32_t nblk_pad, uint32_t blob_w_pad) {
+    return (size_t)nblk_pad * 8 + 4 * 64 * 8 + (size_t)blob_w_pad * 8 + (size_t)nblk_pad * 4;
+}
+
+__global__ __launch_bounds__(64) void zz_sticky_run_kernel(ZzRunParams P) {
+    const int lane = threadIdx.x;
+    const int64_t chain = blockIdx.x;
+    const int64_t d = P.d;
+    const uint32_t nblk = P.nblk;
+    const uint32_t W = P.blob_w, SW = P.blob_sw, PW = P.blob_pw, KMAX = P.blob_kmax;
+    const uint32_t R = 4 + PW + KMAX;
+
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* bk = reinterpret_cast<double*>(smem);
+    double* sx = bk + P.nblk_pad;
+    double* sth = sx + 64;
+    double* LU = sth + 64;   // logs of the 64 candidate draws nm + lane
+    double* UU = LU + 64;    // the draws themselves
+    uint64_t* lb = reinterpret_cast<uint64_t*>(UU + 64);
+    uint32_t* bi = reinterpret_cast<uint32_t*>(lb + P.blob_w_pad);
+
+    ZzRec* rec = P.rec + chain * d;
+    double* keys = P.keys + chain * P.dk;
+    double* thf = P.thf + chain * d;
+    DevChain* hdr = P.hdr + chain;
+    pdmp_event* ev = P.ev ? P.ev + chain * P.trace_cap : nullptr;
+    double* cmut = P.c_chain ? (P.c_chain + chain * d) : nullptr;
+
+    uint32_t status = hdr->c.status;
+    if (status == PDMP_CHAIN_BOUND_VIOLATED || status == PDMP_CHAIN_STALLED) return;
+    const uint64_t seed = hdr->seed;
+    uint64_t nm = hdr->c.ndraw_main;
+    uint64_t num = hdr->c.num, nacc = hdr->c.nacc, ntrace = hdr->c.ntrace, nevents = hdr->c.nevents;
+    double t_last = hdr->c.t_last;
+    double t_event = hdr->t_event;
+    status = PDMP_CHAIN_OK;
+    const double T = P.T;
+    const bool stop_before = (P.flags & PDMP_RUN_STOP_BEFORE) != 0;
+    const bool adapt = P.adapt != 0;
+
+    for (uint32_t b = lane; b < nblk; b += 64) {
+        const double* kp = keys + (size_t)b * 64;
+        double mk = kp[0];
+        uint32_t mi = 0;
+#pragma unroll 8
+        for (int q = 1; q < 64; ++q) {
+            const double v = kp[q];
+            if (v < mk) {
+                mk = v;
+                mi = q;
+            }
+        }
+        bk[b] = mk;
+        bi[b] = b * 64 + mi;
+    }
+    LDS_ORDER();
+
+    auto queue_update = [&](uint32_t j, double kj) {
+        const uint32_t bj = j >> 6;
+        LDS_ORDER();
+        const double cur = bk[bj];
+        const uint32_t ci = bi[bj];
+        if (kj < cur || (kj == cur && j < ci)) {
+            if (lane == 0) {
+                bk[bj] = kj;
+                bi[bj] = j;
+            }
+        } else if (ci == j) {
+            const double kv = __hip_atomic_load(keys + (size_t)bj * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double mn = wave_min_f64(kv);
+            const uint64_t bl = __ballot(kv == mn);
+            const int arg = bl ? (__ffsll((unsigned long long)bl) - 1) : 0;
+            if (lane == 0) {
+                bk[bj] = mn;
+                bi[bj] = bj * 64 + (uint32_t)arg;
+            }
+        }
+        LDS_ORDER();
+    };
+
+    bool running = stop_before || (t_event < T);
+    while (running) {
+        if (P.trace_cap > 0 && ntrace >= (uint64_t)P.trace_cap) {
+            status = PDMP_CHAIN_TRACE_FULL;
+            break;
+        }
+        // ---------------- peek(Q), src/ss_fact.jl:83
+        double mk = PDMP_INF;
+        uint32_t mb = 0xffffffffu;
+        for (uint32_t b = lane; b < nblk; b += 64) {
+            const double v = bk[b];
+            if (v < mk) {
+                mk = v;
+                mb = b;
+            }
+        }
+        const double tp = wave_min_f64(mk);
+        if (!(tp < PDMP_INF)) {
+            status = PDMP_CHAIN_STALLED;
+            break;
+        }
+        if (stop_before && !(tp < T)) break;
+        const uint64_t ball = __ballot(mk == tp);
+        uint32_t blk;
+        if (__popcll(ball) == 1) {
+            blk = readlane_u32(mb, __ffsll((unsigned long long)ball) - 1);
+        } else {
+            blk = wave_min_u32((mk == tp) ? mb : 0xffffffffu);
+        }
+        const uint32_t i = uniform_u32(bi[blk]);
+        t_last = tp;
+
+        {
+            const uint64_t* bsrc = P.blob + (size_t)i * P.blob_w_pad;
+            for (uint32_t w = lane; w < W; w += 64) lb[w] = bsrc[w];
+        }
+        const ZzRec* ri = rec + i;
+        const double told_i = ri->t_old, a_i = ri->a, b_i = ri->b;
+        const bool f_i = ri->acc != 0;
+        const double x_i0 = ri->x, th_i0 = ri->th;
+        {
+            const double u = pdmp_u01(seed, PDMP_STREAM_MAIN, nm + (uint64_t)lane);
+            UU[lane] = u;
+            LU[lane] = pdmp_log(u);
+        }
+        LDS_ORDER();
+        const uint64_t hw = lb[0];
+        const int k = (int)uniform_u32((uint32_t)(hw & 0xff));
+        const int m = (int)uniform_u32((uint32_t)((hw >> 8) & 0xff));
+        const int self = (int)uniform_u32((uint32_t)((hw >> 16) & 0xff));
+        const int kjmax = (int)uniform_u32((uint32_t)((hw >> 24) & 0xff));
+        uint32_t s = i;
+        if (lane < m) {
+            const uint64_t sw = lb[1 + (lane >> 1)];
+            s = (lane & 1) ? (uint32_t)(sw >> 32) : (uint32_t)sw;
+        }
+        ZzRec* rs = rec + s;
+        double x = 0.0, th = 0.0, t = 0.0, I = 0.0;
+        if (lane < m) {
+            x = rs->x;
+            th = rs->th;
+            t = rs->t;
+            I = rs->I;
+        }
+        const uint32_t sub = 1 + SW + (uint32_t)lane * R;
+        double tv = 0.0, cj = 0.0;
+        if (lane < k) {
+            tv = __longlong_as_double((long long)lb[sub + 0]);
+            cj = cmut ? cmut[s] : __longlong_as_double((long long)lb[sub + 2]);
+        }
+        auto move_lane = [&]() {  // t[i], x[i] = t′, x[i] + θ[i]*(t′ - t[i])
+            const double dt = tp - t;
+            const double xn = x + th * dt;
+            I = I + dt * ((x + xn) * 0.5);
+            x = xn;
+            t = tp;
+        };
+
+        const bool is_freeze = uniform_u32(f_i ? 1u : 0u) != 0;
+        const bool is_thaw = !is_freeze && uniform_u32((x_i0 == 0 && th_i0 == 0) ? 1u : 0u) != 0;
+        uint32_t ndraw0 = 0;     // draws consumed before the per-coordinate re-bound draws
+        bool rebound_set = false;  // lane takes part in the re-bound
+        bool emit = true;
+        bool moved_hi = false;     // lanes k..m were (ss)moved
+        double key_self_extra = PDMP_INF;  // freeze: the thaw clock of i (i itself is not re-bounded)
+        bool violated = false;
+        double told_self = 0.0;
+        bool write_self_bound = false;
+
+        if (is_freeze) {  // ---- case 1, :87-107
+            if (lane == self) move_lane();  // smove_forward!(i, ...), :88
+            const double xs = readlane_f64(x, self);
+            if (fabs(xs) > 1e-8) {  // :89-91 error("x[i] = ... !≈ 0")
+                status = PDMP_CHAIN_BOUND_VIOLATED;
+                break;
+            }
+            if (lane == self) {
+                thf[s] = th;      // θf[i], θ[i] = θ[i], 0.0, :93
+                x = 0.0 * th;     // x[i] = -0*θ[i], :92 (Int -0 == 0: the sign is θ's)
+                th = 0.0;
+            }
+            key_self_extra = tp - LU[0] / P.kappa[i];  // Q[i] = t[i] - log(rand())/κ[i], :96
+            ndraw0 = 1;
+            told_self = tp;
+            write_self_bound = true;
+            if (!P.strong_upperbounds) {  // :97-107
+                if (lane < m && th != 0.0) move_lane();
+                moved_hi = true;
+                rebound_set = (lane < k) && (th != 0.0);
+            }
+        } else if (is_thaw) {  // ---- case 2, :108-123
+            if (lane == self) {
+                t = tp;          // :109
+                th = thf[s];     // θ[i], θf[i] = θf[i], 0.0, :110
+                thf[s] = 0.0;
+                if (P.reversible) th *= (UU[0] < 0.5) ? -1.0 : 1.0;  // :111-113
+            }
+            ndraw0 = P.reversible ? 1u : 0u;
+            if (lane < m && th != 0.0) move_lane();  // :115-116 (i itself: x + θ*0)
+            moved_hi = true;
+            rebound_set = (lane < k) && (th != 0.0);  // :117-123
+        } else {  // ---- reflection proposal, :124-152
+            if (lane < k && th != 0.0) move_lane();  // :125
+            double g = 0.0;
+            for (int p = 0; p < k; ++p) g += readlane_f64(tv, p) * readlane_f64(x, p);
+            if (P.tb.gmu_t) g = g - P.tb.gmu_t[i];
+            const double th_s = readlane_f64(th, self);
+            const double l = pos_part(g * th_s);
+            const double lbound = pos_part(a_i + b_i * (tp - told_i));  // :128
+            num += 1;
+            ndraw0 = 1;
+            if (UU[0] * lbound < l) {  // :130
+                nacc += 1;
+                if (l > lbound) {  // :132
+                    if (!adapt) {
+                        status = PDMP_CHAIN_BOUND_VIOLATED;
+                        if (lane < k) {
+                            rs->x = x;
+                            rs->t = t;
+                            rs->I = I;
+                        }
+                        nm += 1;
+                        break;
+                    }
+                    nacc = 0;  // acc = num = 0, :134
+                    num = 0;
+                    violated = true;
+                }
+                if (lane >= k && lane < m && th != 0.0) move_lane();  // :138
+                moved_hi = true;
+                if (lane == self) th = -th;  // :139
+                rebound_set = (lane < k) && (th != 0.0);
+            } else {  // :147-151
+                rebound_set = (lane == self);
+                emit = false;
+            }
+        }
+        const int nst = moved_hi ? m : k;
+        if (lane < nst) {
+            sx[lane] = x;
+            sth[lane] = th;
+        }
+        LDS_ORDER();
+        // ---------------- ab + queue_time! for the re-bound set, :54-65
+        const uint64_t rball = __ballot(rebound_set);
+        const uint32_t rank = (uint32_t)__popcll(rball & ((1ull << lane) - 1ull));
+        double key = PDMP_INF;
+        if (rebound_set) {
+            const double gmu = __longlong_as_double((long long)lb[sub + 1]);
+            const int kj = (int)(lb[sub + 3] & 0xff);
+            double gx = 0.0, gt = 0.0;
+            for (int base = 0; base < kjmax; base += 8) {
+                const uint64_t pw = lb[sub + 4 + (base >> 3)];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int pp = base + q;
+                    if (pp < kj) {
+                        const double v = __longlong_as_double((long long)lb[sub + 4 + PW + pp]);
+                        const int ps = (int)((pw >> (8 * q)) & 0xff);
+                        gx += v * sx[ps];
+                        gt += v * sth[ps];
+                    }
+                }
+            }
+            if (violated && lane == self) {
+                cj *= P.factor;
+                cmut[s] = cj;
+            }
+            const double a = cj + (gx - gmu) * th;
+            const double b = cj / 100 + th * gt;
+            const double L = LU[ndraw0 + rank];
+            const double trefl = dev_poisson_time_L(a, b, L);
+            const double tfreeze = (th * x >= 0) ? PDMP_INF : (-x / th);  // freezing_time, :10-16
+            const bool fz = tfreeze <= trefl;                              // :57
+            key = t + (fz ? tfreeze : trefl);
+            rs->t_old = t;
+            rs->a = a;
+            rs->b = b;
+            rs->acc = fz ? 1u : 0u;
+            keys[s] = key;
+        }
+        nm += (uint64_t)ndraw0 + (uint64_t)__popcll(rball);
+        if (lane < nst || lane == self) {
+            rs->x = x;
+            rs->th = th;
+            rs->t = t;
+            rs->I = I;
+        }
+        if (write_self_bound && lane == self) {
+            rs->t_old = told_self;  // t_old[i] = t[i], :94
+            rs->acc = 0;            // f[i] = false, :95
+            keys[s] = key_self_extra;
+        }
+        if (is_thaw && lane == self && !rebound_set) rs->t_old = tp;  // :114 (only reachable if θf was 0)
+        // ---------------- level 1 of the queue
+        if (write_self_bound) queue_update(i, key_self_extra);
+        for (int jj = 0; jj < k; ++jj) {
+            if (!((rball >> jj) & 1ull)) continue;
+            queue_update(readlane_u32(s, jj), readlane_f64(key, jj));
+        }
+        if (emit) {  // push!(Ξ, event(i, t, x, θ, F)), :154
+            const double t_s = readlane_f64(t, self), x_s = readlane_f64(x, self), th_s2 = readlane_f64(th, self);
+            if (ev && lane == 0) {
+                pdmp_event e;
+                e.t = t_s;
+                e.i = (int64_t)i;
+                e.x = x_s;
+                e.theta = th_s2;
+                ev[ntrace] = e;
+            }
+            ntrace += 1;
+            nevents += 1;
+            t_event = tp;
+            if (!stop_before && !(tp < T)) running = false;
+        }
+        LDS_ORDER();
+    }
+
+    if (lane == 0) {
+        hdr->c.t_last = t_last;
+        hdr->t_event = t_event;
+        hdr->c.num = num;
+        hdr->c.nacc = nacc;
+        hdr->c.ntrace = ntrace;
+        hdr->c.nevents = nevents;
+        hdr->c.ndraw_main = nm;
         hdr->c.status = status;
     }
 }
@@ -1312,6 +1663,17 @@ int launch_zz_local_spec(const ZzRunParams& p, int64_t nchains, void* stream) {
     } else {
         hipLaunchKernelGGL(zz_local_spec_kernel<8>, grid, block, lds, (hipStream_t)stream, p);
     }
+    return (int)hipGetLastError();
+}
+
+int launch_zz_sticky_run(const ZzRunParams& p, int64_t nchains, void* stream) {
+    const size_t lds = zz_sticky_lds_bytes(p.nblk_pad, p.blob_w_pad);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(zz_sticky_run_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(zz_sticky_run_kernel, dim3((unsigned)nchains), dim3(64), lds, (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }
 

@@ -64,6 +64,10 @@ class Ensemble:
         _lib.check(self._L.pdmp_ensemble_set_flow_zigzag(self._h, _ptr(cp), _ptr(rv), _ptr(nz), _ptr(mu), _ptr(sg),
                                                         float(F.λref), float(F.ρ)))
 
+    def set_sticky(self, kappa, reversible=False, strong_upperbounds=False):
+        kappa = _f64(kappa).reshape(self.d)
+        _lib.check(self._L.pdmp_ensemble_set_sticky(self._h, _ptr(kappa), int(bool(reversible)), int(bool(strong_upperbounds))))
+
     def set_flow_bps(self, B: BouncyParticle):
         G = B.Γ
         if G.shape != (self.d, self.d):

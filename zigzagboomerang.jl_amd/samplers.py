@@ -46,7 +46,15 @@ def pdmp(target, t0, x0, θ0, T, c, F, *, factor=1.8, adapt=False, seed=DEFAULT_
     return _zigzag(_lib.SAMPLER_ZIGZAG_ALL, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, trace_capacity, trace)
 
 
-def _zigzag(sampler, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, trace_capacity, trace):
+def sspdmp(target, t0, x0, θ0, T, c, F, κ, *, reversible=False, strong_upperbounds=False, factor=1.5, adapt=False,
+           seed=DEFAULT_SEED, device=0, trace_capacity=None, trace=True):
+    """Sticky ZigZag: sspdmp(∇ϕ, t0, x0, θ0, T, c, F::ZigZag, κ, args...; reversible, strong_upperbounds, factor=1.5,
+    adapt) (src/ss_fact.jl:159-160,217) -> Ξ, (t, x, θ), (acc, num), c with scalar acc, num (:175,214)."""
+    return _zigzag(_lib.SAMPLER_STICKY_ZIGZAG, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, trace_capacity, trace,
+                   sticky=(np.asarray(κ, dtype=np.float64), reversible, strong_upperbounds))
+
+
+def _zigzag(sampler, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, trace_capacity, trace, sticky=None):
     if not isinstance(F, ZigZag):
         raise TypeError("the device path supports F::ZigZag")
     if not isinstance(target, GaussianTarget):
@@ -68,6 +76,8 @@ def _zigzag(sampler, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, 
     try:
         ens.set_flow(F)
         ens.set_target(target)
+        if sticky is not None:
+            ens.set_sticky(*sticky)
         ens.set_state(t0, X0, TH0, c, seeds)
         events = [[] for _ in range(nch)]
         while True:
@@ -89,9 +99,10 @@ def _zigzag(sampler, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, 
         traces.append(FactTrace(F, t0, X0[k].copy(), TH0[k].copy(), ev))
     num = cnt["num"].astype(np.int64)
     c_out = fs["c"] if adapt else np.broadcast_to(c, (nch, d)).copy()
+    acc = cnt["nacc"].astype(np.int64) if sticky is not None else fs["acc"]  # sticky: scalar acc (src/ss_fact.jl:175)
     if single:
-        return traces[0], (fs["t"][0], fs["x"][0], fs["theta"][0]), (fs["acc"][0], int(num[0])), c_out[0]
-    return traces, (fs["t"], fs["x"], fs["theta"]), (fs["acc"], num), c_out
+        return traces[0], (fs["t"][0], fs["x"][0], fs["theta"][0]), (acc[0], int(num[0])), c_out[0]
+    return traces, (fs["t"], fs["x"], fs["theta"]), (acc, num), c_out
 
 
 def _bps(t0, x0, θ0, T, c, B, factor, adapt, seed, device, trace_capacity, trace):
