@@ -79,11 +79,20 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
+    # test hooks (never set by the driver): run several ranks on ONE device with the gloo backend to exercise the N>1 path
+    backend = os.environ.get("PDMP_BENCH_BACKEND", "nccl")
+    if os.environ.get("PDMP_BENCH_SINGLE_DEVICE"):
+        local_rank = 0
+    red_dev = "cpu"
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+            red_dev = "cuda"
+        else:
+            dist.init_process_group(backend)
 
     pkg = load_package()
     pkg.build.build()
@@ -104,8 +113,9 @@ def main():
         ens.sync()
         if dist is not None:
             dist.barrier()
-            import torch
-            torch.cuda.synchronize()
+            if red_dev == "cuda":
+                import torch
+                torch.cuda.synchronize()
 
     def step(k):
         T = (k + 1) * args.dt
@@ -168,9 +178,9 @@ def main():
     # aggregate over ranks: max time, summed work
     if dist is not None:
         import torch
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        ww = torch.tensor([float(num), float(nacc), float(nev), float(bad)], dtype=torch.float64, device="cuda")
+        ww = torch.tensor([float(num), float(nacc), float(nev), float(bad)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(ww, op=dist.ReduceOp.SUM)
         elapsed = float(tt.item())
         num_all, nacc_all, nev_all, bad_all = [float(v) for v in ww.tolist()]
