@@ -10,6 +10,7 @@
  *   pdmp_philox4x32_10   counter-based RNG (Salmon et al., SC'11), keyed (seed_lo, seed_hi)
  *   pdmp_u01             draw #n of a chain's stream as a double in the OPEN interval (0,1)
  *   pdmp_log             natural log for positive normal doubles, < 1 ulp, only + - * / on doubles
+ *   pdmp_exp             exp, < 1 ulp, only + - * / on doubles (logistic targets)
  *   pdmp_randexp         -log(u)                       (replaces Random.randexp, src/poissontime.jl:77)
  *   pdmp_randn           Box-Muller normal             (replaces Random.randn,   src/dynamics.jl:115)
  *
@@ -148,6 +149,44 @@ PDMP_HD double pdmp_log(double x) {
     double R = t2 + t1;
     double dk = (double)k;
     return ((((s * (hfsq + R)) + (dk * ln2_lo)) - hfsq) + f) + (dk * ln2_hi);
+}
+
+/* ---------------------------------------------------------------- exp */
+/*
+ * exp(x) = 2^k exp(r), k = round(x/ln2), r = x - k ln2 (two-part constant), exp(r) = 1 + r + r c/(2 - c) with the
+ * classic degree-5 polynomial c = r - r^2 (P1 + r^2 (P2 + ...)) (Sun fdlibm).  < 1 ulp; only + - * / on doubles, so the
+ * result is bit-identical on x86-64 and gfx950.  Saturates: x > 709.78 -> +Inf, x < -745.13 -> 0.
+ * Replaces Base.exp inside the logistic targets' sigmoid (scripts/logistic.jl:33).
+ */
+PDMP_HD double pdmp_exp(double x) {
+    const double ln2_hi = 0x1.62e42fee00000p-1;   /* 6.93147180369123816490e-01 */
+    const double ln2_lo = 0x1.a39ef35793c76p-33;  /* 1.90821492927058770002e-10 */
+    const double invln2 = 0x1.71547652b82fep+0;   /* 1.44269504088896338700e+00 */
+    const double P1 = 0x1.555555555553ep-3;       /*  1.66666666666666019037e-01 */
+    const double P2 = -0x1.6c16c16bebd93p-9;      /* -2.77777777770155933842e-03 */
+    const double P3 = 0x1.1566aaf25de2cp-14;      /*  6.61375632143793436117e-05 */
+    const double P4 = -0x1.bbd41c5d26bf1p-20;     /* -1.65339022054652515390e-06 */
+    const double P5 = 0x1.6376972bea4d0p-25;      /*  4.13813679705723846039e-08 */
+    if (x != x) return x;
+    if (x > 709.782712893384) return __builtin_inf();
+    if (x < -745.1332191019411) return 0.0;
+    const double kf = x * invln2 + ((x < 0) ? -0.5 : 0.5);
+    const int32_t k = (int32_t)kf; /* truncation toward zero of (x/ln2 +- 1/2) = round to nearest */
+    const double dk = (double)k;
+    const double hi = x - dk * ln2_hi;
+    const double lo = dk * ln2_lo;
+    const double r = hi - lo;
+    const double z = r * r;
+    const double c = r - z * (P1 + z * (P2 + z * (P3 + z * (P4 + z * P5))));
+    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    /* scale by 2^k in two steps so that subnormal results round once */
+    if (k >= -1021 && k <= 1023) {
+        return y * pdmp_u2f((uint64_t)(1023 + k) << 52);
+    } else if (k > 1023) {
+        return (y * 0x1.0p+1023) * pdmp_u2f((uint64_t)(1023 + (k - 1023)) << 52);
+    } else {
+        return (y * pdmp_u2f((uint64_t)(1023 + (k + 1000)) << 52)) * 0x1.0p-1000;
+    }
 }
 
 PDMP_HD double pdmp_randexp_from_u(double u) {

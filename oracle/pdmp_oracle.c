@@ -342,6 +342,47 @@ static inline double zz_grad(const zz_ctx* cx, int64_t i, const double* x) {
     return g;
 }
 
+/* sigmoid(x) = inv(one(x) + exp(-x)), scripts/logistic.jl:33; sigmoidn, nsigmoid :56-57 */
+static inline double lg_sigmoid(double x) {
+    return 1.0 / (1.0 + pdmp_exp(-x));
+}
+static inline double lg_sigmoidn(double x) {
+    return lg_sigmoid(-x);
+}
+static inline double lg_nsigmoid(double x) {
+    return -lg_sigmoid(x);
+}
+
+/* ∇ϕmoving = γ0*x[i] - fdot_moving(...), scripts/logistic.jl:78-95,107 (idot_moving!: src/common.jl:33-42) */
+static double logistic_grad_moving(const orc_zz_params* p, int64_t j, double* t, double* x, const double* th, double tp,
+                                   uint64_t seed, uint64_t* ng) {
+    const orc_csc* A = p->lg_A;
+    const orc_csc* At = p->lg_At;
+    const double prior = p->lg_gamma0 * x[j];
+    double s = 0.0;
+    const int64_t r0 = A->colptr[j];
+    const int64_t l = A->colptr[j + 1] - r0;
+    const int64_t k = p->lg_k;
+    for (int64_t q = 0; q < k; ++q) {
+        const int64_t ii = r0 + (int64_t)pdmp_randint(seed, PDMP_STREAM_GLOBAL, (*ng)++, (uint32_t)l); /* rand(sampler) */
+        const int64_t row = A->rowval[ii];
+        const double v = A->nzval[ii];
+        double u = 0.0; /* idot_moving!(At, rows[i], t, x, θ, t′, F) */
+        for (int64_t e = At->colptr[row]; e < At->colptr[row + 1]; ++e) {
+            const int64_t cc = At->rowval[e];
+            move1(cc, t, x, th, tp);
+            u += At->nzval[e] * x[cc];
+        }
+        const double w = (double)l / (double)k * v;
+        s += w * p->lg_y[row] * lg_sigmoidn(u);
+        s += w * p->lg_ny[row] * lg_nsigmoid(u);
+        const double u0 = orc_idot(At, row, p->lg_mu);
+        s -= w * p->lg_y[row] * lg_sigmoidn(u0);
+        s -= w * p->lg_ny[row] * lg_nsigmoid(u0);
+    }
+    return prior - s;
+}
+
 int orc_spdmp_zigzag(int64_t d, const orc_zz_params* p, double t0, double T, double* x, double* th,
                      double* c, double* t, int64_t* acc, orc_trace* tr, orc_zz_result* res) {
     zz_ctx cx;
@@ -428,7 +469,8 @@ int orc_spdmp_zigzag(int64_t d, const orc_zz_params* p, double t0, double T, dou
                 trace_push(tr, t[i], i, x[i], th[i]); /* :143 */
                 break;
             }
-            double gi = zz_grad(&cx, i, x);                     /* :118 */
+            double gi = (p->target_kind == 1) ? logistic_grad_moving(p, i, t, x, th, tp, seed, &ng)
+                                              : zz_grad(&cx, i, x); /* :118 */
             double l = pos(gi * th[i]);                         /* :119, src/fact_samplers.jl:28-30 */
             double lb = pos(ba[i] + bb[i] * (t[i] - t_old[i])); /* :119, src/sfact.jl:70 */
             num += 1;                                           /* :120 */

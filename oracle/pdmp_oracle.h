@@ -95,6 +95,18 @@ typedef struct {
     int64_t max_events; /* <=0: unlimited */
     int stop_before_T;  /* 0: reference loop `while t' < T` (last event has t' >= T);
                            1: pause BEFORE popping a key >= T (slice boundary used by the device engine) */
+    /* target_kind 1: subsampled logistic regression with control variate, evaluated with SelfMoving()/ExtendedForm:
+     * ∇ϕmoving(t,x,θ,i,t′,F,A,At,μ,y,ny,k) = γ0*x[i] - fdot_moving(A,At,i,t,x,θ,t′,F,μ,y,ny,k)
+     * (scripts/logistic.jl:78-95,107,167; ∇ϕ_ dispatch src/sfact.jl:67-68).  The k subsample indices come from the
+     * global rng (PDMP_STREAM_GLOBAL), one draw each. */
+    int target_kind;       /* 0: Gaussian (fields above), 1: logistic */
+    const orc_csc* lg_A;   /* n x p design, CSC (column = coordinate) */
+    const orc_csc* lg_At;  /* p x n = A', CSC (column = observation) */
+    const double* lg_y;    /* [n] successes */
+    const double* lg_ny;   /* [n] m - y */
+    const double* lg_mu;   /* [p] control-variate point μ */
+    double lg_gamma0;      /* prior precision γ0 */
+    int64_t lg_k;          /* subsample size */
 } orc_zz_params;
 
 typedef struct {

@@ -44,7 +44,9 @@ class _ZZParams(C.Structure):
                 ("lambda_ref", C.c_double), ("rho", C.c_double),
                 ("target_gamma", C.POINTER(_Csc)), ("target_mu", C.c_void_p),
                 ("move_all", C.c_int), ("adapt", C.c_int), ("factor", C.c_double),
-                ("seed", C.c_uint64), ("max_events", C.c_int64), ("stop_before_T", C.c_int)]
+                ("seed", C.c_uint64), ("max_events", C.c_int64), ("stop_before_T", C.c_int),
+                ("target_kind", C.c_int), ("lg_A", C.POINTER(_Csc)), ("lg_At", C.POINTER(_Csc)), ("lg_y", C.c_void_p),
+                ("lg_ny", C.c_void_p), ("lg_mu", C.c_void_p), ("lg_gamma0", C.c_double), ("lg_k", C.c_int64)]
 
 
 class _ZZResult(C.Structure):
@@ -187,7 +189,7 @@ def idot(A, j, x):
 
 def spdmp_zigzag(bound_gamma, bound_mu, target_gamma, x0, theta0, c, T, *, t0=0.0, target_mu=None,
                  sigma=None, lambda_ref=0.0, rho=0.0, move_all=False, adapt=False, factor=1.8, seed=1,
-                 max_events=0, stop_before_T=False, want_trace=True):
+                 max_events=0, stop_before_T=False, want_trace=True, logistic=None):
     """Local ZigZag (reference spdmp / pdmp for ZigZag).  Returns dict(events, t, x, theta, acc, num, c, ...)."""
     L = lib()
     gb = bound_gamma if isinstance(bound_gamma, CscHolder) else CscHolder(bound_gamma)
@@ -199,6 +201,14 @@ def spdmp_zigzag(bound_gamma, bound_mu, target_gamma, x0, theta0, c, T, *, t0=0.
     p = _ZZParams(C.pointer(gb.c), mu.ctypes.data, sg.ctypes.data, lambda_ref, rho, C.pointer(gt.c),
                   tmu.ctypes.data if tmu is not None else None, int(move_all), int(adapt), factor, seed,
                   max_events, int(stop_before_T))
+    if logistic is not None:  # dict(A, At, y, ny, mu, gamma0, k): target_kind 1
+        lA = logistic["A"] if isinstance(logistic["A"], CscHolder) else CscHolder(logistic["A"])
+        lAt = logistic["At"] if isinstance(logistic["At"], CscHolder) else CscHolder(logistic["At"])
+        ly, lny, lmu = _f64(logistic["y"]), _f64(logistic["ny"]), _f64(logistic["mu"])
+        p.target_kind = 1
+        p.lg_A, p.lg_At = C.pointer(lA.c), C.pointer(lAt.c)
+        p.lg_y, p.lg_ny, p.lg_mu = ly.ctypes.data, lny.ctypes.data, lmu.ctypes.data
+        p.lg_gamma0, p.lg_k = float(logistic["gamma0"]), int(logistic["k"])
     x = _f64(x0).copy()
     th = _f64(theta0).copy()
     cc = _f64(c).copy()

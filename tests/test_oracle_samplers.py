@@ -197,3 +197,21 @@ def test_sticky_d8_no_sticking(pkg):
     S = np.linalg.inv(G.toarray())
     assert np.mean(np.abs(xs.mean(axis=0))) < 2 / math.sqrt(T) * 1.5
     assert np.mean(np.abs(np.cov(xs.T) - S)) < 2.5 / math.sqrt(T)
+
+
+def test_logistic_subsampled_target_statistics(pkg):
+    """Config C4 (scripts/logistic.jl): spdmp with ∇ϕmoving (SelfMoving, k = 10 subsample rows, control variate at the
+    mode μ), Zdrop = ZigZag(Γdrop, μ, σ), c = 0.01, adapt = true, factor = 5.  The posterior is close to its Laplace
+    approximation N(μ, Γ⁻¹): time averages land within a fraction of a posterior sd of μ."""
+    P = pkg.problems.logistic_problem(m=20)
+    assert (P["n"], P["p"]) == (8840, 442)  # README.md:45
+    lg = dict(A=P["A"], At=P["At"], y=P["y"], ny=P["ny"], mu=P["mu"], gamma0=P["gamma0"], k=10)
+    r = O.spdmp_zigzag(P["Gdrop"], P["mu"], P["Gdrop"], P["x0"], P["theta0"], P["c"], 150.0, seed=3, adapt=True, factor=5.0,
+                       logistic=lg, sigma=P["sigma"])
+    assert r["status"] == 0 and r["ndraw_global"] == 10 * r["num"] and r["c"].max() > P["c"].max()
+    tr = pkg.FactTrace(None, 0.0, P["x0"], P["theta0"], r["events"])
+    m, v = pkg.trace.moments(tr, 150.0)
+    sd = np.sqrt(np.diag(np.linalg.inv(P["G"].toarray())))
+    z = (m - P["mu"]) / sd
+    assert np.abs(z).mean() < 0.5 and np.abs(z).max() < 4.0
+    assert 0.5 < np.median(v / sd ** 2) < 1.5

@@ -43,3 +43,77 @@ def maintest_precision(d=8, seed=2):
     G = sp.csc_matrix(S @ S.T)
     G.sort_indices()
     return G
+
+
+def sparse_design(levels=(20, 20), r=2, m=20, rng=None):
+    """Mock design matrix with categorical factors, their pairwise interactions and r continuous regressors --
+    scripts/sparsedesign.jl:2-26 (own RNG, same construction).  Returns CSC [n = m p, p]."""
+    rng = np.random.default_rng(2) if rng is None else rng
+    d = list(levels)
+    K = len(d)
+    p = sum(d) + (sum(d) ** 2 - sum(v * v for v in d)) // 2 + r
+    n = m * p
+    D = np.concatenate([[0], np.cumsum(d)])
+    rows, cols, vals = [], [], []
+    for i in range(n):
+        lev = []
+        on = []
+        for k in range(K):
+            lev.append(int(rng.integers(D[k], D[k + 1])))
+            on.append(rng.random() < (d[k] - 1) / d[k])
+            if on[k]:
+                rows.append(i)
+                cols.append(lev[k])
+                vals.append(1.0)
+        j = int(D[-1])
+        for k in range(K):
+            for k2 in range(k):
+                # CartesianIndices((d[k], d[k2])): first index fastest
+                if on[k] and on[k2]:
+                    c1, c2 = lev[k] - D[k], lev[k2] - D[k2]
+                    rows.append(i)
+                    cols.append(j + c2 * d[k] + c1)
+                    vals.append(0.3)
+                j += d[k] * d[k2]
+        for _ in range(r):
+            rows.append(i)
+            cols.append(j)
+            vals.append(0.1 * rng.standard_normal())
+            j += 1
+        assert j == p
+    A = sp.csc_matrix((vals, (rows, cols)), shape=(n, p))
+    A.sort_indices()
+    return A
+
+
+def logistic_problem(levels=(20, 20), r=2, m=20, gamma0=0.01, seed=2, droptol=1e-2):
+    """Sparse logistic regression set-up of scripts/logistic.jl:21-158 (config C4): design A, data y, Newton mode μ,
+    Hessian Γ at μ, its sparsified version Γdrop (droptol 1e-2), σ = sqrt(diag(inv Γ)), θ0 = ±σ, c = 0.01."""
+    rng = np.random.default_rng(seed)
+    A = sparse_design(levels, r, m, rng)
+    n, p = A.shape
+    xtrue = 5 * rng.standard_normal(p)
+    sig = lambda u: 1.0 / (1.0 + np.exp(-u))  # noqa: E731
+    y = (rng.random(n) < sig(A @ xtrue)).astype(np.float64)
+    ny = 1.0 - y
+    x = 0.1 * rng.random(p)
+    At = sp.csc_matrix(A.T)
+    At.sort_indices()
+    for _ in range(30):  # Newton steps towards the mode, :120-125
+        u = A @ x
+        g = gamma0 * x - A.T @ (y * sig(-u)) + A.T @ (ny * sig(u))
+        w = sig(u) * sig(-u)
+        H = gamma0 * sp.identity(p, format="csc") + (A.T @ sp.diags(w) @ A)
+        x = x - sp.linalg.spsolve(sp.csc_matrix(H), g)
+    mu = x
+    u = A @ mu
+    G = sp.csc_matrix(gamma0 * sp.identity(p, format="csc") + (A.T @ sp.diags(sig(u) * sig(-u)) @ A))
+    G = sp.csc_matrix((G + G.T) * 0.5)
+    Gd = G.copy()
+    Gd.data[np.abs(Gd.data) <= droptol] = 0.0
+    Gd.eliminate_zeros()
+    Gd.sort_indices()
+    sigma = np.sqrt(np.diag(np.linalg.inv(G.toarray())))
+    theta0 = rng.choice([-1.0, 1.0], p) * sigma
+    return dict(A=A, At=At, y=y, ny=ny, mu=mu, gamma0=gamma0, G=G, Gdrop=Gd, sigma=sigma, theta0=theta0, x0=mu.copy(),
+                c=0.01 * np.ones(p), xtrue=xtrue, n=n, p=p)
