@@ -101,7 +101,7 @@ int pdmp_device_count(void);
 
 /*
  * Test hook: evaluate the shared numerical contract (include/pdmp_detmath.h) on the device for draws
- * k = 0..n-1 of `seed`; out is [6 x n] row-major: u01, pdmp_log(u), a/b, sqrt, poisson_time, pdmp_randn.
+ * k = 0..n-1 of `seed`; out is [7 x n] row-major: u01, pdmp_log(u), a/b, sqrt, poisson_time, pdmp_randn, pdmp_exp.
  * A host evaluation of the same expressions must agree bit-for-bit (tests/test_gpu_detmath.py).
  */
 pdmp_status pdmp_debug_math_probe(int device, uint64_t seed, int64_t n, double* out);
@@ -127,6 +127,18 @@ pdmp_status pdmp_ensemble_set_flow_zigzag(pdmp_ensemble* ens, const int64_t* col
 pdmp_status pdmp_ensemble_set_target_gaussian_csc(pdmp_ensemble* ens, const int64_t* colptr,
                                                   const int64_t* rowval, const double* nzval,
                                                   const double* mu);
+
+/*
+ * Target of config C4: subsampled logistic regression with a control variate at μ, evaluated with SelfMoving():
+ *   ∇ϕmoving(t,x,θ,i,t′,F,A,At,μ,y,ny,k) = γ0*x[i] − fdot_moving(A,At,i,t,x,θ,t′,F,μ,y,ny,k)   (scripts/logistic.jl:78-95,107,167)
+ * A is the n x p design in CSC (column = coordinate), At = A' in CSC (column = observation), y / ny the per-observation
+ * success / failure counts, k_sub the subsample size; the k_sub row indices of every proposal are draws of the chain's
+ * PDMP_STREAM_GLOBAL stream (the reference takes them from Julia's global rng).  Must follow set_flow_zigzag.
+ */
+pdmp_status pdmp_ensemble_set_target_logistic(pdmp_ensemble* ens, int64_t n, const int64_t* A_colptr,
+                                              const int64_t* A_rowval, const double* A_nzval, const int64_t* At_colptr,
+                                              const int64_t* At_rowval, const double* At_nzval, const double* y,
+                                              const double* ny, const double* mu, double gamma0, int64_t k_sub);
 
 /*
  * Initial state (src/sfact.jl:164-190): x0, theta0 are [nchains x d] row-major; c is [d] (copied; with

@@ -971,7 +971,7 @@ double orc_spdmp_zigzag_ensemble(int64_t d, const orc_zz_params* p, double t0, d
 
 /* ------------------------------------------------------------------ host side of the device math probe */
 /* Same expressions as math_probe_kernel (zigzagboomerang.jl_amd/csrc/pdmp_kernels.hip), evaluated with the
- * oracle's own poisson_time and libm sqrt: out is [6 x n] row-major. */
+ * oracle's own poisson_time and libm sqrt: out is [7 x n] row-major. */
 void orc_math_probe(uint64_t seed, int64_t n, double* out) {
     for (int64_t k = 0; k < n; ++k) {
         const double u = pdmp_u01(seed, 0u, (uint64_t)k);
@@ -985,6 +985,7 @@ void orc_math_probe(uint64_t seed, int64_t n, double* out) {
         out[3 * n + k] = sqrt(u * 1000.0 + v);
         out[4 * n + k] = orc_poisson_time(a, b, w);
         out[5 * n + k] = pdmp_randn(seed, 3u, (uint64_t)k);
+        out[6 * n + k] = pdmp_exp((u - 0.5) * 60.0 + v);
     }
 }
 double orc_log(double x) { return pdmp_log(x); }

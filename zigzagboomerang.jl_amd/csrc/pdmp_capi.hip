@@ -100,6 +100,15 @@ struct pdmp_ensemble {
     DevBuf<double> d_keys, d_c_chain, d_jprev, d_sum;
     DevBuf<pdmp::DevChain> d_hdr;
     DevBuf<pdmp_event> d_ev;
+    // general-degree kernel + logistic target
+    bool needs_general = false;
+    uint32_t mmax_all = 0;
+    int target_kind = 0;
+    DevBuf<uint16_t> d_pos16, d_selfpos16;
+    DevBuf<int64_t> lg_Acp, lg_Arv, lg_Atcp, lg_Atrv;
+    DevBuf<double> lg_Anz, lg_Atnz, lg_y, lg_ny, lg_u0;
+    double lg_gamma0 = 0.0;
+    int64_t lg_k = 0;
     // sticky ZigZag
     DevBuf<double> d_kappa, d_thf;
     bool has_kappa = false;
@@ -157,12 +166,12 @@ pdmp_status pdmp_debug_math_probe(int device, uint64_t seed, int64_t n, double* 
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(PDMP_ERR_NO_DEVICE, "no HIP device visible");
     HIP_TRY(hipSetDevice(device));
     DevBuf<double> buf;
-    pdmp_status st = buf.alloc((size_t)(6 * n));
+    pdmp_status st = buf.alloc((size_t)(7 * n));
     if (st != PDMP_OK) return st;
     int rc = pdmp::launch_math_probe(seed, n, buf.p, nullptr);
     if (rc != 0) return fail(PDMP_ERR_HIP, "math probe launch failed: %s", hipGetErrorString((hipError_t)rc));
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, buf.p, (size_t)(6 * n) * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, buf.p, (size_t)(7 * n) * sizeof(double), hipMemcpyDeviceToHost));
     return PDMP_OK;
 }
 
@@ -229,9 +238,12 @@ pdmp_status pdmp_ensemble_set_flow_zigzag(pdmp_ensemble* e, const int64_t* colpt
         e->colptr[i] = (uint32_t)colptr[i];
     }
     std::vector<uint8_t> selfpos(d, 0);
+    std::vector<uint16_t> selfpos16(d, 0);
+    bool general = false;
+    uint32_t mmax_all = 0;
     for (int64_t i = 0; i < d; ++i) {
         const int64_t k = colptr[i + 1] - colptr[i];
-        if (k > 64) return fail(PDMP_ERR_UNSUPPORTED, "column %lld has %lld > 64 non-zeros", (long long)i, (long long)k);
+        if (k > 4096) return fail(PDMP_ERR_UNSUPPORTED, "column %lld has %lld > 4096 non-zeros", (long long)i, (long long)k);
         bool has_diag = false;
         for (int64_t p = colptr[i]; p < colptr[i + 1]; ++p) {
             const int64_t r = rowval[p];
@@ -241,6 +253,7 @@ pdmp_status pdmp_ensemble_set_flow_zigzag(pdmp_ensemble* e, const int64_t* colpt
             if (r == i) {
                 has_diag = true;
                 selfpos[i] = (uint8_t)(p - colptr[i]);
+                selfpos16[i] = (uint16_t)(p - colptr[i]);
             }
             e->rowval[p] = (uint32_t)r;
         }
@@ -270,6 +283,8 @@ pdmp_status pdmp_ensemble_set_flow_zigzag(pdmp_ensemble* e, const int64_t* colpt
     std::vector<uint32_t> qptr(nnz + 1, 0);
     std::vector<uint8_t> pos;
     pos.reserve((size_t)nnz * 5);
+    std::vector<uint16_t> pos16;
+    pos16.reserve((size_t)nnz * 5);
     std::vector<uint32_t> tmp;
     for (int64_t i = 0; i < d; ++i) {
         const uint32_t c0 = e->colptr[i], c1 = e->colptr[i + 1];
@@ -286,9 +301,11 @@ pdmp_status pdmp_ensemble_set_flow_zigzag(pdmp_ensemble* e, const int64_t* colpt
             if (!std::binary_search(e->rowval.begin() + c0, e->rowval.begin() + c1, v)) sidx.push_back(v);
         }
         const size_t m = sidx.size() - s0;
-        if (m > 64)
-            return fail(PDMP_ERR_UNSUPPORTED, "two-hop neighbourhood of coordinate %lld has %zu > 64 members",
+        if (m > 4096)
+            return fail(PDMP_ERR_UNSUPPORTED, "two-hop neighbourhood of coordinate %lld has %zu > 4096 members",
                         (long long)i, m);
+        if (m > 64 || (c1 - c0) > 64) general = true;  // beyond one lane per member: pdmp_general.hip
+        mmax_all = std::max<uint32_t>(mmax_all, (uint32_t)m);
         sptr[i + 1] = (uint32_t)sidx.size();
         // positions inside S[i] of the members of G1[j], j = G1[i][jj]
         for (uint32_t p = c0; p < c1; ++p) {
@@ -308,11 +325,15 @@ pdmp_status pdmp_ensemble_set_flow_zigzag(pdmp_ensemble* e, const int64_t* colpt
                                 "pattern of Γ is not symmetric: row %u of column %u is not reachable from %lld", r, j,
                                 (long long)i);
                 pos.push_back((uint8_t)where);
+                pos16.push_back((uint16_t)where);
             }
         }
     }
     qptr[nnz] = (uint32_t)pos.size();
     if (pos.empty()) pos.push_back(0);
+    if (pos16.empty()) pos16.push_back(0);
+    e->needs_general = general;
+    e->mmax_all = mmax_all;
 
     e->h_gmu_b = gmu;
     e->h_sptr = sptr;
@@ -332,6 +353,9 @@ pdmp_status pdmp_ensemble_set_flow_zigzag(pdmp_ensemble* e, const int64_t* colpt
     if ((st = e->d_pos.upload(pos)) != PDMP_OK) return st;
     if ((st = e->d_selfpos.upload(selfpos)) != PDMP_OK) return st;
     if ((st = e->d_sigma.upload(e->sigma)) != PDMP_OK) return st;
+    if ((st = e->d_pos16.upload(pos16)) != PDMP_OK) return st;
+    if ((st = e->d_selfpos16.upload(selfpos16)) != PDMP_OK) return st;
+    e->target_kind = 0;
 
     const int64_t nkeys = d + 1;  // slot d is the refresh clock (+Inf when λref = 0)
     e->nblk = (uint32_t)((nkeys + 63) / 64);
@@ -371,6 +395,7 @@ pdmp_status pdmp_ensemble_set_target_gaussian_csc(pdmp_ensemble* e, const int64_
         gmu_t[i] = s;
     }
     e->has_tmu = (mu != nullptr);
+    e->target_kind = 0;
     e->h_tval = tval;
     pdmp_status st;
     if ((st = e->d_tval.upload(tval)) != PDMP_OK) return st;
@@ -448,6 +473,57 @@ static pdmp_status build_blob(pdmp_ensemble* e, const double* c) {
     return e->d_blob.upload(blob);
 }
 
+} // extern "C" (reopened below)
+
+extern "C" pdmp_status pdmp_ensemble_set_target_logistic(pdmp_ensemble* e, int64_t n, const int64_t* A_colptr,
+                                                         const int64_t* A_rowval, const double* A_nzval,
+                                                         const int64_t* At_colptr, const int64_t* At_rowval,
+                                                         const double* At_nzval, const double* y, const double* ny,
+                                                         const double* mu, double gamma0, int64_t k_sub) {
+    if (!e || !A_colptr || !A_rowval || !A_nzval || !At_colptr || !At_rowval || !At_nzval || !y || !ny || !mu)
+        return fail(PDMP_ERR_INVALID, "null argument");
+    if (!e->has_flow) return fail(PDMP_ERR_INVALID, "set_flow_zigzag must be called first");
+    if (n <= 0 || k_sub <= 0) return fail(PDMP_ERR_INVALID, "n and k_sub must be positive");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const int64_t p = e->cfg.d;
+    const int64_t nnzA = A_colptr[p], nnzAt = At_colptr[n];
+    if (A_colptr[0] != 0 || At_colptr[0] != 0 || nnzA != nnzAt) return fail(PDMP_ERR_INVALID, "A / At are inconsistent");
+    for (int64_t j = 0; j < p; ++j)
+        if (A_colptr[j + 1] <= A_colptr[j])
+            return fail(PDMP_ERR_UNSUPPORTED, "coordinate %lld has no observation (rand over an empty range)", (long long)j);
+    std::vector<double> u0((size_t)n, 0.0);  // idot(At, row, μ), src/common.jl:16-24 order
+    for (int64_t r = 0; r < n; ++r) {
+        double s = 0.0;
+        for (int64_t q = At_colptr[r]; q < At_colptr[r + 1]; ++q) {
+            if (At_rowval[q] < 0 || At_rowval[q] >= p) return fail(PDMP_ERR_INVALID, "At row index out of range");
+            s += At_nzval[q] * mu[At_rowval[q]];
+        }
+        u0[r] = s;
+    }
+    pdmp_status st;
+    if ((st = e->lg_Acp.upload(std::vector<int64_t>(A_colptr, A_colptr + p + 1))) != PDMP_OK) return st;
+    if ((st = e->lg_Arv.upload(std::vector<int64_t>(A_rowval, A_rowval + nnzA))) != PDMP_OK) return st;
+    if ((st = e->lg_Anz.upload(std::vector<double>(A_nzval, A_nzval + nnzA))) != PDMP_OK) return st;
+    if ((st = e->lg_Atcp.upload(std::vector<int64_t>(At_colptr, At_colptr + n + 1))) != PDMP_OK) return st;
+    if ((st = e->lg_Atrv.upload(std::vector<int64_t>(At_rowval, At_rowval + nnzAt))) != PDMP_OK) return st;
+    if ((st = e->lg_Atnz.upload(std::vector<double>(At_nzval, At_nzval + nnzAt))) != PDMP_OK) return st;
+    if ((st = e->lg_y.upload(std::vector<double>(y, y + n))) != PDMP_OK) return st;
+    if ((st = e->lg_ny.upload(std::vector<double>(ny, ny + n))) != PDMP_OK) return st;
+    if ((st = e->lg_u0.upload(u0)) != PDMP_OK) return st;
+    // the kernels' table struct wants tval / gmu_t allocated even if unused
+    if ((st = e->d_tval.upload(std::vector<double>((size_t)e->nnz, 0.0))) != PDMP_OK) return st;
+    if ((st = e->d_gmu_t.upload(std::vector<double>((size_t)p, 0.0))) != PDMP_OK) return st;
+    e->has_tmu = false;
+    e->lg_gamma0 = gamma0;
+    e->lg_k = k_sub;
+    e->target_kind = 1;
+    e->has_target = true;
+    e->has_state = false;
+    return PDMP_OK;
+}
+
+extern "C" {
+
 static pdmp_status alloc_state(pdmp_ensemble* e) {
     const int64_t d = e->cfg.d, n = e->cfg.nchains;
     pdmp_status st;
@@ -475,7 +551,16 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
     if (st != PDMP_OK) return st;
     std::vector<double> cv(c, c + d);
     if ((st = e->d_c.upload(cv)) != PDMP_OK) return st;
-    if ((st = build_blob(e, c)) != PDMP_OK) return st;
+    if (e->needs_general || e->target_kind == 1) {
+        if (e->cfg.sampler != PDMP_SAMPLER_ZIGZAG_LOCAL || e->lambda_ref > 0)
+            return fail(PDMP_ERR_UNSUPPORTED,
+                        "neighbourhoods beyond 64 members / the logistic target run on the general kernel: spdmp without refresh only");
+        if (pdmp::zz_general_lds_bytes(e->nblk_pad, (e->mmax_all + 63u) & ~63u) > 160 * 1024)
+            return fail(PDMP_ERR_UNSUPPORTED, "LDS budget exceeded by the general kernel");
+        e->use_spec = false;
+    } else if ((st = build_blob(e, c)) != PDMP_OK) {
+        return st;
+    }
     DevBuf<double> sx, sth;
     DevBuf<uint64_t> sseed;
     if (x0) {
@@ -604,6 +689,29 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
     P.reversible = e->reversible;
     P.strong_upperbounds = e->strong_upperbounds;
     const bool spec_ok = e->use_spec && dbg_cap == 0 && !P.has_refresh && !P.move_all && !sticky;
+    if (e->needs_general || e->target_kind == 1) {
+        pdmp::ZzGeneralParams Q{};
+        Q.pos16 = e->d_pos16.p;
+        Q.selfpos16 = e->d_selfpos16.p;
+        Q.mmax_pad = (e->mmax_all + 63u) & ~63u;
+        Q.target_kind = e->target_kind;
+        Q.A_colptr = e->lg_Acp.p;
+        Q.A_rowval = e->lg_Arv.p;
+        Q.A_nzval = e->lg_Anz.p;
+        Q.At_colptr = e->lg_Atcp.p;
+        Q.At_rowval = e->lg_Atrv.p;
+        Q.At_nzval = e->lg_Atnz.p;
+        Q.y = e->lg_y.p;
+        Q.ny = e->lg_ny.p;
+        Q.u0 = e->lg_u0.p;
+        Q.gamma0 = e->lg_gamma0;
+        Q.ksub = e->lg_k;
+        int rcg = pdmp::launch_zz_general_run(P, Q, e->cfg.nchains, s);
+        if (rcg != 0) return fail(PDMP_ERR_HIP, "zz_general_run launch failed: %s", hipGetErrorString((hipError_t)rcg));
+        HIP_TRY(hipEventRecord(e->ev1, s));
+        e->timed = true;
+        return PDMP_OK;
+    }
     int rc = sticky ? pdmp::launch_zz_sticky_run(P, e->cfg.nchains, s) : spec_ok ? pdmp::launch_zz_local_spec(P, e->cfg.nchains, s)
                                            : pdmp::launch_zz_local_run(P, e->cfg.nchains, s);
     if (rc != 0) return fail(PDMP_ERR_HIP, "zz_local_run launch failed: %s", hipGetErrorString((hipError_t)rc));

@@ -112,6 +112,27 @@ struct ZzInitParams {
     double* thf;
 };
 
+// General-degree local ZigZag (pdmp_general.hip): CSC tables instead of the blob, optional logistic target
+struct ZzGeneralParams {
+    const uint16_t* __restrict__ pos16;      // like ZzTables::pos, 16-bit positions inside S[i]
+    const uint16_t* __restrict__ selfpos16;  // position of i inside G1[i]
+    uint32_t mmax_pad;                       // LDS scratch slots (max |S[i]|, padded)
+    int32_t target_kind;                     // 0 Gaussian CSC, 1 subsampled logistic (scripts/logistic.jl:107)
+    const int64_t* __restrict__ A_colptr;    // design A (n x p), CSC by coordinate
+    const int64_t* __restrict__ A_rowval;
+    const double* __restrict__ A_nzval;
+    const int64_t* __restrict__ At_colptr;   // A' (p x n), CSC by observation
+    const int64_t* __restrict__ At_rowval;
+    const double* __restrict__ At_nzval;
+    const double* __restrict__ y;
+    const double* __restrict__ ny;
+    const double* __restrict__ u0;           // idot(At, row, μ) per observation (control variate)
+    double gamma0;
+    int64_t ksub;
+};
+int launch_zz_general_run(const ZzRunParams& p, const ZzGeneralParams& q, int64_t nchains, void* stream);
+size_t zz_general_lds_bytes(uint32_t nblk_pad, uint32_t mmax_pad);
+
 // Bouncy particle sampler (pdmp_bps.hip): per chain x[d], θ[d] (SoA), 8 scalars {t, a, b, t′, τref, c, -, -}
 struct BpsRunParams {
     const int64_t* __restrict__ colptr;

@@ -1,0 +1,365 @@
+// pdmp_general.hip -- local ZigZag event loop for neighbourhoods of ANY size (|G1[i]|, |S[i]| up to 4096) and for the
+// subsampled logistic target of config C4 (scripts/logistic.jl:78-95,107: ∇ϕmoving with SelfMoving()).
+//
+// Same chain semantics as zz_local_run_kernel (spdmp_inner!, src/sfact.jl:73-145; one chain per wavefront, two-level
+// 64-ary queue), but the neighbourhood is walked in chunks of 64 lanes and the read-only tables are the flow's CSC arrays
+// (no per-coordinate blob: its size grows with the square of the column count).  Moved coordinates are written back at
+// once and the (x, θ) of S[i] are staged in LDS by position.  This is the correctness path for dense-ish graphs such as
+// the droptol-Hessian of the logistic regression (one column has 167 entries, two-hop sets reach 293); the grid-Laplace
+// north star never comes here.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+#include "../../include/pdmp_detmath.h"
+#include "pdmp_engine.hpp"
+
+namespace pdmp {
+
+#define G_INF __builtin_inf()
+#define G_ORDER()                        \
+    do {                                 \
+        __builtin_amdgcn_wave_barrier(); \
+        asm volatile("" ::: "memory");   \
+    } while (0)
+
+__device__ __forceinline__ double g_readlane(double v, int srclane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ uint32_t g_uniform(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+template <int CTRL>
+__device__ __forceinline__ double g_dpp(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double g_wave_min(double v) {
+    v = __builtin_fmin(v, g_dpp<0xB1>(v));
+    v = __builtin_fmin(v, g_dpp<0x4E>(v));
+    v = __builtin_fmin(v, g_dpp<0x141>(v));
+    v = __builtin_fmin(v, g_dpp<0x140>(v));
+    const double r0 = g_readlane(v, 0), r1 = g_readlane(v, 16), r2 = g_readlane(v, 32), r3 = g_readlane(v, 48);
+    return __builtin_fmin(__builtin_fmin(r0, r1), __builtin_fmin(r2, r3));
+}
+__device__ __forceinline__ double g_pos(double x) {
+    return (x > 0.0) ? x : ((x != x) ? x : 0.0);
+}
+// poisson_time(a, b, u), src/poissontime.jl:8-30
+__device__ __forceinline__ double g_poisson_time(double a, double b, double u) {
+    const double L = pdmp_log(u);
+    if (b > 0) {
+        const double r = a / b;
+        if (a < 0) return sqrt(-L * 2.0 / b) - r;
+        return sqrt(r * r - L * 2.0 / b) - r;
+    } else if (b == 0) {
+        return (a > 0) ? (-L / a) : G_INF;
+    } else {
+        if (a <= 0) return G_INF;
+        if (-L <= -(a * a) / b + (a * a) / (2 * b)) {
+            const double r = a / b;
+            return -sqrt(r * r - L * 2.0 / b) - r;
+        }
+        return G_INF;
+    }
+}
+// sigmoid(x) = inv(one(x) + exp(-x)), scripts/logistic.jl:33
+__device__ __forceinline__ double g_sigmoid(double x) {
+    return 1.0 / (1.0 + pdmp_exp(-x));
+}
+
+size_t zz_general_lds_bytes(uint32_t nblk_pad, uint32_t mmax_pad) {
+    return (size_t)nblk_pad * 8 + (size_t)2 * mmax_pad * 8 + (size_t)nblk_pad * 4;
+}
+
+__global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGeneralParams Q) {
+    const int lane = threadIdx.x;
+    const int64_t chain = blockIdx.x;
+    const int64_t d = P.d;
+    const uint32_t nblk = P.nblk;
+
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* bk = reinterpret_cast<double*>(smem);
+    double* sx = bk + P.nblk_pad;       // [mmax_pad] x of S[i] by position
+    double* sth = sx + Q.mmax_pad;      // [mmax_pad] θ of S[i]
+    uint32_t* bi = reinterpret_cast<uint32_t*>(sth + Q.mmax_pad);
+
+    ZzRec* rec = P.rec + chain * d;
+    double* keys = P.keys + chain * P.dk;
+    DevChain* hdr = P.hdr + chain;
+    pdmp_event* ev = P.ev ? P.ev + chain * P.trace_cap : nullptr;
+    double* cmut = P.c_chain ? (P.c_chain + chain * d) : nullptr;
+    const double* cvec = cmut ? cmut : P.tb.c_shared;
+
+    uint32_t status = hdr->c.status;
+    if (status == PDMP_CHAIN_BOUND_VIOLATED || status == PDMP_CHAIN_STALLED) return;
+    const uint64_t seed = hdr->seed;
+    uint64_t nm = hdr->c.ndraw_main, ng = hdr->c.ndraw_global;
+    uint64_t num = hdr->c.num, nacc = hdr->c.nacc, ntrace = hdr->c.ntrace, nevents = hdr->c.nevents;
+    double t_last = hdr->c.t_last;
+    double t_event = hdr->t_event;
+    status = PDMP_CHAIN_OK;
+    const double T = P.T;
+    const bool stop_before = (P.flags & PDMP_RUN_STOP_BEFORE) != 0;
+    const bool adapt = P.adapt != 0;
+
+    for (uint32_t b = lane; b < nblk; b += 64) {
+        const double* kp = keys + (size_t)b * 64;
+        double mk = kp[0];
+        uint32_t mi = 0;
+#pragma unroll 8
+        for (int q = 1; q < 64; ++q) {
+            const double v = kp[q];
+            if (v < mk) {
+                mk = v;
+                mi = q;
+            }
+        }
+        bk[b] = mk;
+        bi[b] = b * 64 + mi;
+    }
+    G_ORDER();
+
+    auto queue_update = [&](uint32_t j, double kj) {
+        const uint32_t bj = j >> 6;
+        G_ORDER();
+        const double cur = bk[bj];
+        const uint32_t ci = bi[bj];
+        if (kj < cur || (kj == cur && j < ci)) {
+            if (lane == 0) {
+                bk[bj] = kj;
+                bi[bj] = j;
+            }
+        } else if (ci == j) {
+            const double kv = __hip_atomic_load(keys + (size_t)bj * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double mn = g_wave_min(kv);
+            const uint64_t bl = __ballot(kv == mn);
+            const int arg = bl ? (__ffsll((unsigned long long)bl) - 1) : 0;
+            if (lane == 0) {
+                bk[bj] = mn;
+                bi[bj] = bj * 64 + (uint32_t)arg;
+            }
+        }
+        G_ORDER();
+    };
+    // move the members S[i][p0 .. p1) to time tp, write them back, stage (x, θ) by position
+    auto move_members = [&](uint32_t sp0, uint32_t p0, uint32_t p1, double tp) {
+        for (uint32_t base = p0; base < p1; base += 64) {
+            const uint32_t pp = base + (uint32_t)lane;
+            if (pp < p1) {
+                const uint32_t j = P.tb.sidx[sp0 + pp];
+                ZzRec* r = rec + j;
+                const double x0 = r->x, th0 = r->th, t0 = r->t, I0 = r->I;
+                const double dt = tp - t0;
+                const double xn = x0 + th0 * dt;  // smove_forward!, src/sfact.jl:6-12
+                r->x = xn;
+                r->t = tp;
+                r->I = I0 + dt * ((x0 + xn) * 0.5);
+                sx[pp] = xn;
+                sth[pp] = th0;
+            }
+        }
+        G_ORDER();
+    };
+
+    bool running = stop_before || (t_event < T);
+    while (running) {
+        if (P.trace_cap > 0 && ntrace >= (uint64_t)P.trace_cap) {
+            status = PDMP_CHAIN_TRACE_FULL;
+            break;
+        }
+        // ---------------- peek(Q), src/sfact.jl:77
+        double mk = G_INF;
+        uint32_t mb = 0xffffffffu;
+        for (uint32_t b = lane; b < nblk; b += 64) {
+            const double v = bk[b];
+            if (v < mk) {
+                mk = v;
+                mb = b;
+            }
+        }
+        const double tp = g_wave_min(mk);
+        if (!(tp < G_INF)) {
+            status = PDMP_CHAIN_STALLED;
+            break;
+        }
+        if (stop_before && !(tp < T)) break;
+        uint32_t blk;
+        {
+            const uint64_t ball = __ballot(mk == tp);
+            uint32_t cand = (mk == tp) ? mb : 0xffffffffu;  // exact ties: lowest block
+            for (int off = 32; off >= 1; off >>= 1) {
+                const uint32_t o = (uint32_t)__shfl_xor((int)cand, off, 64);
+                cand = (o < cand) ? o : cand;
+            }
+            (void)ball;
+            blk = g_uniform(cand);
+        }
+        const uint32_t i = g_uniform(bi[blk]);
+        t_last = tp;
+
+        const uint32_t cp0 = P.tb.colptr[i];
+        const uint32_t k = P.tb.colptr[i + 1] - cp0;
+        const uint32_t sp0 = P.tb.sptr[i];
+        const uint32_t m = P.tb.sptr[i + 1] - sp0;
+        const uint32_t self = Q.selfpos16[i];
+        const ZzRec* ri = rec + i;
+        const double told_i = ri->t_old, a_i = ri->a, b_i = ri->b;
+        const uint64_t acc_i = ri->acc;
+
+        move_members(sp0, 0, k, tp);  // smove_forward!(G, i, ...), :82
+        // ---------------- gradient
+        double g;
+        if (Q.target_kind == 0) {  // ∇ϕ(x, i) = idot(Γt, i, x) [- idot(Γt, i, μt)]
+            g = 0.0;
+            for (uint32_t p = 0; p < k; ++p) g += P.tb.tval[cp0 + p] * sx[p];
+            if (P.tb.gmu_t) g = g - P.tb.gmu_t[i];
+        } else {
+            // ∇ϕmoving = γ0*x[i] - fdot_moving(A, At, i, t, x, θ, t′, F, μ, y, ny, k), scripts/logistic.jl:78-95,107
+            const double prior = Q.gamma0 * sx[self];
+            double s = 0.0;
+            const int64_t r0 = Q.A_colptr[i];
+            const int64_t l = Q.A_colptr[i + 1] - r0;
+            for (int64_t q = 0; q < Q.ksub; ++q) {
+                const int64_t ii = r0 + (int64_t)pdmp_randint(seed, PDMP_STREAM_GLOBAL, ng, (uint32_t)l);  // rand(sampler)
+                ng += 1;
+                const int64_t row = Q.A_rowval[ii];
+                const double v = Q.A_nzval[ii];
+                // idot_moving!(At, row, t, x, θ, t′, F), src/common.jl:33-42: move the row's coordinates, then dot
+                const int64_t e0 = Q.At_colptr[row];
+                const int ne = (int)(Q.At_colptr[row + 1] - e0);
+                double u = 0.0;
+                for (int eb = 0; eb < ne; eb += 64) {
+                    const int e = eb + lane;
+                    double xe = 0.0, we = 0.0;
+                    if (e < ne) {
+                        const int64_t cc = Q.At_rowval[e0 + e];
+                        we = Q.At_nzval[e0 + e];
+                        ZzRec* r = rec + cc;
+                        const double x0 = r->x, th0 = r->th, t0 = r->t, I0 = r->I;
+                        const double dt = tp - t0;
+                        xe = x0 + th0 * dt;
+                        r->x = xe;
+                        r->t = tp;
+                        r->I = I0 + dt * ((x0 + xe) * 0.5);
+                    }
+                    const int cnt = (ne - eb < 64) ? (ne - eb) : 64;
+                    for (int z = 0; z < cnt; ++z) u += g_readlane(we, z) * g_readlane(xe, z);
+                }
+                const double w = (double)l / (double)Q.ksub * v;
+                const double yr = Q.y[row], nyr = Q.ny[row], u0 = Q.u0[row];
+                s += w * yr * g_sigmoid(-u);        // sigmoidn(u) = sigmoid(-u)
+                s += w * nyr * (-g_sigmoid(u));     // nsigmoid(u) = -sigmoid(u)
+                s -= w * yr * g_sigmoid(-u0);
+                s -= w * nyr * (-g_sigmoid(u0));
+            }
+            g = prior - s;
+        }
+        const double th_i = sth[self];
+        const double l_rate = g_pos(g * th_i);                       // :119
+        const double lbound = g_pos(a_i + b_i * (tp - told_i));     // :119
+        num += 1;
+        const double ucoin = pdmp_u01(seed, PDMP_STREAM_MAIN, nm);  // :121
+        nm += 1;
+        const bool accept = (ucoin * lbound < l_rate);
+        bool violated = false;
+        if (accept) {
+            nacc += 1;
+            violated = (l_rate >= lbound);  // :123
+            if (violated && !adapt) {
+                status = PDMP_CHAIN_BOUND_VIOLATED;
+                break;
+            }
+            if (violated && lane == 0) cmut[i] = cvec[i] * P.factor;  // adapt!(c, i, factor), :127
+            move_members(sp0, k, m, tp);                              // smove_forward!(G2, i, ...), :129
+            if (lane == 0) {
+                sth[self] = -th_i;  // reflect!, :130
+                rec[i].th = -th_i;
+                rec[i].acc = acc_i + 1;
+            }
+            G_ORDER();
+        }
+        // ---------------- re-bound: all of G1[i] on accept (:131-135), i alone on reject (:137-139)
+        const uint32_t jj0 = accept ? 0u : self;
+        const uint32_t jj1 = accept ? k : self + 1u;
+        for (uint32_t base = jj0; base < jj1; base += 64) {
+            const uint32_t jj = base + (uint32_t)lane;
+            if (jj < jj1) {
+                const uint32_t j = P.tb.rowval[cp0 + jj];
+                const uint32_t cj0 = P.tb.colptr[j];
+                const uint32_t kj = P.tb.colptr[j + 1] - cj0;
+                const uint32_t q0 = P.tb.qptr[cp0 + jj];
+                double gx = 0.0, gt = 0.0;
+                for (uint32_t pp = 0; pp < kj; ++pp) {
+                    const double v = P.tb.bval[cj0 + pp];
+                    const uint32_t ps = Q.pos16[q0 + pp];
+                    gx += v * sx[ps];
+                    gt += v * sth[ps];
+                }
+                const double cj = cvec[j];
+                const double thj = sth[jj];
+                const double a = cj + (gx - P.tb.gmu_b[j]) * thj;  // src/fact_samplers.jl:51
+                const double b = cj / 100 + thj * gt;             // :52
+                const uint64_t di = accept ? (nm + (uint64_t)jj) : nm;
+                const double key = tp + g_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, di));
+                ZzRec* r = rec + j;
+                r->t_old = tp;
+                r->a = a;
+                r->b = b;
+                keys[j] = key;
+            }
+        }
+        nm += accept ? (uint64_t)k : 1u;
+        // ---------------- level 1 of the queue (keys[] already hold the new values)
+        for (uint32_t jj = jj0; jj < jj1; ++jj) {
+            const uint32_t j = P.tb.rowval[cp0 + jj];
+            const double kj = __hip_atomic_load(keys + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            queue_update(g_uniform(j), kj);
+        }
+        if (accept) {
+            if (ev && lane == 0) {
+                pdmp_event e;
+                e.t = tp;
+                e.i = (int64_t)i;
+                e.x = sx[self];
+                e.theta = -th_i;
+                ev[ntrace] = e;
+            }
+            ntrace += 1;
+            nevents += 1;
+            t_event = tp;
+            if (!stop_before && !(tp < T)) running = false;
+        }
+        G_ORDER();
+    }
+
+    if (lane == 0) {
+        hdr->c.t_last = t_last;
+        hdr->t_event = t_event;
+        hdr->c.num = num;
+        hdr->c.nacc = nacc;
+        hdr->c.ntrace = ntrace;
+        hdr->c.nevents = nevents;
+        hdr->c.ndraw_main = nm;
+        hdr->c.ndraw_global = ng;
+        hdr->c.status = status;
+    }
+}
+
+int launch_zz_general_run(const ZzRunParams& p, const ZzGeneralParams& q, int64_t nchains, void* stream) {
+    const size_t lds = zz_general_lds_bytes(p.nblk_pad, q.mmax_pad);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(zz_general_run_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(zz_general_run_kernel, dim3((unsigned)nchains), dim3(64), lds, (hipStream_t)stream, p, q);
+    return (int)hipGetLastError();
+}
+
+}  // namespace pdmp

@@ -1630,6 +1630,7 @@ __global__ __launch_bounds__(256) void math_probe_kernel(uint64_t seed, int64_t 
     out[3 * n + k] = sqrt(u * 1000.0 + v);
     out[4 * n + k] = dev_poisson_time(a, b, w);
     out[5 * n + k] = pdmp_randn(seed, 3u, (uint64_t)k);
+    out[6 * n + k] = pdmp_exp((u - 0.5) * 60.0 + v);
 }
 
 int launch_math_probe(uint64_t seed, int64_t n, double* out, void* stream) {

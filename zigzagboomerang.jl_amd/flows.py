@@ -70,6 +70,26 @@ class GaussianTarget:
 
 
 @dataclass
+class LogisticTarget:
+    """Subsampled logistic-regression gradient with a control variate at μ, evaluated with SelfMoving():
+    ∇ϕmoving(t,x,θ,i,t′,F,A,At,μ,y,ny,k) = γ0*x[i] − fdot_moving(A,At,i,...)  (scripts/logistic.jl:78-95,107,167) --
+    the device-resident stand-in for that closure and its `args = (SelfMoving(), A, At, μ, y, ny, k)`."""
+    A: sp.csc_matrix      # n x p design
+    y: np.ndarray         # [n] successes
+    ny: np.ndarray        # [n] failures (m - y)
+    μ: np.ndarray         # [p] control-variate point (the mode)
+    γ0: float = 0.01
+    k: int = 10
+
+    def __post_init__(self):
+        self.A = _csc(self.A)
+        self.At = _csc(self.A.T)
+        self.y = np.ascontiguousarray(self.y, dtype=np.float64)
+        self.ny = np.ascontiguousarray(self.ny, dtype=np.float64)
+        self.μ = np.ascontiguousarray(self.μ, dtype=np.float64)
+
+
+@dataclass
 class FactTrace:
     """FactTrace(F, t0, x0, θ0, events) -- src/trace.jl:7-13; events are (t, i, x_i, θ_i), i 0-based."""
     F: object
