@@ -688,7 +688,16 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
     P.thf = e->d_thf.p;
     P.reversible = e->reversible;
     P.strong_upperbounds = e->strong_upperbounds;
+    const char* phenv = getenv("PDMP_PHASE");
+    DevBuf<double> phbuf;
     const bool spec_ok = e->use_spec && dbg_cap == 0 && !P.has_refresh && !P.move_all && !sticky;
+    if (phenv && spec_ok) {
+        pdmp_status st3 = phbuf.alloc(16);
+        if (st3 != PDMP_OK) return st3;
+        HIP_TRY(hipMemset(phbuf.p, 0, 16 * sizeof(double)));
+        P.dbg = phbuf.p;
+        P.dbg_cap = 0;
+    }
     if (e->needs_general || e->target_kind == 1) {
         pdmp::ZzGeneralParams Q{};
         Q.pos16 = e->d_pos16.p;
@@ -717,6 +726,14 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
     if (rc != 0) return fail(PDMP_ERR_HIP, "zz_local_run launch failed: %s", hipGetErrorString((hipError_t)rc));
     HIP_TRY(hipEventRecord(e->ev1, s));
     e->timed = true;
+    if (phenv && spec_ok) {
+        HIP_TRY(hipDeviceSynchronize());
+        double hp[16];
+        HIP_TRY(hipMemcpy(hp, phbuf.p, sizeof hp, hipMemcpyDeviceToHost));
+        fprintf(stderr, "PHASE iters=%.0f cycles/iter:", hp[10]);
+        for (int q = 0; q < 9; ++q) fprintf(stderr, " p%d=%.0f", q, hp[10] > 0 ? hp[q] / hp[10] : 0.0);
+        fprintf(stderr, "\n");
+    }
     if (dbg_cap > 0) {
         HIP_TRY(hipDeviceSynchronize());
         std::vector<double> hd((size_t)dbg_cap * 16);

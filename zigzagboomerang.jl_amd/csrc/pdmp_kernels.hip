@@ -1106,7 +1106,7 @@ __device__ __forceinline__ double row_min_f64(double v) {
     return v;
 }
 
-template <int NE>
+template <int NE, bool PROF>
 __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
     constexpr int E = 4;
     const int lane = threadIdx.x;
@@ -1131,7 +1131,7 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
     double* Mr = LBr + 4;                                  // [4] validation minima (+4 spare)
     uint32_t* bi = reinterpret_cast<uint32_t*>(Mr + 8);    // [nblk_pad]
     uint32_t* Z = bi + P.nblk_pad;                         // [64] zone ids
-    uint32_t* Kr = Z + 64;                                 // [4] k per event
+    uint32_t* Kr = Z + 64;                                 // [4] k per event (+12 spare)
 
     double* sx = SX + g * 16;
     double* sth = STH + g * 16;
@@ -1174,6 +1174,19 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
     }
     LDS_ORDER();
 
+    uint64_t rng_base = ~0ull;  // first draw index held in U/LU (none yet)
+    // optional per-phase cycle accounting of chain 0 (PDMP_PHASE env): where does an iteration's latency go?
+    uint64_t ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t ph_t0 = PROF ? (uint64_t)__builtin_readcyclecounter() : 0;
+    uint64_t ph_iters = 0;
+#define PHASE(k)                                                  \
+    do {                                                          \
+        if (PROF) {                                               \
+            const uint64_t now_ = (uint64_t)__builtin_readcyclecounter(); \
+            ph[k] += now_ - ph_t0;                                \
+            ph_t0 = now_;                                         \
+        }                                                         \
+    } while (0)
     bool running = stop_before || (t_event < T);
     while (running) {
         if (P.trace_cap > 0 && ntrace >= (uint64_t)P.trace_cap) {
@@ -1223,6 +1236,8 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
             if (first_inf) status = PDMP_CHAIN_STALLED;
             break;
         }
+        PHASE(0);
+        if (PROF) ph_iters += 1;
         const bool gvalid = g < Esel;
         const double tp = (g == 0) ? tpr[0] : (g == 1) ? tpr[1] : (g == 2) ? tpr[2] : tpr[3];
         const uint32_t blk = (g == 0) ? blkr[0] : (g == 1) ? blkr[1] : (g == 2) ? blkr[2] : blkr[3];
@@ -1252,13 +1267,18 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
             kq[2] = k23.x;
             kq[3] = k23.y;
         }
-        // ---------------- the 64 candidate draws of this iteration: draw nm + lane and its log
-        {
+        // ---------------- candidate draws: LDS holds draws rng_base .. rng_base+63 of the chain's stream and their logs.
+        // An iteration consumes at most E*(1+KMAX) <= 64 of them (about 10 on C3), so one wave-wide Philox + log call
+        // serves several iterations; the window is refilled only when the worst case would run past its end.
+        if (nm < rng_base || nm + (uint64_t)E * (1u + KMAX) > rng_base + 64u) {
+            rng_base = nm;
             const double u = pdmp_u01(seed, PDMP_STREAM_MAIN, nm + (uint64_t)lane);
             U[lane] = u;
             LU[lane] = pdmp_log(u);
         }
+        const uint32_t rng_off = (uint32_t)(nm - rng_base);
         LDS_ORDER();
+        PHASE(1);
         // ---------------- neighbourhood header and member list
         int k = 0, m = 0, self = 0, kjmax = 0;
         uint32_t s = 0xffffff00u + (uint32_t)lane;
@@ -1274,6 +1294,7 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
             }
         }
         const bool member = gvalid && gl < m;
+        PHASE(2);
         ZzRec* rs = rec + (member ? s : i);
         double x = 0.0, th = 0.0, t = 0.0, I = 0.0;
         if (member) {
@@ -1305,6 +1326,7 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
             myconf = myconf && member;
         }
         const uint64_t confball = __ballot(myconf);
+        PHASE(3);
 
         // ---------------- smove_forward!(G, i, ...), gradient, rates
         if (gvalid && gl < k) {
@@ -1347,7 +1369,7 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
             violr[r] = false;
             offr[r + 1] = offr[r];
             if (r < Esel) {
-                const double coin = U[offr[r]];
+                const double coin = U[rng_off + offr[r]];
                 const double l = Lr[r], lbound = LBr[r];
                 accr[r] = (coin * lbound < l);             // :121
                 violr[r] = accr[r] && (l >= lbound);       // :123
@@ -1357,6 +1379,7 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
         const bool accept = (g == 0) ? accr[0] : (g == 1) ? accr[1] : (g == 2) ? accr[2] : accr[3];
         const bool violated = (g == 0) ? violr[0] : (g == 1) ? violr[1] : (g == 2) ? violr[2] : violr[3];
         const uint32_t myoff = (g == 0) ? offr[0] : (g == 1) ? offr[1] : (g == 2) ? offr[2] : offr[3];
+        PHASE(4);
 
         int nmoved = k;
         if (gvalid && accept) {
@@ -1403,11 +1426,12 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
             if (violated && gl == self) cj *= P.factor;  // adapt!(c, i, factor), :127 (stored at commit)
             a = cj + (gx - gmu) * th;
             b = cj / 100 + th * gt;
-            const double L = LU[myoff + 1 + (accept ? (uint32_t)gl : 0u)];
+            const double L = LU[rng_off + myoff + 1 + (accept ? (uint32_t)gl : 0u)];
             key = t + dev_poisson_time_L(a, b, L);
             if ((s >> 6) == blk) pk[s & 63] = key;
         }
         LDS_ORDER();
+        PHASE(5);
         // ---------------- patched minimum of the popped block, and everything this event could expose
         double rowmin, candmin;
         uint32_t cand;
@@ -1473,6 +1497,7 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
             }
         }
         Rc = (int)uniform_u32((uint32_t)Rc);
+        PHASE(6);
 
         // ---------------- commit the valid prefix
         const bool commit = gvalid && g < Rc;
@@ -1509,6 +1534,7 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
         }
         LDS_ORDER();
         // ---------------- level-1 updates for re-bounded neighbours living in other blocks, in event order
+        PHASE(7);
         for (int r = 0; r < Rc; ++r) {
             const bool acc_r = (r == 0) ? accr[0] : (r == 1) ? accr[1] : (r == 2) ? accr[2] : accr[3];
             if (!acc_r) continue;
@@ -1541,6 +1567,7 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
             }
         }
         // ---------------- counters
+        PHASE(8);
         if (Rc > 0) {
             num += (uint64_t)Rc;
             nacc += nacc_c;
@@ -1557,6 +1584,11 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
         LDS_ORDER();
     }
 
+    if (PROF && P.dbg && chain == 0 && lane == 0) {
+        for (int q = 0; q < 10; ++q) P.dbg[q] = (double)ph[q];
+        P.dbg[10] = (double)ph_iters;
+    }
+#undef PHASE
     if (lane == 0) {
         hdr->c.t_last = t_last;
         hdr->t_event = t_event;
@@ -1655,14 +1687,16 @@ int launch_zz_local_spec(const ZzRunParams& p, int64_t nchains, void* stream) {
     const size_t lds = zz_spec_lds_bytes(p.nblk_pad, p.blob_w_pad);
     const int ne = (int)((p.nblk + 63) / 64);
     dim3 grid((unsigned)nchains), block(64);
-    if (ne <= 1) {
-        hipLaunchKernelGGL(zz_local_spec_kernel<1>, grid, block, lds, (hipStream_t)stream, p);
+    if (p.dbg) {  // per-phase cycle profile (PDMP_PHASE env)
+        hipLaunchKernelGGL((zz_local_spec_kernel<8, true>), grid, block, lds, (hipStream_t)stream, p);
+    } else if (ne <= 1) {
+        hipLaunchKernelGGL((zz_local_spec_kernel<1, false>), grid, block, lds, (hipStream_t)stream, p);
     } else if (ne <= 2) {
-        hipLaunchKernelGGL(zz_local_spec_kernel<2>, grid, block, lds, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((zz_local_spec_kernel<2, false>), grid, block, lds, (hipStream_t)stream, p);
     } else if (ne <= 5) {
-        hipLaunchKernelGGL(zz_local_spec_kernel<5>, grid, block, lds, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((zz_local_spec_kernel<5, false>), grid, block, lds, (hipStream_t)stream, p);
     } else {
-        hipLaunchKernelGGL(zz_local_spec_kernel<8>, grid, block, lds, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((zz_local_spec_kernel<8, false>), grid, block, lds, (hipStream_t)stream, p);
     }
     return (int)hipGetLastError();
 }
