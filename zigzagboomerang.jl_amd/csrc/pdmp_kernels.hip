@@ -1091,10 +1091,26 @@ __global__ __launch_bounds__(64) void zz_sticky_run_kernel(ZzRunParams P) {
 // memory-level parallelism per wavefront and one instruction stream for 4 events.
 // Requirements: |S[i]| <= 16, max column nnz <= 15, d + 1 <= 64 * 8 * 64; otherwise zz_local_run_kernel is used.
 
+// LDS layout of the speculative kernel: every fixed-size array sits at a compile-time offset (folds into the DS
+// instruction's immediate, no SGPR per array); the three size-dependent arrays come last.
+constexpr uint32_t SP_U = 0;        // [64] f64 draws rng_base + lane
+constexpr uint32_t SP_LU = 512;     // [64] f64 their logs
+constexpr uint32_t SP_SX = 1024;    // [4][16] f64
+constexpr uint32_t SP_STH = 1536;   // [4][16] f64
+constexpr uint32_t SP_PK = 2048;    // [4][64] f64 patched key blocks
+constexpr uint32_t SP_SLT = 4096;   // [4] f64 candidate keys
+constexpr uint32_t SP_SLH = 4128;   // [4] f64 second-best entry of the offering lanes
+constexpr uint32_t SP_LR = 4160;    // [4] f64 true rates
+constexpr uint32_t SP_LBR = 4192;   // [4] f64 bounds
+constexpr uint32_t SP_MR = 4224;    // [4] f64 what each event exposes (validation)
+constexpr uint32_t SP_Z = 4256;     // [64] u32 zone ids
+constexpr uint32_t SP_KR = 4512;    // [4] u32 k per event
+constexpr uint32_t SP_SLB = 4528;   // [4] u32 candidate blocks
+constexpr uint32_t SP_OFR = 4544;   // [8] u32 draw offsets after 0..4 events
+constexpr uint32_t SP_LB = 4576;    // [4][Wpad] u64 blobs, then bk[nblk_pad] f64, bi[nblk_pad] u32
+
 size_t zz_spec_lds_bytes(uint32_t nblk_pad, uint32_t blob_w_pad) {
-    // bk | U | LU | SX | STH | PK[4][64] | LB[4][Wpad] | Lr,LBr,Mr (4 each, padded to 16) | bi | Z[64] | Kr[4]
-    return (size_t)nblk_pad * 8 + (size_t)(64 * 4 + 4 * 64) * 8 + (size_t)4 * blob_w_pad * 8 + 16 * 8 +
-           (size_t)nblk_pad * 4 + 64 * 4 + 16 * 4;
+    return (size_t)SP_LB + (size_t)4 * blob_w_pad * 8 + (size_t)nblk_pad * 8 + (size_t)nblk_pad * 4;
 }
 
 // minimum over the 16 lanes of a DPP row, returned in every lane of the row
@@ -1119,24 +1135,24 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
     const uint32_t R_ = 4 + PW + KMAX;
 
     extern __shared__ __align__(16) unsigned char smem[];
-    double* bk = reinterpret_cast<double*>(smem);          // [nblk_pad]
-    double* U = bk + P.nblk_pad;                           // [64] uniforms nm + lane
-    double* LU = U + 64;                                   // [64] their logs
-    double* SX = LU + 64;                                  // [4][16]
-    double* STH = SX + 64;                                 // [4][16]
-    double* PK = STH + 64;                                 // [4][64]
-    uint64_t* LB = reinterpret_cast<uint64_t*>(PK + 256);  // [4][Wpad]
-    double* Lr = reinterpret_cast<double*>(LB + 4 * P.blob_w_pad);  // [4] true rates
-    double* LBr = Lr + 4;                                  // [4] bounds
-    double* Mr = LBr + 4;                                  // [4] validation minima (+4 spare)
-    uint32_t* bi = reinterpret_cast<uint32_t*>(Mr + 8);    // [nblk_pad]
-    uint32_t* Z = bi + P.nblk_pad;                         // [64] zone ids
-    uint32_t* Kr = Z + 64;                                 // [4] k per event (+12 spare)
-
-    double* sx = SX + g * 16;
-    double* sth = STH + g * 16;
-    double* pk = PK + g * 64;
-    uint64_t* lb = LB + (size_t)g * P.blob_w_pad;
+    double* const U = reinterpret_cast<double*>(smem + SP_U);
+    double* const LU = reinterpret_cast<double*>(smem + SP_LU);
+    double* const SLT = reinterpret_cast<double*>(smem + SP_SLT);
+    double* const SLH = reinterpret_cast<double*>(smem + SP_SLH);
+    double* const Lr = reinterpret_cast<double*>(smem + SP_LR);
+    double* const LBr = reinterpret_cast<double*>(smem + SP_LBR);
+    double* const Mr = reinterpret_cast<double*>(smem + SP_MR);
+    uint32_t* const Z = reinterpret_cast<uint32_t*>(smem + SP_Z);
+    uint32_t* const Kr = reinterpret_cast<uint32_t*>(smem + SP_KR);
+    uint32_t* const SLB = reinterpret_cast<uint32_t*>(smem + SP_SLB);
+    uint32_t* const OFR = reinterpret_cast<uint32_t*>(smem + SP_OFR);
+    double* const bk = reinterpret_cast<double*>(smem + SP_LB + (size_t)4 * P.blob_w_pad * 8);
+    uint32_t* const bi = reinterpret_cast<uint32_t*>(bk + P.nblk_pad);
+    // per-group views
+    double* const sx = reinterpret_cast<double*>(smem + SP_SX) + g * 16;
+    double* const sth = reinterpret_cast<double*>(smem + SP_STH) + g * 16;
+    double* const pk = reinterpret_cast<double*>(smem + SP_PK) + g * 64;
+    uint64_t* const lb = reinterpret_cast<uint64_t*>(smem + SP_LB) + (size_t)g * P.blob_w_pad;
 
     ZzRec* rec = P.rec + chain * d;
     double* keys = P.keys + chain * P.dk;
@@ -1147,8 +1163,8 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
     uint32_t status = hdr->c.status;
     if (status == PDMP_CHAIN_BOUND_VIOLATED || status == PDMP_CHAIN_STALLED) return;
     const uint64_t seed = hdr->seed;
-    uint64_t nm = hdr->c.ndraw_main;
-    uint64_t num = hdr->c.num, nacc = hdr->c.nacc, ntrace = hdr->c.ntrace, nevents = hdr->c.nevents;
+    const uint64_t nm0 = hdr->c.ndraw_main, ntrace0 = hdr->c.ntrace;
+    uint32_t dnm = 0, dnum = 0, dnacc = 0;  // 32-bit deltas of this launch (a launch advances a chain by far < 2^32 draws)
     double t_last = hdr->c.t_last;
     double t_event = hdr->t_event;
     status = PDMP_CHAIN_OK;
@@ -1156,6 +1172,9 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
     const double T = P.T;
     const bool stop_before = (P.flags & PDMP_RUN_STOP_BEFORE) != 0;
     const bool adapt = P.adapt != 0;
+    const uint32_t trace_room = (P.trace_cap > 0)
+                                    ? (uint32_t)(((uint64_t)P.trace_cap > ntrace0) ? ((uint64_t)P.trace_cap - ntrace0) : 0)
+                                    : 0xffffffffu;  // events this launch may still record
 
     for (uint32_t b = lane; b < nblk; b += 64) {
         const double* kp = keys + (size_t)b * 64;
@@ -1174,29 +1193,29 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
     }
     LDS_ORDER();
 
-    uint64_t rng_base = ~0ull;  // first draw index held in U/LU (none yet)
-    // optional per-phase cycle accounting of chain 0 (PDMP_PHASE env): where does an iteration's latency go?
+    uint32_t rng_base = 0xffffffffu;  // first draw (as a delta to nm0) held in U/LU; none yet
     uint64_t ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t ph_t0 = PROF ? (uint64_t)__builtin_readcyclecounter() : 0;
     uint64_t ph_iters = 0;
-#define PHASE(k)                                                  \
-    do {                                                          \
-        if (PROF) {                                               \
+#define PHASE(k)                                                          \
+    do {                                                                  \
+        if (PROF) {                                                       \
             const uint64_t now_ = (uint64_t)__builtin_readcyclecounter(); \
-            ph[k] += now_ - ph_t0;                                \
-            ph_t0 = now_;                                         \
-        }                                                         \
+            ph[k] += now_ - ph_t0;                                        \
+            ph_t0 = now_;                                                 \
+        }                                                                 \
     } while (0)
+
     bool running = stop_before || (t_event < T);
     while (running) {
-        if (P.trace_cap > 0 && ntrace >= (uint64_t)P.trace_cap) {
+        if (dnacc >= trace_room) {
             status = PDMP_CHAIN_TRACE_FULL;
             break;
         }
         // ---------------- select E candidate events: lane l owns the level-1 entries l, l+64, ...; it offers its best
         // entry and remembers its second best.  A lane offers only ONE entry per iteration, so the candidates are the E
         // smallest entries only if no lane holds two of them -- the lane's second best therefore enters the validation
-        // bound of every later event (hid[r]), which keeps the commit rule exact.
+        // bound of every later event, which keeps the commit rule exact.  Winners publish straight into LDS slots.
         double best = PDMP_INF, second = PDMP_INF;
         uint32_t bestb = 0;
 #pragma unroll
@@ -1208,26 +1227,23 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
             bestb = lt ? b : bestb;
             best = lt ? v : best;
         }
-        double tpr[E], hid[E];
-        uint32_t blkr[E];
         int Esel = 0;
         bool first_inf = false;
 #pragma unroll
         for (int r = 0; r < E; ++r) {
-            tpr[r] = PDMP_INF;
-            hid[r] = PDMP_INF;
-            blkr[r] = 0;
             if (Esel == r) {
-                const double tp = wave_min_f64(best);
-                if (!(tp < PDMP_INF)) {
+                const double tpr = wave_min_f64(best);
+                if (!(tpr < PDMP_INF)) {
                     if (r == 0) first_inf = true;
-                } else if (!(stop_before && !(tp < T))) {
-                    const uint64_t ball = __ballot(best == tp);
+                } else if (!(stop_before && !(tpr < T))) {
+                    const uint64_t ball = __ballot(best == tpr);
                     const int wl = __ffsll((unsigned long long)ball) - 1;
-                    blkr[r] = readlane_u32(bestb, wl);
-                    hid[r] = readlane_f64(second, wl);
-                    if (lane == wl) best = PDMP_INF;
-                    tpr[r] = tp;
+                    if (lane == wl) {
+                        SLT[r] = best;
+                        SLH[r] = second;
+                        SLB[r] = bestb;
+                        best = PDMP_INF;
+                    }
                     Esel = r + 1;
                 }
             }
@@ -1236,11 +1252,13 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
             if (first_inf) status = PDMP_CHAIN_STALLED;
             break;
         }
+        LDS_ORDER();
         PHASE(0);
         if (PROF) ph_iters += 1;
         const bool gvalid = g < Esel;
-        const double tp = (g == 0) ? tpr[0] : (g == 1) ? tpr[1] : (g == 2) ? tpr[2] : tpr[3];
-        const uint32_t blk = (g == 0) ? blkr[0] : (g == 1) ? blkr[1] : (g == 2) ? blkr[2] : blkr[3];
+        const double tp = gvalid ? SLT[g] : PDMP_INF;
+        const uint32_t blk = gvalid ? SLB[g] : 0u;
+        const double hidg = gvalid ? SLH[g] : PDMP_INF;
         const uint32_t i = gvalid ? bi[blk] : 0u;
 
         // ---------------- level-1 loads (functions of i alone), per group
@@ -1270,13 +1288,13 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
         // ---------------- candidate draws: LDS holds draws rng_base .. rng_base+63 of the chain's stream and their logs.
         // An iteration consumes at most E*(1+KMAX) <= 64 of them (about 10 on C3), so one wave-wide Philox + log call
         // serves several iterations; the window is refilled only when the worst case would run past its end.
-        if (nm < rng_base || nm + (uint64_t)E * (1u + KMAX) > rng_base + 64u) {
-            rng_base = nm;
-            const double u = pdmp_u01(seed, PDMP_STREAM_MAIN, nm + (uint64_t)lane);
+        if (dnm < rng_base || dnm + E * (1u + KMAX) > rng_base + 64u) {
+            rng_base = dnm;
+            const double u = pdmp_u01(seed, PDMP_STREAM_MAIN, nm0 + (uint64_t)dnm + (uint64_t)lane);
             U[lane] = u;
             LU[lane] = pdmp_log(u);
         }
-        const uint32_t rng_off = (uint32_t)(nm - rng_base);
+        const uint32_t rng_off = dnm - rng_base;
         LDS_ORDER();
         PHASE(1);
         // ---------------- neighbourhood header and member list
@@ -1359,26 +1377,31 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
             }
         }
         LDS_ORDER();
-        // ---------------- accept chain in time order (wave-uniform, every lane computes it)
-        bool accr[E], violr[E];
-        uint32_t offr[E + 1];
-        offr[0] = 0;
+        // ---------------- accept chain in time order: every lane walks it (per-lane arithmetic on LDS broadcasts, no
+        // scalar registers), keeping only its own group's outcome
+        uint32_t accept_u = 0, violated_u = 0, myoff = 0;
+        {
+            uint32_t off = 0;
 #pragma unroll
-        for (int r = 0; r < E; ++r) {
-            accr[r] = false;
-            violr[r] = false;
-            offr[r + 1] = offr[r];
-            if (r < Esel) {
-                const double coin = U[rng_off + offr[r]];
-                const double l = Lr[r], lbound = LBr[r];
-                accr[r] = (coin * lbound < l);             // :121
-                violr[r] = accr[r] && (l >= lbound);       // :123
-                offr[r + 1] = offr[r] + (accr[r] ? (1u + Kr[r]) : 2u);
+            for (int r = 0; r < E; ++r) {
+                if (g == r) myoff = off;
+                if (lane == 0) OFR[r] = off;
+                if (r < Esel) {
+                    const double coin = U[rng_off + off];
+                    const double l = Lr[r], lbound = LBr[r];
+                    const uint32_t a_r = (coin * lbound < l) ? 1u : 0u;        // :121
+                    const uint32_t v_r = (a_r && (l >= lbound)) ? 1u : 0u;     // :123
+                    off += a_r ? (1u + Kr[r]) : 2u;
+                    if (g == r) {
+                        accept_u = a_r;
+                        violated_u = v_r;
+                    }
+                }
             }
+            if (lane == 0) OFR[E] = off;
         }
-        const bool accept = (g == 0) ? accr[0] : (g == 1) ? accr[1] : (g == 2) ? accr[2] : accr[3];
-        const bool violated = (g == 0) ? violr[0] : (g == 1) ? violr[1] : (g == 2) ? violr[2] : violr[3];
-        const uint32_t myoff = (g == 0) ? offr[0] : (g == 1) ? offr[1] : (g == 2) ? offr[2] : offr[3];
+        const bool accept = accept_u != 0;
+        const bool violated = violated_u != 0;
         PHASE(4);
 
         int nmoved = k;
@@ -1457,50 +1480,57 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
             rowmin = row_min_f64(lm);
         }
         const uint64_t winball = __ballot(gvalid && candmin == rowmin);
-        const int wl = __ffs((unsigned)((winball >> (16 * g)) & 0xffffu)) - 1;
+        const int wl2 = __ffs((unsigned)((winball >> (16 * g)) & 0xffffu)) - 1;
         const double keymin = row_min_f64(key);
-        const double Mg = min_f64(rowmin, keymin);
-        double Mv[E];
-#pragma unroll
-        for (int r = 0; r < E; ++r) Mv[r] = readlane_f64(Mg, 16 * r);
-
-        // ---------------- validate: longest prefix that equals sequential processing
-        int Rc = 0;            // committed events
-        uint32_t nacc_c = 0;   // accepted among them
-        double prefM = PDMP_INF;
-        bool stop_chain = false;
-#pragma unroll
-        for (int r = 0; r < E; ++r) {
-            if (r < Esel && Rc == r && !stop_chain) {
-                const bool conf = ((confball >> (16 * r)) & 0xffffull) != 0;
-                const bool ok = (r == 0) || (!conf && prefM > tpr[r]);
-                if (ok) {
-                    if (violr[r] && !adapt) {
-                        status = PDMP_CHAIN_BOUND_VIOLATED;  // reference: error(...), :124
-                        stop_chain = true;
-                    } else {
-                        Rc = r + 1;
-                        prefM = min_f64(prefM, min_f64(Mv[r], hid[r]));
-                        if (accr[r]) {
-                            nacc_c += 1;
-                            if (P.trace_cap > 0 && ntrace + nacc_c >= (uint64_t)P.trace_cap) {
-                                status = PDMP_CHAIN_TRACE_FULL;
-                                stop_chain = true;
-                            }
-                            if (!stop_before && !(tpr[r] < T)) {  // `while t′ < T`
-                                running = false;
-                                stop_chain = true;
-                            }
-                        }
+        const double expose = min_f64(min_f64(rowmin, keymin), hidg);
+        if (gl == 0) Mr[g] = expose;
+        LDS_ORDER();
+        // ---------------- validate: event g commits iff all earlier ones do, its zone is disjoint from theirs, and nothing
+        // they produce or expose comes before it.  Per-lane evaluation + ballots; the prefix is resolved on the scalar unit.
+        uint32_t Rc;
+        uint32_t nacc_c;
+        {
+            const double m0 = Mr[0], m1 = Mr[1], m2 = Mr[2];
+            const double pref = (g == 0) ? PDMP_INF : (g == 1) ? m0 : (g == 2) ? min_f64(m0, m1) : min_f64(min_f64(m0, m1), m2);
+            const bool confg = ((confball >> (16 * g)) & 0xffffull) != 0;
+            const bool okg = gvalid && ((g == 0) || (!confg && pref > tp));
+            const bool vstop = violated && !adapt;  // reference: error(...), :124 -> the event is not committed
+            const uint64_t okball = __ballot(okg && !vstop && gl == 0);
+            const uint64_t vball = __ballot(okg && vstop && gl == 0);
+            const uint64_t accball = __ballot(gvalid && accept && gl == 0);
+            // compact one bit per group
+            auto bits4 = [](uint64_t m_) -> uint32_t {
+                return (uint32_t)((m_ & 1ull) | ((m_ >> 15) & 2ull) | ((m_ >> 30) & 4ull) | ((m_ >> 45) & 8ull));
+            };
+            const uint32_t okb = bits4(okball), vb = bits4(vball), accb = bits4(accball);
+            uint32_t r_ok = 0;
+            while (r_ok < (uint32_t)E && ((okb >> r_ok) & 1u)) ++r_ok;
+            // stop AFTER an accepted event that fills the trace or passes T (`while t′ < T`)
+            Rc = 0;
+            nacc_c = 0;
+            bool stopped = false;
+            for (uint32_t r = 0; r < r_ok && !stopped; ++r) {
+                Rc = r + 1;
+                if ((accb >> r) & 1u) {
+                    nacc_c += 1;
+                    if (dnacc + nacc_c >= trace_room && P.trace_cap > 0) {
+                        status = PDMP_CHAIN_TRACE_FULL;
+                        stopped = true;
+                    }
+                    if (!stop_before && !(uniform_f64(SLT[r]) < T)) {
+                        running = false;
+                        stopped = true;
                     }
                 }
             }
+            // the first event that does not commit violates its bound (and nothing stopped the chain before it)
+            if (!stopped && r_ok < (uint32_t)E && ((vb >> r_ok) & 1u)) status = PDMP_CHAIN_BOUND_VIOLATED;
         }
-        Rc = (int)uniform_u32((uint32_t)Rc);
         PHASE(6);
 
         // ---------------- commit the valid prefix
-        const bool commit = gvalid && g < Rc;
+        const bool commit = gvalid && (uint32_t)g < Rc;
+        const uint64_t accball2 = __ballot(commit && accept && gl == 0);
         if (commit) {
             if (gl < nmoved) {
                 rs->x = x;
@@ -1516,35 +1546,32 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
                 if (violated && gl == self) cmut[s] = cj;
             }
             if (accept && gl == self) rs->acc = acc_i + 1;
-            if (gl == wl) {
+            if (gl == wl2) {
                 bk[blk] = rowmin;
                 bi[blk] = cand;
             }
             if (accept && gl == self && ev) {
-                uint32_t rank = 0;
-#pragma unroll
-                for (int r = 0; r < E; ++r) rank += (r < g && accr[r]) ? 1u : 0u;
+                const uint32_t rank = (uint32_t)__popcll(accball2 & ((1ull << (16 * g)) - 1ull));
                 pdmp_event e;
                 e.t = tp;
                 e.i = (int64_t)i;
                 e.x = x;
                 e.theta = th;
-                ev[ntrace + rank] = e;
+                ev[ntrace0 + dnacc + rank] = e;
             }
         }
         LDS_ORDER();
-        // ---------------- level-1 updates for re-bounded neighbours living in other blocks, in event order
         PHASE(7);
-        for (int r = 0; r < Rc; ++r) {
-            const bool acc_r = (r == 0) ? accr[0] : (r == 1) ? accr[1] : (r == 2) ? accr[2] : accr[3];
-            if (!acc_r) continue;
-            const uint32_t own = (r == 0) ? blkr[0] : (r == 1) ? blkr[1] : (r == 2) ? blkr[2] : blkr[3];
+        // ---------------- level-1 updates for re-bounded neighbours living in other blocks, in event order
+        for (uint32_t r = 0; r < Rc; ++r) {
+            if (!((accball2 >> (16 * r)) & 1ull)) continue;
+            const uint32_t own = uniform_u32(SLB[r]);
             const int kr = (int)uniform_u32(Kr[r]);
             for (int jj = 0; jj < kr; ++jj) {
-                const uint32_t j = readlane_u32(s, 16 * r + jj);
+                const uint32_t j = readlane_u32(s, 16 * (int)r + jj);
                 const uint32_t bj = j >> 6;
                 if (bj == own) continue;
-                const double kj = readlane_f64(key, 16 * r + jj);
+                const double kj = readlane_f64(key, 16 * (int)r + jj);
                 LDS_ORDER();
                 const double cur = bk[bj];
                 const uint32_t ci = bi[bj];
@@ -1566,19 +1593,16 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
                 }
             }
         }
-        // ---------------- counters
         PHASE(8);
+        // ---------------- counters
         if (Rc > 0) {
-            num += (uint64_t)Rc;
-            nacc += nacc_c;
-            ntrace += nacc_c;
-            nevents += nacc_c;
-            nm += (Rc == 1) ? offr[1] : (Rc == 2) ? offr[2] : (Rc == 3) ? offr[3] : offr[4];
-            t_last = (Rc == 1) ? tpr[0] : (Rc == 2) ? tpr[1] : (Rc == 3) ? tpr[2] : tpr[3];
-#pragma unroll
-            for (int r = 0; r < E; ++r) {
-                if (r < Rc && accr[r]) t_event = tpr[r];
-            }
+            dnum += Rc;
+            dnacc += nacc_c;
+            dnm += uniform_u32(OFR[Rc]);
+            t_last = uniform_f64(SLT[Rc - 1]);
+            const uint32_t accc = (uint32_t)(((accball2 & 1ull)) | ((accball2 >> 15) & 2ull) | ((accball2 >> 30) & 4ull) |
+                                             ((accball2 >> 45) & 8ull));
+            if (accc) t_event = uniform_f64(SLT[31 - __builtin_clz(accc)]);
         }
         if (status != PDMP_CHAIN_OK) break;
         LDS_ORDER();
@@ -1592,11 +1616,11 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
     if (lane == 0) {
         hdr->c.t_last = t_last;
         hdr->t_event = t_event;
-        hdr->c.num = num;
-        hdr->c.nacc = nacc;
-        hdr->c.ntrace = ntrace;
-        hdr->c.nevents = nevents;
-        hdr->c.ndraw_main = nm;
+        hdr->c.num += dnum;
+        hdr->c.nacc += dnacc;
+        hdr->c.ntrace = ntrace0 + dnacc;
+        hdr->c.nevents += dnacc;
+        hdr->c.ndraw_main = nm0 + dnm;
         hdr->c.status = status;
     }
 }
