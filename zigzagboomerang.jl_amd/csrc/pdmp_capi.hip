@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "pdmp_engine.hpp"
@@ -90,6 +91,8 @@ struct pdmp_ensemble {
     uint32_t blob_w = 0, blob_w_pad = 0, blob_sw = 0, blob_pw = 0, blob_kmax = 0, blob_mmax = 0;
     bool use_spec = false;  // speculative 4-events-per-iteration kernel (zz_local_spec_kernel)
     DevBuf<uint64_t> d_blob;
+    DevBuf<uint32_t> d_tix;
+    size_t n_templates = 0;
 
     // device tables
     DevBuf<uint32_t> d_colptr, d_rowval, d_sptr, d_sidx, d_qptr;
@@ -441,7 +444,9 @@ static pdmp_status build_blob(pdmp_ensemble* e, const double* c) {
         const uint32_t s0 = e->h_sptr[i], m = e->h_sptr[i + 1] - s0;
         uint32_t kjmax = 0;
         for (uint32_t w = 0; w < m; ++w) {
-            const uint64_t id = e->h_sidx[s0 + w];
+            // member ids RELATIVE to i (two's complement u32): coordinates with the same local structure -- every interior
+            // point of a lattice -- then share one program, and the table shrinks from d programs to a few dozen
+            const uint64_t id = (uint32_t)(e->h_sidx[s0 + w] - (uint32_t)i);
             B[1 + (w >> 1)] |= (w & 1) ? (id << 32) : id;
         }
         for (uint32_t jj = 0; jj < k; ++jj) {
@@ -461,6 +466,30 @@ static pdmp_status build_blob(pdmp_ensemble* e, const double* c) {
         }
         B[0] = (uint64_t)k | ((uint64_t)m << 8) | ((uint64_t)e->h_selfpos[i] << 16) | ((uint64_t)kjmax << 24);
     }
+    // de-duplicate identical programs
+    std::vector<uint32_t> tix((size_t)d, 0);
+    std::vector<uint64_t> templates;
+    {
+        std::unordered_map<std::string, uint32_t> seen;
+        seen.reserve(1024);
+        for (int64_t i = 0; i < d; ++i) {
+            const uint64_t* B = blob.data() + (size_t)i * Wpad;
+            std::string key(reinterpret_cast<const char*>(B), (size_t)Wpad * 8);
+            auto it = seen.find(key);
+            if (it == seen.end()) {
+                const uint32_t id = (uint32_t)seen.size();
+                seen.emplace(std::move(key), id);
+                templates.insert(templates.end(), B, B + Wpad);
+                tix[i] = id;
+            } else {
+                tix[i] = it->second;
+            }
+        }
+        e->n_templates = seen.size();
+    }
+    blob.swap(templates);
+    pdmp_status stt = e->d_tix.upload(tix);
+    if (stt != PDMP_OK) return stt;
     e->blob_w = W;
     e->blob_w_pad = Wpad;
     e->blob_sw = SW;
@@ -655,6 +684,7 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
     P.ev = e->cfg.trace_capacity > 0 ? e->d_ev.p : nullptr;
     P.c_chain = e->cfg.adapt ? e->d_c_chain.p : nullptr;
     P.blob = e->d_blob.p;
+    P.tix = e->d_tix.p;
     DevBuf<double> dbgbuf;
     const char* dbgenv = getenv("PDMP_DEBUG");
     const int64_t dbg_cap = dbgenv ? atoll(dbgenv) : 0;

@@ -72,7 +72,8 @@ struct ZzRunParams {
     double* c_chain;  // per-chain bounds when adapt, else nullptr
     double* dbg;  // optional [dbg_cap x 16] per-proposal diagnostics of chain 0 (PDMP_DEBUG env), else nullptr
     int64_t dbg_cap;
-    const uint64_t* __restrict__ blob;  // [d x blob_w] neighbourhood programs (layout: pdmp_capi.hip build_blob)
+    const uint64_t* __restrict__ blob;  // [ntemplates x blob_w_pad] neighbourhood programs (layout: pdmp_capi.hip build_blob)
+    const uint32_t* __restrict__ tix;   // [d] template of coordinate i (coordinates with the same relative program share one)
     uint32_t blob_w, blob_w_pad, blob_sw, blob_pw, blob_kmax;
     int64_t d;
     int64_t dk;        // padded key count per chain (multiple of 64)

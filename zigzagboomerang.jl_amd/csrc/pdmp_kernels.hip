@@ -376,13 +376,13 @@ __global__ __launch_bounds__(64) void zz_local_run_kernel(ZzRunParams P) {
             if (move_all) {
                 sweep_all(tp);
             } else {
-                const uint64_t* bsrc = P.blob + (size_t)i1 * P.blob_w_pad;
+                const uint64_t* bsrc = P.blob + (size_t)P.tix[i1] * P.blob_w_pad;
                 for (uint32_t w = lane; w < W; w += 64) lb[w] = bsrc[w];
                 LDS_ORDER();
                 const int k1 = (int)uniform_u32((uint32_t)(lb[0] & 0xff));
                 if (lane < k1) {
                     const uint64_t sw = lb[1 + (lane >> 1)];
-                    const uint32_t s1 = (lane & 1) ? (uint32_t)(sw >> 32) : (uint32_t)sw;
+                    const uint32_t s1 = i1 + ((lane & 1) ? (uint32_t)(sw >> 32) : (uint32_t)sw);  // ids are stored relative to i
                     ZzRec* r1 = rec + s1;
                     const double x0 = r1->x, th0 = r1->th, t0 = r1->t, I0 = r1->I;
                     const double dt = tp - t0;
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(64) void zz_local_run_kernel(ZzRunParams P) {
             const uint32_t i2 = pdmp_randint(seed, PDMP_STREAM_GLOBAL, ng, (uint32_t)d);
             ng += 1;
             {
-                const uint64_t* bsrc = P.blob + (size_t)i2 * P.blob_w_pad;
+                const uint64_t* bsrc = P.blob + (size_t)P.tix[i2] * P.blob_w_pad;
                 for (uint32_t w = lane; w < W; w += 64) lb[w] = bsrc[w];
             }
             LDS_ORDER();
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(64) void zz_local_run_kernel(ZzRunParams P) {
             uint32_t s = i2;
             if (lane < m) {
                 const uint64_t sw = lb[1 + (lane >> 1)];
-                s = (lane & 1) ? (uint32_t)(sw >> 32) : (uint32_t)sw;
+                s = i2 + ((lane & 1) ? (uint32_t)(sw >> 32) : (uint32_t)sw);
             }
             ZzRec* rs = rec + s;
             double x = 0.0, th = 0.0, t = 0.0, I = 0.0;
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(64) void zz_local_run_kernel(ZzRunParams P) {
 
         // ---------------- level-1 loads: everything that is a function of i alone
         {
-            const uint64_t* bsrc = P.blob + (size_t)i * P.blob_w_pad;
+            const uint64_t* bsrc = P.blob + (size_t)P.tix[i] * P.blob_w_pad;
             for (uint32_t w = lane; w < W; w += 64) lb[w] = bsrc[w];
         }
         const ZzRec* ri = rec + i;
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(64) void zz_local_run_kernel(ZzRunParams P) {
         uint32_t s = i;
         if (lane < m) {
             const uint64_t sw = lb[1 + (lane >> 1)];
-            s = (lane & 1) ? (uint32_t)(sw >> 32) : (uint32_t)sw;
+            s = i + ((lane & 1) ? (uint32_t)(sw >> 32) : (uint32_t)sw);
         }
         ZzRec* rs = rec + s;
         // ---------------- level-2 loads: positions of G[i] and (speculatively) of G2[i]
@@ -854,7 +854,7 @@ __global__ __launch_bounds__(64) void zz_sticky_run_kernel(ZzRunParams P) {
         t_last = tp;
 
         {
-            const uint64_t* bsrc = P.blob + (size_t)i * P.blob_w_pad;
+            const uint64_t* bsrc = P.blob + (size_t)P.tix[i] * P.blob_w_pad;
             for (uint32_t w = lane; w < W; w += 64) lb[w] = bsrc[w];
         }
         const ZzRec* ri = rec + i;
@@ -875,7 +875,7 @@ __global__ __launch_bounds__(64) void zz_sticky_run_kernel(ZzRunParams P) {
         uint32_t s = i;
         if (lane < m) {
             const uint64_t sw = lb[1 + (lane >> 1)];
-            s = (lane & 1) ? (uint32_t)(sw >> 32) : (uint32_t)sw;
+            s = i + ((lane & 1) ? (uint32_t)(sw >> 32) : (uint32_t)sw);
         }
         ZzRec* rs = rec + s;
         double x = 0.0, th = 0.0, t = 0.0, I = 0.0;
@@ -1263,27 +1263,12 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
 
         // ---------------- level-1 loads (functions of i alone), per group
         {
-            const ulonglong2* bsrc = reinterpret_cast<const ulonglong2*>(P.blob + (size_t)i * P.blob_w_pad);
+            const uint32_t tixi = gvalid ? P.tix[i] : 0u;
+            const ulonglong2* bsrc = reinterpret_cast<const ulonglong2*>(P.blob + (size_t)tixi * P.blob_w_pad);
             ulonglong2* bdst = reinterpret_cast<ulonglong2*>(lb);
             if (gvalid) {
                 for (uint32_t w = gl; w < W2; w += 16) bdst[w] = bsrc[w];
             }
-        }
-        const ZzRec* ri = rec + i;
-        double told_i = 0.0, a_i = 0.0, b_i = 0.0;
-        uint64_t acc_i = 0;
-        double kq[4] = {PDMP_INF, PDMP_INF, PDMP_INF, PDMP_INF};
-        if (gvalid) {
-            told_i = ri->t_old;
-            a_i = ri->a;
-            b_i = ri->b;
-            acc_i = ri->acc;
-            const double2* kp = reinterpret_cast<const double2*>(keys + (size_t)blk * 64 + gl * 4);
-            const double2 k01 = kp[0], k23 = kp[1];
-            kq[0] = k01.x;
-            kq[1] = k01.y;
-            kq[2] = k23.x;
-            kq[3] = k23.y;
         }
         // ---------------- candidate draws: LDS holds draws rng_base .. rng_base+63 of the chain's stream and their logs.
         // An iteration consumes at most E*(1+KMAX) <= 64 of them (about 10 on C3), so one wave-wide Philox + log call
@@ -1308,7 +1293,7 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
             kjmax = (int)((hw >> 24) & 0xff);
             if (gl < m) {
                 const uint64_t sw = lb[1 + (gl >> 1)];
-                s = (gl & 1) ? (uint32_t)(sw >> 32) : (uint32_t)sw;
+                s = i + ((gl & 1) ? (uint32_t)(sw >> 32) : (uint32_t)sw);
             }
         }
         const bool member = gvalid && gl < m;
@@ -1320,6 +1305,25 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
             th = rs->th;
             t = rs->t;
             I = rs->I;
+        }
+        // All HBM-latency loads of the iteration are issued HERE, in one batch, behind the compiler barrier of the blob
+        // hand-off: vmcnt retires in order, so an HBM load issued before the (L2-hot) blob load would make the blob wait a
+        // full HBM latency -- two serialized HBM round trips per iteration instead of one.
+        const ZzRec* ri = rec + i;
+        double told_i = 0.0, a_i = 0.0, b_i = 0.0;
+        uint64_t acc_i = 0;
+        double kq[4] = {PDMP_INF, PDMP_INF, PDMP_INF, PDMP_INF};
+        if (gvalid) {
+            told_i = ri->t_old;
+            a_i = ri->a;
+            b_i = ri->b;
+            acc_i = ri->acc;
+            const double2* kp = reinterpret_cast<const double2*>(keys + (size_t)blk * 64 + gl * 4);
+            const double2 k01 = kp[0], k23 = kp[1];
+            kq[0] = k01.x;
+            kq[1] = k01.y;
+            kq[2] = k23.x;
+            kq[3] = k23.y;
         }
         Z[lane] = s;
         const uint32_t sub = 1 + SW + (uint32_t)gl * R_;
