@@ -1300,7 +1300,8 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
         PHASE(2);
         ZzRec* rs = rec + (member ? s : i);
         double x = 0.0, th = 0.0, t = 0.0, I = 0.0;
-        if (member) {
+        const bool lazy_g2 = (P.flags & 0x100) != 0;  // fetch G2[i] only once the event is accepted (default)
+        if (member && (!lazy_g2 || gl < k)) {
             x = rs->x;
             th = rs->th;
             t = rs->t;
@@ -1411,6 +1412,12 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
         int nmoved = k;
         if (gvalid && accept) {
             if (gl >= k && gl < m) {  // smove_forward!(G2, i, ...), :129
+                if (lazy_g2) {
+                    x = rs->x;
+                    th = rs->th;
+                    t = rs->t;
+                    I = rs->I;
+                }
                 const double dt = tp - t;
                 const double xn = x + th * dt;
                 I = I + dt * ((x + xn) * 0.5);
