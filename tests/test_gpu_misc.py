@@ -1,0 +1,68 @@
+"""Error paths of the C ABI and the RCCL plumbing on one GPU (-m gpu)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+def test_unsupported_and_invalid_inputs_fail_loudly(gpu_pkg):
+    pkg = gpu_pkg
+    E = pkg._lib.PdmpError
+    d = 6
+    G = pkg.problems.gmrf_precision(3)[:6, :6].tocsc()
+    G.sort_indices()
+    with pkg.Ensemble(2, d) as ens:
+        with pytest.raises(E) as ei:  # state before flow/target
+            ens.set_state(0.0, np.zeros((2, d)), np.ones((2, d)), np.ones(d), np.arange(2))
+        assert ei.value.code == 1
+        nodiag = sp.csc_matrix(np.array([[0.0, 1.0], [1.0, 2.0]]))
+        with pkg.Ensemble(1, 2) as e2:
+            with pytest.raises(E) as ei:  # Γ[0,0] structurally zero: i must belong to G1[i]
+                e2.set_flow(pkg.ZigZag(nodiag, np.zeros(2), np.ones(2)))
+            assert ei.value.code == 4
+        ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
+        dense = sp.csc_matrix(np.ones((d, d)))
+        with pytest.raises(E) as ei:  # target entries outside the flow's pattern (src/sfact.jl:116)
+            ens.set_target(pkg.GaussianTarget(dense))
+        assert ei.value.code == 4
+        with pytest.raises(E):  # run before state
+            ens.run(1.0)
+    with pytest.raises(E) as ei:  # BPS keeps the state in registers: d <= 1024
+        pkg.Ensemble(1, 2048, sampler=pkg._lib.SAMPLER_BPS)
+    assert ei.value.code == 4
+    with pkg.Ensemble(1, d, sampler=pkg._lib.SAMPLER_STICKY_ZIGZAG) as es:
+        es.set_flow(pkg.ZigZag(G, np.zeros(d)))
+        es.set_target(pkg.GaussianTarget(G))
+        with pytest.raises(E):  # κ missing
+            es.set_state(0.0, np.zeros((1, d)), np.ones((1, d)), np.ones(d), np.arange(1))
+
+
+def test_stalled_chain_is_reported_not_hung(gpu_pkg):
+    """Every bound rate identically zero (a = 0, b < 0 -> poisson_time = Inf, src/poissontime.jl:22-23): the queue is all
+    +Inf, the chain is reported PDMP_CHAIN_STALLED and the kernel returns instead of spinning."""
+    pkg = gpu_pkg
+    d = 4
+    G = sp.identity(d, format="csc")
+    with pkg.Ensemble(2, d, trace_capacity=16) as ens:
+        ens.set_flow(pkg.ZigZag(-1.0 * G, np.zeros(d), np.ones(d)))
+        ens.set_target(pkg.GaussianTarget(G))
+        ens.set_state(0.0, np.zeros((2, d)), np.ones((2, d)), np.zeros(d), np.arange(2))
+        ens.run(10.0)
+        cnt = ens.counters()
+        assert np.all(cnt["status"] == pkg._lib.CHAIN_STALLED) and np.all(cnt["nevents"] == 0) and np.all(cnt["num"] == 0)
+        ens.run(20.0)  # sticky status: a stalled chain stays put
+        assert np.all(ens.counters()["status"] == pkg._lib.CHAIN_STALLED)
+
+
+def test_rccl_world1_gather_of_device_resident_traces():
+    """The post-run collectives on the real backend (nccl == RCCL), world_size 1, on a zero-copy view of the engine's trace.
+    Runs in a fresh interpreter in the order bench.py uses for N > 1: torch (and its HIP runtime) first, then the engine."""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_world1_script.py")
+    r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
