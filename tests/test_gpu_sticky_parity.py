@@ -73,3 +73,20 @@ def test_golden_sticky1d(gpu_pkg, golden):
     for f in ("t", "i", "x", "theta"):
         assert np.array_equal(tr.events[f], golden["sticky1d_events"][f])
     assert [int(num), int(acc)] == golden["sticky1d_counts"].tolist()
+
+
+def test_sticky_p10000_variable_selection_scale(gpu_pkg):
+    """The scale of config C5 (p = 10 000, spike-and-slab variable selection): sticky ZigZag on a sparse Gaussian slab
+    (100 x 100 grid-Laplace precision), thaw rates κ = (γ0/√2π)/(1/w − 1) with w = 1/2 (scripts/sticky/
+    sticky_logistic_sparse.jl:194-197).  Chains match the oracle; a sizeable fraction of coordinates is stuck at 0."""
+    pkg = gpu_pkg
+    G = pkg.problems.gmrf_precision(100, eps=0.5)
+    d = G.shape[0]
+    rng = np.random.default_rng(5)
+    x0 = rng.standard_normal((2, d))
+    th0 = rng.choice([-1.0, 1.0], (2, d))
+    gamma0, w = 0.5, 0.5
+    kappa = np.full(d, (gamma0 / math.sqrt(2 * math.pi)) / (1 / w - 1))
+    tr = check(pkg, G, G, None, x0, th0, pkg.problems.column_norms(G), kappa, 3.0, seed=50)
+    frozen = np.mean([np.mean(np.abs(q.events["theta"][-2000:]) == 0) for q in tr])
+    assert 0.05 < frozen < 0.95
