@@ -242,6 +242,31 @@ PDMP_HD void pdmp_sincos2pi(double v, double* s_out, double* c_out) {
     }
 }
 
+/* sin and cos of an arbitrary angle |x| < 2^20: three-term Cody-Waite reduction by pi/2 (every product n*pio2_k is exact),
+ * then the kernels above.  Replaces Base.sincos in the Boomerang rotation (src/sfact.jl:29-36, src/dynamics.jl:29-36). */
+PDMP_HD void pdmp_sincos(double x, double* s_out, double* c_out) {
+    const double invpio2 = 0x1.45f306dc9c883p-1; /* 2/pi */
+    const double pio2_1 = 0x1.921fb54400000p+0;  /* first 33 bits of pi/2 */
+    const double pio2_2 = 0x1.0b4611a600000p-34; /* next 33 bits */
+    const double pio2_3 = 0x1.3198a2e000000p-69; /* next 33 bits */
+    const double pio2_3t = 0x1.b839a252049c1p-104;
+    const double fnr = x * invpio2 + ((x < 0) ? -0.5 : 0.5);
+    const int32_t n = (int32_t)fnr;
+    const double fn = (double)n;
+    double r = x - fn * pio2_1;
+    r = r - fn * pio2_2;
+    r = r - fn * pio2_3;
+    r = r - fn * pio2_3t;
+    const double sr = pdmp_sin_poly(r);
+    const double cr = pdmp_cos_poly(r);
+    switch (n & 3) {
+    case 0: *s_out = sr;  *c_out = cr;  break;
+    case 1: *s_out = cr;  *c_out = -sr; break;
+    case 2: *s_out = -sr; *c_out = -cr; break;
+    default: *s_out = -cr; *c_out = sr; break;
+    }
+}
+
 #if defined(__HIPCC__)
 #define PDMP_SQRT(x) __builtin_sqrt(x)
 #else

@@ -101,7 +101,7 @@ int pdmp_device_count(void);
 
 /*
  * Test hook: evaluate the shared numerical contract (include/pdmp_detmath.h) on the device for draws
- * k = 0..n-1 of `seed`; out is [7 x n] row-major: u01, pdmp_log(u), a/b, sqrt, poisson_time, pdmp_randn, pdmp_exp.
+ * k = 0..n-1 of `seed`; out is [8 x n] row-major: u01, pdmp_log(u), a/b, sqrt, poisson_time, pdmp_randn, pdmp_exp, sin+2cos of pdmp_sincos.
  * A host evaluation of the same expressions must agree bit-for-bit (tests/test_gpu_detmath.py).
  */
 pdmp_status pdmp_debug_math_probe(int device, uint64_t seed, int64_t n, double* out);
@@ -117,6 +117,16 @@ void pdmp_ensemble_destroy(pdmp_ensemble* ens);
 pdmp_status pdmp_ensemble_set_flow_zigzag(pdmp_ensemble* ens, const int64_t* colptr, const int64_t* rowval,
                                           const double* nzval, const double* mu, const double* sigma,
                                           double lambda_ref, double rho);
+
+/*
+ * Flow F = FactBoomerang(Γ, μ, λref, σ; ρ) (src/types.jl:71-79) for spdmp: Hamiltonian rotation about μ between events
+ * (src/sfact.jl:29-36), rate ((∇ϕ_i − (x_i−μ_i)Γ_ii)θ_i)⁺ (src/fact_samplers.jl:37-39), bound a = c_i√(x_i²+θ_i²)·z + (x_i²+θ_i²)Γ_ii,
+ * b = 0 (:58-65), mandatory refresh θ_i = ρθ_i + ρ̄σ_i·randn at rate λref > 0 (src/sfact.jl:103, src/fact_samplers.jl:18).
+ * Same arguments as set_flow_zigzag; sampler must be PDMP_SAMPLER_ZIGZAG_LOCAL (the factorised driver spdmp).
+ */
+pdmp_status pdmp_ensemble_set_flow_factboomerang(pdmp_ensemble* ens, const int64_t* colptr, const int64_t* rowval,
+                                                 const double* nzval, const double* mu, const double* sigma,
+                                                 double lambda_ref, double rho);
 
 /*
  * Target ∇ϕ(x, i) = Γt[:,i]·x  [ − Γt[:,i]·μt ]  (idot, src/common.jl:16-24; closure of

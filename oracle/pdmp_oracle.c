@@ -328,6 +328,45 @@ static inline void move_all(int64_t d, double* t, double* x, const double* th, d
     for (int64_t j = 0; j < d; ++j) move1(j, t, x, th, tp);
 }
 
+/* smove_forward!(G, i, t, x, θ, t′, B::FactBoomerang), src/sfact.jl:29-36: rotation about μ by the elapsed time */
+static inline void boom_move1(int64_t j, double* t, double* x, double* th, double tp, const double* mu) {
+    const double tau = tp - t[j];
+    double s, c;
+    pdmp_sincos(tau, &s, &c);
+    const double xo = x[j], tho = th[j];
+    x[j] = (xo - mu[j]) * c + tho * s + mu[j];
+    th[j] = -(xo - mu[j]) * s + tho * c;
+    t[j] = tp;
+}
+static inline void flow_move_nbrs(int kind, const double* mu, const nbr_graph* g, int64_t i, double* t, double* x, double* th,
+                                  double tp) {
+    if (!kind) {
+        move_nbrs(g, i, t, x, th, tp);
+        return;
+    }
+    for (int64_t p = g->ptr[i]; p < g->ptr[i + 1]; ++p) boom_move1(g->idx[p], t, x, th, tp, mu);
+}
+static inline void flow_move_all(int kind, const double* mu, int64_t d, double* t, double* x, double* th, double tp) {
+    if (!kind) {
+        move_all(d, t, x, th, tp);
+        return;
+    }
+    for (int64_t j = 0; j < d; ++j) boom_move1(j, t, x, th, tp, mu);
+}
+/* ab(G, i, x, θ, c, Z::FactBoomerang), src/fact_samplers.jl:58-65 */
+static inline void boom_ab(const orc_csc* G, const double* mu, const double* diag, int64_t i, const double* x,
+                           const double* th, const double* c, double* a, double* b) {
+    double zz = 0.0;
+    for (int64_t p = G->colptr[i]; p < G->colptr[i + 1]; ++p) {
+        const int64_t j = G->rowval[p];
+        zz += (x[j] - mu[j]) * (x[j] - mu[j]) + th[j] * th[j];
+    }
+    const double z = sqrt(zz);
+    const double z2 = x[i] * x[i] + th[i] * th[i];
+    *a = c[i] * sqrt(z2) * z + z2 * diag[i];
+    *b = 0.0;
+}
+
 /* ab(G, i, x, θ, c, Z::ZigZag), src/fact_samplers.jl:50-54 with loosen(c,x) = c + x (:41) */
 static inline void zz_ab(const orc_csc* G, const double* gmu, int64_t i, const double* x, const double* th,
                          const double* c, double* a, double* b) {
@@ -401,7 +440,23 @@ int orc_spdmp_zigzag(int64_t d, const orc_zz_params* p, double t0, double T, dou
         cx.gmu_target = (double*)malloc((size_t)d * sizeof(double));
         for (int64_t i = 0; i < d; ++i) cx.gmu_target[i] = orc_idot(p->target_gamma, i, p->target_mu);
     }
-    const int hasrefresh = p->lambda_ref > 0; /* src/fact_samplers.jl:19 */
+    const int kind = p->flow_kind;
+    const double* fmu = p->bound_mu;
+    double* fdiag = (double*)malloc((size_t)d * sizeof(double)); /* Γ[i,i] */
+    for (int64_t i = 0; i < d; ++i) {
+        fdiag[i] = 0.0;
+        for (int64_t q = p->bound_gamma->colptr[i]; q < p->bound_gamma->colptr[i + 1]; ++q)
+            if (p->bound_gamma->rowval[q] == i) fdiag[i] = p->bound_gamma->nzval[q];
+    }
+    const double rhobar = sqrt(1 - p->rho * p->rho);
+#define FLOW_AB(j, aa, bb)                                                             \
+    do {                                                                               \
+        if (kind)                                                                      \
+            boom_ab(p->bound_gamma, fmu, fdiag, (j), x, th, c, (aa), (bb));              \
+        else                                                                           \
+            zz_ab(p->bound_gamma, cx.gmu_bound, (j), x, th, c, (aa), (bb));             \
+    } while (0)
+    const int hasrefresh = kind ? 1 : (p->lambda_ref > 0); /* src/fact_samplers.jl:18-19 */
     const uint64_t seed = p->seed;
     uint64_t nm = 0, ng = 0; /* draw counters: main stream, "global rng" stream */
 
@@ -414,7 +469,7 @@ int orc_spdmp_zigzag(int64_t d, const orc_zz_params* p, double t0, double T, dou
         acc[i] = 0;
     }
     orc_pq* Q = orc_pq_new(d + 1);
-    for (int64_t i = 0; i < d; ++i) zz_ab(p->bound_gamma, cx.gmu_bound, i, x, th, c, &ba[i], &bb[i]); /* :184 */
+    for (int64_t i = 0; i < d; ++i) FLOW_AB(i, &ba[i], &bb[i]); /* :184 */
     for (int64_t i = 0; i < d; ++i) {
         /* :186  enqueue!(Q, i => poisson_time(b[i], rand(rng)))   (t0 is NOT added in the reference) */
         orc_pq_enqueue(Q, i, orc_poisson_time(ba[i], bb[i], pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)));
@@ -447,21 +502,26 @@ int orc_spdmp_zigzag(int64_t d, const orc_zz_params* p, double t0, double T, dou
             int refresh = i >= d; /* :78 */
             if (refresh) i = (int64_t)pdmp_randint(seed, PDMP_STREAM_GLOBAL, ng++, (uint32_t)d); /* :80 */
             if (p->move_all) {
-                move_all(d, t, x, th, tp); /* :19 */
+                flow_move_all(kind, fmu, d, t, x, th, tp); /* :19 */
             } else {
-                move_nbrs(&cx.g1, i, t, x, th, tp); /* :82 (G = G1, Matched) */
+                flow_move_nbrs(kind, fmu, &cx.g1, i, t, x, th, tp); /* :82 (G = G1, Matched) */
             }
             if (refresh) {
                 i = (int64_t)pdmp_randint(seed, PDMP_STREAM_GLOBAL, ng++, (uint32_t)d); /* :84 */
-                if (!p->move_all) move_nbrs(&cx.g2, i, t, x, th, tp);                    /* :85 */
-                /* :100-101  θ[i] = F.σ[i]*rand(rng, (-1,1)) */
-                double u = pdmp_u01(seed, PDMP_STREAM_MAIN, nm++);
-                th[i] = p->sigma[i] * ((u < 0.5) ? -1.0 : 1.0);
+                if (!p->move_all) flow_move_nbrs(kind, fmu, &cx.g2, i, t, x, th, tp);    /* :85 */
+                if (kind) {
+                    /* :103  θ[i] = F.ρ*θ[i] + F.ρ̄*F.σ[i]*randn(rng, eltype(θ)) */
+                    th[i] = p->rho * th[i] + rhobar * p->sigma[i] * pdmp_randn(seed, PDMP_STREAM_MAIN, nm++);
+                } else {
+                    /* :100-101  θ[i] = F.σ[i]*rand(rng, (-1,1)) */
+                    double u = pdmp_u01(seed, PDMP_STREAM_MAIN, nm++);
+                    th[i] = p->sigma[i] * ((u < 0.5) ? -1.0 : 1.0);
+                }
                 /* :108  Q[n+1] = t′ + waiting_time_ref(F)  (global rng) */
                 orc_pq_set(Q, d, tp + (-pdmp_log(pdmp_u01(seed, PDMP_STREAM_GLOBAL, ng++)) / p->lambda_ref));
                 for (int64_t q = cx.g1.ptr[i]; q < cx.g1.ptr[i + 1]; ++q) { /* :110-114 */
                     int64_t j = cx.g1.idx[q];
-                    zz_ab(p->bound_gamma, cx.gmu_bound, j, x, th, c, &ba[j], &bb[j]);
+                    FLOW_AB(j, &ba[j], &bb[j]);
                     t_old[j] = t[j];
                     orc_pq_set(Q, j, t[j] + orc_poisson_time(ba[j], bb[j], pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)));
                 }
@@ -471,7 +531,8 @@ int orc_spdmp_zigzag(int64_t d, const orc_zz_params* p, double t0, double T, dou
             }
             double gi = (p->target_kind == 1) ? logistic_grad_moving(p, i, t, x, th, tp, seed, &ng)
                                               : zz_grad(&cx, i, x); /* :118 */
-            double l = pos(gi * th[i]);                         /* :119, src/fact_samplers.jl:28-30 */
+            double l = kind ? pos((gi - (x[i] - fmu[i]) * fdiag[i]) * th[i])  /* src/fact_samplers.jl:37-39 */
+                            : pos(gi * th[i]);                               /* :119, src/fact_samplers.jl:28-30 */
             double lb = pos(ba[i] + bb[i] * (t[i] - t_old[i])); /* :119, src/sfact.jl:70 */
             num += 1;                                           /* :120 */
             if (pdmp_u01(seed, PDMP_STREAM_MAIN, nm++) * lb < l) { /* :121 */
@@ -485,18 +546,18 @@ int orc_spdmp_zigzag(int64_t d, const orc_zz_params* p, double t0, double T, dou
                     }
                     c[i] *= p->factor; /* :127, src/fact_samplers.jl:67-70 */
                 }
-                if (!p->move_all) move_nbrs(&cx.g2, i, t, x, th, tp); /* :129 */
+                if (!p->move_all) flow_move_nbrs(kind, fmu, &cx.g2, i, t, x, th, tp); /* :129 */
                 th[i] = -th[i];                                        /* :130, src/dynamics.jl:46-49 */
                 for (int64_t q = cx.g1.ptr[i]; q < cx.g1.ptr[i + 1]; ++q) { /* :131-135 */
                     int64_t j = cx.g1.idx[q];
-                    zz_ab(p->bound_gamma, cx.gmu_bound, j, x, th, c, &ba[j], &bb[j]);
+                    FLOW_AB(j, &ba[j], &bb[j]);
                     t_old[j] = t[j];
                     orc_pq_set(Q, j, t[j] + orc_poisson_time(ba[j], bb[j], pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)));
                 }
                 trace_push(tr, t[i], i, x[i], th[i]); /* :143 with event() :50-52 */
                 break;
             } else { /* :136-140 */
-                zz_ab(p->bound_gamma, cx.gmu_bound, i, x, th, c, &ba[i], &bb[i]);
+                FLOW_AB(i, &ba[i], &bb[i]);
                 t_old[i] = t[i];
                 orc_pq_set(Q, i, t[i] + orc_poisson_time(ba[i], bb[i], pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)));
                 continue;
@@ -520,6 +581,8 @@ int orc_spdmp_zigzag(int64_t d, const orc_zz_params* p, double t0, double T, dou
     free(t_old);
     free(ba);
     free(bb);
+    free(fdiag);
+#undef FLOW_AB
     free(cx.gmu_bound);
     free(cx.gmu_target);
     graph_free(&cx.g1);
@@ -971,7 +1034,7 @@ double orc_spdmp_zigzag_ensemble(int64_t d, const orc_zz_params* p, double t0, d
 
 /* ------------------------------------------------------------------ host side of the device math probe */
 /* Same expressions as math_probe_kernel (zigzagboomerang.jl_amd/csrc/pdmp_kernels.hip), evaluated with the
- * oracle's own poisson_time and libm sqrt: out is [7 x n] row-major. */
+ * oracle's own poisson_time and libm sqrt: out is [8 x n] row-major. */
 void orc_math_probe(uint64_t seed, int64_t n, double* out) {
     for (int64_t k = 0; k < n; ++k) {
         const double u = pdmp_u01(seed, 0u, (uint64_t)k);
@@ -986,6 +1049,11 @@ void orc_math_probe(uint64_t seed, int64_t n, double* out) {
         out[4 * n + k] = orc_poisson_time(a, b, w);
         out[5 * n + k] = pdmp_randn(seed, 3u, (uint64_t)k);
         out[6 * n + k] = pdmp_exp((u - 0.5) * 60.0 + v);
+        {
+            double sn_, cs_;
+            pdmp_sincos((w - 0.5) * 400.0, &sn_, &cs_);
+            out[7 * n + k] = sn_ + 2.0 * cs_;
+        }
     }
 }
 double orc_log(double x) { return pdmp_log(x); }

@@ -107,6 +107,10 @@ typedef struct {
     const double* lg_mu;   /* [p] control-variate point μ */
     double lg_gamma0;      /* prior precision γ0 */
     int64_t lg_k;          /* subsample size */
+    /* flow_kind 1: F = FactBoomerang(Γ, μ, λref, σ; ρ) (src/types.jl:71-79) instead of ZigZag: Hamiltonian rotation between
+     * events (src/sfact.jl:29-36), rate (∇ϕi − (x_i−μ_i)Γ_ii)θ_i (src/fact_samplers.jl:37-39), constant bound a = c_i√z2·z + z2·Γ_ii,
+     * b = 0 (:58-65), mandatory refresh θ_i = ρθ_i + ρ̄σ_i·randn (src/sfact.jl:103; hasrefresh, src/fact_samplers.jl:18). */
+    int flow_kind;
 } orc_zz_params;
 
 typedef struct {

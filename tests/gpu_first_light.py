@@ -32,7 +32,7 @@ def probe():
     n = 1 << 20
     dev = pkg._lib.math_probe(12345, n)
     host = O.math_probe(12345, n)
-    names = ["u01", "log", "div", "sqrt", "poisson_time", "randn", "exp"]
+    names = ["u01", "log", "div", "sqrt", "poisson_time", "randn", "exp", "sincos"]
     ok = True
     for r, nm in enumerate(names):
         same = (dev[r] == host[r]) | (np.isnan(dev[r]) & np.isnan(host[r]))

@@ -46,7 +46,8 @@ class _ZZParams(C.Structure):
                 ("move_all", C.c_int), ("adapt", C.c_int), ("factor", C.c_double),
                 ("seed", C.c_uint64), ("max_events", C.c_int64), ("stop_before_T", C.c_int),
                 ("target_kind", C.c_int), ("lg_A", C.POINTER(_Csc)), ("lg_At", C.POINTER(_Csc)), ("lg_y", C.c_void_p),
-                ("lg_ny", C.c_void_p), ("lg_mu", C.c_void_p), ("lg_gamma0", C.c_double), ("lg_k", C.c_int64)]
+                ("lg_ny", C.c_void_p), ("lg_mu", C.c_void_p), ("lg_gamma0", C.c_double), ("lg_k", C.c_int64),
+                ("flow_kind", C.c_int)]
 
 
 class _ZZResult(C.Structure):
@@ -135,7 +136,7 @@ def lib():
 
 
 def math_probe(seed, n):
-    out = np.empty((7, n))
+    out = np.empty((8, n))
     lib().orc_math_probe(int(seed), int(n), out.ctypes.data)
     return out
 
@@ -189,7 +190,7 @@ def idot(A, j, x):
 
 def spdmp_zigzag(bound_gamma, bound_mu, target_gamma, x0, theta0, c, T, *, t0=0.0, target_mu=None,
                  sigma=None, lambda_ref=0.0, rho=0.0, move_all=False, adapt=False, factor=1.8, seed=1,
-                 max_events=0, stop_before_T=False, want_trace=True, logistic=None):
+                 max_events=0, stop_before_T=False, want_trace=True, logistic=None, factboomerang=False):
     """Local ZigZag (reference spdmp / pdmp for ZigZag).  Returns dict(events, t, x, theta, acc, num, c, ...)."""
     L = lib()
     gb = bound_gamma if isinstance(bound_gamma, CscHolder) else CscHolder(bound_gamma)
@@ -201,6 +202,7 @@ def spdmp_zigzag(bound_gamma, bound_mu, target_gamma, x0, theta0, c, T, *, t0=0.
     p = _ZZParams(C.pointer(gb.c), mu.ctypes.data, sg.ctypes.data, lambda_ref, rho, C.pointer(gt.c),
                   tmu.ctypes.data if tmu is not None else None, int(move_all), int(adapt), factor, seed,
                   max_events, int(stop_before_T))
+    p.flow_kind = 1 if factboomerang else 0
     if logistic is not None:  # dict(A, At, y, ny, mu, gamma0, k): target_kind 1
         lA = logistic["A"] if isinstance(logistic["A"], CscHolder) else CscHolder(logistic["A"])
         lAt = logistic["At"] if isinstance(logistic["At"], CscHolder) else CscHolder(logistic["At"])

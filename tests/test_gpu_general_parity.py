@@ -51,3 +51,51 @@ def test_config_c4_logistic_subsampled_matches_oracle(gpu_pkg):
             assert np.array_equal(tr[k].events[f], r["events"][f]), (k, f)
         assert int(num[k]) == r["num"] and np.array_equal(acc[k], r["acc"]) and np.array_equal(cout[k], r["c"])
         assert np.array_equal(x[k], r["x"]) and np.array_equal(t[k], r["t"])
+
+
+def _check_zz(pkg, F, G_t, x0, th0, c, T, seed, **okw):
+    tr, (t, x, th), (acc, num), cout = pkg.spdmp(pkg.GaussianTarget(G_t), 0.0, x0, th0, T, c, F, seed=seed,
+                                                 adapt=okw.get("adapt", False))
+    for k in range(x0.shape[0]):
+        r = O.spdmp_zigzag(F.Γ, F.μ, G_t, x0[k], th0[k], c, T, seed=seed + k, lambda_ref=F.λref, rho=F.ρ, sigma=F.σ, **okw)
+        assert r["status"] == 0 and len(tr[k].events) == len(r["events"]) > 20, (k, len(tr[k].events), len(r["events"]))
+        for f in ("i", "t", "x", "theta"):
+            assert np.array_equal(tr[k].events[f], r["events"][f]), (k, f)
+        assert int(num[k]) == r["num"] and np.array_equal(acc[k], r["acc"])
+        assert np.array_equal(x[k], r["x"]) and np.array_equal(th[k], r["theta"]) and np.array_equal(t[k], r["t"])
+    return tr
+
+
+def test_factboomerang_matches_oracle(gpu_pkg):
+    """spdmp with F::FactBoomerang (src/fact_samplers.jl:37-39,58-65; rotation src/sfact.jl:29-36; refresh :103)."""
+    pkg = gpu_pkg
+    G = pkg.problems.maintest_precision(8)
+    rng = np.random.default_rng(2)
+    Gz = sp.csc_matrix(1.2 * G)
+    F = pkg.FactBoomerang(Gz, np.zeros(8), 0.3)
+    x0 = rng.random((4, 8))
+    th0 = F.σ * rng.standard_normal((4, 8))
+    _check_zz(pkg, F, Gz, x0, th0, pkg.problems.column_norms(G), 150.0, 70, factboomerang=True)
+    # non-zero μ, ρ > 0, a lattice with several key blocks
+    G2 = pkg.problems.gmrf_precision(9)
+    d = 81
+    mu = 0.2 * rng.standard_normal(d)
+    F2 = pkg.FactBoomerang(G2, mu, 0.5, ρ=0.4)
+    x0 = rng.standard_normal((2, d))
+    th0 = F2.σ * rng.standard_normal((2, d))
+    _check_zz(pkg, F2, G2, x0, th0, 2.0 * pkg.problems.column_norms(G2), 20.0, 80, factboomerang=True)
+
+
+def test_refresh_on_the_general_kernel(gpu_pkg):
+    """ZigZag with λref > 0 on a graph whose neighbourhoods exceed one wavefront (general kernel's refresh branch)."""
+    pkg = gpu_pkg
+    rng = np.random.default_rng(3)
+    d = 150
+    R = sp.random(d, d, density=0.08, random_state=rng, data_rvs=rng.standard_normal, format="csc")
+    G = sp.csc_matrix(R @ R.T + 2.0 * sp.identity(d))
+    G.sort_indices()
+    sig = 0.5 + rng.random(d)
+    F = pkg.ZigZag(G, np.zeros(d), sig, λref=0.4)
+    x0 = rng.standard_normal((2, d))
+    th0 = sig * rng.choice([-1.0, 1.0], (2, d))
+    _check_zz(pkg, F, G, x0, th0, 2.0 * pkg.problems.column_norms(G), 4.0, 90)

@@ -215,3 +215,24 @@ def test_logistic_subsampled_target_statistics(pkg):
     z = (m - P["mu"]) / sd
     assert np.abs(z).mean() < 0.5 and np.abs(z).max() < 4.0
     assert 0.5 < np.median(v / sd ** 2) < 1.5
+
+
+def test_factboomerang_statistics_d8(pkg):
+    """test/maintest.jl:112-137 (SFactBoomerang): Z = FactBoomerang(1.2Γ, 0, 0.3), target ∇ϕ(x,i) = idot(Z.Γ, i, x), T = 3000,
+    discretize dt = 0.5 with the Boomerang rotation; the stationary law is N(0, inv(1.2Γ))."""
+    G = pkg.problems.maintest_precision(8)
+    d, T = 8, 3000.0
+    Gz = sp.csc_matrix(1.2 * G)
+    rng = np.random.default_rng(4)
+    x0 = rng.random(d)
+    sig = np.asarray(Gz.diagonal()) ** -0.5
+    th0 = sig * rng.standard_normal(d)
+    c = pkg.problems.column_norms(G)
+    r = O.spdmp_zigzag(Gz, np.zeros(d), Gz, x0, th0, c, T, seed=9, lambda_ref=0.3, sigma=sig, factboomerang=True)
+    assert r["status"] == 0 and r["nrefresh"] > 500 and len(r["events"]) == r["nacc"] + r["nrefresh"]
+    Z = pkg.FactBoomerang(Gz, np.zeros(d), 0.3)
+    tr = pkg.FactTrace(Z, 0.0, x0, th0, r["events"])
+    ts, xs = pkg.trace.discretize(tr, 0.5)
+    S = np.linalg.inv(Gz.toarray())
+    assert np.mean(np.abs(xs.mean(axis=0))) < 2 / math.sqrt(T) * 1.5
+    assert np.mean(np.abs(np.cov(xs.T) - S)) < 4 / math.sqrt(T)

@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = [
     "pdmp_ensemble_trace_reset", "pdmp_ensemble_final_state", "pdmp_ensemble_batch_means",
     "pdmp_ensemble_trace_dev", "pdmp_ensemble_counters_dev", "pdmp_debug_math_probe",
     "pdmp_ensemble_set_flow_bps", "pdmp_ensemble_set_state_bps", "pdmp_ensemble_bps_trace_copy",
-    "pdmp_ensemble_bps_final_state", "pdmp_ensemble_set_sticky", "pdmp_ensemble_set_target_logistic",
+    "pdmp_ensemble_bps_final_state", "pdmp_ensemble_set_sticky", "pdmp_ensemble_set_target_logistic", "pdmp_ensemble_set_flow_factboomerang",
 ]
 
 
@@ -74,6 +74,7 @@ def load():
     L.pdmp_ensemble_destroy.argtypes = [vp]
     L.pdmp_ensemble_destroy.restype = None
     L.pdmp_ensemble_set_flow_zigzag.argtypes = [vp, vp, vp, vp, vp, vp, f64, f64]
+    L.pdmp_ensemble_set_flow_factboomerang.argtypes = [vp, vp, vp, vp, vp, vp, f64, f64]
     L.pdmp_ensemble_set_target_gaussian_csc.argtypes = [vp, vp, vp, vp, vp]
     L.pdmp_ensemble_set_state.argtypes = [vp, f64, vp, vp, vp, vp]
     L.pdmp_ensemble_set_state_synthetic.argtypes = [vp, f64, vp, C.c_uint64]
@@ -109,7 +110,7 @@ def check(code):
 
 
 def math_probe(seed, n, device=0):
-    out = np.empty((7, n))
+    out = np.empty((8, n))
     check(load().pdmp_debug_math_probe(int(device), int(seed), int(n), out.ctypes.data))
     return out
 

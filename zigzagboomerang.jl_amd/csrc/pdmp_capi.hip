@@ -103,7 +103,9 @@ struct pdmp_ensemble {
     DevBuf<double> d_keys, d_c_chain, d_jprev, d_sum;
     DevBuf<pdmp::DevChain> d_hdr;
     DevBuf<pdmp_event> d_ev;
-    // general-degree kernel + logistic target
+    // general-degree kernel + logistic target + FactBoomerang
+    int flow_kind = 0;
+    DevBuf<double> d_mu, d_diag;
     bool needs_general = false;
     uint32_t mmax_all = 0;
     int target_kind = 0;
@@ -169,12 +171,12 @@ pdmp_status pdmp_debug_math_probe(int device, uint64_t seed, int64_t n, double* 
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(PDMP_ERR_NO_DEVICE, "no HIP device visible");
     HIP_TRY(hipSetDevice(device));
     DevBuf<double> buf;
-    pdmp_status st = buf.alloc((size_t)(7 * n));
+    pdmp_status st = buf.alloc((size_t)(8 * n));
     if (st != PDMP_OK) return st;
     int rc = pdmp::launch_math_probe(seed, n, buf.p, nullptr);
     if (rc != 0) return fail(PDMP_ERR_HIP, "math probe launch failed: %s", hipGetErrorString((hipError_t)rc));
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, buf.p, (size_t)(7 * n) * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, buf.p, (size_t)(8 * n) * sizeof(double), hipMemcpyDeviceToHost));
     return PDMP_OK;
 }
 
@@ -222,9 +224,8 @@ void pdmp_ensemble_destroy(pdmp_ensemble* e) {
     delete e;
 }
 
-pdmp_status pdmp_ensemble_set_flow_zigzag(pdmp_ensemble* e, const int64_t* colptr, const int64_t* rowval,
-                                          const double* nzval, const double* mu, const double* sigma,
-                                          double lambda_ref, double rho) {
+static pdmp_status set_flow_common(pdmp_ensemble* e, const int64_t* colptr, const int64_t* rowval, const double* nzval,
+                                   const double* mu, const double* sigma, double lambda_ref, double rho, int kind) {
     if (!e || !colptr || !rowval || !nzval) return fail(PDMP_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(e->cfg.device));
     const int64_t d = e->cfg.d;
@@ -335,8 +336,16 @@ pdmp_status pdmp_ensemble_set_flow_zigzag(pdmp_ensemble* e, const int64_t* colpt
     qptr[nnz] = (uint32_t)pos.size();
     if (pos.empty()) pos.push_back(0);
     if (pos16.empty()) pos16.push_back(0);
-    e->needs_general = general;
+    e->flow_kind = kind;
+    e->needs_general = general || kind == 1;  // FactBoomerang runs on the general kernel
     e->mmax_all = mmax_all;
+    {
+        std::vector<double> diag((size_t)d, 0.0);
+        for (int64_t i = 0; i < d; ++i) diag[i] = e->bval[e->colptr[i] + selfpos16[i]];
+        pdmp_status sd = e->d_diag.upload(diag);
+        if (sd != PDMP_OK) return sd;
+        if ((sd = e->d_mu.upload(e->mu)) != PDMP_OK) return sd;
+    }
 
     e->h_gmu_b = gmu;
     e->h_sptr = sptr;
@@ -368,6 +377,21 @@ pdmp_status pdmp_ensemble_set_flow_zigzag(pdmp_ensemble* e, const int64_t* colpt
     e->has_target = false;
     e->has_state = false;
     return PDMP_OK;
+}
+
+pdmp_status pdmp_ensemble_set_flow_zigzag(pdmp_ensemble* e, const int64_t* colptr, const int64_t* rowval,
+                                          const double* nzval, const double* mu, const double* sigma,
+                                          double lambda_ref, double rho) {
+    return set_flow_common(e, colptr, rowval, nzval, mu, sigma, lambda_ref, rho, 0);
+}
+
+pdmp_status pdmp_ensemble_set_flow_factboomerang(pdmp_ensemble* e, const int64_t* colptr, const int64_t* rowval,
+                                                 const double* nzval, const double* mu, const double* sigma,
+                                                 double lambda_ref, double rho) {
+    if (e && e->cfg.sampler != PDMP_SAMPLER_ZIGZAG_LOCAL)
+        return fail(PDMP_ERR_UNSUPPORTED, "FactBoomerang is available for the factorised driver spdmp (PDMP_SAMPLER_ZIGZAG_LOCAL)");
+    if (!(lambda_ref > 0)) return fail(PDMP_ERR_INVALID, "FactBoomerang needs a strictly positive refreshment rate");
+    return set_flow_common(e, colptr, rowval, nzval, mu, sigma, lambda_ref, rho, 1);
 }
 
 pdmp_status pdmp_ensemble_set_target_gaussian_csc(pdmp_ensemble* e, const int64_t* colptr, const int64_t* rowval,
@@ -581,9 +605,11 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
     std::vector<double> cv(c, c + d);
     if ((st = e->d_c.upload(cv)) != PDMP_OK) return st;
     if (e->needs_general || e->target_kind == 1) {
-        if (e->cfg.sampler != PDMP_SAMPLER_ZIGZAG_LOCAL || e->lambda_ref > 0)
+        if (e->cfg.sampler != PDMP_SAMPLER_ZIGZAG_LOCAL)
             return fail(PDMP_ERR_UNSUPPORTED,
-                        "neighbourhoods beyond 64 members / the logistic target run on the general kernel: spdmp without refresh only");
+                        "neighbourhoods beyond 64 members / the logistic target / FactBoomerang run on the general kernel: spdmp only");
+        if (e->target_kind == 1 && (e->flow_kind == 1 || e->lambda_ref > 0))
+            return fail(PDMP_ERR_UNSUPPORTED, "the logistic target is implemented for ZigZag without refresh");
         if (pdmp::zz_general_lds_bytes(e->nblk_pad, (e->mmax_all + 63u) & ~63u) > 160 * 1024)
             return fail(PDMP_ERR_UNSUPPORTED, "LDS budget exceeded by the general kernel");
         e->use_spec = false;
@@ -618,6 +644,9 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
     P.t0 = t0;
     P.lambda_ref = e->lambda_ref;
     P.has_refresh = e->lambda_ref > 0;
+    P.flow_kind = e->flow_kind;
+    P.mu = e->d_mu.p;
+    P.diag = e->d_diag.p;
     P.sticky = sticky ? 1 : 0;
     if (sticky) {
         if (e->d_thf.n != (size_t)(n * d) && (st = e->d_thf.alloc((size_t)(n * d))) != PDMP_OK) return st;
@@ -747,6 +776,10 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         Q.u0 = e->lg_u0.p;
         Q.gamma0 = e->lg_gamma0;
         Q.ksub = e->lg_k;
+        Q.flow_kind = e->flow_kind;
+        Q.mu = e->d_mu.p;
+        Q.diag = e->d_diag.p;
+        Q.rho = e->rho;
         int rcg = pdmp::launch_zz_general_run(P, Q, e->cfg.nchains, s);
         if (rcg != 0) return fail(PDMP_ERR_HIP, "zz_general_run launch failed: %s", hipGetErrorString((hipError_t)rcg));
         HIP_TRY(hipEventRecord(e->ev1, s));

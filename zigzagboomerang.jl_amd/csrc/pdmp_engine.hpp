@@ -111,6 +111,9 @@ struct ZzInitParams {
     int32_t has_refresh;
     int32_t sticky;  // src/ss_fact.jl:178-188: initial key = min(reflection proposal, hitting time of 0), flag f[i]
     double* thf;
+    int32_t flow_kind;               // 1: FactBoomerang bound ab (src/fact_samplers.jl:58-65)
+    const double* __restrict__ mu;   // [d]
+    const double* __restrict__ diag; // [d]
 };
 
 // General-degree local ZigZag (pdmp_general.hip): CSC tables instead of the blob, optional logistic target
@@ -130,6 +133,11 @@ struct ZzGeneralParams {
     const double* __restrict__ u0;           // idot(At, row, μ) per observation (control variate)
     double gamma0;
     int64_t ksub;
+    // flow_kind 1: FactBoomerang (src/types.jl:71-79)
+    int32_t flow_kind;
+    const double* __restrict__ mu;    // [d] flow mean
+    const double* __restrict__ diag;  // [d] Γ[i,i]
+    double rho;
 };
 int launch_zz_general_run(const ZzRunParams& p, const ZzGeneralParams& q, int64_t nchains, void* stream);
 size_t zz_general_lds_bytes(uint32_t nblk_pad, uint32_t mmax_pad);

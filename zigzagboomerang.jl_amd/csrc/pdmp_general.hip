@@ -74,7 +74,7 @@ __device__ __forceinline__ double g_sigmoid(double x) {
 }
 
 size_t zz_general_lds_bytes(uint32_t nblk_pad, uint32_t mmax_pad) {
-    return (size_t)nblk_pad * 8 + (size_t)2 * mmax_pad * 8 + (size_t)nblk_pad * 4;
+    return (size_t)nblk_pad * 8 + (size_t)3 * mmax_pad * 8 + (size_t)nblk_pad * 4;
 }
 
 __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGeneralParams Q) {
@@ -87,7 +87,8 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
     double* bk = reinterpret_cast<double*>(smem);
     double* sx = bk + P.nblk_pad;       // [mmax_pad] x of S[i] by position
     double* sth = sx + Q.mmax_pad;      // [mmax_pad] θ of S[i]
-    uint32_t* bi = reinterpret_cast<uint32_t*>(sth + Q.mmax_pad);
+    double* smu = sth + Q.mmax_pad;     // [mmax_pad] μ of S[i] (FactBoomerang)
+    uint32_t* bi = reinterpret_cast<uint32_t*>(smu + Q.mmax_pad);
 
     ZzRec* rec = P.rec + chain * d;
     double* keys = P.keys + chain * P.dk;
@@ -101,6 +102,10 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
     const uint64_t seed = hdr->seed;
     uint64_t nm = hdr->c.ndraw_main, ng = hdr->c.ndraw_global;
     uint64_t num = hdr->c.num, nacc = hdr->c.nacc, ntrace = hdr->c.ntrace, nevents = hdr->c.nevents;
+    uint64_t nrefresh = hdr->c.nrefresh;
+    const bool boom = Q.flow_kind == 1;
+    const bool has_refresh = P.has_refresh != 0;
+    const double rhobar = sqrt(1 - Q.rho * Q.rho);
     double t_last = hdr->c.t_last;
     double t_event = hdr->t_event;
     status = PDMP_CHAIN_OK;
@@ -156,15 +161,90 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
                 ZzRec* r = rec + j;
                 const double x0 = r->x, th0 = r->th, t0 = r->t, I0 = r->I;
                 const double dt = tp - t0;
-                const double xn = x0 + th0 * dt;  // smove_forward!, src/sfact.jl:6-12
-                r->x = xn;
-                r->t = tp;
-                r->I = I0 + dt * ((x0 + xn) * 0.5);
-                sx[pp] = xn;
-                sth[pp] = th0;
+                if (!boom) {
+                    const double xn = x0 + th0 * dt;  // smove_forward!, src/sfact.jl:6-12
+                    r->x = xn;
+                    r->t = tp;
+                    r->I = I0 + dt * ((x0 + xn) * 0.5);
+                    sx[pp] = xn;
+                    sth[pp] = th0;
+                } else {
+                    // smove_forward!(G, i, t, x, θ, t′, B::FactBoomerang), src/sfact.jl:29-36: rotation about μ
+                    const double mj = Q.mu[j];
+                    double sn, cs;
+                    pdmp_sincos(dt, &sn, &cs);
+                    const double xn = (x0 - mj) * cs + th0 * sn + mj;
+                    const double thn = -(x0 - mj) * sn + th0 * cs;
+                    r->x = xn;
+                    r->th = thn;
+                    r->t = tp;
+                    r->I = I0 + (mj * dt + (x0 - mj) * sn + th0 * (1.0 - cs));
+                    sx[pp] = xn;
+                    sth[pp] = thn;
+                    smu[pp] = mj;
+                }
             }
         }
         G_ORDER();
+    };
+    // stage members WITHOUT moving them (refresh branch: G1[i] is re-bounded at the coordinates' own clocks)
+    auto stage_members = [&](uint32_t sp0, uint32_t p0, uint32_t p1) {
+        for (uint32_t base = p0; base < p1; base += 64) {
+            const uint32_t pp = base + (uint32_t)lane;
+            if (pp < p1) {
+                const uint32_t j = P.tb.sidx[sp0 + pp];
+                sx[pp] = rec[j].x;
+                sth[pp] = rec[j].th;
+                if (boom) smu[pp] = Q.mu[j];
+            }
+        }
+        G_ORDER();
+    };
+    // ab + new event time for the members jj0 .. jj1 of G1[i]; own_clock: Q[j] = t[j] + ... at j's own (stale) clock
+    auto rebound = [&](uint32_t cp0, uint32_t jj0, uint32_t jj1, double tp, uint64_t draw0, bool per_member_draw,
+                       bool own_clock) {
+        for (uint32_t base = jj0; base < jj1; base += 64) {
+            const uint32_t jj = base + (uint32_t)lane;
+            if (jj < jj1) {
+                const uint32_t j = P.tb.rowval[cp0 + jj];
+                const uint32_t cj0 = P.tb.colptr[j];
+                const uint32_t kj = P.tb.colptr[j + 1] - cj0;
+                const uint32_t q0 = P.tb.qptr[cp0 + jj];
+                const double cj = cvec[j];
+                const double xj = sx[jj], thj = sth[jj];
+                double a, b;
+                if (!boom) {
+                    double gx = 0.0, gt = 0.0;
+                    for (uint32_t pp = 0; pp < kj; ++pp) {
+                        const double v = P.tb.bval[cj0 + pp];
+                        const uint32_t ps = Q.pos16[q0 + pp];
+                        gx += v * sx[ps];
+                        gt += v * sth[ps];
+                    }
+                    a = cj + (gx - P.tb.gmu_b[j]) * thj;  // src/fact_samplers.jl:51
+                    b = cj / 100 + thj * gt;             // :52
+                } else {
+                    double zz = 0.0;  // ab(G, i, x, θ, c, Z::FactBoomerang), src/fact_samplers.jl:58-65
+                    for (uint32_t pp = 0; pp < kj; ++pp) {
+                        const uint32_t ps = Q.pos16[q0 + pp];
+                        const double dx = sx[ps] - smu[ps];
+                        zz += dx * dx + sth[ps] * sth[ps];
+                    }
+                    const double z = sqrt(zz);
+                    const double z2 = xj * xj + thj * thj;
+                    a = cj * sqrt(z2) * z + z2 * Q.diag[j];
+                    b = 0.0;
+                }
+                ZzRec* r = rec + j;
+                const double tj = own_clock ? r->t : tp;
+                const uint64_t di = per_member_draw ? (draw0 + (uint64_t)jj) : draw0;
+                const double key = tj + g_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, di));
+                r->t_old = tj;
+                r->a = a;
+                r->b = b;
+                keys[j] = key;
+            }
+        }
     };
 
     bool running = stop_before || (t_event < T);
@@ -212,6 +292,60 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
         const double told_i = ri->t_old, a_i = ri->a, b_i = ri->b;
         const uint64_t acc_i = ri->acc;
 
+        if (has_refresh && i == (uint32_t)d) {
+            // ---------------- refresh clock, src/sfact.jl:78-114 (quirks restated: two independent global-rng coordinate
+            // draws :80,:84; G1[i] re-bounded at the coordinates' own clocks :110-114)
+            const uint32_t i1 = pdmp_randint(seed, PDMP_STREAM_GLOBAL, ng, (uint32_t)d);
+            ng += 1;
+            move_members(P.tb.sptr[i1], 0, P.tb.colptr[i1 + 1] - P.tb.colptr[i1], tp);  // :82
+            const uint32_t i2 = pdmp_randint(seed, PDMP_STREAM_GLOBAL, ng, (uint32_t)d);
+            ng += 1;
+            const uint32_t cp2 = P.tb.colptr[i2];
+            const uint32_t k2 = P.tb.colptr[i2 + 1] - cp2;
+            const uint32_t sp2 = P.tb.sptr[i2];
+            const uint32_t m2 = P.tb.sptr[i2 + 1] - sp2;
+            const uint32_t self2 = Q.selfpos16[i2];
+            move_members(sp2, k2, m2, tp);  // smove_forward!(G2, i, ...), :85
+            stage_members(sp2, 0, k2);
+            double thn;
+            if (boom) {  // :103  θ[i] = ρ θ[i] + ρ̄ σ[i] randn(rng)
+                thn = Q.rho * sth[self2] + rhobar * P.tb.sigma[i2] * pdmp_randn(seed, PDMP_STREAM_MAIN, nm);
+            } else {     // :100-101  θ[i] = σ[i] rand(rng, (-1,1))
+                thn = P.tb.sigma[i2] * ((pdmp_u01(seed, PDMP_STREAM_MAIN, nm) < 0.5) ? -1.0 : 1.0);
+            }
+            nm += 1;
+            G_ORDER();
+            if (lane == 0) {
+                sth[self2] = thn;
+                rec[i2].th = thn;
+            }
+            G_ORDER();
+            const double newref = tp + (-pdmp_log(pdmp_u01(seed, PDMP_STREAM_GLOBAL, ng))) / P.lambda_ref;  // :108
+            ng += 1;
+            rebound(cp2, 0, k2, tp, nm, true, true);  // :110-114
+            nm += (uint64_t)k2;
+            if (lane == 0) keys[d] = newref;
+            for (uint32_t jj = 0; jj <= k2; ++jj) {
+                const uint32_t j = (jj < k2) ? P.tb.rowval[cp2 + jj] : (uint32_t)d;
+                const double kj = __hip_atomic_load(keys + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                queue_update(g_uniform(j), kj);
+            }
+            if (ev && lane == 0) {  // event(i, t, x, θ, F) = (t[i], i, x[i], θ[i]) at i's own clock, :143
+                pdmp_event e;
+                e.t = __hip_atomic_load(&rec[i2].t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                e.i = (int64_t)i2;
+                e.x = sx[self2];
+                e.theta = thn;
+                ev[ntrace] = e;
+            }
+            nrefresh += 1;
+            ntrace += 1;
+            nevents += 1;
+            t_event = tp;
+            if (!stop_before && !(tp < T)) running = false;
+            G_ORDER();
+            continue;
+        }
         move_members(sp0, 0, k, tp);  // smove_forward!(G, i, ...), :82
         // ---------------- gradient
         double g;
@@ -261,7 +395,8 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
             g = prior - s;
         }
         const double th_i = sth[self];
-        const double l_rate = g_pos(g * th_i);                       // :119
+        const double l_rate = boom ? g_pos((g - (sx[self] - Q.mu[i]) * Q.diag[i]) * th_i)  // src/fact_samplers.jl:37-39
+                                   : g_pos(g * th_i);                                        // :119
         const double lbound = g_pos(a_i + b_i * (tp - told_i));     // :119
         num += 1;
         const double ucoin = pdmp_u01(seed, PDMP_STREAM_MAIN, nm);  // :121
@@ -287,33 +422,7 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
         // ---------------- re-bound: all of G1[i] on accept (:131-135), i alone on reject (:137-139)
         const uint32_t jj0 = accept ? 0u : self;
         const uint32_t jj1 = accept ? k : self + 1u;
-        for (uint32_t base = jj0; base < jj1; base += 64) {
-            const uint32_t jj = base + (uint32_t)lane;
-            if (jj < jj1) {
-                const uint32_t j = P.tb.rowval[cp0 + jj];
-                const uint32_t cj0 = P.tb.colptr[j];
-                const uint32_t kj = P.tb.colptr[j + 1] - cj0;
-                const uint32_t q0 = P.tb.qptr[cp0 + jj];
-                double gx = 0.0, gt = 0.0;
-                for (uint32_t pp = 0; pp < kj; ++pp) {
-                    const double v = P.tb.bval[cj0 + pp];
-                    const uint32_t ps = Q.pos16[q0 + pp];
-                    gx += v * sx[ps];
-                    gt += v * sth[ps];
-                }
-                const double cj = cvec[j];
-                const double thj = sth[jj];
-                const double a = cj + (gx - P.tb.gmu_b[j]) * thj;  // src/fact_samplers.jl:51
-                const double b = cj / 100 + thj * gt;             // :52
-                const uint64_t di = accept ? (nm + (uint64_t)jj) : nm;
-                const double key = tp + g_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, di));
-                ZzRec* r = rec + j;
-                r->t_old = tp;
-                r->a = a;
-                r->b = b;
-                keys[j] = key;
-            }
-        }
+        rebound(cp0, jj0, jj1, tp, nm, accept, false);
         nm += accept ? (uint64_t)k : 1u;
         // ---------------- level 1 of the queue (keys[] already hold the new values)
         for (uint32_t jj = jj0; jj < jj1; ++jj) {
@@ -347,6 +456,7 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
         hdr->c.nevents = nevents;
         hdr->c.ndraw_main = nm;
         hdr->c.ndraw_global = ng;
+        hdr->c.nrefresh = nrefresh;
         hdr->c.status = status;
     }
 }

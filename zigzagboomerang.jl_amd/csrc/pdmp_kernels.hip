@@ -139,8 +139,21 @@ __global__ __launch_bounds__(256) void zz_init_kernel(ZzInitParams P) {
         }
         const double ci = P.tb.c_shared[i];
         if (P.c_chain) P.c_chain[chain * d + i] = ci;
-        const double a = ci + (gx - P.tb.gmu_b[i]) * thi;  // src/fact_samplers.jl:51
-        const double b = ci / 100 + thi * gt;             // :52
+        double a = ci + (gx - P.tb.gmu_b[i]) * thi;  // src/fact_samplers.jl:51
+        double b = ci / 100 + thi * gt;             // :52
+        if (P.flow_kind == 1) {  // ab(G, i, x, θ, c, Z::FactBoomerang), src/fact_samplers.jl:58-65
+            double zz = 0.0;
+            for (uint32_t p = P.tb.colptr[i]; p < P.tb.colptr[i + 1]; ++p) {
+                const uint32_t r = P.tb.rowval[p];
+                const double dx = x_of(r) - P.mu[r];
+                const double tr = th_of(r);
+                zz += dx * dx + tr * tr;
+            }
+            const double z = sqrt(zz);
+            const double z2 = xi * xi + thi * thi;
+            a = ci * sqrt(z2) * z + z2 * P.diag[i];
+            b = 0.0;
+        }
         double key = dev_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, (uint64_t)i));  // :186
         uint64_t fflag = 0;
         if (P.sticky) {
@@ -1698,6 +1711,11 @@ __global__ __launch_bounds__(256) void math_probe_kernel(uint64_t seed, int64_t 
     out[4 * n + k] = dev_poisson_time(a, b, w);
     out[5 * n + k] = pdmp_randn(seed, 3u, (uint64_t)k);
     out[6 * n + k] = pdmp_exp((u - 0.5) * 60.0 + v);
+    {
+        double sn_, cs_;
+        pdmp_sincos((w - 0.5) * 400.0, &sn_, &cs_);
+        out[7 * n + k] = sn_ + 2.0 * cs_;
+    }
 }
 
 int launch_math_probe(uint64_t seed, int64_t n, double* out, void* stream) {

@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .flows import BouncyParticle, GaussianTarget, LogisticTarget, ZigZag
+from .flows import BouncyParticle, FactBoomerang, GaussianTarget, LogisticTarget, ZigZag
 
 
 def _i64(a):
@@ -61,8 +61,8 @@ class Ensemble:
             raise ValueError("flow Γ has the wrong shape")
         cp, rv, nz = _i64(G.indptr), _i64(G.indices), _f64(G.data)
         mu, sg = _f64(F.μ), _f64(F.σ)
-        _lib.check(self._L.pdmp_ensemble_set_flow_zigzag(self._h, _ptr(cp), _ptr(rv), _ptr(nz), _ptr(mu), _ptr(sg),
-                                                        float(F.λref), float(F.ρ)))
+        fn = self._L.pdmp_ensemble_set_flow_factboomerang if isinstance(F, FactBoomerang) else self._L.pdmp_ensemble_set_flow_zigzag
+        _lib.check(fn(self._h, _ptr(cp), _ptr(rv), _ptr(nz), _ptr(mu), _ptr(sg), float(F.λref), float(F.ρ)))
 
     def set_sticky(self, kappa, reversible=False, strong_upperbounds=False):
         kappa = _f64(kappa).reshape(self.d)

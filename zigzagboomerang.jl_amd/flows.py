@@ -44,6 +44,24 @@ class ZigZag:
 
 
 @dataclass
+class FactBoomerang:
+    """FactBoomerang(Γ, μ, λ, σ=diag(Γ).^(-0.5); ρ=0.0) -- src/types.jl:71-79: factorised Boomerang dynamics preserving
+    N(μ, inv(Diagonal(Γ))), refreshment rate λ > 0."""
+    Γ: sp.csc_matrix
+    μ: np.ndarray
+    λref: float
+    σ: Optional[np.ndarray] = None
+    ρ: float = 0.0
+
+    def __post_init__(self):
+        self.Γ = _csc(self.Γ)
+        self.μ = np.ascontiguousarray(self.μ, dtype=np.float64)
+        if self.σ is None:
+            self.σ = np.asarray(self.Γ.diagonal(), dtype=np.float64) ** (-0.5)
+        self.σ = np.ascontiguousarray(self.σ, dtype=np.float64)
+
+
+@dataclass
 class BouncyParticle:
     """BouncyParticle(Γ, μ, λ; ρ=0.0) -- src/types.jl:35-45 (mass L = cholesky(Symmetric(Γ)).L)."""
     Γ: sp.csc_matrix

@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _lib
 from .engine import Ensemble
-from .flows import BouncyParticle, FactTrace, GaussianTarget, LogisticTarget, PDMPTrace, ZigZag
+from .flows import BouncyParticle, FactBoomerang, FactTrace, GaussianTarget, LogisticTarget, PDMPTrace, ZigZag
 
 DEFAULT_SEED = 0x5EED0000
 
@@ -55,8 +55,8 @@ def sspdmp(target, t0, x0, θ0, T, c, F, κ, *, reversible=False, strong_upperbo
 
 
 def _zigzag(sampler, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, trace_capacity, trace, sticky=None):
-    if not isinstance(F, ZigZag):
-        raise TypeError("the device path supports F::ZigZag")
+    if not isinstance(F, (ZigZag, FactBoomerang)):
+        raise TypeError("the device path supports F::ZigZag and F::FactBoomerang")
     if not isinstance(target, (GaussianTarget, LogisticTarget)):
         raise TypeError("target must be one of the device-resident families (GaussianTarget, LogisticTarget)")
     x0 = np.asarray(x0, dtype=np.float64)

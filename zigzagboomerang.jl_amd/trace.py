@@ -5,7 +5,19 @@ are the callers' post-processing, not part of the device hot pat
 """
 import numpy as np
 
-from .flows import FactTrace
+from .flows import FactBoomerang, FactTrace
+
+
+def _flow(tr, x, th, dt):
+    """move_forward!(dt, ...) in place: linear for ZigZag (src/dynamics.jl:11-15), rotation about μ for FactBoomerang (:29-36)."""
+    if isinstance(tr.F, FactBoomerang):
+        mu = tr.F.μ
+        s, c = np.sin(dt), np.cos(dt)
+        xn = (x - mu) * c + th * s + mu
+        th[:] = -(x - mu) * s + th * c
+        x[:] = xn
+    else:
+        x += th * dt
 
 
 def collect(tr: FactTrace):
@@ -42,12 +54,12 @@ def discretize(tr: FactTrace, dt):
                 break
             ti = ev["t"][k]
             if t + step < ti:
-                x += th * step
+                _flow(tr, x, th, step)
                 t += step
                 break
             d_t = ti - t
             step -= d_t
-            x += th * d_t
+            _flow(tr, x, th, d_t)
             t = ti
             i = ev["i"][k]
             x[i] = ev["x"][k]
