@@ -30,22 +30,24 @@ def test_dense_ish_gaussian_needs_the_general_kernel(gpu_pkg):
         assert np.array_equal(x[k], r["x"]) and np.array_equal(th[k], r["theta"]) and np.array_equal(t[k], r["t"])
 
 
-def test_config_c4_logistic_subsampled_matches_oracle(gpu_pkg):
-    """scripts/logistic.jl:167: spdmp(∇ϕmoving, t0, x0, θ0, T, c, Zdrop, SelfMoving(), A, At, μ, y, ny, 10; adapt=true, factor=5)."""
+@pytest.mark.parametrize("ksub,T", [(10, 4.0), (40, 1.5), (70, 1.0)])
+def test_config_c4_logistic_subsampled_matches_oracle(gpu_pkg, ksub, T):
+    """scripts/logistic.jl:167: spdmp(∇ϕmoving, t0, x0, θ0, T, c, Zdrop, SelfMoving(), A, At, μ, y, ny, 10; adapt=true, factor=5).
+    k = 40 and 70 push the sampled rows' entries past one 64-lane chunk / the rows past one wavefront."""
     pkg = gpu_pkg
     P = pkg.problems.logistic_problem(m=20)
-    nch, T = 3, 4.0
+    nch = 3
     rng = np.random.default_rng(0)
     X0 = np.tile(P["x0"], (nch, 1))
     TH0 = P["sigma"] * rng.choice([-1.0, 1.0], (nch, P["p"]))
     Z = pkg.ZigZag(P["Gdrop"], P["mu"], P["sigma"])
-    target = pkg.LogisticTarget(P["A"], P["y"], P["ny"], P["mu"], P["gamma0"], 10)
+    target = pkg.LogisticTarget(P["A"], P["y"], P["ny"], P["mu"], P["gamma0"], ksub)
     tr, (t, x, th), (acc, num), cout = pkg.spdmp(target, 0.0, X0, TH0, T, P["c"], Z, seed=31, adapt=True, factor=5.0)
-    lg = dict(A=P["A"], At=P["At"], y=P["y"], ny=P["ny"], mu=P["mu"], gamma0=P["gamma0"], k=10)
+    lg = dict(A=P["A"], At=P["At"], y=P["y"], ny=P["ny"], mu=P["mu"], gamma0=P["gamma0"], k=ksub)
     for k in range(nch):
         r = O.spdmp_zigzag(P["Gdrop"], P["mu"], P["Gdrop"], X0[k], TH0[k], P["c"], T, seed=31 + k, adapt=True, factor=5.0,
                            logistic=lg, sigma=P["sigma"])
-        assert r["status"] == 0 and len(r["events"]) > 100
+        assert r["status"] == 0 and len(r["events"]) > 30
         assert len(tr[k].events) == len(r["events"]), (k, len(tr[k].events), len(r["events"]))
         for f in ("i", "t", "x", "theta"):
             assert np.array_equal(tr[k].events[f], r["events"][f]), (k, f)

@@ -15,6 +15,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "../../include/pdmp_detmath.h"
 #include "pdmp_engine.hpp"
 
 namespace {
@@ -111,7 +112,7 @@ struct pdmp_ensemble {
     int target_kind = 0;
     DevBuf<uint16_t> d_pos16, d_selfpos16;
     DevBuf<int64_t> lg_Acp, lg_Arv, lg_Atcp, lg_Atrv;
-    DevBuf<double> lg_Anz, lg_Atnz, lg_y, lg_ny, lg_u0;
+    DevBuf<double> lg_Anz, lg_Atnz, lg_y, lg_ny, lg_u0, lg_ns0;
     double lg_gamma0 = 0.0;
     int64_t lg_k = 0;
     // sticky ZigZag
@@ -544,14 +545,17 @@ extern "C" pdmp_status pdmp_ensemble_set_target_logistic(pdmp_ensemble* e, int64
     for (int64_t j = 0; j < p; ++j)
         if (A_colptr[j + 1] <= A_colptr[j])
             return fail(PDMP_ERR_UNSUPPORTED, "coordinate %lld has no observation (rand over an empty range)", (long long)j);
-    std::vector<double> u0((size_t)n, 0.0);  // idot(At, row, μ), src/common.jl:16-24 order
+    // control-variate terms sigmoidn(u0), nsigmoid(u0) with u0 = idot(At, row, μ) (src/common.jl:16-24 order): constants of
+    // the observation, evaluated here with the SAME deterministic exp the kernels use (bit-identical on x86-64 and gfx950)
+    std::vector<double> sn0((size_t)n, 0.0), ns0((size_t)n, 0.0);
     for (int64_t r = 0; r < n; ++r) {
         double s = 0.0;
         for (int64_t q = At_colptr[r]; q < At_colptr[r + 1]; ++q) {
             if (At_rowval[q] < 0 || At_rowval[q] >= p) return fail(PDMP_ERR_INVALID, "At row index out of range");
             s += At_nzval[q] * mu[At_rowval[q]];
         }
-        u0[r] = s;
+        sn0[r] = 1.0 / (1.0 + pdmp_exp(s));     // sigmoidn(u0) = sigmoid(-u0) = inv(1 + exp(u0))
+        ns0[r] = -(1.0 / (1.0 + pdmp_exp(-s)));  // nsigmoid(u0) = -sigmoid(u0)
     }
     pdmp_status st;
     if ((st = e->lg_Acp.upload(std::vector<int64_t>(A_colptr, A_colptr + p + 1))) != PDMP_OK) return st;
@@ -562,7 +566,8 @@ extern "C" pdmp_status pdmp_ensemble_set_target_logistic(pdmp_ensemble* e, int64
     if ((st = e->lg_Atnz.upload(std::vector<double>(At_nzval, At_nzval + nnzAt))) != PDMP_OK) return st;
     if ((st = e->lg_y.upload(std::vector<double>(y, y + n))) != PDMP_OK) return st;
     if ((st = e->lg_ny.upload(std::vector<double>(ny, ny + n))) != PDMP_OK) return st;
-    if ((st = e->lg_u0.upload(u0)) != PDMP_OK) return st;
+    if ((st = e->lg_u0.upload(sn0)) != PDMP_OK) return st;
+    if ((st = e->lg_ns0.upload(ns0)) != PDMP_OK) return st;
     // the kernels' table struct wants tval / gmu_t allocated even if unused
     if ((st = e->d_tval.upload(std::vector<double>((size_t)e->nnz, 0.0))) != PDMP_OK) return st;
     if ((st = e->d_gmu_t.upload(std::vector<double>((size_t)p, 0.0))) != PDMP_OK) return st;
@@ -773,7 +778,8 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         Q.At_nzval = e->lg_Atnz.p;
         Q.y = e->lg_y.p;
         Q.ny = e->lg_ny.p;
-        Q.u0 = e->lg_u0.p;
+        Q.sn0 = e->lg_u0.p;
+        Q.ns0 = e->lg_ns0.p;
         Q.gamma0 = e->lg_gamma0;
         Q.ksub = e->lg_k;
         Q.flow_kind = e->flow_kind;

@@ -130,7 +130,8 @@ struct ZzGeneralParams {
     const double* __restrict__ At_nzval;
     const double* __restrict__ y;
     const double* __restrict__ ny;
-    const double* __restrict__ u0;           // idot(At, row, μ) per observation (control variate)
+    const double* __restrict__ sn0;          // sigmoidn(idot(At, row, μ)) per observation (control variate, tabulated on the host)
+    const double* __restrict__ ns0;          // nsigmoid(idot(At, row, μ))
     double gamma0;
     int64_t ksub;
     // flow_kind 1: FactBoomerang (src/types.jl:71-79)

@@ -74,7 +74,7 @@ __device__ __forceinline__ double g_sigmoid(double x) {
 }
 
 size_t zz_general_lds_bytes(uint32_t nblk_pad, uint32_t mmax_pad) {
-    return (size_t)nblk_pad * 8 + (size_t)3 * mmax_pad * 8 + (size_t)nblk_pad * 4;
+    return (size_t)nblk_pad * 8 + (size_t)3 * mmax_pad * 8 + (size_t)nblk_pad * 4 + 64 * 8;
 }
 
 __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGeneralParams Q) {
@@ -89,6 +89,7 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
     double* sth = sx + Q.mmax_pad;      // [mmax_pad] θ of S[i]
     double* smu = sth + Q.mmax_pad;     // [mmax_pad] μ of S[i] (FactBoomerang)
     uint32_t* bi = reinterpret_cast<uint32_t*>(smu + Q.mmax_pad);
+    double* sprod = reinterpret_cast<double*>(bi + P.nblk_pad);  // [64] products A'[e, row] * x[e] of one chunk
 
     ZzRec* rec = P.rec + chain * d;
     double* keys = P.keys + chain * P.dk;
@@ -349,6 +350,7 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
         move_members(sp0, 0, k, tp);  // smove_forward!(G, i, ...), :82
         // ---------------- gradient
         double g;
+        double urow = 0.0;
         if (Q.target_kind == 0) {  // ∇ϕ(x, i) = idot(Γt, i, x) [- idot(Γt, i, μt)]
             g = 0.0;
             for (uint32_t p = 0; p < k; ++p) g += P.tb.tval[cp0 + p] * sx[p];
@@ -359,39 +361,76 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
             double s = 0.0;
             const int64_t r0 = Q.A_colptr[i];
             const int64_t l = Q.A_colptr[i + 1] - r0;
-            for (int64_t q = 0; q < Q.ksub; ++q) {
-                const int64_t ii = r0 + (int64_t)pdmp_randint(seed, PDMP_STREAM_GLOBAL, ng, (uint32_t)l);  // rand(sampler)
-                ng += 1;
+            // The k_sub sampled observations are handled 64 at a time, one per lane: the draws, the row look-ups and the
+            // sigmoids run side by side; only the sums keep the reference's order (u over a row's entries, s over q).
+            // Moving a coordinate twice to the same t′ is the identity (dt = 0), so rows that share coordinates may move
+            // them concurrently: every lane writes the same values.
+            for (int64_t qb = 0; qb < Q.ksub; qb += 64) {
+                const int nq = (int)((Q.ksub - qb < 64) ? (Q.ksub - qb) : 64);
+                const bool qa = lane < nq;
+                // rand(sampler): draw ng + q of the global-rng stream
+                const uint32_t rdraw = pdmp_randint(seed, PDMP_STREAM_GLOBAL, ng + (uint64_t)qb + (uint64_t)lane, (uint32_t)l);
+                const int64_t ii = r0 + (int64_t)(qa ? rdraw : 0u);
                 const int64_t row = Q.A_rowval[ii];
                 const double v = Q.A_nzval[ii];
-                // idot_moving!(At, row, t, x, θ, t′, F), src/common.jl:33-42: move the row's coordinates, then dot
                 const int64_t e0 = Q.At_colptr[row];
-                const int ne = (int)(Q.At_colptr[row + 1] - e0);
-                double u = 0.0;
-                for (int eb = 0; eb < ne; eb += 64) {
-                    const int e = eb + lane;
-                    double xe = 0.0, we = 0.0;
-                    if (e < ne) {
-                        const int64_t cc = Q.At_rowval[e0 + e];
-                        we = Q.At_nzval[e0 + e];
+                const int ne = qa ? (int)(Q.At_colptr[row + 1] - e0) : 0;
+                const double yr = Q.y[row], nyr = Q.ny[row], sn0 = Q.sn0[row], ns0 = Q.ns0[row];
+                int incl = ne;  // inclusive scan of the row lengths over the lanes
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int o = __shfl_up(incl, off, 64);
+                    if (lane >= off) incl += o;
+                }
+                const int etot = __builtin_amdgcn_readlane(incl, 63);
+                const int excl = incl - ne;
+                // idot_moving!(At, row, t, x, θ, t′, F), src/common.jl:33-42: move the rows' coordinates; products to LDS
+                for (int fb = 0; fb < etot; fb += 64) {
+                    const int f = fb + lane;
+                    int q = 0;
+                    for (int z = 0; z < nq; ++z) q += (__builtin_amdgcn_readlane(incl, z) <= f) ? 1 : 0;
+                    q = (q < nq) ? q : (nq - 1);
+                    const int exq = __shfl(excl, q, 64);
+                    const int e0lo = __shfl((int)(uint32_t)(uint64_t)e0, q, 64);
+                    const int e0hi = __shfl((int)(uint32_t)((uint64_t)e0 >> 32), q, 64);
+                    if (f < etot) {
+                        const int64_t eq = (int64_t)(((uint64_t)(uint32_t)e0hi << 32) | (uint64_t)(uint32_t)e0lo) + (int64_t)(f - exq);
+                        const int64_t cc = Q.At_rowval[eq];
+                        const double we = Q.At_nzval[eq];
                         ZzRec* r = rec + cc;
                         const double x0 = r->x, th0 = r->th, t0 = r->t, I0 = r->I;
                         const double dt = tp - t0;
-                        xe = x0 + th0 * dt;
+                        const double xe = x0 + th0 * dt;
                         r->x = xe;
                         r->t = tp;
                         r->I = I0 + dt * ((x0 + xe) * 0.5);
+                        sprod[lane] = we * xe;
                     }
-                    const int cnt = (ne - eb < 64) ? (ne - eb) : 64;
-                    for (int z = 0; z < cnt; ++z) u += g_readlane(we, z) * g_readlane(xe, z);
+                    G_ORDER();
+                    // every lane continues the running sum of its row over the entries of this chunk, in entry order
+                    {
+                        const int z0 = (excl > fb) ? excl : fb, z1 = (incl < fb + 64) ? incl : (fb + 64);
+                        if (z0 < z1) {
+                            double u = (excl >= fb) ? 0.0 : urow;
+                            for (int z = z0; z < z1; ++z) u += sprod[z - fb];
+                            urow = u;
+                        }
+                    }
+                    G_ORDER();
                 }
+                const double u = (ne > 0) ? urow : 0.0;
                 const double w = (double)l / (double)Q.ksub * v;
-                const double yr = Q.y[row], nyr = Q.ny[row], u0 = Q.u0[row];
-                s += w * yr * g_sigmoid(-u);        // sigmoidn(u) = sigmoid(-u)
-                s += w * nyr * (-g_sigmoid(u));     // nsigmoid(u) = -sigmoid(u)
-                s -= w * yr * g_sigmoid(-u0);
-                s -= w * nyr * (-g_sigmoid(u0));
+                const double t1 = w * yr * g_sigmoid(-u);     // sigmoidn(u) = sigmoid(-u)
+                const double t2 = w * nyr * (-g_sigmoid(u));  // nsigmoid(u) = -sigmoid(u)
+                const double t3 = w * yr * sn0;               // sigmoidn(u0), u0 = idot(At, row, μ): tabulated per observation
+                const double t4 = w * nyr * ns0;              // nsigmoid(u0)
+                for (int z = 0; z < nq; ++z) {
+                    s += g_readlane(t1, z);
+                    s += g_readlane(t2, z);
+                    s -= g_readlane(t3, z);
+                    s -= g_readlane(t4, z);
+                }
             }
+            ng += (uint64_t)Q.ksub;
             g = prior - s;
         }
         const double th_i = sth[self];
