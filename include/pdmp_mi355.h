@@ -212,6 +212,18 @@ pdmp_status pdmp_ensemble_batch_means(pdmp_ensemble* ens, double T_prev, double 
  */
 pdmp_status pdmp_ensemble_set_sticky(pdmp_ensemble* ens, const double* kappa, int reversible, int strong_upperbounds);
 
+/* ------------------------------------------------------------------ adaptscale (σ tuning in the refresh branch)
+ *
+ * spdmp(...; adaptscale=true) (src/sfact.jl:74,86-99,163): each refresh of coordinate i first retunes F.σ[i] -- ZigZag:
+ * log σ[i] is pulled towards 0.3 accepted reflections per unit time and θ[i] = σ[i]·sign(θ[i]) is set WITHOUT a random draw
+ * (:87-91); FactBoomerang: σ[i] *= exp(±0.03·min(1, √(τ/λref))) once τ = (1+2ρ/(1−ρ))/(t[i]·λref) < 0.2 (:93-98).  The
+ * reference mutates F.σ in place; here σ becomes per-chain device state, initialised from the flow's sigma at set_state
+ * and read back with pdmp_ensemble_final_sigma ([n x d]).  Needs a refresh clock (lambda_ref > 0), PDMP_SAMPLER_ZIGZAG_LOCAL
+ * and the Gaussian target.  Call after set_flow_* and before set_state.  x^y is evaluated as pdmp_exp(y·pdmp_log x).
+ */
+pdmp_status pdmp_ensemble_set_adaptscale(pdmp_ensemble* ens, int enable);
+pdmp_status pdmp_ensemble_final_sigma(pdmp_ensemble* ens, int64_t chain_first, int64_t n, double* sigma);
+
 /* ------------------------------------------------------------------ Bouncy particle sampler (PDMP_SAMPLER_BPS)
  *
  * pdmp(∇ϕ!, t0, x0, θ0, T, c, B::BouncyParticle; adapt, factor=2.0) -> Ξ::PDMPTrace, (t, x, θ), (acc, num), c

@@ -449,6 +449,11 @@ int orc_spdmp_zigzag(int64_t d, const orc_zz_params* p, double t0, double T, dou
             if (p->bound_gamma->rowval[q] == i) fdiag[i] = p->bound_gamma->nzval[q];
     }
     const double rhobar = sqrt(1 - p->rho * p->rho);
+    double* sig = NULL; /* F.σ: mutable under adaptscale */
+    if (p->sigma) {
+        sig = (double*)malloc((size_t)d * sizeof(double));
+        memcpy(sig, p->sigma, (size_t)d * sizeof(double));
+    }
 #define FLOW_AB(j, aa, bb)                                                             \
     do {                                                                               \
         if (kind)                                                                      \
@@ -509,13 +514,32 @@ int orc_spdmp_zigzag(int64_t d, const orc_zz_params* p, double t0, double T, dou
             if (refresh) {
                 i = (int64_t)pdmp_randint(seed, PDMP_STREAM_GLOBAL, ng++, (uint32_t)d); /* :84 */
                 if (!p->move_all) flow_move_nbrs(kind, fmu, &cx.g2, i, t, x, th, tp);    /* :85 */
-                if (kind) {
-                    /* :103  θ[i] = F.ρ*θ[i] + F.ρ̄*F.σ[i]*randn(rng, eltype(θ)) */
-                    th[i] = p->rho * th[i] + rhobar * p->sigma[i] * pdmp_randn(seed, PDMP_STREAM_MAIN, nm++);
+                if (p->adaptscale && !kind) { /* :86-91 */
+                    const double adapt_g = 0.01, adapt_t0 = 15., adapt_k = 0.75;
+                    const double pre = pdmp_log(2.0) - sqrt(1.0 + tp) / (adapt_g * (1.0 + tp + adapt_t0)) *
+                                                           pdmp_log((double)(1 + acc[i]) / (1.0 + 0.3 * tp));
+                    const double eta = pdmp_exp(-adapt_k * pdmp_log(1 + tp)); /* (1 + t′)^(-adapt_κ) */
+                    sig[i] = pdmp_exp(eta * pre + (1 - eta) * pdmp_log(sig[i]));
+                    th[i] = sig[i] * ((th[i] > 0) ? 1.0 : ((th[i] < 0) ? -1.0 : th[i])); /* σ[i]*sign(θ[i]) */
                 } else {
-                    /* :100-101  θ[i] = F.σ[i]*rand(rng, (-1,1)) */
-                    double u = pdmp_u01(seed, PDMP_STREAM_MAIN, nm++);
-                    th[i] = p->sigma[i] * ((u < 0.5) ? -1.0 : 1.0);
+                    if (p->adaptscale) { /* :93-98 */
+                        const double effi = (1 + 2 * p->rho / (1 - p->rho));
+                        const double tau = effi / (t[i] * p->lambda_ref);
+                        if (tau < 0.2) {
+                            const double r = 0.3 * t[i] / (double)acc[i];
+                            const double dir = (double)((r > 1.66) - (r < 0.6));
+                            const double sq = sqrt(tau / p->lambda_ref);
+                            sig[i] = sig[i] * pdmp_exp(dir * 0.03 * ((1.0 < sq) ? 1.0 : sq));
+                        }
+                    }
+                    if (kind) {
+                        /* :103  θ[i] = F.ρ*θ[i] + F.ρ̄*F.σ[i]*randn(rng, eltype(θ)) */
+                        th[i] = p->rho * th[i] + rhobar * sig[i] * pdmp_randn(seed, PDMP_STREAM_MAIN, nm++);
+                    } else {
+                        /* :100-101  θ[i] = F.σ[i]*rand(rng, (-1,1)) */
+                        double u = pdmp_u01(seed, PDMP_STREAM_MAIN, nm++);
+                        th[i] = sig[i] * ((u < 0.5) ? -1.0 : 1.0);
+                    }
                 }
                 /* :108  Q[n+1] = t′ + waiting_time_ref(F)  (global rng) */
                 orc_pq_set(Q, d, tp + (-pdmp_log(pdmp_u01(seed, PDMP_STREAM_GLOBAL, ng++)) / p->lambda_ref));
@@ -577,6 +601,8 @@ int orc_spdmp_zigzag(int64_t d, const orc_zz_params* p, double t0, double T, dou
         res->t_last = tp;
         res->status = status;
     }
+    if (p->sigma_out && sig) memcpy(p->sigma_out, sig, (size_t)d * sizeof(double));
+    free(sig);
     orc_pq_free(Q);
     free(t_old);
     free(ba);

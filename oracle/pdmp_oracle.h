@@ -111,6 +111,12 @@ typedef struct {
      * events (src/sfact.jl:29-36), rate (∇ϕi − (x_i−μ_i)Γ_ii)θ_i (src/fact_samplers.jl:37-39), constant bound a = c_i√z2·z + z2·Γ_ii,
      * b = 0 (:58-65), mandatory refresh θ_i = ρθ_i + ρ̄σ_i·randn (src/sfact.jl:103; hasrefresh, src/fact_samplers.jl:18). */
     int flow_kind;
+    /* adaptscale = true (src/sfact.jl:86-99): the refresh branch retunes σ[i] before redrawing θ[i].  ZigZag: Robbins-Monro
+     * style update of log σ[i] towards 0.3 accepted reflections per unit time, then θ[i] = σ[i]·sign(θ[i]) WITHOUT a random
+     * draw (:87-91); FactBoomerang: σ[i] *= exp(±0.03·min(1, √(τ/λref))) when τ = (1+2ρ/(1−ρ))/(t[i]·λref) < 0.2 (:93-98).
+     * σ is then per-chain state: sigma_out (d, may be NULL) receives the final values.  `^` is exp(y·log x) here. */
+    int adaptscale;
+    double* sigma_out;
 } orc_zz_params;
 
 typedef struct {

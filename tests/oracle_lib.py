@@ -47,7 +47,7 @@ class _ZZParams(C.Structure):
                 ("seed", C.c_uint64), ("max_events", C.c_int64), ("stop_before_T", C.c_int),
                 ("target_kind", C.c_int), ("lg_A", C.POINTER(_Csc)), ("lg_At", C.POINTER(_Csc)), ("lg_y", C.c_void_p),
                 ("lg_ny", C.c_void_p), ("lg_mu", C.c_void_p), ("lg_gamma0", C.c_double), ("lg_k", C.c_int64),
-                ("flow_kind", C.c_int)]
+                ("flow_kind", C.c_int), ("adaptscale", C.c_int), ("sigma_out", C.c_void_p)]
 
 
 class _ZZResult(C.Structure):
@@ -190,7 +190,8 @@ def idot(A, j, x):
 
 def spdmp_zigzag(bound_gamma, bound_mu, target_gamma, x0, theta0, c, T, *, t0=0.0, target_mu=None,
                  sigma=None, lambda_ref=0.0, rho=0.0, move_all=False, adapt=False, factor=1.8, seed=1,
-                 max_events=0, stop_before_T=False, want_trace=True, logistic=None, factboomerang=False):
+                 max_events=0, stop_before_T=False, want_trace=True, logistic=None, factboomerang=False,
+                 adaptscale=False):
     """Local ZigZag (reference spdmp / pdmp for ZigZag).  Returns dict(events, t, x, theta, acc, num, c, ...)."""
     L = lib()
     gb = bound_gamma if isinstance(bound_gamma, CscHolder) else CscHolder(bound_gamma)
@@ -203,6 +204,9 @@ def spdmp_zigzag(bound_gamma, bound_mu, target_gamma, x0, theta0, c, T, *, t0=0.
                   tmu.ctypes.data if tmu is not None else None, int(move_all), int(adapt), factor, seed,
                   max_events, int(stop_before_T))
     p.flow_kind = 1 if factboomerang else 0
+    sg_out = np.array(sg)
+    p.adaptscale = int(adaptscale)
+    p.sigma_out = sg_out.ctypes.data
     if logistic is not None:  # dict(A, At, y, ny, mu, gamma0, k): target_kind 1
         lA = logistic["A"] if isinstance(logistic["A"], CscHolder) else CscHolder(logistic["A"])
         lAt = logistic["At"] if isinstance(logistic["At"], CscHolder) else CscHolder(logistic["At"])
@@ -227,7 +231,8 @@ def spdmp_zigzag(bound_gamma, bound_mu, target_gamma, x0, theta0, c, T, *, t0=0.
         ev = np.frombuffer(buf, dtype=EVENT_DTYPE).copy()
     L.orc_trace_free(C.byref(tr))
     return dict(events=ev, t=t, x=x, theta=th, acc=acc, num=res.num, nacc=res.nacc, nrefresh=res.nrefresh,
-                c=cc, status=st, ndraw_main=res.ndraw_main, ndraw_global=res.ndraw_global, t_last=res.t_last)
+                c=cc, status=st, ndraw_main=res.ndraw_main, ndraw_global=res.ndraw_global, t_last=res.t_last,
+                sigma=sg_out)
 
 
 def pdmp_zigzag1d(mu, sigma2, x0, theta0, T, c, *, adapt=False, factor=2.0, seed=1, cap=1 << 20):

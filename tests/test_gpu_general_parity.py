@@ -101,3 +101,35 @@ def test_refresh_on_the_general_kernel(gpu_pkg):
     x0 = rng.standard_normal((2, d))
     th0 = sig * rng.choice([-1.0, 1.0], (2, d))
     _check_zz(pkg, F, G, x0, th0, 2.0 * pkg.problems.column_norms(G), 4.0, 90)
+
+
+def test_adaptscale_matches_oracle(gpu_pkg):
+    """spdmp(...; adaptscale=true), src/sfact.jl:86-99: σ tuned in the refresh branch (ZigZag: no draw, θ = σ·sign θ;
+    FactBoomerang: multiplicative step once τ < 0.2).  Events, final state and the tuned σ are bit-identical."""
+    pkg = gpu_pkg
+    G = pkg.problems.maintest_precision(8)
+    d = 8
+    rng = np.random.default_rng(4)
+    for boom in (False, True):
+        sig0 = np.full(d, 2.0)
+        x0 = rng.standard_normal((3, d))
+        c = np.full(d, 10.0)
+        if boom:
+            F = pkg.FactBoomerang(sp.csc_matrix(G), np.zeros(d), 2.0, σ=sig0, ρ=0.5)
+            th0 = sig0 * rng.standard_normal((3, d))
+        else:
+            F = pkg.ZigZag(sp.csc_matrix(G), np.zeros(d), sig0, λref=0.5)
+            th0 = sig0 * rng.choice([-1.0, 1.0], (3, d))
+        T = 400.0
+        tr, (t, x, th), (acc, num), cout = pkg.spdmp(pkg.GaussianTarget(G), 0.0, x0, th0, T, c, F, seed=120, adapt=True,
+                                                     adaptscale=True)
+        for k in range(3):
+            r = O.spdmp_zigzag(F.Γ, F.μ, G, x0[k], th0[k], c, T, seed=120 + k, lambda_ref=F.λref, rho=F.ρ, sigma=sig0,
+                               adapt=True, adaptscale=True, factboomerang=boom)
+            assert r["status"] == 0 and r["nrefresh"] > 50 and len(tr[k].events) == len(r["events"])
+            for f in ("i", "t", "x", "theta"):
+                assert np.array_equal(tr[k].events[f], r["events"][f]), (boom, k, f)
+            assert int(num[k]) == r["num"] and np.array_equal(acc[k], r["acc"]) and np.array_equal(cout[k], r["c"])
+            assert np.array_equal(x[k], r["x"]) and np.array_equal(th[k], r["theta"]) and np.array_equal(t[k], r["t"])
+            assert np.array_equal(tr[k].F.σ, r["sigma"]) and not np.array_equal(r["sigma"], sig0)
+    assert np.array_equal(F.σ, sig0)  # an ensemble call leaves the caller's flow alone

@@ -236,3 +236,26 @@ def test_factboomerang_statistics_d8(pkg):
     S = np.linalg.inv(Gz.toarray())
     assert np.mean(np.abs(xs.mean(axis=0))) < 2 / math.sqrt(T) * 1.5
     assert np.mean(np.abs(np.cov(xs.T) - S)) < 4 / math.sqrt(T)
+
+
+def test_adaptscale_tunes_sigma_towards_the_target_reflection_rate(pkg):
+    """src/sfact.jl:86-91: under adaptscale the ZigZag refresh branch steers every coordinate towards 0.3 accepted
+    reflections per unit time by rescaling σ[i] (speed); no event-level pin exists in the reference's tests."""
+    G = pkg.problems.maintest_precision(8)
+    d = 8
+    rng = np.random.default_rng(1)
+    sg = np.full(d, 2.0)
+    x0 = rng.standard_normal(d)
+    th0 = sg * rng.choice([-1.0, 1.0], d)
+    T = 4000.0
+    r = O.spdmp_zigzag(G, np.zeros(d), G, x0, th0, np.full(d, 10.0), T, seed=3, lambda_ref=0.5, sigma=sg,
+                       adaptscale=True, adapt=True)
+    assert r["status"] == 0 and r["nrefresh"] > 1000
+    rate = r["acc"] / T
+    assert np.all(rate > 0.2) and np.all(rate < 0.6), rate
+    assert np.all(r["sigma"] < 2.0) and np.all(r["sigma"] > 0.2)
+    # speeds follow σ: |θ_i| of the final state equals the tuned σ_i or the σ_i of an earlier refresh (never 2.0 again)
+    assert np.all(np.abs(r["theta"]) < 2.0)
+    # without adaptscale σ is left alone
+    r0 = O.spdmp_zigzag(G, np.zeros(d), G, x0, th0, np.full(d, 10.0), 50.0, seed=3, lambda_ref=0.5, sigma=sg, adapt=True)
+    assert np.array_equal(r0["sigma"], sg)

@@ -118,6 +118,8 @@ struct pdmp_ensemble {
     // sticky ZigZag
     DevBuf<double> d_kappa, d_thf;
     bool has_kappa = false;
+    bool adaptscale = false;
+    DevBuf<double> d_sig_chain;
     int reversible = 0, strong_upperbounds = 0;
     // BPS
     DevBuf<int64_t> b_colptr, b_rowval;
@@ -374,6 +376,7 @@ static pdmp_status set_flow_common(pdmp_ensemble* e, const int64_t* colptr, cons
     e->nblk = (uint32_t)((nkeys + 63) / 64);
     e->nblk_pad = (e->nblk + 1u) & ~1u;
     e->dk = (int64_t)e->nblk * 64;
+    e->adaptscale = false;
     e->has_flow = true;
     e->has_target = false;
     e->has_state = false;
@@ -609,14 +612,21 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
     if (st != PDMP_OK) return st;
     std::vector<double> cv(c, c + d);
     if ((st = e->d_c.upload(cv)) != PDMP_OK) return st;
-    if (e->needs_general || e->target_kind == 1) {
+    if (e->needs_general || e->target_kind == 1 || e->adaptscale) {
         if (e->cfg.sampler != PDMP_SAMPLER_ZIGZAG_LOCAL)
             return fail(PDMP_ERR_UNSUPPORTED,
-                        "neighbourhoods beyond 64 members / the logistic target / FactBoomerang run on the general kernel: spdmp only");
+                        "neighbourhoods beyond 64 members / the logistic target / FactBoomerang / adaptscale run on the general "
+                        "kernel: spdmp only");
         if (e->target_kind == 1 && (e->flow_kind == 1 || e->lambda_ref > 0))
             return fail(PDMP_ERR_UNSUPPORTED, "the logistic target is implemented for ZigZag without refresh");
         if (pdmp::zz_general_lds_bytes(e->nblk_pad, (e->mmax_all + 63u) & ~63u) > 160 * 1024)
             return fail(PDMP_ERR_UNSUPPORTED, "LDS budget exceeded by the general kernel");
+        if (e->adaptscale) {
+            if (e->target_kind == 1) return fail(PDMP_ERR_UNSUPPORTED, "adaptscale needs the refresh clock; the logistic target has none");
+            std::vector<double> sg((size_t)(n * d));
+            for (int64_t k = 0; k < n; ++k) std::copy(e->sigma.begin(), e->sigma.end(), sg.begin() + (size_t)(k * d));
+            if ((st = e->d_sig_chain.upload(sg)) != PDMP_OK) return st;
+        }
         e->use_spec = false;
     } else if ((st = build_blob(e, c)) != PDMP_OK) {
         return st;
@@ -764,8 +774,10 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         P.dbg = phbuf.p;
         P.dbg_cap = 0;
     }
-    if (e->needs_general || e->target_kind == 1) {
+    if (e->needs_general || e->target_kind == 1 || e->adaptscale) {
         pdmp::ZzGeneralParams Q{};
+        Q.sig_chain = e->adaptscale ? e->d_sig_chain.p : nullptr;
+        Q.adaptscale = e->adaptscale ? 1 : 0;
         Q.pos16 = e->d_pos16.p;
         Q.selfpos16 = e->d_selfpos16.p;
         Q.mmax_pad = (e->mmax_all + 63u) & ~63u;
@@ -955,6 +967,33 @@ pdmp_status pdmp_ensemble_set_sticky(pdmp_ensemble* e, const double* kappa, int 
     e->strong_upperbounds = strong_upperbounds;
     e->has_kappa = true;
     e->has_state = false;
+    return PDMP_OK;
+}
+
+pdmp_status pdmp_ensemble_set_adaptscale(pdmp_ensemble* e, int enable) {
+    if (!e) return fail(PDMP_ERR_INVALID, "null argument");
+    if (!e->has_flow) return fail(PDMP_ERR_INVALID, "set_flow_* must be called first");
+    if (enable && e->cfg.sampler != PDMP_SAMPLER_ZIGZAG_LOCAL)
+        return fail(PDMP_ERR_UNSUPPORTED, "adaptscale is a keyword of spdmp (src/sfact.jl:163): PDMP_SAMPLER_ZIGZAG_LOCAL only");
+    if (enable && !(e->lambda_ref > 0))
+        return fail(PDMP_ERR_INVALID, "adaptscale acts in the refresh branch (src/sfact.jl:86): lambda_ref must be positive");
+    e->adaptscale = enable != 0;
+    e->has_state = false;
+    return PDMP_OK;
+}
+
+pdmp_status pdmp_ensemble_final_sigma(pdmp_ensemble* e, int64_t chain_first, int64_t n, double* sigma) {
+    if (!e || !sigma) return fail(PDMP_ERR_INVALID, "null argument");
+    if (!e->has_state) return fail(PDMP_ERR_INVALID, "no state");
+    const int64_t d = e->cfg.d;
+    if (chain_first < 0 || n < 0 || chain_first + n > e->cfg.nchains) return fail(PDMP_ERR_INVALID, "chain range out of bounds");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    if (e->adaptscale) {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(hipMemcpy(sigma, e->d_sig_chain.p + chain_first * d, (size_t)(n * d) * sizeof(double), hipMemcpyDeviceToHost));
+    } else {
+        for (int64_t k = 0; k < n; ++k) std::copy(e->sigma.begin(), e->sigma.end(), sigma + k * d);
+    }
     return PDMP_OK;
 }
 

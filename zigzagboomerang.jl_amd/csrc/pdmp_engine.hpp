@@ -139,6 +139,9 @@ struct ZzGeneralParams {
     const double* __restrict__ mu;    // [d] flow mean
     const double* __restrict__ diag;  // [d] Γ[i,i]
     double rho;
+    // adaptscale (src/sfact.jl:86-99): per-chain σ [nchains x d], nullptr when off
+    double* __restrict__ sig_chain;
+    int32_t adaptscale;
 };
 int launch_zz_general_run(const ZzRunParams& p, const ZzGeneralParams& q, int64_t nchains, void* stream);
 size_t zz_general_lds_bytes(uint32_t nblk_pad, uint32_t mmax_pad);

@@ -97,6 +97,7 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
     pdmp_event* ev = P.ev ? P.ev + chain * P.trace_cap : nullptr;
     double* cmut = P.c_chain ? (P.c_chain + chain * d) : nullptr;
     const double* cvec = cmut ? cmut : P.tb.c_shared;
+    double* sigc = Q.sig_chain ? (Q.sig_chain + chain * d) : nullptr;
 
     uint32_t status = hdr->c.status;
     if (status == PDMP_CHAIN_BOUND_VIOLATED || status == PDMP_CHAIN_STALLED) return;
@@ -131,24 +132,29 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
     }
     G_ORDER();
 
-    auto queue_update = [&](uint32_t j, double kj) {
-        const uint32_t bj = j >> 6;
+    // level 1 of the queue after keys[] of G1[i][jj0 .. jj1) (and optionally of one extra coordinate) changed: every 64-key
+    // block that holds a changed key is rescanned once (min, lowest index on ties -- the same pair the per-key update keeps)
+    auto requeue = [&](uint32_t cp0, uint32_t jj0, uint32_t jj1, bool has_extra, uint32_t extra_j) {
         G_ORDER();
-        const double cur = bk[bj];
-        const uint32_t ci = bi[bj];
-        if (kj < cur || (kj == cur && j < ci)) {
-            if (lane == 0) {
-                bk[bj] = kj;
-                bi[bj] = j;
-            }
-        } else if (ci == j) {
-            const double kv = __hip_atomic_load(keys + (size_t)bj * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const double mn = g_wave_min(kv);
-            const uint64_t bl = __ballot(kv == mn);
-            const int arg = bl ? (__ffsll((unsigned long long)bl) - 1) : 0;
-            if (lane == 0) {
-                bk[bj] = mn;
-                bi[bj] = bj * 64 + (uint32_t)arg;
+        const uint32_t cnt = jj1 - jj0 + (has_extra ? 1u : 0u);
+        for (uint32_t base = 0; base < cnt; base += 64) {
+            const uint32_t q = base + (uint32_t)lane;
+            const bool valid = q < cnt;
+            uint32_t bj = 0xffffffffu;
+            if (valid) bj = ((jj0 + q < jj1) ? P.tb.rowval[cp0 + jj0 + q] : extra_j) >> 6;
+            uint64_t todo = __ballot(valid);
+            while (todo) {
+                const int lead = __ffsll((unsigned long long)todo) - 1;
+                const uint32_t bsel = (uint32_t)__builtin_amdgcn_readlane((int)bj, lead);
+                todo &= ~__ballot(bj == bsel);
+                const double kv = __hip_atomic_load(keys + (size_t)bsel * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const double mn = g_wave_min(kv);
+                const uint64_t bl = __ballot(kv == mn);
+                const int arg = bl ? (__ffsll((unsigned long long)bl) - 1) : 0;
+                if (lane == 0) {
+                    bk[bsel] = mn;
+                    bi[bsel] = bsel * 64 + (uint32_t)arg;
+                }
             }
         }
         G_ORDER();
@@ -309,12 +315,36 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
             move_members(sp2, k2, m2, tp);  // smove_forward!(G2, i, ...), :85
             stage_members(sp2, 0, k2);
             double thn;
-            if (boom) {  // :103  θ[i] = ρ θ[i] + ρ̄ σ[i] randn(rng)
-                thn = Q.rho * sth[self2] + rhobar * P.tb.sigma[i2] * pdmp_randn(seed, PDMP_STREAM_MAIN, nm);
-            } else {     // :100-101  θ[i] = σ[i] rand(rng, (-1,1))
-                thn = P.tb.sigma[i2] * ((pdmp_u01(seed, PDMP_STREAM_MAIN, nm) < 0.5) ? -1.0 : 1.0);
+            double sg2 = sigc ? sigc[i2] : P.tb.sigma[i2];
+            if (Q.adaptscale && !boom) {  // :86-91, no random draw
+                const double adapt_g = 0.01, adapt_t0 = 15., adapt_k = 0.75;
+                const double acc2 = (double)(1 + (int64_t)rec[i2].acc);
+                const double pre = pdmp_log(2.0) - sqrt(1.0 + tp) / (adapt_g * (1.0 + tp + adapt_t0)) *
+                                                       pdmp_log(acc2 / (1.0 + 0.3 * tp));
+                const double eta = pdmp_exp(-adapt_k * pdmp_log(1 + tp));  // (1 + t′)^(-adapt_κ)
+                sg2 = pdmp_exp(eta * pre + (1 - eta) * pdmp_log(sg2));
+                const double tho = sth[self2];
+                thn = sg2 * ((tho > 0) ? 1.0 : ((tho < 0) ? -1.0 : tho));  // σ[i]*sign(θ[i])
+            } else {
+                if (Q.adaptscale) {  // :93-98
+                    const double ti2 = rec[i2].t;
+                    const double effi = (1 + 2 * Q.rho / (1 - Q.rho));
+                    const double tau = effi / (ti2 * P.lambda_ref);
+                    if (tau < 0.2) {
+                        const double r = 0.3 * ti2 / (double)(int64_t)rec[i2].acc;
+                        const double dir = (double)((r > 1.66) - (r < 0.6));
+                        const double sq = sqrt(tau / P.lambda_ref);
+                        sg2 = sg2 * pdmp_exp(dir * 0.03 * ((1.0 < sq) ? 1.0 : sq));
+                    }
+                }
+                if (boom) {  // :103  θ[i] = ρ θ[i] + ρ̄ σ[i] randn(rng)
+                    thn = Q.rho * sth[self2] + rhobar * sg2 * pdmp_randn(seed, PDMP_STREAM_MAIN, nm);
+                } else {     // :100-101  θ[i] = σ[i] rand(rng, (-1,1))
+                    thn = sg2 * ((pdmp_u01(seed, PDMP_STREAM_MAIN, nm) < 0.5) ? -1.0 : 1.0);
+                }
+                nm += 1;
             }
-            nm += 1;
+            if (sigc && lane == 0) sigc[i2] = sg2;
             G_ORDER();
             if (lane == 0) {
                 sth[self2] = thn;
@@ -326,11 +356,7 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
             rebound(cp2, 0, k2, tp, nm, true, true);  // :110-114
             nm += (uint64_t)k2;
             if (lane == 0) keys[d] = newref;
-            for (uint32_t jj = 0; jj <= k2; ++jj) {
-                const uint32_t j = (jj < k2) ? P.tb.rowval[cp2 + jj] : (uint32_t)d;
-                const double kj = __hip_atomic_load(keys + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                queue_update(g_uniform(j), kj);
-            }
+            requeue(cp2, 0, k2, true, (uint32_t)d);
             if (ev && lane == 0) {  // event(i, t, x, θ, F) = (t[i], i, x[i], θ[i]) at i's own clock, :143
                 pdmp_event e;
                 e.t = __hip_atomic_load(&rec[i2].t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -464,11 +490,7 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
         rebound(cp0, jj0, jj1, tp, nm, accept, false);
         nm += accept ? (uint64_t)k : 1u;
         // ---------------- level 1 of the queue (keys[] already hold the new values)
-        for (uint32_t jj = jj0; jj < jj1; ++jj) {
-            const uint32_t j = P.tb.rowval[cp0 + jj];
-            const double kj = __hip_atomic_load(keys + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            queue_update(g_uniform(j), kj);
-        }
+        requeue(cp0, jj0, jj1, false, 0u);
         if (accept) {
             if (ev && lane == 0) {
                 pdmp_event e;

@@ -68,6 +68,17 @@ class Ensemble:
         kappa = _f64(kappa).reshape(self.d)
         _lib.check(self._L.pdmp_ensemble_set_sticky(self._h, _ptr(kappa), int(bool(reversible)), int(bool(strong_upperbounds))))
 
+    def set_adaptscale(self, enable=True):
+        """spdmp(...; adaptscale=true), src/sfact.jl:86-99: σ becomes per-chain state tuned in the refresh branch."""
+        _lib.check(self._L.pdmp_ensemble_set_adaptscale(self._h, int(bool(enable))))
+
+    def final_sigma(self, chain_first=0, n=None):
+        if n is None:
+            n = self.nchains - chain_first
+        sg = np.empty((n, self.d))
+        _lib.check(self._L.pdmp_ensemble_final_sigma(self._h, int(chain_first), int(n), _ptr(sg)))
+        return sg
+
     def set_flow_bps(self, B: BouncyParticle):
         G = B.Γ
         if G.shape != (self.d, self.d):

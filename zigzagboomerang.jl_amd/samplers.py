@@ -8,6 +8,8 @@ coordinates are 0-based; x0/θ0 may be [nchains, d] to run an ensemble (outputs 
 axis).  Everything else -- argument order, keyword names, the 4-tuple returned, the error raised when the
 bound `c` is too small with adapt=false -- follows the reference.
 """
+import copy
+
 import numpy as np
 
 from . import _lib
@@ -26,11 +28,15 @@ def _drain(ens, events):
     ens.trace_reset()
 
 
-def spdmp(target, t0, x0, θ0, T, c, F, *, factor=1.8, adapt=False, seed=DEFAULT_SEED, device=0,
+def spdmp(target, t0, x0, θ0, T, c, F, *, factor=1.8, adapt=False, adaptscale=False, seed=DEFAULT_SEED, device=0,
           trace_capacity=None, trace=True):
     """Local ZigZag: spdmp(∇ϕ, t0, x0, θ0, T, c, F::ZigZag, args...) with G = Matched() (src/sfact.jl:214).
-    Returns Ξ, (t, x, θ), (acc, num), c like the reference (:211)."""
-    return _zigzag(_lib.SAMPLER_ZIGZAG_LOCAL, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, trace_capacity, trace)
+    Returns Ξ, (t, x, θ), (acc, num), c like the reference (:211).
+
+    adaptscale=True (src/sfact.jl:86-99) tunes σ in the refresh branch.  Like the reference, a single-chain call mutates
+    F.σ in place; for an ensemble every chain's tuned σ is the `σ` of the flow attached to its trace (Ξ[k].F.σ)."""
+    return _zigzag(_lib.SAMPLER_ZIGZAG_LOCAL, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, trace_capacity, trace,
+                   adaptscale=adaptscale)
 
 
 def pdmp(target, t0, x0, θ0, T, c, F, *, factor=1.8, adapt=False, seed=DEFAULT_SEED, device=0,
@@ -54,7 +60,8 @@ def sspdmp(target, t0, x0, θ0, T, c, F, κ, *, reversible=False, strong_upperbo
                    sticky=(np.asarray(κ, dtype=np.float64), reversible, strong_upperbounds))
 
 
-def _zigzag(sampler, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, trace_capacity, trace, sticky=None):
+def _zigzag(sampler, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, trace_capacity, trace, sticky=None,
+            adaptscale=False):
     if not isinstance(F, (ZigZag, FactBoomerang)):
         raise TypeError("the device path supports F::ZigZag and F::FactBoomerang")
     if not isinstance(target, (GaussianTarget, LogisticTarget)):
@@ -78,6 +85,8 @@ def _zigzag(sampler, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, 
         ens.set_target(target)
         if sticky is not None:
             ens.set_sticky(*sticky)
+        if adaptscale:
+            ens.set_adaptscale(True)
         ens.set_state(t0, X0, TH0, c, seeds)
         events = [[] for _ in range(nch)]
         while True:
@@ -91,12 +100,20 @@ def _zigzag(sampler, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, 
                 break
         fs = ens.final_state()
         cnt = ens.counters()
+        sig = ens.final_sigma() if adaptscale else None
     finally:
         ens.close()
     traces = []
     for k in range(nch):
         ev = np.concatenate(events[k]) if events[k] else np.empty(0, dtype=_lib.EVENT_DTYPE)
-        traces.append(FactTrace(F, t0, X0[k].copy(), TH0[k].copy(), ev))
+        Fk = F
+        if sig is not None:
+            if single:
+                F.σ[:] = sig[0]  # the reference mutates F.σ (src/sfact.jl:90,97)
+            else:
+                Fk = copy.copy(F)
+                Fk.σ = sig[k].copy()
+        traces.append(FactTrace(Fk, t0, X0[k].copy(), TH0[k].copy(), ev))
     num = cnt["num"].astype(np.int64)
     c_out = fs["c"] if adapt else np.broadcast_to(c, (nch, d)).copy()
     acc = cnt["nacc"].astype(np.int64) if sticky is not None else fs["acc"]  # sticky: scalar acc (src/ss_fact.jl:175)
