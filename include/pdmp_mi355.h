@@ -233,6 +233,15 @@ pdmp_status pdmp_ensemble_final_sigma(pdmp_ensemble* ens, int64_t chain_first, i
  */
 pdmp_status pdmp_ensemble_set_flow_bps(pdmp_ensemble* ens, const int64_t* colptr, const int64_t* rowval,
                                        const double* nzval, const double* mu, double lambda_ref, double rho);
+
+/* Flow = Boomerang(Γ, μ_flow, λref; ρ) (src/types.jl:59-66) with Γ = I, i.e. mass L = I: Hamiltonian rotation about μ_flow
+ * between events (src/dynamics.jl:29-36), grad_correct! ∇ϕx −= x − μ_flow (src/not_fact_samplers.jl:9-12), constant bound
+ * (√(‖θ‖² + ‖x − μ_flow‖²)·c, 0, Inf) (:34-36); same pdmp_inner! loop, events, counters and entry points as the bouncy
+ * particle (create the ensemble with PDMP_SAMPLER_BPS).  The CSC matrix and mu_target describe the TARGET
+ * ∇ϕ!(y, x) = Γt(x − μt) (test/maintest.jl:146).  A reference measure with Γ ≠ I (general cholesky L) is not implemented. */
+pdmp_status pdmp_ensemble_set_flow_boomerang(pdmp_ensemble* ens, const int64_t* colptr, const int64_t* rowval,
+                                             const double* nzval, const double* mu_target, const double* mu_flow,
+                                             double lambda_ref, double rho);
 /* x0, theta0: [nchains x d]; c: the scalar bound constant (GlobalBound(c)); seeds: [nchains] */
 pdmp_status pdmp_ensemble_set_state_bps(pdmp_ensemble* ens, double t0, const double* x0, const double* theta0, double c,
                                         const uint64_t* seeds);

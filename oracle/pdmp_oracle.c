@@ -695,6 +695,42 @@ static void bps_grad(const orc_csc* G, const double* mu, const double* x, double
     for (int64_t r = 0; r < d; ++r) y[r] = orc_idot(G, r, tmp);
 }
 
+/* move_forward!(τ, t, x, θ, Flow): BouncyParticle src/dynamics.jl:11-15 (linear), Boomerang :29-36 (rotation about μ) */
+static void nf_move(const orc_bps_params* p, int64_t d, double tau, double* x, double* th) {
+    if (p->flow_kind == 0) {
+        for (int64_t k = 0; k < d; ++k) x[k] += th[k] * tau;
+    } else {
+        double sn, cs;
+        pdmp_sincos(tau, &sn, &cs);
+        for (int64_t k = 0; k < d; ++k) {
+            const double m = p->flow_mu[k];
+            const double xn = (x[k] - m) * cs + th[k] * sn + m;
+            const double tn = -(x[k] - m) * sn + th[k] * cs;
+            x[k] = xn;
+            th[k] = tn;
+        }
+    }
+}
+/* ∇ϕx = ∇ϕ!(∇ϕx, x) then grad_correct!, src/not_fact_samplers.jl:5-12: Boomerang subtracts L'\(L\(x − μ)) = x − μ for L = I */
+static void nf_grad(const orc_bps_params* p, int64_t d, const double* x, double* tmp, double* g) {
+    bps_grad(p->gamma, p->mu, x, tmp, g, d);
+    if (p->flow_kind == 1)
+        for (int64_t k = 0; k < d; ++k) g[k] -= x[k] - p->flow_mu[k];
+}
+/* ab(x, θ, C::GlobalBound, ∇ϕx, v, Flow), src/not_fact_samplers.jl:26-28 (BouncyParticle), :34-36 (Boomerang) */
+static void nf_ab(const orc_bps_params* p, int64_t d, double c, const double* x, const double* th, const double* g,
+                  double* tmp, double* gth, double* a, double* b) {
+    if (p->flow_kind == 0) {
+        *a = c + dot_wave64(th, g, d);
+        for (int64_t r = 0; r < d; ++r) gth[r] = orc_idot(p->gamma, r, th);
+        *b = dot_wave64(th, gth, d);
+    } else {
+        for (int64_t k = 0; k < d; ++k) tmp[k] = x[k] - p->flow_mu[k];
+        *a = sqrt(dot_wave64(th, th, d) + dot_wave64(tmp, tmp, d)) * c; /* sqrt(normsq(θ) + normsq(x − μ))*C.c */
+        *b = 0.0;
+    }
+}
+
 int orc_pdmp_bps(int64_t d, const orc_bps_params* p, double t0, double T, double* x, double* th, double* t_ev,
                  double* x_ev, double* th_ev, int64_t ev_cap, orc_bps_result* res) {
     const uint64_t seed = p->seed;
@@ -707,29 +743,25 @@ int orc_pdmp_bps(int64_t d, const orc_bps_params* p, double t0, double T, double
     int64_t num = 0, acc = 0, nrefresh = 0, nev = 0;
     int status = ORC_OK;
     const double rho = p->rho, rhobar = sqrt(1 - rho * rho); /* src/dynamics.jl:113 */
+    double a, b;
 
     double tau_ref = -pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)) / p->lambda_ref; /* :121 */
-    bps_grad(p->gamma, p->mu, x, tmp, g, d);                                             /* :122-123 */
-    /* ab(x, θ, C::GlobalBound, ...) = (C.c + θ'(Γ(x-μ)), θ'(Γθ), Inf), :26-28 */
-    double a = c + dot_wave64(th, g, d);
-    for (int64_t r = 0; r < d; ++r) gth[r] = orc_idot(p->gamma, r, th);
-    double b = dot_wave64(th, gth, d);
+    nf_grad(p, d, x, tmp, g);                                                            /* :122-123 */
+    nf_ab(p, d, c, x, th, g, tmp, gth, &a, &b);                                          /* :126 */
     double tp = t + orc_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)); /* next_time :43-50, :135 */
 
     while (t < T) { /* :136 */
         for (;;) {  /* pdmp_inner!, :52-97 */
             if (tau_ref < tp) { /* :55 refresh */
                 double tau = tau_ref - t;
-                t += tau; /* move_forward!, src/dynamics.jl:11-15 */
-                for (int64_t k = 0; k < d; ++k) x[k] += th[k] * tau;
-                /* refresh!, src/dynamics.jl:112-118 with L = I:  θ .*= ρ; θ .+= ρ̄*randn(rng,d) */
+                t += tau; /* move_forward!, :56 */
+                nf_move(p, d, tau, x, th);
+                /* refresh!, src/dynamics.jl:112-126 with L = I:  θ .*= ρ; θ .+= ρ̄*randn(rng,d) */
                 for (int64_t k = 0; k < d; ++k) th[k] *= rho;
                 for (int64_t k = 0; k < d; ++k) th[k] += rhobar * pdmp_randn(seed, PDMP_STREAM_MAIN, nm++);
-                bps_grad(p->gamma, p->mu, x, tmp, g, d);                                      /* :58-59 */
+                nf_grad(p, d, x, tmp, g);                                                     /* :58-59 */
                 tau_ref = t + (-pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)) / p->lambda_ref); /* :61 */
-                a = c + dot_wave64(th, g, d);                                                 /* :62 */
-                for (int64_t r = 0; r < d; ++r) gth[r] = orc_idot(p->gamma, r, th);
-                b = dot_wave64(th, gth, d);
+                nf_ab(p, d, c, x, th, g, tmp, gth, &a, &b);                                   /* :62 */
                 tp = t + orc_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)); /* :63 */
                 nrefresh++;
                 break; /* :64 return */
@@ -737,8 +769,8 @@ int orc_pdmp_bps(int64_t d, const orc_bps_params* p, double t0, double T, double
             /* renew branch :65-71 is unreachable with GlobalBound (abc[3] = Inf) */
             double tau = tp - t; /* :73 */
             t += tau;
-            for (int64_t k = 0; k < d; ++k) x[k] += th[k] * tau; /* :74 */
-            bps_grad(p->gamma, p->mu, x, tmp, g, d);              /* :75-76 */
+            nf_move(p, d, tau, x, th); /* :74 */
+            nf_grad(p, d, x, tmp, g);  /* :75-76 */
             double gt = dot_wave64(g, th, d);
             double l = pos(gt);            /* λ, :14 */
             double lb = pos(a + b * tau);  /* :77 */
@@ -752,21 +784,16 @@ int orc_pdmp_bps(int64_t d, const orc_bps_params* p, double t0, double T, double
                     }
                     c *= p->factor; /* :83 */
                 }
-                /* reflect!, src/dynamics.jl:90-93 with L = I: θ .-= (2 dot(∇ϕx,θ)/normsq(∇ϕx)) ∇ϕx */
+                /* reflect!, src/dynamics.jl:90-97 with L = I: θ .-= (2 dot(∇ϕx,θ)/normsq(∇ϕx)) ∇ϕx */
                 double nrm = dot_wave64(g, g, d);
                 double coef = 2 * gt / nrm;
                 for (int64_t k = 0; k < d; ++k) th[k] -= coef * g[k];
-                /* :86-87 gradient again (x unchanged) */
-                a = c + dot_wave64(th, g, d); /* :88 */
-                for (int64_t r = 0; r < d; ++r) gth[r] = orc_idot(p->gamma, r, th);
-                b = dot_wave64(th, gth, d);
+                /* :86-87 gradient again (x unchanged: same values) */
+                nf_ab(p, d, c, x, th, g, tmp, gth, &a, &b);                               /* :88 */
                 tp = t + orc_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)); /* :89 */
                 break;                                                                    /* :90 */
             } else {
-                a = c + dot_wave64(th, g, d); /* :92 */
-                /* b = θ'Γθ unchanged in value, recomputed by the reference; recompute for bit parity */
-                for (int64_t r = 0; r < d; ++r) gth[r] = orc_idot(p->gamma, r, th);
-                b = dot_wave64(th, gth, d);
+                nf_ab(p, d, c, x, th, g, tmp, gth, &a, &b);                               /* :92 (recomputed: bit parity) */
                 tp = t + orc_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)); /* :93 */
             }
         }

@@ -162,6 +162,11 @@ typedef struct {
     double factor;
     uint64_t seed;
     int64_t max_events;
+    /* flow_kind 1: Flow = Boomerang(I, flow_mu, λref; ρ) (src/types.jl:59-66, L = I): Hamiltonian rotation about flow_mu
+     * (src/dynamics.jl:29-36), grad_correct! ∇ϕx −= x − flow_mu (src/not_fact_samplers.jl:9-12), constant bound
+     * a = √(‖θ‖² + ‖x − flow_mu‖²)·c, b = 0 (:34-36).  gamma/mu above are then the TARGET's precision and mean. */
+    int flow_kind;
+    const double* flow_mu;
 } orc_bps_params;
 typedef struct {
     int64_t num, nacc, nrefresh, nevents;

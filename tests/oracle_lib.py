@@ -59,7 +59,7 @@ class _ZZResult(C.Structure):
 class _BpsParams(C.Structure):
     _fields_ = [("gamma", C.POINTER(_Csc)), ("mu", C.c_void_p), ("lambda_ref", C.c_double),
                 ("rho", C.c_double), ("c", C.c_double), ("adapt", C.c_int), ("factor", C.c_double),
-                ("seed", C.c_uint64), ("max_events", C.c_int64)]
+                ("seed", C.c_uint64), ("max_events", C.c_int64), ("flow_kind", C.c_int), ("flow_mu", C.c_void_p)]
 
 
 class _BpsResult(C.Structure):
@@ -248,12 +248,17 @@ def pdmp_zigzag1d(mu, sigma2, x0, theta0, T, c, *, adapt=False, factor=2.0, seed
 
 
 def pdmp_bps(gamma, mu, x0, theta0, c, T, *, t0=0.0, lambda_ref=1.0, rho=0.0, adapt=False, factor=2.0,
-             seed=1, max_events=0, ev_cap=0, want_events=True):
+             seed=1, max_events=0, ev_cap=0, want_events=True, boomerang_mu=None):
+    """BPS (gamma, mu = flow AND target) or, with boomerang_mu, Boomerang(I, boomerang_mu, λref; ρ) on the Gaussian
+    target (gamma, mu)."""
     L = lib()
     g = gamma if isinstance(gamma, CscHolder) else CscHolder(gamma)
     d = g.n
     muv = _f64(mu if mu is not None else np.zeros(d))
     p = _BpsParams(C.pointer(g.c), muv.ctypes.data, lambda_ref, rho, c, int(adapt), factor, seed, max_events)
+    if boomerang_mu is not None:
+        fmu = _f64(boomerang_mu)
+        p.flow_kind, p.flow_mu = 1, fmu.ctypes.data
     x = _f64(x0).copy()
     th = _f64(theta0).copy()
     if want_events:

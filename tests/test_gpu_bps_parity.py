@@ -91,3 +91,36 @@ def test_slicing_is_exact(gpu_pkg):
     for k in range(3):
         r = O.pdmp_bps(G, None, x0[k], th0[k], 1e-3, 20.0, lambda_ref=1.0, seed=70 + k, ev_cap=10000)
         assert np.array_equal(np.concatenate(ts[k]), r["t_ev"]) and np.array_equal(fs["x"][k], r["x"])
+
+
+def test_boomerang_matches_oracle(gpu_pkg):
+    """pdmp(∇ϕ!, t0, x0, θ0, T, c, B::Boomerang) (test/maintest.jl:139-154: Γ = S S' target, λref = 0.5, c = 16) with the
+    identity mass the device implements: rotation, grad_correct!, the constant bound; bit-exact events and state.  Also a
+    diagonal target with non-zero means (register-only path), d = 100 (two slots per lane) and adapt."""
+    pkg = gpu_pkg
+    rng = np.random.default_rng(21)
+
+    def chk(Gt, mut, muf, x0, th0, c, T, lam, rho=0.0, adapt=False, seed=5):
+        d = Gt.shape[0]
+        B = pkg.Boomerang(sp.identity(d, format="csc"), muf, lam, rho)
+        tr, (t, x, th), (acc, num), cout = pkg.pdmp(pkg.GaussianTarget(Gt, mut), 0.0, x0, th0, T, c, B, adapt=adapt, seed=seed)
+        for k in range(x0.shape[0]):
+            r = O.pdmp_bps(Gt, mut, x0[k], th0[k], c, T, lambda_ref=lam, rho=rho, adapt=adapt, seed=seed + k, ev_cap=200000,
+                           boomerang_mu=muf)
+            assert r["status"] == 0 and r["nevents"] > 10
+            assert len(tr[k].t) == r["nevents"], (k, len(tr[k].t), r["nevents"])
+            assert np.array_equal(tr[k].t, r["t_ev"]) and np.array_equal(tr[k].x, r["x_ev"]) and np.array_equal(tr[k].θ, r["theta_ev"])
+            assert (int(acc[k]), int(num[k])) == (r["nacc"], r["num"])
+            assert t[k] == r["t"] and np.array_equal(x[k], r["x"]) and np.array_equal(th[k], r["theta"]) and cout[k] == r["c"]
+        return tr
+
+    G = pkg.problems.maintest_precision(8)
+    tr = chk(G, None, np.zeros(8), rng.standard_normal((3, 8)), rng.standard_normal((3, 8)), 16.0, 300.0, 0.5, seed=60)
+    # the discretised path of a Boomerang trace rotates between events: sample mean near 0 (loose, short run)
+    ts, xs = pkg.trace.discretize(tr[0], 0.1)
+    assert len(ts) > 2000 and np.mean(np.abs(xs.mean(0))) < 0.5
+    Gd = sp.diags(0.5 + rng.random(20), format="csc")
+    chk(Gd, rng.standard_normal(20), 0.3 * rng.standard_normal(20), rng.standard_normal((2, 20)), rng.standard_normal((2, 20)),
+        4.0, 100.0, 1.0, rho=0.4, seed=61)
+    G2 = pkg.problems.gmrf_precision(10)
+    chk(G2, None, np.zeros(100), rng.standard_normal((2, 100)), rng.standard_normal((2, 100)), 2.0, 30.0, 0.8, adapt=True, seed=62)

@@ -19,7 +19,8 @@ d, nch, T, dT = 1024, 4096, 100.0, 10.0
 rng = np.random.default_rng(0)
 x0 = rng.standard_normal((nch, d))
 th0 = rng.standard_normal((nch, d))
-cap = 64
+cap = int(sys.argv[1]) if len(sys.argv) > 1 else 512  # events per chain per launch: cap x 16 392 B x 4096 chains of HBM (512 -> 34 GB)
+dT = float(sys.argv[2]) if len(sys.argv) > 2 else dT
 ens = pkg.Ensemble(nch, d, sampler=pkg._lib.SAMPLER_BPS, trace_capacity=cap)
 ens.set_flow_bps(pkg.BouncyParticle(sp.identity(d, format="csc"), np.zeros(d), 1.0))
 ens.set_state_bps(0.0, x0, th0, 1e-3, np.arange(nch, dtype=np.uint64) + 0x5EED0000)

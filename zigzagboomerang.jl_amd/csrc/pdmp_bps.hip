@@ -1,5 +1,6 @@
 // pdmp_bps.hip -- Bouncy Particle Sampler ensemble on gfx950: pdmp_inner! (src/not_fact_samplers.jl:52-97) under the
 // driver loop `while t < T` (:136-144), GlobalBound(c), Gaussian target ∇ϕ!(y,x) = Γ(x-μ), mass L = I.
+// BOOM = true: the same loop for Flow = Boomerang(I, μ_flow, λref; ρ) (rotation, grad_correct!, constant bound).
 //
 // One chain per wavefront.  The d-vectors x, θ, ∇ϕ live in REGISTERS (element e = slot*64 + lane, NS slots per lane), so a
 // proposal touches HBM only to emit an event: (t, copy(x), copy(θ)) = 8(2d+1) bytes, written fully coalesced
@@ -65,7 +66,7 @@ __device__ __forceinline__ double bps_poisson_time(double a, double b, double u)
     }
 }
 
-template <int NS, bool DIAG>
+template <int NS, bool DIAG, bool BOOM>
 __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
     const int lane = threadIdx.x;
     const int64_t chain = blockIdx.x;
@@ -139,13 +140,58 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
         return wave_sum_f64(part);
     };
     // ab(x, θ, C::GlobalBound, ...) = (c + θ'(Γ(x-μ)), θ'(Γθ), Inf), src/not_fact_samplers.jl:26-28, and next_time :43-50
+    // Boomerang: ab(x, θ, C::GlobalBound, ...) = (sqrt(normsq(θ) + normsq(x − μ))·c, 0, Inf), src/not_fact_samplers.jl:34-36
+    auto boom_a = [&]() -> double {
+        double dx[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int64_t e = (int64_t)s * 64 + lane;
+            dx[s] = (e < d) ? (x[s] - P.mu_flow[e]) : 0.0;
+        }
+        return sqrt(dot(th, th) + dot(dx, dx)) * c;
+    };
     auto rebound = [&]() {
-        a = c + dot(th, g);
-        double gt[NS];
-        apply_gamma(th, false, gt);
-        b = dot(th, gt);
+        if (BOOM) {
+            a = boom_a();
+            b = 0.0;
+        } else {
+            a = c + dot(th, g);
+            double gt[NS];
+            apply_gamma(th, false, gt);
+            b = dot(th, gt);
+        }
         tp = t + bps_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, nm));
         nm += 1;
+    };
+    // move_forward!(τ, t, x, θ, Flow): linear (src/dynamics.jl:11-15) or the rotation about μ (:29-36)
+    auto move = [&](double tau) {
+        if (BOOM) {
+            double sn, cs;
+            pdmp_sincos(tau, &sn, &cs);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int64_t e = (int64_t)s * 64 + lane;
+                const double m = (e < d) ? P.mu_flow[e] : 0.0;
+                const double xn = (x[s] - m) * cs + th[s] * sn + m;
+                const double tn = -(x[s] - m) * sn + th[s] * cs;
+                x[s] = xn;
+                th[s] = tn;
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) x[s] += th[s] * tau;
+        }
+    };
+    // ∇ϕx = ∇ϕ!(∇ϕx, x); grad_correct!: Boomerang subtracts L'\(L\(x − μ)) = x − μ for L = I (src/not_fact_samplers.jl:9-12)
+    auto gradient = [&]() {
+        apply_gamma(x, true, g);
+        if (BOOM) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int64_t e = (int64_t)s * 64 + lane;
+                if (e < d) g[s] -= x[s] - P.mu_flow[e];
+            }
+        }
     };
 
     bool running = stop_before || (t < T);  // `while t < T`, :136
@@ -162,9 +208,8 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
         }
         if (stop_before && !(tnext < T)) break;
         const double tau = tnext - t;  // :56 / :73
-        t += tau;                      // move_forward!, src/dynamics.jl:11-15
-#pragma unroll
-        for (int s = 0; s < NS; ++s) x[s] += th[s] * tau;
+        t += tau;
+        move(tau);
         bool emit = false;
         if (is_ref) {
             // refresh!, src/dynamics.jl:112-118 with L = I: θ .*= ρ; θ .+= ρ̄ randn(rng, d)  (draw nm + e for element e)
@@ -175,14 +220,14 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
                 if (e < d) th[s] += rhobar * pdmp_randn(seed, PDMP_STREAM_MAIN, nm + (uint64_t)e);
             }
             nm += (uint64_t)d;
-            apply_gamma(x, true, g);                                                                       // :58-59
+            gradient();                                                                                    // :58-59
             tau_ref = t + (-pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm)) / P.lambda_ref);                  // :61
             nm += 1;
             rebound();  // :62-63
             nrefresh += 1;
             emit = true;  // :64
         } else {
-            apply_gamma(x, true, g);  // :75-76
+            gradient();  // :75-76
             const double gt = dot(g, th);
             const double l = bps_pos(gt);            // λ, :14
             const double lb = bps_pos(a + b * tau);  // :77
@@ -206,7 +251,8 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
                 rebound();  // :86-89
                 emit = true;  // :90
             } else {
-                a = c + gt;  // :92 (θ'g == g'θ bit for bit; b = θ'Γθ is unchanged because θ is)
+                if (BOOM) a = boom_a();  // :92 recomputed after the rotation (b stays 0)
+                else a = c + gt;         // :92 (θ'g == g'θ bit for bit; b = θ'Γθ is unchanged because θ is)
                 tp = t + bps_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, nm));  // :93
                 nm += 1;
             }
@@ -261,7 +307,7 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
 }
 
 // Initial state, src/not_fact_samplers.jl:117-135: τref = randexp(rng)/λref (draw 0), ∇ϕx, abc = ab(...), t′ = next_time (draw 1).
-template <int NS, bool DIAG>
+template <int NS, bool BOOM>
 __global__ __launch_bounds__(64) void bps_init_kernel(BpsRunParams P, const uint64_t* seeds, double t0, double c0) {
     const int lane = threadIdx.x;
     const int64_t chain = blockIdx.x;
@@ -307,9 +353,21 @@ __global__ __launch_bounds__(64) void bps_init_kernel(BpsRunParams P, const uint
     };
     const double tau_ref = -pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, 0)) / P.lambda_ref;  // :121
     apply_gamma(x, true, g);                                                               // :122-123
-    const double a = c0 + dot(th, g);                                                      // :126
-    apply_gamma(th, false, gt);
-    const double b = dot(th, gt);
+    double a, b;
+    if (BOOM) {  // grad_correct! only shifts g (unused by the Boomerang bound); ab, src/not_fact_samplers.jl:34-36
+        double dx[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int64_t e = (int64_t)s * 64 + lane;
+            dx[s] = (e < d) ? (x[s] - P.mu_flow[e]) : 0.0;
+        }
+        a = sqrt(dot(th, th) + dot(dx, dx)) * c0;
+        b = 0.0;
+    } else {
+        a = c0 + dot(th, g);                                                               // :126
+        apply_gamma(th, false, gt);
+        b = dot(th, gt);
+    }
     const double tp = t0 + bps_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, 1));    // :135
     if (lane == 0) {
         double* sc = P.scal + chain * 8;
@@ -345,12 +403,17 @@ static int launch_ns(const BpsRunParams& p, int64_t nchains, bool diag, bool ini
                      double c0, void* stream) {
     const size_t lds = (size_t)p.d * 8;
     dim3 grid((unsigned)nchains), block(64);
+    const bool boom = p.flow_kind == 1;
     if (init) {
-        hipLaunchKernelGGL((bps_init_kernel<NS, false>), grid, block, lds, (hipStream_t)stream, p, seeds, t0, c0);
+        if (boom) hipLaunchKernelGGL((bps_init_kernel<NS, true>), grid, block, lds, (hipStream_t)stream, p, seeds, t0, c0);
+        else hipLaunchKernelGGL((bps_init_kernel<NS, false>), grid, block, lds, (hipStream_t)stream, p, seeds, t0, c0);
+    } else if (boom) {
+        if (diag) hipLaunchKernelGGL((bps_run_kernel<NS, true, true>), grid, block, 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((bps_run_kernel<NS, false, true>), grid, block, lds, (hipStream_t)stream, p);
     } else if (diag) {
-        hipLaunchKernelGGL((bps_run_kernel<NS, true>), grid, block, 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((bps_run_kernel<NS, true, false>), grid, block, 0, (hipStream_t)stream, p);
     } else {
-        hipLaunchKernelGGL((bps_run_kernel<NS, false>), grid, block, lds, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((bps_run_kernel<NS, false, false>), grid, block, lds, (hipStream_t)stream, p);
     }
     return (int)hipGetLastError();
 }

@@ -123,7 +123,8 @@ struct pdmp_ensemble {
     int reversible = 0, strong_upperbounds = 0;
     // BPS
     DevBuf<int64_t> b_colptr, b_rowval;
-    DevBuf<double> b_nzval, b_mu, b_x, b_th, b_scal, b_ev_t, b_ev_x, b_ev_th;
+    DevBuf<double> b_nzval, b_mu, b_mu_flow, b_x, b_th, b_scal, b_ev_t, b_ev_x, b_ev_th;
+    int bps_flow_kind = 0;
     bool bps_diag = false;
     double bps_lambda = 0.0, bps_rho = 0.0;
 
@@ -698,6 +699,8 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         B.rowval = e->b_rowval.p;
         B.nzval = e->b_nzval.p;
         B.mu = e->b_mu.p;
+        B.mu_flow = e->b_mu_flow.p;
+        B.flow_kind = e->bps_flow_kind;
         B.x = e->b_x.p;
         B.th = e->b_th.p;
         B.scal = e->b_scal.p;
@@ -997,8 +1000,8 @@ pdmp_status pdmp_ensemble_final_sigma(pdmp_ensemble* e, int64_t chain_first, int
     return PDMP_OK;
 }
 
-pdmp_status pdmp_ensemble_set_flow_bps(pdmp_ensemble* e, const int64_t* colptr, const int64_t* rowval, const double* nzval,
-                                       const double* mu, double lambda_ref, double rho) {
+static pdmp_status set_flow_nf(pdmp_ensemble* e, const int64_t* colptr, const int64_t* rowval, const double* nzval,
+                               const double* mu, double lambda_ref, double rho, int kind, const double* mu_flow) {
     if (!e || !colptr || !rowval || !nzval) return fail(PDMP_ERR_INVALID, "null argument");
     if (e->cfg.sampler != PDMP_SAMPLER_BPS) return fail(PDMP_ERR_INVALID, "ensemble was not created with PDMP_SAMPLER_BPS");
     if (!(lambda_ref > 0)) return fail(PDMP_ERR_INVALID, "BouncyParticle needs a strictly positive refreshment rate");
@@ -1025,10 +1028,25 @@ pdmp_status pdmp_ensemble_set_flow_bps(pdmp_ensemble* e, const int64_t* colptr, 
     std::vector<double> muv(d, 0.0);
     if (mu) muv.assign(mu, mu + d);
     if ((st = e->b_mu.upload(muv)) != PDMP_OK) return st;
+    std::vector<double> mfv(d, 0.0);
+    if (mu_flow) mfv.assign(mu_flow, mu_flow + d);
+    if ((st = e->b_mu_flow.upload(mfv)) != PDMP_OK) return st;
+    e->bps_flow_kind = kind;
     e->has_flow = true;
     e->has_target = true;
     e->has_state = false;
     return PDMP_OK;
+}
+
+pdmp_status pdmp_ensemble_set_flow_bps(pdmp_ensemble* e, const int64_t* colptr, const int64_t* rowval, const double* nzval,
+                                       const double* mu, double lambda_ref, double rho) {
+    return set_flow_nf(e, colptr, rowval, nzval, mu, lambda_ref, rho, 0, nullptr);
+}
+
+pdmp_status pdmp_ensemble_set_flow_boomerang(pdmp_ensemble* e, const int64_t* colptr, const int64_t* rowval,
+                                             const double* nzval, const double* mu_target, const double* mu_flow,
+                                             double lambda_ref, double rho) {
+    return set_flow_nf(e, colptr, rowval, nzval, mu_target, lambda_ref, rho, 1, mu_flow);
 }
 
 pdmp_status pdmp_ensemble_set_state_bps(pdmp_ensemble* e, double t0, const double* x0, const double* theta0, double c,
@@ -1057,6 +1075,8 @@ pdmp_status pdmp_ensemble_set_state_bps(pdmp_ensemble* e, double t0, const doubl
     B.rowval = e->b_rowval.p;
     B.nzval = e->b_nzval.p;
     B.mu = e->b_mu.p;
+    B.mu_flow = e->b_mu_flow.p;
+    B.flow_kind = e->bps_flow_kind;
     B.x = e->b_x.p;
     B.th = e->b_th.p;
     B.scal = e->b_scal.p;

@@ -163,6 +163,8 @@ struct BpsRunParams {
     int64_t trace_cap;
     double T, factor, lambda_ref, rho;
     int32_t flags, adapt;
+    int32_t flow_kind;                  // 0 BouncyParticle, 1 Boomerang (L = I): mu_flow is the centre of rotation
+    const double* __restrict__ mu_flow;  // [d]
 };
 int launch_bps_init(const BpsRunParams& p, int64_t nchains, const uint64_t* seeds, double t0, double c0, void* stream);
 int launch_bps_run(const BpsRunParams& p, int64_t nchains, bool diag, void* stream);

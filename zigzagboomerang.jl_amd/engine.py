@@ -87,6 +87,18 @@ class Ensemble:
         _lib.check(self._L.pdmp_ensemble_set_flow_bps(self._h, _ptr(cp), _ptr(rv), _ptr(nz), _ptr(mu), float(B.λref),
                                                      float(B.ρ)))
 
+    def set_flow_boomerang(self, target, B):
+        """Flow = Boomerang(I, μ, λ; ρ) on the Gaussian target ∇ϕ!(y, x) = Γt(x − μt)."""
+        G = B.Γ
+        if G.shape != (self.d, self.d) or G.nnz != self.d or not np.all(G.diagonal() == 1.0):
+            raise NotImplementedError("Boomerang: only Γ = I (mass L = I) is implemented on the device")
+        Gt = target.Γ
+        cp, rv, nz = _i64(Gt.indptr), _i64(Gt.indices), _f64(Gt.data)
+        mt = _f64(target.μ) if target.μ is not None else None
+        mf = _f64(B.μ)
+        _lib.check(self._L.pdmp_ensemble_set_flow_boomerang(self._h, _ptr(cp), _ptr(rv), _ptr(nz), _ptr(mt), _ptr(mf),
+                                                           float(B.λref), float(B.ρ)))
+
     def set_state_bps(self, t0, x0, theta0, c, seeds):
         x0 = _f64(x0).reshape(self.nchains, self.d)
         theta0 = _f64(theta0).reshape(self.nchains, self.d)

@@ -75,6 +75,20 @@ class BouncyParticle:
 
 
 @dataclass
+class Boomerang:
+    """Boomerang(Γ, μ, λ; ρ=0.0) -- src/types.jl:59-66: Hamiltonian dynamics preserving N(μ, ·) with refreshment rate λ.
+    The device path implements the mass L = I, i.e. Γ must be the identity (a general cholesky(Γ).L is not implemented)."""
+    Γ: sp.csc_matrix
+    μ: np.ndarray
+    λref: float
+    ρ: float = 0.0
+
+    def __post_init__(self):
+        self.Γ = _csc(self.Γ)
+        self.μ = np.ascontiguousarray(self.μ, dtype=np.float64)
+
+
+@dataclass
 class GaussianTarget:
     """∇ϕ(x, i) = Γ[:, i]·x  [− Γ[:, i]·μ]  (idot, src/common.jl:16-24): the device-resident stand-in
     for the reference's `∇ϕ(x, i, Γ) = idot(Γ, i, x)` closure + its `args... = (Γ,)`."""

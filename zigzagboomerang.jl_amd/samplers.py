@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _lib
 from .engine import Ensemble
-from .flows import BouncyParticle, FactBoomerang, FactTrace, GaussianTarget, LogisticTarget, PDMPTrace, ZigZag
+from .flows import Boomerang, BouncyParticle, FactBoomerang, FactTrace, GaussianTarget, LogisticTarget, PDMPTrace, ZigZag
 
 DEFAULT_SEED = 0x5EED0000
 
@@ -49,6 +49,11 @@ def pdmp(target, t0, x0, θ0, T, c, F, *, factor=1.8, adapt=False, seed=DEFAULT_
     returns Ξ::PDMPTrace, (t, x, θ), (acc, num), c."""
     if isinstance(F, BouncyParticle):
         return _bps(t0, x0, θ0, T, c, F, 2.0 if factor == 1.8 else factor, adapt, seed, device, trace_capacity, trace)
+    if isinstance(F, Boomerang):  # pdmp(∇ϕ!, t0, x0, θ0, T, c, B::Boomerang) (test/maintest.jl:139-154); target = GaussianTarget
+        if not isinstance(target, GaussianTarget):
+            raise TypeError("Boomerang: target must be a GaussianTarget (∇ϕ!(y, x) = Γ(x − μ))")
+        return _bps(t0, x0, θ0, T, c, F, 2.0 if factor == 1.8 else factor, adapt, seed, device, trace_capacity, trace,
+                    target=target)
     return _zigzag(_lib.SAMPLER_ZIGZAG_ALL, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, trace_capacity, trace)
 
 
@@ -122,7 +127,7 @@ def _zigzag(sampler, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, 
     return traces, (fs["t"], fs["x"], fs["theta"]), (acc, num), c_out
 
 
-def _bps(t0, x0, θ0, T, c, B, factor, adapt, seed, device, trace_capacity, trace):
+def _bps(t0, x0, θ0, T, c, B, factor, adapt, seed, device, trace_capacity, trace, target=None):
     x0 = np.asarray(x0, dtype=np.float64)
     θ0 = np.asarray(θ0, dtype=np.float64)
     single = x0.ndim == 1
@@ -134,7 +139,10 @@ def _bps(t0, x0, θ0, T, c, B, factor, adapt, seed, device, trace_capacity, trac
     cap = trace_capacity if trace else 0
     ens = Ensemble(nch, d, sampler=_lib.SAMPLER_BPS, adapt=adapt, factor=factor, device=device, trace_capacity=cap)
     try:
-        ens.set_flow_bps(B)
+        if target is not None:
+            ens.set_flow_boomerang(target, B)
+        else:
+            ens.set_flow_bps(B)
         ens.set_state_bps(t0, X0, TH0, float(c), seeds)
         ts = [[] for _ in range(nch)]
         xs = [[] for _ in range(nch)]

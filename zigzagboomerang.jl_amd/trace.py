@@ -5,7 +5,7 @@ are the callers' post-processing, not part of the device hot pat
 """
 import numpy as np
 
-from .flows import FactBoomerang, FactTrace
+from .flows import Boomerang, FactBoomerang, FactTrace, PDMPTrace
 
 
 def _flow(tr, x, th, dt):
@@ -38,8 +38,33 @@ def collect(tr: FactTrace):
     return np.array(ts), np.array(xs)
 
 
-def discretize(tr: FactTrace, dt):
-    """collect(discretize(Ξ, dt)): positions on the grid t0, t0+dt, ... -- src/trace.jl:94-125."""
+def _discretize_pdmp(tr: PDMPTrace, dt):
+    """collect(discretize(Ξ::PDMPTrace, dt)) -- src/trace.jl:102-106,129-150: the grid t0, t0+dt, ... up to (excluding) the
+    last event time; between events the state flows from the latest event (linear, or the Boomerang rotation about μ).
+    Closed form per grid point (the reference accumulates dt steps)."""
+    d = len(tr.x0)
+    if len(tr.t) == 0:
+        return np.array([tr.t0]), tr.x0[None].copy()
+    n = int(np.ceil((tr.t[-1] - tr.t0) / dt))
+    grid = tr.t0 + dt * np.arange(n)
+    grid = grid[grid < tr.t[-1]]
+    te = np.concatenate([[tr.t0], tr.t])
+    X = np.vstack([tr.x0[None], tr.x.reshape(-1, d)])
+    TH = np.vstack([tr.θ0[None], tr.θ.reshape(-1, d)])
+    idx = np.searchsorted(te, grid, side="right") - 1
+    tau = (grid - te[idx])[:, None]
+    if isinstance(tr.F, Boomerang):
+        mu = tr.F.μ
+        xs = (X[idx] - mu) * np.cos(tau) + TH[idx] * np.sin(tau) + mu
+    else:
+        xs = X[idx] + TH[idx] * tau
+    return grid, xs
+
+
+def discretize(tr, dt):
+    """collect(discretize(Ξ, dt)): positions on the grid t0, t0+dt, ... -- src/trace.jl:94-125 (FactTrace), :129-150 (PDMPTrace)."""
+    if isinstance(tr, PDMPTrace):
+        return _discretize_pdmp(tr, dt)
     ev = tr.events
     t, x, th = tr.t0, tr.x0.copy(), tr.θ0.copy()
     ts, xs = [t], [x.copy()]
