@@ -111,6 +111,8 @@ struct pdmp_ensemble {
     uint32_t mmax_all = 0;
     int target_kind = 0;
     DevBuf<uint16_t> d_pos16, d_selfpos16;
+    DevBuf<double> d_qbval;
+    DevBuf<uint32_t> d_member;
     DevBuf<int64_t> lg_Acp, lg_Arv, lg_Atcp, lg_Atrv;
     DevBuf<double> lg_Anz, lg_Atnz, lg_y, lg_ny, lg_u0, lg_ns0;
     double lg_gamma0 = 0.0;
@@ -292,6 +294,8 @@ static pdmp_status set_flow_common(pdmp_ensemble* e, const int64_t* colptr, cons
     std::vector<uint8_t> pos;
     pos.reserve((size_t)nnz * 5);
     std::vector<uint16_t> pos16;
+    std::vector<double> qbval;     // Γ value of every (member j of G1[i], entry of column j) pair, same order as pos16
+    std::vector<uint32_t> member;  // per entry p of column i: {j, k_j, qptr[p], 0} -- one 16-byte load per member
     pos16.reserve((size_t)nnz * 5);
     std::vector<uint32_t> tmp;
     for (int64_t i = 0; i < d; ++i) {
@@ -334,12 +338,21 @@ static pdmp_status set_flow_common(pdmp_ensemble* e, const int64_t* colptr, cons
                                 (long long)i);
                 pos.push_back((uint8_t)where);
                 pos16.push_back((uint16_t)where);
+                qbval.push_back(e->bval[q]);
             }
         }
     }
     qptr[nnz] = (uint32_t)pos.size();
     if (pos.empty()) pos.push_back(0);
     if (pos16.empty()) pos16.push_back(0);
+    if (qbval.empty()) qbval.push_back(0.0);
+    member.resize((size_t)nnz * 4 + 4, 0u);
+    for (int64_t p = 0; p < nnz; ++p) {
+        const uint32_t j = e->rowval[p];
+        member[(size_t)p * 4 + 0] = j;
+        member[(size_t)p * 4 + 1] = e->colptr[j + 1] - e->colptr[j];
+        member[(size_t)p * 4 + 2] = qptr[p];
+    }
     e->flow_kind = kind;
     e->needs_general = general || kind == 1;  // FactBoomerang runs on the general kernel
     e->mmax_all = mmax_all;
@@ -370,6 +383,8 @@ static pdmp_status set_flow_common(pdmp_ensemble* e, const int64_t* colptr, cons
     if ((st = e->d_selfpos.upload(selfpos)) != PDMP_OK) return st;
     if ((st = e->d_sigma.upload(e->sigma)) != PDMP_OK) return st;
     if ((st = e->d_pos16.upload(pos16)) != PDMP_OK) return st;
+    if ((st = e->d_qbval.upload(qbval)) != PDMP_OK) return st;
+    if ((st = e->d_member.upload(member)) != PDMP_OK) return st;
     if ((st = e->d_selfpos16.upload(selfpos16)) != PDMP_OK) return st;
     e->target_kind = 0;
 
@@ -620,7 +635,7 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
                         "kernel: spdmp only");
         if (e->target_kind == 1 && (e->flow_kind == 1 || e->lambda_ref > 0))
             return fail(PDMP_ERR_UNSUPPORTED, "the logistic target is implemented for ZigZag without refresh");
-        if (pdmp::zz_general_lds_bytes(e->nblk_pad, (e->mmax_all + 63u) & ~63u) > 160 * 1024)
+        if (pdmp::zz_general_lds_bytes(e->nblk_pad, (e->mmax_all + 63u) & ~63u, e->flow_kind == 1) > 160 * 1024)
             return fail(PDMP_ERR_UNSUPPORTED, "LDS budget exceeded by the general kernel");
         if (e->adaptscale) {
             if (e->target_kind == 1) return fail(PDMP_ERR_UNSUPPORTED, "adaptscale needs the refresh clock; the logistic target has none");
@@ -770,7 +785,8 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
     const char* phenv = getenv("PDMP_PHASE");
     DevBuf<double> phbuf;
     const bool spec_ok = e->use_spec && dbg_cap == 0 && !P.has_refresh && !P.move_all && !sticky;
-    if (phenv && spec_ok) {
+    const bool general_path = e->needs_general || e->target_kind == 1 || e->adaptscale;
+    if (phenv && (spec_ok || general_path)) {
         pdmp_status st3 = phbuf.alloc(16);
         if (st3 != PDMP_OK) return st3;
         HIP_TRY(hipMemset(phbuf.p, 0, 16 * sizeof(double)));
@@ -782,6 +798,8 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         Q.sig_chain = e->adaptscale ? e->d_sig_chain.p : nullptr;
         Q.adaptscale = e->adaptscale ? 1 : 0;
         Q.pos16 = e->d_pos16.p;
+        Q.qbval = e->d_qbval.p;
+        Q.member = reinterpret_cast<const uint4*>(e->d_member.p);
         Q.selfpos16 = e->d_selfpos16.p;
         Q.mmax_pad = (e->mmax_all + 63u) & ~63u;
         Q.target_kind = e->target_kind;
@@ -805,6 +823,13 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         if (rcg != 0) return fail(PDMP_ERR_HIP, "zz_general_run launch failed: %s", hipGetErrorString((hipError_t)rcg));
         HIP_TRY(hipEventRecord(e->ev1, s));
         e->timed = true;
+        if (phenv) {
+            HIP_TRY(hipDeviceSynchronize());
+            double hp[16];
+            HIP_TRY(hipMemcpy(hp, phbuf.p, sizeof hp, hipMemcpyDeviceToHost));
+            fprintf(stderr, "PHASE(general) proposals=%.0f cycles/proposal: select=%.0f moveG1=%.0f grad=%.0f coin+G2=%.0f rebound=%.0f requeue=%.0f tail=%.0f\n",
+                    hp[10], hp[0] / hp[10], hp[1] / hp[10], hp[2] / hp[10], hp[3] / hp[10], hp[4] / hp[10], hp[5] / hp[10], hp[6] / hp[10]);
+        }
         return PDMP_OK;
     }
     int rc = sticky ? pdmp::launch_zz_sticky_run(P, e->cfg.nchains, s) : spec_ok ? pdmp::launch_zz_local_spec(P, e->cfg.nchains, s)

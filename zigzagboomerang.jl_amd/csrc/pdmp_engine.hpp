@@ -120,6 +120,8 @@ struct ZzInitParams {
 struct ZzGeneralParams {
     const uint16_t* __restrict__ pos16;      // like ZzTables::pos, 16-bit positions inside S[i]
     const uint16_t* __restrict__ selfpos16;  // position of i inside G1[i]
+    const double* __restrict__ qbval;        // like pos16: the Γ value of the same (member, entry) pair
+    const uint4* __restrict__ member;        // per entry p of column i: {j, k_j, qptr[p], -}
     uint32_t mmax_pad;                       // LDS scratch slots (max |S[i]|, padded)
     int32_t target_kind;                     // 0 Gaussian CSC, 1 subsampled logistic (scripts/logistic.jl:107)
     const int64_t* __restrict__ A_colptr;    // design A (n x p), CSC by coordinate
@@ -144,7 +146,7 @@ struct ZzGeneralParams {
     int32_t adaptscale;
 };
 int launch_zz_general_run(const ZzRunParams& p, const ZzGeneralParams& q, int64_t nchains, void* stream);
-size_t zz_general_lds_bytes(uint32_t nblk_pad, uint32_t mmax_pad);
+size_t zz_general_lds_bytes(uint32_t nblk_pad, uint32_t mmax_pad, bool boom);
 
 // Bouncy particle sampler (pdmp_bps.hip): per chain x[d], θ[d] (SoA), 8 scalars {t, a, b, t′, τref, c, -, -}
 struct BpsRunParams {

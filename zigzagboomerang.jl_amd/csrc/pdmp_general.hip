@@ -73,10 +73,13 @@ __device__ __forceinline__ double g_sigmoid(double x) {
     return 1.0 / (1.0 + pdmp_exp(-x));
 }
 
-size_t zz_general_lds_bytes(uint32_t nblk_pad, uint32_t mmax_pad) {
-    return (size_t)nblk_pad * 8 + (size_t)3 * mmax_pad * 8 + (size_t)nblk_pad * 4 + 64 * 8;
+#define G_PCH 128u  // (member, entry) products staged per chunk by the re-bound step
+
+size_t zz_general_lds_bytes(uint32_t nblk_pad, uint32_t mmax_pad, bool boom) {
+    return (size_t)nblk_pad * 8 + (size_t)(boom ? 3 : 2) * mmax_pad * 8 + (size_t)nblk_pad * 4 + (size_t)2 * G_PCH * 8;
 }
 
+template <bool PROF>
 __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGeneralParams Q) {
     const int lane = threadIdx.x;
     const int64_t chain = blockIdx.x;
@@ -87,9 +90,11 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
     double* bk = reinterpret_cast<double*>(smem);
     double* sx = bk + P.nblk_pad;       // [mmax_pad] x of S[i] by position
     double* sth = sx + Q.mmax_pad;      // [mmax_pad] θ of S[i]
-    double* smu = sth + Q.mmax_pad;     // [mmax_pad] μ of S[i] (FactBoomerang)
-    uint32_t* bi = reinterpret_cast<uint32_t*>(smu + Q.mmax_pad);
-    double* sprod = reinterpret_cast<double*>(bi + P.nblk_pad);  // [64] products A'[e, row] * x[e] of one chunk
+    double* smu = sth + Q.mmax_pad;     // [mmax_pad] μ of S[i] (FactBoomerang only: not allocated for ZigZag)
+    uint32_t* bi = reinterpret_cast<uint32_t*>(smu + ((Q.flow_kind == 1) ? Q.mmax_pad : 0u));
+    double* px = reinterpret_cast<double*>(bi + P.nblk_pad);  // [G_PCH] products of the bound's dot products, one chunk
+    double* pt = px + G_PCH;                                   // [G_PCH]
+    double* sprod = px;  // [64] products A'[e, row] * x[e] of one chunk (logistic gradient; not live at the same time)
 
     ZzRec* rec = P.rec + chain * d;
     double* keys = P.keys + chain * P.dk;
@@ -114,6 +119,17 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
     const double T = P.T;
     const bool stop_before = (P.flags & PDMP_RUN_STOP_BEFORE) != 0;
     const bool adapt = P.adapt != 0;
+    // PDMP_PHASE=1: cycles per phase, chain 0 (diagnostic build of the same loop)
+    uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t ph_t0 = PROF ? (uint64_t)__builtin_readcyclecounter() : 0;
+#define GPHASE(k)                                                         \
+    do {                                                                  \
+        if (PROF) {                                                       \
+            const uint64_t now_ = (uint64_t)__builtin_readcyclecounter(); \
+            ph[k] += now_ - ph_t0;                                        \
+            ph_t0 = now_;                                                 \
+        }                                                                 \
+    } while (0)
 
     for (uint32_t b = lane; b < nblk; b += 64) {
         const double* kp = keys + (size_t)b * 64;
@@ -207,37 +223,81 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
         }
         G_ORDER();
     };
-    // ab + new event time for the members jj0 .. jj1 of G1[i]; own_clock: Q[j] = t[j] + ... at j's own (stale) clock
+    // ab + new event time for the members jj0 .. jj1 of G1[i]; own_clock: Q[j] = t[j] + ... at j's own (stale) clock.
+    // The dot products Γ[:,j]·x, Γ[:,j]·θ keep idot's order (ascending row, src/common.jl:16-24) but their PRODUCTS are formed
+    // 64 at a time: the (member, entry) pairs of one pass are contiguous in pos16 / qbidx, the lanes stream them through LDS
+    // in chunks of G_PCH, and every lane then adds up the run that belongs to its member.  (One lane per member walking its
+    // column alone pays an L2 round trip per entry: 167 in a row for the intercept of config C4.)
     auto rebound = [&](uint32_t cp0, uint32_t jj0, uint32_t jj1, double tp, uint64_t draw0, bool per_member_draw,
                        bool own_clock) {
         for (uint32_t base = jj0; base < jj1; base += 64) {
             const uint32_t jj = base + (uint32_t)lane;
-            if (jj < jj1) {
-                const uint32_t j = P.tb.rowval[cp0 + jj];
-                const uint32_t cj0 = P.tb.colptr[j];
-                const uint32_t kj = P.tb.colptr[j + 1] - cj0;
-                const uint32_t q0 = P.tb.qptr[cp0 + jj];
+            const bool valid = jj < jj1;
+            const uint32_t jjc = valid ? jj : (jj1 - 1u);
+            const uint4 mrec = Q.member[cp0 + jjc];
+            const uint32_t j = mrec.x;
+            const uint32_t kj = valid ? mrec.y : 0u;
+            const uint32_t q0 = mrec.z;
+            const uint32_t last = (base + 64u < jj1) ? (base + 64u) : jj1;
+            const uint32_t qs = P.tb.qptr[cp0 + base], qe = P.tb.qptr[cp0 + last];
+            double s1 = 0.0, s2 = 0.0;  // ZigZag: Γ[:,j]·x, Γ[:,j]·θ; FactBoomerang: Σ (x−μ)² + θ²
+            for (uint32_t cb = qs; cb < qe; cb += G_PCH) {
+                const uint32_t ce = (cb + G_PCH < qe) ? (cb + G_PCH) : qe;
+                G_ORDER();
+                for (uint32_t f = cb + (uint32_t)lane; f < ce; f += 64) {
+                    const uint32_t ps = Q.pos16[f];
+                    if (!boom) {
+                        const double v = Q.qbval[f];
+                        px[f - cb] = v * sx[ps];
+                        pt[f - cb] = v * sth[ps];
+                    } else {
+                        const double dx = sx[ps] - smu[ps];
+                        px[f - cb] = dx * dx + sth[ps] * sth[ps];
+                    }
+                }
+                G_ORDER();
+                const uint32_t z0 = (q0 > cb) ? q0 : cb, z1 = (q0 + kj < ce) ? (q0 + kj) : ce;
+                // sequential sums; the LDS reads of 8 terms are issued together, the adds stay in order
+                uint32_t z = z0;
+                if (!boom) {
+                    for (; z + 8 <= z1; z += 8) {
+                        double u[8], w[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            u[q] = px[z - cb + q];
+                            w[q] = pt[z - cb + q];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            s1 += u[q];
+                            s2 += w[q];
+                        }
+                    }
+                    for (; z < z1; ++z) {
+                        s1 += px[z - cb];
+                        s2 += pt[z - cb];
+                    }
+                } else {
+                    for (; z + 8 <= z1; z += 8) {
+                        double u[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) u[q] = px[z - cb + q];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) s1 += u[q];
+                    }
+                    for (; z < z1; ++z) s1 += px[z - cb];
+                }
+            }
+            G_ORDER();
+            if (valid) {
                 const double cj = cvec[j];
                 const double xj = sx[jj], thj = sth[jj];
                 double a, b;
                 if (!boom) {
-                    double gx = 0.0, gt = 0.0;
-                    for (uint32_t pp = 0; pp < kj; ++pp) {
-                        const double v = P.tb.bval[cj0 + pp];
-                        const uint32_t ps = Q.pos16[q0 + pp];
-                        gx += v * sx[ps];
-                        gt += v * sth[ps];
-                    }
-                    a = cj + (gx - P.tb.gmu_b[j]) * thj;  // src/fact_samplers.jl:51
-                    b = cj / 100 + thj * gt;             // :52
+                    a = cj + (s1 - P.tb.gmu_b[j]) * thj;  // src/fact_samplers.jl:51
+                    b = cj / 100 + thj * s2;             // :52
                 } else {
-                    double zz = 0.0;  // ab(G, i, x, θ, c, Z::FactBoomerang), src/fact_samplers.jl:58-65
-                    for (uint32_t pp = 0; pp < kj; ++pp) {
-                        const uint32_t ps = Q.pos16[q0 + pp];
-                        const double dx = sx[ps] - smu[ps];
-                        zz += dx * dx + sth[ps] * sth[ps];
-                    }
-                    const double z = sqrt(zz);
+                    const double z = sqrt(s1);  // ab(G, i, x, θ, c, Z::FactBoomerang), src/fact_samplers.jl:58-65
                     const double z2 = xj * xj + thj * thj;
                     a = cj * sqrt(z2) * z + z2 * Q.diag[j];
                     b = 0.0;
@@ -289,6 +349,7 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
         }
         const uint32_t i = g_uniform(bi[blk]);
         t_last = tp;
+        GPHASE(0);
 
         const uint32_t cp0 = P.tb.colptr[i];
         const uint32_t k = P.tb.colptr[i + 1] - cp0;
@@ -374,6 +435,7 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
             continue;
         }
         move_members(sp0, 0, k, tp);  // smove_forward!(G, i, ...), :82
+        GPHASE(1);
         // ---------------- gradient
         double g;
         double urow = 0.0;
@@ -459,6 +521,7 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
             ng += (uint64_t)Q.ksub;
             g = prior - s;
         }
+        GPHASE(2);
         const double th_i = sth[self];
         const double l_rate = boom ? g_pos((g - (sx[self] - Q.mu[i]) * Q.diag[i]) * th_i)  // src/fact_samplers.jl:37-39
                                    : g_pos(g * th_i);                                        // :119
@@ -484,13 +547,16 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
             }
             G_ORDER();
         }
+        GPHASE(3);
         // ---------------- re-bound: all of G1[i] on accept (:131-135), i alone on reject (:137-139)
         const uint32_t jj0 = accept ? 0u : self;
         const uint32_t jj1 = accept ? k : self + 1u;
         rebound(cp0, jj0, jj1, tp, nm, accept, false);
         nm += accept ? (uint64_t)k : 1u;
+        GPHASE(4);
         // ---------------- level 1 of the queue (keys[] already hold the new values)
         requeue(cp0, jj0, jj1, false, 0u);
+        GPHASE(5);
         if (accept) {
             if (ev && lane == 0) {
                 pdmp_event e;
@@ -506,6 +572,11 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
             if (!stop_before && !(tp < T)) running = false;
         }
         G_ORDER();
+        GPHASE(6);
+    }
+    if (PROF && chain == 0 && lane == 0 && P.dbg) {
+        for (int q = 0; q < 8; ++q) P.dbg[q] = (double)ph[q];
+        P.dbg[10] = (double)(num - hdr->c.num);
     }
 
     if (lane == 0) {
@@ -523,13 +594,16 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
 }
 
 int launch_zz_general_run(const ZzRunParams& p, const ZzGeneralParams& q, int64_t nchains, void* stream) {
-    const size_t lds = zz_general_lds_bytes(p.nblk_pad, q.mmax_pad);
+    const size_t lds = zz_general_lds_bytes(p.nblk_pad, q.mmax_pad, q.flow_kind == 1);
+    const bool prof = p.dbg != nullptr;
+    const void* fn = prof ? reinterpret_cast<const void*>(zz_general_run_kernel<true>)
+                          : reinterpret_cast<const void*>(zz_general_run_kernel<false>);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(zz_general_run_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(zz_general_run_kernel, dim3((unsigned)nchains), dim3(64), lds, (hipStream_t)stream, p, q);
+    if (prof) hipLaunchKernelGGL(zz_general_run_kernel<true>, dim3((unsigned)nchains), dim3(64), lds, (hipStream_t)stream, p, q);
+    else hipLaunchKernelGGL(zz_general_run_kernel<false>, dim3((unsigned)nchains), dim3(64), lds, (hipStream_t)stream, p, q);
     return (int)hipGetLastError();
 }
 
