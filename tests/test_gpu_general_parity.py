@@ -133,3 +133,41 @@ def test_adaptscale_matches_oracle(gpu_pkg):
             assert np.array_equal(x[k], r["x"]) and np.array_equal(th[k], r["theta"]) and np.array_equal(t[k], r["t"])
             assert np.array_equal(tr[k].F.σ, r["sigma"]) and not np.array_equal(r["sigma"], sig0)
     assert np.array_equal(F.σ, sig0)  # an ensemble call leaves the caller's flow alone
+
+
+def test_pdmp_all_on_the_general_kernel(gpu_pkg):
+    """pdmp(∇ϕ, t0, x0, θ0, T, c, Z::FactBoomerang, Z.Γ) (test/maintest.jl:100-105: G = All(), every proposal moves all d
+    coordinates, src/sfact.jl:23-48,236), and the same for a ZigZag whose neighbourhoods exceed one wavefront."""
+    pkg = gpu_pkg
+    G = pkg.problems.maintest_precision(8)
+    rng = np.random.default_rng(6)
+    Gz = sp.csc_matrix(0.85 * G)
+    F = pkg.FactBoomerang(Gz, np.zeros(8), 0.3)
+    x0 = rng.random((3, 8))
+    th0 = F.σ * rng.standard_normal((3, 8))
+    c = pkg.problems.column_norms(G)
+    T, seed = 120.0, 130
+    tr, (t, x, th), (acc, num), cout = pkg.pdmp(pkg.GaussianTarget(Gz), 0.0, x0, th0, T, c, F, seed=seed)
+    for k in range(3):
+        r = O.spdmp_zigzag(F.Γ, F.μ, Gz, x0[k], th0[k], c, T, seed=seed + k, lambda_ref=F.λref, rho=F.ρ, sigma=F.σ,
+                           factboomerang=True, move_all=True)
+        assert r["status"] == 0 and len(tr[k].events) == len(r["events"]) > 20
+        for f in ("i", "t", "x", "theta"):
+            assert np.array_equal(tr[k].events[f], r["events"][f]), (k, f)
+        assert int(num[k]) == r["num"] and np.array_equal(acc[k], r["acc"])
+        assert np.array_equal(x[k], r["x"]) and np.array_equal(th[k], r["theta"]) and np.array_equal(t[k], r["t"])
+    d = 150
+    R = sp.random(d, d, density=0.08, random_state=rng, data_rvs=rng.standard_normal, format="csc")
+    G2 = sp.csc_matrix(R @ R.T + 2.0 * sp.identity(d))
+    G2.sort_indices()
+    Z = pkg.ZigZag(G2, np.zeros(d), np.ones(d), λref=0.3)
+    x0 = rng.standard_normal((2, d))
+    th0 = rng.choice([-1.0, 1.0], (2, d))
+    c2 = 2.0 * pkg.problems.column_norms(G2)
+    tr, (t, x, th), (acc, num), cout = pkg.pdmp(pkg.GaussianTarget(G2), 0.0, x0, th0, 3.0, c2, Z, seed=140)
+    for k in range(2):
+        r = O.spdmp_zigzag(G2, Z.μ, G2, x0[k], th0[k], c2, 3.0, seed=140 + k, lambda_ref=0.3, sigma=Z.σ, move_all=True)
+        assert r["status"] == 0 and len(tr[k].events) == len(r["events"]) > 20
+        for f in ("i", "t", "x", "theta"):
+            assert np.array_equal(tr[k].events[f], r["events"][f]), (k, f)
+        assert np.array_equal(x[k], r["x"]) and np.array_equal(t[k], r["t"]) and int(num[k]) == r["num"]

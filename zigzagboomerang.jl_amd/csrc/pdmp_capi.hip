@@ -408,8 +408,8 @@ pdmp_status pdmp_ensemble_set_flow_zigzag(pdmp_ensemble* e, const int64_t* colpt
 pdmp_status pdmp_ensemble_set_flow_factboomerang(pdmp_ensemble* e, const int64_t* colptr, const int64_t* rowval,
                                                  const double* nzval, const double* mu, const double* sigma,
                                                  double lambda_ref, double rho) {
-    if (e && e->cfg.sampler != PDMP_SAMPLER_ZIGZAG_LOCAL)
-        return fail(PDMP_ERR_UNSUPPORTED, "FactBoomerang is available for the factorised driver spdmp (PDMP_SAMPLER_ZIGZAG_LOCAL)");
+    if (e && e->cfg.sampler != PDMP_SAMPLER_ZIGZAG_LOCAL && e->cfg.sampler != PDMP_SAMPLER_ZIGZAG_ALL)
+        return fail(PDMP_ERR_UNSUPPORTED, "FactBoomerang is available for the factorised drivers spdmp / pdmp (PDMP_SAMPLER_ZIGZAG_LOCAL / _ALL)");
     if (!(lambda_ref > 0)) return fail(PDMP_ERR_INVALID, "FactBoomerang needs a strictly positive refreshment rate");
     return set_flow_common(e, colptr, rowval, nzval, mu, sigma, lambda_ref, rho, 1);
 }
@@ -629,10 +629,12 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
     std::vector<double> cv(c, c + d);
     if ((st = e->d_c.upload(cv)) != PDMP_OK) return st;
     if (e->needs_general || e->target_kind == 1 || e->adaptscale) {
-        if (e->cfg.sampler != PDMP_SAMPLER_ZIGZAG_LOCAL)
+        if (e->cfg.sampler != PDMP_SAMPLER_ZIGZAG_LOCAL && e->cfg.sampler != PDMP_SAMPLER_ZIGZAG_ALL)
             return fail(PDMP_ERR_UNSUPPORTED,
                         "neighbourhoods beyond 64 members / the logistic target / FactBoomerang / adaptscale run on the general "
-                        "kernel: spdmp only");
+                        "kernel: spdmp and pdmp only");
+        if (e->cfg.sampler == PDMP_SAMPLER_ZIGZAG_ALL && e->target_kind == 1)
+            return fail(PDMP_ERR_UNSUPPORTED, "the logistic target moves what it reads (SelfMoving): use PDMP_SAMPLER_ZIGZAG_LOCAL");
         if (e->target_kind == 1 && (e->flow_kind == 1 || e->lambda_ref > 0))
             return fail(PDMP_ERR_UNSUPPORTED, "the logistic target is implemented for ZigZag without refresh");
         if (pdmp::zz_general_lds_bytes(e->nblk_pad, (e->mmax_all + 63u) & ~63u, e->flow_kind == 1) > 160 * 1024)

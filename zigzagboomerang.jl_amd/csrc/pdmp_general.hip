@@ -210,6 +210,32 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
         }
         G_ORDER();
     };
+    // G = All() (pdmp, src/sfact.jl:236): smove_forward!(t, x, θ, t′, F) over all d coordinates (:23-28, :37-48)
+    auto move_everything = [&](double tp) {
+        for (uint32_t base = 0; base < (uint32_t)d; base += 64) {
+            const uint32_t j = base + (uint32_t)lane;
+            if (j < (uint32_t)d) {
+                ZzRec* r = rec + j;
+                const double x0 = r->x, th0 = r->th, t0 = r->t, I0 = r->I;
+                const double dt = tp - t0;
+                if (!boom) {
+                    const double xn = x0 + th0 * dt;
+                    r->x = xn;
+                    r->t = tp;
+                    r->I = I0 + dt * ((x0 + xn) * 0.5);
+                } else {
+                    const double mj = Q.mu[j];
+                    double sn, cs;
+                    pdmp_sincos(dt, &sn, &cs);
+                    r->x = (x0 - mj) * cs + th0 * sn + mj;
+                    r->th = -(x0 - mj) * sn + th0 * cs;
+                    r->t = tp;
+                    r->I = I0 + (mj * dt + (x0 - mj) * sn + th0 * (1.0 - cs));
+                }
+            }
+        }
+        G_ORDER();
+    };
     // stage members WITHOUT moving them (refresh branch: G1[i] is re-bounded at the coordinates' own clocks)
     auto stage_members = [&](uint32_t sp0, uint32_t p0, uint32_t p1) {
         for (uint32_t base = p0; base < p1; base += 64) {
@@ -365,7 +391,8 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
             // draws :80,:84; G1[i] re-bounded at the coordinates' own clocks :110-114)
             const uint32_t i1 = pdmp_randint(seed, PDMP_STREAM_GLOBAL, ng, (uint32_t)d);
             ng += 1;
-            move_members(P.tb.sptr[i1], 0, P.tb.colptr[i1 + 1] - P.tb.colptr[i1], tp);  // :82
+            if (P.move_all) move_everything(tp);
+            else move_members(P.tb.sptr[i1], 0, P.tb.colptr[i1 + 1] - P.tb.colptr[i1], tp);  // :82
             const uint32_t i2 = pdmp_randint(seed, PDMP_STREAM_GLOBAL, ng, (uint32_t)d);
             ng += 1;
             const uint32_t cp2 = P.tb.colptr[i2];
@@ -373,7 +400,8 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
             const uint32_t sp2 = P.tb.sptr[i2];
             const uint32_t m2 = P.tb.sptr[i2 + 1] - sp2;
             const uint32_t self2 = Q.selfpos16[i2];
-            move_members(sp2, k2, m2, tp);  // smove_forward!(G2, i, ...), :85
+            if (P.move_all) stage_members(sp2, k2, m2);  // G2 = nothing (:172): nothing to move, values still needed below
+            else move_members(sp2, k2, m2, tp);           // smove_forward!(G2, i, ...), :85
             stage_members(sp2, 0, k2);
             double thn;
             double sg2 = sigc ? sigc[i2] : P.tb.sigma[i2];
@@ -434,7 +462,12 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
             G_ORDER();
             continue;
         }
-        move_members(sp0, 0, k, tp);  // smove_forward!(G, i, ...), :82
+        if (P.move_all) {
+            move_everything(tp);
+            stage_members(sp0, 0, k);
+        } else {
+            move_members(sp0, 0, k, tp);  // smove_forward!(G, i, ...), :82
+        }
         GPHASE(1);
         // ---------------- gradient
         double g;
@@ -539,7 +572,8 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
                 break;
             }
             if (violated && lane == 0) cmut[i] = cvec[i] * P.factor;  // adapt!(c, i, factor), :127
-            move_members(sp0, k, m, tp);                              // smove_forward!(G2, i, ...), :129
+            if (P.move_all) stage_members(sp0, k, m);
+            else move_members(sp0, k, m, tp);                         // smove_forward!(G2, i, ...), :129
             if (lane == 0) {
                 sth[self] = -th_i;  // reflect!, :130
                 rec[i].th = -th_i;
