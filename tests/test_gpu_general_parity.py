@@ -171,3 +171,28 @@ def test_pdmp_all_on_the_general_kernel(gpu_pkg):
         for f in ("i", "t", "x", "theta"):
             assert np.array_equal(tr[k].events[f], r["events"][f]), (k, f)
         assert np.array_equal(x[k], r["x"]) and np.array_equal(t[k], r["t"]) and int(num[k]) == r["num"]
+
+
+def test_golden2_c4_on_the_device(gpu_pkg):
+    """The committed golden vector of config C4 (tests/golden/golden2.npz, made by make_golden2.py) straight from the device."""
+    import hashlib
+    import os
+    pkg = gpu_pkg
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden2.npz"), allow_pickle=False)
+    import importlib.util
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_golden2", os.path.join(here, "golden", "make_golden2.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    L = mg.c4_inputs(gold)  # the fixture carries its inputs (μ, σ, Γdrop come out of LAPACK solves: host dependent bits)
+    th0 = L["th0"]
+    Z = pkg.ZigZag(L["Gdrop"], L["mu"], L["sigma"])
+    target = pkg.LogisticTarget(L["A"], L["y"], L["ny"], L["mu"], L["gamma0"], 10)
+    tr, (t, x, th), (acc, num), cout = pkg.spdmp(target, 0.0, L["x0"], th0, 3.0, L["c"], Z, seed=0x5EED0000, adapt=True, factor=5.0)
+    ev = tr.events
+    assert np.array_equal(ev["i"].astype(np.uint16), gold["c4_idx"]) and np.array_equal(ev["t"][:50], gold["c4_t_head"])
+    assert int(num) == int(gold["c4_n"][0]) and int(acc.sum()) == int(gold["c4_n"][1])
+    h = hashlib.sha256()
+    for a in (ev["t"], ev["x"], ev["theta"], x, th, t, cout, L["sigma"]):
+        h.update(np.ascontiguousarray(a).tobytes())
+    assert h.hexdigest() == str(gold["c4_hash"][0])

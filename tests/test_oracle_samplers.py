@@ -281,3 +281,20 @@ def test_boomerang_statistics_d8(pkg):
     assert len(ts) > 0.9 * T / 0.1
     assert np.mean(np.abs(xs.mean(0))) < 2 / np.sqrt(T)
     assert np.mean(np.abs(np.cov(xs.T) - np.linalg.inv(G.toarray()))) < 2.5 / np.sqrt(T)
+
+
+def test_golden2_newer_paths():
+    """tests/golden/golden2.npz: logistic target (C4), FactBoomerang (spdmp / pdmp All), adaptscale, Boomerang -- the oracle
+    still reproduces the committed index sequences, counters and payload hashes."""
+    import importlib.util
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_golden2", os.path.join(here, "golden", "make_golden2.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    gold = np.load(os.path.join(here, "golden", "golden2.npz"), allow_pickle=False)
+    for name, fn in mg.cases(gold).items():
+        r = fn()
+        assert r["status"] == 0
+        for key, val in mg.summarize(name, r).items():
+            assert np.array_equal(val, gold[key]), key
