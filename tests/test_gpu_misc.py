@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
+import oracle_lib as O
+
 pytestmark = pytest.mark.gpu
 
 
@@ -66,3 +68,34 @@ def test_rccl_world1_gather_of_device_resident_traces():
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_world1_script.py")
     r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_degenerate_sizes_match_oracle(gpu_pkg):
+    """Edge cases: d = 1, a diagonal Γ (every neighbourhood is {i}), one chain, T <= t0 (`while t′ < T` never runs: empty trace,
+    state and clocks untouched, no draw beyond the d initial ones)."""
+    import scipy.sparse as sp
+    pkg = gpu_pkg
+    rng = np.random.default_rng(8)
+    for d in (1, 3, 65):
+        G = sp.diags(0.5 + rng.random(d), format="csc")
+        x0 = rng.standard_normal((2, d))
+        th0 = rng.choice([-1.0, 1.0], (2, d))
+        c = pkg.problems.column_norms(G) + 0.1
+        for T in (0.0, 25.0):
+            tr, (t, x, th), (acc, num), _ = pkg.spdmp(pkg.GaussianTarget(G), 0.0, x0, th0, T, c, pkg.ZigZag(G, np.zeros(d)), seed=900)
+            for k in range(2):
+                r = O.spdmp_zigzag(G, None, G, x0[k], th0[k], c, T, seed=900 + k)
+                assert r["status"] == 0 and len(tr[k].events) == len(r["events"])
+                for f in ("i", "t", "x", "theta"):
+                    assert np.array_equal(tr[k].events[f], r["events"][f]), (d, T, k, f)
+                assert int(num[k]) == r["num"] and np.array_equal(x[k], r["x"]) and np.array_equal(t[k], r["t"])
+                if T == 0.0:
+                    assert len(tr[k].events) == 0 and np.array_equal(x[k], x0[k]) and np.all(t[k] == 0.0)
+    # the same degenerate horizon for the other samplers
+    B = pkg.BouncyParticle(sp.identity(4, format="csc"), np.zeros(4), 1.0)
+    trb, (tb, xb, thb), (accb, numb), _ = pkg.pdmp(None, 0.0, x0[:1, :4].copy(), th0[:1, :4].copy(), 0.0, 1e-3, B, seed=5)
+    assert len(trb[0].t) == 0 and int(numb[0]) == 0 and np.array_equal(xb[0], x0[0, :4])
+    Gs = sp.diags(np.ones(3), format="csc")
+    trs, (ts, xs, ths), (accs, nums), _ = pkg.sspdmp(pkg.GaussianTarget(Gs), 0.0, x0[:1, :3].copy(), th0[:1, :3].copy(), 0.0,
+                                                     np.ones(3), pkg.ZigZag(Gs, np.zeros(3)), np.ones(3), seed=6)
+    assert len(trs[0].events) == 0 and np.array_equal(xs[0], x0[0, :3])
