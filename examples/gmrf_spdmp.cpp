@@ -1,0 +1,84 @@
+// gmrf_spdmp.cpp -- the reference's scripts/gaussianrandomfield.jl (local ZigZag on a grid-Laplace GMRF, :15-41) written
+// against the C++ host mirror include/pdmp_mi355.hpp:   Γ = 0.01 I + gridlaplacian(n, n) (scripts/gridlaplace.jl:4-21),
+// ∇ϕ(x, i, Γ) = idot(Γ, i, x), Z = ZigZag(Γ, 0), c[i] = ‖Γ[:, i]‖₂, spdmp(∇ϕ, t0, x0, θ0, T, c, Z, Γ).
+//   usage: gmrf_spdmp [n=16] [T=20] [seed]      prints one line: d events num acc fnv1a64(payload) t_last
+// tests/test_gpu_cpp_host.py runs it on the GPU box and checks the line against the CPU oracle.
+#include <cinttypes>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "pdmp_mi355.hpp"
+
+static pdmp::SparseCSC gmrf_precision(int n, double eps) {
+    // graph Laplacian of the n x n lattice (4-neighbour), plus eps on the diagonal; CSC, rows ascending
+    pdmp::SparseCSC G;
+    G.n = (int64_t)n * n;
+    G.colptr.push_back(0);
+    for (int r = 0; r < n; ++r) {
+        for (int q = 0; q < n; ++q) {
+            const int64_t i = (int64_t)r * n + q;
+            int deg = (r > 0) + (r < n - 1) + (q > 0) + (q < n - 1);
+            if (r > 0) { G.rowval.push_back(i - n); G.nzval.push_back(-1.0); }
+            if (q > 0) { G.rowval.push_back(i - 1); G.nzval.push_back(-1.0); }
+            G.rowval.push_back(i);
+            G.nzval.push_back((double)deg + eps);
+            if (q < n - 1) { G.rowval.push_back(i + 1); G.nzval.push_back(-1.0); }
+            if (r < n - 1) { G.rowval.push_back(i + n); G.nzval.push_back(-1.0); }
+            G.colptr.push_back((int64_t)G.rowval.size());
+        }
+    }
+    return G;
+}
+
+static uint64_t fnv1a(uint64_t h, const void* p, size_t n) {
+    const unsigned char* b = static_cast<const unsigned char*>(p);
+    for (size_t k = 0; k < n; ++k) {
+        h ^= b[k];
+        h *= 1099511628211ull;
+    }
+    return h;
+}
+
+int main(int argc, char** argv) {
+    const int n = argc > 1 ? std::atoi(argv[1]) : 16;
+    const double T = argc > 2 ? std::atof(argv[2]) : 20.0;
+    pdmp::Options opt;
+    if (argc > 3) opt.seed = std::strtoull(argv[3], nullptr, 0);
+    try {
+        pdmp::ZigZag Z;
+        Z.Gamma = gmrf_precision(n, 0.01);
+        const int64_t d = Z.Gamma.n;
+        Z.mu.assign((size_t)d, 0.0);
+        pdmp::GaussianTarget target{Z.Gamma, {}};
+        std::vector<double> x0((size_t)d), th0((size_t)d), c((size_t)d);
+        for (int64_t i = 0; i < d; ++i) {
+            x0[(size_t)i] = (double)((i * 37) % 101) / 50.0 - 1.0;
+            th0[(size_t)i] = (i % 3 == 0) ? -1.0 : 1.0;
+            double s = 0.0;  // c[i] = norm(Γ[:, i], 2), scripts/gaussianrandomfield.jl:33 (sum in row order)
+            for (int64_t p = Z.Gamma.colptr[(size_t)i]; p < Z.Gamma.colptr[(size_t)i + 1]; ++p)
+                s += Z.Gamma.nzval[(size_t)p] * Z.Gamma.nzval[(size_t)p];
+            c[(size_t)i] = std::sqrt(s);
+        }
+        auto R = pdmp::spdmp(target, 0.0, x0, th0, T, c, Z, opt);
+        uint64_t h = 14695981039346656037ull;
+        int64_t acc = 0;
+        for (const auto& e : R.trace.events) {
+            h = fnv1a(h, &e.t, 8);
+            h = fnv1a(h, &e.i, 8);
+            h = fnv1a(h, &e.x, 8);
+            h = fnv1a(h, &e.theta, 8);
+        }
+        h = fnv1a(h, R.x.data(), R.x.size() * 8);
+        h = fnv1a(h, R.theta.data(), R.theta.size() * 8);
+        h = fnv1a(h, R.t.data(), R.t.size() * 8);
+        for (int64_t a : R.acc) acc += a;
+        std::printf("%" PRId64 " %zu %" PRId64 " %" PRId64 " %016" PRIx64 " %.17g\n", d, R.trace.events.size(), R.num, acc, h,
+                    R.trace.events.empty() ? 0.0 : R.trace.events.back().t);
+    } catch (const std::exception& ex) {
+        std::fprintf(stderr, "gmrf_spdmp: %s\n", ex.what());
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,61 @@
+"""The C++ host mirror (include/pdmp_mi355.hpp) and its example program: compile check here, parity on the GPU box."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _exe(pkg):
+    exes = pkg.build.build_examples()
+    exe = [e for e in exes if e.endswith("gmrf_spdmp")]
+    assert exe and os.access(exe[0], os.X_OK)
+    return exe[0]
+
+
+def _fnv1a(h, data):
+    for b in data:
+        h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def test_cpp_example_builds_and_fails_loudly_without_a_device(pkg):
+    """g++ -std=c++17 against the header; without a gfx950 device the program must exit non-zero with the ABI's error text
+    (no CPU fallback).  On a GPU box this test only checks the build."""
+    exe = _exe(pkg)
+    if pkg._lib.device_count() > 0:
+        return
+    p = subprocess.run([exe, "4", "1"], capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "no CPU fallback" in p.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_spdmp_matches_oracle(gpu_pkg):
+    """examples/gmrf_spdmp.cpp (scripts/gaussianrandomfield.jl through pdmp::spdmp) on the device vs the CPU oracle: event count,
+    counters and an FNV-1a of every event + the final (x, θ, t)."""
+    pkg = gpu_pkg
+    exe = _exe(pkg)
+    n, T, seed = 16, 20.0, 0x1234
+    p = subprocess.run([exe, str(n), repr(T), hex(seed)], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr
+    d_s, nev_s, num_s, acc_s, h_s, tl_s = p.stdout.split()
+    G = pkg.problems.gmrf_precision(n, eps=0.01)
+    d = n * n
+    i = np.arange(d)
+    x0 = ((i * 37) % 101) / 50.0 - 1.0
+    th0 = np.where(i % 3 == 0, -1.0, 1.0)
+    Gc = G.tocsc()
+    c = np.array([np.sqrt(sum(v * v for v in Gc.data[Gc.indptr[k]:Gc.indptr[k + 1]])) for k in range(d)])
+    r = O.spdmp_zigzag(G, None, G, x0, th0, c, T, seed=seed)
+    assert r["status"] == 0
+    ev = r["events"]
+    assert int(d_s) == d and int(nev_s) == len(ev) and int(num_s) == r["num"] and int(acc_s) == int(r["acc"].sum())
+    h = 14695981039346656037
+    h = _fnv1a(h, ev.tobytes())  # records are (t, i, x, theta), 32 B, the order the program hashes
+    h = _fnv1a(h, r["x"].tobytes() + r["theta"].tobytes() + r["t"].tobytes())
+    assert int(h_s, 16) == h
+    assert float(tl_s) == ev["t"][-1]

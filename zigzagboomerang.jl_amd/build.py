@@ -59,5 +59,35 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+EXAMPLES_DIR = os.path.join(os.path.dirname(PKG_DIR), "examples")
+
+
+def build_examples(verbose=False):
+    """Compile the C++ host programs of examples/ (g++, C++17) against include/pdmp_mi355.hpp and the in-tree library."""
+    out_dir = os.path.join(EXAMPLES_DIR, "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    built = []
+    for name in sorted(os.listdir(EXAMPLES_DIR)):
+        if not name.endswith(".cpp"):
+            continue
+        src = os.path.join(EXAMPLES_DIR, name)
+        exe = os.path.join(out_dir, name[:-4])
+        hdrs = [os.path.join(os.path.dirname(PKG_DIR), "include", h) for h in ("pdmp_mi355.hpp", "pdmp_mi355.h")]
+        if os.path.exists(exe) and os.path.getmtime(exe) >= max(os.path.getmtime(f) for f in [src, LIB_PATH] + hdrs):
+            built.append(exe)
+            continue
+        tmp = exe + ".tmp.%d" % os.getpid()
+        cmd = [shutil.which("g++") or "g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-I", os.path.join(os.path.dirname(PKG_DIR), "include"),
+               src, "-L", LIB_DIR, "-lpdmp_mi355", "-Wl,-rpath,$ORIGIN/../../zigzagboomerang.jl_amd/lib",
+               "-Wl,-rpath-link,/opt/rocm/lib", "-o", tmp]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        os.replace(tmp, exe)
+        built.append(exe)
+    return built
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_examples(verbose=True))
