@@ -10,6 +10,17 @@ import oracle_lib as O
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["spec", "seq"])
+def kernel_mode(request, monkeypatch):
+    """Every case runs twice: on the speculative 4-events-per-iteration kernel (default where the neighbourhoods allow it) and
+    with PDMP_KERNEL=seq on the one-event-per-iteration kernel; both must equal the oracle bit for bit."""
+    if request.param == "seq":
+        monkeypatch.setenv("PDMP_KERNEL", "seq")
+    else:
+        monkeypatch.delenv("PDMP_KERNEL", raising=False)
+    return request.param
+
+
 def check(pkg, Gb, G, mu_t, x0, th0, c, kappa, T, seed, adapt=False, reversible=False, strong=False, mu_b=None):
     d = G.shape[0]
     Z = pkg.ZigZag(Gb, np.zeros(d) if mu_b is None else mu_b)
@@ -90,3 +101,37 @@ def test_sticky_p10000_variable_selection_scale(gpu_pkg):
     tr = check(pkg, G, G, None, x0, th0, pkg.problems.column_norms(G), kappa, 3.0, seed=50)
     frozen = np.mean([np.mean(np.abs(q.events["theta"][-2000:]) == 0) for q in tr])
     assert 0.05 < frozen < 0.95
+
+
+def test_sticky_trace_refill_and_time_slices(gpu_pkg):
+    """A 50-event trace buffer forces many TRACE_FULL stops and resumes inside one sspdmp call; STOP_BEFORE slices followed by
+    the reference tail give the same chain (both kernels, via the autouse fixture)."""
+    pkg = gpu_pkg
+    G = pkg.problems.gmrf_precision(12, eps=0.5)
+    d = G.shape[0]
+    rng = np.random.default_rng(77)
+    x0 = rng.standard_normal((3, d))
+    th0 = rng.choice([-1.0, 1.0], (3, d))
+    c = pkg.problems.column_norms(G)
+    kappa = np.full(d, 0.3)
+    T = 6.0
+    Z = pkg.ZigZag(G, np.zeros(d))
+    tr, (t, x, th), (acc, num), _ = pkg.sspdmp(pkg.GaussianTarget(G), 0.0, x0, th0, T, c, Z, kappa, seed=300, trace_capacity=50)
+    refs = [O.sspdmp_zigzag(G, None, G, x0[k], th0[k], c, kappa, T, seed=300 + k) for k in range(3)]
+    for k, r in enumerate(refs):
+        assert r["status"] == 0 and len(r["events"]) > 200
+        for f in ("i", "t", "x", "theta"):
+            assert np.array_equal(tr[k].events[f], r["events"][f]), (k, f)
+        assert (int(acc[k]), int(num[k])) == (r["nacc"], r["num"]) and np.array_equal(x[k], r["x"]) and np.array_equal(t[k], r["t"])
+    with pkg.Ensemble(3, d, sampler=pkg._lib.SAMPLER_STICKY_ZIGZAG, trace_capacity=4096) as ens:
+        ens.set_flow(Z)
+        ens.set_target(pkg.GaussianTarget(G))
+        ens.set_sticky(kappa)
+        ens.set_state(0.0, x0, th0, c, np.arange(3, dtype=np.uint64) + 300)
+        for Tk in (1.5, 1.5, 4.0):  # a repeated boundary is a no-op
+            ens.run(Tk, pkg._lib.RUN_STOP_BEFORE)
+        ens.run(T, pkg._lib.RUN_REFERENCE_TAIL)
+        cnt = ens.counters()
+        for k, r in enumerate(refs):
+            ev = ens.trace(k, counters=cnt)
+            assert len(ev) == len(r["events"]) and np.array_equal(ev["t"], r["events"]["t"]) and np.array_equal(ev["i"], r["events"]["i"])

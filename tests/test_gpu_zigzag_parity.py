@@ -14,6 +14,17 @@ import oracle_lib as O
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["spec", "seq"])
+def kernel_mode(request, monkeypatch):
+    """Every case runs twice: on the speculative 4-events-per-iteration kernel (default where the neighbourhoods allow it) and
+    with PDMP_KERNEL=seq on the one-event-per-iteration kernel; both must equal the oracle bit for bit."""
+    if request.param == "seq":
+        monkeypatch.setenv("PDMP_KERNEL", "seq")
+    else:
+        monkeypatch.delenv("PDMP_KERNEL", raising=False)
+    return request.param
+
+
 def assert_chain_equal(tr_ev, fs, k, num, r, label=""):
     oe = r["events"]
     assert len(tr_ev) == len(oe), (label, len(tr_ev), len(oe))

@@ -834,8 +834,9 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         }
         return PDMP_OK;
     }
-    int rc = sticky ? pdmp::launch_zz_sticky_run(P, e->cfg.nchains, s) : spec_ok ? pdmp::launch_zz_local_spec(P, e->cfg.nchains, s)
-                                           : pdmp::launch_zz_local_run(P, e->cfg.nchains, s);
+    const bool sticky_spec = sticky && e->use_spec && dbg_cap == 0;  // same requirements as the ZigZag speculative kernel
+    int rc = sticky ? (sticky_spec ? pdmp::launch_zz_sticky_spec(P, e->cfg.nchains, s) : pdmp::launch_zz_sticky_run(P, e->cfg.nchains, s))
+                    : spec_ok ? pdmp::launch_zz_local_spec(P, e->cfg.nchains, s) : pdmp::launch_zz_local_run(P, e->cfg.nchains, s);
     if (rc != 0) return fail(PDMP_ERR_HIP, "zz_local_run launch failed: %s", hipGetErrorString((hipError_t)rc));
     HIP_TRY(hipEventRecord(e->ev1, s));
     e->timed = true;

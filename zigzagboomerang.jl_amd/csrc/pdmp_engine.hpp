@@ -176,6 +176,7 @@ int launch_zz_init(const ZzInitParams& p, void* stream);
 int launch_zz_local_run(const ZzRunParams& p, int64_t nchains, void* stream);
 int launch_zz_local_spec(const ZzRunParams& p, int64_t nchains, void* stream);
 int launch_zz_sticky_run(const ZzRunParams& p, int64_t nchains, void* stream);
+int launch_zz_sticky_spec(const ZzRunParams& p, int64_t nchains, void* stream);
 bool zz_spec_supported(uint32_t nblk, uint32_t mmax, uint32_t kmax);
 size_t zz_spec_lds_bytes(uint32_t nblk_pad, uint32_t blob_w_pad);
 int launch_zz_unpack(const ZzRec* rec, const double* c_src, int64_t c_stride, int64_t d, int64_t chain_first,

@@ -1649,6 +1649,565 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
     }
 }
 
+// ------------------------------------------------------------------------------------------ speculative sticky loop
+//
+// zz_local_spec_kernel's scheme (up to 4 events of one chain per iteration, one per 16-lane row, exact validation, commit of
+// the valid prefix) for sspdmp_inner! (src/ss_fact.jl:78-157).  What changes per event:
+//   type      freeze (f[i], :87-107), thaw (x[i] == 0 && θ[i] == 0, :108-123) or reflection proposal (:124-152); known from i's own
+//             record, so every record of S[i] is fetched up front (no lazy G2)
+//   moves     only coordinates with θ != 0 (ssmove_forward!, :25-45)
+//   draws     freeze: the thaw clock (1) + one per re-bounded neighbour unless strong_upperbounds; thaw: the reversible coin
+//             (0/1) + one per non-frozen member of G1[i]; proposal: coin + one per non-frozen member on accept, coin + 1 on reject.
+//             The offsets of later events follow from the types and accept outcomes of the earlier ones, resolved in the same
+//             per-lane chain walk; a re-bounded lane uses draw (offset + head + its rank among the re-bounded lanes)
+//   keys      queue_time! (:54-66): min(reflection proposal, hitting time of 0), the winner recorded in the record's flag word
+//   events    freeze, thaw and accepted reflection are all trace events (:154); (acc, num) are scalars and are reset to 0 by
+//             an adapted bound violation (:134)
+// Validation and commit are those of the ZigZag kernel (zone disjointness + exposure bound), so the committed sequence is
+// bit-identical to zz_sticky_run_kernel and to the oracle.
+constexpr uint32_t SPS_TY = 4576;   // [4] u32 event type: 0 proposal, 1 freeze, 2 thaw
+constexpr uint32_t SPS_NR = 4592;   // [4] u32 re-bounded lanes if the event "happens" (accept / freeze / thaw)
+constexpr uint32_t SPS_ND = 4608;   // [4] u32 head draws (coin / thaw clock / reversible coin)
+constexpr uint32_t SPS_LB = 4640;   // [4][Wpad] u64 blobs, then bk[nblk_pad] f64, bi[nblk_pad] u32
+
+size_t zz_sticky_spec_lds_bytes(uint32_t nblk_pad, uint32_t blob_w_pad) {
+    return (size_t)SPS_LB + (size_t)4 * blob_w_pad * 8 + (size_t)nblk_pad * 8 + (size_t)nblk_pad * 4;
+}
+
+template <int NE>
+__global__ __launch_bounds__(64) void zz_sticky_spec_kernel(ZzRunParams P) {
+    constexpr int E = 4;
+    const int lane = threadIdx.x;
+    const int g = lane >> 4;
+    const int gl = lane & 15;
+    const int64_t chain = blockIdx.x;
+    const int64_t d = P.d;
+    const uint32_t nblk = P.nblk;
+    const uint32_t W2 = P.blob_w_pad >> 1, SW = P.blob_sw, PW = P.blob_pw, KMAX = P.blob_kmax;
+    const uint32_t R_ = 4 + PW + KMAX;
+
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* const U = reinterpret_cast<double*>(smem + SP_U);
+    double* const LU = reinterpret_cast<double*>(smem + SP_LU);
+    double* const SLT = reinterpret_cast<double*>(smem + SP_SLT);
+    double* const SLH = reinterpret_cast<double*>(smem + SP_SLH);
+    double* const Lr = reinterpret_cast<double*>(smem + SP_LR);
+    double* const LBr = reinterpret_cast<double*>(smem + SP_LBR);
+    double* const Mr = reinterpret_cast<double*>(smem + SP_MR);
+    uint32_t* const Z = reinterpret_cast<uint32_t*>(smem + SP_Z);
+    uint32_t* const SLB = reinterpret_cast<uint32_t*>(smem + SP_SLB);
+    uint32_t* const OFR = reinterpret_cast<uint32_t*>(smem + SP_OFR);
+    uint32_t* const TY = reinterpret_cast<uint32_t*>(smem + SPS_TY);
+    uint32_t* const NR = reinterpret_cast<uint32_t*>(smem + SPS_NR);
+    uint32_t* const ND = reinterpret_cast<uint32_t*>(smem + SPS_ND);
+    double* const bk = reinterpret_cast<double*>(smem + SPS_LB + (size_t)4 * P.blob_w_pad * 8);
+    uint32_t* const bi = reinterpret_cast<uint32_t*>(bk + P.nblk_pad);
+    double* const sx = reinterpret_cast<double*>(smem + SP_SX) + g * 16;
+    double* const sth = reinterpret_cast<double*>(smem + SP_STH) + g * 16;
+    double* const pk = reinterpret_cast<double*>(smem + SP_PK) + g * 64;
+    uint64_t* const lb = reinterpret_cast<uint64_t*>(smem + SPS_LB) + (size_t)g * P.blob_w_pad;
+
+    ZzRec* rec = P.rec + chain * d;
+    double* keys = P.keys + chain * P.dk;
+    double* thf = P.thf + chain * d;
+    DevChain* hdr = P.hdr + chain;
+    pdmp_event* ev = P.ev ? P.ev + chain * P.trace_cap : nullptr;
+    double* cmut = P.c_chain ? (P.c_chain + chain * d) : nullptr;
+
+    uint32_t status = hdr->c.status;
+    if (status == PDMP_CHAIN_BOUND_VIOLATED || status == PDMP_CHAIN_STALLED) return;
+    const uint64_t seed = hdr->seed;
+    const uint64_t nm0 = hdr->c.ndraw_main, ntrace0 = hdr->c.ntrace;
+    uint64_t num = hdr->c.num, nacc = hdr->c.nacc;  // scalars with the reset quirk (:134): kept absolute
+    uint32_t dnm = 0, dnev = 0;                     // draws / trace events of this launch
+    double t_last = hdr->c.t_last;
+    double t_event = hdr->t_event;
+    status = PDMP_CHAIN_OK;
+
+    const double T = P.T;
+    const bool stop_before = (P.flags & PDMP_RUN_STOP_BEFORE) != 0;
+    const bool adapt = P.adapt != 0;
+    const bool strong = P.strong_upperbounds != 0;
+    const bool reversible = P.reversible != 0;
+    const uint32_t trace_room = (P.trace_cap > 0)
+                                    ? (uint32_t)(((uint64_t)P.trace_cap > ntrace0) ? ((uint64_t)P.trace_cap - ntrace0) : 0)
+                                    : 0xffffffffu;
+
+    for (uint32_t b = lane; b < nblk; b += 64) {
+        const double* kp = keys + (size_t)b * 64;
+        double mk = kp[0];
+        uint32_t mi = 0;
+#pragma unroll 8
+        for (int q = 1; q < 64; ++q) {
+            const double v = kp[q];
+            if (v < mk) {
+                mk = v;
+                mi = q;
+            }
+        }
+        bk[b] = mk;
+        bi[b] = b * 64 + mi;
+    }
+    LDS_ORDER();
+
+    uint32_t rng_base = 0xffffffffu;
+    bool running = stop_before || (t_event < T);
+    while (running) {
+        if (dnev >= trace_room) {
+            status = PDMP_CHAIN_TRACE_FULL;
+            break;
+        }
+        // ---------------- select (as zz_local_spec_kernel)
+        double best = PDMP_INF, second = PDMP_INF;
+        uint32_t bestb = 0;
+#pragma unroll
+        for (int q = 0; q < NE; ++q) {
+            const uint32_t b = (uint32_t)lane + 64u * q;
+            const double v = (b < nblk) ? bk[b] : PDMP_INF;
+            const bool lt = v < best;
+            second = min_f64(second, lt ? best : v);
+            bestb = lt ? b : bestb;
+            best = lt ? v : best;
+        }
+        int Esel = 0;
+        bool first_inf = false;
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            if (Esel == r) {
+                const double tpr = wave_min_f64(best);
+                if (!(tpr < PDMP_INF)) {
+                    if (r == 0) first_inf = true;
+                } else if (!(stop_before && !(tpr < T))) {
+                    const uint64_t ball = __ballot(best == tpr);
+                    const int wl = __ffsll((unsigned long long)ball) - 1;
+                    if (lane == wl) {
+                        SLT[r] = best;
+                        SLH[r] = second;
+                        SLB[r] = bestb;
+                        best = PDMP_INF;
+                    }
+                    Esel = r + 1;
+                }
+            }
+        }
+        if (Esel == 0) {
+            if (first_inf) status = PDMP_CHAIN_STALLED;
+            break;
+        }
+        LDS_ORDER();
+        const bool gvalid = g < Esel;
+        const double tp = gvalid ? SLT[g] : PDMP_INF;
+        const uint32_t blk = gvalid ? SLB[g] : 0u;
+        const double hidg = gvalid ? SLH[g] : PDMP_INF;
+        const uint32_t i = gvalid ? bi[blk] : 0u;
+
+        {
+            const uint32_t tixi = gvalid ? P.tix[i] : 0u;
+            const ulonglong2* bsrc = reinterpret_cast<const ulonglong2*>(P.blob + (size_t)tixi * P.blob_w_pad);
+            ulonglong2* bdst = reinterpret_cast<ulonglong2*>(lb);
+            if (gvalid) {
+                for (uint32_t w = gl; w < W2; w += 16) bdst[w] = bsrc[w];
+            }
+        }
+        if (dnm < rng_base || dnm + E * (1u + KMAX) > rng_base + 64u) {
+            rng_base = dnm;
+            const double u = pdmp_u01(seed, PDMP_STREAM_MAIN, nm0 + (uint64_t)dnm + (uint64_t)lane);
+            U[lane] = u;
+            LU[lane] = pdmp_log(u);
+        }
+        const uint32_t rng_off = dnm - rng_base;
+        LDS_ORDER();
+        int k = 0, m = 0, self = 0, kjmax = 0;
+        uint32_t s = 0xffffff00u + (uint32_t)lane;
+        if (gvalid) {
+            const uint64_t hw = lb[0];
+            k = (int)(hw & 0xff);
+            m = (int)((hw >> 8) & 0xff);
+            self = (int)((hw >> 16) & 0xff);
+            kjmax = (int)((hw >> 24) & 0xff);
+            if (gl < m) {
+                const uint64_t sw = lb[1 + (gl >> 1)];
+                s = i + ((gl & 1) ? (uint32_t)(sw >> 32) : (uint32_t)sw);
+            }
+        }
+        const bool member = gvalid && gl < m;
+        ZzRec* rs = rec + (member ? s : i);
+        double x = 0.0, th = 0.0, t = 0.0, I = 0.0;
+        if (member) {
+            x = rs->x;
+            th = rs->th;
+            t = rs->t;
+            I = rs->I;
+        }
+        const ZzRec* ri = rec + i;
+        double told_i = 0.0, a_i = 0.0, b_i = 0.0, thf_i = 0.0, kappa_i = 1.0;
+        uint64_t flag_i = 0;
+        double kq[4] = {PDMP_INF, PDMP_INF, PDMP_INF, PDMP_INF};
+        if (gvalid) {
+            told_i = ri->t_old;
+            a_i = ri->a;
+            b_i = ri->b;
+            flag_i = ri->acc;
+            thf_i = thf[i];
+            kappa_i = P.kappa[i];
+            const double2* kp = reinterpret_cast<const double2*>(keys + (size_t)blk * 64 + gl * 4);
+            const double2 k01 = kp[0], k23 = kp[1];
+            kq[0] = k01.x;
+            kq[1] = k01.y;
+            kq[2] = k23.x;
+            kq[3] = k23.y;
+        }
+        Z[lane] = s;
+        const uint32_t sub = 1 + SW + (uint32_t)gl * R_;
+        double cj = 0.0;
+        if (gvalid && gl < k) cj = cmut ? cmut[s] : __longlong_as_double((long long)lb[sub + 2]);
+        // raw (x, θ) of the members: the event type needs i's own pair
+        if (member) {
+            sx[gl] = x;
+            sth[gl] = th;
+        }
+
+        // ---------------- zone conflicts with earlier groups
+        LDS_ORDER();
+        bool myconf = false;
+        {
+            const uint2* Z2 = reinterpret_cast<const uint2*>(Z);
+#pragma unroll
+            for (int q = 0; q < E - 1; ++q) {
+                bool hit = false;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint2 zz = Z2[q * 8 + j];
+                    hit = hit || (zz.x == s) || (zz.y == s);
+                }
+                myconf = myconf || (hit && (q < g));
+            }
+            myconf = myconf && member;
+        }
+        const uint64_t confball = __ballot(myconf);
+
+        // ---------------- event type, moves that do not depend on a draw, gradient
+        const double x_i0 = gvalid ? sx[self] : 1.0, th_i0 = gvalid ? sth[self] : 1.0;
+        const bool is_freeze = gvalid && (flag_i != 0);
+        const bool is_thaw = gvalid && !is_freeze && (x_i0 == 0 && th_i0 == 0);
+        const bool is_prop = gvalid && !is_freeze && !is_thaw;
+        auto move_lane = [&]() {  // t[i], x[i] = t′, x[i] + θ[i]*(t′ - t[i])
+            const double dt = tp - t;
+            const double xn = x + th * dt;
+            I = I + dt * ((x + xn) * 0.5);
+            x = xn;
+            t = tp;
+        };
+        bool xerr = false;        // freeze with |x[i]| > 1e-8: the reference errors (:89-91)
+        double thf_new = 0.0;     // value thf[i] takes at commit (freeze: saved speed; thaw: 0)
+        if (is_freeze) {
+            if (gl == self) {
+                move_lane();  // smove_forward!(i, ...), :88
+                xerr = fabs(x) > 1e-8;
+                thf_new = th;  // θf[i], θ[i] = θ[i], 0.0, :93
+                x = 0.0 * th;  // x[i] = -0*θ[i], :92
+                th = 0.0;
+            }
+            if (!strong && member && th != 0.0) move_lane();  // ssmove_forward!(G, i) and (G2, i), :98-99
+        } else if (is_thaw) {
+            if (gl == self) {
+                t = tp;        // :109
+                th = thf_i;    // θ[i], θf[i] = θf[i], 0.0, :110 (sign under `reversible` resolved with the draw below)
+            }
+            if (member && th != 0.0) move_lane();  // :115-116 (i itself: x + θ*0)
+        } else if (is_prop) {
+            if (gl < k && th != 0.0) move_lane();  // :125
+        }
+        const uint64_t xerrball = __ballot(xerr);
+        LDS_ORDER();
+        if (member) {
+            sx[gl] = x;
+            sth[gl] = th;
+        }
+        LDS_ORDER();
+        // re-bounded lanes if the event happens: non-frozen members of G1[i] (freeze: i itself now has θ = 0; nothing if strong)
+        const bool reb_if = gvalid && gl < k && th != 0.0 && !(is_freeze && strong);
+        const uint64_t rebball = __ballot(reb_if);
+        const uint32_t rowmask = (uint32_t)((rebball >> (16 * g)) & 0xffffull);
+        {
+            double gr = 0.0;
+            for (uint32_t p = 0; p < KMAX; ++p) {
+                if ((int)p < k) gr += __longlong_as_double((long long)lb[1 + SW + p * R_]) * sx[p];
+            }
+            if (gvalid) {
+                if (P.tb.gmu_t) gr = gr - P.tb.gmu_t[i];
+                const double th_i = sth[self];
+                const double l = pos_part(gr * th_i);
+                const double lbound = pos_part(a_i + b_i * (tp - told_i));  // :128
+                if (gl == 0) {
+                    Lr[g] = l;
+                    LBr[g] = lbound;
+                    TY[g] = is_freeze ? 1u : (is_thaw ? 2u : 0u);
+                    NR[g] = (uint32_t)__popc(rowmask);
+                    ND[g] = is_freeze ? 1u : (is_thaw ? (reversible ? 1u : 0u) : 1u);
+                }
+            }
+        }
+        LDS_ORDER();
+        // ---------------- chain walk in time order: draw offsets, accept outcomes
+        uint32_t accept_u = 0, violated_u = 0, myoff = 0;
+        {
+            uint32_t off = 0;
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                if (g == r) myoff = off;
+                if (lane == 0) OFR[r] = off;
+                if (r < Esel) {
+                    const uint32_t ty = TY[r];
+                    const double coin = U[rng_off + off];
+                    const double l = Lr[r], lbound = LBr[r];
+                    const uint32_t a_r = (ty != 0u) ? 1u : ((coin * lbound < l) ? 1u : 0u);  // :130
+                    const uint32_t v_r = (ty == 0u && a_r && (l > lbound)) ? 1u : 0u;      // :132
+                    off += a_r ? (ND[r] + NR[r]) : 2u;
+                    if (g == r) {
+                        accept_u = a_r;
+                        violated_u = v_r;
+                    }
+                }
+            }
+            if (lane == 0) OFR[E] = off;
+        }
+        const bool happens = gvalid && accept_u != 0;  // freeze, thaw or accepted reflection: a trace event
+        const bool violated = violated_u != 0;
+
+        if (happens && is_prop) {
+            if (gl >= k && gl < m && th != 0.0) move_lane();  // ssmove_forward!(G2, i), :138
+            if (gl == self) th = -th;                         // reflect!, :139
+        }
+        if (happens && is_thaw && reversible && gl == self) th *= (U[rng_off + myoff] < 0.5) ? -1.0 : 1.0;  // :111-113
+        if (member) {
+            sx[gl] = x;
+            sth[gl] = th;
+        }
+        {
+            double2* pk2 = reinterpret_cast<double2*>(pk + gl * 4);
+            pk2[0] = make_double2(kq[0], kq[1]);
+            pk2[1] = make_double2(kq[2], kq[3]);
+        }
+        LDS_ORDER();
+        // ---------------- ab + queue_time! (:54-66) for the re-bound set
+        const bool active = gvalid && (happens ? reb_if : (gl == self));
+        double key = PDMP_INF, a = 0.0, b = 0.0;
+        uint32_t fzflag = 0;
+        if (active) {
+            const double gmu = __longlong_as_double((long long)lb[sub + 1]);
+            const int kj = (int)(lb[sub + 3] & 0xff);
+            double gx = 0.0, gt = 0.0;
+            for (int base = 0; base < kjmax; base += 8) {
+                const uint64_t pw = lb[sub + 4 + (base >> 3)];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int pp = base + q;
+                    if (pp < kj) {
+                        const double v = __longlong_as_double((long long)lb[sub + 4 + PW + pp]);
+                        const int ps = (int)((pw >> (8 * q)) & 0xff);
+                        gx += v * sx[ps];
+                        gt += v * sth[ps];
+                    }
+                }
+            }
+            if (violated && gl == self) cj *= P.factor;  // adapt!(c, i, factor), :135
+            a = cj + (gx - gmu) * th;
+            b = cj / 100 + th * gt;
+            const uint32_t rank = happens ? (uint32_t)__popc(rowmask & ((1u << gl) - 1u)) : 0u;
+            const uint32_t head = happens ? ((is_prop || is_freeze) ? 1u : (reversible ? 1u : 0u)) : 1u;
+            const double L = LU[rng_off + myoff + head + rank];
+            const double trefl = dev_poisson_time_L(a, b, L);
+            const double tfreeze = (th * x >= 0) ? PDMP_INF : (-x / th);  // freezing_time, :10-16
+            const bool fz = tfreeze <= trefl;                              // :57
+            fzflag = fz ? 1u : 0u;
+            key = t + (fz ? tfreeze : trefl);
+        }
+        if (is_freeze && gl == self) key = tp - LU[rng_off + myoff] / kappa_i;  // Q[i] = t[i] - log(rand())/κ[i], :96
+        const bool newkey = active || (is_freeze && gl == self);
+        if (newkey && (s >> 6) == blk) pk[s & 63] = key;
+        LDS_ORDER();
+        // ---------------- patched minimum of the popped block, exposure
+        double rowmin, candmin;
+        uint32_t cand;
+        {
+            const double2* pk2 = reinterpret_cast<const double2*>(pk + gl * 4);
+            const double2 p01 = pk2[0], p23 = pk2[1];
+            double lm = p01.x;
+            uint32_t li = 0;
+            if (p01.y < lm) {
+                lm = p01.y;
+                li = 1;
+            }
+            if (p23.x < lm) {
+                lm = p23.x;
+                li = 2;
+            }
+            if (p23.y < lm) {
+                lm = p23.y;
+                li = 3;
+            }
+            candmin = lm;
+            cand = blk * 64u + (uint32_t)gl * 4u + li;
+            rowmin = row_min_f64(lm);
+        }
+        const uint64_t winball = __ballot(gvalid && candmin == rowmin);
+        const int wl2 = __ffs((unsigned)((winball >> (16 * g)) & 0xffffu)) - 1;
+        const double keymin = row_min_f64(newkey ? key : PDMP_INF);
+        const double expose = min_f64(min_f64(rowmin, keymin), hidg);
+        if (gl == 0) Mr[g] = expose;
+        LDS_ORDER();
+        // ---------------- validate
+        uint32_t Rc;
+        uint32_t happb_c;  // bit r: committed event r is a trace event
+        {
+            const double m0 = Mr[0], m1 = Mr[1], m2 = Mr[2];
+            const double pref = (g == 0) ? PDMP_INF : (g == 1) ? m0 : (g == 2) ? min_f64(m0, m1) : min_f64(min_f64(m0, m1), m2);
+            const bool confg = ((confball >> (16 * g)) & 0xffffull) != 0;
+            const bool okg = gvalid && ((g == 0) || (!confg && pref > tp));
+            const bool xerrg = ((xerrball >> (16 * g)) & 0xffffull) != 0;
+            const bool vstop = (violated && !adapt) || xerrg;  // reference: error(...), :90, :133
+            const uint64_t okball = __ballot(okg && !vstop && gl == 0);
+            const uint64_t vball = __ballot(okg && vstop && gl == 0);
+            const uint64_t happball = __ballot(happens && gl == 0);
+            auto bits4 = [](uint64_t m_) -> uint32_t {
+                return (uint32_t)((m_ & 1ull) | ((m_ >> 15) & 2ull) | ((m_ >> 30) & 4ull) | ((m_ >> 45) & 8ull));
+            };
+            const uint32_t okb = bits4(okball), vb = bits4(vball), happb = bits4(happball);
+            uint32_t r_ok = 0;
+            while (r_ok < (uint32_t)E && ((okb >> r_ok) & 1u)) ++r_ok;
+            Rc = 0;
+            happb_c = 0;
+            uint32_t nev_c = 0;
+            bool stopped = false;
+            for (uint32_t r = 0; r < r_ok && !stopped; ++r) {
+                Rc = r + 1;
+                if ((happb >> r) & 1u) {
+                    happb_c |= 1u << r;
+                    nev_c += 1;
+                    if (dnev + nev_c >= trace_room && P.trace_cap > 0) {
+                        status = PDMP_CHAIN_TRACE_FULL;
+                        stopped = true;
+                    }
+                    if (!stop_before && !(uniform_f64(SLT[r]) < T)) {
+                        running = false;
+                        stopped = true;
+                    }
+                }
+            }
+            if (!stopped && r_ok < (uint32_t)E && ((vb >> r_ok) & 1u)) status = PDMP_CHAIN_BOUND_VIOLATED;
+        }
+
+        // ---------------- commit the valid prefix
+        const bool commit = gvalid && (uint32_t)g < Rc;
+        const uint64_t happball2 = __ballot(commit && happens && gl == 0);
+        const uint64_t nkball = __ballot(commit && newkey);
+        if (commit) {
+            if (member && (happens || gl < k)) {  // what was (possibly) moved; frozen members write back their own values
+                rs->x = x;
+                rs->th = th;
+                rs->t = t;
+                rs->I = I;
+            }
+            if (active) {
+                rs->t_old = t;
+                rs->a = a;
+                rs->b = b;
+                rs->acc = fzflag;
+                keys[s] = key;
+                if (violated && gl == self) cmut[s] = cj;
+            }
+            if (gl == self) {
+                if (is_freeze) {
+                    rs->t_old = tp;  // :94
+                    rs->acc = 0;     // f[i] = false, :95
+                    keys[s] = key;
+                    thf[s] = thf_new;
+                } else if (is_thaw) {
+                    thf[s] = 0.0;
+                    if (!active) rs->t_old = tp;  // :114 (i is not re-bounded when its saved speed was 0)
+                }
+            }
+            if (gl == wl2) {
+                bk[blk] = rowmin;
+                bi[blk] = cand;
+            }
+            if (happens && gl == self && ev) {
+                const uint32_t rank = (uint32_t)__popcll(happball2 & ((1ull << (16 * g)) - 1ull));
+                pdmp_event e;
+                e.t = t;  // event(i, t, x, θ, F) = (t[i], i, x[i], θ[i]), :154
+                e.i = (int64_t)i;
+                e.x = x;
+                e.theta = th;
+                ev[ntrace0 + dnev + rank] = e;
+            }
+        }
+        LDS_ORDER();
+        // ---------------- level-1 updates for new keys living in other blocks, in event order
+        for (uint32_t r = 0; r < Rc; ++r) {
+            uint32_t lanes = (uint32_t)((nkball >> (16 * r)) & 0xffffull);
+            const uint32_t own = uniform_u32(SLB[r]);
+            while (lanes) {
+                const int jj = __ffs((int)lanes) - 1;
+                lanes &= lanes - 1u;
+                const uint32_t j = readlane_u32(s, 16 * (int)r + jj);
+                const uint32_t bj = j >> 6;
+                if (bj == own) continue;
+                const double kj = readlane_f64(key, 16 * (int)r + jj);
+                LDS_ORDER();
+                const double cur = bk[bj];
+                const uint32_t ci = bi[bj];
+                if (kj < cur || (kj == cur && j < ci)) {
+                    if (lane == 0) {
+                        bk[bj] = kj;
+                        bi[bj] = j;
+                    }
+                } else if (ci == j) {
+                    const double kv = __hip_atomic_load(keys + (size_t)bj * 64 + lane, __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT);
+                    const double mn = wave_min_f64(kv);
+                    const uint64_t bl = __ballot(kv == mn);
+                    const int arg = bl ? (__ffsll((unsigned long long)bl) - 1) : 0;
+                    if (lane == 0) {
+                        bk[bj] = mn;
+                        bi[bj] = bj * 64 + (uint32_t)arg;
+                    }
+                }
+            }
+        }
+        // ---------------- counters (scalar acc, num with the reset of an adapted violation, :131-136)
+        if (Rc > 0) {
+            const uint64_t violball = __ballot(commit && violated && gl == 0);
+            for (uint32_t r = 0; r < Rc; ++r) {
+                if (uniform_u32(TY[r]) != 0u) continue;
+                num += 1;
+                if ((happb_c >> r) & 1u) nacc += 1;
+                if ((violball >> (16 * r)) & 1ull) {
+                    num = 0;
+                    nacc = 0;
+                }
+            }
+            dnev += (uint32_t)__popc(happb_c);
+            dnm += uniform_u32(OFR[Rc]);
+            t_last = uniform_f64(SLT[Rc - 1]);
+            if (happb_c) t_event = uniform_f64(SLT[31 - __builtin_clz(happb_c)]);
+        }
+        if (status != PDMP_CHAIN_OK) break;
+        LDS_ORDER();
+    }
+
+    if (lane == 0) {
+        hdr->c.t_last = t_last;
+        hdr->t_event = t_event;
+        hdr->c.num = num;
+        hdr->c.nacc = nacc;
+        hdr->c.ntrace = ntrace0 + dnev;
+        hdr->c.nevents += dnev;
+        hdr->c.ndraw_main = nm0 + dnm;
+        hdr->c.status = status;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ unpack / moments
 
 // final state (t, x, θ), acc, c of chains [chain_first, chain_first + n): src/sfact.jl:211
@@ -1750,6 +2309,22 @@ int launch_zz_local_spec(const ZzRunParams& p, int64_t nchains, void* stream) {
         hipLaunchKernelGGL((zz_local_spec_kernel<5, false>), grid, block, lds, (hipStream_t)stream, p);
     } else {
         hipLaunchKernelGGL((zz_local_spec_kernel<8, false>), grid, block, lds, (hipStream_t)stream, p);
+    }
+    return (int)hipGetLastError();
+}
+
+int launch_zz_sticky_spec(const ZzRunParams& p, int64_t nchains, void* stream) {
+    const size_t lds = zz_sticky_spec_lds_bytes(p.nblk_pad, p.blob_w_pad);
+    const int ne = (int)((p.nblk + 63) / 64);
+    dim3 grid((unsigned)nchains), block(64);
+    if (ne <= 1) {
+        hipLaunchKernelGGL((zz_sticky_spec_kernel<1>), grid, block, lds, (hipStream_t)stream, p);
+    } else if (ne <= 2) {
+        hipLaunchKernelGGL((zz_sticky_spec_kernel<2>), grid, block, lds, (hipStream_t)stream, p);
+    } else if (ne <= 5) {
+        hipLaunchKernelGGL((zz_sticky_spec_kernel<5>), grid, block, lds, (hipStream_t)stream, p);
+    } else {
+        hipLaunchKernelGGL((zz_sticky_spec_kernel<8>), grid, block, lds, (hipStream_t)stream, p);
     }
     return (int)hipGetLastError();
 }
