@@ -54,7 +54,24 @@ def cpu_baseline(pkg, G, c, budget_s=15.0):
     TH0 = np.stack([O.synthetic_state(SEED0 + k, d)[1] for k in range(nch)])
     secs, num, acc = O.spdmp_zigzag_ensemble(G, None, G, X0, TH0, c, T, seed0=SEED0, nthreads=ncores)
     s_single, n_single, a_single = O.spdmp_zigzag_ensemble(G, None, G, X0[:1], TH0[:1], c, min(T, 4.0), seed0=SEED0, nthreads=1)
-    return {"value": acc / secs, "unit": "reflection events/s", "cores": ncores, "kind": "port",
+    # the reference's own multithreaded path, src/parallel.jl (ONE chain split over K chunk threads + a coordinator): its bound
+    # must be block diagonal over the chunks, so the cross-chunk couplings are dropped from the bounding Γ and adapt is on
+    par = None
+    try:
+        import scipy.sparse as sp
+        K = 8
+        k = d // K
+        coo = sp.coo_matrix(G)
+        keep = (coo.row // k) == (coo.col // k)
+        Gb = sp.csc_matrix((coo.data[keep], (coo.row[keep], coo.col[keep])), shape=G.shape)
+        Gb.sort_indices()
+        rp = O.parallel_spdmp(Gb, None, G, x0, th0, 2.0 * c, 2.0, K, 0.1, seed=SEED0, adapt=True, want_trace=False)
+        if rp["status"] == 0:
+            par = {"threads": K, "delta": 0.1, "events_per_s": rp["nacc"] / rp["seconds"], "sync_rounds": int(rp["rounds"]),
+                   "sample": "one chain of config C3 to T=2, restatement of parallel_spdmp (src/parallel.jl:104-253)"}
+    except Exception as exc:  # the baseline is reported-only: never fail the bench on it
+        par = {"error": str(exc)}
+    return {"value": acc / secs, "unit": "reflection events/s", "cores": ncores, "kind": "port", "parallel_jl": par,
             "sample": f"{nch} chains of config C3 (d=16384) to T={T:.2f} on {ncores} threads, chain-parallel; "
                       f"same algorithm/seeds/event sequence as the GPU chains",
             "proposals_per_s": num / secs, "single_thread_events_per_s": a_single / s_single,

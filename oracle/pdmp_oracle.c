@@ -1088,6 +1088,367 @@ double orc_spdmp_zigzag_ensemble(int64_t d, const orc_zz_params* p, double t0, d
 /* ------------------------------------------------------------------ host side of the device math probe */
 /* Same expressions as math_probe_kernel (zigzagboomerang.jl_amd/csrc/pdmp_kernels.hip), evaluated with the
  * oracle's own poisson_time and libm sqrt: out is [8 x n] row-major. */
+/* ------------------------------------------------------------------ threaded local ZigZag: src/parallel.jl
+ *
+ * CPU BASELINE ONLY (north star: "the reference single-threaded and src/parallel.jl multithreaded CPU paths timed on the
+ * box's own host cores").  One chain, K worker threads, each owning a contiguous chunk of k = d/K coordinates and its own
+ * queue (Partition, :5-30).  A worker processes the "inner" coordinates of its chunk (all of G[i] inside the chunk, :114)
+ * until the top of its queue is a boundary coordinate or lies more than Δ past its last hand-off (:76-77); it then clears
+ * its latch bit and sleeps (:78-95).  When every worker sleeps, the coordinator (parallel_spdmp_outer!, :176-253) merges the
+ * event lists, walks the reported coordinates in time order, processes those whose neighbouring chunks have all reached
+ * that time with the same step (parallel_innermost!, :34-61) and wakes the chunks it served.  The bounding Γ must be block
+ * diagonal over the chunks (:124-127), the target's neighbourhoods G may cross them.
+ * Thread interleaving makes the event sequence run-dependent (as in the reference, whose workers seed Rng() themselves,
+ * :68,183): pinned statistically only (test/testparallel.jl:59-73).  Workers draw from Philox stream 16 + thread id.
+ */
+#include <pthread.h>
+
+typedef struct par_ctx par_ctx;
+typedef struct {
+    par_ctx* cx;
+    int ti;
+    pthread_t th;
+    pthread_mutex_t m;   /* wakeup[ti] */
+    pthread_cond_t cv;
+    int wake, done;      /* set by the coordinator under m */
+    /* ret[] = i, t′, acc, num (:78) */
+    int64_t ret_i, ret_acc, ret_num;
+    double ret_t;
+    orc_trace events;
+    uint64_t ndraw;
+} par_worker;
+
+struct par_ctx {
+    int64_t d, k; /* chunk size */
+    int K;
+    const orc_zz_params* p;
+    zz_ctx zc;
+    nbr_graph g, g1, g2; /* G (target pattern), G1 (bound pattern), G2 = two-hop(G1) \ G */
+    double *t, *x, *th, *c, *t_old, *ba, *bb;
+    unsigned char* inner;
+    orc_pq** Q;
+    double t0, delta;
+    int adapt;
+    double factor;
+    /* latch (:143): bit ti set while worker ti runs */
+    pthread_mutex_t lm;
+    pthread_cond_t lcv;
+    uint64_t active;
+    int error;
+    par_worker* w;
+};
+
+static nbr_graph graph_g2x(const nbr_graph* g1, const nbr_graph* gsub, int64_t d) {
+    nbr_graph g;
+    g.ptr = (int64_t*)malloc((size_t)(d + 1) * sizeof(int64_t));
+    int64_t cap = 16 * d + 16, n = 0;
+    g.idx = (int64_t*)malloc((size_t)cap * sizeof(int64_t));
+    int64_t* tmp = NULL;
+    int64_t tmpcap = 0;
+    for (int64_t i = 0; i < d; ++i) {
+        g.ptr[i] = n;
+        int64_t m = 0;
+        for (int64_t q = g1->ptr[i]; q < g1->ptr[i + 1]; ++q) m += g1->ptr[g1->idx[q] + 1] - g1->ptr[g1->idx[q]];
+        if (m > tmpcap) {
+            tmpcap = 2 * m;
+            tmp = (int64_t*)realloc(tmp, (size_t)tmpcap * sizeof(int64_t));
+        }
+        m = 0;
+        for (int64_t q = g1->ptr[i]; q < g1->ptr[i + 1]; ++q) {
+            int64_t j = g1->idx[q];
+            for (int64_t r = g1->ptr[j]; r < g1->ptr[j + 1]; ++r) tmp[m++] = g1->idx[r];
+        }
+        qsort(tmp, (size_t)m, sizeof(int64_t), cmp_i64);
+        int64_t last = -1;
+        for (int64_t e = 0; e < m; ++e) {
+            int64_t v = tmp[e];
+            if (v == last) continue;
+            last = v;
+            int in_g = 0;
+            for (int64_t q = gsub->ptr[i]; q < gsub->ptr[i + 1]; ++q)
+                if (gsub->idx[q] == v) in_g = 1;
+            if (in_g) continue;
+            if (n == cap) {
+                cap *= 2;
+                g.idx = (int64_t*)realloc(g.idx, (size_t)cap * sizeof(int64_t));
+            }
+            g.idx[n++] = v;
+        }
+    }
+    g.ptr[d] = n;
+    free(tmp);
+    return g;
+}
+
+/* parallel_innermost!, src/parallel.jl:34-61; returns 1 on an accepted reflection, -1 on a bound violation without adapt */
+static int par_innermost(par_ctx* cx, uint64_t seed, uint32_t stream, uint64_t* nd, int64_t i, double tp) {
+    double *t = cx->t, *x = cx->x, *th = cx->th;
+    move_nbrs(&cx->g, i, t, x, th, tp);              /* :36 */
+    const double gi = zz_grad(&cx->zc, i, x);         /* :37 */
+    const double l = pos(gi * th[i]);                 /* :38 */
+    const double lb = pos(cx->ba[i] + cx->bb[i] * (t[i] - cx->t_old[i]));
+    if (pdmp_u01(seed, stream, (*nd)++) * lb < l) {   /* :40 */
+        if (l >= lb) {                                /* :41 */
+            if (!cx->adapt) return -1;
+            cx->c[i] *= cx->factor;                   /* :43 */
+        }
+        move_nbrs(&cx->g2, i, t, x, th, tp);          /* :45 */
+        th[i] = -th[i];                               /* :46 */
+        for (int64_t q = cx->g1.ptr[i]; q < cx->g1.ptr[i + 1]; ++q) { /* :47-52 */
+            const int64_t j = cx->g1.idx[q];
+            zz_ab(cx->p->bound_gamma, cx->zc.gmu_bound, j, x, th, cx->c, &cx->ba[j], &cx->bb[j]);
+            cx->t_old[j] = t[j];
+            orc_pq_set(cx->Q[j / cx->k], j % cx->k, t[j] + orc_poisson_time(cx->ba[j], cx->bb[j], pdmp_u01(seed, stream, (*nd)++)));
+        }
+        return 1;
+    }
+    zz_ab(cx->p->bound_gamma, cx->zc.gmu_bound, i, x, th, cx->c, &cx->ba[i], &cx->bb[i]); /* :55-58 */
+    cx->t_old[i] = t[i];
+    orc_pq_set(cx->Q[i / cx->k], i % cx->k, t[i] + orc_poisson_time(cx->ba[i], cx->bb[i], pdmp_u01(seed, stream, (*nd)++)));
+    return 0;
+}
+
+/* parallel_spdmp_inner!, src/parallel.jl:63-102 */
+static void* par_worker_main(void* arg) {
+    par_worker* w = (par_worker*)arg;
+    par_ctx* cx = w->cx;
+    const int ti = w->ti;
+    const uint64_t seed = cx->p->seed;
+    int64_t acc = 0, num = 0;
+    double tnext = cx->t0 + cx->delta; /* :67 */
+    for (;;) {
+        num += 1; /* :70 */
+        int64_t ii;
+        double tp;
+        orc_pq_peek(cx->Q[ti], &ii, &tp); /* :71 */
+        const int64_t i = (int64_t)ti * cx->k + ii;
+        if (!cx->inner[i] || tp > tnext) { /* :73 */
+            tnext = tp + cx->delta;
+            w->ret_i = i;
+            w->ret_t = tp;
+            w->ret_acc = acc;
+            w->ret_num = num;
+            pthread_mutex_lock(&w->m); /* lock(wakeup), :81 */
+            pthread_mutex_lock(&cx->lm);
+            cx->active &= ~(1ull << ti); /* :79 */
+            if (cx->active == 0) pthread_cond_broadcast(&cx->lcv); /* last one turns the light off, :82-87 */
+            pthread_mutex_unlock(&cx->lm);
+            while (!w->wake) pthread_cond_wait(&w->cv, &w->m); /* :90 */
+            w->wake = 0;
+            const int done = w->done;
+            pthread_mutex_unlock(&w->m);
+            if (done) return NULL; /* :92-95 */
+            acc = num = 0;         /* :96 */
+        } else {
+            const int ok = par_innermost(cx, seed, 16u + (uint32_t)ti, &w->ndraw, i, tp); /* :98 */
+            if (ok < 0) {
+                cx->error = 1; /* reference: error(...) inside the task; here the chunk simply parks for good */
+                w->ret_i = i;
+                w->ret_t = INFINITY;
+                w->ret_acc = acc;
+                w->ret_num = num;
+                pthread_mutex_lock(&w->m);
+                pthread_mutex_lock(&cx->lm);
+                cx->active &= ~(1ull << ti);
+                if (cx->active == 0) pthread_cond_broadcast(&cx->lcv);
+                pthread_mutex_unlock(&cx->lm);
+                while (!w->wake) pthread_cond_wait(&w->cv, &w->m);
+                pthread_mutex_unlock(&w->m);
+                return NULL;
+            }
+            if (!ok) continue; /* :99 */
+            acc += 1;
+            trace_push(&w->events, cx->t[i], i, cx->x[i], cx->th[i]); /* :101 */
+        }
+    }
+}
+
+int orc_parallel_spdmp(int64_t d, const orc_zz_params* p, int K, double delta, double t0, double T, double* x, double* th,
+                       double* c, double* t_out, orc_trace* tr, orc_par_result* res) {
+    if (K < 1 || K > 64 || d % K != 0) return ORC_BOUND_VIOLATED;
+    par_ctx cx;
+    memset(&cx, 0, sizeof cx);
+    cx.d = d;
+    cx.K = K;
+    cx.k = d / K; /* Partition(nt, n) = Partition{div(n, nt)}, :26 */
+    cx.p = p;
+    cx.t0 = t0;
+    cx.delta = delta;
+    cx.adapt = p->adapt;
+    cx.factor = p->factor;
+    cx.x = x;
+    cx.th = th;
+    cx.c = c;
+    cx.t = t_out;
+    cx.g = graph_g1(p->target_gamma);      /* G = pattern of the target's Γ (test/testparallel.jl:49) */
+    cx.g1 = graph_g1(p->bound_gamma);      /* :117 */
+    cx.g2 = graph_g2x(&cx.g1, &cx.g, d);   /* :121 */
+    cx.zc.d = d;
+    cx.zc.p = p;
+    cx.zc.gmu_bound = (double*)malloc((size_t)d * sizeof(double));
+    for (int64_t i = 0; i < d; ++i) cx.zc.gmu_bound[i] = orc_idot(p->bound_gamma, i, p->bound_mu);
+    cx.zc.gmu_target = NULL;
+    if (p->target_mu) {
+        cx.zc.gmu_target = (double*)malloc((size_t)d * sizeof(double));
+        for (int64_t i = 0; i < d; ++i) cx.zc.gmu_target[i] = orc_idot(p->target_gamma, i, p->target_mu);
+    }
+    int status = ORC_OK;
+    /* :124-127 "Upper bounds may not depend across chunks." (G1 ⊆ G is asserted at :119) */
+    for (int64_t i = 0; i < d && status == ORC_OK; ++i)
+        for (int64_t q = cx.g2.ptr[i]; q < cx.g2.ptr[i + 1]; ++q)
+            if (cx.g2.idx[q] / cx.k != i / cx.k) status = ORC_BOUND_VIOLATED;
+    for (int64_t i = 0; i < d && status == ORC_OK; ++i)
+        for (int64_t q = cx.g1.ptr[i]; q < cx.g1.ptr[i + 1]; ++q)
+            if (cx.g1.idx[q] / cx.k != i / cx.k) status = ORC_BOUND_VIOLATED;
+    cx.inner = (unsigned char*)malloc((size_t)d);
+    for (int64_t i = 0; i < d; ++i) { /* :114 */
+        cx.inner[i] = 1;
+        for (int64_t q = cx.g.ptr[i]; q < cx.g.ptr[i + 1]; ++q)
+            if (cx.g.idx[q] / cx.k != i / cx.k) cx.inner[i] = 0;
+    }
+    cx.t_old = (double*)malloc((size_t)d * sizeof(double));
+    cx.ba = (double*)malloc((size_t)d * sizeof(double));
+    cx.bb = (double*)malloc((size_t)d * sizeof(double));
+    cx.Q = (orc_pq**)malloc((size_t)K * sizeof(orc_pq*));
+    uint64_t nd0 = 0;
+    for (int64_t i = 0; i < d; ++i) cx.t[i] = cx.t_old[i] = t0;
+    for (int ti = 0; ti < K; ++ti) cx.Q[ti] = orc_pq_new(cx.k);
+    for (int64_t i = 0; i < d; ++i) zz_ab(p->bound_gamma, cx.zc.gmu_bound, i, x, th, c, &cx.ba[i], &cx.bb[i]); /* :132 */
+    for (int64_t i = 0; i < d; ++i) /* :133-136 (global rng -> main stream here) */
+        orc_pq_enqueue(cx.Q[i / cx.k], i % cx.k, orc_poisson_time(cx.ba[i], cx.bb[i], pdmp_u01(p->seed, PDMP_STREAM_MAIN, nd0++)));
+    pthread_mutex_init(&cx.lm, NULL);
+    pthread_cond_init(&cx.lcv, NULL);
+    cx.w = (par_worker*)calloc((size_t)K, sizeof(par_worker));
+    double* tpr = (double*)malloc((size_t)K * sizeof(double));   /* t′ per chunk, :109 */
+    double* evtime = (double*)calloc((size_t)K, sizeof(double));
+    int* perm = (int*)malloc((size_t)K * sizeof(int));
+    int64_t* waitfor = (int64_t*)calloc((size_t)K, sizeof(int64_t)); /* 0 = none; i + 1 otherwise */
+    int64_t acc = 0, num = 0, rounds = 0, spawns = 0;
+    uint64_t nd_outer = 0;
+    struct timespec ts0, ts1;
+    clock_gettime(CLOCK_MONOTONIC, &ts0);
+    if (status == ORC_OK) {
+        for (int ti = 0; ti < K; ++ti) {
+            tpr[ti] = t0;
+            perm[ti] = ti;
+            par_worker* w = &cx.w[ti];
+            w->cx = &cx;
+            w->ti = ti;
+            pthread_mutex_init(&w->m, NULL);
+            pthread_cond_init(&w->cv, NULL);
+            orc_trace_init(&w->events);
+            cx.active |= 1ull << ti; /* :156 */
+        }
+        for (int ti = 0; ti < K; ++ti) pthread_create(&cx.w[ti].th, NULL, par_worker_main, &cx.w[ti]); /* :157 */
+        /* parallel_spdmp_outer!, :176-253 */
+        double tmin = t0;
+        while (tmin < T) {
+            pthread_mutex_lock(&cx.lm); /* :186-193 */
+            while (cx.active != 0) pthread_cond_wait(&cx.lcv, &cx.lm);
+            pthread_mutex_unlock(&cx.lm);
+            for (int ti = 0; ti < K; ++ti) { /* :194-203 */
+                if (waitfor[ti] == 0) {
+                    par_worker* w = &cx.w[ti];
+                    spawns += 1;
+                    for (int64_t e = 0; e < w->events.n; ++e)
+                        trace_push(tr, w->events.ev[e].t, w->events.ev[e].i, w->events.ev[e].x, w->events.ev[e].theta);
+                    w->events.n = 0;
+                    evtime[ti] = w->ret_t;
+                }
+            }
+            for (int a = 1; a < K; ++a) { /* sortperm!(perm, evtime, alg=InsertionSort), :204 (perm is reused) */
+                const int v = perm[a];
+                int b = a - 1;
+                while (b >= 0 && evtime[perm[b]] > evtime[v]) {
+                    perm[b + 1] = perm[b];
+                    --b;
+                }
+                perm[b + 1] = v;
+            }
+            for (int a = 0; a < K; ++a) { /* :206-233 */
+                const int ti = perm[a];
+                par_worker* w = &cx.w[ti];
+                const int64_t i = w->ret_i;
+                const double tpi = w->ret_t;
+                if (waitfor[ti] == 0) {
+                    num += w->ret_num;
+                    acc += w->ret_acc;
+                    tpr[ti] = tpi;
+                }
+                waitfor[ti] = 0;
+                for (int64_t q = cx.g.ptr[i]; q < cx.g.ptr[i + 1]; ++q) { /* :216-222 */
+                    const int64_t j = cx.g.idx[q];
+                    if (j == i) continue;
+                    if (tpr[j / cx.k] < tpi) waitfor[ti] = i + 1;
+                }
+                if (waitfor[ti] != 0) continue;
+                if (!(tpi < INFINITY)) continue; /* a parked chunk (error) */
+                const int ok = par_innermost(&cx, p->seed, 15u, &nd_outer, i, tpi); /* :226 */
+                if (ok < 0) {
+                    cx.error = 1;
+                } else if (ok) {
+                    acc += 1;
+                    trace_push(tr, cx.t[i], i, cx.x[i], cx.th[i]); /* :230 */
+                }
+            }
+            tmin = tpr[0];
+            for (int ti = 1; ti < K; ++ti) tmin = (tpr[ti] < tmin) ? tpr[ti] : tmin; /* :235 */
+            if (cx.error) tmin = T; /* reference: the error propagates; stop everything */
+            rounds += 1;
+            for (int ti = 0; ti < K; ++ti) { /* :241-249 */
+                if (waitfor[ti] == 0 || tmin >= T) {
+                    par_worker* w = &cx.w[ti];
+                    pthread_mutex_lock(&cx.lm);
+                    cx.active |= 1ull << ti;
+                    pthread_mutex_unlock(&cx.lm);
+                    pthread_mutex_lock(&w->m);
+                    w->wake = 1;
+                    w->done = tmin >= T;
+                    pthread_cond_signal(&w->cv);
+                    pthread_mutex_unlock(&w->m);
+                }
+            }
+        }
+        for (int ti = 0; ti < K; ++ti) pthread_join(cx.w[ti].th, NULL); /* :163-165 */
+        if (cx.error) status = ORC_BOUND_VIOLATED;
+    }
+    clock_gettime(CLOCK_MONOTONIC, &ts1);
+    if (res) {
+        res->num = num;
+        res->nacc = acc;
+        res->rounds = rounds;
+        res->spawns = spawns;
+        res->seconds = (double)(ts1.tv_sec - ts0.tv_sec) + 1e-9 * (double)(ts1.tv_nsec - ts0.tv_nsec);
+        res->status = status;
+    }
+    for (int ti = 0; ti < K; ++ti) {
+        if (cx.w[ti].cx) {
+            orc_trace_free(&cx.w[ti].events);
+            pthread_mutex_destroy(&cx.w[ti].m);
+            pthread_cond_destroy(&cx.w[ti].cv);
+        }
+        orc_pq_free(cx.Q[ti]);
+    }
+    pthread_mutex_destroy(&cx.lm);
+    pthread_cond_destroy(&cx.lcv);
+    free(cx.w);
+    free(tpr);
+    free(evtime);
+    free(perm);
+    free(waitfor);
+    free(cx.Q);
+    free(cx.t_old);
+    free(cx.ba);
+    free(cx.bb);
+    free(cx.inner);
+    free(cx.zc.gmu_bound);
+    free(cx.zc.gmu_target);
+    graph_free(&cx.g);
+    graph_free(&cx.g1);
+    graph_free(&cx.g2);
+    return status;
+}
+
 void orc_math_probe(uint64_t seed, int64_t n, double* out) {
     for (int64_t k = 0; k < n; ++k) {
         const double u = pdmp_u01(seed, 0u, (uint64_t)k);

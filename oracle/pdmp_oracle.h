@@ -206,6 +206,18 @@ double orc_spdmp_zigzag_ensemble(int64_t d, const orc_zz_params* p, double t0, d
                                  const double* x0, const double* theta0, const double* c, uint64_t seed0,
                                  int nthreads, int64_t* num_total, int64_t* acc_total);
 
+/* Threaded local ZigZag of src/parallel.jl (parallel_spdmp, :104-150): ONE chain on K <= 64 worker threads + a coordinator;
+ * timing baseline only (the event order depends on thread interleaving, as in the reference).  The bound's Γ (p->bound_gamma)
+ * must be block diagonal over the K chunks of d/K coordinates (:124-127); p->target_gamma supplies G.  tr receives the events
+ * (unsorted by time across chunks, like Ξ before the final sort! of :167). */
+typedef struct {
+    int64_t num, nacc, rounds, spawns;
+    double seconds; /* wall time of the threaded section */
+    int status;
+} orc_par_result;
+int orc_parallel_spdmp(int64_t d, const orc_zz_params* p, int K, double delta, double t0, double T, double* x, double* theta,
+                       double* c, double* t_out, orc_trace* tr, orc_par_result* res);
+
 /* helpers for the tests: the shared numerical contract evaluated on the host */
 void orc_math_probe(uint64_t seed, int64_t n, double* out);
 double orc_log(double x);

@@ -235,6 +235,43 @@ def spdmp_zigzag(bound_gamma, bound_mu, target_gamma, x0, theta0, c, T, *, t0=0.
                 sigma=sg_out)
 
 
+class _ParResult(C.Structure):
+    _fields_ = [("num", C.c_int64), ("nacc", C.c_int64), ("rounds", C.c_int64), ("spawns", C.c_int64),
+                ("seconds", C.c_double), ("status", C.c_int)]
+
+
+def parallel_spdmp(bound_gamma, bound_mu, target_gamma, x0, theta0, c, T, K, delta, *, t0=0.0, adapt=False, factor=1.8,
+                   seed=1, want_trace=True):
+    """src/parallel.jl parallel_spdmp restated with pthreads (CPU baseline; event order is run dependent)."""
+    L = lib()
+    gb = bound_gamma if isinstance(bound_gamma, CscHolder) else CscHolder(bound_gamma)
+    gt = target_gamma if isinstance(target_gamma, CscHolder) else CscHolder(target_gamma)
+    d = gb.n
+    mu = _f64(bound_mu if bound_mu is not None else np.zeros(d))
+    sg = np.ones(d)
+    p = _ZZParams(C.pointer(gb.c), mu.ctypes.data, sg.ctypes.data, 0.0, 0.0, C.pointer(gt.c), None, 0, int(adapt), factor, seed,
+                  0, 0)
+    x = _f64(x0).copy()
+    th = _f64(theta0).copy()
+    cc = _f64(c).copy()
+    t = np.empty(d)
+    tr = _Trace()
+    L.orc_trace_init(C.byref(tr))
+    res = _ParResult()
+    L.orc_parallel_spdmp.restype = C.c_int
+    st = L.orc_parallel_spdmp(C.c_int64(d), C.byref(p), C.c_int(K), C.c_double(delta), C.c_double(t0), C.c_double(T),
+                              x.ctypes.data_as(C.c_void_p), th.ctypes.data_as(C.c_void_p), cc.ctypes.data_as(C.c_void_p),
+                              t.ctypes.data_as(C.c_void_p), C.byref(tr) if want_trace else None, C.byref(res))
+    ev = np.empty(0, dtype=EVENT_DTYPE)
+    if want_trace and tr.n:
+        buf = (C.c_char * (tr.n * EVENT_DTYPE.itemsize)).from_address(tr.ev)
+        ev = np.frombuffer(buf, dtype=EVENT_DTYPE).copy()
+        ev = ev[np.argsort(ev["t"], kind="stable")]  # sort!(Ξ.events, by=ev->ev[1]), src/parallel.jl:167
+    L.orc_trace_free(C.byref(tr))
+    return dict(events=ev, t=t, x=x, theta=th, c=cc, num=res.num, nacc=res.nacc, rounds=res.rounds, spawns=res.spawns,
+                seconds=res.seconds, status=st)
+
+
 def pdmp_zigzag1d(mu, sigma2, x0, theta0, T, c, *, adapt=False, factor=2.0, seed=1, cap=1 << 20):
     L = lib()
     out = np.empty(cap, dtype=EVENT1D_DTYPE)

@@ -298,3 +298,35 @@ def test_golden2_newer_paths():
         assert r["status"] == 0
         for key, val in mg.summarize(name, r).items():
             assert np.array_equal(val, gold[key]), key
+
+
+def test_threaded_parallel_spdmp_statistics():
+    """test/testparallel.jl:22-73 ("Parallel ZigZag": d = 20 tridiagonal Γ, K = 2 chunks, bound Γ2 = Γ without the cross-chunk
+    entries, c = 5‖Γ[:, i]‖, Δ = 0.05, T = 1000): 0.1/√T < mean|mean(tr)| < 4/√T and mean|cov − Γ⁻¹| < 4/√T, plus the Partition
+    index map round trip (:4-20).  The event order depends on thread timing, as in the reference: statistics only."""
+    import scipy.sparse as sp
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    d, K, T, delta = 20, 2, 1000.0, 0.05
+    G = sp.diags([np.ones(d), -0.4 * np.ones(d - 1), -0.4 * np.ones(d - 1)], [0, 1, -1], format="csc")
+    k = d // K
+    coo = G.tocoo()
+    keep = (coo.row // k) == (coo.col // k)
+    G2 = sp.csc_matrix((coo.data[keep], (coo.row[keep], coo.col[keep])), shape=G.shape)
+    G2.sort_indices()
+    for i in range(d):  # partition(i) = (chunk, offset); partition(chunk, offset) = i
+        q1, q2 = divmod(i, k)
+        assert q1 * k + q2 == i and 0 <= q1 < K
+    rng = np.random.default_rng(1)
+    x0 = 0.1 * rng.standard_normal(d)
+    th0 = rng.choice([-1.0, 1.0], d)
+    c = 5 * pkg.problems.column_norms(G)
+    r = O.parallel_spdmp(G2, None, G, x0, th0, c, T, K, delta, seed=7)
+    assert r["status"] == 0 and r["nacc"] == len(r["events"]) > 2000 and r["rounds"] > 10
+    assert np.all(np.diff(r["events"]["t"]) >= 0)
+    tr = pkg.FactTrace(pkg.ZigZag(G2, np.zeros(d)), 0.0, x0, th0, r["events"])
+    assert 0.1 / np.sqrt(T) < np.mean(np.abs(pkg.trace.mean(tr))) < 4 / np.sqrt(T)
+    ts, xs = pkg.trace.discretize(tr, 0.5)
+    assert np.mean(np.abs(np.cov(xs.T) - np.linalg.inv(G.toarray()))) < 4 / np.sqrt(T)
+    # a bound that couples the chunks is refused ("Upper bounds may not depend across chunks.", src/parallel.jl:124-127)
+    assert O.parallel_spdmp(G, None, G, x0, th0, c, 1.0, K, delta, seed=7)["status"] != 0
