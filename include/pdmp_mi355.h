@@ -224,6 +224,21 @@ pdmp_status pdmp_ensemble_set_sticky(pdmp_ensemble* ens, const double* kappa, in
 pdmp_status pdmp_ensemble_set_adaptscale(pdmp_ensemble* ens, int enable);
 pdmp_status pdmp_ensemble_final_sigma(pdmp_ensemble* ens, int64_t chain_first, int64_t n, double* sigma);
 
+/* ------------------------------------------------------------------ c::LocalBound (src/local.jl)
+ *
+ * spdmp(∇ϕ, t0, x0, θ0, T, C::LocalBound, F::ZigZag, args...) (src/local.jl:95-149): the bound of coordinate j is built from the
+ * target's own directional derivatives, b[j] = (c_j + ∇ϕj·θ_j, c_j/100 + vj, 2/c_j/|θ_j|) (:2-6) with (∇ϕj, vj) =
+ * (Γt[:,j]·x − Γt[:,j]·μt, θ_j·Γt[:,j]·θ) for the Gaussian target (the `(∇ϕi, vi)` callback of performance/smartbound.jl:45-59),
+ * and expires after its horizon: next_time (src/not_fact_samplers.jl:43-50) queues min(proposal, horizon) and a `renew` flag;
+ * a renew event re-bounds j without a thinning step (:36-43).  The queue is initialised with t0 + τ (:122).  ZigZag flow without
+ * refresh clock, Gaussian target whose pattern equals the flow's, PDMP_SAMPLER_ZIGZAG_LOCAL.  Call after set_flow / set_target,
+ * before set_state; `c` of set_state is then LocalBound(c).c.
+ * Ties: coordinates with equal c_i/|θ_i| re-bounded at the same instant get EXACTLY equal horizon keys; the reference pops tied
+ * keys in heap order (src/priorityqueue.jl:46-77), this engine by lowest index.  Both are valid orders of simultaneous events of
+ * independent clocks, but the random streams then pair differently: bit parity with the reference needs distinct c_i/|θ_i|.
+ */
+pdmp_status pdmp_ensemble_set_local_bound(pdmp_ensemble* ens, int enable);
+
 /* ------------------------------------------------------------------ Bouncy particle sampler (PDMP_SAMPLER_BPS)
  *
  * pdmp(∇ϕ!, t0, x0, θ0, T, c, B::BouncyParticle; adapt, factor=2.0) -> Ξ::PDMPTrace, (t, x, θ), (acc, num), c

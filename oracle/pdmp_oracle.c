@@ -462,6 +462,26 @@ int orc_spdmp_zigzag(int64_t d, const orc_zz_params* p, double t0, double T, dou
             zz_ab(p->bound_gamma, cx.gmu_bound, (j), x, th, c, (aa), (bb));             \
     } while (0)
     const int hasrefresh = kind ? 1 : (p->lambda_ref > 0); /* src/fact_samplers.jl:18-19 */
+    /* C::LocalBound (src/local.jl): b[j] = ab(G, j, x, θ, C, ∇ϕj, vj, Z) = (c_j + ∇ϕj θ_j, c_j/100 + vj, 2/c_j/|θ_j|) (:2-6) with the
+     * target's own derivatives (∇ϕj, vj) = (idot(Γt, j, x) − ..., θ_j·idot(Γt, j, θ)) (performance/smartbound.jl:45-59), and
+     * τ, renew[j] = next_time(t[j], b[j], rand(rng)) (src/not_fact_samplers.jl:43-50): the bound expires after its horizon. */
+    unsigned char* renew = p->local_bound ? (unsigned char*)calloc((size_t)d, 1) : NULL;
+#define REQUEUE(j, tbase)                                                                                   \
+    do {                                                                                                    \
+        if (p->local_bound) {                                                                               \
+            const double gj_ = zz_grad(&cx, (j), x);                                                        \
+            const double vj_ = th[(j)] * orc_idot(p->target_gamma, (j), th);                                \
+            ba[(j)] = c[(j)] + gj_ * th[(j)];                                                               \
+            bb[(j)] = c[(j)] / 100 + vj_;                                                                   \
+            const double hz_ = 2.0 / c[(j)] / fabs(th[(j)]);                                                \
+            const double dt_ = orc_poisson_time(ba[(j)], bb[(j)], pdmp_u01(seed, PDMP_STREAM_MAIN, nm++));  \
+            renew[(j)] = dt_ > hz_;                                                                         \
+            orc_pq_set(Q, (j), (tbase) + (renew[(j)] ? hz_ : dt_));                                         \
+        } else {                                                                                            \
+            FLOW_AB((j), &ba[(j)], &bb[(j)]);                                                               \
+            orc_pq_set(Q, (j), (tbase) + orc_poisson_time(ba[(j)], bb[(j)], pdmp_u01(seed, PDMP_STREAM_MAIN, nm++))); \
+        }                                                                                                   \
+    } while (0)
     const uint64_t seed = p->seed;
     uint64_t nm = 0, ng = 0; /* draw counters: main stream, "global rng" stream */
 
@@ -474,10 +494,24 @@ int orc_spdmp_zigzag(int64_t d, const orc_zz_params* p, double t0, double T, dou
         acc[i] = 0;
     }
     orc_pq* Q = orc_pq_new(d + 1);
-    for (int64_t i = 0; i < d; ++i) FLOW_AB(i, &ba[i], &bb[i]); /* :184 */
-    for (int64_t i = 0; i < d; ++i) {
-        /* :186  enqueue!(Q, i => poisson_time(b[i], rand(rng)))   (t0 is NOT added in the reference) */
-        orc_pq_enqueue(Q, i, orc_poisson_time(ba[i], bb[i], pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)));
+    if (p->local_bound) {
+        /* src/local.jl:119-124: b[i] = ab(...), τ, renew[i] = next_time(t[i], b[i], rand(rng)), enqueue!(Q, i => τ) (τ includes t0) */
+        for (int64_t i = 0; i < d; ++i) {
+            const double gi_ = zz_grad(&cx, i, x);
+            const double vi_ = th[i] * orc_idot(p->target_gamma, i, th);
+            ba[i] = c[i] + gi_ * th[i];
+            bb[i] = c[i] / 100 + vi_;
+            const double hz = 2.0 / c[i] / fabs(th[i]);
+            const double dt = orc_poisson_time(ba[i], bb[i], pdmp_u01(seed, PDMP_STREAM_MAIN, nm++));
+            renew[i] = dt > hz;
+            orc_pq_enqueue(Q, i, t0 + (renew[i] ? hz : dt));
+        }
+    } else {
+        for (int64_t i = 0; i < d; ++i) FLOW_AB(i, &ba[i], &bb[i]); /* :184 */
+        for (int64_t i = 0; i < d; ++i) {
+            /* :186  enqueue!(Q, i => poisson_time(b[i], rand(rng)))   (t0 is NOT added in the reference) */
+            orc_pq_enqueue(Q, i, orc_poisson_time(ba[i], bb[i], pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)));
+        }
     }
     if (hasrefresh) {
         /* :189  waiting_time_ref(rng, F) = randexp(rng)/λref, src/dynamics.jl:100 */
@@ -553,6 +587,11 @@ int orc_spdmp_zigzag(int64_t d, const orc_zz_params* p, double t0, double T, dou
                 trace_push(tr, t[i], i, x[i], th[i]); /* :143 */
                 break;
             }
+            if (p->local_bound && renew[i]) { /* src/local.jl:36-43: the bound of i expired -- renew it, no proposal */
+                t_old[i] = t[i];
+                REQUEUE(i, t[i]);
+                continue;
+            }
             double gi = (p->target_kind == 1) ? logistic_grad_moving(p, i, t, x, th, tp, seed, &ng)
                                               : zz_grad(&cx, i, x); /* :118 */
             double l = kind ? pos((gi - (x[i] - fmu[i]) * fdiag[i]) * th[i])  /* src/fact_samplers.jl:37-39 */
@@ -572,18 +611,16 @@ int orc_spdmp_zigzag(int64_t d, const orc_zz_params* p, double t0, double T, dou
                 }
                 if (!p->move_all) flow_move_nbrs(kind, fmu, &cx.g2, i, t, x, th, tp); /* :129 */
                 th[i] = -th[i];                                        /* :130, src/dynamics.jl:46-49 */
-                for (int64_t q = cx.g1.ptr[i]; q < cx.g1.ptr[i + 1]; ++q) { /* :131-135 */
+                for (int64_t q = cx.g1.ptr[i]; q < cx.g1.ptr[i + 1]; ++q) { /* :131-135; src/local.jl:61-67 */
                     int64_t j = cx.g1.idx[q];
-                    FLOW_AB(j, &ba[j], &bb[j]);
                     t_old[j] = t[j];
-                    orc_pq_set(Q, j, t[j] + orc_poisson_time(ba[j], bb[j], pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)));
+                    REQUEUE(j, t[j]);
                 }
                 trace_push(tr, t[i], i, x[i], th[i]); /* :143 with event() :50-52 */
                 break;
-            } else { /* :136-140 */
-                FLOW_AB(i, &ba[i], &bb[i]);
+            } else { /* :136-140; src/local.jl:68-73 */
                 t_old[i] = t[i];
-                orc_pq_set(Q, i, t[i] + orc_poisson_time(ba[i], bb[i], pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)));
+                REQUEUE(i, t[i]);
                 continue;
             }
         }
@@ -604,10 +641,12 @@ int orc_spdmp_zigzag(int64_t d, const orc_zz_params* p, double t0, double T, dou
     if (p->sigma_out && sig) memcpy(p->sigma_out, sig, (size_t)d * sizeof(double));
     free(sig);
     orc_pq_free(Q);
+    free(renew);
     free(t_old);
     free(ba);
     free(bb);
     free(fdiag);
+#undef REQUEUE
 #undef FLOW_AB
     free(cx.gmu_bound);
     free(cx.gmu_target);

@@ -117,6 +117,9 @@ typedef struct {
      * σ is then per-chain state: sigma_out (d, may be NULL) receives the final values.  `^` is exp(y·log x) here. */
     int adaptscale;
     double* sigma_out;
+    /* c::LocalBound (src/local.jl:2-6,10-78,95-149): bounds from the target's own first and second directional derivatives with
+     * an expiry horizon 2/c_i/|θ_i|; ZigZag flow, Gaussian target, no refresh clock (the reference's refresh branch is JointFlow only). */
+    int local_bound;
 } orc_zz_params;
 
 typedef struct {

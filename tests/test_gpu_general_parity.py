@@ -196,3 +196,30 @@ def test_golden2_c4_on_the_device(gpu_pkg):
     for a in (ev["t"], ev["x"], ev["theta"], x, th, t, cout, L["sigma"]):
         h.update(np.ascontiguousarray(a).tobytes())
     assert h.hexdigest() == str(gold["c4_hash"][0])
+
+
+def test_local_bound_matches_oracle(gpu_pkg):
+    """spdmp(∇ϕ, t0, x0, θ0, T, C::LocalBound, F::ZigZag, Γ) (src/local.jl:2-6,10-78,95-149): bounds from the target's own
+    derivatives, expiry horizon 2/c_i/|θ_i| with `renew` events, queue initialised at t0 + τ; d = 8 dense-ish Γ with a target
+    mean and non-unit speeds, and a lattice with several key blocks; adapt on."""
+    pkg = gpu_pkg
+    rng = np.random.default_rng(9)
+    G = pkg.problems.maintest_precision(8)
+    cases = [(G, rng.standard_normal(8) * 0.3, rng.random((3, 8)), rng.choice([-1.0, -0.5, 0.5, 1.0], (3, 8)), 0.5, 300.0, 0.7),
+             (pkg.problems.gmrf_precision(12), None, rng.standard_normal((2, 144)), rng.choice([-1.0, 1.0], (2, 144)), 1.0, 15.0, 0.0)]
+    for Gc, mu_t, x0, th0, cmul, T, t0 in cases:
+        d = Gc.shape[0]
+        # distinct c_i: equal horizons 2/c_i/|θ_i| started from equal clocks give EXACTLY tied queue keys, which the reference's
+        # binary heap and the device's tournament order differently (elsewhere ties have probability zero)
+        c = cmul * pkg.problems.column_norms(Gc) * (1.0 + 0.01 * rng.random(d))
+        Z = pkg.ZigZag(Gc, np.zeros(d))
+        tr, (t, x, th), (acc, num), cout = pkg.spdmp(pkg.GaussianTarget(Gc, mu_t), t0, x0, th0, T, pkg.LocalBound(c), Z, seed=210,
+                                                     adapt=True)
+        for k in range(x0.shape[0]):
+            r = O.spdmp_zigzag(Gc, None, Gc, x0[k], th0[k], c, T, t0=t0, target_mu=mu_t, seed=210 + k, adapt=True, local_bound=True)
+            assert r["status"] == 0 and len(tr[k].events) == len(r["events"]) > 50, (k, len(tr[k].events), len(r["events"]))
+            for f in ("i", "t", "x", "theta"):
+                assert np.array_equal(tr[k].events[f], r["events"][f]), (k, f)
+            assert int(num[k]) == r["num"] and np.array_equal(acc[k], r["acc"]) and np.array_equal(cout[k], r["c"])
+            assert np.array_equal(x[k], r["x"]) and np.array_equal(th[k], r["theta"]) and np.array_equal(t[k], r["t"])
+            assert r["ndraw_main"] > r["num"] + r["nacc"]  # renew events consume draws without proposals

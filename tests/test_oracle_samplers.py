@@ -330,3 +330,23 @@ def test_threaded_parallel_spdmp_statistics():
     assert np.mean(np.abs(np.cov(xs.T) - np.linalg.inv(G.toarray()))) < 4 / np.sqrt(T)
     # a bound that couples the chunks is refused ("Upper bounds may not depend across chunks.", src/parallel.jl:124-127)
     assert O.parallel_spdmp(G, None, G, x0, th0, c, 1.0, K, delta, seed=7)["status"] != 0
+
+
+def test_local_bound_statistics_d8(pkg):
+    """spdmp with c::LocalBound (src/local.jl): no reference test pins it (performance/smartbound.jl only runs it), so the pin is the
+    ZigZag envelope of test/maintest.jl:32-33 on the same target, plus the structure of the scheme: horizons expire (`renew` events
+    draw without proposing) and, the Gaussian local bound being exact, no bound is ever adapted."""
+    G = pkg.problems.maintest_precision(8)
+    d = 8
+    rng = np.random.default_rng(1)
+    x0 = rng.random(d)
+    th0 = rng.choice([-1.0, 1.0], d)
+    T = 2000.0
+    c = 0.5 * pkg.problems.column_norms(G)
+    r = O.spdmp_zigzag(G, None, G, x0, th0, c, T, seed=3, local_bound=True, adapt=True)
+    assert r["status"] == 0 and np.array_equal(r["c"], c)
+    assert r["ndraw_main"] > d + r["num"] + r["nacc"] + (r["num"] - r["nacc"])  # more draws than proposals explain: renew events
+    tr = pkg.FactTrace(pkg.ZigZag(G, np.zeros(d)), 0.0, x0, th0, r["events"])
+    ts, xs = pkg.trace.discretize(tr, 0.5)
+    assert np.mean(np.abs(xs.mean(0))) < 2 / np.sqrt(T)
+    assert np.mean(np.abs(np.cov(xs.T) - np.linalg.inv(G.toarray()))) < 2.5 / np.sqrt(T)

@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = [
     "pdmp_ensemble_trace_reset", "pdmp_ensemble_final_state", "pdmp_ensemble_batch_means",
     "pdmp_ensemble_trace_dev", "pdmp_ensemble_counters_dev", "pdmp_debug_math_probe",
     "pdmp_ensemble_set_flow_bps", "pdmp_ensemble_set_state_bps", "pdmp_ensemble_bps_trace_copy",
-    "pdmp_ensemble_bps_final_state", "pdmp_ensemble_set_sticky", "pdmp_ensemble_set_adaptscale", "pdmp_ensemble_final_sigma", "pdmp_ensemble_set_flow_boomerang", "pdmp_ensemble_set_target_logistic", "pdmp_ensemble_set_flow_factboomerang",
+    "pdmp_ensemble_bps_final_state", "pdmp_ensemble_set_sticky", "pdmp_ensemble_set_adaptscale", "pdmp_ensemble_final_sigma", "pdmp_ensemble_set_flow_boomerang", "pdmp_ensemble_set_local_bound", "pdmp_ensemble_set_target_logistic", "pdmp_ensemble_set_flow_factboomerang",
 ]
 
 
@@ -93,6 +93,7 @@ def load():
     L.pdmp_ensemble_set_target_logistic.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, f64, i64]
     L.pdmp_ensemble_set_sticky.argtypes = [vp, vp, C.c_int, C.c_int]
     L.pdmp_ensemble_set_adaptscale.argtypes = [vp, C.c_int]
+    L.pdmp_ensemble_set_local_bound.argtypes = [vp, C.c_int]
     L.pdmp_ensemble_final_sigma.argtypes = [vp, i64, i64, vp]
     L.pdmp_ensemble_set_flow_bps.argtypes = [vp, vp, vp, vp, vp, f64, f64]
     L.pdmp_ensemble_set_flow_boomerang.argtypes = [vp, vp, vp, vp, vp, vp, f64, f64]

@@ -121,6 +121,8 @@ struct pdmp_ensemble {
     DevBuf<double> d_kappa, d_thf;
     bool has_kappa = false;
     bool adaptscale = false;
+    bool local_bound = false;
+    DevBuf<double> d_qtval;
     DevBuf<double> d_sig_chain;
     int reversible = 0, strong_upperbounds = 0;
     // BPS
@@ -392,6 +394,7 @@ static pdmp_status set_flow_common(pdmp_ensemble* e, const int64_t* colptr, cons
     e->nblk = (uint32_t)((nkeys + 63) / 64);
     e->nblk_pad = (e->nblk + 1u) & ~1u;
     e->dk = (int64_t)e->nblk * 64;
+    e->local_bound = false;
     e->adaptscale = false;
     e->has_flow = true;
     e->has_target = false;
@@ -628,7 +631,7 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
     if (st != PDMP_OK) return st;
     std::vector<double> cv(c, c + d);
     if ((st = e->d_c.upload(cv)) != PDMP_OK) return st;
-    if (e->needs_general || e->target_kind == 1 || e->adaptscale) {
+    if (e->needs_general || e->target_kind == 1 || e->adaptscale || e->local_bound) {
         if (e->cfg.sampler != PDMP_SAMPLER_ZIGZAG_LOCAL && e->cfg.sampler != PDMP_SAMPLER_ZIGZAG_ALL)
             return fail(PDMP_ERR_UNSUPPORTED,
                         "neighbourhoods beyond 64 members / the logistic target / FactBoomerang / adaptscale run on the general "
@@ -639,6 +642,20 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
             return fail(PDMP_ERR_UNSUPPORTED, "the logistic target is implemented for ZigZag without refresh");
         if (pdmp::zz_general_lds_bytes(e->nblk_pad, (e->mmax_all + 63u) & ~63u, e->flow_kind == 1) > 160 * 1024)
             return fail(PDMP_ERR_UNSUPPORTED, "LDS budget exceeded by the general kernel");
+        if (e->local_bound) {
+            if (e->cfg.sampler != PDMP_SAMPLER_ZIGZAG_LOCAL || e->flow_kind != 0 || e->lambda_ref > 0 || e->target_kind != 0)
+                return fail(PDMP_ERR_UNSUPPORTED,
+                            "LocalBound (src/local.jl) is implemented for spdmp with a ZigZag flow without refresh and the Gaussian target");
+            // the target's Γ values in the (member j of G1[i], entry of column j) layout of the re-bound tables
+            std::vector<double> qtval;
+            qtval.reserve(e->h_qptr.empty() ? 0 : e->h_qptr.back());
+            for (int64_t pp = 0; pp < e->nnz; ++pp) {
+                const uint32_t j = e->rowval[pp];
+                for (uint32_t q = e->colptr[j]; q < e->colptr[j + 1]; ++q) qtval.push_back(e->h_tval[q]);
+            }
+            if (qtval.empty()) qtval.push_back(0.0);
+            if ((st = e->d_qtval.upload(qtval)) != PDMP_OK) return st;
+        }
         if (e->adaptscale) {
             if (e->target_kind == 1) return fail(PDMP_ERR_UNSUPPORTED, "adaptscale needs the refresh clock; the logistic target has none");
             std::vector<double> sg((size_t)(n * d));
@@ -681,7 +698,8 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
     P.mu = e->d_mu.p;
     P.diag = e->d_diag.p;
     P.sticky = sticky ? 1 : 0;
-    if (sticky) {
+    P.local_bound = e->local_bound ? 1 : 0;
+    if (sticky || e->local_bound) {
         if (e->d_thf.n != (size_t)(n * d) && (st = e->d_thf.alloc((size_t)(n * d))) != PDMP_OK) return st;
         P.thf = e->d_thf.p;
     }
@@ -787,7 +805,7 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
     const char* phenv = getenv("PDMP_PHASE");
     DevBuf<double> phbuf;
     const bool spec_ok = e->use_spec && dbg_cap == 0 && !P.has_refresh && !P.move_all && !sticky;
-    const bool general_path = e->needs_general || e->target_kind == 1 || e->adaptscale;
+    const bool general_path = e->needs_general || e->target_kind == 1 || e->adaptscale || e->local_bound;
     if (phenv && (spec_ok || general_path)) {
         pdmp_status st3 = phbuf.alloc(16);
         if (st3 != PDMP_OK) return st3;
@@ -795,8 +813,11 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         P.dbg = phbuf.p;
         P.dbg_cap = 0;
     }
-    if (e->needs_general || e->target_kind == 1 || e->adaptscale) {
+    if (general_path) {
         pdmp::ZzGeneralParams Q{};
+        Q.local_bound = e->local_bound ? 1 : 0;
+        Q.qtval = e->d_qtval.p;
+        Q.renew_chain = e->local_bound ? e->d_thf.p : nullptr;
         Q.sig_chain = e->adaptscale ? e->d_sig_chain.p : nullptr;
         Q.adaptscale = e->adaptscale ? 1 : 0;
         Q.pos16 = e->d_pos16.p;
@@ -997,6 +1018,14 @@ pdmp_status pdmp_ensemble_set_sticky(pdmp_ensemble* e, const double* kappa, int 
     e->reversible = reversible;
     e->strong_upperbounds = strong_upperbounds;
     e->has_kappa = true;
+    e->has_state = false;
+    return PDMP_OK;
+}
+
+pdmp_status pdmp_ensemble_set_local_bound(pdmp_ensemble* e, int enable) {
+    if (!e) return fail(PDMP_ERR_INVALID, "null argument");
+    if (!e->has_flow) return fail(PDMP_ERR_INVALID, "set_flow_* must be called first");
+    e->local_bound = enable != 0;
     e->has_state = false;
     return PDMP_OK;
 }

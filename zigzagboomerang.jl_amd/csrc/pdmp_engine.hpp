@@ -114,6 +114,7 @@ struct ZzInitParams {
     int32_t flow_kind;               // 1: FactBoomerang bound ab (src/fact_samplers.jl:58-65)
     const double* __restrict__ mu;   // [d]
     const double* __restrict__ diag; // [d]
+    int32_t local_bound;             // c::LocalBound (src/local.jl): bounds from the target's derivatives + expiry horizon; thf = renew flags
 };
 
 // General-degree local ZigZag (pdmp_general.hip): CSC tables instead of the blob, optional logistic target
@@ -141,6 +142,11 @@ struct ZzGeneralParams {
     const double* __restrict__ mu;    // [d] flow mean
     const double* __restrict__ diag;  // [d] Γ[i,i]
     double rho;
+    // c::LocalBound (src/local.jl:2-6,10-78): qtval = the TARGET's Γ values in the (member, entry) layout of qbval; renew flags in
+    // renew_chain [nchains x d] (0.0 / 1.0)
+    int32_t local_bound;
+    const double* __restrict__ qtval;
+    double* renew_chain;  // written and re-read by the same wave: no __restrict__ (a scalar-cache load would see stale flags)
     // adaptscale (src/sfact.jl:86-99): per-chain σ [nchains x d], nullptr when off
     double* __restrict__ sig_chain;
     int32_t adaptscale;

@@ -103,6 +103,8 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
     double* cmut = P.c_chain ? (P.c_chain + chain * d) : nullptr;
     const double* cvec = cmut ? cmut : P.tb.c_shared;
     double* sigc = Q.sig_chain ? (Q.sig_chain + chain * d) : nullptr;
+    const bool local = Q.local_bound != 0;
+    double* rnw = local ? (Q.renew_chain + chain * d) : nullptr;
 
     uint32_t status = hdr->c.status;
     if (status == PDMP_CHAIN_BOUND_VIOLATED || status == PDMP_CHAIN_STALLED) return;
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
                 for (uint32_t f = cb + (uint32_t)lane; f < ce; f += 64) {
                     const uint32_t ps = Q.pos16[f];
                     if (!boom) {
-                        const double v = Q.qbval[f];
+                        const double v = local ? Q.qtval[f] : Q.qbval[f];
                         px[f - cb] = v * sx[ps];
                         pt[f - cb] = v * sth[ps];
                     } else {
@@ -319,7 +321,13 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
                 const double cj = cvec[j];
                 const double xj = sx[jj], thj = sth[jj];
                 double a, b;
-                if (!boom) {
+                double hz = G_INF;
+                if (local) {  // ab(G, j, x, θ, C::LocalBound, ∇ϕj, vj, Z), src/local.jl:2-6
+                    const double gj = P.tb.gmu_t ? (s1 - P.tb.gmu_t[j]) : s1;
+                    a = cj + gj * thj;
+                    b = cj / 100 + thj * s2;
+                    hz = 2.0 / cj / fabs(thj);
+                } else if (!boom) {
                     a = cj + (s1 - P.tb.gmu_b[j]) * thj;  // src/fact_samplers.jl:51
                     b = cj / 100 + thj * s2;             // :52
                 } else {
@@ -331,7 +339,13 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
                 ZzRec* r = rec + j;
                 const double tj = own_clock ? r->t : tp;
                 const uint64_t di = per_member_draw ? (draw0 + (uint64_t)jj) : draw0;
-                const double key = tj + g_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, di));
+                double dtn = g_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, di));
+                if (local) {  // next_time, src/not_fact_samplers.jl:43-50: the bound expires after its horizon
+                    const bool rn = dtn > hz;
+                    dtn = rn ? hz : dtn;
+                    rnw[j] = rn ? 1.0 : 0.0;
+                }
+                const double key = tj + dtn;
                 r->t_old = tj;
                 r->a = a;
                 r->b = b;
@@ -467,6 +481,14 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
             stage_members(sp0, 0, k);
         } else {
             move_members(sp0, 0, k, tp);  // smove_forward!(G, i, ...), :82
+        }
+        if (local && g_uniform((__hip_atomic_load(rnw + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) ? 1u : 0u)) {
+            // src/local.jl:36-43: the bound of i expired -- renew it from the moved state (one draw), no proposal
+            rebound(cp0, self, self + 1u, tp, nm, false, false);
+            nm += 1;
+            requeue(cp0, self, self + 1u, false, 0u);
+            G_ORDER();
+            continue;
         }
         GPHASE(1);
         // ---------------- gradient

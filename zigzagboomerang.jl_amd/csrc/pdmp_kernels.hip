@@ -154,7 +154,28 @@ __global__ __launch_bounds__(256) void zz_init_kernel(ZzInitParams P) {
             a = ci * sqrt(z2) * z + z2 * P.diag[i];
             b = 0.0;
         }
-        double key = dev_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, (uint64_t)i));  // :186
+        double key;
+        if (P.local_bound) {
+            // src/local.jl:119-124: b[i] = ab(G, i, x, θ, C::LocalBound, ∇ϕi, vi, Z) (:2-6) from the TARGET's derivatives,
+            // τ, renew[i] = next_time(t[i], b[i], rand(rng)) (src/not_fact_samplers.jl:43-50): τ includes t0
+            double hx = 0.0, ht = 0.0;
+            for (uint32_t p = P.tb.colptr[i]; p < P.tb.colptr[i + 1]; ++p) {
+                const uint32_t r = P.tb.rowval[p];
+                const double v = P.tb.tval[p];
+                hx += v * x_of(r);
+                ht += v * th_of(r);
+            }
+            const double gi = P.tb.gmu_t ? (hx - P.tb.gmu_t[i]) : hx;
+            a = ci + gi * thi;
+            b = ci / 100 + thi * ht;
+            const double hz = 2.0 / ci / fabs(thi);
+            const double dt = dev_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, (uint64_t)i));
+            const bool rn = dt > hz;
+            key = P.t0 + (rn ? hz : dt);
+            P.thf[chain * d + i] = rn ? 1.0 : 0.0;
+        } else {
+            key = dev_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, (uint64_t)i));  // :186
+        }
         uint64_t fflag = 0;
         if (P.sticky) {
             // src/ss_fact.jl:178-188: the first event of i is the earlier of its reflection proposal and its hitting time of 0

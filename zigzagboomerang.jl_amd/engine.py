@@ -68,6 +68,10 @@ class Ensemble:
         kappa = _f64(kappa).reshape(self.d)
         _lib.check(self._L.pdmp_ensemble_set_sticky(self._h, _ptr(kappa), int(bool(reversible)), int(bool(strong_upperbounds))))
 
+    def set_local_bound(self, enable=True):
+        """c::LocalBound, src/local.jl: bounds from the target's own derivatives with an expiry horizon."""
+        _lib.check(self._L.pdmp_ensemble_set_local_bound(self._h, int(bool(enable))))
+
     def set_adaptscale(self, enable=True):
         """spdmp(...; adaptscale=true), src/sfact.jl:86-99: σ becomes per-chain state tuned in the refresh branch."""
         _lib.check(self._L.pdmp_ensemble_set_adaptscale(self._h, int(bool(enable))))

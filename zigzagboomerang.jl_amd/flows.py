@@ -75,6 +75,12 @@ class BouncyParticle:
 
 
 @dataclass
+class LocalBound:
+    """LocalBound(c) -- src/types.jl:121-123: pass as `c` to spdmp to select the bounds of src/local.jl."""
+    c: np.ndarray
+
+
+@dataclass
 class Boomerang:
     """Boomerang(Γ, μ, λ; ρ=0.0) -- src/types.jl:59-66: Hamiltonian dynamics preserving N(μ, ·) with refreshment rate λ.
     The device path implements the mass L = I, i.e. Γ must be the identity (a general cholesky(Γ).L is not implemented)."""

@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _lib
 from .engine import Ensemble
-from .flows import Boomerang, BouncyParticle, FactBoomerang, FactTrace, GaussianTarget, LogisticTarget, PDMPTrace, ZigZag
+from .flows import Boomerang, BouncyParticle, FactBoomerang, LocalBound, FactTrace, GaussianTarget, LogisticTarget, PDMPTrace, ZigZag
 
 DEFAULT_SEED = 0x5EED0000
 
@@ -77,7 +77,8 @@ def _zigzag(sampler, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, 
     X0 = np.atleast_2d(x0)
     TH0 = np.atleast_2d(θ0)
     nch, d = X0.shape
-    c = np.asarray(c, dtype=np.float64)
+    local_bound = isinstance(c, LocalBound)  # spdmp(∇ϕ, t0, x0, θ0, T, C::LocalBound, F, args...), src/local.jl:95-149
+    c = np.asarray(c.c if local_bound else c, dtype=np.float64)
     seeds = (np.uint64(seed) + np.arange(nch, dtype=np.uint64)) if np.isscalar(seed) else np.asarray(seed, np.uint64)
     if trace_capacity is None:
         # ~0.8 reflections per coordinate per unit time on the GMRF; generous first guess, refilled on demand
@@ -92,6 +93,8 @@ def _zigzag(sampler, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, 
             ens.set_sticky(*sticky)
         if adaptscale:
             ens.set_adaptscale(True)
+        if local_bound:
+            ens.set_local_bound(True)
         ens.set_state(t0, X0, TH0, c, seeds)
         events = [[] for _ in range(nch)]
         while True:
