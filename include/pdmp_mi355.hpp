@@ -83,6 +83,7 @@ struct Options {  // the reference's keyword arguments
     double factor = 1.8;
     bool adapt = false;
     bool adaptscale = false;
+    bool local_bound = false;  // c is LocalBound(c): spdmp(∇ϕ, t0, x0, θ0, T, C::LocalBound, F, args...), src/local.jl:95-149
     uint64_t seed = 0x5EED0000ull;
     int device = 0;
     int64_t trace_capacity = 0;  // 0: sized from d and T, refilled on demand
@@ -199,6 +200,7 @@ Result<FactTrace> factorised(int sampler, const Target& target, double t0, const
     set_target(e, target);
     if (kappa) check(pdmp_ensemble_set_sticky(e.get(), kappa->data(), o.reversible ? 1 : 0, o.strong_upperbounds ? 1 : 0));
     if (o.adaptscale) check(pdmp_ensemble_set_adaptscale(e.get(), 1));
+    if (o.local_bound) check(pdmp_ensemble_set_local_bound(e.get(), 1));
     const uint64_t seed = o.seed;
     check(pdmp_ensemble_set_state(e.get(), t0, x0.data(), theta0.data(), c.data(), &seed));
     Result<FactTrace> R;
