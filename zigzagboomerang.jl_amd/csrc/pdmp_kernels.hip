@@ -1156,6 +1156,117 @@ __device__ __forceinline__ double row_min_f64(double v) {
     return v;
 }
 
+
+// ---- pieces shared by the two speculative kernels (always inlined: same code as written in place) ----
+
+// Select up to E candidate events: lane l owns the level-1 entries l, l+64, ...; it offers its best entry and remembers its
+// second best.  A lane offers only ONE entry per iteration, so the candidates are the E smallest entries only if no lane holds
+// two of them -- the lane's second best therefore enters the validation bound of every later event, which keeps the commit rule
+// exact.  Winners publish (key, second best, block) straight into the LDS slots.  Returns the number selected.
+template <int NE, int E>
+__device__ __forceinline__ int spec_select(const double* bk, uint32_t nblk, int lane, bool stop_before, double T, double* SLT,
+                                           double* SLH, uint32_t* SLB, bool& first_inf) {
+    double best = PDMP_INF, second = PDMP_INF;
+    uint32_t bestb = 0;
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+        const uint32_t b = (uint32_t)lane + 64u * q;
+        const double v = (b < nblk) ? bk[b] : PDMP_INF;
+        const bool lt = v < best;
+        second = min_f64(second, lt ? best : v);
+        bestb = lt ? b : bestb;
+        best = lt ? v : best;
+    }
+    int Esel = 0;
+    first_inf = false;
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        if (Esel == r) {
+            const double tpr = wave_min_f64(best);
+            if (!(tpr < PDMP_INF)) {
+                if (r == 0) first_inf = true;
+            } else if (!(stop_before && !(tpr < T))) {
+                const uint64_t ball = __ballot(best == tpr);
+                const int wl = __ffsll((unsigned long long)ball) - 1;
+                if (lane == wl) {
+                    SLT[r] = best;
+                    SLH[r] = second;
+                    SLB[r] = bestb;
+                    best = PDMP_INF;
+                }
+                Esel = r + 1;
+            }
+        }
+    }
+    return Esel;
+}
+
+// Zone conflicts with earlier groups (exact: compare member ids through LDS): does this lane's member id occur in the zone of
+// a group q < g?
+template <int E>
+__device__ __forceinline__ bool spec_zone_conflict(const uint32_t* Z, uint32_t s, int g, bool member) {
+    const uint2* Z2 = reinterpret_cast<const uint2*>(Z);
+    bool myconf = false;
+#pragma unroll
+    for (int q = 0; q < E - 1; ++q) {
+        bool hit = false;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint2 zz = Z2[q * 8 + j];
+            hit = hit || (zz.x == s) || (zz.y == s);
+        }
+        myconf = myconf || (hit && (q < g));
+    }
+    return myconf && member;
+}
+
+// Minimum of the group's patched copy of the popped key block (4 keys per lane): row minimum, this lane's candidate.
+__device__ __forceinline__ void spec_patched_min(const double* pk, int gl, uint32_t blk, double& rowmin, double& candmin,
+                                                 uint32_t& cand) {
+    const double2* pk2 = reinterpret_cast<const double2*>(pk + gl * 4);
+    const double2 p01 = pk2[0], p23 = pk2[1];
+    double lm = p01.x;
+    uint32_t li = 0;
+    if (p01.y < lm) {
+        lm = p01.y;
+        li = 1;
+    }
+    if (p23.x < lm) {
+        lm = p23.x;
+        li = 2;
+    }
+    if (p23.y < lm) {
+        lm = p23.y;
+        li = 3;
+    }
+    candmin = lm;
+    cand = blk * 64u + (uint32_t)gl * 4u + li;
+    rowmin = row_min_f64(lm);
+}
+
+// Level-1 entry of the block of coordinate j after keys[j] became kj (j's block is not the event's own popped block).
+__device__ __forceinline__ void spec_level1_update(double* bk, uint32_t* bi, const double* keys, int lane, uint32_t j, double kj) {
+    const uint32_t bj = j >> 6;
+    LDS_ORDER();
+    const double cur = bk[bj];
+    const uint32_t ci = bi[bj];
+    if (kj < cur || (kj == cur && j < ci)) {
+        if (lane == 0) {
+            bk[bj] = kj;
+            bi[bj] = j;
+        }
+    } else if (ci == j) {
+        const double kv = __hip_atomic_load(keys + (size_t)bj * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double mn = wave_min_f64(kv);
+        const uint64_t bl = __ballot(kv == mn);
+        const int arg = bl ? (__ffsll((unsigned long long)bl) - 1) : 0;
+        if (lane == 0) {
+            bk[bj] = mn;
+            bi[bj] = bj * 64 + (uint32_t)arg;
+        }
+    }
+}
+
 template <int NE, bool PROF>
 __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
     constexpr int E = 4;
@@ -1246,42 +1357,9 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
             status = PDMP_CHAIN_TRACE_FULL;
             break;
         }
-        // ---------------- select E candidate events: lane l owns the level-1 entries l, l+64, ...; it offers its best
-        // entry and remembers its second best.  A lane offers only ONE entry per iteration, so the candidates are the E
-        // smallest entries only if no lane holds two of them -- the lane's second best therefore enters the validation
-        // bound of every later event, which keeps the commit rule exact.  Winners publish straight into LDS slots.
-        double best = PDMP_INF, second = PDMP_INF;
-        uint32_t bestb = 0;
-#pragma unroll
-        for (int q = 0; q < NE; ++q) {
-            const uint32_t b = (uint32_t)lane + 64u * q;
-            const double v = (b < nblk) ? bk[b] : PDMP_INF;
-            const bool lt = v < best;
-            second = min_f64(second, lt ? best : v);
-            bestb = lt ? b : bestb;
-            best = lt ? v : best;
-        }
-        int Esel = 0;
-        bool first_inf = false;
-#pragma unroll
-        for (int r = 0; r < E; ++r) {
-            if (Esel == r) {
-                const double tpr = wave_min_f64(best);
-                if (!(tpr < PDMP_INF)) {
-                    if (r == 0) first_inf = true;
-                } else if (!(stop_before && !(tpr < T))) {
-                    const uint64_t ball = __ballot(best == tpr);
-                    const int wl = __ffsll((unsigned long long)ball) - 1;
-                    if (lane == wl) {
-                        SLT[r] = best;
-                        SLH[r] = second;
-                        SLB[r] = bestb;
-                        best = PDMP_INF;
-                    }
-                    Esel = r + 1;
-                }
-            }
-        }
+        // ---------------- select up to E candidate events (spec_select)
+        bool first_inf;
+        const int Esel = spec_select<NE, E>(bk, nblk, lane, stop_before, T, SLT, SLH, SLB, first_inf);
         if (Esel == 0) {
             if (first_inf) status = PDMP_CHAIN_STALLED;
             break;
@@ -1367,22 +1445,7 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
 
         // ---------------- zone conflicts with earlier groups (exact: compare member ids)
         LDS_ORDER();
-        bool myconf = false;
-        {
-            const uint2* Z2 = reinterpret_cast<const uint2*>(Z);
-#pragma unroll
-            for (int q = 0; q < E - 1; ++q) {
-                bool hit = false;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const uint2 zz = Z2[q * 8 + j];
-                    hit = hit || (zz.x == s) || (zz.y == s);
-                }
-                myconf = myconf || (hit && (q < g));
-            }
-            myconf = myconf && member;
-        }
-        const uint64_t confball = __ballot(myconf);
+        const uint64_t confball = __ballot(spec_zone_conflict<E>(Z, s, g, member));
         PHASE(3);
 
         // ---------------- smove_forward!(G, i, ...), gradient, rates
@@ -1503,27 +1566,7 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
         // ---------------- patched minimum of the popped block, and everything this event could expose
         double rowmin, candmin;
         uint32_t cand;
-        {
-            const double2* pk2 = reinterpret_cast<const double2*>(pk + gl * 4);
-            const double2 p01 = pk2[0], p23 = pk2[1];
-            double lm = p01.x;
-            uint32_t li = 0;
-            if (p01.y < lm) {
-                lm = p01.y;
-                li = 1;
-            }
-            if (p23.x < lm) {
-                lm = p23.x;
-                li = 2;
-            }
-            if (p23.y < lm) {
-                lm = p23.y;
-                li = 3;
-            }
-            candmin = lm;
-            cand = blk * 64u + (uint32_t)gl * 4u + li;
-            rowmin = row_min_f64(lm);
-        }
+        spec_patched_min(pk, gl, blk, rowmin, candmin, cand);
         const uint64_t winball = __ballot(gvalid && candmin == rowmin);
         const int wl2 = __ffs((unsigned)((winball >> (16 * g)) & 0xffffu)) - 1;
         const double keymin = row_min_f64(key);
@@ -1614,28 +1657,8 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
             const int kr = (int)uniform_u32(Kr[r]);
             for (int jj = 0; jj < kr; ++jj) {
                 const uint32_t j = readlane_u32(s, 16 * (int)r + jj);
-                const uint32_t bj = j >> 6;
-                if (bj == own) continue;
-                const double kj = readlane_f64(key, 16 * (int)r + jj);
-                LDS_ORDER();
-                const double cur = bk[bj];
-                const uint32_t ci = bi[bj];
-                if (kj < cur || (kj == cur && j < ci)) {
-                    if (lane == 0) {
-                        bk[bj] = kj;
-                        bi[bj] = j;
-                    }
-                } else if (ci == j) {
-                    const double kv = __hip_atomic_load(keys + (size_t)bj * 64 + lane, __ATOMIC_RELAXED,
-                                                        __HIP_MEMORY_SCOPE_AGENT);
-                    const double mn = wave_min_f64(kv);
-                    const uint64_t bl = __ballot(kv == mn);
-                    const int arg = bl ? (__ffsll((unsigned long long)bl) - 1) : 0;
-                    if (lane == 0) {
-                        bk[bj] = mn;
-                        bi[bj] = bj * 64 + (uint32_t)arg;
-                    }
-                }
+                if ((j >> 6) == own) continue;
+                spec_level1_update(bk, bi, keys, lane, j, readlane_f64(key, 16 * (int)r + jj));
             }
         }
         PHASE(8);
@@ -1778,39 +1801,9 @@ __global__ __launch_bounds__(64) void zz_sticky_spec_kernel(ZzRunParams P) {
             status = PDMP_CHAIN_TRACE_FULL;
             break;
         }
-        // ---------------- select (as zz_local_spec_kernel)
-        double best = PDMP_INF, second = PDMP_INF;
-        uint32_t bestb = 0;
-#pragma unroll
-        for (int q = 0; q < NE; ++q) {
-            const uint32_t b = (uint32_t)lane + 64u * q;
-            const double v = (b < nblk) ? bk[b] : PDMP_INF;
-            const bool lt = v < best;
-            second = min_f64(second, lt ? best : v);
-            bestb = lt ? b : bestb;
-            best = lt ? v : best;
-        }
-        int Esel = 0;
-        bool first_inf = false;
-#pragma unroll
-        for (int r = 0; r < E; ++r) {
-            if (Esel == r) {
-                const double tpr = wave_min_f64(best);
-                if (!(tpr < PDMP_INF)) {
-                    if (r == 0) first_inf = true;
-                } else if (!(stop_before && !(tpr < T))) {
-                    const uint64_t ball = __ballot(best == tpr);
-                    const int wl = __ffsll((unsigned long long)ball) - 1;
-                    if (lane == wl) {
-                        SLT[r] = best;
-                        SLH[r] = second;
-                        SLB[r] = bestb;
-                        best = PDMP_INF;
-                    }
-                    Esel = r + 1;
-                }
-            }
-        }
+        // ---------------- select up to E candidate events (spec_select)
+        bool first_inf;
+        const int Esel = spec_select<NE, E>(bk, nblk, lane, stop_before, T, SLT, SLH, SLB, first_inf);
         if (Esel == 0) {
             if (first_inf) status = PDMP_CHAIN_STALLED;
             break;
@@ -1890,22 +1883,7 @@ __global__ __launch_bounds__(64) void zz_sticky_spec_kernel(ZzRunParams P) {
 
         // ---------------- zone conflicts with earlier groups
         LDS_ORDER();
-        bool myconf = false;
-        {
-            const uint2* Z2 = reinterpret_cast<const uint2*>(Z);
-#pragma unroll
-            for (int q = 0; q < E - 1; ++q) {
-                bool hit = false;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const uint2 zz = Z2[q * 8 + j];
-                    hit = hit || (zz.x == s) || (zz.y == s);
-                }
-                myconf = myconf || (hit && (q < g));
-            }
-            myconf = myconf && member;
-        }
-        const uint64_t confball = __ballot(myconf);
+        const uint64_t confball = __ballot(spec_zone_conflict<E>(Z, s, g, member));
 
         // ---------------- event type, moves that do not depend on a draw, gradient
         const double x_i0 = gvalid ? sx[self] : 1.0, th_i0 = gvalid ? sth[self] : 1.0;
@@ -2051,27 +2029,7 @@ __global__ __launch_bounds__(64) void zz_sticky_spec_kernel(ZzRunParams P) {
         // ---------------- patched minimum of the popped block, exposure
         double rowmin, candmin;
         uint32_t cand;
-        {
-            const double2* pk2 = reinterpret_cast<const double2*>(pk + gl * 4);
-            const double2 p01 = pk2[0], p23 = pk2[1];
-            double lm = p01.x;
-            uint32_t li = 0;
-            if (p01.y < lm) {
-                lm = p01.y;
-                li = 1;
-            }
-            if (p23.x < lm) {
-                lm = p23.x;
-                li = 2;
-            }
-            if (p23.y < lm) {
-                lm = p23.y;
-                li = 3;
-            }
-            candmin = lm;
-            cand = blk * 64u + (uint32_t)gl * 4u + li;
-            rowmin = row_min_f64(lm);
-        }
+        spec_patched_min(pk, gl, blk, rowmin, candmin, cand);
         const uint64_t winball = __ballot(gvalid && candmin == rowmin);
         const int wl2 = __ffs((unsigned)((winball >> (16 * g)) & 0xffffu)) - 1;
         const double keymin = row_min_f64(newkey ? key : PDMP_INF);
@@ -2172,28 +2130,8 @@ __global__ __launch_bounds__(64) void zz_sticky_spec_kernel(ZzRunParams P) {
                 const int jj = __ffs((int)lanes) - 1;
                 lanes &= lanes - 1u;
                 const uint32_t j = readlane_u32(s, 16 * (int)r + jj);
-                const uint32_t bj = j >> 6;
-                if (bj == own) continue;
-                const double kj = readlane_f64(key, 16 * (int)r + jj);
-                LDS_ORDER();
-                const double cur = bk[bj];
-                const uint32_t ci = bi[bj];
-                if (kj < cur || (kj == cur && j < ci)) {
-                    if (lane == 0) {
-                        bk[bj] = kj;
-                        bi[bj] = j;
-                    }
-                } else if (ci == j) {
-                    const double kv = __hip_atomic_load(keys + (size_t)bj * 64 + lane, __ATOMIC_RELAXED,
-                                                        __HIP_MEMORY_SCOPE_AGENT);
-                    const double mn = wave_min_f64(kv);
-                    const uint64_t bl = __ballot(kv == mn);
-                    const int arg = bl ? (__ffsll((unsigned long long)bl) - 1) : 0;
-                    if (lane == 0) {
-                        bk[bj] = mn;
-                        bi[bj] = bj * 64 + (uint32_t)arg;
-                    }
-                }
+                if ((j >> 6) == own) continue;
+                spec_level1_update(bk, bi, keys, lane, j, readlane_f64(key, 16 * (int)r + jj));
             }
         }
         // ---------------- counters (scalar acc, num with the reset of an adapted violation, :131-136)
