@@ -29,8 +29,8 @@ __device__ __forceinline__ double b_readlane(double v, int srclane) {
 template <int CTRL>
 __device__ __forceinline__ double b_dpp(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);  // every lane has a valid source: no tied `old` operand, no copies
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 // all-lanes sum in the oracle's order: xor 1, 2 (quads), 4, 8 (row of 16), then (r0+r1)+(r2+r3)

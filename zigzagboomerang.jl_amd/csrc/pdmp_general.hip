@@ -35,8 +35,8 @@ __device__ __forceinline__ uint32_t g_uniform(uint32_t v) {
 template <int CTRL>
 __device__ __forceinline__ double g_dpp(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);  // every lane has a valid source: no tied `old` operand, no copies
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double g_wave_min(double v) {
