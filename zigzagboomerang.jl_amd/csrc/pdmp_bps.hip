@@ -66,7 +66,15 @@ __device__ __forceinline__ double bps_poisson_time(double a, double b, double u)
     }
 }
 
-template <int NS, bool DIAG, bool BOOM>
+// IDENT: Γ = I and μ = 0 exactly (config C2, the isotropic target): ∇ϕ!(y, x) = 0 + 1·(x − 0) is x itself, so the gradient array,
+// μ and the diagonal leave the register file (256 -> about 100 VGPRs at NS = 16: 1 -> 4 waves per SIMD) and Γθ = θ.
+// Box-Muller normal behind a real call: inlined 16 times, its Philox / log / sincos constants get hoisted into ~80 VGPRs that
+// stay live across the whole event loop; refresh events are rare, a call costs nothing by comparison.
+__device__ __attribute__((noinline)) double bps_randn_call(uint64_t seed, uint64_t n) {
+    return pdmp_randn(seed, PDMP_STREAM_MAIN, n);
+}
+
+template <int NS, bool DIAG, bool BOOM, bool IDENT>
 __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
     const int lane = threadIdx.x;
     const int64_t chain = blockIdx.x;
@@ -88,24 +96,32 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
              nevents = hdr->c.nevents;
     double t = sc[0], a = sc[1], b = sc[2], tp = sc[3], tau_ref = sc[4], c = sc[5];
 
-    double x[NS], th[NS], g[NS], mu[NS], dg[NS];
+    constexpr int NG = IDENT ? 1 : NS;
+    double x[NS], th[NS], g[NG], mu[NG], dg[NG];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const int64_t e = (int64_t)s * 64 + lane;
         const bool in = e < d;
         x[s] = in ? gx[e] : 0.0;
         th[s] = in ? gth[e] : 0.0;
-        mu[s] = in ? P.mu[e] : 0.0;
-        dg[s] = (DIAG && in) ? P.nzval[e] : 0.0;
-        g[s] = 0.0;
+        if constexpr (!IDENT) {
+            mu[s] = in ? P.mu[e] : 0.0;
+            dg[s] = (DIAG && in) ? P.nzval[e] : 0.0;
+            g[s] = 0.0;
+        }
     }
+    if constexpr (IDENT) g[0] = mu[0] = dg[0] = 0.0;
     const double rho = P.rho, rhobar = sqrt(1 - rho * rho);  // src/dynamics.jl:113
     const double T = P.T;
     const bool stop_before = (P.flags & PDMP_RUN_STOP_BEFORE) != 0;
 
     // y = Γ v  with v = in[] (-mu if sub): idot per output element, ascending row order
-    auto apply_gamma = [&](const double (&in)[NS], bool sub_mu, double (&out)[NS]) {
-        if (DIAG) {
+    auto apply_gamma = [&](const double (&in)[NS], bool sub_mu, double (&out)[NG]) {
+        if constexpr (IDENT) {
+            (void)in;
+            (void)sub_mu;
+            (void)out;
+        } else if (DIAG) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const double v = sub_mu ? (in[s] - mu[s]) : in[s];
@@ -151,7 +167,10 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
         return sqrt(dot(th, th) + dot(dx, dx)) * c;
     };
     auto rebound = [&]() {
-        if (BOOM) {
+        if constexpr (IDENT) {
+            a = c + dot(th, x);  // θ'(Γ(x−μ)) with Γ(x−μ) = x
+            b = dot(th, th);     // θ'(Γθ) with Γθ = θ
+        } else if (BOOM) {
             a = boom_a();
             b = 0.0;
         } else {
@@ -184,12 +203,14 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
     };
     // ∇ϕx = ∇ϕ!(∇ϕx, x); grad_correct!: Boomerang subtracts L'\(L\(x − μ)) = x − μ for L = I (src/not_fact_samplers.jl:9-12)
     auto gradient = [&]() {
-        apply_gamma(x, true, g);
-        if (BOOM) {
+        if constexpr (!IDENT) {
+            apply_gamma(x, true, g);
+            if (BOOM) {
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const int64_t e = (int64_t)s * 64 + lane;
-                if (e < d) g[s] -= x[s] - P.mu_flow[e];
+                for (int s = 0; s < NS; ++s) {
+                    const int64_t e = (int64_t)s * 64 + lane;
+                    if (e < d) g[s] -= x[s] - P.mu_flow[e];
+                }
             }
         }
     };
@@ -217,7 +238,7 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
             for (int s = 0; s < NS; ++s) {
                 const int64_t e = (int64_t)s * 64 + lane;
                 th[s] *= rho;
-                if (e < d) th[s] += rhobar * pdmp_randn(seed, PDMP_STREAM_MAIN, nm + (uint64_t)e);
+                if (e < d) th[s] += rhobar * bps_randn_call(seed, nm + (uint64_t)e);
             }
             nm += (uint64_t)d;
             gradient();                                                                                    // :58-59
@@ -228,7 +249,9 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
             emit = true;  // :64
         } else {
             gradient();  // :75-76
-            const double gt = dot(g, th);
+            double gt;
+            if constexpr (IDENT) gt = dot(x, th);
+            else gt = dot(g, th);
             const double l = bps_pos(gt);            // λ, :14
             const double lb = bps_pos(a + b * tau);  // :77
             num += 1;
@@ -244,10 +267,15 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
                     c *= P.factor;  // :83
                 }
                 // reflect!, src/dynamics.jl:90-93 with L = I: θ .-= (2 dot(∇ϕx,θ)/normsq(∇ϕx)) ∇ϕx
-                const double nrm = dot(g, g);
+                double nrm;
+                if constexpr (IDENT) nrm = dot(x, x);
+                else nrm = dot(g, g);
                 const double coef = 2 * gt / nrm;
 #pragma unroll
-                for (int s = 0; s < NS; ++s) th[s] -= coef * g[s];
+                for (int s = 0; s < NS; ++s) {
+                    if constexpr (IDENT) th[s] -= coef * x[s];
+                    else th[s] -= coef * g[s];
+                }
                 rebound();  // :86-89
                 emit = true;  // :90
             } else {
@@ -408,12 +436,14 @@ static int launch_ns(const BpsRunParams& p, int64_t nchains, bool diag, bool ini
         if (boom) hipLaunchKernelGGL((bps_init_kernel<NS, true>), grid, block, lds, (hipStream_t)stream, p, seeds, t0, c0);
         else hipLaunchKernelGGL((bps_init_kernel<NS, false>), grid, block, lds, (hipStream_t)stream, p, seeds, t0, c0);
     } else if (boom) {
-        if (diag) hipLaunchKernelGGL((bps_run_kernel<NS, true, true>), grid, block, 0, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((bps_run_kernel<NS, false, true>), grid, block, lds, (hipStream_t)stream, p);
+        if (diag) hipLaunchKernelGGL((bps_run_kernel<NS, true, true, false>), grid, block, 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((bps_run_kernel<NS, false, true, false>), grid, block, lds, (hipStream_t)stream, p);
+    } else if (diag && p.ident) {
+        hipLaunchKernelGGL((bps_run_kernel<NS, true, false, true>), grid, block, 0, (hipStream_t)stream, p);
     } else if (diag) {
-        hipLaunchKernelGGL((bps_run_kernel<NS, true, false>), grid, block, 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((bps_run_kernel<NS, true, false, false>), grid, block, 0, (hipStream_t)stream, p);
     } else {
-        hipLaunchKernelGGL((bps_run_kernel<NS, false, false>), grid, block, lds, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((bps_run_kernel<NS, false, false, false>), grid, block, lds, (hipStream_t)stream, p);
     }
     return (int)hipGetLastError();
 }

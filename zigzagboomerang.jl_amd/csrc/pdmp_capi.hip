@@ -129,6 +129,7 @@ struct pdmp_ensemble {
     DevBuf<int64_t> b_colptr, b_rowval;
     DevBuf<double> b_nzval, b_mu, b_mu_flow, b_x, b_th, b_scal, b_ev_t, b_ev_x, b_ev_th;
     int bps_flow_kind = 0;
+    bool bps_ident = false;
     bool bps_diag = false;
     double bps_lambda = 0.0, bps_rho = 0.0;
 
@@ -736,6 +737,7 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         B.mu = e->b_mu.p;
         B.mu_flow = e->b_mu_flow.p;
         B.flow_kind = e->bps_flow_kind;
+        B.ident = e->bps_ident ? 1 : 0;
         B.x = e->b_x.p;
         B.th = e->b_th.p;
         B.scal = e->b_scal.p;
@@ -1076,6 +1078,9 @@ static pdmp_status set_flow_nf(pdmp_ensemble* e, const int64_t* colptr, const in
         if (diag && !(colptr[i + 1] - colptr[i] == 1 && rowval[colptr[i]] == i)) diag = false;
     }
     e->bps_diag = diag;
+    bool ident = diag && kind == 0;
+    for (int64_t i = 0; ident && i < d; ++i) ident = (nzval[i] == 1.0) && (!mu || mu[i] == 0.0);
+    e->bps_ident = ident;
     e->bps_lambda = lambda_ref;
     e->bps_rho = rho;
     pdmp_status st;
@@ -1134,6 +1139,7 @@ pdmp_status pdmp_ensemble_set_state_bps(pdmp_ensemble* e, double t0, const doubl
     B.mu = e->b_mu.p;
     B.mu_flow = e->b_mu_flow.p;
     B.flow_kind = e->bps_flow_kind;
+    B.ident = e->bps_ident ? 1 : 0;
     B.x = e->b_x.p;
     B.th = e->b_th.p;
     B.scal = e->b_scal.p;

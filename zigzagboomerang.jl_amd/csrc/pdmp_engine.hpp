@@ -172,6 +172,7 @@ struct BpsRunParams {
     double T, factor, lambda_ref, rho;
     int32_t flags, adapt;
     int32_t flow_kind;                  // 0 BouncyParticle, 1 Boomerang (L = I): mu_flow is the centre of rotation
+    int32_t ident;                      // Γ == I and μ == 0 exactly (isotropic target): gradient-free register layout
     const double* __restrict__ mu_flow;  // [d]
 };
 int launch_bps_init(const BpsRunParams& p, int64_t nchains, const uint64_t* seeds, double t0, double c0, void* stream);
