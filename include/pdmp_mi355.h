@@ -106,6 +106,13 @@ int pdmp_device_count(void);
  */
 pdmp_status pdmp_debug_math_probe(int device, uint64_t seed, int64_t n, double* out);
 
+/*
+ * Measurement hook: time (ms per launch, HIP events) of a write-only kernel with the event-record store pattern of the bouncy
+ * particle kernel -- one wavefront per chain writing `nrec` records of x[d] and θ[d] -- i.e. the HBM write ceiling that the C2
+ * roofline fraction is read against (tools/bench_c2.py).
+ */
+pdmp_status pdmp_debug_write_probe(int device, int64_t nchains, int64_t d, int64_t nrec, int iters, double* ms_out);
+
 pdmp_status pdmp_ensemble_create(const pdmp_config* cfg, pdmp_ensemble** out);
 void pdmp_ensemble_destroy(pdmp_ensemble* ens);
 

@@ -68,10 +68,30 @@ __device__ __forceinline__ double bps_poisson_time(double a, double b, double u)
 
 // IDENT: Γ = I and μ = 0 exactly (config C2, the isotropic target): ∇ϕ!(y, x) = 0 + 1·(x − 0) is x itself, so the gradient array,
 // μ and the diagonal leave the register file (256 -> about 100 VGPRs at NS = 16: 1 -> 4 waves per SIMD) and Γθ = θ.
-// Box-Muller normal behind a real call: inlined 16 times, its Philox / log / sincos constants get hoisted into ~80 VGPRs that
-// stay live across the whole event loop; refresh events are rare, a call costs nothing by comparison.
-__device__ __attribute__((noinline)) double bps_randn_call(uint64_t seed, uint64_t n) {
-    return pdmp_randn(seed, PDMP_STREAM_MAIN, n);
+// poisson_time(a, b, u) with L = log(u) already taken (the draw's index is known before the rates are: the logarithm is
+// evaluated off the critical path)
+__device__ __forceinline__ double bps_poisson_time_L(double a, double b, double L) {
+    if (b > 0) {
+        const double r = a / b;
+        if (a < 0) return sqrt(-L * 2.0 / b) - r;
+        return sqrt(r * r - L * 2.0 / b) - r;
+    } else if (b == 0) {
+        return (a > 0) ? (-L / a) : BPS_INF;
+    } else {
+        if (a <= 0) return BPS_INF;
+        if (-L <= -(a * a) / b + (a * a) / (2 * b)) {
+            const double r = a / b;
+            return -sqrt(r * r - L * 2.0 / b) - r;
+        }
+        return BPS_INF;
+    }
+}
+
+// IDENT: Γ = I and μ = 0 exactly (config C2, the isotropic target): ∇ϕ!(y, x) = 0 + 1·(x − 0) is x itself, so the gradient array,
+// μ and the diagonal leave the register file (256 -> about 100 VGPRs at NS = 16: 1 -> 4 waves per SIMD) and Γθ = θ.
+// t′ − t = poisson_time(a, b, rand(rng)) behind a call as well (log polynomial, two divisions, sqrt: constants and temporaries)
+__device__ __attribute__((noinline)) double bps_next_dt(uint64_t seed, uint64_t n, double a, double b) {
+    return bps_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, n));
 }
 
 template <int NS, bool DIAG, bool BOOM, bool IDENT>
@@ -80,7 +100,7 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
     const int64_t chain = blockIdx.x;
     const int64_t d = P.d;
     extern __shared__ __align__(16) unsigned char smem[];
-    double* tmp = reinterpret_cast<double*>(smem);  // [d] operand of the CSC gather (general Γ only)
+    double* tmp = reinterpret_cast<double*>(smem);  // [d] operand of the CSC gather (general Γ); the normals of a refresh
 
     double* gx = P.x + chain * d;
     double* gth = P.th + chain * d;
@@ -166,7 +186,7 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
         }
         return sqrt(dot(th, th) + dot(dx, dx)) * c;
     };
-    auto rebound = [&]() {
+    auto rebound = [&](double Lnext) {
         if constexpr (IDENT) {
             a = c + dot(th, x);  // θ'(Γ(x−μ)) with Γ(x−μ) = x
             b = dot(th, th);     // θ'(Γθ) with Γθ = θ
@@ -179,7 +199,7 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
             apply_gamma(th, false, gt);
             b = dot(th, gt);
         }
-        tp = t + bps_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, nm));
+        tp = t + bps_poisson_time_L(a, b, Lnext);
         nm += 1;
     };
     // move_forward!(τ, t, x, θ, Flow): linear (src/dynamics.jl:11-15) or the rotation about μ (:29-36)
@@ -234,20 +254,34 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
         bool emit = false;
         if (is_ref) {
             // refresh!, src/dynamics.jl:112-118 with L = I: θ .*= ρ; θ .+= ρ̄ randn(rng, d)  (draw nm + e for element e)
+            // The d normals go through LDS: a ROLLED loop holds one Box-Muller body (its constants and temporaries are live only
+            // here, next to x and θ), the unrolled update then reads them back -- 16 inlined bodies, or a call, cost ~40 VGPRs
+            // across the whole event loop (161 -> 123 at NS = 16: 3 -> 4 waves per SIMD).
+            asm volatile("" ::: "memory");
+#pragma unroll 1
+            for (int s = 0; s < NS; ++s) {
+                const int64_t e = (int64_t)s * 64 + lane;
+                if (e < d) tmp[e] = pdmp_randn(seed, PDMP_STREAM_MAIN, nm + (uint64_t)e);
+            }
+            asm volatile("" ::: "memory");
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int64_t e = (int64_t)s * 64 + lane;
                 th[s] *= rho;
-                if (e < d) th[s] += rhobar * bps_randn_call(seed, nm + (uint64_t)e);
+                if (e < d) th[s] += rhobar * tmp[e];
             }
             nm += (uint64_t)d;
             gradient();                                                                                    // :58-59
             tau_ref = t + (-pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm)) / P.lambda_ref);                  // :61
             nm += 1;
-            rebound();  // :62-63
+            rebound(pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm)));  // :62-63
             nrefresh += 1;
             emit = true;  // :64
         } else {
+            // both draws of a proposal have known indices (coin: nm, next_time: nm + 1 on accept and on reject alike): Philox and
+            // the logarithm run beside the gradient and the reductions instead of after them
+            const double coin = pdmp_u01(seed, PDMP_STREAM_MAIN, nm);
+            const double Lnext = pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm + 1));
             gradient();  // :75-76
             double gt;
             if constexpr (IDENT) gt = dot(x, th);
@@ -255,7 +289,6 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
             const double l = bps_pos(gt);            // λ, :14
             const double lb = bps_pos(a + b * tau);  // :77
             num += 1;
-            const double coin = pdmp_u01(seed, PDMP_STREAM_MAIN, nm);
             nm += 1;
             if (coin * lb <= l) {  // :79
                 nacc += 1;
@@ -276,12 +309,12 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
                     if constexpr (IDENT) th[s] -= coef * x[s];
                     else th[s] -= coef * g[s];
                 }
-                rebound();  // :86-89
+                rebound(Lnext);  // :86-89
                 emit = true;  // :90
             } else {
                 if (BOOM) a = boom_a();  // :92 recomputed after the rotation (b stays 0)
                 else a = c + gt;         // :92 (θ'g == g'θ bit for bit; b = θ'Γθ is unchanged because θ is)
-                tp = t + bps_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, nm));  // :93
+                tp = t + bps_poisson_time_L(a, b, Lnext);  // :93
                 nm += 1;
             }
         }
@@ -436,12 +469,12 @@ static int launch_ns(const BpsRunParams& p, int64_t nchains, bool diag, bool ini
         if (boom) hipLaunchKernelGGL((bps_init_kernel<NS, true>), grid, block, lds, (hipStream_t)stream, p, seeds, t0, c0);
         else hipLaunchKernelGGL((bps_init_kernel<NS, false>), grid, block, lds, (hipStream_t)stream, p, seeds, t0, c0);
     } else if (boom) {
-        if (diag) hipLaunchKernelGGL((bps_run_kernel<NS, true, true, false>), grid, block, 0, (hipStream_t)stream, p);
+        if (diag) hipLaunchKernelGGL((bps_run_kernel<NS, true, true, false>), grid, block, lds, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((bps_run_kernel<NS, false, true, false>), grid, block, lds, (hipStream_t)stream, p);
     } else if (diag && p.ident) {
-        hipLaunchKernelGGL((bps_run_kernel<NS, true, false, true>), grid, block, 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((bps_run_kernel<NS, true, false, true>), grid, block, lds, (hipStream_t)stream, p);
     } else if (diag) {
-        hipLaunchKernelGGL((bps_run_kernel<NS, true, false, false>), grid, block, 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((bps_run_kernel<NS, true, false, false>), grid, block, lds, (hipStream_t)stream, p);
     } else {
         hipLaunchKernelGGL((bps_run_kernel<NS, false, false, false>), grid, block, lds, (hipStream_t)stream, p);
     }
@@ -457,6 +490,28 @@ static int dispatch(const BpsRunParams& p, int64_t nchains, bool diag, bool init
     if (ns <= 8) return launch_ns<8>(p, nchains, diag, init, seeds, t0, c0, stream);
     if (ns <= 16) return launch_ns<16>(p, nchains, diag, init, seeds, t0, c0, stream);
     return -1;
+}
+
+// Write-only probe with the event-record store pattern of bps_run_kernel (one wave per chain, `nrec` records of x(d) and θ(d)
+// written as NS x 512-byte coalesced stores each): the ceiling the C2 roofline fraction is read against.
+__global__ __launch_bounds__(64) void bps_write_probe_kernel(double* ev_x, double* ev_th, int64_t d, int64_t cap, int64_t nrec) {
+    const int lane = threadIdx.x;
+    const int64_t chain = blockIdx.x;
+    double v = (double)chain + 1e-3 * lane;
+    for (int64_t r = 0; r < nrec; ++r) {
+        const int64_t slot = chain * cap + r;
+        double* ex = ev_x + slot * d;
+        double* eth = ev_th + slot * d;
+        for (int64_t e = lane; e < d; e += 64) {
+            ex[e] = v;
+            eth[e] = -v;
+        }
+        v += 1.0;
+    }
+}
+int launch_bps_write_probe(double* ev_x, double* ev_th, int64_t d, int64_t cap, int64_t nrec, int64_t nchains, void* stream) {
+    hipLaunchKernelGGL(bps_write_probe_kernel, dim3((unsigned)nchains), dim3(64), 0, (hipStream_t)stream, ev_x, ev_th, d, cap, nrec);
+    return (int)hipGetLastError();
 }
 
 int launch_bps_init(const BpsRunParams& p, int64_t nchains, const uint64_t* seeds, double t0, double c0, void* stream) {

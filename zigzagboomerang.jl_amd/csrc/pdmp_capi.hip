@@ -174,6 +174,35 @@ int pdmp_device_count(void) {
     return ok;
 }
 
+pdmp_status pdmp_debug_write_probe(int device, int64_t nchains, int64_t d, int64_t nrec, int iters, double* ms_out) {
+    if (!ms_out || nchains <= 0 || d <= 0 || nrec <= 0 || iters <= 0) return fail(PDMP_ERR_INVALID, "bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+        return fail(PDMP_ERR_NO_DEVICE, "no HIP device visible: libpdmp_mi355 has no CPU fallback");
+    HIP_TRY(hipSetDevice(device));
+    DevBuf<double> bx, bt;
+    pdmp_status st;
+    if ((st = bx.alloc((size_t)(nchains * nrec * d))) != PDMP_OK) return st;
+    if ((st = bt.alloc((size_t)(nchains * nrec * d))) != PDMP_OK) return st;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    pdmp::launch_bps_write_probe(bx.p, bt.p, d, nrec, nrec, nchains, nullptr);  // warm-up (page faults, TLB)
+    HIP_TRY(hipEventRecord(e0, nullptr));
+    for (int k = 0; k < iters; ++k) {
+        int rc = pdmp::launch_bps_write_probe(bx.p, bt.p, d, nrec, nrec, nchains, nullptr);
+        if (rc != 0) return fail(PDMP_ERR_HIP, "write probe launch failed (%d)", rc);
+    }
+    HIP_TRY(hipEventRecord(e1, nullptr));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *ms_out = (double)ms / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return PDMP_OK;
+}
+
 pdmp_status pdmp_debug_math_probe(int device, uint64_t seed, int64_t n, double* out) {
     if (!out || n <= 0) return fail(PDMP_ERR_INVALID, "bad argument");
     int ndev = 0;

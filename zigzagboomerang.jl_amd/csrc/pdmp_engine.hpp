@@ -175,6 +175,7 @@ struct BpsRunParams {
     int32_t ident;                      // Γ == I and μ == 0 exactly (isotropic target): gradient-free register layout
     const double* __restrict__ mu_flow;  // [d]
 };
+int launch_bps_write_probe(double* ev_x, double* ev_th, int64_t d, int64_t cap, int64_t nrec, int64_t nchains, void* stream);
 int launch_bps_init(const BpsRunParams& p, int64_t nchains, const uint64_t* seeds, double t0, double c0, void* stream);
 int launch_bps_run(const BpsRunParams& p, int64_t nchains, bool diag, void* stream);
 
