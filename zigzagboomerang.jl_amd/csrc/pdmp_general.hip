@@ -68,6 +68,24 @@ __device__ __forceinline__ double g_poisson_time(double a, double b, double u) {
         return G_INF;
     }
 }
+// the same with L = log(u) already taken (the draw's index is known before the bound is: Philox and the logarithm run while
+// the dot products' operands are still on their way)
+__device__ __forceinline__ double g_poisson_time_L(double a, double b, double L) {
+    if (b > 0) {
+        const double r = a / b;
+        if (a < 0) return sqrt(-L * 2.0 / b) - r;
+        return sqrt(r * r - L * 2.0 / b) - r;
+    } else if (b == 0) {
+        return (a > 0) ? (-L / a) : G_INF;
+    } else {
+        if (a <= 0) return G_INF;
+        if (-L <= -(a * a) / b + (a * a) / (2 * b)) {
+            const double r = a / b;
+            return -sqrt(r * r - L * 2.0 / b) - r;
+        }
+        return G_INF;
+    }
+}
 // sigmoid(x) = inv(one(x) + exp(-x)), scripts/logistic.jl:33
 __device__ __forceinline__ double g_sigmoid(double x) {
     return 1.0 / (1.0 + pdmp_exp(-x));
@@ -268,6 +286,8 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
             const uint32_t q0 = mrec.z;
             const uint32_t last = (base + 64u < jj1) ? (base + 64u) : jj1;
             const uint32_t qs = P.tb.qptr[cp0 + base], qe = P.tb.qptr[cp0 + last];
+            const uint64_t di = per_member_draw ? (draw0 + (uint64_t)jjc) : draw0;
+            const double Ldraw = pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, di));
             double s1 = 0.0, s2 = 0.0;  // ZigZag: Γ[:,j]·x, Γ[:,j]·θ; FactBoomerang: Σ (x−μ)² + θ²
             for (uint32_t cb = qs; cb < qe; cb += G_PCH) {
                 const uint32_t ce = (cb + G_PCH < qe) ? (cb + G_PCH) : qe;
@@ -338,8 +358,7 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
                 }
                 ZzRec* r = rec + j;
                 const double tj = own_clock ? r->t : tp;
-                const uint64_t di = per_member_draw ? (draw0 + (uint64_t)jj) : draw0;
-                double dtn = g_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, di));
+                double dtn = g_poisson_time_L(a, b, Ldraw);
                 if (local) {  // next_time, src/not_fact_samplers.jl:43-50: the bound expires after its horizon
                     const bool rn = dtn > hz;
                     dtn = rn ? hz : dtn;
@@ -482,6 +501,7 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
         } else {
             move_members(sp0, 0, k, tp);  // smove_forward!(G, i, ...), :82
         }
+        const double ucoin = pdmp_u01(seed, PDMP_STREAM_MAIN, nm);  // thinning coin: its index is known before the gradient is
         if (local && g_uniform((__hip_atomic_load(rnw + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) ? 1u : 0u)) {
             // src/local.jl:36-43: the bound of i expired -- renew it from the moved state (one draw), no proposal
             rebound(cp0, self, self + 1u, tp, nm, false, false);
@@ -582,8 +602,7 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
                                    : g_pos(g * th_i);                                        // :119
         const double lbound = g_pos(a_i + b_i * (tp - told_i));     // :119
         num += 1;
-        const double ucoin = pdmp_u01(seed, PDMP_STREAM_MAIN, nm);  // :121
-        nm += 1;
+        nm += 1;  // the coin is draw nm (taken above, before the gradient), :121
         const bool accept = (ucoin * lbound < l_rate);
         bool violated = false;
         if (accept) {
