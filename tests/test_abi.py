@@ -49,3 +49,17 @@ def test_product_never_imports_the_oracle():
                 assert "oracle_lib" not in txt and "liboracle" not in txt, (dp, f)
                 assert not re.search(r'#include\s*[<"][^>"]*oracle', txt), (dp, f)
                 assert not re.search(r'^\s*(from|import)\s+\S*oracle', txt, flags=re.M), (dp, f)
+
+
+def test_headers_are_plain_c99(tmp_path):
+    """include/pdmp_mi355.h and include/pdmp_detmath.h must compile as C99 (the boundary is a C ABI: cgo / ccall / ctypes bind it),
+    with the struct sizes the bindings assume."""
+    import subprocess
+    inc = os.path.join(ROOT, "include")
+    src = tmp_path / "t.c"
+    src.write_text('#include "pdmp_mi355.h"\n#include "pdmp_detmath.h"\n'
+                   "int main(void){ return (int)(sizeof(pdmp_event) != 32) + (int)(sizeof(pdmp_chain_counters) != 72) + "
+                   "(int)(sizeof(pdmp_config) != 48) + (int)(pdmp_log(1.0) != 0.0); }\n")
+    exe = tmp_path / "t"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-ffp-contract=off", "-I", inc, str(src), "-o", str(exe)])
+    assert subprocess.call([str(exe)]) == 0
