@@ -277,6 +277,31 @@ __device__ __forceinline__ double dev_poisson_time_L(double a, double b, double 
         asm volatile("" ::: "memory");   \
     } while (0)
 
+// Level-1 entry (block minimum, argmin) of the block of coordinate j after keys[j] became kj: smaller than the entry -> replace;
+// j WAS the entry and grew -> rescan the 64 keys of the block (lowest index on ties); otherwise nothing to do.
+__device__ __forceinline__ void level1_update(double* bk, uint32_t* bi, const double* keys, int lane, uint32_t j, double kj) {
+    const uint32_t bj = j >> 6;
+    LDS_ORDER();
+    const double cur = bk[bj];
+    const uint32_t ci = bi[bj];
+    if (kj < cur || (kj == cur && j < ci)) {
+        if (lane == 0) {
+            bk[bj] = kj;
+            bi[bj] = j;
+        }
+    } else if (ci == j) {
+        const double kv = __hip_atomic_load(keys + (size_t)bj * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double mn = wave_min_f64(kv);
+        const uint64_t bl = __ballot(kv == mn);
+        const int arg = bl ? (__ffsll((unsigned long long)bl) - 1) : 0;
+        if (lane == 0) {
+            bk[bj] = mn;
+            bi[bj] = bj * 64 + (uint32_t)arg;
+        }
+    }
+}
+
+
 __global__ __launch_bounds__(64) void zz_local_run_kernel(ZzRunParams P) {
     const int lane = threadIdx.x;
     const int64_t chain = blockIdx.x;
@@ -329,25 +354,7 @@ __global__ __launch_bounds__(64) void zz_local_run_kernel(ZzRunParams P) {
     };
     // generic level-1 update for one changed key (j, kj) whose new value is already stored in keys[]
     auto queue_update = [&](uint32_t j, double kj) {
-        const uint32_t bj = j >> 6;
-        LDS_ORDER();
-        const double cur = bk[bj];
-        const uint32_t ci = bi[bj];
-        if (kj < cur || (kj == cur && j < ci)) {
-            if (lane == 0) {
-                bk[bj] = kj;
-                bi[bj] = j;
-            }
-        } else if (ci == j) {
-            const double kv = __hip_atomic_load(keys + (size_t)bj * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const double mn = wave_min_f64(kv);
-            const uint64_t bl = __ballot(kv == mn);
-            const int arg = bl ? (__ffsll((unsigned long long)bl) - 1) : 0;
-            if (lane == 0) {
-                bk[bj] = mn;
-                bi[bj] = bj * 64 + (uint32_t)arg;
-            }
-        }
+        level1_update(bk, bi, keys, lane, j, kj);
         LDS_ORDER();
     };
 
@@ -833,25 +840,7 @@ __global__ __launch_bounds__(64) void zz_sticky_run_kernel(ZzRunParams P) {
     LDS_ORDER();
 
     auto queue_update = [&](uint32_t j, double kj) {
-        const uint32_t bj = j >> 6;
-        LDS_ORDER();
-        const double cur = bk[bj];
-        const uint32_t ci = bi[bj];
-        if (kj < cur || (kj == cur && j < ci)) {
-            if (lane == 0) {
-                bk[bj] = kj;
-                bi[bj] = j;
-            }
-        } else if (ci == j) {
-            const double kv = __hip_atomic_load(keys + (size_t)bj * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const double mn = wave_min_f64(kv);
-            const uint64_t bl = __ballot(kv == mn);
-            const int arg = bl ? (__ffsll((unsigned long long)bl) - 1) : 0;
-            if (lane == 0) {
-                bk[bj] = mn;
-                bi[bj] = bj * 64 + (uint32_t)arg;
-            }
-        }
+        level1_update(bk, bi, keys, lane, j, kj);
         LDS_ORDER();
     };
 
@@ -1242,29 +1231,6 @@ __device__ __forceinline__ void spec_patched_min(const double* pk, int gl, uint3
     candmin = lm;
     cand = blk * 64u + (uint32_t)gl * 4u + li;
     rowmin = row_min_f64(lm);
-}
-
-// Level-1 entry of the block of coordinate j after keys[j] became kj (j's block is not the event's own popped block).
-__device__ __forceinline__ void spec_level1_update(double* bk, uint32_t* bi, const double* keys, int lane, uint32_t j, double kj) {
-    const uint32_t bj = j >> 6;
-    LDS_ORDER();
-    const double cur = bk[bj];
-    const uint32_t ci = bi[bj];
-    if (kj < cur || (kj == cur && j < ci)) {
-        if (lane == 0) {
-            bk[bj] = kj;
-            bi[bj] = j;
-        }
-    } else if (ci == j) {
-        const double kv = __hip_atomic_load(keys + (size_t)bj * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double mn = wave_min_f64(kv);
-        const uint64_t bl = __ballot(kv == mn);
-        const int arg = bl ? (__ffsll((unsigned long long)bl) - 1) : 0;
-        if (lane == 0) {
-            bk[bj] = mn;
-            bi[bj] = bj * 64 + (uint32_t)arg;
-        }
-    }
 }
 
 template <int NE, bool PROF>
@@ -1658,7 +1624,7 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
             for (int jj = 0; jj < kr; ++jj) {
                 const uint32_t j = readlane_u32(s, 16 * (int)r + jj);
                 if ((j >> 6) == own) continue;
-                spec_level1_update(bk, bi, keys, lane, j, readlane_f64(key, 16 * (int)r + jj));
+                level1_update(bk, bi, keys, lane, j, readlane_f64(key, 16 * (int)r + jj));
             }
         }
         PHASE(8);
@@ -2131,7 +2097,7 @@ __global__ __launch_bounds__(64) void zz_sticky_spec_kernel(ZzRunParams P) {
                 lanes &= lanes - 1u;
                 const uint32_t j = readlane_u32(s, 16 * (int)r + jj);
                 if ((j >> 6) == own) continue;
-                spec_level1_update(bk, bi, keys, lane, j, readlane_f64(key, 16 * (int)r + jj));
+                level1_update(bk, bi, keys, lane, j, readlane_f64(key, 16 * (int)r + jj));
             }
         }
         // ---------------- counters (scalar acc, num with the reset of an adapted violation, :131-136)
