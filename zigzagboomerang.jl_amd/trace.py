@@ -97,8 +97,45 @@ def discretize(tr, dt):
     return np.array(ts), np.array(xs)
 
 
-def mean(tr: FactTrace):
-    """mean(Ξ): time average of the piecewise-linear path per coordinate -- src/trace.jl:182-200."""
+def _mean_pdmp(tr: PDMPTrace):
+    """Statistics.mean(Ξ::PDMPTrace) -- src/trace.jl:229-246, restated as written: Σ (x + x₂)(t₂ − t) over consecutive events divided
+    by the LAST event time T -- the reference omits the ½ of the trapezoid rule here (its cummean, :248-266, has it), so this is
+    twice the time average of the interpolated path."""
+    d = len(tr.x0)
+    X = np.vstack([tr.x0[None], np.asarray(tr.x).reshape(-1, d)])
+    te = np.concatenate([[tr.t0], tr.t])
+    y = ((X[:-1] + X[1:]) * np.diff(te)[:, None]).sum(0)
+    return y / tr.t[-1]
+
+
+def cummean(tr):
+    """cummean(Ξ) -- src/trace.jl:203-225 (FactTrace: per coordinate the running (t, ∫x/(2t))) and :248-266 (PDMPTrace: the
+    running vector y/(2t) after every event).  Returns a list of (t, y) array pairs per coordinate, resp. an [n x d] array."""
+    if isinstance(tr, PDMPTrace):
+        d = len(tr.x0)
+        X = np.vstack([tr.x0[None], np.asarray(tr.x).reshape(-1, d)])
+        te = np.concatenate([[tr.t0], tr.t])
+        y = np.cumsum((X[:-1] + X[1:]) * np.diff(te)[:, None], axis=0)
+        return y / (2.0 * te[1:, None])
+    ev = tr.events
+    x = tr.x0.copy()
+    y = np.zeros_like(x)
+    t = np.full(x.shape, tr.t0)
+    ts = [[tr.t0] for _ in x]
+    ys = [[xi] for xi in x]
+    for t2, i, xi, _ in ev:
+        y[i] += (x[i] + xi) * (t2 - t[i])
+        t[i] = t2
+        x[i] = xi
+        ts[i].append(t2)
+        ys[i].append(y[i] / (2 * t2))
+    return [(np.array(a), np.array(b)) for a, b in zip(ts, ys)]
+
+
+def mean(tr):
+    """mean(Ξ): time average of the piecewise-linear path per coordinate -- src/trace.jl:182-200 (FactTrace), :229-246 (PDMPTrace)."""
+    if isinstance(tr, PDMPTrace):
+        return _mean_pdmp(tr)
     ev = tr.events
     x = tr.x0.copy()
     y = np.zeros_like(x)
