@@ -135,3 +135,28 @@ def test_sticky_trace_refill_and_time_slices(gpu_pkg):
         for k, r in enumerate(refs):
             ev = ens.trace(k, counters=cnt)
             assert len(ev) == len(r["events"]) and np.array_equal(ev["t"], r["events"]["t"]) and np.array_equal(ev["i"], r["events"]["i"])
+
+
+def test_sticky_on_large_neighbourhoods(gpu_pkg, kernel_mode):
+    """sspdmp on graphs whose two-hop zones exceed one wavefront (general kernel): random sparse precision with a dense hub column
+    (the shape of a regression's intercept), adapt / reversible / strong_upperbounds variants."""
+    if kernel_mode == "seq":
+        pytest.skip("one kernel serves this case")
+    pkg = gpu_pkg
+    rng = np.random.default_rng(31)
+    d = 120
+    R = sp.random(d, d, density=0.04, random_state=rng, data_rvs=rng.standard_normal, format="lil")
+    R[0, :] = 0.3 * rng.standard_normal(d)  # hub: coordinate 0 neighbours everything
+    A = sp.csc_matrix(R)
+    G = sp.csc_matrix(A.T @ A + 2.0 * sp.identity(d))
+    G.sort_indices()
+    assert np.diff(G.indptr).max() > 64
+    x0 = rng.standard_normal((2, d))
+    th0 = rng.choice([-1.0, 1.0], (2, d))
+    c = 2.0 * pkg.problems.column_norms(G)
+    kappa = rng.uniform(0.2, 1.5, d)
+    check(pkg, G, G, None, x0, th0, c, kappa, 6.0, seed=400, adapt=True)
+    check(pkg, 0.9 * G, G, 0.1 * rng.standard_normal(d), x0, th0, c, kappa, 4.0, seed=401, adapt=True, reversible=True)
+    tr = check(pkg, G, G, None, x0, th0, c, kappa, 4.0, seed=402, adapt=True, strong=True)
+    frozen = np.mean([np.mean(q.events["theta"] == 0) for q in tr])
+    assert 0.05 < frozen < 0.6  # freeze events are a sizeable share of the trace

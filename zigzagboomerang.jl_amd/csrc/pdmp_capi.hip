@@ -662,10 +662,13 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
     std::vector<double> cv(c, c + d);
     if ((st = e->d_c.upload(cv)) != PDMP_OK) return st;
     if (e->needs_general || e->target_kind == 1 || e->adaptscale || e->local_bound) {
-        if (e->cfg.sampler != PDMP_SAMPLER_ZIGZAG_LOCAL && e->cfg.sampler != PDMP_SAMPLER_ZIGZAG_ALL)
+        if (e->cfg.sampler != PDMP_SAMPLER_ZIGZAG_LOCAL && e->cfg.sampler != PDMP_SAMPLER_ZIGZAG_ALL &&
+            e->cfg.sampler != PDMP_SAMPLER_STICKY_ZIGZAG)
             return fail(PDMP_ERR_UNSUPPORTED,
                         "neighbourhoods beyond 64 members / the logistic target / FactBoomerang / adaptscale run on the general "
-                        "kernel: spdmp and pdmp only");
+                        "kernel: spdmp, pdmp and sspdmp only");
+        if (sticky && (e->target_kind == 1 || e->flow_kind == 1 || e->adaptscale || e->local_bound))
+            return fail(PDMP_ERR_UNSUPPORTED, "sspdmp on the general kernel: ZigZag flow, Gaussian target");
         if (e->cfg.sampler == PDMP_SAMPLER_ZIGZAG_ALL && e->target_kind == 1)
             return fail(PDMP_ERR_UNSUPPORTED, "the logistic target moves what it reads (SelfMoving): use PDMP_SAMPLER_ZIGZAG_LOCAL");
         if (e->target_kind == 1 && (e->flow_kind == 1 || e->lambda_ref > 0))
@@ -847,6 +850,7 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
     if (general_path) {
         pdmp::ZzGeneralParams Q{};
         Q.local_bound = e->local_bound ? 1 : 0;
+        Q.sticky = sticky ? 1 : 0;
         Q.qtval = e->d_qtval.p;
         Q.renew_chain = e->local_bound ? e->d_thf.p : nullptr;
         Q.sig_chain = e->adaptscale ? e->d_sig_chain.p : nullptr;

@@ -122,6 +122,9 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
     const double* cvec = cmut ? cmut : P.tb.c_shared;
     double* sigc = Q.sig_chain ? (Q.sig_chain + chain * d) : nullptr;
     const bool local = Q.local_bound != 0;
+    const bool sticky = Q.sticky != 0;
+    uint32_t reb_count = 0;  // sticky: members re-bounded so far by the current rebound() call
+    double* thf = sticky ? (P.thf + chain * d) : nullptr;
     double* rnw = local ? (Q.renew_chain + chain * d) : nullptr;
 
     uint32_t status = hdr->c.status;
@@ -204,7 +207,10 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
                 ZzRec* r = rec + j;
                 const double x0 = r->x, th0 = r->th, t0 = r->t, I0 = r->I;
                 const double dt = tp - t0;
-                if (!boom) {
+                if (sticky && th0 == 0.0) {  // ssmove_forward!, src/ss_fact.jl:36-45: frozen coordinates keep their clock
+                    sx[pp] = x0;
+                    sth[pp] = th0;
+                } else if (!boom) {
                     const double xn = x0 + th0 * dt;  // smove_forward!, src/sfact.jl:6-12
                     r->x = xn;
                     r->t = tp;
@@ -286,7 +292,17 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
             const uint32_t q0 = mrec.z;
             const uint32_t last = (base + 64u < jj1) ? (base + 64u) : jj1;
             const uint32_t qs = P.tb.qptr[cp0 + base], qe = P.tb.qptr[cp0 + last];
-            const uint64_t di = per_member_draw ? (draw0 + (uint64_t)jjc) : draw0;
+            // sticky (src/ss_fact.jl:101-106,118-122,141-146): frozen members (θ[j] == 0) are neither re-bounded nor given a draw;
+            // a re-bounded member takes draw draw0 + (its rank among the re-bounded ones)
+            bool live = valid;
+            uint32_t rank = jjc - jj0;
+            if (sticky) {
+                live = valid && (sth[jjc] != 0.0);
+                const uint64_t lball = __ballot(live);
+                rank = reb_count + (uint32_t)__popcll(lball & ((1ull << lane) - 1ull));
+                reb_count += (uint32_t)__popcll(lball);
+            }
+            const uint64_t di = per_member_draw ? (draw0 + (uint64_t)rank) : draw0;
             const double Ldraw = pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, di));
             double s1 = 0.0, s2 = 0.0;  // ZigZag: Γ[:,j]·x, Γ[:,j]·θ; FactBoomerang: Σ (x−μ)² + θ²
             for (uint32_t cb = qs; cb < qe; cb += G_PCH) {
@@ -337,7 +353,7 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
                 }
             }
             G_ORDER();
-            if (valid) {
+            if (live) {
                 const double cj = cvec[j];
                 const double xj = sx[jj], thj = sth[jj];
                 double a, b;
@@ -363,6 +379,12 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
                     const bool rn = dtn > hz;
                     dtn = rn ? hz : dtn;
                     rnw[j] = rn ? 1.0 : 0.0;
+                }
+                if (sticky) {  // queue_time!, src/ss_fact.jl:54-66: the earlier of the reflection proposal and the hitting time of 0
+                    const double tfreeze = (thj * xj >= 0) ? G_INF : (-xj / thj);  // freezing_time, :10-16
+                    const bool fz = tfreeze <= dtn;
+                    dtn = fz ? tfreeze : dtn;
+                    r->acc = fz ? 1u : 0u;  // f[j]
                 }
                 const double key = tj + dtn;
                 r->t_old = tj;
@@ -492,6 +514,121 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
             nevents += 1;
             t_event = tp;
             if (!stop_before && !(tp < T)) running = false;
+            G_ORDER();
+            continue;
+        }
+        if (sticky) {
+            // ---------------- sspdmp_inner!, src/ss_fact.jl:78-157, for neighbourhoods of any size
+            const double x_i0 = ri->x, th_i0 = ri->th;
+            const bool is_freeze = g_uniform(acc_i != 0 ? 1u : 0u) != 0;  // f[i]: rec.acc holds the flag for sticky chains
+            const bool is_thaw = !is_freeze && g_uniform((x_i0 == 0 && th_i0 == 0) ? 1u : 0u) != 0;
+            bool emit = true;
+            if (is_freeze) {  // case 1, :87-107
+                const double dt = tp - ri->t;
+                const double xs = x_i0 + th_i0 * dt;  // smove_forward!(i, ...), :88
+                if (fabs(xs) > 1e-8) {                // :89-91
+                    status = PDMP_CHAIN_BOUND_VIOLATED;
+                    break;
+                }
+                const double knew = tp - pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm)) / P.kappa[i];  // :96
+                nm += 1;
+                if (lane == 0) {
+                    ZzRec* w = rec + i;
+                    w->I = ri->I + dt * ((x_i0 + xs) * 0.5);
+                    w->x = 0.0 * th_i0;  // x[i] = -0*θ[i], :92
+                    w->th = 0.0;         // :93
+                    w->t = tp;
+                    w->t_old = tp;       // :94
+                    w->acc = 0;          // f[i] = false, :95
+                    thf[i] = th_i0;
+                    keys[i] = knew;
+                }
+                G_ORDER();
+                if (!P.strong_upperbounds) {  // :97-107
+                    move_members(sp0, 0, m, tp);  // G and G2, non-frozen only (i is frozen now)
+                    reb_count = 0;
+                    rebound(cp0, 0, k, tp, nm, true, false);
+                    nm += reb_count;
+                    requeue(cp0, 0, k, false, 0u);  // includes i's own block
+                } else {
+                    requeue(cp0, self, self + 1u, false, 0u);
+                }
+            } else if (is_thaw) {  // case 2, :108-123
+                double thn = thf[i];  // θ[i], θf[i] = θf[i], 0.0, :110
+                uint32_t head = 0;
+                if (P.reversible) {  // :111-113
+                    thn *= (pdmp_u01(seed, PDMP_STREAM_MAIN, nm) < 0.5) ? -1.0 : 1.0;
+                    head = 1;
+                }
+                if (lane == 0) {
+                    ZzRec* w = rec + i;
+                    w->t = tp;      // :109
+                    w->th = thn;
+                    w->t_old = tp;  // :114
+                    thf[i] = 0.0;
+                }
+                G_ORDER();
+                move_members(sp0, 0, m, tp);  // :115-116 (i itself: dt = 0)
+                reb_count = 0;
+                rebound(cp0, 0, k, tp, nm + head, true, false);  // :117-123, non-frozen members including i
+                nm += head + reb_count;
+                requeue(cp0, 0, k, false, 0u);
+            } else {  // reflection proposal, :124-152
+                move_members(sp0, 0, k, tp);  // ssmove_forward!(G, i, ...), :125
+                double g = 0.0;
+                for (uint32_t p = 0; p < k; ++p) g += P.tb.tval[cp0 + p] * sx[p];
+                if (P.tb.gmu_t) g = g - P.tb.gmu_t[i];
+                const double th_i = sth[self];
+                const double l_rate = g_pos(g * th_i);
+                const double lbound = g_pos(a_i + b_i * (tp - told_i));  // :128
+                num += 1;
+                const double coin = pdmp_u01(seed, PDMP_STREAM_MAIN, nm);
+                nm += 1;
+                if (coin * lbound < l_rate) {  // :130
+                    nacc += 1;
+                    if (l_rate > lbound) {  // :132
+                        if (!adapt) {
+                            status = PDMP_CHAIN_BOUND_VIOLATED;
+                            break;
+                        }
+                        nacc = 0;  // acc = num = 0, :134
+                        num = 0;
+                        if (lane == 0) cmut[i] = cvec[i] * P.factor;  // :135
+                    }
+                    move_members(sp0, k, m, tp);  // :138
+                    if (lane == 0) {
+                        sth[self] = -th_i;  // :139
+                        rec[i].th = -th_i;
+                    }
+                    G_ORDER();
+                    reb_count = 0;
+                    rebound(cp0, 0, k, tp, nm, true, false);  // :140-146
+                    nm += reb_count;
+                    requeue(cp0, 0, k, false, 0u);
+                } else {  // :147-151
+                    reb_count = 0;
+                    rebound(cp0, self, self + 1u, tp, nm, true, false);
+                    nm += reb_count;
+                    requeue(cp0, self, self + 1u, false, 0u);
+                    emit = false;
+                }
+            }
+            if (emit) {  // push!(Ξ, event(i, t, x, θ, F)), :154
+                G_ORDER();
+                if (ev && lane == 0) {
+                    const ZzRec* w = rec + i;
+                    pdmp_event e;
+                    e.t = __hip_atomic_load(&w->t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    e.i = (int64_t)i;
+                    e.x = __hip_atomic_load(&w->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    e.theta = __hip_atomic_load(&w->th, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ev[ntrace] = e;
+                }
+                ntrace += 1;
+                nevents += 1;
+                t_event = tp;
+                if (!stop_before && !(tp < T)) running = false;
+            }
             G_ORDER();
             continue;
         }
