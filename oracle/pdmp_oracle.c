@@ -900,12 +900,12 @@ int orc_sspdmp_zigzag(int64_t d, const orc_sticky_params* p, double t0, double T
     double* gmu = (double*)malloc((size_t)d * sizeof(double));
     double* gmt = NULL;
     for (int64_t i = 0; i < d; ++i) gmu[i] = orc_idot(p->bound_gamma, i, p->bound_mu);
-    if (p->target_mu) {
+    if (p->target_mu && !p->logistic) {
         gmt = (double*)malloc((size_t)d * sizeof(double));
         for (int64_t i = 0; i < d; ++i) gmt[i] = orc_idot(p->target_gamma, i, p->target_mu);
     }
     const uint64_t seed = p->seed;
-    uint64_t nm = 0;
+    uint64_t nm = 0, ng = 0;
     double* t_old = (double*)malloc((size_t)d * sizeof(double));
     double* ba = (double*)malloc((size_t)d * sizeof(double));
     double* bb = (double*)malloc((size_t)d * sizeof(double));
@@ -983,8 +983,13 @@ int orc_sspdmp_zigzag(int64_t d, const orc_sticky_params* p, double t0, double T
                 }
             } else { /* :124 reflection proposal */
                 ssmove_nbrs(&g1, i, t, x, th, tp); /* :125 */
-                double gi = orc_idot(p->target_gamma, i, x);
-                if (gmt) gi = gi - gmt[i];
+                double gi;
+                if (p->logistic) { /* ∇ϕ_(∇ϕ, t, x, θ, i, t′, F, S::SelfMoving, args...), src/sfact.jl:68 */
+                    gi = logistic_grad_moving(p->logistic, i, t, x, th, tp, seed, &ng);
+                } else {
+                    gi = orc_idot(p->target_gamma, i, x);
+                    if (gmt) gi = gi - gmt[i];
+                }
                 double l = pos(gi * th[i]);
                 double lb = pos(ba[i] + bb[i] * (t[i] - t_old[i])); /* :128 */
                 num += 1;
@@ -1030,7 +1035,7 @@ finish:
         res->nacc = acc;
         res->nrefresh = 0;
         res->ndraw_main = nm;
-        res->ndraw_global = 0;
+        res->ndraw_global = ng;
         res->t_last = tp;
         res->status = status;
     }

@@ -197,6 +197,11 @@ typedef struct {
     int strong_upperbounds;
     uint64_t seed;
     int64_t max_events;
+    /* logistic != NULL: ∇ϕ = ∇ϕmoving(t, x, θ, i, t′, F, A, At, μ, y, ny, k) with SelfMoving() (scripts/logistic.jl:78-95,107; the
+     * sticky script scripts/sticky/sticky_logistic_sparse.jl:83-100,131 has the same helper): only the lg_* fields and `seed` of
+     * *logistic are read; target_gamma / target_mu are then ignored.  idot_moving! moves what it reads with smove_forward!, frozen
+     * coordinates included (their clock advances, x + 0·dt). */
+    const orc_zz_params* logistic;
 } orc_sticky_params;
 int orc_sspdmp_zigzag(int64_t d, const orc_sticky_params* p, double t0, double T, double* x, double* theta,
                       double* c, double* t_out, orc_trace* tr, orc_zz_result* res);

@@ -72,7 +72,8 @@ class _StickyParams(C.Structure):
     _fields_ = [("bound_gamma", C.POINTER(_Csc)), ("bound_mu", C.c_void_p),
                 ("target_gamma", C.POINTER(_Csc)), ("target_mu", C.c_void_p), ("kappa", C.c_void_p),
                 ("adapt", C.c_int), ("factor", C.c_double), ("reversible", C.c_int),
-                ("strong_upperbounds", C.c_int), ("seed", C.c_uint64), ("max_events", C.c_int64)]
+                ("strong_upperbounds", C.c_int), ("seed", C.c_uint64), ("max_events", C.c_int64),
+                ("logistic", C.POINTER(_ZZParams))]
 
 
 _lib = None
@@ -317,7 +318,7 @@ def pdmp_bps(gamma, mu, x0, theta0, c, T, *, t0=0.0, lambda_ref=1.0, rho=0.0, ad
 
 
 def sspdmp_zigzag(bound_gamma, bound_mu, target_gamma, x0, theta0, c, kappa, T, *, t0=0.0, target_mu=None,
-                  adapt=False, factor=1.5, reversible=False, strong_upperbounds=False, seed=1, max_events=0):
+                  adapt=False, factor=1.5, reversible=False, strong_upperbounds=False, seed=1, max_events=0, logistic=None):
     L = lib()
     gb = bound_gamma if isinstance(bound_gamma, CscHolder) else CscHolder(bound_gamma)
     gt = target_gamma if isinstance(target_gamma, CscHolder) else CscHolder(target_gamma)
@@ -328,6 +329,16 @@ def sspdmp_zigzag(bound_gamma, bound_mu, target_gamma, x0, theta0, c, kappa, T, 
     p = _StickyParams(C.pointer(gb.c), mu.ctypes.data, C.pointer(gt.c),
                       tmu.ctypes.data if tmu is not None else None, kap.ctypes.data, int(adapt), factor,
                       int(reversible), int(strong_upperbounds), seed, max_events)
+    if logistic is not None:  # dict(A, At, y, ny, mu, gamma0, k): ∇ϕmoving with SelfMoving()
+        lA = logistic["A"] if isinstance(logistic["A"], CscHolder) else CscHolder(logistic["A"])
+        lAt = logistic["At"] if isinstance(logistic["At"], CscHolder) else CscHolder(logistic["At"])
+        ly, lny, lmu = _f64(logistic["y"]), _f64(logistic["ny"]), _f64(logistic["mu"])
+        zp = _ZZParams()
+        zp.target_kind = 1
+        zp.lg_A, zp.lg_At = C.pointer(lA.c), C.pointer(lAt.c)
+        zp.lg_y, zp.lg_ny, zp.lg_mu = ly.ctypes.data, lny.ctypes.data, lmu.ctypes.data
+        zp.lg_gamma0, zp.lg_k = float(logistic["gamma0"]), int(logistic["k"])
+        p.logistic = C.pointer(zp)
     x = _f64(x0).copy()
     th = _f64(theta0).copy()
     cc = _f64(c).copy()

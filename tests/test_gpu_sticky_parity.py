@@ -160,3 +160,34 @@ def test_sticky_on_large_neighbourhoods(gpu_pkg, kernel_mode):
     tr = check(pkg, G, G, None, x0, th0, c, kappa, 4.0, seed=402, adapt=True, strong=True)
     frozen = np.mean([np.mean(q.events["theta"] == 0) for q in tr])
     assert 0.05 < frozen < 0.6  # freeze events are a sizeable share of the trace
+
+
+def test_sticky_logistic_spike_and_slab(gpu_pkg, kernel_mode):
+    """sspdmp(∇ϕmoving, t0, x0, θ0, T, c, Zdrop, κ, SelfMoving(), A, At, μ, y, ny, k; adapt=true): the sticky sampler on the
+    subsampled logistic target of scripts/logistic.jl (the model of scripts/sticky/sticky_logistic_sparse.jl with the stock ZigZag
+    bound instead of its hand-written MyBoundLog), κ = (γ0/√2π)/(1/w − 1), w = 1/2 (:194-197)."""
+    if kernel_mode == "seq":
+        pytest.skip("one kernel serves this case")
+    pkg = gpu_pkg
+    L = pkg.problems.logistic_problem(m=20)
+    p = L["p"]
+    rng = np.random.default_rng(12)
+    nch, T = 2, 3.0
+    X0 = np.tile(L["x0"], (nch, 1))
+    TH0 = L["sigma"] * rng.choice([-1.0, 1.0], (nch, p))
+    kappa = np.full(p, (L["gamma0"] / math.sqrt(2 * math.pi)) / (1 / 0.5 - 1))
+    Z = pkg.ZigZag(L["Gdrop"], L["mu"], L["sigma"])
+    target = pkg.LogisticTarget(L["A"], L["y"], L["ny"], L["mu"], L["gamma0"], 10)
+    tr, (t, x, th), (acc, num), cout = pkg.sspdmp(target, 0.0, X0, TH0, T, L["c"], Z, kappa, seed=500, adapt=True, factor=5.0)
+    lg = dict(A=L["A"], At=L["At"], y=L["y"], ny=L["ny"], mu=L["mu"], gamma0=L["gamma0"], k=10)
+    for k in range(nch):
+        r = O.sspdmp_zigzag(L["Gdrop"], L["mu"], L["Gdrop"], X0[k], TH0[k], L["c"], kappa, T, seed=500 + k, adapt=True, factor=5.0,
+                            logistic=lg)
+        assert r["status"] == 0 and len(r["events"]) > 200
+        ev, oe = tr[k].events, r["events"]
+        assert len(ev) == len(oe), (k, len(ev), len(oe))
+        for f in ("i", "t", "x", "theta"):
+            assert np.array_equal(ev[f], oe[f]), (k, f)
+        assert (int(acc[k]), int(num[k])) == (r["nacc"], r["num"]) and np.array_equal(cout[k], r["c"])
+        assert np.array_equal(x[k], r["x"]) and np.array_equal(th[k], r["theta"]) and np.array_equal(t[k], r["t"])
+        assert 0.2 < np.mean(r["theta"] == 0) < 0.95  # a good share of the coefficients sits in the spike

@@ -667,8 +667,8 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
             return fail(PDMP_ERR_UNSUPPORTED,
                         "neighbourhoods beyond 64 members / the logistic target / FactBoomerang / adaptscale run on the general "
                         "kernel: spdmp, pdmp and sspdmp only");
-        if (sticky && (e->target_kind == 1 || e->flow_kind == 1 || e->adaptscale || e->local_bound))
-            return fail(PDMP_ERR_UNSUPPORTED, "sspdmp on the general kernel: ZigZag flow, Gaussian target");
+        if (sticky && (e->flow_kind == 1 || e->adaptscale || e->local_bound))
+            return fail(PDMP_ERR_UNSUPPORTED, "sspdmp on the general kernel: ZigZag flow, Gaussian or logistic target");
         if (e->cfg.sampler == PDMP_SAMPLER_ZIGZAG_ALL && e->target_kind == 1)
             return fail(PDMP_ERR_UNSUPPORTED, "the logistic target moves what it reads (SelfMoving): use PDMP_SAMPLER_ZIGZAG_LOCAL");
         if (e->target_kind == 1 && (e->flow_kind == 1 || e->lambda_ref > 0))

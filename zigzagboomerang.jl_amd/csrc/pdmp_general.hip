@@ -517,145 +517,9 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
             G_ORDER();
             continue;
         }
-        if (sticky) {
-            // ---------------- sspdmp_inner!, src/ss_fact.jl:78-157, for neighbourhoods of any size
-            const double x_i0 = ri->x, th_i0 = ri->th;
-            const bool is_freeze = g_uniform(acc_i != 0 ? 1u : 0u) != 0;  // f[i]: rec.acc holds the flag for sticky chains
-            const bool is_thaw = !is_freeze && g_uniform((x_i0 == 0 && th_i0 == 0) ? 1u : 0u) != 0;
-            bool emit = true;
-            if (is_freeze) {  // case 1, :87-107
-                const double dt = tp - ri->t;
-                const double xs = x_i0 + th_i0 * dt;  // smove_forward!(i, ...), :88
-                if (fabs(xs) > 1e-8) {                // :89-91
-                    status = PDMP_CHAIN_BOUND_VIOLATED;
-                    break;
-                }
-                const double knew = tp - pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm)) / P.kappa[i];  // :96
-                nm += 1;
-                if (lane == 0) {
-                    ZzRec* w = rec + i;
-                    w->I = ri->I + dt * ((x_i0 + xs) * 0.5);
-                    w->x = 0.0 * th_i0;  // x[i] = -0*θ[i], :92
-                    w->th = 0.0;         // :93
-                    w->t = tp;
-                    w->t_old = tp;       // :94
-                    w->acc = 0;          // f[i] = false, :95
-                    thf[i] = th_i0;
-                    keys[i] = knew;
-                }
-                G_ORDER();
-                if (!P.strong_upperbounds) {  // :97-107
-                    move_members(sp0, 0, m, tp);  // G and G2, non-frozen only (i is frozen now)
-                    reb_count = 0;
-                    rebound(cp0, 0, k, tp, nm, true, false);
-                    nm += reb_count;
-                    requeue(cp0, 0, k, false, 0u);  // includes i's own block
-                } else {
-                    requeue(cp0, self, self + 1u, false, 0u);
-                }
-            } else if (is_thaw) {  // case 2, :108-123
-                double thn = thf[i];  // θ[i], θf[i] = θf[i], 0.0, :110
-                uint32_t head = 0;
-                if (P.reversible) {  // :111-113
-                    thn *= (pdmp_u01(seed, PDMP_STREAM_MAIN, nm) < 0.5) ? -1.0 : 1.0;
-                    head = 1;
-                }
-                if (lane == 0) {
-                    ZzRec* w = rec + i;
-                    w->t = tp;      // :109
-                    w->th = thn;
-                    w->t_old = tp;  // :114
-                    thf[i] = 0.0;
-                }
-                G_ORDER();
-                move_members(sp0, 0, m, tp);  // :115-116 (i itself: dt = 0)
-                reb_count = 0;
-                rebound(cp0, 0, k, tp, nm + head, true, false);  // :117-123, non-frozen members including i
-                nm += head + reb_count;
-                requeue(cp0, 0, k, false, 0u);
-            } else {  // reflection proposal, :124-152
-                move_members(sp0, 0, k, tp);  // ssmove_forward!(G, i, ...), :125
-                double g = 0.0;
-                for (uint32_t p = 0; p < k; ++p) g += P.tb.tval[cp0 + p] * sx[p];
-                if (P.tb.gmu_t) g = g - P.tb.gmu_t[i];
-                const double th_i = sth[self];
-                const double l_rate = g_pos(g * th_i);
-                const double lbound = g_pos(a_i + b_i * (tp - told_i));  // :128
-                num += 1;
-                const double coin = pdmp_u01(seed, PDMP_STREAM_MAIN, nm);
-                nm += 1;
-                if (coin * lbound < l_rate) {  // :130
-                    nacc += 1;
-                    if (l_rate > lbound) {  // :132
-                        if (!adapt) {
-                            status = PDMP_CHAIN_BOUND_VIOLATED;
-                            break;
-                        }
-                        nacc = 0;  // acc = num = 0, :134
-                        num = 0;
-                        if (lane == 0) cmut[i] = cvec[i] * P.factor;  // :135
-                    }
-                    move_members(sp0, k, m, tp);  // :138
-                    if (lane == 0) {
-                        sth[self] = -th_i;  // :139
-                        rec[i].th = -th_i;
-                    }
-                    G_ORDER();
-                    reb_count = 0;
-                    rebound(cp0, 0, k, tp, nm, true, false);  // :140-146
-                    nm += reb_count;
-                    requeue(cp0, 0, k, false, 0u);
-                } else {  // :147-151
-                    reb_count = 0;
-                    rebound(cp0, self, self + 1u, tp, nm, true, false);
-                    nm += reb_count;
-                    requeue(cp0, self, self + 1u, false, 0u);
-                    emit = false;
-                }
-            }
-            if (emit) {  // push!(Ξ, event(i, t, x, θ, F)), :154
-                G_ORDER();
-                if (ev && lane == 0) {
-                    const ZzRec* w = rec + i;
-                    pdmp_event e;
-                    e.t = __hip_atomic_load(&w->t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    e.i = (int64_t)i;
-                    e.x = __hip_atomic_load(&w->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    e.theta = __hip_atomic_load(&w->th, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ev[ntrace] = e;
-                }
-                ntrace += 1;
-                nevents += 1;
-                t_event = tp;
-                if (!stop_before && !(tp < T)) running = false;
-            }
-            G_ORDER();
-            continue;
-        }
-        if (P.move_all) {
-            move_everything(tp);
-            stage_members(sp0, 0, k);
-        } else {
-            move_members(sp0, 0, k, tp);  // smove_forward!(G, i, ...), :82
-        }
-        const double ucoin = pdmp_u01(seed, PDMP_STREAM_MAIN, nm);  // thinning coin: its index is known before the gradient is
-        if (local && g_uniform((__hip_atomic_load(rnw + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) ? 1u : 0u)) {
-            // src/local.jl:36-43: the bound of i expired -- renew it from the moved state (one draw), no proposal
-            rebound(cp0, self, self + 1u, tp, nm, false, false);
-            nm += 1;
-            requeue(cp0, self, self + 1u, false, 0u);
-            G_ORDER();
-            continue;
-        }
-        GPHASE(1);
-        // ---------------- gradient
-        double g;
-        double urow = 0.0;
-        if (Q.target_kind == 0) {  // ∇ϕ(x, i) = idot(Γt, i, x) [- idot(Γt, i, μt)]
-            g = 0.0;
-            for (uint32_t p = 0; p < k; ++p) g += P.tb.tval[cp0 + p] * sx[p];
-            if (P.tb.gmu_t) g = g - P.tb.gmu_t[i];
-        } else {
+        // ∇ϕmoving of the subsampled logistic target (SelfMoving: it moves what it reads); needs sx[self] = x[i] at t′
+        auto logistic_gradient = [&]() -> double {
+            double urow = 0.0;
             // ∇ϕmoving = γ0*x[i] - fdot_moving(A, At, i, t, x, θ, t′, F, μ, y, ny, k), scripts/logistic.jl:78-95,107
             const double prior = Q.gamma0 * sx[self];
             double s = 0.0;
@@ -731,7 +595,151 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
                 }
             }
             ng += (uint64_t)Q.ksub;
-            g = prior - s;
+            return prior - s;
+        };
+        if (sticky) {
+            // ---------------- sspdmp_inner!, src/ss_fact.jl:78-157, for neighbourhoods of any size
+            const double x_i0 = ri->x, th_i0 = ri->th;
+            const bool is_freeze = g_uniform(acc_i != 0 ? 1u : 0u) != 0;  // f[i]: rec.acc holds the flag for sticky chains
+            const bool is_thaw = !is_freeze && g_uniform((x_i0 == 0 && th_i0 == 0) ? 1u : 0u) != 0;
+            bool emit = true;
+            if (is_freeze) {  // case 1, :87-107
+                const double dt = tp - ri->t;
+                const double xs = x_i0 + th_i0 * dt;  // smove_forward!(i, ...), :88
+                if (fabs(xs) > 1e-8) {                // :89-91
+                    status = PDMP_CHAIN_BOUND_VIOLATED;
+                    break;
+                }
+                const double knew = tp - pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm)) / P.kappa[i];  // :96
+                nm += 1;
+                if (lane == 0) {
+                    ZzRec* w = rec + i;
+                    w->I = ri->I + dt * ((x_i0 + xs) * 0.5);
+                    w->x = 0.0 * th_i0;  // x[i] = -0*θ[i], :92
+                    w->th = 0.0;         // :93
+                    w->t = tp;
+                    w->t_old = tp;       // :94
+                    w->acc = 0;          // f[i] = false, :95
+                    thf[i] = th_i0;
+                    keys[i] = knew;
+                }
+                G_ORDER();
+                if (!P.strong_upperbounds) {  // :97-107
+                    move_members(sp0, 0, m, tp);  // G and G2, non-frozen only (i is frozen now)
+                    reb_count = 0;
+                    rebound(cp0, 0, k, tp, nm, true, false);
+                    nm += reb_count;
+                    requeue(cp0, 0, k, false, 0u);  // includes i's own block
+                } else {
+                    requeue(cp0, self, self + 1u, false, 0u);
+                }
+            } else if (is_thaw) {  // case 2, :108-123
+                double thn = thf[i];  // θ[i], θf[i] = θf[i], 0.0, :110
+                uint32_t head = 0;
+                if (P.reversible) {  // :111-113
+                    thn *= (pdmp_u01(seed, PDMP_STREAM_MAIN, nm) < 0.5) ? -1.0 : 1.0;
+                    head = 1;
+                }
+                if (lane == 0) {
+                    ZzRec* w = rec + i;
+                    w->t = tp;      // :109
+                    w->th = thn;
+                    w->t_old = tp;  // :114
+                    thf[i] = 0.0;
+                }
+                G_ORDER();
+                move_members(sp0, 0, m, tp);  // :115-116 (i itself: dt = 0)
+                reb_count = 0;
+                rebound(cp0, 0, k, tp, nm + head, true, false);  // :117-123, non-frozen members including i
+                nm += head + reb_count;
+                requeue(cp0, 0, k, false, 0u);
+            } else {  // reflection proposal, :124-152
+                move_members(sp0, 0, k, tp);  // ssmove_forward!(G, i, ...), :125
+                double g = 0.0;
+                if (Q.target_kind == 1) {  // ∇ϕ_(∇ϕ, t, x, θ, i, t′, F, S::SelfMoving, args...), src/sfact.jl:68
+                    g = logistic_gradient();
+                } else {
+                    for (uint32_t p = 0; p < k; ++p) g += P.tb.tval[cp0 + p] * sx[p];
+                    if (P.tb.gmu_t) g = g - P.tb.gmu_t[i];
+                }
+                const double th_i = sth[self];
+                const double l_rate = g_pos(g * th_i);
+                const double lbound = g_pos(a_i + b_i * (tp - told_i));  // :128
+                num += 1;
+                const double coin = pdmp_u01(seed, PDMP_STREAM_MAIN, nm);
+                nm += 1;
+                if (coin * lbound < l_rate) {  // :130
+                    nacc += 1;
+                    if (l_rate > lbound) {  // :132
+                        if (!adapt) {
+                            status = PDMP_CHAIN_BOUND_VIOLATED;
+                            break;
+                        }
+                        nacc = 0;  // acc = num = 0, :134
+                        num = 0;
+                        if (lane == 0) cmut[i] = cvec[i] * P.factor;  // :135
+                    }
+                    move_members(sp0, k, m, tp);  // :138
+                    if (lane == 0) {
+                        sth[self] = -th_i;  // :139
+                        rec[i].th = -th_i;
+                    }
+                    G_ORDER();
+                    reb_count = 0;
+                    rebound(cp0, 0, k, tp, nm, true, false);  // :140-146
+                    nm += reb_count;
+                    requeue(cp0, 0, k, false, 0u);
+                } else {  // :147-151
+                    reb_count = 0;
+                    rebound(cp0, self, self + 1u, tp, nm, true, false);
+                    nm += reb_count;
+                    requeue(cp0, self, self + 1u, false, 0u);
+                    emit = false;
+                }
+            }
+            if (emit) {  // push!(Ξ, event(i, t, x, θ, F)), :154
+                G_ORDER();
+                if (ev && lane == 0) {
+                    const ZzRec* w = rec + i;
+                    pdmp_event e;
+                    e.t = __hip_atomic_load(&w->t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    e.i = (int64_t)i;
+                    e.x = __hip_atomic_load(&w->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    e.theta = __hip_atomic_load(&w->th, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ev[ntrace] = e;
+                }
+                ntrace += 1;
+                nevents += 1;
+                t_event = tp;
+                if (!stop_before && !(tp < T)) running = false;
+            }
+            G_ORDER();
+            continue;
+        }
+        if (P.move_all) {
+            move_everything(tp);
+            stage_members(sp0, 0, k);
+        } else {
+            move_members(sp0, 0, k, tp);  // smove_forward!(G, i, ...), :82
+        }
+        const double ucoin = pdmp_u01(seed, PDMP_STREAM_MAIN, nm);  // thinning coin: its index is known before the gradient is
+        if (local && g_uniform((__hip_atomic_load(rnw + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) ? 1u : 0u)) {
+            // src/local.jl:36-43: the bound of i expired -- renew it from the moved state (one draw), no proposal
+            rebound(cp0, self, self + 1u, tp, nm, false, false);
+            nm += 1;
+            requeue(cp0, self, self + 1u, false, 0u);
+            G_ORDER();
+            continue;
+        }
+        GPHASE(1);
+        // ---------------- gradient
+        double g;
+        if (Q.target_kind == 0) {  // ∇ϕ(x, i) = idot(Γt, i, x) [- idot(Γt, i, μt)]
+            g = 0.0;
+            for (uint32_t p = 0; p < k; ++p) g += P.tb.tval[cp0 + p] * sx[p];
+            if (P.tb.gmu_t) g = g - P.tb.gmu_t[i];
+        } else {
+            g = logistic_gradient();
         }
         GPHASE(2);
         const double th_i = sth[self];
