@@ -97,8 +97,21 @@ size_t zz_general_lds_bytes(uint32_t nblk_pad, uint32_t mmax_pad, bool boom) {
     return (size_t)nblk_pad * 8 + (size_t)(boom ? 3 : 2) * mmax_pad * 8 + (size_t)nblk_pad * 4 + (size_t)2 * G_PCH * 8;
 }
 
-template <bool PROF>
-__global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGeneralParams Q) {
+// LGFAST: instantiation for the plain spdmp + subsampled-logistic configuration (config C4): ZigZag flow, no refresh clock, no
+// G = All(), no LocalBound, no adaptscale, not sticky -- the other modes' branches, scalars and table pointers drop out.
+template <bool PROF, bool LGFAST>
+__global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, ZzGeneralParams Q_in) {
+    ZzRunParams P = P_in;
+    ZzGeneralParams Q = Q_in;
+    if constexpr (LGFAST) {
+        P.move_all = 0;
+        P.has_refresh = 0;
+        Q.local_bound = 0;
+        Q.sticky = 0;
+        Q.flow_kind = 0;
+        Q.adaptscale = 0;
+        Q.target_kind = 1;
+    }
     const int lane = threadIdx.x;
     const int64_t chain = blockIdx.x;
     const int64_t d = P.d;
@@ -816,14 +829,19 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P, ZzGen
 int launch_zz_general_run(const ZzRunParams& p, const ZzGeneralParams& q, int64_t nchains, void* stream) {
     const size_t lds = zz_general_lds_bytes(p.nblk_pad, q.mmax_pad, q.flow_kind == 1);
     const bool prof = p.dbg != nullptr;
-    const void* fn = prof ? reinterpret_cast<const void*>(zz_general_run_kernel<true>)
-                          : reinterpret_cast<const void*>(zz_general_run_kernel<false>);
+    const bool lgfast = !prof && q.target_kind == 1 && !p.move_all && !p.has_refresh && !q.local_bound && !q.sticky &&
+                        q.flow_kind == 0 && !q.adaptscale;
+    const void* fn = prof ? reinterpret_cast<const void*>(zz_general_run_kernel<true, false>)
+                   : lgfast ? reinterpret_cast<const void*>(zz_general_run_kernel<false, true>)
+                            : reinterpret_cast<const void*>(zz_general_run_kernel<false, false>);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    if (prof) hipLaunchKernelGGL(zz_general_run_kernel<true>, dim3((unsigned)nchains), dim3(64), lds, (hipStream_t)stream, p, q);
-    else hipLaunchKernelGGL(zz_general_run_kernel<false>, dim3((unsigned)nchains), dim3(64), lds, (hipStream_t)stream, p, q);
+    const dim3 grid((unsigned)nchains), block(64);
+    if (prof) hipLaunchKernelGGL((zz_general_run_kernel<true, false>), grid, block, lds, (hipStream_t)stream, p, q);
+    else if (lgfast) hipLaunchKernelGGL((zz_general_run_kernel<false, true>), grid, block, lds, (hipStream_t)stream, p, q);
+    else hipLaunchKernelGGL((zz_general_run_kernel<false, false>), grid, block, lds, (hipStream_t)stream, p, q);
     return (int)hipGetLastError();
 }
 
