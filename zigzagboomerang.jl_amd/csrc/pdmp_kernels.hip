@@ -1233,8 +1233,17 @@ __device__ __forceinline__ void spec_patched_min(const double* pk, int gl, uint3
     rowmin = row_min_f64(lm);
 }
 
-template <int NE, bool PROF>
-__global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P) {
+// PLAIN: the configuration of the north-star workload -- adapt = false, target without a mean shift, G2 fetched on accept --
+// as compile-time facts (the per-chain bound array, the Γμ look-up and the eager-G2 path drop out of the instantiation).
+template <int NE, bool PROF, bool PLAIN = false>
+__global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P_in) {
+    ZzRunParams P = P_in;
+    if constexpr (PLAIN) {
+        P.adapt = 0;
+        P.c_chain = nullptr;
+        P.tb.gmu_t = nullptr;
+        P.flags |= 0x100;
+    }
     constexpr int E = 4;
     const int lane = threadIdx.x;
     const int g = lane >> 4;   // group = DPP row = event slot
@@ -2231,7 +2240,9 @@ int launch_zz_local_spec(const ZzRunParams& p, int64_t nchains, void* stream) {
     } else if (ne <= 2) {
         hipLaunchKernelGGL((zz_local_spec_kernel<2, false>), grid, block, lds, (hipStream_t)stream, p);
     } else if (ne <= 5) {
-        hipLaunchKernelGGL((zz_local_spec_kernel<5, false>), grid, block, lds, (hipStream_t)stream, p);
+        const bool plain = !p.adapt && p.c_chain == nullptr && p.tb.gmu_t == nullptr && (p.flags & 0x100);
+        if (plain) hipLaunchKernelGGL((zz_local_spec_kernel<5, false, true>), grid, block, lds, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((zz_local_spec_kernel<5, false>), grid, block, lds, (hipStream_t)stream, p);
     } else {
         hipLaunchKernelGGL((zz_local_spec_kernel<8, false>), grid, block, lds, (hipStream_t)stream, p);
     }
