@@ -1251,7 +1251,9 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P_in) {
     const int64_t chain = blockIdx.x;
     const int64_t d = P.d;
     const uint32_t nblk = P.nblk;
-    const uint32_t W2 = P.blob_w_pad >> 1, SW = P.blob_sw, PW = P.blob_pw, KMAX = P.blob_kmax;
+    // PLAIN also fixes the blob geometry of the 4-neighbour lattice (|G1| <= 5, |S| <= 13): loop bounds and record strides become
+    // immediates
+    const uint32_t W2 = P.blob_w_pad >> 1, SW = PLAIN ? 7u : P.blob_sw, PW = PLAIN ? 1u : P.blob_pw, KMAX = PLAIN ? 5u : P.blob_kmax;
     const uint32_t R_ = 4 + PW + KMAX;
 
     extern __shared__ __align__(16) unsigned char smem[];
@@ -2240,7 +2242,8 @@ int launch_zz_local_spec(const ZzRunParams& p, int64_t nchains, void* stream) {
     } else if (ne <= 2) {
         hipLaunchKernelGGL((zz_local_spec_kernel<2, false>), grid, block, lds, (hipStream_t)stream, p);
     } else if (ne <= 5) {
-        const bool plain = !p.adapt && p.c_chain == nullptr && p.tb.gmu_t == nullptr && (p.flags & 0x100);
+        const bool plain = !p.adapt && p.c_chain == nullptr && p.tb.gmu_t == nullptr && (p.flags & 0x100) && p.blob_sw == 7 &&
+                           p.blob_pw == 1 && p.blob_kmax == 5;
         if (plain) hipLaunchKernelGGL((zz_local_spec_kernel<5, false, true>), grid, block, lds, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((zz_local_spec_kernel<5, false>), grid, block, lds, (hipStream_t)stream, p);
     } else {
