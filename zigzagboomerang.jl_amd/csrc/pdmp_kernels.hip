@@ -1518,10 +1518,10 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P_in) {
             const double gmu = __longlong_as_double((long long)lb[sub + 1]);
             const int kj = (int)(lb[sub + 3] & 0xff);
             double gx = 0.0, gt = 0.0;
-            for (int base = 0; base < kjmax; base += 8) {
+            for (int base = 0; base < (PLAIN ? 1 : kjmax); base += 8) {
                 const uint64_t pw = lb[sub + 4 + (base >> 3)];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
+                for (int q = 0; q < (PLAIN ? 5 : 8); ++q) {
                     const int pp = base + q;
                     if (pp < kj) {
                         const double v = __longlong_as_double((long long)lb[sub + 4 + PW + pp]);
