@@ -1243,6 +1243,7 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P_in) {
         P.c_chain = nullptr;
         P.tb.gmu_t = nullptr;
         P.flags |= 0x100;
+        P.blob_w_pad = 58;  // 1 + SW + KMAX * (4 + PW + KMAX) words of the lattice's blob: LDS offsets become immediates
     }
     constexpr int E = 4;
     const int lane = threadIdx.x;
@@ -2243,7 +2244,7 @@ int launch_zz_local_spec(const ZzRunParams& p, int64_t nchains, void* stream) {
         hipLaunchKernelGGL((zz_local_spec_kernel<2, false>), grid, block, lds, (hipStream_t)stream, p);
     } else if (ne <= 5) {
         const bool plain = !p.adapt && p.c_chain == nullptr && p.tb.gmu_t == nullptr && (p.flags & 0x100) && p.blob_sw == 7 &&
-                           p.blob_pw == 1 && p.blob_kmax == 5;
+                           p.blob_pw == 1 && p.blob_kmax == 5 && p.blob_w_pad == 58;
         if (plain) hipLaunchKernelGGL((zz_local_spec_kernel<5, false, true>), grid, block, lds, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((zz_local_spec_kernel<5, false>), grid, block, lds, (hipStream_t)stream, p);
     } else {
