@@ -1696,8 +1696,19 @@ size_t zz_sticky_spec_lds_bytes(uint32_t nblk_pad, uint32_t blob_w_pad) {
     return (size_t)SPS_LB + (size_t)4 * blob_w_pad * 8 + (size_t)nblk_pad * 8 + (size_t)nblk_pad * 4;
 }
 
-template <int NE>
-__global__ __launch_bounds__(64) void zz_sticky_spec_kernel(ZzRunParams P) {
+// PLAIN: adapt = false, reversible = false, strong_upperbounds = false, target without a mean shift, and the blob geometry of the
+// 4-neighbour lattice (config C5) as compile-time facts
+template <int NE, bool PLAIN = false>
+__global__ __launch_bounds__(64) void zz_sticky_spec_kernel(ZzRunParams P_in) {
+    ZzRunParams P = P_in;
+    if constexpr (PLAIN) {
+        P.adapt = 0;
+        P.c_chain = nullptr;
+        P.tb.gmu_t = nullptr;
+        P.reversible = 0;
+        P.strong_upperbounds = 0;
+        P.blob_w_pad = 58;
+    }
     constexpr int E = 4;
     const int lane = threadIdx.x;
     const int g = lane >> 4;
@@ -1705,7 +1716,7 @@ __global__ __launch_bounds__(64) void zz_sticky_spec_kernel(ZzRunParams P) {
     const int64_t chain = blockIdx.x;
     const int64_t d = P.d;
     const uint32_t nblk = P.nblk;
-    const uint32_t W2 = P.blob_w_pad >> 1, SW = P.blob_sw, PW = P.blob_pw, KMAX = P.blob_kmax;
+    const uint32_t W2 = P.blob_w_pad >> 1, SW = PLAIN ? 7u : P.blob_sw, PW = PLAIN ? 1u : P.blob_pw, KMAX = PLAIN ? 5u : P.blob_kmax;
     const uint32_t R_ = 4 + PW + KMAX;
 
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1975,10 +1986,10 @@ __global__ __launch_bounds__(64) void zz_sticky_spec_kernel(ZzRunParams P) {
             const double gmu = __longlong_as_double((long long)lb[sub + 1]);
             const int kj = (int)(lb[sub + 3] & 0xff);
             double gx = 0.0, gt = 0.0;
-            for (int base = 0; base < kjmax; base += 8) {
+            for (int base = 0; base < (PLAIN ? 1 : kjmax); base += 8) {
                 const uint64_t pw = lb[sub + 4 + (base >> 3)];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
+                for (int q = 0; q < (PLAIN ? 5 : 8); ++q) {
                     const int pp = base + q;
                     if (pp < kj) {
                         const double v = __longlong_as_double((long long)lb[sub + 4 + PW + pp]);
@@ -2262,7 +2273,10 @@ int launch_zz_sticky_spec(const ZzRunParams& p, int64_t nchains, void* stream) {
     } else if (ne <= 2) {
         hipLaunchKernelGGL((zz_sticky_spec_kernel<2>), grid, block, lds, (hipStream_t)stream, p);
     } else if (ne <= 5) {
-        hipLaunchKernelGGL((zz_sticky_spec_kernel<5>), grid, block, lds, (hipStream_t)stream, p);
+        const bool plain = !p.adapt && p.c_chain == nullptr && p.tb.gmu_t == nullptr && !p.reversible && !p.strong_upperbounds &&
+                           p.blob_sw == 7 && p.blob_pw == 1 && p.blob_kmax == 5 && p.blob_w_pad == 58;
+        if (plain) hipLaunchKernelGGL((zz_sticky_spec_kernel<5, true>), grid, block, lds, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((zz_sticky_spec_kernel<5>), grid, block, lds, (hipStream_t)stream, p);
     } else {
         hipLaunchKernelGGL((zz_sticky_spec_kernel<8>), grid, block, lds, (hipStream_t)stream, p);
     }
