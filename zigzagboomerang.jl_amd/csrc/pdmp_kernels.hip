@@ -2256,8 +2256,17 @@ int launch_zz_local_spec(const ZzRunParams& p, int64_t nchains, void* stream) {
     } else if (ne <= 5) {
         const bool plain = !p.adapt && p.c_chain == nullptr && p.tb.gmu_t == nullptr && (p.flags & 0x100) && p.blob_sw == 7 &&
                            p.blob_pw == 1 && p.blob_kmax == 5 && p.blob_w_pad == 58;
-        if (plain) hipLaunchKernelGGL((zz_local_spec_kernel<5, false, true>), grid, block, lds, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((zz_local_spec_kernel<5, false>), grid, block, lds, (hipStream_t)stream, p);
+        // without a refresh clock the last key block holds only the (infinite) refresh slot: when d fills 256 blocks exactly the
+        // queue's first level is scanned as 4 entries per lane instead of 5
+        if (plain && !p.has_refresh && p.d == 256 * 64 && p.nblk == 257) {
+            ZzRunParams q = p;
+            q.nblk = 256;
+            hipLaunchKernelGGL((zz_local_spec_kernel<4, false, true>), grid, block, lds, (hipStream_t)stream, q);
+        } else if (plain) {
+            hipLaunchKernelGGL((zz_local_spec_kernel<5, false, true>), grid, block, lds, (hipStream_t)stream, p);
+        } else {
+            hipLaunchKernelGGL((zz_local_spec_kernel<5, false>), grid, block, lds, (hipStream_t)stream, p);
+        }
     } else {
         hipLaunchKernelGGL((zz_local_spec_kernel<8, false>), grid, block, lds, (hipStream_t)stream, p);
     }
