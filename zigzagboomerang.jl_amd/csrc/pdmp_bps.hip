@@ -94,7 +94,8 @@ __device__ __attribute__((noinline)) double bps_next_dt(uint64_t seed, uint64_t 
     return bps_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, n));
 }
 
-template <int NS, bool DIAG, bool BOOM, bool IDENT>
+// FULL: d == 64 NS exactly, so the `element < d` guards (and their exec-mask bookkeeping) are compile-time true.
+template <int NS, bool DIAG, bool BOOM, bool IDENT, bool FULL = false>
 __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
     const int lane = threadIdx.x;
     const int64_t chain = blockIdx.x;
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const int64_t e = (int64_t)s * 64 + lane;
-        const bool in = e < d;
+        const bool in = FULL || e < d;
         x[s] = in ? gx[e] : 0.0;
         th[s] = in ? gth[e] : 0.0;
         if constexpr (!IDENT) {
@@ -152,14 +153,14 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int64_t e = (int64_t)s * 64 + lane;
-                if (e < d) tmp[e] = sub_mu ? (in[s] - mu[s]) : in[s];
+                if (FULL || e < d) tmp[e] = sub_mu ? (in[s] - mu[s]) : in[s];
             }
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int64_t e = (int64_t)s * 64 + lane;
                 double y = 0.0;
-                if (e < d) {
+                if (FULL || e < d) {
                     for (int64_t p = P.colptr[e]; p < P.colptr[e + 1]; ++p) y += P.nzval[p] * tmp[P.rowval[p]];
                 }
                 out[s] = y;
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int64_t e = (int64_t)s * 64 + lane;
-            if (e < d) part += u[s] * v[s];
+            if (FULL || e < d) part += u[s] * v[s];
         }
         return wave_sum_f64(part);
     };
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int64_t e = (int64_t)s * 64 + lane;
-            dx[s] = (e < d) ? (x[s] - P.mu_flow[e]) : 0.0;
+            dx[s] = (FULL || e < d) ? (x[s] - P.mu_flow[e]) : 0.0;
         }
         return sqrt(dot(th, th) + dot(dx, dx)) * c;
     };
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int64_t e = (int64_t)s * 64 + lane;
-                const double m = (e < d) ? P.mu_flow[e] : 0.0;
+                const double m = (FULL || e < d) ? P.mu_flow[e] : 0.0;
                 const double xn = (x[s] - m) * cs + th[s] * sn + m;
                 const double tn = -(x[s] - m) * sn + th[s] * cs;
                 x[s] = xn;
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     const int64_t e = (int64_t)s * 64 + lane;
-                    if (e < d) g[s] -= x[s] - P.mu_flow[e];
+                    if (FULL || e < d) g[s] -= x[s] - P.mu_flow[e];
                 }
             }
         }
@@ -261,14 +262,14 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
 #pragma unroll 1
             for (int s = 0; s < NS; ++s) {
                 const int64_t e = (int64_t)s * 64 + lane;
-                if (e < d) tmp[e] = pdmp_randn(seed, PDMP_STREAM_MAIN, nm + (uint64_t)e);
+                if (FULL || e < d) tmp[e] = pdmp_randn(seed, PDMP_STREAM_MAIN, nm + (uint64_t)e);
             }
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int64_t e = (int64_t)s * 64 + lane;
                 th[s] *= rho;
-                if (e < d) th[s] += rhobar * tmp[e];
+                if (FULL || e < d) th[s] += rhobar * tmp[e];
             }
             nm += (uint64_t)d;
             gradient();                                                                                    // :58-59
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     const int64_t e = (int64_t)s * 64 + lane;
-                    if (e < d) {
+                    if (FULL || e < d) {
                         ex[e] = x[s];
                         eth[e] = th[s];
                     }
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const int64_t e = (int64_t)s * 64 + lane;
-        if (e < d) {
+        if (FULL || e < d) {
             gx[e] = x[s];
             gth[e] = th[s];
         }
@@ -471,6 +472,8 @@ static int launch_ns(const BpsRunParams& p, int64_t nchains, bool diag, bool ini
     } else if (boom) {
         if (diag) hipLaunchKernelGGL((bps_run_kernel<NS, true, true, false>), grid, block, lds, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((bps_run_kernel<NS, false, true, false>), grid, block, lds, (hipStream_t)stream, p);
+    } else if (diag && p.ident && p.d == (int64_t)NS * 64) {
+        hipLaunchKernelGGL((bps_run_kernel<NS, true, false, true, true>), grid, block, lds, (hipStream_t)stream, p);
     } else if (diag && p.ident) {
         hipLaunchKernelGGL((bps_run_kernel<NS, true, false, true>), grid, block, lds, (hipStream_t)stream, p);
     } else if (diag) {
