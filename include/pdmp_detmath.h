@@ -13,6 +13,7 @@
  *   pdmp_exp             exp, < 1 ulp, only + - * / on doubles (logistic targets)
  *   pdmp_randexp         -log(u)                       (replaces Random.randexp, src/poissontime.jl:77)
  *   pdmp_randn           Box-Muller normal             (replaces Random.randn,   src/dynamics.jl:115)
+ *   pdmp_randn2          both Box-Muller branches of one block (the d-vector refresh of the non-factorised samplers)
  *
  * Everything else (poisson_time, ab, the event loop) is restated INDEPENDENTLY in oracle/ and in the
  * HIP kernels, so that a transcription error on one side shows up as a parity failure.
@@ -289,6 +290,19 @@ PDMP_HD double pdmp_randn(uint64_t seed, uint32_t stream, uint64_t n) {
     double u1 = pdmp_bits_to_u01(((uint64_t)r.v[0] << 32) | (uint64_t)r.v[1]);
     double u2 = pdmp_bits_to_u01(((uint64_t)r.v[2] << 32) | (uint64_t)r.v[3]);
     return pdmp_randn_from_u(u1, u2);
+}
+
+/* Both Box-Muller branches of block #n: z0 = r cos 2πu2, z1 = r sin 2πu2 (two independent standard normals per Philox block). */
+PDMP_HD void pdmp_randn2(uint64_t seed, uint32_t stream, uint64_t n, double* z0, double* z1) {
+    pdmp_u32x4 r = pdmp_philox4x32_10((uint32_t)n, (uint32_t)(n >> 32), stream, 0u, (uint32_t)seed,
+                                      (uint32_t)(seed >> 32));
+    double u1 = pdmp_bits_to_u01(((uint64_t)r.v[0] << 32) | (uint64_t)r.v[1]);
+    double u2 = pdmp_bits_to_u01(((uint64_t)r.v[2] << 32) | (uint64_t)r.v[3]);
+    double rad = PDMP_SQRT(-2.0 * pdmp_log(u1));
+    double s, c;
+    pdmp_sincos2pi(u2, &s, &c);
+    *z0 = rad * c;
+    *z1 = rad * s;
 }
 
 #endif /* PDMP_DETMATH_H */

@@ -796,8 +796,17 @@ int orc_pdmp_bps(int64_t d, const orc_bps_params* p, double t0, double T, double
                 t += tau; /* move_forward!, :56 */
                 nf_move(p, d, tau, x, th);
                 /* refresh!, src/dynamics.jl:112-126 with L = I:  θ .*= ρ; θ .+= ρ̄*randn(rng,d) */
+                /* randn(rng, d): the reference draws d normals from its stream; here the d-vector comes from ⌈d/128⌉·64 Philox
+                 * blocks, both Box-Muller branches of a block in use: element k = 128a + 64b + l (l < 64, b ∈ {0,1}) is branch b
+                 * (cos, sin) of block nm + 64a + l -- the layout in which a 64-lane wavefront holds two elements per lane pair of
+                 * slots, so that one Philox / log / sqrt / sincos evaluation yields two of its normals */
                 for (int64_t k = 0; k < d; ++k) th[k] *= rho;
-                for (int64_t k = 0; k < d; ++k) th[k] += rhobar * pdmp_randn(seed, PDMP_STREAM_MAIN, nm++);
+                for (int64_t k = 0; k < d; ++k) {
+                    double z0, z1;
+                    pdmp_randn2(seed, PDMP_STREAM_MAIN, nm + (uint64_t)(((k >> 7) << 6) + (k & 63)), &z0, &z1);
+                    th[k] += rhobar * (((k >> 6) & 1) ? z1 : z0);
+                }
+                nm += (uint64_t)(((d + 127) >> 7) << 6);
                 nf_grad(p, d, x, tmp, g);                                                     /* :58-59 */
                 tau_ref = t + (-pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)) / p->lambda_ref); /* :61 */
                 nf_ab(p, d, c, x, th, g, tmp, gth, &a, &b);                                   /* :62 */

@@ -258,11 +258,15 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
             // The d normals go through LDS: a ROLLED loop holds one Box-Muller body (its constants and temporaries are live only
             // here, next to x and θ), the unrolled update then reads them back -- 16 inlined bodies, or a call, cost ~40 VGPRs
             // across the whole event loop (161 -> 123 at NS = 16: 3 -> 4 waves per SIMD).
+            // (element 128a + 64b + lane is Box-Muller branch b of block nm + 64a + lane: one evaluation serves two slots)
             asm volatile("" ::: "memory");
 #pragma unroll 1
-            for (int s = 0; s < NS; ++s) {
-                const int64_t e = (int64_t)s * 64 + lane;
-                if (FULL || e < d) tmp[e] = pdmp_randn(seed, PDMP_STREAM_MAIN, nm + (uint64_t)e);
+            for (int a2 = 0; a2 < (NS + 1) / 2; ++a2) {
+                const int64_t e0 = (int64_t)a2 * 128 + lane, e1 = e0 + 64;
+                double z0, z1;
+                pdmp_randn2(seed, PDMP_STREAM_MAIN, nm + (uint64_t)(a2 * 64 + lane), &z0, &z1);
+                if (FULL || e0 < d) tmp[e0] = z0;
+                if (FULL || e1 < d) tmp[e1] = z1;
             }
             asm volatile("" ::: "memory");
 #pragma unroll
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
                 th[s] *= rho;
                 if (FULL || e < d) th[s] += rhobar * tmp[e];
             }
-            nm += (uint64_t)d;
+            nm += (uint64_t)(((d + 127) >> 7) << 6);
             gradient();                                                                                    // :58-59
             tau_ref = t + (-pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm)) / P.lambda_ref);                  // :61
             nm += 1;
