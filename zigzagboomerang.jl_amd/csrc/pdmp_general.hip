@@ -104,6 +104,7 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
     ZzRunParams P = P_in;
     ZzGeneralParams Q = Q_in;
     if constexpr (LGFAST) {
+        Q.ksub = 10;  // k = 10 sampled observations per gradient (scripts/logistic.jl:167): one batch, fixed trip counts
         P.move_all = 0;
         P.has_refresh = 0;
         Q.local_bound = 0;
@@ -829,7 +830,7 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
 int launch_zz_general_run(const ZzRunParams& p, const ZzGeneralParams& q, int64_t nchains, void* stream) {
     const size_t lds = zz_general_lds_bytes(p.nblk_pad, q.mmax_pad, q.flow_kind == 1);
     const bool prof = p.dbg != nullptr;
-    const bool lgfast = !prof && q.target_kind == 1 && !p.move_all && !p.has_refresh && !q.local_bound && !q.sticky &&
+    const bool lgfast = !prof && q.target_kind == 1 && q.ksub == 10 && !p.move_all && !p.has_refresh && !q.local_bound && !q.sticky &&
                         q.flow_kind == 0 && !q.adaptscale;
     const void* fn = prof ? reinterpret_cast<const void*>(zz_general_run_kernel<true, false>)
                    : lgfast ? reinterpret_cast<const void*>(zz_general_run_kernel<false, true>)
