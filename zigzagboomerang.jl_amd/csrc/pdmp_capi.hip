@@ -121,6 +121,7 @@ struct pdmp_ensemble {
     DevBuf<double> d_kappa, d_thf;
     bool has_kappa = false;
     bool adaptscale = false;
+    int64_t lg_nemax = 0;
     bool local_bound = false;
     DevBuf<double> d_qtval;
     DevBuf<double> d_sig_chain;
@@ -626,6 +627,8 @@ extern "C" pdmp_status pdmp_ensemble_set_target_logistic(pdmp_ensemble* e, int64
     e->has_tmu = false;
     e->lg_gamma0 = gamma0;
     e->lg_k = k_sub;
+    e->lg_nemax = 0;
+    for (int64_t r = 0; r < n; ++r) e->lg_nemax = std::max<int64_t>(e->lg_nemax, At_colptr[r + 1] - At_colptr[r]);
     e->target_kind = 1;
     e->has_target = true;
     e->has_state = false;
@@ -873,6 +876,7 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         Q.ns0 = e->lg_ns0.p;
         Q.gamma0 = e->lg_gamma0;
         Q.ksub = e->lg_k;
+        Q.lg_ne_max = (int32_t)std::min<int64_t>(e->lg_nemax, 1 << 30);
         Q.flow_kind = e->flow_kind;
         Q.mu = e->d_mu.p;
         Q.diag = e->d_diag.p;

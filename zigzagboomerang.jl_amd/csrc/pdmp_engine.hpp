@@ -137,6 +137,7 @@ struct ZzGeneralParams {
     const double* __restrict__ ns0;          // nsigmoid(idot(At, row, μ))
     double gamma0;
     int64_t ksub;
+    int32_t lg_ne_max;  // most regressors of any observation (max column length of A')
     int32_t sticky;  // sspdmp (src/ss_fact.jl) on this kernel: rec.acc is the freeze flag f[i], P.thf / P.kappa are in use
     // flow_kind 1: FactBoomerang (src/types.jl:71-79)
     int32_t flow_kind;

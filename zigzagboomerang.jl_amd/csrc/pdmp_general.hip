@@ -554,15 +554,16 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
                 const int64_t e0 = Q.At_colptr[row];
                 const int ne = qa ? (int)(Q.At_colptr[row + 1] - e0) : 0;
                 const double yr = Q.y[row], nyr = Q.ny[row], sn0 = Q.sn0[row], ns0 = Q.ns0[row];
-                int incl = ne;  // inclusive scan of the row lengths over the lanes
-                for (int off = 1; off < 64; off <<= 1) {
+                int incl = ne;  // inclusive scan of the row lengths over the lanes (LGFAST: only lanes 0..9 carry rows)
+                for (int off = 1; off < (LGFAST ? 16 : 64); off <<= 1) {
                     const int o = __shfl_up(incl, off, 64);
                     if (lane >= off) incl += o;
                 }
-                const int etot = __builtin_amdgcn_readlane(incl, 63);
+                const int etot = __builtin_amdgcn_readlane(incl, LGFAST ? 15 : 63);
                 const int excl = incl - ne;
                 // idot_moving!(At, row, t, x, θ, t′, F), src/common.jl:33-42: move the rows' coordinates; products to LDS
-                for (int fb = 0; fb < etot; fb += 64) {
+                // (LGFAST: every observation has at most 6 regressors, so the 10 rows always fit one 64-entry chunk)
+                for (int fb = 0; fb < (LGFAST ? ((etot > 0) ? 1 : 0) : etot); fb += 64) {
                     const int f = fb + lane;
                     int q = 0;
                     for (int z = 0; z < nq; ++z) q += (__builtin_amdgcn_readlane(incl, z) <= f) ? 1 : 0;
@@ -830,7 +831,7 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
 int launch_zz_general_run(const ZzRunParams& p, const ZzGeneralParams& q, int64_t nchains, void* stream) {
     const size_t lds = zz_general_lds_bytes(p.nblk_pad, q.mmax_pad, q.flow_kind == 1);
     const bool prof = p.dbg != nullptr;
-    const bool lgfast = !prof && q.target_kind == 1 && q.ksub == 10 && !p.move_all && !p.has_refresh && !q.local_bound && !q.sticky &&
+    const bool lgfast = !prof && q.target_kind == 1 && q.ksub == 10 && q.lg_ne_max <= 6 && !p.move_all && !p.has_refresh && !q.local_bound && !q.sticky &&
                         q.flow_kind == 0 && !q.adaptscale;
     const void* fn = prof ? reinterpret_cast<const void*>(zz_general_run_kernel<true, false>)
                    : lgfast ? reinterpret_cast<const void*>(zz_general_run_kernel<false, true>)
