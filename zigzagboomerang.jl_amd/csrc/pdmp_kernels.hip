@@ -1191,9 +1191,35 @@ __device__ __forceinline__ int spec_select(const double* bk, uint32_t nblk, int 
 }
 
 // Zone conflicts with earlier groups (exact: compare member ids through LDS): does this lane's member id occur in the zone of
-// a group q < g?
+// a group q < g?  A cheap necessary condition runs first -- the id must lie inside the [min, max] id span of an earlier group's
+// zone (two u32 row reductions, six scalar reads) -- and only if some lane of the wave passes it (about one iteration in three
+// on the 128 x 128 lattice) are the 48 id comparisons made.
+template <int CTRL>
+__device__ __forceinline__ uint32_t zone_dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true);
+}
 template <int E>
 __device__ __forceinline__ bool spec_zone_conflict(const uint32_t* Z, uint32_t s, int g, bool member) {
+    uint32_t lo = member ? s : 0xffffffffu, hi = member ? s : 0u;
+    {
+        uint32_t o;
+        o = zone_dpp_u32<0xB1>(lo);   lo = (o < lo) ? o : lo;
+        o = zone_dpp_u32<0x4E>(lo);   lo = (o < lo) ? o : lo;
+        o = zone_dpp_u32<0x141>(lo);  lo = (o < lo) ? o : lo;
+        o = zone_dpp_u32<0x140>(lo);  lo = (o < lo) ? o : lo;
+        o = zone_dpp_u32<0xB1>(hi);   hi = (o > hi) ? o : hi;
+        o = zone_dpp_u32<0x4E>(hi);   hi = (o > hi) ? o : hi;
+        o = zone_dpp_u32<0x141>(hi);  hi = (o > hi) ? o : hi;
+        o = zone_dpp_u32<0x140>(hi);  hi = (o > hi) ? o : hi;
+    }
+    bool maybe = false;
+#pragma unroll
+    for (int q = 0; q < E - 1; ++q) {
+        const uint32_t lq = readlane_u32(lo, 16 * q), hq = readlane_u32(hi, 16 * q);
+        maybe = maybe || ((q < g) && s >= lq && s <= hq);
+    }
+    maybe = maybe && member;
+    if (__ballot(maybe) == 0) return false;
     const uint2* Z2 = reinterpret_cast<const uint2*>(Z);
     bool myconf = false;
 #pragma unroll
