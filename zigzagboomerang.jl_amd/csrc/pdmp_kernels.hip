@@ -52,19 +52,26 @@ __device__ __forceinline__ double dpp_f64(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// One v_min_f64.  Written as the instruction itself: fmin() of a value that came out of a load or a DPP move is preceded by a
+// canonicalising v_max_f64 x, x per operand (IEEE-mode minnum lowering), i.e. three DP instructions per minimum in the queue
+// reductions.  Keys are never NaN unless a chain has diverged; v_min_f64 then returns the other operand (NaN loses, as +Inf).
 __device__ __forceinline__ double min_f64(double a, double b) {
-    return __builtin_fmin(a, b);  // v_min_f64; keys are never NaN unless a chain has diverged (NaN loses: treated as +Inf)
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
-// Minimum over the 64 lanes, returned wave-uniform.  4 DPP steps inside each row of 16 lanes
-// (quad xor-1, quad xor-2, half-row mirror, row mirror), then the 4 row minima through SGPRs.
+// Minimum over the 64 lanes, returned wave-uniform.  4 DPP steps inside each row of 16 lanes (quad xor-1, quad xor-2, half-row
+// mirror, row mirror), then row_bcast:15 (row r takes lane 15 of row r-1) and row_bcast:31 (rows 2, 3 take lane 31): lane 63 ends
+// with the minimum of the four rows.  Lanes that have no source read 0 and hold garbage afterwards; only lane 63 is read.
 __device__ __forceinline__ double wave_min_f64(double v) {
     v = min_f64(v, dpp_f64<0xB1>(v));   // quad_perm [1,0,3,2]
     v = min_f64(v, dpp_f64<0x4E>(v));   // quad_perm [2,3,0,1]
     v = min_f64(v, dpp_f64<0x141>(v));  // row_half_mirror
     v = min_f64(v, dpp_f64<0x140>(v));  // row_mirror
-    double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16), r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
-    return min_f64(min_f64(r0, r1), min_f64(r2, r3));
+    v = min_f64(v, dpp_f64<0x142>(v));  // row_bcast:15
+    v = min_f64(v, dpp_f64<0x143>(v));  // row_bcast:31
+    return readlane_f64(v, 63);
 }
 
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
