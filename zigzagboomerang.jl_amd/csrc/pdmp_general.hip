@@ -39,13 +39,21 @@ __device__ __forceinline__ double g_dpp(double v) {
     hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
+// one v_min_f64 (fmin() would canonicalise each loaded / DPP-moved operand with a v_max_f64 x, x first); NaN loses
+__device__ __forceinline__ double g_min(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// row steps, then row_bcast:15 / row_bcast:31: lane 63 holds the minimum of the wave (the other lanes garbage)
 __device__ __forceinline__ double g_wave_min(double v) {
-    v = __builtin_fmin(v, g_dpp<0xB1>(v));
-    v = __builtin_fmin(v, g_dpp<0x4E>(v));
-    v = __builtin_fmin(v, g_dpp<0x141>(v));
-    v = __builtin_fmin(v, g_dpp<0x140>(v));
-    const double r0 = g_readlane(v, 0), r1 = g_readlane(v, 16), r2 = g_readlane(v, 32), r3 = g_readlane(v, 48);
-    return __builtin_fmin(__builtin_fmin(r0, r1), __builtin_fmin(r2, r3));
+    v = g_min(v, g_dpp<0xB1>(v));
+    v = g_min(v, g_dpp<0x4E>(v));
+    v = g_min(v, g_dpp<0x141>(v));
+    v = g_min(v, g_dpp<0x140>(v));
+    v = g_min(v, g_dpp<0x142>(v));
+    v = g_min(v, g_dpp<0x143>(v));
+    return g_readlane(v, 63);
 }
 __device__ __forceinline__ double g_pos(double x) {
     return (x > 0.0) ? x : ((x != x) ? x : 0.0);
@@ -71,20 +79,16 @@ __device__ __forceinline__ double g_poisson_time(double a, double b, double u) {
 // the same with L = log(u) already taken (the draw's index is known before the bound is: Philox and the logarithm run while
 // the dot products' operands are still on their way)
 __device__ __forceinline__ double g_poisson_time_L(double a, double b, double L) {
-    if (b > 0) {
-        const double r = a / b;
-        if (a < 0) return sqrt(-L * 2.0 / b) - r;
-        return sqrt(r * r - L * 2.0 / b) - r;
-    } else if (b == 0) {
-        return (a > 0) ? (-L / a) : G_INF;
-    } else {
-        if (a <= 0) return G_INF;
-        if (-L <= -(a * a) / b + (a * a) / (2 * b)) {
-            const double r = a / b;
-            return -sqrt(r * r - L * 2.0 / b) - r;
-        }
-        return G_INF;
-    }
+    // the b != 0 formulas share a / b, L * 2 / b and the square root (sqrt(-L * 2.0 / b) == sqrt(-(L * 2.0 / b)) bit for bit):
+    // lanes that disagree on the signs of a and b run one division pair and one square root, not one set per branch
+    if (b == 0) return (a > 0) ? (-L / a) : G_INF;
+    const double r = a / b;
+    const double q = L * 2.0 / b;
+    const double sq = sqrt((b > 0 && a < 0) ? -q : r * r - q);
+    if (b > 0) return sq - r;
+    if (a <= 0) return G_INF;
+    if (-L <= -(a * a) / b + (a * a) / (2 * b)) return -sq - r;
+    return G_INF;
 }
 // sigmoid(x) = inv(one(x) + exp(-x)), scripts/logistic.jl:33
 __device__ __forceinline__ double g_sigmoid(double x) {

@@ -60,6 +60,11 @@ __device__ __forceinline__ double min_f64(double a, double b) {
     asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+__device__ __forceinline__ double max_f64(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 // Minimum over the 64 lanes, returned wave-uniform.  4 DPP steps inside each row of 16 lanes (quad xor-1, quad xor-2, half-row
 // mirror, row mirror), then row_bcast:15 (row r takes lane 15 of row r-1) and row_bcast:31 (rows 2, 3 take lane 31): lane 63 ends
@@ -250,29 +255,17 @@ size_t zz_local_lds_bytes(uint32_t nblk_pad, uint32_t blob_w_pad) {
 
 // poisson_time(a, b, u) with L = log(u) supplied (src/poissontime.jl:8-30)
 __device__ __forceinline__ double dev_poisson_time_L(double a, double b, double L) {
-    if (b > 0) {
-        const double r = a / b;
-        if (a < 0) {
-            return sqrt(-L * 2.0 / b) - r;
-        } else {
-            return sqrt(r * r - L * 2.0 / b) - r;
-        }
-    } else if (b == 0) {
-        if (a > 0) {
-            return -L / a;
-        } else {
-            return PDMP_INF;
-        }
-    } else {
-        if (a <= 0) {
-            return PDMP_INF;
-        } else if (-L <= -(a * a) / b + (a * a) / (2 * b)) {
-            const double r = a / b;
-            return -sqrt(r * r - L * 2.0 / b) - r;
-        } else {
-            return PDMP_INF;
-        }
-    }
+    // The three b != 0 formulas share a / b, L * 2 / b and the square root (sqrt(-L * 2.0 / b) is sqrt(-(L * 2.0 / b)) bit for
+    // bit), so a wavefront whose lanes disagree on the signs of a and b runs ONE division pair and ONE square root instead of
+    // one set per branch; only the admissibility test of the b < 0 branch keeps its own two divisions.
+    if (b == 0) return (a > 0) ? -L / a : PDMP_INF;
+    const double r = a / b;
+    const double q = L * 2.0 / b;
+    const double sq = sqrt((b > 0 && a < 0) ? -q : r * r - q);
+    if (b > 0) return sq - r;
+    if (a <= 0) return PDMP_INF;
+    if (-L <= -(a * a) / b + (a * a) / (2 * b)) return -sq - r;
+    return PDMP_INF;
 }
 
 // Cross-lane hand-off through LDS inside ONE wavefront: DS operations execute in issue order, so no s_barrier
@@ -1159,19 +1152,29 @@ __device__ __forceinline__ double row_min_f64(double v) {
 // second best.  A lane offers only ONE entry per iteration, so the candidates are the E smallest entries only if no lane holds
 // two of them -- the lane's second best therefore enters the validation bound of every later event, which keeps the commit rule
 // exact.  Winners publish (key, second best, block) straight into the LDS slots.  Returns the number selected.
-template <int NE, int E>
+// FULLQ: the first level has exactly 4 * 64 entries (the launcher's promise for the 128 x 128 lattice): no bounds predicate, and
+// (best, second best, argmin) of the lane's four entries come out of a 5-comparator network instead of a compare-select chain.
+template <int NE, int E, bool FULLQ = false>
 __device__ __forceinline__ int spec_select(const double* bk, uint32_t nblk, int lane, bool stop_before, double T, double* SLT,
                                            double* SLH, uint32_t* SLB, bool& first_inf) {
     double best = PDMP_INF, second = PDMP_INF;
     uint32_t bestb = 0;
+    if constexpr (FULLQ && NE == 4) {
+        const double k0 = bk[lane], k1 = bk[lane + 64], k2 = bk[lane + 128], k3 = bk[lane + 192];
+        const double m01 = min_f64(k0, k1), x01 = max_f64(k0, k1), m23 = min_f64(k2, k3), x23 = max_f64(k2, k3);
+        best = min_f64(m01, m23);
+        second = min_f64(max_f64(m01, m23), min_f64(x01, x23));
+        bestb = (uint32_t)lane + ((k0 == best) ? 0u : (k1 == best) ? 64u : (k2 == best) ? 128u : 192u);  // lowest block on ties
+    } else {
 #pragma unroll
-    for (int q = 0; q < NE; ++q) {
-        const uint32_t b = (uint32_t)lane + 64u * q;
-        const double v = (b < nblk) ? bk[b] : PDMP_INF;
-        const bool lt = v < best;
-        second = min_f64(second, lt ? best : v);
-        bestb = lt ? b : bestb;
-        best = lt ? v : best;
+        for (int q = 0; q < NE; ++q) {
+            const uint32_t b = (uint32_t)lane + 64u * q;
+            const double v = (b < nblk) ? bk[b] : PDMP_INF;
+            const bool lt = v < best;
+            second = min_f64(second, lt ? best : v);
+            bestb = lt ? b : bestb;
+            best = lt ? v : best;
+        }
     }
     int Esel = 0;
     first_inf = false;
@@ -1370,7 +1373,7 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P_in) {
         }
         // ---------------- select up to E candidate events (spec_select)
         bool first_inf;
-        const int Esel = spec_select<NE, E>(bk, nblk, lane, stop_before, T, SLT, SLH, SLB, first_inf);
+        const int Esel = spec_select<NE, E, PLAIN && NE == 4>(bk, nblk, lane, stop_before, T, SLT, SLH, SLB, first_inf);
         if (Esel == 0) {
             if (first_inf) status = PDMP_CHAIN_STALLED;
             break;
