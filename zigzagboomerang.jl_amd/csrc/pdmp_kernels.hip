@@ -2283,18 +2283,25 @@ int launch_zz_local_spec(const ZzRunParams& p, int64_t nchains, void* stream) {
     const size_t lds = zz_spec_lds_bytes(p.nblk_pad, p.blob_w_pad);
     const int ne = (int)((p.nblk + 63) / 64);
     dim3 grid((unsigned)nchains), block(64);
+    const bool plain = !p.adapt && p.c_chain == nullptr && p.tb.gmu_t == nullptr && (p.flags & 0x100) && p.blob_sw == 7 &&
+                       p.blob_pw == 1 && p.blob_kmax == 5 && p.blob_w_pad == 58;
+    // without a refresh clock the last key block holds only the (infinite) refresh slot: when d fills 256 blocks exactly the
+    // queue's first level is scanned as 4 entries per lane instead of 5
+    const bool plain4 = plain && !p.has_refresh && p.d == 256 * 64 && p.nblk == 257;
     if (p.dbg) {  // per-phase cycle profile (PDMP_PHASE env)
-        hipLaunchKernelGGL((zz_local_spec_kernel<8, true>), grid, block, lds, (hipStream_t)stream, p);
+        if (plain4) {
+            ZzRunParams q = p;
+            q.nblk = 256;
+            hipLaunchKernelGGL((zz_local_spec_kernel<4, true, true>), grid, block, lds, (hipStream_t)stream, q);
+        } else {
+            hipLaunchKernelGGL((zz_local_spec_kernel<8, true>), grid, block, lds, (hipStream_t)stream, p);
+        }
     } else if (ne <= 1) {
         hipLaunchKernelGGL((zz_local_spec_kernel<1, false>), grid, block, lds, (hipStream_t)stream, p);
     } else if (ne <= 2) {
         hipLaunchKernelGGL((zz_local_spec_kernel<2, false>), grid, block, lds, (hipStream_t)stream, p);
     } else if (ne <= 5) {
-        const bool plain = !p.adapt && p.c_chain == nullptr && p.tb.gmu_t == nullptr && (p.flags & 0x100) && p.blob_sw == 7 &&
-                           p.blob_pw == 1 && p.blob_kmax == 5 && p.blob_w_pad == 58;
-        // without a refresh clock the last key block holds only the (infinite) refresh slot: when d fills 256 blocks exactly the
-        // queue's first level is scanned as 4 entries per lane instead of 5
-        if (plain && !p.has_refresh && p.d == 256 * 64 && p.nblk == 257) {
+        if (plain4) {
             ZzRunParams q = p;
             q.nblk = 256;
             hipLaunchKernelGGL((zz_local_spec_kernel<4, false, true>), grid, block, lds, (hipStream_t)stream, q);
