@@ -94,6 +94,7 @@ struct pdmp_ensemble {
     DevBuf<uint64_t> d_blob;
     DevBuf<uint32_t> d_tix;
     size_t n_templates = 0;
+    uint32_t common_tix = 0;
 
     // device tables
     DevBuf<uint32_t> d_colptr, d_rowval, d_sptr, d_sidx, d_qptr;
@@ -564,6 +565,9 @@ static pdmp_status build_blob(pdmp_ensemble* e, const double* c) {
             }
         }
         e->n_templates = seen.size();
+        std::vector<int64_t> cnt(seen.size(), 0);
+        for (int64_t i = 0; i < d; ++i) cnt[tix[i]] += 1;
+        e->common_tix = (uint32_t)(std::max_element(cnt.begin(), cnt.end()) - cnt.begin());
     }
     blob.swap(templates);
     pdmp_status stt = e->d_tix.upload(tix);
@@ -804,6 +808,7 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
     P.c_chain = e->cfg.adapt ? e->d_c_chain.p : nullptr;
     P.blob = e->d_blob.p;
     P.tix = e->d_tix.p;
+    P.common_tix = e->common_tix;
     DevBuf<double> dbgbuf;
     const char* dbgenv = getenv("PDMP_DEBUG");
     const int64_t dbg_cap = dbgenv ? atoll(dbgenv) : 0;

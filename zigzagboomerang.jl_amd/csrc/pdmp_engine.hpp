@@ -75,6 +75,7 @@ struct ZzRunParams {
     const uint64_t* __restrict__ blob;  // [ntemplates x blob_w_pad] neighbourhood programs (layout: pdmp_capi.hip build_blob)
     const uint32_t* __restrict__ tix;   // [d] template of coordinate i (coordinates with the same relative program share one)
     uint32_t blob_w, blob_w_pad, blob_sw, blob_pw, blob_kmax;
+    uint32_t common_tix;  // the template most coordinates share (kept in LDS for a whole launch by the 8-event kernel)
     int64_t d;
     int64_t dk;        // padded key count per chain (multiple of 64)
     int64_t trace_cap;

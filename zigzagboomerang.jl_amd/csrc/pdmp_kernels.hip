@@ -17,6 +17,8 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
 
 #include "../../include/pdmp_detmath.h"
 #include "pdmp_engine.hpp"
@@ -1707,6 +1709,604 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P_in) {
     }
 }
 
+// ------------------------------------------------------------------------------------------ 8 events per iteration
+//
+// zz_local_spec_kernel's scheme with EIGHT event slots per iteration, one per 8-lane group, for the north-star workload (the
+// PLAIN configuration on the 128 x 128 lattice: |G1| <= 5 <= 8 lanes, |S| <= 13 <= 16 = two zone members per lane).  The
+// instruction stream of an iteration -- selection, loads, accept chain, validation, commit -- is issued once for eight events
+// instead of four, which is what the kernel is short of (instruction issue and dependent latency, not bandwidth).  What changes:
+//   select    every lane keeps its four first-level entries SORTED and may win several rounds, so the eight candidates are
+//             exactly the eight smallest block minima (no hidden second-best to carry into the validation bound)
+//   templates slot 0 of the LDS blob area holds the lattice's common template for the whole launch; the (border) events of an
+//             iteration that need another one share two spare slots, a third such event ends the iteration's candidate list
+//   members   lane gl of a group owns zone positions gl and gl + 8; positions >= 8 are always G2-only (k <= 5), so their
+//             records are touched on accept only
+//   accept    every lane evaluates the thinning test of every event for the draw offset equal to its lane number; the ballots
+//             are walked on the scalar unit (offset of event r+1 = offset of r + 2 or 1 + k_r), no dependent LDS round trips
+//   LDS       sx/sth and the zone ids live inside the patched-key area (dead until the re-bound has read them): 10 032 bytes
+//             per chain, 16 chains per CU.
+// Validation and commit rules are unchanged, so the committed sequence is bit-identical to the other kernels and the oracle.
+constexpr uint32_t S8_U = 0;        // [64] f64
+constexpr uint32_t S8_LU = 512;     // [64] f64
+constexpr uint32_t S8_PK = 1024;    // [8][64] f64 patched key blocks
+constexpr uint32_t S8_SX = S8_PK;           // [8][16] f64   (aliases PK)
+constexpr uint32_t S8_STH = S8_PK + 1024;   // [8][16] f64   (aliases PK)
+constexpr uint32_t S8_Z = S8_PK + 2048;     // [8][16] u32   (aliases PK)
+constexpr uint32_t S8_SLT = 5120;   // [8] f64 candidate keys
+constexpr uint32_t S8_LR = 5184;    // [8] f64 true rates
+constexpr uint32_t S8_LBR = 5248;   // [8] f64 bounds
+constexpr uint32_t S8_MR = 5312;    // [8] f64 what each event exposes
+constexpr uint32_t S8_SLB = 5376;   // [8] u32 candidate blocks
+constexpr uint32_t S8_OFR = 5408;   // [16] u32 draw offsets after 0..8 events
+constexpr uint32_t S8_LB = 5472;    // [3][58] u64 blob slots
+constexpr uint32_t S8_BK = S8_LB + 3 * 58 * 8;  // [256] f64
+constexpr uint32_t S8_BI = S8_BK + 256 * 8;     // [256] u32
+constexpr uint32_t S8_BYTES = S8_BI + 256 * 4;  // 9936
+
+size_t zz_spec8_lds_bytes() { return S8_BYTES; }
+
+// minimum over the 8 lanes of a group, returned in every lane of the group
+__device__ __forceinline__ double grp8_min_f64(double v) {
+    v = min_f64(v, dpp_f64<0xB1>(v));
+    v = min_f64(v, dpp_f64<0x4E>(v));
+    v = min_f64(v, dpp_f64<0x141>(v));  // row_half_mirror: reverses each half row
+    return v;
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true);
+}
+
+template <bool PROF>
+__global__ __launch_bounds__(64) void zz_local_spec8_kernel(ZzRunParams P) {
+    constexpr int E = 8;
+    constexpr uint32_t SW = 7, PW = 1, KMAX = 5, R_ = 4 + PW + KMAX, WPAD = 58, W2 = WPAD / 2, nblk = 256;
+    const int lane = threadIdx.x;
+    const int g = lane >> 3;  // group = event slot
+    const int gl = lane & 7;  // lane inside the group
+    const int64_t chain = blockIdx.x;
+    const int64_t d = P.d;
+
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* const U = reinterpret_cast<double*>(smem + S8_U);
+    double* const LU = reinterpret_cast<double*>(smem + S8_LU);
+    double* const SLT = reinterpret_cast<double*>(smem + S8_SLT);
+    double* const Lr = reinterpret_cast<double*>(smem + S8_LR);
+    double* const LBr = reinterpret_cast<double*>(smem + S8_LBR);
+    double* const Mr = reinterpret_cast<double*>(smem + S8_MR);
+    uint32_t* const SLB = reinterpret_cast<uint32_t*>(smem + S8_SLB);
+    uint32_t* const OFR = reinterpret_cast<uint32_t*>(smem + S8_OFR);
+    uint32_t* const Z = reinterpret_cast<uint32_t*>(smem + S8_Z);
+    double* const bk = reinterpret_cast<double*>(smem + S8_BK);
+    uint32_t* const bi = reinterpret_cast<uint32_t*>(smem + S8_BI);
+    uint64_t* const LB = reinterpret_cast<uint64_t*>(smem + S8_LB);
+    double* const sx = reinterpret_cast<double*>(smem + S8_SX) + g * 16;
+    double* const sth = reinterpret_cast<double*>(smem + S8_STH) + g * 16;
+    double* const pk = reinterpret_cast<double*>(smem + S8_PK) + g * 64;
+    uint32_t* const zg = Z + g * 16;
+
+    ZzRec* rec = P.rec + chain * d;
+    double* keys = P.keys + chain * P.dk;
+    DevChain* hdr = P.hdr + chain;
+    pdmp_event* ev = P.ev ? P.ev + chain * P.trace_cap : nullptr;
+
+    uint32_t status = hdr->c.status;
+    if (status == PDMP_CHAIN_BOUND_VIOLATED || status == PDMP_CHAIN_STALLED) return;
+    const uint64_t seed = hdr->seed;
+    const uint64_t nm0 = hdr->c.ndraw_main, ntrace0 = hdr->c.ntrace;
+    uint32_t dnm = 0, dnum = 0, dnacc = 0;
+    double t_last = hdr->c.t_last;
+    double t_event = hdr->t_event;
+    status = PDMP_CHAIN_OK;
+
+    const double T = P.T;
+    const bool stop_before = (P.flags & PDMP_RUN_STOP_BEFORE) != 0;
+    const uint32_t trace_room = (P.trace_cap > 0)
+                                    ? (uint32_t)(((uint64_t)P.trace_cap > ntrace0) ? ((uint64_t)P.trace_cap - ntrace0) : 0)
+                                    : 0xffffffffu;
+    const uint32_t common = P.common_tix;
+
+    // slot 0 <- the common template, for the whole launch
+    if (lane < (int)W2) {
+        reinterpret_cast<ulonglong2*>(LB)[lane] = reinterpret_cast<const ulonglong2*>(P.blob + (size_t)common * WPAD)[lane];
+    }
+    for (uint32_t b = lane; b < nblk; b += 64) {
+        const double* kp = keys + (size_t)b * 64;
+        double mk = kp[0];
+        uint32_t mi = 0;
+#pragma unroll 8
+        for (int q = 1; q < 64; ++q) {
+            const double v = kp[q];
+            if (v < mk) {
+                mk = v;
+                mi = q;
+            }
+        }
+        bk[b] = mk;
+        bi[b] = b * 64 + mi;
+    }
+    LDS_ORDER();
+
+    uint32_t rng_base = 0xffffffffu;
+    uint64_t ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t ph_t0 = PROF ? (uint64_t)__builtin_readcyclecounter() : 0;
+    uint64_t ph_iters = 0;
+#define PHASE(k)                                                          \
+    do {                                                                  \
+        if (PROF) {                                                       \
+            const uint64_t now_ = (uint64_t)__builtin_readcyclecounter(); \
+            ph[k] += now_ - ph_t0;                                        \
+            ph_t0 = now_;                                                 \
+        }                                                                 \
+    } while (0)
+
+    bool running = stop_before || (t_event < T);
+    while (running) {
+        if (dnacc >= trace_room) {
+            status = PDMP_CHAIN_TRACE_FULL;
+            break;
+        }
+        // ---------------- select the E smallest block minima.  A lane sorts its four first-level entries (5 comparators on
+        // (key, which-of-four) pairs) and offers them in turn, so nothing smaller than a candidate stays behind.
+        int Esel = 0;
+        bool first_inf = false;
+        {
+            double c0 = bk[lane], c1 = bk[lane + 64], c2 = bk[lane + 128], c3 = bk[lane + 192];
+            uint32_t q0 = 0, q1 = 1, q2 = 2, q3 = 3;
+#define CSWAP(a, b, qa, qb)                   \
+    do {                                      \
+        const bool sw_ = (b) < (a);           \
+        const double lo_ = min_f64((a), (b)); \
+        const double hi_ = max_f64((a), (b)); \
+        const uint32_t ql_ = sw_ ? (qb) : (qa); \
+        const uint32_t qh_ = sw_ ? (qa) : (qb); \
+        (a) = lo_;                            \
+        (b) = hi_;                            \
+        (qa) = ql_;                           \
+        (qb) = qh_;                           \
+    } while (0)
+            CSWAP(c0, c1, q0, q1);
+            CSWAP(c2, c3, q2, q3);
+            CSWAP(c0, c2, q0, q2);
+            CSWAP(c1, c3, q1, q3);
+            CSWAP(c1, c2, q1, q2);
+#undef CSWAP
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                if (Esel == r) {
+                    const double tpr = wave_min_f64(c0);
+                    if (!(tpr < PDMP_INF)) {
+                        if (r == 0) first_inf = true;
+                    } else if (!(stop_before && !(tpr < T))) {
+                        const uint64_t ball = __ballot(c0 == tpr);
+                        const int wl = __ffsll((unsigned long long)ball) - 1;
+                        if (lane == wl) {
+                            SLT[r] = c0;
+                            SLB[r] = (uint32_t)lane + 64u * q0;
+                            c0 = c1;
+                            c1 = c2;
+                            c2 = c3;
+                            c3 = PDMP_INF;
+                            q0 = q1;
+                            q1 = q2;
+                            q2 = q3;
+                        }
+                        Esel = r + 1;
+                    }
+                }
+            }
+        }
+        if (Esel == 0) {
+            if (first_inf) status = PDMP_CHAIN_STALLED;
+            break;
+        }
+        LDS_ORDER();
+        PHASE(0);
+        if (PROF) ph_iters += 1;
+        bool gvalid = g < Esel;
+        const double tp = gvalid ? SLT[g] : PDMP_INF;
+        const uint32_t blk = gvalid ? SLB[g] : 0u;
+        const uint32_t i = gvalid ? bi[blk] : 0u;
+        const uint32_t tixi = gvalid ? P.tix[i] : common;
+
+        // ---------------- candidate draws (window of 64 draws and their logs in LDS, as in zz_local_spec_kernel)
+        if (dnm < rng_base || dnm + E * (1u + KMAX) > rng_base + 64u) {
+            rng_base = dnm;
+            const double u = pdmp_u01(seed, PDMP_STREAM_MAIN, nm0 + (uint64_t)dnm + (uint64_t)lane);
+            U[lane] = u;
+            LU[lane] = pdmp_log(u);
+        }
+        const uint32_t rng_off = dnm - rng_base;
+        // ---------------- blob slots: 0 for the common template, 1 and 2 for the first two events that need another one
+        uint32_t slot = 0;
+        {
+            const bool nc = gvalid && tixi != common;
+            const uint64_t ncball = __ballot(nc && gl == 0);
+            if (ncball != 0) {
+                const uint32_t rank = (uint32_t)__popcll(ncball & ((1ull << (8 * g)) - 1ull));
+                if (__popcll(ncball) > 2) {  // the third such event and everything after it wait for the next iteration
+                    uint64_t m_ = ncball;
+                    m_ &= m_ - 1;
+                    m_ &= m_ - 1;
+                    const int cut = (__ffsll((unsigned long long)m_) - 1) >> 3;
+                    Esel = cut;
+                    gvalid = g < Esel;
+                }
+                if (nc && gvalid) {
+                    slot = 1 + rank;
+                    const ulonglong2* bsrc = reinterpret_cast<const ulonglong2*>(P.blob + (size_t)tixi * WPAD);
+                    ulonglong2* bdst = reinterpret_cast<ulonglong2*>(LB + slot * WPAD);
+                    for (uint32_t w = gl; w < W2; w += 8) bdst[w] = bsrc[w];
+                }
+            }
+        }
+        const uint64_t* lb = LB + slot * WPAD;
+        LDS_ORDER();
+        PHASE(1);
+        // ---------------- neighbourhood header and member list: positions gl and gl + 8 of S[i]
+        int k = 0, m = 0, self = 0;
+        uint32_t sA = 0xffffff00u + (uint32_t)lane, sB = 0xffffff40u + (uint32_t)lane;
+        if (gvalid) {
+            const uint64_t hw = lb[0];
+            k = (int)(hw & 0xff);
+            m = (int)((hw >> 8) & 0xff);
+            self = (int)((hw >> 16) & 0xff);
+            if (gl < m) {
+                const uint64_t sw = lb[1 + (gl >> 1)];
+                sA = i + ((gl & 1) ? (uint32_t)(sw >> 32) : (uint32_t)sw);
+            }
+            if (gl + 8 < m) {
+                const uint64_t sw = lb[5 + (gl >> 1)];
+                sB = i + ((gl & 1) ? (uint32_t)(sw >> 32) : (uint32_t)sw);
+            }
+        }
+        const bool memberA = gvalid && gl < m, memberB = gvalid && gl + 8 < m;
+        PHASE(2);
+        // All HBM loads of the iteration in ONE straight-line batch (no exec-masked regions: lanes without a record of their own
+        // read i's, which coalesces with the group's other readers of it; empty slots read coordinate 0): the wait counters
+        // stay exact and nothing here is serialised behind an earlier round trip.
+        ZzRec* rsA = rec + ((memberA && gl < k) ? sA : i);
+        ZzRec* rsB = rec + (memberB ? sB : i);
+        const ZzRec* ri = rec + i;
+        double x = rsA->x, th = rsA->th, t = rsA->t, I = rsA->I;
+        const double told_i = ri->t_old, a_i = ri->a, b_i = ri->b;
+        const uint64_t acc_i = ri->acc;
+        double kq[8];
+        {
+            const double2* kp = reinterpret_cast<const double2*>(keys + (size_t)blk * 64 + gl * 8);
+            const double2 k01 = kp[0], k23 = kp[1], k45 = kp[2], k67 = kp[3];
+            kq[0] = k01.x;
+            kq[1] = k01.y;
+            kq[2] = k23.x;
+            kq[3] = k23.y;
+            kq[4] = k45.x;
+            kq[5] = k45.y;
+            kq[6] = k67.x;
+            kq[7] = k67.y;
+        }
+        rsA = rec + (memberA ? sA : i);
+        zg[gl] = sA;
+        zg[8 + gl] = sB;
+        const uint32_t sub = 1 + SW + (uint32_t)gl * R_;
+        double cj = 0.0;
+        if (gvalid && gl < k) cj = __longlong_as_double((long long)lb[sub + 2]);
+
+        // ---------------- zone conflicts with earlier groups: id spans first, the exact id comparison only for pairs of groups
+        // whose spans overlap
+        LDS_ORDER();
+        uint64_t confball;
+        {
+            uint32_t lo = memberA ? sA : 0xffffffffu, hi = memberA ? sA : 0u;
+            if (memberB) {
+                lo = (sB < lo) ? sB : lo;
+                hi = (sB > hi) ? sB : hi;
+            }
+            uint32_t o;
+            o = dpp_u32<0xB1>(lo);   lo = (o < lo) ? o : lo;
+            o = dpp_u32<0x4E>(lo);   lo = (o < lo) ? o : lo;
+            o = dpp_u32<0x141>(lo);  lo = (o < lo) ? o : lo;
+            o = dpp_u32<0xB1>(hi);   hi = (o > hi) ? o : hi;
+            o = dpp_u32<0x4E>(hi);   hi = (o > hi) ? o : hi;
+            o = dpp_u32<0x141>(hi);  hi = (o > hi) ? o : hi;
+            bool conflict = false;
+            const uint2* Z2 = reinterpret_cast<const uint2*>(Z);
+#pragma unroll
+            for (int q = 0; q < E - 1; ++q) {
+                const uint32_t lq = readlane_u32(lo, 8 * q), hq = readlane_u32(hi, 8 * q);
+                const bool ov = gvalid && (q < g) && lo <= hq && lq <= hi;
+                if (__ballot(ov) != 0) {
+                    bool hit = false;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const uint2 zz = Z2[q * 8 + j];
+                        hit = hit || (zz.x == sA) || (zz.y == sA) || (zz.x == sB) || (zz.y == sB);
+                    }
+                    conflict = conflict || (ov && hit);
+                }
+            }
+            confball = __ballot(conflict);
+        }
+        PHASE(3);
+
+        // ---------------- smove_forward!(G, i, ...), gradient, rates
+        if (gvalid && gl < k) {
+            const double dt = tp - t;
+            const double xn = x + th * dt;
+            I = I + dt * ((x + xn) * 0.5);
+            x = xn;
+            t = tp;
+            sx[gl] = x;
+            sth[gl] = th;
+        }
+        LDS_ORDER();
+        double l = 0.0, lbound = 0.0;
+        {
+            double gr = 0.0;
+#pragma unroll
+            for (uint32_t p = 0; p < KMAX; ++p) {
+                if ((int)p < k) gr += __longlong_as_double((long long)lb[1 + SW + p * R_]) * sx[p];
+            }
+            if (gvalid) {
+                const double th_i = sth[self];
+                l = pos_part(gr * th_i);
+                lbound = pos_part(a_i + b_i * (tp - told_i));
+                if (gl == 0) {
+                    Lr[g] = l;
+                    LBr[g] = lbound;
+                }
+            }
+        }
+        LDS_ORDER();
+        // ---------------- accept chain in time order.  Lane o evaluates every event's test for the draw at offset o; the ballots
+        // are then walked on the scalar unit: event r reads its bit at the offset the earlier outcomes imply.
+        uint32_t accbits = 0;
+        {
+            const double coin = U[(rng_off + (uint32_t)lane) & 63u];
+            uint64_t am[E];
+#pragma unroll
+            for (int r = 0; r < E; ++r) am[r] = __ballot(coin * LBr[r] < Lr[r]);  // :121
+            uint32_t off = 0;
+            uint32_t offv = 0;
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                offv = (lane == r) ? off : offv;
+                if (r < Esel) {
+                    const uint32_t a_r = (uint32_t)((am[r] >> off) & 1ull);
+                    const uint32_t k_r = readlane_u32((uint32_t)k, 8 * r);
+                    off += a_r ? (1u + k_r) : 2u;
+                    accbits |= a_r << r;
+                }
+            }
+            offv = (lane == E) ? off : offv;
+            if (lane <= E) OFR[lane] = offv;
+        }
+        LDS_ORDER();
+        const uint32_t myoff = OFR[g];
+        const bool accept = gvalid && ((accbits >> g) & 1u) != 0;
+        const bool violated = accept && (l >= lbound);  // :123
+        PHASE(4);
+
+        double x2 = 0.0, th2 = 0.0, t2 = 0.0, I2 = 0.0;
+        if (accept) {
+            if (gl >= k && gl < m) {  // smove_forward!(G2, i, ...), :129
+                x = rsA->x;
+                th = rsA->th;
+                t = rsA->t;
+                I = rsA->I;
+                const double dt = tp - t;
+                const double xn = x + th * dt;
+                I = I + dt * ((x + xn) * 0.5);
+                x = xn;
+                t = tp;
+            }
+            if (memberB) {
+                x2 = rsB->x;
+                th2 = rsB->th;
+                t2 = rsB->t;
+                I2 = rsB->I;
+                const double dt = tp - t2;
+                const double xn = x2 + th2 * dt;
+                I2 = I2 + dt * ((x2 + xn) * 0.5);
+                x2 = xn;
+                t2 = tp;
+                sx[8 + gl] = x2;
+                sth[8 + gl] = th2;
+            }
+            if (gl == self) th = -th;  // reflect!, :130
+            if (gl < m) {
+                sx[gl] = x;
+                sth[gl] = th;
+            }
+        }
+        LDS_ORDER();
+        // ---------------- re-bound (ab + poisson_time) -- results stay in registers until the commit
+        const bool active = gvalid && (accept ? (gl < k) : (gl == self));
+        double key = PDMP_INF, a = 0.0, b = 0.0;
+        if (active) {
+            const double gmu = __longlong_as_double((long long)lb[sub + 1]);
+            const int kj = (int)(lb[sub + 3] & 0xff);
+            const uint64_t pw = lb[sub + 4];
+            double gx = 0.0, gt = 0.0;
+#pragma unroll
+            for (int q = 0; q < (int)KMAX; ++q) {
+                if (q < kj) {
+                    const double v = __longlong_as_double((long long)lb[sub + 4 + PW + q]);
+                    const int ps = (int)((pw >> (8 * q)) & 0xff);
+                    gx += v * sx[ps];
+                    gt += v * sth[ps];
+                }
+            }
+            a = cj + (gx - gmu) * th;
+            b = cj / 100 + th * gt;
+            const double L = LU[(rng_off + myoff + 1u + (accept ? (uint32_t)gl : 0u)) & 63u];
+            key = t + dev_poisson_time_L(a, b, L);
+        }
+        LDS_ORDER();
+        // the patched copy of the popped key block goes where sx / sth / the zone ids were: all their readers are done
+        {
+            double2* pk2 = reinterpret_cast<double2*>(pk + gl * 8);
+            pk2[0] = make_double2(kq[0], kq[1]);
+            pk2[1] = make_double2(kq[2], kq[3]);
+            pk2[2] = make_double2(kq[4], kq[5]);
+            pk2[3] = make_double2(kq[6], kq[7]);
+        }
+        LDS_ORDER();
+        if (active && (sA >> 6) == blk) pk[sA & 63] = key;
+        LDS_ORDER();
+        PHASE(5);
+        // ---------------- patched minimum of the popped block, and everything this event could expose
+        double rowmin;
+        uint32_t cand;
+        int wl2;
+        {
+            const double2* pk2 = reinterpret_cast<const double2*>(pk + gl * 8);
+            const double2 p01 = pk2[0], p23 = pk2[1], p45 = pk2[2], p67 = pk2[3];
+            double lm = p01.x;
+            uint32_t li = 0;
+#define PMIN(v, idx)    \
+    do {                \
+        if ((v) < lm) { \
+            lm = (v);   \
+            li = (idx); \
+        }               \
+    } while (0)
+            PMIN(p01.y, 1);
+            PMIN(p23.x, 2);
+            PMIN(p23.y, 3);
+            PMIN(p45.x, 4);
+            PMIN(p45.y, 5);
+            PMIN(p67.x, 6);
+            PMIN(p67.y, 7);
+#undef PMIN
+            cand = blk * 64u + (uint32_t)gl * 8u + li;
+            rowmin = grp8_min_f64(lm);
+            const uint64_t winball = __ballot(gvalid && lm == rowmin);
+            wl2 = __ffs((unsigned)((winball >> (8 * g)) & 0xffu)) - 1;
+        }
+        const double keymin = grp8_min_f64(key);
+        const double expose = min_f64(rowmin, keymin);
+        if (gl == 0) Mr[g] = expose;
+        LDS_ORDER();
+        // ---------------- validate: event g commits iff all earlier ones do, its zone is disjoint from theirs, and nothing they
+        // produce or expose comes before it
+        uint32_t Rc;
+        uint32_t nacc_c;
+        {
+            double pref = PDMP_INF;
+#pragma unroll
+            for (int q = 0; q < E - 1; ++q) {
+                const double mq = Mr[q];
+                pref = (q < g) ? min_f64(pref, mq) : pref;
+            }
+            const bool confg = ((confball >> (8 * g)) & 0xffull) != 0;
+            const bool okg = gvalid && ((g == 0) || (!confg && pref > tp));
+            const bool vstop = violated;  // reference: error(...), :124 -> the event is not committed
+            const uint64_t okball = __ballot(okg && !vstop && gl == 0);
+            const uint64_t vball = __ballot(okg && vstop && gl == 0);
+            const uint64_t accball = __ballot(accept && gl == 0);
+            uint32_t r_ok = 0;
+            while (r_ok < (uint32_t)E && ((okball >> (8 * r_ok)) & 1ull)) ++r_ok;
+            Rc = 0;
+            nacc_c = 0;
+            bool stopped = false;
+            for (uint32_t r = 0; r < r_ok && !stopped; ++r) {
+                Rc = r + 1;
+                if ((accball >> (8 * r)) & 1ull) {
+                    nacc_c += 1;
+                    if (dnacc + nacc_c >= trace_room && P.trace_cap > 0) {
+                        status = PDMP_CHAIN_TRACE_FULL;
+                        stopped = true;
+                    }
+                    if (!stop_before && !(uniform_f64(SLT[r]) < T)) {
+                        running = false;
+                        stopped = true;
+                    }
+                }
+            }
+            if (!stopped && r_ok < (uint32_t)E && ((vball >> (8 * r_ok)) & 1ull)) status = PDMP_CHAIN_BOUND_VIOLATED;
+        }
+        PHASE(6);
+
+        // ---------------- commit the valid prefix
+        const bool commit = gvalid && (uint32_t)g < Rc;
+        const uint64_t accball2 = __ballot(commit && accept && gl == 0);
+        if (commit) {
+            if (gl < (accept ? m : k)) {
+                rsA->x = x;
+                rsA->th = th;
+                rsA->t = t;
+                rsA->I = I;
+            }
+            if (accept && memberB) {
+                rsB->x = x2;
+                rsB->th = th2;
+                rsB->t = t2;
+                rsB->I = I2;
+            }
+            if (active) {
+                rsA->t_old = t;
+                rsA->a = a;
+                rsA->b = b;
+                keys[sA] = key;
+            }
+            if (accept && gl == self) rsA->acc = acc_i + 1;
+            if (gl == wl2) {
+                bk[blk] = rowmin;
+                bi[blk] = cand;
+            }
+            if (accept && gl == self && ev) {
+                const uint32_t rank = (uint32_t)__popcll(accball2 & ((1ull << (8 * g)) - 1ull));
+                pdmp_event e;
+                e.t = tp;
+                e.i = (int64_t)i;
+                e.x = x;
+                e.theta = th;
+                ev[ntrace0 + dnacc + rank] = e;
+            }
+        }
+        LDS_ORDER();
+        PHASE(7);
+        // ---------------- level-1 updates for re-bounded neighbours living in other blocks, in event order
+        for (uint32_t r = 0; r < Rc; ++r) {
+            if (!((accball2 >> (8 * r)) & 1ull)) continue;
+            const uint32_t own = uniform_u32(SLB[r]);
+            const int kr = (int)readlane_u32((uint32_t)k, 8 * (int)r);
+            for (int jj = 0; jj < kr; ++jj) {
+                const uint32_t j = readlane_u32(sA, 8 * (int)r + jj);
+                if ((j >> 6) == own) continue;
+                level1_update(bk, bi, keys, lane, j, readlane_f64(key, 8 * (int)r + jj));
+            }
+        }
+        PHASE(8);
+        // ---------------- counters
+        if (Rc > 0) {
+            dnum += Rc;
+            dnacc += nacc_c;
+            dnm += uniform_u32(OFR[Rc]);
+            t_last = uniform_f64(SLT[Rc - 1]);
+            if (accball2) t_event = uniform_f64(SLT[(63 - __builtin_clzll(accball2)) >> 3]);
+        }
+        if (status != PDMP_CHAIN_OK) break;
+        LDS_ORDER();
+    }
+
+    if (PROF && P.dbg && chain == 0 && lane == 0) {
+        for (int q = 0; q < 10; ++q) P.dbg[q] = (double)ph[q];
+        P.dbg[10] = (double)ph_iters;
+    }
+#undef PHASE
+    if (lane == 0) {
+        hdr->c.t_last = t_last;
+        hdr->t_event = t_event;
+        hdr->c.num += dnum;
+        hdr->c.nacc += dnacc;
+        hdr->c.ntrace = ntrace0 + dnacc;
+        hdr->c.nevents += dnacc;
+        hdr->c.ndraw_main = nm0 + dnm;
+        hdr->c.status = status;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ speculative sticky loop
 //
 // zz_local_spec_kernel's scheme (up to 4 events of one chain per iteration, one per 16-lane row, exact validation, commit of
@@ -2288,7 +2888,13 @@ int launch_zz_local_spec(const ZzRunParams& p, int64_t nchains, void* stream) {
     // without a refresh clock the last key block holds only the (infinite) refresh slot: when d fills 256 blocks exactly the
     // queue's first level is scanned as 4 entries per lane instead of 5
     const bool plain4 = plain && !p.has_refresh && p.d == 256 * 64 && p.nblk == 257;
-    if (p.dbg) {  // per-phase cycle profile (PDMP_PHASE env)
+    // PDMP_KERNEL=spec4 keeps the 4-events-per-iteration kernel for the lattice workload (A/B runs, tests)
+    const char* force = getenv("PDMP_KERNEL");
+    const bool spec8 = plain4 && p.common_tix != 0xffffffffu && !(force && strcmp(force, "spec4") == 0);
+    if (spec8) {
+        if (p.dbg) hipLaunchKernelGGL((zz_local_spec8_kernel<true>), grid, block, zz_spec8_lds_bytes(), (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((zz_local_spec8_kernel<false>), grid, block, zz_spec8_lds_bytes(), (hipStream_t)stream, p);
+    } else if (p.dbg) {  // per-phase cycle profile (PDMP_PHASE env)
         if (plain4) {
             ZzRunParams q = p;
             q.nblk = 256;
