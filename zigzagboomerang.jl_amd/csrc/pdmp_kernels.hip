@@ -1741,7 +1741,12 @@ constexpr uint32_t S8_OFR = 5408;   // [16] u32 draw offsets after 0..8 events
 constexpr uint32_t S8_LB = 5472;    // [3][58] u64 blob slots
 constexpr uint32_t S8_BK = S8_LB + 3 * 58 * 8;  // [256] f64
 constexpr uint32_t S8_BI = S8_BK + 256 * 8;     // [256] u32
-constexpr uint32_t S8_BYTES = S8_BI + 256 * 4;  // 9936
+constexpr uint32_t SEL_CAP = 16;                // candidates ranked per iteration (power of two)
+constexpr uint32_t S8_TK = S8_BI + 256 * 4;     // [SEL_CAP] f64 candidate keys
+constexpr uint32_t S8_TB = S8_TK + SEL_CAP * 8; // [SEL_CAP] u32 their blocks
+constexpr uint32_t S8_SELDT = S8_TB + SEL_CAP * 4;  // f64 selection threshold above the minimum
+constexpr uint32_t S8_BYTES = S8_SELDT + 8;     // 10136
+constexpr uint32_t S8_PR = S8_SLT;              // [16][4] u32 partial ranks (aliases SLT .. MR, which are written after the ranking)
 
 size_t zz_spec8_lds_bytes() { return S8_BYTES; }
 
@@ -1758,7 +1763,7 @@ __device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
 }
 
 template <bool PROF>
-__global__ __launch_bounds__(64) void zz_local_spec8_kernel(ZzRunParams P) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void zz_local_spec8_kernel(ZzRunParams P) {
     constexpr int E = 8;
     constexpr uint32_t SW = 7, PW = 1, KMAX = 5, R_ = 4 + PW + KMAX, WPAD = 58, W2 = WPAD / 2, nblk = 256;
     const int lane = threadIdx.x;
@@ -1780,6 +1785,10 @@ __global__ __launch_bounds__(64) void zz_local_spec8_kernel(ZzRunParams P) {
     double* const bk = reinterpret_cast<double*>(smem + S8_BK);
     uint32_t* const bi = reinterpret_cast<uint32_t*>(smem + S8_BI);
     uint64_t* const LB = reinterpret_cast<uint64_t*>(smem + S8_LB);
+    double* const TK = reinterpret_cast<double*>(smem + S8_TK);
+    uint32_t* const TB = reinterpret_cast<uint32_t*>(smem + S8_TB);
+    double* const SELDT = reinterpret_cast<double*>(smem + S8_SELDT);
+    uint32_t* const PR = reinterpret_cast<uint32_t*>(smem + S8_PR);
     double* const sx = reinterpret_cast<double*>(smem + S8_SX) + g * 16;
     double* const sth = reinterpret_cast<double*>(smem + S8_STH) + g * 16;
     double* const pk = reinterpret_cast<double*>(smem + S8_PK) + g * 64;
@@ -1806,6 +1815,7 @@ __global__ __launch_bounds__(64) void zz_local_spec8_kernel(ZzRunParams P) {
                                     : 0xffffffffu;
     const uint32_t common = P.common_tix;
 
+    if (lane == 0) SELDT[0] = 1e-3;  // any positive start: the steering rule finds the scale within a few iterations
     // slot 0 <- the common template, for the whole launch
     if (lane < (int)W2) {
         reinterpret_cast<ulonglong2*>(LB)[lane] = reinterpret_cast<const ulonglong2*>(P.blob + (size_t)common * WPAD)[lane];
@@ -1846,54 +1856,109 @@ __global__ __launch_bounds__(64) void zz_local_spec8_kernel(ZzRunParams P) {
             status = PDMP_CHAIN_TRACE_FULL;
             break;
         }
-        // ---------------- select the E smallest block minima.  A lane sorts its four first-level entries (5 comparators on
-        // (key, which-of-four) pairs) and offers them in turn, so nothing smaller than a candidate stays behind.
+        // ---------------- select the (up to) E smallest block minima, in time order, WITHOUT a tournament per candidate: one
+        // wave minimum m, then every first-level entry below the threshold m + sel_dt is a candidate -- four compares and four
+        // population counts tell how many there are.  The candidates (at most SEL_CAP, else the threshold is halved) are compacted
+        // into LDS by ballot prefix counts, each ranks itself against the others with broadcast reads, and ranks 0..E-1 become
+        // the event slots.  Whatever sel_dt is, the slots hold exactly the smallest entries of the queue, so the committed
+        // sequence does not depend on it; it is steered towards ~10 candidates per iteration.
         int Esel = 0;
         bool first_inf = false;
         {
-            double c0 = bk[lane], c1 = bk[lane + 64], c2 = bk[lane + 128], c3 = bk[lane + 192];
-            uint32_t q0 = 0, q1 = 1, q2 = 2, q3 = 3;
-#define CSWAP(a, b, qa, qb)                   \
-    do {                                      \
-        const bool sw_ = (b) < (a);           \
-        const double lo_ = min_f64((a), (b)); \
-        const double hi_ = max_f64((a), (b)); \
-        const uint32_t ql_ = sw_ ? (qb) : (qa); \
-        const uint32_t qh_ = sw_ ? (qa) : (qb); \
-        (a) = lo_;                            \
-        (b) = hi_;                            \
-        (qa) = ql_;                           \
-        (qb) = qh_;                           \
-    } while (0)
-            CSWAP(c0, c1, q0, q1);
-            CSWAP(c2, c3, q2, q3);
-            CSWAP(c0, c2, q0, q2);
-            CSWAP(c1, c3, q1, q3);
-            CSWAP(c1, c2, q1, q2);
-#undef CSWAP
-#pragma unroll
-            for (int r = 0; r < E; ++r) {
-                if (Esel == r) {
-                    const double tpr = wave_min_f64(c0);
-                    if (!(tpr < PDMP_INF)) {
-                        if (r == 0) first_inf = true;
-                    } else if (!(stop_before && !(tpr < T))) {
-                        const uint64_t ball = __ballot(c0 == tpr);
-                        const int wl = __ffsll((unsigned long long)ball) - 1;
-                        if (lane == wl) {
-                            SLT[r] = c0;
-                            SLB[r] = (uint32_t)lane + 64u * q0;
-                            c0 = c1;
-                            c1 = c2;
-                            c2 = c3;
-                            c3 = PDMP_INF;
-                            q0 = q1;
-                            q1 = q2;
-                            q2 = q3;
+            const double k0 = bk[lane], k1 = bk[lane + 64], k2 = bk[lane + 128], k3 = bk[lane + 192];
+            const double mloc = min_f64(min_f64(k0, k1), min_f64(k2, k3));
+            const double mq = wave_min_f64(mloc);
+            if (!(mq < PDMP_INF)) {
+                first_inf = true;
+            } else if (!(stop_before && !(mq < T))) {
+                if (lane < (int)SEL_CAP) TK[lane] = PDMP_INF;
+                double dt_sel = uniform_f64(SELDT[0]);
+                uint64_t M0, M1, M2, M3;
+                bool c0, c1, c2, c3;
+                uint32_t C;
+                for (int tries = 0;; ++tries) {
+                    double tau = mq + dt_sel;
+                    if (stop_before) tau = (T < tau) ? T : tau;
+                    if (tries >= 64) tau = mq;  // a pile of exactly equal keys: the entries equal to the minimum only
+                    c0 = k0 < tau || k0 == mq;
+                    c1 = k1 < tau || k1 == mq;
+                    c2 = k2 < tau || k2 == mq;
+                    c3 = k3 < tau || k3 == mq;
+                    M0 = __ballot(c0);
+                    M1 = __ballot(c1);
+                    M2 = __ballot(c2);
+                    M3 = __ballot(c3);
+                    C = (uint32_t)(__popcll(M0) + __popcll(M1) + __popcll(M2) + __popcll(M3));
+                    if (C <= SEL_CAP) break;
+                    if (tries > 64) {  // more than SEL_CAP entries EQUAL to the minimum: one of them (lowest block) per iteration
+                        const uint64_t one = M0 ? (M0 & (~M0 + 1)) : 0ull;
+                        M1 = M0 ? 0ull : (M1 & (~M1 + 1));
+                        M2 = (M0 | M1) ? 0ull : (M2 & (~M2 + 1));
+                        M3 = (M0 | M1 | M2) ? 0ull : (M3 & (~M3 + 1));
+                        M0 = one;
+                        c0 = ((M0 >> lane) & 1ull) != 0;
+                        c1 = ((M1 >> lane) & 1ull) != 0;
+                        c2 = ((M2 >> lane) & 1ull) != 0;
+                        c3 = ((M3 >> lane) & 1ull) != 0;
+                        C = 1;
+                        break;
+                    }
+                    dt_sel *= 0.5;
+                }
+                // compaction: entry (lane, j) gets index (candidates of slots < j) + (candidates of slot j in lower lanes)
+                const uint32_t b1 = (uint32_t)__popcll(M0), b2 = b1 + (uint32_t)__popcll(M1), b3 = b2 + (uint32_t)__popcll(M2);
+                auto below = [](uint64_t m_) -> uint32_t {
+                    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_, 0u));
+                };
+                if (c0) {
+                    const uint32_t ix = below(M0);
+                    TK[ix] = k0;
+                    TB[ix] = (uint32_t)lane;
+                }
+                if (c1) {
+                    const uint32_t ix = b1 + below(M1);
+                    TK[ix] = k1;
+                    TB[ix] = (uint32_t)lane + 64u;
+                }
+                if (c2) {
+                    const uint32_t ix = b2 + below(M2);
+                    TK[ix] = k2;
+                    TB[ix] = (uint32_t)lane + 128u;
+                }
+                if (c3) {
+                    const uint32_t ix = b3 + below(M3);
+                    TK[ix] = k3;
+                    TB[ix] = (uint32_t)lane + 192u;
+                }
+                LDS_ORDER();
+                // rank of candidate n among all (ties by index), on a 16 x 4 grid: lane = 16 * part + n counts the candidates
+                // 4 * part .. 4 * part + 3 that precede n; the four partial counts meet in LDS.  Unused entries hold +Inf.
+                {
+                    const uint32_t n = (uint32_t)lane & 15u, part = (uint32_t)lane >> 4;
+                    const double own = TK[n];
+                    const double2* T2 = reinterpret_cast<const double2*>(TK + 4 * part);
+                    const double2 o01 = T2[0], o23 = T2[1];
+                    const uint32_t q = 4 * part;
+                    uint32_t pr = 0;
+                    pr += (o01.x < own || (o01.x == own && q + 0 < n)) ? 1u : 0u;
+                    pr += (o01.y < own || (o01.y == own && q + 1 < n)) ? 1u : 0u;
+                    pr += (o23.x < own || (o23.x == own && q + 2 < n)) ? 1u : 0u;
+                    pr += (o23.y < own || (o23.y == own && q + 3 < n)) ? 1u : 0u;
+                    PR[n * 4 + part] = pr;
+                    LDS_ORDER();
+                    if ((uint32_t)lane < C) {
+                        const uint4 p4 = reinterpret_cast<const uint4*>(PR)[lane];
+                        const uint32_t rank = p4.x + p4.y + p4.z + p4.w;
+                        if (rank < (uint32_t)E) {
+                            SLT[rank] = own;
+                            SLB[rank] = TB[lane];
                         }
-                        Esel = r + 1;
                     }
                 }
+                Esel = (C < (uint32_t)E) ? (int)C : E;
+                // steer the threshold: ~10 candidates next time
+                const double f = (C > 12u) ? 0.75 : (C < 9u) ? ((C < 5u) ? 2.0 : 1.25) : 1.0;
+                if (lane == 0) SELDT[0] = dt_sel * f;
             }
         }
         if (Esel == 0) {
