@@ -1729,9 +1729,10 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P_in) {
 constexpr uint32_t S8_U = 0;        // [64] f64
 constexpr uint32_t S8_LU = 512;     // [64] f64
 constexpr uint32_t S8_PK = 1024;    // [8][64] f64 patched key blocks
-constexpr uint32_t S8_SX = S8_PK;           // [8][16] f64   (aliases PK)
-constexpr uint32_t S8_STH = S8_PK + 1024;   // [8][16] f64   (aliases PK)
-constexpr uint32_t S8_Z = S8_PK + 2048;     // [8][16] u32   (aliases PK)
+constexpr uint32_t S8_SXP = 18;             // doubles per group in sx / sth (16 + 2: eight groups on eight different banks)
+constexpr uint32_t S8_SX = S8_PK;           // [8][18] f64   (aliases PK)
+constexpr uint32_t S8_STH = S8_PK + 1152;   // [8][18] f64   (aliases PK)
+constexpr uint32_t S8_Z = S8_PK + 2304;     // [8][16] u32   (aliases PK)
 constexpr uint32_t S8_SLT = 5120;   // [8] f64 candidate keys
 constexpr uint32_t S8_LR = 5184;    // [8] f64 true rates
 constexpr uint32_t S8_LBR = 5248;   // [8] f64 bounds
@@ -1789,10 +1790,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     uint32_t* const TB = reinterpret_cast<uint32_t*>(smem + S8_TB);
     double* const SELDT = reinterpret_cast<double*>(smem + S8_SELDT);
     uint32_t* const PR = reinterpret_cast<uint32_t*>(smem + S8_PR);
-    double* const sx = reinterpret_cast<double*>(smem + S8_SX) + g * 16;
-    double* const sth = reinterpret_cast<double*>(smem + S8_STH) + g * 16;
+    double* const sx = reinterpret_cast<double*>(smem + S8_SX) + g * S8_SXP;
+    double* const sth = reinterpret_cast<double*>(smem + S8_STH) + g * S8_SXP;
     double* const pk = reinterpret_cast<double*>(smem + S8_PK) + g * 64;
     uint32_t* const zg = Z + g * 16;
+    const uint32_t pk_t = (((uint32_t)gl >> 2) & 1u) | (((uint32_t)g & 1u) << 1);
 
     ZzRec* rec = P.rec + chain * d;
     double* keys = P.keys + chain * P.dk;
@@ -2208,15 +2210,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
         LDS_ORDER();
         // the patched copy of the popped key block goes where sx / sth / the zone ids were: all their readers are done
+        // (the four 16-byte pieces of a lane's 64-byte chunk are stored in the order piece ^ pk_t, pk_t = 0..3 over the four lanes
+        // of a quarter wave that would otherwise share their banks: b128 accesses without bank conflicts)
         {
             double2* pk2 = reinterpret_cast<double2*>(pk + gl * 8);
-            pk2[0] = make_double2(kq[0], kq[1]);
-            pk2[1] = make_double2(kq[2], kq[3]);
-            pk2[2] = make_double2(kq[4], kq[5]);
-            pk2[3] = make_double2(kq[6], kq[7]);
+            pk2[0 ^ pk_t] = make_double2(kq[0], kq[1]);
+            pk2[1 ^ pk_t] = make_double2(kq[2], kq[3]);
+            pk2[2 ^ pk_t] = make_double2(kq[4], kq[5]);
+            pk2[3 ^ pk_t] = make_double2(kq[6], kq[7]);
         }
         LDS_ORDER();
-        if (active && (sA >> 6) == blk) pk[sA & 63] = key;
+        if (active && (sA >> 6) == blk) {
+            const uint32_t e_ = sA & 63u, ge_ = e_ >> 3;
+            const uint32_t t_ = ((ge_ >> 2) & 1u) | (((uint32_t)g & 1u) << 1);
+            pk[ge_ * 8u + ((((e_ & 7u) >> 1) ^ t_) << 1) + (e_ & 1u)] = key;
+        }
         LDS_ORDER();
         PHASE(5);
         // ---------------- patched minimum of the popped block, and everything this event could expose
@@ -2225,7 +2233,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         int wl2;
         {
             const double2* pk2 = reinterpret_cast<const double2*>(pk + gl * 8);
-            const double2 p01 = pk2[0], p23 = pk2[1], p45 = pk2[2], p67 = pk2[3];
+            const double2 p01 = pk2[0 ^ pk_t], p23 = pk2[1 ^ pk_t], p45 = pk2[2 ^ pk_t], p67 = pk2[3 ^ pk_t];
             double lm = p01.x;
             uint32_t li = 0;
 #define PMIN(v, idx)    \
