@@ -838,6 +838,7 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
     P.adapt = e->cfg.adapt;
     P.has_refresh = e->lambda_ref > 0;
     P.move_all = e->cfg.sampler == PDMP_SAMPLER_ZIGZAG_ALL;
+    if (getenv("PDMP_DEBUG_PTRS")) fprintf(stderr, "PTRS rec=%p keys=%p hdr=%p ev=%p blob=%p tix=%p\n", (void*)P.rec, (void*)P.keys, (void*)P.hdr, (void*)P.ev, (void*)P.blob, (void*)P.tix);
     HIP_TRY(hipEventRecord(e->ev0, s));
     const bool sticky = e->cfg.sampler == PDMP_SAMPLER_STICKY_ZIGZAG;
     P.kappa = e->d_kappa.p;

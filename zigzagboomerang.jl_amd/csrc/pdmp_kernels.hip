@@ -1758,6 +1758,10 @@ __device__ __forceinline__ double grp8_min_f64(double v) {
     v = min_f64(v, dpp_f64<0x141>(v));  // row_half_mirror: reverses each half row
     return v;
 }
+__device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) {
+    const uint32_t ab = (a < b) ? a : b;
+    return (ab < c) ? ab : c;  // v_min3_u32
+}
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true);
@@ -2082,13 +2086,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 const uint32_t lq = readlane_u32(lo, 8 * q), hq = readlane_u32(hi, 8 * q);
                 const bool ov = gvalid && (q < g) && lo <= hq && lq <= hi;
                 if (__ballot(ov) != 0) {
-                    bool hit = false;
+                    uint32_t mn = 0xffffffffu;  // min over q's sixteen ids of (id ^ mine): 0 iff one of them is mine
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const uint2 zz = Z2[q * 8 + j];
-                        hit = hit || (zz.x == sA) || (zz.y == sA) || (zz.x == sB) || (zz.y == sB);
+                        mn = umin3(mn, zz.x ^ sA, zz.y ^ sA);
+                        mn = umin3(mn, zz.x ^ sB, zz.y ^ sB);
                     }
-                    conflict = conflict || (ov && hit);
+                    conflict = conflict || (ov && mn == 0u);
                 }
             }
             confball = __ballot(conflict);
