@@ -1738,7 +1738,6 @@ constexpr uint32_t S8_LR = 5184;    // [8] f64 true rates
 constexpr uint32_t S8_LBR = 5248;   // [8] f64 bounds
 constexpr uint32_t S8_MR = 5312;    // [8] f64 what each event exposes
 constexpr uint32_t S8_SLB = 5376;   // [8] u32 candidate blocks
-constexpr uint32_t S8_OFR = 5408;   // [16] u32 draw offsets after 0..8 events
 constexpr uint32_t S8_LB = 5472;    // [3][58] u64 blob slots
 constexpr uint32_t S8_BK = S8_LB + 3 * 58 * 8;  // [256] f64
 constexpr uint32_t S8_BI = S8_BK + 256 * 8;     // [256] u32
@@ -1785,7 +1784,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     double* const LBr = reinterpret_cast<double*>(smem + S8_LBR);
     double* const Mr = reinterpret_cast<double*>(smem + S8_MR);
     uint32_t* const SLB = reinterpret_cast<uint32_t*>(smem + S8_SLB);
-    uint32_t* const OFR = reinterpret_cast<uint32_t*>(smem + S8_OFR);
     uint32_t* const Z = reinterpret_cast<uint32_t*>(smem + S8_Z);
     double* const bk = reinterpret_cast<double*>(smem + S8_BK);
     uint32_t* const bi = reinterpret_cast<uint32_t*>(smem + S8_BI);
@@ -2015,23 +2013,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         LDS_ORDER();
         PHASE(1);
         // ---------------- neighbourhood header and member list: positions gl and gl + 8 of S[i]
-        int k = 0, m = 0, self = 0;
-        uint32_t sA = 0xffffff00u + (uint32_t)lane, sB = 0xffffff40u + (uint32_t)lane;
-        if (gvalid) {
-            const uint64_t hw = lb[0];
-            k = (int)(hw & 0xff);
-            m = (int)((hw >> 8) & 0xff);
-            self = (int)((hw >> 16) & 0xff);
-            if (gl < m) {
-                const uint64_t sw = lb[1 + (gl >> 1)];
-                sA = i + ((gl & 1) ? (uint32_t)(sw >> 32) : (uint32_t)sw);
-            }
-            if (gl + 8 < m) {
-                const uint64_t sw = lb[5 + (gl >> 1)];
-                sB = i + ((gl & 1) ? (uint32_t)(sw >> 32) : (uint32_t)sw);
-            }
-        }
-        const bool memberA = gvalid && gl < m, memberB = gvalid && gl + 8 < m;
+        // (straight-line: every lane reads its slot's words, the selects below sort out who is a member)
+        const uint32_t hw = gvalid ? (uint32_t)lb[0] : 0u;
+        const int k = (int)(hw & 0xff), m = (int)((hw >> 8) & 0xff), self = (int)((hw >> 16) & 0xff);
+        const bool memberA = gl < m, memberB = gl + 8 < m;  // (m = 0 in an empty slot)
+        const uint64_t swa = lb[1 + (gl >> 1)], swb = lb[5 + (gl >> 1)];
+        const uint32_t sA = memberA ? i + ((gl & 1) ? (uint32_t)(swa >> 32) : (uint32_t)swa) : 0xffffff00u + (uint32_t)lane;
+        const uint32_t sB = memberB ? i + ((gl & 1) ? (uint32_t)(swb >> 32) : (uint32_t)swb) : 0xffffff40u + (uint32_t)lane;
         PHASE(2);
         // All HBM loads of the iteration in ONE straight-line batch (no exec-masked regions: lanes without a record of their own
         // read i's, which coalesces with the group's other readers of it; empty slots read coordinate 0): the wait counters
@@ -2059,8 +2047,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         zg[gl] = sA;
         zg[8 + gl] = sB;
         const uint32_t sub = 1 + SW + (uint32_t)gl * R_;
-        double cj = 0.0;
-        if (gvalid && gl < k) cj = __longlong_as_double((long long)lb[sub + 2]);
+        const double cj = __longlong_as_double((long long)lb[sub + 2]);  // (used by lanes gl < k only)
 
         // ---------------- zone conflicts with earlier groups: id spans first, the exact id comparison only for pairs of groups
         // whose spans overlap
@@ -2068,10 +2055,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         uint64_t confball;
         {
             uint32_t lo = memberA ? sA : 0xffffffffu, hi = memberA ? sA : 0u;
-            if (memberB) {
-                lo = (sB < lo) ? sB : lo;
-                hi = (sB > hi) ? sB : hi;
-            }
+            lo = (memberB && sB < lo) ? sB : lo;
+            hi = (memberB && sB > hi) ? sB : hi;
             uint32_t o;
             o = dpp_u32<0xB1>(lo);   lo = (o < lo) ? o : lo;
             o = dpp_u32<0x4E>(lo);   lo = (o < lo) ? o : lo;
@@ -2101,7 +2086,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         PHASE(3);
 
         // ---------------- smove_forward!(G, i, ...), gradient, rates
-        if (gvalid && gl < k) {
+        // (every lane runs the move: lanes that hold no G1 member carry i's record and are re-loaded before they matter)
+        {
             const double dt = tp - t;
             const double xn = x + th * dt;
             I = I + dt * ((x + xn) * 0.5);
@@ -2111,49 +2097,45 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             sth[gl] = th;
         }
         LDS_ORDER();
-        double l = 0.0, lbound = 0.0;
+        double l, lbound;
         {
+            // Γ[:, i] . x in ascending row order; the template's entries past k are 0.0 and sx[0..7] are all finite numbers of
+            // this iteration, so the unconditional tail adds exact zeros
             double gr = 0.0;
 #pragma unroll
-            for (uint32_t p = 0; p < KMAX; ++p) {
-                if ((int)p < k) gr += __longlong_as_double((long long)lb[1 + SW + p * R_]) * sx[p];
-            }
-            if (gvalid) {
-                const double th_i = sth[self];
-                l = pos_part(gr * th_i);
-                lbound = pos_part(a_i + b_i * (tp - told_i));
-                if (gl == 0) {
-                    Lr[g] = l;
-                    LBr[g] = lbound;
-                }
+            for (uint32_t p = 0; p < KMAX; ++p) gr += __longlong_as_double((long long)lb[1 + SW + p * R_]) * sx[p];
+            const double th_i = sth[self];
+            l = pos_part(gr * th_i);
+            lbound = pos_part(a_i + b_i * (tp - told_i));
+            if (gl == 0) {
+                Lr[g] = l;
+                LBr[g] = lbound;
             }
         }
         LDS_ORDER();
         // ---------------- accept chain in time order.  Lane o evaluates every event's test for the draw at offset o; the ballots
         // are then walked on the scalar unit: event r reads its bit at the offset the earlier outcomes imply.
+        // The offsets (each <= 48) travel packed six bits apiece in one 64-bit scalar: offset after r events = bits 6r .. 6r+5.
         uint32_t accbits = 0;
+        uint64_t offpack = 0;
         {
             const double coin = U[(rng_off + (uint32_t)lane) & 63u];
             uint64_t am[E];
 #pragma unroll
             for (int r = 0; r < E; ++r) am[r] = __ballot(coin * LBr[r] < Lr[r]);  // :121
             uint32_t off = 0;
-            uint32_t offv = 0;
 #pragma unroll
-            for (int r = 0; r < E; ++r) {
-                offv = (lane == r) ? off : offv;
-                if (r < Esel) {
-                    const uint32_t a_r = (uint32_t)((am[r] >> off) & 1ull);
-                    const uint32_t k_r = readlane_u32((uint32_t)k, 8 * r);
-                    off += a_r ? (1u + k_r) : 2u;
-                    accbits |= a_r << r;
-                }
+            for (int r = 0; r < E; ++r) {  // slots >= Esel hold stale rates: their bits are masked off below, their offsets unused
+                const uint32_t a_r = (uint32_t)(am[r] >> off) & 1u;
+                const uint32_t k_r = readlane_u32((uint32_t)k, 8 * r);
+                off += a_r ? (1u + k_r) : 2u;
+                off = (off < 63u) ? off : 63u;  // (only stale slots can run past the window; keeps the shifts defined)
+                accbits |= a_r << r;
+                offpack |= (uint64_t)off << (6 * (r + 1));
             }
-            offv = (lane == E) ? off : offv;
-            if (lane <= E) OFR[lane] = offv;
+            accbits &= (1u << Esel) - 1u;
         }
-        LDS_ORDER();
-        const uint32_t myoff = OFR[g];
+        const uint32_t myoff = (uint32_t)(offpack >> (6 * g)) & 63u;
         const bool accept = gvalid && ((accbits >> g) & 1u) != 0;
         const bool violated = accept && (l >= lbound);  // :123
         PHASE(4);
@@ -2360,7 +2342,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         if (Rc > 0) {
             dnum += Rc;
             dnacc += nacc_c;
-            dnm += uniform_u32(OFR[Rc]);
+            dnm += (uint32_t)(offpack >> (6 * Rc)) & 63u;
             t_last = uniform_f64(SLT[Rc - 1]);
             if (accball2) t_event = uniform_f64(SLT[(63 - __builtin_clzll(accball2)) >> 3]);
         }
