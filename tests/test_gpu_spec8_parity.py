@@ -1,0 +1,84 @@
+"""The 8-events-per-iteration kernel of the north-star workload (d = 16384 lattice, zz_local_spec8_kernel) against the
+4-event kernel, the one-event kernel and the oracle: identical event sequences, counters and final states (-m gpu).
+
+The lattice's border coordinates (6 % of them) use other blob templates than the common one, so these runs also cover
+the kernel's spare template slots and the early end of a candidate list when an iteration holds more than two of them."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+MODES = (None, "spec4", "seq")  # None: the default dispatch = the 8-event kernel for this workload
+
+
+def _run_sliced(pkg, monkeypatch, mode, nch, cap, slices, seed0):
+    if mode is None:
+        monkeypatch.delenv("PDMP_KERNEL", raising=False)
+    else:
+        monkeypatch.setenv("PDMP_KERNEL", mode)
+    G = pkg.problems.gmrf_precision(128)
+    d = G.shape[0]
+    c = pkg.problems.column_norms(G)
+    evs = [[] for _ in range(nch)]
+    with pkg.Ensemble(nch, d, trace_capacity=cap) as ens:
+        ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
+        ens.set_target(pkg.GaussianTarget(G))
+        ens.set_state_synthetic(0.0, c, seed0)
+        for Tk, flag in slices:
+            while True:
+                ens.run(Tk, flag)
+                cnt = ens.counters()
+                if cap > 0:
+                    for k in range(nch):
+                        evs[k].append(ens.trace(k, counters=cnt))
+                    ens.trace_reset()
+                if not np.any(cnt["status"] == pkg._lib.CHAIN_TRACE_FULL):
+                    break
+        cnt = ens.counters()
+        fs = ens.final_state()
+    ev = [np.concatenate(e) if e else None for e in evs]
+    return G, c, ev, cnt, fs
+
+
+def test_sliced_runs_with_trace_refills_agree_across_kernels_and_with_the_oracle(gpu_pkg, monkeypatch):
+    pkg = gpu_pkg
+    T = 0.3
+    slices = ((0.11, pkg._lib.RUN_STOP_BEFORE), (0.2, pkg._lib.RUN_STOP_BEFORE), (T, pkg._lib.RUN_REFERENCE_TAIL))
+    nch, seed0 = 6, 0xABC000
+    runs = {m: _run_sliced(pkg, monkeypatch, m, nch, 1500, slices, seed0) for m in MODES}
+    G, c, ev8, cnt8, fs8 = runs[None]
+    assert np.all(cnt8["status"] == pkg._lib.CHAIN_OK)
+    for m in ("spec4", "seq"):
+        _, _, ev, cnt, fs = runs[m]
+        for f in ("num", "nacc", "nevents", "ndraw_main", "t_last", "status"):
+            assert np.array_equal(cnt8[f], cnt[f]), (m, f)
+        for f in ("t", "x", "theta", "acc"):
+            assert np.array_equal(fs8[f], fs[f]), (m, f)
+        for k in range(nch):
+            assert np.array_equal(ev8[k], ev[k]), (m, k)
+    d = G.shape[0]
+    for k in (0, nch - 1):
+        x0, th0 = O.synthetic_state(seed0 + k, d)
+        r = O.spdmp_zigzag(G, None, G, x0, th0, c, T, seed=seed0 + k)
+        assert len(ev8[k]) == len(r["events"]) and int(cnt8["num"][k]) == r["num"]
+        for f in ("t", "i", "x", "theta"):
+            assert np.array_equal(ev8[k][f], r["events"][f]), (k, f)
+        assert np.array_equal(fs8["x"][k], r["x"]) and np.array_equal(fs8["theta"][k], r["theta"])
+        assert np.array_equal(fs8["t"][k], r["t"]) and int(cnt8["ndraw_main"][k]) == r["ndraw_main"]
+        # border coordinates did fire (other templates than the common one were in play)
+        rows, cols = ev8[k]["i"] // 128, ev8[k]["i"] % 128
+        assert np.any((rows < 2) | (rows > 125) | (cols < 2) | (cols > 125))
+
+
+def test_count_only_mode_equals_traced_mode(gpu_pkg, monkeypatch):
+    pkg = gpu_pkg
+    slices = ((0.15, pkg._lib.RUN_STOP_BEFORE),)
+    _, _, _, cnt0, fs0 = _run_sliced(pkg, monkeypatch, None, 64, 0, slices, 77)
+    _, _, ev, cnt1, fs1 = _run_sliced(pkg, monkeypatch, None, 64, 4000, slices, 77)
+    for f in ("num", "nacc", "nevents", "ndraw_main", "t_last"):
+        assert np.array_equal(cnt0[f], cnt1[f]), f
+    for f in ("t", "x", "theta", "acc"):
+        assert np.array_equal(fs0[f], fs1[f]), f
+    assert all(len(ev[k]) == int(cnt1["nevents"][k]) for k in range(64))
