@@ -2064,24 +2064,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             o = dpp_u32<0xB1>(hi);   hi = (o > hi) ? o : hi;
             o = dpp_u32<0x4E>(hi);   hi = (o > hi) ? o : hi;
             o = dpp_u32<0x141>(hi);  hi = (o > hi) ? o : hi;
-            bool conflict = false;
-            const uint2* Z2 = reinterpret_cast<const uint2*>(Z);
+            // A pair of groups (q < g) whose spans overlap is compared exactly by the WHOLE wave: lane L holds id L & 15 of g
+            // against ids 4 (L >> 4) .. + 3 of q -- the 256 id pairs in four xor / two min instructions per lane.  Empty
+            // positions hold sentinels that equal nothing.
+            uint32_t confmask = 0;
+            const uint4* Z4 = reinterpret_cast<const uint4*>(Z);
 #pragma unroll
             for (int q = 0; q < E - 1; ++q) {
                 const uint32_t lq = readlane_u32(lo, 8 * q), hq = readlane_u32(hi, 8 * q);
-                const bool ov = gvalid && (q < g) && lo <= hq && lq <= hi;
-                if (__ballot(ov) != 0) {
-                    uint32_t mn = 0xffffffffu;  // min over q's sixteen ids of (id ^ mine): 0 iff one of them is mine
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const uint2 zz = Z2[q * 8 + j];
-                        mn = umin3(mn, zz.x ^ sA, zz.y ^ sA);
-                        mn = umin3(mn, zz.x ^ sB, zz.y ^ sB);
-                    }
-                    conflict = conflict || (ov && mn == 0u);
+                uint64_t ovb = __ballot(gvalid && (q < g) && gl == 0 && lo <= hq && lq <= hi);
+                while (ovb != 0) {
+                    const int gsel = (__ffsll((unsigned long long)ovb) - 1) >> 3;
+                    ovb &= ovb - 1;
+                    const uint32_t idg = Z[gsel * 16 + (lane & 15)];
+                    const uint4 zq = Z4[q * 4 + (lane >> 4)];
+                    const uint32_t mn = umin3(idg ^ zq.x, idg ^ zq.y, umin3(idg ^ zq.z, idg ^ zq.w, 0xffffffffu));
+                    if (__ballot(mn == 0u) != 0) confmask |= 1u << gsel;
                 }
             }
-            confball = __ballot(conflict);
+            confball = confmask;
         }
         PHASE(3);
 
@@ -2258,7 +2259,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 const double mq = Mr[q];
                 pref = (q < g) ? min_f64(pref, mq) : pref;
             }
-            const bool confg = ((confball >> (8 * g)) & 0xffull) != 0;
+            const bool confg = ((confball >> g) & 1ull) != 0;
             const bool okg = gvalid && ((g == 0) || (!confg && pref > tp));
             const bool vstop = violated;  // reference: error(...), :124 -> the event is not committed
             const uint64_t okball = __ballot(okg && !vstop && gl == 0);
