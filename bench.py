@@ -235,7 +235,7 @@ def main():
             "unhealthy_chains": bad_all,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "zz_local_spec_kernel", "kernel_ms_avg": k_ms,
+                         "kernel": "zz_local_spec8_kernel", "kernel_ms_avg": k_ms,
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "model": "224*num + 48*(num-nacc) + 616*nacc bytes (SURVEY 8d3)"},
         }
