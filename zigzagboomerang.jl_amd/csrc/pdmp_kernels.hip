@@ -1726,30 +1726,37 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P_in) {
 //   LDS       sx/sth and the zone ids live inside the patched-key area (dead until the re-bound has read them): 10 032 bytes
 //             per chain, 16 chains per CU.
 // Validation and commit rules are unchanged, so the committed sequence is bit-identical to the other kernels and the oracle.
-constexpr uint32_t S8_U = 0;        // [64] f64
-constexpr uint32_t S8_LU = 512;     // [64] f64
-constexpr uint32_t S8_PK = 1024;    // [8][64] f64 patched key blocks
-constexpr uint32_t S8_SXP = 18;             // doubles per group in sx / sth (16 + 2: eight groups on eight different banks)
-constexpr uint32_t S8_SX = S8_PK;           // [8][18] f64   (aliases PK)
-constexpr uint32_t S8_STH = S8_PK + 1152;   // [8][18] f64   (aliases PK)
-constexpr uint32_t S8_Z = S8_PK + 2304;     // [8][16] u32   (aliases PK)
-constexpr uint32_t S8_SLT = 5120;   // [8] f64 candidate keys
-constexpr uint32_t S8_LR = 5184;    // [8] f64 true rates
-constexpr uint32_t S8_LBR = 5248;   // [8] f64 bounds
-constexpr uint32_t S8_MR = 5312;    // [8] f64 what each event exposes
-constexpr uint32_t S8_SLB = 5376;   // [8] u32 candidate blocks
-constexpr uint32_t S8_LB = 5472;    // [3][58] u64 blob slots
-constexpr uint32_t S8_BK = S8_LB + 3 * 58 * 8;  // [256] f64
-constexpr uint32_t S8_BI = S8_BK + 256 * 8;     // [256] u32
-constexpr uint32_t SEL_CAP = 16;                // candidates ranked per iteration (power of two)
-constexpr uint32_t S8_TK = S8_BI + 256 * 4;     // [SEL_CAP] f64 candidate keys
-constexpr uint32_t S8_TB = S8_TK + SEL_CAP * 8; // [SEL_CAP] u32 their blocks
-constexpr uint32_t S8_SELDT = S8_TB + SEL_CAP * 4;  // f64 selection threshold above the minimum
-constexpr uint32_t S8_BYTES = S8_SELDT + 8;     // 10136
+constexpr uint32_t S8_LU = 0;       // [64] f64 logs of the draw window (the draws themselves stay in a register per lane)
+constexpr uint32_t S8_R = 512;      // 2816 bytes used in turn by: TK/TB (selection), zone ids + sx/sth, the patched key blocks
+constexpr uint32_t S8_SXP = 18;     // doubles per group in sx / sth (16 + 2: eight groups on eight different banks)
+constexpr uint32_t S8_SX = S8_R;            // [8][18] f64
+constexpr uint32_t S8_STH = S8_R + 1152;    // [8][18] f64
+constexpr uint32_t S8_Z = S8_R + 2304;      // [8][16] u32 zone ids
+constexpr uint32_t S8_PK = S8_R;            // [8][32] f64 patched key blocks (sx / sth / zone ids are dead by then)
+constexpr uint32_t SEL_CAP = 16;            // candidates ranked per iteration (power of two)
+constexpr uint32_t S8_TK = S8_R;            // [SEL_CAP] f64 candidate keys (selection only)
+constexpr uint32_t S8_TB = S8_R + SEL_CAP * 8;  // [SEL_CAP] u32 their blocks
+constexpr uint32_t S8_SLT = 3328;   // [8] f64 candidate keys
+constexpr uint32_t S8_LR = 3392;    // [8] f64 true rates
+constexpr uint32_t S8_LBR = 3456;   // [8] f64 bounds
+constexpr uint32_t S8_MR = 3520;    // [8] f64 what each event exposes
+constexpr uint32_t S8_SLB = 3584;   // [8] u32 candidate blocks
+constexpr uint32_t S8_LB = 3616;    // [3][58] u64 blob slots
+constexpr uint32_t S8_NBLK = 512;   // first-level entries: key blocks of 32 (four 64-byte sectors per popped block)
+constexpr uint32_t S8_BK = S8_LB + 3 * 58 * 8;      // [512] f64 block minima
+constexpr uint32_t S8_BI = S8_BK + S8_NBLK * 8;     // [512] u16 their coordinates (d = 16384)
+constexpr uint32_t S8_SELDT = S8_BI + S8_NBLK * 2;  // f64 selection threshold above the minimum
+constexpr uint32_t S8_BYTES = S8_SELDT + 8;         // 10136
 constexpr uint32_t S8_PR = S8_SLT;              // [16][4] u32 partial ranks (aliases SLT .. MR, which are written after the ranking)
 
 size_t zz_spec8_lds_bytes() { return S8_BYTES; }
 
+// value of lane `src` (any lane, per-lane choice): two ds_bpermute_b32
+__device__ __forceinline__ double bperm_f64(double v, uint32_t src) {
+    const int lo = __builtin_amdgcn_ds_bpermute((int)(src << 2), __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute((int)(src << 2), __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
 // minimum over the 8 lanes of a group, returned in every lane of the group
 __device__ __forceinline__ double grp8_min_f64(double v) {
     v = min_f64(v, dpp_f64<0xB1>(v));
@@ -1769,7 +1776,7 @@ __device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
 template <bool PROF>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void zz_local_spec8_kernel(ZzRunParams P) {
     constexpr int E = 8;
-    constexpr uint32_t SW = 7, PW = 1, KMAX = 5, R_ = 4 + PW + KMAX, WPAD = 58, W2 = WPAD / 2, nblk = 256;
+    constexpr uint32_t SW = 7, PW = 1, KMAX = 5, R_ = 4 + PW + KMAX, WPAD = 58, W2 = WPAD / 2, nblk = S8_NBLK;
     const int lane = threadIdx.x;
     const int g = lane >> 3;  // group = event slot
     const int gl = lane & 7;  // lane inside the group
@@ -1777,7 +1784,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const int64_t d = P.d;
 
     extern __shared__ __align__(16) unsigned char smem[];
-    double* const U = reinterpret_cast<double*>(smem + S8_U);
     double* const LU = reinterpret_cast<double*>(smem + S8_LU);
     double* const SLT = reinterpret_cast<double*>(smem + S8_SLT);
     double* const Lr = reinterpret_cast<double*>(smem + S8_LR);
@@ -1786,7 +1792,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     uint32_t* const SLB = reinterpret_cast<uint32_t*>(smem + S8_SLB);
     uint32_t* const Z = reinterpret_cast<uint32_t*>(smem + S8_Z);
     double* const bk = reinterpret_cast<double*>(smem + S8_BK);
-    uint32_t* const bi = reinterpret_cast<uint32_t*>(smem + S8_BI);
+    uint16_t* const bi = reinterpret_cast<uint16_t*>(smem + S8_BI);
     uint64_t* const LB = reinterpret_cast<uint64_t*>(smem + S8_LB);
     double* const TK = reinterpret_cast<double*>(smem + S8_TK);
     uint32_t* const TB = reinterpret_cast<uint32_t*>(smem + S8_TB);
@@ -1794,9 +1800,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     uint32_t* const PR = reinterpret_cast<uint32_t*>(smem + S8_PR);
     double* const sx = reinterpret_cast<double*>(smem + S8_SX) + g * S8_SXP;
     double* const sth = reinterpret_cast<double*>(smem + S8_STH) + g * S8_SXP;
-    double* const pk = reinterpret_cast<double*>(smem + S8_PK) + g * 64;
+    double* const pk = reinterpret_cast<double*>(smem + S8_PK) + g * 32;
     uint32_t* const zg = Z + g * 16;
-    const uint32_t pk_t = (((uint32_t)gl >> 2) & 1u) | (((uint32_t)g & 1u) << 1);
+    const uint32_t pk_t = (uint32_t)g & 1u;  // odd groups store the two 16-byte pieces of a lane's chunk swapped: no bank conflicts
 
     ZzRec* rec = P.rec + chain * d;
     double* keys = P.keys + chain * P.dk;
@@ -1825,11 +1831,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         reinterpret_cast<ulonglong2*>(LB)[lane] = reinterpret_cast<const ulonglong2*>(P.blob + (size_t)common * WPAD)[lane];
     }
     for (uint32_t b = lane; b < nblk; b += 64) {
-        const double* kp = keys + (size_t)b * 64;
+        const double* kp = keys + (size_t)b * 32;
         double mk = kp[0];
         uint32_t mi = 0;
 #pragma unroll 8
-        for (int q = 1; q < 64; ++q) {
+        for (int q = 1; q < 32; ++q) {
             const double v = kp[q];
             if (v < mk) {
                 mk = v;
@@ -1837,11 +1843,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             }
         }
         bk[b] = mk;
-        bi[b] = b * 64 + mi;
+        bi[b] = (uint16_t)(b * 32 + mi);
     }
     LDS_ORDER();
 
     uint32_t rng_base = 0xffffffffu;
+    double ureg = 0.0;  // draw rng_base + lane of the chain's stream
     uint64_t ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t ph_t0 = PROF ? (uint64_t)__builtin_readcyclecounter() : 0;
     uint64_t ph_iters = 0;
@@ -1869,70 +1876,58 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         int Esel = 0;
         bool first_inf = false;
         {
-            const double k0 = bk[lane], k1 = bk[lane + 64], k2 = bk[lane + 128], k3 = bk[lane + 192];
-            const double mloc = min_f64(min_f64(k0, k1), min_f64(k2, k3));
+            double kk[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) kk[j] = bk[lane + 64 * j];
+            const double mloc = min_f64(min_f64(min_f64(kk[0], kk[1]), min_f64(kk[2], kk[3])),
+                                        min_f64(min_f64(kk[4], kk[5]), min_f64(kk[6], kk[7])));
             const double mq = wave_min_f64(mloc);
             if (!(mq < PDMP_INF)) {
                 first_inf = true;
             } else if (!(stop_before && !(mq < T))) {
                 if (lane < (int)SEL_CAP) TK[lane] = PDMP_INF;
                 double dt_sel = uniform_f64(SELDT[0]);
-                uint64_t M0, M1, M2, M3;
-                bool c0, c1, c2, c3;
+                uint64_t M[8];
+                bool cc[8];
                 uint32_t C;
                 for (int tries = 0;; ++tries) {
-                    double tau = mq + dt_sel;
-                    if (stop_before) tau = (T < tau) ? T : tau;
+                    double tau = mq + dt_sel;  // (>= mq: the minimum itself always qualifies)
                     if (tries >= 64) tau = mq;  // a pile of exactly equal keys: the entries equal to the minimum only
-                    c0 = k0 < tau || k0 == mq;
-                    c1 = k1 < tau || k1 == mq;
-                    c2 = k2 < tau || k2 == mq;
-                    c3 = k3 < tau || k3 == mq;
-                    M0 = __ballot(c0);
-                    M1 = __ballot(c1);
-                    M2 = __ballot(c2);
-                    M3 = __ballot(c3);
-                    C = (uint32_t)(__popcll(M0) + __popcll(M1) + __popcll(M2) + __popcll(M3));
+                    C = 0;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        cc[j] = kk[j] <= tau && !(stop_before && !(kk[j] < T));
+                        M[j] = __ballot(cc[j]);
+                        C += (uint32_t)__popcll(M[j]);
+                    }
                     if (C <= SEL_CAP) break;
                     if (tries > 64) {  // more than SEL_CAP entries EQUAL to the minimum: one of them (lowest block) per iteration
-                        const uint64_t one = M0 ? (M0 & (~M0 + 1)) : 0ull;
-                        M1 = M0 ? 0ull : (M1 & (~M1 + 1));
-                        M2 = (M0 | M1) ? 0ull : (M2 & (~M2 + 1));
-                        M3 = (M0 | M1 | M2) ? 0ull : (M3 & (~M3 + 1));
-                        M0 = one;
-                        c0 = ((M0 >> lane) & 1ull) != 0;
-                        c1 = ((M1 >> lane) & 1ull) != 0;
-                        c2 = ((M2 >> lane) & 1ull) != 0;
-                        c3 = ((M3 >> lane) & 1ull) != 0;
+                        bool taken = false;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const uint64_t low = (!taken && M[j]) ? (M[j] & (~M[j] + 1)) : 0ull;
+                            taken = taken || (M[j] != 0);
+                            M[j] = low;
+                            cc[j] = ((M[j] >> lane) & 1ull) != 0;
+                        }
                         C = 1;
                         break;
                     }
                     dt_sel *= 0.5;
                 }
                 // compaction: entry (lane, j) gets index (candidates of slots < j) + (candidates of slot j in lower lanes)
-                const uint32_t b1 = (uint32_t)__popcll(M0), b2 = b1 + (uint32_t)__popcll(M1), b3 = b2 + (uint32_t)__popcll(M2);
                 auto below = [](uint64_t m_) -> uint32_t {
                     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_, 0u));
                 };
-                if (c0) {
-                    const uint32_t ix = below(M0);
-                    TK[ix] = k0;
-                    TB[ix] = (uint32_t)lane;
-                }
-                if (c1) {
-                    const uint32_t ix = b1 + below(M1);
-                    TK[ix] = k1;
-                    TB[ix] = (uint32_t)lane + 64u;
-                }
-                if (c2) {
-                    const uint32_t ix = b2 + below(M2);
-                    TK[ix] = k2;
-                    TB[ix] = (uint32_t)lane + 128u;
-                }
-                if (c3) {
-                    const uint32_t ix = b3 + below(M3);
-                    TK[ix] = k3;
-                    TB[ix] = (uint32_t)lane + 192u;
+                uint32_t base = 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (cc[j]) {
+                        const uint32_t ix = base + below(M[j]);
+                        TK[ix] = kk[j];
+                        TB[ix] = (uint32_t)lane + 64u * j;
+                    }
+                    base += (uint32_t)__popcll(M[j]);
                 }
                 LDS_ORDER();
                 // rank of candidate n among all (ties by index), on a 16 x 4 grid: lane = 16 * part + n counts the candidates
@@ -1975,15 +1970,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         bool gvalid = g < Esel;
         const double tp = gvalid ? SLT[g] : PDMP_INF;
         const uint32_t blk = gvalid ? SLB[g] : 0u;
-        const uint32_t i = gvalid ? bi[blk] : 0u;
+        const uint32_t i = gvalid ? (uint32_t)bi[blk] : 0u;
         const uint32_t tixi = gvalid ? P.tix[i] : common;
 
         // ---------------- candidate draws (window of 64 draws and their logs in LDS, as in zz_local_spec_kernel)
         if (dnm < rng_base || dnm + E * (1u + KMAX) > rng_base + 64u) {
             rng_base = dnm;
-            const double u = pdmp_u01(seed, PDMP_STREAM_MAIN, nm0 + (uint64_t)dnm + (uint64_t)lane);
-            U[lane] = u;
-            LU[lane] = pdmp_log(u);
+            ureg = pdmp_u01(seed, PDMP_STREAM_MAIN, nm0 + (uint64_t)dnm + (uint64_t)lane);
+            LU[lane] = pdmp_log(ureg);
         }
         const uint32_t rng_off = dnm - rng_base;
         // ---------------- blob slots: 0 for the common template, 1 and 2 for the first two events that need another one
@@ -2030,18 +2024,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         double x = rsA->x, th = rsA->th, t = rsA->t, I = rsA->I;
         const double told_i = ri->t_old, a_i = ri->a, b_i = ri->b;
         const uint64_t acc_i = ri->acc;
-        double kq[8];
+        double kq[4];
         {
-            const double2* kp = reinterpret_cast<const double2*>(keys + (size_t)blk * 64 + gl * 8);
-            const double2 k01 = kp[0], k23 = kp[1], k45 = kp[2], k67 = kp[3];
+            const double2* kp = reinterpret_cast<const double2*>(keys + (size_t)blk * 32 + gl * 4);
+            const double2 k01 = kp[0], k23 = kp[1];
             kq[0] = k01.x;
             kq[1] = k01.y;
             kq[2] = k23.x;
             kq[3] = k23.y;
-            kq[4] = k45.x;
-            kq[5] = k45.y;
-            kq[6] = k67.x;
-            kq[7] = k67.y;
         }
         rsA = rec + (memberA ? sA : i);
         zg[gl] = sA;
@@ -2120,7 +2110,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         uint32_t accbits = 0;
         uint64_t offpack = 0;
         {
-            const double coin = U[(rng_off + (uint32_t)lane) & 63u];
+            const double coin = bperm_f64(ureg, (rng_off + (uint32_t)lane) & 63u);
             uint64_t am[E];
 #pragma unroll
             for (int r = 0; r < E; ++r) am[r] = __ballot(coin * LBr[r] < Lr[r]);  // :121
@@ -2201,17 +2191,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         // (the four 16-byte pieces of a lane's 64-byte chunk are stored in the order piece ^ pk_t, pk_t = 0..3 over the four lanes
         // of a quarter wave that would otherwise share their banks: b128 accesses without bank conflicts)
         {
-            double2* pk2 = reinterpret_cast<double2*>(pk + gl * 8);
+            double2* pk2 = reinterpret_cast<double2*>(pk + gl * 4);
             pk2[0 ^ pk_t] = make_double2(kq[0], kq[1]);
             pk2[1 ^ pk_t] = make_double2(kq[2], kq[3]);
-            pk2[2 ^ pk_t] = make_double2(kq[4], kq[5]);
-            pk2[3 ^ pk_t] = make_double2(kq[6], kq[7]);
         }
         LDS_ORDER();
-        if (active && (sA >> 6) == blk) {
-            const uint32_t e_ = sA & 63u, ge_ = e_ >> 3;
-            const uint32_t t_ = ((ge_ >> 2) & 1u) | (((uint32_t)g & 1u) << 1);
-            pk[ge_ * 8u + ((((e_ & 7u) >> 1) ^ t_) << 1) + (e_ & 1u)] = key;
+        if (active && (sA >> 5) == blk) {
+            const uint32_t e_ = sA & 31u;
+            pk[(e_ & ~3u) + ((((e_ & 3u) >> 1) ^ pk_t) << 1) + (e_ & 1u)] = key;
         }
         LDS_ORDER();
         PHASE(5);
@@ -2220,8 +2207,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         uint32_t cand;
         int wl2;
         {
-            const double2* pk2 = reinterpret_cast<const double2*>(pk + gl * 8);
-            const double2 p01 = pk2[0 ^ pk_t], p23 = pk2[1 ^ pk_t], p45 = pk2[2 ^ pk_t], p67 = pk2[3 ^ pk_t];
+            const double2* pk2 = reinterpret_cast<const double2*>(pk + gl * 4);
+            const double2 p01 = pk2[0 ^ pk_t], p23 = pk2[1 ^ pk_t];
             double lm = p01.x;
             uint32_t li = 0;
 #define PMIN(v, idx)    \
@@ -2234,12 +2221,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             PMIN(p01.y, 1);
             PMIN(p23.x, 2);
             PMIN(p23.y, 3);
-            PMIN(p45.x, 4);
-            PMIN(p45.y, 5);
-            PMIN(p67.x, 6);
-            PMIN(p67.y, 7);
 #undef PMIN
-            cand = blk * 64u + (uint32_t)gl * 8u + li;
+            cand = blk * 32u + (uint32_t)gl * 4u + li;
             rowmin = grp8_min_f64(lm);
             const uint64_t winball = __ballot(gvalid && lm == rowmin);
             wl2 = __ffs((unsigned)((winball >> (8 * g)) & 0xffu)) - 1;
@@ -2313,7 +2296,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             if (accept && gl == self) rsA->acc = acc_i + 1;
             if (gl == wl2) {
                 bk[blk] = rowmin;
-                bi[blk] = cand;
+                bi[blk] = (uint16_t)cand;
             }
             if (accept && gl == self && ev) {
                 const uint32_t rank = (uint32_t)__popcll(accball2 & ((1ull << (8 * g)) - 1ull));
@@ -2334,8 +2317,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             const int kr = (int)readlane_u32((uint32_t)k, 8 * (int)r);
             for (int jj = 0; jj < kr; ++jj) {
                 const uint32_t j = readlane_u32(sA, 8 * (int)r + jj);
-                if ((j >> 6) == own) continue;
-                level1_update(bk, bi, keys, lane, j, readlane_f64(key, 8 * (int)r + jj));
+                if ((j >> 5) == own) continue;
+                // first-level entry of j's 32-key block: a lower key replaces it; if j WAS the entry and grew, the block is rescanned
+                const double kj = readlane_f64(key, 8 * (int)r + jj);
+                const uint32_t bj = j >> 5;
+                LDS_ORDER();
+                const double cur = bk[bj];
+                const uint32_t ci = bi[bj];
+                if (kj < cur || (kj == cur && j < ci)) {
+                    if (lane == 0) {
+                        bk[bj] = kj;
+                        bi[bj] = (uint16_t)j;
+                    }
+                } else if (ci == j) {
+                    const double kv = __hip_atomic_load(keys + (size_t)bj * 32 + (lane & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const double mn = wave_min_f64(kv);
+                    const uint64_t bl = __ballot(kv == mn);
+                    const int arg = bl ? (__ffsll((unsigned long long)bl) - 1) : 0;
+                    if (lane == 0) {
+                        bk[bj] = mn;
+                        bi[bj] = (uint16_t)(bj * 32 + (uint32_t)arg);
+                    }
+                }
             }
         }
         PHASE(8);
