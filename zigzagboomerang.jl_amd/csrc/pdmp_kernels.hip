@@ -1751,6 +1751,14 @@ constexpr uint32_t S8_PR = S8_SLT;              // [16][4] u32 partial ranks (al
 
 size_t zz_spec8_lds_bytes() { return S8_BYTES; }
 
+// the largest double below a finite x (x > 0, or x < 0, or x == 0 all handled by the integer image)
+__device__ __forceinline__ double pdmp_below(double x) {
+    long long b = __double_as_longlong(x);
+    if (x > 0) b -= 1;
+    else if (x < 0) b += 1;
+    else b = (long long)0x8000000000000001ull;  // -denorm_min
+    return __longlong_as_double(b);
+}
 // value of lane `src` (any lane, per-lane choice): two ds_bpermute_b32
 __device__ __forceinline__ double bperm_f64(double v, uint32_t src) {
     const int lo = __builtin_amdgcn_ds_bpermute((int)(src << 2), __double2loint(v));
@@ -1887,29 +1895,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             } else if (!(stop_before && !(mq < T))) {
                 if (lane < (int)SEL_CAP) TK[lane] = PDMP_INF;
                 double dt_sel = uniform_f64(SELDT[0]);
-                uint64_t M[8];
-                bool cc[8];
+                // (the candidate masks are recomputed where they are needed instead of being kept: eight 64-bit masks would
+                // crowd the scalar registers)
+                double tau;
                 uint32_t C;
+                bool pile = false;
                 for (int tries = 0;; ++tries) {
-                    double tau = mq + dt_sel;  // (>= mq: the minimum itself always qualifies)
+                    tau = mq + dt_sel;  // (>= mq: the minimum itself always qualifies)
+                    if (stop_before && !(tau < T)) tau = pdmp_below(T);
                     if (tries >= 64) tau = mq;  // a pile of exactly equal keys: the entries equal to the minimum only
                     C = 0;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        cc[j] = kk[j] <= tau && !(stop_before && !(kk[j] < T));
-                        M[j] = __ballot(cc[j]);
-                        C += (uint32_t)__popcll(M[j]);
-                    }
+                    for (int j = 0; j < 8; ++j) C += (uint32_t)__popcll(__ballot(kk[j] <= tau));
                     if (C <= SEL_CAP) break;
                     if (tries > 64) {  // more than SEL_CAP entries EQUAL to the minimum: one of them (lowest block) per iteration
-                        bool taken = false;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const uint64_t low = (!taken && M[j]) ? (M[j] & (~M[j] + 1)) : 0ull;
-                            taken = taken || (M[j] != 0);
-                            M[j] = low;
-                            cc[j] = ((M[j] >> lane) & 1ull) != 0;
-                        }
+                        pile = true;
                         C = 1;
                         break;
                     }
@@ -1922,12 +1922,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 uint32_t base = 0;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    if (cc[j]) {
-                        const uint32_t ix = base + below(M[j]);
+                    const bool cj_ = kk[j] <= tau;
+                    uint64_t Mj = __ballot(cj_);
+                    if (pile) Mj = (base == 0 && Mj) ? (Mj & (~Mj + 1)) : 0ull;
+                    if (cj_ && ((Mj >> lane) & 1ull)) {
+                        const uint32_t ix = base + below(Mj);
                         TK[ix] = kk[j];
                         TB[ix] = (uint32_t)lane + 64u * j;
                     }
-                    base += (uint32_t)__popcll(M[j]);
+                    base += (uint32_t)__popcll(Mj);
                 }
                 LDS_ORDER();
                 // rank of candidate n among all (ties by index), on a 16 x 4 grid: lane = 16 * part + n counts the candidates
@@ -2111,13 +2114,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         uint64_t offpack = 0;
         {
             const double coin = bperm_f64(ureg, (rng_off + (uint32_t)lane) & 63u);
-            uint64_t am[E];
-#pragma unroll
-            for (int r = 0; r < E; ++r) am[r] = __ballot(coin * LBr[r] < Lr[r]);  // :121
             uint32_t off = 0;
 #pragma unroll
             for (int r = 0; r < E; ++r) {  // slots >= Esel hold stale rates: their bits are masked off below, their offsets unused
-                const uint32_t a_r = (uint32_t)(am[r] >> off) & 1u;
+                const uint64_t am_r = __ballot(coin * LBr[r] < Lr[r]);  // :121
+                const uint32_t a_r = (uint32_t)(am_r >> off) & 1u;
                 const uint32_t k_r = readlane_u32((uint32_t)k, 8 * r);
                 off += a_r ? (1u + k_r) : 2u;
                 off = (off < 63u) ? off : 63u;  // (only stale slots can run past the window; keeps the shifts defined)
