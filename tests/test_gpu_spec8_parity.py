@@ -82,3 +82,41 @@ def test_count_only_mode_equals_traced_mode(gpu_pkg, monkeypatch):
     for f in ("t", "x", "theta", "acc"):
         assert np.array_equal(fs0[f], fs1[f]), f
     assert all(len(ev[k]) == int(cnt1["nevents"][k]) for k in range(64))
+
+
+def test_bound_violation_stops_the_chain_at_the_same_event_in_all_kernels(gpu_pkg, monkeypatch):
+    """c too small: the first proposal with l >= lbound that is accepted ends the chain (reference: error(...),
+    src/sfact.jl:124) -- same status, proposal count and trace prefix on the 8-event, 4-event and one-event kernels."""
+    pkg = gpu_pkg
+    G = pkg.problems.gmrf_precision(128)
+    d = G.shape[0]
+    c = 1e-3 * pkg.problems.column_norms(G)  # with the bound's precision 0.5 G < G the affine bound is too low
+    res = {}
+    for m in MODES:
+        if m is None:
+            monkeypatch.delenv("PDMP_KERNEL", raising=False)
+        else:
+            monkeypatch.setenv("PDMP_KERNEL", m)
+        with pkg.Ensemble(8, d, trace_capacity=20000) as ens:
+            ens.set_flow(pkg.ZigZag(0.5 * G, np.zeros(d)))
+            ens.set_target(pkg.GaussianTarget(G))
+            ens.set_state_synthetic(0.0, c, 4242)
+            ens.run(0.5, pkg._lib.RUN_STOP_BEFORE)
+            cnt = ens.counters()
+            res[m] = (cnt, [ens.trace(k, counters=cnt) for k in range(8)], ens.final_state())
+    cnt8, ev8, fs8 = res[None]
+    assert np.any(cnt8["status"] == pkg._lib.CHAIN_BOUND_VIOLATED)
+    for m in ("spec4", "seq"):
+        cnt, ev, fs = res[m]
+        for f in ("status", "num", "nacc", "nevents", "ndraw_main", "t_last"):
+            assert np.array_equal(cnt8[f], cnt[f]), (m, f)
+        for k in range(8):
+            assert np.array_equal(ev8[k], ev[k]), (m, k)
+        for f in ("t", "x", "theta"):
+            assert np.array_equal(fs8[f], fs[f]), (m, f)
+    # ... and it is the oracle's state at the violation (proposal counted, G[i] moved, nothing reflected or re-bounded)
+    k = int(np.flatnonzero(cnt8["status"] == pkg._lib.CHAIN_BOUND_VIOLATED)[0])
+    x0, th0 = O.synthetic_state(4242 + k, d)
+    r = O.spdmp_zigzag(0.5 * G, None, G, x0, th0, c, 0.5, seed=4242 + k, stop_before_T=True)
+    assert r["status"] != 0 and int(cnt8["num"][k]) == r["num"] and len(ev8[k]) == len(r["events"])
+    assert np.array_equal(fs8["x"][k], r["x"]) and np.array_equal(fs8["t"][k], r["t"]) and np.array_equal(fs8["theta"][k], r["theta"])

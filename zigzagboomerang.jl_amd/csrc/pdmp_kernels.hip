@@ -1326,6 +1326,7 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P_in) {
     const uint64_t seed = hdr->seed;
     const uint64_t nm0 = hdr->c.ndraw_main, ntrace0 = hdr->c.ntrace;
     uint32_t dnm = 0, dnum = 0, dnacc = 0;  // 32-bit deltas of this launch (a launch advances a chain by far < 2^32 draws)
+    uint32_t vnacc = 0;                     // 1 if the launch ends on a bound violation (acc is bumped before the check)
     double t_last = hdr->c.t_last;
     double t_event = hdr->t_event;
     status = PDMP_CHAIN_OK;
@@ -1593,6 +1594,7 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P_in) {
         // they produce or expose comes before it.  Per-lane evaluation + ballots; the prefix is resolved on the scalar unit.
         uint32_t Rc;
         uint32_t nacc_c;
+        int vsel = -1;  // the event that violates its bound, if it is the chain's next one
         {
             const double m0 = Mr[0], m1 = Mr[1], m2 = Mr[2];
             const double pref = (g == 0) ? PDMP_INF : (g == 1) ? m0 : (g == 2) ? min_f64(m0, m1) : min_f64(min_f64(m0, m1), m2);
@@ -1628,7 +1630,10 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P_in) {
                 }
             }
             // the first event that does not commit violates its bound (and nothing stopped the chain before it)
-            if (!stopped && r_ok < (uint32_t)E && ((vb >> r_ok) & 1u)) status = PDMP_CHAIN_BOUND_VIOLATED;
+            if (!stopped && r_ok < (uint32_t)E && ((vb >> r_ok) & 1u)) {
+                status = PDMP_CHAIN_BOUND_VIOLATED;
+                vsel = (int)r_ok;
+            }
         }
         PHASE(6);
 
@@ -1678,6 +1683,18 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P_in) {
             }
         }
         PHASE(8);
+        // ---------------- the violating proposal itself (reference: counted, G[i] moved, acc bumped -- then error(...), :120-124):
+        // what zz_local_run_kernel and the oracle leave behind
+        if (vsel >= 0) {
+            if (g == vsel && gl < k) {
+                rs->x = x;
+                rs->t = t;
+                rs->I = I;
+            }
+            dnum += 1;
+            vnacc = 1;
+            dnm += uniform_u32(OFR[vsel]) + 1u - (Rc > 0 ? uniform_u32(OFR[Rc]) : 0u);
+        }
         // ---------------- counters
         if (Rc > 0) {
             dnum += Rc;
@@ -1688,6 +1705,7 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P_in) {
                                              ((accball2 >> 45) & 8ull));
             if (accc) t_event = uniform_f64(SLT[31 - __builtin_clz(accc)]);
         }
+        if (vsel >= 0) t_last = uniform_f64(SLT[vsel]);  // the violating event's time is the chain's current time
         if (status != PDMP_CHAIN_OK) break;
         LDS_ORDER();
     }
@@ -1701,7 +1719,7 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P_in) {
         hdr->c.t_last = t_last;
         hdr->t_event = t_event;
         hdr->c.num += dnum;
-        hdr->c.nacc += dnacc;
+        hdr->c.nacc += dnacc + vnacc;
         hdr->c.ntrace = ntrace0 + dnacc;
         hdr->c.nevents += dnacc;
         hdr->c.ndraw_main = nm0 + dnm;
@@ -1822,6 +1840,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const uint64_t seed = hdr->seed;
     const uint64_t nm0 = hdr->c.ndraw_main, ntrace0 = hdr->c.ntrace;
     uint32_t dnm = 0, dnum = 0, dnacc = 0;
+    uint32_t vnacc = 0;  // 1 if the launch ends on a bound violation (acc is bumped before the check)
     double t_last = hdr->c.t_last;
     double t_event = hdr->t_event;
     status = PDMP_CHAIN_OK;
@@ -2236,6 +2255,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         // produce or expose comes before it
         uint32_t Rc;
         uint32_t nacc_c;
+        int vsel = -1;  // the event that violates its bound, if it is the chain's next one
         {
             double pref = PDMP_INF;
 #pragma unroll
@@ -2268,7 +2288,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                     }
                 }
             }
-            if (!stopped && r_ok < (uint32_t)E && ((vball >> (8 * r_ok)) & 1ull)) status = PDMP_CHAIN_BOUND_VIOLATED;
+            if (!stopped && r_ok < (uint32_t)E && ((vball >> (8 * r_ok)) & 1ull)) {
+                status = PDMP_CHAIN_BOUND_VIOLATED;
+                vsel = (int)r_ok;
+            }
         }
         PHASE(6);
 
@@ -2343,6 +2366,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             }
         }
         PHASE(8);
+        // ---------------- the violating proposal itself (reference: counted, G[i] moved, acc bumped -- then error(...), :120-124):
+        // what zz_local_run_kernel and the oracle leave behind
+        if (vsel >= 0) {
+            if (g == vsel && gl < k) {
+                rsA->x = x;
+                rsA->t = t;
+                rsA->I = I;
+            }
+            dnum += 1;
+            vnacc = 1;
+            dnm += ((uint32_t)(offpack >> (6 * vsel)) & 63u) + 1u - ((uint32_t)(offpack >> (6 * Rc)) & 63u);
+        }
         // ---------------- counters
         if (Rc > 0) {
             dnum += Rc;
@@ -2351,6 +2386,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             t_last = uniform_f64(SLT[Rc - 1]);
             if (accball2) t_event = uniform_f64(SLT[(63 - __builtin_clzll(accball2)) >> 3]);
         }
+        if (vsel >= 0) t_last = uniform_f64(SLT[vsel]);  // the violating event's time is the chain's current time
         if (status != PDMP_CHAIN_OK) break;
         LDS_ORDER();
     }
@@ -2364,7 +2400,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         hdr->c.t_last = t_last;
         hdr->t_event = t_event;
         hdr->c.num += dnum;
-        hdr->c.nacc += dnacc;
+        hdr->c.nacc += dnacc + vnacc;
         hdr->c.ntrace = ntrace0 + dnacc;
         hdr->c.nevents += dnacc;
         hdr->c.ndraw_main = nm0 + dnm;
