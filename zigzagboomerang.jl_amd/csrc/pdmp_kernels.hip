@@ -2765,6 +2765,8 @@ __global__ __launch_bounds__(64) void zz_sticky_spec_kernel(ZzRunParams P_in) {
         // ---------------- validate
         uint32_t Rc;
         uint32_t happb_c;  // bit r: committed event r is a trace event
+        int vsel = -1;       // the event that stops the chain with an error, if it is the chain's next one
+        bool vprop = false;  // ... and it is a proposal that violates its bound (not the x[i] != 0 check of a freeze)
         {
             const double m0 = Mr[0], m1 = Mr[1], m2 = Mr[2];
             const double pref = (g == 0) ? PDMP_INF : (g == 1) ? m0 : (g == 2) ? min_f64(m0, m1) : min_f64(min_f64(m0, m1), m2);
@@ -2800,7 +2802,11 @@ __global__ __launch_bounds__(64) void zz_sticky_spec_kernel(ZzRunParams P_in) {
                     }
                 }
             }
-            if (!stopped && r_ok < (uint32_t)E && ((vb >> r_ok) & 1u)) status = PDMP_CHAIN_BOUND_VIOLATED;
+            if (!stopped && r_ok < (uint32_t)E && ((vb >> r_ok) & 1u)) {
+                status = PDMP_CHAIN_BOUND_VIOLATED;
+                vsel = (int)r_ok;
+                vprop = ((bits4(__ballot(okg && violated && !adapt && !xerrg && gl == 0)) >> r_ok) & 1u) != 0;
+            }
         }
 
         // ---------------- commit the valid prefix
@@ -2876,6 +2882,21 @@ __global__ __launch_bounds__(64) void zz_sticky_spec_kernel(ZzRunParams P_in) {
             dnm += uniform_u32(OFR[Rc]);
             t_last = uniform_f64(SLT[Rc - 1]);
             if (happb_c) t_event = uniform_f64(SLT[31 - __builtin_clz(happb_c)]);
+        }
+        // the event the chain stops on (reference: error(...), :90 / :133): the proposal was counted, its coin drawn, acc bumped and
+        // G[i] moved before the check -- what zz_sticky_run_kernel and the oracle leave behind
+        if (vsel >= 0) {
+            if (vprop) {
+                if (g == vsel && gl < k) {
+                    rs->x = x;
+                    rs->t = t;
+                    rs->I = I;
+                }
+                num += 1;
+                nacc += 1;
+                dnm += uniform_u32(OFR[vsel]) + 1u - (Rc > 0 ? uniform_u32(OFR[Rc]) : 0u);
+            }
+            t_last = uniform_f64(SLT[vsel]);
         }
         if (status != PDMP_CHAIN_OK) break;
         LDS_ORDER();
