@@ -1732,17 +1732,21 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P_in) {
 // zz_local_spec_kernel's scheme with EIGHT event slots per iteration, one per 8-lane group, for the north-star workload (the
 // PLAIN configuration on the 128 x 128 lattice: |G1| <= 5 <= 8 lanes, |S| <= 13 <= 16 = two zone members per lane).  The
 // instruction stream of an iteration -- selection, loads, accept chain, validation, commit -- is issued once for eight events
-// instead of four, which is what the kernel is short of (instruction issue and dependent latency, not bandwidth).  What changes:
-//   select    every lane keeps its four first-level entries SORTED and may win several rounds, so the eight candidates are
-//             exactly the eight smallest block minima (no hidden second-best to carry into the validation bound)
+// instead of four.  The kernel sits at the memory system's random-sector rate and at the instruction issue rate of 4 waves per
+// SIMD at the same time, so both the sectors and the instructions per event count.  What changes:
+//   queue     the first level has 512 entries over key blocks of 32: a popped block is four 64-byte sectors, not eight
+//   select    one wave minimum m, then every first-level entry <= m + sel_dt is a candidate (compares + population counts);
+//             the candidates (<= 16, else sel_dt is halved) are compacted into LDS by ballot prefix counts and rank
+//             themselves against each other; ranks 0..7 become the slots.  The slots hold exactly the smallest entries in
+//             time order whatever sel_dt is, so there is no hidden second-best to carry into the validation bound
 //   templates slot 0 of the LDS blob area holds the lattice's common template for the whole launch; the (border) events of an
 //             iteration that need another one share two spare slots, a third such event ends the iteration's candidate list
 //   members   lane gl of a group owns zone positions gl and gl + 8; positions >= 8 are always G2-only (k <= 5), so their
-//             records are touched on accept only
+//             records are touched on accept only; all HBM loads of an iteration are one straight-line batch
 //   accept    every lane evaluates the thinning test of every event for the draw offset equal to its lane number; the ballots
 //             are walked on the scalar unit (offset of event r+1 = offset of r + 2 or 1 + k_r), no dependent LDS round trips
-//   LDS       sx/sth and the zone ids live inside the patched-key area (dead until the re-bound has read them): 10 032 bytes
-//             per chain, 16 chains per CU.
+//   LDS       10 136 bytes per chain = 16 chains per CU: the selection scratch, then zone ids + sx/sth, then the patched key
+//             blocks take turns in one 2816-byte area; pitches and piece order are chosen against bank conflicts
 // Validation and commit rules are unchanged, so the committed sequence is bit-identical to the other kernels and the oracle.
 constexpr uint32_t S8_LU = 0;       // [64] f64 logs of the draw window (the draws themselves stay in a register per lane)
 constexpr uint32_t S8_R = 512;      // 2816 bytes used in turn by: TK/TB (selection), zone ids + sx/sth, the patched key blocks
