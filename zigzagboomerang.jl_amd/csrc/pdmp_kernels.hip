@@ -1903,7 +1903,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         // population counts tell how many there are.  The candidates (at most SEL_CAP, else the threshold is halved) are compacted
         // into LDS by ballot prefix counts, each ranks itself against the others with broadcast reads, and ranks 0..E-1 become
         // the event slots.  Whatever sel_dt is, the slots hold exactly the smallest entries of the queue, so the committed
-        // sequence does not depend on it; it is steered towards ~10 candidates per iteration.
+        // sequence does not depend on it; it is steered towards ~12 candidates per iteration.
         int Esel = 0;
         bool first_inf = false;
         {
@@ -1982,7 +1982,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 }
                 Esel = (C < (uint32_t)E) ? (int)C : E;
                 // steer the threshold: ~10 candidates next time
-                const double f = (C > 12u) ? 0.75 : (C < 9u) ? ((C < 5u) ? 2.0 : 1.25) : 1.0;
+                const double f = (C > 14u) ? 0.8 : (C < 11u) ? ((C < 6u) ? 2.0 : 1.2) : 1.0;
                 if (lane == 0) SELDT[0] = dt_sel * f;
             }
         }
