@@ -213,6 +213,9 @@ def main():
         if os.path.exists(tpath):
             tp = json.load(open(tpath))
             traffic = tp["hbm_bytes_per_proposal"] * (num / args.steps)
+        # the measured ceiling for scattered 32-byte sectors (tools/sector_probe.py): what the traffic above can at most run at
+        spath = os.path.join(ROOT, "profiles", "r01_sector_probe.json")
+        scattered = json.load(open(spath)) if os.path.exists(spath) else None
         out = {
             "metric": "reflection events/sec, d=16384 local ZigZag (spdmp), ensemble of independent chains",
             "value": nev_all / elapsed,
@@ -236,6 +239,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "zz_local_spec8_kernel", "kernel_ms_avg": k_ms,
+                         "traffic_GBps": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
+                         "scattered_sector_ceiling_GBps": ({"read": scattered["read_GBps"],
+                                                            "read+writeback": scattered["read_plus_writeback_GBps"]}
+                                                           if scattered else None),
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "model": "224*num + 48*(num-nacc) + 616*nacc bytes (SURVEY 8d3)"},
         }

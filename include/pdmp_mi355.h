@@ -113,6 +113,13 @@ pdmp_status pdmp_debug_math_probe(int device, uint64_t seed, int64_t n, double* 
  */
 pdmp_status pdmp_debug_write_probe(int device, int64_t nchains, int64_t d, int64_t nrec, int iters, double* ms_out);
 
+/* Test/measurement hook: time per launch (ms) of a kernel that does nothing but the scattered record traffic of the local ZigZag
+ * event loop -- one wavefront per chain, every lane reads the 32-byte first half of 4 pseudo-random 64-byte records of its chain
+ * per round, `rounds` times, and with write != 0 stores them back changed.  nchains * d * 64 bytes are allocated for it.  The
+ * sector rate it reaches is the practical ceiling quoted beside the event loop's own. */
+pdmp_status pdmp_debug_sector_probe(int device, int64_t nchains, int64_t d, int rounds, int write, int iters,
+                                             double* ms_out);
+
 pdmp_status pdmp_ensemble_create(const pdmp_config* cfg, pdmp_ensemble** out);
 void pdmp_ensemble_destroy(pdmp_ensemble* ens);
 

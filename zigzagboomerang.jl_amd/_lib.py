@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = [
     "pdmp_ensemble_trace_reset", "pdmp_ensemble_final_state", "pdmp_ensemble_batch_means",
     "pdmp_ensemble_trace_dev", "pdmp_ensemble_counters_dev", "pdmp_debug_math_probe",
     "pdmp_ensemble_set_flow_bps", "pdmp_ensemble_set_state_bps", "pdmp_ensemble_bps_trace_copy",
-    "pdmp_ensemble_bps_final_state", "pdmp_ensemble_set_sticky", "pdmp_ensemble_set_adaptscale", "pdmp_ensemble_final_sigma", "pdmp_ensemble_set_flow_boomerang", "pdmp_ensemble_set_local_bound", "pdmp_debug_write_probe", "pdmp_ensemble_set_target_logistic", "pdmp_ensemble_set_flow_factboomerang",
+    "pdmp_ensemble_bps_final_state", "pdmp_ensemble_set_sticky", "pdmp_ensemble_set_adaptscale", "pdmp_ensemble_final_sigma", "pdmp_ensemble_set_flow_boomerang", "pdmp_ensemble_set_local_bound", "pdmp_debug_write_probe", "pdmp_debug_sector_probe", "pdmp_ensemble_set_target_logistic", "pdmp_ensemble_set_flow_factboomerang",
 ]
 
 
@@ -91,6 +91,7 @@ def load():
     L.pdmp_ensemble_counters_dev.argtypes = [vp, C.POINTER(vp)]
     L.pdmp_debug_math_probe.argtypes = [C.c_int, C.c_uint64, i64, vp]
     L.pdmp_debug_write_probe.argtypes = [C.c_int, i64, i64, i64, C.c_int, C.POINTER(C.c_double)]
+    L.pdmp_debug_sector_probe.argtypes = [C.c_int, i64, i64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
     L.pdmp_ensemble_set_target_logistic.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, f64, i64]
     L.pdmp_ensemble_set_sticky.argtypes = [vp, vp, C.c_int, C.c_int]
     L.pdmp_ensemble_set_adaptscale.argtypes = [vp, C.c_int]
@@ -118,6 +119,13 @@ def write_probe(nchains, d, nrec, iters=3, device=0):
     """ms per launch of the write-only kernel with the BPS event-record store pattern (HBM write ceiling)."""
     ms = C.c_double()
     check(load().pdmp_debug_write_probe(int(device), int(nchains), int(d), int(nrec), int(iters), C.byref(ms)))
+    return ms.value
+
+
+def sector_probe(nchains, d, rounds, write, iters=3, device=0):
+    """ms per launch of the random 32-byte-sector read (write != 0: read + write back) kernel: the scattered-traffic ceiling."""
+    ms = C.c_double()
+    check(load().pdmp_debug_sector_probe(int(device), int(nchains), int(d), int(rounds), int(write), int(iters), C.byref(ms)))
     return ms.value
 
 

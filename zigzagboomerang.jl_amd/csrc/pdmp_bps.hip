@@ -521,6 +521,51 @@ int launch_bps_write_probe(double* ev_x, double* ev_th, int64_t d, int64_t cap, 
     return (int)hipGetLastError();
 }
 
+// Random 32-byte-sector traffic of the local ZigZag kernels' record accesses, and nothing else: one wavefront per chain, every lane
+// reads the first half of four pseudo-random 64-byte records of its chain per round (and, with `write`, stores it back changed).
+// The rate this reaches is the practical ceiling for the scattered part of the event loop's memory traffic.
+__global__ __launch_bounds__(64) void sector_probe_kernel(double* rec, int64_t d, int rounds, int write, double* sink) {
+    const int lane = threadIdx.x;
+    const int64_t chain = blockIdx.x;
+    double* base = rec + chain * d * 8;
+    uint32_t h = (uint32_t)chain * 2654435761u + (uint32_t)lane * 40503u + 12345u;
+    double acc = 0.0;
+    for (int r = 0; r < rounds; ++r) {
+        double2* p[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            h = h * 1664525u + 1013904223u;
+            p[q] = reinterpret_cast<double2*>(base + (size_t)((h >> 8) % (uint32_t)d) * 8);
+        }
+        double2 a[4], b[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            a[q] = p[q][0];
+            b[q] = p[q][1];
+        }
+        if (write == 2) {  // whole 64-byte records (is a second 32-byte sector of the same record free?)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double2 c2 = p[q][2], d2 = p[q][3];
+                acc += c2.x + d2.y;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc += a[q].x + b[q].y;
+            if (write == 1) {
+                p[q][0] = make_double2(a[q].x + 1.0, a[q].y);
+                p[q][1] = make_double2(b[q].x, b[q].y + 1.0);
+            }
+        }
+    }
+    if (acc == 123.456) sink[0] = acc;
+}
+int launch_sector_probe(double* rec, int64_t d, int64_t nchains, int rounds, int write, double* sink, void* stream) {
+    hipLaunchKernelGGL(sector_probe_kernel, dim3((unsigned)nchains), dim3(64), 0, (hipStream_t)stream, rec, d, rounds, write, sink);
+    return (int)hipGetLastError();
+}
+
 int launch_bps_init(const BpsRunParams& p, int64_t nchains, const uint64_t* seeds, double t0, double c0, void* stream) {
     return dispatch(p, nchains, false, true, seeds, t0, c0, stream);
 }

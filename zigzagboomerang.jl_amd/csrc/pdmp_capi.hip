@@ -205,6 +205,36 @@ pdmp_status pdmp_debug_write_probe(int device, int64_t nchains, int64_t d, int64
     return PDMP_OK;
 }
 
+pdmp_status pdmp_debug_sector_probe(int device, int64_t nchains, int64_t d, int rounds, int write, int iters, double* ms_out) {
+    if (!ms_out || nchains <= 0 || d <= 0 || rounds <= 0 || iters <= 0) return fail(PDMP_ERR_INVALID, "bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+        return fail(PDMP_ERR_NO_DEVICE, "no HIP device visible: libpdmp_mi355 has no CPU fallback");
+    HIP_TRY(hipSetDevice(device));
+    DevBuf<double> rec, sink;
+    pdmp_status st;
+    if ((st = rec.alloc((size_t)(nchains * d * 8))) != PDMP_OK) return st;
+    if ((st = sink.alloc(8)) != PDMP_OK) return st;
+    HIP_TRY(hipMemset(rec.p, 0, (size_t)(nchains * d * 8) * sizeof(double)));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    pdmp::launch_sector_probe(rec.p, d, nchains, rounds, write, sink.p, nullptr);  // warm-up
+    HIP_TRY(hipEventRecord(e0, nullptr));
+    for (int k = 0; k < iters; ++k) {
+        int rc = pdmp::launch_sector_probe(rec.p, d, nchains, rounds, write, sink.p, nullptr);
+        if (rc != 0) return fail(PDMP_ERR_HIP, "sector probe launch failed (%d)", rc);
+    }
+    HIP_TRY(hipEventRecord(e1, nullptr));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *ms_out = (double)ms / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return PDMP_OK;
+}
+
 pdmp_status pdmp_debug_math_probe(int device, uint64_t seed, int64_t n, double* out) {
     if (!out || n <= 0) return fail(PDMP_ERR_INVALID, "bad argument");
     int ndev = 0;

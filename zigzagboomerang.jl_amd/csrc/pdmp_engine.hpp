@@ -179,6 +179,7 @@ struct BpsRunParams {
     const double* __restrict__ mu_flow;  // [d]
 };
 int launch_bps_write_probe(double* ev_x, double* ev_th, int64_t d, int64_t cap, int64_t nrec, int64_t nchains, void* stream);
+int launch_sector_probe(double* rec, int64_t d, int64_t nchains, int rounds, int write, double* sink, void* stream);
 int launch_bps_init(const BpsRunParams& p, int64_t nchains, const uint64_t* seeds, double t0, double c0, void* stream);
 int launch_bps_run(const BpsRunParams& p, int64_t nchains, bool diag, void* stream);
 
