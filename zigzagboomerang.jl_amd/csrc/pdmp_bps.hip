@@ -543,17 +543,21 @@ __global__ __launch_bounds__(64) void sector_probe_kernel(double* rec, int64_t d
             a[q] = p[q][0];
             b[q] = p[q][1];
         }
-        if (write == 2) {  // whole 64-byte records (is a second 32-byte sector of the same record free?)
+        if (write >= 2) {  // whole 64-byte records (is a second 32-byte sector of the same record free?)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const double2 c2 = p[q][2], d2 = p[q][3];
                 acc += c2.x + d2.y;
+                if (write == 3) {  // ... and written back whole
+                    p[q][2] = make_double2(c2.x + 1.0, c2.y);
+                    p[q][3] = make_double2(d2.x, d2.y + 1.0);
+                }
             }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             acc += a[q].x + b[q].y;
-            if (write == 1) {
+            if (write == 1 || write == 3) {
                 p[q][0] = make_double2(a[q].x + 1.0, a[q].y);
                 p[q][1] = make_double2(b[q].x, b[q].y + 1.0);
             }
