@@ -13,12 +13,12 @@ pytestmark = pytest.mark.gpu
 MODES = (None, "spec4", "seq")  # None: the default dispatch = the 8-event kernel for this workload
 
 
-def _run_sliced(pkg, monkeypatch, mode, nch, cap, slices, seed0):
+def _run_sliced(pkg, monkeypatch, mode, nch, cap, slices, seed0, n=128):
     if mode is None:
         monkeypatch.delenv("PDMP_KERNEL", raising=False)
     else:
         monkeypatch.setenv("PDMP_KERNEL", mode)
-    G = pkg.problems.gmrf_precision(128)
+    G = pkg.problems.gmrf_precision(n)
     d = G.shape[0]
     c = pkg.problems.column_norms(G)
     evs = [[] for _ in range(nch)]
@@ -141,3 +141,28 @@ def test_many_chains_longer_run_three_kernels_agree(gpu_pkg, monkeypatch):
         dig[m] = (h.hexdigest(), int(cnt["num"].sum()), int(np.sum(cnt["status"] != 0)))
     assert dig[None][2] == 0 and dig[None][1] > 1.2e7
     assert dig[None] == dig["spec4"] == dig["seq"], dig
+
+
+@pytest.mark.parametrize("n,T", [(46, 1.5), (64, 1.0), (100, 0.5), (127, 0.3)])
+def test_other_lattice_sizes_use_the_same_kernel(gpu_pkg, monkeypatch, n, T):
+    """The 8-event kernel serves every n x n lattice with 2048 <= d <= 16384 (its first level covers ceil(d / 32) blocks, the
+    rest stay +Inf): d = 2116 (not a multiple of 32), 4096, 10 000, 16 129 against the other kernels and the oracle."""
+    pkg = gpu_pkg
+    slices = ((0.4 * T, pkg._lib.RUN_STOP_BEFORE), (T, pkg._lib.RUN_REFERENCE_TAIL))
+    runs = {m: _run_sliced(pkg, monkeypatch, m, 5, 3000, slices, 9000 + n, n=n) for m in MODES}
+    G, c, ev8, cnt8, fs8 = runs[None]
+    d = G.shape[0]
+    assert np.all(cnt8["status"] == pkg._lib.CHAIN_OK)
+    for m in ("spec4", "seq"):
+        _, _, ev, cnt, fs = runs[m]
+        for f in ("num", "nacc", "nevents", "ndraw_main", "t_last"):
+            assert np.array_equal(cnt8[f], cnt[f]), (m, f)
+        for f in ("t", "x", "theta", "acc"):
+            assert np.array_equal(fs8[f], fs[f]), (m, f)
+        for k in range(5):
+            assert np.array_equal(ev8[k], ev[k]), (m, k)
+    x0, th0 = O.synthetic_state(9000 + n, d)
+    r = O.spdmp_zigzag(G, None, G, x0, th0, c, T, seed=9000 + n)
+    assert len(ev8[0]) == len(r["events"]) and int(cnt8["num"][0]) == r["num"]
+    for f in ("t", "i", "x", "theta"):
+        assert np.array_equal(ev8[0][f], r["events"][f]), f

@@ -543,7 +543,7 @@ __global__ __launch_bounds__(64) void sector_probe_kernel(double* rec, int64_t d
             a[q] = p[q][0];
             b[q] = p[q][1];
         }
-        if (write >= 2) {  // whole 64-byte records (is a second 32-byte sector of the same record free?)
+        if (write == 2 || write == 3) {  // whole 64-byte records (is a second 32-byte sector of the same record free?)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const double2 c2 = p[q][2], d2 = p[q][3];

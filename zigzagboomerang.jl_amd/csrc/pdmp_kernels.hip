@@ -1806,7 +1806,8 @@ __device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
 template <bool PROF>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void zz_local_spec8_kernel(ZzRunParams P) {
     constexpr int E = 8;
-    constexpr uint32_t SW = 7, PW = 1, KMAX = 5, R_ = 4 + PW + KMAX, WPAD = 58, W2 = WPAD / 2, nblk = S8_NBLK;
+    constexpr uint32_t SW = 7, PW = 1, KMAX = 5, R_ = 4 + PW + KMAX, WPAD = 58, W2 = WPAD / 2;
+    const uint32_t nblk = P.nblk;  // 32-key blocks that hold coordinates (<= S8_NBLK); first-level entries beyond stay +Inf
     const int lane = threadIdx.x;
     const int g = lane >> 3;  // group = event slot
     const int gl = lane & 7;  // lane inside the group
@@ -1875,6 +1876,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
         bk[b] = mk;
         bi[b] = (uint16_t)(b * 32 + mi);
+    }
+    for (uint32_t b = nblk + lane; b < S8_NBLK; b += 64) {
+        bk[b] = PDMP_INF;
+        bi[b] = 0;
     }
     LDS_ORDER();
 
@@ -3016,10 +3021,15 @@ int launch_zz_local_spec(const ZzRunParams& p, int64_t nchains, void* stream) {
     const bool plain4 = plain && !p.has_refresh && p.d == 256 * 64 && p.nblk == 257;
     // PDMP_KERNEL=spec4 keeps the 4-events-per-iteration kernel for the lattice workload (A/B runs, tests)
     const char* force = getenv("PDMP_KERNEL");
-    const bool spec8 = plain4 && p.common_tix != 0xffffffffu && !(force && strcmp(force, "spec4") == 0);
+    // the 8-event kernel: the lattice blob geometry, no refresh clock, 2048 <= d <= 16384 (its first level has 512 entries over
+    // 32-key blocks; below 64 blocks there are too few candidates for eight slots)
+    const bool spec8 = plain && !p.has_refresh && p.d >= 2048 && p.d <= (int64_t)S8_NBLK * 32 &&
+                       !(force && strcmp(force, "spec4") == 0);
     if (spec8) {
-        if (p.dbg) hipLaunchKernelGGL((zz_local_spec8_kernel<true>), grid, block, zz_spec8_lds_bytes(), (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((zz_local_spec8_kernel<false>), grid, block, zz_spec8_lds_bytes(), (hipStream_t)stream, p);
+        ZzRunParams q = p;
+        q.nblk = (uint32_t)((p.d + 31) / 32);
+        if (p.dbg) hipLaunchKernelGGL((zz_local_spec8_kernel<true>), grid, block, zz_spec8_lds_bytes(), (hipStream_t)stream, q);
+        else hipLaunchKernelGGL((zz_local_spec8_kernel<false>), grid, block, zz_spec8_lds_bytes(), (hipStream_t)stream, q);
     } else if (p.dbg) {  // per-phase cycle profile (PDMP_PHASE env)
         if (plain4) {
             ZzRunParams q = p;
