@@ -191,3 +191,15 @@ def test_sticky_logistic_spike_and_slab(gpu_pkg, kernel_mode):
         assert (int(acc[k]), int(num[k])) == (r["nacc"], r["num"]) and np.array_equal(cout[k], r["c"])
         assert np.array_equal(x[k], r["x"]) and np.array_equal(th[k], r["theta"]) and np.array_equal(t[k], r["t"])
         assert 0.2 < np.mean(r["theta"] == 0) < 0.95  # a good share of the coefficients sits in the spike
+
+
+@pytest.mark.parametrize("n,T", [(46, 6.0), (100, 1.5)])
+def test_sticky_on_larger_lattices(gpu_pkg, n, T):
+    """Lattices of several key blocks (d = 2116 is not a multiple of 64; d = 10 000 is config C5's size)."""
+    pkg = gpu_pkg
+    G = pkg.problems.gmrf_precision(n)
+    d = n * n
+    rng = np.random.default_rng(n)
+    x0 = rng.standard_normal((3, d))
+    th0 = rng.choice([-1.0, 1.0], (3, d))
+    check(pkg, G, G, None, x0, th0, pkg.problems.column_norms(G), 0.3 + rng.random(d), T, seed=500 + n)
