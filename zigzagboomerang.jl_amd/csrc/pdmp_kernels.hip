@@ -1771,6 +1771,11 @@ constexpr uint32_t S8_SELDT = S8_BI + S8_NBLK * 2;  // f64 selection threshold a
 constexpr uint32_t S8_BYTES = S8_SELDT + 8;         // 10136
 constexpr uint32_t S8_PR = S8_SLT;              // [16][4] u32 partial ranks (aliases SLT .. MR, which are written after the ranking)
 
+static_assert(S8_BYTES <= 10240, "the 8-event kernel needs 16 workgroups per CU: 160 KB / 16");
+static_assert(S8_R + 2816 <= S8_SLT && S8_Z + 8 * 16 * 4 <= S8_SLT && S8_PK + 8 * 32 * 8 <= S8_SLT, "shared scratch area overflows");
+static_assert(S8_TB + SEL_CAP * 4 <= S8_Z, "selection scratch must not reach the zone ids");
+static_assert(S8_SLB + 8 * 4 <= S8_LB && (S8_LB % 16) == 0 && (S8_BK % 16) == 0 && (S8_STH % 16) == 0 && (S8_Z % 16) == 0,
+              "LDS sub-arrays must stay 16-byte aligned");
 size_t zz_spec8_lds_bytes() { return S8_BYTES; }
 
 // the largest double below a finite x (x > 0, or x < 0, or x == 0 all handled by the integer image)
