@@ -13,9 +13,9 @@ pkg = load_package()
 d, rounds = 16384, 1000
 for nch in [int(a) for a in sys.argv[1:]] or [4096]:
     out = {"nchains": nch}
-    for write in (0, 1, 2, 3):
+    for write in (0, 1, 2, 3, 5, 6):
         ms = pkg._lib.sector_probe(nch, d, rounds, write)
-        sectors = nch * 64 * 4 * rounds * (1, 2, 2, 4)[write]  # 32-byte sector operations
-        out[("read", "read+write", "read 64 B records", "read+write 64 B records")[write]] = {"ms": round(ms, 3), "sectors_per_s": sectors / (ms * 1e-3),
+        sectors = nch * 64 * 4 * rounds * {0: 1, 1: 2, 2: 2, 3: 4, 5: 3, 6: 3}[write]  # 32-byte sector operations
+        out[{0: "read", 1: "read+write", 2: "read 64 B records", 3: "read+write 64 B records", 5: "read 3 hot halves at 64 B pitch", 6: "read 3 hot halves packed"}[write]] = {"ms": round(ms, 3), "sectors_per_s": sectors / (ms * 1e-3),
                                                    "GB_per_s": sectors * 32 / (ms * 1e-3) / 1e9}
     print(json.dumps(out))

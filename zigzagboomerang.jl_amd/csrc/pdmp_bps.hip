@@ -535,13 +535,21 @@ __global__ __launch_bounds__(64) void sector_probe_kernel(double* rec, int64_t d
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             h = h * 1664525u + 1013904223u;
-            p[q] = reinterpret_cast<double2*>(base + (size_t)((h >> 8) % (uint32_t)d) * 8);
+            p[q] = reinterpret_cast<double2*>(base + (size_t)((h >> 8) % (uint32_t)(d - 4)) * 8);
         }
         double2 a[4], b[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             a[q] = p[q][0];
             b[q] = p[q][1];
+        }
+        if (write == 5 || write == 6) {  // a lattice row's three neighbours: hot halves at 64-byte pitch (5) or packed at 32 (6)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const size_t pitch = (write == 5) ? 4 : 2;  // in double2 units
+                const double2 l0 = p[q][pitch], l1 = p[q][pitch + 1], r0 = p[q][2 * pitch], r1 = p[q][2 * pitch + 1];
+                acc += l0.x + l1.y + r0.x + r1.y;
+            }
         }
         if (write == 2 || write == 3) {  // whole 64-byte records (is a second 32-byte sector of the same record free?)
 #pragma unroll
