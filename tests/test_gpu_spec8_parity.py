@@ -166,3 +166,37 @@ def test_other_lattice_sizes_use_the_same_kernel(gpu_pkg, monkeypatch, n, T):
     assert len(ev8[0]) == len(r["events"]) and int(cnt8["num"][0]) == r["num"]
     for f in ("t", "i", "x", "theta"):
         assert np.array_equal(ev8[0][f], r["events"][f]), f
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_adapt_and_target_mean_on_a_lattice_of_spec8_size(gpu_pkg, monkeypatch, mode):
+    """`adapt = true` with bounds that are too small at first (c is multiplied by `factor` on violations, returned per chain) and a
+    target with a mean: the 8-event kernel's second instantiation, the 4-event and the one-event kernel against the oracle."""
+    pkg = gpu_pkg
+    if mode is None:
+        monkeypatch.delenv("PDMP_KERNEL", raising=False)
+    else:
+        monkeypatch.setenv("PDMP_KERNEL", mode)
+    n = 48
+    G = pkg.problems.gmrf_precision(n)
+    d = n * n
+    rng = np.random.default_rng(48)
+    x0 = rng.standard_normal((3, d))
+    th0 = rng.choice([-1.0, 1.0], (3, d))
+    mu_t = 0.2 * rng.standard_normal(d)
+    c = 0.05 * pkg.problems.column_norms(G)
+    T, seed = 1.2, 4800
+    Z = pkg.ZigZag(0.8 * G, np.zeros(d))
+    tr, fs, (acc, num), cout = pkg.spdmp(pkg.GaussianTarget(G, mu_t), 0.0, x0, th0, T, c, Z, seed=seed, adapt=True, factor=1.7)
+    grew = 0
+    for k in range(3):
+        r = O.spdmp_zigzag(0.8 * G, None, G, x0[k], th0[k], c, T, seed=seed + k, adapt=True, factor=1.7, target_mu=mu_t)
+        assert r["status"] == 0
+        ev, oe = tr[k].events, r["events"]
+        assert len(ev) == len(oe) and int(num[k]) == r["num"]
+        for f in ("i", "t", "x", "theta"):
+            assert np.array_equal(ev[f], oe[f]), (k, f)
+        assert np.array_equal(fs[0][k], r["t"]) and np.array_equal(fs[1][k], r["x"]) and np.array_equal(fs[2][k], r["theta"])
+        assert np.array_equal(acc[k], r["acc"]) and np.array_equal(cout[k], r["c"])
+        grew += int(np.count_nonzero(cout[k] != c))
+    assert grew > 0  # the adaptation did happen

@@ -1808,7 +1808,9 @@ __device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true);
 }
 
-template <bool PROF>
+// FULL: also `adapt` (per-chain bounds c, multiplied by `factor` when a proposal violates its bound, src/fact_samplers.jl:67-70)
+// and a target with a mean (Γμ subtracted from the gradient); the north-star instantiation has neither.
+template <bool PROF, bool FULL = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void zz_local_spec8_kernel(ZzRunParams P) {
     constexpr int E = 8;
     constexpr uint32_t SW = 7, PW = 1, KMAX = 5, R_ = 4 + PW + KMAX, WPAD = 58, W2 = WPAD / 2;
@@ -1844,6 +1846,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     double* keys = P.keys + chain * P.dk;
     DevChain* hdr = P.hdr + chain;
     pdmp_event* ev = P.ev ? P.ev + chain * P.trace_cap : nullptr;
+    double* cmut = (FULL && P.c_chain) ? (P.c_chain + chain * d) : nullptr;
+    const bool adapt = FULL && P.adapt != 0;
 
     uint32_t status = hdr->c.status;
     if (status == PDMP_CHAIN_BOUND_VIOLATED || status == PDMP_CHAIN_STALLED) return;
@@ -2073,7 +2077,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         zg[gl] = sA;
         zg[8 + gl] = sB;
         const uint32_t sub = 1 + SW + (uint32_t)gl * R_;
-        const double cj = __longlong_as_double((long long)lb[sub + 2]);  // (used by lanes gl < k only)
+        double cj = __longlong_as_double((long long)lb[sub + 2]);  // (used by lanes gl < k only)
+        if (FULL && cmut) cj = cmut[(gl < k) ? sA : i];
 
         // ---------------- zone conflicts with earlier groups: id spans first, the exact id comparison only for pairs of groups
         // whose spans overlap
@@ -2131,6 +2136,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             double gr = 0.0;
 #pragma unroll
             for (uint32_t p = 0; p < KMAX; ++p) gr += __longlong_as_double((long long)lb[1 + SW + p * R_]) * sx[p];
+            if (FULL && P.tb.gmu_t) gr = gr - P.tb.gmu_t[i];
             const double th_i = sth[self];
             l = pos_part(gr * th_i);
             lbound = pos_part(a_i + b_i * (tp - told_i));
@@ -2215,6 +2221,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                     gt += v * sth[ps];
                 }
             }
+            if (FULL && violated && gl == self) cj *= P.factor;  // adapt!(c, i, factor), :127 (stored at commit)
             a = cj + (gx - gmu) * th;
             b = cj / 100 + th * gt;
             const double L = LU[(rng_off + myoff + 1u + (accept ? (uint32_t)gl : 0u)) & 63u];
@@ -2279,7 +2286,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             }
             const bool confg = ((confball >> g) & 1ull) != 0;
             const bool okg = gvalid && ((g == 0) || (!confg && pref > tp));
-            const bool vstop = violated;  // reference: error(...), :124 -> the event is not committed
+            const bool vstop = violated && !adapt;  // reference: error(...), :124 -> the event is not committed
             const uint64_t okball = __ballot(okg && !vstop && gl == 0);
             const uint64_t vball = __ballot(okg && vstop && gl == 0);
             const uint64_t accball = __ballot(accept && gl == 0);
@@ -2330,6 +2337,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 rsA->a = a;
                 rsA->b = b;
                 keys[sA] = key;
+                if (FULL && violated && gl == self) cmut[sA] = cj;
             }
             if (accept && gl == self) rsA->acc = acc_i + 1;
             if (gl == wl2) {
@@ -3028,13 +3036,16 @@ int launch_zz_local_spec(const ZzRunParams& p, int64_t nchains, void* stream) {
     const char* force = getenv("PDMP_KERNEL");
     // the 8-event kernel: the lattice blob geometry, no refresh clock, 2048 <= d <= 16384 (its first level has 512 entries over
     // 32-key blocks; below 64 blocks there are too few candidates for eight slots)
-    const bool spec8 = plain && !p.has_refresh && p.d >= 2048 && p.d <= (int64_t)S8_NBLK * 32 &&
+    const bool geom = (p.flags & 0x100) && p.blob_sw == 7 && p.blob_pw == 1 && p.blob_kmax == 5 && p.blob_w_pad == 58;
+    const bool spec8 = geom && !p.has_refresh && p.d >= 2048 && p.d <= (int64_t)S8_NBLK * 32 &&
                        !(force && strcmp(force, "spec4") == 0);
     if (spec8) {
         ZzRunParams q = p;
         q.nblk = (uint32_t)((p.d + 31) / 32);
-        if (p.dbg) hipLaunchKernelGGL((zz_local_spec8_kernel<true>), grid, block, zz_spec8_lds_bytes(), (hipStream_t)stream, q);
-        else hipLaunchKernelGGL((zz_local_spec8_kernel<false>), grid, block, zz_spec8_lds_bytes(), (hipStream_t)stream, q);
+        if (p.dbg && plain) hipLaunchKernelGGL((zz_local_spec8_kernel<true>), grid, block, zz_spec8_lds_bytes(), (hipStream_t)stream, q);
+        else if (p.dbg) hipLaunchKernelGGL((zz_local_spec8_kernel<true, true>), grid, block, zz_spec8_lds_bytes(), (hipStream_t)stream, q);
+        else if (plain) hipLaunchKernelGGL((zz_local_spec8_kernel<false>), grid, block, zz_spec8_lds_bytes(), (hipStream_t)stream, q);
+        else hipLaunchKernelGGL((zz_local_spec8_kernel<false, true>), grid, block, zz_spec8_lds_bytes(), (hipStream_t)stream, q);
     } else if (p.dbg) {  // per-phase cycle profile (PDMP_PHASE env)
         if (plain4) {
             ZzRunParams q = p;
