@@ -1768,7 +1768,8 @@ constexpr uint32_t S8_NBLK = 512;   // first-level entries: key blocks of 32 (fo
 constexpr uint32_t S8_BK = S8_LB + 3 * 58 * 8;      // [512] f64 block minima
 constexpr uint32_t S8_BI = S8_BK + S8_NBLK * 8;     // [512] u16 their coordinates (d = 16384)
 constexpr uint32_t S8_SELDT = S8_BI + S8_NBLK * 2;  // f64 selection threshold above the minimum
-constexpr uint32_t S8_BYTES = S8_SELDT + 8;         // 10136
+constexpr uint32_t S8_CL = S8_SELDT + 8;            // [64] u8 claims of the parallel first-level update
+constexpr uint32_t S8_BYTES = S8_CL + 64;           // 10200
 constexpr uint32_t S8_PR = S8_SLT;              // [16][4] u32 partial ranks (aliases SLT .. MR, which are written after the ranking)
 
 static_assert(S8_BYTES <= 10240, "the 8-event kernel needs 16 workgroups per CU: 160 KB / 16");
@@ -2356,35 +2357,58 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
         LDS_ORDER();
         PHASE(7);
-        // ---------------- level-1 updates for re-bounded neighbours living in other blocks, in event order
-        for (uint32_t r = 0; r < Rc; ++r) {
-            if (!((accball2 >> (8 * r)) & 1ull)) continue;
-            const uint32_t own = uniform_u32(SLB[r]);
-            const int kr = (int)readlane_u32((uint32_t)k, 8 * (int)r);
-            for (int jj = 0; jj < kr; ++jj) {
-                const uint32_t j = readlane_u32(sA, 8 * (int)r + jj);
-                if ((j >> 5) == own) continue;
-                // first-level entry of j's 32-key block: a lower key replaces it; if j WAS the entry and grew, the block is rescanned
-                const double kj = readlane_f64(key, 8 * (int)r + jj);
-                const uint32_t bj = j >> 5;
-                LDS_ORDER();
-                const double cur = bk[bj];
-                const uint32_t ci = bi[bj];
-                if (kj < cur || (kj == cur && j < ci)) {
-                    if (lane == 0) {
-                        bk[bj] = kj;
-                        bi[bj] = (uint16_t)j;
-                    }
-                } else if (ci == j) {
-                    const double kv = __hip_atomic_load(keys + (size_t)bj * 32 + (lane & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const double mn = wave_min_f64(kv);
-                    const uint64_t bl = __ballot(kv == mn);
-                    const int arg = bl ? (__ffsll((unsigned long long)bl) - 1) : 0;
-                    if (lane == 0) {
-                        bk[bj] = mn;
-                        bi[bj] = (uint16_t)(bj * 32 + (uint32_t)arg);
+        // ---------------- level-1 updates for re-bounded neighbours living in other blocks.  The final entry of a block is the
+        // smallest (key, coordinate) among its old entry and the new keys, whatever the order -- so when no two of these lanes aim
+        // at one block (checked through a small claim table) and none has to rescan, every lane updates its block by itself, in
+        // one LDS round trip for all of them; otherwise the updates are made one by one in event order.
+        const bool upd = commit && accept && gl < k && (sA >> 5) != blk;
+        if (__ballot(upd) != 0) {
+            uint8_t* const CL = reinterpret_cast<uint8_t*>(smem + S8_CL);
+            LDS_ORDER();
+            const uint32_t bjv = upd ? (sA >> 5) : 0u;
+            const double curv = bk[bjv];
+            const uint32_t civ = bi[bjv];
+            const bool lower = upd && (key < curv || (key == curv && sA < civ));
+            const bool resc = upd && !lower && civ == sA;
+            if (lower) CL[bjv & 63u] = (uint8_t)lane;
+            LDS_ORDER();
+            const bool lost = lower && CL[bjv & 63u] != (uint8_t)lane;
+            if (__ballot(lost || resc) == 0) {
+                if (lower) {
+                    bk[bjv] = key;
+                    bi[bjv] = (uint16_t)sA;
+                }
+            } else {
+            for (uint32_t r = 0; r < Rc; ++r) {
+                if (!((accball2 >> (8 * r)) & 1ull)) continue;
+                const uint32_t own = uniform_u32(SLB[r]);
+                const int kr = (int)readlane_u32((uint32_t)k, 8 * (int)r);
+                for (int jj = 0; jj < kr; ++jj) {
+                    const uint32_t j = readlane_u32(sA, 8 * (int)r + jj);
+                    if ((j >> 5) == own) continue;
+                    // first-level entry of j's 32-key block: a lower key replaces it; if j WAS the entry and grew, the block is rescanned
+                    const double kj = readlane_f64(key, 8 * (int)r + jj);
+                    const uint32_t bj = j >> 5;
+                    LDS_ORDER();
+                    const double cur = bk[bj];
+                    const uint32_t ci = bi[bj];
+                    if (kj < cur || (kj == cur && j < ci)) {
+                        if (lane == 0) {
+                            bk[bj] = kj;
+                            bi[bj] = (uint16_t)j;
+                        }
+                    } else if (ci == j) {
+                        const double kv = __hip_atomic_load(keys + (size_t)bj * 32 + (lane & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const double mn = wave_min_f64(kv);
+                        const uint64_t bl = __ballot(kv == mn);
+                        const int arg = bl ? (__ffsll((unsigned long long)bl) - 1) : 0;
+                        if (lane == 0) {
+                            bk[bj] = mn;
+                            bi[bj] = (uint16_t)(bj * 32 + (uint32_t)arg);
+                        }
                     }
                 }
+            }
             }
         }
         PHASE(8);
