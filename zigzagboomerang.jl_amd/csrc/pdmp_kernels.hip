@@ -1756,8 +1756,8 @@ constexpr uint32_t S8_STH = S8_R + 1152;    // [8][18] f64
 constexpr uint32_t S8_Z = S8_R + 2304;      // [8][16] u32 zone ids
 constexpr uint32_t S8_PK = S8_R;            // [8][32] f64 patched key blocks (sx / sth / zone ids are dead by then)
 constexpr uint32_t SEL_CAP = 16;            // candidates ranked per iteration (power of two)
-constexpr uint32_t S8_TK = S8_R;            // [SEL_CAP] f64 candidate keys (selection only)
-constexpr uint32_t S8_TB = S8_R + SEL_CAP * 8;  // [SEL_CAP] u32 their blocks
+constexpr uint32_t S8_TK = S8_R;            // [64] f64 candidate keys (selection only; the first SEL_CAP are ranked)
+constexpr uint32_t S8_TB = S8_R + 64 * 8;       // [64] u32 their blocks (the first SEL_CAP are ranked)
 constexpr uint32_t S8_SLT = 3328;   // [8] f64 candidate keys
 constexpr uint32_t S8_LR = 3392;    // [8] f64 true rates
 constexpr uint32_t S8_LBR = 3456;   // [8] f64 bounds
@@ -1774,7 +1774,7 @@ constexpr uint32_t S8_PR = S8_SLT;              // [16][4] u32 partial ranks (al
 
 static_assert(S8_BYTES <= 10240, "the 8-event kernel needs 16 workgroups per CU: 160 KB / 16");
 static_assert(S8_R + 2816 <= S8_SLT && S8_Z + 8 * 16 * 4 <= S8_SLT && S8_PK + 8 * 32 * 8 <= S8_SLT, "shared scratch area overflows");
-static_assert(S8_TB + SEL_CAP * 4 <= S8_Z, "selection scratch must not reach the zone ids");
+static_assert(S8_TB + 64 * 4 <= S8_Z, "selection scratch must not reach the zone ids");
 static_assert(S8_SLB + 8 * 4 <= S8_LB && (S8_LB % 16) == 0 && (S8_BK % 16) == 0 && (S8_STH % 16) == 0 && (S8_Z % 16) == 0,
               "LDS sub-arrays must stay 16-byte aligned");
 size_t zz_spec8_lds_bytes() { return S8_BYTES; }
@@ -1935,40 +1935,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 double dt_sel = uniform_f64(SELDT[0]);
                 // (the candidate masks are recomputed where they are needed instead of being kept: eight 64-bit masks would
                 // crowd the scalar registers)
-                double tau;
-                uint32_t C;
-                bool pile = false;
-                for (int tries = 0;; ++tries) {
-                    tau = mq + dt_sel;  // (>= mq: the minimum itself always qualifies)
-                    if (stop_before && !(tau < T)) tau = pdmp_below(T);
-                    if (tries >= 64) tau = mq;  // a pile of exactly equal keys: the entries equal to the minimum only
-                    C = 0;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) C += (uint32_t)__popcll(__ballot(kk[j] <= tau));
-                    if (C <= SEL_CAP) break;
-                    if (tries > 64) {  // more than SEL_CAP entries EQUAL to the minimum: one of them (lowest block) per iteration
-                        pile = true;
-                        C = 1;
-                        break;
-                    }
-                    dt_sel *= 0.5;
-                }
-                // compaction: entry (lane, j) gets index (candidates of slots < j) + (candidates of slot j in lower lanes)
+                // Compaction: entry (lane, j) gets index (candidates of slots < j) + (candidates of slot j in lower lanes).  There is
+                // no separate counting pass: the scratch arrays take up to 64 candidates, and a pass that ends with more than
+                // SEL_CAP is repeated with half the threshold.
                 auto below = [](uint64_t m_) -> uint32_t {
                     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_, 0u));
                 };
-                uint32_t base = 0;
+                double tau;
+                uint32_t C;
+                for (int tries = 0;; ++tries) {
+                    tau = mq + dt_sel;  // (>= mq: the minimum itself always qualifies)
+                    if (stop_before && !(tau < T)) tau = pdmp_below(T);
+                    const bool pile = tries > 64;  // more than SEL_CAP entries EQUAL to the minimum: one (lowest block) per iteration
+                    if (tries >= 64) tau = mq;     // a pile of exactly equal keys: the entries equal to the minimum only
+                    uint32_t base = 0;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const bool cj_ = kk[j] <= tau;
-                    uint64_t Mj = __ballot(cj_);
-                    if (pile) Mj = (base == 0 && Mj) ? (Mj & (~Mj + 1)) : 0ull;
-                    if (cj_ && ((Mj >> lane) & 1ull)) {
-                        const uint32_t ix = base + below(Mj);
-                        TK[ix] = kk[j];
-                        TB[ix] = (uint32_t)lane + 64u * j;
+                    for (int j = 0; j < 8; ++j) {
+                        const bool cj_ = kk[j] <= tau;
+                        uint64_t Mj = __ballot(cj_);
+                        if (pile) Mj = (base == 0 && Mj) ? (Mj & (~Mj + 1)) : 0ull;
+                        if (cj_ && ((Mj >> lane) & 1ull)) {
+                            const uint32_t ix = base + below(Mj);
+                            if (ix < 64u) {
+                                TK[ix] = kk[j];
+                                TB[ix] = (uint32_t)lane + 64u * j;
+                            }
+                        }
+                        base += (uint32_t)__popcll(Mj);
                     }
-                    base += (uint32_t)__popcll(Mj);
+                    C = base;
+                    if (C <= SEL_CAP) break;
+                    dt_sel *= 0.5;
+                    LDS_ORDER();
+                    if (lane < (int)SEL_CAP) TK[lane] = PDMP_INF;  // (entries past the new count must read +Inf in the ranking)
                 }
                 LDS_ORDER();
                 // rank of candidate n among all (ties by index), on a 16 x 4 grid: lane = 16 * part + n counts the candidates
