@@ -2290,12 +2290,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             const uint64_t okball = __ballot(okg && !vstop && gl == 0);
             const uint64_t vball = __ballot(okg && vstop && gl == 0);
             const uint64_t accball = __ballot(accept && gl == 0);
-            uint32_t r_ok = 0;
-            while (r_ok < (uint32_t)E && ((okball >> (8 * r_ok)) & 1ull)) ++r_ok;
+            // length of the run of committable slots from slot 0 (one bit per slot at bit 8 r): first zero among those bits
+            const uint64_t gap = ~okball & 0x0101010101010101ull;
+            const uint32_t r_ok = gap ? (uint32_t)((__ffsll((unsigned long long)gap) - 1) >> 3) : (uint32_t)E;
             Rc = 0;
             nacc_c = 0;
             bool stopped = false;
-            for (uint32_t r = 0; r < r_ok && !stopped; ++r) {
+            // the usual case needs no walk: the slice mode stops on time alone, and the trace has room for every accepted slot
+            const uint32_t nacc_all = (uint32_t)__popcll(accball & ((r_ok < 8u) ? ((1ull << (8 * r_ok)) - 1ull) : ~0ull));
+            const bool plainrun = stop_before && !(P.trace_cap > 0 && dnacc + nacc_all >= trace_room);
+            if (plainrun) {
+                Rc = r_ok;
+                nacc_c = nacc_all;
+            }
+            for (uint32_t r = 0; !plainrun && r < r_ok && !stopped; ++r) {
                 Rc = r + 1;
                 if ((accball >> (8 * r)) & 1ull) {
                     nacc_c += 1;
