@@ -2100,12 +2100,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             // positions hold sentinels that equal nothing.
             uint32_t confmask = 0;
             const uint4* Z4 = reinterpret_cast<const uint4*>(Z);
-#pragma unroll
-            for (int q = 0; q < E - 1; ++q) {
-                const uint32_t lq = readlane_u32(lo, 8 * q), hq = readlane_u32(hi, 8 * q);
-                uint64_t ovb = __ballot(gvalid && (q < g) && gl == 0 && lo <= hq && lq <= hi);
+            // lane gl of group g looks at the pair (g, q = gl): one ballot finds all pairs of groups whose spans overlap
+            {
+                const uint32_t lq = (uint32_t)__builtin_amdgcn_ds_bpermute(32 * gl, (int)lo);  // span of group gl (its lane 0)
+                const uint32_t hq = (uint32_t)__builtin_amdgcn_ds_bpermute(32 * gl, (int)hi);
+                uint64_t ovb = __ballot(gvalid && gl < g && lo <= hq && lq <= hi);
                 while (ovb != 0) {
-                    const int gsel = (__ffsll((unsigned long long)ovb) - 1) >> 3;
+                    const int bit = __ffsll((unsigned long long)ovb) - 1;
+                    const int gsel = bit >> 3, q = bit & 7;
                     ovb &= ovb - 1;
                     const uint32_t idg = Z[gsel * 16 + (lane & 15)];
                     const uint4 zq = Z4[q * 4 + (lane >> 4)];
