@@ -1671,15 +1671,37 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P_in) {
         }
         LDS_ORDER();
         PHASE(7);
-        // ---------------- level-1 updates for re-bounded neighbours living in other blocks, in event order
-        for (uint32_t r = 0; r < Rc; ++r) {
-            if (!((accball2 >> (16 * r)) & 1ull)) continue;
-            const uint32_t own = uniform_u32(SLB[r]);
-            const int kr = (int)uniform_u32(Kr[r]);
-            for (int jj = 0; jj < kr; ++jj) {
-                const uint32_t j = readlane_u32(s, 16 * (int)r + jj);
-                if ((j >> 6) == own) continue;
-                level1_update(bk, bi, keys, lane, j, readlane_f64(key, 16 * (int)r + jj));
+        // ---------------- level-1 updates for re-bounded neighbours living in other blocks.  A block's final entry is the
+        // smallest (key, coordinate) among its old entry and the new keys, whatever the order: when no two of these lanes aim at
+        // one block (claims through the now idle zone-id array) and none has to rescan, every lane updates its block by itself in
+        // one LDS round trip; otherwise one by one in event order.
+        const bool upd = commit && accept && gl < k && (s >> 6) != blk;
+        if (__ballot(upd) != 0) {
+            LDS_ORDER();
+            const uint32_t bjv = upd ? (s >> 6) : 0u;
+            const double curv = bk[bjv];
+            const uint32_t civ = bi[bjv];
+            const bool lower = upd && (key < curv || (key == curv && s < civ));
+            const bool resc = upd && !lower && civ == s;
+            if (lower) Z[bjv & 63u] = (uint32_t)lane;
+            LDS_ORDER();
+            const bool lost = lower && Z[bjv & 63u] != (uint32_t)lane;
+            if (__ballot(lost || resc) == 0) {
+                if (lower) {
+                    bk[bjv] = key;
+                    bi[bjv] = s;
+                }
+            } else {
+            for (uint32_t r = 0; r < Rc; ++r) {
+                if (!((accball2 >> (16 * r)) & 1ull)) continue;
+                const uint32_t own = uniform_u32(SLB[r]);
+                const int kr = (int)uniform_u32(Kr[r]);
+                for (int jj = 0; jj < kr; ++jj) {
+                    const uint32_t j = readlane_u32(s, 16 * (int)r + jj);
+                    if ((j >> 6) == own) continue;
+                    level1_update(bk, bi, keys, lane, j, readlane_f64(key, 16 * (int)r + jj));
+                }
+            }
             }
         }
         PHASE(8);
