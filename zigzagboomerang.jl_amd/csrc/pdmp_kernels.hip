@@ -1609,13 +1609,20 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P_in) {
                 return (uint32_t)((m_ & 1ull) | ((m_ >> 15) & 2ull) | ((m_ >> 30) & 4ull) | ((m_ >> 45) & 8ull));
             };
             const uint32_t okb = bits4(okball), vb = bits4(vball), accb = bits4(accball);
-            uint32_t r_ok = 0;
-            while (r_ok < (uint32_t)E && ((okb >> r_ok) & 1u)) ++r_ok;
+            const uint32_t gap = ~okb & 0xfu;  // the run of committable slots from slot 0 ends at the first zero bit
+            const uint32_t r_ok = gap ? (uint32_t)(__ffs((int)gap) - 1) : (uint32_t)E;
             // stop AFTER an accepted event that fills the trace or passes T (`while t′ < T`)
             Rc = 0;
             nacc_c = 0;
             bool stopped = false;
-            for (uint32_t r = 0; r < r_ok && !stopped; ++r) {
+            // the usual case needs no walk: the slice mode stops on time alone, and the trace has room for every accepted slot
+            const uint32_t acc_run = accb & ((1u << r_ok) - 1u);
+            const bool plainrun = stop_before && !(P.trace_cap > 0 && dnacc + (uint32_t)__popc(acc_run) >= trace_room);
+            if (plainrun) {
+                Rc = r_ok;
+                nacc_c = (uint32_t)__popc(acc_run);
+            }
+            for (uint32_t r = 0; !plainrun && r < r_ok && !stopped; ++r) {
                 Rc = r + 1;
                 if ((accb >> r) & 1u) {
                     nacc_c += 1;
@@ -2858,13 +2865,20 @@ __global__ __launch_bounds__(64) void zz_sticky_spec_kernel(ZzRunParams P_in) {
                 return (uint32_t)((m_ & 1ull) | ((m_ >> 15) & 2ull) | ((m_ >> 30) & 4ull) | ((m_ >> 45) & 8ull));
             };
             const uint32_t okb = bits4(okball), vb = bits4(vball), happb = bits4(happball);
-            uint32_t r_ok = 0;
-            while (r_ok < (uint32_t)E && ((okb >> r_ok) & 1u)) ++r_ok;
+            const uint32_t gap = ~okb & 0xfu;  // the run of committable slots from slot 0 ends at the first zero bit
+            const uint32_t r_ok = gap ? (uint32_t)(__ffs((int)gap) - 1) : (uint32_t)E;
             Rc = 0;
             happb_c = 0;
             uint32_t nev_c = 0;
             bool stopped = false;
-            for (uint32_t r = 0; r < r_ok && !stopped; ++r) {
+            // the usual case needs no walk: the slice mode stops on time alone, and the trace has room for every event of the run
+            const uint32_t happ_run = happb & ((1u << r_ok) - 1u);
+            const bool plainrun = stop_before && !(P.trace_cap > 0 && dnev + (uint32_t)__popc(happ_run) >= trace_room);
+            if (plainrun) {
+                Rc = r_ok;
+                happb_c = happ_run;
+            }
+            for (uint32_t r = 0; !plainrun && r < r_ok && !stopped; ++r) {
                 Rc = r + 1;
                 if ((happb >> r) & 1u) {
                     happb_c |= 1u << r;
