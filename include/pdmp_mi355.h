@@ -257,21 +257,43 @@ pdmp_status pdmp_ensemble_set_local_bound(pdmp_ensemble* ens, int enable);
  *
  * pdmp(∇ϕ!, t0, x0, θ0, T, c, B::BouncyParticle; adapt, factor=2.0) -> Ξ::PDMPTrace, (t, x, θ), (acc, num), c
  * (src/not_fact_samplers.jl:117-147,395-396) with GlobalBound(c) and the Gaussian target ∇ϕ!(y, x) = Γ(x − μ)
- * (test/maintest.jl:163).  Mass matrix L = I (config C2: Γ = I); a general cholesky(Γ).L is not implemented.
+ * (test/maintest.jl:163).  Γ is B.Γ: it enters ab() (:26-28) and, here, the target.  The mass factor B.L =
+ * cholesky(Symmetric(Γ)).L (src/types.jl:43) is identity for Γ = I (config C2); for any other Γ the caller must hand it over
+ * with pdmp_ensemble_set_mass_cholesky before set_state_bps, which otherwise returns PDMP_ERR_UNSUPPORTED.
  * Events are (t, copy(x), copy(θ)) (:39-41); dot products use the fixed summation order stated in oracle/pdmp_oracle.c.
  */
 pdmp_status pdmp_ensemble_set_flow_bps(pdmp_ensemble* ens, const int64_t* colptr, const int64_t* rowval,
                                        const double* nzval, const double* mu, double lambda_ref, double rho);
 
-/* Flow = Boomerang(Γ, μ_flow, λref; ρ) (src/types.jl:59-66) with Γ = I, i.e. mass L = I: Hamiltonian rotation about μ_flow
- * between events (src/dynamics.jl:29-36), grad_correct! ∇ϕx −= x − μ_flow (src/not_fact_samplers.jl:9-12), constant bound
+/* Flow = Boomerang(Γ, μ_flow, λref; ρ) (src/types.jl:59-66): Hamiltonian rotation about μ_flow between events
+ * (src/dynamics.jl:29-36), grad_correct! ∇ϕx −= L'\(L\(x − μ_flow)) (src/not_fact_samplers.jl:9-12), constant bound
  * (√(‖θ‖² + ‖x − μ_flow‖²)·c, 0, Inf) (:34-36); same pdmp_inner! loop, events, counters and entry points as the bouncy
  * particle (create the ensemble with PDMP_SAMPLER_BPS).  The CSC matrix and mu_target describe the TARGET
- * ∇ϕ!(y, x) = Γt(x − μt) (test/maintest.jl:146).  A reference measure with Γ ≠ I (general cholesky L) is not implemented. */
+ * ∇ϕ!(y, x) = Γt(x − μt) (test/maintest.jl:146).  The flow's own Γ enters only through its factor L = cholesky(Symmetric(Γ)).L
+ * (src/types.jl:66): identity unless pdmp_ensemble_set_mass_cholesky supplies one. */
 pdmp_status pdmp_ensemble_set_flow_boomerang(pdmp_ensemble* ens, const int64_t* colptr, const int64_t* rowval,
                                              const double* nzval, const double* mu_target, const double* mu_flow,
                                              double lambda_ref, double rho);
-/* x0, theta0: [nchains x d]; c: the scalar bound constant (GlobalBound(c)); seeds: [nchains] */
+/*
+ * Mass factor F.L of BouncyParticle / Boomerang (src/types.jl:43,66): a LOWER-triangular d x d matrix in CSC form (rows
+ * ascending, hence the diagonal entry first in its column; non-zero diagonal).  Used by reflect!
+ * θ .-= (2⟨∇ϕx,θ⟩/‖L\∇ϕx‖²)·L'\(L\∇ϕx) (src/dynamics.jl:90-97), refresh! θ = ρθ + ρ̄·L'\randn(d) (:112-126) and Boomerang's
+ * grad_correct! (src/not_fact_samplers.jl:9-12).  The reference factorises inside the constructor (dense LAPACK, or CHOLMOD with
+ * its fill-reducing permutation for a sparse Γ, whose `.L` is the factor of the PERMUTED matrix); the caller -- the Julia shim
+ * passes `sparse(B.L)` -- owns that choice, the engine only solves with what it is given, by column-oriented substitution in
+ * the order oracle/pdmp_oracle.c states.  Call after set_flow_bps / set_flow_boomerang and before set_state_bps.
+ */
+pdmp_status pdmp_ensemble_set_mass_cholesky(pdmp_ensemble* ens, const int64_t* colptr, const int64_t* rowval,
+                                            const double* nzval);
+/*
+ * local_bound: `c` of set_state_bps is LocalBound(c).c -- ab = (c + ⟨θ,∇ϕx⟩, v, 2√d/c/‖θ‖₂) with v = θ'Γθ (the second
+ * directional derivative a `(∇ϕx, v)` gradient callback returns for the Gaussian target), next_time's horizon and the renew
+ * branch of pdmp_inner! (src/not_fact_samplers.jl:29-31,43-50,65-71); BouncyParticle only.
+ * subsample: kwarg `subsample` (:53,90): an accepted reflection does not end pdmp_inner!, only refreshments are recorded.
+ * Call after set_flow_* and before set_state_bps.
+ */
+pdmp_status pdmp_ensemble_set_bps_options(pdmp_ensemble* ens, int local_bound, int subsample);
+/* x0, theta0: [nchains x d]; c: the scalar bound constant (GlobalBound(c) or LocalBound(c)); seeds: [nchains] */
 pdmp_status pdmp_ensemble_set_state_bps(pdmp_ensemble* ens, double t0, const double* x0, const double* theta0, double c,
                                         const uint64_t* seeds);
 /* events [first, first+count) of one chain: t [count], x and theta [count x d] (any may be NULL) */

@@ -750,24 +750,115 @@ static void nf_move(const orc_bps_params* p, int64_t d, double tau, double* x, d
         }
     }
 }
-/* ∇ϕx = ∇ϕ!(∇ϕx, x) then grad_correct!, src/not_fact_samplers.jl:5-12: Boomerang subtracts L'\(L\(x − μ)) = x − μ for L = I */
-static void nf_grad(const orc_bps_params* p, int64_t d, const double* x, double* tmp, double* g) {
-    bps_grad(p->gamma, p->mu, x, tmp, g, d);
-    if (p->flow_kind == 1)
-        for (int64_t k = 0; k < d; ++k) g[k] -= x[k] - p->flow_mu[k];
+/*
+ * Mass matrix: F.L = cholesky(Symmetric(Γ)).L (src/types.jl:43,66), a lower-triangular factor handed over in CSC form (rows
+ * ascending, so the diagonal entry is the FIRST of its column).  The reference solves with LAPACK/CHOLMOD (order of operations
+ * unspecified); the order is FIXED here to column-oriented substitution, which a wavefront reproduces exactly:
+ *   y = L \ b :  for j = 0..d-1:    y_j = b_j / L_jj;  b_r -= L_rj * y_j  for the rows r > j of column j (ascending)
+ *   z = L' \ y:  for j = d-1..0:    z_j = y_j / L_jj;  y_r -= L_jr * z_j  for the columns r < j of ROW j of L (ascending r)
+ * (row j of L = column j of L', built once as a CSC transpose).  Every b_r receives its updates in the order of j, and no
+ * update is a sum of more than one product, so no summation order is left open.
+ */
+typedef struct {
+    int64_t d;
+    int64_t* cp; /* L, diag first */
+    int64_t* rv;
+    double* nz;
+    int64_t* tcp; /* L' (upper), diag last */
+    int64_t* trv;
+    double* tnz;
+} tri_factor;
+
+static int tri_build(tri_factor* F, const orc_csc* L) {
+    const int64_t d = L->n, nnz = L->colptr[d];
+    F->d = d;
+    F->cp = (int64_t*)malloc((size_t)(d + 1) * sizeof(int64_t));
+    F->rv = (int64_t*)malloc((size_t)(nnz ? nnz : 1) * sizeof(int64_t));
+    F->nz = (double*)malloc((size_t)(nnz ? nnz : 1) * sizeof(double));
+    F->tcp = (int64_t*)calloc((size_t)(d + 2), sizeof(int64_t));
+    F->trv = (int64_t*)malloc((size_t)(nnz ? nnz : 1) * sizeof(int64_t));
+    F->tnz = (double*)malloc((size_t)(nnz ? nnz : 1) * sizeof(double));
+    memcpy(F->cp, L->colptr, (size_t)(d + 1) * sizeof(int64_t));
+    memcpy(F->rv, L->rowval, (size_t)nnz * sizeof(int64_t));
+    memcpy(F->nz, L->nzval, (size_t)nnz * sizeof(double));
+    for (int64_t j = 0; j < d; ++j) {
+        if (F->cp[j + 1] <= F->cp[j] || F->rv[F->cp[j]] != j) return -1; /* not lower triangular with a stored diagonal */
+        for (int64_t p = F->cp[j]; p < F->cp[j + 1]; ++p) F->tcp[F->rv[p] + 2]++;
+    }
+    for (int64_t j = 0; j < d; ++j) F->tcp[j + 2] += F->tcp[j + 1];
+    for (int64_t j = 0; j < d; ++j)
+        for (int64_t p = F->cp[j]; p < F->cp[j + 1]; ++p) {
+            int64_t q = F->tcp[F->rv[p] + 1]++;
+            F->trv[q] = j;
+            F->tnz[q] = F->nz[p];
+        }
+    return 0;
 }
-/* ab(x, θ, C::GlobalBound, ∇ϕx, v, Flow), src/not_fact_samplers.jl:26-28 (BouncyParticle), :34-36 (Boomerang) */
+static void tri_free(tri_factor* F) {
+    free(F->cp);
+    free(F->rv);
+    free(F->nz);
+    free(F->tcp);
+    free(F->trv);
+    free(F->tnz);
+}
+/* b <- L \ b */
+static void tri_solve_lower(const tri_factor* F, double* b) {
+    for (int64_t j = 0; j < F->d; ++j) {
+        const double yj = b[j] / F->nz[F->cp[j]];
+        b[j] = yj;
+        for (int64_t p = F->cp[j] + 1; p < F->cp[j + 1]; ++p) b[F->rv[p]] = b[F->rv[p]] - F->nz[p] * yj;
+    }
+}
+/* y <- L' \ y */
+static void tri_solve_upper(const tri_factor* F, double* y) {
+    for (int64_t j = F->d - 1; j >= 0; --j) {
+        const double zj = y[j] / F->tnz[F->tcp[j + 1] - 1];
+        y[j] = zj;
+        for (int64_t p = F->tcp[j]; p < F->tcp[j + 1] - 1; ++p) y[F->trv[p]] = y[F->trv[p]] - F->tnz[p] * zj;
+    }
+}
+
+/* ∇ϕx = ∇ϕ!(∇ϕx, x) then grad_correct!, src/not_fact_samplers.jl:5-12: Boomerang subtracts L'\(L\(x − μ)) (= x − μ for L = I) */
+static void nf_grad(const orc_bps_params* p, const tri_factor* M, int64_t d, const double* x, double* tmp, double* g) {
+    bps_grad(p->gamma, p->mu, x, tmp, g, d);
+    if (p->flow_kind == 1) {
+        if (M) {
+            for (int64_t k = 0; k < d; ++k) tmp[k] = x[k] - p->flow_mu[k];
+            tri_solve_lower(M, tmp);
+            tri_solve_upper(M, tmp);
+            for (int64_t k = 0; k < d; ++k) g[k] -= tmp[k];
+        } else {
+            for (int64_t k = 0; k < d; ++k) g[k] -= x[k] - p->flow_mu[k];
+        }
+    }
+}
+/* ab(x, θ, C::GlobalBound, ∇ϕx, v, Flow), src/not_fact_samplers.jl:26-28 (BouncyParticle), :34-36 (Boomerang);
+ * ab(x, θ, C::LocalBound, ∇ϕx, v, B::BouncyParticle) = (c + dot(θ, ∇ϕx), v, 2√d/c/‖θ‖₂), :29-31, with v = θ'Γθ, the second
+ * directional derivative a `(∇ϕx, v)`-returning gradient callback supplies for the Gaussian target */
 static void nf_ab(const orc_bps_params* p, int64_t d, double c, const double* x, const double* th, const double* g,
-                  double* tmp, double* gth, double* a, double* b) {
+                  double* tmp, double* gth, double* a, double* b, double* horizon) {
+    *horizon = INFINITY;
     if (p->flow_kind == 0) {
         *a = c + dot_wave64(th, g, d);
         for (int64_t r = 0; r < d; ++r) gth[r] = orc_idot(p->gamma, r, th);
         *b = dot_wave64(th, gth, d);
+        if (p->local_bound) *horizon = 2 * sqrt((double)d) / c / sqrt(dot_wave64(th, th, d));
     } else {
         for (int64_t k = 0; k < d; ++k) tmp[k] = x[k] - p->flow_mu[k];
         *a = sqrt(dot_wave64(th, th, d) + dot_wave64(tmp, tmp, d)) * c; /* sqrt(normsq(θ) + normsq(x − μ))*C.c */
         *b = 0.0;
     }
+}
+/* next_time(t, abc, z), src/not_fact_samplers.jl:43-50 */
+static double nf_next_time(double t, double a, double b, double horizon, double u, int* renew) {
+    const double dt = orc_poisson_time(a, b, u);
+    if (dt > horizon) {
+        *renew = 1;
+        return t + horizon;
+    }
+    *renew = 0;
+    return t + dt;
 }
 
 int orc_pdmp_bps(int64_t d, const orc_bps_params* p, double t0, double T, double* x, double* th, double* t_ev,
@@ -777,17 +868,31 @@ int orc_pdmp_bps(int64_t d, const orc_bps_params* p, double t0, double T, double
     double* g = (double*)malloc((size_t)d * sizeof(double));
     double* tmp = (double*)malloc((size_t)d * sizeof(double));
     double* gth = (double*)malloc((size_t)d * sizeof(double));
+    double* w = (double*)malloc((size_t)d * sizeof(double));
+    tri_factor Mf;
+    const tri_factor* M = NULL;
+    if (p->mass_L) {
+        if (p->mass_L->n != d || tri_build(&Mf, p->mass_L) != 0) {
+            free(g);
+            free(tmp);
+            free(gth);
+            free(w);
+            return ORC_BAD_INPUT;
+        }
+        M = &Mf;
+    }
     double t = t0;
     double c = p->c;
     int64_t num = 0, acc = 0, nrefresh = 0, nev = 0;
     int status = ORC_OK;
     const double rho = p->rho, rhobar = sqrt(1 - rho * rho); /* src/dynamics.jl:113 */
-    double a, b;
+    double a, b, hz;
+    int renew = 0;
 
     double tau_ref = -pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)) / p->lambda_ref; /* :121 */
-    nf_grad(p, d, x, tmp, g);                                                            /* :122-123 */
-    nf_ab(p, d, c, x, th, g, tmp, gth, &a, &b);                                          /* :126 */
-    double tp = t + orc_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)); /* next_time :43-50, :135 */
+    nf_grad(p, M, d, x, tmp, g);                                                         /* :122-123 */
+    nf_ab(p, d, c, x, th, g, tmp, gth, &a, &b, &hz);                                     /* :126 */
+    double tp = nf_next_time(t, a, b, hz, pdmp_u01(seed, PDMP_STREAM_MAIN, nm++), &renew); /* :43-50, :135 */
 
     while (t < T) { /* :136 */
         for (;;) {  /* pdmp_inner!, :52-97 */
@@ -795,7 +900,7 @@ int orc_pdmp_bps(int64_t d, const orc_bps_params* p, double t0, double T, double
                 double tau = tau_ref - t;
                 t += tau; /* move_forward!, :56 */
                 nf_move(p, d, tau, x, th);
-                /* refresh!, src/dynamics.jl:112-126 with L = I:  θ .*= ρ; θ .+= ρ̄*randn(rng,d) */
+                /* refresh!, src/dynamics.jl:112-126:  θ .*= ρ; u = ρ̄*(L'\randn(rng, d)); θ .+= u */
                 /* randn(rng, d): the reference draws d normals from its stream; here the d-vector comes from ⌈d/128⌉·64 Philox
                  * blocks, both Box-Muller branches of a block in use: element k = 128a + 64b + l (l < 64, b ∈ {0,1}) is branch b
                  * (cos, sin) of block nm + 64a + l -- the layout in which a 64-lane wavefront holds two elements per lane pair of
@@ -804,21 +909,31 @@ int orc_pdmp_bps(int64_t d, const orc_bps_params* p, double t0, double T, double
                 for (int64_t k = 0; k < d; ++k) {
                     double z0, z1;
                     pdmp_randn2(seed, PDMP_STREAM_MAIN, nm + (uint64_t)(((k >> 7) << 6) + (k & 63)), &z0, &z1);
-                    th[k] += rhobar * (((k >> 6) & 1) ? z1 : z0);
+                    w[k] = ((k >> 6) & 1) ? z1 : z0;
                 }
+                if (M) tri_solve_upper(M, w);
+                for (int64_t k = 0; k < d; ++k) th[k] += rhobar * w[k];
                 nm += (uint64_t)(((d + 127) >> 7) << 6);
-                nf_grad(p, d, x, tmp, g);                                                     /* :58-59 */
+                nf_grad(p, M, d, x, tmp, g);                                                  /* :58-59 */
                 tau_ref = t + (-pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)) / p->lambda_ref); /* :61 */
-                nf_ab(p, d, c, x, th, g, tmp, gth, &a, &b);                                   /* :62 */
-                tp = t + orc_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)); /* :63 */
+                nf_ab(p, d, c, x, th, g, tmp, gth, &a, &b, &hz);                              /* :62 */
+                tp = nf_next_time(t, a, b, hz, pdmp_u01(seed, PDMP_STREAM_MAIN, nm++), &renew); /* :63 */
                 nrefresh++;
                 break; /* :64 return */
             }
-            /* renew branch :65-71 is unreachable with GlobalBound (abc[3] = Inf) */
+            if (renew) { /* :65-71: the bound's horizon expired (LocalBound only): move, re-bound, no thinning step */
+                double tau = tp - t;
+                t += tau;
+                nf_move(p, d, tau, x, th);
+                nf_grad(p, M, d, x, tmp, g);
+                nf_ab(p, d, c, x, th, g, tmp, gth, &a, &b, &hz);
+                tp = nf_next_time(t, a, b, hz, pdmp_u01(seed, PDMP_STREAM_MAIN, nm++), &renew);
+                continue;
+            }
             double tau = tp - t; /* :73 */
             t += tau;
-            nf_move(p, d, tau, x, th); /* :74 */
-            nf_grad(p, d, x, tmp, g);  /* :75-76 */
+            nf_move(p, d, tau, x, th);   /* :74 */
+            nf_grad(p, M, d, x, tmp, g); /* :75-76 */
             double gt = dot_wave64(g, th, d);
             double l = pos(gt);            /* λ, :14 */
             double lb = pos(a + b * tau);  /* :77 */
@@ -832,17 +947,26 @@ int orc_pdmp_bps(int64_t d, const orc_bps_params* p, double t0, double T, double
                     }
                     c *= p->factor; /* :83 */
                 }
-                /* reflect!, src/dynamics.jl:90-97 with L = I: θ .-= (2 dot(∇ϕx,θ)/normsq(∇ϕx)) ∇ϕx */
-                double nrm = dot_wave64(g, g, d);
-                double coef = 2 * gt / nrm;
-                for (int64_t k = 0; k < d; ++k) th[k] -= coef * g[k];
+                /* reflect!, src/dynamics.jl:90-97: θ .-= (2 dot(∇ϕx,θ)/normsq(L\∇ϕx)) (L'\(L\∇ϕx)) */
+                if (M) {
+                    memcpy(w, g, (size_t)d * sizeof(double));
+                    tri_solve_lower(M, w);
+                    double nrm = dot_wave64(w, w, d);
+                    tri_solve_upper(M, w);
+                    double coef = 2 * gt / nrm;
+                    for (int64_t k = 0; k < d; ++k) th[k] -= coef * w[k];
+                } else {
+                    double nrm = dot_wave64(g, g, d);
+                    double coef = 2 * gt / nrm;
+                    for (int64_t k = 0; k < d; ++k) th[k] -= coef * g[k];
+                }
                 /* :86-87 gradient again (x unchanged: same values) */
-                nf_ab(p, d, c, x, th, g, tmp, gth, &a, &b);                               /* :88 */
-                tp = t + orc_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)); /* :89 */
-                break;                                                                    /* :90 */
+                nf_ab(p, d, c, x, th, g, tmp, gth, &a, &b, &hz);                              /* :88 */
+                tp = nf_next_time(t, a, b, hz, pdmp_u01(seed, PDMP_STREAM_MAIN, nm++), &renew); /* :89 */
+                if (!p->subsample) break;                                                     /* :90 */
             } else {
-                nf_ab(p, d, c, x, th, g, tmp, gth, &a, &b);                               /* :92 (recomputed: bit parity) */
-                tp = t + orc_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)); /* :93 */
+                nf_ab(p, d, c, x, th, g, tmp, gth, &a, &b, &hz);                              /* :92 (recomputed: bit parity) */
+                tp = nf_next_time(t, a, b, hz, pdmp_u01(seed, PDMP_STREAM_MAIN, nm++), &renew); /* :93 */
             }
         }
         /* push!(Ξ, event(t, x, θ, Flow)) = (t, copy(x), copy(θ), nothing), :138, :39-41 */
@@ -871,6 +995,8 @@ finish:
     free(g);
     free(tmp);
     free(gth);
+    free(w);
+    if (M) tri_free(&Mf);
     return status;
 }
 

@@ -77,6 +77,7 @@ int orc_pq_check(const orc_pq* q); /* 1 if heap order + index map are consistent
 #define ORC_BOUND_VIOLATED 1 /* l >= lb with adapt=false: the reference throws (src/sfact.jl:124) */
 #define ORC_STALLED 2        /* queue minimum is +Inf: no further event can occur               */
 #define ORC_TRACE_LIMIT 3    /* max_events reached                                                */
+#define ORC_BAD_INPUT 4      /* malformed argument (e.g. a mass factor that is not lower triangular) */
 
 typedef struct {
     /* flow Z = ZigZag(Gamma, mu, sigma; lambda_ref, rho)  (src/types.jl:19-27) */
@@ -151,8 +152,8 @@ int64_t orc_pdmp_zigzag1d(double mu, double sigma2, double x, double theta, doub
 
 /*
  * Bouncy particle sampler, src/not_fact_samplers.jl:52-97 under the driver :117-147, GlobalBound(c),
- * Gaussian target grad phi!(y,x) = Gamma*(x - mu_t) written as CSC mat-vec, mass L = identity
- * (cholesky(Symmetric(Gamma)).L for Gamma = I, config C2; general L is out of scope this round).
+ * Gaussian target grad phi!(y,x) = Gamma*(x - mu_t) written as CSC mat-vec, mass factor L supplied by the
+ * caller (mass_L below; NULL = identity, exact for Gamma = I, config C2).
  * Events: t_ev[k], and x_ev/theta_ev rows of length d (copy(x), copy(theta), src/not_fact_samplers.jl:39-41).
  */
 typedef struct {
@@ -170,6 +171,12 @@ typedef struct {
      * a = √(‖θ‖² + ‖x − flow_mu‖²)·c, b = 0 (:34-36).  gamma/mu above are then the TARGET's precision and mean. */
     int flow_kind;
     const double* flow_mu;
+    /* Mass factor F.L = cholesky(Symmetric(Γ)).L (src/types.jl:43,66) as a lower-triangular CSC matrix (NULL: identity), used by
+     * reflect! (src/dynamics.jl:90-97), refresh! (:112-126) and Boomerang's grad_correct! (src/not_fact_samplers.jl:9-12); the
+     * substitution order is fixed in pdmp_oracle.c (tri_solve_lower / tri_solve_upper). */
+    const orc_csc* mass_L;
+    int local_bound; /* c::LocalBound (src/not_fact_samplers.jl:29-31): horizon 2√d/c/‖θ‖ and the renew branch :65-71 (BPS only) */
+    int subsample;   /* kwarg subsample (:53,90): an accepted reflection does not end pdmp_inner! */
 } orc_bps_params;
 typedef struct {
     int64_t num, nacc, nrefresh, nevents;

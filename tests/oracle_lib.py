@@ -59,7 +59,8 @@ class _ZZResult(C.Structure):
 class _BpsParams(C.Structure):
     _fields_ = [("gamma", C.POINTER(_Csc)), ("mu", C.c_void_p), ("lambda_ref", C.c_double),
                 ("rho", C.c_double), ("c", C.c_double), ("adapt", C.c_int), ("factor", C.c_double),
-                ("seed", C.c_uint64), ("max_events", C.c_int64), ("flow_kind", C.c_int), ("flow_mu", C.c_void_p)]
+                ("seed", C.c_uint64), ("max_events", C.c_int64), ("flow_kind", C.c_int), ("flow_mu", C.c_void_p),
+                ("mass_L", C.POINTER(_Csc)), ("local_bound", C.c_int), ("subsample", C.c_int)]
 
 
 class _BpsResult(C.Structure):
@@ -287,9 +288,10 @@ def pdmp_zigzag1d(mu, sigma2, x0, theta0, T, c, *, adapt=False, factor=2.0, seed
 
 
 def pdmp_bps(gamma, mu, x0, theta0, c, T, *, t0=0.0, lambda_ref=1.0, rho=0.0, adapt=False, factor=2.0,
-             seed=1, max_events=0, ev_cap=0, want_events=True, boomerang_mu=None):
-    """BPS (gamma, mu = flow AND target) or, with boomerang_mu, Boomerang(I, boomerang_mu, λref; ρ) on the Gaussian
-    target (gamma, mu)."""
+             seed=1, max_events=0, ev_cap=0, want_events=True, boomerang_mu=None, mass_L=None, local_bound=False,
+             subsample=False):
+    """BPS (gamma, mu = flow AND target) or, with boomerang_mu, Boomerang(·, boomerang_mu, λref; ρ) on the Gaussian
+    target (gamma, mu).  mass_L: the lower-triangular factor F.L (scipy sparse / dense), None = identity."""
     L = lib()
     g = gamma if isinstance(gamma, CscHolder) else CscHolder(gamma)
     d = g.n
@@ -298,6 +300,10 @@ def pdmp_bps(gamma, mu, x0, theta0, c, T, *, t0=0.0, lambda_ref=1.0, rho=0.0, ad
     if boomerang_mu is not None:
         fmu = _f64(boomerang_mu)
         p.flow_kind, p.flow_mu = 1, fmu.ctypes.data
+    if mass_L is not None:
+        mh = mass_L if isinstance(mass_L, CscHolder) else CscHolder(mass_L)
+        p.mass_L = C.pointer(mh.c)
+    p.local_bound, p.subsample = int(bool(local_bound)), int(bool(subsample))
     x = _f64(x0).copy()
     th = _f64(theta0).copy()
     if want_events:

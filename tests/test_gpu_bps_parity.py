@@ -8,12 +8,17 @@ import oracle_lib as O
 pytestmark = pytest.mark.gpu
 
 
-def check(pkg, G, mu, x0, th0, c, T, lam, rho=0.0, adapt=False, seed=5, factor=2.0):
-    B = pkg.BouncyParticle(G, np.zeros(G.shape[0]) if mu is None else mu, lam, rho)
-    tr, (t, x, th), (acc, num), cout = pkg.pdmp(None, 0.0, x0, th0, T, c, B, adapt=adapt, seed=seed, factor=factor)
+def check(pkg, G, mu, x0, th0, c, T, lam, rho=0.0, adapt=False, seed=5, factor=2.0, L="chol", local_bound=False,
+          subsample=False):
+    """L = "chol": the reference's constructor BouncyParticle(Γ, μ, λ; ρ) with B.L = cholesky(Symmetric(Γ)).L (src/types.jl:43);
+    otherwise an explicit factor (the reference's 6-field constructor)."""
+    B = pkg.BouncyParticle(G, np.zeros(G.shape[0]) if mu is None else mu, lam, rho, **({} if isinstance(L, str) else {"L": L}))
+    cc = pkg.LocalBound(np.array([c])) if local_bound else c
+    tr, (t, x, th), (acc, num), cout = pkg.pdmp(None, 0.0, x0, th0, T, cc, B, adapt=adapt, seed=seed, factor=factor,
+                                                subsample=subsample)
     for k in range(x0.shape[0]):
         r = O.pdmp_bps(G, mu, x0[k], th0[k], c, T, lambda_ref=lam, rho=rho, adapt=adapt, factor=factor, seed=seed + k,
-                       ev_cap=200000)
+                       ev_cap=200000, mass_L=B.L, local_bound=local_bound, subsample=subsample)
         assert r["status"] == 0
         assert len(tr[k].t) == r["nevents"], (k, len(tr[k].t), r["nevents"])
         assert np.array_equal(tr[k].t, r["t_ev"]) and np.array_equal(tr[k].x, r["x_ev"]) and np.array_equal(tr[k].θ, r["theta_ev"])
@@ -33,14 +38,79 @@ def test_isotropic_gaussian_config_c2_shape(gpu_pkg, d):
 
 
 def test_general_sparse_precision_and_mean(gpu_pkg):
-    """test/maintest.jl:156-172: Γ = S S', λref = 0.5, c = 1.1 (mass L = I), plus a non-zero μ and ρ > 0."""
-    G = gpu_pkg.problems.maintest_precision(8)
+    """test/maintest.jl:156-172: Γ = S S', λref = 0.5, c = 1.1 with the mass factor L = cholesky(Γ).L of the reference's
+    constructor (reflect! / refresh! solve with L and L', src/dynamics.jl:90-97,112-126), plus a non-zero μ and ρ > 0; then the
+    same with an explicit identity factor (the identity-mass process, bit-identical to passing no factor to the oracle)."""
+    pkg = gpu_pkg
+    G = pkg.problems.maintest_precision(8)
     rng = np.random.default_rng(3)
     x0, th0 = rng.standard_normal((4, 8)), rng.standard_normal((4, 8))
-    check(gpu_pkg, G, None, x0, th0, 1.1, 60.0, 0.5, seed=8)
-    check(gpu_pkg, G, rng.standard_normal(8), x0, th0, 1.1, 40.0, 0.7, rho=0.3, seed=9)
-    G2 = gpu_pkg.problems.gmrf_precision(10)  # d = 100: two slots per lane, pentadiagonal gather through LDS
-    check(gpu_pkg, G2, None, rng.standard_normal((2, 100)), rng.standard_normal((2, 100)), 0.5, 6.0, 1.0, seed=10)
+    tr = check(pkg, G, None, x0, th0, 1.1, 60.0, 0.5, seed=8)
+    check(pkg, G, rng.standard_normal(8), x0, th0, 1.1, 40.0, 0.7, rho=0.3, seed=9)
+    G2 = pkg.problems.gmrf_precision(10)  # d = 100: two slots per lane, pentadiagonal gather and a banded factor through LDS
+    check(pkg, G2, None, rng.standard_normal((2, 100)), rng.standard_normal((2, 100)), 0.5, 6.0, 1.0, seed=10)
+    I8 = sp.identity(8, format="csc")
+    tr_i = check(pkg, G, None, x0, th0, 1.1, 60.0, 0.5, seed=8, L=I8)
+    assert not np.array_equal(tr[0].t[:40], tr_i[0].t[:40])  # the factor matters
+    for k in range(2):  # identity factor == the oracle without a factor
+        r = O.pdmp_bps(G, None, x0[k], th0[k], 1.1, 60.0, lambda_ref=0.5, seed=8 + k, ev_cap=200000)
+        assert np.array_equal(tr_i[k].t, r["t_ev"]) and np.array_equal(tr_i[k].θ, r["theta_ev"])
+
+
+def test_reference_bps_envelope_with_cholesky_mass(gpu_pkg):
+    """@testset "Bouncy Particle Sampler" (test/maintest.jl:156-172) on the device as the reference runs it -- B =
+    BouncyParticle(Γ0, 0, 0.5) INCLUDING its L = cholesky(Symmetric(Γ0)).L, c = 1.1, T = 300, dt = 0.1 -- inside the reference's
+    thresholds 2/sqrt(T) (majority of three seeds), every chain bit-identical to the oracle."""
+    pkg = gpu_pkg
+    G = pkg.problems.maintest_precision(8)
+    d, T = 8, 300.0
+    rng = np.random.default_rng(3)
+    x0, th0 = rng.standard_normal((3, d)), rng.standard_normal((3, d))
+    tr = check(pkg, G, None, x0, th0, 1.1, T, 0.5, seed=8)
+    S = np.linalg.inv(G.toarray())
+    ok = 0
+    for k in range(3):
+        ts, xs = pkg.trace.discretize(tr[k], 0.1)
+        ok += (np.mean(np.abs(xs.mean(0))) < 2 / np.sqrt(T)) and (np.mean(np.abs(np.cov(xs.T) - S)) < 2 / np.sqrt(T))
+    assert ok >= 2
+
+
+def test_mass_factor_is_required_for_a_general_gamma(gpu_pkg):
+    """C ABI: BouncyParticle(Γ ≠ I) without its factor is refused (PDMP_ERR_UNSUPPORTED), never run with a silent L = I; a
+    malformed factor is PDMP_ERR_INVALID."""
+    pkg = gpu_pkg
+    G = pkg.problems.maintest_precision(8)
+    B = pkg.BouncyParticle(G, np.zeros(8), 0.5)
+    x0 = np.zeros((1, 8))
+    with pkg.Ensemble(1, 8, sampler=pkg._lib.SAMPLER_BPS, trace_capacity=8) as ens:
+        B_no = pkg.BouncyParticle(G, np.zeros(8), 0.5)
+        B_no.L = None
+        ens.set_flow_bps(B_no)
+        with pytest.raises(pkg._lib.PdmpError) as ei:
+            ens.set_state_bps(0.0, x0, x0 + 1.0, 1.1, np.array([1], dtype=np.uint64))
+        assert ei.value.code == pkg._lib.PDMP_ERR_UNSUPPORTED and "cholesky" in str(ei.value)
+        bad = pkg.BouncyParticle(G, np.zeros(8), 0.5, L=sp.csc_matrix(np.triu(B.L.toarray().T)))  # upper triangular
+        with pytest.raises(pkg._lib.PdmpError) as ei:
+            ens.set_flow_bps(bad)
+        assert ei.value.code == pkg._lib.PDMP_ERR_INVALID
+        ens.set_flow_bps(B)  # with the factor: accepted
+        ens.set_state_bps(0.0, x0, x0 + 1.0, 1.1, np.array([1], dtype=np.uint64))
+
+
+def test_local_bound_and_subsample(gpu_pkg):
+    """c::LocalBound of the non-factorised sampler (src/not_fact_samplers.jl:29-31, renew branch :65-71; LocalBound(20) is the
+    reference's own value, test/maintest.jl:182) and the `subsample` keyword (:53,90), with and without the mass factor."""
+    pkg = gpu_pkg
+    G = pkg.problems.maintest_precision(8)
+    rng = np.random.default_rng(4)
+    x0, th0 = rng.standard_normal((3, 8)), rng.standard_normal((3, 8))
+    tr = check(pkg, G, None, x0, th0, 20.0, 30.0, 0.5, seed=3, local_bound=True)
+    check(pkg, G, None, x0, th0, 20.0, 30.0, 0.5, seed=3, local_bound=True, L=sp.identity(8, format="csc"))
+    check(pkg, G, None, x0, th0, 1.1, 60.0, 0.5, seed=4, local_bound=True, rho=0.2)
+    trs = check(pkg, G, None, x0, th0, 1.1, 100.0, 0.5, seed=5, subsample=True)
+    assert all(len(q.t) > 20 for q in trs) and all(len(q.t) > 10 for q in tr)
+    G2 = pkg.problems.gmrf_precision(10)
+    check(pkg, G2, None, rng.standard_normal((2, 100)), rng.standard_normal((2, 100)), 8.0, 4.0, 1.0, seed=6, local_bound=True)
 
 
 def test_adapt_and_violation(gpu_pkg):
@@ -100,13 +170,13 @@ def test_boomerang_matches_oracle(gpu_pkg):
     pkg = gpu_pkg
     rng = np.random.default_rng(21)
 
-    def chk(Gt, mut, muf, x0, th0, c, T, lam, rho=0.0, adapt=False, seed=5):
+    def chk(Gt, mut, muf, x0, th0, c, T, lam, rho=0.0, adapt=False, seed=5, Gf=None):
         d = Gt.shape[0]
-        B = pkg.Boomerang(sp.identity(d, format="csc"), muf, lam, rho)
+        B = pkg.Boomerang(sp.identity(d, format="csc") if Gf is None else Gf, muf, lam, rho)
         tr, (t, x, th), (acc, num), cout = pkg.pdmp(pkg.GaussianTarget(Gt, mut), 0.0, x0, th0, T, c, B, adapt=adapt, seed=seed)
         for k in range(x0.shape[0]):
             r = O.pdmp_bps(Gt, mut, x0[k], th0[k], c, T, lambda_ref=lam, rho=rho, adapt=adapt, seed=seed + k, ev_cap=200000,
-                           boomerang_mu=muf)
+                           boomerang_mu=muf, mass_L=B.L)
             assert r["status"] == 0 and r["nevents"] > 10
             assert len(tr[k].t) == r["nevents"], (k, len(tr[k].t), r["nevents"])
             assert np.array_equal(tr[k].t, r["t_ev"]) and np.array_equal(tr[k].x, r["x_ev"]) and np.array_equal(tr[k].θ, r["theta_ev"])
@@ -124,3 +194,10 @@ def test_boomerang_matches_oracle(gpu_pkg):
         4.0, 100.0, 1.0, rho=0.4, seed=61)
     G2 = pkg.problems.gmrf_precision(10)
     chk(G2, None, np.zeros(100), rng.standard_normal((2, 100)), rng.standard_normal((2, 100)), 2.0, 30.0, 0.8, adapt=True, seed=62)
+    # test/maintest.jl:145 as written: B = Boomerang(Γ0, 0, 0.5) with Γ0 = Γ, i.e. L = cholesky(Γ).L in reflect!, refresh! and
+    # grad_correct! (src/not_fact_samplers.jl:9-12)
+    # (with that factor grad_correct! subtracts Γ⁻¹(x − μ), not Γ(x − μ): the constant bound is no bound any more -- the reference
+    # marks its covariance test @test_broken -- so `adapt` is on)
+    chk(G, None, np.zeros(8), rng.standard_normal((2, 8)), rng.standard_normal((2, 8)), 16.0, 100.0, 0.5, seed=63, Gf=G, adapt=True)
+    chk(G2, None, 0.1 * rng.standard_normal(100), rng.standard_normal((2, 100)), rng.standard_normal((2, 100)), 4.0, 10.0, 0.8,
+        rho=0.3, seed=64, Gf=G2, adapt=True)

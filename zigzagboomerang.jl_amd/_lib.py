@@ -14,6 +14,7 @@ PDMP_OK = 0
 ERR_NAMES = {0: "PDMP_OK", 1: "PDMP_ERR_INVALID", 2: "PDMP_ERR_NO_DEVICE", 3: "PDMP_ERR_HIP",
              4: "PDMP_ERR_UNSUPPORTED", 5: "PDMP_ERR_NOMEM"}
 
+PDMP_ERR_INVALID, PDMP_ERR_NO_DEVICE, PDMP_ERR_HIP, PDMP_ERR_UNSUPPORTED, PDMP_ERR_NOMEM = 1, 2, 3, 4, 5
 SAMPLER_ZIGZAG_LOCAL, SAMPLER_ZIGZAG_ALL, SAMPLER_BPS, SAMPLER_STICKY_ZIGZAG = 0, 1, 2, 3
 CHAIN_OK, CHAIN_BOUND_VIOLATED, CHAIN_STALLED, CHAIN_TRACE_FULL = 0, 1, 2, 3
 RUN_REFERENCE_TAIL, RUN_STOP_BEFORE = 0, 1
@@ -34,6 +35,7 @@ EXPORTED_SYMBOLS = [
     "pdmp_ensemble_trace_dev", "pdmp_ensemble_counters_dev", "pdmp_debug_math_probe",
     "pdmp_ensemble_set_flow_bps", "pdmp_ensemble_set_state_bps", "pdmp_ensemble_bps_trace_copy",
     "pdmp_ensemble_bps_final_state", "pdmp_ensemble_set_sticky", "pdmp_ensemble_set_adaptscale", "pdmp_ensemble_final_sigma", "pdmp_ensemble_set_flow_boomerang", "pdmp_ensemble_set_local_bound", "pdmp_debug_write_probe", "pdmp_debug_sector_probe", "pdmp_ensemble_set_target_logistic", "pdmp_ensemble_set_flow_factboomerang",
+    "pdmp_ensemble_set_mass_cholesky", "pdmp_ensemble_set_bps_options",
 ]
 
 
@@ -100,6 +102,8 @@ def load():
     L.pdmp_ensemble_set_flow_bps.argtypes = [vp, vp, vp, vp, vp, f64, f64]
     L.pdmp_ensemble_set_flow_boomerang.argtypes = [vp, vp, vp, vp, vp, vp, f64, f64]
     L.pdmp_ensemble_set_state_bps.argtypes = [vp, f64, vp, vp, f64, vp]
+    L.pdmp_ensemble_set_mass_cholesky.argtypes = [vp, vp, vp, vp]
+    L.pdmp_ensemble_set_bps_options.argtypes = [vp, C.c_int, C.c_int]
     L.pdmp_ensemble_bps_trace_copy.argtypes = [vp, i64, i64, i64, vp, vp, vp]
     L.pdmp_ensemble_bps_final_state.argtypes = [vp, i64, i64, vp, vp, vp, vp]
     for name in EXPORTED_SYMBOLS:

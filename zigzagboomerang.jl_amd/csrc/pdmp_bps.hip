@@ -95,7 +95,10 @@ __device__ __attribute__((noinline)) double bps_next_dt(uint64_t seed, uint64_t 
 }
 
 // FULL: d == 64 NS exactly, so the `element < d` guards (and their exec-mask bookkeeping) are compile-time true.
-template <int NS, bool DIAG, bool BOOM, bool IDENT, bool FULL = false>
+// EXT: the extended instantiation (general Γ only) adds what the fast ones leave out -- a caller-supplied mass factor L
+// (reflect!, refresh!, Boomerang's grad_correct!: column-oriented substitution through LDS, the order oracle/pdmp_oracle.c
+// fixes), c::LocalBound with its horizon and the renew branch (src/not_fact_samplers.jl:29-31,65-71), and `subsample` (:90).
+template <int NS, bool DIAG, bool BOOM, bool IDENT, bool FULL = false, bool EXT = false>
 __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
     const int lane = threadIdx.x;
     const int64_t chain = blockIdx.x;
@@ -116,6 +119,9 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
     uint64_t num = hdr->c.num, nacc = hdr->c.nacc, nrefresh = hdr->c.nrefresh, ntrace = hdr->c.ntrace,
              nevents = hdr->c.nevents;
     double t = sc[0], a = sc[1], b = sc[2], tp = sc[3], tau_ref = sc[4], c = sc[5];
+    bool renew = EXT && sc[6] != 0.0;  // next_time's flag (src/not_fact_samplers.jl:43-50): t′ is the bound's expiry, not a proposal
+    double hz = EXT ? sc[7] : BPS_INF; // abc[3]
+    const bool has_mass = EXT && P.Lcp != nullptr;
 
     constexpr int NG = IDENT ? 1 : NS;
     double x[NS], th[NS], g[NG], mu[NG], dg[NG];
@@ -187,6 +193,55 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
         }
         return sqrt(dot(th, th) + dot(dx, dx)) * c;
     };
+    // tmp <- L \ tmp and tmp <- L' \ tmp: column-oriented substitution (one column per step, its off-diagonal entries one per
+    // lane), every element updated in the order of the columns -- exactly tri_solve_lower / tri_solve_upper of the oracle.
+    // One wavefront: DS operations retire in order, so a step sees the previous step's updates without a barrier.
+    auto solve_lower = [&]() {
+        for (int64_t j = 0; j < d; ++j) {
+            asm volatile("" ::: "memory");
+            const int32_t p0 = P.Lcp[j], p1 = P.Lcp[j + 1];
+            const double yj = tmp[j] / P.Lnz[p0];
+            asm volatile("" ::: "memory");
+            if (lane == 0) tmp[j] = yj;
+            for (int32_t p = p0 + 1 + lane; p < p1; p += 64) {
+                const int32_t r = P.Lrv[p];
+                tmp[r] = tmp[r] - P.Lnz[p] * yj;
+            }
+        }
+        asm volatile("" ::: "memory");
+    };
+    auto solve_upper = [&]() {
+        for (int64_t j = d - 1; j >= 0; --j) {
+            asm volatile("" ::: "memory");
+            const int32_t p0 = P.Ucp[j], p1 = P.Ucp[j + 1] - 1;
+            const double zj = tmp[j] / P.Unz[p1];
+            asm volatile("" ::: "memory");
+            if (lane == 0) tmp[j] = zj;
+            for (int32_t p = p0 + lane; p < p1; p += 64) {
+                const int32_t r = P.Urv[p];
+                tmp[r] = tmp[r] - P.Unz[p] * zj;
+            }
+        }
+        asm volatile("" ::: "memory");
+    };
+    auto to_lds = [&](const double (&v)[NS]) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int64_t e = (int64_t)s * 64 + lane;
+            if (FULL || e < d) tmp[e] = v[s];
+        }
+        asm volatile("" ::: "memory");
+    };
+    auto from_lds = [&](double (&v)[NS]) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int64_t e = (int64_t)s * 64 + lane;
+            v[s] = (FULL || e < d) ? tmp[e] : 0.0;
+        }
+        asm volatile("" ::: "memory");
+    };
     auto rebound = [&](double Lnext) {
         if constexpr (IDENT) {
             a = c + dot(th, x);  // θ'(Γ(x−μ)) with Γ(x−μ) = x
@@ -200,7 +255,15 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
             apply_gamma(th, false, gt);
             b = dot(th, gt);
         }
-        tp = t + bps_poisson_time_L(a, b, Lnext);
+        if constexpr (EXT) {
+            // ab(x, θ, C::LocalBound, ∇ϕx, v, B) = (c + dot(θ, ∇ϕx), v, 2√d/c/‖θ‖₂), :29-31; next_time, :43-50
+            hz = (P.local_bound && !BOOM) ? 2 * sqrt((double)d) / c / sqrt(dot(th, th)) : BPS_INF;
+            const double dt = bps_poisson_time_L(a, b, Lnext);
+            renew = dt > hz;
+            tp = renew ? t + hz : t + dt;
+        } else {
+            tp = t + bps_poisson_time_L(a, b, Lnext);
+        }
         nm += 1;
     };
     // move_forward!(τ, t, x, θ, Flow): linear (src/dynamics.jl:11-15) or the rotation about μ (:29-36)
@@ -227,10 +290,25 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
         if constexpr (!IDENT) {
             apply_gamma(x, true, g);
             if (BOOM) {
+                if (has_mass) {  // grad_correct!: y .-= L'\(L\(x − μ)), src/not_fact_samplers.jl:9-12
+                    double dx[NS];
 #pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    const int64_t e = (int64_t)s * 64 + lane;
-                    if (FULL || e < d) g[s] -= x[s] - P.mu_flow[e];
+                    for (int s = 0; s < NS; ++s) {
+                        const int64_t e = (int64_t)s * 64 + lane;
+                        dx[s] = (FULL || e < d) ? (x[s] - P.mu_flow[e]) : 0.0;
+                    }
+                    to_lds(dx);
+                    solve_lower();
+                    solve_upper();
+                    from_lds(dx);
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) g[s] -= dx[s];
+                } else {
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        const int64_t e = (int64_t)s * 64 + lane;
+                        if (FULL || e < d) g[s] -= x[s] - P.mu_flow[e];
+                    }
                 }
             }
         }
@@ -269,6 +347,7 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
                 if (FULL || e1 < d) tmp[e1] = z1;
             }
             asm volatile("" ::: "memory");
+            if (has_mass) solve_upper();  // u = ρ̄*(L'\randn(rng, d)), src/dynamics.jl:115
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int64_t e = (int64_t)s * 64 + lane;
@@ -282,6 +361,10 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
             rebound(pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm)));  // :62-63
             nrefresh += 1;
             emit = true;  // :64
+        } else if (EXT && renew) {
+            // :65-71: the bound expired -- move (done above), gradient, new bound, new proposal; no thinning step, no event
+            gradient();
+            rebound(pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm)));
         } else {
             // both draws of a proposal have known indices (coin: nm, next_time: nm + 1 on accept and on reject alike): Philox and
             // the logarithm run beside the gradient and the reductions instead of after them
@@ -305,21 +388,43 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
                     c *= P.factor;  // :83
                 }
                 // reflect!, src/dynamics.jl:90-93 with L = I: θ .-= (2 dot(∇ϕx,θ)/normsq(∇ϕx)) ∇ϕx
-                double nrm;
-                if constexpr (IDENT) nrm = dot(x, x);
-                else nrm = dot(g, g);
-                const double coef = 2 * gt / nrm;
+                if (has_mass) {
+                    // θ .-= (2 dot(∇ϕx,θ)/normsq(L\∇ϕx)) (L'\(L\∇ϕx)), src/dynamics.jl:90-93
+                    if constexpr (!IDENT) {
+                        double w[NS];
+                        to_lds(g);
+                        solve_lower();
+                        from_lds(w);
+                        const double nrm = dot(w, w);
+                        solve_upper();
+                        from_lds(w);
+                        const double coef = 2 * gt / nrm;
 #pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    if constexpr (IDENT) th[s] -= coef * x[s];
-                    else th[s] -= coef * g[s];
+                        for (int s = 0; s < NS; ++s) th[s] -= coef * w[s];
+                    }
+                } else {
+                    double nrm;
+                    if constexpr (IDENT) nrm = dot(x, x);
+                    else nrm = dot(g, g);
+                    const double coef = 2 * gt / nrm;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        if constexpr (IDENT) th[s] -= coef * x[s];
+                        else th[s] -= coef * g[s];
+                    }
                 }
                 rebound(Lnext);  // :86-89
-                emit = true;  // :90
+                emit = !(EXT && P.subsample);  // :90 `!subsample && return`
             } else {
                 if (BOOM) a = boom_a();  // :92 recomputed after the rotation (b stays 0)
                 else a = c + gt;         // :92 (θ'g == g'θ bit for bit; b = θ'Γθ is unchanged because θ is)
-                tp = t + bps_poisson_time_L(a, b, Lnext);  // :93
+                const double dt = bps_poisson_time_L(a, b, Lnext);  // :93 (the horizon is unchanged: θ and c are)
+                if constexpr (EXT) {
+                    renew = dt > hz;
+                    tp = renew ? t + hz : t + dt;
+                } else {
+                    tp = t + dt;
+                }
                 nm += 1;
             }
         }
@@ -360,6 +465,10 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
         sc[3] = tp;
         sc[4] = tau_ref;
         sc[5] = c;
+        if constexpr (EXT) {
+            sc[6] = renew ? 1.0 : 0.0;
+            sc[7] = hz;
+        }
         hdr->c.t_last = t;
         hdr->t_event = t;
         hdr->c.num = num;
@@ -434,7 +543,15 @@ __global__ __launch_bounds__(64) void bps_init_kernel(BpsRunParams P, const uint
         apply_gamma(th, false, gt);
         b = dot(th, gt);
     }
-    const double tp = t0 + bps_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, 1));    // :135
+    double tp = t0 + bps_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, 1));          // :135
+    double hz = BPS_INF;
+    bool renew = false;
+    if (!BOOM && P.local_bound) {  // next_time with the LocalBound horizon, :29-31,43-50
+        hz = 2 * sqrt((double)d) / c0 / sqrt(dot(th, th));
+        const double dt = bps_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, 1));
+        renew = dt > hz;
+        tp = renew ? t0 + hz : t0 + dt;
+    }
     if (lane == 0) {
         double* sc = P.scal + chain * 8;
         sc[0] = t0;
@@ -443,8 +560,8 @@ __global__ __launch_bounds__(64) void bps_init_kernel(BpsRunParams P, const uint
         sc[3] = tp;
         sc[4] = tau_ref;
         sc[5] = c0;
-        sc[6] = 0.0;
-        sc[7] = 0.0;
+        sc[6] = renew ? 1.0 : 0.0;
+        sc[7] = hz;
         DevChain h;
         h.c.t_last = t0;
         h.c.num = 0;
@@ -473,6 +590,9 @@ static int launch_ns(const BpsRunParams& p, int64_t nchains, bool diag, bool ini
     if (init) {
         if (boom) hipLaunchKernelGGL((bps_init_kernel<NS, true>), grid, block, lds, (hipStream_t)stream, p, seeds, t0, c0);
         else hipLaunchKernelGGL((bps_init_kernel<NS, false>), grid, block, lds, (hipStream_t)stream, p, seeds, t0, c0);
+    } else if (p.ext) {
+        if (boom) hipLaunchKernelGGL((bps_run_kernel<NS, false, true, false, false, true>), grid, block, lds, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((bps_run_kernel<NS, false, false, false, false, true>), grid, block, lds, (hipStream_t)stream, p);
     } else if (boom) {
         if (diag) hipLaunchKernelGGL((bps_run_kernel<NS, true, true, false>), grid, block, lds, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((bps_run_kernel<NS, false, true, false>), grid, block, lds, (hipStream_t)stream, p);
@@ -530,6 +650,58 @@ __global__ __launch_bounds__(64) void sector_probe_kernel(double* rec, int64_t d
     double* base = rec + chain * d * 8;
     uint32_t h = (uint32_t)chain * 2654435761u + (uint32_t)lane * 40503u + 12345u;
     double acc = 0.0;
+    if (write >= 7) {
+        // WIDE requests: a group of lanes reads one contiguous, aligned run as a unit (the TA merges the lanes of one instruction
+        // that fall into one 128-byte line into a single request).  7/8: groups of 4 lanes, a random 128-byte line, each lane two
+        // 16-byte pieces (read / read and write back); 9/10: groups of 2 lanes, a random 64-byte record; 11/12: groups of 8 lanes of
+        // which 6 read a 96-byte run at a random 32-byte boundary (a lattice row's three hot records packed back to back).
+        const int gsz = (write <= 8) ? 4 : (write <= 10) ? 2 : 8;
+        const int gl = lane & (gsz - 1);
+        const bool wr = (write == 8 || write == 10 || write == 12);
+        uint32_t hg = (uint32_t)chain * 2654435761u + (uint32_t)(lane / gsz) * 40503u + 12345u;
+        for (int r = 0; r < rounds; ++r) {
+            double2* p[4];
+            double2* p2[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                hg = hg * 1664525u + 1013904223u;
+                const uint32_t rnd = hg >> 8;
+                if (write <= 8) {
+                    double* line = base + (size_t)(rnd % (uint32_t)(d / 2 - 2)) * 16;  // 128-byte lines
+                    p[q] = reinterpret_cast<double2*>(line) + gl;
+                    p2[q] = p[q] + 4;
+                } else if (write <= 10) {
+                    double* recp = base + (size_t)(rnd % (uint32_t)(d - 4)) * 8;  // 64-byte records
+                    p[q] = reinterpret_cast<double2*>(recp) + gl;
+                    p2[q] = p[q] + 2;
+                } else {
+                    double* run = base + (size_t)(rnd % (uint32_t)(2 * d - 16)) * 4;  // 32-byte boundary, 96 bytes
+                    p[q] = reinterpret_cast<double2*>(run) + (gl < 6 ? gl : 0);
+                    p2[q] = p[q];
+                }
+            }
+            double2 a[4], b[4];
+            const bool act = (write <= 10) || gl < 6;
+            if (act) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    a[q] = p[q][0];
+                    if (write <= 10) b[q] = p2[q][0];
+                    else b[q] = a[q];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc += a[q].x + b[q].y;
+                    if (wr) {
+                        p[q][0] = make_double2(a[q].x + 1.0, a[q].y);
+                        if (write <= 10) p2[q][0] = make_double2(b[q].x, b[q].y + 1.0);
+                    }
+                }
+            }
+        }
+        if (acc == 123.456) sink[0] = acc;
+        return;
+    }
     for (int r = 0; r < rounds; ++r) {
         double2* p[4];
 #pragma unroll

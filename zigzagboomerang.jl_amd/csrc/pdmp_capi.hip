@@ -134,6 +134,12 @@ struct pdmp_ensemble {
     bool bps_ident = false;
     bool bps_diag = false;
     double bps_lambda = 0.0, bps_rho = 0.0;
+    bool bps_gamma_is_I = false;  // flow Γ == I exactly: cholesky(Γ).L = I needs no factor from the caller
+    bool bps_has_mass = false;    // a factor was supplied (identity factors are dropped: has_mass_tables stays false)
+    bool bps_mass_tables = false;
+    int bps_local_bound = 0, bps_subsample = 0;
+    DevBuf<int32_t> m_Lcp, m_Lrv, m_Ucp, m_Urv;
+    DevBuf<double> m_Lnz, m_Unz;
 
     pdmp::ZzTables tables() const {
         pdmp::ZzTables tb{};
@@ -792,6 +798,8 @@ pdmp_status pdmp_ensemble_set_state_synthetic(pdmp_ensemble* e, double t0, const
     return init_state(e, t0, nullptr, nullptr, c, nullptr, seed0);
 }
 
+static void fill_bps_ext(const pdmp_ensemble* e, pdmp::BpsRunParams& B);
+
 pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* stream) {
     if (!e) return fail(PDMP_ERR_INVALID, "null argument");
     if (!e->has_state) return fail(PDMP_ERR_INVALID, "set_state must be called before run");
@@ -822,6 +830,7 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         B.rho = e->bps_rho;
         B.flags = flags;
         B.adapt = e->cfg.adapt;
+        fill_bps_ext(e, B);
         HIP_TRY(hipEventRecord(e->ev0, s));
         int rcb = pdmp::launch_bps_run(B, e->cfg.nchains, e->bps_diag, s);
         if (rcb != 0) return fail(PDMP_ERR_HIP, "bps_run launch failed (%d)", rcb);
@@ -1154,6 +1163,11 @@ static pdmp_status set_flow_nf(pdmp_ensemble* e, const int64_t* colptr, const in
     bool ident = diag && kind == 0;
     for (int64_t i = 0; ident && i < d; ++i) ident = (nzval[i] == 1.0) && (!mu || mu[i] == 0.0);
     e->bps_ident = ident;
+    bool gI = diag;
+    for (int64_t i = 0; gI && i < d; ++i) gI = (nzval[i] == 1.0);
+    e->bps_gamma_is_I = gI;
+    e->bps_has_mass = e->bps_mass_tables = false;
+    e->bps_local_bound = e->bps_subsample = 0;
     e->bps_lambda = lambda_ref;
     e->bps_rho = rho;
     pdmp_status st;
@@ -1184,10 +1198,86 @@ pdmp_status pdmp_ensemble_set_flow_boomerang(pdmp_ensemble* e, const int64_t* co
     return set_flow_nf(e, colptr, rowval, nzval, mu_target, lambda_ref, rho, 1, mu_flow);
 }
 
+static void fill_bps_ext(const pdmp_ensemble* e, pdmp::BpsRunParams& B) {
+    B.local_bound = e->bps_local_bound;
+    B.subsample = e->bps_subsample;
+    B.ext = (e->bps_mass_tables || e->bps_local_bound || e->bps_subsample) ? 1 : 0;
+    if (e->bps_mass_tables) {
+        B.Lcp = e->m_Lcp.p;
+        B.Lrv = e->m_Lrv.p;
+        B.Lnz = e->m_Lnz.p;
+        B.Ucp = e->m_Ucp.p;
+        B.Urv = e->m_Urv.p;
+        B.Unz = e->m_Unz.p;
+    }
+}
+
+pdmp_status pdmp_ensemble_set_mass_cholesky(pdmp_ensemble* e, const int64_t* colptr, const int64_t* rowval,
+                                            const double* nzval) {
+    if (!e || !colptr || !rowval || !nzval) return fail(PDMP_ERR_INVALID, "null argument");
+    if (e->cfg.sampler != PDMP_SAMPLER_BPS || !e->has_flow)
+        return fail(PDMP_ERR_INVALID, "set_flow_bps / set_flow_boomerang first (PDMP_SAMPLER_BPS)");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const int64_t d = e->cfg.d;
+    if (colptr[0] != 0) return fail(PDMP_ERR_INVALID, "colptr[0] must be 0 (0-based CSC)");
+    const int64_t nnz = colptr[d];
+    if (nnz < d || nnz >= ((int64_t)1 << 31)) return fail(PDMP_ERR_INVALID, "mass factor: bad number of entries");
+    bool identity = (nnz == d);
+    for (int64_t j = 0; j < d; ++j) {
+        if (colptr[j + 1] <= colptr[j]) return fail(PDMP_ERR_INVALID, "mass factor: empty column %lld", (long long)j);
+        if (rowval[colptr[j]] != j) return fail(PDMP_ERR_INVALID, "mass factor must be LOWER triangular with a stored diagonal");
+        const double djj = nzval[colptr[j]];
+        if (!(djj != 0.0) || djj != djj) return fail(PDMP_ERR_INVALID, "mass factor: zero or NaN diagonal at %lld", (long long)j);
+        for (int64_t p = colptr[j] + 1; p < colptr[j + 1]; ++p)
+            if (rowval[p] <= rowval[p - 1] || rowval[p] >= d) return fail(PDMP_ERR_INVALID, "mass factor: rows not ascending / out of range");
+        if (djj != 1.0) identity = false;
+    }
+    e->bps_has_mass = true;
+    e->bps_mass_tables = false;
+    e->has_state = false;
+    if (identity) return PDMP_OK;  // L = I: x / 1.0 and no off-diagonal updates -- the identity-mass kernels are bit-identical
+    std::vector<int32_t> lcp(colptr, colptr + d + 1), lrv(rowval, rowval + nnz), ucp(d + 2, 0), urv((size_t)nnz);
+    std::vector<double> lnz(nzval, nzval + nnz), unz((size_t)nnz);
+    for (int64_t p = 0; p < nnz; ++p) ucp[(size_t)rowval[p] + 2]++;
+    for (int64_t j = 0; j < d; ++j) ucp[(size_t)j + 2] += ucp[(size_t)j + 1];
+    for (int64_t j = 0; j < d; ++j)
+        for (int64_t p = colptr[j]; p < colptr[j + 1]; ++p) {
+            const int32_t q = ucp[(size_t)rowval[p] + 1]++;
+            urv[(size_t)q] = (int32_t)j;
+            unz[(size_t)q] = nzval[p];
+        }
+    ucp.pop_back();
+    pdmp_status st;
+    if ((st = e->m_Lcp.upload(lcp)) != PDMP_OK) return st;
+    if ((st = e->m_Lrv.upload(lrv)) != PDMP_OK) return st;
+    if ((st = e->m_Lnz.upload(lnz)) != PDMP_OK) return st;
+    if ((st = e->m_Ucp.upload(ucp)) != PDMP_OK) return st;
+    if ((st = e->m_Urv.upload(urv)) != PDMP_OK) return st;
+    if ((st = e->m_Unz.upload(unz)) != PDMP_OK) return st;
+    e->bps_mass_tables = true;
+    return PDMP_OK;
+}
+
+pdmp_status pdmp_ensemble_set_bps_options(pdmp_ensemble* e, int local_bound, int subsample) {
+    if (!e) return fail(PDMP_ERR_INVALID, "null argument");
+    if (e->cfg.sampler != PDMP_SAMPLER_BPS || !e->has_flow)
+        return fail(PDMP_ERR_INVALID, "set_flow_bps / set_flow_boomerang first (PDMP_SAMPLER_BPS)");
+    if (local_bound && e->bps_flow_kind != 0)
+        return fail(PDMP_ERR_UNSUPPORTED, "c::LocalBound is defined for BouncyParticle only (src/not_fact_samplers.jl:29-31)");
+    e->bps_local_bound = local_bound ? 1 : 0;
+    e->bps_subsample = subsample ? 1 : 0;
+    e->has_state = false;
+    return PDMP_OK;
+}
+
 pdmp_status pdmp_ensemble_set_state_bps(pdmp_ensemble* e, double t0, const double* x0, const double* theta0, double c,
                                         const uint64_t* seeds) {
     if (!e || !x0 || !theta0 || !seeds) return fail(PDMP_ERR_INVALID, "null argument");
     if (e->cfg.sampler != PDMP_SAMPLER_BPS || !e->has_flow) return fail(PDMP_ERR_INVALID, "set_flow_bps first");
+    if (e->bps_flow_kind == 0 && !e->bps_gamma_is_I && !e->bps_has_mass)
+        return fail(PDMP_ERR_UNSUPPORTED,
+                    "BouncyParticle(Γ ≠ I) carries the mass factor L = cholesky(Symmetric(Γ)).L (src/types.jl:43): pass it with "
+                    "pdmp_ensemble_set_mass_cholesky (an identity factor selects the identity mass explicitly)");
     HIP_TRY(hipSetDevice(e->cfg.device));
     const int64_t d = e->cfg.d, n = e->cfg.nchains, cap = e->cfg.trace_capacity;
     pdmp_status st;
@@ -1220,6 +1310,7 @@ pdmp_status pdmp_ensemble_set_state_bps(pdmp_ensemble* e, double t0, const doubl
     B.d = d;
     B.lambda_ref = e->bps_lambda;
     B.rho = e->bps_rho;
+    fill_bps_ext(e, B);
     int rc = pdmp::launch_bps_init(B, n, sseed.p, t0, c, e->stream);
     if (rc != 0) return fail(PDMP_ERR_HIP, "bps_init launch failed (%d)", rc);
     HIP_TRY(hipStreamSynchronize(e->stream));

@@ -177,6 +177,15 @@ struct BpsRunParams {
     int32_t flow_kind;                  // 0 BouncyParticle, 1 Boomerang (L = I): mu_flow is the centre of rotation
     int32_t ident;                      // Γ == I and μ == 0 exactly (isotropic target): gradient-free register layout
     const double* __restrict__ mu_flow;  // [d]
+    // extended instantiation (ext != 0): mass factor L (lower CSC, diagonal first) and L' (upper CSC, diagonal last), nullptr =
+    // identity; c::LocalBound; subsample
+    int32_t ext, local_bound, subsample, pad_;
+    const int32_t* __restrict__ Lcp;
+    const int32_t* __restrict__ Lrv;
+    const double* __restrict__ Lnz;
+    const int32_t* __restrict__ Ucp;
+    const int32_t* __restrict__ Urv;
+    const double* __restrict__ Unz;
 };
 int launch_bps_write_probe(double* ev_x, double* ev_th, int64_t d, int64_t cap, int64_t nrec, int64_t nchains, void* stream);
 int launch_sector_probe(double* rec, int64_t d, int64_t nchains, int rounds, int write, double* sink, void* stream);

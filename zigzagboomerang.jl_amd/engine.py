@@ -90,18 +90,34 @@ class Ensemble:
         cp, rv, nz, mu = _i64(G.indptr), _i64(G.indices), _f64(G.data), _f64(B.μ)
         _lib.check(self._L.pdmp_ensemble_set_flow_bps(self._h, _ptr(cp), _ptr(rv), _ptr(nz), _ptr(mu), float(B.λref),
                                                      float(B.ρ)))
+        self._set_mass(B)
+
+    def _set_mass(self, B):
+        """B.L = cholesky(Symmetric(Γ)).L (src/types.jl:43,66); None = identity."""
+        L = getattr(B, "L", None)
+        if L is None:
+            return
+        if L.shape != (self.d, self.d):
+            raise ValueError("mass factor L has the wrong shape")
+        cp, rv, nz = _i64(L.indptr), _i64(L.indices), _f64(L.data)
+        _lib.check(self._L.pdmp_ensemble_set_mass_cholesky(self._h, _ptr(cp), _ptr(rv), _ptr(nz)))
+
+    def set_bps_options(self, local_bound=False, subsample=False):
+        """c::LocalBound (src/not_fact_samplers.jl:29-31,65-71) and the `subsample` keyword (:53,90) of the non-factorised sampler."""
+        _lib.check(self._L.pdmp_ensemble_set_bps_options(self._h, int(bool(local_bound)), int(bool(subsample))))
 
     def set_flow_boomerang(self, target, B):
-        """Flow = Boomerang(I, μ, λ; ρ) on the Gaussian target ∇ϕ!(y, x) = Γt(x − μt)."""
+        """Flow = Boomerang(Γ, μ, λ; ρ) on the Gaussian target ∇ϕ!(y, x) = Γt(x − μt)."""
         G = B.Γ
-        if G.shape != (self.d, self.d) or G.nnz != self.d or not np.all(G.diagonal() == 1.0):
-            raise NotImplementedError("Boomerang: only Γ = I (mass L = I) is implemented on the device")
+        if G.shape != (self.d, self.d):
+            raise ValueError("flow Γ has the wrong shape")
         Gt = target.Γ
         cp, rv, nz = _i64(Gt.indptr), _i64(Gt.indices), _f64(Gt.data)
         mt = _f64(target.μ) if target.μ is not None else None
         mf = _f64(B.μ)
         _lib.check(self._L.pdmp_ensemble_set_flow_boomerang(self._h, _ptr(cp), _ptr(rv), _ptr(nz), _ptr(mt), _ptr(mf),
                                                            float(B.λref), float(B.ρ)))
+        self._set_mass(B)
 
     def set_state_bps(self, t0, x0, theta0, c, seeds):
         x0 = _f64(x0).reshape(self.nchains, self.d)

@@ -61,17 +61,40 @@ class FactBoomerang:
         self.σ = np.ascontiguousarray(self.σ, dtype=np.float64)
 
 
+def _is_identity(G):
+    return G.nnz == G.shape[0] and np.array_equal(G.indices, np.arange(G.shape[0])) and bool(np.all(G.data == 1.0))
+
+
+def cholesky_lower(Γ):
+    """L = cholesky(Symmetric(Γ)).L (src/types.jl:43,66) as a lower-triangular CSC matrix, factorised densely in the NATURAL
+    ordering.  For a dense Γ this is the reference's factor up to LAPACK rounding; for a SparseMatrixCSC the reference calls
+    CHOLMOD, whose `.L` is the factor of the fill-reducing PERMUTATION of Γ -- a different (equally valid) mass matrix that a
+    caller who wants it bit for bit passes explicitly as `L=`."""
+    A = Γ.toarray() if sp.issparse(Γ) else np.asarray(Γ, dtype=np.float64)
+    A = np.triu(A) + np.triu(A, 1).T  # Symmetric(Γ) reads the upper triangle
+    L = sp.csc_matrix(np.tril(np.linalg.cholesky(A)))
+    L.sort_indices()
+    return L
+
+
 @dataclass
 class BouncyParticle:
-    """BouncyParticle(Γ, μ, λ; ρ=0.0) -- src/types.jl:35-45 (mass L = cholesky(Symmetric(Γ)).L)."""
+    """BouncyParticle(Γ, μ, λ; ρ=0.0) -- src/types.jl:35-45.  L is the mass factor the reference stores in the struct
+    (`cholesky(Symmetric(Γ)).L`, :43): computed here when not given (None and Γ = I: identity); the 6-field constructor
+    BouncyParticle(Γ, μ, λ, ρ, U, L) of the reference corresponds to passing `L=` explicitly."""
     Γ: sp.csc_matrix
     μ: np.ndarray
     λref: float
     ρ: float = 0.0
+    L: Optional[sp.csc_matrix] = None
 
     def __post_init__(self):
         self.Γ = _csc(self.Γ)
         self.μ = np.ascontiguousarray(self.μ, dtype=np.float64)
+        if self.L is None:
+            self.L = None if _is_identity(self.Γ) else cholesky_lower(self.Γ)
+        else:
+            self.L = _csc(self.L)
 
 
 @dataclass
@@ -82,16 +105,21 @@ class LocalBound:
 
 @dataclass
 class Boomerang:
-    """Boomerang(Γ, μ, λ; ρ=0.0) -- src/types.jl:59-66: Hamiltonian dynamics preserving N(μ, ·) with refreshment rate λ.
-    The device path implements the mass L = I, i.e. Γ must be the identity (a general cholesky(Γ).L is not implemented)."""
+    """Boomerang(Γ, μ, λ; ρ=0.0) -- src/types.jl:59-66: Hamiltonian dynamics preserving N(μ, ·) with refreshment rate λ; Γ enters
+    through its factor L = cholesky(Symmetric(Γ)).L only (reflect!, refresh!, grad_correct!), see BouncyParticle."""
     Γ: sp.csc_matrix
     μ: np.ndarray
     λref: float
     ρ: float = 0.0
+    L: Optional[sp.csc_matrix] = None
 
     def __post_init__(self):
         self.Γ = _csc(self.Γ)
         self.μ = np.ascontiguousarray(self.μ, dtype=np.float64)
+        if self.L is None:
+            self.L = None if _is_identity(self.Γ) else cholesky_lower(self.Γ)
+        else:
+            self.L = _csc(self.L)
 
 
 @dataclass

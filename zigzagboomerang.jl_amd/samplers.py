@@ -39,21 +39,25 @@ def spdmp(target, t0, x0, θ0, T, c, F, *, factor=1.8, adapt=False, adaptscale=F
                    adaptscale=adaptscale)
 
 
-def pdmp(target, t0, x0, θ0, T, c, F, *, factor=1.8, adapt=False, seed=DEFAULT_SEED, device=0,
+def pdmp(target, t0, x0, θ0, T, c, F, *, factor=1.8, adapt=False, subsample=False, seed=DEFAULT_SEED, device=0,
          trace_capacity=None, trace=True):
     """pdmp(∇ϕ, t0, x0, θ0, T, c, F::ZigZag, args...) = spdmp(..., All(), ...) (src/sfact.jl:236): every proposal moves
     ALL coordinates (no sparsity assumption on ∇ϕ); same return value as spdmp.
 
     pdmp(∇ϕ!, t0, x0, θ0, T, c, B::BouncyParticle; adapt, factor=2.0) (src/not_fact_samplers.jl:117,395-396) when F is a
-    BouncyParticle: the target is ∇ϕ!(y, x) = B.Γ(x − B.μ) (pass target=None), c is the scalar of GlobalBound(c);
-    returns Ξ::PDMPTrace, (t, x, θ), (acc, num), c."""
+    BouncyParticle: the target is ∇ϕ!(y, x) = B.Γ(x − B.μ) (pass target=None), c is the scalar of GlobalBound(c) or a
+    LocalBound(c) (src/not_fact_samplers.jl:29-31; the second derivative v = θ'Γθ is the Gaussian target's own);
+    `subsample` as in the reference (:53,90); returns Ξ::PDMPTrace, (t, x, θ), (acc, num), c."""
     if isinstance(F, BouncyParticle):
-        return _bps(t0, x0, θ0, T, c, F, 2.0 if factor == 1.8 else factor, adapt, seed, device, trace_capacity, trace)
+        return _bps(t0, x0, θ0, T, c, F, 2.0 if factor == 1.8 else factor, adapt, seed, device, trace_capacity, trace,
+                    subsample=subsample)
     if isinstance(F, Boomerang):  # pdmp(∇ϕ!, t0, x0, θ0, T, c, B::Boomerang) (test/maintest.jl:139-154); target = GaussianTarget
         if not isinstance(target, GaussianTarget):
             raise TypeError("Boomerang: target must be a GaussianTarget (∇ϕ!(y, x) = Γ(x − μ))")
         return _bps(t0, x0, θ0, T, c, F, 2.0 if factor == 1.8 else factor, adapt, seed, device, trace_capacity, trace,
-                    target=target)
+                    target=target, subsample=subsample)
+    if subsample:
+        raise TypeError("subsample is a keyword of the non-factorised pdmp (BouncyParticle / Boomerang)")
     return _zigzag(_lib.SAMPLER_ZIGZAG_ALL, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, trace_capacity, trace)
 
 
@@ -130,7 +134,10 @@ def _zigzag(sampler, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, 
     return traces, (fs["t"], fs["x"], fs["theta"]), (acc, num), c_out
 
 
-def _bps(t0, x0, θ0, T, c, B, factor, adapt, seed, device, trace_capacity, trace, target=None):
+def _bps(t0, x0, θ0, T, c, B, factor, adapt, seed, device, trace_capacity, trace, target=None, subsample=False):
+    local_bound = isinstance(c, LocalBound)
+    if local_bound:
+        c = float(np.asarray(c.c, dtype=np.float64).reshape(-1)[0])
     x0 = np.asarray(x0, dtype=np.float64)
     θ0 = np.asarray(θ0, dtype=np.float64)
     single = x0.ndim == 1
@@ -146,6 +153,8 @@ def _bps(t0, x0, θ0, T, c, B, factor, adapt, seed, device, trace_capacity, trac
             ens.set_flow_boomerang(target, B)
         else:
             ens.set_flow_bps(B)
+        if local_bound or subsample:
+            ens.set_bps_options(local_bound, subsample)
         ens.set_state_bps(t0, X0, TH0, float(c), seeds)
         ts = [[] for _ in range(nch)]
         xs = [[] for _ in range(nch)]
