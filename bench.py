@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--grid", type=int, default=GRID)
     ap.add_argument("--dt", type=float, default=DT_STEP)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ess-batches", type=int, default=32, help="B: batches per chain of the ESS run after the timed region (0: skip)")
+    ap.add_argument("--ess-batch-len", type=float, default=2.0, help="b: length of an ESS batch in process time")
     ap.add_argument("--no-trace", action="store_true", help="count events only (diagnostic; not the headline mode)")
     args = ap.parse_args()
 
@@ -163,34 +165,45 @@ def main():
     nacc = tot1["nacc"] - tot0["nacc"]
     nev = tot1["nevents"] - tot0["nevents"]
 
-    # ESS/s: batch means of the exact path integral, one batch per extra slice AFTER the timed region
+    # ESS/s: batch means INSIDE each chain over one long run after the timed region (which serves as burn-in):
+    # B = 32 batches of length b, sigma2_asym = b * pooled within-chain variance of the batch means,
+    # ESS_i = N * B * b * Var_pi,i / sigma2_asym,i at 32 probe coordinates with exact Var_pi = diag(inv(Gamma)); divided by the
+    # GPU seconds (kernel time) that produced the path.  Validated in tests/test_gpu_ess.py against a closed-form target.
     ess = None
-    if rank == 0 and world == 1 and not args.no_trace and args.steps >= 4:
-        B = 8
+    if rank == 0 and world == 1 and not args.no_trace and args.ess_batches >= 2:
+        B, b = args.ess_batches, args.ess_batch_len
         T0 = (args.warmup + args.steps) * args.dt
-        s1 = np.zeros(d)
-        s2 = np.zeros(d)
-        t_ess = time.perf_counter()
-        ens.batch_means(0.0, T0)  # sets the baseline J(T0); its Y over [0,T0] is discarded (burn-in)
-        for b in range(B):
-            Tb = T0 + (b + 1) * args.dt
-            ens.run(Tb, pkg._lib.RUN_STOP_BEFORE)
-            ens.trace_reset()
-            a, q = ens.batch_means(Tb - args.dt, Tb)
-            s1 += a
-            s2 += q
-        t_ess = time.perf_counter() - t_ess
-        n = B * nch
-        var_y = (s2 - s1 * s1 / n) / (n - 1)
+        ess_ms = 0.0
+        ens.ess_begin(T0)
+        for kb in range(B):
+            Tb = T0 + (kb + 1) * b
+            # a batch is advanced in slices of dT so that the trace segments (sized for one step) are recycled as in the timed steps
+            nsl = max(1, int(round(b / args.dt)))
+            for q in range(nsl):
+                ens.run(T0 + kb * b + (q + 1) * (b / nsl), pkg._lib.RUN_STOP_BEFORE, sync=False)
+                ess_ms += ens.last_run_ms()
+                if cap:
+                    ens.trace_reset()
+            ens.ess_batch(Tb)
+        sy, sy2, sm, sm2, nb, _, _ = ens.ess_end()
         import scipy.sparse.linalg as spla
         lu = spla.splu(G.tocsc())
         probes = np.linspace(0, d - 1, 32).astype(int)
         var_pi = np.array([lu.solve(np.eye(1, d, p).ravel())[p] for p in probes])
-        ess_i = n * var_pi / np.maximum(var_y[probes], 1e-300)  # ESS over all chains and batches, per coordinate
-        ess = {"definition": "batch means of exact path integrals, B=8 batches x all chains, 32 probe coordinates, "
-                             "Var_pi = exact diag(inv(Gamma))",
-               "ess_min_per_s": float(ess_i.min() / t_ess), "ess_median_per_s": float(np.median(ess_i) / t_ess),
-               "seconds": t_ess}
+        r = pkg.ess.batch_means_ess(sy[probes], sy2[probes], sm[probes], sm2[probes], nch, B, b, var_pi)
+        gpu_s = ess_ms * 1e-3
+        ess_b = nch * B * b * var_pi / np.maximum(r["sigma2_between"], 1e-300)
+        ess = {"definition": f"within-chain batch means of exact path integrals: B={B} batches of length b={b} per chain after "
+                             f"burn-in T0={T0}, sigma2_asym = b*pooled within-chain Var(batch means), ESS_i = N*B*b*Var_pi,i/"
+                             "sigma2_asym,i at 32 probe coordinates, Var_pi = exact diag(inv(Gamma)); per GPU second of the run "
+                             "that produced the path",
+               "ess_min_per_s": float(r["ess"].min() / gpu_s), "ess_median_per_s": float(np.median(r["ess"]) / gpu_s),
+               "ess_per_chain_time_median": float(np.median(r["ess_per_time"])),
+               "between_chain_check": {"ess_min_per_s": float(ess_b.min() / gpu_s), "ess_median_per_s": float(np.median(ess_b) / gpu_s),
+                                       "note": "from the spread of the N chain means over the same run; lower than the within-chain "
+                                               "figure when modes slower than the run (the lattice's constant mode, eigenvalue 0.01) "
+                                               "have not mixed -- chains start at x0 ~ N(0, I), not at stationarity"},
+               "gpu_seconds": gpu_s, "batches": B, "batch_len": b}
 
     # aggregate over ranks: max time, summed work
     if dist is not None:

@@ -217,6 +217,24 @@ pdmp_status pdmp_ensemble_final_state(pdmp_ensemble* ens, int64_t chain_first, i
  */
 pdmp_status pdmp_ensemble_batch_means(pdmp_ensemble* ens, double T_prev, double T, double* sum_y, double* sum_y2);
 
+/*
+ * Effective sample size by batch means INSIDE each chain (no counterpart in the reference; integrand as above).  All chains
+ * paused with PDMP_RUN_STOP_BEFORE at the times named:
+ *   ess_begin(T0)   after burn-in: snapshots the path integrals J_i(T0) of every chain;
+ *   ess_batch(T)    closes the batch (T_last, T]: Y = (J(T) − J(T_last))/(T − T_last) per chain and coordinate, device sums
+ *                   ΣY and ΣY² over chains and batches (call it B times with equally long batches);
+ *   ess_end(...)    the chain means over the whole run, M = (J(T_B) − J(T0))/(T_B − T0): ΣM and ΣM² over chains; returns all
+ *                   four [d] sums, the number of batches and the run's end points.
+ * With N chains, B batches of length b:  within-chain  S_w = ΣY² − B·ΣM²,  σ²_asym = b·S_w/(N(B−1))  (pooled over chains),
+ * between-chain  σ²_asym ≈ B·b·(ΣM² − (ΣM)²/N)/(N−1)  (valid at stationarity),  ESS_i = N·B·b·Var_π,i/σ²_asym,i
+ * (zigzagboomerang.jl_amd/ess.py).  ZigZag flows only (a FactBoomerang path rotates between events: PDMP_ERR_UNSUPPORTED, as for
+ * pdmp_ensemble_batch_means).
+ */
+pdmp_status pdmp_ensemble_ess_begin(pdmp_ensemble* ens, double T0);
+pdmp_status pdmp_ensemble_ess_batch(pdmp_ensemble* ens, double T);
+pdmp_status pdmp_ensemble_ess_end(pdmp_ensemble* ens, double* sum_y, double* sum_y2, double* sum_m, double* sum_m2,
+                                  int64_t* nbatches, double* T0, double* T1);
+
 /* ------------------------------------------------------------------ sticky ZigZag (PDMP_SAMPLER_STICKY_ZIGZAG)
  *
  * sspdmp(∇ϕ, t0, x0, θ0, T, c, F::ZigZag, κ, args...; reversible=false, strong_upperbounds=false, factor=1.5, adapt)

@@ -23,7 +23,8 @@ def test_fact_trace_mean_cummean_collect_discretize_subtrace(pkg):
         assert t[0] == 0.0 and np.all(np.diff(t) > 0)
         assert abs(y[-1] * t[-1] / T - m[i]) < 1e-12  # same integral, normalised by T instead of the coordinate's last event time
     ts, xs = pkg.trace.collect(tr)  # :44-63, last event not applied
-    assert len(ts) == len(tr.events) and np.all(np.diff(ts) >= 0)
+    assert len(ts) == 1 + len(tr.events) == len(tr) and np.all(np.diff(ts) >= 0)  # Base.length(FT), src/trace.jl:42
+    assert ts[-1] == ts[-2] and np.array_equal(xs[-1], xs[-2])  # the last event is never applied (:56)
     td, xd = pkg.trace.discretize(tr, 0.5)  # :94-125
     assert np.allclose(np.diff(td), 0.5) and xd.shape == (len(td), 8)
     J = np.array([1, 4, 6])
@@ -52,3 +53,103 @@ def test_pdmp_trace_mean_cummean_discretize(pkg):
     k = np.searchsorted(tr.t, td[10], side="right") - 1
     xk = (tr.x[k] if k >= 0 else x0) + (tr.θ[k] if k >= 0 else th0) * (td[10] - (tr.t[k] if k >= 0 else 0.0))
     assert np.allclose(xd[10], xk)
+
+
+def _sequential_collect(tr, boom):
+    """Base.iterate(FT::FactTrace) written as the reference writes it (src/trace.jl:44-63): move ALL coordinates to the event time
+    (move_forward!: linear, src/dynamics.jl:11-15, or the rotation about μ, :29-36), then overwrite x[i], θ[i]; the last event is
+    not applied and the final state is yielded twice."""
+    t, x, th = tr.t0, tr.x0.copy(), tr.θ0.copy()
+    ts, xs = [t], [x.copy()]
+    ev = tr.events
+    for k in range(len(ev) - 1):
+        t2, i, xi, thi = ev[k]
+        if boom:
+            mu, s, c = tr.F.μ, np.sin(t2 - t), np.cos(t2 - t)
+            x, th = (x - mu) * c + th * s + mu, -(x - mu) * s + th * c
+        else:
+            x = x + th * (t2 - t)
+        t = t2
+        x[i], th[i] = xi, thi
+        ts.append(t)
+        xs.append(x.copy())
+    ts.append(t)
+    xs.append(x.copy())
+    return np.array(ts), np.array(xs)
+
+
+def _sequential_discretize(tr, dt, boom):
+    """Base.iterate(D::Discretize{<:FactTrace}) as written (src/trace.jl:106-125)."""
+    ev = tr.events
+    t, x, th = tr.t0, tr.x0.copy(), tr.θ0.copy()
+    ts, xs = [t], [x.copy()]
+    k, n = 0, len(ev)
+
+    def flow(x, th, tau):
+        if boom:
+            mu, s, c = tr.F.μ, np.sin(tau), np.cos(tau)
+            return (x - mu) * c + th * s + mu, -(x - mu) * s + th * c
+        return x + th * tau, th
+
+    while True:
+        step, done = dt, False
+        while True:
+            if k >= n:
+                done = True
+                break
+            ti = ev["t"][k]
+            if t + step < ti:
+                x, th = flow(x, th, step)
+                t += step
+                break
+            x, th = flow(x, th, ti - t)
+            step -= ti - t
+            t = ti
+            x[ev["i"][k]], th[ev["i"][k]] = ev["x"][k], ev["theta"][k]
+            k += 1
+        if done:
+            break
+        ts.append(t)
+        xs.append(x.copy())
+    return np.array(ts), np.array(xs)
+
+
+def test_vectorised_consumers_equal_the_reference_loops(pkg):
+    """The closed-form, per-coordinate consumers against event-by-event restatements of src/trace.jl, for a ZigZag trace and for a
+    FactBoomerang trace (whose path ROTATES between events: collect must not move it linearly)."""
+    tr = _fact_trace(pkg, T=60.0)
+    ts, xs = pkg.trace.collect(tr)
+    ts0, xs0 = _sequential_collect(tr, False)
+    assert np.array_equal(ts, ts0) and np.allclose(xs, xs0, rtol=0, atol=1e-11)
+    td, xd = pkg.trace.discretize(tr, 0.37)
+    td0, xd0 = _sequential_discretize(tr, 0.37, False)
+    assert len(td) == len(td0) and np.allclose(td, td0, rtol=0, atol=1e-10) and np.allclose(xd, xd0, rtol=0, atol=1e-9)
+    # mean / inclusion_prob / moments against the per-event loops of src/trace.jl:161-200
+    ev = tr.events
+    x, t, y, p = tr.x0.copy(), np.full(8, tr.t0), np.zeros(8), np.zeros(8)
+    T = ev["t"][-1]
+    for t2, i, xi, _ in ev:
+        y[i] += (x[i] + xi) * (t2 - t[i]) * (1 / (2 * T))
+        p[i] += ((x[i] != 0) | (xi != 0)) * (t2 - t[i]) / T
+        t[i], x[i] = t2, xi
+    assert np.array_equal(pkg.trace.mean(tr), y) and np.array_equal(pkg.trace.inclusion_prob(tr), p)
+    m, v = pkg.trace.moments(tr, 50.0)
+    grid, xg = pkg.trace.discretize(tr, 0.001)
+    sel = grid < 50.0
+    assert np.allclose(m, xg[sel].mean(0), atol=2e-3) and np.allclose(v, xg[sel].var(0), atol=5e-3)
+    # FactBoomerang: events from the oracle, rotation between events
+    G = pkg.problems.maintest_precision(8)
+    rng = np.random.default_rng(5)
+    x0, th0 = rng.standard_normal(8), rng.standard_normal(8)
+    F = pkg.FactBoomerang(sp.csc_matrix(1.2 * G), 0.1 * rng.standard_normal(8), 0.3)
+    r = O.spdmp_zigzag(F.Γ, F.μ, G, x0, th0, 2.0 * pkg.problems.column_norms(G), 40.0, seed=4, lambda_ref=0.3, sigma=F.σ,
+                       factboomerang=True, adapt=True)
+    trb = pkg.FactTrace(F, 0.0, x0, th0, r["events"])
+    assert len(trb.events) > 50
+    ts, xs = pkg.trace.collect(trb)
+    ts0, xs0 = _sequential_collect(trb, True)
+    assert np.array_equal(ts, ts0) and np.allclose(xs, xs0, rtol=0, atol=1e-10)
+    assert not np.allclose(xs, _sequential_collect(trb, False)[1], atol=1e-3)  # a linear move is a different path
+    td, xd = pkg.trace.discretize(trb, 0.25)
+    td0, xd0 = _sequential_discretize(trb, 0.25, True)
+    assert len(td) == len(td0) and np.allclose(xd, xd0, rtol=0, atol=1e-9)

@@ -36,6 +36,7 @@ EXPORTED_SYMBOLS = [
     "pdmp_ensemble_set_flow_bps", "pdmp_ensemble_set_state_bps", "pdmp_ensemble_bps_trace_copy",
     "pdmp_ensemble_bps_final_state", "pdmp_ensemble_set_sticky", "pdmp_ensemble_set_adaptscale", "pdmp_ensemble_final_sigma", "pdmp_ensemble_set_flow_boomerang", "pdmp_ensemble_set_local_bound", "pdmp_debug_write_probe", "pdmp_debug_sector_probe", "pdmp_ensemble_set_target_logistic", "pdmp_ensemble_set_flow_factboomerang",
     "pdmp_ensemble_set_mass_cholesky", "pdmp_ensemble_set_bps_options",
+    "pdmp_ensemble_ess_begin", "pdmp_ensemble_ess_batch", "pdmp_ensemble_ess_end",
 ]
 
 
@@ -54,7 +55,8 @@ _lib = None
 
 
 def lib_path():
-    return _build.LIB_PATH
+    """The in-tree engine library; PDMP_MI355_LIB selects another build of it (an experimental variant made by build.py --variant)."""
+    return os.environ.get("PDMP_MI355_LIB") or _build.LIB_PATH
 
 
 def load():
@@ -102,6 +104,9 @@ def load():
     L.pdmp_ensemble_set_flow_bps.argtypes = [vp, vp, vp, vp, vp, f64, f64]
     L.pdmp_ensemble_set_flow_boomerang.argtypes = [vp, vp, vp, vp, vp, vp, f64, f64]
     L.pdmp_ensemble_set_state_bps.argtypes = [vp, f64, vp, vp, f64, vp]
+    L.pdmp_ensemble_ess_begin.argtypes = [vp, f64]
+    L.pdmp_ensemble_ess_batch.argtypes = [vp, f64]
+    L.pdmp_ensemble_ess_end.argtypes = [vp, vp, vp, vp, vp, C.POINTER(i64), C.POINTER(f64), C.POINTER(f64)]
     L.pdmp_ensemble_set_mass_cholesky.argtypes = [vp, vp, vp, vp]
     L.pdmp_ensemble_set_bps_options.argtypes = [vp, C.c_int, C.c_int]
     L.pdmp_ensemble_bps_trace_copy.argtypes = [vp, i64, i64, i64, vp, vp, vp]

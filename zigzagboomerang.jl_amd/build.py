@@ -31,32 +31,66 @@ def find_hipcc():
     raise RuntimeError("hipcc not found: libpdmp_mi355.so cannot be built (there is no CPU fallback)")
 
 
-def needs_build():
-    if not os.path.exists(LIB_PATH):
+def needs_build(lib_path=LIB_PATH):
+    if not os.path.exists(lib_path):
         return True
     deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
-    return os.path.getmtime(LIB_PATH) < max(os.path.getmtime(p) for p in deps)
+    return os.path.getmtime(lib_path) < max(os.path.getmtime(p) for p in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
-        return LIB_PATH
+def variant_path(variant):
+    return LIB_PATH if not variant else os.path.join(LIB_DIR, "libpdmp_mi355.%s.so" % variant)
+
+
+def build(force=False, verbose=False, variant=None, defines=()):
+    """Compile every source to an object file (in parallel, re-used while newer than the source and the headers) and link them.
+
+    variant / defines: an experimental build `lib/libpdmp_mi355.<variant>.so` with extra -D flags, selected at run time with the
+    environment variable PDMP_MI355_LIB (A/B timing of kernel versions inside one GPU session, tools/ab.sh)."""
+    lib_path = variant_path(variant)
+    if not force and not defines and not needs_build(lib_path):
+        return lib_path
     os.makedirs(LIB_DIR, exist_ok=True)
+    obj_dir = os.path.join(LIB_DIR, "obj" + ("." + variant if variant else ""))
+    os.makedirs(obj_dir, exist_ok=True)
     # several ranks of one node may arrive here together (torchrun): serialise, and let the late ones find the fresh .so
     import fcntl
+    from concurrent.futures import ThreadPoolExecutor
     with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            if force or needs_build():
-                tmp = LIB_PATH + ".tmp.%d" % os.getpid()
-                cmd = [find_hipcc()] + HIPCC_FLAGS + ["-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+            if force or defines or needs_build(lib_path):
+                hipcc = find_hipcc()
+                cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + ["-D" + d for d in defines]
+                hdr_time = max(os.path.getmtime(p) for p in HEADERS)
+
+                def compile_one(src):
+                    srcp = os.path.join(CSRC, src)
+                    obj = os.path.join(obj_dir, src + ".o")
+                    stamp = obj + ".flags"
+                    flags_txt = " ".join(cflags)
+                    fresh = (os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(srcp), hdr_time)
+                             and os.path.exists(stamp) and open(stamp).read() == flags_txt)
+                    if force or not fresh:
+                        cmd = [hipcc] + cflags + ["-c", srcp, "-o", obj]
+                        if verbose:
+                            print(" ".join(cmd))
+                        subprocess.check_call(cmd)
+                        with open(stamp, "w") as f:
+                            f.write(flags_txt)
+                    return obj
+
+                with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:
+                    objs = list(pool.map(compile_one, SOURCES))
+                tmp = lib_path + ".tmp.%d" % os.getpid()
+                cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
                 if verbose:
                     print(" ".join(cmd))
                 subprocess.check_call(cmd)
-                os.replace(tmp, LIB_PATH)  # atomic: a concurrent dlopen never sees a half-written file
+                os.replace(tmp, lib_path)  # atomic: a concurrent dlopen never sees a half-written file
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
-    return LIB_PATH
+    return lib_path
 
 
 EXAMPLES_DIR = os.path.join(os.path.dirname(PKG_DIR), "examples")
@@ -89,5 +123,12 @@ def build_examples(verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
-    print(build_examples(verbose=True))
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--variant", default=None, help="experimental build lib/libpdmp_mi355.<variant>.so")
+    ap.add_argument("-D", dest="defines", action="append", default=[])
+    a = ap.parse_args()
+    print(build(force=a.force, verbose=True, variant=a.variant, defines=tuple(a.defines)))
+    if not a.variant:
+        print(build_examples(verbose=True))

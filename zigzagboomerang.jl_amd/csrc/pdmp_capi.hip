@@ -103,6 +103,9 @@ struct pdmp_ensemble {
     // device state
     DevBuf<pdmp::ZzRec> d_rec;
     DevBuf<double> d_keys, d_c_chain, d_jprev, d_sum;
+    DevBuf<double> d_jstart, d_essacc;  // pdmp_ensemble_ess_*
+    double ess_T0 = 0.0, ess_Tlast = 0.0;
+    int64_t ess_batches = -1;  // -1: no ess_begin yet
     DevBuf<pdmp::DevChain> d_hdr;
     DevBuf<pdmp_event> d_ev;
     // general-degree kernel + logistic target + FactBoomerang
@@ -1068,9 +1071,11 @@ pdmp_status pdmp_ensemble_final_state(pdmp_ensemble* e, int64_t chain_first, int
     return PDMP_OK;
 }
 
+static pdmp_status ess_ready(pdmp_ensemble* e);
+
 pdmp_status pdmp_ensemble_batch_means(pdmp_ensemble* e, double T_prev, double T, double* sum_y, double* sum_y2) {
-    if (!e) return fail(PDMP_ERR_INVALID, "null argument");
-    if (!e->has_state) return fail(PDMP_ERR_INVALID, "no state");
+    pdmp_status st0 = ess_ready(e);
+    if (st0 != PDMP_OK) return st0;
     if (!(T > T_prev)) return fail(PDMP_ERR_INVALID, "T must exceed T_prev");
     HIP_TRY(hipSetDevice(e->cfg.device));
     HIP_TRY(hipDeviceSynchronize());
@@ -1088,6 +1093,70 @@ pdmp_status pdmp_ensemble_batch_means(pdmp_ensemble* e, double T_prev, double T,
     HIP_TRY(hipStreamSynchronize(e->stream));
     if (sum_y) HIP_TRY(hipMemcpy(sum_y, e->d_sum.p, (size_t)d * sizeof(double), hipMemcpyDeviceToHost));
     if (sum_y2) HIP_TRY(hipMemcpy(sum_y2, e->d_sum.p + d, (size_t)d * sizeof(double), hipMemcpyDeviceToHost));
+    return PDMP_OK;
+}
+
+static pdmp_status ess_ready(pdmp_ensemble* e) {
+    if (!e) return fail(PDMP_ERR_INVALID, "null argument");
+    if (e->cfg.sampler == PDMP_SAMPLER_BPS) return fail(PDMP_ERR_INVALID, "path integrals are kept by the factorised samplers only");
+    if (!e->has_state) return fail(PDMP_ERR_INVALID, "no state");
+    if (e->flow_kind != 0)
+        return fail(PDMP_ERR_UNSUPPORTED, "path integrals assume the linear flow of the ZigZag (FactBoomerang rotates between events)");
+    return PDMP_OK;
+}
+
+pdmp_status pdmp_ensemble_ess_begin(pdmp_ensemble* e, double T0) {
+    pdmp_status st = ess_ready(e);
+    if (st != PDMP_OK) return st;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    const int64_t d = e->cfg.d, n = e->cfg.nchains;
+    if (e->d_jprev.n != (size_t)(n * d) && (st = e->d_jprev.alloc((size_t)(n * d))) != PDMP_OK) return st;
+    if (e->d_jstart.n != (size_t)(n * d) && (st = e->d_jstart.alloc((size_t)(n * d))) != PDMP_OK) return st;
+    if (e->d_essacc.n != (size_t)(4 * d) && (st = e->d_essacc.alloc((size_t)(4 * d))) != PDMP_OK) return st;
+    HIP_TRY(hipMemsetAsync(e->d_essacc.p, 0, (size_t)(4 * d) * sizeof(double), e->stream));
+    int rc = pdmp::launch_zz_ess(e->d_rec.p, e->d_jprev.p, e->d_jstart.p, d, n, 0, T0, T0, e->d_essacc.p, e->stream);
+    if (rc != 0) return fail(PDMP_ERR_HIP, "ess launch failed: %s", hipGetErrorString((hipError_t)rc));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->ess_T0 = e->ess_Tlast = T0;
+    e->ess_batches = 0;
+    return PDMP_OK;
+}
+
+pdmp_status pdmp_ensemble_ess_batch(pdmp_ensemble* e, double T) {
+    pdmp_status st = ess_ready(e);
+    if (st != PDMP_OK) return st;
+    if (e->ess_batches < 0) return fail(PDMP_ERR_INVALID, "pdmp_ensemble_ess_begin first");
+    if (!(T > e->ess_Tlast)) return fail(PDMP_ERR_INVALID, "batch end %g does not exceed the previous one %g", T, e->ess_Tlast);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    int rc = pdmp::launch_zz_ess(e->d_rec.p, e->d_jprev.p, e->d_jstart.p, e->cfg.d, e->cfg.nchains, 1, e->ess_Tlast, T,
+                                 e->d_essacc.p, e->stream);
+    if (rc != 0) return fail(PDMP_ERR_HIP, "ess launch failed: %s", hipGetErrorString((hipError_t)rc));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->ess_Tlast = T;
+    e->ess_batches += 1;
+    return PDMP_OK;
+}
+
+pdmp_status pdmp_ensemble_ess_end(pdmp_ensemble* e, double* sum_y, double* sum_y2, double* sum_m, double* sum_m2,
+                                  int64_t* nbatches, double* T0, double* T1) {
+    pdmp_status st = ess_ready(e);
+    if (st != PDMP_OK) return st;
+    if (e->ess_batches < 1) return fail(PDMP_ERR_INVALID, "no batch accumulated (ess_begin, then ess_batch)");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const int64_t d = e->cfg.d;
+    HIP_TRY(hipMemsetAsync(e->d_essacc.p + 2 * d, 0, (size_t)(2 * d) * sizeof(double), e->stream));
+    int rc = pdmp::launch_zz_ess(e->d_rec.p, e->d_jprev.p, e->d_jstart.p, d, e->cfg.nchains, 2, e->ess_T0, e->ess_Tlast,
+                                 e->d_essacc.p, e->stream);
+    if (rc != 0) return fail(PDMP_ERR_HIP, "ess launch failed: %s", hipGetErrorString((hipError_t)rc));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    double* outs[4] = {sum_y, sum_y2, sum_m, sum_m2};
+    for (int k = 0; k < 4; ++k)
+        if (outs[k]) HIP_TRY(hipMemcpy(outs[k], e->d_essacc.p + k * d, (size_t)d * sizeof(double), hipMemcpyDeviceToHost));
+    if (nbatches) *nbatches = e->ess_batches;
+    if (T0) *T0 = e->ess_T0;
+    if (T1) *T1 = e->ess_Tlast;
     return PDMP_OK;
 }
 

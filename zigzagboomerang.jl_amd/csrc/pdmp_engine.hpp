@@ -204,6 +204,8 @@ int launch_zz_unpack(const ZzRec* rec, const double* c_src, int64_t c_stride, in
                      int64_t n, double* t, double* x, double* th, int64_t* acc, double* c, void* stream);
 int launch_zz_batch_means(const ZzRec* rec, double* jprev, int64_t d, int64_t nchains, double T_prev, double T,
                           double* sum_y, double* sum_y2, void* stream);
+int launch_zz_ess(const ZzRec* rec, double* jprev, double* jstart, int64_t d, int64_t nchains, int mode, double T_prev, double T,
+                  double* acc, void* stream);
 size_t zz_local_lds_bytes(uint32_t nblk_pad, uint32_t blob_w_pad);
 int launch_math_probe(uint64_t seed, int64_t n, double* out, void* stream);
 

@@ -2095,8 +2095,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const uint64_t acc_i = ri->acc;
         double kq[4];
         {
+#ifdef PDMP_X_KEYLINES
+            // the block's 256 bytes as TWO whole-line requests: lane gl takes keys 2gl, 2gl+1 of each 128-byte half
+            const double2* kp = reinterpret_cast<const double2*>(keys + (size_t)blk * 32);
+            const double2 k01 = kp[gl], k23 = kp[8 + gl];
+#else
             const double2* kp = reinterpret_cast<const double2*>(keys + (size_t)blk * 32 + gl * 4);
             const double2 k01 = kp[0], k23 = kp[1];
+#endif
             kq[0] = k01.x;
             kq[1] = k01.y;
             kq[2] = k23.x;
@@ -2270,7 +2276,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         LDS_ORDER();
         if (active && (sA >> 5) == blk) {
             const uint32_t e_ = sA & 31u;
+#ifdef PDMP_X_KEYLINES
+            pk[((e_ & 15u) >> 1) * 4u + (((e_ >> 4) ^ pk_t) << 1) + (e_ & 1u)] = key;
+#else
             pk[(e_ & ~3u) + ((((e_ & 3u) >> 1) ^ pk_t) << 1) + (e_ & 1u)] = key;
+#endif
         }
         LDS_ORDER();
         PHASE(5);
@@ -2294,10 +2304,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             PMIN(p23.x, 2);
             PMIN(p23.y, 3);
 #undef PMIN
+#ifdef PDMP_X_KEYLINES
+            cand = blk * 32u + ((li >> 1) << 4) + (uint32_t)gl * 2u + (li & 1u);
+            rowmin = grp8_min_f64(lm);
+            const uint64_t winball = __ballot(gvalid && lm == rowmin);
+            const uint64_t winlo = __ballot(gvalid && lm == rowmin && li < 2u);  // (ties: the lowest coordinate wins)
+            const unsigned wlo = (unsigned)((winlo >> (8 * g)) & 0xffu);
+            wl2 = __ffs(wlo ? wlo : (unsigned)((winball >> (8 * g)) & 0xffu)) - 1;
+#else
             cand = blk * 32u + (uint32_t)gl * 4u + li;
             rowmin = grp8_min_f64(lm);
             const uint64_t winball = __ballot(gvalid && lm == rowmin);
             wl2 = __ffs((unsigned)((winball >> (8 * g)) & 0xffu)) - 1;
+#endif
         }
         const double keymin = grp8_min_f64(key);
         const double expose = min_f64(rowmin, keymin);
@@ -3070,6 +3089,40 @@ __global__ __launch_bounds__(256) void zz_batch_means_kernel(const ZzRec* rec, d
     atomicAdd(sum_y2 + i, s2);
 }
 
+// ESS accumulators (pdmp_ensemble_ess_*): mode 0 snapshots J(T) of every (chain, coordinate) into jprev AND jstart; mode 1 is a
+// batch -- Y = (J − jprev)/ΔT, jprev = J, acc[0] += Y, acc[1] += Y² --; mode 2 closes the run -- the chain's own mean over the
+// whole run M = (J − jstart)/(T − T0), acc[2] += M, acc[3] += M² (jprev / jstart untouched).  acc is [4 x d].
+__global__ __launch_bounds__(256) void zz_ess_kernel(const ZzRec* rec, double* jprev, double* jstart, int64_t d, int64_t nchains,
+                                                     int64_t chains_per_group, int mode, double T_prev, double T, double* acc) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= d) return;
+    const int64_t c0 = (int64_t)blockIdx.y * chains_per_group;
+    const int64_t c1 = (c0 + chains_per_group < nchains) ? (c0 + chains_per_group) : nchains;
+    const double inv = (mode == 0) ? 0.0 : 1.0 / (T - T_prev);
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t ch = c0; ch < c1; ++ch) {
+        const ZzRec* r = rec + ch * d + i;
+        const double dt = T - r->t;
+        const double J = r->I + dt * (r->x + r->th * (dt * 0.5));
+        if (mode == 0) {
+            jprev[ch * d + i] = J;
+            jstart[ch * d + i] = J;
+        } else {
+            const double y = (J - ((mode == 1) ? jprev : jstart)[ch * d + i]) * inv;
+            if (mode == 1) jprev[ch * d + i] = J;
+            s1 += y;
+            s2 += y * y;
+        }
+    }
+    if (mode == 1) {
+        atomicAdd(acc + i, s1);
+        atomicAdd(acc + d + i, s2);
+    } else if (mode == 2) {
+        atomicAdd(acc + 2 * d + i, s1);
+        atomicAdd(acc + 3 * d + i, s2);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ math probe
 //
 // Evaluates the shared numerical contract on the device so that a test can compare it bit-for-bit with
@@ -3221,6 +3274,16 @@ int launch_zz_batch_means(const ZzRec* rec, double* jprev, int64_t d, int64_t nc
     dim3 grid((unsigned)((d + 255) / 256), (unsigned)groups);
     hipLaunchKernelGGL(zz_batch_means_kernel, grid, dim3(256), 0, (hipStream_t)stream, rec, jprev, d, nchains, per,
                        T_prev, T, sum_y, sum_y2);
+    return (int)hipGetLastError();
+}
+
+int launch_zz_ess(const ZzRec* rec, double* jprev, double* jstart, int64_t d, int64_t nchains, int mode, double T_prev, double T,
+                  double* acc, void* stream) {
+    const int64_t groups = (nchains < 64) ? 1 : 64;
+    const int64_t per = (nchains + groups - 1) / groups;
+    dim3 grid((unsigned)((d + 255) / 256), (unsigned)groups);
+    hipLaunchKernelGGL(zz_ess_kernel, grid, dim3(256), 0, (hipStream_t)stream, rec, jprev, jstart, d, nchains, per, mode, T_prev, T,
+                       acc);
     return (int)hipGetLastError();
 }
 

@@ -231,6 +231,19 @@ class Ensemble:
         _lib.check(self._L.pdmp_ensemble_batch_means(self._h, float(T_prev), float(T), _ptr(s1), _ptr(s2)))
         return s1, s2
 
+    def ess_begin(self, T0):
+        _lib.check(self._L.pdmp_ensemble_ess_begin(self._h, float(T0)))
+
+    def ess_batch(self, T):
+        _lib.check(self._L.pdmp_ensemble_ess_batch(self._h, float(T)))
+
+    def ess_end(self):
+        """(ΣY, ΣY², ΣM, ΣM², B, T0, T1): the sums of pdmp_ensemble_ess_end, see include/pdmp_mi355.h and ess.py."""
+        out = [np.empty(self.d) for _ in range(4)]
+        nb, t0, t1 = C.c_int64(), C.c_double(), C.c_double()
+        _lib.check(self._L.pdmp_ensemble_ess_end(self._h, *[_ptr(a) for a in out], C.byref(nb), C.byref(t0), C.byref(t1)))
+        return (*out, int(nb.value), float(t0.value), float(t1.value))
+
     def trace_dev(self):
         p, cap = C.c_void_p(), C.c_int64()
         _lib.check(self._L.pdmp_ensemble_trace_dev(self._h, C.byref(p), C.byref(cap)))

@@ -1,41 +1,96 @@
 """Trace consumers, mirroring src/trace.jl for FactTrace (what every caller of spdmp does next with Ξ).
 
-Events are structured arrays (t, i, x, theta) with 0-based i.  Vectorised numpy, host side only: these
-are the callers' post-processing, not part of the device hot path.
+Events are structured arrays (t, i, x, theta) with 0-based i.  Host side only: these are the callers' post-processing
+(SURVEY.md 8f1), not part of the device hot path.  Everything is vectorised over EVENTS (no interpreter loop per event): a
+coordinate's path depends on its own events only -- between two of them it flows freely (linearly, or by the FactBoomerang's
+rotation about μ_i) -- so the events are grouped per coordinate once (stable sort) and every consumer is a handful of array
+operations; the only Python loops left run over coordinates (collect / discretize), never over events.  The reference moves
+all coordinates step by step (x += θ·Δt per event); the closed forms used here agree with it to rounding.
 """
 import numpy as np
 
 from .flows import Boomerang, FactBoomerang, FactTrace, PDMPTrace
 
 
-def _flow(tr, x, th, dt):
-    """move_forward!(dt, ...) in place: linear for ZigZag (src/dynamics.jl:11-15), rotation about μ for FactBoomerang (:29-36)."""
-    if isinstance(tr.F, FactBoomerang):
-        mu = tr.F.μ
-        s, c = np.sin(dt), np.cos(dt)
-        xn = (x - mu) * c + th * s + mu
-        th[:] = -(x - mu) * s + th * c
-        x[:] = xn
-    else:
-        x += th * dt
+def _is_boom(tr):
+    return isinstance(tr.F, FactBoomerang)
+
+
+def _free_flow(tr, j, x, th, tau):
+    """State of coordinate(s) j a time tau after (x, θ): linear (src/dynamics.jl:11-15) or the rotation about μ_j (:29-36)."""
+    if _is_boom(tr):
+        mu = tr.F.μ[j]
+        s, c = np.sin(tau), np.cos(tau)
+        return (x - mu) * c + th * s + mu, -(x - mu) * s + th * c
+    return x + th * tau, th + 0.0 * tau
+
+
+def _prev_same_coordinate(tr):
+    """For every event k (in time order): time, position and velocity the coordinate had after ITS previous event (the initial
+    state for its first one)."""
+    ev = tr.events
+    n = len(ev)
+    i = ev["i"].astype(np.int64)
+    order = np.argsort(i, kind="stable")  # by coordinate, time order kept inside a coordinate
+    si = i[order]
+    prev_sorted = np.empty(n, dtype=np.int64)
+    if n:
+        prev_sorted[0] = -1
+        prev_sorted[1:] = np.where(si[1:] == si[:-1], order[:-1], -1)
+    prev = np.empty(n, dtype=np.int64)
+    prev[order] = prev_sorted
+    has = prev >= 0
+    pc = np.maximum(prev, 0)
+    tp = np.where(has, ev["t"][pc], tr.t0)
+    xp = np.where(has, ev["x"][pc], tr.x0[i])
+    thp = np.where(has, ev["theta"][pc], tr.θ0[i])
+    return i, tp, xp, thp
+
+
+def _groups(tr):
+    """Events grouped per coordinate: (order, ptr) with order[ptr[j]:ptr[j+1]] the event indices of coordinate j in time order."""
+    i = tr.events["i"].astype(np.int64)
+    order = np.argsort(i, kind="stable")
+    ptr = np.zeros(tr.x0.size + 1, dtype=np.int64)
+    np.cumsum(np.bincount(i, minlength=tr.x0.size), out=ptr[1:])
+    return order, ptr
+
+
+def _states_at(tr, times, upto=None):
+    """x_j(times[r]) for every coordinate j: [len(times) x d].  upto[r] = number of leading events (trace order) applied at row r;
+    None: every event with t <= times[r]."""
+    ev = tr.events
+    d = tr.x0.size
+    order, ptr = _groups(tr)
+    out = np.empty((len(times), d))
+    for j in range(d):
+        own = order[ptr[j]:ptr[j + 1]]
+        if upto is None:
+            pos = np.searchsorted(ev["t"][own], times, side="right") - 1
+        else:
+            pos = np.searchsorted(own, upto - 1, side="right") - 1
+        has = pos >= 0
+        k = own[np.maximum(pos, 0)] if len(own) else np.zeros(len(times), dtype=np.int64)
+        if len(own):
+            tl = np.where(has, ev["t"][k], tr.t0)
+            xl = np.where(has, ev["x"][k], tr.x0[j])
+            thl = np.where(has, ev["theta"][k], tr.θ0[j])
+        else:
+            tl, xl, thl = tr.t0, tr.x0[j], tr.θ0[j]
+        out[:, j] = _free_flow(tr, j, xl, thl, times - tl)[0]
+    return out
 
 
 def collect(tr: FactTrace):
-    """collect(Ξ): list of (t, x) at event times -- Base.iterate(FT::FactTrace), src/trace.jl:44-63.
-
-    Like the reference, the LAST event is not applied (:56)."""
-    t, x, th = tr.t0, tr.x0.copy(), tr.θ0.copy()
-    ts, xs = [t], [x.copy()]
+    """collect(Ξ): (t, x) pairs of Base.iterate(FT::FactTrace), src/trace.jl:44-63 -- the initial state, the state after each
+    event but the last (which is never applied, :56), and that state once more: 1 + length(events) entries (:42)."""
     ev = tr.events
-    for k in range(len(ev) - 1):
-        t2, i, xi, thi = ev[k]
-        x += th * (t2 - t)  # move_forward!, src/dynamics.jl:11-15
-        t = t2
-        x[i] = xi
-        th[i] = thi
-        ts.append(t)
-        xs.append(x.copy())
-    return np.array(ts), np.array(xs)
+    n = len(ev)
+    if n == 0:
+        return np.array([tr.t0]), tr.x0[None].copy()
+    ts = np.concatenate([[tr.t0], ev["t"][:n - 1], [ev["t"][n - 2] if n > 1 else tr.t0]])
+    upto = np.concatenate([[0], np.arange(1, n), [n - 1]])
+    return ts, _states_at(tr, ts, upto=upto)
 
 
 def _discretize_pdmp(tr: PDMPTrace, dt):
@@ -62,39 +117,24 @@ def _discretize_pdmp(tr: PDMPTrace, dt):
 
 
 def discretize(tr, dt):
-    """collect(discretize(Ξ, dt)): positions on the grid t0, t0+dt, ... -- src/trace.jl:94-125 (FactTrace), :129-150 (PDMPTrace)."""
+    """collect(discretize(Ξ, dt)): positions on the grid t0, t0+dt, ... -- src/trace.jl:94-125 (FactTrace: a grid point is
+    emitted while it lies before the last event; events at or before a grid time are applied), :129-150 (PDMPTrace)."""
     if isinstance(tr, PDMPTrace):
         return _discretize_pdmp(tr, dt)
     ev = tr.events
-    t, x, th = tr.t0, tr.x0.copy(), tr.θ0.copy()
-    ts, xs = [t], [x.copy()]
-    k = 0
-    n = len(ev)
-    while True:
-        step = dt
-        done = False
-        while True:
-            if k >= n:
-                done = True
-                break
-            ti = ev["t"][k]
-            if t + step < ti:
-                _flow(tr, x, th, step)
-                t += step
-                break
-            d_t = ti - t
-            step -= d_t
-            _flow(tr, x, th, d_t)
-            t = ti
-            i = ev["i"][k]
-            x[i] = ev["x"][k]
-            th[i] = ev["theta"][k]
-            k += 1
-        if done:
-            break
-        ts.append(t)
-        xs.append(x.copy())
-    return np.array(ts), np.array(xs)
+    if len(ev) == 0:
+        return np.array([tr.t0]), tr.x0[None].copy()
+    # The reference consumes the events IN TRACE ORDER and stops at the first one later than the grid time (:111-113).  A refresh
+    # of a coordinate whose clock lags (src/sfact.jl:84-85: the refreshed i is not moved to t′) is recorded with its stale time, so a
+    # trace with λref > 0 is not sorted; the number of events applied at grid time g is the first index whose time exceeds g,
+    # i.e. a search in the running maximum of the event times.
+    tmax = np.maximum.accumulate(ev["t"])
+    n = int(np.ceil((tmax[-1] - tr.t0) / dt)) + 1
+    grid = tr.t0 + dt * np.arange(n)
+    grid = grid[grid < tmax[-1]]
+    if len(grid) == 0:
+        grid = np.array([tr.t0])
+    return grid, _states_at(tr, grid, upto=np.searchsorted(tmax, grid, side="right"))
 
 
 def _mean_pdmp(tr: PDMPTrace):
@@ -108,6 +148,15 @@ def _mean_pdmp(tr: PDMPTrace):
     return y / tr.t[-1]
 
 
+def _segment_integrals(tr):
+    """Per event k of coordinate i: Δt since i's previous event and the reference's trapezoid term (x_prev + x_k)·Δt, where x_k is
+    the RECORDED position (src/trace.jl:191-195; for a ZigZag the path between two events of i is the chord, so this is exact)."""
+    i, tp, xp, _ = _prev_same_coordinate(tr)
+    ev = tr.events
+    dt = ev["t"] - tp
+    return i, dt, (xp + ev["x"]) * dt, xp
+
+
 def cummean(tr):
     """cummean(Ξ) -- src/trace.jl:203-225 (FactTrace: per coordinate the running (t, ∫x/(2t))) and :248-266 (PDMPTrace: the
     running vector y/(2t) after every event).  Returns a list of (t, y) array pairs per coordinate, resp. an [n x d] array."""
@@ -118,18 +167,15 @@ def cummean(tr):
         y = np.cumsum((X[:-1] + X[1:]) * np.diff(te)[:, None], axis=0)
         return y / (2.0 * te[1:, None])
     ev = tr.events
-    x = tr.x0.copy()
-    y = np.zeros_like(x)
-    t = np.full(x.shape, tr.t0)
-    ts = [[tr.t0] for _ in x]
-    ys = [[xi] for xi in x]
-    for t2, i, xi, _ in ev:
-        y[i] += (x[i] + xi) * (t2 - t[i])
-        t[i] = t2
-        x[i] = xi
-        ts[i].append(t2)
-        ys[i].append(y[i] / (2 * t2))
-    return [(np.array(a), np.array(b)) for a, b in zip(ts, ys)]
+    _, _, term, _ = _segment_integrals(tr)
+    order, ptr = _groups(tr)
+    out = []
+    for j in range(tr.x0.size):
+        own = order[ptr[j]:ptr[j + 1]]
+        t = ev["t"][own]
+        y = np.cumsum(term[own]) / (2 * t) if len(own) else np.empty(0)
+        out.append((np.concatenate([[tr.t0], t]), np.concatenate([[tr.x0[j]], y])))
+    return out
 
 
 def mean(tr):
@@ -137,42 +183,39 @@ def mean(tr):
     if isinstance(tr, PDMPTrace):
         return _mean_pdmp(tr)
     ev = tr.events
-    x = tr.x0.copy()
-    y = np.zeros_like(x)
+    i, _, term, _ = _segment_integrals(tr)
     T = ev["t"][-1]
-    t = np.full(x.shape, tr.t0)
-    scale = 1 / (2 * T)
-    for t2, i, xi, _ in ev:
-        y[i] += (x[i] + xi) * (t2 - t[i]) * scale
-        t[i] = t2
-        x[i] = xi
-    return y
+    return np.bincount(i, weights=term * (1 / (2 * T)), minlength=tr.x0.size)  # (summed per coordinate in event order, like :191-196)
 
 
 def moments(tr: FactTrace, T_end=None):
-    """Exact time averages of x_i and x_i² over [t0, T_end] (segments of coordinate i between ITS events);
-    the tail after a coordinate's last event is extrapolated with its last velocity.  Used by the tests."""
+    """Exact time averages of x_i and x_i² over [t0, T_end] (segments of coordinate i between ITS events, linear flow);
+    the tail after a coordinate's last event is extrapolated with its last velocity.  Used by the tests and the ESS validation."""
     ev = tr.events
     d = tr.x0.size
     if T_end is None:
         T_end = ev["t"][-1]
-    s1 = np.zeros(d)
-    s2 = np.zeros(d)
-    x = tr.x0.copy()
-    th = tr.θ0.copy()
-    t = np.full(d, tr.t0)
-    for t2, i, xi, thi in ev:
-        if t2 > T_end:
-            continue
-        dt = t2 - t[i]
-        xa, xb = x[i], x[i] + th[i] * dt
-        s1[i] += dt * (xa + xb) / 2
-        s2[i] += dt * (xa * xa + xa * xb + xb * xb) / 3
-        t[i], x[i], th[i] = t2, xi, thi
-    dt = T_end - t
-    xb = x + th * dt
-    s1 += dt * (x + xb) / 2
-    s2 += dt * (x * x + x * xb + xb * xb) / 3
+    keep = ev["t"] <= T_end
+    sub = FactTrace(tr.F, tr.t0, tr.x0, tr.θ0, ev[keep])
+    i, tp, xa, tha = _prev_same_coordinate(sub)
+    e = sub.events
+    dt = e["t"] - tp
+    xb = xa + tha * dt
+    s1 = np.bincount(i, weights=dt * (xa + xb) / 2, minlength=d)
+    s2 = np.bincount(i, weights=dt * (xa * xa + xa * xb + xb * xb) / 3, minlength=d)
+    # the open segment after each coordinate's last event
+    tl, xl, thl = np.full(d, tr.t0), tr.x0.astype(np.float64).copy(), tr.θ0.astype(np.float64).copy()
+    if len(e):
+        order, ptr = _groups(sub)
+        last = order[np.maximum(ptr[1:] - 1, 0)]
+        has = ptr[1:] > ptr[:-1]
+        tl = np.where(has, e["t"][last], tl)
+        xl = np.where(has, e["x"][last], xl)
+        thl = np.where(has, e["theta"][last], thl)
+    dt = T_end - tl
+    xb = xl + thl * dt
+    s1 += dt * (xl + xb) / 2
+    s2 += dt * (xl * xl + xl * xb + xb * xb) / 3
     L = T_end - tr.t0
     m = s1 / L
     return m, s2 / L - m * m
@@ -194,12 +237,6 @@ def subtrace(tr: FactTrace, J):
 def inclusion_prob(tr: FactTrace):
     """inclusion_prob(Ξ): fraction of time each coordinate is non-zero -- src/trace.jl:161-178."""
     ev = tr.events
-    x = tr.x0.copy()
-    y = np.zeros_like(x)
+    i, dt, _, xp = _segment_integrals(tr)
     T = ev["t"][-1]
-    t = np.full(x.shape, tr.t0)
-    for t2, i, xi, _ in ev:
-        y[i] += ((x[i] != 0) | (xi != 0)) * (t2 - t[i]) / T
-        t[i] = t2
-        x[i] = xi
-    return y
+    return np.bincount(i, weights=((xp != 0) | (ev["x"] != 0)) * dt / T, minlength=tr.x0.size)
