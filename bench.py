@@ -38,22 +38,59 @@ def algorithmic_bytes(num, nacc):
     return 224.0 * num + 48.0 * (num - nacc) + 616.0 * nacc
 
 
-def cpu_baseline(pkg, G, c, budget_s=15.0):
-    """The CPU oracle (a C port of the reference algorithm, kind="port") on the host cores, bounded sample."""
+def host_cpu_limits():
+    """What the process may actually use: logical CPUs, scheduler affinity, and the cgroup CPU quota (v2 cpu.max / v1 cfs_*)."""
+    info = {"cpu_count": os.cpu_count() or 1, "affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+            "cgroup_quota_cpus": None}
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            info["cgroup_quota_cpus"] = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                info["cgroup_quota_cpus"] = q / per
+        except Exception:
+            pass
+    return info
+
+
+def cpu_baseline(pkg, G, c, budget_s=20.0):
+    """The CPU oracle (a C port of the reference algorithm, kind="port") on the host cores, bounded sample: one chain per thread,
+    thread counts swept once over {1, 8, 32, 64, all usable}; the best rate is the reported value."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     d = G.shape[0]
-    ncores = os.cpu_count() or 1
-    # calibrate on one short chain, then size the sample to ~budget_s of wall time on all cores
+    lim = host_cpu_limits()
+    usable = lim["affinity"] or lim["cpu_count"]
+    if lim["cgroup_quota_cpus"]:
+        usable = max(1, min(usable, int(lim["cgroup_quota_cpus"] + 0.5)))
+    sweep_n = sorted({n for n in (1, 8, 32, 64, usable) if n <= usable})
+    # calibrate on one short chain, then give every setting of the sweep the same wall-time share of the budget
     x0, th0 = O.synthetic_state(SEED0, d)
     s1, n1, a1 = O.spdmp_zigzag_ensemble(G, None, G, x0[None], th0[None], c, 1.0, seed0=SEED0, nthreads=1)
     per_chain_per_T = max(s1, 1e-3)
-    nch = ncores * 2
-    T = float(np.clip(budget_s / (2 * per_chain_per_T), 1.0, 20.0))
-    X0 = np.stack([O.synthetic_state(SEED0 + k, d)[0] for k in range(nch)])
-    TH0 = np.stack([O.synthetic_state(SEED0 + k, d)[1] for k in range(nch)])
-    secs, num, acc = O.spdmp_zigzag_ensemble(G, None, G, X0, TH0, c, T, seed0=SEED0, nthreads=ncores)
-    s_single, n_single, a_single = O.spdmp_zigzag_ensemble(G, None, G, X0[:1], TH0[:1], c, min(T, 4.0), seed0=SEED0, nthreads=1)
+    T = float(np.clip((budget_s / len(sweep_n)) / per_chain_per_T, 0.5, 10.0))
+    nmax = sweep_n[-1]
+    X0 = np.stack([O.synthetic_state(SEED0 + k, d)[0] for k in range(nmax)])
+    TH0 = np.stack([O.synthetic_state(SEED0 + k, d)[1] for k in range(nmax)])
+    sweep = {}
+    best = None
+    for n in sweep_n:
+        secs, num, acc = O.spdmp_zigzag_ensemble(G, None, G, X0[:n], TH0[:n], c, T, seed0=SEED0, nthreads=n)
+        sweep[n] = {"events_per_s": acc / secs, "proposals_per_s": num / secs, "seconds": secs}
+        if best is None or acc / secs > best[1]:
+            best = (n, acc / secs, num / secs, acc / max(num, 1))
+    single = sweep[1]["events_per_s"]
+    eff = best[1] / (single * best[0])
+    why = ""
+    if eff < 0.3:
+        why = (" -- scaling is %.2f of linear at %d threads: " % (eff, best[0]) +
+               ("the cgroup grants %.1f CPUs; " % lim["cgroup_quota_cpus"] if lim["cgroup_quota_cpus"] else "") +
+               "every chain walks 1.4 MB of records + heap at random (d = 16384), so beyond the cores' private caches the threads "
+               "share the host's memory latency, not its arithmetic")
     # the reference's own multithreaded path, src/parallel.jl (ONE chain split over K chunk threads + a coordinator): its bound
     # must be block diagonal over the chunks, so the cross-chunk couplings are dropped from the bounding Γ and adapt is on
     par = None
@@ -71,11 +108,11 @@ def cpu_baseline(pkg, G, c, budget_s=15.0):
                    "sample": "one chain of config C3 to T=2, restatement of parallel_spdmp (src/parallel.jl:104-253)"}
     except Exception as exc:  # the baseline is reported-only: never fail the bench on it
         par = {"error": str(exc)}
-    return {"value": acc / secs, "unit": "reflection events/s", "cores": ncores, "kind": "port", "parallel_jl": par,
-            "sample": f"{nch} chains of config C3 (d=16384) to T={T:.2f} on {ncores} threads, chain-parallel; "
-                      f"same algorithm/seeds/event sequence as the GPU chains",
-            "proposals_per_s": num / secs, "single_thread_events_per_s": a_single / s_single,
-            "acceptance": acc / max(num, 1)}
+    return {"value": best[1], "unit": "reflection events/s", "cores": best[0], "kind": "port", "parallel_jl": par,
+            "sample": f"one chain of config C3 (d=16384) per thread to T={T:.2f}, threads swept over {sweep_n}, best at {best[0]}; "
+                      f"same algorithm/seeds/event sequence as the GPU chains" + why,
+            "proposals_per_s": best[2], "single_thread_events_per_s": single, "acceptance": best[3],
+            "host": lim, "thread_sweep": {str(k): v for k, v in sweep.items()}, "parallel_efficiency": eff}
 
 
 def main():

@@ -1,0 +1,58 @@
+/*
+ * pdmp_debug.h -- diagnostics and measurement hooks of libpdmp_mi355.so.  NOT part of the drop-in boundary (pdmp_mi355.h): nothing a
+ * caller of spdmp / pdmp / sspdmp needs lives here.  Used by tests/ (kernel selection for parity runs, the numerical-contract probe)
+ * and tools/ (phase profiles, memory-system probes).  All state is per ensemble; the library keeps no globals and reads no
+ * environment variables.
+ */
+#ifndef PDMP_DEBUG_H
+#define PDMP_DEBUG_H
+
+#include "pdmp_mi355.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Which event-loop kernel a local-ZigZag / sticky ensemble uses.  AUTO: the widest speculative kernel the neighbourhood geometry
+ * admits (8 events per iteration on lattice-like graphs, else 4, else 1); SEQ: one event per iteration; SPEC4: the 4-event kernel
+ * where the 8-event one would run.  All of them produce the same event sequence bit for bit (tests/test_gpu_spec8_parity.py).
+ * Must be called before set_flow_*. */
+#define PDMP_DEBUG_KERNEL_AUTO 0
+#define PDMP_DEBUG_KERNEL_SEQ 1
+#define PDMP_DEBUG_KERNEL_SPEC4 2
+pdmp_status pdmp_debug_set_kernel(pdmp_ensemble* ens, int kernel);
+/* 4-event kernel: fetch the G2 records of every proposal speculatively instead of on accept only */
+pdmp_status pdmp_debug_set_spec_g2(pdmp_ensemble* ens, int on);
+/* Record the per-phase cycle counts of chain 0 during the following runs (a profiling instantiation of the same loop);
+ * pdmp_debug_phase_profile returns the last run's 16 numbers: kind 1 (speculative kernels) [0..8] cycles per phase, [10] iterations;
+ * kind 2 (general kernel) [0..6] select, move G1, gradient, coin + G2, re-bound, re-queue, tail, [10] proposals. */
+pdmp_status pdmp_debug_set_phase_profile(pdmp_ensemble* ens, int on);
+pdmp_status pdmp_debug_phase_profile(pdmp_ensemble* ens, double* out16, int* kind);
+/* one-event kernel: print the first n proposals of chain 0 to stderr during the next run */
+pdmp_status pdmp_debug_set_proposal_dump(pdmp_ensemble* ens, int64_t n);
+
+/*
+ * Test hook: evaluate the shared numerical contract (include/pdmp_detmath.h) on the device for draws
+ * k = 0..n-1 of `seed`; out is [8 x n] row-major: u01, pdmp_log(u), a/b, sqrt, poisson_time, pdmp_randn, pdmp_exp, sin+2cos of pdmp_sincos.
+ * A host evaluation of the same expressions must agree bit-for-bit (tests/test_gpu_detmath.py).
+ */
+pdmp_status pdmp_debug_math_probe(int device, uint64_t seed, int64_t n, double* out);
+
+/*
+ * Measurement hook: time (ms per launch, HIP events) of a write-only kernel with the event-record store pattern of the bouncy
+ * particle kernel -- one wavefront per chain writing `nrec` records of x[d] and θ[d] -- i.e. the HBM write ceiling that the C2
+ * roofline fraction is read against (tools/bench_c2.py).
+ */
+pdmp_status pdmp_debug_write_probe(int device, int64_t nchains, int64_t d, int64_t nrec, int iters, double* ms_out);
+
+/* Test/measurement hook: time per launch (ms) of a kernel that does nothing but the scattered record traffic of the local ZigZag
+ * event loop -- one wavefront per chain, every lane reads the 32-byte first half of 4 pseudo-random 64-byte records of its chain
+ * per round, `rounds` times, and with write != 0 stores them back changed.  nchains * d * 64 bytes are allocated for it.  The
+ * sector rate it reaches is the practical ceiling quoted beside the event loop's own. */
+pdmp_status pdmp_debug_sector_probe(int device, int64_t nchains, int64_t d, int rounds, int write, int iters,
+                                             double* ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDMP_DEBUG_H */

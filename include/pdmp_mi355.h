@@ -18,7 +18,8 @@
  *   - return codes, never exceptions; per-chain status words replace the reference's `error(...)`
  *     (src/sfact.jl:124): one diverged chain never aborts the ensemble;
  *   - one ensemble is bound to one HIP device; calls on one ensemble must be serialised by the caller,
- *     different ensembles are independent (no globals except the thread-local error string);
+ *     different ensembles are independent (no globals except the thread-local error string; the library reads no
+ *     environment variables -- diagnostics are per-ensemble calls declared in pdmp_debug.h);
  *   - a user gradient closure cannot cross a C ABI: targets are an enumerated set (Gaussian CSC now).
  *   - randomness: chain k draws from Philox4x32-10 keyed by seeds[k]; draw order is the reference's
  *     `rand(rng)` call order (include/pdmp_detmath.h, oracle/pdmp_oracle.h).
@@ -98,27 +99,6 @@ const char* pdmp_last_error(void);
 int pdmp_abi_version(void);
 /* number of usable gfx950 devices (0 if none / HIP not initialisable) */
 int pdmp_device_count(void);
-
-/*
- * Test hook: evaluate the shared numerical contract (include/pdmp_detmath.h) on the device for draws
- * k = 0..n-1 of `seed`; out is [8 x n] row-major: u01, pdmp_log(u), a/b, sqrt, poisson_time, pdmp_randn, pdmp_exp, sin+2cos of pdmp_sincos.
- * A host evaluation of the same expressions must agree bit-for-bit (tests/test_gpu_detmath.py).
- */
-pdmp_status pdmp_debug_math_probe(int device, uint64_t seed, int64_t n, double* out);
-
-/*
- * Measurement hook: time (ms per launch, HIP events) of a write-only kernel with the event-record store pattern of the bouncy
- * particle kernel -- one wavefront per chain writing `nrec` records of x[d] and θ[d] -- i.e. the HBM write ceiling that the C2
- * roofline fraction is read against (tools/bench_c2.py).
- */
-pdmp_status pdmp_debug_write_probe(int device, int64_t nchains, int64_t d, int64_t nrec, int iters, double* ms_out);
-
-/* Test/measurement hook: time per launch (ms) of a kernel that does nothing but the scattered record traffic of the local ZigZag
- * event loop -- one wavefront per chain, every lane reads the 32-byte first half of 4 pseudo-random 64-byte records of its chain
- * per round, `rounds` times, and with write != 0 stores them back changed.  nchains * d * 64 bytes are allocated for it.  The
- * sector rate it reaches is the practical ceiling quoted beside the event loop's own. */
-pdmp_status pdmp_debug_sector_probe(int device, int64_t nchains, int64_t d, int rounds, int write, int iters,
-                                             double* ms_out);
 
 pdmp_status pdmp_ensemble_create(const pdmp_config* cfg, pdmp_ensemble** out);
 void pdmp_ensemble_destroy(pdmp_ensemble* ens);

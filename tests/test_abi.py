@@ -8,20 +8,29 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_functions():
-    src = open(os.path.join(ROOT, "include", "pdmp_mi355.h")).read()
+def declared_functions(header="pdmp_mi355.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(pdmp_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_header_and_binding_agree(pkg):
     assert declared_functions() == sorted(pkg._lib.EXPORTED_SYMBOLS)
+    assert declared_functions("pdmp_debug.h") == sorted(pkg._lib.DEBUG_SYMBOLS)  # diagnostics live in their own header
+    assert not [f for f in declared_functions() if f.startswith("pdmp_debug")]
+
+
+def test_library_reads_no_environment(pkg):
+    """The ABI promises "no globals": no getenv in the library sources (diagnostics are per-ensemble calls, include/pdmp_debug.h)."""
+    csrc = os.path.join(ROOT, "zigzagboomerang.jl_amd", "csrc")
+    for f in os.listdir(csrc):
+        assert "getenv" not in open(os.path.join(csrc, f), errors="replace").read(), f
 
 
 def test_library_loads_and_exports_every_symbol(pkg):
     pkg.build.build()
     L = ctypes.CDLL(pkg._lib.lib_path())
-    for name in declared_functions():
+    for name in declared_functions() + declared_functions("pdmp_debug.h"):
         assert hasattr(L, name), name
     assert pkg._lib.load().pdmp_abi_version() == 1
 
@@ -57,7 +66,7 @@ def test_headers_are_plain_c99(tmp_path):
     import subprocess
     inc = os.path.join(ROOT, "include")
     src = tmp_path / "t.c"
-    src.write_text('#include "pdmp_mi355.h"\n#include "pdmp_detmath.h"\n'
+    src.write_text('#include "pdmp_mi355.h"\n#include "pdmp_debug.h"\n#include "pdmp_detmath.h"\n'
                    "int main(void){ return (int)(sizeof(pdmp_event) != 32) + (int)(sizeof(pdmp_chain_counters) != 72) + "
                    "(int)(sizeof(pdmp_config) != 48) + (int)(pdmp_log(1.0) != 0.0); }\n")
     exe = tmp_path / "t"

@@ -99,3 +99,54 @@ def test_degenerate_sizes_match_oracle(gpu_pkg):
     trs, (ts, xs, ths), (accs, nums), _ = pkg.sspdmp(pkg.GaussianTarget(Gs), 0.0, x0[:1, :3].copy(), th0[:1, :3].copy(), 0.0,
                                                      np.ones(3), pkg.ZigZag(Gs, np.zeros(3)), np.ones(3), seed=6)
     assert len(trs[0].events) == 0 and np.array_equal(xs[0], x0[0, :3])
+
+
+def test_entry_points_of_the_wrong_family_return_a_status(gpu_pkg):
+    """include/pdmp_mi355.h promises return codes, never crashes: factorised-sampler calls on a PDMP_SAMPLER_BPS ensemble (and the
+    reverse), a malformed target pattern, and batch means on a rotating flow are all refused with a status."""
+    pkg = gpu_pkg
+    L = pkg._lib
+    d = 4
+    I4 = sp.identity(d, format="csc")
+    with pkg.Ensemble(2, d, sampler=L.SAMPLER_BPS, trace_capacity=8) as ens:
+        ens.set_flow_bps(pkg.BouncyParticle(I4, np.zeros(d), 1.0))
+        ens.set_state_bps(0.0, np.zeros((2, d)), np.ones((2, d)), 1e-3, np.arange(2, dtype=np.uint64))
+        for call in (lambda: ens.set_flow(pkg.ZigZag(I4, np.zeros(d))), lambda: ens.set_target(pkg.GaussianTarget(I4)),
+                     lambda: ens.set_state(0.0, np.zeros((2, d)), np.ones((2, d)), np.ones(d), np.arange(2)),
+                     lambda: ens.set_state_synthetic(0.0, np.ones(d), 1), lambda: ens.final_state(), lambda: ens.batch_means(0.0, 1.0),
+                     lambda: ens.trace(0, 0, 1), lambda: ens.ess_begin(0.0), lambda: ens.set_local_bound(True)):
+            with pytest.raises(L.PdmpError) as ei:
+                call()
+            assert ei.value.code == L.PDMP_ERR_INVALID, str(ei.value)
+        ens.run(2.0)  # the ensemble is still usable
+        assert ens.counters()["num"].min() > 0
+    with pkg.Ensemble(2, d, trace_capacity=8) as ens:
+        for call in (lambda: ens.set_flow_bps(pkg.BouncyParticle(I4, np.zeros(d), 1.0)),
+                     lambda: ens.set_state_bps(0.0, np.zeros((2, d)), np.ones((2, d)), 1e-3, np.arange(2, dtype=np.uint64)),
+                     lambda: ens.bps_final_state()):
+            with pytest.raises(L.PdmpError) as ei:
+                call()
+            assert ei.value.code == L.PDMP_ERR_INVALID
+        ens.set_flow(pkg.ZigZag(I4, np.zeros(d)))
+        # a target whose colptr runs backwards / whose rows leave the matrix
+        import ctypes as C
+        cp = np.array([0, 1, 0, 1, 2], dtype=np.int64)
+        rv = np.array([0, 3], dtype=np.int64)
+        nz = np.ones(2)
+        st = L.load().pdmp_ensemble_set_target_gaussian_csc(ens._h, cp.ctypes.data, rv.ctypes.data, nz.ctypes.data, None)
+        assert st == L.PDMP_ERR_INVALID
+        cp = np.array([0, 1, 2, 3, 4], dtype=np.int64)
+        rv = np.array([0, 1, 2, 7], dtype=np.int64)
+        st = L.load().pdmp_ensemble_set_target_gaussian_csc(ens._h, cp.ctypes.data, rv.ctypes.data, np.ones(4).ctypes.data, None)
+        assert st == L.PDMP_ERR_INVALID
+    # a FactBoomerang path rotates between events: the linear path integrals are refused
+    G = pkg.problems.maintest_precision(8)
+    with pkg.Ensemble(1, 8, trace_capacity=64) as ens:
+        ens.set_flow(pkg.FactBoomerang(G, np.zeros(8), 0.3))
+        ens.set_target(pkg.GaussianTarget(G))
+        ens.set_state(0.0, np.zeros((1, 8)), np.ones((1, 8)), 2 * pkg.problems.column_norms(G), np.array([3], dtype=np.uint64))
+        ens.run(1.0, L.RUN_STOP_BEFORE)
+        for call in (lambda: ens.batch_means(0.0, 1.0), lambda: ens.ess_begin(1.0)):
+            with pytest.raises(L.PdmpError) as ei:
+                call()
+            assert ei.value.code == L.PDMP_ERR_UNSUPPORTED

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Per-phase cycle profile of the speculative event-loop kernel (chain 0), printed by libpdmp_mi355.so on stderr when
-PDMP_PHASE is set:   PDMP_PHASE=1 python tools/phase_profile.py
+"""Per-phase cycle profile of the speculative event-loop kernel (chain 0), recorded through include/pdmp_debug.h
+(pdmp_debug_set_phase_profile / pdmp_debug_phase_profile):   python tools/phase_profile.py
 Phases: p0 candidate selection · p1 level-1 loads issued + RNG window + blob landed in LDS · p2 header/S read ·
 p3 neighbour records requested, zone-conflict check (ends when the records are needed) · p4 move, gradient, accept chain ·
 p5 G2 move + re-bound · p6 patched block minimum + validation · p7 commit stores · p8 level-1 updates of other blocks."""
@@ -25,6 +25,13 @@ for nch in (256, 1024, 4096):
     ens.run(0.5, pkg._lib.RUN_STOP_BEFORE)
     ens.trace_reset()
     print("chains", nch, flush=True)
+    ens.debug_phase_profile(True)
+    n0 = ens.counters()["num"][0]
     ens.run(1.5, pkg._lib.RUN_STOP_BEFORE)
-    print("kernel ms", ens.last_run_ms(), flush=True)
+    kind, ph = ens.debug_phase_cycles()
+    n1 = ens.counters()["num"][0]
+    it = max(ph[10], 1.0)
+    print("iters=%.0f cycles/iter:" % ph[10], " ".join("p%d=%.0f" % (q, ph[q] / it) for q in range(9)),
+          "| proposals committed per iteration: %.2f" % ((n1 - n0) / it), flush=True)
+    print("kernel ms (profiling instantiation)", ens.last_run_ms(), flush=True)
     ens.close()

@@ -32,12 +32,16 @@ EXPORTED_SYMBOLS = [
     "pdmp_ensemble_set_state", "pdmp_ensemble_set_state_synthetic", "pdmp_ensemble_run", "pdmp_ensemble_sync",
     "pdmp_ensemble_last_run_ms", "pdmp_ensemble_counters", "pdmp_ensemble_totals", "pdmp_ensemble_trace_copy",
     "pdmp_ensemble_trace_reset", "pdmp_ensemble_final_state", "pdmp_ensemble_batch_means",
-    "pdmp_ensemble_trace_dev", "pdmp_ensemble_counters_dev", "pdmp_debug_math_probe",
+    "pdmp_ensemble_trace_dev", "pdmp_ensemble_counters_dev", 
     "pdmp_ensemble_set_flow_bps", "pdmp_ensemble_set_state_bps", "pdmp_ensemble_bps_trace_copy",
-    "pdmp_ensemble_bps_final_state", "pdmp_ensemble_set_sticky", "pdmp_ensemble_set_adaptscale", "pdmp_ensemble_final_sigma", "pdmp_ensemble_set_flow_boomerang", "pdmp_ensemble_set_local_bound", "pdmp_debug_write_probe", "pdmp_debug_sector_probe", "pdmp_ensemble_set_target_logistic", "pdmp_ensemble_set_flow_factboomerang",
+    "pdmp_ensemble_bps_final_state", "pdmp_ensemble_set_sticky", "pdmp_ensemble_set_adaptscale", "pdmp_ensemble_final_sigma", "pdmp_ensemble_set_flow_boomerang", "pdmp_ensemble_set_local_bound", "pdmp_ensemble_set_target_logistic", "pdmp_ensemble_set_flow_factboomerang",
     "pdmp_ensemble_set_mass_cholesky", "pdmp_ensemble_set_bps_options",
     "pdmp_ensemble_ess_begin", "pdmp_ensemble_ess_batch", "pdmp_ensemble_ess_end",
 ]
+# include/pdmp_debug.h: diagnostics, not part of the drop-in boundary
+DEBUG_SYMBOLS = ["pdmp_debug_set_kernel", "pdmp_debug_set_spec_g2", "pdmp_debug_set_phase_profile", "pdmp_debug_phase_profile",
+                 "pdmp_debug_set_proposal_dump", "pdmp_debug_math_probe", "pdmp_debug_write_probe", "pdmp_debug_sector_probe"]
+DEBUG_KERNELS = {"auto": 0, "seq": 1, "spec4": 2}
 
 
 class PdmpConfig(C.Structure):
@@ -111,7 +115,12 @@ def load():
     L.pdmp_ensemble_set_bps_options.argtypes = [vp, C.c_int, C.c_int]
     L.pdmp_ensemble_bps_trace_copy.argtypes = [vp, i64, i64, i64, vp, vp, vp]
     L.pdmp_ensemble_bps_final_state.argtypes = [vp, i64, i64, vp, vp, vp, vp]
-    for name in EXPORTED_SYMBOLS:
+    L.pdmp_debug_set_kernel.argtypes = [vp, C.c_int]
+    L.pdmp_debug_set_spec_g2.argtypes = [vp, C.c_int]
+    L.pdmp_debug_set_phase_profile.argtypes = [vp, C.c_int]
+    L.pdmp_debug_phase_profile.argtypes = [vp, vp, C.POINTER(C.c_int)]
+    L.pdmp_debug_set_proposal_dump.argtypes = [vp, i64]
+    for name in EXPORTED_SYMBOLS + DEBUG_SYMBOLS:
         fn = getattr(L, name)
         if name not in ("pdmp_last_error", "pdmp_abi_version", "pdmp_device_count", "pdmp_ensemble_destroy"):
             fn.restype = C.c_int

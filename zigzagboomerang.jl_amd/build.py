@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libpdmp_mi355.so")
 SOURCES = ["pdmp_capi.hip", "pdmp_kernels.hip", "pdmp_bps.hip", "pdmp_general.hip"]
 HEADERS = [os.path.join(CSRC, "pdmp_engine.hpp"),
            os.path.join(PKG_DIR, "..", "include", "pdmp_mi355.h"),
+           os.path.join(PKG_DIR, "..", "include", "pdmp_debug.h"),
            os.path.join(PKG_DIR, "..", "include", "pdmp_detmath.h")]
 
 # -ffp-contract=off: the kernels must round exactly like the CPU oracle (no fused multiply-add).

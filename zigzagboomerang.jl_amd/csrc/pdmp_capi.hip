@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/pdmp_detmath.h"
+#include "../../include/pdmp_debug.h"
 #include "pdmp_engine.hpp"
 
 namespace {
@@ -103,6 +104,13 @@ struct pdmp_ensemble {
     // device state
     DevBuf<pdmp::ZzRec> d_rec;
     DevBuf<double> d_keys, d_c_chain, d_jprev, d_sum;
+    // diagnostics (include/pdmp_debug.h): per-ensemble state, no process globals
+    int dbg_kernel = 0;            // PDMP_DEBUG_KERNEL_*
+    int dbg_spec_g2 = 0;           // 4-event kernel: fetch the G2 records speculatively
+    int dbg_phase = 0;             // record the per-phase cycle profile of chain 0 during the next runs
+    double dbg_phase_out[16] = {0};
+    int dbg_phase_valid = 0;
+    int64_t dbg_dump = 0;          // dump the first n proposals of chain 0 (one-event kernel) to stderr
     DevBuf<double> d_jstart, d_essacc;  // pdmp_ensemble_ess_*
     double ess_T0 = 0.0, ess_Tlast = 0.0;
     int64_t ess_batches = -1;  // -1: no ess_begin yet
@@ -259,6 +267,47 @@ pdmp_status pdmp_debug_math_probe(int device, uint64_t seed, int64_t n, double* 
     return PDMP_OK;
 }
 
+// The factorised samplers (ZigZag / FactBoomerang / sticky) and the non-factorised ones (BouncyParticle / Boomerang) keep different
+// device state: an entry point of the wrong family is a call-order error, reported as a status (never a crash).
+#define NEED_FACTORISED(e)                                                                                               \
+    do {                                                                                                                 \
+        if ((e) && (e)->cfg.sampler == PDMP_SAMPLER_BPS)                                                                 \
+            return fail(PDMP_ERR_INVALID, "%s: the ensemble was created with PDMP_SAMPLER_BPS (use the pdmp_ensemble_*bps* calls)", \
+                        __func__);                                                                                       \
+    } while (0)
+
+pdmp_status pdmp_debug_set_kernel(pdmp_ensemble* e, int kernel) {
+    if (!e) return fail(PDMP_ERR_INVALID, "null argument");
+    if (kernel != PDMP_DEBUG_KERNEL_AUTO && kernel != PDMP_DEBUG_KERNEL_SEQ && kernel != PDMP_DEBUG_KERNEL_SPEC4)
+        return fail(PDMP_ERR_INVALID, "unknown kernel selector %d", kernel);
+    if (e->has_flow) return fail(PDMP_ERR_INVALID, "pdmp_debug_set_kernel must precede set_flow_*");
+    e->dbg_kernel = kernel;
+    return PDMP_OK;
+}
+pdmp_status pdmp_debug_set_spec_g2(pdmp_ensemble* e, int on) {
+    if (!e) return fail(PDMP_ERR_INVALID, "null argument");
+    e->dbg_spec_g2 = on ? 1 : 0;
+    return PDMP_OK;
+}
+pdmp_status pdmp_debug_set_phase_profile(pdmp_ensemble* e, int on) {
+    if (!e) return fail(PDMP_ERR_INVALID, "null argument");
+    e->dbg_phase = on ? 1 : 0;
+    e->dbg_phase_valid = 0;
+    return PDMP_OK;
+}
+pdmp_status pdmp_debug_phase_profile(pdmp_ensemble* e, double* out16, int* kind) {
+    if (!e || !out16) return fail(PDMP_ERR_INVALID, "null argument");
+    if (!e->dbg_phase_valid) return fail(PDMP_ERR_INVALID, "no phase profile recorded by the last run");
+    memcpy(out16, e->dbg_phase_out, sizeof e->dbg_phase_out);
+    if (kind) *kind = e->dbg_phase_valid;
+    return PDMP_OK;
+}
+pdmp_status pdmp_debug_set_proposal_dump(pdmp_ensemble* e, int64_t n) {
+    if (!e || n < 0) return fail(PDMP_ERR_INVALID, "bad argument");
+    e->dbg_dump = n;
+    return PDMP_OK;
+}
+
 pdmp_status pdmp_ensemble_create(const pdmp_config* cfg, pdmp_ensemble** out) {
     if (!cfg || !out) return fail(PDMP_ERR_INVALID, "null argument");
     *out = nullptr;
@@ -306,6 +355,7 @@ void pdmp_ensemble_destroy(pdmp_ensemble* e) {
 static pdmp_status set_flow_common(pdmp_ensemble* e, const int64_t* colptr, const int64_t* rowval, const double* nzval,
                                    const double* mu, const double* sigma, double lambda_ref, double rho, int kind) {
     if (!e || !colptr || !rowval || !nzval) return fail(PDMP_ERR_INVALID, "null argument");
+    NEED_FACTORISED(e);
     HIP_TRY(hipSetDevice(e->cfg.device));
     const int64_t d = e->cfg.d;
     if (colptr[0] != 0) return fail(PDMP_ERR_INVALID, "colptr[0] must be 0 (0-based CSC)");
@@ -491,10 +541,17 @@ pdmp_status pdmp_ensemble_set_flow_factboomerang(pdmp_ensemble* e, const int64_t
 pdmp_status pdmp_ensemble_set_target_gaussian_csc(pdmp_ensemble* e, const int64_t* colptr, const int64_t* rowval,
                                                   const double* nzval, const double* mu) {
     if (!e || !colptr || !rowval || !nzval) return fail(PDMP_ERR_INVALID, "null argument");
+    NEED_FACTORISED(e);
     if (!e->has_flow) return fail(PDMP_ERR_INVALID, "set_flow_zigzag must be called first");
     HIP_TRY(hipSetDevice(e->cfg.device));
     const int64_t d = e->cfg.d;
     if (colptr[0] != 0) return fail(PDMP_ERR_INVALID, "colptr[0] must be 0 (0-based CSC)");
+    for (int64_t i = 0; i < d; ++i) {
+        if (colptr[i + 1] < colptr[i]) return fail(PDMP_ERR_INVALID, "target colptr not monotone at %lld", (long long)i);
+        for (int64_t p = colptr[i]; p < colptr[i + 1]; ++p)
+            if (rowval[p] < 0 || rowval[p] >= d)
+                return fail(PDMP_ERR_INVALID, "target row index %lld out of range in column %lld", (long long)rowval[p], (long long)i);
+    }
     // align Γt to the flow's pattern: slots absent from Γt carry 0.0 (s + 0.0*x == s bit-for-bit)
     std::vector<double> tval(e->nnz, 0.0), gmu_t(d, 0.0);
     for (int64_t i = 0; i < d; ++i) {
@@ -617,8 +674,8 @@ static pdmp_status build_blob(pdmp_ensemble* e, const double* c) {
     e->blob_pw = PW;
     e->blob_kmax = kmax;
     e->blob_mmax = mmax;
-    const char* force = getenv("PDMP_KERNEL");  // "seq" forces the one-event-per-iteration kernel (A/B runs, tests)
-    e->use_spec = pdmp::zz_spec_supported(e->nblk, mmax, kmax) && !(force && strcmp(force, "seq") == 0) &&
+    // (pdmp_debug_set_kernel(PDMP_DEBUG_KERNEL_SEQ) forces the one-event-per-iteration kernel: A/B runs, parity tests)
+    e->use_spec = pdmp::zz_spec_supported(e->nblk, mmax, kmax) && e->dbg_kernel != PDMP_DEBUG_KERNEL_SEQ &&
                   pdmp::zz_spec_lds_bytes(e->nblk_pad, Wpad) <= 64 * 1024;
     return e->d_blob.upload(blob);
 }
@@ -632,6 +689,7 @@ extern "C" pdmp_status pdmp_ensemble_set_target_logistic(pdmp_ensemble* e, int64
                                                          const double* mu, double gamma0, int64_t k_sub) {
     if (!e || !A_colptr || !A_rowval || !A_nzval || !At_colptr || !At_rowval || !At_nzval || !y || !ny || !mu)
         return fail(PDMP_ERR_INVALID, "null argument");
+    NEED_FACTORISED(e);
     if (!e->has_flow) return fail(PDMP_ERR_INVALID, "set_flow_zigzag must be called first");
     if (n <= 0 || k_sub <= 0) return fail(PDMP_ERR_INVALID, "n and k_sub must be positive");
     HIP_TRY(hipSetDevice(e->cfg.device));
@@ -793,11 +851,13 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
 pdmp_status pdmp_ensemble_set_state(pdmp_ensemble* e, double t0, const double* x0, const double* theta0,
                                     const double* c, const uint64_t* seeds) {
     if (!e || !x0 || !theta0 || !seeds) return fail(PDMP_ERR_INVALID, "null argument");
+    NEED_FACTORISED(e);
     return init_state(e, t0, x0, theta0, c, seeds, 0);
 }
 
 pdmp_status pdmp_ensemble_set_state_synthetic(pdmp_ensemble* e, double t0, const double* c, uint64_t seed0) {
     if (!e) return fail(PDMP_ERR_INVALID, "null argument");
+    NEED_FACTORISED(e);
     return init_state(e, t0, nullptr, nullptr, c, nullptr, seed0);
 }
 
@@ -852,8 +912,7 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
     P.tix = e->d_tix.p;
     P.common_tix = e->common_tix;
     DevBuf<double> dbgbuf;
-    const char* dbgenv = getenv("PDMP_DEBUG");
-    const int64_t dbg_cap = dbgenv ? atoll(dbgenv) : 0;
+    const int64_t dbg_cap = e->dbg_dump;
     if (dbg_cap > 0) {
         pdmp_status st2 = dbgbuf.alloc((size_t)dbg_cap * 16);
         if (st2 != PDMP_OK) return st2;
@@ -875,19 +934,20 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
     P.factor = e->cfg.factor;
     P.lambda_ref = e->lambda_ref;
     // G2[i] is fetched only once an event is accepted (18 % of proposals): same throughput at 4 waves/SIMD, 37 % less HBM
-    // traffic; PDMP_SPEC_G2=1 restores the speculative fetch (3 % faster when the SIMDs are under-occupied)
-    P.flags = flags | (getenv("PDMP_SPEC_G2") ? 0 : 0x100);
+    // traffic; pdmp_debug_set_spec_g2 restores the speculative fetch (3 % faster when the SIMDs are under-occupied)
+    P.flags = flags | (e->dbg_spec_g2 ? 0 : 0x100);
+    P.force_spec4 = e->dbg_kernel == PDMP_DEBUG_KERNEL_SPEC4 ? 1 : 0;
     P.adapt = e->cfg.adapt;
     P.has_refresh = e->lambda_ref > 0;
     P.move_all = e->cfg.sampler == PDMP_SAMPLER_ZIGZAG_ALL;
-    if (getenv("PDMP_DEBUG_PTRS")) fprintf(stderr, "PTRS rec=%p keys=%p hdr=%p ev=%p blob=%p tix=%p\n", (void*)P.rec, (void*)P.keys, (void*)P.hdr, (void*)P.ev, (void*)P.blob, (void*)P.tix);
     HIP_TRY(hipEventRecord(e->ev0, s));
     const bool sticky = e->cfg.sampler == PDMP_SAMPLER_STICKY_ZIGZAG;
     P.kappa = e->d_kappa.p;
     P.thf = e->d_thf.p;
     P.reversible = e->reversible;
     P.strong_upperbounds = e->strong_upperbounds;
-    const char* phenv = getenv("PDMP_PHASE");
+    const bool phenv = e->dbg_phase != 0;
+    e->dbg_phase_valid = 0;
     DevBuf<double> phbuf;
     const bool spec_ok = e->use_spec && dbg_cap == 0 && !P.has_refresh && !P.move_all && !sticky;
     const bool general_path = e->needs_general || e->target_kind == 1 || e->adaptscale || e->local_bound;
@@ -935,10 +995,8 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         e->timed = true;
         if (phenv) {
             HIP_TRY(hipDeviceSynchronize());
-            double hp[16];
-            HIP_TRY(hipMemcpy(hp, phbuf.p, sizeof hp, hipMemcpyDeviceToHost));
-            fprintf(stderr, "PHASE(general) proposals=%.0f cycles/proposal: select=%.0f moveG1=%.0f grad=%.0f coin+G2=%.0f rebound=%.0f requeue=%.0f tail=%.0f\n",
-                    hp[10], hp[0] / hp[10], hp[1] / hp[10], hp[2] / hp[10], hp[3] / hp[10], hp[4] / hp[10], hp[5] / hp[10], hp[6] / hp[10]);
+            HIP_TRY(hipMemcpy(e->dbg_phase_out, phbuf.p, sizeof e->dbg_phase_out, hipMemcpyDeviceToHost));
+            e->dbg_phase_valid = 2;  // general kernel: [0..6] = select, move G1, gradient, coin + G2, re-bound, re-queue, tail; [10] = proposals
         }
         return PDMP_OK;
     }
@@ -950,11 +1008,8 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
     e->timed = true;
     if (phenv && spec_ok) {
         HIP_TRY(hipDeviceSynchronize());
-        double hp[16];
-        HIP_TRY(hipMemcpy(hp, phbuf.p, sizeof hp, hipMemcpyDeviceToHost));
-        fprintf(stderr, "PHASE iters=%.0f cycles/iter:", hp[10]);
-        for (int q = 0; q < 9; ++q) fprintf(stderr, " p%d=%.0f", q, hp[10] > 0 ? hp[q] / hp[10] : 0.0);
-        fprintf(stderr, "\n");
+        HIP_TRY(hipMemcpy(e->dbg_phase_out, phbuf.p, sizeof e->dbg_phase_out, hipMemcpyDeviceToHost));
+        e->dbg_phase_valid = 1;  // speculative kernels: [0..8] = cycles per phase, [10] = iterations
     }
     if (dbg_cap > 0) {
         HIP_TRY(hipDeviceSynchronize());
@@ -1015,6 +1070,7 @@ pdmp_status pdmp_ensemble_totals(pdmp_ensemble* e, uint64_t* num, uint64_t* nacc
 
 pdmp_status pdmp_ensemble_trace_copy(pdmp_ensemble* e, int64_t chain, int64_t first, int64_t count, pdmp_event* out) {
     if (!e || !out) return fail(PDMP_ERR_INVALID, "null argument");
+    NEED_FACTORISED(e);
     if (e->cfg.trace_capacity <= 0) return fail(PDMP_ERR_INVALID, "ensemble was created with trace_capacity = 0");
     if (chain < 0 || chain >= e->cfg.nchains || first < 0 || count < 0 || first + count > e->cfg.trace_capacity)
         return fail(PDMP_ERR_INVALID, "trace range out of bounds");
@@ -1042,6 +1098,7 @@ pdmp_status pdmp_ensemble_trace_reset(pdmp_ensemble* e) {
 pdmp_status pdmp_ensemble_final_state(pdmp_ensemble* e, int64_t chain_first, int64_t n, double* t, double* x,
                                       double* theta, int64_t* acc, double* c) {
     if (!e) return fail(PDMP_ERR_INVALID, "null argument");
+    NEED_FACTORISED(e);
     if (!e->has_state) return fail(PDMP_ERR_INVALID, "no state");
     if (chain_first < 0 || n < 0 || chain_first + n > e->cfg.nchains) return fail(PDMP_ERR_INVALID, "chain range");
     if (n == 0) return PDMP_OK;
@@ -1177,6 +1234,7 @@ pdmp_status pdmp_ensemble_set_sticky(pdmp_ensemble* e, const double* kappa, int 
 
 pdmp_status pdmp_ensemble_set_local_bound(pdmp_ensemble* e, int enable) {
     if (!e) return fail(PDMP_ERR_INVALID, "null argument");
+    NEED_FACTORISED(e);
     if (!e->has_flow) return fail(PDMP_ERR_INVALID, "set_flow_* must be called first");
     e->local_bound = enable != 0;
     e->has_state = false;
@@ -1197,6 +1255,7 @@ pdmp_status pdmp_ensemble_set_adaptscale(pdmp_ensemble* e, int enable) {
 
 pdmp_status pdmp_ensemble_final_sigma(pdmp_ensemble* e, int64_t chain_first, int64_t n, double* sigma) {
     if (!e || !sigma) return fail(PDMP_ERR_INVALID, "null argument");
+    NEED_FACTORISED(e);
     if (!e->has_state) return fail(PDMP_ERR_INVALID, "no state");
     const int64_t d = e->cfg.d;
     if (chain_first < 0 || n < 0 || chain_first + n > e->cfg.nchains) return fail(PDMP_ERR_INVALID, "chain range out of bounds");

@@ -70,7 +70,7 @@ struct ZzRunParams {
     DevChain* hdr;
     pdmp_event* ev;
     double* c_chain;  // per-chain bounds when adapt, else nullptr
-    double* dbg;  // optional [dbg_cap x 16] per-proposal diagnostics of chain 0 (PDMP_DEBUG env), else nullptr
+    double* dbg;  // optional [dbg_cap x 16] per-proposal diagnostics of chain 0 (pdmp_debug_set_proposal_dump), else nullptr
     int64_t dbg_cap;
     const uint64_t* __restrict__ blob;  // [ntemplates x blob_w_pad] neighbourhood programs (layout: pdmp_capi.hip build_blob)
     const uint32_t* __restrict__ tix;   // [d] template of coordinate i (coordinates with the same relative program share one)
@@ -88,6 +88,8 @@ struct ZzRunParams {
     int32_t adapt;
     int32_t has_refresh;
     int32_t move_all;  // G = All(): the `pdmp` driver for ZigZag (src/sfact.jl:236)
+    int32_t force_spec4;  // diagnostics (pdmp_debug_set_kernel): keep the 4-event kernel where the 8-event one would run
+    int32_t pad0_;
     // sticky ZigZag (src/ss_fact.jl)
     const double* __restrict__ kappa;  // [d] thaw rates
     double* thf;                       // [nchains x d] saved speeds θf

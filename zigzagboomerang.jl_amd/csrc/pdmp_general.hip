@@ -160,7 +160,7 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
     const double T = P.T;
     const bool stop_before = (P.flags & PDMP_RUN_STOP_BEFORE) != 0;
     const bool adapt = P.adapt != 0;
-    // PDMP_PHASE=1: cycles per phase, chain 0 (diagnostic build of the same loop)
+    // pdmp_debug_set_phase_profile: cycles per phase, chain 0 (diagnostic build of the same loop)
     uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t ph_t0 = PROF ? (uint64_t)__builtin_readcyclecounter() : 0;
 #define GPHASE(k)                                                         \

@@ -3176,13 +3176,11 @@ int launch_zz_local_spec(const ZzRunParams& p, int64_t nchains, void* stream) {
     // without a refresh clock the last key block holds only the (infinite) refresh slot: when d fills 256 blocks exactly the
     // queue's first level is scanned as 4 entries per lane instead of 5
     const bool plain4 = plain && !p.has_refresh && p.d == 256 * 64 && p.nblk == 257;
-    // PDMP_KERNEL=spec4 keeps the 4-events-per-iteration kernel for the lattice workload (A/B runs, tests)
-    const char* force = getenv("PDMP_KERNEL");
     // the 8-event kernel: the lattice blob geometry, no refresh clock, 2048 <= d <= 16384 (its first level has 512 entries over
     // 32-key blocks; below 64 blocks there are too few candidates for eight slots)
     const bool geom = (p.flags & 0x100) && p.blob_sw == 7 && p.blob_pw == 1 && p.blob_kmax == 5 && p.blob_w_pad == 58;
     const bool spec8 = geom && !p.has_refresh && p.d >= 2048 && p.d <= (int64_t)S8_NBLK * 32 &&
-                       !(force && strcmp(force, "spec4") == 0);
+                       !p.force_spec4;  // (pdmp_debug_set_kernel: A/B runs and parity tests of the 4-event kernel)
     if (spec8) {
         ZzRunParams q = p;
         q.nblk = (uint32_t)((p.d + 31) / 32);
@@ -3190,7 +3188,7 @@ int launch_zz_local_spec(const ZzRunParams& p, int64_t nchains, void* stream) {
         else if (p.dbg) hipLaunchKernelGGL((zz_local_spec8_kernel<true, true>), grid, block, zz_spec8_lds_bytes(), (hipStream_t)stream, q);
         else if (plain) hipLaunchKernelGGL((zz_local_spec8_kernel<false>), grid, block, zz_spec8_lds_bytes(), (hipStream_t)stream, q);
         else hipLaunchKernelGGL((zz_local_spec8_kernel<false, true>), grid, block, zz_spec8_lds_bytes(), (hipStream_t)stream, q);
-    } else if (p.dbg) {  // per-phase cycle profile (PDMP_PHASE env)
+    } else if (p.dbg) {  // per-phase cycle profile (pdmp_debug_set_phase_profile)
         if (plain4) {
             ZzRunParams q = p;
             q.nblk = 256;

@@ -3,6 +3,7 @@
 All compute happens inside libpdmp_mi355.so on the gfx950 device; this file only marshals numpy arrays.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -36,6 +37,29 @@ class Ensemble:
         h = C.c_void_p()
         _lib.check(self._L.pdmp_ensemble_create(C.byref(cfg), C.byref(h)))
         self._h = h
+        # Test / A-B harness switches.  The LIBRARY reads no environment variables (include/pdmp_debug.h: per-ensemble calls);
+        # this host-side wrapper forwards the ones the test-suite and tools/ set, so that samplers.spdmp(...) can be steered
+        # without threading a debug argument through the reference's signatures.
+        k = os.environ.get("PDMP_KERNEL")
+        if k:
+            self.debug_set_kernel(k)
+        if os.environ.get("PDMP_SPEC_G2"):
+            _lib.check(self._L.pdmp_debug_set_spec_g2(self._h, 1))
+
+    # ---- diagnostics (include/pdmp_debug.h)
+    def debug_set_kernel(self, name):
+        """'auto' | 'seq' (one event per iteration) | 'spec4' (4-event kernel where the 8-event one would run); before set_flow."""
+        _lib.check(self._L.pdmp_debug_set_kernel(self._h, _lib.DEBUG_KERNELS[name]))
+
+    def debug_phase_profile(self, on=True):
+        _lib.check(self._L.pdmp_debug_set_phase_profile(self._h, int(bool(on))))
+
+    def debug_phase_cycles(self):
+        """(kind, 16 numbers) recorded by the last run, see include/pdmp_debug.h."""
+        out = np.zeros(16)
+        kind = C.c_int()
+        _lib.check(self._L.pdmp_debug_phase_profile(self._h, _ptr(out), C.byref(kind)))
+        return int(kind.value), out
 
     def close(self):
         if getattr(self, "_h", None):
