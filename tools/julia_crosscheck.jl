@@ -1,0 +1,222 @@
+# julia_crosscheck.jl -- pins the build's CPU oracle (oracle/pdmp_oracle.c) to ZigZagBoomerang.jl ITSELF.
+#
+#   julia --project=<an environment with ZigZagBoomerang v0.13.x> tools/julia_crosscheck.jl [path/to/tests/golden]
+#
+# NOT executable in the build image (no Julia there; SURVEY.md 8c1) -- written for a maintainer of the reference.  It is the one
+# route by which "parity unpinned" can be lifted: the reference's samplers take their uniforms from an `rng` argument
+# (spdmp_inner!, src/sfact.jl:73; pdmp_inner!, src/not_fact_samplers.jl:52), so a counter-based `PhiloxRNG <: AbstractRNG`
+# whose n-th `rand(rng)` is draw n of the engine's stream (include/pdmp_detmath.h: pdmp_u01(seed, PDMP_STREAM_MAIN, n)) makes the
+# REFERENCE replay the very chain the oracle and the gfx950 kernels produce.  The fixtures tests/golden/crosscheck_*.txt hold the
+# inputs and the oracle's event lists (floats as IEEE-754 bit patterns; written by tests/golden/export_crosscheck.py).
+#
+# What is compared: the event INDEX sequence and (acc, num) exactly; event times, positions and velocities to 1e-9 relative
+# (north star: 1e-6).  They cannot be asked to agree to the last bit: the engine's log / sincos (pdmp_log, pdmp_sincos: < 1 ulp,
+# bit-reproducible across x86-64 and gfx950) are not Julia's libm, and the non-factorised samplers' dot products and triangular
+# solves have a fixed order in the engine and BLAS/LAPACK's in Julia.
+#
+# The drivers below restate the ~40 set-up lines of spdmp (src/sfact.jl:162-208), pdmp (src/not_fact_samplers.jl:117-147) and
+# sspdmp (src/ss_fact.jl:159-215) only to pass `rng` in; every step of the event loop is the reference's own *_inner! function.
+using ZigZagBoomerang, SparseArrays, LinearAlgebra, Random
+const ZZB = ZigZagBoomerang
+
+# ------------------------------------------------------------------ Philox4x32-10, keyed per chain (include/pdmp_detmath.h:56-101)
+const M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+function philox4x32_10(c0::UInt32, c1::UInt32, c2::UInt32, c3::UInt32, k0::UInt32, k1::UInt32)
+    for _ in 1:10
+        p0 = UInt64(M0) * UInt64(c0)
+        p1 = UInt64(M1) * UInt64(c2)
+        n0 = (p1 >> 32) % UInt32 ⊻ c1 ⊻ k0
+        n1 = p1 % UInt32
+        n2 = (p0 >> 32) % UInt32 ⊻ c3 ⊻ k1
+        n3 = p0 % UInt32
+        c0, c1, c2, c3 = n0, n1, n2, n3
+        k0 += W0
+        k1 += W1
+    end
+    c0, c1, c2, c3
+end
+bits64(seed::UInt64, stream::UInt32, n::UInt64) = begin
+    r = philox4x32_10(n % UInt32, (n >> 32) % UInt32, stream, 0x00000000, seed % UInt32, (seed >> 32) % UInt32)
+    (UInt64(r[1]) << 32) | UInt64(r[2])
+end
+u01(seed, stream, n) = (Float64(bits64(seed, stream, n) >> 12) + 0.5) * 2.0^-52   # pdmp_bits_to_u01: open interval (0, 1)
+
+mutable struct PhiloxRNG <: AbstractRNG
+    seed::UInt64
+    stream::UInt32
+    n::UInt64          # index of the next draw
+end
+PhiloxRNG(seed::Integer) = PhiloxRNG(UInt64(seed), 0x00000000, UInt64(0))      # PDMP_STREAM_MAIN
+next!(r::PhiloxRNG) = (u = u01(r.seed, r.stream, r.n); r.n += 1; u)
+Random.rand(r::PhiloxRNG, ::Random.SamplerTrivial{Random.CloseOpen01{Float64}}) = next!(r)
+# rand(rng, (-1, 1)) of the refresh branch (src/sfact.jl:101): not used by the fixtures (λref = 0 there)
+Random.randexp(r::PhiloxRNG) = -log(next!(r))                                  # pdmp_randexp
+# randn(rng, d) of refresh! (src/dynamics.jl:115): element k (0-based) is Box-Muller branch (k >> 6) & 1 of block
+# n + 64 (k >> 7) + (k & 63); the vector consumes 64 ⌈d/128⌉ draws (oracle/pdmp_oracle.c: orc_pdmp_bps, refresh branch)
+function boxmuller2(seed, stream, n)
+    # pdmp_randn2 (include/pdmp_detmath.h:296-306): u1 from words 0,1 and u2 from words 2,3 of ONE Philox block
+    r = philox4x32_10(n % UInt32, (n >> 32) % UInt32, stream, 0x00000000, seed % UInt32, (seed >> 32) % UInt32)
+    u1 = (Float64(((UInt64(r[1]) << 32) | UInt64(r[2])) >> 12) + 0.5) * 2.0^-52
+    u2 = (Float64(((UInt64(r[3]) << 32) | UInt64(r[4])) >> 12) + 0.5) * 2.0^-52
+    rad = sqrt(-2.0 * log(u1))
+    s, c = sincospi(2 * u2)
+    rad * c, rad * s
+end
+function Random.randn(r::PhiloxRNG, ::Type{Float64}, d::Integer)
+    z = Vector{Float64}(undef, d)
+    for k in 0:d-1
+        z0, z1 = boxmuller2(r.seed, r.stream, r.n + UInt64(64 * (k >> 7) + (k & 63)))
+        z[k+1] = ((k >> 6) & 1) == 1 ? z1 : z0
+    end
+    r.n += UInt64(64 * cld(d, 128))
+    z
+end
+Random.randn(r::PhiloxRNG, d::Integer) = randn(r, Float64, d)
+
+# ------------------------------------------------------------------ fixtures
+f64(h) = reinterpret(Float64, parse(UInt64, h; base = 16))
+function read_fixture(path)
+    L = readlines(path)
+    D = Dict{String,Any}()
+    k = 1
+    while k <= length(L)
+        w = split(L[k])
+        key = w[1]
+        if key in ("Gamma", "L")
+            n, nnz = parse(Int, w[2]), parse(Int, w[3])
+            I, J, V = Int[], Int[], Float64[]
+            for q in 1:nnz
+                a = split(L[k+q])
+                push!(I, parse(Int, a[1])); push!(J, parse(Int, a[2])); push!(V, f64(a[3]))
+            end
+            D[key] = sparse(I, J, V, n, n)
+            k += nnz
+        elseif key == "events"
+            n = parse(Int, w[2])
+            D["events"] = [split(L[k+q]) for q in 1:n]
+            k += n
+        elseif key in ("sampler",)
+            D[key] = w[2]
+        elseif key in ("seed", "num")
+            D[key] = parse(Int, w[2])
+        elseif key == "acc"
+            D[key] = parse.(Int, w[2:end])
+        else
+            v = f64.(w[2:end])
+            D[key] = length(v) == 1 && !(key in ("x0", "theta0", "c")) ? v[1] : v
+        end
+        k += 1
+    end
+    D
+end
+relerr(a, b) = abs(a - b) / max(abs(a), abs(b), 1e-300)
+
+# ------------------------------------------------------------------ spdmp with the rng injected (src/sfact.jl:162-208)
+function spdmp_with_rng(rng, ∇ϕ, t0, x0, θ0, T, c, F, args...; factor = 1.8, adapt = false)
+    n = length(x0)
+    t′ = t0
+    t = fill(t′, size(θ0)...)
+    t_old = copy(t)
+    G1 = [i => rowvals(F.Γ)[nzrange(F.Γ, i)] for i in eachindex(θ0)]
+    G = G1
+    G2 = [i => setdiff(union((G1[j].second for j in G1[i].second)...), G[i].second) for i in eachindex(G1)]
+    x, θ = copy(x0), copy(θ0)
+    num = 0
+    acc = zeros(Int, length(θ))
+    Q = ZZB.SPriorityQueue{Int,Float64}()
+    b = [ZZB.ab(G1, i, x, θ, c, F) for i in eachindex(θ)]
+    for i in eachindex(θ)
+        ZZB.enqueue!(Q, i => poisson_time(b[i], rand(rng)))
+    end
+    events = Tuple{Float64,Int,Float64,Float64}[]
+    while t′ < T
+        ev, t, x, θ, t′, (acc, num), c, b, t_old = ZZB.spdmp_inner!(rng, G, G1, G2, ∇ϕ, t, x, θ, Q, c, b, t_old, (acc, num), F,
+                                                                   args...; factor = factor, adapt = adapt)
+        push!(events, ev)
+    end
+    events, (t, x, θ), (acc, num), c
+end
+
+function check_spdmp(path)
+    D = read_fixture(path)
+    Γ = D["Gamma"]
+    Z = ZigZag(D["scale"] * Γ, zeros(size(Γ, 1)))                       # bound Γ = scale·Γ, target Γ (test/maintest.jl:23)
+    ∇ϕ(x, i, Γ) = ZZB.idot(Γ, i, x)                                      # test/maintest.jl:9
+    ev, _, (acc, num), _ = spdmp_with_rng(PhiloxRNG(D["seed"]), ∇ϕ, 0.0, D["x0"], D["theta0"], D["T"], copy(D["c"]), Z, Γ)
+    ref = D["events"]
+    @assert length(ev) == length(ref) "event count $(length(ev)) vs $(length(ref))"
+    worst = 0.0
+    for (e, r) in zip(ev, ref)
+        @assert e[2] == parse(Int, r[2]) "event index differs"
+        worst = max(worst, relerr(e[1], f64(r[1])), relerr(e[3], f64(r[3])), relerr(e[4], f64(r[4])))
+    end
+    @assert num == D["num"] && acc == D["acc"]
+    @assert worst < 1e-9
+    println(basename(path), ": ", length(ev), " events, index sequence and (acc, num) identical, max relative deviation ", worst)
+end
+
+# ------------------------------------------------------------------ BouncyParticle with its mass factor (src/not_fact_samplers.jl:117-147)
+function check_bps(path)
+    D = read_fixture(path)
+    Γ, Lf = D["Gamma"], LowerTriangular(Matrix(D["L"]))
+    d = size(Γ, 1)
+    B = BouncyParticle(Γ, zeros(d), D["lambda_ref"], D["rho"], nothing, Lf)   # the 6-field constructor: L as given
+    ∇ϕ!(y, x) = mul!(y, Γ, x)                                                  # test/maintest.jl:163
+    rng = PhiloxRNG(D["seed"])
+    Flow, T = B, D["T"]
+    ∇w = ZZB.Wrapper(∇ϕ!)
+    cb = ZZB.GlobalBound(D["c"])
+    t, x, θ, ∇ϕx = 0.0, copy(D["x0"]), copy(D["theta0"]), copy(D["theta0"])
+    τref = ZZB.waiting_time_ref(rng, Flow)
+    ∇ϕx, v = ∇w(∇ϕx, t, x, θ)
+    ∇ϕx = ZZB.grad_correct!(∇ϕx, x, Flow)
+    num = acc = 0
+    abc = ZZB.ab(x, θ, cb, ∇ϕx, v, Flow)
+    t′, renew = ZZB.next_time(t, abc, rand(rng))
+    ref = D["events"]
+    k = 0
+    worst = 0.0
+    while t < T
+        t, x, θ, (acc, num), cb, abc, (t′, renew), τref, v = ZZB.pdmp_inner!(rng, ∇w, ∇ϕx, t, x, θ, cb, abc, (t′, renew), τref, v,
+                                                                             (acc, num), Flow)
+        k += 1
+        r = ref[k]
+        worst = max(worst, relerr(t, f64(r[1])))
+        for j in 1:d
+            worst = max(worst, abs(x[j] - f64(r[1+j])), abs(θ[j] - f64(r[1+d+j])))
+        end
+    end
+    @assert k == length(ref) && num == D["num"] && acc == D["acc"] "event or proposal counts differ"
+    @assert worst < 1e-9
+    println(basename(path), ": ", k, " events (reflections and refreshments), counts identical, max deviation ", worst)
+end
+
+# ------------------------------------------------------------------ sticky ZigZag: sspdmp draws from the GLOBAL rng (`rand()`, src/ss_fact.jl:54-66,96,179)
+const GLOBAL_PHILOX = Ref{Union{Nothing,PhiloxRNG}}(nothing)
+function check_sspdmp(path)
+    D = read_fixture(path)
+    σ2, μ, κ = D["sigma2"], D["mu"], D["kappa"]
+    ∇ϕ(x, i, μ) = (x[i] - μ) / σ2                                        # test/sticky.jl:13
+    Z = ZigZag(sparse([1.0;;]), [0.0])
+    GLOBAL_PHILOX[] = PhiloxRNG(D["seed"])
+    # the zero-argument rand() is what ss_fact.jl calls: route it (and only it) to the Philox stream for the duration of the run
+    @eval Random.rand() = Main.next!(Main.GLOBAL_PHILOX[])
+    trace, _, (acc, num), _ = sspdmp(∇ϕ, 0.0, D["x0"], D["theta0"], D["T"], D["c"], Z, [κ], μ)
+    ev = trace.events
+    ref = D["events"]
+    @assert length(ev) == length(ref) && num == D["num"] && acc == D["acc"]
+    worst = 0.0
+    for (e, r) in zip(ev, ref)
+        @assert e[2] == parse(Int, r[2])
+        worst = max(worst, relerr(e[1], f64(r[1])), abs(e[3] - f64(r[3])), abs(e[4] - f64(r[4])))
+    end
+    @assert worst < 1e-9
+    println(basename(path), ": ", length(ev), " events (freeze / thaw / reflection), counts identical, max deviation ", worst)
+end
+
+dir = length(ARGS) >= 1 ? ARGS[1] : joinpath(@__DIR__, "..", "tests", "golden")
+check_spdmp(joinpath(dir, "crosscheck_spdmp_d8.txt"))
+check_spdmp(joinpath(dir, "crosscheck_spdmp_grid8.txt"))
+check_bps(joinpath(dir, "crosscheck_bps_d8.txt"))
+check_sspdmp(joinpath(dir, "crosscheck_sspdmp_1d.txt"))
+println("oracle == ZigZagBoomerang.jl on all fixtures")
