@@ -117,3 +117,50 @@ def logistic_problem(levels=(20, 20), r=2, m=20, gamma0=0.01, seed=2, droptol=1e
     theta0 = rng.choice([-1.0, 1.0], p) * sigma
     return dict(A=A, At=At, y=y, ny=ny, mu=mu, gamma0=gamma0, G=G, Gdrop=Gd, sigma=sigma, theta0=theta0, x0=mu.copy(),
                 c=0.01 * np.ones(p), xtrue=xtrue, n=n, p=p)
+
+
+def example_design_matrix(num_rows=50_000, num_categorical=100, num_continuous=10, rng=None):
+    """example_design_matrix(; num_rows) -- scripts/exampledesign.jl:2-13: binary categorical features `rand(num_rows) .> 0.5`
+    followed by standard-normal continuous ones; the column counts are arguments here so that the generator scales to config C5's
+    10⁴ columns in the script's own 10 : 1 proportion.  Returned as CSC (the zeros of the binary columns are not stored)."""
+    rng = np.random.default_rng(2) if rng is None else rng
+    cat = (rng.random((num_rows, num_categorical)) > 0.5).astype(np.float64)
+    con = rng.standard_normal((num_rows, num_continuous))
+    A = sp.csc_matrix(np.hstack([cat, con]))
+    A.sort_indices()
+    return A
+
+
+def spike_slab_logistic_problem(p=10_000, num_rows=2000, gamma0=0.25, w=0.5, seed=2):
+    """Config C5: Bayesian logistic regression with a spike-and-slab prior, p = 10⁴ coefficients.
+
+    Design: example_design_matrix (scripts/exampledesign.jl:2-13) scaled to p columns (10 : 1 categorical : continuous, as in the
+    script's 100 + 10); data as scripts/spikeandslab.jl:36-40: xtrue = randn(p) .* (rand(p) .< 0.2), y ~ Bernoulli(sigmoid(A xtrue));
+    slab N(0, 1/γ0) -- so that ∇ϕ is the `γ0*x[i] − fdot_moving(...)` of scripts/logistic.jl:107 / sticky_logistic_sparse.jl:131 --,
+    spike = the point mass of the sticky sampler with thaw rate κ = (γ0/√2π)/(1/w − 1) (scripts/sticky/sticky_logistic_sparse.jl:197);
+    flow Z = ZigZag(sparse(1.0I, p, p), μ, σ) as scripts/spikeandslab.jl:96,113 (one-coordinate neighbourhoods: ∇ϕmoving moves what
+    it reads itself, SelfMoving()), c = ones(p) with adapt = true (:127-129); μ = the slab posterior's mode (Newton steps in the dual
+    form, the control-variate point of ∇ϕmoving).  num_rows is the population the gradient subsamples from (the script's 50 000
+    rows x 110 columns would be 2.7·10¹⁰ stored entries at 10⁴ columns); the work per proposal depends on k and on the row length
+    (≈ 0.55 p), not on it."""
+    rng = np.random.default_rng(seed)
+    ncon = p // 11
+    A = example_design_matrix(num_rows, p - ncon, ncon, rng)
+    n = A.shape[0]
+    xtrue = rng.standard_normal(p) * (rng.random(p) < 0.2)
+    sig = lambda u: 1.0 / (1.0 + np.exp(-u))  # noqa: E731
+    y = (rng.random(n) < sig(A @ xtrue)).astype(np.float64)
+    ny = 1.0 - y
+    At = sp.csc_matrix(A.T)
+    At.sort_indices()
+    Ad = A.toarray()
+    x = np.zeros(p)
+    for _ in range(12):  # Newton on the slab posterior; (γ0 I + B'B)⁻¹ g = (g − B'(γ0 I + B B')⁻¹ B g)/γ0 with B = W^½ A (n < p)
+        u = Ad @ x
+        g = gamma0 * x - Ad.T @ (y * sig(-u)) + Ad.T @ (ny * sig(u))
+        B = np.sqrt(sig(u) * sig(-u))[:, None] * Ad
+        x = x - (g - B.T @ np.linalg.solve(gamma0 * np.eye(n) + B @ B.T, B @ g)) / gamma0
+    mu = x
+    kappa = np.full(p, (gamma0 / np.sqrt(2 * np.pi)) / (1 / w - 1))
+    return dict(A=A, At=At, y=y, ny=ny, mu=mu, gamma0=gamma0, kappa=kappa, G=sp.identity(p, format="csc"), sigma=np.ones(p),
+                c=np.ones(p), xtrue=xtrue, n=n, p=p, w=w)
