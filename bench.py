@@ -127,6 +127,10 @@ def main():
     ap.add_argument("--ess-batches", type=int, default=32, help="B: batches per chain of the ESS run after the timed region (0: skip)")
     ap.add_argument("--ess-batch-len", type=float, default=2.0, help="b: length of an ESS batch in process time")
     ap.add_argument("--no-trace", action="store_true", help="count events only (diagnostic; not the headline mode)")
+    ap.add_argument("--gather", action="store_true",
+                    help="after the timed region: one more step, then time the post-run exchange (all_gather counts -> gatherv of the "
+                         "trace segments to rank 0 -> reduce of the batch-mean sums); printed as a separate `gather` object")
+    ap.add_argument("--per-rank", action="store_true", help="add per-rank counters and chain-0 digests to the JSON line (tests)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -149,6 +153,20 @@ def main():
             red_dev = "cuda"
         else:
             dist.init_process_group(backend)
+
+    if world == 1 and args.gather:
+        # the exchange is written against torch.distributed: a one-rank group makes N = 1 run the very same code
+        import torch
+        import torch.distributed as dist1
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist1.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+            red_dev = "cuda"
+        else:
+            dist1.init_process_group(backend, rank=0, world_size=1)
+        dist = dist1
 
     pkg = load_package()
     pkg.build.build()
@@ -242,6 +260,39 @@ def main():
                                                "have not mixed -- chains start at x0 ~ N(0, I), not at stationarity"},
                "gpu_seconds": gpu_s, "batches": B, "batch_len": b}
 
+    # post-run exchange (never inside `value`): SURVEY 8e1
+    gather = None
+    if args.gather and cap:
+        import torch
+        par = pkg.parallel
+        Tg = (args.warmup + args.steps + 1) * args.dt if ess is None else None
+        if Tg is None:
+            raise SystemExit("--gather and the ESS run are separate modes: add --ess-batches 0")
+        T_prev = (args.warmup + args.steps) * args.dt
+        ens.batch_means(0.0, T_prev)  # baseline J(T_prev)
+        ens.run(Tg, pkg._lib.RUN_STOP_BEFORE)
+        sy, sy2 = ens.batch_means(T_prev, Tg)
+        staging = "device" if red_dev == "cuda" else "host"
+        barrier()
+        tg0 = time.perf_counter()
+        counts_by_rank, gathered, sy, sy2 = par.gather_ensemble(ens, sy, sy2, staging=staging)
+        if red_dev == "cuda" or dist is None:
+            torch.cuda.synchronize()
+        barrier()
+        tg = time.perf_counter() - tg0
+        if dist is not None:
+            tgt = torch.tensor([tg], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tgt, op=dist.ReduceOp.MAX)
+            tg = float(tgt.item())
+        if rank == 0:
+            nev_g = int(sum(int(c.sum().item()) for c in counts_by_rank))
+            assert sum(int(t.shape[0]) for t in gathered) == nev_g
+            gather = {"seconds": tg, "events": nev_g, "bytes": 32 * nev_g, "GBps": 32 * nev_g / tg / 1e9,
+                      "chains": int(sum(c.numel() for c in counts_by_rank)), "staging": staging,
+                      "steps": "all_gather(counts) -> grouped isend/irecv of the trace segments to rank 0 -> reduce(SUM) of 2 x d sums",
+                      "first_event_time_rank_last": float(gathered[-1][0, 0].item()) if gathered[-1].shape[0] else None,
+                      "mean_of_batch_means": float(np.mean(sy) / (nch * world))}
+
     # aggregate over ranks: max time, summed work
     if dist is not None:
         import torch
@@ -253,6 +304,17 @@ def main():
         num_all, nacc_all, nev_all, bad_all = [float(v) for v in ww.tolist()]
     else:
         num_all, nacc_all, nev_all, bad_all = float(num), float(nacc), float(nev), float(bad)
+
+    per_rank = None
+    if args.per_rank:
+        c0 = cnt[0]
+        mine = {"rank": rank, "seed_first": int(SEED0 + rank * nch), "num": int(num), "nacc": int(nacc), "nevents": int(nev),
+                "chain0": {"num": int(c0["num"]), "nacc": int(c0["nacc"]), "ndraw_main": int(c0["ndraw_main"]), "t_last": float(c0["t_last"])}}
+        if dist is not None:
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, mine)
+        else:
+            per_rank = [mine]
 
     if rank == 0:
         k_ms = float(np.mean(kernel_ms))
@@ -296,6 +358,11 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "model": "224*num + 48*(num-nacc) + 616*nacc bytes (SURVEY 8d3)"},
         }
+        out["totals"] = {"num": num_all, "nacc": nacc_all, "nevents": nev_all, "T_end": (args.warmup + args.steps) * args.dt}
+        if per_rank is not None:
+            out["per_rank"] = per_rank
+        if gather is not None:
+            out["gather"] = gather
         if ess is not None:
             out["ess"] = ess
         if world == 1 and not args.no_cpu_baseline:

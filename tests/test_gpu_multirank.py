@@ -1,0 +1,150 @@
+"""The N > 1 path EXECUTED (-m gpu): bench.py launched exactly as the driver launches it (torch.distributed.run, one process per
+rank), two ranks sharing device 0 through the bench's own test hooks (PDMP_BENCH_SINGLE_DEVICE, PDMP_BENCH_BACKEND=gloo: RCCL
+refuses two ranks on one GPU), and the engine -- not the oracle -- producing the shards of a world-2 gather."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SEED0 = 0x5EED0000
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_bench(nranks, extra, env_extra=None, timeout=900):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    if nranks == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + extra
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(nranks)] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_on_one_device(gpu_pkg):
+    """bench.py --gpus 2 with two ranks (2048 chains each) against the same work done by one rank of 4096 chains: the JSON
+    contract, rank-disjoint seeds (rank 1's first chain IS global chain 2048, checked against the oracle), summed counters equal
+    to the single-rank run's (chains are independent: sharding must not change a single proposal), and the timed post-run
+    exchange (--gather) delivering every event to rank 0."""
+    pkg = gpu_pkg
+    steps, warm, nch = 3, 1, 2048
+    common = ["--steps", str(steps), "--warmup", str(warm), "--no-cpu-baseline", "--ess-batches", "0", "--per-rank", "--gather"]
+    two = _run_bench(2, common + ["--chains", str(nch)], {"PDMP_BENCH_SINGLE_DEVICE": "1", "PDMP_BENCH_BACKEND": "gloo"})
+    assert two["n_gpus"] == 2 and two["steps"] == steps and two["warmup"] == warm and two["scaling"] == "weak"
+    assert two["unit"] == "reflection events/s" and two["higher_is_better"] is True and two["dtype"] == "f64"
+    assert two["config"]["chains_per_gpu"] == nch and two["unhealthy_chains"] == 0
+    assert two["value"] > 0 and abs(two["value"] - two["totals"]["nevents"] / (two["ms_per_step"] * 1e-3 * steps)) < 1e-6 * two["value"]
+    pr = two["per_rank"]
+    assert [q["rank"] for q in pr] == [0, 1] and [q["seed_first"] for q in pr] == [SEED0, SEED0 + nch]
+    assert sum(q["num"] for q in pr) == two["totals"]["num"] and sum(q["nevents"] for q in pr) == two["totals"]["nevents"]
+    # rank r's local chain 0 is global chain r * 2048: the oracle with that seed reproduces its counters at the end of the timed run
+    G = pkg.problems.gmrf_precision(128)
+    c = pkg.problems.column_norms(G)
+    T_end = (steps + warm) * 1.0
+    for q in pr:
+        x0, th0 = O.synthetic_state(q["seed_first"], G.shape[0])
+        r = O.spdmp_zigzag(G, None, G, x0, th0, c, T_end, seed=q["seed_first"], stop_before_T=True, want_trace=False)
+        assert (q["chain0"]["num"], q["chain0"]["nacc"], q["chain0"]["ndraw_main"]) == (r["num"], r["nacc"], r["ndraw_main"]), q
+    # the same 4096 chains on ONE rank: identical totals (warm-up + timed steps counted the same way)
+    one = _run_bench(1, common[:-1] + ["--chains", str(2 * nch)])
+    assert one["n_gpus"] == 1 and one["totals"] == two["totals"]
+    # the exchange: every event of the extra step reached rank 0, from both ranks
+    g = two["gather"]
+    assert g["chains"] == 2 * nch and g["events"] > 0.5 * 0.7 * 16384 * 2 * nch and g["bytes"] == 32 * g["events"]
+    assert g["seconds"] > 0 and g["staging"] == "host" and T_end <= g["first_event_time_rank_last"] <= T_end + 1.0
+    assert abs(g["mean_of_batch_means"]) < 0.05
+
+
+def _engine_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, ROOT)
+    import torch  # first: one HIP runtime per process, the one torch ships
+    import torch.distributed as dist
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    par = pkg.parallel
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        nch_total, T = 7, 6.0
+        first, n = par.shard_range(nch_total, rank, world)
+        G = pkg.problems.gmrf_precision(48)  # the 8-event kernel's geometry
+        d = G.shape[0]
+        c = pkg.problems.column_norms(G)
+        with pkg.Ensemble(n, d, trace_capacity=16384) as ens:
+            ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
+            ens.set_target(pkg.GaussianTarget(G))
+            ens.set_state_synthetic(0.0, c, 4000 + first)  # seeds 4000 + global chain id
+            ens.run(T, pkg._lib.RUN_STOP_BEFORE)
+            sy, sy2 = ens.batch_means(0.0, T)
+            counts, gathered, sy, sy2 = par.gather_ensemble(ens, sy, sy2, staging="host")
+        if rank == 0:
+            out = []
+            for r_, t in enumerate(gathered):
+                ev = par.tensor_to_events(t, pkg._lib.EVENT_DTYPE)
+                off = 0
+                for cnt in counts[r_].tolist():
+                    out.append(ev[off:off + cnt].copy().tobytes())
+                    off += cnt
+            q.put((out, sy, sy2))
+        else:
+            q.put(None)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_gather_with_the_engine_producing_the_shards(gpu_pkg):
+    """tests/test_parallel_gloo.py with the ENGINE in the ranks: two processes, each with its own ensemble on the device (chains
+    [0,4) and [4,7), seeds 4000 + global chain id), exchange through parallel.gather_ensemble; rank 0 ends up with exactly the
+    traces and batch-mean sums of one process running all 7 chains, and every trace equals the oracle's."""
+    import torch.multiprocessing as mp
+    pkg = gpu_pkg
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_engine_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    traces, sy, sy2 = [r for r in res if r is not None][0]
+    G = pkg.problems.gmrf_precision(48)
+    d = G.shape[0]
+    c = pkg.problems.column_norms(G)
+    assert len(traces) == 7
+    with pkg.Ensemble(7, d, trace_capacity=16384) as ens:
+        ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
+        ens.set_target(pkg.GaussianTarget(G))
+        ens.set_state_synthetic(0.0, c, 4000)
+        ens.run(6.0, pkg._lib.RUN_STOP_BEFORE)
+        s1, s2 = ens.batch_means(0.0, 6.0)
+        cnt = ens.counters()
+        for k in range(7):
+            assert ens.trace(k, counters=cnt).tobytes() == traces[k], k
+    assert np.allclose(sy, s1, rtol=1e-13, atol=1e-15) and np.allclose(sy2, s2, rtol=1e-13, atol=1e-15)
+    for k in (0, 4, 6):  # first chain of each rank and the last one, against the oracle
+        x0, th0 = O.synthetic_state(4000 + k, d)
+        r = O.spdmp_zigzag(G, None, G, x0, th0, c, 6.0, seed=4000 + k, stop_before_T=True)
+        assert r["events"].tobytes() == traces[k]

@@ -32,6 +32,7 @@ class Ensemble:
         self.nchains, self.d = int(nchains), int(d)
         self.trace_capacity = int(trace_capacity)
         self.adapt = bool(adapt)
+        self.device = int(device)
         cfg = _lib.PdmpConfig(C.sizeof(_lib.PdmpConfig), int(device), int(sampler), int(bool(adapt)), float(factor),
                               self.nchains, self.d, self.trace_capacity)
         h = C.c_void_p()

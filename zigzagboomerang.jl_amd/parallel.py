@@ -90,3 +90,35 @@ def cuda_tensor_from_ptr(ptr, nbytes, device_index):
         __cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
 
     return torch.as_tensor(_Holder(), device=torch.device("cuda", device_index))
+
+
+def gather_ensemble(ens, sum_y=None, sum_y2=None, *, staging="device", dst=0, group=None):
+    """The whole post-run exchange of one rank's ensemble, straight from the engine's device memory:
+    all_gather of the per-chain event counts -> gatherv of the trace segments to `dst` (every peer sends over its own xGMI link) ->
+    reduce(SUM) of the batch-mean accumulators.  The segments are compacted on the device from a zero-copy view of the engine's
+    trace buffer (pdmp_ensemble_trace_dev); staging="host" moves them to host memory first (the gloo backend of the CPU tests and of
+    the several-ranks-on-one-GPU test).  Returns (counts_by_rank, gathered, sum_y, sum_y2); `gathered` is a list of [n_r, 4]
+    float64 tensors (raw 32-byte records) on dst, None elsewhere."""
+    import torch
+    cnt = ens.counters()
+    counts = torch.from_numpy(cnt["ntrace"].astype(np.int64))
+    cap = ens.trace_capacity
+    if cap > 0:
+        ptr, cap2 = ens.trace_dev()
+        assert cap2 == cap
+        raw = cuda_tensor_from_ptr(ptr, ens.nchains * cap * 32, ens.device).view(torch.float64).view(ens.nchains, cap, 4)
+        dcounts = counts.to(raw.device)
+        mask = torch.arange(cap, device=raw.device)[None, :] < dcounts[:, None]
+        seg = raw[mask]  # chain-major, event order inside a chain: the layout tensor_to_events / the counts describe
+    else:
+        seg = torch.empty((0, 4), dtype=torch.float64, device=torch.device("cuda", ens.device))
+        dcounts = counts.to(seg.device) * 0
+    if staging == "host":
+        seg, dcounts = seg.cpu(), dcounts.cpu()
+    counts_by_rank = all_gather_counts(dcounts, group)
+    gathered = gatherv_events(seg, counts_by_rank, dst, group)
+    if sum_y is not None:
+        ty, ty2 = torch.from_numpy(np.asarray(sum_y)).to(seg.device), torch.from_numpy(np.asarray(sum_y2)).to(seg.device)
+        reduce_moments(ty, ty2, dst, group)
+        sum_y, sum_y2 = ty.cpu().numpy(), ty2.cpu().numpy()
+    return counts_by_rank, gathered, sum_y, sum_y2
