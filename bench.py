@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""bench.py -- reflection events/s (+ ESS/s) of the local-ZigZag hot path on config C3.
+"""bench.py -- reflection events/s (+ ESS/s) of the local-ZigZag hot path on config C3 (default), and with --config C2|C4|C5 the same
+JSON line for BASELINE.json's other GPU configurations (their own metric, byte model and roofline object).
 
 Workload (BASELINE.json configs[2], the one `metric` is quoted on):
     Γ = 0.01 I + gridlaplacian(128,128)  (scripts/gridlaplace.jl:4-21, scripts/gaussianrandomfield.jl:15), d = 16384,
@@ -36,6 +37,48 @@ SEED0 = 0x5EED0000
 def algorithmic_bytes(num, nacc):
     """224 B per proposal + 48 B per rejection + 616 B per accepted reflection."""
     return 224.0 * num + 48.0 * (num - nacc) + 616.0 * nacc
+
+
+def source_hash():
+    """SHA-256 over the kernel sources and the shared headers: ties a PMC summary under profiles/ to the build it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "zigzagboomerang.jl_amd", "csrc")
+    for f in sorted(os.listdir(base)):
+        h.update(open(os.path.join(base, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "pdmp_detmath.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline_config(pkg, config, budget_s=12.0):
+    """Single-thread CPU oracle on ONE chain of the secondary configuration (kind="port"), bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    import scipy.sparse as sp
+    rng = np.random.default_rng(5)
+    t0 = time.perf_counter()
+    if config == "C2":
+        d = 1024
+        r = O.pdmp_bps(sp.identity(d, format="csc"), None, rng.standard_normal(d), rng.standard_normal(d), 1e-3, 40.0, lambda_ref=1.0,
+                       seed=SEED0, want_events=False)
+        ev, what = r["nevents"], "one BPS chain d=1024 to T=40"
+    elif config == "C4":
+        P = pkg.problems.logistic_problem(m=20)
+        lg = dict(A=P["A"], At=P["At"], y=P["y"], ny=P["ny"], mu=P["mu"], gamma0=P["gamma0"], k=10)
+        t0 = time.perf_counter()
+        r = O.spdmp_zigzag(P["Gdrop"], P["mu"], P["Gdrop"], P["x0"], P["sigma"] * rng.choice([-1.0, 1.0], P["p"]), P["c"], 60.0, seed=SEED0,
+                           adapt=True, factor=5.0, logistic=lg, want_trace=False)
+        ev, what = r["nacc"], "one chain of the subsampled logistic regression (n=8840, p=442) to T=60"
+    else:
+        P = pkg.problems.spike_slab_logistic_problem(p=10_000, num_rows=2000)
+        lg = dict(A=P["A"], At=P["At"], y=P["y"], ny=P["ny"], mu=P["mu"], gamma0=P["gamma0"], k=12)
+        x0, th0 = O.synthetic_state(SEED0, P["p"])
+        t0 = time.perf_counter()
+        r = O.sspdmp_zigzag(P["G"], P["mu"], P["G"], x0, th0, P["c"], P["kappa"], 1.0, seed=SEED0, adapt=True, factor=1.5, logistic=lg)
+        ev, what = len(r["events"]), "one sticky chain of the p=10000 logistic spike-and-slab to T=1"
+    secs = time.perf_counter() - t0
+    return {"value": ev / secs, "unit": "events/s", "cores": 1, "kind": "port", "sample": what + f" ({secs:.1f} s), single thread",
+            "host": host_cpu_limits()}
 
 
 def host_cpu_limits():
@@ -115,14 +158,112 @@ def cpu_baseline(pkg, G, c, budget_s=20.0):
             "host": lim, "thread_sweep": {str(k): v for k, v in sweep.items()}, "parallel_efficiency": eff}
 
 
+CONFIG_DEFAULTS = {"C3": dict(chains=4096, dt=1.0), "C2": dict(chains=4096, dt=30.0), "C4": dict(chains=8192, dt=2.0),
+                   "C5": dict(chains=4096, dt=0.005)}
+
+
+def make_workload(pkg, args, rank, local_rank):
+    """The ensemble of `--config` (C3 = the headline workload, default; C2 / C4 / C5 = BASELINE.json's other GPU configurations, each
+    with the same JSON schema and its own roofline object) plus what the generic timing loop needs to know about it."""
+    L = pkg._lib
+    nch, dt = args.chains, args.dt
+    seed0 = SEED0 + rank * nch
+    W = {"config": args.config, "trace_full_retry": True}
+    if args.config == "C3":
+        G = pkg.problems.gmrf_precision(args.grid)
+        d = G.shape[0]
+        c = pkg.problems.column_norms(G)
+        # events per chain per unit time ~0.8 d (SURVEY 8d3); 2x head-room, recycled every step
+        cap = 0 if args.no_trace else int(2.0 * d * dt) + 1024
+        ens = pkg.Ensemble(nch, d, device=local_rank, trace_capacity=cap)
+        ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
+        ens.set_target(pkg.GaussianTarget(G))
+        ens.set_state_synthetic(0.0, c, seed0)
+        W.update(G=G, c=c, d=d, cap=cap, ens=ens, kernel="zz_local_spec8_kernel", unit="reflection events/s",
+                 metric="reflection events/sec, d=16384 local ZigZag (spdmp), ensemble of independent chains",
+                 workload=f"C3: local ZigZag spdmp on Gamma=0.01I+gridlaplacian({args.grid},{args.grid}), d={d}, {nch} chains/GPU, "
+                          f"step = advance all chains by dT={dt}, traces {'off' if args.no_trace else 'on (32 B/event)'}",
+                 model="224*num + 48*(num-nacc) + 616*nacc bytes (SURVEY 8d3)",
+                 bytes=lambda w: algorithmic_bytes(w["num"], w["nacc"]))
+    elif args.config == "C2":
+        import scipy.sparse as sp
+        d = 1024
+        cap = 512  # events per chain per launch: 512 x 16 392 B x 4096 chains = 34 GB of HBM (a step of dT = 30 is ~410 events)
+        rng = np.random.default_rng(1000 + rank)
+        ens = pkg.Ensemble(nch, d, sampler=L.SAMPLER_BPS, factor=2.0, device=local_rank, trace_capacity=cap)
+        ens.set_flow_bps(pkg.BouncyParticle(sp.identity(d, format="csc"), np.zeros(d), 1.0))
+        ens.set_state_bps(0.0, rng.standard_normal((nch, d)), rng.standard_normal((nch, d)), 1e-3,
+                          np.arange(nch, dtype=np.uint64) + np.uint64(seed0))
+        W.update(d=d, cap=cap, ens=ens, kernel="bps_run_kernel", unit="events/s",
+                 metric="trace events/sec (reflections + refreshments), Bouncy Particle d=1024 isotropic Gaussian, ensemble of independent chains",
+                 workload=f"C2: BouncyParticle(I, 0, lambda_ref=1), c=1e-3 (scripts/not_fact.jl:23-28), d={d}, {nch} chains/GPU, step = advance "
+                          f"all chains by dT={dt}, full PDMPTrace records (t, copy(x), copy(theta)) = {8 * (2 * d + 1)} B per event",
+                 model="8(2d+1) bytes WRITTEN per event, 0 read: x, theta, grad live in registers (SURVEY 8d3)",
+                 bytes=lambda w: 8.0 * (2 * d + 1) * w["nevents"])
+    elif args.config == "C4":
+        P = pkg.problems.logistic_problem(m=20)
+        d = P["p"]
+        ksub = 10
+        cap = 0 if args.no_trace else int(600 * dt) + 512
+        rng = np.random.default_rng(2000 + rank)
+        ens = pkg.Ensemble(nch, d, adapt=True, factor=5.0, device=local_rank, trace_capacity=cap)
+        ens.set_flow(pkg.ZigZag(P["Gdrop"], P["mu"], P["sigma"]))
+        ens.set_target(pkg.LogisticTarget(P["A"], P["y"], P["ny"], P["mu"], P["gamma0"], ksub))
+        ens.set_state(0.0, np.tile(P["x0"], (nch, 1)), P["sigma"] * rng.choice([-1.0, 1.0], (nch, d)), P["c"],
+                      np.arange(nch, dtype=np.uint64) + np.uint64(seed0))
+        # neighbourhood sizes of the bounding graph and row lengths of the design, as plain averages over coordinates / observations
+        G = P["Gdrop"]
+        kbar = float(np.diff(G.indptr).mean())
+        B = (abs(G) > 0).astype(np.int64)
+        g2 = (B @ B)
+        g2bar = float((np.diff(g2.tocsc().indptr) - np.diff(G.indptr)).mean())
+        rbar = float(np.diff(P["At"].indptr).mean())
+        per_prop = kbar * 40 + 24 + ksub * rbar * 40
+        per_rej = 48.0
+        per_acc = g2bar * 40 + 8 + kbar * (8 + 16 + 8) + kbar * 16 + 16 + 32
+        W.update(d=d, cap=cap, ens=ens, kernel="zz_general_run_kernel", unit="reflection events/s",
+                 metric="reflection events/sec, subsampled sparse logistic regression n=8840 p=442 (local ZigZag), ensemble of independent chains",
+                 workload=f"C4: spdmp with grad-phi-moving (k={ksub} subsample, SelfMoving, control variate at the mode), Zdrop bounds, c=0.01, adapt, "
+                          f"factor 5 (scripts/logistic.jl:167), n={P['n']}, p={d}, {nch} chains/GPU (one GPU's share of 65 536), step = advance "
+                          f"all chains by dT={dt}",
+                 model=f"per proposal k*40+24 + ksub*r*40 = {per_prop:.0f} B (k={kbar:.2f} neighbours, r={rbar:.2f} regressors per observation), "
+                       f"+48 B per rejection, +{per_acc:.0f} B per accepted reflection (|G2|={g2bar:.1f}): SURVEY 8d3's model with this graph",
+                 bytes=lambda w: per_prop * w["num"] + per_rej * (w["num"] - w["nacc"]) + per_acc * w["nacc"])
+    elif args.config == "C5":
+        P = pkg.problems.spike_slab_logistic_problem(p=10_000, num_rows=2000)
+        d = P["p"]
+        ksub = 12
+        cap = 0 if args.no_trace else int(30000 * dt) + 1024
+        ens = pkg.Ensemble(nch, d, sampler=L.SAMPLER_STICKY_ZIGZAG, adapt=True, factor=1.5, device=local_rank, trace_capacity=cap)
+        ens.set_flow(pkg.ZigZag(P["G"], P["mu"], P["sigma"]))
+        ens.set_target(pkg.LogisticTarget(P["A"], P["y"], P["ny"], P["mu"], P["gamma0"], ksub))
+        ens.set_sticky(P["kappa"])
+        ens.set_state_synthetic(0.0, P["c"], seed0)
+        rbar = float(np.diff(P["At"].indptr).mean())
+        per_grad = ksub * rbar * 40 + 40 + 24
+        W.update(d=d, cap=cap, ens=ens, kernel="zz_general_run_kernel", unit="events/s", ksub=ksub,
+                 metric="trace events/sec (reflections + freezes + thaws), sticky ZigZag on the logistic spike-and-slab p=10000, ensemble of independent chains",
+                 workload=f"C5: sspdmp with grad-phi-moving (k={ksub}, SelfMoving) on example_design_matrix scaled to p={d} columns x {P['n']} rows "
+                          f"(scripts/exampledesign.jl), Gaussian slab gamma0={P['gamma0']}, kappa=(gamma0/sqrt(2pi))/(1/w-1) w={P['w']}, Z=ZigZag(I,mu), "
+                          f"c=1, adapt (scripts/spikeandslab.jl:96-129), {nch} chains/GPU, step = advance all chains by dT={dt}",
+                 model=f"per gradient evaluation ksub*r*40 + 64 = {per_grad:.0f} B (r={rbar:.0f} coefficients per sampled observation, each moved: "
+                       f"24 B read + 16 B written), + 96 B per trace event (record, bound, key, thaw clock)",
+                 bytes=lambda w: per_grad * w["grads"] + 96.0 * w["nevents"])
+    else:
+        raise SystemExit(f"unknown --config {args.config}")
+    return W
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="C3", choices=sorted(CONFIG_DEFAULTS),
+                    help="C3 (default): the headline workload; C2 / C4 / C5: the other GPU configurations of BASELINE.json")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--chains", type=int, default=CHAINS_PER_GPU, help="chains per GPU")
+    ap.add_argument("--chains", type=int, default=None, help="chains per GPU (default: the configuration's)")
     ap.add_argument("--grid", type=int, default=GRID)
-    ap.add_argument("--dt", type=float, default=DT_STEP)
+    ap.add_argument("--dt", type=float, default=None, help="process time per step (default: the configuration's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ess-batches", type=int, default=32, help="B: batches per chain of the ESS run after the timed region (0: skip)")
     ap.add_argument("--ess-batch-len", type=float, default=2.0, help="b: length of an ESS batch in process time")
@@ -132,6 +273,14 @@ def main():
                          "trace segments to rank 0 -> reduce of the batch-mean sums); printed as a separate `gather` object")
     ap.add_argument("--per-rank", action="store_true", help="add per-rank counters and chain-0 digests to the JSON line (tests)")
     args = ap.parse_args()
+    if args.chains is None:
+        args.chains = CONFIG_DEFAULTS[args.config]["chains"]
+    if args.dt is None:
+        args.dt = CONFIG_DEFAULTS[args.config]["dt"]
+    if args.config != "C3":
+        args.ess_batches = 0  # path integrals / the trace exchange are wired to the headline workload
+        if args.gather:
+            raise SystemExit("--gather is implemented for the headline workload (--config C3)")
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -172,16 +321,9 @@ def main():
     pkg.build.build()
     if pkg._lib.device_count() < 1:
         raise SystemExit("bench.py: no gfx950 device visible; the engine has no CPU fallback")
-    G = pkg.problems.gmrf_precision(args.grid)
-    d = G.shape[0]
-    c = pkg.problems.column_norms(G)
-    nch = args.chains
-    # events per chain per unit time ~0.8 d; 2x head-room, recycled every step
-    cap = 0 if args.no_trace else int(2.0 * d * args.dt) + 1024
-    ens = pkg.Ensemble(nch, d, device=local_rank, trace_capacity=cap)
-    ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
-    ens.set_target(pkg.GaussianTarget(G))
-    ens.set_state_synthetic(0.0, c, SEED0 + rank * nch)
+    W = make_workload(pkg, args, rank, local_rank)
+    ens, d, cap, nch = W["ens"], W["d"], W["cap"], args.chains
+    G, c = W.get("G"), W.get("c")
 
     def barrier():
         ens.sync()
@@ -191,34 +333,49 @@ def main():
                 import torch
                 torch.cuda.synchronize()
 
+    launches = [0]
+
     def step(k):
         T = (k + 1) * args.dt
-        ens.run(T, pkg._lib.RUN_STOP_BEFORE, sync=False)
-        ms = ens.last_run_ms()  # HIP events on the launch stream; also waits for the kernel
-        if cap:
-            ens.trace_reset()
-        return ms
+        ms = 0.0
+        while True:
+            ens.run(T, pkg._lib.RUN_STOP_BEFORE, sync=False)
+            ms += ens.last_run_ms()  # HIP events on the launch stream; also waits for the kernel
+            launches[0] += 1
+            full = False
+            if cap:
+                if args.config != "C3":  # a chain whose segment filled up pauses with TRACE_FULL: drain and continue the slice
+                    full = bool(np.any(ens.counters()["status"] == pkg._lib.CHAIN_TRACE_FULL))
+                ens.trace_reset()
+            if not full:
+                return ms
 
-    tot_prev = None
+    def work_counters():
+        cn = ens.counters()
+        # sticky chains reset (acc, num) whenever a bound is adapted (src/ss_fact.jl:134): gradient evaluations are counted by the
+        # draws of the subsampling stream instead (ksub per evaluation)
+        return {"num": int(cn["num"].sum()), "nacc": int(cn["nacc"].sum()), "nevents": int(cn["nevents"].sum()),
+                "grads": int(cn["ndraw_global"].sum()) // W.get("ksub", 1)}
+
     for k in range(args.warmup):
         step(k)
     barrier()
-    tot0 = ens.totals()
+    w0 = work_counters()
+    launches[0] = 0
     kernel_ms = []
-    sum_y = np.zeros(d)
-    sum_y2 = np.zeros(d)
     t_start = time.perf_counter()
     for k in range(args.warmup, args.warmup + args.steps):
         kernel_ms.append(step(k))
     barrier()
     elapsed = time.perf_counter() - t_start
-    tot1 = ens.totals()
+    w1 = work_counters()
     cnt = ens.counters()
     bad = int(np.count_nonzero(cnt["status"] != pkg._lib.CHAIN_OK))
 
-    num = tot1["num"] - tot0["num"]
-    nacc = tot1["nacc"] - tot0["nacc"]
-    nev = tot1["nevents"] - tot0["nevents"]
+    work = {key: w1[key] - w0[key] for key in w0}
+    num, nacc, nev = work["num"], work["nacc"], work["nevents"]
+    if args.config == "C5":
+        num = work["grads"]
 
     # ESS/s: batch means INSIDE each chain over one long run after the timed region (which serves as burn-in):
     # B = 32 batches of length b, sigma2_asym = b * pooled within-chain variance of the batch means,
@@ -317,21 +474,30 @@ def main():
             per_rank = [mine]
 
     if rank == 0:
-        k_ms = float(np.mean(kernel_ms))
-        bytes_launch = algorithmic_bytes(num, nacc) / args.steps
+        # per kernel LAUNCH (a step of C2 / C4 / C5 is several launches when trace segments fill up)
+        nlaunch = max(launches[0], 1)
+        k_ms = float(np.sum(kernel_ms)) / nlaunch
+        bytes_launch = W["bytes"](work) / nlaunch
         achieved = bytes_launch / (k_ms * 1e-3) / 1e9
+        # HBM traffic per launch from the PMC passes of THIS build (tools/profile_round.sh writes profiles/traffic.json with the hash of
+        # the kernel sources; a stale file is ignored rather than quoted)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_per_proposal.json")
+        traffic_src = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             tp = json.load(open(tpath))
-            traffic = tp["hbm_bytes_per_proposal"] * (num / args.steps)
+            ent = tp.get("configs", {}).get(args.config)
+            if ent and tp.get("source_hash") == source_hash():
+                units = {"proposal": num, "event": nev}[ent["per"]]
+                traffic = ent["hbm_bytes_per_unit"] * units / nlaunch
+                traffic_src = ent.get("source")
         # the measured ceiling for scattered 32-byte sectors (tools/sector_probe.py): what the traffic above can at most run at
         spath = os.path.join(ROOT, "profiles", "r01_sector_probe.json")
-        scattered = json.load(open(spath)) if os.path.exists(spath) else None
+        scattered = json.load(open(spath)) if (os.path.exists(spath) and args.config == "C3") else None
         out = {
-            "metric": "reflection events/sec, d=16384 local ZigZag (spdmp), ensemble of independent chains",
+            "metric": W["metric"],
             "value": nev_all / elapsed,
-            "unit": "reflection events/s",
+            "unit": W["unit"],
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -341,22 +507,20 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"C3: local ZigZag spdmp on Gamma=0.01I+gridlaplacian({args.grid},{args.grid}), d={d}, "
-                                   f"{nch} chains/GPU, step = advance all chains by dT={args.dt}, traces "
-                                   f"{'off' if args.no_trace else 'on (32 B/event)'}",
+            "config": {"workload": W["workload"],
                        "chains_per_gpu": nch, "d": d, "dT": args.dt, "parallelism": f"chains sharded x{world}, no collective in the run"},
             "proposals_per_s": num_all / elapsed,
             "acceptance": nacc_all / max(num_all, 1.0),
             "unhealthy_chains": bad_all,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "zz_local_spec8_kernel", "kernel_ms_avg": k_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": W["kernel"], "kernel_ms_avg": k_ms, "launches_per_step": nlaunch / args.steps,
                          "traffic_GBps": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
                          "scattered_sector_ceiling_GBps": ({"read": scattered["read_GBps"],
                                                             "read+writeback": scattered["read_plus_writeback_GBps"]}
                                                            if scattered else None),
                          "algorithmic_bytes_per_launch": bytes_launch,
-                         "model": "224*num + 48*(num-nacc) + 616*nacc bytes (SURVEY 8d3)"},
+                         "model": W["model"]},
         }
         out["totals"] = {"num": num_all, "nacc": nacc_all, "nevents": nev_all, "T_end": (args.warmup + args.steps) * args.dt}
         if per_rank is not None:
@@ -366,7 +530,7 @@ def main():
         if ess is not None:
             out["ess"] = ess
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pkg, G, c)
+            out["cpu_baseline"] = cpu_baseline(pkg, G, c) if args.config == "C3" else cpu_baseline_config(pkg, args.config)
         print(json.dumps(out), flush=True)
     ens.close()
     if dist is not None:

@@ -1,0 +1,30 @@
+#!/bin/bash
+# Everything the round's profiles/ files are made from, in one GPU session:  tools/profile_round.sh <tag> [configs...]
+#   per configuration: bench.py's JSON line, rocprofv3 --kernel-trace --stats of the same command, and the L2<->fabric request counters / WRITE_SIZE in
+#   SEPARATE --pmc passes (never combined with other trace domains); for C3 also the SQ passes; once: the PMC calibration on the
+#   sector probe (a kernel whose HBM bytes are known exactly).  Raw output under gpurun_out/<tag>/, summaries are made by
+#   tools/profile_collect.py (run here, copied into profiles/ by the caller).
+set -u
+TAG=$1; shift
+CONFIGS=${@:-C3 C2 C4 C5}
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd /tmp
+for C in $CONFIGS; do
+  case $C in C3) ST=8;; C2) ST=8;; C4) ST=6;; C5) ST=4;; esac
+  ARGS="--config $C --steps $ST --warmup 2 --no-cpu-baseline --ess-batches 0"
+  python $ROOT/bench.py $ARGS 2>/dev/null | grep '^{' > "$OUT/${C}_bench.json"
+  timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/${C}_stats" -o st --output-format csv -- python $ROOT/bench.py $ARGS > "$OUT/${C}_stats.log" 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum -d "$OUT/${C}_pmc" -o fetch --output-format csv -- python $ROOT/bench.py $ARGS > "$OUT/${C}_fetch.log" 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d "$OUT/${C}_pmc" -o write --output-format csv -- python $ROOT/bench.py $ARGS > "$OUT/${C}_write.log" 2>&1
+  if [ "$C" = C3 ]; then
+    timeout 900 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d "$OUT/${C}_pmc" -o sq1 --output-format csv -- python $ROOT/bench.py $ARGS > "$OUT/${C}_sq1.log" 2>&1
+    timeout 900 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT -d "$OUT/${C}_pmc" -o sq2 --output-format csv -- python $ROOT/bench.py $ARGS > "$OUT/${C}_sq2.log" 2>&1
+  fi
+done
+# calibration: the request-size counters against exactly known bytes in the event loop's own access patterns
+$ROOT/tools/pmc_reqsize_cal.sh "$OUT/cal" > "$OUT/cal.jsonl" 2>"$OUT/cal.log"
+python $ROOT/tools/profile_collect.py "$OUT" "$TAG"
+ls "$OUT"
