@@ -178,8 +178,12 @@ def make_workload(pkg, args, rank, local_rank):
         ens = pkg.Ensemble(nch, d, device=local_rank, trace_capacity=cap)
         ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
         ens.set_target(pkg.GaussianTarget(G))
+        if not args.exact:
+            ens.set_gradient_tracking(True)
         ens.set_state_synthetic(0.0, c, seed0)
-        W.update(G=G, c=c, d=d, cap=cap, ens=ens, kernel="zz_local_spec8_kernel", unit="reflection events/s",
+        W.update(G=G, c=c, d=d, cap=cap, ens=ens, kernel="zz_local_spec8_kernel" if args.exact else "zz_local_track_kernel",
+                 unit="reflection events/s", evaluation="moving (bit-identical to the oracle)" if args.exact else
+                 "tracked gradients (index sequence identical, floats to 1e-9: tests/test_gpu_track_parity.py)",
                  metric="reflection events/sec, d=16384 local ZigZag (spdmp), ensemble of independent chains",
                  workload=f"C3: local ZigZag spdmp on Gamma=0.01I+gridlaplacian({args.grid},{args.grid}), d={d}, {nch} chains/GPU, "
                           f"step = advance all chains by dT={dt}, traces {'off' if args.no_trace else 'on (32 B/event)'}",
@@ -272,6 +276,8 @@ def main():
                     help="after the timed region: one more step, then time the post-run exchange (all_gather counts -> gatherv of the "
                          "trace segments to rank 0 -> reduce of the batch-mean sums); printed as a separate `gather` object")
     ap.add_argument("--per-rank", action="store_true", help="add per-rank counters and chain-0 digests to the JSON line (tests)")
+    ap.add_argument("--exact", action="store_true",
+                    help="C3: the bit-identical moving evaluation (zz_local_spec8_kernel) instead of the tracked-gradient one")
     args = ap.parse_args()
     if args.chains is None:
         args.chains = CONFIG_DEFAULTS[args.config]["chains"]
@@ -507,7 +513,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": W["workload"],
+            "config": {"workload": W["workload"] + (f"; evaluation: {W['evaluation']}" if "evaluation" in W else ""),
                        "chains_per_gpu": nch, "d": d, "dT": args.dt, "parallelism": f"chains sharded x{world}, no collective in the run"},
             "proposals_per_s": num_all / elapsed,
             "acceptance": nacc_all / max(num_all, 1.0),

@@ -236,6 +236,21 @@ pdmp_status pdmp_ensemble_set_sticky(pdmp_ensemble* ens, const double* kappa, in
 pdmp_status pdmp_ensemble_set_adaptscale(pdmp_ensemble* ens, int enable);
 pdmp_status pdmp_ensemble_final_sigma(pdmp_ensemble* ens, int64_t chain_first, int64_t n, double* sigma);
 
+/* ------------------------------------------------------------------ tracked gradients (an evaluation strategy, not a sampler)
+ *
+ * enable = 1: the local ZigZag loop keeps, per coordinate, g_i = Γ[:,i]·x and gd_i = Γ[:,i]·θ instead of moving G[i] and gathering them at
+ * every proposal (src/sfact.jl:82,116): a proposal then touches its own record only and an accepted reflection its G1 neighbours
+ * -- about half the HBM traffic of the moving evaluation.  Same process, same draws, same thinning decisions: the event INDEX sequence,
+ * accept / reject outcomes, (acc, num) and adapted bounds equal the reference's exactly; event times, positions and the final
+ * (t, x, θ) agree to ~1e-13 relative instead of bit for bit, because sums that are advanced are not rounded like sums that are
+ * recomputed (tests/test_gpu_track_parity.py: 1e-9; the default, enable = 0, stays bit-identical).  pdmp_ensemble_final_state rebuilds
+ * the reference's lazy clocks t[j] (src/sfact.jl:211) from the times of the last proposal / accept around j.
+ * Requirements (else set_state returns PDMP_ERR_UNSUPPORTED -- never a silent fall-back): PDMP_SAMPLER_ZIGZAG_LOCAL, ZigZag flow
+ * without refresh, Gaussian target, symmetric Γ, lattice-like neighbourhoods (|G1| <= 5, |S| <= 13) and 2048 <= d <= 16384.
+ * Call before set_state.
+ */
+pdmp_status pdmp_ensemble_set_gradient_tracking(pdmp_ensemble* ens, int enable);
+
 /* ------------------------------------------------------------------ c::LocalBound (src/local.jl)
  *
  * spdmp(∇ϕ, t0, x0, θ0, T, C::LocalBound, F::ZigZag, args...) (src/local.jl:95-149): the bound of coordinate j is built from the

@@ -1,0 +1,157 @@
+"""Tracked-gradient evaluation of the local ZigZag (pdmp_ensemble_set_gradient_tracking, zz_local_track_kernel) against the oracle
+(-m gpu): the event INDEX sequence, accept / reject outcomes, counters and adapted bounds are exact; event times, positions and the final
+state agree to 1e-9 relative (measured: ~1e-13; north star: 1e-6) -- sums that are advanced are not rounded like sums recomputed."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+def close(a, b, tol=TOL):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return a.shape == b.shape and bool(np.all(np.abs(a - b) <= tol * np.maximum(1.0, np.maximum(np.abs(a), np.abs(b)))))
+
+
+def check_chain(ev, fs_t, fs_x, fs_th, acc, num, cout, r):
+    oe = r["events"]
+    assert len(ev) == len(oe), (len(ev), len(oe))
+    assert np.array_equal(ev["i"], oe["i"])                     # index / reflection bookkeeping: exact
+    assert np.array_equal(ev["theta"], oe["theta"])             # velocities are ±θ0: exact
+    assert close(ev["t"], oe["t"]) and close(ev["x"], oe["x"])
+    assert int(num) == r["num"] and np.array_equal(acc, r["acc"])
+    assert np.array_equal(fs_th, r["theta"]) and close(fs_t, r["t"]) and close(fs_x, r["x"])
+    if cout is not None:
+        assert np.array_equal(cout, r["c"])
+
+
+@pytest.mark.parametrize("n,T", [(48, 12.0), (64, 6.0), (47, 5.0)])
+def test_tracked_matches_oracle_on_lattices(gpu_pkg, n, T):
+    """The north-star workload's relatives (n x n grid-Laplace GMRFs; 47 is odd: border templates everywhere), bound Γ == target Γ."""
+    pkg = gpu_pkg
+    G = pkg.problems.gmrf_precision(n)
+    d = n * n
+    rng = np.random.default_rng(n)
+    nch = 3
+    x0 = rng.standard_normal((nch, d))
+    th0 = rng.choice([-1.0, 1.0], (nch, d))
+    c = pkg.problems.column_norms(G)
+    tr, (t, x, th), (acc, num), _ = pkg.spdmp(pkg.GaussianTarget(G), 0.0, x0, th0, T, c, pkg.ZigZag(G, np.zeros(d)), seed=700 + n, tracked=True)
+    dev_t = 0.0
+    for k in range(nch):
+        r = O.spdmp_zigzag(G, None, G, x0[k], th0[k], c, T, seed=700 + n + k)
+        assert r["status"] == 0 and len(r["events"]) > 1000
+        check_chain(tr[k].events, t[k], x[k], th[k], acc[k], num[k], None, r)
+        dev_t = max(dev_t, float(np.max(np.abs(tr[k].events["t"] - r["events"]["t"]))))
+    assert dev_t < 1e-11  # what is actually observed: a few 1e-14
+
+
+def test_tracked_with_looser_bound_mean_and_adapt(gpu_pkg):
+    """The FULL instantiation: bounding Γ = 0.9 Γ (test/maintest.jl:23: two pairs of tracked sums), a target mean, and adapt with bounds
+    that start too small (c is multiplied by `factor` on violations, src/fact_samplers.jl:67-70): adapted bounds equal the oracle's."""
+    pkg = gpu_pkg
+    n = 50
+    G = pkg.problems.gmrf_precision(n)
+    d = n * n
+    rng = np.random.default_rng(5)
+    mu = 0.3 * rng.standard_normal(d)
+    nch, T = 2, 6.0
+    x0 = rng.standard_normal((nch, d))
+    th0 = rng.choice([-1.0, 1.0], (nch, d))
+    c = 0.2 * pkg.problems.column_norms(G)
+    Z = pkg.ZigZag(sp.csc_matrix(0.9 * G), mu)
+    tr, (t, x, th), (acc, num), cout = pkg.spdmp(pkg.GaussianTarget(G, mu), 0.0, x0, th0, T, c, Z, seed=31, adapt=True, factor=1.8, tracked=True)
+    for k in range(nch):
+        r = O.spdmp_zigzag(0.9 * G, mu, G, x0[k], th0[k], c, T, seed=31 + k, target_mu=mu, adapt=True, factor=1.8)
+        assert r["status"] == 0 and r["c"].max() > c.max()
+        check_chain(tr[k].events, t[k], x[k], th[k], acc[k], num[k], cout[k], r)
+
+
+def test_tracked_slices_trace_refills_and_violation(gpu_pkg):
+    """Slices with PDMP_RUN_STOP_BEFORE, a trace buffer that fills up several times, the reference tail (last event at t′ >= T), path
+    integrals (batch means) against the host integral of the trace, and a bound violation without adapt (status, not a crash)."""
+    pkg = gpu_pkg
+    L = pkg._lib
+    n = 48
+    G = pkg.problems.gmrf_precision(n)
+    d = n * n
+    c = pkg.problems.column_norms(G)
+    nch = 2
+    with pkg.Ensemble(nch, d, trace_capacity=3000) as ens:
+        ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
+        ens.set_target(pkg.GaussianTarget(G))
+        ens.set_gradient_tracking(True)
+        ens.set_state_synthetic(0.0, c, 4242)
+        evs = [[] for _ in range(nch)]
+        for Tk, flag in ((1.7, L.RUN_STOP_BEFORE), (4.0, L.RUN_STOP_BEFORE), (6.5, L.RUN_REFERENCE_TAIL)):
+            while True:
+                ens.run(Tk, flag)
+                cnt = ens.counters()
+                for k in range(nch):
+                    evs[k].append(ens.trace(k, counters=cnt))
+                ens.trace_reset()
+                if not np.any(cnt["status"] == L.CHAIN_TRACE_FULL):
+                    break
+            if Tk == 4.0:
+                s1, s2 = ens.batch_means(0.0, 4.0)
+        fs = ens.final_state()
+        cnt = ens.counters()
+    ys = []
+    for k in range(nch):
+        x0, th0 = O.synthetic_state(4242 + k, d)
+        r = O.spdmp_zigzag(G, None, G, x0, th0, c, 6.5, seed=4242 + k)
+        ev = np.concatenate(evs[k])
+        check_chain(ev, fs["t"][k], fs["x"][k], fs["theta"][k], fs["acc"][k], cnt["num"][k], None, r)
+        assert ev["t"][-1] >= 6.5
+        ys.append(pkg.trace.moments(pkg.FactTrace(None, 0.0, x0, th0, r["events"]), 4.0)[0])
+    assert np.allclose(s1, np.sum(ys, axis=0), rtol=1e-9, atol=1e-11) and np.allclose(s2, np.sum(np.square(ys), axis=0), rtol=1e-9, atol=1e-11)
+    # a bounding Γ below the target's with a tiny c, adapt off: the reference throws (src/sfact.jl:124); here the chains stop with
+    # BOUND_VIOLATED exactly where the oracle stops
+    rng = np.random.default_rng(1)
+    x0 = 3 * rng.standard_normal((2, d))
+    th0 = rng.choice([-1.0, 1.0], (2, d))
+    Gb = sp.csc_matrix(0.3 * G)
+    cs = np.full(d, 1e-6)
+    with pytest.raises(RuntimeError, match="Tuning parameter `c` too small"):
+        pkg.spdmp(pkg.GaussianTarget(G), 0.0, x0, th0, 5.0, cs, pkg.ZigZag(Gb, np.zeros(d)), seed=3, tracked=True)
+    with pkg.Ensemble(2, d, trace_capacity=4096) as ens:
+        ens.set_flow(pkg.ZigZag(Gb, np.zeros(d)))
+        ens.set_target(pkg.GaussianTarget(G))
+        ens.set_gradient_tracking(True)
+        ens.set_state(0.0, x0, th0, cs, np.array([3, 4], dtype=np.uint64))
+        ens.run(5.0)
+        cnt = ens.counters()
+        for k in range(2):
+            r = O.spdmp_zigzag(Gb, None, G, x0[k], th0[k], cs, 5.0, seed=3 + k)
+            assert r["status"] == O.ORC_BOUND_VIOLATED and cnt["status"][k] == L.CHAIN_BOUND_VIOLATED
+            assert int(cnt["num"][k]) == r["num"] and int(cnt["nacc"][k]) == r["nacc"]
+            ev = ens.trace(k, counters=cnt)
+            assert np.array_equal(ev["i"], r["events"]["i"]) and close(ev["t"], r["events"]["t"])
+
+
+def test_tracking_is_refused_where_it_does_not_apply(gpu_pkg):
+    """Opt-in means no silent fall-back: graphs outside the lattice geometry, a refresh clock or the sticky sampler return
+    PDMP_ERR_UNSUPPORTED at set_state."""
+    pkg = gpu_pkg
+    L = pkg._lib
+    G = pkg.problems.maintest_precision(8)
+    with pkg.Ensemble(1, 8) as ens:
+        ens.set_flow(pkg.ZigZag(G, np.zeros(8)))
+        ens.set_target(pkg.GaussianTarget(G))
+        ens.set_gradient_tracking(True)
+        with pytest.raises(L.PdmpError) as ei:
+            ens.set_state_synthetic(0.0, np.ones(8), 1)
+        assert ei.value.code == L.PDMP_ERR_UNSUPPORTED
+        ens.set_gradient_tracking(False)
+        ens.set_state_synthetic(0.0, 2 * pkg.problems.column_norms(G), 1)
+    Gl = pkg.problems.gmrf_precision(48)
+    with pkg.Ensemble(1, 48 * 48) as ens:
+        ens.set_flow(pkg.ZigZag(Gl, np.zeros(48 * 48), λref=0.1))
+        ens.set_target(pkg.GaussianTarget(Gl))
+        ens.set_gradient_tracking(True)
+        with pytest.raises(L.PdmpError) as ei:
+            ens.set_state_synthetic(0.0, pkg.problems.column_norms(Gl), 1)
+        assert ei.value.code == L.PDMP_ERR_UNSUPPORTED

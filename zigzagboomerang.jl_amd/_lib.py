@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = [
     "pdmp_ensemble_set_flow_bps", "pdmp_ensemble_set_state_bps", "pdmp_ensemble_bps_trace_copy",
     "pdmp_ensemble_bps_final_state", "pdmp_ensemble_set_sticky", "pdmp_ensemble_set_adaptscale", "pdmp_ensemble_final_sigma", "pdmp_ensemble_set_flow_boomerang", "pdmp_ensemble_set_local_bound", "pdmp_ensemble_set_target_logistic", "pdmp_ensemble_set_flow_factboomerang",
     "pdmp_ensemble_set_mass_cholesky", "pdmp_ensemble_set_bps_options",
-    "pdmp_ensemble_ess_begin", "pdmp_ensemble_ess_batch", "pdmp_ensemble_ess_end",
+    "pdmp_ensemble_ess_begin", "pdmp_ensemble_ess_batch", "pdmp_ensemble_ess_end", "pdmp_ensemble_set_gradient_tracking",
 ]
 # include/pdmp_debug.h: diagnostics, not part of the drop-in boundary
 DEBUG_SYMBOLS = ["pdmp_debug_set_kernel", "pdmp_debug_set_spec_g2", "pdmp_debug_set_phase_profile", "pdmp_debug_phase_profile",
@@ -104,6 +104,7 @@ def load():
     L.pdmp_ensemble_set_sticky.argtypes = [vp, vp, C.c_int, C.c_int]
     L.pdmp_ensemble_set_adaptscale.argtypes = [vp, C.c_int]
     L.pdmp_ensemble_set_local_bound.argtypes = [vp, C.c_int]
+    L.pdmp_ensemble_set_gradient_tracking.argtypes = [vp, C.c_int]
     L.pdmp_ensemble_final_sigma.argtypes = [vp, i64, i64, vp]
     L.pdmp_ensemble_set_flow_bps.argtypes = [vp, vp, vp, vp, vp, f64, f64]
     L.pdmp_ensemble_set_flow_boomerang.argtypes = [vp, vp, vp, vp, vp, vp, f64, f64]

@@ -111,6 +111,9 @@ struct pdmp_ensemble {
     double dbg_phase_out[16] = {0};
     int dbg_phase_valid = 0;
     int64_t dbg_dump = 0;          // dump the first n proposals of chain 0 (one-event kernel) to stderr
+    // tracked-gradient kernel (pdmp_ensemble_set_gradient_tracking)
+    bool track_requested = false, track = false, track_two_sums = false;
+    double t0_state = 0.0;
     DevBuf<double> d_jstart, d_essacc;  // pdmp_ensemble_ess_*
     double ess_T0 = 0.0, ess_Tlast = 0.0;
     int64_t ess_batches = -1;  // -1: no ess_begin yet
@@ -741,7 +744,8 @@ extern "C" {
 static pdmp_status alloc_state(pdmp_ensemble* e) {
     const int64_t d = e->cfg.d, n = e->cfg.nchains;
     pdmp_status st;
-    if (e->d_rec.n != (size_t)(n * d) && (st = e->d_rec.alloc((size_t)(n * d))) != PDMP_OK) return st;
+    const size_t nrec = (size_t)(n * d) * (e->track ? 2 : 1);  // TrRec is two ZzRec long
+    if (e->d_rec.n != nrec && (st = e->d_rec.alloc(nrec)) != PDMP_OK) return st;
     if (e->d_keys.n != (size_t)(n * e->dk) && (st = e->d_keys.alloc((size_t)(n * e->dk))) != PDMP_OK) return st;
     if (e->d_hdr.n != (size_t)n && (st = e->d_hdr.alloc((size_t)n)) != PDMP_OK) return st;
     if (e->cfg.adapt && e->d_c_chain.n != (size_t)(n * d) && (st = e->d_c_chain.alloc((size_t)(n * d))) != PDMP_OK)
@@ -761,6 +765,32 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
     if (!c) return fail(PDMP_ERR_INVALID, "c is required");
     HIP_TRY(hipSetDevice(e->cfg.device));
     const int64_t d = e->cfg.d, n = e->cfg.nchains;
+    e->track = false;
+    if (e->track_requested) {
+        // opt-in, so never a silent fall-back: everything the tracked-gradient kernel needs is checked here
+        if (e->cfg.sampler != PDMP_SAMPLER_ZIGZAG_LOCAL || e->needs_general || e->target_kind != 0 || e->flow_kind != 0 || e->adaptscale ||
+            e->local_bound || e->lambda_ref > 0 || e->dbg_kernel != PDMP_DEBUG_KERNEL_AUTO || e->dbg_dump > 0)
+            return fail(PDMP_ERR_UNSUPPORTED, "gradient tracking: spdmp with a ZigZag flow without refresh and the Gaussian target only");
+        // Γ[i,j] is read where the reference reads Γ[j,i] (the stored column of the reflecting coordinate): both matrices must be symmetric
+        bool sym = true, two = false;
+        for (int64_t col = 0; col < d && sym; ++col)
+            for (uint32_t pp = e->colptr[col]; pp < e->colptr[col + 1] && sym; ++pp) {
+                const uint32_t row = e->rowval[pp];
+                const uint32_t* lo = e->rowval.data() + e->colptr[row];
+                const uint32_t* hi = e->rowval.data() + e->colptr[row + 1];
+                const uint32_t* it = std::lower_bound(lo, hi, (uint32_t)col);
+                if (it == hi || *it != (uint32_t)col) {
+                    sym = false;
+                    break;
+                }
+                const size_t q = (size_t)(it - e->rowval.data());
+                if (e->bval[q] != e->bval[pp] || e->h_tval[q] != e->h_tval[pp]) sym = false;
+                if (e->bval[pp] != e->h_tval[pp]) two = true;
+            }
+        if (!sym) return fail(PDMP_ERR_UNSUPPORTED, "gradient tracking needs symmetric precision matrices (flow and target)");
+        e->track_two_sums = two;
+        e->track = true;
+    }
     pdmp_status st = alloc_state(e);
     if (st != PDMP_OK) return st;
     std::vector<double> cv(c, c + d);
@@ -836,6 +866,22 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
     P.diag = e->d_diag.p;
     P.sticky = sticky ? 1 : 0;
     P.local_bound = e->local_bound ? 1 : 0;
+    if (e->track) {
+        pdmp::ZzRunParams G{};
+        G.blob_sw = e->blob_sw;
+        G.blob_pw = e->blob_pw;
+        G.blob_kmax = e->blob_kmax;
+        G.blob_w_pad = e->blob_w_pad;
+        G.has_refresh = 0;
+        G.d = d;
+        if (!e->use_spec || !pdmp::zz_spec8_geometry(G)) {
+            e->track = false;
+            return fail(PDMP_ERR_UNSUPPORTED,
+                        "gradient tracking runs on the 8-event kernel's geometry: lattice-like graphs (|G1| <= 5, |S| <= 13), 2048 <= d <= 16384");
+        }
+    }
+    P.track = e->track ? 1 : 0;
+    e->t0_state = t0;
     if (sticky || e->local_bound) {
         if (e->d_thf.n != (size_t)(n * d) && (st = e->d_thf.alloc((size_t)(n * d))) != PDMP_OK) return st;
         P.thf = e->d_thf.p;
@@ -1000,6 +1046,20 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         }
         return PDMP_OK;
     }
+    if (e->track) {
+        if (dbg_cap > 0) return fail(PDMP_ERR_UNSUPPORTED, "the proposal dump belongs to the one-event kernel");
+        P.track_two_sums = e->track_two_sums ? 1 : 0;
+        int rct = pdmp::launch_zz_local_track(P, e->cfg.nchains, s);
+        if (rct != 0) return fail(PDMP_ERR_HIP, "zz_local_track launch failed (%d)", rct);
+        HIP_TRY(hipEventRecord(e->ev1, s));
+        e->timed = true;
+        if (phenv) {
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipMemcpy(e->dbg_phase_out, phbuf.p, sizeof e->dbg_phase_out, hipMemcpyDeviceToHost));
+            e->dbg_phase_valid = 1;
+        }
+        return PDMP_OK;
+    }
     const bool sticky_spec = sticky && e->use_spec && dbg_cap == 0;  // same requirements as the ZigZag speculative kernel
     int rc = sticky ? (sticky_spec ? pdmp::launch_zz_sticky_spec(P, e->cfg.nchains, s) : pdmp::launch_zz_sticky_run(P, e->cfg.nchains, s))
                     : spec_ok ? pdmp::launch_zz_local_spec(P, e->cfg.nchains, s) : pdmp::launch_zz_local_run(P, e->cfg.nchains, s);
@@ -1116,8 +1176,10 @@ pdmp_status pdmp_ensemble_final_state(pdmp_ensemble* e, int64_t chain_first, int
     if (c && (st = bc.alloc(cnt)) != PDMP_OK) return st;
     const double* c_src = e->cfg.adapt ? e->d_c_chain.p : e->d_c.p;
     const int64_t c_stride = e->cfg.adapt ? d : 0;
-    int rc = pdmp::launch_zz_unpack(e->d_rec.p, c_src, c_stride, d, chain_first, n, bt.p, bx.p, bth.p, bacc.p, bc.p,
-                                    e->stream);
+    int rc = e->track ? pdmp::launch_zz_track_unpack(reinterpret_cast<const pdmp::TrRec*>(e->d_rec.p), e->tables(), c_src, c_stride, d,
+                                                     chain_first, n, e->t0_state, bt.p, bx.p, bth.p, bacc.p, bc.p, e->stream)
+                       : pdmp::launch_zz_unpack(e->d_rec.p, c_src, c_stride, d, chain_first, n, bt.p, bx.p, bth.p, bacc.p, bc.p,
+                                                e->stream);
     if (rc != 0) return fail(PDMP_ERR_HIP, "unpack launch failed: %s", hipGetErrorString((hipError_t)rc));
     HIP_TRY(hipStreamSynchronize(e->stream));
     if (t) HIP_TRY(hipMemcpy(t, bt.p, cnt * sizeof(double), hipMemcpyDeviceToHost));
@@ -1144,7 +1206,7 @@ pdmp_status pdmp_ensemble_batch_means(pdmp_ensemble* e, double T_prev, double T,
     }
     if (e->d_sum.n != (size_t)(2 * d) && (st = e->d_sum.alloc((size_t)(2 * d))) != PDMP_OK) return st;
     HIP_TRY(hipMemset(e->d_sum.p, 0, (size_t)(2 * d) * sizeof(double)));
-    int rc = pdmp::launch_zz_batch_means(e->d_rec.p, e->d_jprev.p, d, n, T_prev, T, e->d_sum.p, e->d_sum.p + d,
+    int rc = pdmp::launch_zz_batch_means(e->d_rec.p, e->track ? 128 : 64, e->d_jprev.p, d, n, T_prev, T, e->d_sum.p, e->d_sum.p + d,
                                          e->stream);
     if (rc != 0) return fail(PDMP_ERR_HIP, "batch_means launch failed: %s", hipGetErrorString((hipError_t)rc));
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1172,7 +1234,7 @@ pdmp_status pdmp_ensemble_ess_begin(pdmp_ensemble* e, double T0) {
     if (e->d_jstart.n != (size_t)(n * d) && (st = e->d_jstart.alloc((size_t)(n * d))) != PDMP_OK) return st;
     if (e->d_essacc.n != (size_t)(4 * d) && (st = e->d_essacc.alloc((size_t)(4 * d))) != PDMP_OK) return st;
     HIP_TRY(hipMemsetAsync(e->d_essacc.p, 0, (size_t)(4 * d) * sizeof(double), e->stream));
-    int rc = pdmp::launch_zz_ess(e->d_rec.p, e->d_jprev.p, e->d_jstart.p, d, n, 0, T0, T0, e->d_essacc.p, e->stream);
+    int rc = pdmp::launch_zz_ess(e->d_rec.p, e->track ? 128 : 64, e->d_jprev.p, e->d_jstart.p, d, n, 0, T0, T0, e->d_essacc.p, e->stream);
     if (rc != 0) return fail(PDMP_ERR_HIP, "ess launch failed: %s", hipGetErrorString((hipError_t)rc));
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->ess_T0 = e->ess_Tlast = T0;
@@ -1187,7 +1249,7 @@ pdmp_status pdmp_ensemble_ess_batch(pdmp_ensemble* e, double T) {
     if (!(T > e->ess_Tlast)) return fail(PDMP_ERR_INVALID, "batch end %g does not exceed the previous one %g", T, e->ess_Tlast);
     HIP_TRY(hipSetDevice(e->cfg.device));
     HIP_TRY(hipDeviceSynchronize());
-    int rc = pdmp::launch_zz_ess(e->d_rec.p, e->d_jprev.p, e->d_jstart.p, e->cfg.d, e->cfg.nchains, 1, e->ess_Tlast, T,
+    int rc = pdmp::launch_zz_ess(e->d_rec.p, e->track ? 128 : 64, e->d_jprev.p, e->d_jstart.p, e->cfg.d, e->cfg.nchains, 1, e->ess_Tlast, T,
                                  e->d_essacc.p, e->stream);
     if (rc != 0) return fail(PDMP_ERR_HIP, "ess launch failed: %s", hipGetErrorString((hipError_t)rc));
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1204,7 +1266,7 @@ pdmp_status pdmp_ensemble_ess_end(pdmp_ensemble* e, double* sum_y, double* sum_y
     HIP_TRY(hipSetDevice(e->cfg.device));
     const int64_t d = e->cfg.d;
     HIP_TRY(hipMemsetAsync(e->d_essacc.p + 2 * d, 0, (size_t)(2 * d) * sizeof(double), e->stream));
-    int rc = pdmp::launch_zz_ess(e->d_rec.p, e->d_jprev.p, e->d_jstart.p, d, e->cfg.nchains, 2, e->ess_T0, e->ess_Tlast,
+    int rc = pdmp::launch_zz_ess(e->d_rec.p, e->track ? 128 : 64, e->d_jprev.p, e->d_jstart.p, d, e->cfg.nchains, 2, e->ess_T0, e->ess_Tlast,
                                  e->d_essacc.p, e->stream);
     if (rc != 0) return fail(PDMP_ERR_HIP, "ess launch failed: %s", hipGetErrorString((hipError_t)rc));
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1228,6 +1290,14 @@ pdmp_status pdmp_ensemble_set_sticky(pdmp_ensemble* e, const double* kappa, int 
     e->reversible = reversible;
     e->strong_upperbounds = strong_upperbounds;
     e->has_kappa = true;
+    e->has_state = false;
+    return PDMP_OK;
+}
+
+pdmp_status pdmp_ensemble_set_gradient_tracking(pdmp_ensemble* e, int enable) {
+    if (!e) return fail(PDMP_ERR_INVALID, "null argument");
+    NEED_FACTORISED(e);
+    e->track_requested = enable != 0;
     e->has_state = false;
     return PDMP_OK;
 }

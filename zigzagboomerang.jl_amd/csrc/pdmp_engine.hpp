@@ -37,6 +37,18 @@ struct alignas(64) ZzRec {
 };
 static_assert(sizeof(ZzRec) == 64, "record must be one 64-byte sector");
 
+// Record of the tracked-gradient kernel (zz_local_track_kernel): ONE 128-byte line per coordinate, four 32-byte sectors ordered by
+// how often they are written -- a rejected proposal of i dirties sector 2 only, an accepted one sectors 0-3 of i and 1-3 of its
+// neighbours.  Sector 0 has the field order of ZzRec's first half, so the path-integral kernels read both layouts.
+struct alignas(128) TrRec {
+    double x, th, tx, I;        // position at its own clock tx (brought up on i's accepts only), velocity, ∫ x dt up to tx
+    double g, gd, tg;           // g = Γt[:,i]·x and gd = Γt[:,i]·θ at time tg: ∇ϕ_i(t′) = g + gd (t′ − tg) − (Γt μt)_i
+    uint64_t acc;               // accepted reflections of i
+    double a, b, t_old, tprop;  // bound (src/fact_samplers.jl:50-54) and the time of i's last proposal
+    double gb, gdb, tacc, pad;  // the same sums with the bounding Γ (when it differs from the target's); time of i's last accept
+};
+static_assert(sizeof(TrRec) == 128, "tracked record must be one 128-byte line");
+
 struct alignas(128) DevChain {
     pdmp_chain_counters c;  // 72 bytes, copied out verbatim by pdmp_ensemble_counters
     uint64_t seed;
@@ -89,7 +101,7 @@ struct ZzRunParams {
     int32_t has_refresh;
     int32_t move_all;  // G = All(): the `pdmp` driver for ZigZag (src/sfact.jl:236)
     int32_t force_spec4;  // diagnostics (pdmp_debug_set_kernel): keep the 4-event kernel where the 8-event one would run
-    int32_t pad0_;
+    int32_t track_two_sums;  // tracked-gradient kernel: the bounding Γ differs from the target's (two pairs of sums per coordinate)
     // sticky ZigZag (src/ss_fact.jl)
     const double* __restrict__ kappa;  // [d] thaw rates
     double* thf;                       // [nchains x d] saved speeds θf
@@ -118,6 +130,7 @@ struct ZzInitParams {
     const double* __restrict__ mu;   // [d]
     const double* __restrict__ diag; // [d]
     int32_t local_bound;             // c::LocalBound (src/local.jl): bounds from the target's derivatives + expiry horizon; thf = renew flags
+    int32_t track;                   // records are TrRec (tracked-gradient kernel): also g = Γt[:,i]·x0, gd = Γt[:,i]·θ0 and the bound's sums
 };
 
 // General-degree local ZigZag (pdmp_general.hip): CSC tables instead of the blob, optional logistic target
@@ -204,10 +217,14 @@ bool zz_spec_supported(uint32_t nblk, uint32_t mmax, uint32_t kmax);
 size_t zz_spec_lds_bytes(uint32_t nblk_pad, uint32_t blob_w_pad);
 int launch_zz_unpack(const ZzRec* rec, const double* c_src, int64_t c_stride, int64_t d, int64_t chain_first,
                      int64_t n, double* t, double* x, double* th, int64_t* acc, double* c, void* stream);
-int launch_zz_batch_means(const ZzRec* rec, double* jprev, int64_t d, int64_t nchains, double T_prev, double T,
+int launch_zz_batch_means(const ZzRec* rec, int64_t rec_stride, double* jprev, int64_t d, int64_t nchains, double T_prev, double T,
                           double* sum_y, double* sum_y2, void* stream);
-int launch_zz_ess(const ZzRec* rec, double* jprev, double* jstart, int64_t d, int64_t nchains, int mode, double T_prev, double T,
-                  double* acc, void* stream);
+int launch_zz_local_track(const ZzRunParams& p, int64_t nchains, void* stream);
+bool zz_spec8_geometry(const ZzRunParams& p);  // the 8-event kernels' requirements on the neighbourhood blob and on d
+int launch_zz_track_unpack(const TrRec* rec, const ZzTables& tb, const double* c_src, int64_t c_stride, int64_t d, int64_t chain_first,
+                           int64_t n, double t0, double* t, double* x, double* th, int64_t* acc, double* c, void* stream);
+int launch_zz_ess(const ZzRec* rec, int64_t rec_stride, double* jprev, double* jstart, int64_t d, int64_t nchains, int mode, double T_prev,
+                  double T, double* acc, void* stream);
 size_t zz_local_lds_bytes(uint32_t nblk_pad, uint32_t blob_w_pad);
 int launch_math_probe(uint64_t seed, int64_t n, double* out, void* stream);
 

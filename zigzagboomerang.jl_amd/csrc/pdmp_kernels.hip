@@ -202,6 +202,35 @@ __global__ __launch_bounds__(256) void zz_init_kernel(ZzInitParams P) {
             }
             if (P.thf) P.thf[chain * d + i] = 0.0;
         }
+        if (P.track) {
+            // tracked-gradient records: the target's sums next to the bound's (gx, gt above ARE the bound's sums at t0)
+            double hx = 0.0, ht = 0.0;
+            for (uint32_t p = P.tb.colptr[i]; p < P.tb.colptr[i + 1]; ++p) {
+                const uint32_t r = P.tb.rowval[p];
+                const double v = P.tb.tval[p];
+                hx += v * x_of(r);
+                ht += v * th_of(r);
+            }
+            TrRec r;
+            r.x = xi;
+            r.th = thi;
+            r.tx = P.t0;
+            r.I = 0.0;
+            r.g = hx;
+            r.gd = ht;
+            r.tg = P.t0;
+            r.acc = 0;
+            r.a = a;
+            r.b = b;
+            r.t_old = P.t0;
+            r.tprop = P.t0;
+            r.gb = gx;
+            r.gdb = gt;
+            r.tacc = P.t0;
+            r.pad = 0.0;
+            (reinterpret_cast<TrRec*>(P.rec) + chain * d)[i] = r;
+            keys[i] = key;
+        } else {
         ZzRec r;
         r.x = xi;
         r.th = thi;
@@ -213,6 +242,7 @@ __global__ __launch_bounds__(256) void zz_init_kernel(ZzInitParams P) {
         r.acc = fflag;  // sticky: f[i] ("the next event of i is a freeze"), src/ss_fact.jl:165; otherwise acc[i] = 0
         rec[i] = r;
         keys[i] = key;
+        }
     } else if (i < P.dk) {
         double key = PDMP_INF;
         if (i == d && P.has_refresh) {
@@ -2511,6 +2541,686 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     }
 }
 
+// ------------------------------------------------------------------------------------------ tracked-gradient loop
+//
+// zz_local_spec8_kernel's scheme (eight event slots per iteration, threshold selection, scalar accept walk, exact validation, commit of
+// the valid prefix) on a different evaluation of the SAME process: instead of moving the neighbourhood G[i] to t′ at every proposal and
+// gathering Γ[:,i]·x from it (src/sfact.jl:82,116 -- five scattered read-modify-writes per proposal, each a whole 128-byte line from HBM,
+// profiles/r02_*_pmc_calibration.txt), every coordinate carries g_i = Γ[:,i]·x and its rate of change gd_i = Γ[:,i]·θ.  Both are exact
+// between reflections (the flow is linear), so a proposal reads ONE line -- its own record -- and a rejected one writes one sector of it;
+// only an accepted reflection (18 % of the proposals on the lattice) visits the neighbours j ∈ G1[i], to bring their sums to t′, add
+// Γ[i,j] δθ_i to gd_j and re-bound them.  The draws, the thinning test, the bounds and the queue are the reference's; the floating-point
+// values of g differ from a fresh gather in the last bits (sums are advanced, not recomputed), so this kernel reproduces the reference's
+// event INDEX sequence, accept/reject outcomes and counters exactly and its times / positions to ~1e-13 (tests: 1e-9; north star: 1e-6),
+// where zz_local_spec8_kernel is bit-identical.  The process is not chaotic -- a relative perturbation of 1e-10 of x0 stays 1e-10 after
+// 5·10⁴ events, with an identical index sequence (measured on the oracle) -- so the agreement does not decay with the run length.
+// Opt-in (pdmp_ensemble_set_gradient_tracking); needs the lattice blob geometry of the 8-event kernel and symmetric Γ.
+// The reference's lazy clocks t[j] and positions x[j] at those clocks (src/sfact.jl:211) are rebuilt on demand by zz_track_unpack_kernel
+// from the times of the last proposal / accept around j.
+// FULL: `adapt` (per-chain bounds c), a target with a mean, and a bounding Γ whose values differ from the target's (two pairs of tracked
+// sums); the north-star instantiation has none of these.
+template <bool PROF, bool FULL = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void zz_local_track_kernel(ZzRunParams P) {
+    constexpr int E = 8;
+    constexpr uint32_t SW = 7, PW = 1, KMAX = 5, R_ = 4 + PW + KMAX, WPAD = 58, W2 = WPAD / 2;
+    const uint32_t nblk = P.nblk;  // 32-key blocks that hold coordinates (<= S8_NBLK); first-level entries beyond stay +Inf
+    const int lane = threadIdx.x;
+    const int g = lane >> 3;  // group = event slot
+    const int gl = lane & 7;  // lane inside the group
+    const int64_t chain = blockIdx.x;
+    const int64_t d = P.d;
+
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* const LU = reinterpret_cast<double*>(smem + S8_LU);
+    double* const SLT = reinterpret_cast<double*>(smem + S8_SLT);
+    double* const Lr = reinterpret_cast<double*>(smem + S8_LR);
+    double* const LBr = reinterpret_cast<double*>(smem + S8_LBR);
+    double* const Mr = reinterpret_cast<double*>(smem + S8_MR);
+    uint32_t* const SLB = reinterpret_cast<uint32_t*>(smem + S8_SLB);
+    uint32_t* const Z = reinterpret_cast<uint32_t*>(smem + S8_Z);
+    double* const bk = reinterpret_cast<double*>(smem + S8_BK);
+    uint16_t* const bi = reinterpret_cast<uint16_t*>(smem + S8_BI);
+    uint64_t* const LB = reinterpret_cast<uint64_t*>(smem + S8_LB);
+    double* const TK = reinterpret_cast<double*>(smem + S8_TK);
+    uint32_t* const TB = reinterpret_cast<uint32_t*>(smem + S8_TB);
+    double* const SELDT = reinterpret_cast<double*>(smem + S8_SELDT);
+    uint32_t* const PR = reinterpret_cast<uint32_t*>(smem + S8_PR);
+    double* const pk = reinterpret_cast<double*>(smem + S8_PK) + g * 32;
+    uint32_t* const zg = Z + g * 16;
+    const uint32_t pk_t = (uint32_t)g & 1u;  // odd groups store the two 16-byte pieces of a lane's chunk swapped: no bank conflicts
+
+    TrRec* rec = reinterpret_cast<TrRec*>(P.rec) + chain * d;
+    const bool two_sums = FULL && P.track_two_sums != 0;  // the bounding Γ differs from the target's: (gb, gdb) next to (g, gd)
+    double* keys = P.keys + chain * P.dk;
+    DevChain* hdr = P.hdr + chain;
+    pdmp_event* ev = P.ev ? P.ev + chain * P.trace_cap : nullptr;
+    double* cmut = (FULL && P.c_chain) ? (P.c_chain + chain * d) : nullptr;
+    const bool adapt = FULL && P.adapt != 0;
+
+    uint32_t status = hdr->c.status;
+    if (status == PDMP_CHAIN_BOUND_VIOLATED || status == PDMP_CHAIN_STALLED) return;
+    const uint64_t seed = hdr->seed;
+    const uint64_t nm0 = hdr->c.ndraw_main, ntrace0 = hdr->c.ntrace;
+    uint32_t dnm = 0, dnum = 0, dnacc = 0;
+    uint32_t vnacc = 0;  // 1 if the launch ends on a bound violation (acc is bumped before the check)
+    double t_last = hdr->c.t_last;
+    double t_event = hdr->t_event;
+    status = PDMP_CHAIN_OK;
+
+    const double T = P.T;
+    const bool stop_before = (P.flags & PDMP_RUN_STOP_BEFORE) != 0;
+    const uint32_t trace_room = (P.trace_cap > 0)
+                                    ? (uint32_t)(((uint64_t)P.trace_cap > ntrace0) ? ((uint64_t)P.trace_cap - ntrace0) : 0)
+                                    : 0xffffffffu;
+    const uint32_t common = P.common_tix;
+
+    if (lane == 0) SELDT[0] = 1e-3;  // any positive start: the steering rule finds the scale within a few iterations
+    // slot 0 <- the common template, for the whole launch
+    if (lane < (int)W2) {
+        reinterpret_cast<ulonglong2*>(LB)[lane] = reinterpret_cast<const ulonglong2*>(P.blob + (size_t)common * WPAD)[lane];
+    }
+    for (uint32_t b = lane; b < nblk; b += 64) {
+        const double* kp = keys + (size_t)b * 32;
+        double mk = kp[0];
+        uint32_t mi = 0;
+#pragma unroll 8
+        for (int q = 1; q < 32; ++q) {
+            const double v = kp[q];
+            if (v < mk) {
+                mk = v;
+                mi = q;
+            }
+        }
+        bk[b] = mk;
+        bi[b] = (uint16_t)(b * 32 + mi);
+    }
+    for (uint32_t b = nblk + lane; b < S8_NBLK; b += 64) {
+        bk[b] = PDMP_INF;
+        bi[b] = 0;
+    }
+    LDS_ORDER();
+
+    uint32_t rng_base = 0xffffffffu;
+    double ureg = 0.0;  // draw rng_base + lane of the chain's stream
+    uint64_t ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t ph_t0 = PROF ? (uint64_t)__builtin_readcyclecounter() : 0;
+    uint64_t ph_iters = 0;
+#define PHASE(k)                                                          \
+    do {                                                                  \
+        if (PROF) {                                                       \
+            const uint64_t now_ = (uint64_t)__builtin_readcyclecounter(); \
+            ph[k] += now_ - ph_t0;                                        \
+            ph_t0 = now_;                                                 \
+        }                                                                 \
+    } while (0)
+
+    bool running = stop_before || (t_event < T);
+    while (running) {
+        if (dnacc >= trace_room) {
+            status = PDMP_CHAIN_TRACE_FULL;
+            break;
+        }
+        // ---------------- select the (up to) E smallest block minima, in time order, WITHOUT a tournament per candidate: one
+        // wave minimum m, then every first-level entry below the threshold m + sel_dt is a candidate -- four compares and four
+        // population counts tell how many there are.  The candidates (at most SEL_CAP, else the threshold is halved) are compacted
+        // into LDS by ballot prefix counts, each ranks itself against the others with broadcast reads, and ranks 0..E-1 become
+        // the event slots.  Whatever sel_dt is, the slots hold exactly the smallest entries of the queue, so the committed
+        // sequence does not depend on it; it is steered towards ~12 candidates per iteration.
+        int Esel = 0;
+        bool first_inf = false;
+        {
+            double kk[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) kk[j] = bk[lane + 64 * j];
+            const double mloc = min_f64(min_f64(min_f64(kk[0], kk[1]), min_f64(kk[2], kk[3])),
+                                        min_f64(min_f64(kk[4], kk[5]), min_f64(kk[6], kk[7])));
+            const double mq = wave_min_f64(mloc);
+            if (!(mq < PDMP_INF)) {
+                first_inf = true;
+            } else if (!(stop_before && !(mq < T))) {
+                if (lane < (int)SEL_CAP) TK[lane] = PDMP_INF;
+                double dt_sel = uniform_f64(SELDT[0]);
+                // (the candidate masks are recomputed where they are needed instead of being kept: eight 64-bit masks would
+                // crowd the scalar registers)
+                // Compaction: entry (lane, j) gets index (candidates of slots < j) + (candidates of slot j in lower lanes).  There is
+                // no separate counting pass: the scratch arrays take up to 64 candidates, and a pass that ends with more than
+                // SEL_CAP is repeated with half the threshold.
+                auto below = [](uint64_t m_) -> uint32_t {
+                    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_, 0u));
+                };
+                double tau;
+                uint32_t C;
+                for (int tries = 0;; ++tries) {
+                    tau = mq + dt_sel;  // (>= mq: the minimum itself always qualifies)
+                    if (stop_before && !(tau < T)) tau = pdmp_below(T);
+                    const bool pile = tries > 64;  // more than SEL_CAP entries EQUAL to the minimum: one (lowest block) per iteration
+                    if (tries >= 64) tau = mq;     // a pile of exactly equal keys: the entries equal to the minimum only
+                    uint32_t base = 0;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const bool cj_ = kk[j] <= tau;
+                        uint64_t Mj = __ballot(cj_);
+                        if (pile) Mj = (base == 0 && Mj) ? (Mj & (~Mj + 1)) : 0ull;
+                        if (cj_ && ((Mj >> lane) & 1ull)) {
+                            const uint32_t ix = base + below(Mj);
+                            if (ix < 64u) {
+                                TK[ix] = kk[j];
+                                TB[ix] = (uint32_t)lane + 64u * j;
+                            }
+                        }
+                        base += (uint32_t)__popcll(Mj);
+                    }
+                    C = base;
+                    if (C <= SEL_CAP) break;
+                    dt_sel *= 0.5;
+                    LDS_ORDER();
+                    if (lane < (int)SEL_CAP) TK[lane] = PDMP_INF;  // (entries past the new count must read +Inf in the ranking)
+                }
+                LDS_ORDER();
+                // rank of candidate n among all (ties by index), on a 16 x 4 grid: lane = 16 * part + n counts the candidates
+                // 4 * part .. 4 * part + 3 that precede n; the four partial counts meet in LDS.  Unused entries hold +Inf.
+                {
+                    const uint32_t n = (uint32_t)lane & 15u, part = (uint32_t)lane >> 4;
+                    const double own = TK[n];
+                    const double2* T2 = reinterpret_cast<const double2*>(TK + 4 * part);
+                    const double2 o01 = T2[0], o23 = T2[1];
+                    const uint32_t q = 4 * part;
+                    uint32_t pr = 0;
+                    pr += (o01.x < own || (o01.x == own && q + 0 < n)) ? 1u : 0u;
+                    pr += (o01.y < own || (o01.y == own && q + 1 < n)) ? 1u : 0u;
+                    pr += (o23.x < own || (o23.x == own && q + 2 < n)) ? 1u : 0u;
+                    pr += (o23.y < own || (o23.y == own && q + 3 < n)) ? 1u : 0u;
+                    PR[n * 4 + part] = pr;
+                    LDS_ORDER();
+                    if ((uint32_t)lane < C) {
+                        const uint4 p4 = reinterpret_cast<const uint4*>(PR)[lane];
+                        const uint32_t rank = p4.x + p4.y + p4.z + p4.w;
+                        if (rank < (uint32_t)E) {
+                            SLT[rank] = own;
+                            SLB[rank] = TB[lane];
+                        }
+                    }
+                }
+                Esel = (C < (uint32_t)E) ? (int)C : E;
+                // steer the threshold: ~10 candidates next time
+                const double f = (C > 14u) ? 0.8 : (C < 11u) ? ((C < 6u) ? 2.0 : 1.2) : 1.0;
+                if (lane == 0) SELDT[0] = dt_sel * f;
+            }
+        }
+        if (Esel == 0) {
+            if (first_inf) status = PDMP_CHAIN_STALLED;
+            break;
+        }
+        LDS_ORDER();
+        PHASE(0);
+        if (PROF) ph_iters += 1;
+        bool gvalid = g < Esel;
+        const double tp = gvalid ? SLT[g] : PDMP_INF;
+        const uint32_t blk = gvalid ? SLB[g] : 0u;
+        const uint32_t i = gvalid ? (uint32_t)bi[blk] : 0u;
+        const uint32_t tixi = gvalid ? P.tix[i] : common;
+
+        // ---------------- candidate draws (window of 64 draws and their logs in LDS, as in zz_local_spec_kernel)
+        if (dnm < rng_base || dnm + E * (1u + KMAX) > rng_base + 64u) {
+            rng_base = dnm;
+            ureg = pdmp_u01(seed, PDMP_STREAM_MAIN, nm0 + (uint64_t)dnm + (uint64_t)lane);
+            LU[lane] = pdmp_log(ureg);
+        }
+        const uint32_t rng_off = dnm - rng_base;
+        // ---------------- blob slots: 0 for the common template, 1 and 2 for the first two events that need another one
+        uint32_t slot = 0;
+        {
+            const bool nc = gvalid && tixi != common;
+            const uint64_t ncball = __ballot(nc && gl == 0);
+            if (ncball != 0) {
+                const uint32_t rank = (uint32_t)__popcll(ncball & ((1ull << (8 * g)) - 1ull));
+                if (__popcll(ncball) > 2) {  // the third such event and everything after it wait for the next iteration
+                    uint64_t m_ = ncball;
+                    m_ &= m_ - 1;
+                    m_ &= m_ - 1;
+                    const int cut = (__ffsll((unsigned long long)m_) - 1) >> 3;
+                    Esel = cut;
+                    gvalid = g < Esel;
+                }
+                if (nc && gvalid) {
+                    slot = 1 + rank;
+                    const ulonglong2* bsrc = reinterpret_cast<const ulonglong2*>(P.blob + (size_t)tixi * WPAD);
+                    ulonglong2* bdst = reinterpret_cast<ulonglong2*>(LB + slot * WPAD);
+                    for (uint32_t w = gl; w < W2; w += 8) bdst[w] = bsrc[w];
+                }
+            }
+        }
+        const uint64_t* lb = LB + slot * WPAD;
+        LDS_ORDER();
+        PHASE(1);
+        // ---------------- neighbourhood header and member list: positions gl and gl + 8 of S[i]
+        // (straight-line: every lane reads its slot's words, the selects below sort out who is a member)
+        const uint32_t hw = gvalid ? (uint32_t)lb[0] : 0u;
+        const int k = (int)(hw & 0xff), m = (int)((hw >> 8) & 0xff), self = (int)((hw >> 16) & 0xff);
+        (void)m;
+        const bool memberA = gl < k;  // the zone of an event is G1[i]: nothing else is read or written (k = 0 in an empty slot)
+        const uint64_t swa = lb[1 + (gl >> 1)];
+        const uint32_t sA = memberA ? i + ((gl & 1) ? (uint32_t)(swa >> 32) : (uint32_t)swa) : 0xffffff00u + (uint32_t)lane;
+        const uint32_t sB = 0xffffff40u + (uint32_t)lane;
+        constexpr bool memberB = false;
+        PHASE(2);
+        // All HBM loads of the iteration in ONE straight-line batch (no exec-masked regions: lanes without a record of their own
+        // read i's, which coalesces with the group's other readers of it; empty slots read coordinate 0): the wait counters
+        // stay exact and nothing here is serialised behind an earlier round trip.
+        // own record of i (one 128-byte line; every lane of the group reads the same addresses) and the popped key block
+        TrRec* const ri = rec + i;
+        double x = ri->x, th = ri->th, tx = ri->tx, I = ri->I;
+        const double g_i = ri->g, gd_i = ri->gd, tg_i = ri->tg;
+        const uint64_t acc_i = ri->acc;
+        const double told_i = ri->t_old, a_i = ri->a, b_i = ri->b;
+        double gb_i = 0.0, gdb_i = 0.0;
+        if (two_sums) {
+            gb_i = ri->gb;
+            gdb_i = ri->gdb;
+        }
+        double kq[4];
+        {
+            const double2* kp = reinterpret_cast<const double2*>(keys + (size_t)blk * 32 + gl * 4);
+            const double2 k01 = kp[0], k23 = kp[1];
+            kq[0] = k01.x;
+            kq[1] = k01.y;
+            kq[2] = k23.x;
+            kq[3] = k23.y;
+        }
+        TrRec* const rsA = rec + (memberA ? sA : i);
+        zg[gl] = sA;
+        zg[8 + gl] = sB;
+        const uint32_t sub = 1 + SW + (uint32_t)gl * R_;
+        double cj = __longlong_as_double((long long)lb[sub + 2]);  // (used by lanes gl < k only)
+        if (FULL && cmut) cj = cmut[(gl < k) ? sA : i];
+
+        // ---------------- zone conflicts with earlier groups: id spans first, the exact id comparison only for pairs of groups
+        // whose spans overlap
+        LDS_ORDER();
+        uint64_t confball;
+        {
+            uint32_t lo = memberA ? sA : 0xffffffffu, hi = memberA ? sA : 0u;
+            lo = (memberB && sB < lo) ? sB : lo;
+            hi = (memberB && sB > hi) ? sB : hi;
+            uint32_t o;
+            o = dpp_u32<0xB1>(lo);   lo = (o < lo) ? o : lo;
+            o = dpp_u32<0x4E>(lo);   lo = (o < lo) ? o : lo;
+            o = dpp_u32<0x141>(lo);  lo = (o < lo) ? o : lo;
+            o = dpp_u32<0xB1>(hi);   hi = (o > hi) ? o : hi;
+            o = dpp_u32<0x4E>(hi);   hi = (o > hi) ? o : hi;
+            o = dpp_u32<0x141>(hi);  hi = (o > hi) ? o : hi;
+            // A pair of groups (q < g) whose spans overlap is compared exactly by the WHOLE wave: lane L holds id L & 15 of g
+            // against ids 4 (L >> 4) .. + 3 of q -- the 256 id pairs in four xor / two min instructions per lane.  Empty
+            // positions hold sentinels that equal nothing.
+            uint32_t confmask = 0;
+            const uint4* Z4 = reinterpret_cast<const uint4*>(Z);
+            // lane gl of group g looks at the pair (g, q = gl): one ballot finds all pairs of groups whose spans overlap
+            {
+                const uint32_t lq = (uint32_t)__builtin_amdgcn_ds_bpermute(32 * gl, (int)lo);  // span of group gl (its lane 0)
+                const uint32_t hq = (uint32_t)__builtin_amdgcn_ds_bpermute(32 * gl, (int)hi);
+                uint64_t ovb = __ballot(gvalid && gl < g && lo <= hq && lq <= hi);
+                while (ovb != 0) {
+                    const int bit = __ffsll((unsigned long long)ovb) - 1;
+                    const int gsel = bit >> 3, q = bit & 7;
+                    ovb &= ovb - 1;
+                    const uint32_t idg = Z[gsel * 16 + (lane & 15)];
+                    const uint4 zq = Z4[q * 4 + (lane >> 4)];
+                    const uint32_t mn = umin3(idg ^ zq.x, idg ^ zq.y, umin3(idg ^ zq.z, idg ^ zq.w, 0xffffffffu));
+                    if (__ballot(mn == 0u) != 0) confmask |= 1u << gsel;
+                }
+            }
+            confball = confmask;
+        }
+        PHASE(3);
+
+        // ---------------- rates: the tracked sums stand in for smove_forward!(G, i, ...) + idot (src/sfact.jl:82,116-119): g_i(t′) = g_i + gd_i (t′ − tg_i)
+        double l, lbound;
+        const double g_now = g_i + gd_i * (tp - tg_i);
+        const double gb_now = two_sums ? (gb_i + gdb_i * (tp - tg_i)) : g_now;
+        {
+            double gr = g_now;
+            if (FULL && P.tb.gmu_t) gr = gr - P.tb.gmu_t[i];
+            l = pos_part(gr * th);
+            lbound = pos_part(a_i + b_i * (tp - told_i));
+            if (gl == 0) {
+                Lr[g] = l;
+                LBr[g] = lbound;
+            }
+        }
+        LDS_ORDER();
+        // ---------------- accept chain in time order.  Lane o evaluates every event's test for the draw at offset o; the ballots
+        // are then walked on the scalar unit: event r reads its bit at the offset the earlier outcomes imply.
+        // The offsets (each <= 48) travel packed six bits apiece in one 64-bit scalar: offset after r events = bits 6r .. 6r+5.
+        uint32_t accbits = 0;
+        uint64_t offpack = 0;
+        {
+            const double coin = bperm_f64(ureg, (rng_off + (uint32_t)lane) & 63u);
+            uint32_t off = 0;
+#pragma unroll
+            for (int r = 0; r < E; ++r) {  // slots >= Esel hold stale rates: their bits are masked off below, their offsets unused
+                const uint64_t am_r = __ballot(coin * LBr[r] < Lr[r]);  // :121
+                const uint32_t a_r = (uint32_t)(am_r >> off) & 1u;
+                const uint32_t k_r = readlane_u32((uint32_t)k, 8 * r);
+                off += a_r ? (1u + k_r) : 2u;
+                off = (off < 63u) ? off : 63u;  // (only stale slots can run past the window; keeps the shifts defined)
+                accbits |= a_r << r;
+                offpack |= (uint64_t)off << (6 * (r + 1));
+            }
+            accbits &= (1u << Esel) - 1u;
+        }
+        const uint32_t myoff = (uint32_t)(offpack >> (6 * g)) & 63u;
+        const bool accept = gvalid && ((accbits >> g) & 1u) != 0;
+        const bool violated = accept && (l >= lbound);  // :123
+        PHASE(4);
+
+        // ---------------- accept: reflect!(i) (:130) changes θ_i by δ; every j in G1[i] brings its sums to t′, takes Γ[i,j] δ into its
+        // velocity sum and is re-bounded (:131-135); reject: i is re-bounded from its own sums (:137-140)
+        const bool active = gvalid && (accept ? (gl < k) : (gl == self));
+        double key = PDMP_INF, a = 0.0, b = 0.0;
+        double gj = g_now, gdj = gd_i, gbj = gb_now, gdbj = two_sums ? gdb_i : gd_i, thj = th;
+        if (accept && gl == self) {  // event(i, t, x, θ, F) needs x_i at t′ (src/sfact.jl:50-52): the position is brought up on accepts only
+            const double dtx = tp - tx;
+            const double xn = x + th * dtx;
+            I = I + dtx * ((x + xn) * 0.5);
+            x = xn;
+            tx = tp;
+        }
+        if (active) {
+            const double th_new_i = accept ? -th : th;
+            const double delta = accept ? (th_new_i - th) : 0.0;
+            if (accept && gl != self) {
+                thj = rsA->th;
+                const double gj0 = rsA->g, gdj0 = rsA->gd, tgj = rsA->tg;
+                gj = gj0 + gdj0 * (tp - tgj);
+                gdj = gdj0;
+                if (two_sums) {
+                    const double gbj0 = rsA->gb, gdbj0 = rsA->gdb;
+                    gbj = gbj0 + gdbj0 * (tp - tgj);
+                    gdbj = gdbj0;
+                } else {
+                    gbj = gj;
+                    gdbj = gdj;
+                }
+            } else {
+                thj = th_new_i;
+            }
+            const double gmu = __longlong_as_double((long long)lb[sub + 1]);
+            if (accept) {
+                // Γt[i, j] = Γt[j, i] (the stored column of i; the precision matrix is symmetric, checked on the host) and Γ[i, j] of
+                // the bounding matrix: the entry of column j that sits at i's position
+                const double ct = __longlong_as_double((long long)lb[sub + 0]);
+                gdj += ct * delta;
+                if (two_sums) {
+                    const int kj = (int)(lb[sub + 3] & 0xff);
+                    const uint64_t pw = lb[sub + 4];
+                    double cbv = 0.0;
+#pragma unroll
+                    for (int q = 0; q < (int)KMAX; ++q) {
+                        const int ps = (int)((pw >> (8 * q)) & 0xff);
+                        if (q < kj && ps == self) cbv = __longlong_as_double((long long)lb[sub + 4 + PW + q]);
+                    }
+                    gdbj += cbv * delta;
+                } else {
+                    gdbj = gdj;
+                }
+            }
+            if (FULL && violated && gl == self) cj *= P.factor;  // adapt!(c, i, factor), :127 (stored at commit)
+            a = cj + (gbj - gmu) * thj;
+            b = cj / 100 + thj * gdbj;
+            const double L = LU[(rng_off + myoff + 1u + (accept ? (uint32_t)gl : 0u)) & 63u];
+            key = tp + dev_poisson_time_L(a, b, L);
+        }
+        LDS_ORDER();
+        // the patched copy of the popped key block goes where the zone ids were: all their readers are done
+        // (the four 16-byte pieces of a lane's 64-byte chunk are stored in the order piece ^ pk_t, pk_t = 0..3 over the four lanes
+        // of a quarter wave that would otherwise share their banks: b128 accesses without bank conflicts)
+        {
+            double2* pk2 = reinterpret_cast<double2*>(pk + gl * 4);
+            pk2[0 ^ pk_t] = make_double2(kq[0], kq[1]);
+            pk2[1 ^ pk_t] = make_double2(kq[2], kq[3]);
+        }
+        LDS_ORDER();
+        if (active && (sA >> 5) == blk) {
+            const uint32_t e_ = sA & 31u;
+#ifdef PDMP_X_KEYLINES
+            pk[((e_ & 15u) >> 1) * 4u + (((e_ >> 4) ^ pk_t) << 1) + (e_ & 1u)] = key;
+#else
+            pk[(e_ & ~3u) + ((((e_ & 3u) >> 1) ^ pk_t) << 1) + (e_ & 1u)] = key;
+#endif
+        }
+        LDS_ORDER();
+        PHASE(5);
+        // ---------------- patched minimum of the popped block, and everything this event could expose
+        double rowmin;
+        uint32_t cand;
+        int wl2;
+        {
+            const double2* pk2 = reinterpret_cast<const double2*>(pk + gl * 4);
+            const double2 p01 = pk2[0 ^ pk_t], p23 = pk2[1 ^ pk_t];
+            double lm = p01.x;
+            uint32_t li = 0;
+#define PMIN(v, idx)    \
+    do {                \
+        if ((v) < lm) { \
+            lm = (v);   \
+            li = (idx); \
+        }               \
+    } while (0)
+            PMIN(p01.y, 1);
+            PMIN(p23.x, 2);
+            PMIN(p23.y, 3);
+#undef PMIN
+#ifdef PDMP_X_KEYLINES
+            cand = blk * 32u + ((li >> 1) << 4) + (uint32_t)gl * 2u + (li & 1u);
+            rowmin = grp8_min_f64(lm);
+            const uint64_t winball = __ballot(gvalid && lm == rowmin);
+            const uint64_t winlo = __ballot(gvalid && lm == rowmin && li < 2u);  // (ties: the lowest coordinate wins)
+            const unsigned wlo = (unsigned)((winlo >> (8 * g)) & 0xffu);
+            wl2 = __ffs(wlo ? wlo : (unsigned)((winball >> (8 * g)) & 0xffu)) - 1;
+#else
+            cand = blk * 32u + (uint32_t)gl * 4u + li;
+            rowmin = grp8_min_f64(lm);
+            const uint64_t winball = __ballot(gvalid && lm == rowmin);
+            wl2 = __ffs((unsigned)((winball >> (8 * g)) & 0xffu)) - 1;
+#endif
+        }
+        const double keymin = grp8_min_f64(key);
+        const double expose = min_f64(rowmin, keymin);
+        if (gl == 0) Mr[g] = expose;
+        LDS_ORDER();
+        // ---------------- validate: event g commits iff all earlier ones do, its zone is disjoint from theirs, and nothing they
+        // produce or expose comes before it
+        uint32_t Rc;
+        uint32_t nacc_c;
+        int vsel = -1;  // the event that violates its bound, if it is the chain's next one
+        {
+            double pref = PDMP_INF;
+#pragma unroll
+            for (int q = 0; q < E - 1; ++q) {
+                const double mq = Mr[q];
+                pref = (q < g) ? min_f64(pref, mq) : pref;
+            }
+            const bool confg = ((confball >> g) & 1ull) != 0;
+            const bool okg = gvalid && ((g == 0) || (!confg && pref > tp));
+            const bool vstop = violated && !adapt;  // reference: error(...), :124 -> the event is not committed
+            const uint64_t okball = __ballot(okg && !vstop && gl == 0);
+            const uint64_t vball = __ballot(okg && vstop && gl == 0);
+            const uint64_t accball = __ballot(accept && gl == 0);
+            // length of the run of committable slots from slot 0 (one bit per slot at bit 8 r): first zero among those bits
+            const uint64_t gap = ~okball & 0x0101010101010101ull;
+            const uint32_t r_ok = gap ? (uint32_t)((__ffsll((unsigned long long)gap) - 1) >> 3) : (uint32_t)E;
+            Rc = 0;
+            nacc_c = 0;
+            bool stopped = false;
+            // the usual case needs no walk: the slice mode stops on time alone, and the trace has room for every accepted slot
+            const uint32_t nacc_all = (uint32_t)__popcll(accball & ((r_ok < 8u) ? ((1ull << (8 * r_ok)) - 1ull) : ~0ull));
+            const bool plainrun = stop_before && !(P.trace_cap > 0 && dnacc + nacc_all >= trace_room);
+            if (plainrun) {
+                Rc = r_ok;
+                nacc_c = nacc_all;
+            }
+            for (uint32_t r = 0; !plainrun && r < r_ok && !stopped; ++r) {
+                Rc = r + 1;
+                if ((accball >> (8 * r)) & 1ull) {
+                    nacc_c += 1;
+                    if (dnacc + nacc_c >= trace_room && P.trace_cap > 0) {
+                        status = PDMP_CHAIN_TRACE_FULL;
+                        stopped = true;
+                    }
+                    if (!stop_before && !(uniform_f64(SLT[r]) < T)) {
+                        running = false;
+                        stopped = true;
+                    }
+                }
+            }
+            if (!stopped && r_ok < (uint32_t)E && ((vball >> (8 * r_ok)) & 1ull)) {
+                status = PDMP_CHAIN_BOUND_VIOLATED;
+                vsel = (int)r_ok;
+            }
+        }
+        PHASE(6);
+
+        // ---------------- commit the valid prefix
+        const bool commit = gvalid && (uint32_t)g < Rc;
+        const uint64_t accball2 = __ballot(commit && accept && gl == 0);
+        if (commit) {
+            if (active) {
+                if (accept) {
+                    rsA->g = gj;
+                    rsA->gd = gdj;
+                    rsA->tg = tp;
+                    if (two_sums) {
+                        rsA->gb = gbj;
+                        rsA->gdb = gdbj;
+                    }
+                }
+                rsA->a = a;
+                rsA->b = b;
+                rsA->t_old = tp;
+                keys[sA] = key;
+                if (FULL && violated && gl == self) cmut[sA] = cj;
+                if (gl == self) {
+                    ri->tprop = tp;  // every proposal of i moves G[i] to t′ in the reference: kept to rebuild its clocks (zz_track_unpack_kernel)
+                    if (accept) {
+                        ri->x = x;
+                        ri->th = -th;
+                        ri->tx = tx;
+                        ri->I = I;
+                        ri->acc = acc_i + 1;
+                        ri->tacc = tp;   // an accepted event also moves G2[i]
+                    }
+                }
+            }
+            if (gl == wl2) {
+                bk[blk] = rowmin;
+                bi[blk] = (uint16_t)cand;
+            }
+            if (accept && gl == self && ev) {
+                const uint32_t rank = (uint32_t)__popcll(accball2 & ((1ull << (8 * g)) - 1ull));
+                pdmp_event e;
+                e.t = tp;
+                e.i = (int64_t)i;
+                e.x = x;
+                e.theta = -th;
+                ev[ntrace0 + dnacc + rank] = e;
+            }
+        }
+        LDS_ORDER();
+        PHASE(7);
+        // ---------------- level-1 updates for re-bounded neighbours living in other blocks.  The final entry of a block is the
+        // smallest (key, coordinate) among its old entry and the new keys, whatever the order -- so when no two of these lanes aim
+        // at one block (checked through a small claim table) and none has to rescan, every lane updates its block by itself, in
+        // one LDS round trip for all of them; otherwise the updates are made one by one in event order.
+        const bool upd = commit && accept && gl < k && (sA >> 5) != blk;
+        if (__ballot(upd) != 0) {
+            uint8_t* const CL = reinterpret_cast<uint8_t*>(smem + S8_CL);
+            LDS_ORDER();
+            const uint32_t bjv = upd ? (sA >> 5) : 0u;
+            const double curv = bk[bjv];
+            const uint32_t civ = bi[bjv];
+            const bool lower = upd && (key < curv || (key == curv && sA < civ));
+            const bool resc = upd && !lower && civ == sA;
+            if (lower) CL[bjv & 63u] = (uint8_t)lane;
+            LDS_ORDER();
+            const bool lost = lower && CL[bjv & 63u] != (uint8_t)lane;
+            if (__ballot(lost || resc) == 0) {
+                if (lower) {
+                    bk[bjv] = key;
+                    bi[bjv] = (uint16_t)sA;
+                }
+            } else {
+            for (uint32_t r = 0; r < Rc; ++r) {
+                if (!((accball2 >> (8 * r)) & 1ull)) continue;
+                const uint32_t own = uniform_u32(SLB[r]);
+                const int kr = (int)readlane_u32((uint32_t)k, 8 * (int)r);
+                for (int jj = 0; jj < kr; ++jj) {
+                    const uint32_t j = readlane_u32(sA, 8 * (int)r + jj);
+                    if ((j >> 5) == own) continue;
+                    // first-level entry of j's 32-key block: a lower key replaces it; if j WAS the entry and grew, the block is rescanned
+                    const double kj = readlane_f64(key, 8 * (int)r + jj);
+                    const uint32_t bj = j >> 5;
+                    LDS_ORDER();
+                    const double cur = bk[bj];
+                    const uint32_t ci = bi[bj];
+                    if (kj < cur || (kj == cur && j < ci)) {
+                        if (lane == 0) {
+                            bk[bj] = kj;
+                            bi[bj] = (uint16_t)j;
+                        }
+                    } else if (ci == j) {
+                        const double kv = __hip_atomic_load(keys + (size_t)bj * 32 + (lane & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const double mn = wave_min_f64(kv);
+                        const uint64_t bl = __ballot(kv == mn);
+                        const int arg = bl ? (__ffsll((unsigned long long)bl) - 1) : 0;
+                        if (lane == 0) {
+                            bk[bj] = mn;
+                            bi[bj] = (uint16_t)(bj * 32 + (uint32_t)arg);
+                        }
+                    }
+                }
+            }
+            }
+        }
+        PHASE(8);
+        // ---------------- the violating proposal itself (reference: counted, G[i] moved, acc bumped -- then error(...), :120-124):
+        // what zz_local_run_kernel and the oracle leave behind
+        if (vsel >= 0) {
+            if (g == vsel && gl == self) ri->tprop = uniform_f64(SLT[vsel]);
+            dnum += 1;
+            vnacc = 1;
+            dnm += ((uint32_t)(offpack >> (6 * vsel)) & 63u) + 1u - ((uint32_t)(offpack >> (6 * Rc)) & 63u);
+        }
+        // ---------------- counters
+        if (Rc > 0) {
+            dnum += Rc;
+            dnacc += nacc_c;
+            dnm += (uint32_t)(offpack >> (6 * Rc)) & 63u;
+            t_last = uniform_f64(SLT[Rc - 1]);
+            if (accball2) t_event = uniform_f64(SLT[(63 - __builtin_clzll(accball2)) >> 3]);
+        }
+        if (vsel >= 0) t_last = uniform_f64(SLT[vsel]);  // the violating event's time is the chain's current time
+        if (status != PDMP_CHAIN_OK) break;
+        LDS_ORDER();
+    }
+
+    if (PROF && P.dbg && chain == 0 && lane == 0) {
+        for (int q = 0; q < 10; ++q) P.dbg[q] = (double)ph[q];
+        P.dbg[10] = (double)ph_iters;
+    }
+#undef PHASE
+    if (lane == 0) {
+        hdr->c.t_last = t_last;
+        hdr->t_event = t_event;
+        hdr->c.num += dnum;
+        hdr->c.nacc += dnacc + vnacc;
+        hdr->c.ntrace = ntrace0 + dnacc;
+        hdr->c.nevents += dnacc;
+        hdr->c.ndraw_main = nm0 + dnm;
+        hdr->c.status = status;
+    }
+}
+
+
 // ------------------------------------------------------------------------------------------ speculative sticky loop
 //
 // zz_local_spec_kernel's scheme (up to 4 events of one chain per iteration, one per 16-lane row, exact validation, commit of
@@ -3064,12 +3774,42 @@ __global__ __launch_bounds__(256) void zz_unpack_kernel(const ZzRec* rec, const 
     if (c) c[o] = c_src[(chain_first + n) * c_stride + i];
 }
 
+// Final state of tracked-gradient chains in the reference's terms (src/sfact.jl:211: per-coordinate lazy clocks t, positions AT those
+// clocks, velocities): the reference's t[j] is the time of the last proposal inside G[j] or of the last accepted event inside S[j] (an
+// accept moves G2 as well, :129), whichever is later -- both are kept per coordinate (tprop, tacc); x[j] is the tracked position moved
+// linearly from its own clock to that time.
+__global__ __launch_bounds__(256) void zz_track_unpack_kernel(const TrRec* rec0, ZzTables tb, const double* c_src, int64_t c_stride, int64_t d,
+                                                              int64_t chain_first, double t0, double* t, double* x, double* th,
+                                                              int64_t* acc, double* c) {
+    const int64_t n = blockIdx.x;
+    const int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x;
+    if (i >= d) return;
+    const TrRec* rec = rec0 + (chain_first + n) * d;
+    const TrRec r = rec[i];
+    double tr = t0;
+    const uint32_t k = tb.colptr[i + 1] - tb.colptr[i];
+    const uint32_t s0 = tb.sptr[i], s1 = tb.sptr[i + 1];
+    for (uint32_t p = s0; p < s1; ++p) {  // S[i] = G1[i] followed by G2[i]; the patterns are symmetric: j ∈ S[i] <=> i ∈ S[j]
+        const uint32_t j = tb.sidx[p];
+        const double tpj = rec[j].tprop, taj = rec[j].tacc;
+        if (p - s0 < k && tpj > tr) tr = tpj;
+        if (taj > tr) tr = taj;
+    }
+    const int64_t o = n * d + i;
+    if (t) t[o] = tr;
+    if (x) x[o] = r.x + r.th * (tr - r.tx);
+    if (th) th[o] = r.th;
+    if (acc) acc[o] = (int64_t)r.acc;
+    if (c) c[o] = c_src[(chain_first + n) * c_stride + i];
+}
+
 // Batch means of the exact path integral: J = I + ∫_t^T (x + θ(s-t)) ds, Y = (J - Jprev)/ΔT per chain,
 // ΣY and ΣY² over chains.  Threads own a coordinate and walk a group of chains (records are 64 B, so a
 // warp of consecutive coordinates reads consecutive sectors).
-__global__ __launch_bounds__(256) void zz_batch_means_kernel(const ZzRec* rec, double* jprev, int64_t d,
+__global__ __launch_bounds__(256) void zz_batch_means_kernel(const ZzRec* rec0, int64_t rec_stride, double* jprev, int64_t d,
                                                              int64_t nchains, int64_t chains_per_group,
                                                              double T_prev, double T, double* sum_y, double* sum_y2) {
+    // (rec_stride: 64 for ZzRec, 128 for TrRec, whose first sector has the same fields)
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= d) return;
     const int64_t c0 = (int64_t)blockIdx.y * chains_per_group;
@@ -3077,7 +3817,7 @@ __global__ __launch_bounds__(256) void zz_batch_means_kernel(const ZzRec* rec, d
     const double inv = 1.0 / (T - T_prev);
     double s1 = 0.0, s2 = 0.0;
     for (int64_t ch = c0; ch < c1; ++ch) {
-        const ZzRec* r = rec + ch * d + i;
+        const ZzRec* r = reinterpret_cast<const ZzRec*>(reinterpret_cast<const char*>(rec0) + (ch * d + i) * rec_stride);
         const double dt = T - r->t;
         const double J = r->I + dt * (r->x + r->th * (dt * 0.5));
         const double y = (J - jprev[ch * d + i]) * inv;
@@ -3092,8 +3832,9 @@ __global__ __launch_bounds__(256) void zz_batch_means_kernel(const ZzRec* rec, d
 // ESS accumulators (pdmp_ensemble_ess_*): mode 0 snapshots J(T) of every (chain, coordinate) into jprev AND jstart; mode 1 is a
 // batch -- Y = (J − jprev)/ΔT, jprev = J, acc[0] += Y, acc[1] += Y² --; mode 2 closes the run -- the chain's own mean over the
 // whole run M = (J − jstart)/(T − T0), acc[2] += M, acc[3] += M² (jprev / jstart untouched).  acc is [4 x d].
-__global__ __launch_bounds__(256) void zz_ess_kernel(const ZzRec* rec, double* jprev, double* jstart, int64_t d, int64_t nchains,
-                                                     int64_t chains_per_group, int mode, double T_prev, double T, double* acc) {
+__global__ __launch_bounds__(256) void zz_ess_kernel(const ZzRec* rec0, int64_t rec_stride, double* jprev, double* jstart, int64_t d,
+                                                     int64_t nchains, int64_t chains_per_group, int mode, double T_prev, double T,
+                                                     double* acc) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= d) return;
     const int64_t c0 = (int64_t)blockIdx.y * chains_per_group;
@@ -3101,7 +3842,7 @@ __global__ __launch_bounds__(256) void zz_ess_kernel(const ZzRec* rec, double* j
     const double inv = (mode == 0) ? 0.0 : 1.0 / (T - T_prev);
     double s1 = 0.0, s2 = 0.0;
     for (int64_t ch = c0; ch < c1; ++ch) {
-        const ZzRec* r = rec + ch * d + i;
+        const ZzRec* r = reinterpret_cast<const ZzRec*>(reinterpret_cast<const char*>(rec0) + (ch * d + i) * rec_stride);
         const double dt = T - r->t;
         const double J = r->I + dt * (r->x + r->th * (dt * 0.5));
         if (mode == 0) {
@@ -3265,23 +4006,49 @@ int launch_zz_unpack(const ZzRec* rec, const double* c_src, int64_t c_stride, in
     return (int)hipGetLastError();
 }
 
-int launch_zz_batch_means(const ZzRec* rec, double* jprev, int64_t d, int64_t nchains, double T_prev, double T,
+int launch_zz_track_unpack(const TrRec* rec, const ZzTables& tb, const double* c_src, int64_t c_stride, int64_t d, int64_t chain_first,
+                           int64_t n, double t0, double* t, double* x, double* th, int64_t* acc, double* c, void* stream) {
+    dim3 grid((unsigned)n, (unsigned)((d + 255) / 256));
+    hipLaunchKernelGGL(zz_track_unpack_kernel, grid, dim3(256), 0, (hipStream_t)stream, rec, tb, c_src, c_stride, d, chain_first, t0, t, x,
+                       th, acc, c);
+    return (int)hipGetLastError();
+}
+
+bool zz_spec8_geometry(const ZzRunParams& p) {
+    return p.blob_sw == 7 && p.blob_pw == 1 && p.blob_kmax == 5 && p.blob_w_pad == 58 && !p.has_refresh && p.d >= 2048 &&
+           p.d <= (int64_t)S8_NBLK * 32;
+}
+
+int launch_zz_local_track(const ZzRunParams& p, int64_t nchains, void* stream) {
+    if (!zz_spec8_geometry(p)) return -1;
+    dim3 grid((unsigned)nchains), block(64);
+    ZzRunParams q = p;
+    q.nblk = (uint32_t)((p.d + 31) / 32);
+    const bool plain = !p.adapt && p.c_chain == nullptr && p.tb.gmu_t == nullptr && !p.track_two_sums;
+    if (p.dbg && plain) hipLaunchKernelGGL((zz_local_track_kernel<true>), grid, block, zz_spec8_lds_bytes(), (hipStream_t)stream, q);
+    else if (p.dbg) hipLaunchKernelGGL((zz_local_track_kernel<true, true>), grid, block, zz_spec8_lds_bytes(), (hipStream_t)stream, q);
+    else if (plain) hipLaunchKernelGGL((zz_local_track_kernel<false>), grid, block, zz_spec8_lds_bytes(), (hipStream_t)stream, q);
+    else hipLaunchKernelGGL((zz_local_track_kernel<false, true>), grid, block, zz_spec8_lds_bytes(), (hipStream_t)stream, q);
+    return (int)hipGetLastError();
+}
+
+int launch_zz_batch_means(const ZzRec* rec, int64_t rec_stride, double* jprev, int64_t d, int64_t nchains, double T_prev, double T,
                           double* sum_y, double* sum_y2, void* stream) {
     const int64_t groups = (nchains < 64) ? 1 : 64;
     const int64_t per = (nchains + groups - 1) / groups;
     dim3 grid((unsigned)((d + 255) / 256), (unsigned)groups);
-    hipLaunchKernelGGL(zz_batch_means_kernel, grid, dim3(256), 0, (hipStream_t)stream, rec, jprev, d, nchains, per,
+    hipLaunchKernelGGL(zz_batch_means_kernel, grid, dim3(256), 0, (hipStream_t)stream, rec, rec_stride, jprev, d, nchains, per,
                        T_prev, T, sum_y, sum_y2);
     return (int)hipGetLastError();
 }
 
-int launch_zz_ess(const ZzRec* rec, double* jprev, double* jstart, int64_t d, int64_t nchains, int mode, double T_prev, double T,
-                  double* acc, void* stream) {
+int launch_zz_ess(const ZzRec* rec, int64_t rec_stride, double* jprev, double* jstart, int64_t d, int64_t nchains, int mode, double T_prev,
+                  double T, double* acc, void* stream) {
     const int64_t groups = (nchains < 64) ? 1 : 64;
     const int64_t per = (nchains + groups - 1) / groups;
     dim3 grid((unsigned)((d + 255) / 256), (unsigned)groups);
-    hipLaunchKernelGGL(zz_ess_kernel, grid, dim3(256), 0, (hipStream_t)stream, rec, jprev, jstart, d, nchains, per, mode, T_prev, T,
-                       acc);
+    hipLaunchKernelGGL(zz_ess_kernel, grid, dim3(256), 0, (hipStream_t)stream, rec, rec_stride, jprev, jstart, d, nchains, per, mode,
+                       T_prev, T, acc);
     return (int)hipGetLastError();
 }
 

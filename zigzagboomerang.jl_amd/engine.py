@@ -97,6 +97,10 @@ class Ensemble:
         """c::LocalBound, src/local.jl: bounds from the target's own derivatives with an expiry horizon."""
         _lib.check(self._L.pdmp_ensemble_set_local_bound(self._h, int(bool(enable))))
 
+    def set_gradient_tracking(self, enable=True):
+        """Tracked gradients (include/pdmp_mi355.h): same event sequence, half the HBM traffic, floats to ~1e-13 instead of bit for bit."""
+        _lib.check(self._L.pdmp_ensemble_set_gradient_tracking(self._h, int(bool(enable))))
+
     def set_adaptscale(self, enable=True):
         """spdmp(...; adaptscale=true), src/sfact.jl:86-99: σ becomes per-chain state tuned in the refresh branch."""
         _lib.check(self._L.pdmp_ensemble_set_adaptscale(self._h, int(bool(enable))))

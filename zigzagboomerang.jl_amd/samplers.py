@@ -29,14 +29,16 @@ def _drain(ens, events):
 
 
 def spdmp(target, t0, x0, θ0, T, c, F, *, factor=1.8, adapt=False, adaptscale=False, seed=DEFAULT_SEED, device=0,
-          trace_capacity=None, trace=True):
+          trace_capacity=None, trace=True, tracked=False):
     """Local ZigZag: spdmp(∇ϕ, t0, x0, θ0, T, c, F::ZigZag, args...) with G = Matched() (src/sfact.jl:214).
     Returns Ξ, (t, x, θ), (acc, num), c like the reference (:211).
 
     adaptscale=True (src/sfact.jl:86-99) tunes σ in the refresh branch.  Like the reference, a single-chain call mutates
-    F.σ in place; for an ensemble every chain's tuned σ is the `σ` of the flow attached to its trace (Ξ[k].F.σ)."""
+    F.σ in place; for an ensemble every chain's tuned σ is the `σ` of the flow attached to its trace (Ξ[k].F.σ).
+
+    tracked=True (engine-only keyword): the tracked-gradient evaluation of the same process (pdmp_ensemble_set_gradient_tracking)."""
     return _zigzag(_lib.SAMPLER_ZIGZAG_LOCAL, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, trace_capacity, trace,
-                   adaptscale=adaptscale)
+                   adaptscale=adaptscale, tracked=tracked)
 
 
 def pdmp(target, t0, x0, θ0, T, c, F, *, factor=1.8, adapt=False, subsample=False, seed=DEFAULT_SEED, device=0,
@@ -70,7 +72,7 @@ def sspdmp(target, t0, x0, θ0, T, c, F, κ, *, reversible=False, strong_upperbo
 
 
 def _zigzag(sampler, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, trace_capacity, trace, sticky=None,
-            adaptscale=False):
+            adaptscale=False, tracked=False):
     if not isinstance(F, (ZigZag, FactBoomerang)):
         raise TypeError("the device path supports F::ZigZag and F::FactBoomerang")
     if not isinstance(target, (GaussianTarget, LogisticTarget)):
@@ -99,6 +101,8 @@ def _zigzag(sampler, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, 
             ens.set_adaptscale(True)
         if local_bound:
             ens.set_local_bound(True)
+        if tracked:
+            ens.set_gradient_tracking(True)
         ens.set_state(t0, X0, TH0, c, seeds)
         events = [[] for _ in range(nch)]
         while True:
