@@ -21,6 +21,8 @@ for nch in (256, 1024, 4096):
     ens = pkg.Ensemble(nch, d, trace_capacity=40000)
     ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
     ens.set_target(pkg.GaussianTarget(G))
+    if os.environ.get("TRACK"):
+        ens.set_gradient_tracking(True)  # TRACK=1: the tracked-gradient kernel (same phases)
     ens.set_state_synthetic(0.0, c, 0x5EED0000)
     ens.run(0.5, pkg._lib.RUN_STOP_BEFORE)
     ens.trace_reset()
