@@ -155,3 +155,55 @@ def test_tracking_is_refused_where_it_does_not_apply(gpu_pkg):
         with pytest.raises(L.PdmpError) as ei:
             ens.set_state_synthetic(0.0, pkg.problems.column_norms(Gl), 1)
         assert ei.value.code == L.PDMP_ERR_UNSUPPORTED
+
+
+@pytest.fixture(scope="module")
+def c3_tracked(gpu_pkg):
+    """Config C3 at full size (d = 16384, 4096 chains) on the tracked-gradient kernel -- what bench.py times."""
+    pkg = gpu_pkg
+    G = pkg.problems.gmrf_precision(128)
+    d = G.shape[0]
+    c = pkg.problems.column_norms(G)
+    nch, T, cap = 4096, 1.0, 20000
+    runs = {}
+    for tracked in (True, False):
+        ens = pkg.Ensemble(nch, d, trace_capacity=cap)
+        ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
+        ens.set_target(pkg.GaussianTarget(G))
+        ens.set_gradient_tracking(tracked)
+        ens.set_state_synthetic(0.0, c, 0x5EED0000)
+        ens.run(T, pkg._lib.RUN_STOP_BEFORE)
+        runs[tracked] = (ens, ens.counters())
+    yield pkg, G, c, runs, T
+    for ens, _ in runs.values():
+        ens.close()
+
+
+def test_full_size_counters_equal_the_exact_kernel_for_every_chain(c3_tracked):
+    """4096 chains x d = 16384 to T = 1: the tracked kernel and the bit-identical moving kernel agree on EVERY chain's proposal count,
+    accept count, event count and number of draws consumed (integer bookkeeping of ~3·10⁸ proposals), all chains healthy."""
+    pkg, G, c, runs, T = c3_tracked
+    ct, ce = runs[True][1], runs[False][1]
+    assert np.all(ct["status"] == pkg._lib.CHAIN_OK) and np.all(ce["status"] == pkg._lib.CHAIN_OK)
+    for f in ("num", "nacc", "nevents", "ntrace", "ndraw_main"):
+        assert np.array_equal(ct[f], ce[f]), f
+    assert close(ct["t_last"], ce["t_last"])
+    assert ct["num"].sum() > 2.0e8
+
+
+def test_full_size_traces_and_states_against_exact_kernel_and_oracle(c3_tracked):
+    pkg, G, c, runs, T = c3_tracked
+    d = G.shape[0]
+    (et, ct), (ee, ce) = runs[True], runs[False]
+    for k in (0, 1, 1234, 4095):
+        a, b = et.trace(k, counters=ct), ee.trace(k, counters=ce)
+        assert np.array_equal(a["i"], b["i"]) and np.array_equal(a["theta"], b["theta"]) and close(a["t"], b["t"]) and close(a["x"], b["x"])
+        fa, fb = et.final_state(k, 1), ee.final_state(k, 1)
+        assert np.array_equal(fa["acc"], fb["acc"]) and np.array_equal(fa["theta"], fb["theta"])
+        assert close(fa["t"], fb["t"]) and close(fa["x"], fb["x"])  # the rebuilt lazy clocks are the reference's
+    x0, th0 = O.synthetic_state(0x5EED0000, d)
+    r = O.spdmp_zigzag(G, None, G, x0, th0, c, T, seed=0x5EED0000, stop_before_T=True)
+    ev = et.trace(0, counters=ct)
+    assert len(ev) == len(r["events"]) and int(ct["num"][0]) == r["num"]
+    assert np.array_equal(ev["i"], r["events"]["i"]) and close(ev["t"], r["events"]["t"]) and close(ev["x"], r["events"]["x"])
+    assert float(np.max(np.abs(ev["t"] - r["events"]["t"]))) < 1e-11
