@@ -492,14 +492,11 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             tp = json.load(open(tpath))
-            ent = tp.get("configs", {}).get(args.config)
+            ent = tp.get("configs", {}).get("C3X" if (args.config == "C3" and args.exact) else args.config)
             if ent and tp.get("source_hash") == source_hash():
                 units = {"proposal": num, "event": nev}[ent["per"]]
                 traffic = ent["hbm_bytes_per_unit"] * units / nlaunch
                 traffic_src = ent.get("source")
-        # the measured ceiling for scattered 32-byte sectors (tools/sector_probe.py): what the traffic above can at most run at
-        spath = os.path.join(ROOT, "profiles", "r01_sector_probe.json")
-        scattered = json.load(open(spath)) if (os.path.exists(spath) and args.config == "C3") else None
         out = {
             "metric": W["metric"],
             "value": nev_all / elapsed,
@@ -522,9 +519,6 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": W["kernel"], "kernel_ms_avg": k_ms, "launches_per_step": nlaunch / args.steps,
                          "traffic_GBps": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
-                         "scattered_sector_ceiling_GBps": ({"read": scattered["read_GBps"],
-                                                            "read+writeback": scattered["read_plus_writeback_GBps"]}
-                                                           if scattered else None),
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "model": W["model"]},
         }
