@@ -28,6 +28,9 @@ pdmp_status pdmp_debug_set_spec_g2(pdmp_ensemble* ens, int on);
  * kind 2 (general kernel) [0..6] select, move G1, gradient, coin + G2, re-bound, re-queue, tail, [10] proposals. */
 pdmp_status pdmp_debug_set_phase_profile(pdmp_ensemble* ens, int on);
 pdmp_status pdmp_debug_phase_profile(pdmp_ensemble* ens, double* out16, int* kind);
+/* gradient tracking: keep the 8-lane-group kernel (zz_local_track_kernel) where the one-proposal-per-lane kernel (zz_local_trackw_kernel)
+ * would run -- both commit the same sequence */
+pdmp_status pdmp_debug_set_track_groups(pdmp_ensemble* ens, int on);
 /* one-event kernel: print the first n proposals of chain 0 to stderr during the next run */
 pdmp_status pdmp_debug_set_proposal_dump(pdmp_ensemble* ens, int64_t n);
 

@@ -111,8 +111,10 @@ struct pdmp_ensemble {
     double dbg_phase_out[16] = {0};
     int dbg_phase_valid = 0;
     int64_t dbg_dump = 0;          // dump the first n proposals of chain 0 (one-event kernel) to stderr
+    int dbg_track_groups = 0;      // gradient tracking: keep the 8-lane-group kernel where the one-proposal-per-lane kernel would run
     // tracked-gradient kernel (pdmp_ensemble_set_gradient_tracking)
     bool track_requested = false, track = false, track_two_sums = false;
+    int32_t lattice_n = 0;  // the flow's graph is the n x n 5-point lattice in column-major numbering (0: it is not)
     double t0_state = 0.0;
     DevBuf<double> d_jstart, d_essacc;  // pdmp_ensemble_ess_*
     double ess_T0 = 0.0, ess_Tlast = 0.0;
@@ -303,6 +305,11 @@ pdmp_status pdmp_debug_phase_profile(pdmp_ensemble* e, double* out16, int* kind)
     if (!e->dbg_phase_valid) return fail(PDMP_ERR_INVALID, "no phase profile recorded by the last run");
     memcpy(out16, e->dbg_phase_out, sizeof e->dbg_phase_out);
     if (kind) *kind = e->dbg_phase_valid;
+    return PDMP_OK;
+}
+pdmp_status pdmp_debug_set_track_groups(pdmp_ensemble* e, int on) {
+    if (!e) return fail(PDMP_ERR_INVALID, "null argument");
+    e->dbg_track_groups = on ? 1 : 0;
     return PDMP_OK;
 }
 pdmp_status pdmp_debug_set_proposal_dump(pdmp_ensemble* e, int64_t n) {
@@ -790,6 +797,30 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
         if (!sym) return fail(PDMP_ERR_UNSUPPORTED, "gradient tracking needs symmetric precision matrices (flow and target)");
         e->track_two_sums = two;
         e->track = true;
+        // the n x n 5-point lattice in column-major numbering (scripts/gridlaplace.jl): G1[i] = {i-n, i-1, i, i+1, i+n} inside the grid
+        e->lattice_n = 0;
+        {
+            int64_t nl = (int64_t)std::llround(std::sqrt((double)d));
+            bool lat = nl * nl == d && nl >= 16 && nl <= 128;
+            for (int64_t col = 0; lat && col < nl; ++col)
+                for (int64_t row = 0; lat && row < nl; ++row) {
+                    const int64_t ii = row + nl * col;
+                    uint32_t want[5];
+                    int nw = 0;
+                    if (col > 0) want[nw++] = (uint32_t)(ii - nl);
+                    if (row > 0) want[nw++] = (uint32_t)(ii - 1);
+                    want[nw++] = (uint32_t)ii;
+                    if (row < nl - 1) want[nw++] = (uint32_t)(ii + 1);
+                    if (col < nl - 1) want[nw++] = (uint32_t)(ii + nl);
+                    if ((int64_t)(e->colptr[ii + 1] - e->colptr[ii]) != nw) {
+                        lat = false;
+                        break;
+                    }
+                    for (int q = 0; q < nw; ++q)
+                        if (e->rowval[e->colptr[ii] + q] != want[q]) lat = false;
+                }
+            if (lat) e->lattice_n = (int32_t)nl;
+        }
     }
     pdmp_status st = alloc_state(e);
     if (st != PDMP_OK) return st;
@@ -1049,7 +1080,11 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
     if (e->track) {
         if (dbg_cap > 0) return fail(PDMP_ERR_UNSUPPORTED, "the proposal dump belongs to the one-event kernel");
         P.track_two_sums = e->track_two_sums ? 1 : 0;
-        int rct = pdmp::launch_zz_local_track(P, e->cfg.nchains, s);
+        P.lattice_n = e->lattice_n;
+        P.lattice_magic = e->lattice_n ? (uint32_t)(((uint64_t)1 << 32) / (uint64_t)e->lattice_n + 1) : 0u;
+        // one proposal per lane where the graph is the plain lattice (pdmp_trackw.hip); PDMP_DEBUG_KERNEL_SPEC4 keeps the 8-lane-group kernel
+        const bool wide = pdmp::zz_trackw_supported(P) && e->dbg_track_groups == 0;
+        int rct = wide ? pdmp::launch_zz_local_trackw(P, e->cfg.nchains, s) : pdmp::launch_zz_local_track(P, e->cfg.nchains, s);
         if (rct != 0) return fail(PDMP_ERR_HIP, "zz_local_track launch failed (%d)", rct);
         HIP_TRY(hipEventRecord(e->ev1, s));
         e->timed = true;

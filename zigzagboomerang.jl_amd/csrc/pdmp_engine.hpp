@@ -102,6 +102,8 @@ struct ZzRunParams {
     int32_t move_all;  // G = All(): the `pdmp` driver for ZigZag (src/sfact.jl:236)
     int32_t force_spec4;  // diagnostics (pdmp_debug_set_kernel): keep the 4-event kernel where the 8-event one would run
     int32_t track_two_sums;  // tracked-gradient kernel: the bounding Γ differs from the target's (two pairs of sums per coordinate)
+    int32_t lattice_n;       // n if the graph is the n x n 5-point lattice in column-major numbering (i = row + n col), else 0
+    uint32_t lattice_magic;  // ceil(2^32 / n): column of i = umulhi(i, magic) for i < 2^16
     // sticky ZigZag (src/ss_fact.jl)
     const double* __restrict__ kappa;  // [d] thaw rates
     double* thf;                       // [nchains x d] saved speeds θf
@@ -220,6 +222,8 @@ int launch_zz_unpack(const ZzRec* rec, const double* c_src, int64_t c_stride, in
 int launch_zz_batch_means(const ZzRec* rec, int64_t rec_stride, double* jprev, int64_t d, int64_t nchains, double T_prev, double T,
                           double* sum_y, double* sum_y2, void* stream);
 int launch_zz_local_track(const ZzRunParams& p, int64_t nchains, void* stream);
+int launch_zz_local_trackw(const ZzRunParams& p, int64_t nchains, void* stream);  // pdmp_trackw.hip: one proposal per lane
+bool zz_trackw_supported(const ZzRunParams& p);
 bool zz_spec8_geometry(const ZzRunParams& p);  // the 8-event kernels' requirements on the neighbourhood blob and on d
 int launch_zz_track_unpack(const TrRec* rec, const ZzTables& tb, const double* c_src, int64_t c_stride, int64_t d, int64_t chain_first,
                            int64_t n, double t0, double* t, double* x, double* th, int64_t* acc, double* c, void* stream);
