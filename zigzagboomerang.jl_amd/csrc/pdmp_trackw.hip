@@ -157,6 +157,12 @@ constexpr uint32_t W_BYTES = 9624;
 constexpr uint32_t W_NBLK = 512;
 constexpr int W_CMAX = 56;           // candidates per iteration (7 block-scan passes of 8)
 constexpr int W_AMAX = 8;            // accepted events per iteration (one group each)
+// steering of the selection threshold (measured: 1.3 / 0.85 / 6 is 3 % slower, 1.1 / 0.7 / 2 as well)
+#ifndef W_GROW
+#define W_GROW 1.15
+#define W_SHRINK 0.8
+#define W_SLACK 3u
+#endif
 static_assert(W_BYTES <= 10240, "16 chains per CU: 160 KB / 16");
 
 template <bool PROF>
@@ -473,24 +479,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const uint64_t accball = __ballot(acc);
         const int nacc_it = __popcll(accball);
         if (acc) ACL[__popcll(accball & ((1ull << lane) - 1ull))] = (uint16_t)lane;
-        // ---------------- the re-bound of a rejected proposal (:137-140), by its own lane
-        double a2, b2, key2;
-        {
-            const double L = pdmp_log(U[(dnm + off + 1u) & 255u]);
-            a2 = c_i + g_now * th;
-            b2 = c_i / 100 + th * gd_i;
-            key2 = tp + w_poisson_time_L(a2, b2, L);
-        }
-        // new minimum of the popped block of a rejected event, and what the event exposes
-        double rowmin = W_INF;
-        uint32_t cand = i;
-        if (ev && !acc) {
-            const double rest = RM[lane];
-            const uint32_t rarg = RC[lane];
-            const bool mine = key2 < rest || (key2 == rest && i < rarg);
-            rowmin = mine ? key2 : rest;
-            cand = mine ? i : rarg;
-        }
         W_ORDER();
         WPHASE(2);
         // ---------------- accepted events, one 8-lane group each: members of G1[i] (ascending, :131-135)
@@ -531,6 +519,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const uint64_t acc_ia = ria->acc;
         const double thj0 = rj->th, gj0 = rj->g, gdj0 = rj->gd, tgj = rj->tg;
         const double cjm = P.tb.c_shared[jm];
+        const double2* const kpa = reinterpret_cast<const double2*>(keys + (size_t)blka * 32 + gl * 4);
+        const double2 ka01 = kpa[0], ka23 = kpa[1];  // the popped block of the accepted event (patched below)
+        // (the loads of the accepted events' groups are in flight: the rejected proposals' re-bounds -- logarithm, divisions, square root, no memory -- run under them)
+        // ---------------- the re-bound of a rejected proposal (:137-140), by its own lane
+        double a2, b2, key2;
+        {
+            const double L = pdmp_log(U[(dnm + off + 1u) & 255u]);
+            a2 = c_i + g_now * th;
+            b2 = c_i / 100 + th * gd_i;
+            key2 = tp + w_poisson_time_L(a2, b2, L);
+        }
+        // new minimum of the popped block of a rejected event, and what the event exposes
+        double rowmin = W_INF;
+        uint32_t cand = i;
+        if (ev && !acc) {
+            const double rest = RM[lane];
+            const uint32_t rarg = RC[lane];
+            const bool mine = key2 < rest || (key2 == rest && i < rarg);
+            rowmin = mine ? key2 : rest;
+            cand = mine ? i : rarg;
+        }
         double keyj = W_INF, aj = 0.0, bj = 0.0, gj = 0.0, gdj = 0.0;
         const bool selfl = mem && jm == ia;
         {
@@ -555,9 +564,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         uint32_t cand_a = 0;
         int wl_a = -1;
         {
-            const double2* kp = reinterpret_cast<const double2*>(keys + (size_t)blka * 32 + gl * 4);
-            const double2 k01 = kp[0], k23 = kp[1];
-            double kq[4] = {k01.x, k01.y, k23.x, k23.y};
+            double kq[4] = {ka01.x, ka01.y, ka23.x, ka23.y};
 #pragma unroll
             for (int m = 0; m < 5; ++m) {
                 const uint32_t src = (uint32_t)(lane & ~7) + (uint32_t)m;
@@ -735,7 +742,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         // steer the selection threshold by what commits: two popped blocks whose SECOND keys fall inside the window end the prefix (only block
         // minima are candidates), which caps it near sqrt(#blocks); candidates far beyond that are wasted work
         if (lane == 0)
-            SELDT[0] = dt_used * ((Rc >= (uint32_t)Csel) ? 1.3 : ((Rc + 6u < (uint32_t)Csel) ? 0.85 : 1.0));
+            SELDT[0] = dt_used * ((Rc >= (uint32_t)Csel) ? W_GROW : ((Rc + W_SLACK < (uint32_t)Csel) ? W_SHRINK : 1.0));
         // ---------------- counters; the violating proposal itself (counted, acc bumped, then error(...), :120-124)
         if (Rc > 0u) {
             const uint32_t costL = (uint32_t)__builtin_amdgcn_readlane((int)cost, (int)(Rc - 1u));
