@@ -1,7 +1,8 @@
 // gmrf_spdmp.cpp -- the reference's scripts/gaussianrandomfield.jl (local ZigZag on a grid-Laplace GMRF, :15-41) written
 // against the C++ host mirror include/pdmp_mi355.hpp:   Γ = 0.01 I + gridlaplacian(n, n) (scripts/gridlaplace.jl:4-21),
 // ∇ϕ(x, i, Γ) = idot(Γ, i, x), Z = ZigZag(Γ, 0), c[i] = ‖Γ[:, i]‖₂, spdmp(∇ϕ, t0, x0, θ0, T, c, Z, Γ).
-//   usage: gmrf_spdmp [n=16] [T=20] [seed]      prints one line: d events num acc fnv1a64(payload) t_last
+//   usage: gmrf_spdmp [n=16] [T=20] [seed] [tracked]      prints one line: d events num acc fnv1a64(payload) t_last
+//   (a 4th argument selects the tracked-gradient evaluation, Options::tracked: n x n lattices with n*n >= 2048)
 // tests/test_gpu_cpp_host.py runs it on the GPU box and checks the line against the CPU oracle.
 #include <cinttypes>
 #include <cmath>
@@ -46,6 +47,7 @@ int main(int argc, char** argv) {
     const double T = argc > 2 ? std::atof(argv[2]) : 20.0;
     pdmp::Options opt;
     if (argc > 3) opt.seed = std::strtoull(argv[3], nullptr, 0);
+    if (argc > 4) opt.tracked = true;
     try {
         pdmp::ZigZag Z;
         Z.Gamma = gmrf_precision(n, 0.01);

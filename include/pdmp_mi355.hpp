@@ -54,16 +54,20 @@ struct FactBoomerang {
     std::vector<double> mu, sigma;
     double lambda_ref = 0.1, rho = 0.0;
 };
-// BouncyParticle(Γ, μ, λ; ρ=0)  src/types.jl:35-45 (mass L = I)
+// BouncyParticle(Γ, μ, λ, ρ, U, L)  src/types.jl:35-45.  L is the mass factor the reference's short constructor computes as
+// cholesky(Symmetric(Γ)).L (:43): LOWER triangular CSC with a stored diagonal; leave it empty (n == 0) only for Γ = I -- the engine refuses a
+// general Γ without its factor (PDMP_ERR_UNSUPPORTED) instead of running with a silent L = I.
 struct BouncyParticle {
     SparseCSC Gamma;
     std::vector<double> mu;
     double lambda_ref = 1.0, rho = 0.0;
+    SparseCSC L;
 };
-// Boomerang(I, μ, λ; ρ=0)  src/types.jl:59-66 (identity mass only)
+// Boomerang(Γ, μ, λ; ρ=0)  src/types.jl:59-66: Γ enters through its factor L only (empty: identity)
 struct Boomerang {
     std::vector<double> mu;
     double lambda_ref = 1.0, rho = 0.0;
+    SparseCSC L;
 };
 // ∇ϕ(x, i, Γ) = idot(Γ, i, x) [- idot(Γ, i, μ)]  (scripts/gaussianrandomfield.jl:25)
 struct GaussianTarget {
@@ -83,7 +87,11 @@ struct Options {  // the reference's keyword arguments
     double factor = 1.8;
     bool adapt = false;
     bool adaptscale = false;
-    bool local_bound = false;  // c is LocalBound(c): spdmp(∇ϕ, t0, x0, θ0, T, C::LocalBound, F, args...), src/local.jl:95-149
+    bool local_bound = false;  // c is LocalBound(c): spdmp(∇ϕ, t0, x0, θ0, T, C::LocalBound, F, args...), src/local.jl:95-149; for the
+                               // non-factorised pdmp: src/not_fact_samplers.jl:29-31,65-71
+    bool subsample = false;    // pdmp(∇ϕ!, ...; subsample) of the non-factorised samplers, src/not_fact_samplers.jl:53,90
+    bool tracked = false;      // engine-only: tracked-gradient evaluation of spdmp (pdmp_ensemble_set_gradient_tracking): same event
+                               // indices / counters / bounds, floats to ~1e-13 instead of bit for bit
     uint64_t seed = 0x5EED0000ull;
     int device = 0;
     int64_t trace_capacity = 0;  // 0: sized from d and T, refilled on demand
@@ -201,6 +209,7 @@ Result<FactTrace> factorised(int sampler, const Target& target, double t0, const
     if (kappa) check(pdmp_ensemble_set_sticky(e.get(), kappa->data(), o.reversible ? 1 : 0, o.strong_upperbounds ? 1 : 0));
     if (o.adaptscale) check(pdmp_ensemble_set_adaptscale(e.get(), 1));
     if (o.local_bound) check(pdmp_ensemble_set_local_bound(e.get(), 1));
+    if (o.tracked) check(pdmp_ensemble_set_gradient_tracking(e.get(), 1));
     const uint64_t seed = o.seed;
     check(pdmp_ensemble_set_state(e.get(), t0, x0.data(), theta0.data(), c.data(), &seed));
     Result<FactTrace> R;
@@ -294,6 +303,8 @@ inline Result<PDMPTrace> pdmp(double t0, const std::vector<double>& x0, const st
     Ensemble e(1, d, PDMP_SAMPLER_BPS, o, cap);
     check(pdmp_ensemble_set_flow_bps(e.get(), B.Gamma.colptr.data(), B.Gamma.rowval.data(), B.Gamma.nzval.data(),
                                      detail::opt(B.mu), B.lambda_ref, B.rho));
+    if (B.L.n > 0) check(pdmp_ensemble_set_mass_cholesky(e.get(), B.L.colptr.data(), B.L.rowval.data(), B.L.nzval.data()));
+    if (o.local_bound || o.subsample) check(pdmp_ensemble_set_bps_options(e.get(), o.local_bound ? 1 : 0, o.subsample ? 1 : 0));
     return detail::not_factorised(e, t0, x0, theta0, T, c, o);
 }
 // pdmp(∇ϕ!, t0, x0, θ0, T, c, B::Boomerang; ...) with ∇ϕ!(y, x) = Γt(x − μt)  -- test/maintest.jl:139-154
@@ -306,6 +317,8 @@ inline Result<PDMPTrace> pdmp(const GaussianTarget& target, double t0, const std
     check(pdmp_ensemble_set_flow_boomerang(e.get(), target.Gamma.colptr.data(), target.Gamma.rowval.data(),
                                            target.Gamma.nzval.data(), detail::opt(target.mu), detail::opt(B.mu), B.lambda_ref,
                                            B.rho));
+    if (B.L.n > 0) check(pdmp_ensemble_set_mass_cholesky(e.get(), B.L.colptr.data(), B.L.rowval.data(), B.L.nzval.data()));
+    if (o.subsample) check(pdmp_ensemble_set_bps_options(e.get(), 0, 1));
     return detail::not_factorised(e, t0, x0, theta0, T, c, o);
 }
 

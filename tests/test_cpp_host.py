@@ -59,3 +59,32 @@ def test_cpp_spdmp_matches_oracle(gpu_pkg):
     h = _fnv1a(h, r["x"].tobytes() + r["theta"].tobytes() + r["t"].tobytes())
     assert int(h_s, 16) == h
     assert float(tl_s) == ev["t"][-1]
+
+
+@pytest.mark.gpu
+def test_cpp_spdmp_tracked_option(gpu_pkg):
+    """Options::tracked through the C++ mirror on a 48 x 48 lattice: the same number of events, proposals and accepted reflections as the
+    oracle and the same last event time to 1e-9 (the tracked evaluation is index-exact, not bit-exact: the payload hash differs from
+    the moving evaluation's, which the second run reproduces)."""
+    pkg = gpu_pkg
+    exe = _exe(pkg)
+    n, T, seed = 48, 4.0, 0x77
+    out = {}
+    for mode in ("tracked", "exact"):
+        args = [exe, str(n), repr(T), hex(seed)] + (["tracked"] if mode == "tracked" else [])
+        p = subprocess.run(args, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr
+        out[mode] = p.stdout.split()
+    G = pkg.problems.gmrf_precision(n, eps=0.01)
+    d = n * n
+    i = np.arange(d)
+    x0 = ((i * 37) % 101) / 50.0 - 1.0
+    th0 = np.where(i % 3 == 0, -1.0, 1.0)
+    Gc = G.tocsc()
+    c = np.array([np.sqrt(sum(v * v for v in Gc.data[Gc.indptr[k]:Gc.indptr[k + 1]])) for k in range(d)])
+    r = O.spdmp_zigzag(G, None, G, x0, th0, c, T, seed=seed)
+    for mode in ("tracked", "exact"):
+        d_s, nev_s, num_s, acc_s, h_s, tl_s = out[mode]
+        assert int(d_s) == d and int(nev_s) == len(r["events"]) and int(num_s) == r["num"] and int(acc_s) == int(r["acc"].sum())
+        assert abs(float(tl_s) - r["events"]["t"][-1]) <= 1e-9 * r["events"]["t"][-1]
+    assert float(out["exact"][5]) == r["events"]["t"][-1] and out["exact"][4] != out["tracked"][4]
