@@ -135,6 +135,14 @@ __device__ __forceinline__ double w_shfl(double v, uint32_t src) {
     return __hiloint2double(hi, lo);
 }
 
+// (second − first) key of a block as a 16-bit hint: units of 2^-20, rounded down, 65535 = "at least 0.0625 away (or unknown large)"
+__device__ __forceinline__ uint32_t w_qdelta(double delta) {
+    return (delta < 0.0624) ? (uint32_t)(delta * 1048576.0) : 65535u;  // (NaN from Inf − Inf compares false: 65535)
+}
+__device__ __forceinline__ double w_udelta(uint32_t q) {
+    return (q >= 65535u) ? W_INF : (double)q * (1.0 / 1048576.0);
+}
+
 }  // namespace
 
 // LDS layout (bytes)
@@ -146,14 +154,14 @@ constexpr uint32_t W_TK = 7680;      // [64] f64 candidate keys, compaction orde
 constexpr uint32_t W_RM = 8192;      // [64] f64 minimum of the popped block without its popped coordinate / patched minimum (accepted events)
 constexpr uint32_t W_SLB = 8704;     // [64] u16 event blocks, rank order
 constexpr uint32_t W_TB = 8832;      // [64] u16 candidate blocks, compaction order; later RC[e]: coordinate of RM[e]
-constexpr uint32_t W_ID = 8960;      // [64] u16 event coordinates
-constexpr uint32_t W_OFF = 9088;     // [64] u16 draw offsets of the events
-constexpr uint32_t W_ACL = 9216;     // [8] u16 the accepted events
-constexpr uint32_t W_RO = 9232;      // [64] u8 owner of each rank (duplicate detection)
-constexpr uint32_t W_CL = 9296;      // [64] u8 claims of the parallel first-level update
-constexpr uint32_t W_SELDT = 9360;   // f64 selection threshold above the minimum
-constexpr uint32_t W_CP = 9368;      // [64] u32 column pointers of the events' coordinates
-constexpr uint32_t W_BYTES = 9624;
+constexpr uint32_t W_D2R = 8960;     // [64] u16 (second − first) minimum of a popped block's other keys, quantised (hint)
+constexpr uint32_t W_ACL = 9088;     // [8] u16 the accepted events
+constexpr uint32_t W_RO = 9104;      // [64] u8 owner of each rank (duplicate detection); later the claims of the parallel first-level update
+constexpr uint32_t W_CL = W_RO;
+constexpr uint32_t W_SELDT = 9168;   // f64 selection threshold above the minimum
+constexpr uint32_t W_D2 = 9176;      // [512] u16 per block: (second smallest key − smallest key) in units of 2^-20, rounded DOWN, saturating -- a HINT
+                                     // that lets the selection stop where a popped block's second key would end the committable prefix anyway
+constexpr uint32_t W_BYTES = 10200;
 constexpr uint32_t W_NBLK = 512;
 constexpr int W_CMAX = 56;           // candidates per iteration (7 block-scan passes of 8)
 constexpr int W_AMAX = 8;            // accepted events per iteration (one group each)
@@ -185,13 +193,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     uint16_t* const SLB = reinterpret_cast<uint16_t*>(smem + W_SLB);
     uint16_t* const TB = reinterpret_cast<uint16_t*>(smem + W_TB);
     uint16_t* const RC = TB;
-    uint16_t* const ID = reinterpret_cast<uint16_t*>(smem + W_ID);
-    uint16_t* const OFF = reinterpret_cast<uint16_t*>(smem + W_OFF);
+    uint16_t* const D2 = reinterpret_cast<uint16_t*>(smem + W_D2);
+    uint16_t* const D2R = reinterpret_cast<uint16_t*>(smem + W_D2R);
     uint16_t* const ACL = reinterpret_cast<uint16_t*>(smem + W_ACL);
     uint8_t* const RO = reinterpret_cast<uint8_t*>(smem + W_RO);
     uint8_t* const CL = reinterpret_cast<uint8_t*>(smem + W_CL);
     double* const SELDT = reinterpret_cast<double*>(smem + W_SELDT);
-    uint32_t* const CP = reinterpret_cast<uint32_t*>(smem + W_CP);
 
     TrRec* const rec = reinterpret_cast<TrRec*>(P.rec) + chain * d;
     double* const keys = P.keys + chain * P.dk;
@@ -216,22 +223,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     if (lane == 0) SELDT[0] = 1e-3;
     for (uint32_t b = lane; b < nblk; b += 64) {
         const double* kp = keys + (size_t)b * 32;
-        double mk = kp[0];
+        double mk = kp[0], m2 = W_INF;
         uint32_t mi = 0;
 #pragma unroll 8
         for (int q = 1; q < 32; ++q) {
             const double v = kp[q];
             if (v < mk) {
+                m2 = mk;
                 mk = v;
                 mi = q;
+            } else if (v < m2) {
+                m2 = v;
             }
         }
         bk[b] = mk;
         bi[b] = (uint16_t)(b * 32 + mi);
+        D2[b] = (uint16_t)w_qdelta(m2 - mk);
     }
     for (uint32_t b = nblk + lane; b < W_NBLK; b += 64) {
         bk[b] = W_INF;
         bi[b] = 0;
+        D2[b] = 65535;
     }
     W_ORDER();
 
@@ -354,14 +366,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         W_ORDER();
         WPHASE(0);
         if (PROF) ph_iters += 1;
-        const int Csel = C;
+        const int Craw = C;
 
         // ---------------- lane r = event r: own record, neighbourhood size, c_i
         bool ev = lane < C;
         const double tp = ev ? SLT[lane] : W_INF;
         const uint32_t blk = ev ? (uint32_t)SLB[lane] : 0u;
         const uint32_t i = ev ? (uint32_t)bi[blk] : 0u;
-        ID[lane] = (uint16_t)i;
         const TrRec* const ri = rec + i;
         const double th = ri->th;
         const double g_i = ri->g, gd_i = ri->gd, tg_i = ri->tg;
@@ -372,6 +383,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         // lattice coordinates packed for the zone test: byte 0 = row, byte 1 = column
         const uint32_t col_i = __umulhi(i, nmagic);
         const uint32_t rc_i = (i - col_i * nlat) | (col_i << 8);
+        // ---------------- (the own-record loads are in flight) where would the committable prefix end anyway?  (a) zones: event r cannot
+        // commit with an earlier event whose G1 meets its own (Manhattan distance <= 2); (b) the second key of an earlier event's block, which
+        // becomes that block's minimum once its first is popped -- known approximately from the D2 hints (a lower bound: cuts early at worst).
+        // Candidates from the first such position on are dropped BEFORE their key blocks are read; the exact tests follow in `validate`.
+        {
+            uint64_t confb = 0;
+            for (int m = 0; m < C - 1; ++m) {
+                const uint32_t rcm = (uint32_t)__builtin_amdgcn_readlane((int)rc_i, m);
+                const uint32_t sad = __builtin_amdgcn_sad_u8(rc_i, rcm, 0u);
+                const uint64_t near = __ballot(sad <= 2u);
+                confb |= near & (~0ull << (m + 1));
+            }
+            const double lb2 = ev ? (tp + w_udelta((uint32_t)D2[blk])) : W_INF;
+            const double prevl = w_shfl(lb2, (uint32_t)((lane > 0) ? lane - 1 : 0));
+            const double pmin = w_scan_min_f64((lane > 0) ? prevl : W_INF);
+            const bool cut = ev && lane > 0 && (((confb >> lane) & 1ull) || !(pmin > tp));
+            const uint64_t cb = __ballot(cut);
+            if (cb) {
+                const int c0 = __ffsll((unsigned long long)cb) - 1;
+                C = (c0 < C) ? c0 : C;
+            }
+            ev = lane < C;
+            // steer the threshold so that the raw candidate list is just longer than what can commit
+            if (lane == 0) SELDT[0] = dt_used * ((C >= Craw) ? W_GROW : ((C + (int)W_SLACK < Craw) ? W_SHRINK : 1.0));
+        }
         // ---------------- popped blocks without their popped coordinate: 8 events per pass, one per 8-lane group (4 keys per lane)
         W_ORDER();
         {
@@ -385,7 +421,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                     const int e = 8 * (p0 + q) + g;
                     const bool eg = e < C;
                     be4[q] = eg ? (uint32_t)SLB[eg ? e : 0] : 0u;
-                    ie4[q] = eg ? (uint32_t)ID[eg ? e : 0] : 0xffffffffu;
+                    const uint32_t ib = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((uint32_t)(eg ? e : 0) << 2), (int)i);
+                    ie4[q] = eg ? ib : 0xffffffffu;
                     const double2* kp = reinterpret_cast<const double2*>(keys + (size_t)be4[q] * 32 + gl * 4);
                     k01[q] = kp[0];
                     k23[q] = kp[1];
@@ -400,26 +437,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                     if (c0 + 1u == ie4[q]) kq1 = W_INF;
                     if (c0 + 2u == ie4[q]) kq2 = W_INF;
                     if (c0 + 3u == ie4[q]) kq3 = W_INF;
-                    double lm = kq0;
+                    double lm = kq0, lm2 = W_INF;
                     uint32_t li = 0;
                     if (kq1 < lm) {
+                        lm2 = lm;
                         lm = kq1;
                         li = 1;
+                    } else {
+                        lm2 = kq1;
                     }
                     if (kq2 < lm) {
+                        lm2 = lm;
                         lm = kq2;
                         li = 2;
+                    } else if (kq2 < lm2) {
+                        lm2 = kq2;
                     }
                     if (kq3 < lm) {
+                        lm2 = lm;
                         lm = kq3;
                         li = 3;
+                    } else if (kq3 < lm2) {
+                        lm2 = kq3;
                     }
                     const double gm = w_grp8_min(lm);
                     const uint64_t winball = __ballot(eg && lm == gm);
                     const int wl = __ffs((unsigned)((winball >> (8 * g)) & 0xffu)) - 1;
+                    const double gm2 = w_grp8_min((gl == wl) ? lm2 : lm);  // the second smallest of the 31 other keys
                     if (eg && gl == wl) {
                         RM[e] = gm;
                         RC[e] = (uint16_t)(c0 + li);
+                        D2R[e] = (uint16_t)w_qdelta(gm2 - gm);
                     }
                 }
             }
@@ -474,8 +522,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
         ev = lane < C;
         acc = acc && ev;
-        OFF[lane] = (uint16_t)off;
-        CP[lane] = cp_i;
         const uint64_t accball = __ballot(acc);
         const int nacc_it = __popcll(accball);
         if (acc) ACL[__popcll(accball & ((1ull << lane) - 1ull))] = (uint16_t)lane;
@@ -484,9 +530,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         // ---------------- accepted events, one 8-lane group each: members of G1[i] (ascending, :131-135)
         const bool gact = g < nacc_it;
         const uint32_t ea = gact ? (uint32_t)ACL[g] : 0u;
-        const uint32_t ia = gact ? (uint32_t)ID[ea] : 0u;
+        const uint32_t ia_b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ea << 2), (int)i);
+        const uint32_t off_b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ea << 2), (int)off);
+        const uint32_t cp_b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ea << 2), (int)cp_i);
+        const uint32_t ia = gact ? ia_b : 0u;
         const double tpa = gact ? SLT[ea] : 0.0;
-        const uint32_t offa = gact ? (uint32_t)OFF[ea] : 0u;
+        const uint32_t offa = gact ? off_b : 0u;
         const uint32_t blka = gact ? (uint32_t)SLB[ea] : 0u;
         // G1[ia] on the lattice, ascending: {ia − n, ia − 1, ia, ia + 1, ia + n} inside the grid -- computed, so that the members' records are
         // requested at once; the CSC tables are read for the VALUES only (Γ[j, i] = Γ[i, j]: symmetric, checked on the host)
@@ -509,7 +558,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 }
             }
         }
-        const uint32_t cpa = gact ? CP[ea] : 0u;
+        const uint32_t cpa = gact ? cp_b : 0u;
         const double gam = mem ? P.tb.tval[cpa + (uint32_t)gl] : 0.0;
         TrRec* const rj = rec + jm;
         TrRec* const ria = rec + ia;
@@ -532,13 +581,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
         // new minimum of the popped block of a rejected event, and what the event exposes
         double rowmin = W_INF;
-        uint32_t cand = i;
+        uint32_t cand = i, d2new = 65535u;
         if (ev && !acc) {
             const double rest = RM[lane];
             const uint32_t rarg = RC[lane];
             const bool mine = key2 < rest || (key2 == rest && i < rarg);
             rowmin = mine ? key2 : rest;
             cand = mine ? i : rarg;
+            // hint for the next pop of this block: its second key is `rest` if the new key leads, else the smaller of the new key and the
+            // (lower bound of the) second of the rest
+            const double dr = w_udelta((uint32_t)D2R[lane]);
+            const double dk = key2 - rest;
+            d2new = mine ? w_qdelta(rest - key2) : w_qdelta((dk < dr) ? dk : dr);
         }
         double keyj = W_INF, aj = 0.0, bj = 0.0, gj = 0.0, gdj = 0.0;
         const bool selfl = mem && jm == ia;
@@ -561,7 +615,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
         // the popped block of the accepted event with the members' new keys patched in
         double rowmin_a = W_INF;
-        uint32_t cand_a = 0;
+        uint32_t cand_a = 0, d2_a = 65535u;
         int wl_a = -1;
         {
             double kq[4] = {ka01.x, ka01.y, ka23.x, ka23.y};
@@ -579,23 +633,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                     kq[3] = (w == 3u) ? kv : kq[3];
                 }
             }
-            double lm = kq[0];
+            double lm = kq[0], lm2 = W_INF;
             uint32_t li = 0;
             if (kq[1] < lm) {
+                lm2 = lm;
                 lm = kq[1];
                 li = 1;
+            } else {
+                lm2 = kq[1];
             }
             if (kq[2] < lm) {
+                lm2 = lm;
                 lm = kq[2];
                 li = 2;
+            } else if (kq[2] < lm2) {
+                lm2 = kq[2];
             }
             if (kq[3] < lm) {
+                lm2 = lm;
                 lm = kq[3];
                 li = 3;
+            } else if (kq[3] < lm2) {
+                lm2 = kq[3];
             }
             rowmin_a = w_grp8_min(lm);
             const uint64_t winball = __ballot(gact && lm == rowmin_a);
             wl_a = __ffs((unsigned)((winball >> (8 * g)) & 0xffu)) - 1;
+            d2_a = w_qdelta(w_grp8_min((gl == wl_a) ? lm2 : lm) - rowmin_a);
             cand_a = blka * 32u + (uint32_t)gl * 4u + li;
             const double keymin = w_grp8_min(keyj);
             if (gact && gl == 0) EX[ea] = w_min(rowmin_a, keymin);
@@ -609,14 +673,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             const double expo = ev ? EX[lane] : W_INF;
             const double prev = w_shfl(expo, (uint32_t)((lane > 0) ? lane - 1 : 0));
             const double pref = w_scan_min_f64((lane > 0) ? prev : W_INF);  // exclusive prefix minimum
-            uint64_t confb = 0;
-            for (int m = 0; m < C - 1; ++m) {
-                const uint32_t rcm = (uint32_t)__builtin_amdgcn_readlane((int)rc_i, m);
-                const uint32_t sad = __builtin_amdgcn_sad_u8(rc_i, rcm, 0u);
-                const uint64_t near = __ballot(sad <= 2u);
-                confb |= near & (~0ull << (m + 1));
-            }
-            const bool okr = ev && (lane == 0 || (!((confb >> lane) & 1ull) && pref > tp));
+            const bool okr = ev && (lane == 0 || pref > tp);  // (zone conflicts ended the candidate list already)
             const uint64_t bad = ~__ballot(okr);
             const uint32_t r_ok = bad ? (uint32_t)(__ffsll((unsigned long long)bad) - 1) : 64u;
             Rc = (r_ok < (uint32_t)C) ? r_ok : (uint32_t)C;
@@ -654,6 +711,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             keys[i] = key2;
             bk[blk] = rowmin;
             bi[blk] = (uint16_t)cand;
+            D2[blk] = (uint16_t)d2new;
         }
         const bool gcommit = gact && ea < Rc;
         const uint64_t acc_c = accball & ((Rc < 64u) ? ((1ull << Rc) - 1ull) : ~0ull);
@@ -688,6 +746,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             if (gl == wl_a) {
                 bk[blka] = rowmin_a;
                 bi[blka] = (uint16_t)cand_a;
+                D2[blka] = (uint16_t)d2_a;
             }
         }
         W_ORDER();
@@ -705,9 +764,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             W_ORDER();
             const bool lost = lower && CL[bjv & 63u] != (uint8_t)lane;
             if (__ballot(lost || resc) == 0) {
-                if (lower) {
+                if (lower) {  // the old minimum becomes the second key
                     bk[bjv] = keyj;
                     bi[bjv] = (uint16_t)jm;
+                    D2[bjv] = (uint16_t)w_qdelta(curv - keyj);
+                } else if (upd) {  // (a hint: a lost race between two lanes only makes it optimistic, the exact tests do not use it)
+                    const uint32_t qn = w_qdelta(keyj - curv), qo = (uint32_t)D2[bjv];
+                    if (qn < qo) D2[bjv] = (uint16_t)qn;
                 }
             } else {
                 uint64_t todo = __ballot(upd);
@@ -724,25 +787,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                         if (lane == 0) {
                             bk[bj_] = kj;
                             bi[bj_] = (uint16_t)j;
+                            D2[bj_] = (uint16_t)w_qdelta(cur - kj);
                         }
                     } else if (ci == j) {
                         const double kv = __hip_atomic_load(keys + (size_t)bj_ * 32 + (lane & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         const double mn = w_wave_min(kv);
                         const uint64_t bl = __ballot(kv == mn);
                         const int arg = bl ? (__ffsll((unsigned long long)bl) - 1) : 0;
+                        const double m2 = w_wave_min(((lane & 31) == (arg & 31)) ? W_INF : kv);
                         if (lane == 0) {
                             bk[bj_] = mn;
                             bi[bj_] = (uint16_t)(bj_ * 32 + (uint32_t)(arg & 31));
+                            D2[bj_] = (uint16_t)w_qdelta(m2 - mn);
                         }
+                    } else if (lane == 0) {
+                        const uint32_t qn = w_qdelta(kj - cur), qo = (uint32_t)D2[bj_];
+                        if (qn < qo) D2[bj_] = (uint16_t)qn;
                     }
                 }
             }
         }
         WPHASE(6);
-        // steer the selection threshold by what commits: two popped blocks whose SECOND keys fall inside the window end the prefix (only block
-        // minima are candidates), which caps it near sqrt(#blocks); candidates far beyond that are wasted work
-        if (lane == 0)
-            SELDT[0] = dt_used * ((Rc >= (uint32_t)Csel) ? W_GROW : ((Rc + W_SLACK < (uint32_t)Csel) ? W_SHRINK : 1.0));
         // ---------------- counters; the violating proposal itself (counted, acc bumped, then error(...), :120-124)
         if (Rc > 0u) {
             const uint32_t costL = (uint32_t)__builtin_amdgcn_readlane((int)cost, (int)(Rc - 1u));
