@@ -49,6 +49,26 @@ def test_tracked_matches_oracle_on_lattices(gpu_pkg, n, T):
     assert dev_t < 1e-11  # what is actually observed: a few 1e-14
 
 
+@pytest.mark.parametrize("which", [1, 2, 3])
+def test_every_tracked_kernel_commits_the_same_sequence(gpu_pkg, monkeypatch, which):
+    """The three tracked kernels -- 8-lane groups (1), one proposal per lane over key blocks of 32 (2) and of 16 (3, the default where it
+    applies) -- against the oracle on a lattice all of them support (include/pdmp_debug.h: pdmp_debug_set_track_groups)."""
+    pkg = gpu_pkg
+    monkeypatch.setenv("PDMP_TRACK_GROUPS", str(which))
+    n, T, nch = 50, 8.0, 2
+    G = pkg.problems.gmrf_precision(n)
+    d = n * n
+    rng = np.random.default_rng(which)
+    x0 = rng.standard_normal((nch, d))
+    th0 = rng.choice([-1.0, 1.0], (nch, d))
+    c = pkg.problems.column_norms(G)
+    tr, (t, x, th), (acc, num), _ = pkg.spdmp(pkg.GaussianTarget(G), 0.0, x0, th0, T, c, pkg.ZigZag(G, np.zeros(d)), seed=4100, tracked=True)
+    for k in range(nch):
+        r = O.spdmp_zigzag(G, None, G, x0[k], th0[k], c, T, seed=4100 + k)
+        assert r["status"] == 0 and len(r["events"]) > 1000
+        check_chain(tr[k].events, t[k], x[k], th[k], acc[k], num[k], None, r)
+
+
 def test_tracked_with_looser_bound_mean_and_adapt(gpu_pkg):
     """The FULL instantiation: bounding Γ = 0.9 Γ (test/maintest.jl:23: two pairs of tracked sums), a target mean, and adapt with bounds
     that start too small (c is multiplied by `factor` on violations, src/fact_samplers.jl:67-70): adapted bounds equal the oracle's."""

@@ -33,7 +33,7 @@ for nch in (256, 1024, 4096):
     kind, ph = ens.debug_phase_cycles()
     n1 = ens.counters()["num"][0]
     it = max(ph[10], 1.0)
-    print("iters=%.0f cycles/iter:" % ph[10], " ".join("p%d=%.0f" % (q, ph[q] / it) for q in range(9)),
+    print("iters=%.0f cycles/iter:" % ph[10], " ".join("p%d=%.0f" % (q, ph[q] / it) for q in range(10)),
           "| proposals committed per iteration: %.2f" % ((n1 - n0) / it), flush=True)
     print("kernel ms (profiling instantiation)", ens.last_run_ms(), flush=True)
     ens.close()

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
     };
 
     bool running = stop_before || (t < T);  // `while t < T`, :136
-    while (running) {
+    while (running) {  // (no priority turns here: the trace writes bound this kernel, and turns cost 15 % on BASELINE.json's C2)
         if (P.trace_cap > 0 && ntrace >= (uint64_t)P.trace_cap) {
             status = PDMP_CHAIN_TRACE_FULL;
             break;

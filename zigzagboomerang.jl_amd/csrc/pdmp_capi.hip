@@ -100,7 +100,7 @@ struct pdmp_ensemble {
     // device tables
     DevBuf<uint32_t> d_colptr, d_rowval, d_sptr, d_sidx, d_qptr;
     DevBuf<uint8_t> d_pos, d_selfpos;
-    DevBuf<double> d_bval, d_tval, d_gmu_b, d_gmu_t, d_c, d_sigma;
+    DevBuf<double> d_bval, d_tval, d_gmu_b, d_gmu_t, d_c, d_c2, d_sigma;
     // device state
     DevBuf<pdmp::ZzRec> d_rec;
     DevBuf<double> d_keys, d_c_chain, d_jprev, d_sum;
@@ -171,6 +171,7 @@ struct pdmp_ensemble {
         tb.pos = d_pos.p;
         tb.selfpos = d_selfpos.p;
         tb.c_shared = d_c.p;
+        tb.c2_shared = reinterpret_cast<const double2*>(d_c2.p);
         tb.sigma = d_sigma.p;
         return tb;
     }
@@ -309,7 +310,7 @@ pdmp_status pdmp_debug_phase_profile(pdmp_ensemble* e, double* out16, int* kind)
 }
 pdmp_status pdmp_debug_set_track_groups(pdmp_ensemble* e, int on) {
     if (!e) return fail(PDMP_ERR_INVALID, "null argument");
-    e->dbg_track_groups = on ? 1 : 0;
+    e->dbg_track_groups = (on >= 0 && on <= 3) ? on : 0;
     return PDMP_OK;
 }
 pdmp_status pdmp_debug_set_proposal_dump(pdmp_ensemble* e, int64_t n) {
@@ -826,6 +827,14 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
     if (st != PDMP_OK) return st;
     std::vector<double> cv(c, c + d);
     if ((st = e->d_c.upload(cv)) != PDMP_OK) return st;
+    {
+        std::vector<double> c2v((size_t)d * 2);
+        for (int64_t k = 0; k < d; ++k) {
+            c2v[2 * (size_t)k] = c[k];
+            c2v[2 * (size_t)k + 1] = c[k] / 100;
+        }
+        if ((st = e->d_c2.upload(c2v)) != PDMP_OK) return st;
+    }
     if (e->needs_general || e->target_kind == 1 || e->adaptscale || e->local_bound) {
         if (e->cfg.sampler != PDMP_SAMPLER_ZIGZAG_LOCAL && e->cfg.sampler != PDMP_SAMPLER_ZIGZAG_ALL &&
             e->cfg.sampler != PDMP_SAMPLER_STICKY_ZIGZAG)
@@ -1083,8 +1092,11 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         P.lattice_n = e->lattice_n;
         P.lattice_magic = e->lattice_n ? (uint32_t)(((uint64_t)1 << 32) / (uint64_t)e->lattice_n + 1) : 0u;
         // one proposal per lane where the graph is the plain lattice (pdmp_trackw.hip); PDMP_DEBUG_KERNEL_SPEC4 keeps the 8-lane-group kernel
-        const bool wide = pdmp::zz_trackw_supported(P) && e->dbg_track_groups == 0;
-        int rct = wide ? pdmp::launch_zz_local_trackw(P, e->cfg.nchains, s) : pdmp::launch_zz_local_track(P, e->cfg.nchains, s);
+        const bool wide = pdmp::zz_trackw_supported(P) && e->dbg_track_groups != 1;
+        const bool wide16 = wide && pdmp::zz_trackx_supported(P) && e->dbg_track_groups != 2;
+        int rct = wide16 ? pdmp::launch_zz_local_trackx(P, e->cfg.nchains, s)
+                  : wide ? pdmp::launch_zz_local_trackw(P, e->cfg.nchains, s)
+                         : pdmp::launch_zz_local_track(P, e->cfg.nchains, s);
         if (rct != 0) return fail(PDMP_ERR_HIP, "zz_local_track launch failed (%d)", rct);
         HIP_TRY(hipEventRecord(e->ev1, s));
         e->timed = true;

@@ -414,7 +414,9 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
     };
 
     bool running = stop_before || (t_event < T);
+    PrioTurn prio;
     while (running) {
+        prio.step();
         if (P.trace_cap > 0 && ntrace >= (uint64_t)P.trace_cap) {
             status = PDMP_CHAIN_TRACE_FULL;
             break;

@@ -409,7 +409,9 @@ __global__ __launch_bounds__(64) void zz_local_run_kernel(ZzRunParams P) {
     LDS_ORDER();
 
     bool running = stop_before || (t_event < T);  // `while t′ < T`, src/sfact.jl:199
+    PrioTurn prio;
     while (running) {
+        prio.step();
         if (P.trace_cap > 0 && ntrace >= (uint64_t)P.trace_cap) {
             status = PDMP_CHAIN_TRACE_FULL;
             break;
@@ -877,7 +879,9 @@ __global__ __launch_bounds__(64) void zz_sticky_run_kernel(ZzRunParams P) {
     };
 
     bool running = stop_before || (t_event < T);
+    PrioTurn prio;
     while (running) {
+        prio.step();
         if (P.trace_cap > 0 && ntrace >= (uint64_t)P.trace_cap) {
             status = PDMP_CHAIN_TRACE_FULL;
             break;
@@ -1399,7 +1403,9 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P_in) {
     } while (0)
 
     bool running = stop_before || (t_event < T);
+    PrioTurn prio;
     while (running) {
+        prio.step();
         if (dnacc >= trace_room) {
             status = PDMP_CHAIN_TRACE_FULL;
             break;
@@ -1967,7 +1973,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     } while (0)
 
     bool running = stop_before || (t_event < T);
+    PrioTurn prio;
     while (running) {
+        prio.step();
         if (dnacc >= trace_room) {
             status = PDMP_CHAIN_TRACE_FULL;
             break;
@@ -2655,7 +2663,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     } while (0)
 
     bool running = stop_before || (t_event < T);
+    PrioTurn prio;
     while (running) {
+        prio.step();
         if (dnacc >= trace_room) {
             status = PDMP_CHAIN_TRACE_FULL;
             break;
@@ -3335,7 +3345,9 @@ __global__ __launch_bounds__(64) void zz_sticky_spec_kernel(ZzRunParams P_in) {
 
     uint32_t rng_base = 0xffffffffu;
     bool running = stop_before || (t_event < T);
+    PrioTurn prio;
     while (running) {
+        prio.step();
         if (dnev >= trace_room) {
             status = PDMP_CHAIN_TRACE_FULL;
             break;

@@ -1,23 +1,15 @@
-// pdmp_trackw.hip -- the tracked-gradient local ZigZag, ONE PROPOSAL PER LANE (zz_local_trackw_kernel).
+// pdmp_trackx.hip -- zz_local_trackx_kernel: pdmp_trackw.hip's one-proposal-per-lane tracked-gradient kernel over key blocks of SIXTEEN.
 //
-// With tracked gradients (pdmp_kernels.hip: zz_local_track_kernel) a proposal is a scalar piece of work -- one record, one thinning test, one
-// re-bound -- yet the 8-event kernel still spends an 8-lane group and ~150 wavefront instructions on it (selection, templates, validation are
-// paid per iteration of eight).  Here an iteration takes up to 56 candidate events, the smallest block minima of the queue in time order, and
-// gives each to a lane:
-//   select    threshold + compaction as in the 8-event kernel, then every candidate ranks itself against all others (64 compares per lane)
-//   evaluate  lane r: own record, rates, the re-bound it would make if rejected
-//   accept    the draw offset of event r is the number of draws the earlier events consume (2 per reject, 1 + k per accept): a fix-point of
-//             {prefix sum over the lanes, thinning test at that offset}; each round fixes every event up to the next newly accepted one
-//   accepted  (18 %: at most 8 per iteration, the rest waits) one 8-lane group each: the members of G1[i] are brought to t′, take Γ[i,j] δθ_i into
-//             their velocity sums and are re-bounded; the group also rescans the popped key block with the members' new keys patched in
-//   blocks    rejected events: the minimum of the popped block WITHOUT its popped coordinate is scanned by 8-lane groups (8 events per pass) from the
-//             block as it is in HBM; new block minimum = the smaller of that and the new key
-//   validate  event r commits iff all earlier ones do, its zone G1[i_r] meets none of theirs (Manhattan distance of the lattice coordinates <= 2:
-//             one v_sad_u8 per pair) and nothing they produce or expose precedes it (prefix minimum over the lanes)
-//   commit    rejected events by their lanes (one sector + one key), accepted ones by their groups; first-level updates as in the 8-event kernels
-// The committed sequence is the one of zz_local_track_kernel (same draws, same tests, same arithmetic per event): index-exact against the oracle,
-// floats to ~1e-13.  Requirements beyond those of gradient tracking: the n x n lattice in column-major numbering (ids i = row + n col, G1[i] the
-// 5-point stencil), the plain configuration (no adapt, no means, bounding Γ == target Γ), d <= 16384.
+// What limits pdmp_trackw.hip is how many candidates can commit per iteration: only block MINIMA are candidates, so the second key of a
+// popped block that falls inside the candidate window ends the committable prefix -- a birthday bound near sqrt(#blocks) ~ 20 events with 512
+// blocks of 32 keys -- and every candidate reads two 128-byte lines of keys.  Here the queue's first level has 1024 entries over blocks of 16
+// keys (ONE line per block scan, twice the blocks).  1024 doubles are 8 of the 10 KB of LDS a chain may use, so everything else left LDS:
+//   * the ring of uniforms lives in two registers per lane (128 draws; a draw is fetched from its lane with ds_bpermute)
+//   * candidates are ranked by reading each other's keys with v_readlane, the event times are read back from the first level itself
+//   * block-scan results travel from the 8-lane groups to the event lanes through ds_bpermute, not through LDS arrays
+//   * the first level stores the argument of a block minimum as a 4-bit position (one byte)
+// Everything else -- evaluation, fix-point accept chain, accepted events in 8-lane groups, validation, commit -- is pdmp_trackw.hip's, and the
+// committed sequence is the same (index-exact against the oracle, floats to ~1e-13).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -135,34 +127,21 @@ __device__ __forceinline__ double w_shfl(double v, uint32_t src) {
     return __hiloint2double(hi, lo);
 }
 
-// (second − first) key of a block as a 16-bit hint: units of 2^-20, rounded down, 65535 = "at least 0.0625 away (or unknown large)"
-__device__ __forceinline__ uint32_t w_qdelta(double delta) {
-    return (delta < 0.0624) ? (uint32_t)(delta * 1048576.0) : 65535u;  // (NaN from Inf − Inf compares false: 65535)
-}
-__device__ __forceinline__ double w_udelta(uint32_t q) {
-    return (q >= 65535u) ? W_INF : (double)q * (1.0 / 1048576.0);
-}
-
 }  // namespace
 
 // LDS layout (bytes)
-constexpr uint32_t W_BK = 0;         // [512] f64 block minima (first level of the queue, key blocks of 32)
-constexpr uint32_t W_BI = 4096;      // [512] u16 their coordinates
-constexpr uint32_t W_U = 5120;       // [256] f64 ring of uniforms: slot n & 255 holds draw nm0 + n for dnm <= n < wend
-constexpr uint32_t W_SLT = 7168;     // [64] f64 event times, rank order
-constexpr uint32_t W_TK = 7680;      // [64] f64 candidate keys, compaction order; later EX[e]: what event e exposes
-constexpr uint32_t W_RM = 8192;      // [64] f64 minimum of the popped block without its popped coordinate / patched minimum (accepted events)
-constexpr uint32_t W_SLB = 8704;     // [64] u16 event blocks, rank order
-constexpr uint32_t W_TB = 8832;      // [64] u16 candidate blocks, compaction order; later RC[e]: coordinate of RM[e]
-constexpr uint32_t W_D2R = 8960;     // [64] u16 (second − first) minimum of a popped block's other keys, quantised (hint)
-constexpr uint32_t W_ACL = 9088;     // [8] u16 the accepted events
-constexpr uint32_t W_RO = 9104;      // [64] u8 owner of each rank (duplicate detection); later the claims of the parallel first-level update
+constexpr uint32_t W_BK = 0;         // [1024] f64 block minima (first level of the queue, key blocks of 16)
+constexpr uint32_t W_BI = 8192;      // [1024] u8 position of the minimum inside its block
+constexpr uint32_t W_EX = 9216;      // [64] f64 what event e exposes
+constexpr uint32_t W_SLB = 9728;     // [64] u16 event blocks, rank order
+constexpr uint32_t W_TB = 9856;      // [64] u16 candidate blocks, compaction order
+constexpr uint32_t W_ACL = 9984;     // [8] u16 the accepted events
+constexpr uint32_t W_RO = 10000;     // [64] u8 owner of each rank (duplicate detection); later the claims of the parallel first-level update
 constexpr uint32_t W_CL = W_RO;
-constexpr uint32_t W_SELDT = 9168;   // f64 selection threshold above the minimum
-constexpr uint32_t W_D2 = 9176;      // [512] u16 per block: (second smallest key − smallest key) in units of 2^-20, rounded DOWN, saturating -- a HINT
-                                     // that lets the selection stop where a popped block's second key would end the committable prefix anyway
-constexpr uint32_t W_BYTES = 10200;
-constexpr uint32_t W_NBLK = 512;
+constexpr uint32_t W_SELDT = 10064;  // f64 selection threshold above the minimum
+constexpr uint32_t W_BYTES = 10072;
+constexpr uint32_t W_NBLK = 1024;
+constexpr uint32_t W_WIN = 128;      // draws held in registers (two per lane)
 constexpr int W_CMAX = 56;           // candidates per iteration (7 block-scan passes of 8)
 constexpr int W_AMAX = 8;            // accepted events per iteration (one group each)
 // steering of the selection threshold (measured: 1.3 / 0.85 / 6 is 3 % slower, 1.1 / 0.7 / 2 as well)
@@ -174,7 +153,7 @@ constexpr int W_AMAX = 8;            // accepted events per iteration (one group
 static_assert(W_BYTES <= 10240, "16 chains per CU: 160 KB / 16");
 
 template <bool PROF>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void zz_local_trackw_kernel(ZzRunParams P) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void zz_local_trackx_kernel(ZzRunParams P) {
     const int lane = threadIdx.x;
     const int g = lane >> 3, gl = lane & 7;
     const int64_t chain = blockIdx.x;
@@ -184,17 +163,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 
     extern __shared__ __align__(16) unsigned char smem[];
     double* const bk = reinterpret_cast<double*>(smem + W_BK);
-    uint16_t* const bi = reinterpret_cast<uint16_t*>(smem + W_BI);
-    double* const U = reinterpret_cast<double*>(smem + W_U);
-    double* const SLT = reinterpret_cast<double*>(smem + W_SLT);
-    double* const TK = reinterpret_cast<double*>(smem + W_TK);
-    double* const EX = TK;
-    double* const RM = reinterpret_cast<double*>(smem + W_RM);
+    uint8_t* const bi = reinterpret_cast<uint8_t*>(smem + W_BI);
+    double* const EX = reinterpret_cast<double*>(smem + W_EX);
     uint16_t* const SLB = reinterpret_cast<uint16_t*>(smem + W_SLB);
     uint16_t* const TB = reinterpret_cast<uint16_t*>(smem + W_TB);
-    uint16_t* const RC = TB;
-    uint16_t* const D2 = reinterpret_cast<uint16_t*>(smem + W_D2);
-    uint16_t* const D2R = reinterpret_cast<uint16_t*>(smem + W_D2R);
     uint16_t* const ACL = reinterpret_cast<uint16_t*>(smem + W_ACL);
     uint8_t* const RO = reinterpret_cast<uint8_t*>(smem + W_RO);
     uint8_t* const CL = reinterpret_cast<uint8_t*>(smem + W_CL);
@@ -210,7 +182,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const uint64_t seed = hdr->seed;
     const uint64_t nm0 = hdr->c.ndraw_main, ntrace0 = hdr->c.ntrace;
     uint32_t dnm = 0, dnum = 0, dnacc = 0, vnacc = 0;
-    uint32_t wend = 0;  // draws nm0 + [dnm, wend) are in the ring
+    // ring of uniforms in registers: ureg[q] holds draw nm0 + uidx[q], the unique index n in [dnm, dnm + 128) with n % 64 == lane and (n / 64) % 2 == q
+    double ureg[2] = {0.0, 0.0};
+    uint32_t uidx[2] = {0xffffffffu, 0xffffffffu};
     double t_last = hdr->c.t_last;
     double t_event = hdr->t_event;
     status = PDMP_CHAIN_OK;
@@ -222,28 +196,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 
     if (lane == 0) SELDT[0] = 1e-3;
     for (uint32_t b = lane; b < nblk; b += 64) {
-        const double* kp = keys + (size_t)b * 32;
-        double mk = kp[0], m2 = W_INF;
+        const double* kp = keys + (size_t)b * 16;
+        double mk = kp[0];
         uint32_t mi = 0;
 #pragma unroll 8
-        for (int q = 1; q < 32; ++q) {
+        for (int q = 1; q < 16; ++q) {
             const double v = kp[q];
             if (v < mk) {
-                m2 = mk;
                 mk = v;
                 mi = q;
-            } else if (v < m2) {
-                m2 = v;
             }
         }
         bk[b] = mk;
-        bi[b] = (uint16_t)(b * 32 + mi);
-        D2[b] = (uint16_t)w_qdelta(m2 - mk);
+        bi[b] = (uint8_t)mi;
     }
     for (uint32_t b = nblk + lane; b < W_NBLK; b += 64) {
         bk[b] = W_INF;
         bi[b] = 0;
-        D2[b] = 65535;
     }
     W_ORDER();
 
@@ -259,104 +228,126 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }                                                                 \
     } while (0)
 
-    bool running = stop_before || (t_event < T);
     PrioTurn prio;
+    bool running = stop_before || (t_event < T);
     while (running) {
         prio.step();
         if (dnacc >= trace_room) {
             status = PDMP_CHAIN_TRACE_FULL;
             break;
         }
-        // ---------------- ring of uniforms: make draws dnm .. dnm + 255 available
-        while (wend < dnm + 256u) {
-            const uint32_t n = wend + (uint32_t)lane;
-            if (n < dnm + 256u) U[n & 255u] = pdmp_u01(seed, PDMP_STREAM_MAIN, nm0 + (uint64_t)n);
-            wend += 64u;
+        // ---------------- ring of uniforms: draws dnm .. dnm + 127, two per lane
+        {
+            const uint32_t n0 = dnm + (((uint32_t)lane - dnm) & 63u);  // the smallest n >= dnm with n % 64 == lane
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t n = n0 + 64u * (uint32_t)h;
+                const int q = (int)((n >> 6) & 1u);
+                const bool need0 = (q == 0) && uidx[0] != n, need1 = (q == 1) && uidx[1] != n;
+                if (__ballot(need0 || need1) != 0) {
+                    const double u = pdmp_u01(seed, PDMP_STREAM_MAIN, nm0 + (uint64_t)n);
+                    if (need0) {
+                        ureg[0] = u;
+                        uidx[0] = n;
+                    }
+                    if (need1) {
+                        ureg[1] = u;
+                        uidx[1] = n;
+                    }
+                }
+            }
         }
-        wend = (wend < dnm + 256u) ? wend : (dnm + 256u);
+        WPHASE(7);
+        auto draw = [&](uint32_t n) -> double {  // draw nm0 + n for dnm <= n < dnm + 128 (every lane calls it: ds_bpermute)
+            const double v0 = w_shfl(ureg[0], n & 63u), v1 = w_shfl(ureg[1], n & 63u);
+            return ((n >> 6) & 1u) ? v1 : v0;
+        };
         // ---------------- select: every first-level entry <= m + sel_dt, at most W_CMAX of them
         int C = 0;
         bool first_inf = false;
         double dt_used = 0.0;
         {
-            double kk[8];
+            double kk[16];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) kk[j] = bk[lane + 64 * j];
-            const double mloc = w_min(w_min(w_min(kk[0], kk[1]), w_min(kk[2], kk[3])), w_min(w_min(kk[4], kk[5]), w_min(kk[6], kk[7])));
+            for (int j = 0; j < 16; ++j) kk[j] = bk[lane + 64 * j];
+            double mloc = kk[0];
+#pragma unroll
+            for (int j = 1; j < 16; ++j) mloc = w_min(mloc, kk[j]);
             const double mq = w_wave_min(mloc);
             if (!(mq < W_INF)) {
                 first_inf = true;
             } else if (!(stop_before && !(mq < T))) {
-                TK[lane] = W_INF;
                 double dt_sel = w_uniform(SELDT[0]);
-                auto below = [](uint64_t m_) -> uint32_t {
-                    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_, 0u));
-                };
-                uint32_t Cc;
+                // per lane: bit j of cm = first-level entry lane + 64 j is a candidate; the threshold halves until at most W_CMAX are
+                uint32_t cm = 0, ncl = 0, incl = 0, Cc = 0;
+                bool tied = false;
                 for (int tries = 0;; ++tries) {
                     double tau = mq + dt_sel;
                     if (stop_before && !(tau < T)) tau = w_below(T);
-                    const bool pile = tries > 64;
                     if (tries >= 64) tau = mq;
-                    uint32_t base = 0;
+                    cm = 0;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const bool cj_ = kk[j] <= tau;
-                        uint64_t Mj = __ballot(cj_);
-                        if (pile) Mj = (base == 0 && Mj) ? (Mj & (~Mj + 1)) : 0ull;
-                        if (cj_ && ((Mj >> lane) & 1ull)) {
-                            const uint32_t ix = base + below(Mj);
-                            if (ix < 64u) {
-                                TK[ix] = kk[j];
-                                TB[ix] = (uint16_t)((uint32_t)lane + 64u * j);
-                            }
-                        }
-                        base += (uint32_t)__popcll(Mj);
-                    }
-                    Cc = base;
+                    for (int j = 15; j >= 0; --j) cm = cm + cm + ((kk[j] <= tau) ? 1u : 0u);
+                    ncl = (uint32_t)__builtin_popcount(cm);
+                    incl = w_scan_add_u32(ncl);
+                    Cc = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                     if (Cc <= (uint32_t)W_CMAX) break;
+                    if (tries >= 64) {  // more than W_CMAX keys EQUAL the minimum
+                        tied = true;
+                        break;
+                    }
                     dt_sel *= 0.5;
-                    W_ORDER();
-                    TK[lane] = W_INF;
+                }
+                if (tied) {
+                    cm = 0;
+                    ncl = 0;
+                    incl = 0;
+                    Cc = 0;
+                }
+                {
+                    uint32_t ix = incl - ncl, m_ = cm;
+                    while (__ballot(m_ != 0u) != 0) {
+                        if (m_ != 0u) {
+                            TB[ix] = (uint16_t)((uint32_t)lane + 64u * (uint32_t)(__ffs((int)m_) - 1));
+                            ix += 1;
+                            m_ &= m_ - 1u;
+                        }
+                    }
                 }
                 W_ORDER();
-                // rank of candidate `lane` among all: the number of strictly smaller keys (entries past the count hold +Inf)
-                const double own = TK[lane];
+                WPHASE(8);
+                // rank of candidate `lane` among all: the number of strictly smaller keys, read lane by lane (no LDS)
+                const bool isc = (uint32_t)lane < Cc;
+                const uint32_t myb = isc ? (uint32_t)TB[lane] : 0u;
+                const double own = isc ? bk[myb] : W_INF;
                 uint32_t rank = 0;
-                {
-                    const double2* T2 = reinterpret_cast<const double2*>(TK);
-                    const int mh = (int)((Cc + 1u) >> 1);  // (entries past the count hold +Inf: never smaller)
-#pragma unroll 4
-                    for (int m = 0; m < mh; ++m) {
-                        const double2 o = T2[m];
-                        rank += (o.x < own) ? 1u : 0u;
-                        rank += (o.y < own) ? 1u : 0u;
+                for (uint32_t m0 = 0; m0 < Cc; m0 += 4) {  // (lanes past the candidates hold +Inf: reading them changes nothing)
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; ++q) {
+                        const double km = w_readlane(own, (int)(m0 + q));
+                        rank += (km < own) ? 1u : 0u;
                     }
                 }
-                const bool isc = (uint32_t)lane < Cc;
                 if (isc) RO[rank] = (uint8_t)lane;
                 W_ORDER();
                 const bool dup = isc && RO[rank] != (uint8_t)lane;
-                if (__ballot(dup) != 0) {
+                if (tied || __ballot(dup) != 0) {
                     // exactly equal keys among the candidates (probability zero unless keys are tied by construction): one event this
                     // iteration, the tied minimum of the lowest block
-                    const uint64_t mm = __ballot(isc && own == mq);
-                    uint32_t bsel = isc && own == mq ? (uint32_t)TB[lane] : 0xffffffffu;
+                    uint32_t bsel = 0xffffffffu;
+#pragma unroll
+                    for (int j = 15; j >= 0; --j) bsel = (kk[j] == mq) ? ((uint32_t)lane + 64u * (uint32_t)j) : bsel;
                     for (int off = 32; off >= 1; off >>= 1) {
                         const uint32_t o = (uint32_t)__shfl_xor((int)bsel, off, 64);
                         bsel = (o < bsel) ? o : bsel;
                     }
-                    (void)mm;
                     W_ORDER();
-                    if (lane == 0) {
-                        SLT[0] = mq;
-                        SLB[0] = (uint16_t)bsel;
-                    }
+                    if (lane == 0) SLB[0] = (uint16_t)bsel;
                     Cc = 1;
                 } else if (isc) {
-                    SLT[rank] = own;
-                    SLB[rank] = TB[lane];
+                    SLB[rank] = (uint16_t)myb;
                 }
+                WPHASE(9);
                 C = (int)Cc;
                 dt_used = dt_sel;
             }
@@ -372,51 +363,49 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 
         // ---------------- lane r = event r: own record, neighbourhood size, c_i
         bool ev = lane < C;
-        const double tp = ev ? SLT[lane] : W_INF;
         const uint32_t blk = ev ? (uint32_t)SLB[lane] : 0u;
-        const uint32_t i = ev ? (uint32_t)bi[blk] : 0u;
+        const double tp = ev ? bk[blk] : W_INF;  // the event time IS the block minimum
+        const uint32_t i = ev ? (blk * 16u + (uint32_t)bi[blk]) : 0u;
         const TrRec* const ri = rec + i;
         const double th = ri->th;
         const double g_i = ri->g, gd_i = ri->gd, tg_i = ri->tg;
         const double told_i = ri->t_old, a_i = ri->a, b_i = ri->b;
-        const double c_i = P.tb.c_shared[i];
+        const double2 c_i2 = P.tb.c2_shared[i];
+        const double c_i = c_i2.x;
         const uint32_t cp_i = P.tb.colptr[i];
         const uint32_t k_i = P.tb.colptr[i + 1] - cp_i;
         // lattice coordinates packed for the zone test: byte 0 = row, byte 1 = column
         const uint32_t col_i = __umulhi(i, nmagic);
-        const uint32_t rc_i = (i - col_i * nlat) | (col_i << 8);
-        // ---------------- (the own-record loads are in flight) where would the committable prefix end anyway?  (a) zones: event r cannot
-        // commit with an earlier event whose G1 meets its own (Manhattan distance <= 2); (b) the second key of an earlier event's block, which
-        // becomes that block's minimum once its first is popped -- known approximately from the D2 hints (a lower bound: cuts early at worst).
-        // Candidates from the first such position on are dropped BEFORE their key blocks are read; the exact tests follow in `validate`.
+        const uint32_t rc_i = ev ? ((i - col_i * nlat) | (col_i << 8)) : 0xffffu;
+        // ---------------- (the own-record loads are in flight) zones: event r cannot commit with an earlier event whose G1 meets its own
+        // (Manhattan distance of the lattice coordinates <= 2): the candidate list ends at the first such event, BEFORE its key block is read
         {
             uint64_t confb = 0;
-            for (int m = 0; m < C - 1; ++m) {
-                const uint32_t rcm = (uint32_t)__builtin_amdgcn_readlane((int)rc_i, m);
-                const uint32_t sad = __builtin_amdgcn_sad_u8(rc_i, rcm, 0u);
-                const uint64_t near = __ballot(sad <= 2u);
-                confb |= near & (~0ull << (m + 1));
+            for (int m0 = 0; m0 < C - 1; m0 += 4) {  // (lanes past the events hold a far-away cell: reading them changes nothing)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = m0 + q;
+                    const uint32_t rcm = (uint32_t)__builtin_amdgcn_readlane((int)rc_i, m);
+                    const uint32_t sad = __builtin_amdgcn_sad_u8(rc_i, rcm, 0u);
+                    const uint64_t near = __ballot(sad <= 2u);
+                    confb |= near & (~0ull << (m + 1));
+                }
             }
-            const double lb2 = ev ? (tp + w_udelta((uint32_t)D2[blk])) : W_INF;
-            const double prevl = w_shfl(lb2, (uint32_t)((lane > 0) ? lane - 1 : 0));
-            const double pmin = w_scan_min_f64((lane > 0) ? prevl : W_INF);
-            const bool cut = ev && lane > 0 && (((confb >> lane) & 1ull) || !(pmin > tp));
-            const uint64_t cb = __ballot(cut);
+            const uint64_t cb = confb & ((C < 64) ? ((1ull << C) - 1ull) : ~0ull);
             if (cb) {
                 const int c0 = __ffsll((unsigned long long)cb) - 1;
                 C = (c0 < C) ? c0 : C;
             }
             ev = lane < C;
-            // steer the threshold so that the raw candidate list is just longer than what can commit
-            if (lane == 0) SELDT[0] = dt_used * ((C >= Craw) ? W_GROW : ((C + (int)W_SLACK < Craw) ? W_SHRINK : 1.0));
         }
-        // ---------------- popped blocks without their popped coordinate: 8 events per pass, one per 8-lane group (4 keys per lane)
-        W_ORDER();
+        // ---------------- popped blocks without their popped coordinate: 8 events per pass, one per 8-lane group (2 keys per lane = one line
+        // per block).  The results stay in registers (every lane of a group holds its group's) and are fetched by the event lanes with ds_bpermute.
+        double rest = W_INF;     // lane e: minimum of event e's block without coordinate i_e ...
+        uint32_t rarg = 0;       // ... and its coordinate
         {
-            // all loads of a batch of four passes first (one HBM round trip per batch), then the reductions
             const int npass = (C + 7) >> 3;
             for (int p0 = 0; p0 < npass; p0 += 4) {
-                double2 k01[4], k23[4];
+                double2 k2[4];
                 uint32_t be4[4], ie4[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -425,51 +414,40 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                     be4[q] = eg ? (uint32_t)SLB[eg ? e : 0] : 0u;
                     const uint32_t ib = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((uint32_t)(eg ? e : 0) << 2), (int)i);
                     ie4[q] = eg ? ib : 0xffffffffu;
-                    const double2* kp = reinterpret_cast<const double2*>(keys + (size_t)be4[q] * 32 + gl * 4);
-                    k01[q] = kp[0];
-                    k23[q] = kp[1];
+                    k2[q] = make_double2(W_INF, W_INF);
+                    if (eg) k2[q] = reinterpret_cast<const double2*>(keys + (size_t)be4[q] * 16)[gl];
                 }
+                double gmq[4];
+                uint32_t gcq[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int e = 8 * (p0 + q) + g;
-                    const bool eg = e < C;
-                    double kq0 = k01[q].x, kq1 = k01[q].y, kq2 = k23[q].x, kq3 = k23[q].y;
-                    const uint32_t c0 = be4[q] * 32u + (uint32_t)gl * 4u;
+                    gmq[q] = W_INF;
+                    gcq[q] = 0;
+                    if (8 * (p0 + q) >= C) continue;  // (uniform)
+                    double kq0 = k2[q].x, kq1 = k2[q].y;
+                    const uint32_t c0 = be4[q] * 16u + (uint32_t)gl * 2u;
                     if (c0 + 0u == ie4[q]) kq0 = W_INF;
                     if (c0 + 1u == ie4[q]) kq1 = W_INF;
-                    if (c0 + 2u == ie4[q]) kq2 = W_INF;
-                    if (c0 + 3u == ie4[q]) kq3 = W_INF;
-                    double lm = kq0, lm2 = W_INF;
-                    uint32_t li = 0;
-                    if (kq1 < lm) {
-                        lm2 = lm;
-                        lm = kq1;
-                        li = 1;
-                    } else {
-                        lm2 = kq1;
-                    }
-                    if (kq2 < lm) {
-                        lm2 = lm;
-                        lm = kq2;
-                        li = 2;
-                    } else if (kq2 < lm2) {
-                        lm2 = kq2;
-                    }
-                    if (kq3 < lm) {
-                        lm2 = lm;
-                        lm = kq3;
-                        li = 3;
-                    } else if (kq3 < lm2) {
-                        lm2 = kq3;
-                    }
+                    const bool hi = kq1 < kq0;
+                    const double lm = hi ? kq1 : kq0;
+                    const uint32_t lc = c0 + (hi ? 1u : 0u);
                     const double gm = w_grp8_min(lm);
-                    const uint64_t winball = __ballot(eg && lm == gm);
-                    const int wl = __ffs((unsigned)((winball >> (8 * g)) & 0xffu)) - 1;
-                    const double gm2 = w_grp8_min((gl == wl) ? lm2 : lm);  // the second smallest of the 31 other keys
-                    if (eg && gl == wl) {
-                        RM[e] = gm;
-                        RC[e] = (uint16_t)(c0 + li);
-                        D2R[e] = (uint16_t)w_qdelta(gm2 - gm);
+                    const uint64_t winball = __ballot(lm == gm);
+                    const int wl = __ffs((unsigned)((winball >> (8 * g)) & 0xffu)) - 1;  // (>= 0: some lane of the group holds the minimum)
+                    gmq[q] = gm;
+                    gcq[q] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)(lane & ~7) + (uint32_t)wl) << 2), (int)lc);
+                }
+                // event lane e = 8 (p0 + q) + g' takes pass q's value from group g' = e & 7 (any lane of it: its first)
+                const uint32_t srcl = (uint32_t)(lane & 7) * 8u;
+                const int myq = (lane >> 3) - p0;  // which pass of this batch holds lane's event (0..3), if any
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (8 * (p0 + q) >= C) continue;  // (uniform)
+                    const double v = w_shfl(gmq[q], srcl);
+                    const uint32_t c = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(srcl << 2), (int)gcq[q]);
+                    if (myq == q) {
+                        rest = v;
+                        rarg = c;
                     }
                 }
             }
@@ -487,8 +465,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         for (int round = 0; round < 66; ++round) {
             const uint32_t incl = w_scan_add_u32(cost);
             off = incl - cost;
-            const bool inwin = ev && (off + 1u + k_i <= 256u);
-            const double u = U[(dnm + off) & 255u];
+            const bool inwin = ev && (off + 1u + k_i <= W_WIN);
+            const double u = draw(dnm + ((off < 127u) ? off : 127u));
             acc = inwin && (u * lbound < l);  // :121
             const uint32_t nc = ev ? (acc ? (1u + k_i) : 2u) : 0u;
             const bool changed = nc != cost;
@@ -497,7 +475,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
         // events whose draws would leave the ring wait for the next iteration
         {
-            const uint64_t outb = __ballot(ev && !(off + 1u + k_i <= 256u));
+            const uint64_t outb = __ballot(ev && !(off + 1u + k_i <= W_WIN));
             if (outb) {
                 const int cut = __ffsll((unsigned long long)outb) - 1;
                 C = (cut < C) ? cut : C;
@@ -530,15 +508,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         W_ORDER();
         WPHASE(2);
         // ---------------- accepted events, one 8-lane group each: members of G1[i] (ascending, :131-135)
-        const bool gact = g < nacc_it;
-        const uint32_t ea = gact ? (uint32_t)ACL[g] : 0u;
+        // (the groups of the accepted events are the LAST nacc_it groups of the wave, in event order: the low lanes -- lane r = event r -- are
+        // then free to re-bound their rejected proposals in the same evaluation, see below)
+        const int g0 = 8 - nacc_it;
+        const bool gact = g >= g0;
+        const uint32_t ea = gact ? (uint32_t)ACL[g - g0] : 0u;
         const uint32_t ia_b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ea << 2), (int)i);
         const uint32_t off_b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ea << 2), (int)off);
         const uint32_t cp_b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ea << 2), (int)cp_i);
         const uint32_t ia = gact ? ia_b : 0u;
-        const double tpa = gact ? SLT[ea] : 0.0;
-        const uint32_t offa = gact ? off_b : 0u;
         const uint32_t blka = gact ? (uint32_t)SLB[ea] : 0u;
+        const double tpa = gact ? bk[blka] : 0.0;
+        const uint32_t offa = gact ? off_b : 0u;
         // G1[ia] on the lattice, ascending: {ia − n, ia − 1, ia, ia + 1, ia + n} inside the grid -- computed, so that the members' records are
         // requested at once; the CSC tables are read for the VALUES only (Γ[j, i] = Γ[i, j]: symmetric, checked on the host)
         const uint32_t cola = __umulhi(ia, nmagic), rowa = ia - cola * nlat;
@@ -569,44 +550,45 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         double xa = ria->x, txa = ria->tx, Ia = ria->I;
         const uint64_t acc_ia = ria->acc;
         const double thj0 = rj->th, gj0 = rj->g, gdj0 = rj->gd, tgj = rj->tg;
-        const double cjm = P.tb.c_shared[jm];
-        const double2* const kpa = reinterpret_cast<const double2*>(keys + (size_t)blka * 32 + gl * 4);
-        const double2 ka01 = kpa[0], ka23 = kpa[1];  // the popped block of the accepted event (patched below)
-        // (the loads of the accepted events' groups are in flight: the rejected proposals' re-bounds -- logarithm, divisions, square root, no memory -- run under them)
-        // ---------------- the re-bound of a rejected proposal (:137-140), by its own lane
+        const double2 cjm2 = P.tb.c2_shared[jm];
+        const double2 ka01 = reinterpret_cast<const double2*>(keys + (size_t)blka * 16)[gl];  // the popped block of the accepted event (patched below)
+        // ---------------- ONE evaluation of the new bound and key per lane (logarithm, two divisions, square root): the re-bound of a rejected
+        // proposal (:137-140) in its event lane, the re-bound of a member of G1 (:131-135) in its group lane.  A lane that is both (more than
+        // 64 − 8 nacc candidates) evaluates its rejected proposal again below.
+        const bool selfl = mem && jm == ia;
+        const double thj = selfl ? -th_ia : thj0;
+        const double gj = gj0 + gdj0 * (tpa - tgj);
+        const double gdj = gdj0 + gam * (-2.0 * th_ia);  // θ_i -> −θ_i
         double a2, b2, key2;
         {
-            const double L = pdmp_log(U[(dnm + off + 1u) & 255u]);
-            a2 = c_i + g_now * th;
-            b2 = c_i / 100 + th * gd_i;
-            key2 = tp + w_poisson_time_L(a2, b2, L);
+            const uint32_t dix = gact ? (offa + 1u + (uint32_t)gl) : (off + 1u);
+            const double L = pdmp_log(draw(dnm + ((dix < 127u) ? dix : 127u)));
+            const double cc = gact ? cjm2.x : c_i, cc100 = gact ? cjm2.y : c_i2.y;
+            const double gg = gact ? gj : g_now, tt = gact ? thj : th, gdd = gact ? gdj : gd_i;
+            a2 = cc + gg * tt;
+            b2 = cc100 + tt * gdd;
+            key2 = (gact ? tpa : tp) + w_poisson_time_L(a2, b2, L);
+        }
+        const double aj = a2, bj = b2;
+        const double keyj = mem ? key2 : W_INF;
+        if (__ballot(ev && !acc && gact) != 0) {
+            const double L = pdmp_log(draw(dnm + ((off + 1u < 127u) ? off + 1u : 127u)));
+            const double a2e = c_i + g_now * th;
+            const double b2e = c_i2.y + th * gd_i;
+            const double k2e = tp + w_poisson_time_L(a2e, b2e, L);
+            if (gact) {
+                a2 = a2e;
+                b2 = b2e;
+                key2 = k2e;
+            }
         }
         // new minimum of the popped block of a rejected event, and what the event exposes
         double rowmin = W_INF;
-        uint32_t cand = i, d2new = 65535u;
+        uint32_t cand = i;
         if (ev && !acc) {
-            const double rest = RM[lane];
-            const uint32_t rarg = RC[lane];
             const bool mine = key2 < rest || (key2 == rest && i < rarg);
             rowmin = mine ? key2 : rest;
             cand = mine ? i : rarg;
-            // hint for the next pop of this block: its second key is `rest` if the new key leads, else the smaller of the new key and the
-            // (lower bound of the) second of the rest
-            const double dr = w_udelta((uint32_t)D2R[lane]);
-            const double dk = key2 - rest;
-            d2new = mine ? w_qdelta(rest - key2) : w_qdelta((dk < dr) ? dk : dr);
-        }
-        double keyj = W_INF, aj = 0.0, bj = 0.0, gj = 0.0, gdj = 0.0;
-        const bool selfl = mem && jm == ia;
-        {
-            const double delta = -2.0 * th_ia;  // θ_i -> −θ_i
-            const double thj = selfl ? -th_ia : thj0;
-            gj = gj0 + gdj0 * (tpa - tgj);
-            gdj = gdj0 + gam * delta;
-            aj = cjm + gj * thj;
-            bj = cjm / 100 + thj * gdj;
-            const double L = pdmp_log(U[(dnm + offa + 1u + (uint32_t)gl) & 255u]);
-            if (mem) keyj = tpa + w_poisson_time_L(aj, bj, L);
         }
         if (selfl) {  // event(i, t, x, θ, F) (src/sfact.jl:50-52): x_i at t′
             const double dtx = tpa - txa;
@@ -617,52 +599,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
         // the popped block of the accepted event with the members' new keys patched in
         double rowmin_a = W_INF;
-        uint32_t cand_a = 0, d2_a = 65535u;
+        uint32_t cand_a = 0;
         int wl_a = -1;
         {
-            double kq[4] = {ka01.x, ka01.y, ka23.x, ka23.y};
+            double kq0 = ka01.x, kq1 = ka01.y;
 #pragma unroll
             for (int m = 0; m < 5; ++m) {
                 const uint32_t src = (uint32_t)(lane & ~7) + (uint32_t)m;
                 const uint32_t jq = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)jm);
                 const double kv = w_shfl(keyj, src);
-                const bool inblk = ((uint32_t)m < ka) && ((jq >> 5) == blka) && (((jq & 31u) >> 2) == (uint32_t)gl);
+                const bool inblk = ((uint32_t)m < ka) && ((jq >> 4) == blka) && (((jq & 15u) >> 1) == (uint32_t)gl);
                 if (inblk) {
-                    const uint32_t w = jq & 3u;
-                    kq[0] = (w == 0u) ? kv : kq[0];
-                    kq[1] = (w == 1u) ? kv : kq[1];
-                    kq[2] = (w == 2u) ? kv : kq[2];
-                    kq[3] = (w == 3u) ? kv : kq[3];
+                    kq0 = (jq & 1u) ? kq0 : kv;
+                    kq1 = (jq & 1u) ? kv : kq1;
                 }
             }
-            double lm = kq[0], lm2 = W_INF;
-            uint32_t li = 0;
-            if (kq[1] < lm) {
-                lm2 = lm;
-                lm = kq[1];
-                li = 1;
-            } else {
-                lm2 = kq[1];
-            }
-            if (kq[2] < lm) {
-                lm2 = lm;
-                lm = kq[2];
-                li = 2;
-            } else if (kq[2] < lm2) {
-                lm2 = kq[2];
-            }
-            if (kq[3] < lm) {
-                lm2 = lm;
-                lm = kq[3];
-                li = 3;
-            } else if (kq[3] < lm2) {
-                lm2 = kq[3];
-            }
+            const bool hi = kq1 < kq0;
+            const double lm = hi ? kq1 : kq0;
             rowmin_a = w_grp8_min(lm);
             const uint64_t winball = __ballot(gact && lm == rowmin_a);
             wl_a = __ffs((unsigned)((winball >> (8 * g)) & 0xffu)) - 1;
-            d2_a = w_qdelta(w_grp8_min((gl == wl_a) ? lm2 : lm) - rowmin_a);
-            cand_a = blka * 32u + (uint32_t)gl * 4u + li;
+            cand_a = (uint32_t)gl * 2u + (hi ? 1u : 0u);
             const double keymin = w_grp8_min(keyj);
             if (gact && gl == 0) EX[ea] = w_min(rowmin_a, keymin);
         }
@@ -701,6 +658,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             }
             if (stopped) vsel = -1;
         }
+        // steer the threshold so that the raw candidate list is just longer than what can commit
+        if (lane == 0) SELDT[0] = dt_used * (((int)Rc >= Craw) ? W_GROW : (((int)Rc + (int)W_SLACK < Craw) ? W_SHRINK : 1.0));
         WPHASE(4);
         // ---------------- commit the valid prefix
         const bool commit = ev && (uint32_t)lane < Rc;
@@ -712,8 +671,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             rw->tprop = tp;
             keys[i] = key2;
             bk[blk] = rowmin;
-            bi[blk] = (uint16_t)cand;
-            D2[blk] = (uint16_t)d2new;
+            bi[blk] = (uint8_t)(cand & 15u);
         }
         const bool gcommit = gact && ea < Rc;
         const uint64_t acc_c = accball & ((Rc < 64u) ? ((1ull << Rc) - 1ull) : ~0ull);
@@ -747,32 +705,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             }
             if (gl == wl_a) {
                 bk[blka] = rowmin_a;
-                bi[blka] = (uint16_t)cand_a;
-                D2[blka] = (uint16_t)d2_a;
+                bi[blka] = (uint8_t)cand_a;
             }
         }
         W_ORDER();
         WPHASE(5);
         // ---------------- first-level entries of re-bounded neighbours living in other blocks (as in the 8-event kernels)
-        const bool upd = gcommit && mem && (jm >> 5) != blka;
+        const bool upd = gcommit && mem && (jm >> 4) != blka;
         if (__ballot(upd) != 0) {
             W_ORDER();
-            const uint32_t bjv = upd ? (jm >> 5) : 0u;
+            const uint32_t bjv = upd ? (jm >> 4) : 0u;
             const double curv = bk[bjv];
-            const uint32_t civ = bi[bjv];
+            const uint32_t civ = bjv * 16u + (uint32_t)bi[bjv];
             const bool lower = upd && (keyj < curv || (keyj == curv && jm < civ));
             const bool resc = upd && !lower && civ == jm;
             if (lower) CL[bjv & 63u] = (uint8_t)lane;
             W_ORDER();
             const bool lost = lower && CL[bjv & 63u] != (uint8_t)lane;
             if (__ballot(lost || resc) == 0) {
-                if (lower) {  // the old minimum becomes the second key
+                if (lower) {
                     bk[bjv] = keyj;
-                    bi[bjv] = (uint16_t)jm;
-                    D2[bjv] = (uint16_t)w_qdelta(curv - keyj);
-                } else if (upd) {  // (a hint: a lost race between two lanes only makes it optimistic, the exact tests do not use it)
-                    const uint32_t qn = w_qdelta(keyj - curv), qo = (uint32_t)D2[bjv];
-                    if (qn < qo) D2[bjv] = (uint16_t)qn;
+                    bi[bjv] = (uint8_t)(jm & 15u);
                 }
             } else {
                 uint64_t todo = __ballot(upd);
@@ -781,30 +734,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                     todo &= todo - 1;
                     const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)jm, src);
                     const double kj = w_readlane(keyj, src);
-                    const uint32_t bj_ = j >> 5;
+                    const uint32_t bj_ = j >> 4;
                     W_ORDER();
                     const double cur = bk[bj_];
-                    const uint32_t ci = bi[bj_];
+                    const uint32_t ci = bj_ * 16u + (uint32_t)bi[bj_];
                     if (kj < cur || (kj == cur && j < ci)) {
                         if (lane == 0) {
                             bk[bj_] = kj;
-                            bi[bj_] = (uint16_t)j;
-                            D2[bj_] = (uint16_t)w_qdelta(cur - kj);
+                            bi[bj_] = (uint8_t)(j & 15u);
                         }
                     } else if (ci == j) {
-                        const double kv = __hip_atomic_load(keys + (size_t)bj_ * 32 + (lane & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const double kv = __hip_atomic_load(keys + (size_t)bj_ * 16 + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         const double mn = w_wave_min(kv);
                         const uint64_t bl = __ballot(kv == mn);
                         const int arg = bl ? (__ffsll((unsigned long long)bl) - 1) : 0;
-                        const double m2 = w_wave_min(((lane & 31) == (arg & 31)) ? W_INF : kv);
                         if (lane == 0) {
                             bk[bj_] = mn;
-                            bi[bj_] = (uint16_t)(bj_ * 32 + (uint32_t)(arg & 31));
-                            D2[bj_] = (uint16_t)w_qdelta(m2 - mn);
+                            bi[bj_] = (uint8_t)(arg & 15);
                         }
-                    } else if (lane == 0) {
-                        const uint32_t qn = w_qdelta(kj - cur), qo = (uint32_t)D2[bj_];
-                        if (qn < qo) D2[bj_] = (uint16_t)qn;
                     }
                 }
             }
@@ -851,17 +798,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     }
 }
 
-bool zz_trackw_supported(const ZzRunParams& p) {
+bool zz_trackx_supported(const ZzRunParams& p) {
     return p.lattice_n >= 16 && p.lattice_n <= 128 && !p.adapt && p.c_chain == nullptr && p.tb.gmu_t == nullptr && !p.track_two_sums &&
-           !p.has_refresh && p.d >= 2048 && p.d <= (int64_t)W_NBLK * 32;
+           !p.has_refresh && p.d >= 2048 && p.d <= (int64_t)W_NBLK * 16;
 }
 
-int launch_zz_local_trackw(const ZzRunParams& p, int64_t nchains, void* stream) {
+int launch_zz_local_trackx(const ZzRunParams& p, int64_t nchains, void* stream) {
     dim3 grid((unsigned)nchains), block(64);
     ZzRunParams q = p;
-    q.nblk = (uint32_t)((p.d + 31) / 32);
-    if (p.dbg) hipLaunchKernelGGL((zz_local_trackw_kernel<true>), grid, block, W_BYTES, (hipStream_t)stream, q);
-    else hipLaunchKernelGGL((zz_local_trackw_kernel<false>), grid, block, W_BYTES, (hipStream_t)stream, q);
+    q.nblk = (uint32_t)((p.d + 15) / 16);  // (dk is a multiple of 64, the padding keys are +Inf)
+    if (p.dbg) hipLaunchKernelGGL((zz_local_trackx_kernel<true>), grid, block, W_BYTES, (hipStream_t)stream, q);
+    else hipLaunchKernelGGL((zz_local_trackx_kernel<false>), grid, block, W_BYTES, (hipStream_t)stream, q);
     return (int)hipGetLastError();
 }
 

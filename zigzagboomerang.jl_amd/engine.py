@@ -45,7 +45,7 @@ class Ensemble:
         if k:
             self.debug_set_kernel(k)
         if os.environ.get("PDMP_TRACK_GROUPS"):
-            _lib.check(self._L.pdmp_debug_set_track_groups(self._h, 1))
+            _lib.check(self._L.pdmp_debug_set_track_groups(self._h, int(os.environ["PDMP_TRACK_GROUPS"])))
         if os.environ.get("PDMP_SPEC_G2"):
             _lib.check(self._L.pdmp_debug_set_spec_g2(self._h, 1))
 
