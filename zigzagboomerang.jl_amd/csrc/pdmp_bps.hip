@@ -650,6 +650,62 @@ __global__ __launch_bounds__(64) void sector_probe_kernel(double* rec, int64_t d
     double* base = rec + chain * d * 8;
     uint32_t h = (uint32_t)chain * 2654435761u + (uint32_t)lane * 40503u + 12345u;
     double acc = 0.0;
+    if (write >= 13) {
+        // What ONE REJECTED PROPOSAL of the tracked kernels costs the memory system, in two layouts (64 proposals per round and wavefront):
+        //   13: as built -- the coordinate's record line read by its lane (two sectors) and a 32-byte sector of it written back; the key
+        //       block's line read by an 8-lane group (16 B per lane) and one 8-byte key written (TWO dirty lines per proposal)
+        //   14: keys and proposal times interleaved -- the record line only READ; a 256-byte aligned pair of lines read by the group
+        //       (32 B per lane) and 16 bytes of it written (ONE dirty line per proposal)
+        //   15 / 16: the reads of 13 / 14 alone
+        //   17: 13 with non-temporal stores
+        const bool pairs = (write == 14 || write == 16), wr = (write <= 14 || write == 17), nt = (write == 17);
+        const int g = lane >> 3, gl = lane & 7;
+        uint32_t hg = (uint32_t)chain * 2654435761u + (uint32_t)g * 40503u + 777u;
+        for (int r = 0; r < rounds; ++r) {
+            h = h * 1664525u + 1013904223u;
+            double* recl = base + (size_t)((h >> 8) % (uint32_t)(d / 2 - 4)) * 16;
+            const double2 r0 = reinterpret_cast<double2*>(recl)[0], r1 = reinterpret_cast<double2*>(recl)[2];
+            double2 k[8], k2[8];
+            double* bl[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                hg = hg * 1664525u + 1013904223u;
+                const uint32_t rnd = hg >> 8;
+                if (pairs) {
+                    bl[q] = base + (size_t)(rnd % (uint32_t)(d / 4 - 4)) * 32;
+                    k[q] = reinterpret_cast<double2*>(bl[q])[2 * gl];
+                    k2[q] = reinterpret_cast<double2*>(bl[q])[2 * gl + 1];
+                } else {
+                    bl[q] = base + (size_t)(rnd % (uint32_t)(d / 2 - 4)) * 16;
+                    k[q] = reinterpret_cast<double2*>(bl[q])[gl];
+                    k2[q] = k[q];
+                }
+            }
+            acc += r0.x + r1.y;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += k[q].x + k2[q].y;
+            if (wr) {
+                if (nt) {
+                    __builtin_nontemporal_store(r0.x + 1.0, recl + 8);
+                    __builtin_nontemporal_store(r1.y, recl + 9);
+                    __builtin_nontemporal_store(r1.x, recl + 10);
+                    __builtin_nontemporal_store(r1.y, recl + 11);
+                } else if (!pairs) {
+                    reinterpret_cast<double2*>(recl)[4] = make_double2(r0.x + 1.0, r1.y), reinterpret_cast<double2*>(recl)[5] = r1;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (gl == (q & 7)) {
+                        if (pairs) reinterpret_cast<double2*>(bl[q])[2 * gl] = make_double2(k[q].x + 1.0, k[q].y);
+                        else if (nt) __builtin_nontemporal_store(k[q].x + 1.0, bl[q] + 2 * gl);
+                        else bl[q][2 * gl] = k[q].x + 1.0;
+                    }
+                }
+            }
+        }
+        if (acc == 123.456) sink[0] = acc;
+        return;
+    }
     if (write >= 7) {
         // WIDE requests: a group of lanes reads one contiguous, aligned run as a unit (the TA merges the lanes of one instruction
         // that fall into one 128-byte line into a single request).  7/8: groups of 4 lanes, a random 128-byte line, each lane two
