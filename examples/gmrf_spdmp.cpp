@@ -2,7 +2,8 @@
 // against the C++ host mirror include/pdmp_mi355.hpp:   Γ = 0.01 I + gridlaplacian(n, n) (scripts/gridlaplace.jl:4-21),
 // ∇ϕ(x, i, Γ) = idot(Γ, i, x), Z = ZigZag(Γ, 0), c[i] = ‖Γ[:, i]‖₂, spdmp(∇ϕ, t0, x0, θ0, T, c, Z, Γ).
 //   usage: gmrf_spdmp [n=16] [T=20] [seed] [tracked]      prints one line: d events num acc fnv1a64(payload) t_last
-//   (a 4th argument selects the tracked-gradient evaluation, Options::tracked: n x n lattices with n*n >= 2048)
+//   (a 4th argument `tracked` selects the tracked-gradient evaluation, Options::tracked: n x n lattices with n*n >= 2048;
+//    `parallel:K` runs pdmp::parallel_spdmp with K chunks, the bound = Γ without the entries that couple two chunks, c doubled)
 // tests/test_gpu_cpp_host.py runs it on the GPU box and checks the line against the CPU oracle.
 #include <cinttypes>
 #include <cmath>
@@ -47,7 +48,9 @@ int main(int argc, char** argv) {
     const double T = argc > 2 ? std::atof(argv[2]) : 20.0;
     pdmp::Options opt;
     if (argc > 3) opt.seed = std::strtoull(argv[3], nullptr, 0);
-    if (argc > 4) opt.tracked = true;
+    const bool par = argc > 4 && std::strncmp(argv[4], "parallel:", 9) == 0;
+    const int K = par ? std::atoi(argv[4] + 9) : 0;
+    if (argc > 4 && !par) opt.tracked = true;
     try {
         pdmp::ZigZag Z;
         Z.Gamma = gmrf_precision(n, 0.01);
@@ -63,7 +66,22 @@ int main(int argc, char** argv) {
                 s += Z.Gamma.nzval[(size_t)p] * Z.Gamma.nzval[(size_t)p];
             c[(size_t)i] = std::sqrt(s);
         }
-        auto R = pdmp::spdmp(target, 0.0, x0, th0, T, c, Z, opt);
+        pdmp::Result<pdmp::FactTrace> R;
+        if (par) {
+            // test/testparallel.jl:40-49: the bounding Γ is the target's without the cross-chunk entries (kept as zeros on G's pattern, masked)
+            std::vector<uint8_t> mask(Z.Gamma.nzval.size(), 1);
+            const int64_t k = d / K;
+            for (int64_t i = 0; i < d; ++i)
+                for (int64_t p = Z.Gamma.colptr[(size_t)i]; p < Z.Gamma.colptr[(size_t)i + 1]; ++p)
+                    if (Z.Gamma.rowval[(size_t)p] / k != i / k) {
+                        Z.Gamma.nzval[(size_t)p] = 0.0;
+                        mask[(size_t)p] = 0;
+                    }
+            for (auto& v : c) v *= 2.0;
+            R = pdmp::parallel_spdmp(K, target, 0.0, x0, th0, T, c, Z, mask, 0.1, opt);
+        } else {
+            R = pdmp::spdmp(target, 0.0, x0, th0, T, c, Z, opt);
+        }
         uint64_t h = 14695981039346656037ull;
         int64_t acc = 0;
         for (const auto& e : R.trace.events) {

@@ -168,6 +168,19 @@ pdmp_status pdmp_ensemble_set_state_synthetic(pdmp_ensemble* ens, double t0, con
  */
 pdmp_status pdmp_ensemble_run(pdmp_ensemble* ens, double T, int flags, void* stream);
 pdmp_status pdmp_ensemble_sync(pdmp_ensemble* ens);
+/*
+ * parallel_spdmp (src/parallel.jl:104-253): every chain advanced by K wavefronts -- the coordinates cut into K chunks of d / K
+ * (Partition(nt, n), :26), one worker per chunk (parallel_spdmp_inner!, :63-102, horizon Δ = `delta`) and a coordinator for the
+ * coordinates whose neighbourhood leaves their chunk (parallel_spdmp_outer!, :176-253).  PDMP_SAMPLER_ZIGZAG_LOCAL on a Gaussian target,
+ * lambda_ref = 0; `adapt` as configured.  G = the pattern of the flow tables; G1 = the slots with g1_mask[p] != 0 (NULL: all of them), the
+ * structural pattern of the bounding Γ -- pass the bounding Γ on the union pattern with zeros and mask them out when, as in
+ * test/testparallel.jl:40-49, it is the target's Γ without the cross-chunk entries.  "Upper bounds may not depend across chunks." (:124-127)
+ * returns PDMP_ERR_INVALID.  Starts from a fresh state only (set_state, then ONE call); blocks until done.  The trace holds the events in
+ * the order the waves emitted them: sort by time as the reference does (:167); a buffer that is too small sets PDMP_CHAIN_TRACE_FULL and the
+ * trace is incomplete.  Counters: num / nacc as the reference returns them, nrefresh = coordinator rounds.  Bit-identical to the oracle's
+ * threaded restatement (tests/test_gpu_partitioned.py); 1 <= K <= 16, K | d, columns of at most 64 entries.
+ */
+pdmp_status pdmp_ensemble_run_partitioned(pdmp_ensemble* ens, double T, int K, double delta, const uint8_t* g1_mask, void* stream);
 /* duration of the most recent run's event-loop kernel, from HIP events recorded on its stream (syncs) */
 pdmp_status pdmp_ensemble_last_run_ms(pdmp_ensemble* ens, float* ms);
 

@@ -286,6 +286,42 @@ Result<FactTrace> pdmp(const Target& target, double t0, const std::vector<double
                        double T, const std::vector<double>& c, const Flow& F, const Options& o = {}) {
     return detail::factorised(PDMP_SAMPLER_ZIGZAG_ALL, target, t0, x0, theta0, T, c, F, nullptr, o);
 }
+// parallel_spdmp(partition, ∇ϕ, t0, x0, θ0, T, c, G, F::ZigZag; factor, adapt, Δ)  -- src/parallel.jl:104-175: the chain on `nt` wavefronts,
+// one per chunk of d / nt coordinates.  F.Gamma is the bounding Γ written on G's pattern (explicit zeros where it has no entry) and g1_mask
+// marks its own structural entries (empty: all of them); the result's events are sorted by time (:167), acc holds the scalar of the reference.
+template <class Target>
+Result<FactTrace> parallel_spdmp(int nt, const Target& target, double t0, const std::vector<double>& x0, const std::vector<double>& theta0,
+                                 double T, const std::vector<double>& c, const ZigZag& F, const std::vector<uint8_t>& g1_mask,
+                                 double Delta = 0.1, const Options& o = {}) {
+    const int64_t d = (int64_t)x0.size();
+    const int64_t cap = o.trace_capacity > 0 ? o.trace_capacity : 2 * detail::default_capacity(d, t0, T);
+    Ensemble e(1, d, PDMP_SAMPLER_ZIGZAG_LOCAL, o, cap);
+    detail::set_flow(e, F);
+    detail::set_target(e, target);
+    const uint64_t seed = o.seed;
+    check(pdmp_ensemble_set_state(e.get(), t0, x0.data(), theta0.data(), c.data(), &seed));
+    check(pdmp_ensemble_run_partitioned(e.get(), T, nt, Delta, g1_mask.empty() ? nullptr : g1_mask.data(), nullptr));
+    const auto cnt = e.counters();
+    if (cnt[0].status == PDMP_CHAIN_BOUND_VIOLATED) throw std::runtime_error("Tuning parameter `c` too small.");
+    if (cnt[0].status == PDMP_CHAIN_TRACE_FULL) throw std::runtime_error("trace_capacity too small for a partitioned run (it is not resumable)");
+    Result<FactTrace> R;
+    R.trace.t0 = t0;
+    R.trace.x0 = x0;
+    R.trace.theta0 = theta0;
+    R.trace.events.resize((size_t)cnt[0].ntrace);
+    if (cnt[0].ntrace > 0) check(pdmp_ensemble_trace_copy(e.get(), 0, 0, (int64_t)cnt[0].ntrace, R.trace.events.data()));
+    std::stable_sort(R.trace.events.begin(), R.trace.events.end(), [](const pdmp_event& a, const pdmp_event& b) { return a.t < b.t; });
+    R.t.resize((size_t)d);
+    R.x.resize((size_t)d);
+    R.theta.resize((size_t)d);
+    R.c.resize((size_t)d);
+    std::vector<int64_t> acc_vec((size_t)d);
+    check(pdmp_ensemble_final_state(e.get(), 0, 1, R.t.data(), R.x.data(), R.theta.data(), acc_vec.data(), R.c.data()));
+    if (!o.adapt) R.c = c;
+    R.acc.assign(1, (int64_t)cnt[0].nacc);
+    R.num = (int64_t)cnt[0].num;
+    return R;
+}
 // sspdmp(∇ϕ, t0, x0, θ0, T, c, F::ZigZag, κ, args...; reversible, strong_upperbounds, factor=1.5, adapt)  -- src/ss_fact.jl:159-217
 template <class Target>
 Result<FactTrace> sspdmp(const Target& target, double t0, const std::vector<double>& x0, const std::vector<double>& theta0,

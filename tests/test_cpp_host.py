@@ -88,3 +88,34 @@ def test_cpp_spdmp_tracked_option(gpu_pkg):
         assert int(d_s) == d and int(nev_s) == len(r["events"]) and int(num_s) == r["num"] and int(acc_s) == int(r["acc"].sum())
         assert abs(float(tl_s) - r["events"]["t"][-1]) <= 1e-9 * r["events"]["t"][-1]
     assert float(out["exact"][5]) == r["events"]["t"][-1] and out["exact"][4] != out["tracked"][4]
+
+
+@pytest.mark.gpu
+def test_cpp_parallel_spdmp_matches_oracle(gpu_pkg):
+    """pdmp::parallel_spdmp (src/parallel.jl through the C++ mirror, 4 chunks = 4 wavefronts) against the oracle's threaded restatement:
+    event count, (acc, num) and the FNV-1a of the time-sorted events + final (x, θ, t)."""
+    import scipy.sparse as sp
+    pkg = gpu_pkg
+    exe = _exe(pkg)
+    n, T, seed, K = 16, 5.0, 0x4321, 4
+    p = subprocess.run([exe, str(n), repr(T), hex(seed), "parallel:%d" % K], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr
+    d_s, nev_s, num_s, acc_s, h_s, tl_s = p.stdout.split()
+    G = pkg.problems.gmrf_precision(n, eps=0.01)
+    d = n * n
+    i = np.arange(d)
+    x0 = ((i * 37) % 101) / 50.0 - 1.0
+    th0 = np.where(i % 3 == 0, -1.0, 1.0)
+    Gc = G.tocsc()
+    c = 2.0 * np.array([np.sqrt(sum(v * v for v in Gc.data[Gc.indptr[k]:Gc.indptr[k + 1]])) for k in range(d)])
+    coo = sp.coo_matrix(G)
+    keep = (coo.row // (d // K)) == (coo.col // (d // K))
+    G2 = sp.csc_matrix((coo.data[keep], (coo.row[keep], coo.col[keep])), shape=G.shape)
+    G2.sort_indices()
+    r = O.parallel_spdmp(G2, None, G, x0, th0, c, T, K, 0.1, seed=seed)
+    assert r["status"] == 0 and len(r["events"]) > 500
+    ev = r["events"]
+    assert int(d_s) == d and int(nev_s) == len(ev) and int(num_s) == r["num"] and int(acc_s) == r["nacc"]
+    h = _fnv1a(14695981039346656037, ev.tobytes())
+    h = _fnv1a(h, r["x"].tobytes() + r["theta"].tobytes() + r["t"].tobytes())
+    assert int(h_s, 16) == h and float(tl_s) == ev["t"][-1]

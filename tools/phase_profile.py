@@ -34,6 +34,8 @@ for nch in (256, 1024, 4096):
     n1 = ens.counters()["num"][0]
     it = max(ph[10], 1.0)
     print("iters=%.0f cycles/iter:" % ph[10], " ".join("p%d=%.0f" % (q, ph[q] / it) for q in range(10)),
-          "| proposals committed per iteration: %.2f" % ((n1 - n0) / it), flush=True)
+          "| proposals committed per iteration: %.2f" % ((n1 - n0) / it),
+          ("| candidates per iteration: selected %.2f, after the zone cut %.2f, after window / accept limits %.2f" % (ph[11] / it, ph[12] / it, ph[13] / it))
+          if ph[11] > 0 else "", flush=True)
     print("kernel ms (profiling instantiation)", ens.last_run_ms(), flush=True)
     ens.close()

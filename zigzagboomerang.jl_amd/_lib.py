@@ -29,7 +29,7 @@ assert EVENT_DTYPE.itemsize == 32 and COUNTERS_DTYPE.itemsize == 72
 EXPORTED_SYMBOLS = [
     "pdmp_last_error", "pdmp_abi_version", "pdmp_device_count", "pdmp_ensemble_create",
     "pdmp_ensemble_destroy", "pdmp_ensemble_set_flow_zigzag", "pdmp_ensemble_set_target_gaussian_csc",
-    "pdmp_ensemble_set_state", "pdmp_ensemble_set_state_synthetic", "pdmp_ensemble_run", "pdmp_ensemble_sync",
+    "pdmp_ensemble_set_state", "pdmp_ensemble_set_state_synthetic", "pdmp_ensemble_run", "pdmp_ensemble_run_partitioned", "pdmp_ensemble_sync",
     "pdmp_ensemble_last_run_ms", "pdmp_ensemble_counters", "pdmp_ensemble_totals", "pdmp_ensemble_trace_copy",
     "pdmp_ensemble_trace_reset", "pdmp_ensemble_final_state", "pdmp_ensemble_batch_means",
     "pdmp_ensemble_trace_dev", "pdmp_ensemble_counters_dev", 
@@ -87,6 +87,7 @@ def load():
     L.pdmp_ensemble_set_state.argtypes = [vp, f64, vp, vp, vp, vp]
     L.pdmp_ensemble_set_state_synthetic.argtypes = [vp, f64, vp, C.c_uint64]
     L.pdmp_ensemble_run.argtypes = [vp, f64, C.c_int, vp]
+    L.pdmp_ensemble_run_partitioned.argtypes = [vp, f64, C.c_int, f64, vp, vp]
     L.pdmp_ensemble_sync.argtypes = [vp]
     L.pdmp_ensemble_last_run_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.pdmp_ensemble_counters.argtypes = [vp, vp]

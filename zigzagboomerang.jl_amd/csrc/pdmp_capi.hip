@@ -76,6 +76,7 @@ struct pdmp_ensemble {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     bool has_flow = false, has_target = false, has_state = false;
+    bool ran = false;  // a run happened since set_state (pdmp_ensemble_run_partitioned starts from a fresh state only)
 
     // host copies of the flow (needed to align the target and to rebuild tables)
     std::vector<uint32_t> colptr, rowval;
@@ -101,6 +102,7 @@ struct pdmp_ensemble {
     DevBuf<uint32_t> d_colptr, d_rowval, d_sptr, d_sidx, d_qptr;
     DevBuf<uint8_t> d_pos, d_selfpos;
     DevBuf<double> d_bval, d_tval, d_gmu_b, d_gmu_t, d_c, d_c2, d_sigma;
+    DevBuf<pdmp::CoordConst> d_cc;
     // device state
     DevBuf<pdmp::ZzRec> d_rec;
     DevBuf<double> d_keys, d_c_chain, d_jprev, d_sum;
@@ -172,6 +174,7 @@ struct pdmp_ensemble {
         tb.selfpos = d_selfpos.p;
         tb.c_shared = d_c.p;
         tb.c2_shared = reinterpret_cast<const double2*>(d_c2.p);
+        tb.cc_shared = d_cc.p;
         tb.sigma = d_sigma.p;
         return tb;
     }
@@ -834,6 +837,16 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
             c2v[2 * (size_t)k + 1] = c[k] / 100;
         }
         if ((st = e->d_c2.upload(c2v)) != PDMP_OK) return st;
+        std::vector<pdmp::CoordConst> ccv((size_t)d);
+        for (int64_t k = 0; k < d; ++k) {
+            ccv[(size_t)k].c = c[k];
+            ccv[(size_t)k].c100 = c[k] / 100;
+            ccv[(size_t)k].cp = e->colptr.empty() ? 0u : (uint32_t)e->colptr[(size_t)k];
+            ccv[(size_t)k].k = e->colptr.empty() ? 0u : (uint32_t)(e->colptr[(size_t)k + 1] - e->colptr[(size_t)k]);
+            for (int q = 0; q < 5; ++q)
+                ccv[(size_t)k].gam[q] = ((uint32_t)q < ccv[(size_t)k].k && ccv[(size_t)k].k <= 5u && !e->h_tval.empty()) ? e->h_tval[ccv[(size_t)k].cp + (size_t)q] : 0.0;
+        }
+        if ((st = e->d_cc.upload(ccv)) != PDMP_OK) return st;
     }
     if (e->needs_general || e->target_kind == 1 || e->adaptscale || e->local_bound) {
         if (e->cfg.sampler != PDMP_SAMPLER_ZIGZAG_LOCAL && e->cfg.sampler != PDMP_SAMPLER_ZIGZAG_ALL &&
@@ -930,6 +943,7 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
     if (rc != 0) return fail(PDMP_ERR_HIP, "zz_init launch failed: %s", hipGetErrorString((hipError_t)rc));
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->has_state = true;
+    e->ran = false;
     e->timed = false;
     return PDMP_OK;
 }
@@ -954,6 +968,7 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
     if (!e->has_state) return fail(PDMP_ERR_INVALID, "set_state must be called before run");
     if (flags != PDMP_RUN_REFERENCE_TAIL && flags != PDMP_RUN_STOP_BEFORE) return fail(PDMP_ERR_INVALID, "bad flags");
     HIP_TRY(hipSetDevice(e->cfg.device));
+    e->ran = true;
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
     if (e->cfg.sampler == PDMP_SAMPLER_BPS) {
         pdmp::BpsRunParams B{};
@@ -1341,6 +1356,108 @@ pdmp_status pdmp_ensemble_set_sticky(pdmp_ensemble* e, const double* kappa, int 
     return PDMP_OK;
 }
 
+pdmp_status pdmp_ensemble_run_partitioned(pdmp_ensemble* e, double T, int K, double delta, const uint8_t* g1_mask, void* stream) {
+    if (!e) return fail(PDMP_ERR_INVALID, "null argument");
+    if (!e->has_state) return fail(PDMP_ERR_INVALID, "set_state must be called before run");
+    if (e->cfg.sampler != PDMP_SAMPLER_ZIGZAG_LOCAL || e->target_kind != 0 || e->flow_kind != 0 || e->lambda_ref > 0 || e->adaptscale ||
+        e->local_bound || e->track || e->has_kappa)
+        return fail(PDMP_ERR_UNSUPPORTED,
+                    "parallel_spdmp (src/parallel.jl) is built for the local ZigZag on a Gaussian target without refresh clock, "
+                    "adaptscale, LocalBound or gradient tracking");
+    if (e->ran) return fail(PDMP_ERR_UNSUPPORTED, "a partitioned run starts from a fresh state (call set_state first)");
+    const int64_t d = e->cfg.d;
+    if (K < 1 || K > 16 || d % K != 0)
+        return fail(PDMP_ERR_INVALID, "K = %d: need 1 <= K <= 16 chunks of equal size d / K (Partition, src/parallel.jl:26)", K);
+    if (!(delta > 0)) return fail(PDMP_ERR_INVALID, "the horizon Δ must be positive");
+    const int64_t k = d / K;
+    const int64_t nnz = e->nnz;
+    // G = the pattern of the flow tables, G1 = the structural entries of the bounding Γ inside it (all of it without a mask)
+    std::vector<uint8_t> mask((size_t)nnz, 1);
+    if (g1_mask) mask.assign(g1_mask, g1_mask + nnz);
+    std::vector<uint8_t> inner((size_t)d, 1);
+    for (int64_t i = 0; i < d; ++i) {
+        if (e->colptr[i + 1] - e->colptr[i] > 64u)
+            return fail(PDMP_ERR_UNSUPPORTED, "column %lld has %u entries: the partitioned kernel holds one neighbour per lane (64)",
+                        (long long)i, e->colptr[i + 1] - e->colptr[i]);
+        for (uint32_t p = e->colptr[i]; p < e->colptr[i + 1]; ++p) {
+            const int64_t j = e->rowval[p];
+            if (j / k != i / k) {
+                inner[(size_t)i] = 0;  // :114
+                if (mask[p])
+                    return fail(PDMP_ERR_INVALID, "Upper bounds may not depend across chunks. (src/parallel.jl:124-127: Γ[%lld,%lld])",
+                                (long long)j, (long long)i);
+            } else if (!mask[p] && e->bval[p] != 0.0) {
+                return fail(PDMP_ERR_INVALID, "slot (%lld,%lld) is outside the bounding pattern but carries a bound value", (long long)j,
+                            (long long)i);
+            }
+        }
+    }
+    // G2[i] = union of G1[j], j in G1[i], without G[i] (:121); inside the chunk because G1 is
+    std::vector<uint32_t> g2ptr((size_t)d + 1, 0), g2idx;
+    {
+        std::vector<uint32_t> tmp;
+        for (int64_t i = 0; i < d; ++i) {
+            tmp.clear();
+            for (uint32_t p = e->colptr[i]; p < e->colptr[i + 1]; ++p) {
+                if (!mask[p]) continue;
+                const uint32_t j = e->rowval[p];
+                for (uint32_t q = e->colptr[j]; q < e->colptr[j + 1]; ++q)
+                    if (mask[q]) tmp.push_back(e->rowval[q]);
+            }
+            std::sort(tmp.begin(), tmp.end());
+            tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+            for (uint32_t v : tmp) {
+                bool in_g = false;
+                for (uint32_t p = e->colptr[i]; p < e->colptr[i + 1] && !in_g; ++p) in_g = e->rowval[p] == v;
+                if (!in_g) g2idx.push_back(v);
+            }
+            g2ptr[(size_t)i + 1] = (uint32_t)g2idx.size();
+        }
+    }
+    if (g2idx.empty()) g2idx.push_back(0);
+    const int nbc = (int)((k + 63) / 64);
+    const size_t lds = pdmp::zz_partitioned_lds_bytes(K, nbc);
+    if (lds > 64 * 1024)
+        return fail(PDMP_ERR_UNSUPPORTED, "d = %lld needs %zu bytes of LDS for the chunk queues (64 KB per workgroup)", (long long)d, lds);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    DevBuf<uint8_t> d_inner, d_mask;
+    DevBuf<uint32_t> d_g2ptr, d_g2idx;
+    pdmp_status st;
+    if ((st = d_inner.upload(inner)) != PDMP_OK || (st = d_mask.upload(mask)) != PDMP_OK || (st = d_g2ptr.upload(g2ptr)) != PDMP_OK ||
+        (st = d_g2idx.upload(g2idx)) != PDMP_OK)
+        return st;
+    pdmp::ZzPartParams P{};
+    P.tb = e->tables();
+    P.rec = e->d_rec.p;
+    P.keys = e->d_keys.p;
+    P.hdr = e->d_hdr.p;
+    P.ev = e->cfg.trace_capacity > 0 ? e->d_ev.p : nullptr;
+    P.c_chain = e->cfg.adapt ? e->d_c_chain.p : nullptr;
+    P.inner = d_inner.p;
+    P.g1mask = d_mask.p;
+    P.g2ptr = d_g2ptr.p;
+    P.g2idx = d_g2idx.p;
+    P.d = d;
+    P.dk = e->dk;
+    P.trace_cap = e->cfg.trace_capacity;
+    P.k = k;
+    P.K = K;
+    P.nbc = nbc;
+    P.adapt = e->cfg.adapt;
+    P.T = T;
+    P.delta = delta;
+    P.factor = e->cfg.factor;
+    e->ran = true;
+    HIP_TRY(hipEventRecord(e->ev0, s));
+    const int rc = pdmp::launch_zz_partitioned(P, e->cfg.nchains, s);
+    if (rc != 0) return fail(PDMP_ERR_HIP, "zz_partitioned_run launch failed (%d)", rc);
+    HIP_TRY(hipEventRecord(e->ev1, s));
+    e->timed = true;
+    HIP_TRY(hipStreamSynchronize(s));  // (the tables of this call live until here)
+    return PDMP_OK;
+}
+
 pdmp_status pdmp_ensemble_set_gradient_tracking(pdmp_ensemble* e, int enable) {
     if (!e) return fail(PDMP_ERR_INVALID, "null argument");
     NEED_FACTORISED(e);
@@ -1560,6 +1677,7 @@ pdmp_status pdmp_ensemble_set_state_bps(pdmp_ensemble* e, double t0, const doubl
     if (rc != 0) return fail(PDMP_ERR_HIP, "bps_init launch failed (%d)", rc);
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->has_state = true;
+    e->ran = false;
     e->timed = false;
     return PDMP_OK;
 }

@@ -100,6 +100,13 @@ struct PrioTurn {
 };
 #endif
 
+struct CoordConst {
+    double c, c100;
+    uint32_t cp, k;
+    double gam[5];  // Γt[G1[i], i] (tval[cp .. cp + k)) where k <= 5, else unused
+};
+static_assert(sizeof(CoordConst) == 64, "half a line");
+
 // Read-only tables of the local ZigZag kernels (device pointers).
 struct ZzTables {
     const uint32_t* __restrict__ colptr;
@@ -115,6 +122,7 @@ struct ZzTables {
     const uint8_t* __restrict__ selfpos;
     const double* __restrict__ c_shared;
     const double2* __restrict__ c2_shared;  // {c_i, c_i / 100} (the constant bound and its slope, src/sfact.jl:36-39), tracked kernels
+    const CoordConst* __restrict__ cc_shared;  // the same with colptr[i] and |G1[i]|: everything a proposal needs that depends on i alone, 64 bytes
     const double* __restrict__ sigma;
 };
 
@@ -177,6 +185,25 @@ struct ZzInitParams {
     int32_t local_bound;             // c::LocalBound (src/local.jl): bounds from the target's derivatives + expiry horizon; thf = renew flags
     int32_t track;                   // records are TrRec (tracked-gradient kernel): also g = Γt[:,i]·x0, gd = Γt[:,i]·θ0 and the bound's sums
 };
+
+// One chain over K wavefronts (pdmp_partition.hip): the reference's parallel_spdmp (src/parallel.jl)
+struct ZzPartParams {
+    ZzTables tb;
+    ZzRec* rec;
+    double* keys;
+    DevChain* hdr;
+    pdmp_event* ev;
+    double* c_chain;                       // per-chain bounds when adapt, else nullptr
+    const uint8_t* __restrict__ inner;     // [d] G[i] lies inside i's chunk (:114)
+    const uint8_t* __restrict__ g1mask;    // [nnz] the slot is a structural entry of the bounding Γ (G1, :117)
+    const uint32_t* __restrict__ g2ptr;    // [d + 1], [..]: G2[i] = two-hop(G1) \ G[i], ascending (:121)
+    const uint32_t* __restrict__ g2idx;
+    int64_t d, dk, trace_cap, k;
+    int32_t K, nbc, adapt, pad;
+    double T, delta, factor;
+};
+size_t zz_partitioned_lds_bytes(int K, int nbc);
+int launch_zz_partitioned(const ZzPartParams& p, int64_t nchains, void* stream);
 
 // General-degree local ZigZag (pdmp_general.hip): CSC tables instead of the blob, optional logistic target
 struct ZzGeneralParams {

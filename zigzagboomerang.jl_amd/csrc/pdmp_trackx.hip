@@ -218,7 +218,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 
     uint64_t ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t ph_t0 = PROF ? (uint64_t)__builtin_readcyclecounter() : 0;
-    uint64_t ph_iters = 0;
+    uint64_t ph_iters = 0, ph_raw = 0, ph_zone = 0, ph_eval = 0;  // candidates: selected, after the zone cut, after the window and accept limits
 #define WPHASE(k)                                                         \
     do {                                                                  \
         if (PROF) {                                                       \
@@ -359,6 +359,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         W_ORDER();
         WPHASE(0);
         if (PROF) ph_iters += 1;
+        if (PROF) ph_raw += (uint64_t)C;
         const int Craw = C;
 
         // ---------------- lane r = event r: own record, neighbourhood size, c_i
@@ -370,10 +371,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const double th = ri->th;
         const double g_i = ri->g, gd_i = ri->gd, tg_i = ri->tg;
         const double told_i = ri->t_old, a_i = ri->a, b_i = ri->b;
-        const double2 c_i2 = P.tb.c2_shared[i];
+        const double2 c_i2 = *reinterpret_cast<const double2*>(&P.tb.cc_shared[i].c);
         const double c_i = c_i2.x;
-        const uint32_t cp_i = P.tb.colptr[i];
-        const uint32_t k_i = P.tb.colptr[i + 1] - cp_i;
+        const uint32_t k_i = P.tb.cc_shared[i].k;
         // lattice coordinates packed for the zone test: byte 0 = row, byte 1 = column
         const uint32_t col_i = __umulhi(i, nmagic);
         const uint32_t rc_i = ev ? ((i - col_i * nlat) | (col_i << 8)) : 0xffffu;
@@ -452,6 +452,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 }
             }
         }
+        if (PROF) ph_zone += (uint64_t)C;
         W_ORDER();
         WPHASE(1);
         // ---------------- rates from the tracked sums (src/sfact.jl:116-119 with g_i(t′) = g_i + gd_i (t′ − tg_i))
@@ -502,6 +503,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
         ev = lane < C;
         acc = acc && ev;
+        if (PROF) ph_eval += (uint64_t)C;
         const uint64_t accball = __ballot(acc);
         const int nacc_it = __popcll(accball);
         if (acc) ACL[__popcll(accball & ((1ull << lane) - 1ull))] = (uint16_t)lane;
@@ -515,7 +517,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const uint32_t ea = gact ? (uint32_t)ACL[g - g0] : 0u;
         const uint32_t ia_b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ea << 2), (int)i);
         const uint32_t off_b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ea << 2), (int)off);
-        const uint32_t cp_b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ea << 2), (int)cp_i);
         const uint32_t ia = gact ? ia_b : 0u;
         const uint32_t blka = gact ? (uint32_t)SLB[ea] : 0u;
         const double tpa = gact ? bk[blka] : 0.0;
@@ -541,8 +542,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 }
             }
         }
-        const uint32_t cpa = gact ? cp_b : 0u;
-        const double gam = mem ? P.tb.tval[cpa + (uint32_t)gl] : 0.0;
+        const double gam = mem ? P.tb.cc_shared[ia].gam[gl] : 0.0;
         TrRec* const rj = rec + jm;
         TrRec* const ria = rec + ia;
         // (the reflecting coordinate's own fields are read again by its group: the lines are in L2)
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         double xa = ria->x, txa = ria->tx, Ia = ria->I;
         const uint64_t acc_ia = ria->acc;
         const double thj0 = rj->th, gj0 = rj->g, gdj0 = rj->gd, tgj = rj->tg;
-        const double2 cjm2 = P.tb.c2_shared[jm];
+        const double2 cjm2 = *reinterpret_cast<const double2*>(&P.tb.cc_shared[jm].c);
         const double2 ka01 = reinterpret_cast<const double2*>(keys + (size_t)blka * 16)[gl];  // the popped block of the accepted event (patched below)
         // ---------------- ONE evaluation of the new bound and key per lane (logarithm, two divisions, square root): the re-bound of a rejected
         // proposal (:137-140) in its event lane, the re-bound of a member of G1 (:131-135) in its group lane.  A lane that is both (more than
@@ -784,6 +784,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     if (PROF && P.dbg && chain == 0 && lane == 0) {
         for (int q = 0; q < 10; ++q) P.dbg[q] = (double)ph[q];
         P.dbg[10] = (double)ph_iters;
+        P.dbg[11] = (double)ph_raw;
+        P.dbg[12] = (double)ph_zone;
+        P.dbg[13] = (double)ph_eval;
     }
 #undef WPHASE
     if (lane == 0) {

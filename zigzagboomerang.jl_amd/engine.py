@@ -212,6 +212,11 @@ class Ensemble:
         if sync:
             self.sync()
 
+    def run_partitioned(self, T, K, delta, g1_mask=None, stream=None):
+        """parallel_spdmp (src/parallel.jl): every chain over K wavefronts; see pdmp_ensemble_run_partitioned in include/pdmp_mi355.h."""
+        m = None if g1_mask is None else np.ascontiguousarray(g1_mask, dtype=np.uint8)
+        _lib.check(self._L.pdmp_ensemble_run_partitioned(self._h, float(T), int(K), float(delta), None if m is None else _ptr(m), stream))
+
     def sync(self):
         _lib.check(self._L.pdmp_ensemble_sync(self._h))
 

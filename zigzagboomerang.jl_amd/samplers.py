@@ -11,6 +11,7 @@ bound `c` is too small with adapt=false -- follows the reference.
 import copy
 
 import numpy as np
+import scipy.sparse as sp
 
 from . import _lib
 from .engine import Ensemble
@@ -69,6 +70,98 @@ def sspdmp(target, t0, x0, θ0, T, c, F, κ, *, reversible=False, strong_upperbo
     adapt) (src/ss_fact.jl:159-160,217) -> Ξ, (t, x, θ), (acc, num), c with scalar acc, num (:175,214)."""
     return _zigzag(_lib.SAMPLER_STICKY_ZIGZAG, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, trace_capacity, trace,
                    sticky=(np.asarray(κ, dtype=np.float64), reversible, strong_upperbounds))
+
+
+class Partition:
+    """Partition(nt, n) (src/parallel.jl:4-31): n coordinates in nt chunks of k = n ÷ nt; pt(i) -> (chunk, offset), pt(chunk, offset) -> i
+    (0-based here)."""
+
+    def __init__(self, nt, n):
+        self.nt, self.n, self.k = int(nt), int(n), int(n) // int(nt)
+
+    def __len__(self):
+        return self.nt
+
+    def __call__(self, *a):
+        if len(a) == 1:
+            return divmod(int(a[0]), self.k)
+        return int(a[0]) * self.k + int(a[1])
+
+
+def parallel_spdmp(partition, target, t0, x0, θ0, T, c, G, F, *, factor=1.8, adapt=False, Δ=0.1, seed=DEFAULT_SEED, device=0,
+                   trace_capacity=None, trace=True):
+    """parallel_spdmp(partition, ∇ϕ, t0, x0, θ0, T, c, G, F::ZigZag; factor=1.8, adapt=false, Δ=0.1) (src/parallel.jl:104-175):
+    the local ZigZag with the coordinates cut into len(partition) chunks, one worker per chunk and a coordinator -- on the device one
+    WAVEFRONT per chunk (pdmp_ensemble_run_partitioned).  F.Γ is the bounding precision: its pattern G1 must not leave the chunks
+    ("Upper bounds may not depend across chunks.", :124-127).  G: None = the pattern of F.Γ (:113-115), or a sparse matrix whose pattern
+    ⊇ F.Γ's and ⊇ the target's gives the neighbourhoods that are moved before a gradient (test/testparallel.jl:49 passes the target's).
+    Returns Ξ (sorted by time, :167), (t, x, θ), (acc, num); with adapt=True a numpy `c` is updated in place like the reference's."""
+    if not isinstance(F, ZigZag) or isinstance(F, FactBoomerang):
+        raise TypeError("the device path of parallel_spdmp supports F::ZigZag")
+    if not isinstance(target, GaussianTarget):
+        raise TypeError("target must be a GaussianTarget")
+    K = len(partition) if not np.isscalar(partition) else int(partition)
+    x0 = np.asarray(x0, dtype=np.float64)
+    θ0 = np.asarray(θ0, dtype=np.float64)
+    single = x0.ndim == 1
+    X0, TH0 = np.atleast_2d(x0), np.atleast_2d(θ0)
+    nch, d = X0.shape
+    # the flow tables carry G: the bounding Γ on G's pattern with explicit zeros, and the mask of its own structural entries
+    def pattern(A):  # structural pattern (explicit zeros count, as in Julia's rowvals / nzrange)
+        A = sp.csc_matrix(A)
+        B = sp.csc_matrix((np.ones(A.nnz), A.indices.copy(), A.indptr.copy()), shape=A.shape)
+        B.sort_indices()
+        B.sum_duplicates()
+        B.data[:] = 1.0
+        return B
+
+    Gb = F.Γ
+    own = pattern(Gb)
+    pg = own if G is None else pattern(G)
+    U = (pg + own + pattern(target.Γ)).tocsc()
+    U.sort_indices()
+    if U.nnz != pg.nnz:
+        raise ValueError("G must contain the patterns of F.Γ (G ⊇ G1, src/parallel.jl:119) and of the target")
+    cols = np.repeat(np.arange(d), np.diff(U.indptr))
+    rows = U.indices
+    mask = np.asarray(own[rows, cols]).reshape(-1) != 0
+    vals = np.asarray(sp.csc_matrix(Gb)[rows, cols]).reshape(-1)
+    Γu = sp.csc_matrix((vals, rows.copy(), U.indptr.copy()), shape=Gb.shape)
+    Fu = copy.copy(F)
+    Fu.Γ = Γu  # (not through __post_init__: explicit zeros must stay)
+    cc = np.asarray(c, dtype=np.float64)
+    seeds = (np.uint64(seed) + np.arange(nch, dtype=np.uint64)) if np.isscalar(seed) else np.asarray(seed, np.uint64)
+    if trace_capacity is None:
+        trace_capacity = int(min(max(4096, 4.0 * d * max(T - t0, 1.0)), 1 << 24))
+    cap = trace_capacity if trace else 0
+    ens = Ensemble(nch, d, sampler=_lib.SAMPLER_ZIGZAG_LOCAL, adapt=adapt, factor=factor, device=device, trace_capacity=cap)
+    try:
+        ens.set_flow(Fu)
+        ens.set_target(target)
+        ens.set_state(t0, X0, TH0, cc, seeds)
+        ens.run_partitioned(T, K, Δ, mask.astype(np.uint8))
+        cnt = ens.counters()
+        if np.any(cnt["status"] == _lib.CHAIN_BOUND_VIOLATED):
+            raise RuntimeError("Tuning parameter `c` too small.")  # src/parallel.jl:42
+        if np.any(cnt["status"] == _lib.CHAIN_TRACE_FULL):
+            raise RuntimeError("trace_capacity too small for a partitioned run (it is not resumable): %d events" % int(cnt["nevents"].max()))
+        events = [[] for _ in range(nch)]
+        if trace:
+            _drain(ens, events)
+        fs = ens.final_state()
+    finally:
+        ens.close()
+    traces = []
+    for k_ in range(nch):
+        ev = np.concatenate(events[k_]) if events[k_] else np.empty(0, dtype=_lib.EVENT_DTYPE)
+        ev = ev[np.argsort(ev["t"], kind="stable")]  # sort!(Ξ.events, by=ev->ev[1]), :167
+        traces.append(FactTrace(F, t0, X0[k_].copy(), TH0[k_].copy(), ev))
+    acc, num = cnt["nacc"].astype(np.int64), cnt["num"].astype(np.int64)
+    if adapt and single and isinstance(c, np.ndarray) and c.dtype == np.float64:
+        c[:] = fs["c"][0]  # adapt!(c, i, factor) acts on the caller's vector
+    if single:
+        return traces[0], (fs["t"][0], fs["x"][0], fs["theta"][0]), (int(acc[0]), int(num[0]))
+    return traces, (fs["t"], fs["x"], fs["theta"]), (acc, num)
 
 
 def _zigzag(sampler, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, trace_capacity, trace, sticky=None,
