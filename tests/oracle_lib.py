@@ -245,7 +245,8 @@ class _ParResult(C.Structure):
 
 def parallel_spdmp(bound_gamma, bound_mu, target_gamma, x0, theta0, c, T, K, delta, *, t0=0.0, adapt=False, factor=1.8,
                    seed=1, want_trace=True):
-    """src/parallel.jl parallel_spdmp restated with pthreads (CPU baseline; event order is run dependent)."""
+    """src/parallel.jl parallel_spdmp restated with pthreads (CPU baseline and the checker of the device's partitioned mode).  The threads of a
+    round share no data, so the result does not depend on their timing (tests/test_oracle_samplers.py checks it)."""
     L = lib()
     gb = bound_gamma if isinstance(bound_gamma, CscHolder) else CscHolder(bound_gamma)
     gt = target_gamma if isinstance(target_gamma, CscHolder) else CscHolder(target_gamma)

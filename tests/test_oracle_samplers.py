@@ -376,7 +376,8 @@ def test_golden2_newer_paths():
 def test_threaded_parallel_spdmp_statistics():
     """test/testparallel.jl:22-73 ("Parallel ZigZag": d = 20 tridiagonal Γ, K = 2 chunks, bound Γ2 = Γ without the cross-chunk
     entries, c = 5‖Γ[:, i]‖, Δ = 0.05, T = 1000): 0.1/√T < mean|mean(tr)| < 4/√T and mean|cov − Γ⁻¹| < 4/√T, plus the Partition
-    index map round trip (:4-20).  The event order depends on thread timing, as in the reference: statistics only."""
+    index map round trip (:4-20).  The workers of a round touch disjoint data, so the run is deterministic whatever the thread timing
+    (second half of the test) -- which is what lets the device's partitioned mode be checked bit for bit against it."""
     import scipy.sparse as sp
     from __graft_entry__ import load_package
     pkg = load_package()
@@ -401,6 +402,11 @@ def test_threaded_parallel_spdmp_statistics():
     assert 0.1 / np.sqrt(T) < np.mean(np.abs(pkg.trace.mean(tr))) < 4 / np.sqrt(T)
     ts, xs = pkg.trace.discretize(tr, 0.5)
     assert np.mean(np.abs(np.cov(xs.T) - np.linalg.inv(G.toarray()))) < 4 / np.sqrt(T)
+    for _ in range(3):  # deterministic: identical events, counters, rounds and final state on every run
+        r2 = O.parallel_spdmp(G2, None, G, x0, th0, c, 100.0, K, delta, seed=7)
+        r3 = O.parallel_spdmp(G2, None, G, x0, th0, c, 100.0, K, delta, seed=7)
+        assert np.array_equal(r2["events"], r3["events"]) and r2["num"] == r3["num"] and r2["rounds"] == r3["rounds"]
+        assert np.array_equal(r2["x"], r3["x"]) and np.array_equal(r2["t"], r3["t"])
     # a bound that couples the chunks is refused ("Upper bounds may not depend across chunks.", src/parallel.jl:124-127)
     assert O.parallel_spdmp(G, None, G, x0, th0, c, 1.0, K, delta, seed=7)["status"] != 0
 

@@ -1017,7 +1017,7 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
     if (dbg_cap > 0) {
         pdmp_status st2 = dbgbuf.alloc((size_t)dbg_cap * 16);
         if (st2 != PDMP_OK) return st2;
-        HIP_TRY(hipMemset(dbgbuf.p, 0, (size_t)dbg_cap * 16 * sizeof(double)));
+        HIP_TRY(hipMemsetAsync(dbgbuf.p, 0, (size_t)dbg_cap * 16 * sizeof(double), s));
         P.dbg = dbgbuf.p;
         P.dbg_cap = dbg_cap;
     }
@@ -1055,7 +1055,7 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
     if (phenv && (spec_ok || general_path)) {
         pdmp_status st3 = phbuf.alloc(16);
         if (st3 != PDMP_OK) return st3;
-        HIP_TRY(hipMemset(phbuf.p, 0, 16 * sizeof(double)));
+        HIP_TRY(hipMemsetAsync(phbuf.p, 0, 16 * sizeof(double), s));
         P.dbg = phbuf.p;
         P.dbg_cap = 0;
     }
@@ -1211,8 +1211,9 @@ pdmp_status pdmp_ensemble_trace_reset(pdmp_ensemble* e) {
     HIP_TRY(hipDeviceSynchronize());
     // ntrace lives at a fixed offset inside each 128-byte header: zero it with a strided 2-D memset
     const size_t off = offsetof(pdmp::DevChain, c) + offsetof(pdmp_chain_counters, ntrace);
-    HIP_TRY(hipMemset2D(reinterpret_cast<char*>(e->d_hdr.p) + off, sizeof(pdmp::DevChain), 0, sizeof(uint64_t),
-                        (size_t)e->cfg.nchains));
+    HIP_TRY(hipMemset2DAsync(reinterpret_cast<char*>(e->d_hdr.p) + off, sizeof(pdmp::DevChain), 0, sizeof(uint64_t),
+                             (size_t)e->cfg.nchains, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));  // (a memset on the null stream is not ordered against the ensemble's non-blocking stream)
     // status TRACE_FULL -> OK is handled by the kernel at entry (only BOUND_VIOLATED / STALLED are sticky)
     return PDMP_OK;
 }
@@ -1264,10 +1265,10 @@ pdmp_status pdmp_ensemble_batch_means(pdmp_ensemble* e, double T_prev, double T,
     pdmp_status st;
     if (e->d_jprev.n != (size_t)(n * d)) {
         if ((st = e->d_jprev.alloc((size_t)(n * d))) != PDMP_OK) return st;
-        HIP_TRY(hipMemset(e->d_jprev.p, 0, (size_t)(n * d) * sizeof(double)));
+        HIP_TRY(hipMemsetAsync(e->d_jprev.p, 0, (size_t)(n * d) * sizeof(double), e->stream));  // (same stream as the kernel: the ensemble's stream is non-blocking, the null stream does not order against it)
     }
     if (e->d_sum.n != (size_t)(2 * d) && (st = e->d_sum.alloc((size_t)(2 * d))) != PDMP_OK) return st;
-    HIP_TRY(hipMemset(e->d_sum.p, 0, (size_t)(2 * d) * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(e->d_sum.p, 0, (size_t)(2 * d) * sizeof(double), e->stream));
     int rc = pdmp::launch_zz_batch_means(e->d_rec.p, e->track ? 128 : 64, e->d_jprev.p, d, n, T_prev, T, e->d_sum.p, e->d_sum.p + d,
                                          e->stream);
     if (rc != 0) return fail(PDMP_ERR_HIP, "batch_means launch failed: %s", hipGetErrorString((hipError_t)rc));
