@@ -542,7 +542,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 }
             }
         }
-        const double gam = mem ? P.tb.cc_shared[ia].gam[gl] : 0.0;
+        const double gam = mem ? P.tb.cc_shared[ia].gam[gl] : 0.0;  // (from tval[cp + gl] instead: 8 % more L2 misses, no faster)
         TrRec* const rj = rec + jm;
         TrRec* const ria = rec + ia;
         // (the reflecting coordinate's own fields are read again by its group: the lines are in L2)
