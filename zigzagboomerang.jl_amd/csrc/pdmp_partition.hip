@@ -65,12 +65,13 @@ __device__ __forceinline__ double q_poisson_time(double a, double b, double u) {
         return Q_INF;
     }
 }
-// loads / stores of data that another lane or wave of the workgroup wrote: past the vector L1
+// loads / stores of data that another lane or wave of the WORKGROUP wrote (all of a workgroup's waves share one vector L1: workgroup scope
+// keeps them cached; nothing outside the workgroup touches a chain during a launch)
 __device__ __forceinline__ double q_ld(const double* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void q_st(double* p, double v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 }  // namespace
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(1024) void zz_partitioned_run_kernel(ZzPartParams P
         } else {
             m1 = mG && j == (uint32_t)i;
         }
-        __threadfence();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         Q_ORDER();
         const uint64_t m1b = __ballot(m1);
         const uint32_t rk = (uint32_t)__popcll(m1b & ((1ull << lane) - 1ull));
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(1024) void zz_partitioned_run_kernel(ZzPartParams P
             q_st(keys + j, tp + q_poisson_time(aj, bj, uj));
         }
         nd += (uint64_t)__popcll(m1b);
-        __threadfence();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         Q_ORDER();
         uint32_t lastb = 0xffffffffu;
         for (uint64_t todo = m1b; todo; todo &= todo - 1) {
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(1024) void zz_partitioned_run_kernel(ZzPartParams P
                 if (ok) acc += 1;
             }
         }
-        __threadfence();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __syncthreads();
         // ---------------- coordinator phase (one round of parallel_spdmp_outer!)
         if (wave == 0) {
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(1024) void zz_partitioned_run_kernel(ZzPartParams P
                 sh[0] = done ? 1u : 0u;
             }
         }
-        __threadfence();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __syncthreads();
         if (sh[0]) break;
     }
