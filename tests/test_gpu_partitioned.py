@@ -148,3 +148,29 @@ def test_ensemble_of_partitioned_chains(gpu_pkg):
         r = O.parallel_spdmp(G2, None, G, x0[k], th0[k], c, T, K, delta, seed=5000 + k)
         assert r["status"] == 0 and len(r["events"]) > 1000
         assert_identical(r, trs[k], t[k], x[k], th[k], acc[k], num[k])
+
+
+def test_committed_golden_vector_on_the_device(gpu_pkg):
+    """tests/golden/golden2.npz `parallel_*` (made by make_golden2.py from the oracle): index sequence, counters, first event times and
+    the SHA-256 of the time-sorted events and the final state, straight from the device."""
+    import hashlib
+    import importlib.util
+    import os
+    pkg = gpu_pkg
+    here = os.path.dirname(os.path.abspath(__file__))
+    gold = np.load(os.path.join(here, "golden", "golden2.npz"), allow_pickle=False)
+    G = pkg.problems.gmrf_precision(16)
+    d, K = 256, 4
+    G2 = chunk_diagonal(G, K)
+    rl = np.random.default_rng(12)
+    x0, th0 = rl.standard_normal(d), rl.choice([-1.0, 1.0], d)
+    c = 2.0 * pkg.problems.column_norms(G)
+    tr, (t, x, th), (acc, num) = pkg.parallel_spdmp(pkg.Partition(K, d), pkg.GaussianTarget(G), 0.0, x0, th0, 6.0, c, G,
+                                                    pkg.ZigZag(G2, np.zeros(d)), Δ=0.1, seed=81)
+    ev = tr.events
+    assert np.array_equal(ev["i"].astype(np.uint16), gold["parallel_idx"]) and np.array_equal(ev["t"][:50], gold["parallel_t_head"])
+    assert int(num) == int(gold["parallel_n"][0]) and int(acc) == int(gold["parallel_n"][1])
+    h = hashlib.sha256()
+    for a in (ev["t"], ev["x"], ev["theta"], x, th, t, c):
+        h.update(np.ascontiguousarray(a).tobytes())
+    assert h.hexdigest() == str(gold["parallel_hash"][0])

@@ -357,7 +357,7 @@ def test_boomerang_statistics_d8(pkg):
 
 
 def test_golden2_newer_paths():
-    """tests/golden/golden2.npz: logistic target (C4), FactBoomerang (spdmp / pdmp All), adaptscale, Boomerang -- the oracle
+    """tests/golden/golden2.npz: logistic target (C4), FactBoomerang (spdmp / pdmp All), adaptscale, Boomerang, parallel_spdmp -- the oracle
     still reproduces the committed index sequences, counters and payload hashes."""
     import importlib.util
     import os
