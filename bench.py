@@ -181,7 +181,7 @@ def make_workload(pkg, args, rank, local_rank):
         if not args.exact:
             ens.set_gradient_tracking(True)
         ens.set_state_synthetic(0.0, c, seed0)
-        W.update(G=G, c=c, d=d, cap=cap, ens=ens, kernel="zz_local_spec8_kernel" if args.exact else "zz_local_trackx_kernel",
+        W.update(G=G, c=c, d=d, cap=cap, ens=ens, kernel="zz_local_spec8_kernel" if args.exact else "zz_local_trackp_kernel",
                  unit="reflection events/s", evaluation="moving (bit-identical to the oracle)" if args.exact else
                  "tracked gradients (index sequence identical, floats to 1e-9: tests/test_gpu_track_parity.py)",
                  metric="reflection events/sec, d=16384 local ZigZag (spdmp), ensemble of independent chains",

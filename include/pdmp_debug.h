@@ -29,8 +29,9 @@ pdmp_status pdmp_debug_set_spec_g2(pdmp_ensemble* ens, int on);
 pdmp_status pdmp_debug_set_phase_profile(pdmp_ensemble* ens, int on);
 pdmp_status pdmp_debug_phase_profile(pdmp_ensemble* ens, double* out16, int* kind);
 /* gradient tracking: which kernel runs where the one-proposal-per-lane kernels apply (plain lattice graph, no adaptation, 2048 <= d <= 16384).
- * 0 = default (zz_local_trackx_kernel, key blocks of 16), 1 = the 8-lane-group kernel (zz_local_track_kernel), 2 = zz_local_trackw_kernel
- * (key blocks of 32), 3 = zz_local_trackx_kernel -- all of them commit the same sequence */
+ * 0 = default (zz_local_trackp_kernel: (key, time) pairs in blocks of 8, one dirty line per rejected proposal), 1 = the 8-lane-group kernel
+ * (zz_local_track_kernel), 2 = zz_local_trackw_kernel (key blocks of 32), 3 = zz_local_trackx_kernel (key blocks of 16), 4 = zz_local_trackp_kernel
+ * -- all of them commit the same sequence.  The choice fixes the queue's layout: call it BEFORE set_state. */
 pdmp_status pdmp_debug_set_track_groups(pdmp_ensemble* ens, int which);
 /* one-event kernel: print the first n proposals of chain 0 to stderr during the next run */
 pdmp_status pdmp_debug_set_proposal_dump(pdmp_ensemble* ens, int64_t n);

@@ -49,7 +49,7 @@ def test_tracked_matches_oracle_on_lattices(gpu_pkg, n, T):
     assert dev_t < 1e-11  # what is actually observed: a few 1e-14
 
 
-@pytest.mark.parametrize("which", [1, 2, 3])
+@pytest.mark.parametrize("which", [1, 2, 3, 4])
 def test_every_tracked_kernel_commits_the_same_sequence(gpu_pkg, monkeypatch, which):
     """The three tracked kernels -- 8-lane groups (1), one proposal per lane over key blocks of 32 (2) and of 16 (3, the default where it
     applies) -- against the oracle on a lattice all of them support (include/pdmp_debug.h: pdmp_debug_set_track_groups)."""

@@ -14,6 +14,7 @@ pkg = load_package()
 nch, rounds, d = 4096, 500, 16384
 for mode, name in [(15, "record line + key line, reads only"), (13, "record line + key line, both written (as built)"),
                    (17, "record line + key line, both written with non-temporal stores"),
+                   (18, "record line read only + ONE (key, time) line of a block of 8, 16 B of it written"),
                    (16, "record line + 256 B pair, reads only"), (14, "record line + 256 B pair, 16 B of the pair written")]:
     ms = pkg._lib.sector_probe(nch, d, rounds, mode)
     units = nch * rounds * 64

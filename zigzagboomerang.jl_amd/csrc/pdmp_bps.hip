@@ -658,7 +658,8 @@ __global__ __launch_bounds__(64) void sector_probe_kernel(double* rec, int64_t d
         //       (32 B per lane) and 16 bytes of it written (ONE dirty line per proposal)
         //   15 / 16: the reads of 13 / 14 alone
         //   17: 13 with non-temporal stores
-        const bool pairs = (write == 14 || write == 16), wr = (write <= 14 || write == 17), nt = (write == 17);
+        //   18: (key, proposal time) pairs in blocks of EIGHT -- the record line only read, ONE pair line read (16 B per lane) and 16 bytes of it written
+        const bool pairs = (write == 14 || write == 16), wr = (write <= 14 || write >= 17), nt = (write == 17), p8 = (write == 18);
         const int g = lane >> 3, gl = lane & 7;
         uint32_t hg = (uint32_t)chain * 2654435761u + (uint32_t)g * 40503u + 777u;
         for (int r = 0; r < rounds; ++r) {
@@ -685,7 +686,8 @@ __global__ __launch_bounds__(64) void sector_probe_kernel(double* rec, int64_t d
 #pragma unroll
             for (int q = 0; q < 8; ++q) acc += k[q].x + k2[q].y;
             if (wr) {
-                if (nt) {
+                if (p8) {
+                } else if (nt) {
                     __builtin_nontemporal_store(r0.x + 1.0, recl + 8);
                     __builtin_nontemporal_store(r1.y, recl + 9);
                     __builtin_nontemporal_store(r1.x, recl + 10);
@@ -696,7 +698,8 @@ __global__ __launch_bounds__(64) void sector_probe_kernel(double* rec, int64_t d
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     if (gl == (q & 7)) {
-                        if (pairs) reinterpret_cast<double2*>(bl[q])[2 * gl] = make_double2(k[q].x + 1.0, k[q].y);
+                        if (p8) reinterpret_cast<double2*>(bl[q])[gl] = make_double2(k[q].x + 1.0, k[q].y);
+                        else if (pairs) reinterpret_cast<double2*>(bl[q])[2 * gl] = make_double2(k[q].x + 1.0, k[q].y);
                         else if (nt) __builtin_nontemporal_store(k[q].x + 1.0, bl[q] + 2 * gl);
                         else bl[q][2 * gl] = k[q].x + 1.0;
                     }

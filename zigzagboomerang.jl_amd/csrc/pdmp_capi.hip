@@ -116,6 +116,8 @@ struct pdmp_ensemble {
     int dbg_track_groups = 0;      // gradient tracking: keep the 8-lane-group kernel where the one-proposal-per-lane kernel would run
     // tracked-gradient kernel (pdmp_ensemble_set_gradient_tracking)
     bool track_requested = false, track = false, track_two_sums = false;
+    bool track_pairs = false;  // the queue's level 0 is (key, time) pairs in d_kp (pdmp_trackp.hip); decided by set_state
+    DevBuf<double> d_kp;
     int32_t lattice_n = 0;  // the flow's graph is the n x n 5-point lattice in column-major numbering (0: it is not)
     double t0_state = 0.0;
     DevBuf<double> d_jstart, d_essacc;  // pdmp_ensemble_ess_*
@@ -313,7 +315,7 @@ pdmp_status pdmp_debug_phase_profile(pdmp_ensemble* e, double* out16, int* kind)
 }
 pdmp_status pdmp_debug_set_track_groups(pdmp_ensemble* e, int on) {
     if (!e) return fail(PDMP_ERR_INVALID, "null argument");
-    e->dbg_track_groups = (on >= 0 && on <= 3) ? on : 0;
+    e->dbg_track_groups = (on >= 0 && on <= 4) ? on : 0;
     return PDMP_OK;
 }
 pdmp_status pdmp_debug_set_proposal_dump(pdmp_ensemble* e, int64_t n) {
@@ -941,6 +943,24 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
     }
     int rc = pdmp::launch_zz_init(P, e->stream);
     if (rc != 0) return fail(PDMP_ERR_HIP, "zz_init launch failed: %s", hipGetErrorString((hipError_t)rc));
+    e->track_pairs = false;
+    if (e->track) {
+        // which tracked kernel will run is decided HERE (the pair layout belongs to one of them): pdmp_debug_set_track_groups before set_state
+        pdmp::ZzRunParams G{};
+        G.tb = e->tables();
+        G.lattice_n = e->lattice_n;
+        G.adapt = e->cfg.adapt;
+        G.c_chain = e->cfg.adapt ? e->d_c_chain.p : nullptr;
+        G.track_two_sums = e->track_two_sums ? 1 : 0;
+        G.has_refresh = e->lambda_ref > 0;
+        G.d = d;
+        if (pdmp::zz_trackp_supported(G) && (e->dbg_track_groups == 0 || e->dbg_track_groups == 4)) {
+            if (e->d_kp.n != (size_t)(2 * n * e->dk) && (st = e->d_kp.alloc((size_t)(2 * n * e->dk))) != PDMP_OK) return st;
+            rc = pdmp::launch_zz_keys_to_pairs(e->d_keys.p, e->d_kp.p, n * e->dk, t0, e->stream);
+            if (rc != 0) return fail(PDMP_ERR_HIP, "keys_to_pairs launch failed: %s", hipGetErrorString((hipError_t)rc));
+            e->track_pairs = true;
+        }
+    }
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->has_state = true;
     e->ran = false;
@@ -1107,6 +1127,19 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         P.lattice_n = e->lattice_n;
         P.lattice_magic = e->lattice_n ? (uint32_t)(((uint64_t)1 << 32) / (uint64_t)e->lattice_n + 1) : 0u;
         // one proposal per lane where the graph is the plain lattice (pdmp_trackw.hip); PDMP_DEBUG_KERNEL_SPEC4 keeps the 8-lane-group kernel
+        if (e->track_pairs) {
+            P.keys = e->d_kp.p;
+            int rcp = pdmp::launch_zz_local_trackp(P, e->cfg.nchains, s);
+            if (rcp != 0) return fail(PDMP_ERR_HIP, "zz_local_trackp launch failed (%d)", rcp);
+            HIP_TRY(hipEventRecord(e->ev1, s));
+            e->timed = true;
+            if (phenv) {
+                HIP_TRY(hipDeviceSynchronize());
+                HIP_TRY(hipMemcpy(e->dbg_phase_out, phbuf.p, sizeof e->dbg_phase_out, hipMemcpyDeviceToHost));
+                e->dbg_phase_valid = 1;
+            }
+            return PDMP_OK;
+        }
         const bool wide = pdmp::zz_trackw_supported(P) && e->dbg_track_groups != 1;
         const bool wide16 = wide && pdmp::zz_trackx_supported(P) && e->dbg_track_groups != 2;
         int rct = wide16 ? pdmp::launch_zz_local_trackx(P, e->cfg.nchains, s)
@@ -1240,7 +1273,7 @@ pdmp_status pdmp_ensemble_final_state(pdmp_ensemble* e, int64_t chain_first, int
     const double* c_src = e->cfg.adapt ? e->d_c_chain.p : e->d_c.p;
     const int64_t c_stride = e->cfg.adapt ? d : 0;
     int rc = e->track ? pdmp::launch_zz_track_unpack(reinterpret_cast<const pdmp::TrRec*>(e->d_rec.p), e->tables(), c_src, c_stride, d,
-                                                     chain_first, n, e->t0_state, bt.p, bx.p, bth.p, bacc.p, bc.p, e->stream)
+                                                     chain_first, n, e->t0_state, bt.p, bx.p, bth.p, bacc.p, bc.p, e->track_pairs ? e->d_kp.p : nullptr, e->dk, e->stream)
                        : pdmp::launch_zz_unpack(e->d_rec.p, c_src, c_stride, d, chain_first, n, bt.p, bx.p, bth.p, bacc.p, bc.p,
                                                 e->stream);
     if (rc != 0) return fail(PDMP_ERR_HIP, "unpack launch failed: %s", hipGetErrorString((hipError_t)rc));

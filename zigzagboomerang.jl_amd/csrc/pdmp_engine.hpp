@@ -296,9 +296,14 @@ int launch_zz_local_trackw(const ZzRunParams& p, int64_t nchains, void* stream);
 bool zz_trackw_supported(const ZzRunParams& p);
 bool zz_trackx_supported(const ZzRunParams& p);
 int launch_zz_local_trackx(const ZzRunParams& p, int64_t nchains, void* stream);
+bool zz_trackp_supported(const ZzRunParams& p);
+int launch_zz_local_trackp(const ZzRunParams& p, int64_t nchains, void* stream);
+int launch_zz_keys_to_pairs(const double* keys, void* kp, int64_t n, double t0, void* stream);
 bool zz_spec8_geometry(const ZzRunParams& p);  // the 8-event kernels' requirements on the neighbourhood blob and on d
+// kp != nullptr: the (key, time of the last own proposal) pairs of pdmp_trackp.hip hold tprop instead of the records (chain stride dk pairs)
 int launch_zz_track_unpack(const TrRec* rec, const ZzTables& tb, const double* c_src, int64_t c_stride, int64_t d, int64_t chain_first,
-                           int64_t n, double t0, double* t, double* x, double* th, int64_t* acc, double* c, void* stream);
+                           int64_t n, double t0, double* t, double* x, double* th, int64_t* acc, double* c, const double* kp, int64_t dk,
+                           void* stream);
 int launch_zz_ess(const ZzRec* rec, int64_t rec_stride, double* jprev, double* jstart, int64_t d, int64_t nchains, int mode, double T_prev,
                   double T, double* acc, void* stream);
 size_t zz_local_lds_bytes(uint32_t nblk_pad, uint32_t blob_w_pad);

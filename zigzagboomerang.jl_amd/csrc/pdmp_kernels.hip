@@ -3792,18 +3792,19 @@ __global__ __launch_bounds__(256) void zz_unpack_kernel(const ZzRec* rec, const 
 // linearly from its own clock to that time.
 __global__ __launch_bounds__(256) void zz_track_unpack_kernel(const TrRec* rec0, ZzTables tb, const double* c_src, int64_t c_stride, int64_t d,
                                                               int64_t chain_first, double t0, double* t, double* x, double* th,
-                                                              int64_t* acc, double* c) {
+                                                              int64_t* acc, double* c, const double2* kp0, int64_t dk) {
     const int64_t n = blockIdx.x;
     const int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x;
     if (i >= d) return;
     const TrRec* rec = rec0 + (chain_first + n) * d;
     const TrRec r = rec[i];
+    const double2* kp = kp0 ? kp0 + (chain_first + n) * dk : nullptr;
     double tr = t0;
     const uint32_t k = tb.colptr[i + 1] - tb.colptr[i];
     const uint32_t s0 = tb.sptr[i], s1 = tb.sptr[i + 1];
     for (uint32_t p = s0; p < s1; ++p) {  // S[i] = G1[i] followed by G2[i]; the patterns are symmetric: j ∈ S[i] <=> i ∈ S[j]
         const uint32_t j = tb.sidx[p];
-        const double tpj = rec[j].tprop, taj = rec[j].tacc;
+        const double tpj = kp ? kp[j].y : rec[j].tprop, taj = rec[j].tacc;
         if (p - s0 < k && tpj > tr) tr = tpj;
         if (taj > tr) tr = taj;
     }
@@ -4019,10 +4020,11 @@ int launch_zz_unpack(const ZzRec* rec, const double* c_src, int64_t c_stride, in
 }
 
 int launch_zz_track_unpack(const TrRec* rec, const ZzTables& tb, const double* c_src, int64_t c_stride, int64_t d, int64_t chain_first,
-                           int64_t n, double t0, double* t, double* x, double* th, int64_t* acc, double* c, void* stream) {
+                           int64_t n, double t0, double* t, double* x, double* th, int64_t* acc, double* c, const double* kp, int64_t dk,
+                           void* stream) {
     dim3 grid((unsigned)n, (unsigned)((d + 255) / 256));
     hipLaunchKernelGGL(zz_track_unpack_kernel, grid, dim3(256), 0, (hipStream_t)stream, rec, tb, c_src, c_stride, d, chain_first, t0, t, x,
-                       th, acc, c);
+                       th, acc, c, reinterpret_cast<const double2*>(kp), dk);
     return (int)hipGetLastError();
 }
 

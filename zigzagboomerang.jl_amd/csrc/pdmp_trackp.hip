@@ -1,0 +1,871 @@
+// pdmp_trackp.hip -- zz_local_trackp_kernel: pdmp_trackx.hip's one-proposal-per-lane tracked-gradient kernel with ONE dirty line per rejected
+// proposal.
+//
+// What bounds pdmp_trackx.hip is the memory system, and mostly its write-backs: a rejected proposal (82 %) reads its record line
+// and its key block's line and dirties BOTH (bound + proposal time in the record, the new key in the key block); a dirty line costs about 1.8
+// line reads.  Here a rejected proposal dirties one line:
+//   * the queue's level 0 holds PAIRS (key, time of the coordinate's last proposal), 8 coordinates per 128-byte line; the record is only READ by
+//     a proposal -- its bound is re-derived, bit for bit, from what the record and the pair hold: t_old = max(tprop, tg), a = c + (g + gd (t_old − tg)) θ,
+//     b = c/100 + θ gd (every re-bound happens either at the coordinate's own proposal or when g, gd are re-based, so these are the stored values);
+//   * 2048 blocks of 8 do not fit the LDS as doubles, so level 1 is a LOWER BOUND of each block's minimum: (min − base) rounded down to a float,
+//     minus 8 ulp, with the argument's position in the three low bits, compared as integers.  Every block whose bound is within the threshold is
+//     a candidate; its line is read anyway (the exposure test needs the block's second key), which yields the exact minimum -- candidates are
+//     ranked by exact keys, those beyond the exact threshold are no events and just refresh their bound.  Bounds may go stale LOW (a block
+//     minimum whose key rose: its neighbour re-bounds it), never high: lowering is an LDS atomic minimum, and no rescans exist any more.  The
+//     record of a candidate is requested together with its line using the position bits; a position that turns out wrong ends the list there.
+// The committed sequence and every float are those of pdmp_trackx.hip (index-exact against the oracle, floats to ~1e-13).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/pdmp_detmath.h"
+#include "pdmp_engine.hpp"
+
+namespace pdmp {
+
+#define W_INF __builtin_inf()
+#define W_ORDER()                        \
+    do {                                 \
+        __builtin_amdgcn_wave_barrier(); \
+        asm volatile("" ::: "memory");   \
+    } while (0)
+
+namespace {
+
+__device__ __forceinline__ double w_readlane(double v, int srclane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double w_uniform(double v) {
+    int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ double w_dpp(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double w_min(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double w_wave_min(double v) {
+    v = w_min(v, w_dpp<0xB1>(v));
+    v = w_min(v, w_dpp<0x4E>(v));
+    v = w_min(v, w_dpp<0x141>(v));
+    v = w_min(v, w_dpp<0x140>(v));
+    v = w_min(v, w_dpp<0x142>(v));
+    v = w_min(v, w_dpp<0x143>(v));
+    return w_readlane(v, 63);
+}
+// minimum over the 8 lanes of a group, in every lane of the group
+__device__ __forceinline__ double w_grp8_min(double v) {
+    v = w_min(v, w_dpp<0xB1>(v));
+    v = w_min(v, w_dpp<0x4E>(v));
+    v = w_min(v, w_dpp<0x141>(v));
+    return v;
+}
+__device__ __forceinline__ double w_pos(double x) {
+    return (x > 0.0) ? x : ((x != x) ? x : 0.0);
+}
+__device__ __forceinline__ double w_poisson_time_L(double a, double b, double L) {  // src/poissontime.jl:8-30 with L = log(u)
+    if (b == 0) return (a > 0) ? -L / a : W_INF;
+    const double r = a / b;
+    const double q = L * 2.0 / b;
+    const double sq = sqrt((b > 0 && a < 0) ? -q : r * r - q);
+    if (b > 0) return sq - r;
+    if (a <= 0) return W_INF;
+    if (-L <= -(a * a) / b + (a * a) / (2 * b)) return -sq - r;
+    return W_INF;
+}
+__device__ __forceinline__ double w_below(double x) {  // the largest double below a finite x
+    long long b = __double_as_longlong(x);
+    if (x > 0) b -= 1;
+    else if (x < 0) b += 1;
+    else b = (long long)0x8000000000000001ull;
+    return __longlong_as_double(b);
+}
+
+// DPP prefix operations over the 64 lanes (row_shr 1, 2, 3 of the input, then row_shr 4 / 8 of the partial result inside the enabled banks,
+// then row_bcast 15 / 31 across the rows): lanes without a source keep the identity.
+template <int CTRL, int ROWM, int BANKM>
+__device__ __forceinline__ uint32_t w_dpp_id_u32(uint32_t identity, uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)src, CTRL, ROWM, BANKM, false);
+}
+__device__ __forceinline__ uint32_t w_scan_add_u32(uint32_t v) {  // inclusive
+    uint32_t x = v;
+    x += w_dpp_id_u32<0x111, 0xf, 0xf>(0u, v);
+    x += w_dpp_id_u32<0x112, 0xf, 0xf>(0u, v);
+    x += w_dpp_id_u32<0x113, 0xf, 0xf>(0u, v);
+    x += w_dpp_id_u32<0x114, 0xf, 0xe>(0u, x);
+    x += w_dpp_id_u32<0x118, 0xf, 0xc>(0u, x);
+    x += w_dpp_id_u32<0x142, 0xa, 0xf>(0u, x);
+    x += w_dpp_id_u32<0x143, 0xc, 0xf>(0u, x);
+    return x;
+}
+template <int CTRL, int ROWM, int BANKM>
+__device__ __forceinline__ double w_dpp_inf(double src) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(src), CTRL, ROWM, BANKM, false);
+    const int hi = __builtin_amdgcn_update_dpp(0x7FF00000, __double2hiint(src), CTRL, ROWM, BANKM, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double w_scan_min_f64(double v) {  // inclusive
+    double x = v;
+    x = w_min(x, w_dpp_inf<0x111, 0xf, 0xf>(v));
+    x = w_min(x, w_dpp_inf<0x112, 0xf, 0xf>(v));
+    x = w_min(x, w_dpp_inf<0x113, 0xf, 0xf>(v));
+    x = w_min(x, w_dpp_inf<0x114, 0xf, 0xe>(x));
+    x = w_min(x, w_dpp_inf<0x118, 0xf, 0xc>(x));
+    x = w_min(x, w_dpp_inf<0x142, 0xa, 0xf>(x));
+    x = w_min(x, w_dpp_inf<0x143, 0xc, 0xf>(x));
+    return x;
+}
+__device__ __forceinline__ double w_shfl(double v, uint32_t src) {
+    const int lo = __builtin_amdgcn_ds_bpermute((int)(src << 2), __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute((int)(src << 2), __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// level-1 entry: a lower bound of (key - tb) as the bit pattern of a non-negative float, 8 ulp below the rounded-down difference, with the
+// argument's position in the 3 low bits (bit patterns of non-negative floats order like the floats)
+__device__ __forceinline__ uint32_t p_enc(double key, double tb, uint32_t pos) {
+    double dlt = key - tb;
+    dlt = (dlt > 0.0) ? dlt : 0.0;
+    const uint32_t b = __float_as_uint(__double2float_rd(dlt));
+    return (((b >= 8u) ? b - 8u : 0u) & ~7u) | pos;
+}
+// the largest pattern a block with exact minimum <= tau can carry
+__device__ __forceinline__ uint32_t p_thr(double tau, double tb) {
+    double dlt = tau - tb;
+    dlt = (dlt > 0.0) ? dlt : 0.0;
+    return __float_as_uint(__double2float_ru(dlt));
+}
+__device__ __forceinline__ double p_dec(uint32_t bits, double tb) {
+    return w_below(tb + (double)__uint_as_float(bits & ~7u));  // (one ulp below the rounded sum: never above the exact one)
+}
+constexpr uint32_t P_INFBITS = 0x7f7ffff8u;  // patterns from here on: the block is empty (+Inf)
+
+}  // namespace
+
+// LDS layout (bytes)
+constexpr uint32_t W_LB = 0;         // [2048] u32 lower bounds of the block minima (+ argument position), key blocks of 8
+constexpr uint32_t W_EX = 8192;      // [64] f64 what event e exposes; before that the exact block minima of the candidates
+constexpr uint32_t W_RS = 8704;      // [56] f64 candidates: block minimum without the argument
+constexpr uint32_t W_TP = 9152;      // [56] f64 candidates: proposal time stored with the argument
+constexpr uint32_t W_PB = 9600;      // [56] u8 candidates: position of the argument | position of the runner-up << 4
+constexpr uint32_t W_SLB = 9664;     // [64] u16 event blocks, rank order
+constexpr uint32_t W_TB = 9792;      // [64] u16 candidate blocks, compaction order
+constexpr uint32_t W_ACL = 9920;     // [8] u16 the accepted events
+constexpr uint32_t W_RO = 9936;      // [64] u8 candidate of each rank
+constexpr uint32_t W_SELDT = 10000;  // f64 selection threshold above the minimum
+constexpr uint32_t W_BYTES = 10008;
+constexpr uint32_t W_NBLK = 2048;
+constexpr uint32_t W_WIN = 128;      // draws held in registers (two per lane)
+constexpr int W_CMAX = 56;           // candidates per iteration (7 block-scan passes of 8)
+constexpr int W_AMAX = 8;            // accepted events per iteration (one group each)
+#ifndef W_GROW
+#define W_GROW 1.15
+#define W_SHRINK 0.8
+#define W_SLACK 3u
+#endif
+static_assert(W_BYTES <= 10240, "16 chains per CU: 160 KB / 16");
+
+template <bool PROF>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void zz_local_trackp_kernel(ZzRunParams P) {
+    const int lane = threadIdx.x;
+    const int g = lane >> 3, gl = lane & 7;
+    const int64_t chain = blockIdx.x;
+    const int64_t d = P.d;
+    const uint32_t nblk = P.nblk;
+    const uint32_t nlat = (uint32_t)P.lattice_n, nmagic = P.lattice_magic;
+
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t* const lbf = reinterpret_cast<uint32_t*>(smem + W_LB);
+    double* const EX = reinterpret_cast<double*>(smem + W_EX);
+    double* const KM = EX;  // (exact block minima of the candidates, until the events are set up)
+    double* const RS = reinterpret_cast<double*>(smem + W_RS);
+    double* const TPR = reinterpret_cast<double*>(smem + W_TP);
+    uint8_t* const PB = reinterpret_cast<uint8_t*>(smem + W_PB);
+    uint16_t* const SLB = reinterpret_cast<uint16_t*>(smem + W_SLB);
+    uint16_t* const TB = reinterpret_cast<uint16_t*>(smem + W_TB);
+    uint16_t* const ACL = reinterpret_cast<uint16_t*>(smem + W_ACL);
+    uint8_t* const RO = reinterpret_cast<uint8_t*>(smem + W_RO);
+    double* const SELDT = reinterpret_cast<double*>(smem + W_SELDT);
+
+    TrRec* const rec = reinterpret_cast<TrRec*>(P.rec) + chain * d;
+    double2* const kp = reinterpret_cast<double2*>(P.keys) + chain * P.dk;  // (key, time of the last own proposal) per coordinate
+    DevChain* const hdr = P.hdr + chain;
+    pdmp_event* const evout = P.ev ? P.ev + chain * P.trace_cap : nullptr;
+
+    uint32_t status = hdr->c.status;
+    if (status == PDMP_CHAIN_BOUND_VIOLATED || status == PDMP_CHAIN_STALLED) return;
+    const uint64_t seed = hdr->seed;
+    const uint64_t nm0 = hdr->c.ndraw_main, ntrace0 = hdr->c.ntrace;
+    uint32_t dnm = 0, dnum = 0, dnacc = 0, vnacc = 0;
+    // ring of uniforms in registers: ureg[q] holds draw nm0 + uidx[q], the unique index n in [dnm, dnm + 128) with n % 64 == lane and (n / 64) % 2 == q
+    double ureg[2] = {0.0, 0.0};
+    uint32_t uidx[2] = {0xffffffffu, 0xffffffffu};
+    double t_last = hdr->c.t_last;
+    double t_event = hdr->t_event;
+    status = PDMP_CHAIN_OK;
+    const double T = P.T;
+    const bool stop_before = (P.flags & PDMP_RUN_STOP_BEFORE) != 0;
+    const uint32_t trace_room = (P.trace_cap > 0)
+                                    ? (uint32_t)(((uint64_t)P.trace_cap > ntrace0) ? ((uint64_t)P.trace_cap - ntrace0) : 0)
+                                    : 0xffffffffu;
+
+    if (lane == 0) SELDT[0] = 1e-3;
+    // base of the level-1 bounds: below every key (the initial keys of the reference carry no t0, src/sfact.jl:186)
+    double tb;  // (wave-uniform; moves up with the front)
+    {
+        double mloc = t_last;
+        for (uint32_t b = lane; b < nblk; b += 64) {
+            const double2* p = kp + (size_t)b * 8;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) mloc = w_min(mloc, p[q].x);
+        }
+        tb = w_wave_min(mloc);
+    }
+    for (uint32_t b = lane; b < W_NBLK; b += 64) {
+        uint32_t e = P_INFBITS;
+        if (b < nblk) {
+            const double2* p = kp + (size_t)b * 8;
+            double mk = p[0].x;
+            uint32_t mi = 0;
+#pragma unroll
+            for (int q = 1; q < 8; ++q) {
+                const double v = p[q].x;
+                if (v < mk) {
+                    mk = v;
+                    mi = q;
+                }
+            }
+            e = (mk < W_INF) ? p_enc(mk, tb, mi) : P_INFBITS;
+        }
+        lbf[b] = e;
+    }
+    W_ORDER();
+
+    uint64_t ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t ph_t0 = PROF ? (uint64_t)__builtin_readcyclecounter() : 0;
+    uint64_t ph_iters = 0, ph_raw = 0, ph_zone = 0, ph_eval = 0;  // candidates: selected, after the zone cut, after the window and accept limits
+#define WPHASE(k)                                                         \
+    do {                                                                  \
+        if (PROF) {                                                       \
+            const uint64_t now_ = (uint64_t)__builtin_readcyclecounter(); \
+            ph[k] += now_ - ph_t0;                                        \
+            ph_t0 = now_;                                                 \
+        }                                                                 \
+    } while (0)
+
+    PrioTurn prio;
+    bool need_rebase = false;
+    uint32_t idle = 0;  // consecutive iterations without an event
+    bool running = stop_before || (t_event < T);
+    while (running) {
+        prio.step();
+        if (dnacc >= trace_room) {
+            status = PDMP_CHAIN_TRACE_FULL;
+            break;
+        }
+        // ---------------- ring of uniforms: draws dnm .. dnm + 127, two per lane
+        {
+            const uint32_t n0 = dnm + (((uint32_t)lane - dnm) & 63u);  // the smallest n >= dnm with n % 64 == lane
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t n = n0 + 64u * (uint32_t)h;
+                const int q = (int)((n >> 6) & 1u);
+                const bool need0 = (q == 0) && uidx[0] != n, need1 = (q == 1) && uidx[1] != n;
+                if (__ballot(need0 || need1) != 0) {
+                    const double u = pdmp_u01(seed, PDMP_STREAM_MAIN, nm0 + (uint64_t)n);
+                    if (need0) {
+                        ureg[0] = u;
+                        uidx[0] = n;
+                    }
+                    if (need1) {
+                        ureg[1] = u;
+                        uidx[1] = n;
+                    }
+                }
+            }
+        }
+        WPHASE(7);
+        auto draw = [&](uint32_t n) -> double {  // draw nm0 + n for dnm <= n < dnm + 128 (every lane calls it: ds_bpermute)
+            const double v0 = w_shfl(ureg[0], n & 63u), v1 = w_shfl(ureg[1], n & 63u);
+            return ((n >> 6) & 1u) ? v1 : v0;
+        };
+        // ---------------- select: every block whose lower bound is within the threshold, at most W_CMAX of them
+        int C = 0;
+        bool stalled = false, finished = false;
+        double dt_used = 0.0;
+        uint32_t Cc = 0;
+        double tau = 0.0;
+        bool tau_clipped = false;
+        {
+            uint32_t kk[32];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {  // lane's 32 entries: blocks 4 (lane + 64 j) + 0..3 (one 16-byte read each)
+                const uint4 v = reinterpret_cast<const uint4*>(lbf)[lane + 64 * j];
+                kk[4 * j + 0] = v.x;
+                kk[4 * j + 1] = v.y;
+                kk[4 * j + 2] = v.z;
+                kk[4 * j + 3] = v.w;
+            }
+            uint32_t mloc = kk[0];
+#pragma unroll
+            for (int j = 1; j < 32; ++j) mloc = (kk[j] < mloc) ? kk[j] : mloc;
+            for (int off = 32; off >= 1; off >>= 1) {
+                const uint32_t o = (uint32_t)__shfl_xor((int)mloc, off, 64);
+                mloc = (o < mloc) ? o : mloc;
+            }
+            uint32_t mqb = mloc;
+            double mql = p_dec(mqb, tb);  // a lower bound of the next event time
+            if (mqb < P_INFBITS && (need_rebase || mql - tb > 0.25)) {
+                // move the base of the bounds up to the front (a float resolves 2^-24 of its distance from the base)
+#pragma unroll
+                for (int j = 0; j < 32; ++j)
+                    kk[j] = (kk[j] >= P_INFBITS) ? P_INFBITS : p_enc(p_dec(kk[j], tb), mql, kk[j] & 7u);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    reinterpret_cast<uint4*>(lbf)[lane + 64 * j] = make_uint4(kk[4 * j + 0], kk[4 * j + 1], kk[4 * j + 2], kk[4 * j + 3]);
+                tb = mql;
+                need_rebase = false;
+                mloc = kk[0];
+#pragma unroll
+                for (int j = 1; j < 32; ++j) mloc = (kk[j] < mloc) ? kk[j] : mloc;
+                for (int off = 32; off >= 1; off >>= 1) {
+                    const uint32_t o = (uint32_t)__shfl_xor((int)mloc, off, 64);
+                    mloc = (o < mloc) ? o : mloc;
+                }
+                mqb = mloc;
+                mql = p_dec(mqb, tb);
+                W_ORDER();
+            }
+            if (mqb >= P_INFBITS) {
+                stalled = true;
+            } else if (stop_before && !(mql < T)) {
+                finished = true;
+            } else {
+                double dt_sel = w_uniform(SELDT[0]);
+                uint32_t cm = 0, ncl = 0, incl = 0;
+                for (int tries = 0;; ++tries) {
+                    tau = mql + dt_sel;
+                    tau_clipped = false;
+                    if (stop_before && !(tau < T)) {
+                        tau = w_below(T);
+                        tau_clipped = true;
+                    }
+                    if (tries >= 64) tau = mql;
+                    const uint32_t thr = p_thr(tau, tb);
+                    cm = 0;
+#pragma unroll
+                    for (int j = 31; j >= 0; --j) cm = cm + cm + ((kk[j] <= thr) ? 1u : 0u);
+                    ncl = (uint32_t)__builtin_popcount(cm);
+                    incl = w_scan_add_u32(ncl);
+                    Cc = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    if (Cc <= (uint32_t)W_CMAX || tries >= 64) break;
+                    dt_sel *= 0.5;
+                }
+                {
+                    // (more than W_CMAX blocks inside the narrowest threshold: the first W_CMAX are looked at, see below)
+                    uint32_t ix = incl - ncl, m_ = cm;
+                    while (__ballot(m_ != 0u) != 0) {
+                        if (m_ != 0u) {
+                            const uint32_t j = (uint32_t)(__ffs((int)m_) - 1);
+                            if (ix < 64u) TB[ix] = (uint16_t)(4u * ((uint32_t)lane + 64u * (j >> 2)) + (j & 3u));
+                            ix += 1;
+                            m_ &= m_ - 1u;
+                        }
+                    }
+                }
+                dt_used = dt_sel;
+            }
+        }
+        if (stalled) {
+            status = PDMP_CHAIN_STALLED;
+            break;
+        }
+        if (finished) break;
+        W_ORDER();
+        WPHASE(8);
+        const bool crowded = Cc > (uint32_t)W_CMAX;  // exact ties beyond W_CMAX blocks (keys tied by construction): handled one event at a time
+        if (crowded) Cc = (uint32_t)W_CMAX;
+        // ---------------- candidate lane c: its block, the record the position bits point at (requested now, with the block's line)
+        const bool isc = (uint32_t)lane < Cc;
+        const uint32_t cblk = isc ? (uint32_t)TB[lane] : 0u;
+        const uint32_t cpos = isc ? (lbf[cblk] & 7u) : 0u;
+        const uint32_t ci = cblk * 8u + cpos;
+        const TrRec* const rci = rec + ci;
+        const double c_th = rci->th, c_g = rci->g, c_gd = rci->gd, c_tg = rci->tg;
+        const double2 c_c2 = *reinterpret_cast<const double2*>(&P.tb.cc_shared[ci].c);
+        const uint32_t c_k = P.tb.cc_shared[ci].k;
+        // ---------------- the candidates' lines, 8 per pass (one per 8-lane group, one (key, time) pair per lane): exact minimum, its position and
+        // time, the minimum of the rest and its position -- staged in LDS per candidate
+        {
+            const int npass = ((int)Cc + 7) >> 3;
+            for (int p0 = 0; p0 < npass; p0 += 4) {
+                double2 k2[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int e = 8 * (p0 + q) + g;
+                    k2[q] = make_double2(W_INF, 0.0);
+                    if (e < (int)Cc) k2[q] = kp[(size_t)TB[e] * 8 + gl];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (8 * (p0 + q) >= (int)Cc) continue;  // (uniform)
+                    const int e = 8 * (p0 + q) + g;
+                    const double kq = k2[q].x;
+                    const double gm = w_grp8_min(kq);
+                    const uint64_t winball = __ballot(kq == gm);
+                    const int wl = __ffs((unsigned)((winball >> (8 * g)) & 0xffu)) - 1;  // (>= 0)
+                    const double kr = (gl == wl) ? W_INF : kq;
+                    const double gr = w_grp8_min(kr);
+                    const uint64_t rball = __ballot(kr == gr);
+                    const int rl = __ffs((unsigned)((rball >> (8 * g)) & 0xffu)) - 1;
+                    if (gl == wl && e < (int)Cc) {
+                        KM[e] = gm;
+                        RS[e] = gr;
+                        TPR[e] = k2[q].y;
+                        PB[e] = (uint8_t)((uint32_t)wl | ((uint32_t)rl << 4));
+                    }
+                }
+            }
+        }
+        W_ORDER();
+        // ---------------- events = candidates whose exact minimum is within the threshold; everybody refreshes its bound
+        const double c_km = isc ? KM[lane] : W_INF;
+        const uint32_t c_pb = isc ? (uint32_t)PB[lane] : 0u;
+        if (isc) lbf[cblk] = (c_km < W_INF) ? p_enc(c_km, tb, c_pb & 7u) : P_INFBITS;
+        bool isev = isc && c_km <= tau;
+        if (crowded) {
+            // the narrowest threshold still holds more than W_CMAX blocks (their bounds fall into one float bucket): no event this iteration --
+            // the looked-at blocks get exact bounds against a base moved up to the front, which separates them; blocks not looked at come next
+            isev = false;
+            need_rebase = true;
+        }
+        const double own = isev ? c_km : W_INF;
+        uint32_t rank = 0;
+        for (uint32_t m0 = 0; m0 < Cc; m0 += 4) {  // (lanes past the candidates hold +Inf: reading them changes nothing)
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) {
+                const double km = w_readlane(own, (int)(m0 + q));
+                rank += (km < own) ? 1u : 0u;
+            }
+        }
+        const uint64_t evb = __ballot(isev);
+        int nev = __popcll(evb);
+        if (isev) RO[rank] = (uint8_t)lane;
+        W_ORDER();
+        const bool dup = isev && RO[rank] != (uint8_t)lane;
+        if (__ballot(dup) != 0) {
+            // exactly equal keys among the events (probability zero unless keys are tied by construction): one event this iteration, the tied
+            // minimum of the lowest block
+            const double mn = w_wave_min(own);
+            uint32_t bsel = (isev && own == mn) ? cblk : 0xffffffffu;
+            for (int off = 32; off >= 1; off >>= 1) {
+                const uint32_t o = (uint32_t)__shfl_xor((int)bsel, off, 64);
+                bsel = (o < bsel) ? o : bsel;
+            }
+            W_ORDER();
+            if (isev && cblk == bsel) RO[0] = (uint8_t)lane;
+            nev = 1;
+            W_ORDER();
+        }
+        // a candidate whose record was requested at the wrong position ends the list at its rank
+        {
+            const bool wrongpos = isev && (c_pb & 7u) != cpos;
+            uint32_t wr = wrongpos ? rank : 0xffffffffu;
+            for (int off = 32; off >= 1; off >>= 1) {
+                const uint32_t o = (uint32_t)__shfl_xor((int)wr, off, 64);
+                wr = (o < wr) ? o : wr;
+            }
+            if (wr < (uint32_t)nev) nev = (int)wr;
+        }
+        WPHASE(9);
+        C = nev;
+        if (PROF) ph_iters += 1;
+        if (PROF) ph_raw += (uint64_t)Cc;
+        const int Craw = (int)Cc;
+        if (C == 0) {
+            // nothing to do in this window (stale bounds refreshed, a wrong position fixed, or no key before T)
+            if (tau_clipped && !crowded && __ballot(isc && c_km <= tau) == 0) break;  // stop_before: every key is at or beyond T
+            if (++idle > 4096u) {
+                status = PDMP_CHAIN_STALLED;  // (more than W_CMAX exactly tied block minima: keys tied by construction)
+                break;
+            }
+            if (lane == 0) SELDT[0] = dt_used * 2.0;
+            W_ORDER();
+            continue;
+        }
+        // ---------------- lane r = event r: everything moves over from its candidate's lane
+        bool ev = lane < C;
+        const uint32_t src = ev ? (uint32_t)RO[lane] : 0u;
+        const uint32_t blk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)cblk);
+        const uint32_t pbe = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)c_pb);
+        const double tp = ev ? KM[src] : W_INF;  // the event time: the exact block minimum
+        const double rest = ev ? RS[src] : W_INF;
+        const double tprop_i = ev ? TPR[src] : 0.0;
+        const uint32_t i = ev ? (blk * 8u + (pbe & 7u)) : 0u;
+        const uint32_t rarg = blk * 8u + (pbe >> 4);
+        const double th = w_shfl(c_th, src), g_i = w_shfl(c_g, src), gd_i = w_shfl(c_gd, src), tg_i = w_shfl(c_tg, src);
+        const double2 c_i2 = make_double2(w_shfl(c_c2.x, src), w_shfl(c_c2.y, src));
+        const double c_i = c_i2.x;
+        const uint32_t k_i = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)c_k);
+        W_ORDER();
+        if (ev) SLB[lane] = (uint16_t)blk;
+        W_ORDER();
+        WPHASE(0);
+        // lattice coordinates packed for the zone test: byte 0 = row, byte 1 = column
+        const uint32_t col_i = __umulhi(i, nmagic);
+        const uint32_t rc_i = ev ? ((i - col_i * nlat) | (col_i << 8)) : 0xffffu;
+        // ---------------- zones: event r cannot commit with an earlier event whose G1 meets its own (Manhattan distance of the lattice
+        // coordinates <= 2): the list ends at the first such event
+        {
+            uint64_t confb = 0;
+            for (int m0 = 0; m0 < C - 1; m0 += 4) {  // (lanes past the events hold a far-away cell: reading them changes nothing)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = m0 + q;
+                    const uint32_t rcm = (uint32_t)__builtin_amdgcn_readlane((int)rc_i, m);
+                    const uint32_t sad = __builtin_amdgcn_sad_u8(rc_i, rcm, 0u);
+                    const uint64_t near = __ballot(sad <= 2u);
+                    confb |= near & (~0ull << (m + 1));
+                }
+            }
+            const uint64_t cb = confb & ((C < 64) ? ((1ull << C) - 1ull) : ~0ull);
+            if (cb) {
+                const int c0 = __ffsll((unsigned long long)cb) - 1;
+                C = (c0 < C) ? c0 : C;
+            }
+            ev = lane < C;
+        }
+        if (PROF) ph_zone += (uint64_t)C;
+        W_ORDER();
+        WPHASE(1);
+        // ---------------- rates from the tracked sums (src/sfact.jl:116-119 with g_i(t′) = g_i + gd_i (t′ − tg_i))
+        const double g_now = g_i + gd_i * (tp - tg_i);
+        const double l = w_pos(g_now * th);
+        // the bound in force (src/fact_samplers.jl:50-54), re-derived: it was computed at told = the later of the coordinate's last proposal and
+        // the last re-basing of its sums, from exactly these operands
+        const double told_i = (tprop_i > tg_i) ? tprop_i : tg_i;
+        const double a_i = c_i + (g_i + gd_i * (told_i - tg_i)) * th;
+        const double b_i = c_i2.y + th * gd_i;
+        const double lbound = w_pos(a_i + b_i * (tp - told_i));
+        // ---------------- accept chain: offsets and outcomes as a fix-point (every round settles the events up to the next change)
+        uint32_t cost = ev ? 2u : 0u;
+        uint32_t off = 0;
+        bool acc = false;
+        for (int round = 0; round < 66; ++round) {
+            const uint32_t incl = w_scan_add_u32(cost);
+            off = incl - cost;
+            const bool inwin = ev && (off + 1u + k_i <= W_WIN);
+            const double u = draw(dnm + ((off < 127u) ? off : 127u));
+            acc = inwin && (u * lbound < l);  // :121
+            const uint32_t nc = ev ? (acc ? (1u + k_i) : 2u) : 0u;
+            const bool changed = nc != cost;
+            cost = nc;
+            if (__ballot(changed) == 0) break;
+        }
+        // events whose draws would leave the ring wait for the next iteration
+        {
+            const uint64_t outb = __ballot(ev && !(off + 1u + k_i <= W_WIN));
+            if (outb) {
+                const int cut = __ffsll((unsigned long long)outb) - 1;
+                C = (cut < C) ? cut : C;
+            }
+        }
+        // at most W_AMAX accepted events per iteration: the candidate list ends before the next one
+        {
+            uint64_t ab = __ballot(acc) & ((C < 64) ? ((1ull << C) - 1ull) : ~0ull);
+            if (__popcll(ab) > W_AMAX) {
+                uint64_t m_ = ab;
+                for (int q = 0; q < W_AMAX; ++q) m_ &= m_ - 1;
+                C = __ffsll((unsigned long long)m_) - 1;
+            }
+        }
+        // a proposal that violates its bound ends the run (adapt = false: error(...), :124): nothing after it is looked at
+        const bool violated0 = acc && (l >= lbound);
+        int vsel = -1;
+        {
+            const uint64_t vb = __ballot(violated0) & ((C < 64) ? ((1ull << C) - 1ull) : ~0ull);
+            if (vb) {
+                vsel = __ffsll((unsigned long long)vb) - 1;
+                C = vsel;  // the violating event itself is not committed
+            }
+        }
+        ev = lane < C;
+        acc = acc && ev;
+        if (PROF) ph_eval += (uint64_t)C;
+        const uint64_t accball = __ballot(acc);
+        const int nacc_it = __popcll(accball);
+        if (acc) ACL[__popcll(accball & ((1ull << lane) - 1ull))] = (uint16_t)lane;
+        W_ORDER();
+        WPHASE(2);
+        // ---------------- accepted events, one 8-lane group each: members of G1[i] (ascending, :131-135)
+        // (the groups of the accepted events are the LAST nacc_it groups of the wave, in event order: the low lanes -- lane r = event r -- are
+        // then free to re-bound their rejected proposals in the same evaluation, see below)
+        const int g0 = 8 - nacc_it;
+        const bool gact = g >= g0;
+        const uint32_t ea = gact ? (uint32_t)ACL[g - g0] : 0u;
+        const uint32_t ia_b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ea << 2), (int)i);
+        const uint32_t off_b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ea << 2), (int)off);
+        const uint32_t ia = gact ? ia_b : 0u;
+        const uint32_t blka = gact ? (uint32_t)SLB[ea] : 0u;
+        const double tpa_b = w_shfl(tp, ea);
+        const double tpa = gact ? tpa_b : 0.0;
+        const uint32_t offa = gact ? off_b : 0u;
+        // G1[ia] on the lattice, ascending: {ia − n, ia − 1, ia, ia + 1, ia + n} inside the grid -- computed, so that the members' records are
+        // requested at once; the CSC tables are read for the VALUES only (Γ[j, i] = Γ[i, j]: symmetric, checked on the host)
+        const uint32_t cola = __umulhi(ia, nmagic), rowa = ia - cola * nlat;
+        const bool hasL = cola > 0u, hasU = rowa > 0u, hasD = rowa + 1u < nlat, hasR = cola + 1u < nlat;
+        const uint32_t ka = gact ? (1u + (hasL ? 1u : 0u) + (hasU ? 1u : 0u) + (hasD ? 1u : 0u) + (hasR ? 1u : 0u)) : 0u;
+        const bool mem = gact && (uint32_t)gl < ka;
+        uint32_t jm = ia;
+        {
+            // position gl among the present members in the order L, U, self, D, R
+            uint32_t pos = (uint32_t)gl;
+            const uint32_t cand5[5] = {ia - nlat, ia - 1u, ia, ia + 1u, ia + nlat};
+            const bool has5[5] = {hasL, hasU, true, hasD, hasR};
+            uint32_t seen = 0;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                if (has5[q]) {
+                    if (seen == pos && mem) jm = cand5[q];
+                    seen += 1;
+                }
+            }
+        }
+        const double gam = mem ? P.tb.cc_shared[ia].gam[gl] : 0.0;  // (from tval[cp + gl] instead: 8 % more L2 misses, no faster)
+        TrRec* const rj = rec + jm;
+        TrRec* const ria = rec + ia;
+        // (the reflecting coordinate's own fields are read again by its group: the lines are in L2)
+        const double th_ia = ria->th;
+        double xa = ria->x, txa = ria->tx, Ia = ria->I;
+        const uint64_t acc_ia = ria->acc;
+        const double thj0 = rj->th, gj0 = rj->g, gdj0 = rj->gd, tgj = rj->tg;
+        const double2 cjm2 = *reinterpret_cast<const double2*>(&P.tb.cc_shared[jm].c);
+        const double2 ka01 = kp[(size_t)blka * 8 + gl];  // the popped block of the accepted event: one (key, time) pair per lane (patched below)
+        // ---------------- ONE evaluation of the new bound and key per lane (logarithm, two divisions, square root): the re-bound of a rejected
+        // proposal (:137-140) in its event lane, the re-bound of a member of G1 (:131-135) in its group lane.  A lane that is both (more than
+        // 64 − 8 nacc candidates) evaluates its rejected proposal again below.
+        const bool selfl = mem && jm == ia;
+        const double thj = selfl ? -th_ia : thj0;
+        const double gj = gj0 + gdj0 * (tpa - tgj);
+        const double gdj = gdj0 + gam * (-2.0 * th_ia);  // θ_i -> −θ_i
+        double a2, b2, key2;
+        {
+            const uint32_t dix = gact ? (offa + 1u + (uint32_t)gl) : (off + 1u);
+            const double L = pdmp_log(draw(dnm + ((dix < 127u) ? dix : 127u)));
+            const double cc = gact ? cjm2.x : c_i, cc100 = gact ? cjm2.y : c_i2.y;
+            const double gg = gact ? gj : g_now, tt = gact ? thj : th, gdd = gact ? gdj : gd_i;
+            a2 = cc + gg * tt;
+            b2 = cc100 + tt * gdd;
+            key2 = (gact ? tpa : tp) + w_poisson_time_L(a2, b2, L);
+        }
+        const double keyj = mem ? key2 : W_INF;
+        if (__ballot(ev && !acc && gact) != 0) {
+            const double L = pdmp_log(draw(dnm + ((off + 1u < 127u) ? off + 1u : 127u)));
+            const double a2e = c_i + g_now * th;
+            const double b2e = c_i2.y + th * gd_i;
+            const double k2e = tp + w_poisson_time_L(a2e, b2e, L);
+            if (gact) {
+                a2 = a2e;
+                b2 = b2e;
+                key2 = k2e;
+            }
+        }
+        // new minimum of the popped block of a rejected event, and what the event exposes
+        double rowmin = W_INF;
+        uint32_t cand = i;
+        if (ev && !acc) {
+            const bool mine = key2 < rest || (key2 == rest && i < rarg);
+            rowmin = mine ? key2 : rest;
+            cand = mine ? i : rarg;
+        }
+        if (selfl) {  // event(i, t, x, θ, F) (src/sfact.jl:50-52): x_i at t′
+            const double dtx = tpa - txa;
+            const double xn = xa + th_ia * dtx;
+            Ia = Ia + dtx * ((xa + xn) * 0.5);
+            xa = xn;
+            txa = tpa;
+        }
+        // the popped block of the accepted event with the members' new keys patched in
+        double rowmin_a = W_INF;
+        uint32_t cand_a = 0;
+        int wl_a = -1;
+        {
+            double kq = ka01.x;
+#pragma unroll
+            for (int m = 0; m < 5; ++m) {
+                const uint32_t src_ = (uint32_t)(lane & ~7) + (uint32_t)m;
+                const uint32_t jq = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_ << 2), (int)jm);
+                const double kv = w_shfl(keyj, src_);
+                if (((uint32_t)m < ka) && ((jq >> 3) == blka) && ((jq & 7u) == (uint32_t)gl)) kq = kv;
+            }
+            rowmin_a = w_grp8_min(kq);
+            const uint64_t winball = __ballot(gact && kq == rowmin_a);
+            wl_a = __ffs((unsigned)((winball >> (8 * g)) & 0xffu)) - 1;
+            cand_a = (uint32_t)gl;
+            const double keymin = w_grp8_min(keyj);
+            if (gact && gl == 0) EX[ea] = w_min(rowmin_a, keymin);
+        }
+        if (ev && !acc) EX[lane] = rowmin;  // (rowmin <= key2: the new key is one of its candidates)
+        W_ORDER();
+        WPHASE(3);
+        // ---------------- validate: all earlier events commit, zones disjoint, nothing produced or exposed earlier than t′
+        uint32_t Rc;
+        {
+            const double expo = ev ? EX[lane] : W_INF;
+            const double prev = w_shfl(expo, (uint32_t)((lane > 0) ? lane - 1 : 0));
+            const double pref = w_scan_min_f64((lane > 0) ? prev : W_INF);  // exclusive prefix minimum
+            const bool okr = ev && (lane == 0 || pref > tp);  // (zone conflicts ended the candidate list already)
+            const uint64_t bad = ~__ballot(okr);
+            const uint32_t r_ok = bad ? (uint32_t)(__ffsll((unsigned long long)bad) - 1) : 64u;
+            Rc = (r_ok < (uint32_t)C) ? r_ok : (uint32_t)C;
+            if (vsel != (int)Rc) vsel = -1;  // the violating proposal counts only once everything before it is committed
+            // the trace's room and the end of the run (`while t′ < T` looks at accepted events only, :199)
+            const uint64_t accc = accball & ((Rc < 64u) ? ((1ull << Rc) - 1ull) : ~0ull);
+            uint64_t walk = accc;
+            uint32_t na = 0;
+            bool stopped = false;
+            while (walk && !stopped) {
+                const int r = __ffsll((unsigned long long)walk) - 1;
+                walk &= walk - 1;
+                na += 1;
+                if (P.trace_cap > 0 && dnacc + na >= trace_room) {
+                    status = PDMP_CHAIN_TRACE_FULL;
+                    stopped = true;
+                }
+                if (!stop_before && !(w_readlane(tp, r) < T)) {
+                    running = false;
+                    stopped = true;
+                }
+                if (stopped) Rc = (uint32_t)r + 1u;
+            }
+            if (stopped) vsel = -1;
+        }
+        // steer the threshold so that the raw candidate list is just longer than what can commit
+        if (lane == 0) SELDT[0] = dt_used * (((int)Rc >= Craw) ? W_GROW : (((int)Rc + (int)W_SLACK < Craw) ? W_SHRINK : 1.0));
+        WPHASE(4);
+        // ---------------- commit the valid prefix
+        const bool commit = ev && (uint32_t)lane < Rc;
+        if (commit && !acc) {  // a rejected proposal: ONE 16-byte store (the record stays clean), and the block's new bound
+            kp[i] = make_double2(key2, tp);
+            lbf[blk] = (rowmin < W_INF) ? p_enc(rowmin, tb, cand & 7u) : P_INFBITS;
+        }
+        const bool gcommit = gact && ea < Rc;
+        const uint64_t acc_c = accball & ((Rc < 64u) ? ((1ull << Rc) - 1ull) : ~0ull);
+        if (gcommit) {
+            if (mem) {
+                rj->g = gj;
+                rj->gd = gdj;
+                rj->tg = tpa;
+                if (selfl) kp[jm] = make_double2(keyj, tpa);  // (its own proposal)
+                else kp[jm].x = keyj;                         // (the time of j's last own proposal stays)
+            }
+            if (selfl) {
+                ria->x = xa;
+                ria->th = -th_ia;
+                ria->tx = txa;
+                ria->I = Ia;
+                ria->acc = acc_ia + 1;
+                ria->tacc = tpa;
+                if (evout) {
+                    const uint32_t rnk = (uint32_t)__popcll(acc_c & ((1ull << ea) - 1ull));
+                    pdmp_event e;
+                    e.t = tpa;
+                    e.i = (int64_t)ia;
+                    e.x = xa;
+                    e.theta = -th_ia;
+                    evout[ntrace0 + dnacc + rnk] = e;
+                }
+            }
+            if (gl == wl_a) lbf[blka] = (rowmin_a < W_INF) ? p_enc(rowmin_a, tb, cand_a) : P_INFBITS;
+        }
+        W_ORDER();
+        WPHASE(5);
+        // ---------------- bounds of the blocks of re-bounded neighbours: lowered where the new key is below them (an LDS atomic minimum); a key
+        // that ROSE leaves its block's bound stale low, which costs a look at the block later and nothing else
+        {
+            const bool upd = gcommit && mem && (jm >> 3) != blka;
+            if (upd && keyj < W_INF) atomicMin(&lbf[jm >> 3], p_enc(keyj, tb, jm & 7u));
+        }
+        W_ORDER();
+        WPHASE(6);
+        // ---------------- counters; the violating proposal itself (counted, acc bumped, then error(...), :120-124)
+        if (Rc > 0u) {
+            const uint32_t costL = (uint32_t)__builtin_amdgcn_readlane((int)cost, (int)(Rc - 1u));
+            const uint32_t offL = (uint32_t)__builtin_amdgcn_readlane((int)off, (int)(Rc - 1u));
+            dnum += Rc;
+            idle = 0;
+            dnacc += (uint32_t)__popcll(acc_c);
+            dnm += offL + costL;
+            t_last = w_readlane(tp, (int)(Rc - 1u));
+            if (acc_c) t_event = w_readlane(tp, 63 - __builtin_clzll(acc_c));
+        }
+        if (vsel >= 0) {  // (vsel == Rc: every earlier event is committed)
+            const double tpv = w_readlane(tp, vsel);
+            const uint32_t iv = (uint32_t)__builtin_amdgcn_readlane((int)i, vsel);
+            if (lane == 0) kp[iv].y = tpv;
+            dnum += 1;
+            vnacc = 1;
+            dnm += 1;  // its coin
+            t_last = tpv;
+            status = PDMP_CHAIN_BOUND_VIOLATED;
+        }
+        if (status != PDMP_CHAIN_OK) break;
+        W_ORDER();
+    }
+
+    if (PROF && P.dbg && chain == 0 && lane == 0) {
+        for (int q = 0; q < 10; ++q) P.dbg[q] = (double)ph[q];
+        P.dbg[10] = (double)ph_iters;
+        P.dbg[11] = (double)ph_raw;
+        P.dbg[12] = (double)ph_zone;
+        P.dbg[13] = (double)ph_eval;
+    }
+#undef WPHASE
+    if (lane == 0) {
+        hdr->c.t_last = t_last;
+        hdr->t_event = t_event;
+        hdr->c.num += dnum;
+        hdr->c.nacc += dnacc + vnacc;
+        hdr->c.ntrace = ntrace0 + dnacc;
+        hdr->c.nevents += dnacc;
+        hdr->c.ndraw_main = nm0 + dnm;
+        hdr->c.status = status;
+    }
+}
+
+bool zz_trackp_supported(const ZzRunParams& p) {
+    return p.lattice_n >= 16 && p.lattice_n <= 128 && !p.adapt && p.c_chain == nullptr && p.tb.gmu_t == nullptr && !p.track_two_sums &&
+           !p.has_refresh && p.d >= 2048 && p.d <= (int64_t)W_NBLK * 8;
+}
+
+int launch_zz_local_trackp(const ZzRunParams& p, int64_t nchains, void* stream) {
+    dim3 grid((unsigned)nchains), block(64);
+    ZzRunParams q = p;
+    q.nblk = (uint32_t)((p.d + 7) / 8);  // (dk is a multiple of 64, the padding keys are +Inf)
+    if (p.dbg) hipLaunchKernelGGL((zz_local_trackp_kernel<true>), grid, block, W_BYTES, (hipStream_t)stream, q);
+    else hipLaunchKernelGGL((zz_local_trackp_kernel<false>), grid, block, W_BYTES, (hipStream_t)stream, q);
+    return (int)hipGetLastError();
+}
+
+// (key) -> (key, t0) pairs, after the init kernel: every coordinate's last own proposal is the start of the run
+__global__ __launch_bounds__(256) void zz_keys_to_pairs_kernel(const double* __restrict__ keys, double2* __restrict__ kp, int64_t n, double t0) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k < n) kp[k] = make_double2(keys[k], t0);
+}
+int launch_zz_keys_to_pairs(const double* keys, void* kp, int64_t n, double t0, void* stream) {
+    hipLaunchKernelGGL(zz_keys_to_pairs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, keys,
+                       reinterpret_cast<double2*>(kp), n, t0);
+    return (int)hipGetLastError();
+}
+
+}  // namespace pdmp
