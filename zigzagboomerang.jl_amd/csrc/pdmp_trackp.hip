@@ -651,7 +651,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const uint64_t acc_ia = ria->acc;
         const double thj0 = rj->th, gj0 = rj->g, gdj0 = rj->gd, tgj = rj->tg;
         const double2 cjm2 = *reinterpret_cast<const double2*>(&P.tb.cc_shared[jm].c);
-        const double2 ka01 = kp[(size_t)blka * 8 + gl];  // the popped block of the accepted event: one (key, time) pair per lane (patched below)
+        const double resta_b = w_shfl(rest, ea);  // the accepted event's block without it, and where that minimum sits
+        const uint32_t rarga_b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ea << 2), (int)rarg);
         // ---------------- ONE evaluation of the new bound and key per lane (logarithm, two divisions, square root): the re-bound of a rejected
         // proposal (:137-140) in its event lane, the re-bound of a member of G1 (:131-135) in its group lane.  A lane that is both (more than
         // 64 − 8 nacc candidates) evaluates its rejected proposal again below.
@@ -696,23 +697,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             xa = xn;
             txa = tpa;
         }
-        // the popped block of the accepted event with the members' new keys patched in
+        // the accepted event's block: a LOWER BOUND of its new minimum is enough (level 1 holds bounds): the smaller of the block without the
+        // event -- which may still count a member's OLD key: then the bound is stale low and costs a look later -- and the members' new keys in it
         double rowmin_a = W_INF;
         uint32_t cand_a = 0;
         int wl_a = -1;
         {
-            double kq = ka01.x;
-#pragma unroll
-            for (int m = 0; m < 5; ++m) {
-                const uint32_t src_ = (uint32_t)(lane & ~7) + (uint32_t)m;
-                const uint32_t jq = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_ << 2), (int)jm);
-                const double kv = w_shfl(keyj, src_);
-                if (((uint32_t)m < ka) && ((jq >> 3) == blka) && ((jq & 7u) == (uint32_t)gl)) kq = kv;
-            }
-            rowmin_a = w_grp8_min(kq);
-            const uint64_t winball = __ballot(gact && kq == rowmin_a);
-            wl_a = __ffs((unsigned)((winball >> (8 * g)) & 0xffu)) - 1;
-            cand_a = (uint32_t)gl;
+            const double kin = (mem && (jm >> 3) == blka) ? keyj : W_INF;
+            const double kinmin = w_grp8_min(kin);
+            const uint64_t winball = __ballot(gact && kin == kinmin);
+            const int wl = __ffs((unsigned)((winball >> (8 * g)) & 0xffu)) - 1;
+            const uint32_t jwin = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)(lane & ~7) + (uint32_t)(wl < 0 ? 0 : wl)) << 2), (int)jm);
+            const bool restwins = resta_b <= kinmin;
+            rowmin_a = restwins ? resta_b : kinmin;
+            cand_a = restwins ? (rarga_b & 7u) : (jwin & 7u);
+            wl_a = 0;  // (lane 0 of the group stores the bound)
             const double keymin = w_grp8_min(keyj);
             if (gact && gl == 0) EX[ea] = w_min(rowmin_a, keymin);
         }
