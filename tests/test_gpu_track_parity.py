@@ -227,3 +227,23 @@ def test_full_size_traces_and_states_against_exact_kernel_and_oracle(c3_tracked)
     assert len(ev) == len(r["events"]) and int(ct["num"][0]) == r["num"]
     assert np.array_equal(ev["i"], r["events"]["i"]) and close(ev["t"], r["events"]["t"]) and close(ev["x"], r["events"]["x"])
     assert float(np.max(np.abs(ev["t"] - r["events"]["t"]))) < 1e-11
+
+
+@pytest.mark.parametrize("which", [0, 1, 3])
+def test_tracked_with_a_start_time(gpu_pkg, monkeypatch, which):
+    """t0 != 0: the reference's initial queue carries no t0 (src/sfact.jl:186), so the first proposals lie BEFORE the clocks' start; the
+    pair-layout kernel's level-1 base must sit below them."""
+    pkg = gpu_pkg
+    monkeypatch.setenv("PDMP_TRACK_GROUPS", str(which))
+    n, t0, T, nch = 48, 3.0, 7.0, 2
+    G = pkg.problems.gmrf_precision(n)
+    d = n * n
+    rng = np.random.default_rng(60 + which)
+    x0 = rng.standard_normal((nch, d))
+    th0 = rng.choice([-1.0, 1.0], (nch, d))
+    c = pkg.problems.column_norms(G)
+    tr, (t, x, th), (acc, num), _ = pkg.spdmp(pkg.GaussianTarget(G), t0, x0, th0, T, c, pkg.ZigZag(G, np.zeros(d)), seed=6100, tracked=True)
+    for k in range(nch):
+        r = O.spdmp_zigzag(G, None, G, x0[k], th0[k], c, T, seed=6100 + k, t0=t0)
+        assert r["status"] == 0 and len(r["events"]) > 1000
+        check_chain(tr[k].events, t[k], x[k], th[k], acc[k], num[k], None, r)

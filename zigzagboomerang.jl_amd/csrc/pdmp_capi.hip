@@ -954,7 +954,9 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
         G.track_two_sums = e->track_two_sums ? 1 : 0;
         G.has_refresh = e->lambda_ref > 0;
         G.d = d;
-        if (pdmp::zz_trackp_supported(G) && (e->dbg_track_groups == 0 || e->dbg_track_groups == 4)) {
+        // (t0 > 0: the reference's initial keys carry no t0 (src/sfact.jl:186), so the first proposals lie BEFORE the clocks' start and
+        // t_old = max(tprop, tg), which the pair layout relies on, does not hold while time runs backwards: the record-layout kernels serve those)
+        if (pdmp::zz_trackp_supported(G) && !(t0 > 0.0) && (e->dbg_track_groups == 0 || e->dbg_track_groups == 4)) {
             if (e->d_kp.n != (size_t)(2 * n * e->dk) && (st = e->d_kp.alloc((size_t)(2 * n * e->dk))) != PDMP_OK) return st;
             rc = pdmp::launch_zz_keys_to_pairs(e->d_keys.p, e->d_kp.p, n * e->dk, t0, e->stream);
             if (rc != 0) return fail(PDMP_ERR_HIP, "keys_to_pairs launch failed: %s", hipGetErrorString((hipError_t)rc));

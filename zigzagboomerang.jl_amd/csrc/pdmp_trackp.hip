@@ -14,6 +14,8 @@
 //     minimum whose key rose: its neighbour re-bounds it), never high: lowering is an LDS atomic minimum, and no rescans exist any more.  The
 //     record of a candidate is requested together with its line using the position bits; a position that turns out wrong ends the list there.
 // The committed sequence and every float are those of pdmp_trackx.hip (index-exact against the oracle, floats to ~1e-13).
+// t_old = max(tprop, tg) needs time to run forwards: ensembles started at t0 > 0 (whose first proposals lie before t0, the reference's initial
+// keys carry no t0) keep the record layout (pdmp_capi.hip).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
