@@ -527,28 +527,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         // lattice coordinates packed for the zone test: byte 0 = row, byte 1 = column
         const uint32_t col_i = __umulhi(i, nmagic);
         const uint32_t rc_i = ev ? ((i - col_i * nlat) | (col_i << 8)) : 0xffffu;
-        // ---------------- zones: event r cannot commit with an earlier event whose G1 meets its own (Manhattan distance of the lattice
-        // coordinates <= 2): the list ends at the first such event
-        {
-            uint64_t confb = 0;
-            for (int m0 = 0; m0 < C - 1; m0 += 4) {  // (lanes past the events hold a far-away cell: reading them changes nothing)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int m = m0 + q;
-                    const uint32_t rcm = (uint32_t)__builtin_amdgcn_readlane((int)rc_i, m);
-                    const uint32_t sad = __builtin_amdgcn_sad_u8(rc_i, rcm, 0u);
-                    const uint64_t near = __ballot(sad <= 2u);
-                    confb |= near & (~0ull << (m + 1));
-                }
-            }
-            const uint64_t cb = confb & ((C < 64) ? ((1ull << C) - 1ull) : ~0ull);
-            if (cb) {
-                const int c0 = __ffsll((unsigned long long)cb) - 1;
-                C = (c0 < C) ? c0 : C;
-            }
-            ev = lane < C;
-        }
-        if (PROF) ph_zone += (uint64_t)C;
         W_ORDER();
         WPHASE(1);
         // ---------------- rates from the tracked sums (src/sfact.jl:116-119 with g_i(t′) = g_i + gd_i (t′ − tg_i))
@@ -592,6 +570,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 C = __ffsll((unsigned long long)m_) - 1;
             }
         }
+        uint32_t rekey_by = 0xffffffffu;  // the first accepted later event that re-bounds this lane's coordinate (its key is then not this lane's to store)
+        // ---------------- zones.  Only an ACCEPTED event m disturbs a later event r: within lattice distance 1 it changes r's sums (r's outcome
+        // above is then garbage), at distance 2 the two share a neighbour, which matters only if r is accepted too.  A rejected event writes its
+        // own (key, time) pair and nothing else.  The list ends at the first disturbed event (everything before it is unaffected).
+        {
+            uint64_t confb = 0;
+            uint64_t ab = __ballot(acc) & ((C < 64) ? ((1ull << C) - 1ull) : ~0ull);
+            while (ab) {
+                const int m = __ffsll((unsigned long long)ab) - 1;
+                ab &= ab - 1;
+                const uint32_t rcm = (uint32_t)__builtin_amdgcn_readlane((int)rc_i, m);
+                const uint32_t sad = __builtin_amdgcn_sad_u8(rc_i, rcm, 0u);
+                const uint64_t hit = __ballot(sad <= 1u || (sad <= 2u && acc));
+                confb |= hit & (~0ull << (m + 1));
+                // an EARLIER rejected event next to accepted event m: m's group writes that coordinate's new key after it
+                if (sad <= 1u && lane < m && (uint32_t)m < rekey_by) rekey_by = (uint32_t)m;
+            }
+            const uint64_t cb = confb & ((C < 64) ? ((1ull << C) - 1ull) : ~0ull);
+            if (cb) {
+                const int c0 = __ffsll((unsigned long long)cb) - 1;
+                C = (c0 < C) ? c0 : C;
+            }
+        }
+        if (PROF) ph_zone += (uint64_t)C;
         // a proposal that violates its bound ends the run (adapt = false: error(...), :124): nothing after it is looked at
         const bool violated0 = acc && (l >= lbound);
         int vsel = -1;
@@ -758,7 +760,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         // ---------------- commit the valid prefix
         const bool commit = ev && (uint32_t)lane < Rc;
         if (commit && !acc) {  // a rejected proposal: ONE 16-byte store (the record stays clean), and the block's new bound
-            kp[i] = make_double2(key2, tp);
+            if (rekey_by < Rc) kp[i].y = tp;  // (a later accepted neighbour of this iteration stores the key)
+            else kp[i] = make_double2(key2, tp);
             lbf[blk] = (rowmin < W_INF) ? p_enc(rowmin, tb, cand & 7u) : P_INFBITS;
         }
         const bool gcommit = gact && ea < Rc;
