@@ -1108,6 +1108,8 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         Q.gamma0 = e->lg_gamma0;
         Q.ksub = e->lg_k;
         Q.lg_ne_max = (int32_t)std::min<int64_t>(e->lg_nemax, 1 << 30);
+        // rows of thousands of coefficients: ranges that hold about 50 of a row's entries (64 lanes per chunk)
+        Q.lg_range = (e->lg_nemax >= 1024) ? (int32_t)std::max<int64_t>(16, (int64_t)(0.8 * 64.0 * (double)e->cfg.d / (double)e->lg_nemax)) : 0;
         Q.flow_kind = e->flow_kind;
         Q.mu = e->d_mu.p;
         Q.diag = e->d_diag.p;

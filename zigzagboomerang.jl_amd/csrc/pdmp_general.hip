@@ -567,9 +567,58 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
                 }
                 const int etot = __builtin_amdgcn_readlane(incl, LGFAST ? 15 : 63);
                 const int excl = incl - ne;
+                // Long rows of a dense design (thousands of coefficients, the sampled rows share most of their coordinates): swept in coordinate
+                // RANGES, every sampled row's entries inside a range before the next range, so that a record comes from HBM once per evaluation
+                // and from L2 for the other rows (row by row it is re-fetched k_sub times: 10^4 records x 4096 chains do not stay cached).  A row's
+                // running sum still takes its entries in ascending order, and a move is the identity after the first, so nothing else changes.
+                const bool ranged = !LGFAST && Q.lg_range > 0 && etot >= 2048;
+                if (ranged) {
+                    int64_t e_cur = e0;
+                    const int64_t e_end = e0 + (int64_t)ne;
+                    urow = 0.0;
+                    for (int64_t rb = 0; rb < d; rb += Q.lg_range) {
+                        const int64_t rend = rb + Q.lg_range;
+                        for (int z = 0; z < nq; ++z) {
+                            int64_t ec = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)e_cur >> 32), z) << 32) |
+                                                   (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)e_cur, z));
+                            const int64_t ee = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)e_end >> 32), z) << 32) |
+                                                         (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)e_end, z));
+                            double uz = g_readlane(urow, z);
+                            for (;;) {
+                                const int64_t f = ec + lane;
+                                const bool valid = f < ee;
+                                const int64_t cc = valid ? Q.At_rowval[f] : (int64_t)0x7fffffffffffffffll;
+                                const bool inr = valid && cc < rend;  // (entries ascend: the lanes inside the range are a prefix)
+                                const int cnt = __popcll(__ballot(inr));
+                                if (inr) {
+                                    const double we = Q.At_nzval[f];
+                                    ZzRec* r = rec + cc;
+                                    const double x0 = r->x, th0 = r->th, t0 = r->t, I0 = r->I;
+                                    const double dt = tp - t0;
+                                    const double xe = x0 + th0 * dt;
+                                    if (dt != 0.0) {
+                                        r->x = xe;
+                                        r->t = tp;
+                                        r->I = I0 + dt * ((x0 + xe) * 0.5);
+                                    }
+                                    sprod[lane] = we * xe;
+                                }
+                                G_ORDER();
+                                for (int k2 = 0; k2 < cnt; ++k2) uz += sprod[k2];  // (every lane the same sum, in entry order)
+                                G_ORDER();
+                                ec += cnt;
+                                if (cnt < 64) break;
+                            }
+                            if (lane == z) {
+                                e_cur = ec;
+                                urow = uz;
+                            }
+                        }
+                    }
+                }
                 // idot_moving!(At, row, t, x, θ, t′, F), src/common.jl:33-42: move the rows' coordinates; products to LDS
                 // (LGFAST: every observation has at most 6 regressors, so the 10 rows always fit one 64-entry chunk)
-                for (int fb = 0; fb < (LGFAST ? ((etot > 0) ? 1 : 0) : etot); fb += 64) {
+                for (int fb = 0; fb < (ranged ? 0 : (LGFAST ? ((etot > 0) ? 1 : 0) : etot)); fb += 64) {
                     const int f = fb + lane;
                     int q = 0;
                     for (int z = 0; z < nq; ++z) q += (__builtin_amdgcn_readlane(incl, z) <= f) ? 1 : 0;
@@ -585,9 +634,13 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
                         const double x0 = r->x, th0 = r->th, t0 = r->t, I0 = r->I;
                         const double dt = tp - t0;
                         const double xe = x0 + th0 * dt;
-                        r->x = xe;
-                        r->t = tp;
-                        r->I = I0 + dt * ((x0 + xe) * 0.5);
+                        if (dt != 0.0) {  // (a coordinate an earlier row of this evaluation -- or the proposal's own move -- brought to t′ already:
+                                          // the move is the identity, and not storing it keeps a re-fetched line clean: the k_sub rows of a
+                                          // dense design share most of their coordinates)
+                            r->x = xe;
+                            r->t = tp;
+                            r->I = I0 + dt * ((x0 + xe) * 0.5);
+                        }
                         sprod[lane] = we * xe;
                     }
                     G_ORDER();
