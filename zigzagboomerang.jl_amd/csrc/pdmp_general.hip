@@ -103,7 +103,8 @@ size_t zz_general_lds_bytes(uint32_t nblk_pad, uint32_t mmax_pad, bool boom) {
 
 // LGFAST: instantiation for the plain spdmp + subsampled-logistic configuration (config C4): ZigZag flow, no refresh clock, no
 // G = All(), no LocalBound, no adaptscale, not sticky -- the other modes' branches, scalars and table pointers drop out.
-template <bool PROF, bool LGFAST>
+// RANGED: instantiation with the coordinate-range sweep of long logistic rows (two rows in flight: 27 more registers, 4 waves per SIMD)
+template <bool PROF, bool LGFAST, bool RANGED>
 __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, ZzGeneralParams Q_in) {
     ZzRunParams P = P_in;
     ZzGeneralParams Q = Q_in;
@@ -571,47 +572,84 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
                 // RANGES, every sampled row's entries inside a range before the next range, so that a record comes from HBM once per evaluation
                 // and from L2 for the other rows (row by row it is re-fetched k_sub times: 10^4 records x 4096 chains do not stay cached).  A row's
                 // running sum still takes its entries in ascending order, and a move is the identity after the first, so nothing else changes.
-                const bool ranged = !LGFAST && Q.lg_range > 0 && etot >= 2048;
-                if (ranged) {
+                const bool ranged = RANGED && !LGFAST && Q.lg_range > 0 && etot >= 2048;
+                if constexpr (RANGED) if (ranged) {
                     int64_t e_cur = e0;
                     const int64_t e_end = e0 + (int64_t)ne;
                     urow = 0.0;
                     for (int64_t rb = 0; rb < d; rb += Q.lg_range) {
                         const int64_t rend = rb + Q.lg_range;
-                        for (int z = 0; z < nq; ++z) {
-                            int64_t ec = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)e_cur >> 32), z) << 32) |
-                                                   (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)e_cur, z));
-                            const int64_t ee = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)e_end >> 32), z) << 32) |
-                                                         (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)e_end, z));
-                            double uz = g_readlane(urow, z);
-                            for (;;) {
-                                const int64_t f = ec + lane;
-                                const bool valid = f < ee;
-                                const int64_t cc = valid ? Q.At_rowval[f] : (int64_t)0x7fffffffffffffffll;
-                                const bool inr = valid && cc < rend;  // (entries ascend: the lanes inside the range are a prefix)
-                                const int cnt = __popcll(__ballot(inr));
-                                if (inr) {
-                                    const double we = Q.At_nzval[f];
-                                    ZzRec* r = rec + cc;
-                                    const double x0 = r->x, th0 = r->th, t0 = r->t, I0 = r->I;
-                                    const double dt = tp - t0;
-                                    const double xe = x0 + th0 * dt;
-                                    if (dt != 0.0) {
-                                        r->x = xe;
-                                        r->t = tp;
-                                        r->I = I0 + dt * ((x0 + xe) * 0.5);
-                                    }
-                                    sprod[lane] = we * xe;
+                        // two rows at a time: both rows' records are requested before either row's sum runs (the sweep is a chain of HBM round
+                        // trips otherwise); a record both rows move gets the same values stored twice
+                        auto rd64 = [&](int64_t v, int z) -> int64_t {
+                            return (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), z) << 32) |
+                                             (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)v, z));
+                        };
+                        for (int z = 0; z < nq; z += 2) {
+                            const bool hasB = z + 1 < nq;
+                            int64_t ecA = rd64(e_cur, z), ecB = hasB ? rd64(e_cur, z + 1) : 0;
+                            const int64_t eeA = rd64(e_end, z), eeB = hasB ? rd64(e_end, z + 1) : 0;
+                            double uA = g_readlane(urow, z), uB = hasB ? g_readlane(urow, z + 1) : 0.0;
+                            bool doneA = false, doneB = !hasB;
+                            while (!doneA || !doneB) {
+                                const int64_t fA = ecA + lane, fB = ecB + lane;
+                                const bool vA = !doneA && fA < eeA, vB = !doneB && fB < eeB;
+                                const int64_t ccA = vA ? Q.At_rowval[fA] : (int64_t)0x7fffffffffffffffll;
+                                const int64_t ccB = vB ? Q.At_rowval[fB] : (int64_t)0x7fffffffffffffffll;
+                                const bool inA = vA && ccA < rend, inB = vB && ccB < rend;  // (entries ascend: the lanes inside the range are a prefix)
+                                const int cntA = __popcll(__ballot(inA)), cntB = __popcll(__ballot(inB));
+                                double pA = 0.0, pB = 0.0;
+                                ZzRec* const rA = rec + (inA ? ccA : 0);
+                                ZzRec* const rB = rec + (inB ? ccB : 0);
+                                double xA = 0.0, thA = 0.0, tA = 0.0, IA = 0.0, weA = 0.0, xB = 0.0, thB = 0.0, tB = 0.0, IB = 0.0, weB = 0.0;
+                                if (inA) {
+                                    weA = Q.At_nzval[fA];
+                                    xA = rA->x;
+                                    thA = rA->th;
+                                    tA = rA->t;
+                                    IA = rA->I;
                                 }
-                                G_ORDER();
-                                for (int k2 = 0; k2 < cnt; ++k2) uz += sprod[k2];  // (every lane the same sum, in entry order)
-                                G_ORDER();
-                                ec += cnt;
-                                if (cnt < 64) break;
+                                if (inB) {
+                                    weB = Q.At_nzval[fB];
+                                    xB = rB->x;
+                                    thB = rB->th;
+                                    tB = rB->t;
+                                    IB = rB->I;
+                                }
+                                if (inA) {
+                                    const double dt = tp - tA;
+                                    const double xe = xA + thA * dt;
+                                    if (dt != 0.0) {
+                                        rA->x = xe;
+                                        rA->t = tp;
+                                        rA->I = IA + dt * ((xA + xe) * 0.5);
+                                    }
+                                    pA = weA * xe;
+                                }
+                                if (inB) {
+                                    const double dt = tp - tB;
+                                    const double xe = xB + thB * dt;
+                                    if (dt != 0.0) {
+                                        rB->x = xe;
+                                        rB->t = tp;
+                                        rB->I = IB + dt * ((xB + xe) * 0.5);
+                                    }
+                                    pB = weB * xe;
+                                }
+                                for (int k2 = 0; k2 < cntA; ++k2) uA += g_readlane(pA, k2);  // (every lane the same sum, in entry order)
+                                for (int k2 = 0; k2 < cntB; ++k2) uB += g_readlane(pB, k2);
+                                ecA += cntA;
+                                ecB += cntB;
+                                doneA = doneA || cntA < 64;
+                                doneB = doneB || cntB < 64;
                             }
                             if (lane == z) {
-                                e_cur = ec;
-                                urow = uz;
+                                e_cur = ecA;
+                                urow = uA;
+                            }
+                            if (hasB && lane == z + 1) {
+                                e_cur = ecB;
+                                urow = uB;
                             }
                         }
                     }
@@ -892,17 +930,20 @@ int launch_zz_general_run(const ZzRunParams& p, const ZzGeneralParams& q, int64_
     const bool prof = p.dbg != nullptr;
     const bool lgfast = !prof && q.target_kind == 1 && q.ksub == 10 && q.lg_ne_max <= 6 && !p.move_all && !p.has_refresh && !q.local_bound && !q.sticky &&
                         q.flow_kind == 0 && !q.adaptscale;
-    const void* fn = prof ? reinterpret_cast<const void*>(zz_general_run_kernel<true, false>)
-                   : lgfast ? reinterpret_cast<const void*>(zz_general_run_kernel<false, true>)
-                            : reinterpret_cast<const void*>(zz_general_run_kernel<false, false>);
+    const bool rng = !prof && !lgfast && q.target_kind == 1 && q.lg_range > 0;
+    const void* fn = prof ? reinterpret_cast<const void*>(zz_general_run_kernel<true, false, false>)
+                   : lgfast ? reinterpret_cast<const void*>(zz_general_run_kernel<false, true, false>)
+                   : rng ? reinterpret_cast<const void*>(zz_general_run_kernel<false, false, true>)
+                         : reinterpret_cast<const void*>(zz_general_run_kernel<false, false, false>);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
     const dim3 grid((unsigned)nchains), block(64);
-    if (prof) hipLaunchKernelGGL((zz_general_run_kernel<true, false>), grid, block, lds, (hipStream_t)stream, p, q);
-    else if (lgfast) hipLaunchKernelGGL((zz_general_run_kernel<false, true>), grid, block, lds, (hipStream_t)stream, p, q);
-    else hipLaunchKernelGGL((zz_general_run_kernel<false, false>), grid, block, lds, (hipStream_t)stream, p, q);
+    if (prof) hipLaunchKernelGGL((zz_general_run_kernel<true, false, false>), grid, block, lds, (hipStream_t)stream, p, q);
+    else if (lgfast) hipLaunchKernelGGL((zz_general_run_kernel<false, true, false>), grid, block, lds, (hipStream_t)stream, p, q);
+    else if (rng) hipLaunchKernelGGL((zz_general_run_kernel<false, false, true>), grid, block, lds, (hipStream_t)stream, p, q);
+    else hipLaunchKernelGGL((zz_general_run_kernel<false, false, false>), grid, block, lds, (hipStream_t)stream, p, q);
     return (int)hipGetLastError();
 }
 
