@@ -182,6 +182,10 @@ struct pdmp_ensemble {
     }
 };
 
+#ifndef PDMP_LG_FILL
+#define PDMP_LG_FILL 0.95  // lanes of a 64-entry chunk a range fills on average (ranged sweep of long logistic rows; 0.6 .. 1.1 measured on C5)
+#endif
+
 extern "C" {
 
 const char* pdmp_last_error(void) {
@@ -1109,7 +1113,7 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         Q.ksub = e->lg_k;
         Q.lg_ne_max = (int32_t)std::min<int64_t>(e->lg_nemax, 1 << 30);
         // rows of thousands of coefficients: ranges that hold about 50 of a row's entries (64 lanes per chunk)
-        Q.lg_range = (e->lg_nemax >= 1024) ? (int32_t)std::max<int64_t>(16, (int64_t)(0.8 * 64.0 * (double)e->cfg.d / (double)e->lg_nemax)) : 0;
+        Q.lg_range = (e->lg_nemax >= 1024) ? (int32_t)std::max<int64_t>(16, (int64_t)(PDMP_LG_FILL * 64.0 * (double)e->cfg.d / (double)e->lg_nemax)) : 0;
         Q.flow_kind = e->flow_kind;
         Q.mu = e->d_mu.p;
         Q.diag = e->d_diag.p;
