@@ -964,6 +964,8 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
             if (e->d_kp.n != (size_t)(2 * n * e->dk) && (st = e->d_kp.alloc((size_t)(2 * n * e->dk))) != PDMP_OK) return st;
             rc = pdmp::launch_zz_keys_to_pairs(e->d_keys.p, e->d_kp.p, n * e->dk, t0, e->stream);
             if (rc != 0) return fail(PDMP_ERR_HIP, "keys_to_pairs launch failed: %s", hipGetErrorString((hipError_t)rc));
+            rc = pdmp::launch_zz_trackp_consts(e->d_rec.p, e->d_cc.p, d, n, e->stream);
+            if (rc != 0) return fail(PDMP_ERR_HIP, "trackp_consts launch failed: %s", hipGetErrorString((hipError_t)rc));
             e->track_pairs = true;
         }
     }

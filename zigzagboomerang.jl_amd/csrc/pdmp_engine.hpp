@@ -48,6 +48,16 @@ struct alignas(128) TrRec {
     double gb, gdb, tacc, pad;  // the same sums with the bounding Γ (when it differs from the target's); time of i's last accept
 };
 static_assert(sizeof(TrRec) == 128, "tracked record must be one 128-byte line");
+// The same line as pdmp_trackp.hip uses it: the bound and the proposal time are not stored there (they live with the key), and the two free
+// sectors carry what a proposal needs that depends on the coordinate alone -- so that no shared table is read in the event loop.
+struct alignas(128) TrRecP {
+    double x, th, tx, I;
+    double g, gd, tg;
+    uint64_t acc;
+    double c, c100, gam0, gam1;  // the constant bound c_i, c_i / 100 (src/fact_samplers.jl:50-54), Γ[G1[i], i] in G1's order (up to five on the lattice)
+    double gam2, gam3, tacc, gam4;
+};
+static_assert(sizeof(TrRecP) == 128 && offsetof(TrRecP, tacc) == offsetof(TrRec, tacc), "same line, same tacc slot");
 
 struct alignas(128) DevChain {
     pdmp_chain_counters c;  // 72 bytes, copied out verbatim by pdmp_ensemble_counters
@@ -300,6 +310,7 @@ int launch_zz_local_trackx(const ZzRunParams& p, int64_t nchains, void* stream);
 bool zz_trackp_supported(const ZzRunParams& p);
 int launch_zz_local_trackp(const ZzRunParams& p, int64_t nchains, void* stream);
 int launch_zz_keys_to_pairs(const double* keys, void* kp, int64_t n, double t0, void* stream);
+int launch_zz_trackp_consts(void* rec, const CoordConst* cc, int64_t d, int64_t nchains, void* stream);
 bool zz_spec8_geometry(const ZzRunParams& p);  // the 8-event kernels' requirements on the neighbourhood blob and on d
 // kp != nullptr: the (key, time of the last own proposal) pairs of pdmp_trackp.hip hold tprop instead of the records (chain stride dk pairs)
 int launch_zz_track_unpack(const TrRec* rec, const ZzTables& tb, const double* c_src, int64_t c_stride, int64_t d, int64_t chain_first,

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     uint8_t* const RO = reinterpret_cast<uint8_t*>(smem + W_RO);
     double* const SELDT = reinterpret_cast<double*>(smem + W_SELDT);
 
-    TrRec* const rec = reinterpret_cast<TrRec*>(P.rec) + chain * d;
+    TrRecP* const rec = reinterpret_cast<TrRecP*>(P.rec) + chain * d;
     double2* const kp = reinterpret_cast<double2*>(P.keys) + chain * P.dk;  // (key, time of the last own proposal) per coordinate
     DevChain* const hdr = P.hdr + chain;
     pdmp_event* const evout = P.ev ? P.ev + chain * P.trace_cap : nullptr;
@@ -403,10 +403,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const uint32_t cblk = isc ? (uint32_t)TB[lane] : 0u;
         const uint32_t cpos = isc ? (lbf[cblk] & 7u) : 0u;
         const uint32_t ci = cblk * 8u + cpos;
-        const TrRec* const rci = rec + ci;
+        const TrRecP* const rci = rec + ci;
         const double c_th = rci->th, c_g = rci->g, c_gd = rci->gd, c_tg = rci->tg;
-        const double2 c_c2 = *reinterpret_cast<const double2*>(&P.tb.cc_shared[ci].c);
-        const uint32_t c_k = P.tb.cc_shared[ci].k;
+        const double2 c_c2 = *reinterpret_cast<const double2*>(&rci->c);  // (same line: no table in the event loop)
         // ---------------- the candidates' lines, 8 per pass (one per 8-lane group, one (key, time) pair per lane): exact minimum, its position and
         // time, the minimum of the rest and its position -- staged in LDS per candidate
         {
@@ -519,14 +518,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const double th = w_shfl(c_th, src), g_i = w_shfl(c_g, src), gd_i = w_shfl(c_gd, src), tg_i = w_shfl(c_tg, src);
         const double2 c_i2 = make_double2(w_shfl(c_c2.x, src), w_shfl(c_c2.y, src));
         const double c_i = c_i2.x;
-        const uint32_t k_i = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)c_k);
         W_ORDER();
         if (ev) SLB[lane] = (uint16_t)blk;
         W_ORDER();
         WPHASE(0);
         // lattice coordinates packed for the zone test: byte 0 = row, byte 1 = column
         const uint32_t col_i = __umulhi(i, nmagic);
-        const uint32_t rc_i = ev ? ((i - col_i * nlat) | (col_i << 8)) : 0xffffu;
+        const uint32_t row_i = i - col_i * nlat;
+        const uint32_t rc_i = ev ? (row_i | (col_i << 8)) : 0xffffu;
+        // |G1[i]| on the lattice: the cell and its neighbours inside the grid
+        const uint32_t k_i = 1u + (col_i > 0u ? 1u : 0u) + (row_i > 0u ? 1u : 0u) + (row_i + 1u < nlat ? 1u : 0u) + (col_i + 1u < nlat ? 1u : 0u);
         W_ORDER();
         WPHASE(1);
         // ---------------- rates from the tracked sums (src/sfact.jl:116-119 with g_i(t′) = g_i + gd_i (t′ − tg_i))
@@ -646,15 +647,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 }
             }
         }
-        const double gam = mem ? P.tb.cc_shared[ia].gam[gl] : 0.0;  // (from tval[cp + gl] instead: 8 % more L2 misses, no faster)
-        TrRec* const rj = rec + jm;
-        TrRec* const ria = rec + ia;
+        TrRecP* const rj = rec + jm;
+        TrRecP* const ria = rec + ia;
+        double gam = 0.0;  // Γ[jm, ia]: member gl of G1[ia]
+        if (mem) gam = (gl == 0) ? ria->gam0 : (gl == 1) ? ria->gam1 : (gl == 2) ? ria->gam2 : (gl == 3) ? ria->gam3 : ria->gam4;
         // (the reflecting coordinate's own fields are read again by its group: the lines are in L2)
         const double th_ia = ria->th;
         double xa = ria->x, txa = ria->tx, Ia = ria->I;
         const uint64_t acc_ia = ria->acc;
         const double thj0 = rj->th, gj0 = rj->g, gdj0 = rj->gd, tgj = rj->tg;
-        const double2 cjm2 = *reinterpret_cast<const double2*>(&P.tb.cc_shared[jm].c);
+        const double2 cjm2 = *reinterpret_cast<const double2*>(&rj->c);
         const double resta_b = w_shfl(rest, ea);  // the accepted event's block without it, and where that minimum sits
         const uint32_t rarga_b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ea << 2), (int)rarg);
         // ---------------- ONE evaluation of the new bound and key per lane (logarithm, two divisions, square root): the re-bound of a rejected
@@ -859,6 +861,29 @@ int launch_zz_local_trackp(const ZzRunParams& p, int64_t nchains, void* stream) 
     q.nblk = (uint32_t)((p.d + 7) / 8);  // (dk is a multiple of 64, the padding keys are +Inf)
     if (p.dbg) hipLaunchKernelGGL((zz_local_trackp_kernel<true>), grid, block, W_BYTES, (hipStream_t)stream, q);
     else hipLaunchKernelGGL((zz_local_trackp_kernel<false>), grid, block, W_BYTES, (hipStream_t)stream, q);
+    return (int)hipGetLastError();
+}
+
+// the per-coordinate constants into the two free sectors of every record (after the init kernel)
+__global__ __launch_bounds__(256) void zz_trackp_consts_kernel(TrRecP* __restrict__ rec, const CoordConst* __restrict__ cc, int64_t d, int64_t nchains) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= d) return;
+    const CoordConst e = cc[i];
+    for (int64_t ch = blockIdx.y; ch < nchains; ch += gridDim.y) {
+        TrRecP* r = rec + ch * d + i;
+        r->c = e.c;
+        r->c100 = e.c100;
+        r->gam0 = e.gam[0];
+        r->gam1 = e.gam[1];
+        r->gam2 = e.gam[2];
+        r->gam3 = e.gam[3];
+        r->gam4 = e.gam[4];
+    }
+}
+int launch_zz_trackp_consts(void* rec, const CoordConst* cc, int64_t d, int64_t nchains, void* stream) {
+    const unsigned gy = (unsigned)((nchains < 1024) ? nchains : 1024);
+    hipLaunchKernelGGL(zz_trackp_consts_kernel, dim3((unsigned)((d + 255) / 256), gy), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<TrRecP*>(rec), cc, d, nchains);
     return (int)hipGetLastError();
 }
 
