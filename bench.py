@@ -183,7 +183,7 @@ def make_workload(pkg, args, rank, local_rank):
         ens.set_state_synthetic(0.0, c, seed0)
         W.update(G=G, c=c, d=d, cap=cap, ens=ens, kernel="zz_local_spec8_kernel" if args.exact else "zz_local_trackp_kernel",
                  unit="reflection events/s", evaluation="moving (bit-identical to the oracle)" if args.exact else
-                 "tracked gradients (index sequence identical, floats to 1e-9: tests/test_gpu_track_parity.py)",
+                 "tracked gradients (index sequence identical for ~1e9 proposals per flip, floats to 1e-9: tests/test_gpu_track_parity.py, tools/track_soak.py)",
                  metric="reflection events/sec, d=16384 local ZigZag (spdmp), ensemble of independent chains",
                  workload=f"C3: local ZigZag spdmp on Gamma=0.01I+gridlaplacian({args.grid},{args.grid}), d={d}, {nch} chains/GPU, "
                           f"step = advance all chains by dT={dt}, traces {'off' if args.no_trace else 'on (32 B/event)'}",

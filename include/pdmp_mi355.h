@@ -256,7 +256,10 @@ pdmp_status pdmp_ensemble_final_sigma(pdmp_ensemble* ens, int64_t chain_first, i
  * -- about half the HBM traffic of the moving evaluation.  Same process, same draws, same thinning decisions: the event INDEX sequence,
  * accept / reject outcomes, (acc, num) and adapted bounds equal the reference's exactly; event times, positions and the final
  * (t, x, θ) agree to ~1e-13 relative instead of bit for bit, because sums that are advanced are not rounded like sums that are
- * recomputed (tests/test_gpu_track_parity.py: 1e-9; the default, enable = 0, stays bit-identical).  pdmp_ensemble_final_state rebuilds
+ * recomputed (tests/test_gpu_track_parity.py: 1e-9; the default, enable = 0, stays bit-identical).  "Exactly" holds until a float
+ * difference of that size flips an accept test or the order of two nearly simultaneous events -- measured on the north-star workload: one chain
+ * in 4096 after 1.7e9 proposals, about 6e-10 per proposal (tools/track_soak.py); from there on that chain is another realisation of the same
+ * process (the draws land on different events), not a wrong one.  pdmp_ensemble_final_state rebuilds
  * the reference's lazy clocks t[j] (src/sfact.jl:211) from the times of the last proposal / accept around j.
  * Requirements (else set_state returns PDMP_ERR_UNSUPPORTED -- never a silent fall-back): PDMP_SAMPLER_ZIGZAG_LOCAL, ZigZag flow
  * without refresh, Gaussian target, symmetric Γ, lattice-like neighbourhoods (|G1| <= 5, |S| <= 13) and 2048 <= d <= 16384.
