@@ -117,6 +117,8 @@ struct orc_pq {
     int64_t* xs_key; /* 1-based heap positions, xs[k] = key => val */
     double* xs_val;
     int64_t* index;  /* key -> heap position */
+    int lex;         /* 0: the reference's order (isless on the values; tied values pop in heap-shape order, :50);
+                        1: ties broken by the lower key -- the device queues' rule (see spdmp_zigzag_tracked) */
 };
 
 /* isless on Float64 (Base): NaN sorts last, -0.0 < 0.0 */
@@ -126,6 +128,12 @@ static inline int f_isless(double a, double b) {
     if (a < b) return 1;
     if (a == b) return signbit(a) && !signbit(b);
     return 0;
+}
+
+/* "entry (va, ka) comes before entry (vb, kb)" */
+static inline int pq_lt(const orc_pq* q, double va, int64_t ka, double vb, int64_t kb) {
+    if (f_isless(va, vb)) return 1;
+    return q->lex && va == vb && ka < kb;
 }
 
 orc_pq* orc_pq_new(int64_t capacity) {
@@ -154,8 +162,8 @@ static void pq_down(orc_pq* q, int64_t i) {
     int64_t l;
     while ((l = 2 * i) <= q->len) {
         int64_t r = 2 * i + 1;
-        int64_t j = (r > q->len || f_isless(q->xs_val[l], q->xs_val[r])) ? l : r;
-        if (f_isless(q->xs_val[j], xv)) {
+        int64_t j = (r > q->len || pq_lt(q, q->xs_val[l], q->xs_key[l], q->xs_val[r], q->xs_key[r])) ? l : r;
+        if (pq_lt(q, q->xs_val[j], q->xs_key[j], xv, xk)) {
             q->index[q->xs_key[j]] = i;
             q->xs_key[i] = q->xs_key[j];
             q->xs_val[i] = q->xs_val[j];
@@ -174,7 +182,7 @@ static void pq_up(orc_pq* q, int64_t i) {
     double xv = q->xs_val[i];
     while (i > 1) {
         int64_t j = i / 2;
-        if (f_isless(xv, q->xs_val[j])) {
+        if (pq_lt(q, xv, xk, q->xs_val[j], q->xs_key[j])) {
             q->index[q->xs_key[j]] = i;
             q->xs_key[i] = q->xs_key[j];
             q->xs_val[i] = q->xs_val[j];
@@ -422,8 +430,228 @@ static double logistic_grad_moving(const orc_zz_params* p, int64_t j, double* t,
     return prior - s;
 }
 
+/* poisson_time(a, b, u) with L = log(u) already taken (src/poissontime.jl:8-30): the same operations on the same operands as
+ * orc_poisson_time -- (-L)*2/b and -(L*2/b) are the same double -- in the form the tracked kernels evaluate it. */
+static double poisson_time_L(double a, double b, double L) {
+    if (b == 0) return (a > 0) ? -L / a : INFINITY;
+    const double r = a / b;
+    const double q = L * 2.0 / b;
+    if (b > 0) return sqrt((a < 0) ? -q : r * r - q) - r;
+    if (a <= 0) return INFINITY;
+    if (-L <= -(a * a) / b + (a * a) / (2 * b)) return -sqrt(r * r - q) - r;
+    return INFINITY;
+}
+
+/* entry (row, col) of a CSC matrix (0.0 if it is not stored) */
+static double csc_entry(const orc_csc* A, int64_t row, int64_t col) {
+    for (int64_t p = A->colptr[col]; p < A->colptr[col + 1]; ++p)
+        if (A->rowval[p] == row) return A->nzval[p];
+    return 0.0;
+}
+
+/*
+ * TRACKED-GRADIENT evaluation of spdmp_inner! (p->tracked): the bitwise statement of what the device's tracked kernels compute
+ * (zz_local_trackp_kernel, pdmp_trackp.hip; zz_local_track_kernel, pdmp_kernels.hip).  The PROCESS is the reference's -- same queue,
+ * same draws in the same order, same thinning test (src/sfact.jl:116-140), same bounds (src/fact_samplers.jl:50-54) -- but the
+ * gradient is not gathered from a moved neighbourhood (src/sfact.jl:82,116): every coordinate carries
+ *     g_i = Γt[:,i]·x  and  gd_i = Γt[:,i]·θ  at time tg_i      (and gb_i, gdb_i with the bounding Γ when that differs),
+ * which the linear flow advances exactly in real arithmetic, g_i(t′) = g_i + gd_i (t′ − tg_i).  In floating point the advanced sum
+ * and the gathered sum differ in their last bits, so this function is NOT bit-identical to the moving evaluation above (they agree
+ * to ~1e-13; tests/test_oracle_tracked.py holds them to 1e-9 with identical indices), while the DEVICE kernels are held to this
+ * function bit for bit.  Every operation below is written in the kernels' order:
+ *   proposal of i at t′:   g_now = g + gd (t′ − tg);  l = (g_now − (Γt μt)_i) θ_i ⁺;  lb = (a + b (t′ − t_old))⁺      (:119)
+ *   reject:                a = c_i + (gb_now − (Γ μ)_i) θ_i,  b = c_i/100 + θ_i gdb,  t_old = t′,  key = t′ + poisson_time   (:137-140)
+ *   accept, j ∈ G1[i] ascending (:131-135): g_j = g_j + gd_j (t′ − tg_j),  gd_j = gd_j + Γt[j,i]·(−2θ_i),  tg_j = t′, same bound
+ *                          formulas with θ_j (−θ_i for j = i);  x_i is brought to t′ on its own accepts only (event(), :50-52).
+ * The pair-layout kernel does not store (a, b, t_old): it re-derives them from t_old = max(tprop, tg) and the same operands, which
+ * yields the same doubles (a bound is computed either at the coordinate's own proposal or when its sums are re-based).
+ * TIES.  Two finite keys are exactly equal with probability ~2.5e-10 per event on config C3 (event gaps ~1.4e-5, one ulp at t ~ 16 is
+ * 3.6e-15): 4096 chains to T = 20 are 5.9e9 proposals, so a tie or two DOES occur at the north star's scale.  The reference pops tied
+ * keys in the order its heap happens to hold them (src/priorityqueue.jl:46-61, right child on equal children); the device queues pop
+ * the LOWEST COORDINATE first.  Both orders are valid for simultaneous events of independent clocks, but they hand the stream's draws
+ * to different events, so the chains part.  This function is the kernels' checker and uses THEIR rule (the queue below compares
+ * (key, coordinate) pairs); the moving evaluation above keeps the reference's heap.  (Observed: chain 1018 of the C3 ensemble,
+ * coordinates 11340 and 15903 both due at t = 18.887967430385714 in the tracked arithmetic.)
+ * Final state as zz_track_unpack_kernel rebuilds it (src/sfact.jl:211): t[j] = the later of the last proposal inside G1[j] and the
+ * last accepted event inside S[j] = G1[j] ∪ G2[j]; x[j] moved linearly from its own clock to t[j].
+ * Requirements (those of the kernels): ZigZag flow, Gaussian target, no refresh clock, Matched(); the target's Γ is symmetric
+ * and has the pattern of the bounding Γ.
+ */
+static int spdmp_zigzag_tracked(int64_t d, const orc_zz_params* p, double t0, double T, double* x, double* th, double* c, double* t,
+                                int64_t* acc, orc_trace* tr, orc_zz_result* res) {
+    const orc_csc* Gb = p->bound_gamma;
+    const orc_csc* Gt = p->target_gamma;
+    if (p->flow_kind || p->lambda_ref > 0 || p->move_all || p->target_kind || p->local_bound || p->adaptscale) return ORC_BAD_INPUT;
+    if (Gt->colptr[d] != Gb->colptr[d] || memcmp(Gt->colptr, Gb->colptr, (size_t)(d + 1) * sizeof(int64_t)) ||
+        memcmp(Gt->rowval, Gb->rowval, (size_t)Gb->colptr[d] * sizeof(int64_t)))
+        return ORC_BAD_INPUT;
+    const int two_sums = memcmp(Gt->nzval, Gb->nzval, (size_t)Gb->colptr[d] * sizeof(double)) != 0;
+    nbr_graph g1 = graph_g1(Gb);
+    nbr_graph g2 = graph_g2(&g1, d);
+    double* gmu_b = (double*)malloc((size_t)d * sizeof(double));
+    double* gmu_t = p->target_mu ? (double*)malloc((size_t)d * sizeof(double)) : NULL;
+    for (int64_t i = 0; i < d; ++i) gmu_b[i] = orc_idot(Gb, i, p->bound_mu);
+    if (gmu_t)
+        for (int64_t i = 0; i < d; ++i) gmu_t[i] = orc_idot(Gt, i, p->target_mu);
+    double* tx = (double*)malloc((size_t)d * sizeof(double));    /* clock of x_i */
+    double* g = (double*)malloc((size_t)d * sizeof(double));     /* Γt[:,i]·x at tg */
+    double* gd = (double*)malloc((size_t)d * sizeof(double));    /* Γt[:,i]·θ */
+    double* gb = (double*)malloc((size_t)d * sizeof(double));    /* the same with the bounding Γ */
+    double* gdb = (double*)malloc((size_t)d * sizeof(double));
+    double* tg = (double*)malloc((size_t)d * sizeof(double));
+    double* ba = (double*)malloc((size_t)d * sizeof(double));
+    double* bb = (double*)malloc((size_t)d * sizeof(double));
+    double* t_old = (double*)malloc((size_t)d * sizeof(double));
+    double* tprop = (double*)malloc((size_t)d * sizeof(double)); /* last own proposal */
+    double* tacc = (double*)malloc((size_t)d * sizeof(double));  /* last own accept */
+    const uint64_t seed = p->seed;
+    uint64_t nm = 0;
+    orc_pq* Q = orc_pq_new(d + 1);
+    Q->lex = 1; /* exactly tied keys pop lowest coordinate first, as on the device */
+    for (int64_t i = 0; i < d; ++i) {
+        g[i] = orc_idot(Gt, i, x);
+        gd[i] = orc_idot(Gt, i, th);
+        gb[i] = orc_idot(Gb, i, x);
+        gdb[i] = orc_idot(Gb, i, th);
+        tx[i] = tg[i] = t_old[i] = tprop[i] = tacc[i] = t0;
+        acc[i] = 0;
+        ba[i] = c[i] + (gb[i] - gmu_b[i]) * th[i]; /* src/fact_samplers.jl:51 */
+        bb[i] = c[i] / 100 + th[i] * gdb[i];       /* :52 */
+    }
+    for (int64_t i = 0; i < d; ++i) /* src/sfact.jl:186 (t0 is not added) */
+        orc_pq_enqueue(Q, i, orc_poisson_time(ba[i], bb[i], pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)));
+
+    int64_t num = 0, nacc = 0;
+    int status = ORC_OK;
+    double tp = t0;
+    int done = 0;
+    while (!done && tp < T) { /* src/sfact.jl:199 */
+        for (;;) {
+            int64_t i;
+            double tq;
+            orc_pq_peek(Q, &i, &tq); /* :77 */
+            if (p->stop_before_T && !(tq < T)) {
+                done = 1;
+                break;
+            }
+            if (tq == INFINITY) {
+                status = ORC_STALLED;
+                done = 1;
+                break;
+            }
+            tp = tq;
+            const double g_now = g[i] + gd[i] * (tp - tg[i]);
+            const double gb_now = two_sums ? (gb[i] + gdb[i] * (tp - tg[i])) : g_now;
+            double gr = g_now;
+            if (gmu_t) gr = gr - gmu_t[i];
+            const double l = pos(gr * th[i]);                        /* :119 */
+            const double lb = pos(ba[i] + bb[i] * (tp - t_old[i]));   /* :119, src/sfact.jl:70 */
+            num += 1;
+            tprop[i] = tp; /* the reference moved G[i] to t′ (:82) */
+            if (pdmp_u01(seed, PDMP_STREAM_MAIN, nm++) * lb < l) { /* :121 */
+                acc[i] += 1;
+                nacc += 1;
+                if (l >= lb) { /* :123 */
+                    if (!p->adapt) {
+                        status = ORC_BOUND_VIOLATED;
+                        done = 1;
+                        break;
+                    }
+                    c[i] *= p->factor; /* :127 */
+                }
+                const double th_i = th[i];
+                const double delta = -th_i - th_i; /* θ_i -> −θ_i (:130); the kernels form it as (−θ) − θ = −2θ exactly */
+                { /* event(i, t, x, θ, F): x_i at t′ */
+                    const double dtx = tp - tx[i];
+                    x[i] = x[i] + th_i * dtx;
+                    tx[i] = tp;
+                }
+                th[i] = -th_i;
+                tacc[i] = tp;
+                for (int64_t q = g1.ptr[i]; q < g1.ptr[i + 1]; ++q) { /* :131-135 */
+                    const int64_t j = g1.idx[q];
+                    const double ct = Gt->nzval[q]; /* Γt[j, i] (= Γt[i, j]) */
+                    double gj, gdj, gbj, gdbj;
+                    if (j == i) {
+                        gj = g_now;
+                        gdj = gd[i];
+                        gbj = gb_now;
+                        gdbj = two_sums ? gdb[i] : gd[i];
+                    } else {
+                        gj = g[j] + gd[j] * (tp - tg[j]);
+                        gdj = gd[j];
+                        if (two_sums) {
+                            gbj = gb[j] + gdb[j] * (tp - tg[j]);
+                            gdbj = gdb[j];
+                        } else {
+                            gbj = gj;
+                            gdbj = gdj;
+                        }
+                    }
+                    gdj += ct * delta;
+                    if (two_sums) gdbj += csc_entry(Gb, i, j) * delta; /* Γ[i, j]: the entry of column j at row i */
+                    else gdbj = gdj;
+                    g[j] = gj;
+                    gd[j] = gdj;
+                    gb[j] = gbj;
+                    gdb[j] = gdbj;
+                    tg[j] = tp;
+                    ba[j] = c[j] + (gbj - gmu_b[j]) * th[j];
+                    bb[j] = c[j] / 100 + th[j] * gdbj;
+                    t_old[j] = tp;
+                    const double L = pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm++));
+                    orc_pq_set(Q, j, tp + poisson_time_L(ba[j], bb[j], L));
+                }
+                trace_push(tr, tp, i, x[i], th[i]); /* :143 */
+                break;
+            } else { /* :136-140 */
+                ba[i] = c[i] + (gb_now - gmu_b[i]) * th[i];
+                bb[i] = c[i] / 100 + th[i] * (two_sums ? gdb[i] : gd[i]);
+                t_old[i] = tp;
+                const double L = pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm++));
+                orc_pq_set(Q, i, tp + poisson_time_L(ba[i], bb[i], L));
+                continue;
+            }
+        }
+        if (p->max_events > 0 && nacc >= p->max_events && !done) {
+            status = ORC_TRACE_LIMIT;
+            done = 1;
+        }
+    }
+    /* the reference's lazy clocks and the positions at those clocks (zz_track_unpack_kernel) */
+    for (int64_t j = 0; j < d; ++j) {
+        double tr_ = t0;
+        for (int64_t q = g1.ptr[j]; q < g1.ptr[j + 1]; ++q) {
+            const int64_t m = g1.idx[q];
+            if (tprop[m] > tr_) tr_ = tprop[m];
+            if (tacc[m] > tr_) tr_ = tacc[m];
+        }
+        for (int64_t q = g2.ptr[j]; q < g2.ptr[j + 1]; ++q)
+            if (tacc[g2.idx[q]] > tr_) tr_ = tacc[g2.idx[q]];
+        t[j] = tr_;
+    }
+    for (int64_t j = 0; j < d; ++j) x[j] = x[j] + th[j] * (t[j] - tx[j]);
+    if (res) {
+        res->num = num;
+        res->nacc = nacc;
+        res->nrefresh = 0;
+        res->ndraw_main = nm;
+        res->ndraw_global = 0;
+        res->t_last = tp;
+        res->status = status;
+    }
+    orc_pq_free(Q);
+    free(tx); free(g); free(gd); free(gb); free(gdb); free(tg); free(ba); free(bb); free(t_old); free(tprop); free(tacc);
+    free(gmu_b);
+    free(gmu_t);
+    graph_free(&g1);
+    graph_free(&g2);
+    return status;
+}
+
 int orc_spdmp_zigzag(int64_t d, const orc_zz_params* p, double t0, double T, double* x, double* th,
                      double* c, double* t, int64_t* acc, orc_trace* tr, orc_zz_result* res) {
+    if (p->tracked) return spdmp_zigzag_tracked(d, p, t0, T, x, th, c, t, acc, tr, res);
     zz_ctx cx;
     cx.d = d;
     cx.p = p;

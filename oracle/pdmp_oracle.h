@@ -121,6 +121,10 @@ typedef struct {
     /* c::LocalBound (src/local.jl:2-6,10-78,95-149): bounds from the target's own first and second directional derivatives with
      * an expiry horizon 2/c_i/|θ_i|; ZigZag flow, Gaussian target, no refresh clock (the reference's refresh branch is JointFlow only). */
     int local_bound;
+    /* tracked = 1: the tracked-gradient evaluation of the same process (pdmp_oracle.c: spdmp_zigzag_tracked) -- the BITWISE checker of
+     * the device's tracked kernels; agrees with the moving evaluation (tracked = 0, the reference's) in every index and to ~1e-13 in the
+     * floats until a rounding difference flips a thinning test (measured: ~6e-10 per proposal on config C3). */
+    int tracked;
 } orc_zz_params;
 
 typedef struct {

@@ -47,7 +47,8 @@ class _ZZParams(C.Structure):
                 ("seed", C.c_uint64), ("max_events", C.c_int64), ("stop_before_T", C.c_int),
                 ("target_kind", C.c_int), ("lg_A", C.POINTER(_Csc)), ("lg_At", C.POINTER(_Csc)), ("lg_y", C.c_void_p),
                 ("lg_ny", C.c_void_p), ("lg_mu", C.c_void_p), ("lg_gamma0", C.c_double), ("lg_k", C.c_int64),
-                ("flow_kind", C.c_int), ("adaptscale", C.c_int), ("sigma_out", C.c_void_p), ("local_bound", C.c_int)]
+                ("flow_kind", C.c_int), ("adaptscale", C.c_int), ("sigma_out", C.c_void_p), ("local_bound", C.c_int),
+                ("tracked", C.c_int)]
 
 
 class _ZZResult(C.Structure):
@@ -193,8 +194,9 @@ def idot(A, j, x):
 def spdmp_zigzag(bound_gamma, bound_mu, target_gamma, x0, theta0, c, T, *, t0=0.0, target_mu=None,
                  sigma=None, lambda_ref=0.0, rho=0.0, move_all=False, adapt=False, factor=1.8, seed=1,
                  max_events=0, stop_before_T=False, want_trace=True, logistic=None, factboomerang=False,
-                 adaptscale=False, local_bound=False):
-    """Local ZigZag (reference spdmp / pdmp for ZigZag).  Returns dict(events, t, x, theta, acc, num, c, ...)."""
+                 adaptscale=False, local_bound=False, tracked=False):
+    """Local ZigZag (reference spdmp / pdmp for ZigZag).  Returns dict(events, t, x, theta, acc, num, c, ...).
+    tracked=True: the tracked-gradient evaluation of the same process (the bitwise checker of the device's tracked kernels)."""
     L = lib()
     gb = bound_gamma if isinstance(bound_gamma, CscHolder) else CscHolder(bound_gamma)
     gt = target_gamma if isinstance(target_gamma, CscHolder) else CscHolder(target_gamma)
@@ -209,6 +211,7 @@ def spdmp_zigzag(bound_gamma, bound_mu, target_gamma, x0, theta0, c, T, *, t0=0.
     sg_out = np.array(sg)
     p.adaptscale = int(adaptscale)
     p.local_bound = int(local_bound)
+    p.tracked = int(tracked)
     p.sigma_out = sg_out.ctypes.data
     if logistic is not None:  # dict(A, At, y, ny, mu, gamma0, k): target_kind 1
         lA = logistic["A"] if isinstance(logistic["A"], CscHolder) else CscHolder(logistic["A"])

@@ -1,6 +1,11 @@
-"""Tracked-gradient evaluation of the local ZigZag (pdmp_ensemble_set_gradient_tracking, zz_local_track_kernel) against the oracle
-(-m gpu): the event INDEX sequence, accept / reject outcomes, counters and adapted bounds are exact; event times, positions and the final
-state agree to 1e-9 relative (measured: ~1e-13; north star: 1e-6) -- sums that are advanced are not rounded like sums recomputed."""
+"""Tracked-gradient evaluation of the local ZigZag (pdmp_ensemble_set_gradient_tracking, zz_local_trackp_kernel and its relatives) against
+the oracle (-m gpu), twice over:
+  * against the oracle's MOVING evaluation (the restatement of src/sfact.jl:73-145): the event INDEX sequence, accept / reject outcomes,
+    counters and adapted bounds are exact; event times, positions and the final state agree to 1e-9 relative (measured: ~1e-13; north
+    star: 1e-6) -- sums that are advanced are not rounded like sums recomputed;
+  * against the oracle's TRACKED evaluation (oracle/pdmp_oracle.c: spdmp_zigzag_tracked, itself held to the moving one by
+    tests/test_oracle_tracked.py): BIT FOR BIT -- every event time, position, final clock and state -- so that a commit-rule bug of the
+    speculative kernels cannot hide behind the tolerance."""
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -28,6 +33,18 @@ def check_chain(ev, fs_t, fs_x, fs_th, acc, num, cout, r):
         assert np.array_equal(cout, r["c"])
 
 
+def check_chain_bitwise(ev, fs_t, fs_x, fs_th, acc, num, cout, r):
+    """device-tracked == oracle-tracked, tolerance 0"""
+    oe = r["events"]
+    assert len(ev) == len(oe), (len(ev), len(oe))
+    for f in ("i", "t", "x", "theta"):
+        assert np.array_equal(ev[f], oe[f]), f
+    assert int(num) == r["num"] and np.array_equal(acc, r["acc"])
+    assert np.array_equal(fs_th, r["theta"]) and np.array_equal(fs_t, r["t"]) and np.array_equal(fs_x, r["x"])
+    if cout is not None:
+        assert np.array_equal(cout, r["c"])
+
+
 @pytest.mark.parametrize("n,T", [(48, 12.0), (64, 6.0), (47, 5.0)])
 def test_tracked_matches_oracle_on_lattices(gpu_pkg, n, T):
     """The north-star workload's relatives (n x n grid-Laplace GMRFs; 47 is odd: border templates everywhere), bound Γ == target Γ."""
@@ -45,6 +62,8 @@ def test_tracked_matches_oracle_on_lattices(gpu_pkg, n, T):
         r = O.spdmp_zigzag(G, None, G, x0[k], th0[k], c, T, seed=700 + n + k)
         assert r["status"] == 0 and len(r["events"]) > 1000
         check_chain(tr[k].events, t[k], x[k], th[k], acc[k], num[k], None, r)
+        check_chain_bitwise(tr[k].events, t[k], x[k], th[k], acc[k], num[k], None,
+                            O.spdmp_zigzag(G, None, G, x0[k], th0[k], c, T, seed=700 + n + k, tracked=True))
         dev_t = max(dev_t, float(np.max(np.abs(tr[k].events["t"] - r["events"]["t"]))))
     assert dev_t < 1e-11  # what is actually observed: a few 1e-14
 
@@ -67,6 +86,8 @@ def test_every_tracked_kernel_commits_the_same_sequence(gpu_pkg, monkeypatch, wh
         r = O.spdmp_zigzag(G, None, G, x0[k], th0[k], c, T, seed=4100 + k)
         assert r["status"] == 0 and len(r["events"]) > 1000
         check_chain(tr[k].events, t[k], x[k], th[k], acc[k], num[k], None, r)
+        check_chain_bitwise(tr[k].events, t[k], x[k], th[k], acc[k], num[k], None,
+                            O.spdmp_zigzag(G, None, G, x0[k], th0[k], c, T, seed=4100 + k, tracked=True))
 
 
 def test_tracked_with_looser_bound_mean_and_adapt(gpu_pkg):
@@ -88,6 +109,8 @@ def test_tracked_with_looser_bound_mean_and_adapt(gpu_pkg):
         r = O.spdmp_zigzag(0.9 * G, mu, G, x0[k], th0[k], c, T, seed=31 + k, target_mu=mu, adapt=True, factor=1.8)
         assert r["status"] == 0 and r["c"].max() > c.max()
         check_chain(tr[k].events, t[k], x[k], th[k], acc[k], num[k], cout[k], r)
+        check_chain_bitwise(tr[k].events, t[k], x[k], th[k], acc[k], num[k], cout[k],
+                            O.spdmp_zigzag(0.9 * G, mu, G, x0[k], th0[k], c, T, seed=31 + k, target_mu=mu, adapt=True, factor=1.8, tracked=True))
 
 
 def test_tracked_slices_trace_refills_and_violation(gpu_pkg):
@@ -125,6 +148,8 @@ def test_tracked_slices_trace_refills_and_violation(gpu_pkg):
         r = O.spdmp_zigzag(G, None, G, x0, th0, c, 6.5, seed=4242 + k)
         ev = np.concatenate(evs[k])
         check_chain(ev, fs["t"][k], fs["x"][k], fs["theta"][k], fs["acc"][k], cnt["num"][k], None, r)
+        check_chain_bitwise(ev, fs["t"][k], fs["x"][k], fs["theta"][k], fs["acc"][k], cnt["num"][k], None,
+                            O.spdmp_zigzag(G, None, G, x0, th0, c, 6.5, seed=4242 + k, tracked=True))
         assert ev["t"][-1] >= 6.5
         ys.append(pkg.trace.moments(pkg.FactTrace(None, 0.0, x0, th0, r["events"]), 4.0)[0])
     assert np.allclose(s1, np.sum(ys, axis=0), rtol=1e-9, atol=1e-11) and np.allclose(s2, np.sum(np.square(ys), axis=0), rtol=1e-9, atol=1e-11)
@@ -227,6 +252,11 @@ def test_full_size_traces_and_states_against_exact_kernel_and_oracle(c3_tracked)
     assert len(ev) == len(r["events"]) and int(ct["num"][0]) == r["num"]
     assert np.array_equal(ev["i"], r["events"]["i"]) and close(ev["t"], r["events"]["t"]) and close(ev["x"], r["events"]["x"])
     assert float(np.max(np.abs(ev["t"] - r["events"]["t"]))) < 1e-11
+    for k in (0, 4095):  # ... and bit for bit against the oracle's tracked evaluation
+        x0, th0 = O.synthetic_state(0x5EED0000 + k, d)
+        rt = O.spdmp_zigzag(G, None, G, x0, th0, c, T, seed=0x5EED0000 + k, stop_before_T=True, tracked=True)
+        fa = et.final_state(k, 1)
+        check_chain_bitwise(et.trace(k, counters=ct), fa["t"][0], fa["x"][0], fa["theta"][0], fa["acc"][0], ct["num"][k], None, rt)
 
 
 @pytest.mark.parametrize("which", [0, 1, 3])
@@ -247,3 +277,5 @@ def test_tracked_with_a_start_time(gpu_pkg, monkeypatch, which):
         r = O.spdmp_zigzag(G, None, G, x0[k], th0[k], c, T, seed=6100 + k, t0=t0)
         assert r["status"] == 0 and len(r["events"]) > 1000
         check_chain(tr[k].events, t[k], x[k], th[k], acc[k], num[k], None, r)
+        check_chain_bitwise(tr[k].events, t[k], x[k], th[k], acc[k], num[k], None,
+                            O.spdmp_zigzag(G, None, G, x0[k], th0[k], c, T, seed=6100 + k, t0=t0, tracked=True))
