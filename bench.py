@@ -183,7 +183,9 @@ def make_workload(pkg, args, rank, local_rank):
         ens.set_state_synthetic(0.0, c, seed0)
         W.update(G=G, c=c, d=d, cap=cap, ens=ens, kernel="zz_local_spec8_kernel" if args.exact else "zz_local_trackp_kernel",
                  unit="reflection events/s", evaluation="moving (bit-identical to the oracle)" if args.exact else
-                 "tracked gradients (index sequence identical for ~1e9 proposals per flip, floats to 1e-9: tests/test_gpu_track_parity.py, tools/track_soak.py)",
+                 "tracked gradients (bit-identical to the oracle's tracked evaluation; against the moving evaluation: same index sequence until a rounding "
+                 "difference flips a test, ~6e-10 per proposal = 3 of 4096 chains by T=20, floats to 1e-9: tests/test_gpu_track_horizon.py); the "
+                 "bit-identical moving evaluation is timed beside it as `exact`",
                  metric="reflection events/sec, d=16384 local ZigZag (spdmp), ensemble of independent chains",
                  workload=f"C3: local ZigZag spdmp on Gamma=0.01I+gridlaplacian({args.grid},{args.grid}), d={d}, {nch} chains/GPU, "
                           f"step = advance all chains by dT={dt}, traces {'off' if args.no_trace else 'on (32 B/event)'}",
@@ -269,8 +271,13 @@ def main():
     ap.add_argument("--grid", type=int, default=GRID)
     ap.add_argument("--dt", type=float, default=None, help="process time per step (default: the configuration's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--ess-batches", type=int, default=32, help="B: batches per chain of the ESS run after the timed region (0: skip)")
-    ap.add_argument("--ess-batch-len", type=float, default=2.0, help="b: length of an ESS batch in process time")
+    ap.add_argument("--ess-batches", type=int, default=16, help="B: batches per chain of the ESS run after the timed region (0: skip; a power of two)")
+    ap.add_argument("--ess-batch-len", type=float, default=64.0, help="b: length of an ESS batch in process time (the run is B*b long)")
+    ap.add_argument("--no-stationary-start", action="store_true",
+                    help="ESS run: continue the timed ensemble (x0 ~ N(0, I) as scripts/gaussianrandomfield.jl:29) instead of a fresh one "
+                         "started at x0 ~ N(0, inv(Gamma)) exactly; the slow modes are then NOT in equilibrium and the figure is optimistic")
+    ap.add_argument("--exact-steps", type=int, default=5,
+                    help="C3: steps of the bit-identical moving evaluation timed after the headline region and printed as `exact` (0: skip)")
     ap.add_argument("--no-trace", action="store_true", help="count events only (diagnostic; not the headline mode)")
     ap.add_argument("--gather", action="store_true",
                     help="after the timed region: one more step, then time the post-run exchange (all_gather counts -> gatherv of the "
@@ -383,45 +390,89 @@ def main():
     if args.config == "C5":
         num = work["grads"]
 
-    # ESS/s: batch means INSIDE each chain over one long run after the timed region (which serves as burn-in):
-    # B = 32 batches of length b, sigma2_asym = b * pooled within-chain variance of the batch means,
-    # ESS_i = N * B * b * Var_pi,i / sigma2_asym,i at 32 probe coordinates with exact Var_pi = diag(inv(Gamma)); divided by the
-    # GPU seconds (kernel time) that produced the path.  Validated in tests/test_gpu_ess.py against a closed-form target.
+    # The bit-identical evaluation beside the headline (never inside `value`): the same workload, seeds and step on zz_local_spec8_kernel
+    exact = None
+    if rank == 0 and args.config == "C3" and not args.exact and args.exact_steps > 0:
+        ex = pkg.Ensemble(nch, d, device=local_rank, trace_capacity=cap)
+        ex.set_flow(pkg.ZigZag(G, np.zeros(d)))
+        ex.set_target(pkg.GaussianTarget(G))
+        ex.set_state_synthetic(0.0, c, SEED0 + rank * nch)
+        xms = []
+        for k in range(2 + args.exact_steps):
+            ex.run((k + 1) * args.dt, pkg._lib.RUN_STOP_BEFORE, sync=False)
+            xms.append(ex.last_run_ms())
+            if k == 1:
+                xc0 = ex.counters()
+            if cap:
+                ex.trace_reset()
+        xc1 = ex.counters()
+        ex.close()
+        xnum = int(xc1["num"].sum()) - int(xc0["num"].sum())
+        xacc = int(xc1["nacc"].sum()) - int(xc0["nacc"].sum())
+        xs = float(np.sum(xms[2:])) * 1e-3
+        xach = algorithmic_bytes(xnum, xacc) / xs / 1e9
+        exact = {"kernel": "zz_local_spec8_kernel", "evaluation": "moving: bit-identical to the oracle (indices, outcomes, times, positions)",
+                 "steps": args.exact_steps, "ms_per_step": 1e3 * xs / args.exact_steps, "value": xacc / xs, "unit": "reflection events/s",
+                 "proposals_per_s": xnum / xs, "roofline": {"bound": "hbm", "achieved": xach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                            "frac": xach / HBM_PEAK_GBS},
+                 "unhealthy_chains": int(np.count_nonzero(xc1["status"] != pkg._lib.CHAIN_OK)),
+                 "note": "kernel time from HIP events of this process, after the timed region; same seeds, step and trace handling"}
+
+    # ESS/s.  A fresh ensemble of the same shape is started IN STATIONARITY -- x0 ~ N(0, inv(Gamma)) exactly (DCT of the lattice,
+    # problems.gmrf_stationary_sample), theta0 uniform on {+-1} -- and run for B batches of length b on the timed kernel; after every batch
+    # the device returns the path integrals J_i of every chain at 32 probe coordinates (pdmp_ensemble_path_integrals).  With the exact mean 0
+    # and exact Var_pi = diag(inv(Gamma)), sigma2(s) = s * mean (Y_s)^2 over chains and merged batches at every dyadic batch length
+    # s = b .. B*b (ess.multiscale_ess); ESS_i(s) = N*B*b*Var_pi,i / sigma2_i(s) shrinks as s passes the autocorrelation times of the slow
+    # lattice modes (eigenvalue 0.01: ~150 time units), so the HEADLINE is the SMALLEST of them -- the largest s, i.e. the spread of the N
+    # whole-run means -- and `last_doubling` says how far from its plateau that still is.  Divided by the GPU seconds of that run.
     ess = None
-    if rank == 0 and world == 1 and not args.no_trace and args.ess_batches >= 2:
+    if rank == 0 and world == 1 and args.config == "C3" and args.ess_batches >= 1 and not args.gather:
         B, b = args.ess_batches, args.ess_batch_len
-        T0 = (args.warmup + args.steps) * args.dt
+        probes = np.linspace(0, d - 1, 32).astype(np.int64)
+        if args.no_stationary_start:
+            es, T0, start = ens, (args.warmup + args.steps) * args.dt, "continued from the timed run (x0 ~ N(0, I)): slow modes NOT in equilibrium"
+        else:
+            ens.close()
+            rng = np.random.default_rng(SEED0)
+            es = pkg.Ensemble(nch, d, device=local_rank, trace_capacity=cap)
+            es.set_flow(pkg.ZigZag(G, np.zeros(d)))
+            es.set_target(pkg.GaussianTarget(G))
+            if not args.exact:
+                es.set_gradient_tracking(True)
+            es.set_state(0.0, pkg.problems.gmrf_stationary_sample(args.grid, nch, rng), rng.choice([-1.0, 1.0], (nch, d)), c,
+                         np.arange(nch, dtype=np.uint64) + np.uint64(SEED0 + (1 << 24)))
+            T0, start = 0.0, "stationary: x0 ~ N(0, inv(Gamma)) exactly, theta0 uniform on {+-1}"
         ess_ms = 0.0
-        ens.ess_begin(T0)
+        J = [es.path_integrals(T0, probes)]
+        nsl = max(1, int(round(b / args.dt)))
         for kb in range(B):
-            Tb = T0 + (kb + 1) * b
-            # a batch is advanced in slices of dT so that the trace segments (sized for one step) are recycled as in the timed steps
-            nsl = max(1, int(round(b / args.dt)))
-            for q in range(nsl):
-                ens.run(T0 + kb * b + (q + 1) * (b / nsl), pkg._lib.RUN_STOP_BEFORE, sync=False)
-                ess_ms += ens.last_run_ms()
+            for q in range(nsl):  # slices of dT, so that the trace segments (sized for one step) are recycled as in the timed steps
+                es.run(T0 + kb * b + (q + 1) * (b / nsl), pkg._lib.RUN_STOP_BEFORE, sync=False)
+                ess_ms += es.last_run_ms()
                 if cap:
-                    ens.trace_reset()
-            ens.ess_batch(Tb)
-        sy, sy2, sm, sm2, nb, _, _ = ens.ess_end()
-        import scipy.sparse.linalg as spla
-        lu = spla.splu(G.tocsc())
-        probes = np.linspace(0, d - 1, 32).astype(int)
-        var_pi = np.array([lu.solve(np.eye(1, d, p).ravel())[p] for p in probes])
-        r = pkg.ess.batch_means_ess(sy[probes], sy2[probes], sm[probes], sm2[probes], nch, B, b, var_pi)
+                    es.trace_reset()
+            J.append(es.path_integrals(T0 + (kb + 1) * b, probes))
+        ebad = int(np.count_nonzero(es.counters()["status"] != pkg._lib.CHAIN_OK))
+        if es is not ens:
+            es.close()
+        var_pi = pkg.problems.gmrf_marginal_variances(args.grid)[probes]
+        r = pkg.ess.multiscale_ess(np.stack(J), b, var_pi, mean=0.0)
         gpu_s = ess_ms * 1e-3
-        ess_b = nch * B * b * var_pi / np.maximum(r["sigma2_between"], 1e-300)
-        ess = {"definition": f"within-chain batch means of exact path integrals: B={B} batches of length b={b} per chain after "
-                             f"burn-in T0={T0}, sigma2_asym = b*pooled within-chain Var(batch means), ESS_i = N*B*b*Var_pi,i/"
-                             "sigma2_asym,i at 32 probe coordinates, Var_pi = exact diag(inv(Gamma)); per GPU second of the run "
-                             "that produced the path",
-               "ess_min_per_s": float(r["ess"].min() / gpu_s), "ess_median_per_s": float(np.median(r["ess"]) / gpu_s),
-               "ess_per_chain_time_median": float(np.median(r["ess_per_time"])),
-               "between_chain_check": {"ess_min_per_s": float(ess_b.min() / gpu_s), "ess_median_per_s": float(np.median(ess_b) / gpu_s),
-                                       "note": "from the spread of the N chain means over the same run; lower than the within-chain "
-                                               "figure when modes slower than the run (the lattice's constant mode, eigenvalue 0.01) "
-                                               "have not mixed -- chains start at x0 ~ N(0, I), not at stationarity"},
-               "gpu_seconds": gpu_s, "batches": B, "batch_len": b}
+        ex_ess = r["ess_extrapolated"]
+        ess = {"definition": f"N={nch} chains, B={B} batches of length b={b} (run length {B * b}), path integrals of every chain at 32 probe "
+                             "coordinates; sigma2(s) = s*mean(Y_s^2) at dyadic batch lengths s=b..B*b with the exact mean 0; ESS_i(s) = "
+                             "N*B*b*Var_pi,i/sigma2_i(s), Var_pi = exact diag(inv(Gamma)); sigma2 grows with s towards sigma2_asym (bias -Gamma/s), "
+                             "so the HEADLINE uses the Richardson value 2*sigma2(B*b) - sigma2(B*b/2) -- the smallest ESS of all listed; per GPU "
+                             "second of the run that produced the path; min / median over the probes",
+               "start": start,
+               "ess_min_per_s": float(ex_ess.min() / gpu_s), "ess_median_per_s": float(np.median(ex_ess) / gpu_s),
+               "ess_per_chain_time_median": float(np.median(var_pi / r["sigma2_extrapolated"])),
+               "iact_median": float(np.median(r["sigma2_extrapolated"] / (2.0 * var_pi))),
+               "last_doubling_median": float(np.median(r["last_doubling"])), "last_doubling_max": float(np.max(r["last_doubling"])),
+               "by_batch_len": {str(float(sc)): {"ess_min_per_s": float(r["ess"][q].min() / gpu_s),
+                                                 "ess_median_per_s": float(np.median(r["ess"][q]) / gpu_s)}
+                                for q, sc in enumerate(r["scales"])},
+               "unhealthy_chains": ebad, "gpu_seconds": gpu_s, "batches": B, "batch_len": b, "kernel": W["kernel"]}
 
     # post-run exchange (never inside `value`): SURVEY 8e1
     gather = None
@@ -510,10 +561,12 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            "evaluation": ("exact" if args.exact else "tracked") if args.config == "C3" else "exact",
             "config": {"workload": W["workload"] + (f"; evaluation: {W['evaluation']}" if "evaluation" in W else ""),
                        "chains_per_gpu": nch, "d": d, "dT": args.dt, "parallelism": f"chains sharded x{world}, no collective in the run"},
             "proposals_per_s": num_all / elapsed,
-            "acceptance": nacc_all / max(num_all, 1.0),
+            # (sticky chains reset (acc, num) whenever a bound adapts, src/ss_fact.jl:134: no acceptance ratio can be formed from them)
+            "acceptance": (nacc_all / max(num_all, 1.0)) if args.config != "C5" else None,
             "unhealthy_chains": bad_all,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -529,6 +582,8 @@ def main():
             out["gather"] = gather
         if ess is not None:
             out["ess"] = ess
+        if exact is not None:
+            out["exact"] = exact
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, G, c) if args.config == "C3" else cpu_baseline_config(pkg, args.config)
         print(json.dumps(out), flush=True)

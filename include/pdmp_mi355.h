@@ -33,7 +33,10 @@
 extern "C" {
 #endif
 
-#define PDMP_ABI_VERSION 1
+/* 2: pdmp_ensemble_run_partitioned takes the mask's length; pdmp_ensemble_path_integrals, the trace consumers, the G argument
+ *    (pdmp_ensemble_set_neighbourhood), pdmp_ensemble_set_target_bps and the pdmp_comm_* (RCCL) entry points; Boomerang ensembles
+ *    need an explicit mass factor like BouncyParticle ones.  A host binding must check pdmp_abi_version() at load time. */
+#define PDMP_ABI_VERSION 2
 
 typedef enum {
     PDMP_OK = 0,
@@ -172,7 +175,8 @@ pdmp_status pdmp_ensemble_sync(pdmp_ensemble* ens);
  * parallel_spdmp (src/parallel.jl:104-253): every chain advanced by K wavefronts -- the coordinates cut into K chunks of d / K
  * (Partition(nt, n), :26), one worker per chunk (parallel_spdmp_inner!, :63-102, horizon Δ = `delta`) and a coordinator for the
  * coordinates whose neighbourhood leaves their chunk (parallel_spdmp_outer!, :176-253).  PDMP_SAMPLER_ZIGZAG_LOCAL on a Gaussian target,
- * lambda_ref = 0; `adapt` as configured.  G = the pattern of the flow tables; G1 = the slots with g1_mask[p] != 0 (NULL: all of them), the
+ * lambda_ref = 0; `adapt` as configured.  G = the pattern of the flow tables; G1 = the slots with g1_mask[p] != 0 (NULL: all of them;
+ * mask_len must equal the number of stored entries of the Γ given to set_flow_zigzag, else PDMP_ERR_INVALID), the
  * structural pattern of the bounding Γ -- pass the bounding Γ on the union pattern with zeros and mask them out when, as in
  * test/testparallel.jl:40-49, it is the target's Γ without the cross-chunk entries.  "Upper bounds may not depend across chunks." (:124-127)
  * returns PDMP_ERR_INVALID.  Starts from a fresh state only (set_state, then ONE call); blocks until done.  The trace holds the events in
@@ -180,7 +184,8 @@ pdmp_status pdmp_ensemble_sync(pdmp_ensemble* ens);
  * trace is incomplete.  Counters: num / nacc as the reference returns them, nrefresh = coordinator rounds.  Bit-identical to the oracle's
  * threaded restatement (tests/test_gpu_partitioned.py); 1 <= K <= 16, K | d, columns of at most 64 entries.
  */
-pdmp_status pdmp_ensemble_run_partitioned(pdmp_ensemble* ens, double T, int K, double delta, const uint8_t* g1_mask, void* stream);
+pdmp_status pdmp_ensemble_run_partitioned(pdmp_ensemble* ens, double T, int K, double delta, const uint8_t* g1_mask, int64_t mask_len,
+                                          void* stream);
 /* duration of the most recent run's event-loop kernel, from HIP events recorded on its stream (syncs) */
 pdmp_status pdmp_ensemble_last_run_ms(pdmp_ensemble* ens, float* ms);
 
@@ -227,6 +232,14 @@ pdmp_status pdmp_ensemble_ess_begin(pdmp_ensemble* ens, double T0);
 pdmp_status pdmp_ensemble_ess_batch(pdmp_ensemble* ens, double T);
 pdmp_status pdmp_ensemble_ess_end(pdmp_ensemble* ens, double* sum_y, double* sum_y2, double* sum_m, double* sum_m2,
                                   int64_t* nbatches, double* T0, double* T1);
+
+/*
+ * J_i(T) = ∫_{t0}^{T} x_i(s) ds of EVERY chain at `nprobe` probe coordinates (0-based): out is [nchains x nprobe] row-major.  All chains
+ * paused with PDMP_RUN_STOP_BEFORE at T.  Differences of successive calls are per-chain batch integrals, from which the host forms any
+ * ESS estimator (batch means at several batch lengths, between-chain variances: zigzagboomerang.jl_amd/ess.py: multiscale_ess) while the
+ * N x d records stay on the device.  ZigZag flows only, like pdmp_ensemble_batch_means.
+ */
+pdmp_status pdmp_ensemble_path_integrals(pdmp_ensemble* ens, double T, int64_t nprobe, const int64_t* probes, double* out);
 
 /* ------------------------------------------------------------------ sticky ZigZag (PDMP_SAMPLER_STICKY_ZIGZAG)
  *
@@ -299,7 +312,8 @@ pdmp_status pdmp_ensemble_set_flow_bps(pdmp_ensemble* ens, const int64_t* colptr
  * (√(‖θ‖² + ‖x − μ_flow‖²)·c, 0, Inf) (:34-36); same pdmp_inner! loop, events, counters and entry points as the bouncy
  * particle (create the ensemble with PDMP_SAMPLER_BPS).  The CSC matrix and mu_target describe the TARGET
  * ∇ϕ!(y, x) = Γt(x − μt) (test/maintest.jl:146).  The flow's own Γ enters only through its factor L = cholesky(Symmetric(Γ)).L
- * (src/types.jl:66): identity unless pdmp_ensemble_set_mass_cholesky supplies one. */
+ * (src/types.jl:66), which the caller MUST hand over with pdmp_ensemble_set_mass_cholesky before set_state_bps (an identity factor for
+ * Γ = I): without one set_state_bps returns PDMP_ERR_UNSUPPORTED -- never a silent L = I. */
 pdmp_status pdmp_ensemble_set_flow_boomerang(pdmp_ensemble* ens, const int64_t* colptr, const int64_t* rowval,
                                              const double* nzval, const double* mu_target, const double* mu_flow,
                                              double lambda_ref, double rho);

@@ -300,7 +300,7 @@ Result<FactTrace> parallel_spdmp(int nt, const Target& target, double t0, const 
     detail::set_target(e, target);
     const uint64_t seed = o.seed;
     check(pdmp_ensemble_set_state(e.get(), t0, x0.data(), theta0.data(), c.data(), &seed));
-    check(pdmp_ensemble_run_partitioned(e.get(), T, nt, Delta, g1_mask.empty() ? nullptr : g1_mask.data(), nullptr));
+    check(pdmp_ensemble_run_partitioned(e.get(), T, nt, Delta, g1_mask.empty() ? nullptr : g1_mask.data(), (int64_t)g1_mask.size(), nullptr));
     const auto cnt = e.counters();
     if (cnt[0].status == PDMP_CHAIN_BOUND_VIOLATED) throw std::runtime_error("Tuning parameter `c` too small.");
     if (cnt[0].status == PDMP_CHAIN_TRACE_FULL) throw std::runtime_error("trace_capacity too small for a partitioned run (it is not resumable)");
@@ -353,7 +353,15 @@ inline Result<PDMPTrace> pdmp(const GaussianTarget& target, double t0, const std
     check(pdmp_ensemble_set_flow_boomerang(e.get(), target.Gamma.colptr.data(), target.Gamma.rowval.data(),
                                            target.Gamma.nzval.data(), detail::opt(target.mu), detail::opt(B.mu), B.lambda_ref,
                                            B.rho));
-    if (B.L.n > 0) check(pdmp_ensemble_set_mass_cholesky(e.get(), B.L.colptr.data(), B.L.rowval.data(), B.L.nzval.data()));
+    if (B.L.n > 0) {
+        check(pdmp_ensemble_set_mass_cholesky(e.get(), B.L.colptr.data(), B.L.rowval.data(), B.L.nzval.data()));
+    } else {  // (an empty L is this struct's "identity": the ABI wants it spelled out for a Boomerang)
+        std::vector<int64_t> cp((size_t)d + 1), rv((size_t)d);
+        std::vector<double> nz((size_t)d, 1.0);
+        for (int64_t k = 0; k < d; ++k) cp[(size_t)k] = rv[(size_t)k] = k;
+        cp[(size_t)d] = d;
+        check(pdmp_ensemble_set_mass_cholesky(e.get(), cp.data(), rv.data(), nz.data()));
+    }
     if (o.subsample) check(pdmp_ensemble_set_bps_options(e.get(), 0, 1));
     return detail::not_factorised(e, t0, x0, theta0, T, c, o);
 }

@@ -97,6 +97,28 @@ def test_mass_factor_is_required_for_a_general_gamma(gpu_pkg):
         ens.set_state_bps(0.0, x0, x0 + 1.0, 1.1, np.array([1], dtype=np.uint64))
 
 
+def test_boomerang_needs_its_mass_factor_spelled_out(gpu_pkg):
+    """C ABI: the library never sees a Boomerang's Γ (set_flow_boomerang takes the TARGET's), so it cannot know whether L = I is right:
+    set_state_bps without pdmp_ensemble_set_mass_cholesky is PDMP_ERR_UNSUPPORTED; an identity factor is the explicit opt-in."""
+    pkg = gpu_pkg
+    L = pkg._lib
+    d = 8
+    G = pkg.problems.maintest_precision(d)
+    cp, rv, nz = (np.ascontiguousarray(a) for a in (G.indptr.astype(np.int64), G.indices.astype(np.int64), G.data.astype(np.float64)))
+    mu = np.zeros(d)
+    x0 = np.zeros((1, d))
+    seeds = np.array([1], dtype=np.uint64)
+    with pkg.Ensemble(1, d, sampler=L.SAMPLER_BPS, trace_capacity=8) as ens:
+        L.check(ens._L.pdmp_ensemble_set_flow_boomerang(ens._h, cp.ctypes.data, rv.ctypes.data, nz.ctypes.data, None, mu.ctypes.data, 0.5, 0.0))
+        with pytest.raises(L.PdmpError) as ei:
+            ens.set_state_bps(0.0, x0, x0 + 1.0, 1.1, seeds)
+        assert ei.value.code == L.PDMP_ERR_UNSUPPORTED and "cholesky" in str(ei.value)
+        I = sp.identity(d, format="csc")
+        icp, irv, inz = I.indptr.astype(np.int64), I.indices.astype(np.int64), I.data.astype(np.float64)
+        L.check(ens._L.pdmp_ensemble_set_mass_cholesky(ens._h, icp.ctypes.data, irv.ctypes.data, inz.ctypes.data))
+        ens.set_state_bps(0.0, x0, x0 + 1.0, 1.1, seeds)
+
+
 def test_local_bound_and_subsample(gpu_pkg):
     """c::LocalBound of the non-factorised sampler (src/not_fact_samplers.jl:29-31, renew branch :65-71; LocalBound(20) is the
     reference's own value, test/maintest.jl:182) and the `subsample` keyword (:53,90), with and without the mass factor."""

@@ -108,3 +108,75 @@ def test_device_paths_reproduce_the_stationary_moments(gpu_pkg):
     se_var = v_all.std(0, ddof=1) / math.sqrt(nch)
     assert np.all(np.abs(var - var_pi) < 5 * se_var + 0.02 * var_pi), (var / var_pi)
     assert abs(np.mean(var / var_pi) - 1) < 0.04
+
+
+def test_multiscale_estimator_on_the_closed_form_target(gpu_pkg):
+    """ess.multiscale_ess (what bench.py reports) from pdmp_ensemble_path_integrals: d independent N(0,1) coordinates, batches of ONE time
+    unit -- about the autocorrelation time, where plain batch means are 40 % optimistic -- merged dyadically up to 32: σ²(s) approaches
+    2·sqrt(2/π) (not monotonically: the non-reversible ZigZag's autocorrelation has a negative lobe, σ²(4) overshoots by 13 %), the largest
+    scale is within 5 % and so is the Richardson value the bench headlines."""
+    pkg = gpu_pkg
+    d, nch, B, b = 64, 1024, 32, 1.0
+    G = sp.identity(d, format="csc")
+    sig2 = pkg.ess.zigzag1d_gaussian_sigma2_asym(1.0)
+    rng = np.random.default_rng(3)
+    probes = np.arange(0, d, 2)
+    with pkg.Ensemble(nch, d) as ens:
+        ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
+        ens.set_target(pkg.GaussianTarget(G))
+        # stationary start: x0 ~ N(0, 1), θ0 uniform on {±1}
+        ens.set_state(0.0, rng.standard_normal((nch, d)), rng.choice([-1.0, 1.0], (nch, d)), np.full(d, 1.5), np.arange(nch, dtype=np.uint64) + 77)
+        J = [ens.path_integrals(0.0, probes)]
+        for k in range(B):
+            ens.run((k + 1) * b, pkg._lib.RUN_STOP_BEFORE)
+            J.append(ens.path_integrals((k + 1) * b, probes))
+        # the device integrals are the host integrals of the same paths
+        s1, _ = ens.batch_means(0.0, B * b)
+    J = np.stack(J)
+    assert np.allclose(J[-1].sum(axis=0) / (B * b), s1[probes], rtol=1e-12, atol=1e-12)
+    r = pkg.ess.multiscale_ess(J, b, np.ones(probes.size), mean=0.0)
+    assert list(r["scales"]) == [1.0, 2.0, 4.0, 8.0, 16.0, 32.0]
+    med = np.median(r["sigma2"], axis=1) / sig2
+    assert med[0] < 0.7                                        # batches of one autocorrelation time under-state the variance (ESS optimistic) ...
+    assert abs(med[-1] - 1) < 0.05 and abs(med[-2] - 1) < 0.06  # ... 16 - 32 of them are within 5 % ...
+    assert abs(np.median(r["sigma2_extrapolated"]) / sig2 - 1) < 0.05   # ... and so is the extrapolated value (never below the raw one)
+    assert np.all(r["sigma2_extrapolated"] >= r["sigma2"][-1])
+
+
+def test_within_and_between_chain_estimates_agree_from_a_stationary_start(gpu_pkg):
+    """A 48 x 48 lattice GMRF (eps = 0.5, so that its slowest mode relaxes within a few time units) started at x0 ~ N(0, Γ⁻¹) exactly
+    (problems.gmrf_stationary_sample: DCT): the between-chain estimate of σ²_asym (spread of the whole-run means, s = B·b) and the
+    within-chain one (pooled batch means at s = B·b/8, centred on each chain's own mean) agree within a factor 1.5 at all 32 probes,
+    the device moments are N(0, diag Γ⁻¹)'s, and the closed-form marginal variances equal the sparse solve."""
+    pkg = gpu_pkg
+    n, eps = 48, 0.5
+    G = pkg.problems.gmrf_precision(n, eps)
+    d = n * n
+    c = pkg.problems.column_norms(G)
+    nch, B, b = 1024, 32, 4.0
+    rng = np.random.default_rng(8)
+    probes = np.linspace(0, d - 1, 32).astype(np.int64)
+    var_pi = pkg.problems.gmrf_marginal_variances(n, eps)[probes]
+    lu = spla.splu(G.tocsc())
+    assert np.allclose(var_pi, [lu.solve(np.eye(1, d, p).ravel())[p] for p in probes], rtol=1e-10)
+    x0 = pkg.problems.gmrf_stationary_sample(n, nch, rng, eps)
+    assert np.all(np.abs(x0[:, probes].var(axis=0) / var_pi - 1) < 0.25)
+    with pkg.Ensemble(nch, d) as ens:
+        ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
+        ens.set_target(pkg.GaussianTarget(G))
+        ens.set_state(0.0, x0, rng.choice([-1.0, 1.0], (nch, d)), c, np.arange(nch, dtype=np.uint64) + 9000)
+        J = [ens.path_integrals(0.0, probes)]
+        for k in range(B):
+            ens.run((k + 1) * b, pkg._lib.RUN_STOP_BEFORE)
+            J.append(ens.path_integrals((k + 1) * b, probes))
+    J = np.stack(J)
+    r = pkg.ess.multiscale_ess(J, b, var_pi, mean=0.0)
+    between = r["sigma2"][-1]                                    # s = 128: N whole-run means around the known mean 0
+    Y = (J[4::4] - J[:-4:4]) / (4 * b)                            # 8 batches of length 16 per chain
+    within = 16.0 * np.sum((Y - Y.mean(axis=0, keepdims=True)) ** 2, axis=(0, 1)) / (nch * (Y.shape[0] - 1))
+    ratio = between / within
+    assert np.all((ratio > 1 / 1.5) & (ratio < 1.5)), ratio
+    assert abs(np.median(ratio) - 1) < 0.15
+    assert np.all(r["last_doubling"] < 0.2)                      # the plateau is reached
+    m = J[-1].mean(axis=0) / (B * b)
+    assert np.all(np.abs(m) < 5 * np.sqrt(between / (nch * B * b)))

@@ -113,6 +113,9 @@ def test_refusals(gpu_pkg):
     ens.set_flow(pkg.ZigZag(chunk_diagonal(G, K), np.zeros(d)))
     ens.set_target(pkg.GaussianTarget(chunk_diagonal(G, K)))
     ens.set_state(0.0, x0[None], th0[None], c, np.array([1], dtype=np.uint64))
+    with pytest.raises(pkg._lib.PdmpError, match="g1_mask has") as ei:  # a mask made for another pattern: a status, not a stray read
+        ens.run_partitioned(0.5, K, 0.1, np.ones(7, dtype=np.uint8))
+    assert ei.value.code == pkg._lib.PDMP_ERR_INVALID
     ens.run_partitioned(0.5, K, 0.1)
     with pytest.raises(RuntimeError, match="fresh state"):
         ens.run_partitioned(1.0, K, 0.1)

@@ -11,6 +11,7 @@ import numpy as np
 from . import build as _build
 
 PDMP_OK = 0
+ABI_VERSION = 2  # include/pdmp_mi355.h: PDMP_ABI_VERSION
 ERR_NAMES = {0: "PDMP_OK", 1: "PDMP_ERR_INVALID", 2: "PDMP_ERR_NO_DEVICE", 3: "PDMP_ERR_HIP",
              4: "PDMP_ERR_UNSUPPORTED", 5: "PDMP_ERR_NOMEM"}
 
@@ -37,6 +38,7 @@ EXPORTED_SYMBOLS = [
     "pdmp_ensemble_bps_final_state", "pdmp_ensemble_set_sticky", "pdmp_ensemble_set_adaptscale", "pdmp_ensemble_final_sigma", "pdmp_ensemble_set_flow_boomerang", "pdmp_ensemble_set_local_bound", "pdmp_ensemble_set_target_logistic", "pdmp_ensemble_set_flow_factboomerang",
     "pdmp_ensemble_set_mass_cholesky", "pdmp_ensemble_set_bps_options",
     "pdmp_ensemble_ess_begin", "pdmp_ensemble_ess_batch", "pdmp_ensemble_ess_end", "pdmp_ensemble_set_gradient_tracking",
+    "pdmp_ensemble_path_integrals",
 ]
 # include/pdmp_debug.h: diagnostics, not part of the drop-in boundary
 DEBUG_SYMBOLS = ["pdmp_debug_set_kernel", "pdmp_debug_set_spec_g2", "pdmp_debug_set_phase_profile", "pdmp_debug_phase_profile",
@@ -78,6 +80,9 @@ def load():
     L.pdmp_last_error.restype = C.c_char_p
     L.pdmp_abi_version.restype = C.c_int
     L.pdmp_device_count.restype = C.c_int
+    if L.pdmp_abi_version() != ABI_VERSION:  # (PDMP_MI355_LIB can point at any build)
+        raise RuntimeError(f"{path} implements ABI version {L.pdmp_abi_version()}, this binding is written against {ABI_VERSION} "
+                           "(include/pdmp_mi355.h: PDMP_ABI_VERSION)")
     L.pdmp_ensemble_create.argtypes = [C.POINTER(PdmpConfig), C.POINTER(vp)]
     L.pdmp_ensemble_destroy.argtypes = [vp]
     L.pdmp_ensemble_destroy.restype = None
@@ -87,7 +92,7 @@ def load():
     L.pdmp_ensemble_set_state.argtypes = [vp, f64, vp, vp, vp, vp]
     L.pdmp_ensemble_set_state_synthetic.argtypes = [vp, f64, vp, C.c_uint64]
     L.pdmp_ensemble_run.argtypes = [vp, f64, C.c_int, vp]
-    L.pdmp_ensemble_run_partitioned.argtypes = [vp, f64, C.c_int, f64, vp, vp]
+    L.pdmp_ensemble_run_partitioned.argtypes = [vp, f64, C.c_int, f64, vp, i64, vp]
     L.pdmp_ensemble_sync.argtypes = [vp]
     L.pdmp_ensemble_last_run_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.pdmp_ensemble_counters.argtypes = [vp, vp]
@@ -96,6 +101,7 @@ def load():
     L.pdmp_ensemble_trace_reset.argtypes = [vp]
     L.pdmp_ensemble_final_state.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp]
     L.pdmp_ensemble_batch_means.argtypes = [vp, f64, f64, vp, vp]
+    L.pdmp_ensemble_path_integrals.argtypes = [vp, f64, i64, vp, vp]
     L.pdmp_ensemble_trace_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
     L.pdmp_ensemble_counters_dev.argtypes = [vp, C.POINTER(vp)]
     L.pdmp_debug_math_probe.argtypes = [C.c_int, C.c_uint64, i64, vp]

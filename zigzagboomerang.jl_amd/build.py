@@ -14,7 +14,8 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpdmp_mi355.so")
-SOURCES = ["pdmp_capi.hip", "pdmp_kernels.hip", "pdmp_bps.hip", "pdmp_general.hip", "pdmp_trackw.hip", "pdmp_trackx.hip", "pdmp_partition.hip", "pdmp_trackp.hip"]
+SOURCES = ["pdmp_capi.hip", "pdmp_kernels.hip", "pdmp_bps.hip", "pdmp_general.hip", "pdmp_trackw.hip", "pdmp_trackx.hip", "pdmp_partition.hip", "pdmp_trackp.hip",
+           "pdmp_consume.hip"]
 HEADERS = [os.path.join(CSRC, "pdmp_engine.hpp"),
            os.path.join(PKG_DIR, "..", "include", "pdmp_mi355.h"),
            os.path.join(PKG_DIR, "..", "include", "pdmp_debug.h"),
@@ -48,6 +49,9 @@ def build(force=False, verbose=False, variant=None, defines=()):
 
     variant / defines: an experimental build `lib/libpdmp_mi355.<variant>.so` with extra -D flags, selected at run time with the
     environment variable PDMP_MI355_LIB (A/B timing of kernel versions inside one GPU session, tools/ab.sh)."""
+    if defines and not variant:
+        raise ValueError("build(defines=...) needs a variant name: an experimental -D build must not replace the default library "
+                         "(needs_build() compares time stamps only and would keep it)")
     lib_path = variant_path(variant)
     if not force and not defines and not needs_build(lib_path):
         return lib_path

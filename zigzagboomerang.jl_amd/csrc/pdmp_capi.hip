@@ -1385,6 +1385,26 @@ pdmp_status pdmp_ensemble_ess_end(pdmp_ensemble* e, double* sum_y, double* sum_y
     return PDMP_OK;
 }
 
+pdmp_status pdmp_ensemble_path_integrals(pdmp_ensemble* e, double T, int64_t nprobe, const int64_t* probes, double* out) {
+    pdmp_status st = ess_ready(e);
+    if (st != PDMP_OK) return st;
+    if (!probes || !out || nprobe <= 0) return fail(PDMP_ERR_INVALID, "bad argument");
+    const int64_t d = e->cfg.d, n = e->cfg.nchains;
+    for (int64_t k = 0; k < nprobe; ++k)
+        if (probes[k] < 0 || probes[k] >= d) return fail(PDMP_ERR_INVALID, "probe coordinate %lld out of range", (long long)probes[k]);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    DevBuf<int64_t> dp;
+    DevBuf<double> dout;
+    if ((st = dp.upload(std::vector<int64_t>(probes, probes + nprobe))) != PDMP_OK) return st;
+    if ((st = dout.alloc((size_t)(n * nprobe))) != PDMP_OK) return st;
+    int rc = pdmp::launch_zz_path_integrals(e->d_rec.p, e->track ? 128 : 64, d, n, dp.p, nprobe, T, dout.p, e->stream);
+    if (rc != 0) return fail(PDMP_ERR_HIP, "path_integrals launch failed: %s", hipGetErrorString((hipError_t)rc));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(out, dout.p, (size_t)(n * nprobe) * sizeof(double), hipMemcpyDeviceToHost));
+    return PDMP_OK;
+}
+
 pdmp_status pdmp_ensemble_set_sticky(pdmp_ensemble* e, const double* kappa, int reversible, int strong_upperbounds) {
     if (!e || !kappa) return fail(PDMP_ERR_INVALID, "null argument");
     if (e->cfg.sampler != PDMP_SAMPLER_STICKY_ZIGZAG) return fail(PDMP_ERR_INVALID, "ensemble is not a sticky ZigZag");
@@ -1400,7 +1420,8 @@ pdmp_status pdmp_ensemble_set_sticky(pdmp_ensemble* e, const double* kappa, int 
     return PDMP_OK;
 }
 
-pdmp_status pdmp_ensemble_run_partitioned(pdmp_ensemble* e, double T, int K, double delta, const uint8_t* g1_mask, void* stream) {
+pdmp_status pdmp_ensemble_run_partitioned(pdmp_ensemble* e, double T, int K, double delta, const uint8_t* g1_mask, int64_t mask_len,
+                                          void* stream) {
     if (!e) return fail(PDMP_ERR_INVALID, "null argument");
     if (!e->has_state) return fail(PDMP_ERR_INVALID, "set_state must be called before run");
     if (e->cfg.sampler != PDMP_SAMPLER_ZIGZAG_LOCAL || e->target_kind != 0 || e->flow_kind != 0 || e->lambda_ref > 0 || e->adaptscale ||
@@ -1417,6 +1438,9 @@ pdmp_status pdmp_ensemble_run_partitioned(pdmp_ensemble* e, double T, int K, dou
     const int64_t nnz = e->nnz;
     // G = the pattern of the flow tables, G1 = the structural entries of the bounding Γ inside it (all of it without a mask)
     std::vector<uint8_t> mask((size_t)nnz, 1);
+    if (g1_mask && mask_len != nnz)
+        return fail(PDMP_ERR_INVALID, "g1_mask has %lld entries, the flow's pattern %lld (one flag per stored entry of the Γ given to set_flow_zigzag)",
+                    (long long)mask_len, (long long)nnz);
     if (g1_mask) mask.assign(g1_mask, g1_mask + nnz);
     std::vector<uint8_t> inner((size_t)d, 1);
     for (int64_t i = 0; i < d; ++i) {
@@ -1684,6 +1708,10 @@ pdmp_status pdmp_ensemble_set_state_bps(pdmp_ensemble* e, double t0, const doubl
         return fail(PDMP_ERR_UNSUPPORTED,
                     "BouncyParticle(Γ ≠ I) carries the mass factor L = cholesky(Symmetric(Γ)).L (src/types.jl:43): pass it with "
                     "pdmp_ensemble_set_mass_cholesky (an identity factor selects the identity mass explicitly)");
+    if (e->bps_flow_kind == 1 && !e->bps_has_mass)
+        return fail(PDMP_ERR_UNSUPPORTED,
+                    "Boomerang(Γ, μ, λ) carries L = cholesky(Symmetric(Γ)).L (src/types.jl:66) and this library never sees the flow's Γ: "
+                    "pass the factor with pdmp_ensemble_set_mass_cholesky (an identity factor selects the identity mass explicitly)");
     HIP_TRY(hipSetDevice(e->cfg.device));
     const int64_t d = e->cfg.d, n = e->cfg.nchains, cap = e->cfg.trace_capacity;
     pdmp_status st;

@@ -319,6 +319,9 @@ int launch_zz_track_unpack(const TrRec* rec, const ZzTables& tb, const double* c
 int launch_zz_ess(const ZzRec* rec, int64_t rec_stride, double* jprev, double* jstart, int64_t d, int64_t nchains, int mode, double T_prev,
                   double T, double* acc, void* stream);
 size_t zz_local_lds_bytes(uint32_t nblk_pad, uint32_t blob_w_pad);
+// pdmp_consume.hip
+int launch_zz_path_integrals(const ZzRec* rec, int64_t rec_stride, int64_t d, int64_t nchains, const int64_t* probes, int64_t nprobe,
+                             double T, double* out, void* stream);
 int launch_math_probe(uint64_t seed, int64_t n, double* out, void* stream);
 
 }  // namespace pdmp

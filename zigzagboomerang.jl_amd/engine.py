@@ -123,11 +123,15 @@ class Ensemble:
                                                      float(B.ρ)))
         self._set_mass(B)
 
-    def _set_mass(self, B):
-        """B.L = cholesky(Symmetric(Γ)).L (src/types.jl:43,66); None = identity."""
+    def _set_mass(self, B, explicit_identity=False):
+        """B.L = cholesky(Symmetric(Γ)).L (src/types.jl:43,66); None = identity (spelled out for a Boomerang: the library never sees
+        that flow's Γ and refuses to assume L = I)."""
         L = getattr(B, "L", None)
         if L is None:
-            return
+            if not explicit_identity:
+                return
+            import scipy.sparse as sp
+            L = sp.identity(self.d, format="csc")
         if L.shape != (self.d, self.d):
             raise ValueError("mass factor L has the wrong shape")
         cp, rv, nz = _i64(L.indptr), _i64(L.indices), _f64(L.data)
@@ -148,7 +152,7 @@ class Ensemble:
         mf = _f64(B.μ)
         _lib.check(self._L.pdmp_ensemble_set_flow_boomerang(self._h, _ptr(cp), _ptr(rv), _ptr(nz), _ptr(mt), _ptr(mf),
                                                            float(B.λref), float(B.ρ)))
-        self._set_mass(B)
+        self._set_mass(B, explicit_identity=True)
 
     def set_state_bps(self, t0, x0, theta0, c, seeds):
         x0 = _f64(x0).reshape(self.nchains, self.d)
@@ -215,7 +219,8 @@ class Ensemble:
     def run_partitioned(self, T, K, delta, g1_mask=None, stream=None):
         """parallel_spdmp (src/parallel.jl): every chain over K wavefronts; see pdmp_ensemble_run_partitioned in include/pdmp_mi355.h."""
         m = None if g1_mask is None else np.ascontiguousarray(g1_mask, dtype=np.uint8)
-        _lib.check(self._L.pdmp_ensemble_run_partitioned(self._h, float(T), int(K), float(delta), None if m is None else _ptr(m), stream))
+        _lib.check(self._L.pdmp_ensemble_run_partitioned(self._h, float(T), int(K), float(delta), None if m is None else _ptr(m),
+                                                         0 if m is None else int(m.size), stream))
 
     def sync(self):
         _lib.check(self._L.pdmp_ensemble_sync(self._h))
@@ -266,6 +271,13 @@ class Ensemble:
         s2 = np.empty(self.d)
         _lib.check(self._L.pdmp_ensemble_batch_means(self._h, float(T_prev), float(T), _ptr(s1), _ptr(s2)))
         return s1, s2
+
+    def path_integrals(self, T, probes):
+        """J_i(T) = ∫ x_i dt of every chain at the probe coordinates: [nchains x len(probes)] (pdmp_ensemble_path_integrals)."""
+        probes = _i64(probes)
+        out = np.empty((self.nchains, probes.size))
+        _lib.check(self._L.pdmp_ensemble_path_integrals(self._h, float(T), int(probes.size), _ptr(probes), _ptr(out)))
+        return out
 
     def ess_begin(self, T0):
         _lib.check(self._L.pdmp_ensemble_ess_begin(self._h, float(T0)))

@@ -36,6 +36,42 @@ def batch_means_ess(sum_y, sum_y2, sum_m, sum_m2, nchains, nbatches, batch_len, 
                 ess_per_time=var_pi / np.maximum(sig_w, tiny), mean=sum_m / N)
 
 
+def multiscale_ess(J, batch_len, var_pi, mean=0.0):
+    """Batch-means estimates of σ²_asym at EVERY dyadic batch length the run allows, from per-chain path integrals.
+
+    J: [B+1, N, P] -- J_i(T0 + k·b) of N chains at P probe coordinates (Ensemble.path_integrals after every batch), b = batch_len,
+    var_pi: [P] stationary variances, mean: the KNOWN stationary mean (0 for the centred GMRF; chains started in stationarity).
+    For s = b·2^j (j = 0 .. log2 B) the batches are merged 2^j at a time and
+        σ²(s) = s · mean over chains and merged batches of (Y_s − mean)²          (no centring on estimated means: unbiased at any s)
+    which grows with s towards σ²_asym as s passes the integrated autocorrelation times present in x_i; at s = B·b it is the
+    between-chain estimate.  ESS_i(s) = N·B·b·Var_π,i/σ²_i(s) is therefore an UPPER bound that tightens with s: the figure to quote
+    is the one at the largest s, together with how much the last doubling still moved it (`last_doubling`: ≤ a few % = plateau).
+    The bias of batch means is −Γ/s to first order (Γ = 2Σ_k k·γ_k), so σ²_x = 2σ²(2s) − σ²(s) (Richardson) at the two largest
+    lengths removes it: `sigma2_extrapolated`, `ess_extrapolated` -- the conservative figure to headline, validated on the closed-form
+    1-d target with batches of ONE autocorrelation time (tests/test_gpu_ess.py).  Standard error of each σ² is ≈ sqrt(2/(N·B/2^j))
+    relative.  Returns dict(scales [S], sigma2 [S x P], ess [S x P], last_doubling [P], sigma2_extrapolated [P], ess_extrapolated [P])."""
+    J = np.asarray(J, dtype=np.float64)
+    Bp1, N, P = J.shape
+    B = Bp1 - 1
+    if B < 1:
+        raise ValueError("need at least one batch")
+    var_pi = np.asarray(var_pi, dtype=np.float64)
+    scales, sig = [], []
+    m = 1
+    while B % m == 0 and m <= B:
+        Y = (J[m::m] - J[:-m:m]) / (m * batch_len) - mean  # [B/m, N, P]
+        scales.append(m * batch_len)
+        sig.append(m * batch_len * np.mean(Y * Y, axis=(0, 1)))
+        m *= 2
+    sig = np.array(sig)
+    tiny = np.finfo(np.float64).tiny
+    ess = N * B * batch_len * var_pi[None, :] / np.maximum(sig, tiny)
+    last = sig[-1] / np.maximum(sig[-2], tiny) - 1.0 if len(sig) > 1 else np.full(P, np.nan)
+    sig_x = np.maximum(2.0 * sig[-1] - sig[-2], sig[-1]) if len(sig) > 1 else sig[-1]
+    return dict(scales=np.array(scales), sigma2=sig, ess=ess, last_doubling=last, sigma2_extrapolated=sig_x,
+                ess_extrapolated=N * B * batch_len * var_pi / np.maximum(sig_x, tiny))
+
+
 # 1-d ZigZag with unit speed on N(0, s²), canonical rate (θx/s²)⁺, no refreshment: solving the Poisson equation −Lφ = x of the
 # generator L g = θ g' + (θx/s²)⁺(g(x,−θ) − g(x,θ)) gives φ(x,+) − φ(x,−) = 2s², (φ(x,+) + φ(x,−))' = 2|x|, hence
 # σ²_asym = 2⟨φ, x⟩ = E|X|³ = 2·sqrt(2/π)·s³  (Bierkens & Duncan 2017, Example: Gaussian target): the known-answer test of the

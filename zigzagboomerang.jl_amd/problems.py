@@ -29,6 +29,31 @@ def gmrf_precision(n, eps=0.01):
     return G
 
 
+def gmrf_stationary_sample(n, nchains, rng, eps=0.01):
+    """x ~ N(0, Γ⁻¹) exactly for Γ = eps I + gridlaplacian(n, n): the free-boundary path Laplacian is diagonalised by the DCT-II
+    (eigenvalues 2 − 2cos(πk/n)), the grid Laplacian by its tensor square, so x = idctn(z / sqrt(eps + λ_k + λ_l)) with z ~ N(0, I)
+    and the orthonormal transform.  Returns [nchains x n²] in the column-major numbering of gridlaplacian.  Used to start ESS runs in
+    stationarity (a ZigZag's stationary velocities are uniform on {±1}ⁿ, independent of x)."""
+    from scipy.fft import idctn
+    lam1 = 2.0 - 2.0 * np.cos(np.pi * np.arange(n) / n)
+    lam = eps + lam1[:, None] + lam1[None, :]
+    z = rng.standard_normal((nchains, n, n))
+    x = idctn(z / np.sqrt(lam)[None], axes=(1, 2), norm="ortho")
+    return np.ascontiguousarray(x.transpose(0, 2, 1).reshape(nchains, n * n))  # [row, col] -> index row + n col
+
+
+def gmrf_marginal_variances(n, eps=0.01):
+    """diag(Γ⁻¹) of the same matrix in closed form: Σ_kl φ_kl(i)² / (eps + λ_k + λ_l), [n²] in the same numbering."""
+    lam1 = 2.0 - 2.0 * np.cos(np.pi * np.arange(n) / n)
+    j = np.arange(n)
+    V = np.cos(np.pi * np.outer(np.arange(n), j + 0.5) / n) * np.sqrt(2.0 / n)  # V[k, j], orthonormal DCT-II rows
+    V[0] /= np.sqrt(2.0)
+    W = V * V
+    inv = 1.0 / (eps + lam1[:, None] + lam1[None, :])
+    var = W.T @ inv @ W  # var[row, col]
+    return np.ascontiguousarray(var.T.reshape(n * n))
+
+
 def column_norms(G):
     """c[i] = norm(Γ[:, i], 2) -- scripts/gaussianrandomfield.jl:33."""
     G = sp.csc_matrix(G)
