@@ -215,6 +215,10 @@ def make_workload(pkg, args, rank, local_rank):
         ens = pkg.Ensemble(nch, d, adapt=True, factor=5.0, device=local_rank, trace_capacity=cap)
         ens.set_flow(pkg.ZigZag(P["Gdrop"], P["mu"], P["sigma"]))
         ens.set_target(pkg.LogisticTarget(P["A"], P["y"], P["ny"], P["mu"], P["gamma0"], ksub))
+        integrals = os.environ.get("PDMP_BENCH_C4_INTEGRALS", "0") != "0"
+        # (the engine's own ∫x_i dt -- no counterpart in the reference, nothing in this configuration reads it -- costs the state-in-LDS kernel
+        # 8 of 32 bytes per coordinate: 8 instead of 12 chains per CU.  PDMP_BENCH_C4_INTEGRALS=1 keeps it.)
+        ens.set_path_integrals(integrals)
         ens.set_state(0.0, np.tile(P["x0"], (nch, 1)), P["sigma"] * rng.choice([-1.0, 1.0], (nch, d)), P["c"],
                       np.arange(nch, dtype=np.uint64) + np.uint64(seed0))
         # neighbourhood sizes of the bounding graph and row lengths of the design, as plain averages over coordinates / observations
@@ -227,11 +231,12 @@ def make_workload(pkg, args, rank, local_rank):
         per_prop = kbar * 40 + 24 + ksub * rbar * 40
         per_rej = 48.0
         per_acc = g2bar * 40 + 8 + kbar * (8 + 16 + 8) + kbar * 16 + 16 + 32
-        W.update(d=d, cap=cap, ens=ens, kernel="zz_general_run_kernel", unit="reflection events/s",
+        W.update(d=d, cap=cap, ens=ens, kernel="zz_general_run_kernel" if os.environ.get("PDMP_KERNEL") == "seq" else "zz_logistic_lds_kernel",
+                 unit="reflection events/s",
                  metric="reflection events/sec, subsampled sparse logistic regression n=8840 p=442 (local ZigZag), ensemble of independent chains",
                  workload=f"C4: spdmp with grad-phi-moving (k={ksub} subsample, SelfMoving, control variate at the mode), Zdrop bounds, c=0.01, adapt, "
                           f"factor 5 (scripts/logistic.jl:167), n={P['n']}, p={d}, {nch} chains/GPU (one GPU's share of 65 536), step = advance "
-                          f"all chains by dT={dt}",
+                          f"all chains by dT={dt}; chain state resident in LDS for the slice, path integrals {'kept' if integrals else 'off'}",
                  model=f"per proposal k*40+24 + ksub*r*40 = {per_prop:.0f} B (k={kbar:.2f} neighbours, r={rbar:.2f} regressors per observation), "
                        f"+48 B per rejection, +{per_acc:.0f} B per accepted reflection (|G2|={g2bar:.1f}): SURVEY 8d3's model with this graph",
                  bytes=lambda w: per_prop * w["num"] + per_rej * (w["num"] - w["nacc"]) + per_acc * w["nacc"])

@@ -234,6 +234,13 @@ pdmp_status pdmp_ensemble_ess_end(pdmp_ensemble* ens, double* sum_y, double* sum
                                   int64_t* nbatches, double* T0, double* T1);
 
 /*
+ * The engine keeps ∫ x_i dt per chain and coordinate next to the state (what batch_means / ess_* / path_integrals read; the reference has no
+ * such thing).  enable = 0 drops it: those calls then return PDMP_ERR_INVALID, and the kernels that hold a chain's state on chip (small d:
+ * the subsampled logistic target, pdmp_logistic.hip) fit 10 chains per CU instead of 8.  Default: kept.  Call before set_state.
+ */
+pdmp_status pdmp_ensemble_set_path_integrals(pdmp_ensemble* ens, int enable);
+
+/*
  * J_i(T) = ∫_{t0}^{T} x_i(s) ds of EVERY chain at `nprobe` probe coordinates (0-based): out is [nchains x nprobe] row-major.  All chains
  * paused with PDMP_RUN_STOP_BEFORE at T.  Differences of successive calls are per-chain batch integrals, from which the host forms any
  * ESS estimator (batch means at several batch lengths, between-chain variances: zigzagboomerang.jl_amd/ess.py: multiscale_ess) while the

@@ -251,3 +251,62 @@ def test_local_bound_exact_ties_are_ordered_by_index_not_by_heap_shape(gpu_pkg):
     assert k > 0 and np.array_equal(ev[:k], oe[:k])  # identical up to the first tied pop
     # after the divergence the chain is as healthy as before: same event rate within a few per cent, finite state
     assert abs(len(ev) - len(oe)) < 0.1 * len(oe) and np.all(np.isfinite(x)) and np.all(np.abs(th) == 1.0)
+
+
+def test_c4_state_in_lds_equals_state_in_hbm(gpu_pkg):
+    """Config C4's kernel keeps a chain's state in LDS for a whole slice (pdmp_logistic.hip); PDMP_DEBUG_KERNEL_SEQ keeps the records in HBM
+    (pdmp_general.hip).  Same chains on both, in slices with trace refills (state leaves and re-enters LDS at every launch), with and
+    without the engine's path integrals: identical events, counters, final states, adapted bounds, ∫x dt; the integrals' entry points are
+    refused with a status when they were switched off."""
+    pkg = gpu_pkg
+    L = pkg._lib
+    P = pkg.problems.logistic_problem(m=20)
+    d, nch = P["p"], 6
+    rng = np.random.default_rng(4)
+    X0 = np.tile(P["x0"], (nch, 1))
+    TH0 = P["sigma"] * rng.choice([-1.0, 1.0], (nch, d))
+    seeds = np.arange(nch, dtype=np.uint64) + 900
+    runs = {}
+    for name, kernel, integrals in (("lds", "auto", True), ("lds_noI", "auto", False), ("hbm", "seq", True)):
+        with pkg.Ensemble(nch, d, adapt=True, factor=5.0, trace_capacity=400) as ens:
+            ens.debug_set_kernel(kernel)
+            ens.set_flow(pkg.ZigZag(P["Gdrop"], P["mu"], P["sigma"]))
+            ens.set_target(pkg.LogisticTarget(P["A"], P["y"], P["ny"], P["mu"], P["gamma0"], 10))
+            ens.set_path_integrals(integrals)
+            ens.set_state(0.0, X0, TH0, P["c"], seeds)
+            evs = [[] for _ in range(nch)]
+            for Tk in (3.0, 7.5, 12.0):
+                while True:
+                    ens.run(Tk, L.RUN_STOP_BEFORE)
+                    cnt = ens.counters()
+                    for k in range(nch):
+                        evs[k].append(ens.trace(k, counters=cnt))
+                    ens.trace_reset()
+                    if not np.any(cnt["status"] == L.CHAIN_TRACE_FULL):
+                        break
+            if integrals:
+                bm = ens.batch_means(0.0, 12.0)
+                pj = ens.path_integrals(12.0, np.arange(0, d, 7))
+            else:
+                bm = pj = None
+                with pytest.raises(L.PdmpError) as ei:
+                    ens.batch_means(0.0, 12.0)
+                assert ei.value.code == L.PDMP_ERR_INVALID and "switched off" in str(ei.value)
+            runs[name] = (cnt, [np.concatenate(e) for e in evs], ens.final_state(), bm, pj)
+    ref = runs["hbm"]
+    assert ref[0]["nacc"].sum() > 300 and np.all(ref[0]["status"] == L.CHAIN_OK)
+    for name in ("lds", "lds_noI"):
+        cnt, evs, fs, bm, pj = runs[name]
+        for f in ("num", "nacc", "nevents", "ndraw_main", "ndraw_global", "t_last"):
+            assert np.array_equal(cnt[f], ref[0][f]), (name, f)
+        for k in range(nch):
+            for f in ("i", "t", "x", "theta"):
+                assert np.array_equal(evs[k][f], ref[1][k][f]), (name, k, f)
+        for f in ("t", "x", "theta", "acc", "c"):
+            assert np.array_equal(fs[f], ref[2][f]), (name, f)
+        if bm is not None:
+            assert np.array_equal(bm[0], ref[3][0]) and np.array_equal(bm[1], ref[3][1]) and np.array_equal(pj, ref[4])
+    lg = dict(A=P["A"], At=P["At"], y=P["y"], ny=P["ny"], mu=P["mu"], gamma0=P["gamma0"], k=10)
+    r = O.spdmp_zigzag(P["Gdrop"], P["mu"], P["Gdrop"], X0[0], TH0[0], P["c"], 12.0, seed=900, adapt=True, factor=5.0, logistic=lg,
+                       sigma=P["sigma"], stop_before_T=True)
+    assert np.array_equal(runs["lds"][1][0]["t"], r["events"]["t"]) and np.array_equal(runs["lds"][1][0]["i"], r["events"]["i"])

@@ -27,7 +27,7 @@ T += ap.dt
 ens.run(T, L.RUN_STOP_BEFORE)
 kind, ph = ens.debug_phase_cycles()
 n = max(ph[10], 1.0)
-names = ["select", "move G1", "gradient", "coin + G2", "re-bound", "re-queue", "tail"]
+names = ["select", "move G1", "gradient", "coin + G2", "re-bound", "re-queue", "tail / (LDS kernel: own re-bound sums)"]
 print(cfg, "kind", kind, "proposals of chain 0:", int(ph[10]), "kernel ms", round(ens.last_run_ms(), 2))
 tot = sum(ph[:7])
 for q in range(7):

@@ -12,6 +12,6 @@ import csv,glob,collections
 acc=collections.defaultdict(list)
 for f in glob.glob("$OUT/**/*_counter_collection.csv",recursive=True):
     for r in csv.DictReader(open(f)):
-        if "zz_local" in r["Kernel_Name"]: acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if "zz_local" in r["Kernel_Name"] or "zz_general" in r["Kernel_Name"] or "zz_logistic" in r["Kernel_Name"]: acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k,v in sorted(acc.items()): print(f"{k:28s} n={len(v)} mean_last4={sum(v[-4:])/len(v[-4:]):.5g}")
 PY

@@ -136,6 +136,12 @@ struct pdmp_ensemble {
     DevBuf<uint32_t> d_member;
     DevBuf<int64_t> lg_Acp, lg_Arv, lg_Atcp, lg_Atrv;
     DevBuf<double> lg_Anz, lg_Atnz, lg_y, lg_ny, lg_u0, lg_ns0;
+    // packed tables of the LDS-resident logistic kernel (pdmp_logistic.hip); empty when the design does not qualify
+    bool keep_integrals = true;  // pdmp_ensemble_set_path_integrals
+    DevBuf<pdmp::LgCoord> lg_coord;
+    DevBuf<pdmp::LgObs> lg_obs;
+    DevBuf<uint32_t> lg_arow;
+    DevBuf<uint16_t> d_qrow16;
     double lg_gamma0 = 0.0;
     int64_t lg_k = 0;
     // sticky ZigZag
@@ -436,7 +442,7 @@ static pdmp_status set_flow_common(pdmp_ensemble* e, const int64_t* colptr, cons
     std::vector<uint32_t> qptr(nnz + 1, 0);
     std::vector<uint8_t> pos;
     pos.reserve((size_t)nnz * 5);
-    std::vector<uint16_t> pos16;
+    std::vector<uint16_t> pos16, qrow16;
     std::vector<double> qbval;     // Γ value of every (member j of G1[i], entry of column j) pair, same order as pos16
     std::vector<uint32_t> member;  // per entry p of column i: {j, k_j, qptr[p], 0} -- one 16-byte load per member
     pos16.reserve((size_t)nnz * 5);
@@ -481,6 +487,7 @@ static pdmp_status set_flow_common(pdmp_ensemble* e, const int64_t* colptr, cons
                                 (long long)i);
                 pos.push_back((uint8_t)where);
                 pos16.push_back((uint16_t)where);
+                qrow16.push_back((uint16_t)r);  // (used by the small-d kernel only: d < 65536 is checked there)
                 qbval.push_back(e->bval[q]);
             }
         }
@@ -489,6 +496,7 @@ static pdmp_status set_flow_common(pdmp_ensemble* e, const int64_t* colptr, cons
     if (pos.empty()) pos.push_back(0);
     if (pos16.empty()) pos16.push_back(0);
     if (qbval.empty()) qbval.push_back(0.0);
+    if (qrow16.empty()) qrow16.push_back(0);
     member.resize((size_t)nnz * 4 + 4, 0u);
     for (int64_t p = 0; p < nnz; ++p) {
         const uint32_t j = e->rowval[p];
@@ -527,6 +535,7 @@ static pdmp_status set_flow_common(pdmp_ensemble* e, const int64_t* colptr, cons
     if ((st = e->d_sigma.upload(e->sigma)) != PDMP_OK) return st;
     if ((st = e->d_pos16.upload(pos16)) != PDMP_OK) return st;
     if ((st = e->d_qbval.upload(qbval)) != PDMP_OK) return st;
+    if ((st = e->d_qrow16.upload(qrow16)) != PDMP_OK) return st;
     if ((st = e->d_member.upload(member)) != PDMP_OK) return st;
     if ((st = e->d_selfpos16.upload(selfpos16)) != PDMP_OK) return st;
     e->target_kind = 0;
@@ -750,6 +759,48 @@ extern "C" pdmp_status pdmp_ensemble_set_target_logistic(pdmp_ensemble* e, int64
     e->lg_k = k_sub;
     e->lg_nemax = 0;
     for (int64_t r = 0; r < n; ++r) e->lg_nemax = std::max<int64_t>(e->lg_nemax, At_colptr[r + 1] - At_colptr[r]);
+    // packed tables of the LDS-resident kernel (pdmp_logistic.hip): observations with at most 6 regressors, d and nnz(A) within 16 / 32 bits
+    e->lg_coord.release();
+    e->lg_obs.release();
+    e->lg_arow.release();
+    if (e->lg_nemax <= 6 && p < 65536 && nnzA < ((int64_t)1 << 32) && n < ((int64_t)1 << 32)) {
+        std::vector<pdmp::LgCoord> hc((size_t)p);
+        for (int64_t j = 0; j < p; ++j) {
+            pdmp::LgCoord& c = hc[(size_t)j];
+            c.cp0 = e->colptr[(size_t)j];
+            c.k = e->colptr[(size_t)j + 1] - c.cp0;
+            c.sp0 = e->h_sptr[(size_t)j];
+            c.m = e->h_sptr[(size_t)j + 1] - c.sp0;
+            c.self = 0;
+            for (uint32_t q = 0; q < c.k; ++q)
+                if (e->rowval[c.cp0 + q] == (uint32_t)j) c.self = q;
+            c.l = (uint32_t)(A_colptr[j + 1] - A_colptr[j]);
+            c.r0 = (uint32_t)A_colptr[j];
+            c.pad = 0;
+        }
+        std::vector<pdmp::LgObs> ho((size_t)n);
+        memset(ho.data(), 0, ho.size() * sizeof(pdmp::LgObs));
+        for (int64_t r = 0; r < n; ++r) {
+            pdmp::LgObs& o = ho[(size_t)r];
+            o.y = y[r];
+            o.ny = ny[r];
+            o.sn0 = sn0[(size_t)r];
+            o.ns0 = ns0[(size_t)r];
+            o.ne = (uint16_t)(At_colptr[r + 1] - At_colptr[r]);
+            for (int64_t q = At_colptr[r]; q < At_colptr[r + 1]; ++q) {
+                o.val[q - At_colptr[r]] = At_nzval[q];
+                o.idx[q - At_colptr[r]] = (uint16_t)At_rowval[q];
+            }
+        }
+        std::vector<uint32_t> ar((size_t)nnzA);
+        for (int64_t q = 0; q < nnzA; ++q) {
+            if (A_rowval[q] < 0 || A_rowval[q] >= n) return fail(PDMP_ERR_INVALID, "A row index out of range");
+            ar[(size_t)q] = (uint32_t)A_rowval[q];
+        }
+        if ((st = e->lg_coord.upload(hc)) != PDMP_OK) return st;
+        if ((st = e->lg_obs.upload(ho)) != PDMP_OK) return st;
+        if ((st = e->lg_arow.upload(ar)) != PDMP_OK) return st;
+    }
     e->target_kind = 1;
     e->has_target = true;
     e->has_state = false;
@@ -1120,7 +1171,15 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         Q.mu = e->d_mu.p;
         Q.diag = e->d_diag.p;
         Q.rho = e->rho;
-        int rcg = pdmp::launch_zz_general_run(P, Q, e->cfg.nchains, s);
+        pdmp::ZzLogisticTables LT{};
+        LT.coord = e->lg_coord.p;
+        LT.obs = e->lg_obs.p;
+        LT.a_row = e->lg_arow.p;
+        LT.a_val = e->lg_Anz.p;
+        LT.qrow16 = e->d_qrow16.p;
+        // small d: the chain's state lives in LDS for the whole slice (PDMP_DEBUG_KERNEL_SEQ keeps the records in HBM: A/B runs, parity tests)
+        const bool lds_resident = e->dbg_kernel != PDMP_DEBUG_KERNEL_SEQ && pdmp::zz_logistic_lds_supported(P, Q, LT);
+        int rcg = lds_resident ? pdmp::launch_zz_logistic_lds(P, Q, LT, e->keep_integrals, e->cfg.nchains, s) : pdmp::launch_zz_general_run(P, Q, e->cfg.nchains, s);
         if (rcg != 0) return fail(PDMP_ERR_HIP, "zz_general_run launch failed: %s", hipGetErrorString((hipError_t)rcg));
         HIP_TRY(hipEventRecord(e->ev1, s));
         e->timed = true;
@@ -1325,6 +1384,7 @@ static pdmp_status ess_ready(pdmp_ensemble* e) {
     if (!e) return fail(PDMP_ERR_INVALID, "null argument");
     if (e->cfg.sampler == PDMP_SAMPLER_BPS) return fail(PDMP_ERR_INVALID, "path integrals are kept by the factorised samplers only");
     if (!e->has_state) return fail(PDMP_ERR_INVALID, "no state");
+    if (!e->keep_integrals) return fail(PDMP_ERR_INVALID, "the path integrals were switched off (pdmp_ensemble_set_path_integrals)");
     if (e->flow_kind != 0)
         return fail(PDMP_ERR_UNSUPPORTED, "path integrals assume the linear flow of the ZigZag (FactBoomerang rotates between events)");
     return PDMP_OK;
@@ -1382,6 +1442,14 @@ pdmp_status pdmp_ensemble_ess_end(pdmp_ensemble* e, double* sum_y, double* sum_y
     if (nbatches) *nbatches = e->ess_batches;
     if (T0) *T0 = e->ess_T0;
     if (T1) *T1 = e->ess_Tlast;
+    return PDMP_OK;
+}
+
+pdmp_status pdmp_ensemble_set_path_integrals(pdmp_ensemble* e, int enable) {
+    if (!e) return fail(PDMP_ERR_INVALID, "null argument");
+    NEED_FACTORISED(e);
+    e->keep_integrals = enable != 0;
+    e->has_state = false;
     return PDMP_OK;
 }
 

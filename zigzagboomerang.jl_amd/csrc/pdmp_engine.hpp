@@ -253,6 +253,34 @@ struct ZzGeneralParams {
     int32_t adaptscale;
 };
 int launch_zz_general_run(const ZzRunParams& p, const ZzGeneralParams& q, int64_t nchains, void* stream);
+
+// Small-d subsampled logistic ZigZag with the chain state resident in LDS (pdmp_logistic.hip): packed read-only tables
+struct LgCoord {  // everything a proposal needs that depends on the coordinate alone
+    uint32_t cp0, k;    // column of the bounding Γ: G1[i] = rowval[cp0 .. cp0 + k)
+    uint32_t sp0, m;    // S[i] = sidx[sp0 .. sp0 + m) = G1[i] followed by G2[i]
+    uint32_t self, l;   // position of i inside G1[i]; observations with a non-zero entry in column i of the design A
+    uint32_t r0, pad;   // they are a_row / a_val [r0 .. r0 + l)
+};
+static_assert(sizeof(LgCoord) == 32, "one sector");
+struct alignas(128) LgObs {  // one observation (a column of A'): scripts/logistic.jl:86-93
+    double y, ny, sn0, ns0;  // successes, failures, sigmoidn(A'[:,row]·μ), nsigmoid(A'[:,row]·μ)
+    double val[6];           // A'[idx[e], row]
+    uint16_t idx[6];         // its regressors, ascending
+    uint16_t ne, pad16;
+    uint32_t pad[8];
+};
+static_assert(sizeof(LgObs) == 128, "one line");
+struct ZzLogisticTables {
+    const LgCoord* __restrict__ coord;     // [d]
+    const LgObs* __restrict__ obs;         // [n]
+    const uint32_t* __restrict__ a_row;    // [nnz(A)] observation of every entry of A, column by column
+    const double* __restrict__ a_val;      // [nnz(A)]
+    const uint16_t* __restrict__ qrow16;   // like ZzGeneralParams::qbval: the ROW (coordinate) of the same (member, entry) pair
+};
+size_t zz_logistic_lds_bytes(int64_t d, int64_t dk, bool with_I);
+bool zz_logistic_lds_supported(const ZzRunParams& p, const ZzGeneralParams& q, const ZzLogisticTables& lt);
+int launch_zz_logistic_lds(const ZzRunParams& p, const ZzGeneralParams& q, const ZzLogisticTables& lt, bool with_I, int64_t nchains,
+                           void* stream);
 size_t zz_general_lds_bytes(uint32_t nblk_pad, uint32_t mmax_pad, bool boom);
 
 // Bouncy particle sampler (pdmp_bps.hip): per chain x[d], θ[d] (SoA), 8 scalars {t, a, b, t′, τref, c, -, -}

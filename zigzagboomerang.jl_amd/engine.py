@@ -272,6 +272,10 @@ class Ensemble:
         _lib.check(self._L.pdmp_ensemble_batch_means(self._h, float(T_prev), float(T), _ptr(s1), _ptr(s2)))
         return s1, s2
 
+    def set_path_integrals(self, enable=True):
+        """Keep ∫x_i dt next to the state (default) or not (pdmp_ensemble_set_path_integrals); before set_state."""
+        _lib.check(self._L.pdmp_ensemble_set_path_integrals(self._h, int(bool(enable))))
+
     def path_integrals(self, T, probes):
         """J_i(T) = ∫ x_i dt of every chain at the probe coordinates: [nchains x len(probes)] (pdmp_ensemble_path_integrals)."""
         probes = _i64(probes)
