@@ -126,6 +126,16 @@ pdmp_status pdmp_ensemble_set_flow_factboomerang(pdmp_ensemble* ens, const int64
                                                  double lambda_ref, double rho);
 
 /*
+ * The neighbourhood argument of spdmp(∇ϕ, t0, x0, θ0, T, c, G, F, ...) / sspdmp(∇ϕ, t0, x0, θ0, T, c, G, F, κ, ...) (src/sfact.jl:162,171-179;
+ * src/ss_fact.jl:159,167-172): G[i] = g_rowval[g_colptr[i] .. g_colptr[i+1]) (ascending) is what a proposal of i moves before the gradient is
+ * taken (:82) and what the gradient may read (:116); G1[i] = the pattern of column i of the flow's Γ stays what is re-bounded (:131-135), and
+ * G2[i] = ∪_{j ∈ G1[i]} G1[j] \ G[i] what an accepted event moves on top (:178).  G[i] ⊇ G1[i] is required (the reference's @assert, :177):
+ * PDMP_ERR_INVALID otherwise.  Without this call G = Matched() = G1.  Call after set_flow_* and BEFORE set_target_* (the target's pattern
+ * may then use all of G); such ensembles run on the general-neighbourhood kernel.  Not for PDMP_SAMPLER_ZIGZAG_ALL (G = All()).
+ */
+pdmp_status pdmp_ensemble_set_neighbourhood(pdmp_ensemble* ens, const int64_t* g_colptr, const int64_t* g_rowval);
+
+/*
  * Target ∇ϕ(x, i) = Γt[:,i]·x  [ − Γt[:,i]·μt ]  (idot, src/common.jl:16-24; closure of
  * scripts/gaussianrandomfield.jl:25, test/maintest.jl:9).  The pattern of Γt must be contained in the
  * flow's Γ pattern (the reference reads only x[j], j in G[i]: src/sfact.jl:116).  mu may be NULL.

@@ -97,6 +97,9 @@ struct Options {  // the reference's keyword arguments
     int64_t trace_capacity = 0;  // 0: sized from d and T, refilled on demand
     // sspdmp only
     bool reversible = false, strong_upperbounds = false;
+    // the optional argument G of spdmp(∇ϕ, t0, x0, θ0, T, c, G, F, ...) / sspdmp(..., c, G, F, κ, ...) (src/sfact.jl:162, src/ss_fact.jl:159):
+    // column patterns = the G[i] (values unused); empty = Matched().  G ⊇ G1 or the call throws (the reference's @assert, src/sfact.jl:177)
+    SparseCSC G;
 };
 
 using Event = pdmp_event;  // (t, i, x, θ), src/trace.jl:38; i 0-based
@@ -205,6 +208,7 @@ Result<FactTrace> factorised(int sampler, const Target& target, double t0, const
     const int64_t cap = o.trace_capacity > 0 ? o.trace_capacity : default_capacity(d, t0, T);
     Ensemble e(1, d, sampler, o, cap);
     set_flow(e, F);
+    if (o.G.n > 0) check(pdmp_ensemble_set_neighbourhood(e.get(), o.G.colptr.data(), o.G.rowval.data()));
     set_target(e, target);
     if (kappa) check(pdmp_ensemble_set_sticky(e.get(), kappa->data(), o.reversible ? 1 : 0, o.strong_upperbounds ? 1 : 0));
     if (o.adaptscale) check(pdmp_ensemble_set_adaptscale(e.get(), 1));

@@ -649,6 +649,20 @@ static int spdmp_zigzag_tracked(int64_t d, const orc_zz_params* p, double t0, do
     return status;
 }
 
+static nbr_graph graph_g2x(const nbr_graph* g1, const nbr_graph* gsub, int64_t d);
+
+/* @assert all(a.second ⊇ b.second for (a,b) in zip(G, G1)), src/sfact.jl:177 (both ascending) */
+static int graph_contains(const nbr_graph* g, const nbr_graph* g1, int64_t d) {
+    for (int64_t i = 0; i < d; ++i) {
+        int64_t q = g->ptr[i];
+        for (int64_t p = g1->ptr[i]; p < g1->ptr[i + 1]; ++p) {
+            while (q < g->ptr[i + 1] && g->idx[q] < g1->idx[p]) ++q;
+            if (q == g->ptr[i + 1] || g->idx[q] != g1->idx[p]) return 0;
+        }
+    }
+    return 1;
+}
+
 int orc_spdmp_zigzag(int64_t d, const orc_zz_params* p, double t0, double T, double* x, double* th,
                      double* c, double* t, int64_t* acc, orc_trace* tr, orc_zz_result* res) {
     if (p->tracked) return spdmp_zigzag_tracked(d, p, t0, T, x, th, c, t, acc, tr, res);
@@ -656,8 +670,15 @@ int orc_spdmp_zigzag(int64_t d, const orc_zz_params* p, double t0, double T, dou
     cx.d = d;
     cx.p = p;
     cx.g1 = graph_g1(p->bound_gamma);
+    /* the optional argument G (src/sfact.jl:162,171-179): what a proposal moves (:82); Matched() = G1 */
+    nbr_graph gG = p->nbr_G ? graph_g1(p->nbr_G) : cx.g1;
+    if (p->nbr_G && !graph_contains(&gG, &cx.g1, d)) {
+        graph_free(&gG);
+        graph_free(&cx.g1);
+        return ORC_BAD_INPUT;
+    }
     if (!p->move_all) {
-        cx.g2 = graph_g2(&cx.g1, d); /* src/sfact.jl:178 */
+        cx.g2 = p->nbr_G ? graph_g2x(&cx.g1, &gG, d) : graph_g2(&cx.g1, d); /* src/sfact.jl:178 */
     } else {
         cx.g2.ptr = cx.g2.idx = NULL; /* G2 = nothing, src/sfact.jl:175 */
     }
@@ -771,7 +792,7 @@ int orc_spdmp_zigzag(int64_t d, const orc_zz_params* p, double t0, double T, dou
             if (p->move_all) {
                 flow_move_all(kind, fmu, d, t, x, th, tp); /* :19 */
             } else {
-                flow_move_nbrs(kind, fmu, &cx.g1, i, t, x, th, tp); /* :82 (G = G1, Matched) */
+                flow_move_nbrs(kind, fmu, &gG, i, t, x, th, tp); /* :82 (G; Matched: G1) */
             }
             if (refresh) {
                 i = (int64_t)pdmp_randint(seed, PDMP_STREAM_GLOBAL, ng++, (uint32_t)d); /* :84 */
@@ -878,6 +899,7 @@ int orc_spdmp_zigzag(int64_t d, const orc_zz_params* p, double t0, double T, dou
 #undef FLOW_AB
     free(cx.gmu_bound);
     free(cx.gmu_target);
+    if (p->nbr_G) graph_free(&gG);
     graph_free(&cx.g1);
     if (cx.g2.ptr) graph_free(&cx.g2);
     return status;
@@ -1259,7 +1281,14 @@ static inline void queue_time(orc_pq* Q, const double* t, const double* x, const
 int orc_sspdmp_zigzag(int64_t d, const orc_sticky_params* p, double t0, double T, double* x, double* th,
                       double* c, double* t, orc_trace* tr, orc_zz_result* res) {
     nbr_graph g1 = graph_g1(p->bound_gamma);
-    nbr_graph g2 = graph_g2(&g1, d); /* :172 */
+    /* the optional argument G (src/ss_fact.jl:159,167-172): what ssmove_forward!(G, i, ...) moves; nothing = G1 */
+    nbr_graph gG = p->nbr_G ? graph_g1(p->nbr_G) : g1;
+    if (p->nbr_G && !graph_contains(&gG, &g1, d)) {
+        graph_free(&gG);
+        graph_free(&g1);
+        return ORC_BAD_INPUT;
+    }
+    nbr_graph g2 = p->nbr_G ? graph_g2x(&g1, &gG, d) : graph_g2(&g1, d); /* :172 */
     double* gmu = (double*)malloc((size_t)d * sizeof(double));
     double* gmt = NULL;
     for (int64_t i = 0; i < d; ++i) gmu[i] = orc_idot(p->bound_gamma, i, p->bound_mu);
@@ -1314,7 +1343,7 @@ int orc_sspdmp_zigzag(int64_t d, const orc_sticky_params* p, double t0, double T
                 f[i] = 0;
                 orc_pq_set(Q, i, t[i] - pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)) / p->kappa[i]); /* :96 */
                 if (!p->strong_upperbounds) { /* :97-107 */
-                    ssmove_nbrs(&g1, i, t, x, th, tp);
+                    ssmove_nbrs(&gG, i, t, x, th, tp);
                     ssmove_nbrs(&g2, i, t, x, th, tp);
                     for (int64_t q = g1.ptr[i]; q < g1.ptr[i + 1]; ++q) {
                         int64_t j = g1.idx[q];
@@ -1334,7 +1363,7 @@ int orc_sspdmp_zigzag(int64_t d, const orc_sticky_params* p, double t0, double T
                     th[i] *= (u < 0.5) ? -1.0 : 1.0;
                 }
                 t_old[i] = t[i];
-                ssmove_nbrs(&g1, i, t, x, th, tp); /* :115 */
+                ssmove_nbrs(&gG, i, t, x, th, tp); /* :115 */
                 ssmove_nbrs(&g2, i, t, x, th, tp); /* :116 */
                 for (int64_t q = g1.ptr[i]; q < g1.ptr[i + 1]; ++q) { /* :117-123 */
                     int64_t j = g1.idx[q];
@@ -1345,7 +1374,7 @@ int orc_sspdmp_zigzag(int64_t d, const orc_sticky_params* p, double t0, double T
                     }
                 }
             } else { /* :124 reflection proposal */
-                ssmove_nbrs(&g1, i, t, x, th, tp); /* :125 */
+                ssmove_nbrs(&gG, i, t, x, th, tp); /* :125 */
                 double gi;
                 if (p->logistic) { /* ∇ϕ_(∇ϕ, t, x, θ, i, t′, F, S::SelfMoving, args...), src/sfact.jl:68 */
                     gi = logistic_grad_moving(p->logistic, i, t, x, th, tp, seed, &ng);
@@ -1410,6 +1439,7 @@ finish:
     free(f);
     free(gmu);
     free(gmt);
+    if (p->nbr_G) graph_free(&gG);
     graph_free(&g1);
     graph_free(&g2);
     return status;

@@ -125,6 +125,9 @@ typedef struct {
      * the device's tracked kernels; agrees with the moving evaluation (tracked = 0, the reference's) in every index and to ~1e-13 in the
      * floats until a rounding difference flips a thinning test (measured: ~6e-10 per proposal on config C3). */
     int tracked;
+    /* the optional argument G of spdmp / sspdmp (src/sfact.jl:162,171-179; src/ss_fact.jl:159,167-172): column patterns = the G[i] (values
+     * unused); NULL = Matched().  G[i] ⊇ G1[i] or the call returns ORC_BAD_INPUT (the reference's @assert). */
+    const orc_csc* nbr_G;
 } orc_zz_params;
 
 typedef struct {
@@ -213,6 +216,7 @@ typedef struct {
      * *logistic are read; target_gamma / target_mu are then ignored.  idot_moving! moves what it reads with smove_forward!, frozen
      * coordinates included (their clock advances, x + 0·dt). */
     const orc_zz_params* logistic;
+    const orc_csc* nbr_G; /* the optional argument G (src/ss_fact.jl:159,167-172), as in orc_zz_params; NULL = G1 */
 } orc_sticky_params;
 int orc_sspdmp_zigzag(int64_t d, const orc_sticky_params* p, double t0, double T, double* x, double* theta,
                       double* c, double* t_out, orc_trace* tr, orc_zz_result* res);

@@ -48,7 +48,7 @@ class _ZZParams(C.Structure):
                 ("target_kind", C.c_int), ("lg_A", C.POINTER(_Csc)), ("lg_At", C.POINTER(_Csc)), ("lg_y", C.c_void_p),
                 ("lg_ny", C.c_void_p), ("lg_mu", C.c_void_p), ("lg_gamma0", C.c_double), ("lg_k", C.c_int64),
                 ("flow_kind", C.c_int), ("adaptscale", C.c_int), ("sigma_out", C.c_void_p), ("local_bound", C.c_int),
-                ("tracked", C.c_int)]
+                ("tracked", C.c_int), ("nbr_G", C.POINTER(_Csc))]
 
 
 class _ZZResult(C.Structure):
@@ -75,7 +75,7 @@ class _StickyParams(C.Structure):
                 ("target_gamma", C.POINTER(_Csc)), ("target_mu", C.c_void_p), ("kappa", C.c_void_p),
                 ("adapt", C.c_int), ("factor", C.c_double), ("reversible", C.c_int),
                 ("strong_upperbounds", C.c_int), ("seed", C.c_uint64), ("max_events", C.c_int64),
-                ("logistic", C.POINTER(_ZZParams))]
+                ("logistic", C.POINTER(_ZZParams)), ("nbr_G", C.POINTER(_Csc))]
 
 
 _lib = None
@@ -194,7 +194,7 @@ def idot(A, j, x):
 def spdmp_zigzag(bound_gamma, bound_mu, target_gamma, x0, theta0, c, T, *, t0=0.0, target_mu=None,
                  sigma=None, lambda_ref=0.0, rho=0.0, move_all=False, adapt=False, factor=1.8, seed=1,
                  max_events=0, stop_before_T=False, want_trace=True, logistic=None, factboomerang=False,
-                 adaptscale=False, local_bound=False, tracked=False):
+                 adaptscale=False, local_bound=False, tracked=False, G=None):
     """Local ZigZag (reference spdmp / pdmp for ZigZag).  Returns dict(events, t, x, theta, acc, num, c, ...).
     tracked=True: the tracked-gradient evaluation of the same process (the bitwise checker of the device's tracked kernels)."""
     L = lib()
@@ -212,6 +212,9 @@ def spdmp_zigzag(bound_gamma, bound_mu, target_gamma, x0, theta0, c, T, *, t0=0.
     p.adaptscale = int(adaptscale)
     p.local_bound = int(local_bound)
     p.tracked = int(tracked)
+    if G is not None:  # the optional neighbourhood argument: a sparse matrix whose column patterns are the G[i]
+        gh = G if isinstance(G, CscHolder) else CscHolder(G)
+        p.nbr_G = C.pointer(gh.c)
     p.sigma_out = sg_out.ctypes.data
     if logistic is not None:  # dict(A, At, y, ny, mu, gamma0, k): target_kind 1
         lA = logistic["A"] if isinstance(logistic["A"], CscHolder) else CscHolder(logistic["A"])
@@ -328,7 +331,7 @@ def pdmp_bps(gamma, mu, x0, theta0, c, T, *, t0=0.0, lambda_ref=1.0, rho=0.0, ad
 
 
 def sspdmp_zigzag(bound_gamma, bound_mu, target_gamma, x0, theta0, c, kappa, T, *, t0=0.0, target_mu=None,
-                  adapt=False, factor=1.5, reversible=False, strong_upperbounds=False, seed=1, max_events=0, logistic=None):
+                  adapt=False, factor=1.5, reversible=False, strong_upperbounds=False, seed=1, max_events=0, logistic=None, G=None):
     L = lib()
     gb = bound_gamma if isinstance(bound_gamma, CscHolder) else CscHolder(bound_gamma)
     gt = target_gamma if isinstance(target_gamma, CscHolder) else CscHolder(target_gamma)
@@ -349,6 +352,9 @@ def sspdmp_zigzag(bound_gamma, bound_mu, target_gamma, x0, theta0, c, kappa, T, 
         zp.lg_y, zp.lg_ny, zp.lg_mu = ly.ctypes.data, lny.ctypes.data, lmu.ctypes.data
         zp.lg_gamma0, zp.lg_k = float(logistic["gamma0"]), int(logistic["k"])
         p.logistic = C.pointer(zp)
+    if G is not None:
+        gh = G if isinstance(G, CscHolder) else CscHolder(G)
+        p.nbr_G = C.pointer(gh.c)
     x = _f64(x0).copy()
     th = _f64(theta0).copy()
     cc = _f64(c).copy()

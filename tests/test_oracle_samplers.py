@@ -429,3 +429,22 @@ def test_local_bound_statistics_d8(pkg):
     ts, xs = pkg.trace.discretize(tr, 0.5)
     assert np.mean(np.abs(xs.mean(0))) < 2 / np.sqrt(T)
     assert np.mean(np.abs(np.cov(xs.T) - np.linalg.inv(G.toarray()))) < 2.5 / np.sqrt(T)
+
+
+def test_neighbourhood_argument_of_the_oracle(pkg):
+    """G of spdmp(∇ϕ, t0, x0, θ0, T, c, G, F, ...) (src/sfact.jl:162,171-179): G = G1 given explicitly is Matched(); G ⊉ G1 trips the
+    reference's @assert (:177); a larger G changes only which clocks a proposal moves -- the law of the chain is the target's either way."""
+    import scipy.sparse as sp
+    G = pkg.problems.gmrf_precision(6, 0.5)
+    d = 36
+    rng = np.random.default_rng(2)
+    x0, th0 = rng.standard_normal(d), rng.choice([-1.0, 1.0], d)
+    c = 1.5 * pkg.problems.column_norms(G)
+    a = O.spdmp_zigzag(G, None, G, x0, th0, c, 30.0, seed=4)
+    b = O.spdmp_zigzag(G, None, G, x0, th0, c, 30.0, seed=4, G=G)
+    assert np.array_equal(a["events"], b["events"]) and np.array_equal(a["t"], b["t"])
+    assert O.spdmp_zigzag(G, None, G, x0, th0, c, 1.0, seed=4, G=sp.identity(d, format="csc"))["status"] == 4
+    full = sp.csc_matrix(np.ones((d, d)))
+    m = O.spdmp_zigzag(G, None, G, x0, th0, c, 30.0, seed=4, G=full)
+    e = O.spdmp_zigzag(G, None, G, x0, th0, c, 30.0, seed=4, move_all=True)  # G = All() moves the same coordinates ...
+    assert np.array_equal(m["events"], e["events"]) and np.array_equal(m["x"], e["x"])  # ... so the two coincide (G2 is empty either way)

@@ -38,7 +38,7 @@ EXPORTED_SYMBOLS = [
     "pdmp_ensemble_bps_final_state", "pdmp_ensemble_set_sticky", "pdmp_ensemble_set_adaptscale", "pdmp_ensemble_final_sigma", "pdmp_ensemble_set_flow_boomerang", "pdmp_ensemble_set_local_bound", "pdmp_ensemble_set_target_logistic", "pdmp_ensemble_set_flow_factboomerang",
     "pdmp_ensemble_set_mass_cholesky", "pdmp_ensemble_set_bps_options",
     "pdmp_ensemble_ess_begin", "pdmp_ensemble_ess_batch", "pdmp_ensemble_ess_end", "pdmp_ensemble_set_gradient_tracking",
-    "pdmp_ensemble_path_integrals", "pdmp_ensemble_set_path_integrals",
+    "pdmp_ensemble_path_integrals", "pdmp_ensemble_set_path_integrals", "pdmp_ensemble_set_neighbourhood",
 ]
 # include/pdmp_debug.h: diagnostics, not part of the drop-in boundary
 DEBUG_SYMBOLS = ["pdmp_debug_set_kernel", "pdmp_debug_set_spec_g2", "pdmp_debug_set_phase_profile", "pdmp_debug_phase_profile",
@@ -103,6 +103,7 @@ def load():
     L.pdmp_ensemble_batch_means.argtypes = [vp, f64, f64, vp, vp]
     L.pdmp_ensemble_path_integrals.argtypes = [vp, f64, i64, vp, vp]
     L.pdmp_ensemble_set_path_integrals.argtypes = [vp, C.c_int]
+    L.pdmp_ensemble_set_neighbourhood.argtypes = [vp, vp, vp]
     L.pdmp_ensemble_trace_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
     L.pdmp_ensemble_counters_dev.argtypes = [vp, C.POINTER(vp)]
     L.pdmp_debug_math_probe.argtypes = [C.c_int, C.c_uint64, i64, vp]

@@ -129,6 +129,7 @@ struct pdmp_ensemble {
     int flow_kind = 0;
     DevBuf<double> d_mu, d_diag;
     bool needs_general = false;
+    bool has_g1mask = false;  // pdmp_ensemble_set_neighbourhood: the tables' pattern is G ⊋ G1
     uint32_t mmax_all = 0;
     int target_kind = 0;
     DevBuf<uint16_t> d_pos16, d_selfpos16;
@@ -378,8 +379,11 @@ void pdmp_ensemble_destroy(pdmp_ensemble* e) {
     delete e;
 }
 
+// g1mask (optional, one flag per stored entry): the structural entries of the bounding Γ, i.e. G1 (src/sfact.jl:170), when the pattern handed
+// over is the larger neighbourhood G ⊇ G1 of spdmp(∇ϕ, t0, x0, θ0, T, c, G, F, ...) (:162,171-179) with explicit zeros outside G1
 static pdmp_status set_flow_common(pdmp_ensemble* e, const int64_t* colptr, const int64_t* rowval, const double* nzval,
-                                   const double* mu, const double* sigma, double lambda_ref, double rho, int kind) {
+                                   const double* mu, const double* sigma, double lambda_ref, double rho, int kind,
+                                   const uint8_t* g1mask = nullptr) {
     if (!e || !colptr || !rowval || !nzval) return fail(PDMP_ERR_INVALID, "null argument");
     NEED_FACTORISED(e);
     HIP_TRY(hipSetDevice(e->cfg.device));
@@ -409,7 +413,7 @@ static pdmp_status set_flow_common(pdmp_ensemble* e, const int64_t* colptr, cons
             if (r < 0 || r >= d) return fail(PDMP_ERR_INVALID, "row index out of range in column %lld", (long long)i);
             if (p > colptr[i] && rowval[p - 1] >= r)
                 return fail(PDMP_ERR_INVALID, "rows of column %lld are not strictly ascending", (long long)i);
-            if (r == i) {
+            if (r == i && (!g1mask || g1mask[p])) {
                 has_diag = true;
                 selfpos[i] = (uint8_t)(p - colptr[i]);
                 selfpos16[i] = (uint16_t)(p - colptr[i]);
@@ -451,8 +455,10 @@ static pdmp_status set_flow_common(pdmp_ensemble* e, const int64_t* colptr, cons
         const uint32_t c0 = e->colptr[i], c1 = e->colptr[i + 1];
         tmp.clear();
         for (uint32_t p = c0; p < c1; ++p) {
+            if (g1mask && !g1mask[p]) continue;  // G2[i] = ∪_{j ∈ G1[i]} G1[j] \ G[i], src/sfact.jl:178
             const uint32_t j = e->rowval[p];
-            for (uint32_t q = e->colptr[j]; q < e->colptr[j + 1]; ++q) tmp.push_back(e->rowval[q]);
+            for (uint32_t q = e->colptr[j]; q < e->colptr[j + 1]; ++q)
+                if (!g1mask || g1mask[q]) tmp.push_back(e->rowval[q]);
         }
         std::sort(tmp.begin(), tmp.end());
         tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
@@ -472,7 +478,9 @@ static pdmp_status set_flow_common(pdmp_ensemble* e, const int64_t* colptr, cons
         for (uint32_t p = c0; p < c1; ++p) {
             const uint32_t j = e->rowval[p];
             qptr[p] = (uint32_t)pos.size();
+            if (g1mask && !g1mask[p]) continue;  // (a member of G[i] \ G1[i]: moved, never re-bounded)
             for (uint32_t q = e->colptr[j]; q < e->colptr[j + 1]; ++q) {
+                if (g1mask && !g1mask[q]) continue;
                 const uint32_t r = e->rowval[q];
                 size_t where = m;
                 for (size_t w = 0; w < m; ++w) {
@@ -501,11 +509,15 @@ static pdmp_status set_flow_common(pdmp_ensemble* e, const int64_t* colptr, cons
     for (int64_t p = 0; p < nnz; ++p) {
         const uint32_t j = e->rowval[p];
         member[(size_t)p * 4 + 0] = j;
-        member[(size_t)p * 4 + 1] = e->colptr[j + 1] - e->colptr[j];
+        uint32_t kj = 0;
+        for (uint32_t q = e->colptr[j]; q < e->colptr[j + 1]; ++q) kj += (!g1mask || g1mask[q]) ? 1u : 0u;
+        member[(size_t)p * 4 + 1] = (g1mask && !g1mask[p]) ? 0u : kj;
         member[(size_t)p * 4 + 2] = qptr[p];
+        member[(size_t)p * 4 + 3] = (!g1mask || g1mask[p]) ? 1u : 0u;
     }
     e->flow_kind = kind;
-    e->needs_general = general || kind == 1;  // FactBoomerang runs on the general kernel
+    e->has_g1mask = g1mask != nullptr;
+    e->needs_general = general || kind == 1 || e->has_g1mask;  // FactBoomerang and G ⊋ G1 run on the general kernel
     e->mmax_all = mmax_all;
     {
         std::vector<double> diag((size_t)d, 0.0);
@@ -565,6 +577,41 @@ pdmp_status pdmp_ensemble_set_flow_factboomerang(pdmp_ensemble* e, const int64_t
         return fail(PDMP_ERR_UNSUPPORTED, "FactBoomerang is available for the factorised drivers spdmp / pdmp (PDMP_SAMPLER_ZIGZAG_LOCAL / _ALL)");
     if (!(lambda_ref > 0)) return fail(PDMP_ERR_INVALID, "FactBoomerang needs a strictly positive refreshment rate");
     return set_flow_common(e, colptr, rowval, nzval, mu, sigma, lambda_ref, rho, 1);
+}
+
+pdmp_status pdmp_ensemble_set_neighbourhood(pdmp_ensemble* e, const int64_t* g_colptr, const int64_t* g_rowval) {
+    if (!e || !g_colptr || !g_rowval) return fail(PDMP_ERR_INVALID, "null argument");
+    NEED_FACTORISED(e);
+    if (!e->has_flow) return fail(PDMP_ERR_INVALID, "set_flow_zigzag / set_flow_factboomerang first");
+    if (e->has_g1mask) return fail(PDMP_ERR_INVALID, "the neighbourhood was set already: call set_flow_* again first");
+    if (e->cfg.sampler == PDMP_SAMPLER_ZIGZAG_ALL) return fail(PDMP_ERR_INVALID, "pdmp is spdmp with G = All(): it takes no G");
+    const int64_t d = e->cfg.d;
+    if (g_colptr[0] != 0) return fail(PDMP_ERR_INVALID, "colptr[0] must be 0");
+    const int64_t gn = g_colptr[d];
+    if (gn < e->nnz || gn >= (int64_t)1 << 31) return fail(PDMP_ERR_INVALID, "G must contain G1 (src/sfact.jl:177)");
+    std::vector<int64_t> cp(g_colptr, g_colptr + d + 1), rv(g_rowval, g_rowval + gn);
+    std::vector<double> nz((size_t)gn, 0.0);
+    std::vector<uint8_t> mask((size_t)gn, 0);
+    for (int64_t i = 0; i < d; ++i) {
+        if (cp[i + 1] < cp[i]) return fail(PDMP_ERR_INVALID, "G colptr not monotone at %lld", (long long)i);
+        uint32_t q = e->colptr[i];
+        const uint32_t q1 = e->colptr[i + 1];
+        for (int64_t p = cp[i]; p < cp[i + 1]; ++p) {
+            const int64_t r = rv[p];
+            if (r < 0 || r >= d || (p > cp[i] && rv[p - 1] >= r)) return fail(PDMP_ERR_INVALID, "G[%lld] must be ascending and in range", (long long)i);
+            if (q < q1 && (int64_t)e->rowval[q] == r) {
+                nz[(size_t)p] = e->bval[q];
+                mask[(size_t)p] = 1;
+                ++q;
+            }
+        }
+        if (q != q1)  // @assert all(a.second ⊇ b.second for (a, b) in zip(G, G1)), src/sfact.jl:177
+            return fail(PDMP_ERR_INVALID, "G[%lld] does not contain G1[%lld] = rowvals(F.Γ)[nzrange(F.Γ, %lld)] (src/sfact.jl:177)", (long long)i,
+                        (long long)i, (long long)i);
+    }
+    if (gn == e->nnz) return PDMP_OK;  // G == G1: Matched()
+    const std::vector<double> mu = e->mu, sigma = e->sigma;
+    return set_flow_common(e, cp.data(), rv.data(), nz.data(), mu.data(), sigma.data(), e->lambda_ref, e->rho, e->flow_kind, mask.data());
 }
 
 pdmp_status pdmp_ensemble_set_target_gaussian_csc(pdmp_ensemble* e, const int64_t* colptr, const int64_t* rowval,
@@ -1141,6 +1188,7 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
     if (general_path) {
         pdmp::ZzGeneralParams Q{};
         Q.local_bound = e->local_bound ? 1 : 0;
+        Q.masked = e->has_g1mask ? 1 : 0;
         Q.sticky = sticky ? 1 : 0;
         Q.qtval = e->d_qtval.p;
         Q.renew_chain = e->local_bound ? e->d_thf.p : nullptr;
@@ -1498,6 +1546,7 @@ pdmp_status pdmp_ensemble_run_partitioned(pdmp_ensemble* e, double T, int K, dou
                     "parallel_spdmp (src/parallel.jl) is built for the local ZigZag on a Gaussian target without refresh clock, "
                     "adaptscale, LocalBound or gradient tracking");
     if (e->ran) return fail(PDMP_ERR_UNSUPPORTED, "a partitioned run starts from a fresh state (call set_state first)");
+    if (e->has_g1mask) return fail(PDMP_ERR_UNSUPPORTED, "parallel_spdmp takes G as the flow's pattern + g1_mask, not pdmp_ensemble_set_neighbourhood");
     const int64_t d = e->cfg.d;
     if (K < 1 || K > 16 || d % K != 0)
         return fail(PDMP_ERR_INVALID, "K = %d: need 1 <= K <= 16 chunks of equal size d / K (Partition, src/parallel.jl:26)", K);

@@ -246,6 +246,7 @@ struct ZzGeneralParams {
     // c::LocalBound (src/local.jl:2-6,10-78): qtval = the TARGET's Γ values in the (member, entry) layout of qbval; renew flags in
     // renew_chain [nchains x d] (0.0 / 1.0)
     int32_t local_bound;
+    int32_t masked;  // the tables' pattern is G ⊋ G1 (pdmp_ensemble_set_neighbourhood): member[..].w flags the entries of G1 -- only they are re-bounded
     const double* __restrict__ qtval;
     double* renew_chain;  // written and re-read by the same wave: no __restrict__ (a scalar-cache load would see stale flags)
     // adaptscale (src/sfact.jl:86-99): per-chain σ [nchains x d], nullptr when off

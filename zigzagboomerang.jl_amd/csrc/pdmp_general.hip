@@ -109,6 +109,7 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
     ZzRunParams P = P_in;
     ZzGeneralParams Q = Q_in;
     if constexpr (LGFAST) {
+        Q.masked = 0;
         Q.ksub = 10;  // k = 10 sampled observations per gradient (scripts/logistic.jl:167): one batch, fixed trip counts
         P.move_all = 0;
         P.has_refresh = 0;
@@ -315,8 +316,9 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
             // a re-bounded member takes draw draw0 + (its rank among the re-bounded ones)
             bool live = valid;
             uint32_t rank = jjc - jj0;
-            if (sticky) {
-                live = valid && (sth[jjc] != 0.0);
+            if (sticky || Q.masked) {
+                // (G ⊋ G1: the members of G[i] \ G1[i] are moved with the others but neither re-bounded nor given a draw, src/sfact.jl:131)
+                live = valid && (!sticky || sth[jjc] != 0.0) && (!Q.masked || mrec.w != 0u);
                 const uint64_t lball = __ballot(live);
                 rank = reb_count + (uint32_t)__popcll(lball & ((1ull << lane) - 1ull));
                 reb_count += (uint32_t)__popcll(lball);
@@ -518,8 +520,9 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
             G_ORDER();
             const double newref = tp + (-pdmp_log(pdmp_u01(seed, PDMP_STREAM_GLOBAL, ng))) / P.lambda_ref;  // :108
             ng += 1;
+            reb_count = 0;
             rebound(cp2, 0, k2, tp, nm, true, true);  // :110-114
-            nm += (uint64_t)k2;
+            nm += Q.masked ? (uint64_t)reb_count : (uint64_t)k2;
             if (lane == 0) keys[d] = newref;
             requeue(cp2, 0, k2, true, (uint32_t)d);
             if (ev && lane == 0) {  // event(i, t, x, θ, F) = (t[i], i, x[i], θ[i]) at i's own clock, :143
@@ -883,8 +886,9 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
         // ---------------- re-bound: all of G1[i] on accept (:131-135), i alone on reject (:137-139)
         const uint32_t jj0 = accept ? 0u : self;
         const uint32_t jj1 = accept ? k : self + 1u;
+        reb_count = 0;
         rebound(cp0, jj0, jj1, tp, nm, accept, false);
-        nm += accept ? (uint64_t)k : 1u;
+        nm += Q.masked ? (uint64_t)reb_count : (accept ? (uint64_t)k : 1u);
         GPHASE(4);
         // ---------------- level 1 of the queue (keys[] already hold the new values)
         requeue(cp0, jj0, jj1, false, 0u);
@@ -928,7 +932,7 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
 int launch_zz_general_run(const ZzRunParams& p, const ZzGeneralParams& q, int64_t nchains, void* stream) {
     const size_t lds = zz_general_lds_bytes(p.nblk_pad, q.mmax_pad, q.flow_kind == 1);
     const bool prof = p.dbg != nullptr;
-    const bool lgfast = !prof && q.target_kind == 1 && q.ksub == 10 && q.lg_ne_max <= 6 && !p.move_all && !p.has_refresh && !q.local_bound && !q.sticky &&
+    const bool lgfast = !prof && !q.masked && q.target_kind == 1 && q.ksub == 10 && q.lg_ne_max <= 6 && !p.move_all && !p.has_refresh && !q.local_bound && !q.sticky &&
                         q.flow_kind == 0 && !q.adaptscale;
     const bool rng = !prof && !lgfast && q.target_kind == 1 && q.lg_range > 0;
     const void* fn = prof ? reinterpret_cast<const void*>(zz_general_run_kernel<true, false, false>)

@@ -532,7 +532,7 @@ __global__ __launch_bounds__(64) void zz_logistic_lds_kernel(ZzRunParams P, ZzGe
 }
 
 bool zz_logistic_lds_supported(const ZzRunParams& p, const ZzGeneralParams& q, const ZzLogisticTables& lt) {
-    return lt.coord != nullptr && q.target_kind == 1 && q.ksub >= 1 && q.ksub <= 32 && q.lg_ne_max <= 6 && !p.move_all && !p.has_refresh &&
+    return lt.coord != nullptr && !q.masked && q.target_kind == 1 && q.ksub >= 1 && q.ksub <= 32 && q.lg_ne_max <= 6 && !p.move_all && !p.has_refresh &&
            !q.local_bound && !q.sticky && q.flow_kind == 0 && !q.adaptscale && p.dk <= 64 * LG_KREG &&
            zz_logistic_lds_bytes(p.d, p.dk, true) <= 64 * 1024;
 }

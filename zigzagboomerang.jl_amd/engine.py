@@ -91,6 +91,16 @@ class Ensemble:
         fn = self._L.pdmp_ensemble_set_flow_factboomerang if isinstance(F, FactBoomerang) else self._L.pdmp_ensemble_set_flow_zigzag
         _lib.check(fn(self._h, _ptr(cp), _ptr(rv), _ptr(nz), _ptr(mu), _ptr(sg), float(F.λref), float(F.ρ)))
 
+    def set_neighbourhood(self, G):
+        """G of spdmp(∇ϕ, t0, x0, θ0, T, c, G, F, ...) as a sparse matrix whose column patterns are the G[i] (explicit zeros count);
+        after set_flow, before set_target (pdmp_ensemble_set_neighbourhood)."""
+        import scipy.sparse as sp
+        G = sp.csc_matrix(G)
+        P = sp.csc_matrix((np.ones(G.nnz), G.indices.copy(), G.indptr.copy()), shape=G.shape)
+        P.sort_indices()
+        cp, rv = _i64(P.indptr), _i64(P.indices)
+        _lib.check(self._L.pdmp_ensemble_set_neighbourhood(self._h, _ptr(cp), _ptr(rv)))
+
     def set_sticky(self, kappa, reversible=False, strong_upperbounds=False):
         kappa = _f64(kappa).reshape(self.d)
         _lib.check(self._L.pdmp_ensemble_set_sticky(self._h, _ptr(kappa), int(bool(reversible)), int(bool(strong_upperbounds))))

@@ -29,17 +29,31 @@ def _drain(ens, events):
     ens.trace_reset()
 
 
-def spdmp(target, t0, x0, θ0, T, c, F, *, factor=1.8, adapt=False, adaptscale=False, seed=DEFAULT_SEED, device=0,
-          trace_capacity=None, trace=True, tracked=False):
-    """Local ZigZag: spdmp(∇ϕ, t0, x0, θ0, T, c, F::ZigZag, args...) with G = Matched() (src/sfact.jl:214).
+def _split_G(GF, G):
+    """spdmp(∇ϕ, t0, x0, θ0, T, c, F) or spdmp(∇ϕ, t0, x0, θ0, T, c, G, F) as in the reference (src/sfact.jl:162,214); G may also be a keyword."""
+    if len(GF) == 1:
+        return G, GF[0]
+    if len(GF) == 2 and G is None:
+        return GF[0], GF[1]
+    raise TypeError("expected spdmp(target, t0, x0, θ0, T, c, [G,] F, ...)")
+
+
+def spdmp(target, t0, x0, θ0, T, c, *GF, factor=1.8, adapt=False, adaptscale=False, seed=DEFAULT_SEED, device=0,
+          trace_capacity=None, trace=True, tracked=False, G=None):
+    """Local ZigZag: spdmp(∇ϕ, t0, x0, θ0, T, c, [G,] F::ZigZag, args...) (src/sfact.jl:162,214); without G: G = Matched().
     Returns Ξ, (t, x, θ), (acc, num), c like the reference (:211).
+
+    G: the neighbourhoods a proposal moves before its gradient is taken (:82,171-179) -- a sparse matrix whose column patterns are the
+    G[i] (e.g. the target's Γ when the bounding F.Γ is sparser) or a sequence of index arrays; G[i] ⊇ G1[i] = pattern of F.Γ[:, i] is
+    asserted as in the reference (:177).
 
     adaptscale=True (src/sfact.jl:86-99) tunes σ in the refresh branch.  Like the reference, a single-chain call mutates
     F.σ in place; for an ensemble every chain's tuned σ is the `σ` of the flow attached to its trace (Ξ[k].F.σ).
 
     tracked=True (engine-only keyword): the tracked-gradient evaluation of the same process (pdmp_ensemble_set_gradient_tracking)."""
+    G, F = _split_G(GF, G)
     return _zigzag(_lib.SAMPLER_ZIGZAG_LOCAL, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, trace_capacity, trace,
-                   adaptscale=adaptscale, tracked=tracked)
+                   adaptscale=adaptscale, tracked=tracked, G=G)
 
 
 def pdmp(target, t0, x0, θ0, T, c, F, *, factor=1.8, adapt=False, subsample=False, seed=DEFAULT_SEED, device=0,
@@ -64,12 +78,16 @@ def pdmp(target, t0, x0, θ0, T, c, F, *, factor=1.8, adapt=False, subsample=Fal
     return _zigzag(_lib.SAMPLER_ZIGZAG_ALL, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, trace_capacity, trace)
 
 
-def sspdmp(target, t0, x0, θ0, T, c, F, κ, *, reversible=False, strong_upperbounds=False, factor=1.5, adapt=False,
-           seed=DEFAULT_SEED, device=0, trace_capacity=None, trace=True):
-    """Sticky ZigZag: sspdmp(∇ϕ, t0, x0, θ0, T, c, F::ZigZag, κ, args...; reversible, strong_upperbounds, factor=1.5,
-    adapt) (src/ss_fact.jl:159-160,217) -> Ξ, (t, x, θ), (acc, num), c with scalar acc, num (:175,214)."""
+def sspdmp(target, t0, x0, θ0, T, c, *GFκ, reversible=False, strong_upperbounds=False, factor=1.5, adapt=False,
+           seed=DEFAULT_SEED, device=0, trace_capacity=None, trace=True, G=None):
+    """Sticky ZigZag: sspdmp(∇ϕ, t0, x0, θ0, T, c, [G,] F::ZigZag, κ, args...; reversible, strong_upperbounds, factor=1.5,
+    adapt) (src/ss_fact.jl:159-160,217) -> Ξ, (t, x, θ), (acc, num), c with scalar acc, num (:175,214).  G as in spdmp (:167-172)."""
+    if len(GFκ) not in (2, 3):
+        raise TypeError("expected sspdmp(target, t0, x0, θ0, T, c, [G,] F, κ, ...)")
+    G, F = _split_G(GFκ[:-1], G)
+    κ = GFκ[-1]
     return _zigzag(_lib.SAMPLER_STICKY_ZIGZAG, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, trace_capacity, trace,
-                   sticky=(np.asarray(κ, dtype=np.float64), reversible, strong_upperbounds))
+                   sticky=(np.asarray(κ, dtype=np.float64), reversible, strong_upperbounds), G=G)
 
 
 class Partition:
@@ -164,8 +182,22 @@ def parallel_spdmp(partition, target, t0, x0, θ0, T, c, G, F, *, factor=1.8, ad
     return traces, (fs["t"], fs["x"], fs["theta"]), (acc, num)
 
 
+def _pattern_of(G, d):
+    """G as a CSC pattern: a sparse matrix (explicit zeros count, like rowvals / nzrange) or a sequence of index arrays / (i, indices) pairs."""
+    if sp.issparse(G):
+        G = sp.csc_matrix(G)
+        return sp.csc_matrix((np.ones(G.nnz), G.indices.copy(), G.indptr.copy()), shape=G.shape)
+    cols = [np.asarray(g[1] if isinstance(g, tuple) else g, dtype=np.int64) for g in G]
+    if len(cols) != d:
+        raise ValueError("G needs one neighbourhood per coordinate")
+    indptr = np.concatenate([[0], np.cumsum([len(g) for g in cols])])
+    P = sp.csc_matrix((np.ones(int(indptr[-1])), np.concatenate(cols) if cols else np.empty(0, np.int64), indptr), shape=(d, d))
+    P.sort_indices()
+    return P
+
+
 def _zigzag(sampler, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, trace_capacity, trace, sticky=None,
-            adaptscale=False, tracked=False):
+            adaptscale=False, tracked=False, G=None):
     if not isinstance(F, (ZigZag, FactBoomerang)):
         raise TypeError("the device path supports F::ZigZag and F::FactBoomerang")
     if not isinstance(target, (GaussianTarget, LogisticTarget)):
@@ -187,6 +219,13 @@ def _zigzag(sampler, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, 
                    trace_capacity=cap)
     try:
         ens.set_flow(F)
+        if G is not None:
+            try:
+                ens.set_neighbourhood(_pattern_of(G, d))
+            except _lib.PdmpError as exc:
+                if "does not contain G1" in str(exc) or "must contain G1" in str(exc):
+                    raise AssertionError("all(a.second ⊇ b.second for (a,b) in zip(G, G1)) -- src/sfact.jl:177") from exc
+                raise
         ens.set_target(target)
         if sticky is not None:
             ens.set_sticky(*sticky)
