@@ -316,7 +316,8 @@ pdmp_status pdmp_ensemble_set_local_bound(pdmp_ensemble* ens, int enable);
  *
  * pdmp(∇ϕ!, t0, x0, θ0, T, c, B::BouncyParticle; adapt, factor=2.0) -> Ξ::PDMPTrace, (t, x, θ), (acc, num), c
  * (src/not_fact_samplers.jl:117-147,395-396) with GlobalBound(c) and the Gaussian target ∇ϕ!(y, x) = Γ(x − μ)
- * (test/maintest.jl:163).  Γ is B.Γ: it enters ab() (:26-28) and, here, the target.  The mass factor B.L =
+ * (test/maintest.jl:163).  Γ is B.Γ: it enters ab() (:26-28) and -- unless pdmp_ensemble_set_target_gaussian_csc is called AFTER this
+ * (accepted on this family: ∇ϕ!(y, x) = Γt(x − μt) of its own; ab(…GlobalBound…) keeps B.Γ, B.μ, LocalBound takes θ'∇ϕx and θ'Γtθ) -- the target.  The mass factor B.L =
  * cholesky(Symmetric(Γ)).L (src/types.jl:43) is identity for Γ = I (config C2); for any other Γ the caller must hand it over
  * with pdmp_ensemble_set_mass_cholesky before set_state_bps, which otherwise returns PDMP_ERR_UNSUPPORTED.
  * Events are (t, copy(x), copy(θ)) (:39-41); dot products use the fixed summation order stated in oracle/pdmp_oracle.c.

@@ -347,6 +347,22 @@ inline Result<PDMPTrace> pdmp(double t0, const std::vector<double>& x0, const st
     if (o.local_bound || o.subsample) check(pdmp_ensemble_set_bps_options(e.get(), o.local_bound ? 1 : 0, o.subsample ? 1 : 0));
     return detail::not_factorised(e, t0, x0, theta0, T, c, o);
 }
+// pdmp(∇ϕ!, t0, x0, θ0, T, c, B::BouncyParticle; ...) with a target of its own, ∇ϕ!(y, x) = Γt(x − μt): ab(…GlobalBound…) keeps B.Γ, B.μ
+// (src/not_fact_samplers.jl:26-28), gradient / rate / reflection use the target's (:122)
+inline Result<PDMPTrace> pdmp(const GaussianTarget& target, double t0, const std::vector<double>& x0, const std::vector<double>& theta0,
+                              double T, double c, const BouncyParticle& B, Options o = {}) {
+    if (o.factor == 1.8) o.factor = 2.0;
+    const int64_t d = (int64_t)x0.size();
+    const int64_t cap = o.trace_capacity > 0 ? o.trace_capacity : std::max<int64_t>(256, (int64_t)(64 * std::max(T - t0, 1.0)));
+    Ensemble e(1, d, PDMP_SAMPLER_BPS, o, cap);
+    check(pdmp_ensemble_set_flow_bps(e.get(), B.Gamma.colptr.data(), B.Gamma.rowval.data(), B.Gamma.nzval.data(),
+                                     detail::opt(B.mu), B.lambda_ref, B.rho));
+    check(pdmp_ensemble_set_target_gaussian_csc(e.get(), target.Gamma.colptr.data(), target.Gamma.rowval.data(),
+                                                target.Gamma.nzval.data(), detail::opt(target.mu)));
+    if (B.L.n > 0) check(pdmp_ensemble_set_mass_cholesky(e.get(), B.L.colptr.data(), B.L.rowval.data(), B.L.nzval.data()));
+    if (o.local_bound || o.subsample) check(pdmp_ensemble_set_bps_options(e.get(), o.local_bound ? 1 : 0, o.subsample ? 1 : 0));
+    return detail::not_factorised(e, t0, x0, theta0, T, c, o);
+}
 // pdmp(∇ϕ!, t0, x0, θ0, T, c, B::Boomerang; ...) with ∇ϕ!(y, x) = Γt(x − μt)  -- test/maintest.jl:139-154
 inline Result<PDMPTrace> pdmp(const GaussianTarget& target, double t0, const std::vector<double>& x0,
                               const std::vector<double>& theta0, double T, double c, const Boomerang& B, Options o = {}) {

@@ -1071,7 +1071,8 @@ static void tri_solve_upper(const tri_factor* F, double* y) {
 
 /* ∇ϕx = ∇ϕ!(∇ϕx, x) then grad_correct!, src/not_fact_samplers.jl:5-12: Boomerang subtracts L'\(L\(x − μ)) (= x − μ for L = I) */
 static void nf_grad(const orc_bps_params* p, const tri_factor* M, int64_t d, const double* x, double* tmp, double* g) {
-    bps_grad(p->gamma, p->mu, x, tmp, g, d);
+    if (p->flow_kind == 0 && p->target_gamma) bps_grad(p->target_gamma, p->target_mu, x, tmp, g, d); /* ∇ϕ! is the caller's, :122 */
+    else bps_grad(p->gamma, p->mu, x, tmp, g, d);
     if (p->flow_kind == 1) {
         if (M) {
             for (int64_t k = 0; k < d; ++k) tmp[k] = x[k] - p->flow_mu[k];
@@ -1090,8 +1091,17 @@ static void nf_ab(const orc_bps_params* p, int64_t d, double c, const double* x,
                   double* tmp, double* gth, double* a, double* b, double* horizon) {
     *horizon = INFINITY;
     if (p->flow_kind == 0) {
-        *a = c + dot_wave64(th, g, d);
-        for (int64_t r = 0; r < d; ++r) gth[r] = orc_idot(p->gamma, r, th);
+        /* GlobalBound: (c + θ'(B.Γ(x − B.μ)), θ'(B.Γθ), Inf) with the FLOW's Γ, μ (:26-28) -- which is θ'∇ϕx only when the target is
+         * B.Γ(x − B.μ) itself; LocalBound: (c + dot(θ, ∇ϕx), v, ...) with the TARGET's gradient and second derivative v = θ'Γtθ (:29-31) */
+        const int own_target = p->target_gamma != NULL;
+        if (own_target && !p->local_bound) {
+            bps_grad(p->gamma, p->mu, x, tmp, gth, d);
+            *a = c + dot_wave64(th, gth, d);
+        } else {
+            *a = c + dot_wave64(th, g, d);
+        }
+        const orc_csc* Gv = (own_target && p->local_bound) ? p->target_gamma : p->gamma;
+        for (int64_t r = 0; r < d; ++r) gth[r] = orc_idot(Gv, r, th);
         *b = dot_wave64(th, gth, d);
         if (p->local_bound) *horizon = 2 * sqrt((double)d) / c / sqrt(dot_wave64(th, th, d));
     } else {

@@ -184,6 +184,10 @@ typedef struct {
     const orc_csc* mass_L;
     int local_bound; /* c::LocalBound (src/not_fact_samplers.jl:29-31): horizon 2√d/c/‖θ‖ and the renew branch :65-71 (BPS only) */
     int subsample;   /* kwarg subsample (:53,90): an accepted reflection does not end pdmp_inner! */
+    /* BouncyParticle with a target of its own: ∇ϕ!(y, x) = target_gamma (x − target_mu) (the caller's, src/not_fact_samplers.jl:122) while
+     * ab(…GlobalBound…) keeps the flow's B.Γ, B.μ (:26-28).  NULL: the target is B.Γ(x − B.μ) itself. */
+    const orc_csc* target_gamma;
+    const double* target_mu;
 } orc_bps_params;
 typedef struct {
     int64_t num, nacc, nrefresh, nevents;

@@ -61,7 +61,8 @@ class _BpsParams(C.Structure):
     _fields_ = [("gamma", C.POINTER(_Csc)), ("mu", C.c_void_p), ("lambda_ref", C.c_double),
                 ("rho", C.c_double), ("c", C.c_double), ("adapt", C.c_int), ("factor", C.c_double),
                 ("seed", C.c_uint64), ("max_events", C.c_int64), ("flow_kind", C.c_int), ("flow_mu", C.c_void_p),
-                ("mass_L", C.POINTER(_Csc)), ("local_bound", C.c_int), ("subsample", C.c_int)]
+                ("mass_L", C.POINTER(_Csc)), ("local_bound", C.c_int), ("subsample", C.c_int),
+                ("target_gamma", C.POINTER(_Csc)), ("target_mu", C.c_void_p)]
 
 
 class _BpsResult(C.Structure):
@@ -296,7 +297,7 @@ def pdmp_zigzag1d(mu, sigma2, x0, theta0, T, c, *, adapt=False, factor=2.0, seed
 
 def pdmp_bps(gamma, mu, x0, theta0, c, T, *, t0=0.0, lambda_ref=1.0, rho=0.0, adapt=False, factor=2.0,
              seed=1, max_events=0, ev_cap=0, want_events=True, boomerang_mu=None, mass_L=None, local_bound=False,
-             subsample=False):
+             subsample=False, target=None):
     """BPS (gamma, mu = flow AND target) or, with boomerang_mu, Boomerang(·, boomerang_mu, λref; ρ) on the Gaussian
     target (gamma, mu).  mass_L: the lower-triangular factor F.L (scipy sparse / dense), None = identity."""
     L = lib()
@@ -311,6 +312,10 @@ def pdmp_bps(gamma, mu, x0, theta0, c, T, *, t0=0.0, lambda_ref=1.0, rho=0.0, ad
         mh = mass_L if isinstance(mass_L, CscHolder) else CscHolder(mass_L)
         p.mass_L = C.pointer(mh.c)
     p.local_bound, p.subsample = int(bool(local_bound)), int(bool(subsample))
+    if target is not None:  # (Γt, μt): BouncyParticle whose target differs from B.Γ(x − B.μ)
+        th_ = target[0] if isinstance(target[0], CscHolder) else CscHolder(target[0])
+        tmu_ = _f64(target[1] if target[1] is not None else np.zeros(d))
+        p.target_gamma, p.target_mu = C.pointer(th_.c), tmu_.ctypes.data
     x = _f64(x0).copy()
     th = _f64(theta0).copy()
     if want_events:

@@ -223,3 +223,40 @@ def test_boomerang_matches_oracle(gpu_pkg):
     chk(G, None, np.zeros(8), rng.standard_normal((2, 8)), rng.standard_normal((2, 8)), 16.0, 100.0, 0.5, seed=63, Gf=G, adapt=True)
     chk(G2, None, 0.1 * rng.standard_normal(100), rng.standard_normal((2, 100)), rng.standard_normal((2, 100)), 4.0, 10.0, 0.8,
         rho=0.3, seed=64, Gf=G2, adapt=True)
+
+
+def test_bouncy_particle_with_a_target_of_its_own(gpu_pkg):
+    """pdmp(∇ϕ!, t0, x0, θ0, T, c, B::BouncyParticle): ∇ϕ! is the caller's (src/not_fact_samplers.jl:122) while ab(…GlobalBound…) uses the
+    FLOW's B.Γ, B.μ (:26-28).  Target Γt(x − μt) ≠ B.Γ(x − B.μ): gradient, rate and reflection from the target, the bound from the flow
+    (B.Γ = 1.4 Γt dominates, so c stays small); with the flow's mass factor; with LocalBound (a = c + θ'∇ϕx, v = θ'Γtθ, :29-31); adapt."""
+    pkg = gpu_pkg
+    rng = np.random.default_rng(12)
+    for d, nch, T in ((8, 3, 40.0), (100, 2, 5.0)):
+        Gt = pkg.problems.maintest_precision(8) if d == 8 else pkg.problems.gmrf_precision(10, 0.5)
+        mut = 0.3 * rng.standard_normal(d)
+        mub = mut + 0.05 * rng.standard_normal(d)
+        x0, th0 = rng.standard_normal((nch, d)), rng.standard_normal((nch, d))
+        # (scale of B.Γ against Γt, bound, adapt): 1.4 Γt dominates the target; 0.5 Γt with a tiny c violates and adapts
+        for scale, c, kw in ((1.4, 2.5, dict()), (1.4, 2.5, dict(local_bound=True)), (0.5, 1e-3, dict(adapt=True))):
+            Gb = sp.csc_matrix(scale * Gt)
+            B = pkg.BouncyParticle(Gb, mub, 0.6, 0.2)
+            cc = pkg.LocalBound(np.array([c])) if kw.get("local_bound") else c
+            tr, (t, x, th), (acc, num), cout = pkg.pdmp(pkg.GaussianTarget(Gt, mut), 0.0, x0, th0, T, cc, B, seed=77,
+                                                        adapt=kw.get("adapt", False))
+            for k in range(nch):
+                r = O.pdmp_bps(Gb, mub, x0[k], th0[k], c, T, lambda_ref=0.6, rho=0.2, seed=77 + k, ev_cap=200000, mass_L=B.L,
+                               target=(Gt, mut), **kw)
+                assert r["status"] == 0 and r["nevents"] > 10
+                assert np.array_equal(tr[k].t, r["t_ev"]) and np.array_equal(tr[k].x, r["x_ev"]) and np.array_equal(tr[k].θ, r["theta_ev"])
+                assert (int(acc[k]), int(num[k])) == (r["nacc"], r["num"]) and cout[k] == r["c"]
+                assert np.array_equal(x[k], r["x"]) and np.array_equal(th[k], r["theta"])
+            if kw.get("adapt"):
+                assert np.all(cout > 1e-3)
+    # the target Γt(x − μt) == B.Γ(x − B.μ) handed over explicitly is the plain BouncyParticle, bit for bit
+    G = pkg.problems.maintest_precision(8)
+    x0, th0 = rng.standard_normal((2, 8)), rng.standard_normal((2, 8))
+    B = pkg.BouncyParticle(G, np.zeros(8), 0.5)
+    a = pkg.pdmp(None, 0.0, x0, th0, 30.0, 1.1, B, seed=3)
+    b = pkg.pdmp(pkg.GaussianTarget(G, np.zeros(8)), 0.0, x0, th0, 30.0, 1.1, B, seed=3)
+    for k in range(2):
+        assert np.array_equal(a[0][k].t, b[0][k].t) and np.array_equal(a[0][k].x, b[0][k].x)

@@ -143,11 +143,29 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
     const bool stop_before = (P.flags & PDMP_RUN_STOP_BEFORE) != 0;
 
     // y = Γ v  with v = in[] (-mu if sub): idot per output element, ascending row order
-    auto apply_gamma = [&](const double (&in)[NS], bool sub_mu, double (&out)[NG]) {
+    // (target = true: the TARGET's Γt, μt where the ensemble has one of its own -- extended instantiation -- else the flow's)
+    auto apply_gamma = [&](const double (&in)[NS], bool sub_mu, double (&out)[NG], bool target = false) {
         if constexpr (IDENT) {
             (void)in;
             (void)sub_mu;
             (void)out;
+        } else if (EXT && target && P.t_colptr) {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int64_t e = (int64_t)s * 64 + lane;
+                if (FULL || e < d) tmp[e] = sub_mu ? (in[s] - P.t_mu[e]) : in[s];
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int64_t e = (int64_t)s * 64 + lane;
+                double y = 0.0;
+                if (FULL || e < d) {
+                    for (int64_t p = P.t_colptr[e]; p < P.t_colptr[e + 1]; ++p) y += P.t_nzval[p] * tmp[P.t_rowval[p]];
+                }
+                out[s] = y;
+            }
         } else if (DIAG) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -250,9 +268,18 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
             a = boom_a();
             b = 0.0;
         } else {
-            a = c + dot(th, g);
+            // GlobalBound: (c + θ'(B.Γ(x − B.μ)), θ'(B.Γθ)) with the FLOW's Γ, μ (:26-28) -- θ'∇ϕx only when the target is B.Γ(x − B.μ);
+            // LocalBound: (c + dot(θ, ∇ϕx), v) with the TARGET's gradient and v = θ'Γtθ (:29-31)
+            const bool own_target = EXT && P.t_colptr != nullptr;
+            if (own_target && !P.local_bound) {
+                double gb[NG];
+                apply_gamma(x, true, gb);
+                a = c + dot(th, gb);
+            } else {
+                a = c + dot(th, g);
+            }
             double gt[NS];
-            apply_gamma(th, false, gt);
+            apply_gamma(th, false, gt, own_target && P.local_bound);
             b = dot(th, gt);
         }
         if constexpr (EXT) {
@@ -288,7 +315,7 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
     // ∇ϕx = ∇ϕ!(∇ϕx, x); grad_correct!: Boomerang subtracts L'\(L\(x − μ)) = x − μ for L = I (src/not_fact_samplers.jl:9-12)
     auto gradient = [&]() {
         if constexpr (!IDENT) {
-            apply_gamma(x, true, g);
+            apply_gamma(x, true, g, true);
             if (BOOM) {
                 if (has_mass) {  // grad_correct!: y .-= L'\(L\(x − μ)), src/not_fact_samplers.jl:9-12
                     double dx[NS];
@@ -416,8 +443,17 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
                 rebound(Lnext);  // :86-89
                 emit = !(EXT && P.subsample);  // :90 `!subsample && return`
             } else {
-                if (BOOM) a = boom_a();  // :92 recomputed after the rotation (b stays 0)
-                else a = c + gt;         // :92 (θ'g == g'θ bit for bit; b = θ'Γθ is unchanged because θ is)
+                if (BOOM) {
+                    a = boom_a();  // :92 recomputed after the rotation (b stays 0)
+                } else if (EXT && P.t_colptr != nullptr && !P.local_bound) {
+                    if constexpr (!IDENT) {  // :92 with a target of its own: θ'(B.Γ(x − B.μ)) is not θ'∇ϕx
+                        double gb[NG];
+                        apply_gamma(x, true, gb);
+                        a = c + dot(th, gb);
+                    }
+                } else {
+                    a = c + gt;  // :92 (θ'g == g'θ bit for bit; b = θ'Γθ is unchanged because θ is)
+                }
                 const double dt = bps_poisson_time_L(a, b, Lnext);  // :93 (the horizon is unchanged: θ and c are)
                 if constexpr (EXT) {
                     renew = dt > hz;
@@ -526,8 +562,28 @@ __global__ __launch_bounds__(64) void bps_init_kernel(BpsRunParams P, const uint
         }
         return wave_sum_f64(part);
     };
+    auto apply_target = [&](const double (&in)[NS], bool sub_mu, double (&out)[NS]) {  // the ensemble's own target Γt, μt
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int64_t e = (int64_t)s * 64 + lane;
+            if (e < d) tmp[e] = sub_mu ? (in[s] - P.t_mu[e]) : in[s];
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int64_t e = (int64_t)s * 64 + lane;
+            double y = 0.0;
+            if (e < d) {
+                for (int64_t p = P.t_colptr[e]; p < P.t_colptr[e + 1]; ++p) y += P.t_nzval[p] * tmp[P.t_rowval[p]];
+            }
+            out[s] = y;
+        }
+    };
+    const bool own_target = !BOOM && P.t_colptr != nullptr;
     const double tau_ref = -pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, 0)) / P.lambda_ref;  // :121
-    apply_gamma(x, true, g);                                                               // :122-123
+    if (own_target) apply_target(x, true, g);
+    else apply_gamma(x, true, g);                                                          // :122-123
     double a, b;
     if (BOOM) {  // grad_correct! only shifts g (unused by the Boomerang bound); ab, src/not_fact_samplers.jl:34-36
         double dx[NS];
@@ -539,8 +595,15 @@ __global__ __launch_bounds__(64) void bps_init_kernel(BpsRunParams P, const uint
         a = sqrt(dot(th, th) + dot(dx, dx)) * c0;
         b = 0.0;
     } else {
-        a = c0 + dot(th, g);                                                               // :126
-        apply_gamma(th, false, gt);
+        if (own_target && !P.local_bound) {  // ab(…GlobalBound…) with the flow's Γ, μ (:26-28)
+            double gb[NS];
+            apply_gamma(x, true, gb);
+            a = c0 + dot(th, gb);
+        } else {
+            a = c0 + dot(th, g);                                                           // :126
+        }
+        if (own_target && P.local_bound) apply_target(th, false, gt);  // v = θ'Γtθ (:29-31)
+        else apply_gamma(th, false, gt);
         b = dot(th, gt);
     }
     double tp = t0 + bps_poisson_time(a, b, pdmp_u01(seed, PDMP_STREAM_MAIN, 1));          // :135

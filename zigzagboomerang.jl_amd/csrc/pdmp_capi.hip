@@ -165,6 +165,9 @@ struct pdmp_ensemble {
     bool bps_has_mass = false;    // a factor was supplied (identity factors are dropped: has_mass_tables stays false)
     bool bps_mass_tables = false;
     int bps_local_bound = 0, bps_subsample = 0;
+    bool bps_own_target = false;  // set_target_gaussian_csc on a BouncyParticle ensemble: ∇ϕ! differs from B.Γ(x − B.μ)
+    DevBuf<int64_t> bt_colptr, bt_rowval;
+    DevBuf<double> bt_nzval, bt_mu;
     DevBuf<int32_t> m_Lcp, m_Lrv, m_Ucp, m_Urv;
     DevBuf<double> m_Lnz, m_Unz;
 
@@ -617,6 +620,33 @@ pdmp_status pdmp_ensemble_set_neighbourhood(pdmp_ensemble* e, const int64_t* g_c
 pdmp_status pdmp_ensemble_set_target_gaussian_csc(pdmp_ensemble* e, const int64_t* colptr, const int64_t* rowval,
                                                   const double* nzval, const double* mu) {
     if (!e || !colptr || !rowval || !nzval) return fail(PDMP_ERR_INVALID, "null argument");
+    if (e->cfg.sampler == PDMP_SAMPLER_BPS) {
+        // pdmp(∇ϕ!, t0, x0, θ0, T, c, B::BouncyParticle): ∇ϕ! is the caller's (src/not_fact_samplers.jl:122), ab(…GlobalBound…) uses B.Γ, B.μ
+        // (:26-28).  A Gaussian target of its own: ∇ϕ!(y, x) = Γt(x − μt).
+        if (!e->has_flow || e->bps_flow_kind != 0)
+            return fail(PDMP_ERR_INVALID, "a target of its own follows set_flow_bps (set_flow_boomerang takes the target directly)");
+        HIP_TRY(hipSetDevice(e->cfg.device));
+        const int64_t dd = e->cfg.d;
+        if (colptr[0] != 0) return fail(PDMP_ERR_INVALID, "colptr[0] must be 0 (0-based CSC)");
+        const int64_t tn = colptr[dd];
+        if (tn <= 0 || tn >= (int64_t)1 << 31) return fail(PDMP_ERR_INVALID, "bad nnz %lld", (long long)tn);
+        for (int64_t i = 0; i < dd; ++i) {
+            if (colptr[i + 1] < colptr[i]) return fail(PDMP_ERR_INVALID, "target colptr not monotone at %lld", (long long)i);
+            for (int64_t p = colptr[i]; p < colptr[i + 1]; ++p)
+                if (rowval[p] < 0 || rowval[p] >= dd || (p > colptr[i] && rowval[p - 1] >= rowval[p]))
+                    return fail(PDMP_ERR_INVALID, "target column %lld: rows must be ascending and in range", (long long)i);
+        }
+        pdmp_status stb;
+        if ((stb = e->bt_colptr.upload(std::vector<int64_t>(colptr, colptr + dd + 1))) != PDMP_OK) return stb;
+        if ((stb = e->bt_rowval.upload(std::vector<int64_t>(rowval, rowval + tn))) != PDMP_OK) return stb;
+        if ((stb = e->bt_nzval.upload(std::vector<double>(nzval, nzval + tn))) != PDMP_OK) return stb;
+        std::vector<double> tm((size_t)dd, 0.0);
+        if (mu) tm.assign(mu, mu + dd);
+        if ((stb = e->bt_mu.upload(tm)) != PDMP_OK) return stb;
+        e->bps_own_target = true;
+        e->has_state = false;
+        return PDMP_OK;
+    }
     NEED_FACTORISED(e);
     if (!e->has_flow) return fail(PDMP_ERR_INVALID, "set_flow_zigzag must be called first");
     HIP_TRY(hipSetDevice(e->cfg.device));
@@ -1714,6 +1744,7 @@ static pdmp_status set_flow_nf(pdmp_ensemble* e, const int64_t* colptr, const in
     for (int64_t i = 0; gI && i < d; ++i) gI = (nzval[i] == 1.0);
     e->bps_gamma_is_I = gI;
     e->bps_has_mass = e->bps_mass_tables = false;
+    e->bps_own_target = false;
     e->bps_local_bound = e->bps_subsample = 0;
     e->bps_lambda = lambda_ref;
     e->bps_rho = rho;
@@ -1748,7 +1779,14 @@ pdmp_status pdmp_ensemble_set_flow_boomerang(pdmp_ensemble* e, const int64_t* co
 static void fill_bps_ext(const pdmp_ensemble* e, pdmp::BpsRunParams& B) {
     B.local_bound = e->bps_local_bound;
     B.subsample = e->bps_subsample;
-    B.ext = (e->bps_mass_tables || e->bps_local_bound || e->bps_subsample) ? 1 : 0;
+    B.ext = (e->bps_mass_tables || e->bps_local_bound || e->bps_subsample || e->bps_own_target) ? 1 : 0;
+    if (e->bps_own_target) {
+        B.t_colptr = e->bt_colptr.p;
+        B.t_rowval = e->bt_rowval.p;
+        B.t_nzval = e->bt_nzval.p;
+        B.t_mu = e->bt_mu.p;
+        B.ident = 0;  // (the gradient-free register layout belongs to the isotropic TARGET)
+    }
     if (e->bps_mass_tables) {
         B.Lcp = e->m_Lcp.p;
         B.Lrv = e->m_Lrv.p;

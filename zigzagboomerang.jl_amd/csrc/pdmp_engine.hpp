@@ -307,6 +307,11 @@ struct BpsRunParams {
     // extended instantiation (ext != 0): mass factor L (lower CSC, diagonal first) and L' (upper CSC, diagonal last), nullptr =
     // identity; c::LocalBound; subsample
     int32_t ext, local_bound, subsample, pad_;
+    // BouncyParticle with a target of its own (nullptr: the target is B.Γ(x − B.μ)): ∇ϕ!(y, x) = Γt(x − μt); extended instantiation only
+    const int64_t* __restrict__ t_colptr;
+    const int64_t* __restrict__ t_rowval;
+    const double* __restrict__ t_nzval;
+    const double* __restrict__ t_mu;
     const int32_t* __restrict__ Lcp;
     const int32_t* __restrict__ Lrv;
     const double* __restrict__ Lnz;

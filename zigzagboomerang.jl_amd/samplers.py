@@ -62,12 +62,15 @@ def pdmp(target, t0, x0, θ0, T, c, F, *, factor=1.8, adapt=False, subsample=Fal
     ALL coordinates (no sparsity assumption on ∇ϕ); same return value as spdmp.
 
     pdmp(∇ϕ!, t0, x0, θ0, T, c, B::BouncyParticle; adapt, factor=2.0) (src/not_fact_samplers.jl:117,395-396) when F is a
-    BouncyParticle: the target is ∇ϕ!(y, x) = B.Γ(x − B.μ) (pass target=None), c is the scalar of GlobalBound(c) or a
+    BouncyParticle: the target is ∇ϕ!(y, x) = B.Γ(x − B.μ) (pass target=None) or a GaussianTarget of its own -- ab(…GlobalBound…) then
+    keeps the flow's B.Γ, B.μ while gradient, rate and reflection use the target's (src/not_fact_samplers.jl:26-28,122) --, c is the scalar of GlobalBound(c) or a
     LocalBound(c) (src/not_fact_samplers.jl:29-31; the second derivative v = θ'Γθ is the Gaussian target's own);
     `subsample` as in the reference (:53,90); returns Ξ::PDMPTrace, (t, x, θ), (acc, num), c."""
     if isinstance(F, BouncyParticle):
+        if target is not None and not isinstance(target, GaussianTarget):
+            raise TypeError("BouncyParticle: target is None (∇ϕ!(y, x) = B.Γ(x − B.μ)) or a GaussianTarget of its own")
         return _bps(t0, x0, θ0, T, c, F, 2.0 if factor == 1.8 else factor, adapt, seed, device, trace_capacity, trace,
-                    subsample=subsample)
+                    target=target, subsample=subsample)
     if isinstance(F, Boomerang):  # pdmp(∇ϕ!, t0, x0, θ0, T, c, B::Boomerang) (test/maintest.jl:139-154); target = GaussianTarget
         if not isinstance(target, GaussianTarget):
             raise TypeError("Boomerang: target must be a GaussianTarget (∇ϕ!(y, x) = Γ(x − μ))")
@@ -285,10 +288,12 @@ def _bps(t0, x0, θ0, T, c, B, factor, adapt, seed, device, trace_capacity, trac
     cap = trace_capacity if trace else 0
     ens = Ensemble(nch, d, sampler=_lib.SAMPLER_BPS, adapt=adapt, factor=factor, device=device, trace_capacity=cap)
     try:
-        if target is not None:
+        if isinstance(B, Boomerang):
             ens.set_flow_boomerang(target, B)
         else:
             ens.set_flow_bps(B)
+            if target is not None:  # ∇ϕ! of its own; ab(…GlobalBound…) keeps B.Γ, B.μ (src/not_fact_samplers.jl:26-28,122)
+                ens.set_target(target)
         if local_bound or subsample:
             ens.set_bps_options(local_bound, subsample)
         ens.set_state_bps(t0, X0, TH0, float(c), seeds)
