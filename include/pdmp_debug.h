@@ -28,10 +28,11 @@ pdmp_status pdmp_debug_set_spec_g2(pdmp_ensemble* ens, int on);
  * kind 2 (general kernel) [0..6] select, move G1, gradient, coin + G2, re-bound, re-queue, tail, [10] proposals. */
 pdmp_status pdmp_debug_set_phase_profile(pdmp_ensemble* ens, int on);
 pdmp_status pdmp_debug_phase_profile(pdmp_ensemble* ens, double* out16, int* kind);
-/* gradient tracking: which kernel runs where the one-proposal-per-lane kernels apply (plain lattice graph, no adaptation, 2048 <= d <= 16384).
- * 0 = default (zz_local_trackp_kernel: (key, time) pairs in blocks of 8, one dirty line per rejected proposal), 1 = the 8-lane-group kernel
- * (zz_local_track_kernel), 2 = zz_local_trackw_kernel (key blocks of 32), 3 = zz_local_trackx_kernel (key blocks of 16), 4 = zz_local_trackp_kernel
- * -- all of them commit the same sequence.  The choice fixes the queue's layout: call it BEFORE set_state. */
+/* gradient tracking: which kernel runs where the one-proposal-per-lane kernel applies (plain lattice graph, no adaptation, 2048 <= d <= 16384).
+ * 0 = default (zz_local_trackp_kernel: (key, t_old) pairs in blocks of 8, one dirty line per rejected proposal), 1 = the 8-lane-group kernel
+ * (zz_local_track_kernel, which also serves adaptation, a target mean, a looser bounding Γ and lattice-like graphs) -- both compute the same
+ * floats and commit the same sequence.  The choice fixes the queue's layout: call it BEFORE set_state.  (Rounds 1-2 carried two more
+ * variants, key blocks of 32 and of 16 in the record layout; they were superseded and removed.) */
 pdmp_status pdmp_debug_set_track_groups(pdmp_ensemble* ens, int which);
 /* one-event kernel: print the first n proposals of chain 0 to stderr during the next run */
 pdmp_status pdmp_debug_set_proposal_dump(pdmp_ensemble* ens, int64_t n);

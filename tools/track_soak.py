@@ -19,7 +19,7 @@ G = pkg.problems.gmrf_precision(128)
 d = G.shape[0]
 c = pkg.problems.column_norms(G)
 ens = {}
-for name, tracked, which in (("pairs", True, 0), ("blocks16", True, 3), ("exact", False, 0)):
+for name, tracked, which in (("pairs", True, 0), ("blocks16", True, 1), ("exact", False, 0)):  # ("blocks16": now the 8-lane-group kernel)
     e = pkg.Ensemble(4096, d, trace_capacity=0)
     pkg._lib.check(e._L.pdmp_debug_set_track_groups(e._h, which))
     e.set_flow(pkg.ZigZag(G, np.zeros(d)))

@@ -329,7 +329,7 @@ pdmp_status pdmp_debug_phase_profile(pdmp_ensemble* e, double* out16, int* kind)
 }
 pdmp_status pdmp_debug_set_track_groups(pdmp_ensemble* e, int on) {
     if (!e) return fail(PDMP_ERR_INVALID, "null argument");
-    e->dbg_track_groups = (on >= 0 && on <= 4) ? on : 0;
+    e->dbg_track_groups = (on == 1) ? 1 : 0;
     return PDMP_OK;
 }
 pdmp_status pdmp_debug_set_proposal_dump(pdmp_ensemble* e, int64_t n) {
@@ -1086,9 +1086,7 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
         G.track_two_sums = e->track_two_sums ? 1 : 0;
         G.has_refresh = e->lambda_ref > 0;
         G.d = d;
-        // (t0 > 0: the reference's initial keys carry no t0 (src/sfact.jl:186), so the first proposals lie BEFORE the clocks' start and
-        // t_old = max(tprop, tg), which the pair layout relies on, does not hold while time runs backwards: the record-layout kernels serve those)
-        if (pdmp::zz_trackp_supported(G) && !(t0 > 0.0) && (e->dbg_track_groups == 0 || e->dbg_track_groups == 4)) {
+        if (pdmp::zz_trackp_supported(G) && e->dbg_track_groups == 0) {
             if (e->d_kp.n != (size_t)(2 * n * e->dk) && (st = e->d_kp.alloc((size_t)(2 * n * e->dk))) != PDMP_OK) return st;
             rc = pdmp::launch_zz_keys_to_pairs(e->d_keys.p, e->d_kp.p, n * e->dk, t0, e->stream);
             if (rc != 0) return fail(PDMP_ERR_HIP, "keys_to_pairs launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -1273,7 +1271,7 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         P.track_two_sums = e->track_two_sums ? 1 : 0;
         P.lattice_n = e->lattice_n;
         P.lattice_magic = e->lattice_n ? (uint32_t)(((uint64_t)1 << 32) / (uint64_t)e->lattice_n + 1) : 0u;
-        // one proposal per lane where the graph is the plain lattice (pdmp_trackw.hip); PDMP_DEBUG_KERNEL_SPEC4 keeps the 8-lane-group kernel
+        // one proposal per lane where the graph is the plain lattice (pdmp_trackp.hip); elsewhere, and on request, the 8-lane-group kernel
         if (e->track_pairs) {
             P.keys = e->d_kp.p;
             int rcp = pdmp::launch_zz_local_trackp(P, e->cfg.nchains, s);
@@ -1287,11 +1285,7 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
             }
             return PDMP_OK;
         }
-        const bool wide = pdmp::zz_trackw_supported(P) && e->dbg_track_groups != 1;
-        const bool wide16 = wide && pdmp::zz_trackx_supported(P) && e->dbg_track_groups != 2;
-        int rct = wide16 ? pdmp::launch_zz_local_trackx(P, e->cfg.nchains, s)
-                  : wide ? pdmp::launch_zz_local_trackw(P, e->cfg.nchains, s)
-                         : pdmp::launch_zz_local_track(P, e->cfg.nchains, s);
+        int rct = pdmp::launch_zz_local_track(P, e->cfg.nchains, s);
         if (rct != 0) return fail(PDMP_ERR_HIP, "zz_local_track launch failed (%d)", rct);
         HIP_TRY(hipEventRecord(e->ev1, s));
         e->timed = true;

@@ -4,18 +4,21 @@
 // What bounds pdmp_trackx.hip is the memory system, and mostly its write-backs: a rejected proposal (82 %) reads its record line
 // and its key block's line and dirties BOTH (bound + proposal time in the record, the new key in the key block); a dirty line costs about 1.8
 // line reads.  Here a rejected proposal dirties one line:
-//   * the queue's level 0 holds PAIRS (key, time of the coordinate's last proposal), 8 coordinates per 128-byte line; the record is only READ by
-//     a proposal -- its bound is re-derived, bit for bit, from what the record and the pair hold: t_old = max(tprop, tg), a = c + (g + gd (t_old − tg)) θ,
-//     b = c/100 + θ gd (every re-bound happens either at the coordinate's own proposal or when g, gd are re-based, so these are the stored values);
+//   * the queue's level 0 holds PAIRS (key, t_old = the time the coordinate's bound was last computed: its own last proposal or the last
+//     re-basing of its sums, whichever came later), 8 coordinates per 128-byte line; the record is only READ by a proposal -- its bound is
+//     re-derived, bit for bit, from what the record and the pair hold: a = c + (g + gd (t_old − tg)) θ, b = c/100 + θ gd (every re-bound happens
+//     either at the coordinate's own proposal or when g, gd are re-based, so these are the stored values);
 //   * 2048 blocks of 8 do not fit the LDS as doubles, so level 1 is a LOWER BOUND of each block's minimum: (min − base) rounded down to a float,
 //     minus 8 ulp, with the argument's position in the three low bits, compared as integers.  Every block whose bound is within the threshold is
 //     a candidate; its line is read anyway (the exposure test needs the block's second key), which yields the exact minimum -- candidates are
 //     ranked by exact keys, those beyond the exact threshold are no events and just refresh their bound.  Bounds may go stale LOW (a block
 //     minimum whose key rose: its neighbour re-bounds it), never high: lowering is an LDS atomic minimum, and no rescans exist any more.  The
 //     record of a candidate is requested together with its line using the position bits; a position that turns out wrong ends the list there.
-// The committed sequence and every float are those of pdmp_trackx.hip (index-exact against the oracle, floats to ~1e-13).
-// t_old = max(tprop, tg) needs time to run forwards: ensembles started at t0 > 0 (whose first proposals lie before t0, the reference's initial
-// keys carry no t0) keep the record layout (pdmp_capi.hip).
+// The committed sequence and every float are those of the oracle's tracked evaluation (oracle/pdmp_oracle.c: spdmp_zigzag_tracked), bit for bit;
+// against the moving evaluation: index-exact, floats to ~1e-13.  Ensembles started at t0 > 0 -- whose first proposals lie BEFORE t0, the
+// reference's initial keys carry no t0 (src/sfact.jl:186) -- run here too: t_old is stored, not inferred from an order of times.  The final
+// clocks (zz_track_unpack_kernel) take t_old where the record layout has the time of the last own proposal: the same maximum, because a
+// re-basing of j's sums is an accepted event of some n ∈ G1[j], which moved all of S[n] ⊇ G1[j] and is counted there.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     double* const SELDT = reinterpret_cast<double*>(smem + W_SELDT);
 
     TrRecP* const rec = reinterpret_cast<TrRecP*>(P.rec) + chain * d;
-    double2* const kp = reinterpret_cast<double2*>(P.keys) + chain * P.dk;  // (key, time of the last own proposal) per coordinate
+    double2* const kp = reinterpret_cast<double2*>(P.keys) + chain * P.dk;  // (key, t_old) per coordinate
     DevChain* const hdr = P.hdr + chain;
     pdmp_event* const evout = P.ev ? P.ev + chain * P.trace_cap : nullptr;
 
@@ -533,9 +536,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         // ---------------- rates from the tracked sums (src/sfact.jl:116-119 with g_i(t′) = g_i + gd_i (t′ − tg_i))
         const double g_now = g_i + gd_i * (tp - tg_i);
         const double l = w_pos(g_now * th);
-        // the bound in force (src/fact_samplers.jl:50-54), re-derived: it was computed at told = the later of the coordinate's last proposal and
-        // the last re-basing of its sums, from exactly these operands
-        const double told_i = (tprop_i > tg_i) ? tprop_i : tg_i;
+        // the bound in force (src/fact_samplers.jl:50-54), re-derived: it was computed at t_old (the coordinate's last proposal or the last
+        // re-basing of its sums, whichever came later: stored with the key) from exactly these operands
+        const double told_i = tprop_i;
         const double a_i = c_i + (g_i + gd_i * (told_i - tg_i)) * th;
         const double b_i = c_i2.y + th * gd_i;
         const double lbound = w_pos(a_i + b_i * (tp - told_i));
@@ -762,8 +765,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         // ---------------- commit the valid prefix
         const bool commit = ev && (uint32_t)lane < Rc;
         if (commit && !acc) {  // a rejected proposal: ONE 16-byte store (the record stays clean), and the block's new bound
-            if (rekey_by < Rc) kp[i].y = tp;  // (a later accepted neighbour of this iteration stores the key)
-            else kp[i] = make_double2(key2, tp);
+            if (!(rekey_by < Rc)) kp[i] = make_double2(key2, tp);  // (else a later accepted neighbour of this iteration re-bounds i: its pair)
             lbf[blk] = (rowmin < W_INF) ? p_enc(rowmin, tb, cand & 7u) : P_INFBITS;
         }
         const bool gcommit = gact && ea < Rc;
@@ -773,8 +775,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 rj->g = gj;
                 rj->gd = gdj;
                 rj->tg = tpa;
-                if (selfl) kp[jm] = make_double2(keyj, tpa);  // (its own proposal)
-                else kp[jm].x = keyj;                         // (the time of j's last own proposal stays)
+                kp[jm] = make_double2(keyj, tpa);  // (the bound of every member is computed now)
             }
             if (selfl) {
                 ria->x = xa;
