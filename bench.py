@@ -306,12 +306,14 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
+    comm = None  # the engine's own RCCL communicator (pdmp_comm_*): the default for N > 1 and for --gather -- no torch in the process
     # test hooks (never set by the driver): run several ranks on ONE device with the gloo backend to exercise the N>1 path
-    backend = os.environ.get("PDMP_BENCH_BACKEND", "nccl")
+    # (RCCL refuses two ranks on one GPU); PDMP_BENCH_BACKEND=nccl selects torch.distributed over RCCL, the round-2 path
+    backend = os.environ.get("PDMP_BENCH_BACKEND", "engine")
     if os.environ.get("PDMP_BENCH_SINGLE_DEVICE"):
         local_rank = 0
     red_dev = "cpu"
-    if world > 1:
+    if world > 1 and backend != "engine":
         import torch
         import torch.distributed as dist
         if backend == "nccl":
@@ -321,8 +323,8 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    if world == 1 and args.gather:
-        # the exchange is written against torch.distributed: a one-rank group makes N = 1 run the very same code
+    if world == 1 and args.gather and backend != "engine":
+        # the exchange written against torch.distributed: a one-rank group makes N = 1 run the very same code
         import torch
         import torch.distributed as dist1
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -339,12 +341,17 @@ def main():
     pkg.build.build()
     if pkg._lib.device_count() < 1:
         raise SystemExit("bench.py: no gfx950 device visible; the engine has no CPU fallback")
+    if backend == "engine" and (world > 1 or args.gather):
+        # ncclCommInitRank through the library (the 128-byte id travels over a TCP rendezvous on MASTER_ADDR: parallel.exchange_unique_id)
+        comm = pkg.parallel.Comm(rank, world, local_rank)
     W = make_workload(pkg, args, rank, local_rank)
     ens, d, cap, nch = W["ens"], W["d"], W["cap"], args.chains
     G, c = W.get("G"), W.get("c")
 
     def barrier():
         ens.sync()
+        if comm is not None:
+            comm.barrier()
         if dist is not None:
             dist.barrier()
             if red_dev == "cuda":
@@ -481,7 +488,26 @@ def main():
 
     # post-run exchange (never inside `value`): SURVEY 8e1
     gather = None
-    if args.gather and cap:
+    if args.gather and cap and comm is not None:
+        Tg = (args.warmup + args.steps + 1) * args.dt
+        T_prev = (args.warmup + args.steps) * args.dt
+        ens.batch_means(0.0, T_prev)  # baseline J(T_prev)
+        ens.run(Tg, pkg._lib.RUN_STOP_BEFORE)
+        barrier()
+        tg0 = time.perf_counter()
+        widths, counts_all, devbuf = comm.gather_traces(ens, root=0, to_host=False)  # the events stay on the root's device
+        sy, sy2 = comm.reduce_moments(ens, T_prev, Tg, root=0)
+        barrier()
+        tg = float(comm.allreduce([time.perf_counter() - tg0], "max")[0])
+        if rank == 0:
+            nev_g = int(counts_all.sum())
+            assert devbuf[1] == nev_g
+            gather = {"seconds": tg, "events": nev_g, "bytes": 32 * nev_g, "GBps": 32 * nev_g / tg / 1e9, "chains": int(widths.sum()),
+                      "staging": "device", "backend": "engine (librccl linked by libpdmp_mi355.so)",
+                      "steps": "ncclAllGather(counts) -> device compaction -> grouped ncclSend/ncclRecv of the trace segments to rank 0 -> "
+                               "ncclReduce(SUM) of 2 x d sums (pdmp_ensemble_gather_traces, pdmp_ensemble_reduce_moments)",
+                      "mean_of_batch_means": float(np.mean(sy) / (nch * world))}
+    elif args.gather and cap:
         import torch
         par = pkg.parallel
         Tg = (args.warmup + args.steps + 1) * args.dt if ess is None else None
@@ -513,7 +539,10 @@ def main():
                       "mean_of_batch_means": float(np.mean(sy) / (nch * world))}
 
     # aggregate over ranks: max time, summed work
-    if dist is not None:
+    if comm is not None and world > 1:
+        elapsed = float(comm.allreduce([elapsed], "max")[0])
+        num_all, nacc_all, nev_all, bad_all = [float(v) for v in comm.allreduce([float(num), float(nacc), float(nev), float(bad)], "sum")]
+    elif dist is not None:
         import torch
         tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -529,7 +558,13 @@ def main():
         c0 = cnt[0]
         mine = {"rank": rank, "seed_first": int(SEED0 + rank * nch), "num": int(num), "nacc": int(nacc), "nevents": int(nev),
                 "chain0": {"num": int(c0["num"]), "nacc": int(c0["nacc"]), "ndraw_main": int(c0["ndraw_main"]), "t_last": float(c0["t_last"])}}
-        if dist is not None:
+        if comm is not None and world > 1:
+            vec = np.zeros((world, 8))
+            vec[rank] = [mine["seed_first"], mine["num"], mine["nacc"], mine["nevents"], c0["num"], c0["nacc"], c0["ndraw_main"], c0["t_last"]]
+            vec = comm.allreduce(vec, "sum").reshape(world, 8)
+            per_rank = [{"rank": r, "seed_first": int(v[0]), "num": int(v[1]), "nacc": int(v[2]), "nevents": int(v[3]),
+                         "chain0": {"num": int(v[4]), "nacc": int(v[5]), "ndraw_main": int(v[6]), "t_last": float(v[7])}} for r, v in enumerate(vec)]
+        elif dist is not None:
             per_rank = [None] * world
             dist.all_gather_object(per_rank, mine)
         else:
@@ -568,7 +603,8 @@ def main():
             "data": "synthetic",
             "evaluation": ("exact" if args.exact else "tracked") if args.config == "C3" else "exact",
             "config": {"workload": W["workload"] + (f"; evaluation: {W['evaluation']}" if "evaluation" in W else ""),
-                       "chains_per_gpu": nch, "d": d, "dT": args.dt, "parallelism": f"chains sharded x{world}, no collective in the run"},
+                       "chains_per_gpu": nch, "d": d, "dT": args.dt, "parallelism": f"chains sharded x{world}, no collective in the run"
+                                      + (" (reductions of this line: " + ("pdmp_comm_allreduce, RCCL linked by the engine" if comm is not None else "torch.distributed " + backend) + ")" if world > 1 else "")},
             "proposals_per_s": num_all / elapsed,
             # (sticky chains reset (acc, num) whenever a bound adapts, src/ss_fact.jl:134: no acceptance ratio can be formed from them)
             "acceptance": (nacc_all / max(num_all, 1.0)) if args.config != "C5" else None,
@@ -593,6 +629,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(pkg, G, c) if args.config == "C3" else cpu_baseline_config(pkg, args.config)
         print(json.dumps(out), flush=True)
     ens.close()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -364,6 +364,44 @@ pdmp_status pdmp_ensemble_bps_trace_copy(pdmp_ensemble* ens, int64_t chain, int6
 pdmp_status pdmp_ensemble_bps_final_state(pdmp_ensemble* ens, int64_t chain_first, int64_t n, double* t, double* x,
                                           double* theta, double* c);
 
+/* what the ensemble was created with (any pointer may be NULL) */
+pdmp_status pdmp_ensemble_info(pdmp_ensemble* ens, int64_t* nchains, int64_t* d, int64_t* trace_capacity, int* device);
+
+/* ------------------------------------------------------------------ the post-run exchange of a sharded ensemble (RCCL over xGMI)
+ *
+ * Chains are independent: rank r of R runs its own block of them with NO collective (one process, one ensemble, one communicator per GPU).
+ * What follows a run (nothing in the reference -- it is single-process):
+ *   pdmp_comm_unique_id     on ONE rank: an opaque PDMP_COMM_ID_BYTES token (ncclGetUniqueId) the host hands to the other ranks by its own means
+ *                           (MPI.jl, a file, a socket: zigzagboomerang.jl_amd/parallel.py uses a TCP rendezvous on MASTER_ADDR);
+ *   pdmp_comm_init          on every rank, collectively (ncclCommInitRank on `device`);
+ *   pdmp_comm_barrier / pdmp_comm_allreduce (host doubles, PDMP_COMM_SUM | PDMP_COMM_MAX): timing and counter reductions of a benchmark;
+ *   pdmp_ensemble_gather_traces   collective.  Every rank learns nchains_by_rank [world] and counts (events in the trace buffer of every
+ *                           chain of the whole ensemble, rank-major; counts_cap entries available).  The trace segments travel to `root`:
+ *                           ncclAllGather of the counts -> each rank compacts its segments on the device -> ONE grouped ncclSend / ncclRecv
+ *                           (a gatherv: every peer streams over its own direct xGMI link).  On root the events of all chains lie back to back in
+ *                           rank-major, chain-major order in a device buffer the communicator owns (*events_dev, valid until the next gather on
+ *                           it or pdmp_comm_destroy) and, if events_host != NULL, are copied there (events_cap events available);
+ *   pdmp_ensemble_reduce_moments  collective: pdmp_ensemble_batch_means on every rank, ncclReduce(sum) of the 2 d sums onto root's sum_y, sum_y2.
+ * Calls on one communicator are serialised by the caller.  world = 1 is valid (the same code path on one GPU).
+ */
+#define PDMP_COMM_ID_BYTES 128
+#define PDMP_COMM_SUM 0
+#define PDMP_COMM_MAX 1
+typedef struct pdmp_comm pdmp_comm;
+pdmp_status pdmp_comm_unique_id(void* id, int64_t id_bytes);
+pdmp_status pdmp_comm_init(const void* id, int rank, int world, int device, pdmp_comm** out);
+void pdmp_comm_destroy(pdmp_comm* comm);
+pdmp_status pdmp_comm_info(const pdmp_comm* comm, int* rank, int* world);
+pdmp_status pdmp_comm_barrier(pdmp_comm* comm);
+pdmp_status pdmp_comm_allreduce(pdmp_comm* comm, double* inout, int64_t n, int op);
+pdmp_status pdmp_ensemble_gather_traces(pdmp_ensemble* ens, pdmp_comm* comm, int root, int64_t* nchains_by_rank, uint64_t* counts,
+                                        int64_t counts_cap, pdmp_event* events_host, int64_t events_cap, void** events_dev,
+                                        int64_t* nevents_total);
+/* events [first, first + count) of what the last pdmp_ensemble_gather_traces left on this rank (root), device -> host */
+pdmp_status pdmp_comm_gathered_copy(pdmp_comm* comm, pdmp_event* out, int64_t first, int64_t count);
+pdmp_status pdmp_ensemble_reduce_moments(pdmp_ensemble* ens, pdmp_comm* comm, int root, double T_prev, double T, double* sum_y,
+                                         double* sum_y2);
+
 /* raw device pointers for zero-copy consumers (e.g. an RCCL gather of trace segments) */
 pdmp_status pdmp_ensemble_trace_dev(pdmp_ensemble* ens, void** events_dev, int64_t* capacity);
 pdmp_status pdmp_ensemble_counters_dev(pdmp_ensemble* ens, void** counters_dev);

@@ -111,7 +111,7 @@ def test_entry_points_of_the_wrong_family_return_a_status(gpu_pkg):
     with pkg.Ensemble(2, d, sampler=L.SAMPLER_BPS, trace_capacity=8) as ens:
         ens.set_flow_bps(pkg.BouncyParticle(I4, np.zeros(d), 1.0))
         ens.set_state_bps(0.0, np.zeros((2, d)), np.ones((2, d)), 1e-3, np.arange(2, dtype=np.uint64))
-        for call in (lambda: ens.set_flow(pkg.ZigZag(I4, np.zeros(d))), lambda: ens.set_target(pkg.GaussianTarget(I4)),
+        for call in (lambda: ens.set_flow(pkg.ZigZag(I4, np.zeros(d))),  # (set_target IS accepted here: a BouncyParticle with a target of its own)
                      lambda: ens.set_state(0.0, np.zeros((2, d)), np.ones((2, d)), np.ones(d), np.arange(2)),
                      lambda: ens.set_state_synthetic(0.0, np.ones(d), 1), lambda: ens.final_state(), lambda: ens.batch_means(0.0, 1.0),
                      lambda: ens.trace(0, 0, 1), lambda: ens.ess_begin(0.0), lambda: ens.set_local_bound(True)):
@@ -150,3 +150,41 @@ def test_entry_points_of_the_wrong_family_return_a_status(gpu_pkg):
             with pytest.raises(L.PdmpError) as ei:
                 call()
             assert ei.value.code == L.PDMP_ERR_UNSUPPORTED
+
+
+def test_engine_rccl_entry_points_world1(gpu_pkg):
+    """pdmp_comm_* / pdmp_ensemble_gather_traces / pdmp_ensemble_reduce_moments (RCCL linked by the library itself, no torch in the process):
+    a one-rank communicator runs the very code path of N ranks -- ncclCommInitRank, ncclAllGather of the counts, device-side compaction of the
+    trace segments, the grouped send / recv (empty at world 1: the root's own segment is a device copy), ncclReduce, ncclAllReduce."""
+    pkg = gpu_pkg
+    G = pkg.problems.gmrf_precision(8)
+    d, nch, cap = 64, 5, 4096
+    c = pkg.problems.column_norms(G)
+    with pkg.parallel.Comm(0, 1, 0) as comm, pkg.Ensemble(nch, d, trace_capacity=cap) as ens:
+        ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
+        ens.set_target(pkg.GaussianTarget(G))
+        ens.set_state_synthetic(0.0, c, 77)
+        ens.run(10.0, pkg._lib.RUN_STOP_BEFORE)
+        cnt = ens.counters()
+        widths, counts, ev = comm.gather_traces(ens)
+        host = np.concatenate([ens.trace(k, counters=cnt) for k in range(nch)])
+        assert widths.tolist() == [nch] and counts.tolist() == cnt["ntrace"].tolist() and len(host) > 1000
+        assert np.array_equal(ev, host)  # chain-major, event order inside a chain
+        w2, c2, devbuf = comm.gather_traces(ens, to_host=False)
+        assert devbuf[1] == len(host) and devbuf[0]
+        s1, s2 = ens.batch_means(0.0, 10.0)
+        with pkg.Ensemble(nch, d, trace_capacity=cap) as e2:  # (batch_means keeps a running J: a fresh ensemble for the collective form)
+            e2.set_flow(pkg.ZigZag(G, np.zeros(d)))
+            e2.set_target(pkg.GaussianTarget(G))
+            e2.set_state_synthetic(0.0, c, 77)
+            e2.run(10.0, pkg._lib.RUN_STOP_BEFORE)
+            r1, r2 = comm.reduce_moments(e2, 0.0, 10.0)
+        assert np.array_equal(r1, s1) and np.array_equal(r2, s2)
+        assert comm.allreduce([1.5, -2.0], "max").tolist() == [1.5, -2.0] and comm.allreduce([3.0], "sum").tolist() == [3.0]
+        comm.barrier()
+        with pytest.raises(pkg._lib.PdmpError):  # an ensemble without a trace buffer has nothing to gather
+            with pkg.Ensemble(1, d) as e0:
+                e0.set_flow(pkg.ZigZag(G, np.zeros(d)))
+                e0.set_target(pkg.GaussianTarget(G))
+                e0.set_state_synthetic(0.0, c, 1)
+                comm.gather_traces(e0)

@@ -96,3 +96,40 @@ def test_world2_gather_and_reduce_match_single_process(pkg):
         assert root[1][k] == r["events"].tobytes()
         ys.append(pkg.trace.moments(pkg.FactTrace(None, 0.0, x0, th0, r["events"]), 5.0)[0])
     assert np.allclose(root[2], np.sum(ys, axis=0)) and np.allclose(root[3], np.sum(np.square(ys), axis=0))
+
+
+def _uid_worker(rank, world, port, q):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from __graft_entry__ import load_package
+    par = load_package().parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    uid = par.exchange_unique_id(rank, world, lambda: bytes(range(128)), timeout=60.0)
+    q.put((rank, uid))
+
+
+def test_unique_id_rendezvous_three_ranks():
+    """The host-side hand-over of the RCCL communicator id (parallel.exchange_unique_id: a bare TCP rendezvous next to MASTER_PORT), three
+    processes, the clients started BEFORE the server exists: every rank ends up with rank 0's 128 bytes."""
+    import multiprocessing as mp
+    import socket
+    import time
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_uid_worker, args=(r, 3, port, q)) for r in (2, 1)]
+    for p in ps:
+        p.start()
+    time.sleep(1.0)
+    p0 = ctx.Process(target=_uid_worker, args=(0, 3, port, q))
+    p0.start()
+    got = dict(q.get(timeout=120) for _ in range(3))
+    for p in ps + [p0]:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0] == got[1] == got[2] == bytes(range(128))

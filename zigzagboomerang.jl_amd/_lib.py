@@ -38,7 +38,9 @@ EXPORTED_SYMBOLS = [
     "pdmp_ensemble_bps_final_state", "pdmp_ensemble_set_sticky", "pdmp_ensemble_set_adaptscale", "pdmp_ensemble_final_sigma", "pdmp_ensemble_set_flow_boomerang", "pdmp_ensemble_set_local_bound", "pdmp_ensemble_set_target_logistic", "pdmp_ensemble_set_flow_factboomerang",
     "pdmp_ensemble_set_mass_cholesky", "pdmp_ensemble_set_bps_options",
     "pdmp_ensemble_ess_begin", "pdmp_ensemble_ess_batch", "pdmp_ensemble_ess_end", "pdmp_ensemble_set_gradient_tracking",
-    "pdmp_ensemble_path_integrals", "pdmp_ensemble_set_path_integrals", "pdmp_ensemble_set_neighbourhood",
+    "pdmp_ensemble_path_integrals", "pdmp_ensemble_set_path_integrals", "pdmp_ensemble_set_neighbourhood", "pdmp_ensemble_info",
+    "pdmp_comm_unique_id", "pdmp_comm_init", "pdmp_comm_destroy", "pdmp_comm_info", "pdmp_comm_barrier", "pdmp_comm_allreduce",
+    "pdmp_ensemble_gather_traces", "pdmp_ensemble_reduce_moments", "pdmp_comm_gathered_copy",
 ]
 # include/pdmp_debug.h: diagnostics, not part of the drop-in boundary
 DEBUG_SYMBOLS = ["pdmp_debug_set_kernel", "pdmp_debug_set_spec_g2", "pdmp_debug_set_phase_profile", "pdmp_debug_phase_profile",
@@ -104,6 +106,17 @@ def load():
     L.pdmp_ensemble_path_integrals.argtypes = [vp, f64, i64, vp, vp]
     L.pdmp_ensemble_set_path_integrals.argtypes = [vp, C.c_int]
     L.pdmp_ensemble_set_neighbourhood.argtypes = [vp, vp, vp]
+    L.pdmp_ensemble_info.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(C.c_int)]
+    L.pdmp_comm_unique_id.argtypes = [vp, i64]
+    L.pdmp_comm_init.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.pdmp_comm_destroy.argtypes = [vp]
+    L.pdmp_comm_destroy.restype = None
+    L.pdmp_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.pdmp_comm_barrier.argtypes = [vp]
+    L.pdmp_comm_allreduce.argtypes = [vp, vp, i64, C.c_int]
+    L.pdmp_ensemble_gather_traces.argtypes = [vp, vp, C.c_int, vp, vp, i64, vp, i64, C.POINTER(vp), C.POINTER(i64)]
+    L.pdmp_ensemble_reduce_moments.argtypes = [vp, vp, C.c_int, f64, f64, vp, vp]
+    L.pdmp_comm_gathered_copy.argtypes = [vp, vp, i64, i64]
     L.pdmp_ensemble_trace_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
     L.pdmp_ensemble_counters_dev.argtypes = [vp, C.POINTER(vp)]
     L.pdmp_debug_math_probe.argtypes = [C.c_int, C.c_uint64, i64, vp]
@@ -133,7 +146,7 @@ def load():
     L.pdmp_debug_set_track_groups.argtypes = [vp, C.c_int]
     for name in EXPORTED_SYMBOLS + DEBUG_SYMBOLS:
         fn = getattr(L, name)
-        if name not in ("pdmp_last_error", "pdmp_abi_version", "pdmp_device_count", "pdmp_ensemble_destroy"):
+        if name not in ("pdmp_last_error", "pdmp_abi_version", "pdmp_device_count", "pdmp_ensemble_destroy", "pdmp_comm_destroy"):
             fn.restype = C.c_int
     _lib = L
     return L

@@ -15,7 +15,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpdmp_mi355.so")
 SOURCES = ["pdmp_capi.hip", "pdmp_kernels.hip", "pdmp_bps.hip", "pdmp_general.hip", "pdmp_partition.hip", "pdmp_trackp.hip",
-           "pdmp_consume.hip", "pdmp_logistic.hip"]
+           "pdmp_consume.hip", "pdmp_logistic.hip", "pdmp_comm.hip"]
 HEADERS = [os.path.join(CSRC, "pdmp_engine.hpp"),
            os.path.join(PKG_DIR, "..", "include", "pdmp_mi355.h"),
            os.path.join(PKG_DIR, "..", "include", "pdmp_debug.h"),
@@ -88,7 +88,8 @@ def build(force=False, verbose=False, variant=None, defines=()):
                 with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:
                     objs = list(pool.map(compile_one, SOURCES))
                 tmp = lib_path + ".tmp.%d" % os.getpid()
-                cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
+                # (librccl for pdmp_comm.hip: the post-run gather / reduce links RCCL directly)
+                cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
                 if verbose:
                     print(" ".join(cmd))
                 subprocess.check_call(cmd)

@@ -201,6 +201,17 @@ extern "C" {
 const char* pdmp_last_error(void) {
     return g_err.c_str();
 }
+void pdmp_set_last_error_(const char* msg) {  // (pdmp_comm.hip: the other translation unit of the library)
+    g_err = msg ? msg : "";
+}
+pdmp_status pdmp_ensemble_info(pdmp_ensemble* e, int64_t* nchains, int64_t* d, int64_t* trace_capacity, int* device) {
+    if (!e) return fail(PDMP_ERR_INVALID, "null argument");
+    if (nchains) *nchains = e->cfg.nchains;
+    if (d) *d = e->cfg.d;
+    if (trace_capacity) *trace_capacity = e->cfg.trace_capacity;
+    if (device) *device = e->cfg.device;
+    return PDMP_OK;
+}
 
 int pdmp_abi_version(void) {
     return PDMP_ABI_VERSION;
