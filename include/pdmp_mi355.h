@@ -364,6 +364,29 @@ pdmp_status pdmp_ensemble_bps_trace_copy(pdmp_ensemble* ens, int64_t chain, int6
 pdmp_status pdmp_ensemble_bps_final_state(pdmp_ensemble* ens, int64_t chain_first, int64_t n, double* t, double* x,
                                           double* theta, double* c);
 
+/* ------------------------------------------------------------------ trace consumers on the device (what callers do next with Ξ)
+ *
+ * mean(Ξ) (src/trace.jl:182-200) and collect(discretize(Ξ, dt)) (:94-125) of every chain's FactTrace, computed from the engine's trace
+ * buffer slice by slice, so that a trace set far larger than the buffer (config C3: 8 MB per chain x 4096) is consumed without ever leaving
+ * the device:
+ *   consume_begin(grid_dt, grid_points)  after set_state, before the first run: snapshots (t0, x0, θ0) as every coordinate's cursor;
+ *                                        grid_points > 0 reserves [nchains x grid_points x d] doubles for the grid t0 + k·grid_dt;
+ *   consume()                            after EVERY run slice and before trace_reset: applies the buffered events (each coordinate's in
+ *                                        order) -- the trapezoid sums of mean, the grid points a finished segment covers;
+ *   consume_mean(chain_first, n, ...)    mean [n x d] and the last event time T of each chain (the reference's scale 1/(2T));
+ *   consume_discretized(chain, k_first, k_count, out, npoints, grid_dev)
+ *                                        rows k_first .. of chain's grid positions [k_count x d]; *npoints = number of grid times the
+ *                                        reference would emit so far (those before the chain's last event; at least t0); *grid_dev = the
+ *                                        whole device array, for consumers that stay on the device.  Any of the three may be NULL.
+ * Time-ordered traces of piecewise-linear paths only: ZigZag flow without refresh clock (spdmp, pdmp, sspdmp).  Values are those of
+ * zigzagboomerang.jl_amd/trace.py (discretize: bitwise; mean: the same sums scaled once instead of term by term).
+ */
+pdmp_status pdmp_ensemble_consume_begin(pdmp_ensemble* ens, double grid_dt, int64_t grid_points);
+pdmp_status pdmp_ensemble_consume(pdmp_ensemble* ens);
+pdmp_status pdmp_ensemble_consume_mean(pdmp_ensemble* ens, int64_t chain_first, int64_t n, double* mean, double* T_last);
+pdmp_status pdmp_ensemble_consume_discretized(pdmp_ensemble* ens, int64_t chain, int64_t k_first, int64_t k_count, double* out,
+                                              int64_t* npoints, void** grid_dev);
+
 /* what the ensemble was created with (any pointer may be NULL) */
 pdmp_status pdmp_ensemble_info(pdmp_ensemble* ens, int64_t* nchains, int64_t* d, int64_t* trace_capacity, int* device);
 

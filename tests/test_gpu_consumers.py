@@ -1,0 +1,106 @@
+"""Device-side trace consumers (pdmp_ensemble_consume_*, pdmp_consume.hip) against zigzagboomerang.jl_amd/trace.py on the SAME device traces
+(-m gpu): collect(discretize(Ξ, dt)) (src/trace.jl:94-125) bit for bit, mean(Ξ) (:182-200) to rounding (the same sums, scaled once instead of
+term by term) -- with a trace buffer far smaller than the trace, recycled after every slice, so the consumers see the events in pieces."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(pkg, ens, G, c, T_slices, dt, K, seed, tracked, sticky=None):
+    d = G.shape[0]
+    nch = ens.nchains
+    L = pkg._lib
+    ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
+    ens.set_target(pkg.GaussianTarget(G))
+    if sticky is not None:
+        ens.set_sticky(sticky)
+    if tracked:
+        ens.set_gradient_tracking(True)
+    rng = np.random.default_rng(seed)
+    x0, th0 = rng.standard_normal((nch, d)), rng.choice([-1.0, 1.0], (nch, d))
+    ens.set_state(0.0, x0, th0, c, np.arange(nch, dtype=np.uint64) + seed)
+    ens.consume_begin(dt, K)
+    evs = [[] for _ in range(nch)]
+    refills = 0
+    for Tk in T_slices:
+        while True:
+            ens.run(Tk, L.RUN_STOP_BEFORE)
+            cnt = ens.counters()
+            ens.consume()
+            for k in range(nch):
+                evs[k].append(ens.trace(k, counters=cnt))
+            ens.trace_reset()
+            if not np.any(cnt["status"] == L.CHAIN_TRACE_FULL):
+                break
+            refills += 1
+    traces = [pkg.FactTrace(None, 0.0, x0[k], th0[k], np.concatenate(evs[k])) for k in range(nch)]
+    return traces, refills
+
+
+@pytest.mark.parametrize("tracked", [False, True])
+def test_discretize_and_mean_on_the_device(gpu_pkg, tracked):
+    pkg = gpu_pkg
+    n = 48
+    G = pkg.problems.gmrf_precision(n)
+    d = n * n
+    c = pkg.problems.column_norms(G)
+    nch, dt, K = 3, 0.37, 64
+    with pkg.Ensemble(nch, d, trace_capacity=1500) as ens:  # ~2000 events per unit time: the buffer fills several times per slice
+        traces, refills = _run(pkg, ens, G, c, (2.0, 5.5, 9.0), dt, K, 50, tracked)
+        assert refills > 5
+        m, T = ens.consume_mean()
+        for k in range(nch):
+            tr = traces[k]
+            assert len(tr.events) > 10000 and T[k] == tr.events["t"][-1]
+            grid, X = pkg.trace.discretize(tr, dt)
+            got = ens.consume_discretized(k)
+            assert got.shape == X.shape and len(grid) > 20
+            assert np.array_equal(got, X)                       # bit for bit
+            ref = pkg.trace.mean(tr)
+            assert np.allclose(m[k], ref, rtol=1e-12, atol=1e-15)
+        # a later slice extends both (the cursors persist; points flushed earlier are re-emitted with the same values)
+        ens.run(11.0, pkg._lib.RUN_STOP_BEFORE)
+    # dense duplicates inside a chunk: d = 8 coordinates, every chunk of 256 events holds each of them ~32 times
+    G4 = pkg.problems.maintest_precision(8)
+    with pkg.Ensemble(2, 8, trace_capacity=300) as ens:
+        traces, refills = _run(pkg, ens, G4, 2.0 * pkg.problems.column_norms(G4), (40.0, 130.0), 0.9, 160, 7, False)
+        assert refills >= 1 and min(len(t.events) for t in traces) > 256
+        m, T = ens.consume_mean()
+        for k in range(2):
+            grid, X = pkg.trace.discretize(traces[k], 0.9)
+            assert np.array_equal(ens.consume_discretized(k), X) and len(grid) > 100
+            assert np.allclose(m[k], pkg.trace.mean(traces[k]), rtol=1e-12, atol=1e-15)
+
+
+def test_consumers_on_sticky_traces_and_refusals(gpu_pkg):
+    pkg = gpu_pkg
+    L = pkg._lib
+    n = 16
+    G = pkg.problems.gmrf_precision(n, 0.5)
+    d = n * n
+    c = 1.5 * pkg.problems.column_norms(G)
+    with pkg.Ensemble(2, d, sampler=L.SAMPLER_STICKY_ZIGZAG, factor=1.5, trace_capacity=900) as ens:
+        traces, refills = _run(pkg, ens, G, c, (6.0, 14.0), 0.5, 40, 3, False, sticky=np.full(d, 0.8))
+        m, T = ens.consume_mean()
+        for k in range(2):
+            assert np.sum(traces[k].events["theta"] == 0.0) > 20  # freezes in the trace
+            grid, X = pkg.trace.discretize(traces[k], 0.5)
+            assert np.array_equal(ens.consume_discretized(k), X)
+            assert np.allclose(m[k], pkg.trace.mean(traces[k]), rtol=1e-12, atol=1e-15)
+    with pkg.Ensemble(1, d, trace_capacity=100) as ens:
+        ens.set_flow(pkg.ZigZag(G, np.zeros(d), λref=0.2))
+        ens.set_target(pkg.GaussianTarget(G))
+        ens.set_state_synthetic(0.0, c, 1)
+        with pytest.raises(L.PdmpError) as ei:  # a refresh clock: the trace is not time-ordered (src/sfact.jl:84-85)
+            ens.consume_begin(0.5, 10)
+        assert ei.value.code == L.PDMP_ERR_UNSUPPORTED
+    with pkg.Ensemble(1, d, trace_capacity=100) as ens:
+        ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
+        ens.set_target(pkg.GaussianTarget(G))
+        ens.set_state_synthetic(0.0, c, 1)
+        with pytest.raises(L.PdmpError):
+            ens.consume()  # consume_begin first
+        ens.run(0.5, L.RUN_STOP_BEFORE)
+        with pytest.raises(L.PdmpError):
+            ens.consume_begin(0.5, 10)  # ... and before the first run

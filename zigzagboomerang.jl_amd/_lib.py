@@ -39,6 +39,7 @@ EXPORTED_SYMBOLS = [
     "pdmp_ensemble_set_mass_cholesky", "pdmp_ensemble_set_bps_options",
     "pdmp_ensemble_ess_begin", "pdmp_ensemble_ess_batch", "pdmp_ensemble_ess_end", "pdmp_ensemble_set_gradient_tracking",
     "pdmp_ensemble_path_integrals", "pdmp_ensemble_set_path_integrals", "pdmp_ensemble_set_neighbourhood", "pdmp_ensemble_info",
+    "pdmp_ensemble_consume_begin", "pdmp_ensemble_consume", "pdmp_ensemble_consume_mean", "pdmp_ensemble_consume_discretized",
     "pdmp_comm_unique_id", "pdmp_comm_init", "pdmp_comm_destroy", "pdmp_comm_info", "pdmp_comm_barrier", "pdmp_comm_allreduce",
     "pdmp_ensemble_gather_traces", "pdmp_ensemble_reduce_moments", "pdmp_comm_gathered_copy",
 ]
@@ -107,6 +108,10 @@ def load():
     L.pdmp_ensemble_set_path_integrals.argtypes = [vp, C.c_int]
     L.pdmp_ensemble_set_neighbourhood.argtypes = [vp, vp, vp]
     L.pdmp_ensemble_info.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(C.c_int)]
+    L.pdmp_ensemble_consume_begin.argtypes = [vp, f64, i64]
+    L.pdmp_ensemble_consume.argtypes = [vp]
+    L.pdmp_ensemble_consume_mean.argtypes = [vp, i64, i64, vp, vp]
+    L.pdmp_ensemble_consume_discretized.argtypes = [vp, i64, i64, i64, vp, C.POINTER(i64), C.POINTER(vp)]
     L.pdmp_comm_unique_id.argtypes = [vp, i64]
     L.pdmp_comm_init.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     L.pdmp_comm_destroy.argtypes = [vp]

@@ -139,6 +139,12 @@ struct pdmp_ensemble {
     DevBuf<double> lg_Anz, lg_Atnz, lg_y, lg_ny, lg_u0, lg_ns0;
     // packed tables of the LDS-resident logistic kernel (pdmp_logistic.hip); empty when the design does not qualify
     bool keep_integrals = true;  // pdmp_ensemble_set_path_integrals
+    // streaming trace consumers (pdmp_ensemble_consume_*): cursor per (chain, coordinate), per-chain progress, the discretisation grid
+    DevBuf<unsigned char> d_ccur, d_cmeta;
+    DevBuf<double> d_cgrid;
+    bool consuming = false;
+    double cons_dt = 0.0;
+    int64_t cons_K = 0;
     DevBuf<pdmp::LgCoord> lg_coord;
     DevBuf<pdmp::LgObs> lg_obs;
     DevBuf<uint32_t> lg_arow;
@@ -1110,6 +1116,7 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
     e->has_state = true;
     e->ran = false;
     e->timed = false;
+    e->consuming = false;
     return PDMP_OK;
 }
 
@@ -1525,6 +1532,91 @@ pdmp_status pdmp_ensemble_ess_end(pdmp_ensemble* e, double* sum_y, double* sum_y
     if (nbatches) *nbatches = e->ess_batches;
     if (T0) *T0 = e->ess_T0;
     if (T1) *T1 = e->ess_Tlast;
+    return PDMP_OK;
+}
+
+pdmp_status pdmp_ensemble_consume_begin(pdmp_ensemble* e, double grid_dt, int64_t grid_points) {
+    if (!e) return fail(PDMP_ERR_INVALID, "null argument");
+    NEED_FACTORISED(e);
+    if (!e->has_state || e->ran) return fail(PDMP_ERR_INVALID, "consume_begin follows set_state and precedes the first run (it snapshots x0, θ0)");
+    if (e->cfg.trace_capacity <= 0) return fail(PDMP_ERR_INVALID, "ensemble was created with trace_capacity = 0");
+    if (e->flow_kind != 0 || e->lambda_ref > 0)
+        return fail(PDMP_ERR_UNSUPPORTED, "the device consumers take time-ordered traces of piecewise-linear paths: ZigZag without refresh clock");
+    if (grid_points < 0 || (grid_points > 0 && !(grid_dt > 0))) return fail(PDMP_ERR_INVALID, "grid_dt must be positive");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const int64_t d = e->cfg.d, n = e->cfg.nchains;
+    pdmp_status st;
+    if ((st = e->d_ccur.alloc((size_t)(n * d) * pdmp::consume_cursor_bytes())) != PDMP_OK) return st;
+    if ((st = e->d_cmeta.alloc((size_t)n * pdmp::consume_meta_bytes())) != PDMP_OK) return st;
+    e->d_cgrid.release();
+    if (grid_points > 0) {
+        if ((st = e->d_cgrid.alloc((size_t)(n * grid_points * d))) != PDMP_OK) return st;
+        HIP_TRY(hipMemsetAsync(e->d_cgrid.p, 0, (size_t)(n * grid_points * d) * sizeof(double), e->stream));
+    }
+    int rc = pdmp::launch_consume_init(e->d_rec.p, e->track ? 128 : 64, d, n, e->t0_state, e->d_ccur.p, e->d_cmeta.p, e->stream);
+    if (rc != 0) return fail(PDMP_ERR_HIP, "consume_init launch failed: %s", hipGetErrorString((hipError_t)rc));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->consuming = true;
+    e->cons_dt = grid_dt;
+    e->cons_K = grid_points;
+    return PDMP_OK;
+}
+
+pdmp_status pdmp_ensemble_consume(pdmp_ensemble* e) {
+    if (!e) return fail(PDMP_ERR_INVALID, "null argument");
+    if (!e->consuming || !e->has_state) return fail(PDMP_ERR_INVALID, "pdmp_ensemble_consume_begin first");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    int rc = pdmp::launch_consume_events(e->d_ev.p, e->cfg.trace_capacity, e->d_hdr.p, e->cfg.d, e->cfg.nchains, e->d_ccur.p, e->d_cmeta.p,
+                                         e->d_cgrid.p, e->cons_K, e->t0_state, e->cons_dt, e->stream);
+    if (rc != 0) return fail(PDMP_ERR_HIP, "consume launch failed: %s", hipGetErrorString((hipError_t)rc));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return PDMP_OK;
+}
+
+pdmp_status pdmp_ensemble_consume_mean(pdmp_ensemble* e, int64_t chain_first, int64_t n, double* mean, double* T_last) {
+    if (!e || !mean) return fail(PDMP_ERR_INVALID, "null argument");
+    if (!e->consuming) return fail(PDMP_ERR_INVALID, "pdmp_ensemble_consume_begin first");
+    if (chain_first < 0 || n <= 0 || chain_first + n > e->cfg.nchains) return fail(PDMP_ERR_INVALID, "chain range");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const int64_t d = e->cfg.d;
+    DevBuf<double> bm, bt;
+    pdmp_status st;
+    if ((st = bm.alloc((size_t)(n * d))) != PDMP_OK) return st;
+    if ((st = bt.alloc((size_t)n)) != PDMP_OK) return st;
+    int rc = pdmp::launch_consume_mean(d, chain_first, n, e->d_ccur.p, e->d_cmeta.p, bm.p, bt.p, e->stream);
+    if (rc != 0) return fail(PDMP_ERR_HIP, "consume_mean launch failed: %s", hipGetErrorString((hipError_t)rc));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(mean, bm.p, (size_t)(n * d) * sizeof(double), hipMemcpyDeviceToHost));
+    if (T_last) HIP_TRY(hipMemcpy(T_last, bt.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    return PDMP_OK;
+}
+
+pdmp_status pdmp_ensemble_consume_discretized(pdmp_ensemble* e, int64_t chain, int64_t k_first, int64_t k_count, double* out, int64_t* npoints,
+                                              void** grid_dev) {
+    if (!e) return fail(PDMP_ERR_INVALID, "null argument");
+    if (!e->consuming || e->cons_K <= 0) return fail(PDMP_ERR_INVALID, "pdmp_ensemble_consume_begin with a grid first");
+    if (chain < 0 || chain >= e->cfg.nchains || k_first < 0 || k_count < 0 || k_first + k_count > e->cons_K)
+        return fail(PDMP_ERR_INVALID, "chain / grid range");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const int64_t d = e->cfg.d;
+    // the points after every coordinate's last event, up to the chain's last event time (idempotent)
+    int rc = pdmp::launch_consume_flush(d, e->cfg.nchains, e->d_ccur.p, e->d_cmeta.p, e->d_cgrid.p, e->cons_K, e->t0_state, e->cons_dt, e->stream);
+    if (rc != 0) return fail(PDMP_ERR_HIP, "consume_flush launch failed: %s", hipGetErrorString((hipError_t)rc));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (out && k_count)
+        HIP_TRY(hipMemcpy(out, e->d_cgrid.p + (chain * e->cons_K + k_first) * d, (size_t)(k_count * d) * sizeof(double), hipMemcpyDeviceToHost));
+    if (npoints) {
+        // collect(discretize(Ξ, dt)) emits a grid time while it lies before the last event (src/trace.jl:111-113); at least t0 itself
+        std::vector<unsigned char> mh(pdmp::consume_meta_bytes());
+        HIP_TRY(hipMemcpy(mh.data(), e->d_cmeta.p + (size_t)chain * pdmp::consume_meta_bytes(), mh.size(), hipMemcpyDeviceToHost));
+        double tl;
+        memcpy(&tl, mh.data() + 8, sizeof tl);
+        int64_t np = 0;
+        while (np < e->cons_K && e->t0_state + e->cons_dt * (double)np < tl) ++np;
+        *npoints = np > 0 ? np : 1;
+    }
+    if (grid_dev) *grid_dev = e->d_cgrid.p;
     return PDMP_OK;
 }
 

@@ -282,6 +282,31 @@ class Ensemble:
         _lib.check(self._L.pdmp_ensemble_batch_means(self._h, float(T_prev), float(T), _ptr(s1), _ptr(s2)))
         return s1, s2
 
+    # ---- trace consumers on the device (pdmp_ensemble_consume_*)
+    def consume_begin(self, grid_dt=0.0, grid_points=0):
+        _lib.check(self._L.pdmp_ensemble_consume_begin(self._h, float(grid_dt), int(grid_points)))
+
+    def consume(self):
+        _lib.check(self._L.pdmp_ensemble_consume(self._h))
+
+    def consume_mean(self, chain_first=0, n=None):
+        """(mean [n x d], T_last [n]): mean(Ξ) of src/trace.jl:182-200 per chain, from the device-side cursors."""
+        if n is None:
+            n = self.nchains - chain_first
+        m, T = np.empty((n, self.d)), np.empty(n)
+        _lib.check(self._L.pdmp_ensemble_consume_mean(self._h, int(chain_first), int(n), _ptr(m), _ptr(T)))
+        return m, T
+
+    def consume_discretized(self, chain, k_first=0, k_count=None):
+        """(grid times, positions [npoints x d]) of collect(discretize(Ξ, dt)) for one chain (src/trace.jl:94-125)."""
+        npts = C.c_int64()
+        _lib.check(self._L.pdmp_ensemble_consume_discretized(self._h, int(chain), 0, 0, None, C.byref(npts), None))
+        k_count = int(npts.value) - k_first if k_count is None else int(k_count)
+        out = np.empty((max(k_count, 0), self.d))
+        if k_count > 0:
+            _lib.check(self._L.pdmp_ensemble_consume_discretized(self._h, int(chain), int(k_first), k_count, _ptr(out), None, None))
+        return out
+
     def set_path_integrals(self, enable=True):
         """Keep ∫x_i dt next to the state (default) or not (pdmp_ensemble_set_path_integrals); before set_state."""
         _lib.check(self._L.pdmp_ensemble_set_path_integrals(self._h, int(bool(enable))))
