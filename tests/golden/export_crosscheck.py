@@ -65,7 +65,87 @@ def main():
         f.write("num %d\nacc %d\nevents %d\n" % (int(g["sticky1d_counts"][0]), int(g["sticky1d_counts"][1]), len(ev)))
         for e in ev:
             f.write("%s %d %s %s\n" % (hx([e["t"]]), int(e["i"]) + 1, hx([e["x"]]), hx([e["theta"]])))
+    write_more()
     print("wrote crosscheck_*.txt")
+
+
+def write_fact(f, r, d):
+    f.write("num %d\nacc %s\nnrefresh %d\nevents %d\n" % (r["num"], " ".join(str(int(a)) for a in r["acc"]), r["nrefresh"], len(r["events"])))
+    for e in r["events"]:
+        f.write("%s %d %s %s\n" % (hx([e["t"]]), int(e["i"]) + 1, hx([e["x"]]), hx([e["theta"]])))
+
+
+def write_more():
+    """Round 3: every other family the engine builds -- FactBoomerang spdmp, ZigZag with a refresh clock, the factorised LocalBound,
+    Boomerang, the subsampled logistic gradient -- so that ONE Julia run pins them all (tools/julia_crosscheck.jl: check_*)."""
+    rng = np.random.default_rng(11)
+    G = P.maintest_precision(8)
+    d = 8
+    c = P.column_norms(G)
+    # (a) FactBoomerang, test/maintest.jl:114-137: Z = FactBoomerang(1.2Γ, 0, 0.3), ∇ϕ(x, i, Γ) = idot(Γ, i, x)
+    x0 = rng.random(d)
+    Gf = sp.csc_matrix(1.2 * G)
+    th0 = rng.standard_normal(d) / np.sqrt(Gf.diagonal())
+    sigma = 1.0 / np.sqrt(Gf.diagonal())  # FactBoomerang(Γ, μ, λ) sets σ = (Vector(diag(Γ))).^(-0.5), src/types.jl:79
+    r = O.spdmp_zigzag(Gf, np.zeros(d), G, x0, th0, c, 30.0, seed=21, lambda_ref=0.3, sigma=sigma, factboomerang=True)
+    assert r["status"] == 0 and r["nrefresh"] > 3
+    with open(os.path.join(HERE, "crosscheck_factboomerang_d8.txt"), "w") as f:
+        f.write("sampler factboomerang\nseed 21\nT %s\nscale %s\nlambda_ref %s\n" % (hx([30.0]), hx([1.2]), hx([0.3])))
+        write_matrix(f, "Gamma", G)
+        f.write("x0 %s\ntheta0 %s\nc %s\n" % (hx(x0), hx(th0), hx(c)))
+        write_fact(f, r, d)
+    # (b) ZigZag with a refresh clock λref = 0.4 (src/sfact.jl:78-114; test/staticarrays.jl:45 uses one): σ = 1
+    x0, th0 = rng.standard_normal(d), rng.choice([-1.0, 1.0], d)
+    r = O.spdmp_zigzag(G, np.zeros(d), G, x0, th0, 1.5 * c, 40.0, seed=22, lambda_ref=0.4)
+    assert r["status"] == 0 and r["nrefresh"] > 5
+    with open(os.path.join(HERE, "crosscheck_zigzag_refresh_d8.txt"), "w") as f:
+        f.write("sampler zigzag_refresh\nseed 22\nT %s\nscale %s\nlambda_ref %s\n" % (hx([40.0]), hx([1.0]), hx([0.4])))
+        write_matrix(f, "Gamma", G)
+        f.write("x0 %s\ntheta0 %s\nc %s\n" % (hx(x0), hx(th0), hx(1.5 * c)))
+        write_fact(f, r, d)
+    # (c) factorised LocalBound, src/local.jl:95-149 with the (∇ϕi, vi) callback of performance/smartbound.jl:45-59; distinct c_i/|θ_i|
+    # (tied horizons are the one documented divergence: INTEGRATION.md)
+    x0 = rng.standard_normal(d)
+    th0 = rng.choice([-1.0, 1.0], d) * (1.0 + 0.1 * np.arange(d))
+    cl = 0.6 * c
+    r = O.spdmp_zigzag(G, np.zeros(d), G, x0, th0, cl, 25.0, seed=23, local_bound=True)
+    assert r["status"] == 0 and len(r["events"]) > 50
+    with open(os.path.join(HERE, "crosscheck_localbound_d8.txt"), "w") as f:
+        f.write("sampler localbound\nseed 23\nT %s\nscale %s\n" % (hx([25.0]), hx([1.0])))
+        write_matrix(f, "Gamma", G)
+        f.write("x0 %s\ntheta0 %s\nc %s\n" % (hx(x0), hx(th0), hx(cl)))
+        write_fact(f, r, d)
+    # (d) Boomerang, test/maintest.jl:139-154: B = Boomerang(Γ, 0, 0.5), c = 16, ∇ϕ!(y, x) = Γx, L = cholesky(Γ).L
+    x0, th0 = rng.standard_normal(d), rng.standard_normal(d)
+    Lc = np.tril(np.linalg.cholesky(G.toarray()))
+    r = O.pdmp_bps(G, None, x0, th0, 16.0, 15.0, lambda_ref=0.5, seed=24, ev_cap=5000, boomerang_mu=np.zeros(d), mass_L=sp.csc_matrix(Lc))
+    assert r["status"] == 0 and r["nevents"] > 5
+    with open(os.path.join(HERE, "crosscheck_boomerang_d8.txt"), "w") as f:
+        f.write("sampler boomerang\nseed 24\nT %s\nlambda_ref %s\nrho %s\nc %s\n" % (hx([15.0]), hx([0.5]), hx([0.0]), hx([16.0])))
+        write_matrix(f, "Gamma", G)
+        write_matrix(f, "L", Lc)
+        f.write("x0 %s\ntheta0 %s\n" % (hx(x0), hx(th0)))
+        f.write("num %d\nacc %d\nevents %d\n" % (r["num"], r["nacc"], r["nevents"]))
+        for k in range(r["nevents"]):
+            f.write("%s %s %s\n" % (hx([r["t_ev"][k]]), hx(r["x_ev"][k]), hx(r["theta_ev"][k])))
+    # (e) subsampled logistic gradient ∇ϕmoving (scripts/logistic.jl:78-107,167) on sparse_design([2, 2], 2, 6): n = 60, p = 10
+    Pl = P.logistic_problem(levels=(2, 2), r=2, m=6, seed=5)
+    p_ = Pl["p"]
+    lg = dict(A=Pl["A"], At=Pl["At"], y=Pl["y"], ny=Pl["ny"], mu=Pl["mu"], gamma0=Pl["gamma0"], k=3)
+    th0 = Pl["sigma"] * rng.choice([-1.0, 1.0], p_)
+    r = O.spdmp_zigzag(Pl["Gdrop"], Pl["mu"], Pl["Gdrop"], Pl["x0"], th0, Pl["c"], 30.0, seed=25, adapt=True, factor=5.0, logistic=lg, sigma=Pl["sigma"])
+    assert r["status"] == 0 and len(r["events"]) > 30
+    with open(os.path.join(HERE, "crosscheck_logistic_p%d.txt" % p_), "w") as f:
+        f.write("sampler logistic\nseed 25\nT %s\ngamma0 %s\nksub 3\nfactor %s\n" % (hx([30.0]), hx([Pl["gamma0"]]), hx([5.0])))
+        A = sp.coo_matrix(Pl["A"])
+        f.write("A %d %d %d\n" % (A.shape[0], A.shape[1], A.nnz))
+        for i, j, v in zip(A.row, A.col, A.data):
+            f.write("%d %d %s\n" % (i + 1, j + 1, hx([v])))
+        write_matrix(f, "Gamma", Pl["Gdrop"])
+        f.write("y %s\nny %s\nmu %s\nsigma %s\n" % (hx(Pl["y"]), hx(Pl["ny"]), hx(Pl["mu"]), hx(Pl["sigma"])))
+        f.write("x0 %s\ntheta0 %s\nc %s\ncout %s\n" % (hx(Pl["x0"]), hx(th0), hx(Pl["c"]), hx(r["c"])))
+        f.write("ndraw_global %d\n" % r["ndraw_global"])
+        write_fact(f, r, p_)
 
 
 if __name__ == "__main__":

@@ -8,6 +8,8 @@
 # whose n-th `rand(rng)` is draw n of the engine's stream (include/pdmp_detmath.h: pdmp_u01(seed, PDMP_STREAM_MAIN, n)) makes the
 # REFERENCE replay the very chain the oracle and the gfx950 kernels produce.  The fixtures tests/golden/crosscheck_*.txt hold the
 # inputs and the oracle's event lists (floats as IEEE-754 bit patterns; written by tests/golden/export_crosscheck.py).
+# Families covered (round 3: all the engine builds): local ZigZag (d8, grid8), BouncyParticle with L, sticky ZigZag, FactBoomerang,
+# ZigZag with a refresh clock, the factorised LocalBound, Boomerang with L, the subsampled logistic gradient.
 #
 # What is compared: the event INDEX sequence and (acc, num) exactly; event times, positions and velocities to 1e-9 relative
 # (north star: 1e-6).  They cannot be asked to agree to the last bit: the engine's log / sincos (pdmp_log, pdmp_sincos: < 1 ulp,
@@ -97,7 +99,7 @@ function read_fixture(path)
             k += n
         elseif key in ("sampler",)
             D[key] = w[2]
-        elseif key in ("seed", "num")
+        elseif key in ("seed", "num", "nrefresh", "ksub", "ndraw_global")
             D[key] = parse(Int, w[2])
         elseif key == "acc"
             D[key] = parse.(Int, w[2:end])
@@ -214,9 +216,218 @@ function check_sspdmp(path)
     println(basename(path), ": ", length(ev), " events (freeze / thaw / reflection), counts identical, max deviation ", worst)
 end
 
+# ================================================================== round 3: the other families the engine builds
+#
+# Draws the reference takes from Julia's GLOBAL rng inside spdmp_inner! -- `rand(1:n)` twice per refresh (src/sfact.jl:80,84) and
+# `waiting_time_ref(F)` = randexp()/λref (:108, src/dynamics.jl:99) -- and inside the scripts' subsampler (`rand(sampler)`,
+# scripts/logistic.jl:84) are draws of the chain's PDMP_STREAM_GLOBAL stream in the engine (include/pdmp_detmath.h): routed here the way
+# check_sspdmp routes `rand()`.
+const GLOBAL_STREAM = Ref{Union{Nothing,PhiloxRNG}}(nothing)
+global_bits!() = (g = GLOBAL_STREAM[]; b = bits64(g.seed, g.stream, g.n); g.n += 1; b)
+global_randint!(n) = Int(((global_bits!() >> 32) * UInt64(n)) >> 32) + 1                 # pdmp_randint, 1-based
+global_u01!() = (Float64(global_bits!() >> 12) + 0.5) * 2.0^-52
+function route_global_rng!(seed)
+    GLOBAL_STREAM[] = PhiloxRNG(UInt64(seed), 0x00000001, UInt64(0))                     # PDMP_STREAM_GLOBAL
+    @eval Random.rand(r::UnitRange{Int}) = first(r) - 1 + Main.global_randint!(length(r))
+    @eval Random.randexp() = -log(Main.global_u01!())
+end
+# rand(rng, (-1, 1)) of the ZigZag refresh (src/sfact.jl:101): the engine takes ONE uniform, u < 1/2 -> -1 (oracle/pdmp_oracle.c)
+Random.rand(r::PhiloxRNG, ::Random.SamplerTrivial{Tuple{Int,Int}}) = next!(r) < 0.5 ? -1 : 1
+Random.rand(r::PhiloxRNG, t::Tuple{Int,Int}) = next!(r) < 0.5 ? t[1] : t[2]
+# randn(rng, Float64) of the FactBoomerang refresh (:103): branch 0 of the Box-Muller pair of ONE Philox block (pdmp_randn)
+function Random.randn(r::PhiloxRNG, ::Type{Float64})
+    z0, _ = boxmuller2(r.seed, r.stream, r.n)
+    r.n += 1
+    z0
+end
+Random.randn(r::PhiloxRNG) = randn(r, Float64)
+
+function compare_fact(path, ev, acc, num, D; tol = 1e-9)
+    ref = D["events"]
+    @assert length(ev) == length(ref) "event count $(length(ev)) vs $(length(ref))"
+    worst = 0.0
+    for (e, r) in zip(ev, ref)
+        @assert e[2] == parse(Int, r[2]) "event index differs"
+        worst = max(worst, relerr(e[1], f64(r[1])), abs(e[3] - f64(r[3])), abs(e[4] - f64(r[4])))
+    end
+    @assert num == D["num"] && collect(acc) == D["acc"]
+    @assert worst < tol
+    println(basename(path), ": ", length(ev), " events, index sequence and (acc, num) identical, max deviation ", worst)
+end
+
+# spdmp with rng injected and the refresh key enqueued (src/sfact.jl:162-208 incl. :188-190)
+function spdmp_refresh_with_rng(rng, ∇ϕ, t0, x0, θ0, T, c, F, args...; factor = 1.8, adapt = false)
+    n = length(x0)
+    t′ = t0
+    t = fill(t′, size(θ0)...)
+    t_old = copy(t)
+    G1 = [i => rowvals(F.Γ)[nzrange(F.Γ, i)] for i in eachindex(θ0)]
+    G = G1
+    G2 = [i => setdiff(union((G1[j].second for j in G1[i].second)...), G[i].second) for i in eachindex(G1)]
+    x, θ = copy(x0), copy(θ0)
+    num = 0
+    acc = zeros(Int, length(θ))
+    Q = ZZB.SPriorityQueue{Int,Float64}()
+    b = [ZZB.ab(G1, i, x, θ, c, F) for i in eachindex(θ)]
+    for i in eachindex(θ)
+        ZZB.enqueue!(Q, i => poisson_time(b[i], rand(rng)))
+    end
+    if ZZB.hasrefresh(F)
+        ZZB.enqueue!(Q, (n + 1) => ZZB.waiting_time_ref(rng, F))                        # :189, the SEEDED stream
+    end
+    events = Tuple{Float64,Int,Float64,Float64}[]
+    while t′ < T
+        ev, t, x, θ, t′, (acc, num), c, b, t_old = ZZB.spdmp_inner!(rng, G, G1, G2, ∇ϕ, t, x, θ, Q, c, b, t_old, (acc, num), F,
+                                                                   args...; factor = factor, adapt = adapt)
+        push!(events, ev)
+    end
+    events, (t, x, θ), (acc, num), c
+end
+
+# FactBoomerang, test/maintest.jl:114-137; and the ZigZag with a refresh clock (src/sfact.jl:78-114)
+function check_refreshing(path)
+    D = read_fixture(path)
+    Γ = D["Gamma"]
+    d = size(Γ, 1)
+    F = D["sampler"] == "factboomerang" ? FactBoomerang(D["scale"] * Γ, zeros(d), D["lambda_ref"]) :
+                                          ZigZag(D["scale"] * Γ, zeros(d), ones(d); λref = D["lambda_ref"])
+    ∇ϕ(x, i, Γ) = ZZB.idot(Γ, i, x)
+    route_global_rng!(D["seed"])
+    ev, _, (acc, num), _ = spdmp_refresh_with_rng(PhiloxRNG(D["seed"]), ∇ϕ, 0.0, D["x0"], D["theta0"], D["T"], copy(D["c"]), F, Γ)
+    compare_fact(path, ev, acc, num, D)   # (refresh events are trace events too: the count and the indices cover them)
+end
+
+# factorised LocalBound, src/local.jl:95-149, with the Gaussian target's (∇ϕi, vi) callback (performance/smartbound.jl:45-59)
+function check_localbound(path)
+    D = read_fixture(path)
+    Γ = D["Gamma"]
+    d = size(Γ, 1)
+    F = ZigZag(Γ, zeros(d))
+    ∇ϕv(t, x, θ, i, t′, F, Γ) = (ZZB.idot(Γ, i, x), θ[i] * ZZB.idot(Γ, i, θ))
+    rng = PhiloxRNG(D["seed"])
+    C = ZZB.LocalBound(copy(D["c"]))
+    n, t0, T = d, 0.0, D["T"]
+    t′ = t0
+    t = fill(t′, d)
+    t_old = copy(t)
+    G = [i => rowvals(F.Γ)[nzrange(F.Γ, i)] for i in 1:d]
+    G2 = [i => setdiff(union((G[j].second for j in G[i].second)...), G[i].second) for i in eachindex(G)]
+    x, θ = copy(D["x0"]), copy(D["theta0"])
+    num = 0
+    acc = zeros(Int, d)
+    Q = ZZB.SPriorityQueue{Int,Float64}()
+    ∇ϕi, vi = ∇ϕv(t, x, θ, 1, t′, F, Γ)
+    b = fill(ZZB.ab(G, 1, x, θ, C, ∇ϕi, vi, F), n)
+    renew = zeros(Bool, n)
+    for i in 1:d                                                                        # src/local.jl:119-124
+        ∇ϕi, vi = ∇ϕv(t, x, θ, i, t′, F, Γ)
+        b[i] = ZZB.ab(G, i, x, θ, C, ∇ϕi, vi, F)
+        τ, renew[i] = ZZB.next_time(t[i], b[i], rand(rng))
+        ZZB.enqueue!(Q, i => τ)
+    end
+    events = Tuple{Float64,Int,Float64,Float64}[]
+    while t′ < T
+        ev, t, x, θ, t′, (acc, num), C, (b, renew), t_old = ZZB.spdmp_inner!(rng, G, G2, ∇ϕv, t, x, θ, Q, C, (b, renew), t_old, (acc, num), F, Γ)
+        push!(events, ev)
+    end
+    compare_fact(path, events, acc, num, D)
+end
+
+# Boomerang, test/maintest.jl:139-154, with its factor as given
+function check_boomerang(path)
+    D = read_fixture(path)
+    Γ, Lf = D["Gamma"], LowerTriangular(Matrix(D["L"]))
+    d = size(Γ, 1)
+    B = Boomerang(Γ, zeros(d), D["lambda_ref"], D["rho"], Lf)                           # the constructor with L as given (src/types.jl:59-66)
+    ∇ϕ!(y, x) = mul!(y, Γ, x)
+    rng = PhiloxRNG(D["seed"])
+    Flow, T = B, D["T"]
+    ∇w = ZZB.Wrapper(∇ϕ!)
+    cb = ZZB.GlobalBound(D["c"])
+    t, x, θ, ∇ϕx = 0.0, copy(D["x0"]), copy(D["theta0"]), copy(D["theta0"])
+    τref = ZZB.waiting_time_ref(rng, Flow)
+    ∇ϕx, v = ∇w(∇ϕx, t, x, θ)
+    ∇ϕx = ZZB.grad_correct!(∇ϕx, x, Flow)
+    num = acc = 0
+    abc = ZZB.ab(x, θ, cb, ∇ϕx, v, Flow)
+    t′, renew = ZZB.next_time(t, abc, rand(rng))
+    ref = D["events"]
+    k = 0
+    worst = 0.0
+    while t < T
+        t, x, θ, (acc, num), cb, abc, (t′, renew), τref, v = ZZB.pdmp_inner!(rng, ∇w, ∇ϕx, t, x, θ, cb, abc, (t′, renew), τref, v,
+                                                                             (acc, num), Flow)
+        k += 1
+        r = ref[k]
+        worst = max(worst, relerr(t, f64(r[1])))
+        for j in 1:d
+            worst = max(worst, abs(x[j] - f64(r[1+j])), abs(θ[j] - f64(r[1+d+j])))
+        end
+    end
+    @assert k == length(ref) && num == D["num"] && acc == D["acc"][1] "event or proposal counts differ"
+    @assert worst < 1e-8   # (the rotation's sincos and two triangular solves per event: looser than the factorised samplers)
+    println(basename(path), ": ", k, " events, counts identical, max deviation ", worst)
+end
+
+# the subsampled logistic gradient with its control variate, scripts/logistic.jl:78-95,107,167 -- the script's helper restated here
+# (it is not package code) with the package's own idot_moving! (src/common.jl:33-42) and the subsample indices on the global stream
+sigmoid_(x) = inv(one(x) + exp(-x))
+function fdot_moving_(A, At, j, t, x, θ, t′, F, μ, y, ny, k)
+    rows, vals = rowvals(A), nonzeros(A)
+    s = zero(eltype(A))
+    r = nzrange(A, j)
+    l = length(r)
+    for _ in 1:k
+        i = first(r) - 1 + global_randint!(l)                                           # rand(sampler), :84
+        u = ZZB.idot_moving!(At, rows[i], t, x, θ, t′, F)
+        s += l/k*vals[i]*y[rows[i]]*sigmoid_(-u)
+        s += l/k*vals[i]*ny[rows[i]]*(-sigmoid_(u))
+        u0 = ZZB.idot(At, rows[i], μ)
+        s -= l/k*vals[i]*y[rows[i]]*sigmoid_(-u0)
+        s -= l/k*vals[i]*ny[rows[i]]*(-sigmoid_(u0))
+    end
+    s
+end
+function read_logistic(path)   # the fixture carries the design as "A n p nnz" + triplets; everything else as read_fixture
+    L = readlines(path)
+    k = findfirst(l -> startswith(l, "A "), L)
+    w = split(L[k])
+    n, p, nnz = parse(Int, w[2]), parse(Int, w[3]), parse(Int, w[4])
+    I, J, V = Int[], Int[], Float64[]
+    for q in 1:nnz
+        a = split(L[k+q])
+        push!(I, parse(Int, a[1])); push!(J, parse(Int, a[2])); push!(V, f64(a[3]))
+    end
+    tmp = tempname()
+    write(tmp, join(vcat(L[1:k-1], L[k+nnz+1:end]), "\n") * "\n")
+    D = read_fixture(tmp)
+    D["A"] = sparse(I, J, V, n, p)
+    D
+end
+function check_logistic(path)
+    D = read_logistic(path)
+    A = D["A"]
+    At = SparseMatrixCSC(A')
+    γ0, ksub = D["gamma0"], D["ksub"]
+    Z = ZigZag(D["Gamma"], D["mu"], D["sigma"])
+    ∇ϕmoving(t, x, θ, i, t′, F, A, At, μ, y, ny, k) = γ0*x[i] - fdot_moving_(A, At, i, t, x, θ, t′, F, μ, y, ny, k)
+    route_global_rng!(D["seed"])
+    c = copy(D["c"])
+    ev, _, (acc, num), cout = spdmp_with_rng(PhiloxRNG(D["seed"]), ∇ϕmoving, 0.0, D["x0"], D["theta0"], D["T"], c, Z,
+                                             ZZB.SelfMoving(), A, At, D["mu"], D["y"], D["ny"], ksub; factor = D["factor"], adapt = true)
+    compare_fact(path, ev, acc, num, D)
+    @assert cout == D["cout"] "adapted bounds differ"
+    @assert GLOBAL_STREAM[].n == D["ndraw_global"]
+end
+
 dir = length(ARGS) >= 1 ? ARGS[1] : joinpath(@__DIR__, "..", "tests", "golden")
 check_spdmp(joinpath(dir, "crosscheck_spdmp_d8.txt"))
 check_spdmp(joinpath(dir, "crosscheck_spdmp_grid8.txt"))
 check_bps(joinpath(dir, "crosscheck_bps_d8.txt"))
 check_sspdmp(joinpath(dir, "crosscheck_sspdmp_1d.txt"))
+check_refreshing(joinpath(dir, "crosscheck_factboomerang_d8.txt"))
+check_refreshing(joinpath(dir, "crosscheck_zigzag_refresh_d8.txt"))
+check_localbound(joinpath(dir, "crosscheck_localbound_d8.txt"))
+check_boomerang(joinpath(dir, "crosscheck_boomerang_d8.txt"))
+check_logistic(joinpath(dir, "crosscheck_logistic_p10.txt"))
 println("oracle == ZigZagBoomerang.jl on all fixtures")
