@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 # C3: zz_local_trackw_kernel (one proposal per lane) or zz_local_track_kernel (8-lane groups) -- matched by their common prefix
-MAIN = {"C3": "zz_local_track", "C3X": "zz_local_spec8_kernel", "C2": "bps_run_kernel", "C4": "zz_general_run_kernel",
+MAIN = {"C3": "zz_local_track", "C3X": "zz_local_spec8_kernel", "C2": "bps_run_kernel", "C4": "zz_logistic_lds_kernel",
         "C5": "zz_general_run_kernel"}
 
 
