@@ -20,6 +20,8 @@ extern "C" {
 #define PDMP_DEBUG_KERNEL_AUTO 0
 #define PDMP_DEBUG_KERNEL_SEQ 1
 #define PDMP_DEBUG_KERNEL_SPEC4 2
+#define PDMP_DEBUG_KERNEL_SPEC8 3 /* the 8-event kernel (8-lane groups): what AUTO runs for the moving evaluation on a lattice */
+#define PDMP_DEBUG_KERNEL_EXACTP 4 /* the one-proposal-per-lane kernel of the moving evaluation (bit-identical; slower) */
 pdmp_status pdmp_debug_set_kernel(pdmp_ensemble* ens, int kernel);
 /* 4-event kernel: fetch the G2 records of every proposal speculatively instead of on accept only */
 pdmp_status pdmp_debug_set_spec_g2(pdmp_ensemble* ens, int on);

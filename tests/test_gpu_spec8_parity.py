@@ -1,5 +1,5 @@
 """The 8-events-per-iteration kernel of the north-star workload (d = 16384 lattice, zz_local_spec8_kernel) against the
-4-event kernel, the one-event kernel and the oracle: identical event sequences, counters and final states (-m gpu).
+4-event kernel, the one-event kernel, the one-proposal-per-lane kernel and the oracle: identical event sequences, counters and final states (-m gpu).
 
 The lattice's border coordinates (6 % of them) use other blob templates than the common one, so these runs also cover
 the kernel's spare template slots and the early end of a candidate list when an iteration holds more than two of them."""
@@ -10,7 +10,9 @@ import oracle_lib as O
 
 pytestmark = pytest.mark.gpu
 
-MODES = (None, "spec4", "seq")  # None: the default dispatch = the 8-event kernel for this workload
+MODES = (None, "spec4", "seq", "exactp")  # None: the default dispatch = the 8-event kernel for this workload
+OTHERS = MODES[1:]  # "exactp": the one-proposal-per-lane kernel (pdmp_exactp.hip), opt-in; serves Γ_bound == Γ_target without adaptation
+BASIC = MODES[:3]
 
 
 def _run_sliced(pkg, monkeypatch, mode, nch, cap, slices, seed0, n=128):
@@ -50,7 +52,7 @@ def test_sliced_runs_with_trace_refills_agree_across_kernels_and_with_the_oracle
     runs = {m: _run_sliced(pkg, monkeypatch, m, nch, 1500, slices, seed0) for m in MODES}
     G, c, ev8, cnt8, fs8 = runs[None]
     assert np.all(cnt8["status"] == pkg._lib.CHAIN_OK)
-    for m in ("spec4", "seq"):
+    for m in OTHERS:
         _, _, ev, cnt, fs = runs[m]
         for f in ("num", "nacc", "nevents", "ndraw_main", "t_last", "status"):
             assert np.array_equal(cnt8[f], cnt[f]), (m, f)
@@ -92,7 +94,7 @@ def test_bound_violation_stops_the_chain_at_the_same_event_in_all_kernels(gpu_pk
     d = G.shape[0]
     c = 1e-3 * pkg.problems.column_norms(G)  # with the bound's precision 0.5 G < G the affine bound is too low
     res = {}
-    for m in MODES:
+    for m in BASIC:  # (a bounding matrix other than the target's: not the one-proposal-per-lane kernel's case)
         if m is None:
             monkeypatch.delenv("PDMP_KERNEL", raising=False)
         else:
@@ -140,7 +142,7 @@ def test_many_chains_longer_run_three_kernels_agree(gpu_pkg, monkeypatch):
             h.update(np.ascontiguousarray(fs[f]).tobytes())
         dig[m] = (h.hexdigest(), int(cnt["num"].sum()), int(np.sum(cnt["status"] != 0)))
     assert dig[None][2] == 0 and dig[None][1] > 1.2e7
-    assert dig[None] == dig["spec4"] == dig["seq"], dig
+    assert dig[None] == dig["spec4"] == dig["seq"] == dig["exactp"], dig
 
 
 @pytest.mark.parametrize("n,T", [(46, 1.5), (64, 1.0), (100, 0.5), (127, 0.3)])
@@ -153,7 +155,7 @@ def test_other_lattice_sizes_use_the_same_kernel(gpu_pkg, monkeypatch, n, T):
     G, c, ev8, cnt8, fs8 = runs[None]
     d = G.shape[0]
     assert np.all(cnt8["status"] == pkg._lib.CHAIN_OK)
-    for m in ("spec4", "seq"):
+    for m in OTHERS:
         _, _, ev, cnt, fs = runs[m]
         for f in ("num", "nacc", "nevents", "ndraw_main", "t_last"):
             assert np.array_equal(cnt8[f], cnt[f]), (m, f)
@@ -168,7 +170,7 @@ def test_other_lattice_sizes_use_the_same_kernel(gpu_pkg, monkeypatch, n, T):
         assert np.array_equal(ev8[0][f], r["events"][f]), f
 
 
-@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("mode", BASIC)
 def test_adapt_and_target_mean_on_a_lattice_of_spec8_size(gpu_pkg, monkeypatch, mode):
     """`adapt = true` with bounds that are too small at first (c is multiplied by `factor` on violations, returned per chain) and a
     target with a mean: the 8-event kernel's second instantiation, the 4-event and the one-event kernel against the oracle."""
@@ -200,3 +202,36 @@ def test_adapt_and_target_mean_on_a_lattice_of_spec8_size(gpu_pkg, monkeypatch, 
         assert np.array_equal(acc[k], r["acc"]) and np.array_equal(cout[k], r["c"])
         grew += int(np.count_nonzero(cout[k] != c))
     assert grew > 0  # the adaptation did happen
+
+
+def test_rounding_level_violation_with_the_targets_own_matrix(gpu_pkg, monkeypatch):
+    """Γ_bound == Γ_target and c at rounding level: the affine bound equals the rate up to the last bits, so an accepted proposal
+    with l >= l̄ -- error(...) in the reference, src/sfact.jl:124 -- does occur.  This is the only way into the violation path of
+    the one-proposal-per-lane kernel (it serves equal matrices only): same stop, counters, trace and state as the other kernels."""
+    pkg = gpu_pkg
+    G = pkg.problems.gmrf_precision(64)
+    d = G.shape[0]
+    c = 1e-17 * pkg.problems.column_norms(G)
+    res = {}
+    for m in MODES:
+        if m is None:
+            monkeypatch.delenv("PDMP_KERNEL", raising=False)
+        else:
+            monkeypatch.setenv("PDMP_KERNEL", m)
+        with pkg.Ensemble(16, d, trace_capacity=30000) as ens:
+            ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
+            ens.set_target(pkg.GaussianTarget(G))
+            ens.set_state_synthetic(0.0, c, 0xC0DE)
+            ens.run(2.0, pkg._lib.RUN_STOP_BEFORE)
+            cnt = ens.counters()
+            res[m] = (cnt, [ens.trace(k, counters=cnt) for k in range(16)], ens.final_state())
+    cnt8, ev8, fs8 = res[None]
+    assert np.any(cnt8["status"] == pkg._lib.CHAIN_BOUND_VIOLATED)
+    for m in OTHERS:
+        cnt, ev, fs = res[m]
+        for f in ("status", "num", "nacc", "nevents", "ndraw_main", "t_last"):
+            assert np.array_equal(cnt8[f], cnt[f]), (m, f)
+        for k in range(16):
+            assert np.array_equal(ev8[k], ev[k]), (m, k)
+        for f in ("t", "x", "theta", "acc"):
+            assert np.array_equal(fs8[f], fs[f]), (m, f)

@@ -46,7 +46,7 @@ EXPORTED_SYMBOLS = [
 # include/pdmp_debug.h: diagnostics, not part of the drop-in boundary
 DEBUG_SYMBOLS = ["pdmp_debug_set_kernel", "pdmp_debug_set_spec_g2", "pdmp_debug_set_phase_profile", "pdmp_debug_phase_profile",
                  "pdmp_debug_set_proposal_dump", "pdmp_debug_set_track_groups", "pdmp_debug_math_probe", "pdmp_debug_write_probe", "pdmp_debug_sector_probe"]
-DEBUG_KERNELS = {"auto": 0, "seq": 1, "spec4": 2}
+DEBUG_KERNELS = {"auto": 0, "seq": 1, "spec4": 2, "spec8": 3, "exactp": 4}
 
 
 class PdmpConfig(C.Structure):

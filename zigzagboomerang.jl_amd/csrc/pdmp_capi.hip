@@ -116,6 +116,7 @@ struct pdmp_ensemble {
     int dbg_track_groups = 0;      // gradient tracking: keep the 8-lane-group kernel where the one-proposal-per-lane kernel would run
     // tracked-gradient kernel (pdmp_ensemble_set_gradient_tracking)
     bool track_requested = false, track = false, track_two_sums = false;
+    bool exactp = false;       // the moving evaluation runs on zz_local_exactp_kernel (plain lattice; decided by set_state)
     bool track_pairs = false;  // the queue's level 0 is (key, time) pairs in d_kp (pdmp_trackp.hip); decided by set_state
     DevBuf<double> d_kp;
     int32_t lattice_n = 0;  // the flow's graph is the n x n 5-point lattice in column-major numbering (0: it is not)
@@ -320,7 +321,8 @@ pdmp_status pdmp_debug_math_probe(int device, uint64_t seed, int64_t n, double* 
 
 pdmp_status pdmp_debug_set_kernel(pdmp_ensemble* e, int kernel) {
     if (!e) return fail(PDMP_ERR_INVALID, "null argument");
-    if (kernel != PDMP_DEBUG_KERNEL_AUTO && kernel != PDMP_DEBUG_KERNEL_SEQ && kernel != PDMP_DEBUG_KERNEL_SPEC4)
+    if (kernel != PDMP_DEBUG_KERNEL_AUTO && kernel != PDMP_DEBUG_KERNEL_SEQ && kernel != PDMP_DEBUG_KERNEL_SPEC4 && kernel != PDMP_DEBUG_KERNEL_SPEC8 &&
+        kernel != PDMP_DEBUG_KERNEL_EXACTP)
         return fail(PDMP_ERR_INVALID, "unknown kernel selector %d", kernel);
     if (e->has_flow) return fail(PDMP_ERR_INVALID, "pdmp_debug_set_kernel must precede set_flow_*");
     e->dbg_kernel = kernel;
@@ -903,6 +905,32 @@ extern "C" pdmp_status pdmp_ensemble_set_target_logistic(pdmp_ensemble* e, int64
 
 extern "C" {
 
+// the n x n 5-point lattice in column-major numbering (scripts/gridlaplace.jl): G1[i] = {i-n, i-1, i, i+1, i+n} inside the grid
+static void detect_lattice(pdmp_ensemble* e) {
+    const int64_t d = e->cfg.d;
+    e->lattice_n = 0;
+    int64_t nl = (int64_t)std::llround(std::sqrt((double)d));
+    bool lat = nl * nl == d && nl >= 16 && nl <= 128 && !e->colptr.empty();
+    for (int64_t col = 0; lat && col < nl; ++col)
+        for (int64_t row = 0; lat && row < nl; ++row) {
+            const int64_t ii = row + nl * col;
+            uint32_t want[5];
+            int nw = 0;
+            if (col > 0) want[nw++] = (uint32_t)(ii - nl);
+            if (row > 0) want[nw++] = (uint32_t)(ii - 1);
+            want[nw++] = (uint32_t)ii;
+            if (row < nl - 1) want[nw++] = (uint32_t)(ii + 1);
+            if (col < nl - 1) want[nw++] = (uint32_t)(ii + nl);
+            if ((int64_t)(e->colptr[ii + 1] - e->colptr[ii]) != nw) {
+                lat = false;
+                break;
+            }
+            for (int q = 0; q < nw; ++q)
+                if (e->rowval[e->colptr[ii] + q] != want[q]) lat = false;
+        }
+    if (lat) e->lattice_n = (int32_t)nl;
+}
+
 static pdmp_status alloc_state(pdmp_ensemble* e) {
     const int64_t d = e->cfg.d, n = e->cfg.nchains;
     pdmp_status st;
@@ -952,29 +980,20 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
         if (!sym) return fail(PDMP_ERR_UNSUPPORTED, "gradient tracking needs symmetric precision matrices (flow and target)");
         e->track_two_sums = two;
         e->track = true;
-        // the n x n 5-point lattice in column-major numbering (scripts/gridlaplace.jl): G1[i] = {i-n, i-1, i, i+1, i+n} inside the grid
-        e->lattice_n = 0;
-        {
-            int64_t nl = (int64_t)std::llround(std::sqrt((double)d));
-            bool lat = nl * nl == d && nl >= 16 && nl <= 128;
-            for (int64_t col = 0; lat && col < nl; ++col)
-                for (int64_t row = 0; lat && row < nl; ++row) {
-                    const int64_t ii = row + nl * col;
-                    uint32_t want[5];
-                    int nw = 0;
-                    if (col > 0) want[nw++] = (uint32_t)(ii - nl);
-                    if (row > 0) want[nw++] = (uint32_t)(ii - 1);
-                    want[nw++] = (uint32_t)ii;
-                    if (row < nl - 1) want[nw++] = (uint32_t)(ii + 1);
-                    if (col < nl - 1) want[nw++] = (uint32_t)(ii + nl);
-                    if ((int64_t)(e->colptr[ii + 1] - e->colptr[ii]) != nw) {
-                        lat = false;
-                        break;
-                    }
-                    for (int q = 0; q < nw; ++q)
-                        if (e->rowval[e->colptr[ii] + q] != want[q]) lat = false;
-                }
-            if (lat) e->lattice_n = (int32_t)nl;
+        detect_lattice(e);
+    }
+    // the bit-identical one-proposal-per-lane kernel (pdmp_exactp.hip; opt-in with PDMP_DEBUG_KERNEL_EXACTP: measured at 2x the 8-event
+    // kernel's time) wants the plain lattice with the bounding Γ equal to the target's
+    e->exactp = false;
+    if (!e->track_requested && e->cfg.sampler == PDMP_SAMPLER_ZIGZAG_LOCAL && !e->needs_general && e->target_kind == 0 && e->flow_kind == 0 &&
+        !e->adaptscale && !e->local_bound && !(e->lambda_ref > 0) && !e->cfg.adapt && !e->has_tmu && e->dbg_kernel == PDMP_DEBUG_KERNEL_EXACTP &&
+        e->dbg_dump == 0 && e->h_tval.size() == e->bval.size()) {
+        bool same = true, mu0 = true;
+        for (size_t q = 0; q < e->bval.size() && same; ++q) same = e->bval[q] == e->h_tval[q];
+        for (size_t q = 0; q < e->h_gmu_b.size() && mu0; ++q) mu0 = e->h_gmu_b[q] == 0.0;
+        if (same && mu0) {
+            detect_lattice(e);
+            e->exactp = e->lattice_n != 0;
         }
     }
     pdmp_status st = alloc_state(e);
@@ -1314,6 +1333,24 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         }
         return PDMP_OK;
     }
+    if (e->exactp && spec_ok) {
+        P.lattice_n = e->lattice_n;
+        P.lattice_magic = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)e->lattice_n + 1);
+        if (pdmp::zz_exactp_supported(P)) {
+            int rcx = pdmp::launch_zz_local_exactp(P, e->cfg.nchains, s);
+            if (rcx != 0) return fail(PDMP_ERR_HIP, "zz_local_exactp launch failed (%d)", rcx);
+            HIP_TRY(hipEventRecord(e->ev1, s));
+            e->timed = true;
+            if (phenv) {  // [10] iterations, [11] candidates, [12] left by the zone test, [13] committed, [14] events among the candidates
+                HIP_TRY(hipDeviceSynchronize());
+                HIP_TRY(hipMemcpy(e->dbg_phase_out, phbuf.p, sizeof e->dbg_phase_out, hipMemcpyDeviceToHost));
+                e->dbg_phase_valid = 1;
+            }
+            return PDMP_OK;
+        }
+    }
+    if (e->dbg_kernel == PDMP_DEBUG_KERNEL_EXACTP)  // asked for by name: never another kernel in its place
+        return fail(PDMP_ERR_UNSUPPORTED, "PDMP_DEBUG_KERNEL_EXACTP: spdmp on a plain lattice (16 <= n <= 128, d >= 2048) with the bounding matrix equal to the target's, no adaptation, and a trace or no trace");
     const bool sticky_spec = sticky && e->use_spec && dbg_cap == 0;  // same requirements as the ZigZag speculative kernel
     int rc = sticky ? (sticky_spec ? pdmp::launch_zz_sticky_spec(P, e->cfg.nchains, s) : pdmp::launch_zz_sticky_run(P, e->cfg.nchains, s))
                     : spec_ok ? pdmp::launch_zz_local_spec(P, e->cfg.nchains, s) : pdmp::launch_zz_local_run(P, e->cfg.nchains, s);

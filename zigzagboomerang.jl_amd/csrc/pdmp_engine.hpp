@@ -337,6 +337,8 @@ int launch_zz_unpack(const ZzRec* rec, const double* c_src, int64_t c_stride, in
 int launch_zz_batch_means(const ZzRec* rec, int64_t rec_stride, double* jprev, int64_t d, int64_t nchains, double T_prev, double T,
                           double* sum_y, double* sum_y2, void* stream);
 int launch_zz_local_track(const ZzRunParams& p, int64_t nchains, void* stream);
+bool zz_exactp_supported(const ZzRunParams& p);  // pdmp_exactp.hip: the moving evaluation, one proposal per lane
+int launch_zz_local_exactp(const ZzRunParams& p, int64_t nchains, void* stream);
 bool zz_trackp_supported(const ZzRunParams& p);
 int launch_zz_local_trackp(const ZzRunParams& p, int64_t nchains, void* stream);
 int launch_zz_keys_to_pairs(const double* keys, void* kp, int64_t n, double t0, void* stream);
