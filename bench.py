@@ -343,7 +343,18 @@ def main():
         raise SystemExit("bench.py: no gfx950 device visible; the engine has no CPU fallback")
     if backend == "engine" and (world > 1 or args.gather):
         # ncclCommInitRank through the library (the 128-byte id travels over a TCP rendezvous on MASTER_ADDR: parallel.exchange_unique_id)
-        comm = pkg.parallel.Comm(rank, world, local_rank)
+        try:
+            comm = pkg.parallel.Comm(rank, world, local_rank)
+        except Exception as exc:  # e.g. the TCP rendezvous port range is closed on this node: the torch.distributed path still measures
+            if world == 1:
+                raise
+            print(f"bench.py: rank {rank}: pdmp_comm_init failed ({exc}); falling back to torch.distributed over RCCL", file=sys.stderr, flush=True)
+            import torch
+            import torch.distributed as dist
+            backend = "nccl"
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            red_dev = "cuda"
     W = make_workload(pkg, args, rank, local_rank)
     ens, d, cap, nch = W["ens"], W["d"], W["cap"], args.chains
     G, c = W.get("G"), W.get("c")
