@@ -243,6 +243,15 @@ __global__ __launch_bounds__(64) void zz_logistic_lds_kernel(ZzRunParams P, ZzGe
         }
     };
 
+    // Random numbers, two blocks of 64 kept in registers: lane r holds draw gbase + r of the global-rng stream (its 64 bits: the sampled
+    // observations are pdmp_randint of them) and draw mbase + r of the main stream (the uniform and its logarithm).  A proposal uses k_sub of
+    // the first and 2 (rejected) or 1 + k (accepted) of the second, so one Philox pass serves 6 proposals' observations, one Philox + log pass
+    // ~13 proposals' coins and bounds -- instead of one of each per proposal.  The lanes that WORK on the sampled observations are the ones
+    // that hold their draws: [goff, goff + k_sub), goff = ng − gbase.
+    constexpr uint32_t LG_MMARGIN = 26;  // members of an accepted event whose draws the block is guaranteed to hold (more: formed on demand)
+    uint64_t gbase = ng - 64u, mbase = nm - 64u;  // (empty blocks: the first iteration fills them)
+    uint64_t gbits = 0;
+    double mu = 0.0, mL = 0.0;
     bool running = stop_before || (t_event < T);
     PrioTurn prio;
     while (running) {
@@ -272,11 +281,19 @@ __global__ __launch_bounds__(64) void zz_logistic_lds_kernel(ZzRunParams P, ZzGe
         // ---------------- every random number of the iteration, one Philox evaluation: lane q < k_sub -> draw ng + q of the global-rng stream
         // (rand(sampler), scripts/logistic.jl:84); lane k_sub -> the thinning coin, draw nm (:121); lane k_sub + 1 + r -> draw nm + 1 + r, the
         // uniform of the r-th re-bound of this proposal (r = 0: the rejected proposal's own, :139; r < k: the members of an accepted one, :134)
-        const bool qa = lane < nq;
-        const uint64_t bits = pdmp_bits64(seed, qa ? PDMP_STREAM_GLOBAL : PDMP_STREAM_MAIN,
-                                          qa ? (ng + (uint64_t)lane) : (nm + (uint64_t)(lane - nq)));
-        const double Lmem = pdmp_log(pdmp_bits_to_u01(bits));
-        const double ucoin = l_readlane(pdmp_bits_to_u01(bits), nq);
+        if ((uint32_t)(ng - gbase) + (uint32_t)nq > 64u) {  // (uniform)
+            gbase = ng;
+            gbits = pdmp_bits64(seed, PDMP_STREAM_GLOBAL, ng + (uint64_t)lane);
+        }
+        if ((uint32_t)(nm - mbase) + 2u + LG_MMARGIN > 64u) {
+            mbase = nm;
+            mu = pdmp_bits_to_u01(pdmp_bits64(seed, PDMP_STREAM_MAIN, nm + (uint64_t)lane));
+            mL = pdmp_log(mu);
+        }
+        const uint32_t goff = (uint32_t)(ng - gbase), moff = (uint32_t)(nm - mbase);
+        const bool qa = (uint32_t)lane - goff < (uint32_t)nq;
+        const uint64_t bits = gbits;
+        const double ucoin = l_readlane(mu, (int)moff);
         const uint32_t cp0 = H.cp0, k = H.k, sp0 = H.sp0, m = H.m;
         // [2]: G1[i] and its Γ values, the sampled entries of column i of the design, the members' table entries
         const uint32_t rdraw = (uint32_t)(((bits >> 32) * (uint64_t)H.l) >> 32);  // pdmp_randint
@@ -350,11 +367,11 @@ __global__ __launch_bounds__(64) void zz_logistic_lds_kernel(ZzRunParams P, ZzGe
             const double t3 = w * c0.x * c0.z;              // sigmoidn(u0), u0 = idot(At, row, μ): tabulated per observation
             const double t4 = w * c0.y * c0.w;              // nsigmoid(u0)
             double s = 0.0;
-            for (int z = 0; z < nq; ++z) {
-                s += l_readlane(t1, z);
-                s += l_readlane(t2, z);
-                s -= l_readlane(t3, z);
-                s -= l_readlane(t4, z);
+            for (int z = 0; z < nq; ++z) {  // (in the order of the draws, scripts/logistic.jl:84-92)
+                s += l_readlane(t1, (int)goff + z);
+                s += l_readlane(t2, (int)goff + z);
+                s -= l_readlane(t3, (int)goff + z);
+                s -= l_readlane(t4, (int)goff + z);
             }
             ng += (uint64_t)Q.ksub;
             g = prior - s;
@@ -370,7 +387,7 @@ __global__ __launch_bounds__(64) void zz_logistic_lds_kernel(ZzRunParams P, ZzGe
             // ---------------- rejected (:137-139): the bound from the sums taken above
             const double a = c_i + (s1r - gmu_i) * th_i;  // src/fact_samplers.jl:51
             const double b = c_i / 100 + th_i * s2r;      // :52
-            const double key = tp + l_poisson_time_L(a, b, l_readlane(Lmem, nq + 1));
+            const double key = tp + l_poisson_time_L(a, b, l_readlane(mL, (int)moff + 1));
             if (lane == 0) {
                 ZzRec* r = rec + i;
                 r->t_old = tp;
@@ -417,9 +434,9 @@ __global__ __launch_bounds__(64) void zz_logistic_lds_kernel(ZzRunParams P, ZzGe
             const double cj_tab = (base == 0) ? cj0 : cvec[valid ? j : i];
             const double cj = (j == i) ? ci_new : cj_tab;  // (c_i as adapted by THIS proposal travels in a register)
             const double gmu = (base == 0) ? gmu0 : P.tb.gmu_b[valid ? j : i];
-            // draw nm + jj (nm already counts the coin): taken at the top of the iteration where the lanes reach, else now
-            const uint32_t src = (uint32_t)nq + 1u + jj;
-            double Ldraw = l_shfl(Lmem, (src < 64u) ? src : 63u);
+            // draw nm + jj (nm already counts the coin): from the block where it reaches, else formed now
+            const uint32_t src = moff + 1u + jj;
+            double Ldraw = l_shfl(mL, (src < 64u) ? src : 63u);
             if (__ballot(valid && src >= 64u) != 0) {
                 const double Lx = pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm + (uint64_t)jj));
                 Ldraw = (src >= 64u) ? Lx : Ldraw;
