@@ -3,7 +3,8 @@
 // ∇ϕ(x, i, Γ) = idot(Γ, i, x), Z = ZigZag(Γ, 0), c[i] = ‖Γ[:, i]‖₂, spdmp(∇ϕ, t0, x0, θ0, T, c, Z, Γ).
 //   usage: gmrf_spdmp [n=16] [T=20] [seed] [tracked]      prints one line: d events num acc fnv1a64(payload) t_last
 //   (a 4th argument `tracked` selects the tracked-gradient evaluation, Options::tracked: n x n lattices with n*n >= 2048;
-//    `parallel:K` runs pdmp::parallel_spdmp with K chunks, the bound = Γ without the entries that couple two chunks, c doubled)
+//    `parallel:K` runs pdmp::parallel_spdmp with K chunks, the bound = Γ without the entries that couple two chunks, c doubled;
+//    `1d` runs n chains of the 1-d Boomerang sampler of src/zigzagboom1d.jl through pdmp::pdmp(..., Boomerang1d))
 // tests/test_gpu_cpp_host.py runs it on the GPU box and checks the line against the CPU oracle.
 #include <cinttypes>
 #include <cmath>
@@ -50,7 +51,28 @@ int main(int argc, char** argv) {
     if (argc > 3) opt.seed = std::strtoull(argv[3], nullptr, 0);
     const bool par = argc > 4 && std::strncmp(argv[4], "parallel:", 9) == 0;
     const int K = par ? std::atoi(argv[4] + 9) : 0;
-    if (argc > 4 && !par) opt.tracked = true;
+    if (argc > 4 && !par && std::strcmp(argv[4], "1d") != 0) opt.tracked = true;
+    if (argc > 4 && std::strcmp(argv[4], "1d") == 0) {
+        // test/test1d.jl:51-52 through pdmp::pdmp(..., Boomerang1d): n chains from x0 = 1.41 + 0.01 k, θ0 = 0.5, Boomerang1d(1.1, 1.2, 0.5),
+        // the noisy gradient, c = 10; prints: n events(total) fnv1a64(all events, chain by chain) acceptance(chain 0)
+        try {
+            std::vector<double> x0((size_t)n), th0((size_t)n, 0.5);
+            for (int k = 0; k < n; ++k) x0[(size_t)k] = 1.41 + 0.01 * k;
+            opt.trace_capacity = 50;  // (every chain is resumed many times)
+            const auto R = pdmp::pdmp(pdmp::GaussianTarget1d{3.14159265358979323846 / 3, 1.3, 0.1}, x0, th0, T, 10.0, pdmp::Boomerang1d{1.1, 1.2, 0.5}, opt);
+            uint64_t h = 14695981039346656037ull;
+            size_t total = 0;
+            for (const auto& r : R) {
+                total += r.trace.size();
+                h = fnv1a(h, r.trace.data(), r.trace.size() * sizeof(pdmp_event1d));
+            }
+            std::printf("%d %zu %016" PRIx64 " %.17g\n", n, total, h, R[0].acceptance);
+            return 0;
+        } catch (const std::exception& ex) {
+            std::fprintf(stderr, "gmrf_spdmp 1d: %s\n", ex.what());
+            return 1;
+        }
+    }
     try {
         pdmp::ZigZag Z;
         Z.Gamma = gmrf_precision(n, 0.01);

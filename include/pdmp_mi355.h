@@ -425,6 +425,43 @@ pdmp_status pdmp_comm_gathered_copy(pdmp_comm* comm, pdmp_event* out, int64_t fi
 pdmp_status pdmp_ensemble_reduce_moments(pdmp_ensemble* ens, pdmp_comm* comm, int root, double T_prev, double T, double* sum_y,
                                          double* sum_y2);
 
+/* ------------------------------------------------------------------ the one-dimensional samplers
+ *
+ * pdmp(∇ϕ, x, θ, T, c, Flow::Union{ZigZag1d, Boomerang1d}; adapt = false, factor = 2.0) -> Ξ::Vector{(t, x, θ)}, acc/num
+ * (src/zigzagboom1d.jl:34-67; ab :15-16, λ :5-6, move_forward src/dynamics.jl:66-68,79-82) for an ensemble of independent chains, one
+ * chain per LANE.  The gradient is the device-resident form of the reference's own test closure (test/test1d.jl:9-10):
+ * ∇ϕ(x) = (x − mu)/sigma2 + noise·(rand() − 0.5).  Draw order: the reference's calls on its global generator, in program order, are the
+ * draws of the chain's main stream.  One call runs every chain until t >= T, a bound violation (adapt = 0: PDMP_CHAIN_BOUND_VIOLATED, the
+ * reference's error(...)) or a full event buffer (PDMP_CHAIN_TRACE_FULL: call again with the returned state -- the run continues exactly
+ * where it stopped).  state[k] on the first call: {x, theta, c} = the start, started = 0, everything else 0.  events: host buffer
+ * [nchains x trace_capacity], nevents[k] of chain k's row are valid (the first one of a fresh run is (0, x0, θ0), :36).  Host pointers only.
+ */
+#define PDMP_1D_ZIGZAG 0
+#define PDMP_1D_BOOMERANG 1
+typedef struct {
+    uint32_t struct_size; /* sizeof(pdmp_1d_config) */
+    int32_t device;
+    int32_t flow;  /* PDMP_1D_ZIGZAG: ZigZag1d(); PDMP_1D_BOOMERANG: Boomerang1d(b_sigma, b_mu, b_lambda) (src/types.jl:82-100) */
+    int32_t adapt; /* c *= factor on a violated bound instead of stopping (:54-56) */
+    double factor;
+    int64_t nchains;
+    int64_t trace_capacity;
+    double mu, sigma2, noise;        /* the target's gradient (test/test1d.jl:5-10) */
+    double b_sigma, b_mu, b_lambda; /* Boomerang1d's Σ, μ, λref */
+} pdmp_1d_config;
+typedef struct {
+    double t, x, theta;
+} pdmp_event1d;
+typedef struct {
+    double t, x, theta, c; /* time, position, velocity, tuning parameter (grows under adapt) */
+    double a, b, t_next, t_ref; /* the bound in force, the next proposal and refresh times */
+    uint64_t ndraw;             /* draws of the main stream consumed */
+    int64_t num, acc;           /* proposals, accepted proposals (:38,51,53) */
+    int32_t started, status;    /* status: PDMP_CHAIN_* */
+} pdmp_1d_state;
+pdmp_status pdmp_1d_run(const pdmp_1d_config* cfg, pdmp_1d_state* state /* [nchains], in/out */, const uint64_t* seeds /* [nchains] */,
+                        double T, pdmp_event1d* events /* [nchains x trace_capacity] */, int64_t* nevents /* [nchains] */);
+
 /* raw device pointers for zero-copy consumers (e.g. an RCCL gather of trace segments) */
 pdmp_status pdmp_ensemble_trace_dev(pdmp_ensemble* ens, void** events_dev, int64_t* capacity);
 pdmp_status pdmp_ensemble_counters_dev(pdmp_ensemble* ens, void** counters_dev);

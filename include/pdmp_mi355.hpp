@@ -386,6 +386,77 @@ inline Result<PDMPTrace> pdmp(const GaussianTarget& target, double t0, const std
     return detail::not_factorised(e, t0, x0, theta0, T, c, o);
 }
 
+// ---- the one-dimensional samplers: pdmp(∇ϕ, x, θ, T, c, Flow::Union{ZigZag1d, Boomerang1d}; adapt, factor = 2.0) -> Ξ, acc/num
+// (src/zigzagboom1d.jl:34-67).  ∇ϕ(x) = (x − μ)/σ² + noise (rand() − 0.5) (test/test1d.jl:9-10).
+struct ZigZag1d {};
+struct Boomerang1d {
+    double Sigma = 1.0, mu = 0.0, lambda_ref = 1.0;  // Boomerang1d(Σ, μ, λ), src/types.jl:89-100
+};
+struct GaussianTarget1d {
+    double mu = 0.0, sigma2 = 1.0, noise = 0.0;
+};
+struct Result1d {
+    std::vector<pdmp_event1d> trace;  // Ξ: (t, x, θ), the first entry (0, x0, θ0)
+    double acceptance;                // acc/num
+    double c;                         // the tuning parameter after adaptation
+};
+namespace detail {
+inline std::vector<Result1d> run_1d(pdmp_1d_config cfg, const std::vector<double>& x0, const std::vector<double>& theta0, double T, double c,
+                                    const Options& o) {
+    const size_t n = x0.size();
+    cfg.struct_size = (uint32_t)sizeof(pdmp_1d_config);
+    cfg.device = o.device;
+    cfg.adapt = o.adapt ? 1 : 0;
+    cfg.factor = (o.factor == 1.8) ? 2.0 : o.factor;  // (the 1-d driver's default, :34)
+    cfg.nchains = (int64_t)n;
+    cfg.trace_capacity = o.trace_capacity > 0 ? o.trace_capacity : 4096;
+    std::vector<pdmp_1d_state> st(n);
+    std::vector<uint64_t> seeds(n);
+    for (size_t k = 0; k < n; ++k) {
+        st[k] = pdmp_1d_state{};
+        st[k].x = x0[k];
+        st[k].theta = theta0[k];
+        st[k].c = c;
+        seeds[k] = o.seed + k;
+    }
+    std::vector<pdmp_event1d> ev(n * (size_t)cfg.trace_capacity);
+    std::vector<int64_t> nev(n);
+    std::vector<Result1d> out(n);
+    for (;;) {
+        check(pdmp_1d_run(&cfg, st.data(), seeds.data(), T, ev.data(), nev.data()));
+        bool again = false;
+        for (size_t k = 0; k < n; ++k) {
+            out[k].trace.insert(out[k].trace.end(), ev.begin() + (ptrdiff_t)(k * (size_t)cfg.trace_capacity),
+                                ev.begin() + (ptrdiff_t)(k * (size_t)cfg.trace_capacity + (size_t)nev[k]));
+            if (st[k].status == PDMP_CHAIN_BOUND_VIOLATED) throw std::runtime_error("Tuning parameter `c` too small.");  // :55
+            again = again || st[k].status == PDMP_CHAIN_TRACE_FULL;
+        }
+        if (!again) break;
+    }
+    for (size_t k = 0; k < n; ++k) {
+        out[k].acceptance = st[k].num ? (double)st[k].acc / (double)st[k].num : 0.0;
+        out[k].c = st[k].c;
+    }
+    return out;
+}
+}  // namespace detail
+inline std::vector<Result1d> pdmp(const GaussianTarget1d& g, const std::vector<double>& x0, const std::vector<double>& theta0, double T, double c,
+                                  const ZigZag1d&, const Options& o = {}) {
+    pdmp_1d_config cfg{};
+    cfg.flow = PDMP_1D_ZIGZAG;
+    cfg.mu = g.mu, cfg.sigma2 = g.sigma2, cfg.noise = g.noise;
+    cfg.b_sigma = 1.0, cfg.b_mu = 0.0, cfg.b_lambda = 1.0;
+    return detail::run_1d(cfg, x0, theta0, T, c, o);
+}
+inline std::vector<Result1d> pdmp(const GaussianTarget1d& g, const std::vector<double>& x0, const std::vector<double>& theta0, double T, double c,
+                                  const Boomerang1d& B, const Options& o = {}) {
+    pdmp_1d_config cfg{};
+    cfg.flow = PDMP_1D_BOOMERANG;
+    cfg.mu = g.mu, cfg.sigma2 = g.sigma2, cfg.noise = g.noise;
+    cfg.b_sigma = B.Sigma, cfg.b_mu = B.mu, cfg.b_lambda = B.lambda_ref;
+    return detail::run_1d(cfg, x0, theta0, T, c, o);
+}
+
 }  // namespace pdmp
 
 #endif  // PDMP_MI355_HPP

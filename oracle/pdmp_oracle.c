@@ -954,6 +954,112 @@ int64_t orc_pdmp_zigzag1d(double mu, double sigma2, double x, double th, double 
     return n;
 }
 
+/* The same loop for both 1-d flows (src/zigzagboom1d.jl:34-67) with the gradient of the reference's own test, test/test1d.jl:9-10:
+ * ∇ϕ(x) = (x − μ)/σ² + noise·(rand() − 0.5).  Every random number of this function is a call on the global generator in the
+ * reference; here they are the draws of the chain's MAIN stream in program order: [randexp of the first refresh time (Boomerang1d, :37)],
+ * the first event time (:40), then per iteration either {randn (:44), randexp (:45)} or {[the gradient's noise (:50)], the coin (:52)},
+ * followed by the next event time (:64).  state (in/out) makes a run resumable when the event buffer fills. */
+int64_t orc_pdmp_1d(const orc_1d_params* p, orc_1d_state* st, double T, orc_event1d* out, int64_t cap) {
+    const int boom = p->flow == 1;
+    double t = st->t, x = st->x, th = st->theta, c = st->c, a = st->a, b = st->b, tp = st->t_next, t_ref = st->t_ref;
+    uint64_t nm = st->ndraw;
+    int64_t num = st->num, acc = st->acc, n = 0;
+    if (!st->started) {
+        t = 0.0; /* :35 */
+        if (n < cap) {
+            out[n].t = t;
+            out[n].x = x;
+            out[n].theta = th;
+        }
+        n++; /* :36 */
+        t_ref = boom ? t + pdmp_randexp_from_u(pdmp_u01(p->seed, PDMP_STREAM_MAIN, nm++)) / p->b_lambda : INFINITY; /* :19-20,37 */
+        if (boom) {
+            a = sqrt(th * th + (x - p->b_mu) * (x - p->b_mu)) * c; /* ab, :16 */
+            b = 0.0;
+        } else {
+            a = c + th * x; /* ab, :15 */
+            b = th * th;
+        }
+        tp = t + orc_poisson_time(a, b, pdmp_u01(p->seed, PDMP_STREAM_MAIN, nm++)); /* :40 */
+        st->started = 1;
+    }
+    int status = 0;
+    while (t < T) { /* :41 */
+        if (n >= cap) {
+            status = 3; /* event buffer full: state saved, call again */
+            break;
+        }
+        if (t_ref < tp) { /* :42 */
+            const double tau = t_ref - t;
+            double sn, cs;
+            pdmp_sincos(tau, &sn, &cs); /* move_forward, src/dynamics.jl:79-82 (only Boomerang1d has a finite t_ref) */
+            const double xn = (x - p->b_mu) * cs + th * sn + p->b_mu;
+            t = t + tau;
+            x = xn;
+            th = sqrt(p->b_sigma) * pdmp_randn(p->seed, PDMP_STREAM_MAIN, nm++);                      /* :44 */
+            t_ref = t + pdmp_randexp_from_u(pdmp_u01(p->seed, PDMP_STREAM_MAIN, nm++)) / p->b_lambda; /* :45 */
+            out[n].t = t;
+            out[n].x = x;
+            out[n].theta = th;
+            n++; /* :46 */
+        } else {
+            const double tau = tp - t; /* :48 */
+            if (boom) {
+                double sn, cs;
+                pdmp_sincos(tau, &sn, &cs);
+                const double xn = (x - p->b_mu) * cs + th * sn + p->b_mu, tn = -(x - p->b_mu) * sn + th * cs;
+                x = xn;
+                th = tn;
+                t = t + tau;
+            } else {
+                t = tau + t; /* src/dynamics.jl:66-68 */
+                x = x + th * tau;
+            }
+            double gx = (x - p->mu) / p->sigma2;                                                        /* test/test1d.jl:9 */
+            if (p->noise != 0.0) gx = gx + p->noise * (pdmp_u01(p->seed, PDMP_STREAM_MAIN, nm++) - 0.5); /* :10 */
+            const double l = boom ? pos(th * (gx - (x - p->b_mu) / p->b_sigma)) : pos(th * gx); /* λ, :5-6 */
+            const double lb = pos(a + b * tau);                                                 /* λ_bar, :9,50 */
+            num += 1;
+            if (pdmp_u01(p->seed, PDMP_STREAM_MAIN, nm++) * lb < l) { /* :52 */
+                acc += 1;
+                if (l >= lb) { /* :54 */
+                    if (!p->adapt) {
+                        status = 1; /* error("Tuning parameter `c` too small."), :55 */
+                        break;
+                    }
+                    c *= p->factor; /* :56 */
+                }
+                th = -th; /* :58 */
+                out[n].t = t;
+                out[n].x = x;
+                out[n].theta = th;
+                n++; /* :60 */
+            }
+        }
+        if (boom) {
+            a = sqrt(th * th + (x - p->b_mu) * (x - p->b_mu)) * c; /* :63 */
+            b = 0.0;
+        } else {
+            a = c + th * x;
+            b = th * th;
+        }
+        tp = t + orc_poisson_time(a, b, pdmp_u01(p->seed, PDMP_STREAM_MAIN, nm++)); /* :64 */
+    }
+    st->t = t;
+    st->x = x;
+    st->theta = th;
+    st->c = c;
+    st->a = a;
+    st->b = b;
+    st->t_next = tp;
+    st->t_ref = t_ref;
+    st->ndraw = nm;
+    st->num = num;
+    st->acc = acc;
+    st->status = status;
+    return n;
+}
+
 /* ------------------------------------------------------------------ BPS: src/not_fact_samplers.jl */
 
 /*

@@ -153,6 +153,20 @@ int orc_spdmp_zigzag(int64_t d, const orc_zz_params* p, double t0, double T, dou
 typedef struct {
     double t, x, theta;
 } orc_event1d;
+/* Both 1-d flows of src/zigzagboom1d.jl:34-67 (flow 0: ZigZag1d, 1: Boomerang1d(Σ, μ, λref)) on the target of test/test1d.jl:9-10,
+ * ∇ϕ(x) = (x − mu)/sigma2 + noise (rand() − 0.5); resumable through the state (started = 0 on the first call: x, theta, c are the start). */
+typedef struct {
+    int32_t flow, adapt;
+    double factor, mu, sigma2, noise, b_sigma, b_mu, b_lambda;
+    uint64_t seed;
+} orc_1d_params;
+typedef struct {
+    double t, x, theta, c, a, b, t_next, t_ref;
+    uint64_t ndraw;
+    int64_t num, acc;
+    int32_t started, status; /* status: 0 ok, 1 bound violated (adapt = 0), 3 event buffer full */
+} orc_1d_state;
+int64_t orc_pdmp_1d(const orc_1d_params* p, orc_1d_state* st, double T, orc_event1d* out, int64_t cap);
 int64_t orc_pdmp_zigzag1d(double mu, double sigma2, double x, double theta, double T, double c, int adapt,
                           double factor, uint64_t seed, orc_event1d* out, int64_t cap, int64_t* acc,
                           int64_t* num);

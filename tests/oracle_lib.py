@@ -295,6 +295,36 @@ def pdmp_zigzag1d(mu, sigma2, x0, theta0, T, c, *, adapt=False, factor=2.0, seed
     return out[:min(n, cap)].copy(), acc.value, num.value
 
 
+class Orc1dParams(C.Structure):
+    _fields_ = [("flow", C.c_int32), ("adapt", C.c_int32), ("factor", C.c_double), ("mu", C.c_double), ("sigma2", C.c_double),
+                ("noise", C.c_double), ("b_sigma", C.c_double), ("b_mu", C.c_double), ("b_lambda", C.c_double), ("seed", C.c_uint64)]
+
+
+class Orc1dState(C.Structure):
+    _fields_ = [("t", C.c_double), ("x", C.c_double), ("theta", C.c_double), ("c", C.c_double), ("a", C.c_double), ("b", C.c_double),
+                ("t_next", C.c_double), ("t_ref", C.c_double), ("ndraw", C.c_uint64), ("num", C.c_int64), ("acc", C.c_int64),
+                ("started", C.c_int32), ("status", C.c_int32)]
+
+
+def pdmp_1d(mu, sigma2, x0, theta0, T, c, *, flow="zigzag", boomerang=(1.0, 0.0, 1.0), noise=0.0, adapt=False, factor=2.0, seed=1, cap=1 << 16):
+    """src/zigzagboom1d.jl:34-67 for ZigZag1d() / Boomerang1d(Σ, μ, λref) on ∇ϕ(x) = (x − mu)/sigma2 + noise (rand() − 0.5); the event
+    buffer of `cap` entries is refilled until the run ends.  Returns dict(events, acc, num, c, ndraw, status)."""
+    L = lib()
+    L.orc_pdmp_1d.restype = C.c_int64
+    L.orc_pdmp_1d.argtypes = [C.POINTER(Orc1dParams), C.POINTER(Orc1dState), C.c_double, C.c_void_p, C.c_int64]
+    p = Orc1dParams(1 if flow == "boomerang" else 0, int(adapt), factor, mu, sigma2, noise, boomerang[0], boomerang[1], boomerang[2], seed)
+    st = Orc1dState()
+    st.x, st.theta, st.c, st.started = x0, theta0, c, 0
+    parts = []
+    while True:
+        out = np.empty(cap, dtype=EVENT1D_DTYPE)
+        n = L.orc_pdmp_1d(C.byref(p), C.byref(st), T, out.ctypes.data, cap)
+        parts.append(out[:n].copy())
+        if st.status != 3:
+            break
+    return dict(events=np.concatenate(parts), acc=st.acc, num=st.num, c=st.c, ndraw=st.ndraw, status=st.status, t=st.t, x=st.x, theta=st.theta)
+
+
 def pdmp_bps(gamma, mu, x0, theta0, c, T, *, t0=0.0, lambda_ref=1.0, rho=0.0, adapt=False, factor=2.0,
              seed=1, max_events=0, ev_cap=0, want_events=True, boomerang_mu=None, mass_L=None, local_bound=False,
              subsample=False, target=None):

@@ -38,6 +38,7 @@ def test_library_loads_and_exports_every_symbol(pkg):
 def test_struct_sizes(pkg):
     assert ctypes.sizeof(pkg._lib.PdmpConfig) == 48
     assert pkg._lib.EVENT_DTYPE.itemsize == 32 and pkg._lib.COUNTERS_DTYPE.itemsize == 72
+    assert ctypes.sizeof(pkg._lib.Config1d) == 88 and pkg._lib.EVENT1D_DTYPE.itemsize == 24 and pkg._lib.STATE1D_DTYPE.itemsize == 96  # pdmp_1d_*
 
 
 def test_no_cpu_fallback_without_device(pkg):

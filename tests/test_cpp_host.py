@@ -119,3 +119,25 @@ def test_cpp_parallel_spdmp_matches_oracle(gpu_pkg):
     h = _fnv1a(14695981039346656037, ev.tobytes())
     h = _fnv1a(h, r["x"].tobytes() + r["theta"].tobytes() + r["t"].tobytes())
     assert int(h_s, 16) == h and float(tl_s) == ev["t"][-1]
+
+
+@pytest.mark.gpu
+def test_cpp_1d_sampler_matches_oracle(gpu_pkg):
+    """pdmp::pdmp(GaussianTarget1d, x0, θ0, T, c, Boomerang1d) of the C++ mirror (examples/gmrf_spdmp.cpp, mode `1d`): every event of every
+    chain, hashed chain by chain, equals the oracle's; the event buffers hold 50 events, so the runs are resumed dozens of times."""
+    pkg = gpu_pkg
+    exe = _exe(pkg)
+    n, T, seed = 70, 400.0, 0x77
+    p = subprocess.run([exe, str(n), repr(T), hex(seed), "1d"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr
+    n_s, tot_s, h_s, acc_s = p.stdout.split()
+    h, total, acc0 = 14695981039346656037, 0, None
+    for k in range(n):
+        r = O.pdmp_1d(3.14159265358979323846 / 3, 1.3, 1.41 + 0.01 * k, 0.5, T, 10.0, flow="boomerang", boomerang=(1.1, 1.2, 0.5), noise=0.1,
+                      seed=seed + k)
+        assert r["status"] == 0
+        total += len(r["events"])
+        h = _fnv1a(h, r["events"].tobytes())
+        if k == 0:
+            acc0 = r["acc"] / r["num"]
+    assert int(n_s) == n and int(tot_s) == total and int(h_s, 16) == h and float(acc_s) == acc0

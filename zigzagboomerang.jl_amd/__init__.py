@@ -8,4 +8,5 @@ through `__graft_entry__.load_package()` under the module name `zigzagboomerang_
 from . import _lib, build, ess, parallel, problems, trace  # noqa: F401
 from .engine import Ensemble  # noqa: F401
 from .samplers import Partition, parallel_spdmp, pdmp, spdmp, sspdmp  # noqa: F401
-from .flows import Boomerang, BouncyParticle, LocalBound, FactBoomerang, FactTrace, GaussianTarget, LogisticTarget, PDMPTrace, ZigZag  # noqa: F401
+from .flows import (Boomerang, Boomerang1d, BouncyParticle, LocalBound, FactBoomerang, FactTrace, GaussianTarget, GaussianTarget1d,  # noqa: F401
+                    LogisticTarget, PDMPTrace, ZigZag, ZigZag1d)

@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = [
     "pdmp_ensemble_set_mass_cholesky", "pdmp_ensemble_set_bps_options",
     "pdmp_ensemble_ess_begin", "pdmp_ensemble_ess_batch", "pdmp_ensemble_ess_end", "pdmp_ensemble_set_gradient_tracking",
     "pdmp_ensemble_path_integrals", "pdmp_ensemble_set_path_integrals", "pdmp_ensemble_set_neighbourhood", "pdmp_ensemble_info",
-    "pdmp_ensemble_consume_begin", "pdmp_ensemble_consume", "pdmp_ensemble_consume_mean", "pdmp_ensemble_consume_discretized",
+    "pdmp_ensemble_consume_begin", "pdmp_ensemble_consume", "pdmp_ensemble_consume_mean", "pdmp_ensemble_consume_discretized", "pdmp_1d_run",
     "pdmp_comm_unique_id", "pdmp_comm_init", "pdmp_comm_destroy", "pdmp_comm_info", "pdmp_comm_barrier", "pdmp_comm_allreduce",
     "pdmp_ensemble_gather_traces", "pdmp_ensemble_reduce_moments", "pdmp_comm_gathered_copy",
 ]
@@ -112,6 +112,8 @@ def load():
     L.pdmp_ensemble_consume.argtypes = [vp]
     L.pdmp_ensemble_consume_mean.argtypes = [vp, i64, i64, vp, vp]
     L.pdmp_ensemble_consume_discretized.argtypes = [vp, i64, i64, i64, vp, C.POINTER(i64), C.POINTER(vp)]
+    L.pdmp_1d_run.argtypes = [C.POINTER(Config1d), vp, vp, C.c_double, vp, vp]
+    L.pdmp_1d_run.restype = C.c_int
     L.pdmp_comm_unique_id.argtypes = [vp, i64]
     L.pdmp_comm_init.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     L.pdmp_comm_destroy.argtypes = [vp]
@@ -155,6 +157,17 @@ def load():
             fn.restype = C.c_int
     _lib = L
     return L
+
+
+class Config1d(C.Structure):  # pdmp_1d_config
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("flow", C.c_int32), ("adapt", C.c_int32), ("factor", C.c_double),
+                ("nchains", C.c_int64), ("trace_capacity", C.c_int64), ("mu", C.c_double), ("sigma2", C.c_double), ("noise", C.c_double),
+                ("b_sigma", C.c_double), ("b_mu", C.c_double), ("b_lambda", C.c_double)]
+
+
+EVENT1D_DTYPE = np.dtype([("t", "<f8"), ("x", "<f8"), ("theta", "<f8")])
+STATE1D_DTYPE = np.dtype([("t", "<f8"), ("x", "<f8"), ("theta", "<f8"), ("c", "<f8"), ("a", "<f8"), ("b", "<f8"), ("t_next", "<f8"),
+                          ("t_ref", "<f8"), ("ndraw", "<u8"), ("num", "<i8"), ("acc", "<i8"), ("started", "<i4"), ("status", "<i4")])
 
 
 def check(code):

@@ -123,6 +123,38 @@ class Boomerang:
 
 
 @dataclass
+class ZigZag1d:
+    """ZigZag1d() -- src/types.jl:82-86: the 1-d ZigZag (x(τ), θ(τ)) = (x + θτ, θ), src/dynamics.jl:66-68."""
+
+
+@dataclass
+class Boomerang1d:
+    """Boomerang1d(Σ, μ, λ) / Boomerang1d(μ, λ) / Boomerang1d(λ) -- src/types.jl:89-100: rotation around μ (src/dynamics.jl:79-82),
+    refreshment θ ~ N(0, Σ) at rate λref."""
+    Σ: float = 1.0
+    μ: float = 0.0
+    λref: float = 1.0
+
+    def __init__(self, *a):
+        if len(a) == 1:
+            self.Σ, self.μ, self.λref = 1.0, 0.0, float(a[0])
+        elif len(a) == 2:
+            self.Σ, self.μ, self.λref = 1.0, float(a[0]), float(a[1])
+        elif len(a) == 3:
+            self.Σ, self.μ, self.λref = float(a[0]), float(a[1]), float(a[2])
+        else:
+            raise TypeError("Boomerang1d(λ), Boomerang1d(μ, λ) or Boomerang1d(Σ, μ, λ)")
+
+
+@dataclass
+class GaussianTarget1d:
+    """∇ϕ(x) = (x − μ)/σ² [+ noise·(rand() − 0.5)]: the closures of test/test1d.jl:9-10 (`∇ϕ`, `∇ϕhat` with noise = 0.1)."""
+    μ: float = 0.0
+    σ2: float = 1.0
+    noise: float = 0.0
+
+
+@dataclass
 class GaussianTarget:
     """∇ϕ(x, i) = Γ[:, i]·x  [− Γ[:, i]·μ]  (idot, src/common.jl:16-24): the device-resident stand-in
     for the reference's `∇ϕ(x, i, Γ) = idot(Γ, i, x)` closure + its `args... = (Γ,)`."""

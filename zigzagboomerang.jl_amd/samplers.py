@@ -15,7 +15,8 @@ import scipy.sparse as sp
 
 from . import _lib
 from .engine import Ensemble
-from .flows import Boomerang, BouncyParticle, FactBoomerang, LocalBound, FactTrace, GaussianTarget, LogisticTarget, PDMPTrace, ZigZag
+from .flows import (Boomerang, Boomerang1d, BouncyParticle, FactBoomerang, LocalBound, FactTrace, GaussianTarget, GaussianTarget1d, LogisticTarget,
+                    PDMPTrace, ZigZag, ZigZag1d)
 
 DEFAULT_SEED = 0x5EED0000
 
@@ -56,8 +57,59 @@ def spdmp(target, t0, x0, θ0, T, c, *GF, factor=1.8, adapt=False, adaptscale=Fa
                    adaptscale=adaptscale, tracked=tracked, G=G)
 
 
-def pdmp(target, t0, x0, θ0, T, c, F, *, factor=1.8, adapt=False, subsample=False, seed=DEFAULT_SEED, device=0,
-         trace_capacity=None, trace=True):
+def pdmp(target, *args, factor=1.8, adapt=False, subsample=False, seed=DEFAULT_SEED, device=0, trace_capacity=None, trace=True):
+    """pdmp(∇ϕ, t0, x0, θ0, T, c, F, ...) -- the d-dimensional drivers, see _pdmp_nd -- or, with a 1-d flow as the sixth argument,
+    pdmp(∇ϕ, x, θ, T, c, Flow::Union{ZigZag1d, Boomerang1d}; adapt=false, factor=2.0) -> Ξ, acc/num  (src/zigzagboom1d.jl:34-67)."""
+    if len(args) == 5 and isinstance(args[4], (ZigZag1d, Boomerang1d)):
+        if subsample:
+            raise TypeError("subsample is a keyword of the non-factorised pdmp (BouncyParticle / Boomerang)")
+        x0, θ0, T, c, Flow = args
+        return _pdmp_1d(target, x0, θ0, T, c, Flow, 2.0 if factor == 1.8 else factor, adapt, seed, device, trace_capacity)
+    if len(args) != 6:
+        raise TypeError("expected pdmp(target, t0, x0, θ0, T, c, F, ...) or pdmp(target, x, θ, T, c, Flow1d, ...)")
+    return _pdmp_nd(target, *args, factor=factor, adapt=adapt, subsample=subsample, seed=seed, device=device, trace_capacity=trace_capacity,
+                    trace=trace)
+
+
+def _pdmp_1d(target, x0, θ0, T, c, Flow, factor, adapt, seed, device, trace_capacity):
+    """The 1-d samplers as an ensemble (one chain per lane, pdmp_1d_run): scalars run one chain and return (Ξ, acc/num) like the reference
+    (:66), arrays of starting points run len(x0) chains (seeds seed + k) and return lists.  Ξ: structured array of (t, x, theta), the first
+    entry being (0, x0, θ0) (:36).  c may be a scalar or one value per chain."""
+    import ctypes as C
+    if not isinstance(target, GaussianTarget1d):
+        raise TypeError("the 1-d samplers take a GaussianTarget1d (∇ϕ(x) = (x − μ)/σ² + noise (rand() − 0.5), test/test1d.jl:9-10)")
+    scalar = np.ndim(x0) == 0
+    x0 = np.atleast_1d(np.asarray(x0, dtype=np.float64))
+    n = len(x0)
+    θ0 = np.broadcast_to(np.asarray(θ0, dtype=np.float64), (n,))
+    cc = np.broadcast_to(np.asarray(c, dtype=np.float64), (n,))
+    cap = int(trace_capacity) if trace_capacity else int(max(1024, min(1 << 20, 4 * max(float(T), 1.0))))
+    boom = isinstance(Flow, Boomerang1d)
+    cfg = _lib.Config1d(C.sizeof(_lib.Config1d), int(device), 1 if boom else 0, int(bool(adapt)), float(factor), n, cap, float(target.μ),
+                        float(target.σ2), float(target.noise), Flow.Σ if boom else 1.0, Flow.μ if boom else 0.0, Flow.λref if boom else 1.0)
+    st = np.zeros(n, dtype=_lib.STATE1D_DTYPE)
+    st["x"], st["theta"], st["c"] = x0, θ0, cc
+    seeds = np.uint64(seed) + np.arange(n, dtype=np.uint64)
+    ev = np.empty((n, cap), dtype=_lib.EVENT1D_DTYPE)
+    nev = np.zeros(n, dtype=np.int64)
+    L = _lib.load()
+    parts = [[] for _ in range(n)]
+    while True:
+        _lib.check(L.pdmp_1d_run(C.byref(cfg), st.ctypes.data, seeds.ctypes.data, float(T), ev.ctypes.data, nev.ctypes.data))
+        for k in range(n):
+            if nev[k]:
+                parts[k].append(ev[k, :nev[k]].copy())
+        if np.any(st["status"] == _lib.CHAIN_BOUND_VIOLATED):
+            raise RuntimeError("Tuning parameter `c` too small.")  # :55
+        if not np.any(st["status"] == _lib.CHAIN_TRACE_FULL):
+            break
+    Ξ = [np.concatenate(p) for p in parts]
+    ratio = st["acc"] / np.maximum(st["num"], 1)
+    return (Ξ[0], float(ratio[0])) if scalar else (Ξ, ratio)
+
+
+def _pdmp_nd(target, t0, x0, θ0, T, c, F, *, factor=1.8, adapt=False, subsample=False, seed=DEFAULT_SEED, device=0,
+             trace_capacity=None, trace=True):
     """pdmp(∇ϕ, t0, x0, θ0, T, c, F::ZigZag, args...) = spdmp(..., All(), ...) (src/sfact.jl:236): every proposal moves
     ALL coordinates (no sparsity assumption on ∇ϕ); same return value as spdmp.
 

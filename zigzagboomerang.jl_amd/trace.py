@@ -116,6 +116,48 @@ def _discretize_pdmp(tr: PDMPTrace, dt):
     return grid, xs
 
 
+def discretize_1d(events, flow, dt):
+    """discretize(x::Vector, Flow::Union{ZigZag1d, Boomerang1d}, dt) -- src/discretise.jl:10-42, the skeleton of the 1-d samplers to a
+    trajectory: the clock advances by dt inside a segment (the step that would cross the next event is shortened and the remainder carried
+    into the following segment, :28-29), the state flows by move_forward from the previous grid point (src/dynamics.jl:66-68,79-82), the last
+    segment is not emitted (:18) and the final clock / position is appended (:40).  events: structured (t, x, theta).  Returns (t, x)."""
+    from .flows import Boomerang1d
+    boom = isinstance(flow, Boomerang1d)
+    mu = flow.μ if boom else 0.0
+    n = len(events)
+    ts, xs = [0.0], [float(events["x"][0])]
+    clock, dt_cur = 0.0, float(dt)
+    xi, th = float(events["x"][0]), float(events["theta"][0])
+
+    def move(tau, clock, xi, th):
+        if boom:
+            s, c = np.sin(tau), np.cos(tau)
+            return clock + tau, (xi - mu) * c + th * s + mu, -(xi - mu) * s + th * c
+        return tau + clock, xi + th * tau, th
+
+    k = 0
+    while k < n - 2:
+        tau_next = float(events["t"][k + 1])
+        while clock + dt_cur <= tau_next:
+            if th == 0.0:
+                clock += dt_cur
+            else:
+                clock, xi, th = move(dt_cur, clock, xi, th)
+            ts.append(clock)
+            xs.append(xi)
+            dt_cur = float(dt)
+        dt_cur = dt_cur - (tau_next - clock)
+        if th == 0.0:
+            clock = tau_next
+        else:
+            clock, xi, th = move(tau_next - clock, clock, xi, th)
+        k += 1
+        xi, th = float(events["x"][k]), float(events["theta"][k])
+    ts.append(clock)
+    xs.append(xi)
+    return np.array(ts), np.array(xs)
+
+
 def discretize(tr, dt):
     """collect(discretize(Ξ, dt)): positions on the grid t0, t0+dt, ... -- src/trace.jl:94-125 (FactTrace: a grid point is
     emitted while it lies before the last event; events at or before a grid time are applied), :129-150 (PDMPTrace)."""
