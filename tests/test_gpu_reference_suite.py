@@ -120,3 +120,31 @@ def test_sticky_szigzag(gpu_pkg, Γ):
     m, xs = _stats(pkg, trace, 0.5)
     assert m < 2 / math.sqrt(T)
     assert np.mean(np.abs(np.cov(xs.T) - np.linalg.inv(Γ.toarray()))) < 2.5 / math.sqrt(T)
+
+
+def test_1d_samplers(gpu_pkg):
+    """test/test1d.jl:1-66 on the device: ZigZag1d with ∇ϕhat, Boomerang1d(1.0) with ∇ϕ, Boomerang1d(1.1, 1.2, 0.5) with ∇ϕhat; T = 8000,
+    the three chains in one call each (the reference's thresholds; the streams are named as in tests/test_oracle_1d.py)."""
+    pkg = gpu_pkg
+    μ, σ2, T = math.pi / 3, 1.3, 8000.0
+    noisy, exact = pkg.GaussianTarget1d(μ, σ2, 0.1), pkg.GaussianTarget1d(μ, σ2, 0.0)
+
+    def envelopes(out, flow, k):
+        n = len(out)
+        assert T / 10 < n < T * 10
+        ts, xs = pkg.trace.discretize_1d(out, flow, 0.01)
+        d_ = np.diff(ts[:len(ts) // 3])
+        assert abs(d_.min() - d_.max()) < 1e-10
+        assert abs(xs.mean() - μ) < k / math.sqrt(n)
+        assert abs(xs.var(ddof=1) - σ2) < (2.5 if k == 2 else k) / math.sqrt(n)
+
+    out1, _ = pkg.pdmp(noisy, 1.01, -1.5, T, 10.0, pkg.ZigZag1d(), seed=3)
+    est = np.sum((out1["x"][:-1] + out1["x"][1:]) / 2 * np.diff(out1["t"])) / T
+    assert abs(est - μ) < 2 / math.sqrt(len(out1))
+    envelopes(out1, pkg.ZigZag1d(), 2)
+    B = pkg.Boomerang1d(1.0)
+    out2, _ = pkg.pdmp(exact, 1.41, 0.5, T, 1.6, B, seed=4)
+    envelopes(out2, B, 5)
+    B = pkg.Boomerang1d(1.1, 1.2, 0.5)
+    out3, _ = pkg.pdmp(noisy, 1.41, 0.5, T, 10.0, B, seed=3)
+    envelopes(out3, B, 5)
