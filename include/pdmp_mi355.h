@@ -374,6 +374,7 @@ pdmp_status pdmp_ensemble_bps_final_state(pdmp_ensemble* ens, int64_t chain_firs
  *   consume()                            after EVERY run slice and before trace_reset: applies the buffered events (each coordinate's in
  *                                        order) -- the trapezoid sums of mean, the grid points a finished segment covers;
  *   consume_mean(chain_first, n, ...)    mean [n x d] and the last event time T of each chain (the reference's scale 1/(2T));
+ *   consume_inclusion(chain_first, n, ...)  inclusion_prob [n x d] (:161-178: time with x_i ≠ 0 before or after an event of i, over T);
  *   consume_discretized(chain, k_first, k_count, out, npoints, grid_dev)
  *                                        rows k_first .. of chain's grid positions [k_count x d]; *npoints = number of grid times the
  *                                        reference would emit so far (those before the chain's last event; at least t0); *grid_dev = the
@@ -384,6 +385,8 @@ pdmp_status pdmp_ensemble_bps_final_state(pdmp_ensemble* ens, int64_t chain_firs
 pdmp_status pdmp_ensemble_consume_begin(pdmp_ensemble* ens, double grid_dt, int64_t grid_points);
 pdmp_status pdmp_ensemble_consume(pdmp_ensemble* ens);
 pdmp_status pdmp_ensemble_consume_mean(pdmp_ensemble* ens, int64_t chain_first, int64_t n, double* mean, double* T_last);
+/* inclusion_prob(Ξ) (src/trace.jl:161-178) per chain: the fraction of [t0, T] each coordinate spent away from 0 -- what a sticky run is made for */
+pdmp_status pdmp_ensemble_consume_inclusion(pdmp_ensemble* ens, int64_t chain_first, int64_t n, double* prob, double* T_last);
 pdmp_status pdmp_ensemble_consume_discretized(pdmp_ensemble* ens, int64_t chain, int64_t k_first, int64_t k_count, double* out,
                                               int64_t* npoints, void** grid_dev);
 

@@ -88,6 +88,11 @@ def test_consumers_on_sticky_traces_and_refusals(gpu_pkg):
             grid, X = pkg.trace.discretize(traces[k], 0.5)
             assert np.array_equal(ens.consume_discretized(k), X)
             assert np.allclose(m[k], pkg.trace.mean(traces[k]), rtol=1e-12, atol=1e-15)
+        p, Tp = ens.consume_inclusion()
+        for k in range(2):  # inclusion_prob(Ξ), src/trace.jl:161-178: what a sticky run is for
+            ref = pkg.trace.inclusion_prob(traces[k])
+            assert np.allclose(p[k], ref, rtol=1e-12, atol=1e-15) and Tp[k] == traces[k].events["t"][-1]
+            assert 0.05 < ref.mean() < 0.95 and ref.min() < 0.9  # coordinates do spend time at 0
     with pkg.Ensemble(1, d, trace_capacity=100) as ens:
         ens.set_flow(pkg.ZigZag(G, np.zeros(d), λref=0.2))
         ens.set_target(pkg.GaussianTarget(G))

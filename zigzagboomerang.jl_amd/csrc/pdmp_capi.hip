@@ -1629,6 +1629,24 @@ pdmp_status pdmp_ensemble_consume_mean(pdmp_ensemble* e, int64_t chain_first, in
     return PDMP_OK;
 }
 
+pdmp_status pdmp_ensemble_consume_inclusion(pdmp_ensemble* e, int64_t chain_first, int64_t n, double* prob, double* T_last) {
+    if (!e || !prob) return fail(PDMP_ERR_INVALID, "null argument");
+    if (!e->consuming) return fail(PDMP_ERR_INVALID, "pdmp_ensemble_consume_begin first");
+    if (chain_first < 0 || n <= 0 || chain_first + n > e->cfg.nchains) return fail(PDMP_ERR_INVALID, "chain range");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const int64_t d = e->cfg.d;
+    DevBuf<double> bm, bt;
+    pdmp_status st;
+    if ((st = bm.alloc((size_t)(n * d))) != PDMP_OK) return st;
+    if ((st = bt.alloc((size_t)n)) != PDMP_OK) return st;
+    int rc = pdmp::launch_consume_inclusion(d, chain_first, n, e->d_ccur.p, e->d_cmeta.p, bm.p, bt.p, e->stream);
+    if (rc != 0) return fail(PDMP_ERR_HIP, "consume_inclusion launch failed: %s", hipGetErrorString((hipError_t)rc));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(prob, bm.p, (size_t)(n * d) * sizeof(double), hipMemcpyDeviceToHost));
+    if (T_last) HIP_TRY(hipMemcpy(T_last, bt.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    return PDMP_OK;
+}
+
 pdmp_status pdmp_ensemble_consume_discretized(pdmp_ensemble* e, int64_t chain, int64_t k_first, int64_t k_count, double* out, int64_t* npoints,
                                               void** grid_dev) {
     if (!e) return fail(PDMP_ERR_INVALID, "null argument");

@@ -44,6 +44,7 @@ int launch_zz_path_integrals(const ZzRec* rec, int64_t rec_stride, int64_t d, in
 // refresh clock; the sticky sampler's traces included).
 struct ConsumeCursor {
     double t, x, th, y;  // clock, position, velocity after the coordinate's last consumed event; Σ (x_prev + x_k)(t_k − t_prev)
+    double z;            // Σ (x_prev ≠ 0 | x_k ≠ 0)(t_k − t_prev): the time the coordinate was not stuck at 0 (inclusion_prob, src/trace.jl:161-178)
 };
 struct ConsumeMeta {
     uint64_t consumed;  // events of this chain consumed so far (global event index)
@@ -68,6 +69,7 @@ __global__ __launch_bounds__(256) void consume_init_kernel(const ZzRec* rec0, in
     c.x = r->x;  // (before any run: the records hold x0, θ0 at t0)
     c.th = r->th;
     c.y = 0.0;
+    c.z = 0.0;
     cur[k] = c;
 }
 
@@ -127,6 +129,7 @@ __global__ __launch_bounds__(256) void consume_events_kernel(const pdmp_event* e
                 ConsumeCursor c = cur[i];
                 consume_emit(grid, d, K, t0, dt, i, c, evt.t, false);
                 c.y += (c.x + evt.x) * (evt.t - c.t);  // src/trace.jl:193 without the common factor 1/(2T)
+                if (c.x != 0.0 || evt.x != 0.0) c.z += evt.t - c.t;  // :172 without the common factor 1/T (−0.0 of a freeze counts as 0)
                 c.t = evt.t;
                 c.x = evt.x;
                 c.th = evt.theta;
@@ -165,6 +168,24 @@ __global__ __launch_bounds__(256) void consume_mean_kernel(int64_t d, int64_t ch
     const double T = meta[chain].t_last;
     mean_out[k] = cur0[chain * d + i].y * (1 / (2 * T));  // y[i] summed over i's events, scaled once (src/trace.jl:190 scales every term)
     if (i == 0 && T_out) T_out[q] = T;
+}
+
+__global__ __launch_bounds__(256) void consume_inclusion_kernel(int64_t d, int64_t chain_first, int64_t n, const ConsumeCursor* cur0,
+                                                                const ConsumeMeta* meta, double* out, double* T_out) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n * d) return;
+    const int64_t q = k / d, i = k - q * d;
+    const int64_t chain = chain_first + q;
+    const double T = meta[chain].t_last;
+    out[k] = cur0[chain * d + i].z / T;  // (src/trace.jl:172 divides every term)
+    if (i == 0 && T_out) T_out[q] = T;
+}
+
+int launch_consume_inclusion(int64_t d, int64_t chain_first, int64_t n, const void* cur, const void* meta, double* out, double* T_out, void* stream) {
+    const int64_t tot = n * d;
+    hipLaunchKernelGGL(consume_inclusion_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d, chain_first, n,
+                       static_cast<const ConsumeCursor*>(cur), static_cast<const ConsumeMeta*>(meta), out, T_out);
+    return (int)hipGetLastError();
 }
 
 size_t consume_cursor_bytes() { return sizeof(ConsumeCursor); }

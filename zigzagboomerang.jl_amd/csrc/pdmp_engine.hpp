@@ -359,6 +359,7 @@ int launch_consume_events(const pdmp_event* ev, int64_t cap, const DevChain* hdr
                           int64_t K, double t0, double dt, void* stream);
 int launch_consume_flush(int64_t d, int64_t nchains, const void* cur, const void* meta, double* grid, int64_t K, double t0, double dt, void* stream);
 int launch_consume_mean(int64_t d, int64_t chain_first, int64_t n, const void* cur, const void* meta, double* mean_out, double* T_out, void* stream);
+int launch_consume_inclusion(int64_t d, int64_t chain_first, int64_t n, const void* cur, const void* meta, double* out, double* T_out, void* stream);
 int launch_zz_path_integrals(const ZzRec* rec, int64_t rec_stride, int64_t d, int64_t nchains, const int64_t* probes, int64_t nprobe,
                              double T, double* out, void* stream);
 int launch_math_probe(uint64_t seed, int64_t n, double* out, void* stream);

@@ -297,6 +297,14 @@ class Ensemble:
         _lib.check(self._L.pdmp_ensemble_consume_mean(self._h, int(chain_first), int(n), _ptr(m), _ptr(T)))
         return m, T
 
+    def consume_inclusion(self, chain_first=0, n=None):
+        """(inclusion_prob [n x d], T_last [n]): inclusion_prob(Ξ) of src/trace.jl:161-178 per chain, from the device-side cursors."""
+        if n is None:
+            n = self.nchains - chain_first
+        p, T = np.empty((n, self.d)), np.empty(n)
+        _lib.check(self._L.pdmp_ensemble_consume_inclusion(self._h, int(chain_first), int(n), _ptr(p), _ptr(T)))
+        return p, T
+
     def consume_discretized(self, chain, k_first=0, k_count=None):
         """(grid times, positions [npoints x d]) of collect(discretize(Ξ, dt)) for one chain (src/trace.jl:94-125)."""
         npts = C.c_int64()
