@@ -260,3 +260,26 @@ def test_bouncy_particle_with_a_target_of_its_own(gpu_pkg):
     b = pkg.pdmp(pkg.GaussianTarget(G, np.zeros(8)), 0.0, x0, th0, 30.0, 1.1, B, seed=3)
     for k in range(2):
         assert np.array_equal(a[0][k].t, b[0][k].t) and np.array_equal(a[0][k].x, b[0][k].x)
+
+
+@pytest.mark.parametrize("d", [1025, 2048, 3000, 4096])
+def test_more_than_1024_coordinates(gpu_pkg, d):
+    """The reference has no limit on d (src/not_fact_samplers.jl:117-147); beyond 1024 the vectors leave the plain register file (32 / 64
+    slots per lane in AGPRs and scratch: the general instantiation).  Isotropic as config C2, and a tridiagonal Γ with its Cholesky factor
+    and a mean (every solve goes through d dependent steps: short horizon)."""
+    pkg = gpu_pkg
+    rng = np.random.default_rng(d)
+    nch = 2
+    x0, th0 = rng.standard_normal((nch, d)), rng.standard_normal((nch, d))
+    tr = check(pkg, sp.identity(d, format="csc"), None, x0, th0, 1e-3, 3.0, 1.0, seed=70 + d)
+    assert all(len(q.t) > 2 for q in tr)
+    if d <= 2048:
+        G = sp.diags([np.full(d - 1, -0.4), np.full(d, 1.2), np.full(d - 1, -0.4)], [-1, 0, 1], format="csc")
+        check(pkg, G, 0.1 * rng.standard_normal(d), x0, th0, 0.5, 0.4, 1.0, rho=0.2, seed=90 + d)
+
+
+def test_4097_coordinates_are_refused(gpu_pkg):
+    pkg = gpu_pkg
+    with pytest.raises(pkg._lib.PdmpError) as ei:
+        pkg.Ensemble(1, 4097, sampler=pkg._lib.SAMPLER_BPS)
+    assert ei.value.code == pkg._lib.PDMP_ERR_UNSUPPORTED

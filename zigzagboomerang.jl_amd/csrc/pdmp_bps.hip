@@ -343,6 +343,18 @@ __global__ __launch_bounds__(64) void bps_run_kernel(BpsRunParams P) {
 
     bool running = stop_before || (t < T);  // `while t < T`, :136
     while (running) {  // (no priority turns here: the trace writes bound this kernel, and turns cost 15 % on BASELINE.json's C2)
+        if constexpr (NS > 16) {  // (the counters are wave-uniform: said so, they live in scalar registers instead of competing with 5 x NS doubles)
+            auto uni = [](uint64_t v) -> uint64_t {
+                return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
+                       (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+            };
+            num = uni(num);
+            nacc = uni(nacc);
+            nrefresh = uni(nrefresh);
+            ntrace = uni(ntrace);
+            nevents = uni(nevents);
+            nm = uni(nm);
+        }
         if (P.trace_cap > 0 && ntrace >= (uint64_t)P.trace_cap) {
             status = PDMP_CHAIN_TRACE_FULL;
             break;
@@ -671,6 +683,22 @@ static int launch_ns(const BpsRunParams& p, int64_t nchains, bool diag, bool ini
     return (int)hipGetLastError();
 }
 
+template <int NS>
+static int launch_big(const BpsRunParams& p, int64_t nchains, bool init, const uint64_t* seeds, double t0, double c0, void* stream) {
+    const size_t lds = (size_t)p.d * 8;
+    dim3 grid((unsigned)nchains), block(64);
+    const bool boom = p.flow_kind == 1;
+    if (init) {
+        if (boom) hipLaunchKernelGGL((bps_init_kernel<NS, true>), grid, block, lds, (hipStream_t)stream, p, seeds, t0, c0);
+        else hipLaunchKernelGGL((bps_init_kernel<NS, false>), grid, block, lds, (hipStream_t)stream, p, seeds, t0, c0);
+    } else if (boom) {
+        hipLaunchKernelGGL((bps_run_kernel<NS, false, true, false, false, true>), grid, block, lds, (hipStream_t)stream, p);
+    } else {
+        hipLaunchKernelGGL((bps_run_kernel<NS, false, false, false, false, true>), grid, block, lds, (hipStream_t)stream, p);
+    }
+    return (int)hipGetLastError();
+}
+
 static int dispatch(const BpsRunParams& p, int64_t nchains, bool diag, bool init, const uint64_t* seeds, double t0,
                     double c0, void* stream) {
     const int64_t ns = (p.d + 63) / 64;
@@ -679,6 +707,10 @@ static int dispatch(const BpsRunParams& p, int64_t nchains, bool diag, bool init
     if (ns <= 4) return launch_ns<4>(p, nchains, diag, init, seeds, t0, c0, stream);
     if (ns <= 8) return launch_ns<8>(p, nchains, diag, init, seeds, t0, c0, stream);
     if (ns <= 16) return launch_ns<16>(p, nchains, diag, init, seeds, t0, c0, stream);
+    // beyond 1024 coordinates the vectors no longer fit the register file as they are used here: the general instantiation (every option) is
+    // compiled for 32 and 64 slots per lane, the compiler keeping what does not fit in AGPRs and scratch -- a capability, not a fast path
+    if (ns <= 32) return launch_big<32>(p, nchains, init, seeds, t0, c0, stream);
+    if (ns <= 64) return launch_big<64>(p, nchains, init, seeds, t0, c0, stream);
     return -1;
 }
 

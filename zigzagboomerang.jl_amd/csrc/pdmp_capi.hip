@@ -367,8 +367,8 @@ pdmp_status pdmp_ensemble_create(const pdmp_config* cfg, pdmp_ensemble** out) {
     if (cfg->sampler != PDMP_SAMPLER_ZIGZAG_LOCAL && cfg->sampler != PDMP_SAMPLER_ZIGZAG_ALL &&
         cfg->sampler != PDMP_SAMPLER_BPS && cfg->sampler != PDMP_SAMPLER_STICKY_ZIGZAG)
         return fail(PDMP_ERR_UNSUPPORTED, "sampler %d has no device kernel yet", cfg->sampler);
-    if (cfg->sampler == PDMP_SAMPLER_BPS && cfg->d > 1024)
-        return fail(PDMP_ERR_UNSUPPORTED, "BPS keeps x, θ, ∇ϕ in registers: d <= 1024 (got %lld)", (long long)cfg->d);
+    if (cfg->sampler == PDMP_SAMPLER_BPS && cfg->d > 4096)
+        return fail(PDMP_ERR_UNSUPPORTED, "BPS keeps x, θ, ∇ϕ in registers (d <= 1024) or registers + scratch (d <= 4096): got %lld", (long long)cfg->d);
     if (cfg->trace_capacity < 0) return fail(PDMP_ERR_INVALID, "trace_capacity < 0");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
