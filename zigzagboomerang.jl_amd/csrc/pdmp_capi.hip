@@ -137,6 +137,7 @@ struct pdmp_ensemble {
     DevBuf<double> d_qbval;
     DevBuf<uint32_t> d_member;
     DevBuf<int64_t> lg_Acp, lg_Arv, lg_Atcp, lg_Atrv;
+    DevBuf<uint32_t> lg_Atrv32;
     DevBuf<double> lg_Anz, lg_Atnz, lg_y, lg_ny, lg_u0, lg_ns0;
     // packed tables of the LDS-resident logistic kernel (pdmp_logistic.hip); empty when the design does not qualify
     bool keep_integrals = true;  // pdmp_ensemble_set_path_integrals
@@ -842,6 +843,11 @@ extern "C" pdmp_status pdmp_ensemble_set_target_logistic(pdmp_ensemble* e, int64
     if ((st = e->lg_Anz.upload(std::vector<double>(A_nzval, A_nzval + nnzA))) != PDMP_OK) return st;
     if ((st = e->lg_Atcp.upload(std::vector<int64_t>(At_colptr, At_colptr + n + 1))) != PDMP_OK) return st;
     if ((st = e->lg_Atrv.upload(std::vector<int64_t>(At_rowval, At_rowval + nnzAt))) != PDMP_OK) return st;
+    {
+        std::vector<uint32_t> r32((size_t)nnzAt);
+        for (int64_t q = 0; q < nnzAt; ++q) r32[(size_t)q] = (uint32_t)At_rowval[q];
+        if ((st = e->lg_Atrv32.upload(r32)) != PDMP_OK) return st;
+    }
     if ((st = e->lg_Atnz.upload(std::vector<double>(At_nzval, At_nzval + nnzAt))) != PDMP_OK) return st;
     if ((st = e->lg_y.upload(std::vector<double>(y, y + n))) != PDMP_OK) return st;
     if ((st = e->lg_ny.upload(std::vector<double>(ny, ny + n))) != PDMP_OK) return st;
@@ -1270,6 +1276,7 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         Q.A_nzval = e->lg_Anz.p;
         Q.At_colptr = e->lg_Atcp.p;
         Q.At_rowval = e->lg_Atrv.p;
+        Q.At_row32 = e->lg_Atrv32.p;
         Q.At_nzval = e->lg_Atnz.p;
         Q.y = e->lg_y.p;
         Q.ny = e->lg_ny.p;

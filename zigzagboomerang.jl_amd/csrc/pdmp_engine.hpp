@@ -228,6 +228,7 @@ struct ZzGeneralParams {
     const double* __restrict__ A_nzval;
     const int64_t* __restrict__ At_colptr;   // A' (p x n), CSC by observation
     const int64_t* __restrict__ At_rowval;
+    const uint32_t* __restrict__ At_row32;  // the same indices in 4 bytes (p < 2^31): what the sweeps of long rows stream
     const double* __restrict__ At_nzval;
     const double* __restrict__ y;
     const double* __restrict__ ny;

@@ -594,26 +594,55 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
                             const int64_t eeA = rd64(e_end, z), eeB = hasB ? rd64(e_end, z + 1) : 0;
                             double uA = g_readlane(urow, z), uB = hasB ? g_readlane(urow, z + 1) : 0.0;
                             bool doneA = false, doneB = !hasB;
-                            while (!doneA || !doneB) {
+                            // the entries' column indices and coefficients of the NEXT chunk are requested before the records of this one: how far a
+                            // chunk reaches depends on the indices alone (the entries inside the range are a prefix), so the index stream runs one
+                            // round trip ahead of the record stream instead of alternating with it
+                            const uint32_t NOIX = 0x7fffffffu;
+                            uint32_t ccA = NOIX, ccB = NOIX;
+                            double weA = 0.0, weB = 0.0;
+                            {
                                 const int64_t fA = ecA + lane, fB = ecB + lane;
-                                const bool vA = !doneA && fA < eeA, vB = !doneB && fB < eeB;
-                                const int64_t ccA = vA ? Q.At_rowval[fA] : (int64_t)0x7fffffffffffffffll;
-                                const int64_t ccB = vB ? Q.At_rowval[fB] : (int64_t)0x7fffffffffffffffll;
-                                const bool inA = vA && ccA < rend, inB = vB && ccB < rend;  // (entries ascend: the lanes inside the range are a prefix)
-                                const int cntA = __popcll(__ballot(inA)), cntB = __popcll(__ballot(inB));
-                                double pA = 0.0, pB = 0.0;
-                                ZzRec* const rA = rec + (inA ? ccA : 0);
-                                ZzRec* const rB = rec + (inB ? ccB : 0);
-                                double xA = 0.0, thA = 0.0, tA = 0.0, IA = 0.0, weA = 0.0, xB = 0.0, thB = 0.0, tB = 0.0, IB = 0.0, weB = 0.0;
-                                if (inA) {
+                                if (fA < eeA) {
+                                    ccA = Q.At_row32[fA];
                                     weA = Q.At_nzval[fA];
+                                }
+                                if (hasB && fB < eeB) {
+                                    ccB = Q.At_row32[fB];
+                                    weB = Q.At_nzval[fB];
+                                }
+                            }
+                            while (!doneA || !doneB) {
+                                const bool inA = !doneA && ccA != NOIX && (int64_t)ccA < rend;  // (entries ascend: the lanes inside the range are a prefix)
+                                const bool inB = !doneB && ccB != NOIX && (int64_t)ccB < rend;
+                                const int cntA = __popcll(__ballot(inA)), cntB = __popcll(__ballot(inB));
+                                const bool lastA = doneA || cntA < 64, lastB = doneB || cntB < 64;
+                                uint32_t nccA = NOIX, nccB = NOIX;
+                                double nweA = 0.0, nweB = 0.0;
+                                if (!lastA) {
+                                    const int64_t fn = ecA + 64 + lane;
+                                    if (fn < eeA) {
+                                        nccA = Q.At_row32[fn];
+                                        nweA = Q.At_nzval[fn];
+                                    }
+                                }
+                                if (!lastB) {
+                                    const int64_t fn = ecB + 64 + lane;
+                                    if (fn < eeB) {
+                                        nccB = Q.At_row32[fn];
+                                        nweB = Q.At_nzval[fn];
+                                    }
+                                }
+                                double pA = 0.0, pB = 0.0;
+                                ZzRec* const rA = rec + (inA ? ccA : 0u);
+                                ZzRec* const rB = rec + (inB ? ccB : 0u);
+                                double xA = 0.0, thA = 0.0, tA = 0.0, IA = 0.0, xB = 0.0, thB = 0.0, tB = 0.0, IB = 0.0;
+                                if (inA) {
                                     xA = rA->x;
                                     thA = rA->th;
                                     tA = rA->t;
                                     IA = rA->I;
                                 }
                                 if (inB) {
-                                    weB = Q.At_nzval[fB];
                                     xB = rB->x;
                                     thB = rB->th;
                                     tB = rB->t;
@@ -643,8 +672,12 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
                                 for (int k2 = 0; k2 < cntB; ++k2) uB += g_readlane(pB, k2);
                                 ecA += cntA;
                                 ecB += cntB;
-                                doneA = doneA || cntA < 64;
-                                doneB = doneB || cntB < 64;
+                                doneA = lastA;
+                                doneB = lastB;
+                                ccA = nccA;
+                                weA = nweA;
+                                ccB = nccB;
+                                weB = nweB;
                             }
                             if (lane == z) {
                                 e_cur = ecA;
@@ -669,7 +702,7 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
                     const int e0hi = __shfl((int)(uint32_t)((uint64_t)e0 >> 32), q, 64);
                     if (f < etot) {
                         const int64_t eq = (int64_t)(((uint64_t)(uint32_t)e0hi << 32) | (uint64_t)(uint32_t)e0lo) + (int64_t)(f - exq);
-                        const int64_t cc = Q.At_rowval[eq];
+                        const int64_t cc = (int64_t)Q.At_row32[eq];
                         const double we = Q.At_nzval[eq];
                         ZzRec* r = rec + cc;
                         const double x0 = r->x, th0 = r->th, t0 = r->t, I0 = r->I;
