@@ -138,6 +138,7 @@ struct pdmp_ensemble {
     DevBuf<uint32_t> d_member;
     DevBuf<int64_t> lg_Acp, lg_Arv, lg_Atcp, lg_Atrv;
     DevBuf<uint32_t> lg_Atrv32;
+    DevBuf<double> d_hot;  // the moving halves of the records, packed, while a launch sweeps long logistic rows (pdmp_general.hip)
     DevBuf<double> lg_Anz, lg_Atnz, lg_y, lg_ny, lg_u0, lg_ns0;
     // packed tables of the LDS-resident logistic kernel (pdmp_logistic.hip); empty when the design does not qualify
     bool keep_integrals = true;  // pdmp_ensemble_set_path_integrals
@@ -1286,6 +1287,14 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         Q.ksub = e->lg_k;
         Q.lg_ne_max = (int32_t)std::min<int64_t>(e->lg_nemax, 1 << 30);
         // rows of thousands of coefficients: ranges that hold about 50 of a row's entries (64 lanes per chunk)
+        Q.hot = nullptr;
+        if (e->lg_nemax >= 1024) {
+            if (!e->d_hot.p) {
+                pdmp_status sth_ = e->d_hot.alloc((size_t)e->cfg.nchains * (size_t)e->cfg.d * 4);
+                if (sth_ != PDMP_OK) return sth_;
+            }
+            Q.hot = e->d_hot.p;
+        }
         Q.lg_range = (e->lg_nemax >= 1024) ? (int32_t)std::max<int64_t>(16, (int64_t)(PDMP_LG_FILL * 64.0 * (double)e->cfg.d / (double)e->lg_nemax)) : 0;
         Q.flow_kind = e->flow_kind;
         Q.mu = e->d_mu.p;

@@ -237,6 +237,7 @@ struct ZzGeneralParams {
     double gamma0;
     int64_t ksub;
     int32_t lg_ne_max;  // most regressors of any observation (max column length of A')
+    double* hot;        // [nchains x d x 4] scratch for the split state of the ranged sweeps (x, θ, t, ∫x dt per coordinate), or null
     int32_t lg_range;   // > 0: long rows (dense designs) are swept in coordinate ranges of this width, all sampled rows per range (see pdmp_general.hip)
     int32_t sticky;  // sspdmp (src/ss_fact.jl) on this kernel: rec.acc is the freeze flag f[i], P.thf / P.kappa are in use
     // flow_kind 1: FactBoomerang (src/types.jl:71-79)

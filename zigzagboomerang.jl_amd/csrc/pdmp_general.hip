@@ -96,9 +96,16 @@ __device__ __forceinline__ double g_sigmoid(double x) {
 }
 
 #define G_PCH 128u  // (member, entry) products staged per chunk by the re-bound step
+#define G_PROW 65u  // doubles between the product lines of two sampled rows (ranged sweep)
 
 size_t zz_general_lds_bytes(uint32_t nblk_pad, uint32_t mmax_pad, bool boom) {
     return (size_t)nblk_pad * 8 + (size_t)(boom ? 3 : 2) * mmax_pad * 8 + (size_t)nblk_pad * 4 + (size_t)2 * G_PCH * 8;
+}
+// ... plus, for the ranged sweep of long logistic rows, one line of products per sampled row (65 doubles apart: the lanes that add them up
+// read different banks)
+size_t zz_general_ranged_lds_bytes(int ksub) {  // (what the product lines need beyond the chunk buffers they overlay)
+    const size_t need = (size_t)ksub * G_PROW * 8, have = (size_t)2 * G_PCH * 8;
+    return need > have ? need - have : 0;
 }
 
 // LGFAST: instantiation for the plain spdmp + subsampled-logistic configuration (config C4): ZigZag flow, no refresh clock, no
@@ -135,6 +142,15 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
     double* sprod = px;  // [64] products A'[e, row] * x[e] of one chunk (logistic gradient; not live at the same time)
 
     ZzRec* rec = P.rec + chain * d;
+    // The moving half of a record -- (x, θ, t, ∫x dt) -- is reached through H(j): the first 32 bytes of rec[j], or, where the engine has split the
+    // ensemble's state for this launch (the sweeps of long logistic rows, config C5: half the bytes per swept coordinate and twice the
+    // coordinates per cache line), entry j of a packed array.  The bound, the accept flag and the keys stay where they are.
+    struct ZzHot {
+        double x, th, t, I;
+    };
+    char* const hot_base = Q.hot ? reinterpret_cast<char*>(Q.hot + (size_t)chain * (size_t)d * 4) : reinterpret_cast<char*>(rec);
+    const int64_t hot_stride = Q.hot ? 32 : 64;
+    auto H = [&](int64_t j) -> ZzHot* { return reinterpret_cast<ZzHot*>(hot_base + j * hot_stride); };
     double* keys = P.keys + chain * P.dk;
     DevChain* hdr = P.hdr + chain;
     pdmp_event* ev = P.ev ? P.ev + chain * P.trace_cap : nullptr;
@@ -224,7 +240,7 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
             const uint32_t pp = base + (uint32_t)lane;
             if (pp < p1) {
                 const uint32_t j = P.tb.sidx[sp0 + pp];
-                ZzRec* r = rec + j;
+                ZzHot* r = H(j);
                 const double x0 = r->x, th0 = r->th, t0 = r->t, I0 = r->I;
                 const double dt = tp - t0;
                 if (sticky && th0 == 0.0) {  // ssmove_forward!, src/ss_fact.jl:36-45: frozen coordinates keep their clock
@@ -261,7 +277,7 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
         for (uint32_t base = 0; base < (uint32_t)d; base += 64) {
             const uint32_t j = base + (uint32_t)lane;
             if (j < (uint32_t)d) {
-                ZzRec* r = rec + j;
+                ZzHot* r = H(j);
                 const double x0 = r->x, th0 = r->th, t0 = r->t, I0 = r->I;
                 const double dt = tp - t0;
                 if (!boom) {
@@ -288,8 +304,8 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
             const uint32_t pp = base + (uint32_t)lane;
             if (pp < p1) {
                 const uint32_t j = P.tb.sidx[sp0 + pp];
-                sx[pp] = rec[j].x;
-                sth[pp] = rec[j].th;
+                sx[pp] = H(j)->x;
+                sth[pp] = H(j)->th;
                 if (boom) smu[pp] = Q.mu[j];
             }
         }
@@ -394,7 +410,7 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
                     b = 0.0;
                 }
                 ZzRec* r = rec + j;
-                const double tj = own_clock ? r->t : tp;
+                const double tj = own_clock ? H(j)->t : tp;
                 double dtn = g_poisson_time_L(a, b, Ldraw);
                 if (local) {  // next_time, src/not_fact_samplers.jl:43-50: the bound expires after its horizon
                     const bool rn = dtn > hz;
@@ -494,7 +510,7 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
                 thn = sg2 * ((tho > 0) ? 1.0 : ((tho < 0) ? -1.0 : tho));  // σ[i]*sign(θ[i])
             } else {
                 if (Q.adaptscale) {  // :93-98
-                    const double ti2 = rec[i2].t;
+                    const double ti2 = H(i2)->t;
                     const double effi = (1 + 2 * Q.rho / (1 - Q.rho));
                     const double tau = effi / (ti2 * P.lambda_ref);
                     if (tau < 0.2) {
@@ -515,7 +531,7 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
             G_ORDER();
             if (lane == 0) {
                 sth[self2] = thn;
-                rec[i2].th = thn;
+                H(i2)->th = thn;
             }
             G_ORDER();
             const double newref = tp + (-pdmp_log(pdmp_u01(seed, PDMP_STREAM_GLOBAL, ng))) / P.lambda_ref;  // :108
@@ -527,7 +543,7 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
             requeue(cp2, 0, k2, true, (uint32_t)d);
             if (ev && lane == 0) {  // event(i, t, x, θ, F) = (t[i], i, x[i], θ[i]) at i's own clock, :143
                 pdmp_event e;
-                e.t = __hip_atomic_load(&rec[i2].t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                e.t = __hip_atomic_load(&H(i2)->t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 e.i = (int64_t)i2;
                 e.x = sx[self2];
                 e.theta = thn;
@@ -577,31 +593,39 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
                 // running sum still takes its entries in ascending order, and a move is the identity after the first, so nothing else changes.
                 const bool ranged = RANGED && !LGFAST && Q.lg_range > 0 && etot >= 2048;
                 if constexpr (RANGED) if (ranged) {
+                    // Lane z keeps row z's cursor and running sum.  A super-step takes ONE chunk of every row that still has entries inside the
+                    // range -- two rows at a time, so that both rows' records are requested before either is used --, moves the coordinates and
+                    // leaves the products in LDS, one line of 64 per row; then every row's products are added up by ITS lane, all rows side by
+                    // side, in entry order.  (Summing a row's chunk with wave-uniform readlane + add costs 3 instructions per matrix entry for
+                    // the whole wavefront -- 2·10⁵ per gradient of config C5, which made this kernel VALU-bound; now it is one LDS read and
+                    // one add per entry of the LONGEST chunk of the super-step.)
                     int64_t e_cur = e0;
                     const int64_t e_end = e0 + (int64_t)ne;
                     urow = 0.0;
+                    double* const prodm = px;  // [k_sub][G_PROW]: over the bound's chunk buffers (not live during a gradient) and beyond
+                    const uint32_t NOIX = 0x7fffffffu;
+                    auto rd64 = [&](int64_t v, int z) -> int64_t {
+                        return (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), z) << 32) |
+                                         (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)v, z));
+                    };
+                    const uint64_t allrows = (nq >= 64) ? ~0ull : ((1ull << nq) - 1ull);
                     for (int64_t rb = 0; rb < d; rb += Q.lg_range) {
                         const int64_t rend = rb + Q.lg_range;
-                        // two rows at a time: both rows' records are requested before either row's sum runs (the sweep is a chain of HBM round
-                        // trips otherwise); a record both rows move gets the same values stored twice
-                        auto rd64 = [&](int64_t v, int z) -> int64_t {
-                            return (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), z) << 32) |
-                                             (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)v, z));
-                        };
-                        for (int z = 0; z < nq; z += 2) {
-                            const bool hasB = z + 1 < nq;
-                            int64_t ecA = rd64(e_cur, z), ecB = hasB ? rd64(e_cur, z + 1) : 0;
-                            const int64_t eeA = rd64(e_end, z), eeB = hasB ? rd64(e_end, z + 1) : 0;
-                            double uA = g_readlane(urow, z), uB = hasB ? g_readlane(urow, z + 1) : 0.0;
-                            bool doneA = false, doneB = !hasB;
-                            // the entries' column indices and coefficients of the NEXT chunk are requested before the records of this one: how far a
-                            // chunk reaches depends on the indices alone (the entries inside the range are a prefix), so the index stream runs one
-                            // round trip ahead of the record stream instead of alternating with it
-                            const uint32_t NOIX = 0x7fffffffu;
-                            uint32_t ccA = NOIX, ccB = NOIX;
-                            double weA = 0.0, weB = 0.0;
-                            {
+                        uint64_t active = allrows;  // rows that may still have entries below rend (wave-uniform)
+                        while (active) {
+                            int mycnt = 0;
+                            uint64_t m_ = active;
+                            while (m_) {
+                                const int zA = __ffsll((unsigned long long)m_) - 1;
+                                m_ &= m_ - 1;
+                                const bool hasB = m_ != 0;
+                                const int zB = hasB ? (__ffsll((unsigned long long)m_) - 1) : zA;
+                                if (hasB) m_ &= m_ - 1;
+                                const int64_t ecA = rd64(e_cur, zA), eeA = rd64(e_end, zA);
+                                const int64_t ecB = rd64(e_cur, zB), eeB = rd64(e_end, zB);
                                 const int64_t fA = ecA + lane, fB = ecB + lane;
+                                uint32_t ccA = NOIX, ccB = NOIX;
+                                double weA = 0.0, weB = 0.0;
                                 if (fA < eeA) {
                                     ccA = Q.At_row32[fA];
                                     weA = Q.At_nzval[fA];
@@ -610,31 +634,11 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
                                     ccB = Q.At_row32[fB];
                                     weB = Q.At_nzval[fB];
                                 }
-                            }
-                            while (!doneA || !doneB) {
-                                const bool inA = !doneA && ccA != NOIX && (int64_t)ccA < rend;  // (entries ascend: the lanes inside the range are a prefix)
-                                const bool inB = !doneB && ccB != NOIX && (int64_t)ccB < rend;
+                                const bool inA = ccA != NOIX && (int64_t)ccA < rend;  // (entries ascend: the lanes inside the range are a prefix)
+                                const bool inB = ccB != NOIX && (int64_t)ccB < rend;
                                 const int cntA = __popcll(__ballot(inA)), cntB = __popcll(__ballot(inB));
-                                const bool lastA = doneA || cntA < 64, lastB = doneB || cntB < 64;
-                                uint32_t nccA = NOIX, nccB = NOIX;
-                                double nweA = 0.0, nweB = 0.0;
-                                if (!lastA) {
-                                    const int64_t fn = ecA + 64 + lane;
-                                    if (fn < eeA) {
-                                        nccA = Q.At_row32[fn];
-                                        nweA = Q.At_nzval[fn];
-                                    }
-                                }
-                                if (!lastB) {
-                                    const int64_t fn = ecB + 64 + lane;
-                                    if (fn < eeB) {
-                                        nccB = Q.At_row32[fn];
-                                        nweB = Q.At_nzval[fn];
-                                    }
-                                }
-                                double pA = 0.0, pB = 0.0;
-                                ZzRec* const rA = rec + (inA ? ccA : 0u);
-                                ZzRec* const rB = rec + (inB ? ccB : 0u);
+                                ZzHot* const rA = H(inA ? ccA : 0u);
+                                ZzHot* const rB = H(inB ? ccB : 0u);
                                 double xA = 0.0, thA = 0.0, tA = 0.0, IA = 0.0, xB = 0.0, thB = 0.0, tB = 0.0, IB = 0.0;
                                 if (inA) {
                                     xA = rA->x;
@@ -651,14 +655,14 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
                                 if (inA) {
                                     const double dt = tp - tA;
                                     const double xe = xA + thA * dt;
-                                    if (dt != 0.0) {
+                                    if (dt != 0.0) {  // (a coordinate an earlier row -- or the proposal's own move -- brought to t′ already)
                                         rA->x = xe;
                                         rA->t = tp;
                                         rA->I = IA + dt * ((xA + xe) * 0.5);
                                     }
-                                    pA = weA * xe;
+                                    prodm[zA * G_PROW + lane] = weA * xe;
                                 }
-                                if (inB) {
+                                if (inB) {  // (a record both rows move gets the same values stored twice)
                                     const double dt = tp - tB;
                                     const double xe = xB + thB * dt;
                                     if (dt != 0.0) {
@@ -666,27 +670,28 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
                                         rB->t = tp;
                                         rB->I = IB + dt * ((xB + xe) * 0.5);
                                     }
-                                    pB = weB * xe;
+                                    prodm[zB * G_PROW + lane] = weB * xe;
                                 }
-                                for (int k2 = 0; k2 < cntA; ++k2) uA += g_readlane(pA, k2);  // (every lane the same sum, in entry order)
-                                for (int k2 = 0; k2 < cntB; ++k2) uB += g_readlane(pB, k2);
-                                ecA += cntA;
-                                ecB += cntB;
-                                doneA = lastA;
-                                doneB = lastB;
-                                ccA = nccA;
-                                weA = nweA;
-                                ccB = nccB;
-                                weB = nweB;
+                                if (lane == zA) {
+                                    e_cur = ecA + cntA;
+                                    mycnt = cntA;
+                                }
+                                if (cntA < 64) active &= ~(1ull << zA);
+                                if (hasB) {
+                                    if (lane == zB) {
+                                        e_cur = ecB + cntB;
+                                        mycnt = cntB;
+                                    }
+                                    if (cntB < 64) active &= ~(1ull << zB);
+                                }
                             }
-                            if (lane == z) {
-                                e_cur = ecA;
-                                urow = uA;
+                            G_ORDER();
+                            for (int k2 = 0; k2 < 64; ++k2) {
+                                const bool more = k2 < mycnt;
+                                if (__ballot(more) == 0) break;
+                                if (more) urow += prodm[lane * G_PROW + k2];
                             }
-                            if (hasB && lane == z + 1) {
-                                e_cur = ecB;
-                                urow = uB;
-                            }
+                            G_ORDER();
                         }
                     }
                 }
@@ -704,7 +709,7 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
                         const int64_t eq = (int64_t)(((uint64_t)(uint32_t)e0hi << 32) | (uint64_t)(uint32_t)e0lo) + (int64_t)(f - exq);
                         const int64_t cc = (int64_t)Q.At_row32[eq];
                         const double we = Q.At_nzval[eq];
-                        ZzRec* r = rec + cc;
+                        ZzHot* r = H(cc);
                         const double x0 = r->x, th0 = r->th, t0 = r->t, I0 = r->I;
                         const double dt = tp - t0;
                         const double xe = x0 + th0 * dt;
@@ -747,12 +752,12 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
         };
         if (sticky) {
             // ---------------- sspdmp_inner!, src/ss_fact.jl:78-157, for neighbourhoods of any size
-            const double x_i0 = ri->x, th_i0 = ri->th;
+            const double x_i0 = H(i)->x, th_i0 = H(i)->th;
             const bool is_freeze = g_uniform(acc_i != 0 ? 1u : 0u) != 0;  // f[i]: rec.acc holds the flag for sticky chains
             const bool is_thaw = !is_freeze && g_uniform((x_i0 == 0 && th_i0 == 0) ? 1u : 0u) != 0;
             bool emit = true;
             if (is_freeze) {  // case 1, :87-107
-                const double dt = tp - ri->t;
+                const double dt = tp - H(i)->t;
                 const double xs = x_i0 + th_i0 * dt;  // smove_forward!(i, ...), :88
                 if (fabs(xs) > 1e-8) {                // :89-91
                     status = PDMP_CHAIN_BOUND_VIOLATED;
@@ -762,10 +767,11 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
                 nm += 1;
                 if (lane == 0) {
                     ZzRec* w = rec + i;
-                    w->I = ri->I + dt * ((x_i0 + xs) * 0.5);
-                    w->x = 0.0 * th_i0;  // x[i] = -0*θ[i], :92
-                    w->th = 0.0;         // :93
-                    w->t = tp;
+                    ZzHot* wh = H(i);
+                    wh->I = wh->I + dt * ((x_i0 + xs) * 0.5);
+                    wh->x = 0.0 * th_i0;  // x[i] = -0*θ[i], :92
+                    wh->th = 0.0;         // :93
+                    wh->t = tp;
                     w->t_old = tp;       // :94
                     w->acc = 0;          // f[i] = false, :95
                     thf[i] = th_i0;
@@ -790,8 +796,8 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
                 }
                 if (lane == 0) {
                     ZzRec* w = rec + i;
-                    w->t = tp;      // :109
-                    w->th = thn;
+                    H(i)->t = tp;      // :109
+                    H(i)->th = thn;
                     w->t_old = tp;  // :114
                     thf[i] = 0.0;
                 }
@@ -830,7 +836,7 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
                     move_members(sp0, k, m, tp);  // :138
                     if (lane == 0) {
                         sth[self] = -th_i;  // :139
-                        rec[i].th = -th_i;
+                        H(i)->th = -th_i;
                     }
                     G_ORDER();
                     reb_count = 0;
@@ -848,7 +854,7 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
             if (emit) {  // push!(Ξ, event(i, t, x, θ, F)), :154
                 G_ORDER();
                 if (ev && lane == 0) {
-                    const ZzRec* w = rec + i;
+                    const ZzHot* w = H(i);
                     pdmp_event e;
                     e.t = __hip_atomic_load(&w->t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     e.i = (int64_t)i;
@@ -910,7 +916,7 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
             else move_members(sp0, k, m, tp);                         // smove_forward!(G2, i, ...), :129
             if (lane == 0) {
                 sth[self] = -th_i;  // reflect!, :130
-                rec[i].th = -th_i;
+                H(i)->th = -th_i;
                 rec[i].acc = acc_i + 1;
             }
             G_ORDER();
@@ -962,12 +968,29 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
     }
 }
 
-int launch_zz_general_run(const ZzRunParams& p, const ZzGeneralParams& q, int64_t nchains, void* stream) {
-    const size_t lds = zz_general_lds_bytes(p.nblk_pad, q.mmax_pad, q.flow_kind == 1);
+// the moving halves of the records to a packed array and back (one pass over the state each way: ~1 % of a C5 slice)
+__global__ __launch_bounds__(256) void zz_hot_split_kernel(const ZzRec* __restrict__ rec, double* __restrict__ hot, int64_t n) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const double2 a = *reinterpret_cast<const double2*>(&rec[k].x), b = *reinterpret_cast<const double2*>(&rec[k].t);
+    reinterpret_cast<double2*>(hot)[2 * k] = a;
+    reinterpret_cast<double2*>(hot)[2 * k + 1] = b;
+}
+__global__ __launch_bounds__(256) void zz_hot_merge_kernel(ZzRec* __restrict__ rec, const double* __restrict__ hot, int64_t n) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    *reinterpret_cast<double2*>(&rec[k].x) = reinterpret_cast<const double2*>(hot)[2 * k];
+    *reinterpret_cast<double2*>(&rec[k].t) = reinterpret_cast<const double2*>(hot)[2 * k + 1];
+}
+
+int launch_zz_general_run(const ZzRunParams& p, const ZzGeneralParams& q_in, int64_t nchains, void* stream) {
+    ZzGeneralParams q = q_in;
+    size_t lds = zz_general_lds_bytes(p.nblk_pad, q.mmax_pad, q.flow_kind == 1);
     const bool prof = p.dbg != nullptr;
     const bool lgfast = !prof && !q.masked && q.target_kind == 1 && q.ksub == 10 && q.lg_ne_max <= 6 && !p.move_all && !p.has_refresh && !q.local_bound && !q.sticky &&
                         q.flow_kind == 0 && !q.adaptscale;
     const bool rng = !prof && !lgfast && q.target_kind == 1 && q.lg_range > 0;
+    if (rng) lds += zz_general_ranged_lds_bytes(q.ksub);
     const void* fn = prof ? reinterpret_cast<const void*>(zz_general_run_kernel<true, false, false>)
                    : lgfast ? reinterpret_cast<const void*>(zz_general_run_kernel<false, true, false>)
                    : rng ? reinterpret_cast<const void*>(zz_general_run_kernel<false, false, true>)
@@ -977,6 +1000,16 @@ int launch_zz_general_run(const ZzRunParams& p, const ZzGeneralParams& q, int64_
         if (e != hipSuccess) return (int)e;
     }
     const dim3 grid((unsigned)nchains), block(64);
+    // the ranged sweeps run on the split state (see H() in the kernel); every other instantiation keeps the records as they are
+    const bool split = rng && q.hot != nullptr;
+    if (!split) q.hot = nullptr;
+    const int64_t nrec = nchains * p.d;
+    if (split) {
+        hipLaunchKernelGGL(zz_hot_split_kernel, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p.rec, q.hot, nrec);
+        hipLaunchKernelGGL((zz_general_run_kernel<false, false, true>), grid, block, lds, (hipStream_t)stream, p, q);
+        hipLaunchKernelGGL(zz_hot_merge_kernel, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p.rec, q.hot, nrec);
+        return (int)hipGetLastError();
+    }
     if (prof) hipLaunchKernelGGL((zz_general_run_kernel<true, false, false>), grid, block, lds, (hipStream_t)stream, p, q);
     else if (lgfast) hipLaunchKernelGGL((zz_general_run_kernel<false, true, false>), grid, block, lds, (hipStream_t)stream, p, q);
     else if (rng) hipLaunchKernelGGL((zz_general_run_kernel<false, false, true>), grid, block, lds, (hipStream_t)stream, p, q);
