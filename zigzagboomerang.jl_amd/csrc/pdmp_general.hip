@@ -97,6 +97,9 @@ __device__ __forceinline__ double g_sigmoid(double x) {
 
 #define G_PCH 128u  // (member, entry) products staged per chunk by the re-bound step
 #define G_PROW 65u  // doubles between the product lines of two sampled rows (ranged sweep)
+#ifndef G_NR
+#define G_NR 3     // sampled rows whose records are in flight together in the ranged sweep
+#endif
 
 size_t zz_general_lds_bytes(uint32_t nblk_pad, uint32_t mmax_pad, bool boom) {
     return (size_t)nblk_pad * 8 + (size_t)(boom ? 3 : 2) * mmax_pad * 8 + (size_t)nblk_pad * 4 + (size_t)2 * G_PCH * 8;
@@ -594,7 +597,7 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
                 const bool ranged = RANGED && !LGFAST && Q.lg_range > 0 && etot >= 2048;
                 if constexpr (RANGED) if (ranged) {
                     // Lane z keeps row z's cursor and running sum.  A super-step takes ONE chunk of every row that still has entries inside the
-                    // range -- two rows at a time, so that both rows' records are requested before either is used --, moves the coordinates and
+                    // range -- G_NR rows at a time, so that all their records are requested before any is used --, moves the coordinates and
                     // leaves the products in LDS, one line of 64 per row; then every row's products are added up by ITS lane, all rows side by
                     // side, in entry order.  (Summing a row's chunk with wave-uniform readlane + add costs 3 instructions per matrix entry for
                     // the whole wavefront -- 2·10⁵ per gradient of config C5, which made this kernel VALU-bound; now it is one LDS read and
@@ -616,73 +619,63 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
                             int mycnt = 0;
                             uint64_t m_ = active;
                             while (m_) {
-                                const int zA = __ffsll((unsigned long long)m_) - 1;
-                                m_ &= m_ - 1;
-                                const bool hasB = m_ != 0;
-                                const int zB = hasB ? (__ffsll((unsigned long long)m_) - 1) : zA;
-                                if (hasB) m_ &= m_ - 1;
-                                const int64_t ecA = rd64(e_cur, zA), eeA = rd64(e_end, zA);
-                                const int64_t ecB = rd64(e_cur, zB), eeB = rd64(e_end, zB);
-                                const int64_t fA = ecA + lane, fB = ecB + lane;
-                                uint32_t ccA = NOIX, ccB = NOIX;
-                                double weA = 0.0, weB = 0.0;
-                                if (fA < eeA) {
-                                    ccA = Q.At_row32[fA];
-                                    weA = Q.At_nzval[fA];
-                                }
-                                if (hasB && fB < eeB) {
-                                    ccB = Q.At_row32[fB];
-                                    weB = Q.At_nzval[fB];
-                                }
-                                const bool inA = ccA != NOIX && (int64_t)ccA < rend;  // (entries ascend: the lanes inside the range are a prefix)
-                                const bool inB = ccB != NOIX && (int64_t)ccB < rend;
-                                const int cntA = __popcll(__ballot(inA)), cntB = __popcll(__ballot(inB));
-                                ZzHot* const rA = H(inA ? ccA : 0u);
-                                ZzHot* const rB = H(inB ? ccB : 0u);
-                                double xA = 0.0, thA = 0.0, tA = 0.0, IA = 0.0, xB = 0.0, thB = 0.0, tB = 0.0, IB = 0.0;
-                                if (inA) {
-                                    xA = rA->x;
-                                    thA = rA->th;
-                                    tA = rA->t;
-                                    IA = rA->I;
-                                }
-                                if (inB) {
-                                    xB = rB->x;
-                                    thB = rB->th;
-                                    tB = rB->t;
-                                    IB = rB->I;
-                                }
-                                if (inA) {
-                                    const double dt = tp - tA;
-                                    const double xe = xA + thA * dt;
-                                    if (dt != 0.0) {  // (a coordinate an earlier row -- or the proposal's own move -- brought to t′ already)
-                                        rA->x = xe;
-                                        rA->t = tp;
-                                        rA->I = IA + dt * ((xA + xe) * 0.5);
+                                // G_NR rows at a time: all their records are requested before any is used
+                                int zr[G_NR];
+                                bool has[G_NR];
+                                int64_t ec[G_NR];
+                                uint32_t cc[G_NR];
+                                double we[G_NR];
+                                bool in[G_NR];
+                                int cnt[G_NR];
+#pragma unroll
+                                for (int r = 0; r < G_NR; ++r) {
+                                    has[r] = m_ != 0;
+                                    zr[r] = has[r] ? (__ffsll((unsigned long long)m_) - 1) : zr[0];
+                                    if (has[r]) m_ &= m_ - 1;
+                                    ec[r] = rd64(e_cur, zr[r]);
+                                    const int64_t ee = rd64(e_end, zr[r]);
+                                    const int64_t f = ec[r] + lane;
+                                    cc[r] = NOIX;
+                                    we[r] = 0.0;
+                                    if (has[r] && f < ee) {
+                                        cc[r] = Q.At_row32[f];
+                                        we[r] = Q.At_nzval[f];
                                     }
-                                    prodm[zA * G_PROW + lane] = weA * xe;
                                 }
-                                if (inB) {  // (a record both rows move gets the same values stored twice)
-                                    const double dt = tp - tB;
-                                    const double xe = xB + thB * dt;
-                                    if (dt != 0.0) {
-                                        rB->x = xe;
-                                        rB->t = tp;
-                                        rB->I = IB + dt * ((xB + xe) * 0.5);
+                                double x_[G_NR], th_[G_NR], t_[G_NR], I_[G_NR];
+#pragma unroll
+                                for (int r = 0; r < G_NR; ++r) {
+                                    in[r] = cc[r] != NOIX && (int64_t)cc[r] < rend;  // (entries ascend: the lanes inside the range are a prefix)
+                                    cnt[r] = __popcll(__ballot(in[r]));
+                                    x_[r] = th_[r] = t_[r] = I_[r] = 0.0;
+                                    if (in[r]) {
+                                        const ZzHot* const h = H(cc[r]);
+                                        x_[r] = h->x;
+                                        th_[r] = h->th;
+                                        t_[r] = h->t;
+                                        I_[r] = h->I;
                                     }
-                                    prodm[zB * G_PROW + lane] = weB * xe;
                                 }
-                                if (lane == zA) {
-                                    e_cur = ecA + cntA;
-                                    mycnt = cntA;
-                                }
-                                if (cntA < 64) active &= ~(1ull << zA);
-                                if (hasB) {
-                                    if (lane == zB) {
-                                        e_cur = ecB + cntB;
-                                        mycnt = cntB;
+#pragma unroll
+                                for (int r = 0; r < G_NR; ++r) {
+                                    if (in[r]) {  // (a record two rows move gets the same values stored twice)
+                                        ZzHot* const h = H(cc[r]);
+                                        const double dt = tp - t_[r];
+                                        const double xe = x_[r] + th_[r] * dt;
+                                        if (dt != 0.0) {  // (a coordinate an earlier row -- or the proposal's own move -- brought to t′ already)
+                                            h->x = xe;
+                                            h->t = tp;
+                                            h->I = I_[r] + dt * ((x_[r] + xe) * 0.5);
+                                        }
+                                        prodm[zr[r] * G_PROW + lane] = we[r] * xe;
                                     }
-                                    if (cntB < 64) active &= ~(1ull << zB);
+                                    if (has[r]) {
+                                        if (lane == zr[r]) {
+                                            e_cur = ec[r] + cnt[r];
+                                            mycnt = cnt[r];
+                                        }
+                                        if (cnt[r] < 64) active &= ~(1ull << zr[r]);
+                                    }
                                 }
                             }
                             G_ORDER();
