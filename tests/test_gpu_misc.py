@@ -33,8 +33,8 @@ def test_unsupported_and_invalid_inputs_fail_loudly(gpu_pkg):
         assert ei.value.code == 4
         with pytest.raises(E):  # run before state
             ens.run(1.0)
-    with pytest.raises(E) as ei:  # BPS keeps the state in registers: d <= 1024
-        pkg.Ensemble(1, 2048, sampler=pkg._lib.SAMPLER_BPS)
+    with pytest.raises(E) as ei:  # BPS keeps the state in registers (and scratch beyond 1024 coordinates): d <= 4096
+        pkg.Ensemble(1, 4097, sampler=pkg._lib.SAMPLER_BPS)
     assert ei.value.code == 4
     with pkg.Ensemble(1, d, sampler=pkg._lib.SAMPLER_STICKY_ZIGZAG) as es:
         es.set_flow(pkg.ZigZag(G, np.zeros(d)))
