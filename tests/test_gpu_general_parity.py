@@ -267,9 +267,13 @@ def test_c4_state_in_lds_equals_state_in_hbm(gpu_pkg):
     TH0 = P["sigma"] * rng.choice([-1.0, 1.0], (nch, d))
     seeds = np.arange(nch, dtype=np.uint64) + 900
     runs = {}
-    for name, kernel, integrals in (("lds", "auto", True), ("lds_noI", "auto", False), ("hbm", "seq", True)):
+    # ... and the same state with SEVERAL chains per wavefront, each in a row of 32 or 16 lanes (pdmp_logrows.hip, opt-in: measured slower,
+    # DESIGN.md §5a): 6 chains = rows that are full, half full and -- in the last wavefront -- absent
+    for name, kernel, integrals, rows in (("lds", "auto", True, 0), ("lds_noI", "auto", False, 0), ("hbm", "seq", True, 0),
+                                          ("rows32", "auto", True, 32), ("rows16", "auto", True, 16), ("rows16_noI", "auto", False, 16)):
         with pkg.Ensemble(nch, d, adapt=True, factor=5.0, trace_capacity=400) as ens:
             ens.debug_set_kernel(kernel)
+            ens.debug_set_logistic_rows(rows)
             ens.set_flow(pkg.ZigZag(P["Gdrop"], P["mu"], P["sigma"]))
             ens.set_target(pkg.LogisticTarget(P["A"], P["y"], P["ny"], P["mu"], P["gamma0"], 10))
             ens.set_path_integrals(integrals)
@@ -295,7 +299,7 @@ def test_c4_state_in_lds_equals_state_in_hbm(gpu_pkg):
             runs[name] = (cnt, [np.concatenate(e) for e in evs], ens.final_state(), bm, pj)
     ref = runs["hbm"]
     assert ref[0]["nacc"].sum() > 300 and np.all(ref[0]["status"] == L.CHAIN_OK)
-    for name in ("lds", "lds_noI"):
+    for name in ("lds", "lds_noI", "rows32", "rows16", "rows16_noI"):
         cnt, evs, fs, bm, pj = runs[name]
         for f in ("num", "nacc", "nevents", "ndraw_main", "ndraw_global", "t_last"):
             assert np.array_equal(cnt[f], ref[0][f]), (name, f)

@@ -15,7 +15,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpdmp_mi355.so")
 SOURCES = ["pdmp_capi.hip", "pdmp_kernels.hip", "pdmp_bps.hip", "pdmp_general.hip", "pdmp_partition.hip", "pdmp_trackp.hip",
-           "pdmp_consume.hip", "pdmp_logistic.hip", "pdmp_comm.hip", "pdmp_exactp.hip", "pdmp_1d.hip"]
+           "pdmp_consume.hip", "pdmp_logistic.hip", "pdmp_comm.hip", "pdmp_exactp.hip", "pdmp_1d.hip", "pdmp_logrows.hip"]
 HEADERS = [os.path.join(CSRC, "pdmp_engine.hpp"),
            os.path.join(PKG_DIR, "..", "include", "pdmp_mi355.h"),
            os.path.join(PKG_DIR, "..", "include", "pdmp_debug.h"),

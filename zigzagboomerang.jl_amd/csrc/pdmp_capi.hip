@@ -108,6 +108,7 @@ struct pdmp_ensemble {
     DevBuf<double> d_keys, d_c_chain, d_jprev, d_sum;
     // diagnostics (include/pdmp_debug.h): per-ensemble state, no process globals
     int dbg_kernel = 0;            // PDMP_DEBUG_KERNEL_*
+    int dbg_lg_rows = -1;          // chains per wavefront of the LDS-resident logistic kernel: -1 default, 0 / 16 / 32 = one chain, rows of 16, of 32 lanes
     int dbg_spec_g2 = 0;           // 4-event kernel: fetch the G2 records speculatively
     int dbg_phase = 0;             // record the per-phase cycle profile of chain 0 during the next runs
     double dbg_phase_out[16] = {0};
@@ -201,6 +202,9 @@ struct pdmp_ensemble {
     }
 };
 
+#ifndef PDMP_LG_ROWS_DEFAULT
+#define PDMP_LG_ROWS_DEFAULT 0  // chains per wavefront of the LDS-resident logistic kernel by default: 0 = one (pdmp_logistic.hip), 16 / 32 = rows (pdmp_logrows.hip)
+#endif
 #ifndef PDMP_LG_FILL
 #define PDMP_LG_FILL 0.95  // lanes of a 64-entry chunk a range fills on average (ranged sweep of long logistic rows; 0.6 .. 1.1 measured on C5)
 #endif
@@ -351,6 +355,11 @@ pdmp_status pdmp_debug_phase_profile(pdmp_ensemble* e, double* out16, int* kind)
 pdmp_status pdmp_debug_set_track_groups(pdmp_ensemble* e, int on) {
     if (!e) return fail(PDMP_ERR_INVALID, "null argument");
     e->dbg_track_groups = (on == 1) ? 1 : 0;
+    return PDMP_OK;
+}
+pdmp_status pdmp_debug_set_logistic_rows(pdmp_ensemble* e, int w) {
+    if (!e || (w != -1 && w != 0 && w != 16 && w != 32)) return fail(PDMP_ERR_INVALID, "row width: -1 (default), 0 (one chain per wavefront), 16 or 32");
+    e->dbg_lg_rows = w;
     return PDMP_OK;
 }
 pdmp_status pdmp_debug_set_proposal_dump(pdmp_ensemble* e, int64_t n) {
@@ -1308,7 +1317,12 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         LT.qrow16 = e->d_qrow16.p;
         // small d: the chain's state lives in LDS for the whole slice (PDMP_DEBUG_KERNEL_SEQ keeps the records in HBM: A/B runs, parity tests)
         const bool lds_resident = e->dbg_kernel != PDMP_DEBUG_KERNEL_SEQ && pdmp::zz_logistic_lds_supported(P, Q, LT);
-        int rcg = lds_resident ? pdmp::launch_zz_logistic_lds(P, Q, LT, e->keep_integrals, e->cfg.nchains, s) : pdmp::launch_zz_general_run(P, Q, e->cfg.nchains, s);
+        // ... several chains per wavefront where the draws of a proposal fit a row (pdmp_logrows.hip); pdmp_debug_set_logistic_rows picks the width
+        const int rows_w = !lds_resident ? 0 : (e->dbg_lg_rows >= 0 ? e->dbg_lg_rows : PDMP_LG_ROWS_DEFAULT);
+        const bool rows = rows_w > 0 && pdmp::zz_logistic_rows_supported(P, Q, LT, rows_w);
+        if (lds_resident && e->dbg_lg_rows > 0 && !rows) return fail(PDMP_ERR_UNSUPPORTED, "pdmp_debug_set_logistic_rows: this ensemble does not fit rows of %d lanes", rows_w);
+        int rcg = rows ? pdmp::launch_zz_logistic_rows(P, Q, LT, e->keep_integrals, rows_w, e->cfg.nchains, s)
+                       : lds_resident ? pdmp::launch_zz_logistic_lds(P, Q, LT, e->keep_integrals, e->cfg.nchains, s) : pdmp::launch_zz_general_run(P, Q, e->cfg.nchains, s);
         if (rcg != 0) return fail(PDMP_ERR_HIP, "zz_general_run launch failed: %s", hipGetErrorString((hipError_t)rcg));
         HIP_TRY(hipEventRecord(e->ev1, s));
         e->timed = true;

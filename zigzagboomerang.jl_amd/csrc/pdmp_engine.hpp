@@ -284,6 +284,11 @@ size_t zz_logistic_lds_bytes(int64_t d, int64_t dk, bool with_I);
 bool zz_logistic_lds_supported(const ZzRunParams& p, const ZzGeneralParams& q, const ZzLogisticTables& lt);
 int launch_zz_logistic_lds(const ZzRunParams& p, const ZzGeneralParams& q, const ZzLogisticTables& lt, bool with_I, int64_t nchains,
                            void* stream);
+// 64 / W chains per wavefront, each in a row of W = 16 or 32 lanes (pdmp_logrows.hip)
+size_t zz_logistic_rows_lds_bytes(int64_t d, int W, bool with_I);
+bool zz_logistic_rows_supported(const ZzRunParams& p, const ZzGeneralParams& q, const ZzLogisticTables& lt, int W);
+int launch_zz_logistic_rows(const ZzRunParams& p, const ZzGeneralParams& q, const ZzLogisticTables& lt, bool with_I, int W, int64_t nchains,
+                            void* stream);
 size_t zz_general_lds_bytes(uint32_t nblk_pad, uint32_t mmax_pad, bool boom);
 
 // Bouncy particle sampler (pdmp_bps.hip): per chain x[d], θ[d] (SoA), 8 scalars {t, a, b, t′, τref, c, -, -}

@@ -46,6 +46,8 @@ class Ensemble:
             self.debug_set_kernel(k)
         if os.environ.get("PDMP_TRACK_GROUPS"):
             _lib.check(self._L.pdmp_debug_set_track_groups(self._h, int(os.environ["PDMP_TRACK_GROUPS"])))
+        if os.environ.get("PDMP_LG_ROWS"):
+            _lib.check(self._L.pdmp_debug_set_logistic_rows(self._h, int(os.environ["PDMP_LG_ROWS"])))
         if os.environ.get("PDMP_SPEC_G2"):
             _lib.check(self._L.pdmp_debug_set_spec_g2(self._h, 1))
 
@@ -53,6 +55,10 @@ class Ensemble:
     def debug_set_kernel(self, name):
         """'auto' | 'seq' (one event per iteration) | 'spec4' (4-event kernel where the 8-event one would run); before set_flow."""
         _lib.check(self._L.pdmp_debug_set_kernel(self._h, _lib.DEBUG_KERNELS[name]))
+
+    def debug_set_logistic_rows(self, row_width):
+        """Chains per wavefront of the LDS-resident logistic kernel: -1 default, 0 one chain, 16 / 32 = rows of that many lanes (pdmp_logrows.hip)."""
+        _lib.check(self._L.pdmp_debug_set_logistic_rows(self._h, int(row_width)))
 
     def debug_phase_profile(self, on=True):
         _lib.check(self._L.pdmp_debug_set_phase_profile(self._h, int(bool(on))))
