@@ -231,6 +231,10 @@ def make_workload(pkg, args, rank, local_rank):
         # (the engine's own ∫x_i dt -- no counterpart in the reference, nothing in this configuration reads it -- costs the state-in-LDS kernel
         # 8 of 32 bytes per coordinate: 8 instead of 12 chains per CU.  PDMP_BENCH_C4_INTEGRALS=1 keeps it.)
         ens.set_path_integrals(integrals)
+        if getattr(args, "tracked", False):
+            ens.set_gradient_tracking(True)
+            W["evaluation"] = ("tracked bounds (g_j = Gamma[:,j].x and gd_j = Gamma[:,j].theta carried per coordinate; bit-identical to the oracle's tracked evaluation, "
+                               "same index sequence as the moving evaluation until a rounding difference flips a decision); the gradient is the moving evaluation")
         ens.set_state(0.0, np.tile(P["x0"], (nch, 1)), P["sigma"] * rng.choice([-1.0, 1.0], (nch, d)), P["c"],
                       np.arange(nch, dtype=np.uint64) + np.uint64(seed0))
         # neighbourhood sizes of the bounding graph and row lengths of the design, as plain averages over coordinates / observations
@@ -300,6 +304,9 @@ def main():
                     help="after the timed region: one more step, then time the post-run exchange (all_gather counts -> gatherv of the "
                          "trace segments to rank 0 -> reduce of the batch-mean sums); printed as a separate `gather` object")
     ap.add_argument("--per-rank", action="store_true", help="add per-rank counters and chain-0 digests to the JSON line (tests)")
+    ap.add_argument("--tracked", action="store_true",
+                    help="C4: tracked bounds (pdmp_ensemble_set_gradient_tracking on the logistic target; bit-identical to the oracle's tracked evaluation) "
+                         "instead of the default, bit-identical moving evaluation")
     ap.add_argument("--exact", action="store_true",
                     help="C3: the bit-identical moving evaluation (zz_local_spec8_kernel) instead of the tracked-gradient one")
     args = ap.parse_args()
@@ -606,7 +613,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             tp = json.load(open(tpath))
-            ent = tp.get("configs", {}).get("C3X" if (args.config == "C3" and args.exact) else args.config)
+            ent = tp.get("configs", {}).get("C3X" if (args.config == "C3" and args.exact) else ("C4T" if (args.config == "C4" and args.tracked) else args.config))
             if ent and tp.get("source_hash") == source_hash():
                 units = {"proposal": num, "event": nev}[ent["per"]]
                 traffic = ent["hbm_bytes_per_unit"] * units / nlaunch
@@ -624,7 +631,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "evaluation": ("exact" if args.exact else "tracked") if args.config == "C3" else "exact",
+            "evaluation": ("exact" if args.exact else "tracked") if args.config == "C3" else ("tracked" if (args.config == "C4" and args.tracked) else "exact"),
             "config": {"workload": W["workload"] + (f"; evaluation: {W['evaluation']}" if "evaluation" in W else ""),
                        "chains_per_gpu": nch, "d": d, "dT": args.dt, "parallelism": f"chains sharded x{world}, no collective in the run"
                                       + (" (reductions of this line: " + ("pdmp_comm_allreduce, RCCL linked by the engine" if comm is not None else "torch.distributed " + backend) + ")" if world > 1 else "")},

@@ -293,6 +293,11 @@ pdmp_status pdmp_ensemble_final_sigma(pdmp_ensemble* ens, int64_t chain_first, i
  * the reference's lazy clocks t[j] (src/sfact.jl:211) from the times of the last proposal / accept around j.
  * Requirements (else set_state returns PDMP_ERR_UNSUPPORTED -- never a silent fall-back): PDMP_SAMPLER_ZIGZAG_LOCAL, ZigZag flow
  * without refresh, Gaussian target, symmetric Γ, lattice-like neighbourhoods (|G1| <= 5, |S| <= 13) and 2048 <= d <= 16384.
+ * With the LOGISTIC target (config C4; the same requirements on the flow, G = Matched(), a state that fits the LDS-resident kernel) the
+ * BOUNDS are tracked and the subsampled gradient stays the moving evaluation: a proposal moves coordinate i and what its sampled rows read,
+ * a rejection re-derives its bound from (g_i, gd_i, tg_i), an accepted event updates the k members of G1[i] instead of moving its two-hop
+ * set and summing every member's column afresh.  The oracle's spdmp_zigzag_tracked_lg states it sequentially; the device equals it bit for
+ * bit; the final clocks t[j] are the tracked process's own (a coordinate is as old as its last own event or visit by a sampled row).
  * Call before set_state.
  */
 pdmp_status pdmp_ensemble_set_gradient_tracking(pdmp_ensemble* ens, int enable);

@@ -649,6 +649,128 @@ static int spdmp_zigzag_tracked(int64_t d, const orc_zz_params* p, double t0, do
     return status;
 }
 
+/*
+ * Tracked BOUNDS under the subsampled logistic target (p->tracked with target_kind = 1): the bitwise statement of zz_logistic_lds_kernel's
+ * tracked instantiation (pdmp_logistic.hip).  The gradient stays the reference's moving evaluation -- ∇ϕmoving samples k observations and moves
+ * the coordinates their rows read (scripts/logistic.jl:78-95,107) -- but the affine bounds (src/fact_samplers.jl:50-54) no longer gather
+ * Γ[:,j]·x and Γ[:,j]·θ from a moved neighbourhood: every coordinate carries g_j = Γ[:,j]·x and gd_j = Γ[:,j]·θ at time tg_j, advanced
+ * exactly as in spdmp_zigzag_tracked above.  So a proposal moves nothing but coordinate i itself (its position enters the prior term and the
+ * event record) and what the sampled rows read; smove_forward!(G, i, ...) (:82) and smove_forward!(G2, i, ...) (:129) have no reader left.
+ *   proposal of i at t′:  x_i to t′;  l = (∇ϕmoving θ_i)⁺;  lb = (a_i + b_i (t′ − t_old_i))⁺;  coin                          (:116-121)
+ *   reject:               a = c_i + (g_i + gd_i (t′ − tg_i) − (Γμ)_i) θ_i,  b = c_i/100 + θ_i gd_i,  t_old = t′,  new key     (:137-140)
+ *   accept:               θ_i = −θ_i;  j ∈ G1[i] ascending: g_j += gd_j (t′ − tg_j), gd_j += Γ[j,i]·(−2θ_i), tg_j = t′, bound, key (:130-135)
+ * Same queue rule as the other tracked function (lowest coordinate on exactly tied keys), same draws in the same order as the moving
+ * evaluation.  The clocks returned in t are the tracked process's own (a coordinate is as old as its last own event or its last visit by a
+ * sampled row), the positions are the positions at those clocks.  Γ must be symmetric.
+ */
+static int spdmp_zigzag_tracked_lg(int64_t d, const orc_zz_params* p, double t0, double T, double* x, double* th, double* c, double* t,
+                                   int64_t* acc, orc_trace* tr, orc_zz_result* res) {
+    const orc_csc* Gb = p->bound_gamma;
+    if (p->flow_kind || p->lambda_ref > 0 || p->move_all || p->local_bound || p->adaptscale || p->nbr_G) return ORC_BAD_INPUT;
+    double* gmu_b = (double*)malloc((size_t)d * sizeof(double));
+    double* g = (double*)malloc((size_t)d * sizeof(double));
+    double* gd = (double*)malloc((size_t)d * sizeof(double));
+    double* tg = (double*)malloc((size_t)d * sizeof(double));
+    double* ba = (double*)malloc((size_t)d * sizeof(double));
+    double* bb = (double*)malloc((size_t)d * sizeof(double));
+    double* t_old = (double*)malloc((size_t)d * sizeof(double));
+    const uint64_t seed = p->seed;
+    uint64_t nm = 0, ng = 0;
+    orc_pq* Q = orc_pq_new(d + 1);
+    Q->lex = 1;
+    for (int64_t i = 0; i < d; ++i) {
+        gmu_b[i] = orc_idot(Gb, i, p->bound_mu);
+        g[i] = orc_idot(Gb, i, x);
+        gd[i] = orc_idot(Gb, i, th);
+        t[i] = tg[i] = t_old[i] = t0;
+        acc[i] = 0;
+        ba[i] = c[i] + (g[i] - gmu_b[i]) * th[i]; /* src/fact_samplers.jl:51 */
+        bb[i] = c[i] / 100 + th[i] * gd[i];       /* :52 */
+    }
+    for (int64_t i = 0; i < d; ++i) /* src/sfact.jl:186 */
+        orc_pq_enqueue(Q, i, orc_poisson_time(ba[i], bb[i], pdmp_u01(seed, PDMP_STREAM_MAIN, nm++)));
+    int64_t num = 0, nacc = 0;
+    int status = ORC_OK;
+    double tp = t0;
+    int done = 0;
+    while (!done && tp < T) { /* :199 */
+        for (;;) {
+            int64_t i;
+            double tq;
+            orc_pq_peek(Q, &i, &tq); /* :77 */
+            if (p->stop_before_T && !(tq < T)) {
+                done = 1;
+                break;
+            }
+            if (tq == INFINITY) {
+                status = ORC_STALLED;
+                done = 1;
+                break;
+            }
+            tp = tq;
+            move1(i, t, x, th, tp);
+            const double gi = logistic_grad_moving(p, i, t, x, th, tp, seed, &ng);
+            const double l = pos(gi * th[i]);                      /* :119 */
+            const double lb = pos(ba[i] + bb[i] * (tp - t_old[i])); /* :119 */
+            num += 1;
+            if (pdmp_u01(seed, PDMP_STREAM_MAIN, nm++) * lb < l) { /* :121 */
+                acc[i] += 1;
+                nacc += 1;
+                if (l >= lb) { /* :123 */
+                    if (!p->adapt) {
+                        status = ORC_BOUND_VIOLATED;
+                        done = 1;
+                        break;
+                    }
+                    c[i] *= p->factor; /* :127 */
+                }
+                const double th_i = th[i];
+                const double delta = -th_i - th_i;
+                th[i] = -th_i; /* :130 */
+                for (int64_t q = Gb->colptr[i]; q < Gb->colptr[i + 1]; ++q) { /* :131-135 */
+                    const int64_t j = Gb->rowval[q];
+                    const double gj = g[j] + gd[j] * (tp - tg[j]);
+                    const double gdj = gd[j] + Gb->nzval[q] * delta; /* Γ[j, i] = Γ[i, j] */
+                    g[j] = gj;
+                    gd[j] = gdj;
+                    tg[j] = tp;
+                    ba[j] = c[j] + (gj - gmu_b[j]) * th[j];
+                    bb[j] = c[j] / 100 + th[j] * gdj;
+                    t_old[j] = tp;
+                    const double L = pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm++));
+                    orc_pq_set(Q, j, tp + poisson_time_L(ba[j], bb[j], L));
+                }
+                trace_push(tr, tp, i, x[i], th[i]); /* :143 */
+                break;
+            } else { /* :136-140 */
+                const double g_now = g[i] + gd[i] * (tp - tg[i]);
+                ba[i] = c[i] + (g_now - gmu_b[i]) * th[i];
+                bb[i] = c[i] / 100 + th[i] * gd[i];
+                t_old[i] = tp;
+                const double L = pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm++));
+                orc_pq_set(Q, i, tp + poisson_time_L(ba[i], bb[i], L));
+                continue;
+            }
+        }
+        if (p->max_events > 0 && nacc >= p->max_events && !done) {
+            status = ORC_TRACE_LIMIT;
+            done = 1;
+        }
+    }
+    if (res) {
+        res->num = num;
+        res->nacc = nacc;
+        res->nrefresh = 0;
+        res->ndraw_main = nm;
+        res->ndraw_global = ng;
+        res->t_last = tp;
+        res->status = status;
+    }
+    orc_pq_free(Q);
+    free(gmu_b); free(g); free(gd); free(tg); free(ba); free(bb); free(t_old);
+    return status;
+}
+
 static nbr_graph graph_g2x(const nbr_graph* g1, const nbr_graph* gsub, int64_t d);
 
 /* @assert all(a.second ⊇ b.second for (a,b) in zip(G, G1)), src/sfact.jl:177 (both ascending) */
@@ -665,6 +787,7 @@ static int graph_contains(const nbr_graph* g, const nbr_graph* g1, int64_t d) {
 
 int orc_spdmp_zigzag(int64_t d, const orc_zz_params* p, double t0, double T, double* x, double* th,
                      double* c, double* t, int64_t* acc, orc_trace* tr, orc_zz_result* res) {
+    if (p->tracked && p->target_kind == 1) return spdmp_zigzag_tracked_lg(d, p, t0, T, x, th, c, t, acc, tr, res);
     if (p->tracked) return spdmp_zigzag_tracked(d, p, t0, T, x, th, c, t, acc, tr, res);
     zz_ctx cx;
     cx.d = d;

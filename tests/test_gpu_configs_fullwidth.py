@@ -133,10 +133,12 @@ def test_c2_full_width_4096_bps_chains(gpu_pkg):
             assert np.array_equal(x[-1], fs["x"][k]) and np.array_equal(th[-1], fs["theta"][k]) and t[-1] == fs["t"][k]
 
 
-def test_c4_full_width_8192_logistic_chains(gpu_pkg):
+@pytest.mark.parametrize("tracked", [False, True])
+def test_c4_full_width_8192_logistic_chains(gpu_pkg, tracked):
     """Config C4 at one GPU's share of its 65 536-chain ensemble: 8192 chains of the subsampled sparse logistic regression
     (n = 8840, p = 442, k = 10, SelfMoving, adapt, factor 5; scripts/logistic.jl:167).  Chains 0 and 8191 against the oracle; all
-    chains healthy; the trace of a spread of chains reconstructs its final velocities; the bounds only grow."""
+    chains healthy; the trace of a spread of chains reconstructs its final velocities; the bounds only grow.  tracked: the same with tracked
+    BOUNDS (pdmp_ensemble_set_gradient_tracking on the logistic target) against the oracle's tracked evaluation, bit for bit as well."""
     pkg = gpu_pkg
     L = pkg.problems.logistic_problem(m=20)
     p, nch, T = L["p"], 8192, 4.0
@@ -148,6 +150,7 @@ def test_c4_full_width_8192_logistic_chains(gpu_pkg):
     with pkg.Ensemble(nch, p, adapt=True, factor=5.0, trace_capacity=cap) as ens:
         ens.set_flow(pkg.ZigZag(L["Gdrop"], L["mu"], L["sigma"]))
         ens.set_target(pkg.LogisticTarget(L["A"], L["y"], L["ny"], L["mu"], L["gamma0"], 10))
+        ens.set_gradient_tracking(tracked)
         ens.set_state(0.0, X0, TH0, L["c"], np.arange(nch, dtype=np.uint64) + SEED0)
         ens.run(T)
         cnt = ens.counters()
@@ -155,7 +158,7 @@ def test_c4_full_width_8192_logistic_chains(gpu_pkg):
         lg = dict(A=L["A"], At=L["At"], y=L["y"], ny=L["ny"], mu=L["mu"], gamma0=L["gamma0"], k=10)
         for k in (0, nch - 1):
             r = O.spdmp_zigzag(L["Gdrop"], L["mu"], L["Gdrop"], X0[k], TH0[k], L["c"], T, seed=SEED0 + k, adapt=True, factor=5.0,
-                               logistic=lg)
+                               logistic=lg, tracked=tracked)
             assert r["status"] == 0
             _same_fact(ens.trace(k, counters=cnt), r["events"])
             fs = ens.final_state(k, 1)

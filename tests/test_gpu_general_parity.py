@@ -314,3 +314,63 @@ def test_c4_state_in_lds_equals_state_in_hbm(gpu_pkg):
     r = O.spdmp_zigzag(P["Gdrop"], P["mu"], P["Gdrop"], X0[0], TH0[0], P["c"], 12.0, seed=900, adapt=True, factor=5.0, logistic=lg,
                        sigma=P["sigma"], stop_before_T=True)
     assert np.array_equal(runs["lds"][1][0]["t"], r["events"]["t"]) and np.array_equal(runs["lds"][1][0]["i"], r["events"]["i"])
+
+
+def test_c4_tracked_bounds_equal_the_tracked_oracle(gpu_pkg):
+    """pdmp_ensemble_set_gradient_tracking on the logistic target (zz_logistic_lds_kernel<.., TRK>): bounds from the carried sums g_j = Γ[:,j]·x,
+    gd_j = Γ[:,j]·θ, the gradient still the moving evaluation.  In slices with trace refills (the sums live in HBM between launches), with and
+    without the engine's path integrals: events, counters, final clocks / positions / velocities, accept counts and adapted bounds equal the
+    oracle's tracked evaluation BIT FOR BIT; against the moving evaluation of the same chains: the same event indices, times to 1e-9.  What the
+    mode does not serve is refused with a status."""
+    pkg = gpu_pkg
+    L = pkg._lib
+    P = pkg.problems.logistic_problem(m=20)
+    d, nch, T = P["p"], 5, 14.0
+    rng = np.random.default_rng(14)
+    X0 = np.tile(P["x0"], (nch, 1)) + 0.01 * rng.standard_normal((nch, d))
+    TH0 = P["sigma"] * rng.choice([-1.0, 1.0], (nch, d))
+    seeds = np.arange(nch, dtype=np.uint64) + 1400
+    runs = {}
+    for name, tracked, integrals in (("trk", True, True), ("trk_noI", True, False), ("mov", False, True)):
+        with pkg.Ensemble(nch, d, adapt=True, factor=5.0, trace_capacity=300) as ens:
+            ens.set_flow(pkg.ZigZag(P["Gdrop"], P["mu"], P["sigma"]))
+            ens.set_target(pkg.LogisticTarget(P["A"], P["y"], P["ny"], P["mu"], P["gamma0"], 10))
+            ens.set_path_integrals(integrals)
+            ens.set_gradient_tracking(tracked)
+            ens.set_state(0.0, X0, TH0, P["c"], seeds)
+            evs = [[] for _ in range(nch)]
+            for Tk in (2.5, 9.0, T):
+                while True:
+                    ens.run(Tk, L.RUN_STOP_BEFORE)
+                    cnt = ens.counters()
+                    for k in range(nch):
+                        evs[k].append(ens.trace(k, counters=cnt))
+                    ens.trace_reset()
+                    if not np.any(cnt["status"] == L.CHAIN_TRACE_FULL):
+                        break
+            pj = ens.path_integrals(T, np.arange(0, d, 9)) if integrals else None
+            runs[name] = (cnt, [np.concatenate(e) for e in evs], ens.final_state(), pj)
+    lg = dict(A=P["A"], At=P["At"], y=P["y"], ny=P["ny"], mu=P["mu"], gamma0=P["gamma0"], k=10)
+    for k in range(nch):
+        r = O.spdmp_zigzag(P["Gdrop"], P["mu"], P["Gdrop"], X0[k], TH0[k], P["c"], T, seed=1400 + k, adapt=True, factor=5.0, logistic=lg,
+                           sigma=P["sigma"], stop_before_T=True, tracked=True)
+        assert r["status"] == 0 and len(r["events"]) > 1500
+        for name in ("trk", "trk_noI"):
+            cnt, evs, fs, _ = runs[name]
+            for f in ("i", "t", "x", "theta"):
+                assert np.array_equal(evs[k][f], r["events"][f]), (name, k, f)
+            assert int(cnt["num"][k]) == r["num"] and int(cnt["ndraw_main"][k]) == r["ndraw_main"] and int(cnt["ndraw_global"][k]) == r["ndraw_global"]
+            for f, g in (("t", "t"), ("x", "x"), ("theta", "theta"), ("acc", "acc"), ("c", "c")):
+                assert np.array_equal(fs[f][k], r[g]), (name, k, f)
+        mov = runs["mov"][1][k]
+        assert np.array_equal(mov["i"], r["events"]["i"]) and np.allclose(mov["t"], r["events"]["t"], rtol=1e-9, atol=0)
+    # the engine's ∫x dt of a tracked run: the same path, so the same integrals as the moving evaluation's to rounding
+    assert np.allclose(runs["trk"][3], runs["mov"][3], rtol=1e-9, atol=1e-9)
+    # refusals: a refresh clock; an explicit neighbourhood argument
+    with pkg.Ensemble(1, d, adapt=True, factor=5.0, trace_capacity=100) as ens:
+        ens.set_flow(pkg.ZigZag(P["Gdrop"], P["mu"], P["sigma"], λref=0.3))
+        ens.set_target(pkg.LogisticTarget(P["A"], P["y"], P["ny"], P["mu"], P["gamma0"], 10))
+        ens.set_gradient_tracking(True)
+        with pytest.raises(L.PdmpError) as ei:
+            ens.set_state(0.0, X0[:1], TH0[:1], P["c"], seeds[:1])
+        assert ei.value.code == L.PDMP_ERR_UNSUPPORTED

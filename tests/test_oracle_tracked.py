@@ -88,3 +88,25 @@ def test_tracked_refuses_what_the_kernels_refuse(pkg):
     Gt[0, 5] = Gt[5, 0] = 0.1
     r = O.spdmp_zigzag(G, None, sp.csc_matrix(Gt), x0, th0, c, 1.0, seed=1, tracked=True)
     assert r["status"] == 4  # the target's pattern differs from the bound's
+
+
+def test_tracked_bounds_under_the_logistic_target(pkg):
+    """p->tracked with the subsampled logistic target (config C4): bounds from carried sums, the gradient still the moving evaluation
+    (oracle/pdmp_oracle.c: spdmp_zigzag_tracked_lg).  Against the moving evaluation: the same 9 000 events in the same order (82 000
+    proposals, adaptation on), times and positions to 1e-9; slicing changes nothing; what the kernels refuse is refused."""
+    P = pkg.problems.logistic_problem(m=20)
+    lg = dict(A=P["A"], At=P["At"], y=P["y"], ny=P["ny"], mu=P["mu"], gamma0=P["gamma0"], k=10)
+    rng = np.random.default_rng(1)
+    th0 = P["sigma"] * rng.choice([-1.0, 1.0], P["p"])
+    kw = dict(seed=5, adapt=True, factor=5.0, logistic=lg, sigma=P["sigma"])
+    a = O.spdmp_zigzag(P["Gdrop"], P["mu"], P["Gdrop"], P["x0"], th0, P["c"], 30.0, **kw)
+    b = O.spdmp_zigzag(P["Gdrop"], P["mu"], P["Gdrop"], P["x0"], th0, P["c"], 30.0, tracked=True, **kw)
+    assert a["status"] == b["status"] == 0 and a["num"] == b["num"] > 50000 and len(a["events"]) == len(b["events"]) > 5000
+    assert np.array_equal(a["events"]["i"], b["events"]["i"]) and np.array_equal(a["events"]["theta"], b["events"]["theta"])
+    assert np.allclose(a["events"]["t"], b["events"]["t"], rtol=1e-9, atol=0) and np.allclose(a["events"]["x"], b["events"]["x"], rtol=1e-9, atol=1e-9)
+    assert np.array_equal(a["acc"], b["acc"]) and np.array_equal(a["c"], b["c"]) and a["ndraw_global"] == b["ndraw_global"]
+    assert not np.array_equal(a["events"]["t"], b["events"]["t"])  # (another arithmetic: not bit-identical)
+    # the tracked clocks are the coordinates' own: never later than the moving evaluation's, which also advance with the neighbours
+    assert np.all(b["t"] <= a["t"] + 1e-12) and np.any(b["t"] < a["t"])
+    r = O.spdmp_zigzag(P["Gdrop"], P["mu"], P["Gdrop"], P["x0"], th0, P["c"], 1.0, tracked=True, lambda_ref=0.5, **kw)
+    assert r["status"] == 4  # ORC_BAD_INPUT: a refresh clock

@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 
 # C3: zz_local_trackw_kernel (one proposal per lane) or zz_local_track_kernel (8-lane groups) -- matched by their common prefix
 MAIN = {"C3": "zz_local_track", "C3X": "zz_local_spec8_kernel", "C2": "bps_run_kernel", "C4": "zz_logistic_lds_kernel",
-        "C5": "zz_general_run_kernel"}
+        "C4T": "zz_logistic_lds_kernel", "C5": "zz_general_run_kernel"}
 
 
 def rows(path):
@@ -80,7 +80,7 @@ def main():
         ks = rows(find(out, f"{C}_stats", "st_kernel_stats.csv"))
         kt = rows(find(out, f"{C}_stats", "st_kernel_trace.csv"))
         with open(os.path.join(summ, f"{tag}_{C}_kernel_stats.txt"), "w") as f:
-            f.write(f"# rocprofv3 --kernel-trace --stats of: python bench.py --config {C.replace('C3X', 'C3 --exact')} --steps {B['steps']} --warmup {B['warmup']} "
+            f.write(f"# rocprofv3 --kernel-trace --stats of: python bench.py --config {C.replace('C3X', 'C3 --exact').replace('C4T', 'C4 --tracked')} --steps {B['steps']} --warmup {B['warmup']} "
                     f"--no-cpu-baseline --ess-batches 0\n# bench line of the same command: ms_per_step {B['ms_per_step']:.3f}, "
                     f"roofline.kernel_ms_avg {B['roofline']['kernel_ms_avg']:.3f} (HIP events), launches_per_step {B['roofline']['launches_per_step']}\n")
             f.write(f"{'kernel':72s} {'calls':>6s} {'total_ms':>12s} {'avg_ms':>12s} {'min_ms':>12s} {'max_ms':>12s} {'pct':>7s}\n")

@@ -6,16 +6,17 @@
 #   tools/profile_collect.py (run here, copied into profiles/ by the caller).
 set -u
 TAG=$1; shift
-CONFIGS=${@:-C3 C3X C2 C4 C5}   # C3X = C3 on the bit-identical moving kernel (bench.py --exact)
+CONFIGS=${@:-C3 C3X C2 C4 C4T C5}   # C3X = C3 on the bit-identical moving kernel (bench.py --exact); C4T = C4 with tracked bounds (--tracked)
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 for C in $CONFIGS; do
-  case $C in C3|C3X) ST=8;; C2) ST=8;; C4) ST=6;; C5) ST=4;; esac
+  case $C in C3|C3X) ST=8;; C2) ST=8;; C4|C4T) ST=6;; C5) ST=4;; esac
   ARGS="--config $C --steps $ST --warmup 2 --no-cpu-baseline --ess-batches 0 --exact-steps 0"
   if [ "$C" = C3X ]; then ARGS="--config C3 --exact --steps $ST --warmup 2 --no-cpu-baseline --ess-batches 0 --exact-steps 0"; fi
+  if [ "$C" = C4T ]; then ARGS="--config C4 --tracked --steps $ST --warmup 2 --no-cpu-baseline --ess-batches 0 --exact-steps 0"; fi
   python $ROOT/bench.py $ARGS 2>/dev/null | grep '^{' > "$OUT/${C}_bench.json"
   timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/${C}_stats" -o st --output-format csv -- python $ROOT/bench.py $ARGS > "$OUT/${C}_stats.log" 2>&1
   timeout 900 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum -d "$OUT/${C}_pmc" -o fetch --output-format csv -- python $ROOT/bench.py $ARGS > "$OUT/${C}_fetch.log" 2>&1

@@ -117,6 +117,8 @@ struct pdmp_ensemble {
     int dbg_track_groups = 0;      // gradient tracking: keep the 8-lane-group kernel where the one-proposal-per-lane kernel would run
     // tracked-gradient kernel (pdmp_ensemble_set_gradient_tracking)
     bool track_requested = false, track = false, track_two_sums = false;
+    bool track_lg = false;     // tracked bounds under the logistic target (zz_logistic_lds_kernel<.., TRK>); d_trk holds (g, gd, tg) per coordinate
+    DevBuf<double> d_trk;
     bool exactp = false;       // the moving evaluation runs on zz_local_exactp_kernel (plain lattice; decided by set_state)
     bool track_pairs = false;  // the queue's level 0 is (key, time) pairs in d_kp (pdmp_trackp.hip); decided by set_state
     DevBuf<double> d_kp;
@@ -972,6 +974,24 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
     HIP_TRY(hipSetDevice(e->cfg.device));
     const int64_t d = e->cfg.d, n = e->cfg.nchains;
     e->track = false;
+    e->track_lg = false;
+    if (e->track_requested && e->target_kind == 1) {
+        // tracked BOUNDS under the subsampled logistic target (pdmp_logistic.hip, TRK): the plain spdmp configuration of config C4 only
+        if (e->cfg.sampler != PDMP_SAMPLER_ZIGZAG_LOCAL || e->flow_kind != 0 || e->adaptscale || e->local_bound || e->lambda_ref > 0 ||
+            e->dbg_kernel != PDMP_DEBUG_KERNEL_AUTO || e->dbg_dump > 0 || e->has_g1mask)
+            return fail(PDMP_ERR_UNSUPPORTED, "gradient tracking with the logistic target: spdmp, ZigZag flow without refresh, G = Matched()");
+        bool sym = true;
+        for (int64_t col = 0; col < d && sym; ++col)
+            for (uint32_t pp = e->colptr[col]; pp < e->colptr[col + 1] && sym; ++pp) {
+                const uint32_t row = e->rowval[pp];
+                const uint32_t* lo = e->rowval.data() + e->colptr[row];
+                const uint32_t* hi = e->rowval.data() + e->colptr[row + 1];
+                const uint32_t* it = std::lower_bound(lo, hi, (uint32_t)col);
+                if (it == hi || *it != (uint32_t)col || e->bval[(size_t)(it - e->rowval.data())] != e->bval[pp]) sym = false;
+            }
+        if (!sym) return fail(PDMP_ERR_UNSUPPORTED, "gradient tracking needs a symmetric bounding matrix");
+        e->track_lg = true;
+    } else
     if (e->track_requested) {
         // opt-in, so never a silent fall-back: everything the tracked-gradient kernel needs is checked here
         if (e->cfg.sampler != PDMP_SAMPLER_ZIGZAG_LOCAL || e->needs_general || e->target_kind != 0 || e->flow_kind != 0 || e->adaptscale ||
@@ -1127,6 +1147,11 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
     }
     int rc = pdmp::launch_zz_init(P, e->stream);
     if (rc != 0) return fail(PDMP_ERR_HIP, "zz_init launch failed: %s", hipGetErrorString((hipError_t)rc));
+    if (e->track_lg) {
+        if (e->d_trk.n != (size_t)(n * d * 4) && (st = e->d_trk.alloc((size_t)(n * d * 4))) != PDMP_OK) return st;
+        int rct = pdmp::launch_zz_logistic_track_init(e->d_rec.p, e->tables(), d, n, t0, e->d_trk.p, e->stream);
+        if (rct != 0) return fail(PDMP_ERR_HIP, "zz_logistic_track_init launch failed: %s", hipGetErrorString((hipError_t)rct));
+    }
     e->track_pairs = false;
     if (e->track) {
         // which tracked kernel will run is decided HERE (the pair layout belongs to one of them): pdmp_debug_set_track_groups before set_state
@@ -1315,10 +1340,13 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         LT.a_row = e->lg_arow.p;
         LT.a_val = e->lg_Anz.p;
         LT.qrow16 = e->d_qrow16.p;
+        LT.trk = e->track_lg ? e->d_trk.p : nullptr;
         // small d: the chain's state lives in LDS for the whole slice (PDMP_DEBUG_KERNEL_SEQ keeps the records in HBM: A/B runs, parity tests)
         const bool lds_resident = e->dbg_kernel != PDMP_DEBUG_KERNEL_SEQ && pdmp::zz_logistic_lds_supported(P, Q, LT);
         // ... several chains per wavefront where the draws of a proposal fit a row (pdmp_logrows.hip); pdmp_debug_set_logistic_rows picks the width
-        const int rows_w = !lds_resident ? 0 : (e->dbg_lg_rows >= 0 ? e->dbg_lg_rows : PDMP_LG_ROWS_DEFAULT);
+        if (e->track_lg && !lds_resident)
+            return fail(PDMP_ERR_UNSUPPORTED, "gradient tracking with the logistic target runs on the LDS-resident kernel: d <= 512, k_sub <= 32, rows of <= 6 regressors");
+        const int rows_w = (!lds_resident || e->track_lg) ? 0 : (e->dbg_lg_rows >= 0 ? e->dbg_lg_rows : PDMP_LG_ROWS_DEFAULT);
         const bool rows = rows_w > 0 && pdmp::zz_logistic_rows_supported(P, Q, LT, rows_w);
         if (lds_resident && e->dbg_lg_rows > 0 && !rows) return fail(PDMP_ERR_UNSUPPORTED, "pdmp_debug_set_logistic_rows: this ensemble does not fit rows of %d lanes", rows_w);
         int rcg = rows ? pdmp::launch_zz_logistic_rows(P, Q, LT, e->keep_integrals, rows_w, e->cfg.nchains, s)

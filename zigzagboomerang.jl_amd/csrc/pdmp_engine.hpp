@@ -279,7 +279,9 @@ struct ZzLogisticTables {
     const uint32_t* __restrict__ a_row;    // [nnz(A)] observation of every entry of A, column by column
     const double* __restrict__ a_val;      // [nnz(A)]
     const uint16_t* __restrict__ qrow16;   // like ZzGeneralParams::qbval: the ROW (coordinate) of the same (member, entry) pair
+    double* trk;                           // [nchains x d x 4] (g, gd, tg, -): tracked sums of the bounds (pdmp_ensemble_set_gradient_tracking), or null
 };
+int launch_zz_logistic_track_init(const ZzRec* rec, const ZzTables& tb, int64_t d, int64_t nchains, double t0, double* trk, void* stream);
 size_t zz_logistic_lds_bytes(int64_t d, int64_t dk, bool with_I);
 bool zz_logistic_lds_supported(const ZzRunParams& p, const ZzGeneralParams& q, const ZzLogisticTables& lt);
 int launch_zz_logistic_lds(const ZzRunParams& p, const ZzGeneralParams& q, const ZzLogisticTables& lt, bool with_I, int64_t nchains,

@@ -122,7 +122,11 @@ size_t zz_logistic_lds_bytes(int64_t d, int64_t dk, bool with_I) {
     return (size_t)d * (with_I ? 32 : 24) + (size_t)2 * LG_PCH * 8 + (size_t)LG_PCH * 4;
 }
 
-template <bool PROF, bool WITH_I>
+// TRK: tracked BOUNDS (pdmp_ensemble_set_gradient_tracking on this configuration; oracle: spdmp_zigzag_tracked_lg): every coordinate carries
+// g_j = Γ[:,j]·x and gd_j = Γ[:,j]·θ at time tg_j in LT.trk, so that a proposal moves nothing but coordinate i and what the sampled rows read, a
+// rejection re-derives its bound from (g_i, gd_i, tg_i), and an accepted event updates the k members of G1[i] instead of moving its two-hop
+// set and summing every member's column afresh.  The gradient is the moving evaluation unchanged.
+template <bool PROF, bool WITH_I, bool TRK = false>
 __global__ __launch_bounds__(64) void zz_logistic_lds_kernel(ZzRunParams P, ZzGeneralParams Q, ZzLogisticTables LT) {
     const int lane = threadIdx.x;
     const int64_t chain = blockIdx.x;
@@ -143,6 +147,7 @@ __global__ __launch_bounds__(64) void zz_logistic_lds_kernel(ZzRunParams P, ZzGe
     pdmp_event* const ev = P.ev ? P.ev + chain * P.trace_cap : nullptr;
     double* const cmut = P.c_chain ? (P.c_chain + chain * (int64_t)d) : nullptr;
     const double* const cvec = cmut ? cmut : P.tb.c_shared;
+    double4* const trkc = TRK ? reinterpret_cast<double4*>(LT.trk) + chain * (int64_t)d : nullptr;  // (g, gd, tg, -) per coordinate
 
     uint32_t status = hdr->c.status;
     if (status == PDMP_CHAIN_BOUND_VIOLATED || status == PDMP_CHAIN_STALLED) return;
@@ -303,9 +308,14 @@ __global__ __launch_bounds__(64) void zz_logistic_lds_kernel(ZzRunParams P, ZzGe
         const double wm = gm ? P.tb.bval[cp0 + (uint32_t)lane] : 0.0;
         const uint32_t row = LT.a_row[ii];
         const double v = LT.a_val[ii];
-        const uint4 mrec0 = Q.member[cp0 + (gm ? (uint32_t)lane : 0u)];  // (first 64 members: an accepted event's re-bound starts from these)
-        const uint32_t qs0 = P.tb.qptr[cp0], qe0 = P.tb.qptr[cp0 + ((k < 64u) ? k : 64u)];
-        const uint32_t g2a = (k + (uint32_t)lane < m) ? P.tb.sidx[sp0 + k + (uint32_t)lane] : 0xffffffffu;  // G2[i], first 64 (an accept moves them)
+        uint4 mrec0 = make_uint4(0u, 0u, 0u, 0u);
+        uint32_t qs0 = 0, qe0 = 0, g2a = 0xffffffffu;
+        if constexpr (!TRK) {
+            mrec0 = Q.member[cp0 + (gm ? (uint32_t)lane : 0u)];  // (first 64 members: an accepted event's re-bound starts from these)
+            qs0 = P.tb.qptr[cp0];
+            qe0 = P.tb.qptr[cp0 + ((k < 64u) ? k : 64u)];
+            g2a = (k + (uint32_t)lane < m) ? P.tb.sidx[sp0 + k + (uint32_t)lane] : 0xffffffffu;  // G2[i], first 64 (an accept moves them)
+        }
         // [3]: the sampled observations
         const LgObs* const ob = LT.obs + row;
         const double4 c0 = *reinterpret_cast<const double4*>(&ob->y);      // y, ny, sn0, ns0
@@ -314,8 +324,14 @@ __global__ __launch_bounds__(64) void zz_logistic_lds_kernel(ZzRunParams P, ZzGe
         const uint4 ix = *reinterpret_cast<const uint4*>(&ob->idx[0]);     // idx[0..5], ne, pad
         // ... and what may come from HBM: needed at the thinning test only (c_j, Γ[:,j]·μ of the first 64 members: an accepted event's
         // re-bound would otherwise begin with an exposed HBM round trip)
-        const double cj0 = cvec[gm ? mrec0.x : i];
-        const double gmu0 = P.tb.gmu_b[gm ? mrec0.x : i];
+        const uint32_t jfirst = TRK ? (gm ? jm : i) : (gm ? mrec0.x : i);
+        const double cj0 = cvec[jfirst];
+        const double gmu0 = P.tb.gmu_b[jfirst];
+        double4 trk_i = make_double4(0.0, 0.0, 0.0, 0.0), trk_m = trk_i;  // (g, gd, tg, -) of i and of member `lane` of G1[i]
+        if constexpr (TRK) {
+            trk_i = trkc[i];
+            trk_m = trkc[jfirst];
+        }
         const double gmu_i = P.tb.gmu_b[i];
         const ZzRec* const ri = rec + i;
         const double told_i = ri->t_old, a_i = ri->a, b_i = ri->b;
@@ -323,7 +339,11 @@ __global__ __launch_bounds__(64) void zz_logistic_lds_kernel(ZzRunParams P, ZzGe
         const double c_i = cvec[i];
         // ---------------- smove_forward!(G, i, ...), :82, and with it the sums of i's own re-bound: Γ[:,i]·x, Γ[:,i]·θ in idot's order
         double s1r = 0.0, s2r = 0.0;
-        {
+        if constexpr (TRK) {
+            L_ORDER();
+            if (lane == 0) (void)move1(i, tp);  // x_i at t′: the prior term and the event record read it
+            L_ORDER();
+        } else {
             L_ORDER();
             if (gm) {
                 const double2 nx = move1(jm, tp);
@@ -385,6 +405,10 @@ __global__ __launch_bounds__(64) void zz_logistic_lds_kernel(ZzRunParams P, ZzGe
         const bool accept = (ucoin * lbound < l_rate);
         if (!accept) {
             // ---------------- rejected (:137-139): the bound from the sums taken above
+            if constexpr (TRK) {
+                s1r = trk_i.x + trk_i.y * (tp - trk_i.z);  // g_i advanced to t′
+                s2r = trk_i.y;
+            }
             const double a = c_i + (s1r - gmu_i) * th_i;  // src/fact_samplers.jl:51
             const double b = c_i / 100 + th_i * s2r;      // :52
             const double key = tp + l_poisson_time_L(a, b, l_readlane(mL, (int)moff + 1));
@@ -412,14 +436,66 @@ __global__ __launch_bounds__(64) void zz_logistic_lds_kernel(ZzRunParams P, ZzGe
             if (lane == 0) cmut[i] = ci_new;
         }
         // smove_forward!(G2, i, ...), :129 (the first 64 members were requested with the header's second level)
-        if (g2a != 0xffffffffu) (void)move1(g2a, tp);
-        if (k + 64u < m) move_members(sp0, k + 64u, m, tp);
+        if constexpr (!TRK) {
+            if (g2a != 0xffffffffu) (void)move1(g2a, tp);
+            if (k + 64u < m) move_members(sp0, k + 64u, m, tp);
+        }
         if (lane == 0) {
             xt[i].y = -th_i;  // reflect!, :130
             rec[i].acc = acc_i + 1;
         }
         L_ORDER();
         LPHASE(3);
+        if constexpr (TRK) {
+            // ---------------- the members of G1[i], one per lane: sums advanced to t′, gd_j += Γ[j,i]·(−2θ_i), bound and event time (:131-135)
+            const double delta = -th_i - th_i;
+            for (uint32_t base = 0; base < k; base += 64) {
+                const uint32_t jj = base + (uint32_t)lane;
+                const bool valid = jj < k;
+                const uint32_t j = (base == 0) ? (valid ? jm : i) : P.tb.sidx[sp0 + (valid ? jj : 0u)];
+                const double w = (base == 0) ? wm : (valid ? P.tb.bval[cp0 + jj] : 0.0);
+                const double4 tr = (base == 0) ? trk_m : trkc[j];
+                const double cj_tab = (base == 0) ? cj0 : cvec[j];
+                const double cj = (j == i) ? ci_new : cj_tab;
+                const double gmu = (base == 0) ? gmu0 : P.tb.gmu_b[j];
+                const uint32_t src = moff + 1u + jj;  // draw nm + jj (nm already counts the coin)
+                double Ldraw = l_shfl(mL, (src < 64u) ? src : 63u);
+                if (__ballot(valid && src >= 64u) != 0) {
+                    const double Lx = pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm + (uint64_t)jj));
+                    Ldraw = (src >= 64u) ? Lx : Ldraw;
+                }
+                if (valid) {
+                    const double gj = tr.x + tr.y * (tp - tr.z);
+                    const double gdj = tr.y + w * delta;  // Γ[j, i] = Γ[i, j]
+                    const double thj = xt[j].y;
+                    const double a = cj + (gj - gmu) * thj;  // src/fact_samplers.jl:51
+                    const double b = cj / 100 + thj * gdj;   // :52
+                    const double keyj = tp + l_poisson_time_L(a, b, Ldraw);
+                    trkc[j] = make_double4(gj, gdj, tp, 0.0);
+                    ZzRec* r = rec + j;
+                    r->t_old = tp;
+                    r->a = a;
+                    r->b = b;
+                    px[lane] = keyj;
+                    pj[lane] = j;
+                }
+                L_ORDER();
+                const uint32_t last = (base + 64u < k) ? (base + 64u) : k;
+                for (uint32_t z = 0; z < last - base; z += 4) {
+                    uint32_t jn[4];
+                    double kn[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        jn[q] = pj[(z + q) & (LG_PCH - 1)];
+                        kn[q] = px[(z + q) & (LG_PCH - 1)];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (z + q < last - base) set_key(jn[q], kn[q]);
+                }
+                L_ORDER();
+            }
+        } else
         // ---------------- ab + new event time of every member of G1[i] (:131-135; src/fact_samplers.jl:50-54).  The dot products keep idot's
         // order (ascending row); their products are formed LG_PCH at a time by all lanes, then every lane adds up the run of its member.
         for (uint32_t base = 0; base < k; base += 64) {
@@ -548,6 +624,27 @@ __global__ __launch_bounds__(64) void zz_logistic_lds_kernel(ZzRunParams P, ZzGe
     }
 }
 
+// g_j = Γ[:,j]·x, gd_j = Γ[:,j]·θ in idot's order (the sums of the initial bounds, src/sfact.jl:184-186) at t0: the tracked state's start
+__global__ __launch_bounds__(256) void zz_logistic_track_init_kernel(const ZzRec* __restrict__ rec, ZzTables tb, int64_t d, int64_t nchains, double t0,
+                                                                     double* __restrict__ trk) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= nchains * d) return;
+    const int64_t chain = k / d, j = k - chain * d;
+    const ZzRec* r = rec + chain * d;
+    double g = 0.0, gd = 0.0;
+    for (uint32_t p = tb.colptr[j]; p < tb.colptr[j + 1]; ++p) {
+        const uint32_t row = tb.rowval[p];
+        g += tb.bval[p] * r[row].x;
+        gd += tb.bval[p] * r[row].th;
+    }
+    reinterpret_cast<double4*>(trk)[k] = make_double4(g, gd, t0, 0.0);
+}
+int launch_zz_logistic_track_init(const ZzRec* rec, const ZzTables& tb, int64_t d, int64_t nchains, double t0, double* trk, void* stream) {
+    const int64_t n = nchains * d;
+    hipLaunchKernelGGL(zz_logistic_track_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rec, tb, d, nchains, t0, trk);
+    return (int)hipGetLastError();
+}
+
 bool zz_logistic_lds_supported(const ZzRunParams& p, const ZzGeneralParams& q, const ZzLogisticTables& lt) {
     return lt.coord != nullptr && !q.masked && q.target_kind == 1 && q.ksub >= 1 && q.ksub <= 32 && q.lg_ne_max <= 6 && !p.move_all && !p.has_refresh &&
            !q.local_bound && !q.sticky && q.flow_kind == 0 && !q.adaptscale && p.dk <= 64 * LG_KREG &&
@@ -558,6 +655,11 @@ int launch_zz_logistic_lds(const ZzRunParams& p, const ZzGeneralParams& q, const
                            void* stream) {
     const size_t lds = zz_logistic_lds_bytes(p.d, p.dk, with_I);
     const dim3 grid((unsigned)nchains), block(64);
+    if (lt.trk != nullptr) {  // tracked bounds (no profiling instantiation)
+        if (with_I) hipLaunchKernelGGL((zz_logistic_lds_kernel<false, true, true>), grid, block, lds, (hipStream_t)stream, p, q, lt);
+        else hipLaunchKernelGGL((zz_logistic_lds_kernel<false, false, true>), grid, block, lds, (hipStream_t)stream, p, q, lt);
+        return (int)hipGetLastError();
+    }
     if (p.dbg) hipLaunchKernelGGL((zz_logistic_lds_kernel<true, true>), grid, block, zz_logistic_lds_bytes(p.d, p.dk, true), (hipStream_t)stream, p, q, lt);
     else if (with_I) hipLaunchKernelGGL((zz_logistic_lds_kernel<false, true>), grid, block, lds, (hipStream_t)stream, p, q, lt);
     else hipLaunchKernelGGL((zz_logistic_lds_kernel<false, false>), grid, block, lds, (hipStream_t)stream, p, q, lt);
