@@ -119,7 +119,7 @@ __device__ __forceinline__ double l_shfl(double v, uint32_t src) {
 
 size_t zz_logistic_lds_bytes(int64_t d, int64_t dk, bool with_I) {
     (void)dk;  // (the event times live in registers: LG_KREG per lane)
-    return (size_t)d * (with_I ? 32 : 24) + (size_t)2 * LG_PCH * 8 + (size_t)LG_PCH * 4;
+    return (size_t)d * (with_I ? 32 : 24) + (size_t)2 * LG_PCH * 8 + (size_t)LG_PCH * 4 + 8;  // (+8: the chunk buffers start on 16 bytes for odd d too)
 }
 
 // TRK: tracked BOUNDS (pdmp_ensemble_set_gradient_tracking on this configuration; oracle: spdmp_zigzag_tracked_lg): every coordinate carries
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(64) void zz_logistic_lds_kernel(ZzRunParams P, ZzGe
     extern __shared__ __align__(16) unsigned char smem[];
     double2* const xt = reinterpret_cast<double2*>(smem);                            // [d] (x_j, θ_j)
     double* const tt = reinterpret_cast<double*>(smem + (size_t)d * 16);             // [d] t_j
-    double* const px = tt + d;                                                       // [LG_PCH] products Γ[r, j] x_r of one chunk; new keys
+    double* const px = tt + d + (d & 1u);                                            // [LG_PCH] products Γ[r, j] x_r of one chunk; new keys (16-byte aligned)
     double* const pt = px + LG_PCH;                                                  // [LG_PCH] products Γ[r, j] θ_r
     uint32_t* const pj = reinterpret_cast<uint32_t*>(pt + LG_PCH);                   // [LG_PCH] coordinates of the new keys
     double* const II = reinterpret_cast<double*>(pj + LG_PCH);                       // [d] ∫ x_j up to t_j (WITH_I)
@@ -386,12 +386,34 @@ __global__ __launch_bounds__(64) void zz_logistic_lds_kernel(ZzRunParams P, ZzGe
             const double t2 = w * c0.y * (-l_sigmoid(u));   // nsigmoid(u) = -sigmoid(u)
             const double t3 = w * c0.x * c0.z;              // sigmoidn(u0), u0 = idot(At, row, μ): tabulated per observation
             const double t4 = w * c0.y * c0.w;              // nsigmoid(u0)
+            // the four terms of every sampled observation go through LDS (over the chunk buffers, idle during a gradient): 2 reads of 16 bytes
+            // and 4 adds per observation instead of 8 v_readlane and 4 adds -- the order of the sum is that of the draws (scripts/logistic.jl:84-92)
             double s = 0.0;
-            for (int z = 0; z < nq; ++z) {  // (in the order of the draws, scripts/logistic.jl:84-92)
-                s += l_readlane(t1, (int)goff + z);
-                s += l_readlane(t2, (int)goff + z);
-                s -= l_readlane(t3, (int)goff + z);
-                s -= l_readlane(t4, (int)goff + z);
+            {
+                double2* const q2 = reinterpret_cast<double2*>(px);  // [k_sub][2] (k_sub <= 32: px and pt together)
+                L_ORDER();
+                if (qa) {
+                    const uint32_t qrel = (uint32_t)lane - goff;
+                    q2[2 * qrel] = make_double2(t1, t2);
+                    q2[2 * qrel + 1] = make_double2(t3, t4);
+                }
+                L_ORDER();
+                for (int z = 0; z < nq; z += 2) {
+                    const double2 a0 = q2[2 * z], b0 = q2[2 * z + 1];
+                    const bool two = z + 1 < nq;
+                    const double2 a1 = q2[two ? 2 * z + 2 : 2 * z], b1 = q2[two ? 2 * z + 3 : 2 * z + 1];
+                    s += a0.x;
+                    s += a0.y;
+                    s -= b0.x;
+                    s -= b0.y;
+                    if (two) {
+                        s += a1.x;
+                        s += a1.y;
+                        s -= b1.x;
+                        s -= b1.y;
+                    }
+                }
+                L_ORDER();
             }
             ng += (uint64_t)Q.ksub;
             g = prior - s;
