@@ -274,7 +274,18 @@ __global__ __launch_bounds__(64) void zz_logistic_lds_kernel(ZzRunParams P, ZzGe
             tp = lt ? kreg[q] : tp;
             i = lt ? ((uint32_t)lane + 64u * (uint32_t)q) : i;
         }
-        l_wave_argmin(tp, i);
+        {
+            // the minimum first (a DPP reduction of the keys alone), then who holds it: one lane in all but exactly tied cases, where the
+            // (key, coordinate) reduction decides as before -- a third fewer vector instructions than reducing pairs every time
+            const double gmin = l_wave_min(tp);
+            const uint64_t holders = __ballot(tp == gmin);
+            if (__popcll(holders) == 1) {
+                i = (uint32_t)__builtin_amdgcn_readlane((int)i, __ffsll((unsigned long long)holders) - 1);
+                tp = gmin;
+            } else {
+                l_wave_argmin(tp, i);
+            }
+        }
         if (!(tp < L_INF)) {
             status = PDMP_CHAIN_STALLED;
             break;
