@@ -125,3 +125,43 @@ def test_every_leaver_is_the_sequential_tracked_sampler_bit_for_bit(c3_horizon):
             for f in ("i", "t", "x", "theta"):
                 assert np.array_equal(ev[f], oe[f]), (k, f)
             _bitwise_state(e.final_state(q, 1), cn[q], oracle_tracked[k], k)
+
+
+def test_c4_tracked_bounds_over_a_long_run(gpu_pkg):
+    """Config C4 (8192 chains of the subsampled logistic regression, adapt, factor 5) to T = 100 with tracked BOUNDS and with the moving
+    evaluation (7·10⁹ proposals each).  The two arithmetics round the positions differently -- the moving evaluation brings G1[i] to every
+    proposal time, the tracked one moves a coordinate only when a sampled row or its own event needs it -- so here chains leave the moving
+    evaluation's index sequence sooner than on the lattice (measured: 270 of 8192 by T = 400, ≈1·10⁻⁸ per proposal).  What makes that
+    acceptable is checked here: EVERY chain whose counters differ is still the sequential sampler in the tracked arithmetic -- a sample of the
+    leavers and chains 0 / 8191 equal the oracle's tracked evaluation bit for bit (counters, clocks, positions, velocities, accept counts,
+    adapted bounds) -- and the two ensembles agree in distribution (acceptance rate and proposal counts per chain)."""
+    pkg = gpu_pkg
+    P = pkg.problems.logistic_problem(m=20)
+    d, nch, T = P["p"], 8192, 100.0
+    rng = np.random.default_rng(7)
+    X0 = np.tile(P["x0"], (nch, 1))
+    TH0 = P["sigma"] * rng.choice([-1.0, 1.0], (nch, d))
+    res = {}
+    for tracked in (True, False):
+        with pkg.Ensemble(nch, d, adapt=True, factor=5.0, trace_capacity=0) as ens:
+            ens.set_flow(pkg.ZigZag(P["Gdrop"], P["mu"], P["sigma"]))
+            ens.set_target(pkg.LogisticTarget(P["A"], P["y"], P["ny"], P["mu"], P["gamma0"], 10))
+            ens.set_path_integrals(False)
+            ens.set_gradient_tracking(tracked)
+            ens.set_state(0.0, X0, TH0, P["c"], np.arange(nch, dtype=np.uint64) + SEED0)
+            ens.run(T, pkg._lib.RUN_STOP_BEFORE)
+            cnt = ens.counters()
+            assert np.all(cnt["status"] == pkg._lib.CHAIN_OK)
+            res[tracked] = (cnt, ens.final_state())
+    a, b = res[True][0], res[False][0]
+    leavers = np.flatnonzero((a["num"] != b["num"]) | (a["nacc"] != b["nacc"]) | (a["ndraw_main"] != b["ndraw_main"]))
+    assert len(leavers) <= 400, len(leavers)
+    assert abs(a["num"].sum() / b["num"].sum() - 1.0) < 1e-3 and abs(a["nacc"].sum() / b["nacc"].sum() - 1.0) < 1e-3
+    lg = dict(A=P["A"], At=P["At"], y=P["y"], ny=P["ny"], mu=P["mu"], gamma0=P["gamma0"], k=10)
+    fs = res[True][1]
+    for k in sorted(set([0, nch - 1] + [int(q) for q in leavers[:3]])):
+        r = O.spdmp_zigzag(P["Gdrop"], P["mu"], P["Gdrop"], X0[k], TH0[k], P["c"], T, seed=SEED0 + k, adapt=True, factor=5.0, logistic=lg,
+                           sigma=P["sigma"], stop_before_T=True, tracked=True, want_trace=False)
+        assert r["status"] == 0 and int(a["num"][k]) == r["num"] and int(a["ndraw_main"][k]) == r["ndraw_main"], k
+        for f, g in (("t", "t"), ("x", "x"), ("theta", "theta"), ("acc", "acc"), ("c", "c")):
+            assert np.array_equal(fs[f][k], r[g]), (k, f)
