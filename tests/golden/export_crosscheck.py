@@ -66,7 +66,26 @@ def main():
         for e in ev:
             f.write("%s %d %s %s\n" % (hx([e["t"]]), int(e["i"]) + 1, hx([e["x"]]), hx([e["theta"]])))
     write_more()
+    write_1d()
     print("wrote crosscheck_*.txt")
+
+
+def write_1d():
+    """The 1-d samplers of src/zigzagboom1d.jl:34-67 on the closures of test/test1d.jl:9-10 (tools/julia_crosscheck.jl: check_1d)."""
+    mu, s2 = np.pi / 3, 1.3
+    for name, kw, x0, th0, c in (("zigzag1d", dict(flow="zigzag", noise=0.1), 1.01, -1.5, 10.0),
+                                 ("boomerang1d", dict(flow="boomerang", boomerang=(1.1, 1.2, 0.5), noise=0.1), 1.41, 0.5, 10.0)):
+        r = O.pdmp_1d(mu, s2, x0, th0, 200.0, c, seed=3, **kw)
+        assert r["status"] == 0 and len(r["events"]) > 50
+        with open(os.path.join(HERE, f"crosscheck_{name}.txt"), "w") as f:
+            f.write("sampler %s\nseed 3\nT %s\nmu %s\nsigma2 %s\nnoise %s\n" % (name, hx([200.0]), hx([mu]), hx([s2]), hx([kw["noise"]])))
+            if name == "boomerang1d":
+                b = kw["boomerang"]
+                f.write("b_sigma %s\nb_mu %s\nb_lambda %s\n" % (hx([b[0]]), hx([b[1]]), hx([b[2]])))
+            f.write("x0 %s\ntheta0 %s\nc %s\n" % (hx([x0]), hx([th0]), hx([c])))
+            f.write("num %d\nacc %d\nndraw %d\nevents %d\n" % (r["num"], r["acc"], r["ndraw"], len(r["events"])))
+            for e in r["events"]:
+                f.write("%s %s %s\n" % (hx([e["t"]]), hx([e["x"]]), hx([e["theta"]])))
 
 
 def write_fact(f, r, d):

@@ -65,3 +65,35 @@ def test_bound_too_small_without_adapt_stops_and_adapts_with_it():
     assert r["status"] == 1                                       # error("Tuning parameter `c` too small."), :55
     a = O.pdmp_1d(2.0, 1.0, 3.0, 1.0, 5000.0, 1e-3, flow="boomerang", boomerang=(1.0, 0.0, 0.5), seed=11, adapt=True)
     assert a["status"] == 0 and a["c"] > 1e-3 and np.log2(a["c"] / 1e-3) == round(np.log2(a["c"] / 1e-3))  # c *= 2.0 a whole number of times
+
+
+@pytest.mark.parametrize("name", ["zigzag1d", "boomerang1d"])
+def test_committed_crosscheck_fixture_is_what_the_oracle_produces(name):
+    """tests/golden/crosscheck_{zigzag1d,boomerang1d}.txt -- what tools/julia_crosscheck.jl: check_1d replays inside ZigZagBoomerang.jl --
+    hold the oracle's events as bit patterns; they must stay in step with the oracle."""
+    import os
+    import struct
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"crosscheck_{name}.txt")
+    f64 = lambda h: struct.unpack(">d", bytes.fromhex(h))[0]
+    D, ev = {}, []
+    lines = open(path).read().split("\n")
+    k = 0
+    while k < len(lines):
+        w = lines[k].split()
+        if not w:
+            k += 1
+            continue
+        if w[0] == "events":
+            n = int(w[1])
+            ev = [tuple(f64(h) for h in lines[k + 1 + q].split()) for q in range(n)]
+            k += n
+        elif w[0] in ("seed", "num", "acc", "ndraw"):
+            D[w[0]] = int(w[1])
+        elif w[0] != "sampler":
+            D[w[0]] = f64(w[1])
+        k += 1
+    kw = dict(flow="zigzag", noise=D["noise"]) if name == "zigzag1d" else dict(flow="boomerang", noise=D["noise"],
+                                                                             boomerang=(D["b_sigma"], D["b_mu"], D["b_lambda"]))
+    r = O.pdmp_1d(D["mu"], D["sigma2"], D["x0"], D["theta0"], D["T"], D["c"], seed=D["seed"], **kw)
+    assert (r["num"], r["acc"], r["ndraw"], len(r["events"])) == (D["num"], D["acc"], D["ndraw"], len(ev))
+    assert [tuple(float(v) for v in e) for e in r["events"]] == ev

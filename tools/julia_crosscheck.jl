@@ -99,7 +99,7 @@ function read_fixture(path)
             k += n
         elseif key in ("sampler",)
             D[key] = w[2]
-        elseif key in ("seed", "num", "nrefresh", "ksub", "ndraw_global")
+        elseif key in ("seed", "num", "nrefresh", "ksub", "ndraw_global", "ndraw")
             D[key] = parse(Int, w[2])
         elseif key == "acc"
             D[key] = parse.(Int, w[2:end])
@@ -420,6 +420,32 @@ function check_logistic(path)
     @assert GLOBAL_STREAM[].n == D["ndraw_global"]
 end
 
+# ------------------------------------------------------------------ the 1-d samplers (src/zigzagboom1d.jl:34-67): every draw is a call on the
+# GLOBAL generator -- rand() for the event times, the coin and the noise of ∇ϕhat (test/test1d.jl:10), randn() for Boomerang1d's refreshed
+# velocity (:44), randexp() inside poisson_time(λref) (:19-20, src/poissontime.jl:80-82) -- and the engine takes them, in program order, from
+# the chain's MAIN stream (oracle/pdmp_oracle.c: orc_pdmp_1d).  Run last: it re-routes the zero-argument generators.
+function check_1d(path)
+    D = read_fixture(path)
+    μ, σ2, noise = D["mu"], D["sigma2"], D["noise"]
+    GLOBAL_PHILOX[] = PhiloxRNG(D["seed"])
+    @eval Random.rand() = Main.next!(Main.GLOBAL_PHILOX[])
+    @eval Random.randn() = randn(Main.GLOBAL_PHILOX[], Float64)
+    @eval Random.randexp() = -log(Main.next!(Main.GLOBAL_PHILOX[]))
+    ∇ϕ(x) = noise == 0 ? (x - μ)/σ2 : (x - μ)/σ2 + noise*(rand() - 0.5)                       # test/test1d.jl:9-10
+    Flow = D["sampler"] == "zigzag1d" ? ZigZag1d() : Boomerang1d(D["b_sigma"], D["b_mu"], D["b_lambda"])
+    out, ratio = ZZB.pdmp(∇ϕ, D["x0"][1], D["theta0"][1], D["T"], D["c"][1], Flow)
+    ref = D["events"]
+    @assert length(out) == length(ref) "event counts differ: $(length(out)) vs $(length(ref))"
+    worst = 0.0
+    for (e, r) in zip(out, ref)
+        worst = max(worst, relerr(e[1], f64(r[1])), abs(e[2] - f64(r[2])), abs(e[3] - f64(r[3])))
+    end
+    @assert worst < 1e-9
+    @assert abs(ratio - D["acc"][1]/D["num"]) < 1e-15
+    @assert GLOBAL_PHILOX[].n == D["ndraw"]
+    println(basename(path), ": ", length(out), " events, acc/num identical, max deviation ", worst)
+end
+
 dir = length(ARGS) >= 1 ? ARGS[1] : joinpath(@__DIR__, "..", "tests", "golden")
 check_spdmp(joinpath(dir, "crosscheck_spdmp_d8.txt"))
 check_spdmp(joinpath(dir, "crosscheck_spdmp_grid8.txt"))
@@ -430,4 +456,6 @@ check_refreshing(joinpath(dir, "crosscheck_zigzag_refresh_d8.txt"))
 check_localbound(joinpath(dir, "crosscheck_localbound_d8.txt"))
 check_boomerang(joinpath(dir, "crosscheck_boomerang_d8.txt"))
 check_logistic(joinpath(dir, "crosscheck_logistic_p10.txt"))
+check_1d(joinpath(dir, "crosscheck_zigzag1d.txt"))
+check_1d(joinpath(dir, "crosscheck_boomerang1d.txt"))
 println("oracle == ZigZagBoomerang.jl on all fixtures")
