@@ -315,8 +315,9 @@ __global__ __launch_bounds__(64) void zz_logistic_lds_kernel(ZzRunParams P, ZzGe
         const uint32_t rdraw = (uint32_t)(((bits >> 32) * (uint64_t)H.l) >> 32);  // pdmp_randint
         const uint32_t ii = H.r0 + (qa ? rdraw : 0u);
         const bool gm = (uint32_t)lane < k;
-        const uint32_t jm = gm ? P.tb.sidx[sp0 + (uint32_t)lane] : 0u;
-        const double wm = gm ? P.tb.bval[cp0 + (uint32_t)lane] : 0.0;
+        // (with tracked bounds only an accepted event, one proposal in seven, looks at G1[i]: its tables are read there, not here)
+        const uint32_t jm = (!TRK && gm) ? P.tb.sidx[sp0 + (uint32_t)lane] : 0u;
+        const double wm = (!TRK && gm) ? P.tb.bval[cp0 + (uint32_t)lane] : 0.0;
         const uint32_t row = LT.a_row[ii];
         const double v = LT.a_val[ii];
         uint4 mrec0 = make_uint4(0u, 0u, 0u, 0u);
@@ -335,13 +336,12 @@ __global__ __launch_bounds__(64) void zz_logistic_lds_kernel(ZzRunParams P, ZzGe
         const uint4 ix = *reinterpret_cast<const uint4*>(&ob->idx[0]);     // idx[0..5], ne, pad
         // ... and what may come from HBM: needed at the thinning test only (c_j, Γ[:,j]·μ of the first 64 members: an accepted event's
         // re-bound would otherwise begin with an exposed HBM round trip)
-        const uint32_t jfirst = TRK ? (gm ? jm : i) : (gm ? mrec0.x : i);
-        const double cj0 = cvec[jfirst];
-        const double gmu0 = P.tb.gmu_b[jfirst];
-        double4 trk_i = make_double4(0.0, 0.0, 0.0, 0.0), trk_m = trk_i;  // (g, gd, tg, -) of i and of member `lane` of G1[i]
+        const uint32_t jfirst = (!TRK && gm) ? mrec0.x : i;
+        const double cj0 = TRK ? 0.0 : cvec[jfirst];
+        const double gmu0 = TRK ? 0.0 : P.tb.gmu_b[jfirst];
+        double4 trk_i = make_double4(0.0, 0.0, 0.0, 0.0);  // (g, gd, tg, -) of i
         if constexpr (TRK) {
             trk_i = trkc[i];
-            trk_m = trkc[jfirst];
         }
         const double gmu_i = P.tb.gmu_b[i];
         const ZzRec* const ri = rec + i;
@@ -485,12 +485,12 @@ __global__ __launch_bounds__(64) void zz_logistic_lds_kernel(ZzRunParams P, ZzGe
             for (uint32_t base = 0; base < k; base += 64) {
                 const uint32_t jj = base + (uint32_t)lane;
                 const bool valid = jj < k;
-                const uint32_t j = (base == 0) ? (valid ? jm : i) : P.tb.sidx[sp0 + (valid ? jj : 0u)];
-                const double w = (base == 0) ? wm : (valid ? P.tb.bval[cp0 + jj] : 0.0);
-                const double4 tr = (base == 0) ? trk_m : trkc[j];
-                const double cj_tab = (base == 0) ? cj0 : cvec[j];
+                const uint32_t j = valid ? P.tb.sidx[sp0 + jj] : i;
+                const double w = valid ? P.tb.bval[cp0 + jj] : 0.0;
+                const double4 tr = trkc[j];
+                const double cj_tab = cvec[j];
                 const double cj = (j == i) ? ci_new : cj_tab;
-                const double gmu = (base == 0) ? gmu0 : P.tb.gmu_b[j];
+                const double gmu = P.tb.gmu_b[j];
                 const uint32_t src = moff + 1u + jj;  // draw nm + jj (nm already counts the coin)
                 double Ldraw = l_shfl(mL, (src < 64u) ? src : 63u);
                 if (__ballot(valid && src >= 64u) != 0) {
