@@ -18,8 +18,9 @@
 //     flight: lanes 0 .. k_sub−1 the sampled observations (global-rng stream), lane k_sub the thinning coin, the lanes above it log(u) of
 //     the draws an accepted event's re-bounds will use (the first of them is the rejected proposal's);
 //   * loads issued level by level -- a wave's loads return in order, so a slow one must never sit in front of a fast one needed sooner:
-//     [1] the header; [2] G1[i] with its Γ values, the sampled entries of the design's column, the members' table entries; [3] the sampled
-//     observations' records, then the only reads that may come from HBM (bound in force, accept count, c_i), needed last;
+//     [1] the header; [2] G1[i] with its Γ values, the sampled entries of the design's column; [3] the sampled observations' records, then
+//     the only reads that may come from HBM (bound in force, accept count, c_i), needed last; what an ACCEPTED event needs on top (the members'
+//     table entries, their c_j and Γ[:,j]·μ, G2[i]) is requested by the accepted event -- one proposal in seven -- and not with every proposal;
 //   * the rejected proposal's new bound (81 % of the proposals) is complete before the outcome is known: Γ[:,i]·x and Γ[:,i]·θ are formed
 //     by the lanes that move G1[i] (x of G1[i] is final then; θ_i flips only on accept, which re-bounds all of G1[i] afresh).
 // The arithmetic, the draw order and the summation orders are those of zz_general_run_kernel<.., LGFAST, ..> (and of the oracle): results are
@@ -322,12 +323,6 @@ __global__ __launch_bounds__(64) void zz_logistic_lds_kernel(ZzRunParams P, ZzGe
         const double v = LT.a_val[ii];
         uint4 mrec0 = make_uint4(0u, 0u, 0u, 0u);
         uint32_t qs0 = 0, qe0 = 0, g2a = 0xffffffffu;
-        if constexpr (!TRK) {
-            mrec0 = Q.member[cp0 + (gm ? (uint32_t)lane : 0u)];  // (first 64 members: an accepted event's re-bound starts from these)
-            qs0 = P.tb.qptr[cp0];
-            qe0 = P.tb.qptr[cp0 + ((k < 64u) ? k : 64u)];
-            g2a = (k + (uint32_t)lane < m) ? P.tb.sidx[sp0 + k + (uint32_t)lane] : 0xffffffffu;  // G2[i], first 64 (an accept moves them)
-        }
         // [3]: the sampled observations
         const LgObs* const ob = LT.obs + row;
         const double4 c0 = *reinterpret_cast<const double4*>(&ob->y);      // y, ny, sn0, ns0
@@ -336,9 +331,7 @@ __global__ __launch_bounds__(64) void zz_logistic_lds_kernel(ZzRunParams P, ZzGe
         const uint4 ix = *reinterpret_cast<const uint4*>(&ob->idx[0]);     // idx[0..5], ne, pad
         // ... and what may come from HBM: needed at the thinning test only (c_j, Γ[:,j]·μ of the first 64 members: an accepted event's
         // re-bound would otherwise begin with an exposed HBM round trip)
-        const uint32_t jfirst = (!TRK && gm) ? mrec0.x : i;
-        const double cj0 = TRK ? 0.0 : cvec[jfirst];
-        const double gmu0 = TRK ? 0.0 : P.tb.gmu_b[jfirst];
+        double cj0 = 0.0, gmu0 = 0.0;
         double4 trk_i = make_double4(0.0, 0.0, 0.0, 0.0);  // (g, gd, tg, -) of i
         if constexpr (TRK) {
             trk_i = trkc[i];
@@ -470,6 +463,13 @@ __global__ __launch_bounds__(64) void zz_logistic_lds_kernel(ZzRunParams P, ZzGe
         }
         // smove_forward!(G2, i, ...), :129 (the first 64 members were requested with the header's second level)
         if constexpr (!TRK) {
+            // (what only an accepted event -- one proposal in seven -- needs is requested here, not with every proposal)
+            mrec0 = Q.member[cp0 + (gm ? (uint32_t)lane : 0u)];  // (first 64 members)
+            qs0 = P.tb.qptr[cp0];
+            qe0 = P.tb.qptr[cp0 + ((k < 64u) ? k : 64u)];
+            g2a = (k + (uint32_t)lane < m) ? P.tb.sidx[sp0 + k + (uint32_t)lane] : 0xffffffffu;  // G2[i], first 64
+            cj0 = cvec[gm ? mrec0.x : i];
+            gmu0 = P.tb.gmu_b[gm ? mrec0.x : i];
             if (g2a != 0xffffffffu) (void)move1(g2a, tp);
             if (k + 64u < m) move_members(sp0, k + 64u, m, tp);
         }
