@@ -1,0 +1,157 @@
+"""The one-proposal-per-lane tracked kernel OFF the benchmark stencil (-m gpu): zz_local_trackp_kernel<.., LAT = false> on graphs whose
+neighbours are not i ± 1, i ± n -- the 7-point 3-d lattice and random symmetric patterns with up to 8 entries per column (`spdmp` takes any
+sparse Γ: src/sfact.jl:170-179 builds G1 / G2 from the CSC pattern, test/maintest.jl:6-8 uses sprandn).  Same two bars as
+tests/test_gpu_track_parity.py: BIT FOR BIT the oracle's tracked evaluation, and the moving evaluation's index sequence / counters with
+floats to 1e-9."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import oracle_lib as O
+from test_gpu_track_parity import check_chain, check_chain_bitwise
+
+pytestmark = pytest.mark.gpu
+
+
+def graphs(pkg, which):
+    if which == "lattice3d":
+        return pkg.problems.lattice3d_precision(13)              # d = 2197, |G1| <= 7, |S| <= 25
+    if which == "random6":
+        return pkg.problems.random_sparse_precision(2500, 6, seed=3)   # |G1| <= 6, |S| up to 26
+    if which == "random8":
+        return pkg.problems.random_sparse_precision(3000, 8, seed=4)   # |G1| <= 8, |S| up to 50: beyond every blob kernel
+    if which == "ragged":
+        # degrees from 1 (a coordinate coupled to nothing: G1 = {i}) to 8, incl. neighbours inside one key block of 8 and across blocks
+        G = sp.lil_matrix(pkg.problems.random_sparse_precision(2304, 8, seed=5))
+        for i in range(0, 2304, 97):  # isolate some coordinates
+            for j in list(G.rows[i]):
+                if j != i:
+                    G[i, j] = 0.0
+                    G[j, i] = 0.0
+        for a in range(0, 2296, 24):  # couple the first two coordinates of some key blocks where both have room
+            b = a + 1
+            if G[a, b] == 0 and np.count_nonzero(G[a].toarray()) < 8 and np.count_nonzero(G[b].toarray()) < 8:
+                G[a, b] = G[b, a] = -0.37
+                G[a, a] += 0.37
+                G[b, b] += 0.37
+        G = sp.csc_matrix(G)
+        G.eliminate_zeros()
+        G.sort_indices()
+        return G
+    raise KeyError(which)
+
+
+@pytest.mark.parametrize("which,T", [("lattice3d", 10.0), ("random6", 6.0), ("random8", 5.0), ("ragged", 5.0)])
+def test_generic_graph_tracked_matches_oracle(gpu_pkg, which, T):
+    pkg = gpu_pkg
+    G = graphs(pkg, which)
+    d = G.shape[0]
+    k = np.diff(G.indptr)
+    assert k.max() <= 8 and abs(G - G.T).max() == 0
+    rng = np.random.default_rng(len(which))
+    nch = 3
+    x0 = rng.standard_normal((nch, d))
+    th0 = rng.choice([-1.0, 1.0], (nch, d))
+    c = pkg.problems.column_norms(G)
+    tr, (t, x, th), (acc, num), _ = pkg.spdmp(pkg.GaussianTarget(G), 0.0, x0, th0, T, c, pkg.ZigZag(G, np.zeros(d)), seed=900, tracked=True)
+    for q in range(nch):
+        rt = O.spdmp_zigzag(G, None, G, x0[q], th0[q], c, T, seed=900 + q, tracked=True)
+        assert rt["status"] == 0 and len(rt["events"]) > 1000
+        check_chain_bitwise(tr[q].events, t[q], x[q], th[q], acc[q], num[q], None, rt)
+        check_chain(tr[q].events, t[q], x[q], th[q], acc[q], num[q], None, O.spdmp_zigzag(G, None, G, x0[q], th0[q], c, T, seed=900 + q))
+
+
+def test_generic_graph_slices_refills_start_time_and_violation(gpu_pkg):
+    """Slices with PDMP_RUN_STOP_BEFORE, a trace buffer that fills up several times, t0 != 0, and a bound violation (status, where the oracle stops)."""
+    pkg = gpu_pkg
+    L = pkg._lib
+    G = graphs(pkg, "random6")
+    d = G.shape[0]
+    c = pkg.problems.column_norms(G)
+    nch, t0 = 2, 1.5
+    with pkg.Ensemble(nch, d, trace_capacity=2500) as ens:
+        ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
+        ens.set_target(pkg.GaussianTarget(G))
+        ens.set_gradient_tracking(True)
+        ens.set_state_synthetic(t0, c, 777)
+        evs = [[] for _ in range(nch)]
+        for Tk, flag in ((2.6, L.RUN_STOP_BEFORE), (4.0, L.RUN_STOP_BEFORE), (5.5, L.RUN_REFERENCE_TAIL)):
+            while True:
+                ens.run(Tk, flag)
+                cnt = ens.counters()
+                for q in range(nch):
+                    evs[q].append(ens.trace(q, counters=cnt))
+                ens.trace_reset()
+                if not np.any(cnt["status"] == L.CHAIN_TRACE_FULL):
+                    break
+        fs = ens.final_state()
+        cnt = ens.counters()
+    for q in range(nch):
+        x0, th0 = O.synthetic_state(777 + q, d)
+        ev = np.concatenate(evs[q])
+        rt = O.spdmp_zigzag(G, None, G, x0, th0, c, 5.5, seed=777 + q, t0=t0, tracked=True)
+        check_chain_bitwise(ev, fs["t"][q], fs["x"][q], fs["theta"][q], fs["acc"][q], cnt["num"][q], None, rt)
+        assert ev["t"][-1] >= 5.5 and len(ev) > 5000
+    rng = np.random.default_rng(2)
+    x0 = 3 * rng.standard_normal((2, d))
+    th0 = rng.choice([-1.0, 1.0], (2, d))
+    # (bound Γ == target Γ: the affine bound is exact up to c, so only a rounding-level c is violated -- after 145 and 276 proposals here)
+    cs = np.full(d, 5e-15)
+    with pkg.Ensemble(2, d, trace_capacity=4096) as ens:
+        ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
+        ens.set_target(pkg.GaussianTarget(G))
+        ens.set_gradient_tracking(True)
+        ens.set_state(0.0, x0, th0, cs, np.array([3, 4], dtype=np.uint64))
+        ens.run(5.0)
+        cnt = ens.counters()
+        for q in range(2):
+            r = O.spdmp_zigzag(G, None, G, x0[q], th0[q], cs, 5.0, seed=3 + q, tracked=True)
+            assert r["status"] == O.ORC_BOUND_VIOLATED and cnt["status"][q] == L.CHAIN_BOUND_VIOLATED
+            assert int(cnt["num"][q]) == r["num"] and int(cnt["nacc"][q]) == r["nacc"] and r["num"] > 100
+            ev = ens.trace(q, counters=cnt)
+            assert np.array_equal(ev["i"], r["events"]["i"]) and np.array_equal(ev["t"], r["events"]["t"])
+
+
+def test_generic_kernel_equals_the_lattice_kernel_on_a_relabelled_lattice(gpu_pkg):
+    """The same process under a permutation of the coordinates: the n x n lattice relabelled at random is 'a random graph' to the engine
+    (LAT = false); every chain's proposal / accept counts differ from the plain lattice's only through the tie rule -- so compare through the
+    oracle: both runs equal their own tracked oracle bit for bit, and the generic one is what a user with an arbitrary numbering gets."""
+    pkg = gpu_pkg
+    n = 48
+    G0 = pkg.problems.gmrf_precision(n)
+    d = n * n
+    perm = np.random.default_rng(11).permutation(d)
+    P = sp.csc_matrix((np.ones(d), (perm, np.arange(d))), shape=(d, d))
+    G = sp.csc_matrix(P @ G0 @ P.T)
+    G.sort_indices()
+    c = pkg.problems.column_norms(G)
+    rng = np.random.default_rng(12)
+    x0 = rng.standard_normal((2, d))
+    th0 = rng.choice([-1.0, 1.0], (2, d))
+    tr, (t, x, th), (acc, num), _ = pkg.spdmp(pkg.GaussianTarget(G), 0.0, x0, th0, 6.0, c, pkg.ZigZag(G, np.zeros(d)), seed=51, tracked=True)
+    for q in range(2):
+        rt = O.spdmp_zigzag(G, None, G, x0[q], th0[q], c, 6.0, seed=51 + q, tracked=True)
+        check_chain_bitwise(tr[q].events, t[q], x[q], th[q], acc[q], num[q], None, rt)
+
+
+def test_generic_graph_full_width(gpu_pkg):
+    """Config C3G at its width: d = 15625 (25^3 lattice) and d = 16384 (random, <= 6 per column), 4096 chains to T = 0.5: all chains healthy, first and
+    last chain bit for bit the tracked oracle."""
+    pkg = gpu_pkg
+    for G in (pkg.problems.lattice3d_precision(25), pkg.problems.random_sparse_precision(16384, 6)):
+        d = G.shape[0]
+        c = pkg.problems.column_norms(G)
+        nch, T = 4096, 0.5
+        with pkg.Ensemble(nch, d, trace_capacity=int(1.5 * d * T) + 1024) as ens:
+            ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
+            ens.set_target(pkg.GaussianTarget(G))
+            ens.set_gradient_tracking(True)
+            ens.set_state_synthetic(0.0, c, 0x5EED0000)
+            ens.run(T, pkg._lib.RUN_STOP_BEFORE)
+            cnt = ens.counters()
+            assert np.all(cnt["status"] == pkg._lib.CHAIN_OK)
+            for q in (0, nch - 1):
+                x0, th0 = O.synthetic_state(0x5EED0000 + q, d)
+                rt = O.spdmp_zigzag(G, None, G, x0, th0, c, T, seed=0x5EED0000 + q, stop_before_T=True, tracked=True)
+                fa = ens.final_state(q, 1)
+                check_chain_bitwise(ens.trace(q, counters=cnt), fa["t"][0], fa["x"][0], fa["theta"][0], fa["acc"][0], cnt["num"][q], None, rt)

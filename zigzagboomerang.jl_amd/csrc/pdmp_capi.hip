@@ -122,6 +122,9 @@ struct pdmp_ensemble {
     bool exactp = false;       // the moving evaluation runs on zz_local_exactp_kernel (plain lattice; decided by set_state)
     bool track_pairs = false;  // the queue's level 0 is (key, time) pairs in d_kp (pdmp_trackp.hip); decided by set_state
     DevBuf<double> d_kp;
+    bool track_generic = false;  // ... on a graph that is not the plain lattice: G1 ids in the records, Γ values in d_gam8 (|G1| <= 8)
+    DevBuf<double> d_gam8;
+    DevBuf<uint16_t> d_nb16;
     int32_t lattice_n = 0;  // the flow's graph is the n x n 5-point lattice in column-major numbering (0: it is not)
     double t0_state = 0.0;
     DevBuf<double> d_jstart, d_essacc;  // pdmp_ensemble_ess_*
@@ -200,6 +203,8 @@ struct pdmp_ensemble {
         tb.c2_shared = reinterpret_cast<const double2*>(d_c2.p);
         tb.cc_shared = d_cc.p;
         tb.sigma = d_sigma.p;
+        tb.gam8 = track_generic ? d_gam8.p : nullptr;
+        tb.nb16 = track_generic ? d_nb16.p : nullptr;
         return tb;
     }
 };
@@ -1125,18 +1130,45 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
     P.diag = e->d_diag.p;
     P.sticky = sticky ? 1 : 0;
     P.local_bound = e->local_bound ? 1 : 0;
+    e->track_generic = false;
+    bool trackp_ok = false;
     if (e->track) {
+        // which tracked kernel will run is decided HERE (the pair layout belongs to one of them): pdmp_debug_set_track_groups before set_state.
+        // One proposal per lane (pdmp_trackp.hip) on the plain lattice, or on any other symmetric graph with |G1| <= 8 (ids and values tabulated).
+        uint32_t kmax_g1 = 0;
+        for (int64_t k = 0; k < d; ++k) kmax_g1 = std::max(kmax_g1, e->colptr[(size_t)k + 1] - e->colptr[(size_t)k]);
+        if (e->lattice_n == 0 && kmax_g1 <= (uint32_t)pdmp::TRACKP_KMAX && d <= 16384 && e->dbg_track_groups == 0) {
+            std::vector<uint16_t> nb((size_t)d * 8, (uint16_t)0xFFFF);
+            std::vector<double> g8((size_t)d * 8, 0.0);
+            for (int64_t k = 0; k < d; ++k)
+                for (uint32_t q = e->colptr[(size_t)k]; q < e->colptr[(size_t)k + 1]; ++q) {
+                    nb[(size_t)k * 8 + (q - e->colptr[(size_t)k])] = (uint16_t)e->rowval[q];
+                    g8[(size_t)k * 8 + (q - e->colptr[(size_t)k])] = e->h_tval[q];
+                }
+            if ((st = e->d_nb16.upload(nb)) != PDMP_OK) return st;
+            if ((st = e->d_gam8.upload(g8)) != PDMP_OK) return st;
+            e->track_generic = true;
+        }
         pdmp::ZzRunParams G{};
+        G.tb = e->tables();
+        G.lattice_n = e->lattice_n;
+        G.adapt = e->cfg.adapt;
+        G.c_chain = e->cfg.adapt ? e->d_c_chain.p : nullptr;
+        G.track_two_sums = e->track_two_sums ? 1 : 0;
+        G.has_refresh = e->lambda_ref > 0;
+        G.d = d;
+        trackp_ok = pdmp::zz_trackp_supported(G) && e->dbg_track_groups == 0;
+        if (!trackp_ok) e->track_generic = false;
         G.blob_sw = e->blob_sw;
         G.blob_pw = e->blob_pw;
         G.blob_kmax = e->blob_kmax;
         G.blob_w_pad = e->blob_w_pad;
         G.has_refresh = 0;
-        G.d = d;
-        if (!e->use_spec || !pdmp::zz_spec8_geometry(G)) {
+        if (!trackp_ok && (!e->use_spec || !pdmp::zz_spec8_geometry(G))) {
             e->track = false;
             return fail(PDMP_ERR_UNSUPPORTED,
-                        "gradient tracking runs on the 8-event kernel's geometry: lattice-like graphs (|G1| <= 5, |S| <= 13), 2048 <= d <= 16384");
+                        "gradient tracking: 2048 <= d <= 16384 and either a symmetric graph with |G1| <= 8 without adaptation, target mean or a "
+                        "bounding matrix of its own (one proposal per lane), or the 8-event kernel's geometry (|G1| <= 5, |S| <= 13)");
         }
     }
     P.track = e->track ? 1 : 0;
@@ -1154,20 +1186,11 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
     }
     e->track_pairs = false;
     if (e->track) {
-        // which tracked kernel will run is decided HERE (the pair layout belongs to one of them): pdmp_debug_set_track_groups before set_state
-        pdmp::ZzRunParams G{};
-        G.tb = e->tables();
-        G.lattice_n = e->lattice_n;
-        G.adapt = e->cfg.adapt;
-        G.c_chain = e->cfg.adapt ? e->d_c_chain.p : nullptr;
-        G.track_two_sums = e->track_two_sums ? 1 : 0;
-        G.has_refresh = e->lambda_ref > 0;
-        G.d = d;
-        if (pdmp::zz_trackp_supported(G) && e->dbg_track_groups == 0) {
+        if (trackp_ok) {
             if (e->d_kp.n != (size_t)(2 * n * e->dk) && (st = e->d_kp.alloc((size_t)(2 * n * e->dk))) != PDMP_OK) return st;
             rc = pdmp::launch_zz_keys_to_pairs(e->d_keys.p, e->d_kp.p, n * e->dk, t0, e->stream);
             if (rc != 0) return fail(PDMP_ERR_HIP, "keys_to_pairs launch failed: %s", hipGetErrorString((hipError_t)rc));
-            rc = pdmp::launch_zz_trackp_consts(e->d_rec.p, e->d_cc.p, d, n, e->stream);
+            rc = pdmp::launch_zz_trackp_consts(e->d_rec.p, e->d_cc.p, e->track_generic ? e->d_nb16.p : nullptr, d, n, e->stream);
             if (rc != 0) return fail(PDMP_ERR_HIP, "trackp_consts launch failed: %s", hipGetErrorString((hipError_t)rc));
             e->track_pairs = true;
         }

@@ -58,6 +58,10 @@ struct alignas(128) TrRecP {
     double gam2, gam3, tacc, gam4;
 };
 static_assert(sizeof(TrRecP) == 128 && offsetof(TrRecP, tacc) == offsetof(TrRec, tacc), "same line, same tacc slot");
+// On a graph that is not the plain lattice (LAT = false) the members of G1[i] cannot be computed from i: the 16 bytes of gam0, gam1 hold
+// G1[i] as eight 16-bit ids (ascending, 0xFFFF past the end) -- they arrive with the line a proposal reads anyway, so an accepted event
+// can request its members' records at once -- and the values Γ[G1[i], i] come from the shared table ZzTables::gam8 (L2-resident, requested
+// side by side with the members' records).
 
 struct alignas(128) DevChain {
     pdmp_chain_counters c;  // 72 bytes, copied out verbatim by pdmp_ensemble_counters
@@ -134,6 +138,9 @@ struct ZzTables {
     const double2* __restrict__ c2_shared;  // {c_i, c_i / 100} (the constant bound and its slope, src/sfact.jl:36-39), tracked kernels
     const CoordConst* __restrict__ cc_shared;  // the same with colptr[i] and |G1[i]|: everything a proposal needs that depends on i alone, 64 bytes
     const double* __restrict__ sigma;
+    // any symmetric graph with |G1| <= 8 on the one-proposal-per-lane tracked kernel (pdmp_trackp.hip, LAT = false):
+    const double* __restrict__ gam8;    // [d][8] Γt[G1[i], i] in G1's order, 0.0 past |G1[i]|
+    const uint16_t* __restrict__ nb16;  // [d][8] G1[i] ascending, 0xFFFF past |G1[i]| (d <= 16384)
 };
 
 struct ZzRunParams {
@@ -351,7 +358,8 @@ int launch_zz_local_exactp(const ZzRunParams& p, int64_t nchains, void* stream);
 bool zz_trackp_supported(const ZzRunParams& p);
 int launch_zz_local_trackp(const ZzRunParams& p, int64_t nchains, void* stream);
 int launch_zz_keys_to_pairs(const double* keys, void* kp, int64_t n, double t0, void* stream);
-int launch_zz_trackp_consts(void* rec, const CoordConst* cc, int64_t d, int64_t nchains, void* stream);
+int launch_zz_trackp_consts(void* rec, const CoordConst* cc, const uint16_t* nb16, int64_t d, int64_t nchains, void* stream);
+constexpr int TRACKP_KMAX = 8;  // |G1[i]| the generic instantiation takes (one member per lane of an 8-lane group)
 bool zz_spec8_geometry(const ZzRunParams& p);  // the 8-event kernels' requirements on the neighbourhood blob and on d
 // kp != nullptr: the (key, time of the last own proposal) pairs of pdmp_trackp.hip hold tprop instead of the records (chain stride dk pairs)
 int launch_zz_track_unpack(const TrRec* rec, const ZzTables& tb, const double* c_src, int64_t c_stride, int64_t d, int64_t chain_first,

@@ -19,6 +19,12 @@
 // reference's initial keys carry no t0 (src/sfact.jl:186) -- run here too: t_old is stored, not inferred from an order of times.  The final
 // clocks (zz_track_unpack_kernel) take t_old where the record layout has the time of the last own proposal: the same maximum, because a
 // re-basing of j's sums is an accepted event of some n ∈ G1[j], which moved all of S[n] ⊇ G1[j] and is counted there.
+//
+// Two instantiations.  LAT = true is the plain n x n lattice (config C3): G1[i] = {i − n, i − 1, i, i + 1, i + n} inside the grid is computed from
+// the index, the zone test is a distance in (row, column).  LAT = false is ANY symmetric sparse Γ with |G1[i]| <= 8 (src/sfact.jl:170-179 takes
+// any CSC pattern; test/maintest.jl:6-8 uses sprandn): G1[i] travels with the record line as eight 16-bit ids, Γ[G1[i], i] comes from a shared
+// table, and the zone tests compare ids -- an accepted event m disturbs a later event r iff i_r ∈ G1[i_m] (r's sums change), or r is accepted
+// too and G1[i_r] ∩ G1[i_m] ≠ ∅ (both write a common member); on the lattice these are the distances 1 and 2.  Everything else is shared.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -169,6 +175,8 @@ constexpr uint32_t W_ACL = 9920;     // [8] u16 the accepted events
 constexpr uint32_t W_RO = 9936;      // [64] u8 candidate of each rank
 constexpr uint32_t W_SELDT = 10000;  // f64 selection threshold above the minimum
 constexpr uint32_t W_BYTES = 10008;
+constexpr uint32_t W_NB = 10016;     // (LAT = false) [8][8] u16 G1 of the accepted events, in event order
+constexpr uint32_t W_BYTES_G = W_NB + 128;
 constexpr uint32_t W_NBLK = 2048;
 constexpr uint32_t W_WIN = 128;      // draws held in registers (two per lane)
 constexpr int W_CMAX = 56;           // candidates per iteration (7 block-scan passes of 8)
@@ -179,9 +187,25 @@ constexpr int W_AMAX = 8;            // accepted events per iteration (one group
 #define W_SHRINK 0.98
 #define W_SLACK 5u
 #endif
-static_assert(W_BYTES <= 10240, "16 chains per CU: 160 KB / 16");
+static_assert(W_BYTES <= 10240 && W_BYTES_G <= 10240, "16 chains per CU: 160 KB / 16");
 
-template <bool PROF>
+namespace {
+// is the 16-bit value v (given twice: v | v << 16) one of the eight halves of nb?
+__device__ __forceinline__ bool nb_has(const uint4 nb, uint32_t v2) {
+    const uint32_t x0 = nb.x ^ v2, x1 = nb.y ^ v2, x2 = nb.z ^ v2, x3 = nb.w ^ v2;
+    const uint32_t z = ((x0 - 0x00010001u) & ~x0) | ((x1 - 0x00010001u) & ~x1) | ((x2 - 0x00010001u) & ~x2) | ((x3 - 0x00010001u) & ~x3);
+    return (z & 0x80008000u) != 0u;  // (a half is zero: the test is exact for "any half", the ids are below 2^15)
+}
+// number of ids in nb: the 0xFFFF halves stand at the end, and a valid id (< 2^15) does not start with a one bit
+__device__ __forceinline__ uint32_t nb_count(const uint4 nb) {
+    const uint64_t hi = ((uint64_t)nb.w << 32) | nb.z, lo = ((uint64_t)nb.y << 32) | nb.x;
+    const uint32_t ph = (~hi == 0ull) ? 4u : ((uint32_t)__builtin_clzll(~hi) >> 4);
+    const uint32_t pl = (~lo == 0ull) ? 4u : ((uint32_t)__builtin_clzll(~lo) >> 4);
+    return 8u - ((ph == 4u) ? 4u + pl : ph);
+}
+}  // namespace
+
+template <bool PROF, bool LAT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void zz_local_trackp_kernel(ZzRunParams P) {
     const int lane = threadIdx.x;
     const int g = lane >> 3, gl = lane & 7;
@@ -202,6 +226,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     uint16_t* const ACL = reinterpret_cast<uint16_t*>(smem + W_ACL);
     uint8_t* const RO = reinterpret_cast<uint8_t*>(smem + W_RO);
     double* const SELDT = reinterpret_cast<double*>(smem + W_SELDT);
+    uint4* const NB4 = reinterpret_cast<uint4*>(smem + W_NB);        // (LAT = false only)
+    uint16_t* const NB16 = reinterpret_cast<uint16_t*>(smem + W_NB);
 
     TrRecP* const rec = reinterpret_cast<TrRecP*>(P.rec) + chain * d;
     double2* const kp = reinterpret_cast<double2*>(P.keys) + chain * P.dk;  // (key, t_old) per coordinate
@@ -409,6 +435,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const TrRecP* const rci = rec + ci;
         const double c_th = rci->th, c_g = rci->g, c_gd = rci->gd, c_tg = rci->tg;
         const double2 c_c2 = *reinterpret_cast<const double2*>(&rci->c);  // (same line: no table in the event loop)
+        uint4 c_nb = make_uint4(0u, 0u, 0u, 0u);
+        if (!LAT) c_nb = *reinterpret_cast<const uint4*>(&rci->gam0);  // G1[ci]: eight 16-bit ids
         // ---------------- the candidates' lines, 8 per pass (one per 8-lane group, one (key, time) pair per lane): exact minimum, its position and
         // time, the minimum of the rest and its position -- staged in LDS per candidate
         {
@@ -525,12 +553,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         if (ev) SLB[lane] = (uint16_t)blk;
         W_ORDER();
         WPHASE(0);
-        // lattice coordinates packed for the zone test: byte 0 = row, byte 1 = column
-        const uint32_t col_i = __umulhi(i, nmagic);
-        const uint32_t row_i = i - col_i * nlat;
-        const uint32_t rc_i = ev ? (row_i | (col_i << 8)) : 0xffffu;
-        // |G1[i]| on the lattice: the cell and its neighbours inside the grid
-        const uint32_t k_i = 1u + (col_i > 0u ? 1u : 0u) + (row_i > 0u ? 1u : 0u) + (row_i + 1u < nlat ? 1u : 0u) + (col_i + 1u < nlat ? 1u : 0u);
+        uint32_t rc_i = 0xffffu, k_i;
+        uint4 nb_i = make_uint4(~0u, ~0u, ~0u, ~0u);
+        if (LAT) {
+            // lattice coordinates packed for the zone test: byte 0 = row, byte 1 = column
+            const uint32_t col_i = __umulhi(i, nmagic);
+            const uint32_t row_i = i - col_i * nlat;
+            rc_i = ev ? (row_i | (col_i << 8)) : 0xffffu;
+            // |G1[i]| on the lattice: the cell and its neighbours inside the grid
+            k_i = 1u + (col_i > 0u ? 1u : 0u) + (row_i > 0u ? 1u : 0u) + (row_i + 1u < nlat ? 1u : 0u) + (col_i + 1u < nlat ? 1u : 0u);
+        } else {
+            // G1[i] came with the candidate's line
+            nb_i.x = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)c_nb.x);
+            nb_i.y = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)c_nb.y);
+            nb_i.z = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)c_nb.z);
+            nb_i.w = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)c_nb.w);
+            k_i = nb_count(nb_i);
+        }
         W_ORDER();
         WPHASE(1);
         // ---------------- rates from the tracked sums (src/sfact.jl:116-119 with g_i(t′) = g_i + gd_i (t′ − tg_i))
@@ -578,7 +617,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         // ---------------- zones.  Only an ACCEPTED event m disturbs a later event r: within lattice distance 1 it changes r's sums (r's outcome
         // above is then garbage), at distance 2 the two share a neighbour, which matters only if r is accepted too.  A rejected event writes its
         // own (key, time) pair and nothing else.  The list ends at the first disturbed event (everything before it is unaffected).
-        {
+        if (LAT) {
             uint64_t confb = 0;
             uint64_t ab = __ballot(acc) & ((C < 64) ? ((1ull << C) - 1ull) : ~0ull);
             while (ab) {
@@ -590,6 +629,41 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 confb |= hit & (~0ull << (m + 1));
                 // an EARLIER rejected event next to accepted event m: m's group writes that coordinate's new key after it
                 if (sad <= 1u && lane < m && (uint32_t)m < rekey_by) rekey_by = (uint32_t)m;
+            }
+            const uint64_t cb = confb & ((C < 64) ? ((1ull << C) - 1ull) : ~0ull);
+            if (cb) {
+                const int c0 = __ffsll((unsigned long long)cb) - 1;
+                C = (c0 < C) ? c0 : C;
+            }
+        } else {
+            // the same two tests on ids.  The accepted events' G1 go to LDS in event order (slot s = the s-th accepted event; the accepted events
+            // that survive the cuts below are a prefix of them, so the slots stay valid); lane (g, gl) of the wave holds member gl of slot g.
+            const uint64_t ab0 = __ballot(acc) & ((C < 64) ? ((1ull << C) - 1ull) : ~0ull);
+            const int nacc0 = __popcll(ab0);  // (<= W_AMAX)
+            if (acc && lane < C) {
+                const int sl = __popcll(ab0 & ((1ull << lane) - 1ull));
+                NB4[sl] = nb_i;
+                ACL[sl] = (uint16_t)lane;
+            }
+            W_ORDER();
+            const uint32_t jt = (g < nacc0) ? (uint32_t)NB16[lane] : 0xffffu;  // (slot g, member gl: NB16[8 g + gl])
+            const uint32_t jt2 = jt | (jt << 16), i2 = i | (i << 16);
+            uint64_t confb = 0, ghit = 0;
+            uint64_t ab = ab0;
+            for (int sl = 0; sl < nacc0; ++sl) {
+                const int m = __ffsll((unsigned long long)ab) - 1;
+                ab &= ab - 1;
+                const uint4 nbm = NB4[sl];  // (one address for the wave: a broadcast read)
+                const bool d1 = ev && nb_has(nbm, i2);  // i_r ∈ G1[i_m]  (m itself included: masked below)
+                confb |= __ballot(d1) & (~0ull << (m + 1));
+                if (d1 && lane < m && (uint32_t)m < rekey_by) rekey_by = (uint32_t)m;
+                // a LATER accepted event that shares a member with m
+                ghit |= __ballot(g > sl && jt != 0xffffu && nb_has(nbm, jt2));
+            }
+            if (ghit) {
+                const int gs = (__ffsll((unsigned long long)ghit) - 1) >> 3;
+                const int r2 = (int)ACL[gs];
+                confb |= 1ull << r2;
             }
             const uint64_t cb = confb & ((C < 64) ? ((1ull << C) - 1ull) : ~0ull);
             if (cb) {
@@ -613,7 +687,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         if (PROF) ph_eval += (uint64_t)C;
         const uint64_t accball = __ballot(acc);
         const int nacc_it = __popcll(accball);
-        if (acc) ACL[__popcll(accball & ((1ull << lane) - 1ull))] = (uint16_t)lane;
+        if (LAT && acc) ACL[__popcll(accball & ((1ull << lane) - 1ull))] = (uint16_t)lane;  // (LAT = false: written with the zones, same slots)
         W_ORDER();
         WPHASE(2);
         // ---------------- accepted events, one 8-lane group each: members of G1[i] (ascending, :131-135)
@@ -629,13 +703,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const double tpa_b = w_shfl(tp, ea);
         const double tpa = gact ? tpa_b : 0.0;
         const uint32_t offa = gact ? off_b : 0u;
+        uint32_t ka = 0, jm = ia;
+        bool mem = false;
+        if (LAT) {
         // G1[ia] on the lattice, ascending: {ia − n, ia − 1, ia, ia + 1, ia + n} inside the grid -- computed, so that the members' records are
         // requested at once; the CSC tables are read for the VALUES only (Γ[j, i] = Γ[i, j]: symmetric, checked on the host)
         const uint32_t cola = __umulhi(ia, nmagic), rowa = ia - cola * nlat;
         const bool hasL = cola > 0u, hasU = rowa > 0u, hasD = rowa + 1u < nlat, hasR = cola + 1u < nlat;
-        const uint32_t ka = gact ? (1u + (hasL ? 1u : 0u) + (hasU ? 1u : 0u) + (hasD ? 1u : 0u) + (hasR ? 1u : 0u)) : 0u;
-        const bool mem = gact && (uint32_t)gl < ka;
-        uint32_t jm = ia;
+        ka = gact ? (1u + (hasL ? 1u : 0u) + (hasU ? 1u : 0u) + (hasD ? 1u : 0u) + (hasR ? 1u : 0u)) : 0u;
+        mem = gact && (uint32_t)gl < ka;
         {
             // position gl among the present members in the order L, U, self, D, R
             uint32_t pos = (uint32_t)gl;
@@ -650,10 +726,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 }
             }
         }
+        } else {
+            // member gl of G1[ia]: the ids the event's candidate lane read with its record (LDS slot g − g0), ascending (:131-135)
+            const uint32_t jraw = gact ? (uint32_t)NB16[8 * (g - g0) + gl] : 0xffffu;
+            mem = jraw != 0xffffu;
+            jm = mem ? jraw : ia;
+        }
         TrRecP* const rj = rec + jm;
         TrRecP* const ria = rec + ia;
         double gam = 0.0;  // Γ[jm, ia]: member gl of G1[ia]
-        if (mem) gam = (gl == 0) ? ria->gam0 : (gl == 1) ? ria->gam1 : (gl == 2) ? ria->gam2 : (gl == 3) ? ria->gam3 : ria->gam4;
+        if (LAT) {
+            if (mem) gam = (gl == 0) ? ria->gam0 : (gl == 1) ? ria->gam1 : (gl == 2) ? ria->gam2 : (gl == 3) ? ria->gam3 : ria->gam4;
+        } else {
+            if (mem) gam = P.tb.gam8[(size_t)ia * 8 + (size_t)gl];  // (shared table, L2: requested next to the members' records)
+        }
         // (the reflecting coordinate's own fields are read again by its group: the lines are in L2)
         const double th_ia = ria->th;
         double xa = ria->x, txa = ria->tx, Ia = ria->I;
@@ -852,7 +938,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 }
 
 bool zz_trackp_supported(const ZzRunParams& p) {
-    return p.lattice_n >= 16 && p.lattice_n <= 128 && !p.adapt && p.c_chain == nullptr && p.tb.gmu_t == nullptr && !p.track_two_sums &&
+    // the plain lattice (neighbours from the index), or any graph whose ids and values are tabulated (|G1| <= TRACKP_KMAX, checked by the host)
+    const bool graph = (p.lattice_n >= 16 && p.lattice_n <= 128) || (p.tb.nb16 != nullptr && p.tb.gam8 != nullptr);
+    return graph && !p.adapt && p.c_chain == nullptr && p.tb.gmu_t == nullptr && !p.track_two_sums &&
            !p.has_refresh && p.d >= 2048 && p.d <= (int64_t)W_NBLK * 8;
 }
 
@@ -860,31 +948,44 @@ int launch_zz_local_trackp(const ZzRunParams& p, int64_t nchains, void* stream) 
     dim3 grid((unsigned)nchains), block(64);
     ZzRunParams q = p;
     q.nblk = (uint32_t)((p.d + 7) / 8);  // (dk is a multiple of 64, the padding keys are +Inf)
-    if (p.dbg) hipLaunchKernelGGL((zz_local_trackp_kernel<true>), grid, block, W_BYTES, (hipStream_t)stream, q);
-    else hipLaunchKernelGGL((zz_local_trackp_kernel<false>), grid, block, W_BYTES, (hipStream_t)stream, q);
+    const bool lat = p.lattice_n != 0;
+    if (lat) {
+        if (p.dbg) hipLaunchKernelGGL((zz_local_trackp_kernel<true, true>), grid, block, W_BYTES, (hipStream_t)stream, q);
+        else hipLaunchKernelGGL((zz_local_trackp_kernel<false, true>), grid, block, W_BYTES, (hipStream_t)stream, q);
+    } else {
+        if (p.dbg) hipLaunchKernelGGL((zz_local_trackp_kernel<true, false>), grid, block, W_BYTES_G, (hipStream_t)stream, q);
+        else hipLaunchKernelGGL((zz_local_trackp_kernel<false, false>), grid, block, W_BYTES_G, (hipStream_t)stream, q);
+    }
     return (int)hipGetLastError();
 }
 
 // the per-coordinate constants into the two free sectors of every record (after the init kernel)
-__global__ __launch_bounds__(256) void zz_trackp_consts_kernel(TrRecP* __restrict__ rec, const CoordConst* __restrict__ cc, int64_t d, int64_t nchains) {
+__global__ __launch_bounds__(256) void zz_trackp_consts_kernel(TrRecP* __restrict__ rec, const CoordConst* __restrict__ cc,
+                                                              const uint16_t* __restrict__ nb16, int64_t d, int64_t nchains) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= d) return;
     const CoordConst e = cc[i];
+    double n01 = 0.0, n23 = 0.0;  // (any graph: G1[i] as eight 16-bit ids where the lattice keeps gam0, gam1)
+    if (nb16) {
+        const double2 v = reinterpret_cast<const double2*>(nb16)[i];
+        n01 = v.x;
+        n23 = v.y;
+    }
     for (int64_t ch = blockIdx.y; ch < nchains; ch += gridDim.y) {
         TrRecP* r = rec + ch * d + i;
         r->c = e.c;
         r->c100 = e.c100;
-        r->gam0 = e.gam[0];
-        r->gam1 = e.gam[1];
+        r->gam0 = nb16 ? n01 : e.gam[0];
+        r->gam1 = nb16 ? n23 : e.gam[1];
         r->gam2 = e.gam[2];
         r->gam3 = e.gam[3];
         r->gam4 = e.gam[4];
     }
 }
-int launch_zz_trackp_consts(void* rec, const CoordConst* cc, int64_t d, int64_t nchains, void* stream) {
+int launch_zz_trackp_consts(void* rec, const CoordConst* cc, const uint16_t* nb16, int64_t d, int64_t nchains, void* stream) {
     const unsigned gy = (unsigned)((nchains < 1024) ? nchains : 1024);
     hipLaunchKernelGGL(zz_trackp_consts_kernel, dim3((unsigned)((d + 255) / 256), gy), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<TrRecP*>(rec), cc, d, nchains);
+                       reinterpret_cast<TrRecP*>(rec), cc, nb16, d, nchains);
     return (int)hipGetLastError();
 }
 

@@ -54,6 +54,49 @@ def gmrf_marginal_variances(n, eps=0.01):
     return np.ascontiguousarray(var.T.reshape(n * n))
 
 
+def lattice3d_precision(n, eps=0.01):
+    """Γ = eps I + graph Laplacian of the n x n x n 7-point lattice (index i = a + n b + n² c): scripts/gridlaplace.jl's construction one
+    dimension up -- |G1| = 7 inside, |S| = 25.  A graph whose neighbours are NOT i ± 1, i ± n of the 2-d numbering (config C3G)."""
+    idx = np.arange(n ** 3).reshape(n, n, n)  # idx[c, b, a]
+    pa = [(idx[:, :, :-1].ravel(), idx[:, :, 1:].ravel()), (idx[:, :-1, :].ravel(), idx[:, 1:, :].ravel()),
+          (idx[:-1, :, :].ravel(), idx[1:, :, :].ravel())]
+    a = np.concatenate([q[0] for q in pa])
+    b = np.concatenate([q[1] for q in pa])
+    N = n ** 3
+    W = sp.coo_matrix((np.ones(a.size), (a, b)), shape=(N, N))
+    W = W + W.T
+    deg = np.asarray(W.sum(axis=1)).ravel()
+    G = sp.csc_matrix(eps * sp.identity(N, format="csc") + sp.diags(deg) - W)
+    G.sort_indices()
+    return G
+
+
+def random_sparse_precision(d, nnz_per_col=6, seed=7, eps=0.05):
+    """A random symmetric sparse precision with at most `nnz_per_col` entries per column, no structure in the numbering: the pattern of
+    test/maintest.jl:6-8 (`sprandn`) scaled to d ~ 16384 and made diagonally dominant so that it is positive definite whatever the pattern.
+    Built as a random graph of maximum degree nnz_per_col - 1 (random perfect matchings laid over each other, duplicates dropped), weights
+    w_ij = -|N(0, 1)|, Γ_ii = eps + Σ_j |w_ij| (config C3G)."""
+    rng = np.random.default_rng(seed)
+    rows, cols = [], []
+    for _ in range(nnz_per_col - 1):
+        perm = rng.permutation(d)
+        h = d // 2
+        rows.append(perm[:h])
+        cols.append(perm[h:2 * h])
+    a = np.concatenate(rows)
+    b = np.concatenate(cols)
+    lo, hi = np.minimum(a, b), np.maximum(a, b)
+    key = np.unique(lo.astype(np.int64) * d + hi)
+    lo, hi = key // d, key % d
+    w = -np.abs(rng.standard_normal(lo.size)) - 0.1
+    W = sp.coo_matrix((w, (lo, hi)), shape=(d, d))
+    W = sp.csc_matrix(W + W.T)
+    diag = eps - np.asarray(W.sum(axis=0)).ravel()
+    G = sp.csc_matrix(W + sp.diags(diag))
+    G.sort_indices()
+    return G
+
+
 def column_norms(G):
     """c[i] = norm(Γ[:, i], 2) -- scripts/gaussianrandomfield.jl:33."""
     G = sp.csc_matrix(G)
