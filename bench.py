@@ -170,7 +170,7 @@ def cpu_baseline(pkg, G, c, budget_s=20.0):
             "host": lim, "thread_sweep": {str(k): v for k, v in sweep.items()}, "parallel_efficiency": eff}
 
 
-CONFIG_DEFAULTS = {"C3": dict(chains=4096, dt=1.0), "C2": dict(chains=4096, dt=30.0), "C4": dict(chains=8192, dt=2.0),
+CONFIG_DEFAULTS = {"C3": dict(chains=4096, dt=1.0), "C3G": dict(chains=4096, dt=1.0), "C2": dict(chains=4096, dt=30.0), "C4": dict(chains=8192, dt=2.0),
                    "C5": dict(chains=4096, dt=0.005)}
 
 
@@ -203,6 +203,37 @@ def make_workload(pkg, args, rank, local_rank):
                           f"step = advance all chains by dT={dt}, traces {'off' if args.no_trace else 'on (32 B/event)'}",
                  model="224*num + 48*(num-nacc) + 616*nacc bytes (SURVEY 8d3)",
                  bytes=lambda w: algorithmic_bytes(w["num"], w["nacc"]))
+    elif args.config == "C3G":
+        # the headline sampler OFF the benchmark stencil: any sparse Γ (src/sfact.jl:170-179 builds G1 / G2 from the CSC pattern)
+        if args.graph == "lattice3d":
+            G = pkg.problems.lattice3d_precision(25)
+            gname = "Gamma=0.01I+Laplacian of the 25x25x25 7-point lattice"
+        else:
+            nz = int(args.graph[len("random"):])
+            G = pkg.problems.random_sparse_precision(16384, nz)
+            gname = f"random symmetric pattern, <= {nz} entries per column, diagonally dominant (test/maintest.jl:6-8's sprandn scaled up)"
+        d = G.shape[0]
+        c = pkg.problems.column_norms(G)
+        cap = 0 if args.no_trace else int(2.5 * d * dt) + 1024
+        ens = pkg.Ensemble(nch, d, device=local_rank, trace_capacity=cap)
+        ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
+        ens.set_target(pkg.GaussianTarget(G))
+        if not args.exact:
+            ens.set_gradient_tracking(True)
+        ens.set_state_synthetic(0.0, c, seed0)
+        kbar = float(np.diff(G.indptr).mean())
+        B = (abs(G) > 0).astype(np.int64)
+        g2bar = float((np.diff((B @ B).tocsc().indptr) - np.diff(G.indptr)).mean())
+        per_prop = kbar * 40 + 24
+        per_acc = g2bar * 40 + 8 + kbar * 32 + kbar * 16 + 16 + 32
+        W.update(G=G, c=c, d=d, cap=cap, ens=ens, kernel="", unit="reflection events/s",
+                 evaluation="moving (bit-identical to the oracle)" if args.exact else "tracked gradients (bit-identical to the oracle's tracked evaluation)",
+                 metric=f"reflection events/sec, d={d} local ZigZag (spdmp) on a sparse Gamma that is not the 2-d lattice, ensemble of independent chains",
+                 workload=f"C3G: local ZigZag spdmp on {gname}, d={d}, {nch} chains/GPU, step = advance all chains by dT={dt}, "
+                          f"traces {'off' if args.no_trace else 'on (32 B/event)'}",
+                 model=f"SURVEY 8d3's model on this graph: per proposal k*40+24 = {per_prop:.0f} B (k={kbar:.2f}), +48 B per rejection, "
+                       f"+{per_acc:.0f} B per accepted reflection (|G2|={g2bar:.1f})",
+                 bytes=lambda w: per_prop * w["num"] + 48.0 * (w["num"] - w["nacc"]) + per_acc * w["nacc"])
     elif args.config == "C2":
         import scipy.sparse as sp
         d = 1024
@@ -307,6 +338,8 @@ def main():
     ap.add_argument("--tracked", action="store_true",
                     help="C4: tracked bounds (pdmp_ensemble_set_gradient_tracking on the logistic target; bit-identical to the oracle's tracked evaluation) "
                          "instead of the default, bit-identical moving evaluation")
+    ap.add_argument("--graph", default="lattice3d", choices=["lattice3d", "random5", "random6", "random7", "random8"],
+                    help="C3G: the 25^3 7-point lattice (d = 15625, |G1| = 7, |S| = 25) or a random symmetric pattern at d = 16384")
     ap.add_argument("--exact", action="store_true",
                     help="C3: the bit-identical moving evaluation (zz_local_spec8_kernel) instead of the tracked-gradient one")
     args = ap.parse_args()
@@ -314,7 +347,10 @@ def main():
         args.chains = CONFIG_DEFAULTS[args.config]["chains"]
     if args.dt is None:
         args.dt = CONFIG_DEFAULTS[args.config]["dt"]
-    if args.config != "C3":
+    if args.config == "C3G":
+        args.ess_batches = 0
+        args.exact_steps = 0
+    elif args.config != "C3":
         args.ess_batches = 0  # path integrals / the trace exchange are wired to the headline workload
         if args.gather:
             raise SystemExit("--gather is implemented for the headline workload (--config C3)")
@@ -415,6 +451,8 @@ def main():
     for k in range(args.warmup):
         step(k)
     barrier()
+    if args.warmup > 0 and ens.kernel_name():
+        W["kernel"] = ens.kernel_name()  # what the engine actually launched (pdmp_debug_last_kernel), not what this script expects
     w0 = work_counters()
     launches[0] = 0
     kernel_ms = []
@@ -631,7 +669,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "evaluation": ("exact" if args.exact else "tracked") if args.config == "C3" else ("tracked" if (args.config == "C4" and args.tracked) else "exact"),
+            "evaluation": ("exact" if args.exact else "tracked") if args.config in ("C3", "C3G") else ("tracked" if (args.config == "C4" and args.tracked) else "exact"),
             "config": {"workload": W["workload"] + (f"; evaluation: {W['evaluation']}" if "evaluation" in W else ""),
                        "chains_per_gpu": nch, "d": d, "dT": args.dt, "parallelism": f"chains sharded x{world}, no collective in the run"
                                       + (" (reductions of this line: " + ("pdmp_comm_allreduce, RCCL linked by the engine" if comm is not None else "torch.distributed " + backend) + ")" if world > 1 else "")},
@@ -656,7 +694,7 @@ def main():
         if exact is not None:
             out["exact"] = exact
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pkg, G, c) if args.config == "C3" else cpu_baseline_config(pkg, args.config)
+            out["cpu_baseline"] = cpu_baseline(pkg, G, c) if args.config in ("C3", "C3G") else cpu_baseline_config(pkg, args.config)
         print(json.dumps(out), flush=True)
     ens.close()
     if comm is not None:

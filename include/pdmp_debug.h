@@ -36,6 +36,8 @@ pdmp_status pdmp_debug_phase_profile(pdmp_ensemble* ens, double* out16, int* kin
  * floats and commit the same sequence.  The choice fixes the queue's layout: call it BEFORE set_state.  (Rounds 1-2 carried two more
  * variants, key blocks of 32 and of 16 in the record layout; they were superseded and removed.) */
 pdmp_status pdmp_debug_set_track_groups(pdmp_ensemble* ens, int which);
+/* name of the event-loop kernel the last pdmp_ensemble_run launched (bench.py prints it with every line: no figure without its kernel) */
+pdmp_status pdmp_debug_last_kernel(pdmp_ensemble* ens, char* out, int64_t cap);
 /* chains per wavefront of the LDS-resident logistic kernel (config C4): -1 the library's default, 0 one chain (pdmp_logistic.hip), 16 or 32 =
  * rows of that many lanes, 4 or 2 chains per wavefront (pdmp_logrows.hip); an ensemble that does not fit the rows asked for is refused at run */
 pdmp_status pdmp_debug_set_logistic_rows(pdmp_ensemble* ens, int row_width);

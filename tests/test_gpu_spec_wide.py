@@ -1,0 +1,90 @@
+"""The moving (bit-identical) evaluation OFF the benchmark stencil (-m gpu): zz_local_spec_kernel<.., WIDE> -- four events per iteration with
+two zone members per lane -- serves two-hop neighbourhoods of 17 .. 32 coordinates (the 7-point 3-d lattice: |S| = 25; random symmetric
+patterns with <= 6 entries per column: |S| <= 26).  Every case runs on the speculative kernel and on the one-event kernel (PDMP_KERNEL=seq);
+both must equal the oracle's restatement of src/sfact.jl:73-145 bit for bit (tolerance 0)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import oracle_lib as O
+from test_gpu_track_generic import graphs
+from test_gpu_zigzag_parity import run_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=["spec", "seq"])
+def kernel_mode(request, monkeypatch):
+    if request.param == "seq":
+        monkeypatch.setenv("PDMP_KERNEL", "seq")
+    else:
+        monkeypatch.delenv("PDMP_KERNEL", raising=False)
+    return request.param
+
+
+@pytest.mark.parametrize("which,T", [("lattice3d", 6.0), ("random6", 5.0)])
+def test_wide_zones_match_oracle(gpu_pkg, kernel_mode, which, T):
+    pkg = gpu_pkg
+    G = graphs(pkg, which)
+    d = G.shape[0]
+    B = (abs(G) > 0).astype(np.int64)
+    mmax = int(np.diff((B @ B).tocsc().indptr).max())
+    assert 16 < mmax <= 32
+    rng = np.random.default_rng(3)
+    run_case(pkg, G, G, rng.standard_normal((3, d)), rng.choice([-1.0, 1.0], (3, d)), pkg.problems.column_norms(G), T, seed=1300)
+    if kernel_mode == "spec":
+        with pkg.Ensemble(1, d) as ens:
+            ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
+            ens.set_target(pkg.GaussianTarget(G))
+            ens.set_state_synthetic(0.0, pkg.problems.column_norms(G), 1)
+            ens.run(0.1)
+            assert ens.kernel_name() == "zz_local_spec_kernel<WIDE>"
+
+
+def test_wide_zones_small_d_loose_bound_mean_adapt(gpu_pkg):
+    """One and two key blocks (d = 125, the 5^3 lattice; every instantiation of the first level), a bounding Γ = 0.9 Γ, a target mean and adapt
+    with bounds that start too small."""
+    pkg = gpu_pkg
+    G = pkg.problems.lattice3d_precision(5)
+    d = G.shape[0]
+    rng = np.random.default_rng(8)
+    mu = 0.3 * rng.standard_normal(d)
+    x0, th0 = rng.standard_normal((3, d)), rng.choice([-1.0, 1.0], (3, d))
+    run_case(pkg, G, sp.csc_matrix(0.9 * G), x0, th0, 0.2 * pkg.problems.column_norms(G), 40.0, seed=41, adapt=True, target_mu=mu)
+    G = pkg.problems.lattice3d_precision(9)   # d = 729: 12 key blocks
+    d = G.shape[0]
+    run_case(pkg, G, G, rng.standard_normal((2, d)), rng.choice([-1.0, 1.0], (2, d)), pkg.problems.column_norms(G), 15.0, seed=42)
+
+
+def test_wide_zones_slices_and_trace_refills(gpu_pkg):
+    pkg = gpu_pkg
+    L = pkg._lib
+    G = graphs(pkg, "lattice3d")
+    d = G.shape[0]
+    c = pkg.problems.column_norms(G)
+    nch = 2
+    with pkg.Ensemble(nch, d, trace_capacity=2000) as ens:
+        ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
+        ens.set_target(pkg.GaussianTarget(G))
+        ens.set_state_synthetic(0.0, c, 555)
+        evs = [[] for _ in range(nch)]
+        for Tk, flag in ((1.3, L.RUN_STOP_BEFORE), (2.9, L.RUN_STOP_BEFORE), (4.0, L.RUN_REFERENCE_TAIL)):
+            while True:
+                ens.run(Tk, flag)
+                cnt = ens.counters()
+                for q in range(nch):
+                    evs[q].append(ens.trace(q, counters=cnt))
+                ens.trace_reset()
+                if not np.any(cnt["status"] == L.CHAIN_TRACE_FULL):
+                    break
+        fs = ens.final_state()
+        cnt = ens.counters()
+    for q in range(nch):
+        x0, th0 = O.synthetic_state(555 + q, d)
+        r = O.spdmp_zigzag(G, None, G, x0, th0, c, 4.0, seed=555 + q)
+        ev = np.concatenate(evs[q])
+        assert len(ev) == len(r["events"]) and len(ev) > 4000 and int(cnt["num"][q]) == r["num"]
+        for f in ("i", "t", "x", "theta"):
+            assert np.array_equal(ev[f], r["events"][f]), f
+        assert np.array_equal(fs["t"][q], r["t"]) and np.array_equal(fs["x"][q], r["x"]) and np.array_equal(fs["theta"][q], r["theta"])
+        assert np.array_equal(fs["acc"][q], r["acc"])

@@ -45,7 +45,7 @@ EXPORTED_SYMBOLS = [
 ]
 # include/pdmp_debug.h: diagnostics, not part of the drop-in boundary
 DEBUG_SYMBOLS = ["pdmp_debug_set_kernel", "pdmp_debug_set_spec_g2", "pdmp_debug_set_phase_profile", "pdmp_debug_phase_profile",
-                 "pdmp_debug_set_proposal_dump", "pdmp_debug_set_track_groups", "pdmp_debug_set_logistic_rows", "pdmp_debug_math_probe", "pdmp_debug_write_probe", "pdmp_debug_sector_probe"]
+                 "pdmp_debug_set_proposal_dump", "pdmp_debug_set_track_groups", "pdmp_debug_last_kernel", "pdmp_debug_set_logistic_rows", "pdmp_debug_math_probe", "pdmp_debug_write_probe", "pdmp_debug_sector_probe"]
 DEBUG_KERNELS = {"auto": 0, "seq": 1, "spec4": 2, "spec8": 3, "exactp": 4}
 
 
@@ -152,6 +152,7 @@ def load():
     L.pdmp_debug_phase_profile.argtypes = [vp, vp, C.POINTER(C.c_int)]
     L.pdmp_debug_set_proposal_dump.argtypes = [vp, i64]
     L.pdmp_debug_set_track_groups.argtypes = [vp, C.c_int]
+    L.pdmp_debug_last_kernel.argtypes = [vp, C.c_char_p, i64]
     L.pdmp_debug_set_logistic_rows.argtypes = [vp, C.c_int]
     for name in EXPORTED_SYMBOLS + DEBUG_SYMBOLS:
         fn = getattr(L, name)

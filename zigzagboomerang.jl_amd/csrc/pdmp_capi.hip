@@ -125,6 +125,7 @@ struct pdmp_ensemble {
     bool track_generic = false;  // ... on a graph that is not the plain lattice: G1 ids in the records, Γ values in d_gam8 (|G1| <= 8)
     DevBuf<double> d_gam8;
     DevBuf<uint16_t> d_nb16;
+    const char* last_kernel = "";  // event-loop kernel of the last pdmp_ensemble_run (pdmp_debug_last_kernel)
     int32_t lattice_n = 0;  // the flow's graph is the n x n 5-point lattice in column-major numbering (0: it is not)
     double t0_state = 0.0;
     DevBuf<double> d_jstart, d_essacc;  // pdmp_ensemble_ess_*
@@ -357,6 +358,11 @@ pdmp_status pdmp_debug_phase_profile(pdmp_ensemble* e, double* out16, int* kind)
     if (!e->dbg_phase_valid) return fail(PDMP_ERR_INVALID, "no phase profile recorded by the last run");
     memcpy(out16, e->dbg_phase_out, sizeof e->dbg_phase_out);
     if (kind) *kind = e->dbg_phase_valid;
+    return PDMP_OK;
+}
+pdmp_status pdmp_debug_last_kernel(pdmp_ensemble* e, char* out, int64_t cap) {
+    if (!e || !out || cap < 1) return fail(PDMP_ERR_INVALID, "null argument");
+    snprintf(out, (size_t)cap, "%s", e->last_kernel);
     return PDMP_OK;
 }
 pdmp_status pdmp_debug_set_track_groups(pdmp_ensemble* e, int on) {
@@ -819,7 +825,7 @@ static pdmp_status build_blob(pdmp_ensemble* e, const double* c) {
     e->blob_mmax = mmax;
     // (pdmp_debug_set_kernel(PDMP_DEBUG_KERNEL_SEQ) forces the one-event-per-iteration kernel: A/B runs, parity tests)
     e->use_spec = pdmp::zz_spec_supported(e->nblk, mmax, kmax) && e->dbg_kernel != PDMP_DEBUG_KERNEL_SEQ &&
-                  pdmp::zz_spec_lds_bytes(e->nblk_pad, Wpad) <= 64 * 1024;
+                  (mmax > 16 ? pdmp::zz_spec_wide_lds_bytes(e->nblk_pad, Wpad) : pdmp::zz_spec_lds_bytes(e->nblk_pad, Wpad)) <= 64 * 1024;
     return e->d_blob.upload(blob);
 }
 
@@ -1251,6 +1257,7 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         B.adapt = e->cfg.adapt;
         fill_bps_ext(e, B);
         HIP_TRY(hipEventRecord(e->ev0, s));
+        e->last_kernel = "bps_run_kernel";
         int rcb = pdmp::launch_bps_run(B, e->cfg.nchains, e->bps_diag, s);
         if (rcb != 0) return fail(PDMP_ERR_HIP, "bps_run launch failed (%d)", rcb);
         HIP_TRY(hipEventRecord(e->ev1, s));
@@ -1372,6 +1379,7 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         const int rows_w = (!lds_resident || e->track_lg) ? 0 : (e->dbg_lg_rows >= 0 ? e->dbg_lg_rows : PDMP_LG_ROWS_DEFAULT);
         const bool rows = rows_w > 0 && pdmp::zz_logistic_rows_supported(P, Q, LT, rows_w);
         if (lds_resident && e->dbg_lg_rows > 0 && !rows) return fail(PDMP_ERR_UNSUPPORTED, "pdmp_debug_set_logistic_rows: this ensemble does not fit rows of %d lanes", rows_w);
+        e->last_kernel = rows ? "zz_logistic_rows_kernel" : lds_resident ? "zz_logistic_lds_kernel" : "zz_general_run_kernel";
         int rcg = rows ? pdmp::launch_zz_logistic_rows(P, Q, LT, e->keep_integrals, rows_w, e->cfg.nchains, s)
                        : lds_resident ? pdmp::launch_zz_logistic_lds(P, Q, LT, e->keep_integrals, e->cfg.nchains, s) : pdmp::launch_zz_general_run(P, Q, e->cfg.nchains, s);
         if (rcg != 0) return fail(PDMP_ERR_HIP, "zz_general_run launch failed: %s", hipGetErrorString((hipError_t)rcg));
@@ -1392,6 +1400,7 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         // one proposal per lane where the graph is the plain lattice (pdmp_trackp.hip); elsewhere, and on request, the 8-lane-group kernel
         if (e->track_pairs) {
             P.keys = e->d_kp.p;
+            e->last_kernel = e->lattice_n ? "zz_local_trackp_kernel" : "zz_local_trackp_kernel<LAT=false>";
             int rcp = pdmp::launch_zz_local_trackp(P, e->cfg.nchains, s);
             if (rcp != 0) return fail(PDMP_ERR_HIP, "zz_local_trackp launch failed (%d)", rcp);
             HIP_TRY(hipEventRecord(e->ev1, s));
@@ -1403,6 +1412,7 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
             }
             return PDMP_OK;
         }
+        e->last_kernel = "zz_local_track_kernel";
         int rct = pdmp::launch_zz_local_track(P, e->cfg.nchains, s);
         if (rct != 0) return fail(PDMP_ERR_HIP, "zz_local_track launch failed (%d)", rct);
         HIP_TRY(hipEventRecord(e->ev1, s));
@@ -1418,6 +1428,7 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         P.lattice_n = e->lattice_n;
         P.lattice_magic = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)e->lattice_n + 1);
         if (pdmp::zz_exactp_supported(P)) {
+            e->last_kernel = "zz_local_exactp_kernel";
             int rcx = pdmp::launch_zz_local_exactp(P, e->cfg.nchains, s);
             if (rcx != 0) return fail(PDMP_ERR_HIP, "zz_local_exactp launch failed (%d)", rcx);
             HIP_TRY(hipEventRecord(e->ev1, s));
@@ -1432,9 +1443,10 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
     }
     if (e->dbg_kernel == PDMP_DEBUG_KERNEL_EXACTP)  // asked for by name: never another kernel in its place
         return fail(PDMP_ERR_UNSUPPORTED, "PDMP_DEBUG_KERNEL_EXACTP: spdmp on a plain lattice (16 <= n <= 128, d >= 2048) with the bounding matrix equal to the target's, no adaptation, and a trace or no trace");
-    const bool sticky_spec = sticky && e->use_spec && dbg_cap == 0;  // same requirements as the ZigZag speculative kernel
+    const bool sticky_spec = sticky && e->use_spec && e->blob_mmax <= 16 && dbg_cap == 0;  // the ZigZag speculative kernel's requirements, one zone member per lane
+    e->last_kernel = sticky ? (sticky_spec ? "zz_sticky_spec_kernel" : "zz_sticky_run_kernel") : "zz_local_run_kernel";
     int rc = sticky ? (sticky_spec ? pdmp::launch_zz_sticky_spec(P, e->cfg.nchains, s) : pdmp::launch_zz_sticky_run(P, e->cfg.nchains, s))
-                    : spec_ok ? pdmp::launch_zz_local_spec(P, e->cfg.nchains, s) : pdmp::launch_zz_local_run(P, e->cfg.nchains, s);
+                    : spec_ok ? pdmp::launch_zz_local_spec(P, e->cfg.nchains, s, &e->last_kernel) : pdmp::launch_zz_local_run(P, e->cfg.nchains, s);
     if (rc != 0) return fail(PDMP_ERR_HIP, "zz_local_run launch failed: %s", hipGetErrorString((hipError_t)rc));
     HIP_TRY(hipEventRecord(e->ev1, s));
     e->timed = true;

@@ -343,11 +343,12 @@ int launch_bps_run(const BpsRunParams& p, int64_t nchains, bool diag, void* stre
 // launch wrappers implemented in pdmp_kernels.hip (hipStream_t passed as void*)
 int launch_zz_init(const ZzInitParams& p, void* stream);
 int launch_zz_local_run(const ZzRunParams& p, int64_t nchains, void* stream);
-int launch_zz_local_spec(const ZzRunParams& p, int64_t nchains, void* stream);
+int launch_zz_local_spec(const ZzRunParams& p, int64_t nchains, void* stream, const char** kname = nullptr);
 int launch_zz_sticky_run(const ZzRunParams& p, int64_t nchains, void* stream);
 int launch_zz_sticky_spec(const ZzRunParams& p, int64_t nchains, void* stream);
 bool zz_spec_supported(uint32_t nblk, uint32_t mmax, uint32_t kmax);
 size_t zz_spec_lds_bytes(uint32_t nblk_pad, uint32_t blob_w_pad);
+size_t zz_spec_wide_lds_bytes(uint32_t nblk_pad, uint32_t blob_w_pad);  // 17 <= |S[i]| <= 32
 int launch_zz_unpack(const ZzRec* rec, const double* c_src, int64_t c_stride, int64_t d, int64_t chain_first,
                      int64_t n, double* t, double* x, double* th, int64_t* acc, double* c, void* stream);
 int launch_zz_batch_means(const ZzRec* rec, int64_t rec_stride, double* jprev, int64_t d, int64_t nchains, double T_prev, double T,

@@ -1168,8 +1168,23 @@ constexpr uint32_t SP_SLB = 4528;   // [4] u32 candidate blocks
 constexpr uint32_t SP_OFR = 4544;   // [8] u32 draw offsets after 0..4 events
 constexpr uint32_t SP_LB = 4576;    // [4][Wpad] u64 blobs, then bk[nblk_pad] f64, bi[nblk_pad] u32
 
+// WIDE (17 <= |S[i]| <= 32: two zone members per lane of a 16-lane row; the second one is always G2-only because |G1| <= 15): the same
+// arrays with 32 slots per group where a slot is a zone member
+// arrays with 32 slots per group where a slot is a zone member.  The patched key blocks take the place of sx / sth once the re-bound has read
+// them (as in the 8-event kernel), so that a chain stays inside 10 KB: 16 chains per CU, all 4096 chains of the ensemble resident at once.
+constexpr uint32_t SPW_SX = 1024;    // [4][32] f64
+constexpr uint32_t SPW_STH = 2048;   // [4][32] f64
+constexpr uint32_t SPW_PK = 1024;    // [4][64] f64 (over sx / sth)
+constexpr uint32_t SPW_SLT = 3072, SPW_SLH = 3104, SPW_LR = 3136, SPW_LBR = 3168, SPW_MR = 3200;
+constexpr uint32_t SPW_Z = 3232;     // [4][32] u32 zone ids
+constexpr uint32_t SPW_KR = 3744, SPW_SLB = 3760, SPW_OFR = 3776;
+constexpr uint32_t SPW_LB = 3808;
+
 size_t zz_spec_lds_bytes(uint32_t nblk_pad, uint32_t blob_w_pad) {
     return (size_t)SP_LB + (size_t)4 * blob_w_pad * 8 + (size_t)nblk_pad * 8 + (size_t)nblk_pad * 4;
+}
+size_t zz_spec_wide_lds_bytes(uint32_t nblk_pad, uint32_t blob_w_pad) {
+    return (size_t)SPW_LB + (size_t)4 * blob_w_pad * 8 + (size_t)nblk_pad * 8 + (size_t)nblk_pad * 4;
 }
 
 // minimum over the 16 lanes of a DPP row, returned in every lane of the row
@@ -1281,6 +1296,46 @@ __device__ __forceinline__ bool spec_zone_conflict(const uint32_t* Z, uint32_t s
     return myconf && member;
 }
 
+// WIDE: two ids per lane (s, s2), 32 per group: Z[q][32]
+template <int E>
+__device__ __forceinline__ bool spec_zone_conflict_wide(const uint32_t* Z, uint32_t s, uint32_t s2, int g, bool member, bool member2) {
+    uint32_t lo = member ? s : 0xffffffffu, hi = member ? s : 0u;
+    lo = (member2 && s2 < lo) ? s2 : lo;
+    hi = (member2 && s2 > hi) ? s2 : hi;
+    {
+        uint32_t o;
+        o = zone_dpp_u32<0xB1>(lo);   lo = (o < lo) ? o : lo;
+        o = zone_dpp_u32<0x4E>(lo);   lo = (o < lo) ? o : lo;
+        o = zone_dpp_u32<0x141>(lo);  lo = (o < lo) ? o : lo;
+        o = zone_dpp_u32<0x140>(lo);  lo = (o < lo) ? o : lo;
+        o = zone_dpp_u32<0xB1>(hi);   hi = (o > hi) ? o : hi;
+        o = zone_dpp_u32<0x4E>(hi);   hi = (o > hi) ? o : hi;
+        o = zone_dpp_u32<0x141>(hi);  hi = (o > hi) ? o : hi;
+        o = zone_dpp_u32<0x140>(hi);  hi = (o > hi) ? o : hi;
+    }
+    bool maybe = false;
+#pragma unroll
+    for (int q = 0; q < E - 1; ++q) {
+        const uint32_t lq = readlane_u32(lo, 16 * q), hq = readlane_u32(hi, 16 * q);
+        maybe = maybe || ((q < g) && ((member && s >= lq && s <= hq) || (member2 && s2 >= lq && s2 <= hq)));
+    }
+    if (__ballot(maybe) == 0) return false;
+    const uint4* Z4 = reinterpret_cast<const uint4*>(Z);
+    bool myconf = false;
+#pragma unroll
+    for (int q = 0; q < E - 1; ++q) {
+        bool hit = false;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint4 zz = Z4[q * 8 + j];
+            hit = hit || (member && (zz.x == s || zz.y == s || zz.z == s || zz.w == s)) ||
+                  (member2 && (zz.x == s2 || zz.y == s2 || zz.z == s2 || zz.w == s2));
+        }
+        myconf = myconf || (hit && (q < g));
+    }
+    return myconf;
+}
+
 // Minimum of the group's patched copy of the popped key block (4 keys per lane): row minimum, this lane's candidate.
 __device__ __forceinline__ void spec_patched_min(const double* pk, int gl, uint32_t blk, double& rowmin, double& candmin,
                                                  uint32_t& cand) {
@@ -1307,8 +1362,9 @@ __device__ __forceinline__ void spec_patched_min(const double* pk, int gl, uint3
 
 // PLAIN: the configuration of the north-star workload -- adapt = false, target without a mean shift, G2 fetched on accept --
 // as compile-time facts (the per-chain bound array, the Γμ look-up and the eager-G2 path drop out of the instantiation).
-template <int NE, bool PROF, bool PLAIN = false>
-__global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P_in) {
+template <int NE, bool PROF, bool PLAIN, bool WIDE>
+__device__ __forceinline__ void zz_local_spec_body(const ZzRunParams& P_in) {
+    static_assert(!(PLAIN && WIDE), "PLAIN is the lattice's geometry");
     ZzRunParams P = P_in;
     if constexpr (PLAIN) {
         P.adapt = 0;
@@ -1330,24 +1386,28 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P_in) {
     const uint32_t R_ = 4 + PW + KMAX;
 
     extern __shared__ __align__(16) unsigned char smem[];
+    constexpr uint32_t O_SX = WIDE ? SPW_SX : SP_SX, O_STH = WIDE ? SPW_STH : SP_STH, O_PK = WIDE ? SPW_PK : SP_PK, O_SLT = WIDE ? SPW_SLT : SP_SLT,
+                       O_SLH = WIDE ? SPW_SLH : SP_SLH, O_LR = WIDE ? SPW_LR : SP_LR, O_LBR = WIDE ? SPW_LBR : SP_LBR, O_MR = WIDE ? SPW_MR : SP_MR,
+                       O_Z = WIDE ? SPW_Z : SP_Z, O_KR = WIDE ? SPW_KR : SP_KR, O_SLB = WIDE ? SPW_SLB : SP_SLB, O_OFR = WIDE ? SPW_OFR : SP_OFR,
+                       O_LB = WIDE ? SPW_LB : SP_LB, GSLOTS = WIDE ? 32u : 16u;
     double* const U = reinterpret_cast<double*>(smem + SP_U);
     double* const LU = reinterpret_cast<double*>(smem + SP_LU);
-    double* const SLT = reinterpret_cast<double*>(smem + SP_SLT);
-    double* const SLH = reinterpret_cast<double*>(smem + SP_SLH);
-    double* const Lr = reinterpret_cast<double*>(smem + SP_LR);
-    double* const LBr = reinterpret_cast<double*>(smem + SP_LBR);
-    double* const Mr = reinterpret_cast<double*>(smem + SP_MR);
-    uint32_t* const Z = reinterpret_cast<uint32_t*>(smem + SP_Z);
-    uint32_t* const Kr = reinterpret_cast<uint32_t*>(smem + SP_KR);
-    uint32_t* const SLB = reinterpret_cast<uint32_t*>(smem + SP_SLB);
-    uint32_t* const OFR = reinterpret_cast<uint32_t*>(smem + SP_OFR);
-    double* const bk = reinterpret_cast<double*>(smem + SP_LB + (size_t)4 * P.blob_w_pad * 8);
+    double* const SLT = reinterpret_cast<double*>(smem + O_SLT);
+    double* const SLH = reinterpret_cast<double*>(smem + O_SLH);
+    double* const Lr = reinterpret_cast<double*>(smem + O_LR);
+    double* const LBr = reinterpret_cast<double*>(smem + O_LBR);
+    double* const Mr = reinterpret_cast<double*>(smem + O_MR);
+    uint32_t* const Z = reinterpret_cast<uint32_t*>(smem + O_Z);
+    uint32_t* const Kr = reinterpret_cast<uint32_t*>(smem + O_KR);
+    uint32_t* const SLB = reinterpret_cast<uint32_t*>(smem + O_SLB);
+    uint32_t* const OFR = reinterpret_cast<uint32_t*>(smem + O_OFR);
+    double* const bk = reinterpret_cast<double*>(smem + O_LB + (size_t)4 * P.blob_w_pad * 8);
     uint32_t* const bi = reinterpret_cast<uint32_t*>(bk + P.nblk_pad);
     // per-group views
-    double* const sx = reinterpret_cast<double*>(smem + SP_SX) + g * 16;
-    double* const sth = reinterpret_cast<double*>(smem + SP_STH) + g * 16;
-    double* const pk = reinterpret_cast<double*>(smem + SP_PK) + g * 64;
-    uint64_t* const lb = reinterpret_cast<uint64_t*>(smem + SP_LB) + (size_t)g * P.blob_w_pad;
+    double* const sx = reinterpret_cast<double*>(smem + O_SX) + g * GSLOTS;
+    double* const sth = reinterpret_cast<double*>(smem + O_STH) + g * GSLOTS;
+    double* const pk = reinterpret_cast<double*>(smem + O_PK) + g * 64;
+    uint64_t* const lb = reinterpret_cast<uint64_t*>(smem + O_LB) + (size_t)g * P.blob_w_pad;
 
     ZzRec* rec = P.rec + chain * d;
     double* keys = P.keys + chain * P.dk;
@@ -1450,6 +1510,7 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P_in) {
         // ---------------- neighbourhood header and member list
         int k = 0, m = 0, self = 0, kjmax = 0;
         uint32_t s = 0xffffff00u + (uint32_t)lane;
+        uint32_t s2 = 0xffffff40u + (uint32_t)lane;  // (WIDE: zone position gl + 16)
         if (gvalid) {
             const uint64_t hw = lb[0];
             k = (int)(hw & 0xff);
@@ -1460,17 +1521,30 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P_in) {
                 const uint64_t sw = lb[1 + (gl >> 1)];
                 s = i + ((gl & 1) ? (uint32_t)(sw >> 32) : (uint32_t)sw);
             }
+            if (WIDE && gl + 16 < m) {
+                const uint64_t sw = lb[1 + 8 + (gl >> 1)];
+                s2 = i + ((gl & 1) ? (uint32_t)(sw >> 32) : (uint32_t)sw);
+            }
         }
         const bool member = gvalid && gl < m;
+        const bool member2 = WIDE && gvalid && gl + 16 < m;
         PHASE(2);
         ZzRec* rs = rec + (member ? s : i);
+        ZzRec* rs2 = rec + (member2 ? s2 : i);
         double x = 0.0, th = 0.0, t = 0.0, I = 0.0;
+        double x2 = 0.0, th2 = 0.0, t2 = 0.0, I2 = 0.0;
         const bool lazy_g2 = (P.flags & 0x100) != 0;  // fetch G2[i] only once the event is accepted (default)
         if (member && (!lazy_g2 || gl < k)) {
             x = rs->x;
             th = rs->th;
             t = rs->t;
             I = rs->I;
+        }
+        if (WIDE && member2 && !lazy_g2) {
+            x2 = rs2->x;
+            th2 = rs2->th;
+            t2 = rs2->t;
+            I2 = rs2->I;
         }
         // All HBM-latency loads of the iteration are issued HERE, in one batch, behind the compiler barrier of the blob
         // hand-off: vmcnt retires in order, so an HBM load issued before the (L2-hot) blob load would make the blob wait a
@@ -1491,14 +1565,20 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P_in) {
             kq[2] = k23.x;
             kq[3] = k23.y;
         }
-        Z[lane] = s;
+        if (WIDE) {
+            Z[g * 32 + gl] = s;
+            Z[g * 32 + 16 + gl] = s2;
+        } else {
+            Z[lane] = s;
+        }
         const uint32_t sub = 1 + SW + (uint32_t)gl * R_;
         double cj = 0.0;
         if (gvalid && gl < k) cj = cmut ? cmut[s] : __longlong_as_double((long long)lb[sub + 2]);
 
         // ---------------- zone conflicts with earlier groups (exact: compare member ids)
         LDS_ORDER();
-        const uint64_t confball = __ballot(spec_zone_conflict<E>(Z, s, g, member));
+        const uint64_t confball = WIDE ? __ballot(spec_zone_conflict_wide<E>(Z, s, s2, g, member, member2))
+                                       : __ballot(spec_zone_conflict<E>(Z, s, g, member));
         PHASE(3);
 
         // ---------------- smove_forward!(G, i, ...), gradient, rates
@@ -1574,6 +1654,21 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P_in) {
                 x = xn;
                 t = tp;
             }
+            if (WIDE && member2) {
+                if (lazy_g2) {
+                    x2 = rs2->x;
+                    th2 = rs2->th;
+                    t2 = rs2->t;
+                    I2 = rs2->I;
+                }
+                const double dt = tp - t2;
+                const double xn = x2 + th2 * dt;
+                I2 = I2 + dt * ((x2 + xn) * 0.5);
+                x2 = xn;
+                t2 = tp;
+                sx[16 + gl] = x2;
+                sth[16 + gl] = th2;
+            }
             nmoved = m;
             if (gl == self) th = -th;  // reflect!, :130
         }
@@ -1581,7 +1676,7 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P_in) {
             sx[gl] = x;
             sth[gl] = th;
         }
-        {
+        if (!WIDE) {
             double2* pk2 = reinterpret_cast<double2*>(pk + gl * 4);
             pk2[0] = make_double2(kq[0], kq[1]);
             pk2[1] = make_double2(kq[2], kq[3]);
@@ -1612,9 +1707,17 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P_in) {
             b = cj / 100 + th * gt;
             const double L = LU[rng_off + myoff + 1 + (accept ? (uint32_t)gl : 0u)];
             key = t + dev_poisson_time_L(a, b, L);
-            if ((s >> 6) == blk) pk[s & 63] = key;
+            if (!WIDE && (s >> 6) == blk) pk[s & 63] = key;
         }
         LDS_ORDER();
+        if (WIDE) {  // the patched key blocks go where sx / sth were: all their readers are done
+            double2* pk2 = reinterpret_cast<double2*>(pk + gl * 4);
+            pk2[0] = make_double2(kq[0], kq[1]);
+            pk2[1] = make_double2(kq[2], kq[3]);
+            LDS_ORDER();
+            if (active && (s >> 6) == blk) pk[s & 63] = key;
+            LDS_ORDER();
+        }
         PHASE(5);
         // ---------------- patched minimum of the popped block, and everything this event could expose
         double rowmin, candmin;
@@ -1689,6 +1792,12 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P_in) {
                 rs->th = th;
                 rs->t = t;
                 rs->I = I;
+            }
+            if (WIDE && accept && member2) {
+                rs2->x = x2;
+                rs2->th = th2;
+                rs2->t = t2;
+                rs2->I = I2;
             }
             if (active) {
                 rs->t_old = t;
@@ -1790,6 +1899,16 @@ __global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P_in) {
         hdr->c.ndraw_main = nm0 + dnm;
         hdr->c.status = status;
     }
+}
+
+template <int NE, bool PROF, bool PLAIN = false>
+__global__ __launch_bounds__(64) void zz_local_spec_kernel(ZzRunParams P_in) {
+    zz_local_spec_body<NE, PROF, PLAIN, false>(P_in);
+}
+// 17 <= |S[i]| <= 32 (two zone members per lane): held to 128 registers, i.e. 4 waves per SIMD with the 16 chains per CU the LDS allows
+template <int NE, bool PROF>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void zz_local_spec_wide_kernel(ZzRunParams P_in) {
+    zz_local_spec_body<NE, PROF, false, true>(P_in);
 }
 
 // ------------------------------------------------------------------------------------------ 8 events per iteration
@@ -3918,10 +4037,11 @@ int launch_zz_init(const ZzInitParams& p, void* stream) {
 }
 
 bool zz_spec_supported(uint32_t nblk, uint32_t mmax, uint32_t kmax) {
-    return mmax <= 16 && kmax <= 15 && nblk <= 64 * 8;
+    // (17 <= mmax <= 32: the WIDE instantiation, two zone members per lane)
+    return mmax <= 32 && kmax <= 15 && nblk <= 64 * 8;
 }
 
-int launch_zz_local_spec(const ZzRunParams& p, int64_t nchains, void* stream) {
+int launch_zz_local_spec(const ZzRunParams& p, int64_t nchains, void* stream, const char** kname) {
     const size_t lds = zz_spec_lds_bytes(p.nblk_pad, p.blob_w_pad);
     const int ne = (int)((p.nblk + 63) / 64);
     dim3 grid((unsigned)nchains), block(64);
@@ -3935,6 +4055,17 @@ int launch_zz_local_spec(const ZzRunParams& p, int64_t nchains, void* stream) {
     const bool geom = (p.flags & 0x100) && p.blob_sw == 7 && p.blob_pw == 1 && p.blob_kmax == 5 && p.blob_w_pad == 58;
     const bool spec8 = geom && !p.has_refresh && p.d >= 2048 && p.d <= (int64_t)S8_NBLK * 32 &&
                        !p.force_spec4;  // (pdmp_debug_set_kernel: A/B runs and parity tests of the 4-event kernel)
+    const bool wide = p.blob_sw > 8;  // |S[i]| up to 32: two zone members per lane
+    if (kname) *kname = spec8 ? "zz_local_spec8_kernel" : wide ? "zz_local_spec_kernel<WIDE>" : "zz_local_spec_kernel";
+    if (wide) {
+        const size_t ldsw = zz_spec_wide_lds_bytes(p.nblk_pad, p.blob_w_pad);
+        if (p.dbg) hipLaunchKernelGGL((zz_local_spec_wide_kernel<8, true>), grid, block, ldsw, (hipStream_t)stream, p);
+        else if (ne <= 1) hipLaunchKernelGGL((zz_local_spec_wide_kernel<1, false>), grid, block, ldsw, (hipStream_t)stream, p);
+        else if (ne <= 2) hipLaunchKernelGGL((zz_local_spec_wide_kernel<2, false>), grid, block, ldsw, (hipStream_t)stream, p);
+        else if (ne <= 5) hipLaunchKernelGGL((zz_local_spec_wide_kernel<5, false>), grid, block, ldsw, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((zz_local_spec_wide_kernel<8, false>), grid, block, ldsw, (hipStream_t)stream, p);
+        return (int)hipGetLastError();
+    }
     if (spec8) {
         ZzRunParams q = p;
         q.nblk = (uint32_t)((p.d + 31) / 32);

@@ -56,6 +56,13 @@ class Ensemble:
         """'auto' | 'seq' (one event per iteration) | 'spec4' (4-event kernel where the 8-event one would run); before set_flow."""
         _lib.check(self._L.pdmp_debug_set_kernel(self._h, _lib.DEBUG_KERNELS[name]))
 
+    def kernel_name(self):
+        """Event-loop kernel of the last run (include/pdmp_debug.h: pdmp_debug_last_kernel); '' before the first run."""
+        import ctypes
+        buf = ctypes.create_string_buffer(96)
+        _lib.check(self._L.pdmp_debug_last_kernel(self._h, buf, 96))
+        return buf.value.decode()
+
     def debug_set_logistic_rows(self, row_width):
         """Chains per wavefront of the LDS-resident logistic kernel: -1 default, 0 one chain, 16 / 32 = rows of that many lanes (pdmp_logrows.hip)."""
         _lib.check(self._L.pdmp_debug_set_logistic_rows(self._h, int(row_width)))
