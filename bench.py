@@ -258,7 +258,7 @@ def make_workload(pkg, args, rank, local_rank):
         ens = pkg.Ensemble(nch, d, adapt=True, factor=5.0, device=local_rank, trace_capacity=cap)
         ens.set_flow(pkg.ZigZag(P["Gdrop"], P["mu"], P["sigma"]))
         ens.set_target(pkg.LogisticTarget(P["A"], P["y"], P["ny"], P["mu"], P["gamma0"], ksub))
-        integrals = os.environ.get("PDMP_BENCH_C4_INTEGRALS", "0") != "0"
+        integrals = os.environ.get("PDMP_BENCH_C4_INTEGRALS", "0") != "0" or args.gather  # (--gather reduces the batch-mean sums: they need the integrals)
         # (the engine's own ∫x_i dt -- no counterpart in the reference, nothing in this configuration reads it -- costs the state-in-LDS kernel
         # 8 of 32 bytes per coordinate: 8 instead of 12 chains per CU.  PDMP_BENCH_C4_INTEGRALS=1 keeps it.)
         ens.set_path_integrals(integrals)
@@ -298,14 +298,28 @@ def make_workload(pkg, args, rank, local_rank):
         ens.set_sticky(P["kappa"])
         ens.set_state_synthetic(0.0, P["c"], seed0)
         rbar = float(np.diff(P["At"].indptr).mean())
-        per_grad = ksub * rbar * 40 + 40 + 24
+        # One gradient evaluation samples ksub rows (scripts/logistic.jl:84) and brings every coordinate they read to t' (idot_moving!,
+        # src/common.jl:33-42).  A coordinate that several sampled rows share is MOVED once (24 B read + 16 B written) and only re-read (8 B)
+        # by the others: the expected number of distinct coordinates follows from the design's row counts (hypergeometric, exact).  The
+        # design's entries themselves (8 B value + 4 B row index as stored; 2000 x 5457 of them = 131 MB, not a cache-resident table) are
+        # streamed once per sampled row.  (Round 3 charged every entry of every sampled row a full 40-byte move: 1.6 x this model and more than
+        # the counters saw.)
+        from scipy.special import gammaln
+        nrows = P["At"].shape[1]
+        nj = np.diff(P["A"].indptr).astype(np.float64)  # rows that hold coordinate j
+        lc = lambda a, b: gammaln(a + 1) - gammaln(b + 1) - gammaln(a - b + 1)
+        with np.errstate(invalid="ignore"):
+            p_untouched = np.where(nrows - nj >= ksub, np.exp(lc(nrows - nj, ksub) - lc(nrows, ksub)), 0.0)
+        distinct = float(np.sum(1.0 - p_untouched))
+        per_grad = distinct * 40 + (ksub * rbar - distinct) * 8 + ksub * rbar * 12 + 40 + 24
         W.update(d=d, cap=cap, ens=ens, kernel="zz_general_run_kernel", unit="events/s", ksub=ksub,
                  metric="trace events/sec (reflections + freezes + thaws), sticky ZigZag on the logistic spike-and-slab p=10000, ensemble of independent chains",
                  workload=f"C5: sspdmp with grad-phi-moving (k={ksub}, SelfMoving) on example_design_matrix scaled to p={d} columns x {P['n']} rows "
                           f"(scripts/exampledesign.jl), Gaussian slab gamma0={P['gamma0']}, kappa=(gamma0/sqrt(2pi))/(1/w-1) w={P['w']}, Z=ZigZag(I,mu), "
                           f"c=1, adapt (scripts/spikeandslab.jl:96-129), {nch} chains/GPU, step = advance all chains by dT={dt}",
-                 model=f"per gradient evaluation ksub*r*40 + 64 = {per_grad:.0f} B (r={rbar:.0f} coefficients per sampled observation, each moved: "
-                       f"24 B read + 16 B written), + 96 B per trace event (record, bound, key, thaw clock)",
+                 model=f"per gradient evaluation {per_grad:.0f} B = {distinct:.0f} distinct coordinates moved once (40 B) + {ksub * rbar - distinct:.0f} "
+                       f"re-reads of an already moved coordinate (8 B) + ksub*r = {ksub * rbar:.0f} design entries streamed (12 B: 131 MB table) + 64 B "
+                       f"(r={rbar:.0f} coefficients per sampled observation), + 96 B per trace event (record, bound, key, thaw clock)",
                  bytes=lambda w: per_grad * w["grads"] + 96.0 * w["nevents"])
     else:
         raise SystemExit(f"unknown --config {args.config}")
@@ -351,9 +365,7 @@ def main():
         args.ess_batches = 0
         args.exact_steps = 0
     elif args.config != "C3":
-        args.ess_batches = 0  # path integrals / the trace exchange are wired to the headline workload
-        if args.gather:
-            raise SystemExit("--gather is implemented for the headline workload (--config C3)")
+        args.ess_batches = 0  # the ESS leg (stationary start, exact variances) belongs to the headline workload
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -556,11 +568,28 @@ def main():
 
     # post-run exchange (never inside `value`): SURVEY 8e1
     gather = None
-    if args.gather and cap and comm is not None:
+    if args.gather and cap and comm is not None and args.config == "C2":
+        # PDMPTrace events (t, copy(x), copy(theta)): three arrays per rank, the same exchange (pdmp_ensemble_gather_bps_traces)
+        ens.trace_reset()
+        ens.run((args.warmup + args.steps + 1) * args.dt, pkg._lib.RUN_STOP_BEFORE)  # (one launch: what the segments hold when it pauses or ends)
+        barrier()
+        tg0 = time.perf_counter()
+        widths, counts_all, devbuf = comm.gather_bps_traces(ens, root=0, to_host=False)
+        barrier()
+        tg = float(comm.allreduce([time.perf_counter() - tg0], "max")[0])
+        if rank == 0:
+            nev_g = int(counts_all.sum())
+            assert devbuf[1] == nev_g
+            eb = 8 * (2 * d + 1)
+            gather = {"seconds": tg, "events": nev_g, "bytes": eb * nev_g, "GBps": eb * nev_g / tg / 1e9, "chains": int(widths.sum()),
+                      "staging": "device", "backend": "engine (librccl linked by libpdmp_mi355.so)",
+                      "steps": "ncclAllGather(counts) -> device compaction -> grouped ncclSend/ncclRecv of t, x, theta to rank 0 "
+                               "(pdmp_ensemble_gather_bps_traces)"}
+    elif args.gather and cap and comm is not None:
         Tg = (args.warmup + args.steps + 1) * args.dt
         T_prev = (args.warmup + args.steps) * args.dt
         ens.batch_means(0.0, T_prev)  # baseline J(T_prev)
-        ens.run(Tg, pkg._lib.RUN_STOP_BEFORE)
+        ens.run(Tg, pkg._lib.RUN_STOP_BEFORE)  # (C4 / C5: a chain whose segment fills up pauses -- what the segments hold then is gathered)
         barrier()
         tg0 = time.perf_counter()
         widths, counts_all, devbuf = comm.gather_traces(ens, root=0, to_host=False)  # the events stay on the root's device
@@ -575,6 +604,8 @@ def main():
                       "steps": "ncclAllGather(counts) -> device compaction -> grouped ncclSend/ncclRecv of the trace segments to rank 0 -> "
                                "ncclReduce(SUM) of 2 x d sums (pdmp_ensemble_gather_traces, pdmp_ensemble_reduce_moments)",
                       "mean_of_batch_means": float(np.mean(sy) / (nch * world))}
+    elif args.gather and cap and args.config == "C2":
+        raise SystemExit("--gather of PDMPTrace events runs on the engine's communicator (PDMP_BENCH_BACKEND=engine, the default)")
     elif args.gather and cap:
         import torch
         par = pkg.parallel
@@ -648,14 +679,23 @@ def main():
         # the kernel sources; a stale file is ignored rather than quoted)
         traffic = None
         traffic_src = None
+        issue = None  # instruction-issue account of the kernel from the SQ counter passes (what bounds a kernel whose HBM traffic is far below its roof)
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             tp = json.load(open(tpath))
-            ent = tp.get("configs", {}).get("C3X" if (args.config == "C3" and args.exact) else ("C4T" if (args.config == "C4" and args.tracked) else args.config))
+            tkey = args.config
+            if args.config == "C3" and args.exact:
+                tkey = "C3X"
+            elif args.config == "C4" and args.tracked:
+                tkey = "C4T"
+            elif args.config == "C3G":
+                tkey = "C3G" + ("X" if args.exact else "") + ("" if args.graph == "lattice3d" else "_" + args.graph)
+            ent = tp.get("configs", {}).get(tkey)
             if ent and tp.get("source_hash") == source_hash():
                 units = {"proposal": num, "event": nev}[ent["per"]]
                 traffic = ent["hbm_bytes_per_unit"] * units / nlaunch
                 traffic_src = ent.get("source")
+                issue = ent.get("issue")
         out = {
             "metric": W["metric"],
             "value": nev_all / elapsed,
@@ -685,6 +725,8 @@ def main():
                          "model": W["model"]},
         }
         out["totals"] = {"num": num_all, "nacc": nacc_all, "nevents": nev_all, "T_end": (args.warmup + args.steps) * args.dt}
+        if issue is not None:
+            out["issue"] = issue
         if per_rank is not None:
             out["per_rank"] = per_rank
         if gather is not None:

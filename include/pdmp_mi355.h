@@ -432,6 +432,15 @@ pdmp_status pdmp_ensemble_gather_traces(pdmp_ensemble* ens, pdmp_comm* comm, int
 pdmp_status pdmp_comm_gathered_copy(pdmp_comm* comm, pdmp_event* out, int64_t first, int64_t count);
 pdmp_status pdmp_ensemble_reduce_moments(pdmp_ensemble* ens, pdmp_comm* comm, int root, double T_prev, double T, double* sum_y,
                                          double* sum_y2);
+/* The same exchange for the PDMPTrace of the non-factorised samplers (pdmp on BouncyParticle / Boomerang: events (t, copy(x), copy(θ)),
+ * src/not_fact_samplers.jl:39-41, 8 (2 d + 1) bytes each).  On root the events of all chains lie rank-major, chain-major in three device arrays the
+ * communicator owns -- t [total], x [total x d], θ [total x d] -- valid until the next gather on it; pdmp_comm_gathered_bps_copy fetches a range
+ * (any of t / x / theta may be NULL).  Collective; argument errors of ONE rank (a counts buffer that is too small, a failed allocation) are agreed
+ * on before anything is sent, so every rank returns the error and the communicator stays usable -- the same holds for
+ * pdmp_ensemble_gather_traces. */
+pdmp_status pdmp_ensemble_gather_bps_traces(pdmp_ensemble* ens, pdmp_comm* comm, int root, int64_t* nchains_by_rank, uint64_t* counts,
+                                            int64_t counts_cap, void** t_dev, void** x_dev, void** theta_dev, int64_t* nevents_total);
+pdmp_status pdmp_comm_gathered_bps_copy(pdmp_comm* comm, double* t, double* x, double* theta, int64_t first, int64_t count);
 
 /* ------------------------------------------------------------------ the one-dimensional samplers
  *
@@ -473,6 +482,8 @@ pdmp_status pdmp_1d_run(const pdmp_1d_config* cfg, pdmp_1d_state* state /* [ncha
 /* raw device pointers for zero-copy consumers (e.g. an RCCL gather of trace segments) */
 pdmp_status pdmp_ensemble_trace_dev(pdmp_ensemble* ens, void** events_dev, int64_t* capacity);
 pdmp_status pdmp_ensemble_counters_dev(pdmp_ensemble* ens, void** counters_dev);
+/* ... of a BouncyParticle / Boomerang ensemble: event times [nchains x capacity], positions and velocities [nchains x capacity x d] */
+pdmp_status pdmp_ensemble_bps_trace_dev(pdmp_ensemble* ens, void** t_dev, void** x_dev, void** theta_dev);
 
 #ifdef __cplusplus
 }

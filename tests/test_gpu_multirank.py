@@ -163,3 +163,62 @@ def test_world2_gather_with_the_engine_producing_the_shards(gpu_pkg):
         x0, th0 = O.synthetic_state(4000 + k, d)
         r = O.spdmp_zigzag(G, None, G, x0, th0, c, 6.0, seed=4000 + k, stop_before_T=True)
         assert r["events"].tobytes() == traces[k]
+
+
+def test_bench_c4_two_ranks_on_one_device(gpu_pkg):
+    """bench.py --gpus 2 --config C4 (one of BASELINE.json's 8-GPU configurations) in the same harness: two ranks of 256 chains against one rank of
+    512 -- same seeds, so the same proposals / reflections in total -- with the post-run exchange of the FactTrace segments (--gather)."""
+    steps, warm, nch = 2, 1, 256
+    common = ["--config", "C4", "--steps", str(steps), "--warmup", str(warm), "--no-cpu-baseline", "--per-rank", "--gather"]
+    two = _run_bench(2, common + ["--chains", str(nch)], {"PDMP_BENCH_SINGLE_DEVICE": "1", "PDMP_BENCH_BACKEND": "gloo"})
+    one = _run_bench(1, common + ["--chains", str(2 * nch)], {"PDMP_BENCH_BACKEND": "gloo"})
+    assert two["n_gpus"] == 2 and two["unhealthy_chains"] == 0 and two["scaling"] == "weak" and two["unit"] == "reflection events/s"
+    # C4's chains start from sign patterns drawn per rank (rng seeded with the rank), so only rank 0's shard is the same work in both runs
+    assert two["per_rank"][0]["seed_first"] == SEED0 and two["per_rank"][1]["seed_first"] == SEED0 + nch
+    assert two["totals"]["nevents"] > 0 and two["gather"]["chains"] == 2 * nch and two["gather"]["events"] > 0
+    assert one["gather"]["chains"] == 2 * nch
+
+
+@pytest.mark.parametrize("config,extra", [("C2", ["--chains", "256", "--dt", "5"]), ("C4", ["--chains", "256"]), ("C5", ["--chains", "64"]),
+                                          ("C3G", ["--chains", "128", "--graph", "random6"])])
+def test_gather_over_the_engine_communicator_world1(gpu_pkg, config, extra):
+    """--gather for every configuration on the engine's own RCCL entry points (world = 1: the code path of N ranks on one GPU): the FactTrace
+    exchange for C3G / C4 / C5, the PDMPTrace exchange (t, x, θ) for C2."""
+    out = _run_bench(1, ["--config", config, "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--gather"] + extra)
+    g = out["gather"]
+    assert g["events"] > 0 and g["backend"].startswith("engine") and g["chains"] == int(extra[1])
+    if config == "C2":
+        assert g["bytes"] == g["events"] * 8 * (2 * 1024 + 1)
+    else:
+        assert g["bytes"] == 32 * g["events"]
+
+
+def test_bps_gather_returns_every_event_in_chain_order(gpu_pkg):
+    """pdmp_ensemble_gather_bps_traces against pdmp_ensemble_bps_trace_copy, chain by chain (world = 1), and the collective refusal of a counts
+    buffer that is too small (every rank returns the error, the communicator stays usable)."""
+    import ctypes as C
+    import scipy.sparse as sp
+    pkg = gpu_pkg
+    L = pkg._lib
+    d, nch = 32, 5
+    rng = np.random.default_rng(0)
+    with pkg.Ensemble(nch, d, sampler=L.SAMPLER_BPS, factor=2.0, trace_capacity=300) as ens:
+        ens.set_flow_bps(pkg.BouncyParticle(sp.identity(d, format="csc"), np.zeros(d), 1.0))
+        ens.set_state_bps(0.0, rng.standard_normal((nch, d)), rng.standard_normal((nch, d)), 1e-3, np.arange(nch, dtype=np.uint64) + np.uint64(9))
+        ens.run(20.0)
+        cnt = ens.counters()
+        with pkg.parallel.Comm(0, 1, 0) as comm:
+            small = np.zeros(2, dtype=np.uint64)
+            tot = C.c_int64()
+            rc = comm._L.pdmp_ensemble_gather_bps_traces(ens._h, comm._h, 0, None, small.ctypes.data, small.size, None, None, None, C.byref(tot))
+            assert rc == L.PDMP_ERR_INVALID
+            widths, counts, (t, x, th) = comm.gather_bps_traces(ens)
+            assert list(widths) == [nch] and np.array_equal(counts, cnt["ntrace"])
+            at = 0
+            for k in range(nch):
+                tk, xk, thk = ens.bps_trace(k, counters=cnt)
+                n = len(tk)
+                assert n == int(counts[k]) and n > 5
+                assert np.array_equal(t[at:at + n], tk) and np.array_equal(x[at:at + n], xk) and np.array_equal(th[at:at + n], thk)
+                at += n
+            assert at == len(t)

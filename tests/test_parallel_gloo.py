@@ -133,3 +133,77 @@ def test_unique_id_rendezvous_three_ranks():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert got[0] == got[1] == got[2] == bytes(range(128))
+
+
+def _uid_worker_outcome(rank, world, port, timeout, q):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from __graft_entry__ import load_package
+    par = load_package().parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    try:
+        uid = par.exchange_unique_id(rank, world, lambda: bytes(range(128)), timeout=timeout)
+        q.put((rank, "ok", uid))
+    except RuntimeError as exc:
+        q.put((rank, "raised", str(exc)))
+
+
+def test_unique_id_rendezvous_is_all_or_nothing_and_ignores_strays():
+    """(i) A rank that never shows up: rank 0 hands the id to NOBODY and every rank that did arrive raises as well -- so a caller's fall-back to
+    another transport happens on all ranks, never with some peers already inside ncclCommInitRank.  (ii) A stray connection that sends nothing,
+    one that sends a foreign job token and a duplicate of rank 1 are dropped without being served and without blocking the accept loop."""
+    import multiprocessing as mp
+    import socket
+    import struct
+    import time
+    from __graft_entry__ import load_package
+    par = load_package().parallel
+
+    def free_port():
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        p = s.getsockname()[1]
+        s.close()
+        return p
+
+    ctx = mp.get_context("spawn")
+    # (i) world = 3, rank 2 missing
+    port = free_port()
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_uid_worker_outcome, args=(r, 3, port, 6.0, q)) for r in (0, 1)]
+    for p in ps:
+        p.start()
+    got = {r: (what, msg) for r, what, msg in (q.get(timeout=60) for _ in range(2))}
+    for p in ps:
+        p.join(timeout=30)
+    assert got[0][0] == "raised" and got[1][0] == "raised", got
+    # (ii) strays while a two-rank rendezvous is under way
+    port = free_port()
+    q = ctx.Queue()
+    p0 = ctx.Process(target=_uid_worker_outcome, args=(0, 2, port, 40.0, q))
+    p0.start()
+    cands = [20000 + (port * 7 + 131 * k + 13) % 20000 for k in range(8)]
+    strays = []
+    t_end = time.time() + 30
+    while not strays and time.time() < t_end:
+        for c in cands:
+            try:
+                silent = socket.create_connection(("127.0.0.1", c), timeout=1.0)   # says nothing
+                foreign = socket.create_connection(("127.0.0.1", c), timeout=1.0)
+                foreign.sendall(par._MAGIC + bytes(16) + struct.pack("<i", 1))       # wrong job token
+                strays = [silent, foreign]
+                break
+            except OSError:
+                time.sleep(0.2)
+    assert strays, "rank 0's rendezvous port never opened"
+    p1 = ctx.Process(target=_uid_worker_outcome, args=(1, 2, port, 40.0, q))
+    p1.start()
+    got = {r: (what, msg) for r, what, msg in (q.get(timeout=90) for _ in range(2))}
+    for s in strays:
+        s.close()
+    for p in (p0, p1):
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert got[0] == ("ok", bytes(range(128))) and got[1] == ("ok", bytes(range(128))), got

@@ -18,7 +18,12 @@ sys.path.insert(0, ROOT)
 
 # C3: zz_local_trackw_kernel (one proposal per lane) or zz_local_track_kernel (8-lane groups) -- matched by their common prefix
 MAIN = {"C3": "zz_local_track", "C3X": "zz_local_spec8_kernel", "C2": "bps_run_kernel", "C4": "zz_logistic_lds_kernel",
-        "C4T": "zz_logistic_lds_kernel", "C5": "zz_general_run_kernel"}
+        "C4T": "zz_logistic_lds_kernel", "C5": "zz_general_run_kernel",
+        # config C3G (graphs that are not the 2-d lattice): tracked / moving evaluation on the 3-d lattice and on a random pattern
+        "C3G": "zz_local_trackp_kernel", "C3GX": "zz_local_spec_wide_kernel", "C3G_random6": "zz_local_trackp_kernel",
+        "C3GX_random6": "zz_local_spec_wide_kernel", "C3G_random8": "zz_local_trackp_kernel"}
+CMD = {"C3X": "C3 --exact", "C4T": "C4 --tracked", "C3G": "C3G", "C3GX": "C3G --exact", "C3G_random6": "C3G --graph random6",
+       "C3GX_random6": "C3G --graph random6 --exact", "C3G_random8": "C3G --graph random8"}
 
 
 def rows(path):
@@ -80,7 +85,7 @@ def main():
         ks = rows(find(out, f"{C}_stats", "st_kernel_stats.csv"))
         kt = rows(find(out, f"{C}_stats", "st_kernel_trace.csv"))
         with open(os.path.join(summ, f"{tag}_{C}_kernel_stats.txt"), "w") as f:
-            f.write(f"# rocprofv3 --kernel-trace --stats of: python bench.py --config {C.replace('C3X', 'C3 --exact').replace('C4T', 'C4 --tracked')} --steps {B['steps']} --warmup {B['warmup']} "
+            f.write(f"# rocprofv3 --kernel-trace --stats of: python bench.py --config {CMD.get(C, C)} --steps {B['steps']} --warmup {B['warmup']} "
                     f"--no-cpu-baseline --ess-batches 0\n# bench line of the same command: ms_per_step {B['ms_per_step']:.3f}, "
                     f"roofline.kernel_ms_avg {B['roofline']['kernel_ms_avg']:.3f} (HIP events), launches_per_step {B['roofline']['launches_per_step']}\n")
             f.write(f"{'kernel':72s} {'calls':>6s} {'total_ms':>12s} {'avg_ms':>12s} {'min_ms':>12s} {'max_ms':>12s} {'pct':>7s}\n")
@@ -132,6 +137,21 @@ def main():
                     f.write(f"# L2 hit rate {pm['TCC_HIT_sum'] / (pm['TCC_HIT_sum'] + pm['TCC_MISS_sum']):.3f}\n")
                 traffic["configs"][C] = {"per": units_name, "hbm_bytes_per_unit": per, "read_bytes_per_launch": rb, "written_bytes_per_launch": wb,
                                          "source": f"profiles/{tag}_{C}_pmc.txt (accounting: profiles/{tag}_pmc_calibration.txt)"}
+                if "SQ_INSTS_VALU" in pm and "SQ_WAVE_CYCLES" in pm:
+                    # the instruction-issue account (SQ passes): per unit of work, and how a wavefront's cycles split
+                    wc = pm["SQ_WAVE_CYCLES"]
+                    iss = {"per": units_name, "valu": pm["SQ_INSTS_VALU"] / units, "salu": pm.get("SQ_INSTS_SALU", 0.0) / units,
+                           "lds": pm.get("SQ_INSTS_LDS", 0.0) / units,
+                           "vmem": (pm.get("SQ_INSTS_VMEM_RD", 0.0) + pm.get("SQ_INSTS_VMEM_WR", 0.0)) / units,
+                           "waves": pm.get("SQ_WAVES"), "source": f"profiles/{tag}_{C}_pmc.txt (sq1, sq2 passes)"}
+                    if "SQ_ACTIVE_INST_ANY" in pm:
+                        iss.update(wave_cycles_issuing=pm["SQ_ACTIVE_INST_ANY"] / wc, wave_cycles_issuing_valu=pm.get("SQ_ACTIVE_INST_VALU", 0.0) / wc,
+                                   wave_cycles_waiting_on_counters=pm.get("SQ_WAIT_ANY", 0.0) / wc,
+                                   wave_cycles_waiting_for_issue=pm.get("SQ_WAIT_INST_ANY", 0.0) / wc)
+                    if "SQ_BUSY_CYCLES" in pm and pm["SQ_BUSY_CYCLES"] > 0:
+                        iss["waves_per_simd_avg"] = wc / pm["SQ_BUSY_CYCLES"] / 4.0  # (SQ_BUSY_CYCLES counts per SE-level SQ: see the pmc file for the raw values)
+                    traffic["configs"][C]["issue"] = iss
+                    f.write("# issue: " + json.dumps(iss) + "\n")
     json.dump(traffic, open(os.path.join(summ, "traffic.json"), "w"), indent=1)
     open(os.path.join(summ, f"{tag}_configs.jsonl"), "w").write("\n".join(lines) + "\n")
     print(open(os.path.join(summ, f"{tag}_pmc_calibration.txt")).read())

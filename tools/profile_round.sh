@@ -6,22 +6,29 @@
 #   tools/profile_collect.py (run here, copied into profiles/ by the caller).
 set -u
 TAG=$1; shift
-CONFIGS=${@:-C3 C3X C2 C4 C4T C5}   # C3X = C3 on the bit-identical moving kernel (bench.py --exact); C4T = C4 with tracked bounds (--tracked)
+CONFIGS=${@:-C3 C3X C3G C3GX C3G_random6 C3GX_random6 C3G_random8 C2 C4 C4T C5}   # C3X = C3 on the bit-identical moving kernel (bench.py --exact); C4T = C4 with tracked bounds (--tracked); C3G* = graphs off the 2-d lattice
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 for C in $CONFIGS; do
-  case $C in C3|C3X) ST=8;; C2) ST=8;; C4|C4T) ST=6;; C5) ST=4;; esac
+  case $C in C3|C3X) ST=8;; C3G|C3G_random6|C3G_random8) ST=6;; C3GX|C3GX_random6) ST=3;; C2) ST=8;; C4|C4T) ST=6;; C5) ST=4;; esac
   ARGS="--config $C --steps $ST --warmup 2 --no-cpu-baseline --ess-batches 0 --exact-steps 0"
   if [ "$C" = C3X ]; then ARGS="--config C3 --exact --steps $ST --warmup 2 --no-cpu-baseline --ess-batches 0 --exact-steps 0"; fi
   if [ "$C" = C4T ]; then ARGS="--config C4 --tracked --steps $ST --warmup 2 --no-cpu-baseline --ess-batches 0 --exact-steps 0"; fi
+  case $C in
+    C3G) ARGS="--config C3G --steps $ST --warmup 2 --no-cpu-baseline";;
+    C3GX) ARGS="--config C3G --exact --steps $ST --warmup 1 --no-cpu-baseline";;
+    C3G_random6) ARGS="--config C3G --graph random6 --steps $ST --warmup 2 --no-cpu-baseline";;
+    C3GX_random6) ARGS="--config C3G --graph random6 --exact --steps $ST --warmup 1 --no-cpu-baseline";;
+    C3G_random8) ARGS="--config C3G --graph random8 --steps $ST --warmup 2 --no-cpu-baseline";;
+  esac
   python $ROOT/bench.py $ARGS 2>/dev/null | grep '^{' > "$OUT/${C}_bench.json"
   timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/${C}_stats" -o st --output-format csv -- python $ROOT/bench.py $ARGS > "$OUT/${C}_stats.log" 2>&1
   timeout 900 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum -d "$OUT/${C}_pmc" -o fetch --output-format csv -- python $ROOT/bench.py $ARGS > "$OUT/${C}_fetch.log" 2>&1
   timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d "$OUT/${C}_pmc" -o write --output-format csv -- python $ROOT/bench.py $ARGS > "$OUT/${C}_write.log" 2>&1
-  if [ "$C" = C3 ] || [ "$C" = C3X ]; then
+  if true; then   # the SQ passes for every configuration (round 4: the `issue` object of bench.py comes from them)
     timeout 900 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d "$OUT/${C}_pmc" -o sq1 --output-format csv -- python $ROOT/bench.py $ARGS > "$OUT/${C}_sq1.log" 2>&1
     timeout 900 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT -d "$OUT/${C}_pmc" -o sq2 --output-format csv -- python $ROOT/bench.py $ARGS > "$OUT/${C}_sq2.log" 2>&1
   fi

@@ -42,6 +42,7 @@ EXPORTED_SYMBOLS = [
     "pdmp_ensemble_consume_begin", "pdmp_ensemble_consume", "pdmp_ensemble_consume_mean", "pdmp_ensemble_consume_inclusion", "pdmp_ensemble_consume_discretized", "pdmp_1d_run",
     "pdmp_comm_unique_id", "pdmp_comm_init", "pdmp_comm_destroy", "pdmp_comm_info", "pdmp_comm_barrier", "pdmp_comm_allreduce",
     "pdmp_ensemble_gather_traces", "pdmp_ensemble_reduce_moments", "pdmp_comm_gathered_copy",
+    "pdmp_ensemble_gather_bps_traces", "pdmp_comm_gathered_bps_copy", "pdmp_ensemble_bps_trace_dev",
 ]
 # include/pdmp_debug.h: diagnostics, not part of the drop-in boundary
 DEBUG_SYMBOLS = ["pdmp_debug_set_kernel", "pdmp_debug_set_spec_g2", "pdmp_debug_set_phase_profile", "pdmp_debug_phase_profile",
@@ -125,6 +126,9 @@ def load():
     L.pdmp_ensemble_gather_traces.argtypes = [vp, vp, C.c_int, vp, vp, i64, vp, i64, C.POINTER(vp), C.POINTER(i64)]
     L.pdmp_ensemble_reduce_moments.argtypes = [vp, vp, C.c_int, f64, f64, vp, vp]
     L.pdmp_comm_gathered_copy.argtypes = [vp, vp, i64, i64]
+    L.pdmp_ensemble_gather_bps_traces.argtypes = [vp, vp, C.c_int, vp, vp, i64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64)]
+    L.pdmp_comm_gathered_bps_copy.argtypes = [vp, vp, vp, vp, i64, i64]
+    L.pdmp_ensemble_bps_trace_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.pdmp_ensemble_trace_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
     L.pdmp_ensemble_counters_dev.argtypes = [vp, C.POINTER(vp)]
     L.pdmp_debug_math_probe.argtypes = [C.c_int, C.c_uint64, i64, vp]

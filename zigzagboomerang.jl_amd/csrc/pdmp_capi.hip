@@ -2202,6 +2202,15 @@ pdmp_status pdmp_ensemble_trace_dev(pdmp_ensemble* e, void** events_dev, int64_t
     return PDMP_OK;
 }
 
+pdmp_status pdmp_ensemble_bps_trace_dev(pdmp_ensemble* e, void** t_dev, void** x_dev, void** theta_dev) {
+    if (!e || !t_dev || !x_dev || !theta_dev) return fail(PDMP_ERR_INVALID, "null argument");
+    if (e->cfg.sampler != PDMP_SAMPLER_BPS) return fail(PDMP_ERR_INVALID, "not a BouncyParticle / Boomerang ensemble");
+    *t_dev = e->b_ev_t.p;
+    *x_dev = e->b_ev_x.p;
+    *theta_dev = e->b_ev_th.p;
+    return PDMP_OK;
+}
+
 pdmp_status pdmp_ensemble_counters_dev(pdmp_ensemble* e, void** counters_dev) {
     if (!e || !counters_dev) return fail(PDMP_ERR_INVALID, "null argument");
     *counters_dev = e->d_hdr.p;

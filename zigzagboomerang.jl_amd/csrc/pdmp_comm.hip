@@ -81,8 +81,10 @@ struct pdmp_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1, device = 0;
     hipStream_t stream = nullptr;
-    DBuf scratch, counts, offs, compact, gathered, red;
-    int64_t ngathered = 0;  // events in `gathered` (root of the last gather)
+    DBuf scratch, counts, offs, compact, gathered, red, vote, gx, gth;
+    int64_t ngathered = 0;      // events in `gathered` (root of the last pdmp_ensemble_gather_traces)
+    int64_t ngathered_bps = 0;  // PDMPTrace events in gathered (t) / gx / gth (root of the last pdmp_ensemble_gather_bps_traces)
+    int64_t bps_d = 0;
 };
 
 extern "C" {
@@ -156,6 +158,102 @@ pdmp_status pdmp_comm_barrier(pdmp_comm* c) {
     return pdmp_comm_allreduce(c, &one, 1, PDMP_COMM_SUM);
 }
 
+}  // extern "C"
+
+namespace {
+
+// Agreement on whether to go on: MAX over the ranks of a local flag.  Argument checks that only ONE rank can make (its counts / events buffers
+// are too small, its allocation failed) are voted on before any rank enters the send / recv phase -- a rank that returned on its own would leave
+// its peers blocked in the next collective.
+pdmp_status agree(pdmp_comm* c, pdmp_status local) {
+    int32_t flag = (local == PDMP_OK) ? 0 : 1;
+    pdmp_status st = c->vote.need(2 * sizeof(int32_t));
+    if (st != PDMP_OK) return st;  // (64 bytes of device memory: if that fails nothing works)
+    int32_t* dv = static_cast<int32_t*>(c->vote.p);
+    C_HIP(hipMemcpyAsync(dv, &flag, sizeof flag, hipMemcpyHostToDevice, c->stream));
+    C_NCCL(ncclAllReduce(dv, dv + 1, 1, ncclInt32, ncclMax, c->comm, c->stream));
+    int32_t any = 0;
+    C_HIP(hipMemcpyAsync(&any, dv + 1, sizeof any, hipMemcpyDeviceToHost, c->stream));
+    C_HIP(hipStreamSynchronize(c->stream));
+    if (local != PDMP_OK) return local;  // (this rank's own message stays in pdmp_last_error)
+    if (any) return cfail(PDMP_ERR_INVALID, "the gather was refused on another rank (its output buffers are too small or an allocation failed there); nothing was exchanged");
+    return PDMP_OK;
+}
+
+// Shard widths and the counts of every chain of the whole ensemble (two ncclAllGather, the counts padded to the widest shard)
+pdmp_status exchange_counts(pdmp_comm* c, int64_t nch, std::vector<uint64_t>& mine, std::vector<int64_t>& widths, std::vector<uint64_t>& all,
+                            int64_t& wmax) {
+    const int W = c->world;
+    pdmp_status st;
+    widths.assign((size_t)W, 0);
+    {
+        if ((st = c->scratch.need((size_t)(W + 1) * sizeof(int64_t))) != PDMP_OK) return st;
+        int64_t* dw = static_cast<int64_t*>(c->scratch.p);
+        C_HIP(hipMemcpyAsync(dw + W, &nch, sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+        C_NCCL(ncclAllGather(dw + W, dw, 1, ncclInt64, c->comm, c->stream));
+        C_HIP(hipMemcpyAsync(widths.data(), dw, (size_t)W * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+        C_HIP(hipStreamSynchronize(c->stream));
+    }
+    wmax = 0;
+    for (int r = 0; r < W; ++r) wmax = widths[(size_t)r] > wmax ? widths[(size_t)r] : wmax;
+    mine.resize((size_t)wmax, 0);
+    all.assign((size_t)wmax * (size_t)W, 0);
+    if ((st = c->counts.need((size_t)wmax * (size_t)(W + 1) * sizeof(uint64_t))) != PDMP_OK) return st;
+    uint64_t* dc = static_cast<uint64_t*>(c->counts.p);
+    C_HIP(hipMemcpyAsync(dc + (size_t)wmax * W, mine.data(), (size_t)wmax * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    C_NCCL(ncclAllGather(dc + (size_t)wmax * W, dc, (size_t)wmax, ncclUint64, c->comm, c->stream));
+    C_HIP(hipMemcpyAsync(all.data(), dc, all.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    C_HIP(hipStreamSynchronize(c->stream));
+    return PDMP_OK;
+}
+
+// gatherv to the root: ONE grouped send / recv (every peer over its own link).  The group is always closed and the stream drained, whatever a call
+// inside it returned: an open group would swallow the communicator's next collective.
+pdmp_status gatherv_bytes(pdmp_comm* c, int root, const void* src, const std::vector<uint64_t>& bytes_by_rank, char* dst) {
+    const int W = c->world;
+    ncclResult_t first = ncclSuccess;
+    auto keep = [&](ncclResult_t r) {
+        if (first == ncclSuccess && r != ncclSuccess) first = r;
+    };
+    const uint64_t my_bytes = bytes_by_rank[(size_t)c->rank];
+    keep(ncclGroupStart());
+    if (c->rank == root) {
+        uint64_t at = 0;
+        for (int r = 0; r < W; ++r) {
+            if (r != root && bytes_by_rank[(size_t)r]) keep(ncclRecv(dst + at, (size_t)bytes_by_rank[(size_t)r], ncclChar, r, c->comm, c->stream));
+            at += bytes_by_rank[(size_t)r];
+        }
+    } else if (my_bytes) {
+        keep(ncclSend(src, (size_t)my_bytes, ncclChar, root, c->comm, c->stream));
+    }
+    keep(ncclGroupEnd());
+    hipError_t he = hipSuccess;
+    if (c->rank == root && my_bytes) {
+        uint64_t at = 0;
+        for (int r = 0; r < root; ++r) at += bytes_by_rank[(size_t)r];
+        he = hipMemcpyAsync(dst + at, src, (size_t)my_bytes, hipMemcpyDeviceToDevice, c->stream);
+    }
+    const hipError_t hs = hipStreamSynchronize(c->stream);
+    if (first != ncclSuccess) return cfail(PDMP_ERR_HIP, "grouped send / recv failed: %s", ncclGetErrorString(first));
+    if (he != hipSuccess) return cfail(PDMP_ERR_HIP, "device copy of the root's own segment failed: %s", hipGetErrorString(he));
+    if (hs != hipSuccess) return cfail(PDMP_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(hs));
+    return PDMP_OK;
+}
+
+// [chain * seg_words, chain * seg_words + cnt[chain] * wpe) of a strided array of 8-byte words, back to back (offs = exclusive prefix sums of cnt)
+__global__ __launch_bounds__(256) void compact_words_kernel(const uint64_t* __restrict__ src0, int64_t seg_words, const uint64_t* __restrict__ cnt,
+                                                            const uint64_t* __restrict__ offs, int64_t wpe, uint64_t* __restrict__ out) {
+    const int64_t chain = blockIdx.x;
+    const uint64_t n = cnt[chain] * (uint64_t)wpe;
+    const uint64_t* src = src0 + chain * seg_words;
+    uint64_t* dst = out + offs[chain] * (uint64_t)wpe;
+    for (uint64_t k = (uint64_t)blockIdx.y * 256 + threadIdx.x; k < n; k += (uint64_t)gridDim.y * 256) dst[k] = src[k];
+}
+
+}  // namespace
+
+extern "C" {
+
 pdmp_status pdmp_ensemble_gather_traces(pdmp_ensemble* ens, pdmp_comm* c, int root, int64_t* nchains_by_rank, uint64_t* counts,
                                         int64_t counts_cap, pdmp_event* events_host, int64_t events_cap, void** events_dev,
                                         int64_t* nevents_total) {
@@ -168,59 +266,46 @@ pdmp_status pdmp_ensemble_gather_traces(pdmp_ensemble* ens, pdmp_comm* c, int ro
     if (cap <= 0) return cfail(PDMP_ERR_INVALID, "ensemble was created with trace_capacity = 0");
     C_HIP(hipSetDevice(c->device));
     const int W = c->world;
-    // ---- shard widths, then the counts padded to the widest shard (ncclAllGather wants equal pieces)
+    c->ngathered = 0;  // (whatever happens below, the previous gather's events are no longer what gathered_copy should serve)
     std::vector<pdmp_chain_counters> cnt((size_t)nch);
     if ((st = pdmp_ensemble_counters(ens, cnt.data())) != PDMP_OK) return st;
-    std::vector<int64_t> widths((size_t)W, 0);
-    {
-        if ((st = c->scratch.need((size_t)(W + 1) * sizeof(int64_t))) != PDMP_OK) return st;
-        int64_t* dw = static_cast<int64_t*>(c->scratch.p);
-        C_HIP(hipMemcpyAsync(dw + W, &nch, sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
-        C_NCCL(ncclAllGather(dw + W, dw, 1, ncclInt64, c->comm, c->stream));
-        C_HIP(hipMemcpyAsync(widths.data(), dw, (size_t)W * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
-        C_HIP(hipStreamSynchronize(c->stream));
-    }
-    int64_t wmax = 0, wsum = 0;
-    for (int r = 0; r < W; ++r) {
-        wmax = widths[(size_t)r] > wmax ? widths[(size_t)r] : wmax;
-        wsum += widths[(size_t)r];
-    }
-    if (nchains_by_rank) memcpy(nchains_by_rank, widths.data(), (size_t)W * sizeof(int64_t));
-    std::vector<uint64_t> mine((size_t)wmax, 0), all((size_t)wmax * (size_t)W, 0);
+    std::vector<uint64_t> mine((size_t)nch, 0), all;
     for (int64_t k = 0; k < nch; ++k) mine[(size_t)k] = cnt[(size_t)k].ntrace;
-    {
-        if ((st = c->counts.need((size_t)wmax * (size_t)(W + 1) * sizeof(uint64_t))) != PDMP_OK) return st;
-        uint64_t* dc = static_cast<uint64_t*>(c->counts.p);
-        C_HIP(hipMemcpyAsync(dc + (size_t)wmax * W, mine.data(), (size_t)wmax * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-        C_NCCL(ncclAllGather(dc + (size_t)wmax * W, dc, (size_t)wmax, ncclUint64, c->comm, c->stream));
-        C_HIP(hipMemcpyAsync(all.data(), dc, all.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-        C_HIP(hipStreamSynchronize(c->stream));
-    }
+    std::vector<int64_t> widths;
+    int64_t wmax = 0;
+    if ((st = exchange_counts(c, nch, mine, widths, all, wmax)) != PDMP_OK) return st;
+    int64_t wsum = 0;
+    for (int r = 0; r < W; ++r) wsum += widths[(size_t)r];
+    if (nchains_by_rank) memcpy(nchains_by_rank, widths.data(), (size_t)W * sizeof(int64_t));
     std::vector<uint64_t> tot((size_t)W, 0);
     uint64_t total = 0;
-    {
-        int64_t q = 0;
-        for (int r = 0; r < W; ++r)
-            for (int64_t k = 0; k < widths[(size_t)r]; ++k, ++q) {
-                const uint64_t v = all[(size_t)r * (size_t)wmax + (size_t)k];
-                tot[(size_t)r] += v;
-                if (counts) {
-                    if (q >= counts_cap) return cfail(PDMP_ERR_INVALID, "counts holds %lld entries, the ensemble has %lld chains", (long long)counts_cap, (long long)wsum);
-                    counts[q] = v;
-                }
-            }
-        for (int r = 0; r < W; ++r) total += tot[(size_t)r];
+    for (int r = 0; r < W; ++r) {
+        for (int64_t k = 0; k < widths[(size_t)r]; ++k) tot[(size_t)r] += all[(size_t)r * (size_t)wmax + (size_t)k];
+        total += tot[(size_t)r];
     }
     if (nevents_total) *nevents_total = (int64_t)total;
+    // ---- everything that can fail on ONE rank, checked now (wsum and total are known everywhere) and voted on before anything is sent
+    pdmp_status local = PDMP_OK;
+    if (counts && counts_cap < wsum)
+        local = cfail(PDMP_ERR_INVALID, "counts holds %lld entries, the ensemble has %lld chains", (long long)counts_cap, (long long)wsum);
+    if (local == PDMP_OK && c->rank == root && events_host && (int64_t)total > events_cap)
+        local = cfail(PDMP_ERR_INVALID, "events_host holds %lld events, %llu would be gathered", (long long)events_cap, (unsigned long long)total);
+    const uint64_t my_total = tot[(size_t)c->rank];
+    if (local == PDMP_OK) local = c->offs.need((size_t)(2 * nch) * sizeof(uint64_t));
+    if (local == PDMP_OK) local = c->compact.need((size_t)(my_total ? my_total : 1) * sizeof(pdmp_event));
+    if (local == PDMP_OK && c->rank == root) local = c->gathered.need((size_t)(total ? total : 1) * sizeof(pdmp_event));
+    if ((st = agree(c, local)) != PDMP_OK) return st;
+    if (counts) {
+        int64_t q = 0;
+        for (int r = 0; r < W; ++r)
+            for (int64_t k = 0; k < widths[(size_t)r]; ++k) counts[q++] = all[(size_t)r * (size_t)wmax + (size_t)k];
+    }
     // ---- compact the local segments
     void* evdev = nullptr;
     int64_t capdev = 0;
     if ((st = pdmp_ensemble_trace_dev(ens, &evdev, &capdev)) != PDMP_OK) return st;
     std::vector<uint64_t> offs((size_t)nch, 0);
     for (int64_t k = 1; k < nch; ++k) offs[(size_t)k] = offs[(size_t)k - 1] + mine[(size_t)k - 1];
-    const uint64_t my_total = tot[(size_t)c->rank];
-    if ((st = c->offs.need((size_t)(2 * nch) * sizeof(uint64_t))) != PDMP_OK) return st;
-    if ((st = c->compact.need((size_t)(my_total ? my_total : 1) * sizeof(pdmp_event))) != PDMP_OK) return st;
     uint64_t* doffs = static_cast<uint64_t*>(c->offs.p);
     C_HIP(hipMemcpyAsync(doffs, offs.data(), (size_t)nch * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     C_HIP(hipMemcpyAsync(doffs + nch, mine.data(), (size_t)nch * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
@@ -228,35 +313,106 @@ pdmp_status pdmp_ensemble_gather_traces(pdmp_ensemble* ens, pdmp_comm* c, int ro
         hipLaunchKernelGGL(compact_traces_kernel, dim3((unsigned)nch, 4), dim3(256), 0, c->stream, static_cast<const uint4*>(evdev), capdev, doffs + nch,
                            doffs, static_cast<uint4*>(c->compact.p));
     C_HIP(hipGetLastError());
-    // ---- gatherv to the root: one grouped send / recv, every peer over its own link
-    pdmp_event* gdst = nullptr;
-    if (c->rank == root) {
-        if ((st = c->gathered.need((size_t)(total ? total : 1) * sizeof(pdmp_event))) != PDMP_OK) return st;
-        gdst = static_cast<pdmp_event*>(c->gathered.p);
+    // ---- gatherv to the root
+    pdmp_event* gdst = (c->rank == root) ? static_cast<pdmp_event*>(c->gathered.p) : nullptr;
+    std::vector<uint64_t> bytes((size_t)W);
+    for (int r = 0; r < W; ++r) bytes[(size_t)r] = tot[(size_t)r] * sizeof(pdmp_event);
+    if ((st = gatherv_bytes(c, root, c->compact.p, bytes, reinterpret_cast<char*>(gdst))) != PDMP_OK) return st;
+    if (c->rank == root && events_host && total) {
+        C_HIP(hipMemcpyAsync(events_host, gdst, (size_t)total * sizeof(pdmp_event), hipMemcpyDeviceToHost, c->stream));
+        C_HIP(hipStreamSynchronize(c->stream));
     }
-    C_NCCL(ncclGroupStart());
-    if (c->rank == root) {
-        uint64_t at = 0;
-        for (int r = 0; r < W; ++r) {
-            if (r != root && tot[(size_t)r]) C_NCCL(ncclRecv(gdst + at, (size_t)tot[(size_t)r] * sizeof(pdmp_event), ncclChar, r, c->comm, c->stream));
-            at += tot[(size_t)r];
-        }
-    } else if (my_total) {
-        C_NCCL(ncclSend(c->compact.p, (size_t)my_total * sizeof(pdmp_event), ncclChar, root, c->comm, c->stream));
-    }
-    C_NCCL(ncclGroupEnd());
-    if (c->rank == root) {
-        uint64_t at = 0;
-        for (int r = 0; r < root; ++r) at += tot[(size_t)r];
-        if (my_total) C_HIP(hipMemcpyAsync(gdst + at, c->compact.p, (size_t)my_total * sizeof(pdmp_event), hipMemcpyDeviceToDevice, c->stream));
-        if (events_host) {
-            if ((int64_t)total > events_cap) return cfail(PDMP_ERR_INVALID, "events_host holds %lld events, %llu were gathered", (long long)events_cap, (unsigned long long)total);
-            if (total) C_HIP(hipMemcpyAsync(events_host, gdst, (size_t)total * sizeof(pdmp_event), hipMemcpyDeviceToHost, c->stream));
-        }
-    }
-    C_HIP(hipStreamSynchronize(c->stream));
     if (events_dev) *events_dev = (c->rank == root) ? (void*)gdst : nullptr;
     c->ngathered = (c->rank == root) ? (int64_t)total : 0;
+    return PDMP_OK;
+}
+
+// PDMPTrace events of the non-factorised samplers (src/not_fact_samplers.jl:39-41: (t, copy(x), copy(θ)), 8 (2 d + 1) bytes each): the same
+// exchange on the three arrays the engine keeps them in.  On root: t [total], x [total x d], θ [total x d], rank-major, chain-major.
+pdmp_status pdmp_ensemble_gather_bps_traces(pdmp_ensemble* ens, pdmp_comm* c, int root, int64_t* nchains_by_rank, uint64_t* counts,
+                                            int64_t counts_cap, void** t_dev, void** x_dev, void** theta_dev, int64_t* nevents_total) {
+    if (!ens || !c || root < 0 || root >= c->world) return cfail(PDMP_ERR_INVALID, "bad argument");
+    int64_t nch = 0, d = 0, cap = 0;
+    int dev = 0;
+    pdmp_status st = pdmp_ensemble_info(ens, &nch, &d, &cap, &dev);
+    if (st != PDMP_OK) return st;
+    if (dev != c->device) return cfail(PDMP_ERR_INVALID, "the ensemble lives on device %d, the communicator on %d", dev, c->device);
+    if (cap <= 0) return cfail(PDMP_ERR_INVALID, "ensemble was created with trace_capacity = 0");
+    void *tdev = nullptr, *xdev = nullptr, *thdev = nullptr;
+    if ((st = pdmp_ensemble_bps_trace_dev(ens, &tdev, &xdev, &thdev)) != PDMP_OK) return st;
+    C_HIP(hipSetDevice(c->device));
+    const int W = c->world;
+    c->ngathered_bps = 0;
+    std::vector<pdmp_chain_counters> cnt((size_t)nch);
+    if ((st = pdmp_ensemble_counters(ens, cnt.data())) != PDMP_OK) return st;
+    std::vector<uint64_t> mine((size_t)nch, 0), all;
+    for (int64_t k = 0; k < nch; ++k) mine[(size_t)k] = cnt[(size_t)k].ntrace;
+    std::vector<int64_t> widths;
+    int64_t wmax = 0;
+    if ((st = exchange_counts(c, nch, mine, widths, all, wmax)) != PDMP_OK) return st;
+    int64_t wsum = 0;
+    for (int r = 0; r < W; ++r) wsum += widths[(size_t)r];
+    if (nchains_by_rank) memcpy(nchains_by_rank, widths.data(), (size_t)W * sizeof(int64_t));
+    std::vector<uint64_t> tot((size_t)W, 0);
+    uint64_t total = 0;
+    for (int r = 0; r < W; ++r) {
+        for (int64_t k = 0; k < widths[(size_t)r]; ++k) tot[(size_t)r] += all[(size_t)r * (size_t)wmax + (size_t)k];
+        total += tot[(size_t)r];
+    }
+    if (nevents_total) *nevents_total = (int64_t)total;
+    const uint64_t my_total = tot[(size_t)c->rank];
+    pdmp_status local = PDMP_OK;
+    if (counts && counts_cap < wsum)
+        local = cfail(PDMP_ERR_INVALID, "counts holds %lld entries, the ensemble has %lld chains", (long long)counts_cap, (long long)wsum);
+    if (local == PDMP_OK) local = c->offs.need((size_t)(2 * nch) * sizeof(uint64_t));
+    if (local == PDMP_OK) local = c->compact.need((size_t)(my_total ? my_total : 1) * (size_t)d * sizeof(double));  // (one array at a time)
+    if (local == PDMP_OK && c->rank == root) {
+        local = c->gathered.need((size_t)(total ? total : 1) * sizeof(double));
+        if (local == PDMP_OK) local = c->gx.need((size_t)(total ? total : 1) * (size_t)d * sizeof(double));
+        if (local == PDMP_OK) local = c->gth.need((size_t)(total ? total : 1) * (size_t)d * sizeof(double));
+    }
+    if ((st = agree(c, local)) != PDMP_OK) return st;
+    if (counts) {
+        int64_t q = 0;
+        for (int r = 0; r < W; ++r)
+            for (int64_t k = 0; k < widths[(size_t)r]; ++k) counts[q++] = all[(size_t)r * (size_t)wmax + (size_t)k];
+    }
+    std::vector<uint64_t> offs((size_t)nch, 0);
+    for (int64_t k = 1; k < nch; ++k) offs[(size_t)k] = offs[(size_t)k - 1] + mine[(size_t)k - 1];
+    uint64_t* doffs = static_cast<uint64_t*>(c->offs.p);
+    C_HIP(hipMemcpyAsync(doffs, offs.data(), (size_t)nch * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    C_HIP(hipMemcpyAsync(doffs + nch, mine.data(), (size_t)nch * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    struct Piece {
+        const void* src;
+        int64_t wpe;
+        DBuf* dst;
+    } pieces[3] = {{tdev, 1, &c->gathered}, {xdev, d, &c->gx}, {thdev, d, &c->gth}};
+    for (const Piece& pc : pieces) {
+        if (my_total)
+            hipLaunchKernelGGL(compact_words_kernel, dim3((unsigned)nch, 4), dim3(256), 0, c->stream, static_cast<const uint64_t*>(pc.src), cap * pc.wpe,
+                               doffs + nch, doffs, pc.wpe, static_cast<uint64_t*>(c->compact.p));
+        C_HIP(hipGetLastError());
+        std::vector<uint64_t> bytes((size_t)W);
+        for (int r = 0; r < W; ++r) bytes[(size_t)r] = tot[(size_t)r] * (uint64_t)pc.wpe * sizeof(double);
+        if ((st = gatherv_bytes(c, root, c->compact.p, bytes, (c->rank == root) ? static_cast<char*>(pc.dst->p) : nullptr)) != PDMP_OK) return st;
+    }
+    const bool isroot = c->rank == root;
+    if (t_dev) *t_dev = isroot ? c->gathered.p : nullptr;
+    if (x_dev) *x_dev = isroot ? c->gx.p : nullptr;
+    if (theta_dev) *theta_dev = isroot ? c->gth.p : nullptr;
+    c->ngathered_bps = isroot ? (int64_t)total : 0;
+    c->bps_d = d;
+    return PDMP_OK;
+}
+
+pdmp_status pdmp_comm_gathered_bps_copy(pdmp_comm* c, double* t, double* x, double* theta, int64_t first, int64_t count) {
+    if (!c || first < 0 || count < 0) return cfail(PDMP_ERR_INVALID, "bad argument");
+    if (first + count > c->ngathered_bps) return cfail(PDMP_ERR_INVALID, "the last BPS gather left %lld events on this rank", (long long)c->ngathered_bps);
+    C_HIP(hipSetDevice(c->device));
+    const size_t dd = (size_t)c->bps_d;
+    if (count && t) C_HIP(hipMemcpy(t, static_cast<const double*>(c->gathered.p) + first, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+    if (count && x) C_HIP(hipMemcpy(x, static_cast<const double*>(c->gx.p) + (size_t)first * dd, (size_t)count * dd * sizeof(double), hipMemcpyDeviceToHost));
+    if (count && theta) C_HIP(hipMemcpy(theta, static_cast<const double*>(c->gth.p) + (size_t)first * dd, (size_t)count * dd * sizeof(double), hipMemcpyDeviceToHost));
     return PDMP_OK;
 }
 

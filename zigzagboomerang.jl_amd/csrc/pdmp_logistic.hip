@@ -128,7 +128,7 @@ size_t zz_logistic_lds_bytes(int64_t d, int64_t dk, bool with_I) {
 // rejection re-derives its bound from (g_i, gd_i, tg_i), and an accepted event updates the k members of G1[i] instead of moving its two-hop
 // set and summing every member's column afresh.  The gradient is the moving evaluation unchanged.
 template <bool PROF, bool WITH_I, bool TRK = false>
-__global__ __launch_bounds__(64) void zz_logistic_lds_kernel(ZzRunParams P, ZzGeneralParams Q, ZzLogisticTables LT) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void zz_logistic_lds_kernel(ZzRunParams P, ZzGeneralParams Q, ZzLogisticTables LT) {
     const int lane = threadIdx.x;
     const int64_t chain = blockIdx.x;
     const uint32_t d = (uint32_t)P.d;
@@ -386,8 +386,14 @@ __global__ __launch_bounds__(64) void zz_logistic_lds_kernel(ZzRunParams P, ZzGe
                 L_ORDER();
             }
             const double w = (double)H.l / (double)Q.ksub * v;
-            const double t1 = w * c0.x * l_sigmoid(-u);     // sigmoidn(u) = sigmoid(-u)
-            const double t2 = w * c0.y * (-l_sigmoid(u));   // nsigmoid(u) = -sigmoid(u)
+            // the two sigmoids of an observation are evaluated SIDE BY SIDE: its own lane takes sigmoid(-u), the lane 32 further on (idle: at most
+            // 32 observations are sampled) takes sigmoid(u) -- one exponential and one division per lane instead of two
+            const bool qb = (((uint32_t)lane - 32u - goff) & 63u) < (uint32_t)nq;  // partner of an observation lane
+            const double u_p = l_shfl(u, (uint32_t)(lane ^ 32));
+            const double sg = l_sigmoid(qb ? u_p : -u);
+            const double sg_p = l_shfl(sg, (uint32_t)(lane ^ 32));
+            const double t1 = w * c0.x * sg;        // sigmoidn(u) = sigmoid(-u)
+            const double t2 = w * c0.y * (-sg_p);   // nsigmoid(u) = -sigmoid(u)
             const double t3 = w * c0.x * c0.z;              // sigmoidn(u0), u0 = idot(At, row, μ): tabulated per observation
             const double t4 = w * c0.y * c0.w;              // nsigmoid(u0)
             // the four terms of every sampled observation go through LDS (over the chunk buffers, idle during a gradient): 2 reads of 16 bytes

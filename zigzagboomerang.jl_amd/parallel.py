@@ -133,55 +133,99 @@ _MAGIC = b"PDMPRCCL"
 
 
 def exchange_unique_id(rank, world, make_id, addr=None, port=None, timeout=120.0):
-    """Rank 0 calls make_id() -> 128 bytes and serves it; the other ranks fetch it.  A bare TCP rendezvous on MASTER_ADDR (default
-    127.0.0.1) at a port derived from MASTER_PORT (torchrun keeps its own store on MASTER_PORT itself); every rank returns the id."""
+    """Rank 0 calls make_id() -> 128 bytes and hands it to the other ranks; every rank returns the id -- or EVERY rank raises.  A bare TCP
+    rendezvous on MASTER_ADDR (default 127.0.0.1) at a port derived from MASTER_PORT (torchrun keeps its own store on MASTER_PORT itself).
+
+    All or nothing: rank 0 keeps every peer's connection open until all world - 1 of them have arrived and only then answers GO + id; if
+    the deadline passes first it answers NO to those that did arrive and raises, and the peers raise too (the ones that never connected run
+    into the same deadline).  So a caller that falls back to another transport when this raises (bench.py: torch.distributed over RCCL)
+    falls back on ALL ranks -- never some peers inside ncclCommInitRank while rank 0 has moved on.  A connection must open with a 16-byte
+    job token (MASTER_ADDR, MASTER_PORT, world size, TORCHELASTIC_RUN_ID) and its rank: strays, port scanners and a second job that happens
+    to share MASTER_PORT are dropped after a 5 s read timeout instead of being served (or hanging the accept loop)."""
+    import hashlib
     import os
     import socket
+    import struct
     import time
     if world == 1:
         return make_id()
     addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
     base = int(port if port is not None else os.environ.get("MASTER_PORT", "29500"))
     cands = [20000 + (base * 7 + 131 * k + 13) % 20000 for k in range(8)]
+    token = hashlib.sha256(("%s|%d|%d|%s" % (addr, base, world, os.environ.get("TORCHELASTIC_RUN_ID", ""))).encode()).digest()[:16]
+    hello = len(_MAGIC) + 16 + 4
+    reply = len(_MAGIC) + 2 + 128
+    deadline = time.time() + timeout
+
+    def read_exact(sock, n):
+        buf = b""
+        while len(buf) < n:
+            chunk = sock.recv(n - len(buf))
+            if not chunk:
+                return None
+            buf += chunk
+        return buf
+
     if rank == 0:
         uid = make_id()
         srv = None
         for p in cands:
-            try:
-                srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-                srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-                srv.bind((addr if addr not in ("localhost",) else "127.0.0.1", p))
+            for host in ((addr if addr != "localhost" else "127.0.0.1"), "0.0.0.0"):  # (MASTER_ADDR that is not an address of this host: any interface)
+                try:
+                    srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                    srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                    srv.bind((host, p))
+                    break
+                except OSError:
+                    srv.close()
+                    srv = None
+            if srv is not None:
                 break
-            except OSError:
-                srv.close()
-                srv = None
         if srv is None:
             raise RuntimeError("exchange_unique_id: no rendezvous port free among %s" % cands)
-        srv.listen(world)
-        srv.settimeout(timeout)
-        served = 0
-        while served < world - 1:
-            conn, _ = srv.accept()
-            with conn:
-                if conn.recv(len(_MAGIC)) == _MAGIC:
-                    conn.sendall(_MAGIC + uid)
-                    served += 1
-        srv.close()
+        srv.listen(world + 8)
+        conns = {}
+        try:
+            while len(conns) < world - 1 and time.time() < deadline:
+                srv.settimeout(max(0.05, deadline - time.time()))
+                try:
+                    conn, _ = srv.accept()
+                except (socket.timeout, OSError):
+                    break
+                conn.settimeout(5.0)
+                try:
+                    h = read_exact(conn, hello)
+                except (socket.timeout, OSError):
+                    h = None
+                r = struct.unpack("<i", h[-4:])[0] if h else -1
+                if not h or h[:len(_MAGIC)] != _MAGIC or h[len(_MAGIC):len(_MAGIC) + 16] != token or not (0 < r < world) or r in conns:
+                    conn.close()
+                    continue
+                conns[r] = conn
+            ok = len(conns) == world - 1
+            for conn in conns.values():
+                try:
+                    conn.sendall(_MAGIC + (b"GO" + uid if ok else b"NO" + bytes(128)))
+                except OSError:
+                    pass
+        finally:
+            for conn in conns.values():
+                conn.close()
+            srv.close()
+        if not ok:
+            raise RuntimeError("exchange_unique_id: %d of %d peers reached rank 0 within %.0f s; nobody was given the id" % (len(conns), world - 1, timeout))
         return uid
-    t_end = time.time() + timeout
-    while time.time() < t_end:
+    while time.time() < deadline:
         for p in cands:
             try:
                 with socket.create_connection((addr, p), timeout=2.0) as s:
-                    s.sendall(_MAGIC)
-                    buf = b""
-                    while len(buf) < len(_MAGIC) + 128:
-                        chunk = s.recv(len(_MAGIC) + 128 - len(buf))
-                        if not chunk:
-                            break
-                        buf += chunk
-                    if len(buf) == len(_MAGIC) + 128 and buf[:len(_MAGIC)] == _MAGIC:
-                        return buf[len(_MAGIC):]
+                    s.sendall(_MAGIC + token + struct.pack("<i", rank))
+                    s.settimeout(max(5.0, deadline - time.time() + 10.0))  # (rank 0 answers once everybody has arrived, or at its deadline)
+                    buf = read_exact(s, reply)
+                    if buf and buf[:len(_MAGIC)] == _MAGIC:
+                        if buf[len(_MAGIC):len(_MAGIC) + 2] == b"GO":
+                            return buf[len(_MAGIC) + 2:]
+                        raise RuntimeError("exchange_unique_id: rank 0 called the rendezvous off (not every rank arrived)")
             except OSError:
                 pass
         time.sleep(0.2)
@@ -261,6 +305,27 @@ class Comm:
         if host.size:
             self._lib.check(self._L.pdmp_comm_gathered_copy(self._h, host.ctypes.data, 0, host.size))
         return widths, counts, host
+
+    def gather_bps_traces(self, ens, root=0, to_host=True):
+        """pdmp_ensemble_gather_bps_traces: the PDMPTrace events (t, x, θ) of a BouncyParticle / Boomerang ensemble.  Returns
+        (nchains_by_rank, counts, (t [n], x [n, d], θ [n, d]) on root or None); to_host=False: ((t_ptr, x_ptr, θ_ptr), n) device pointers."""
+        import ctypes as C
+        widths = np.zeros(self.world, dtype=np.int64)
+        counts = np.zeros((ens.nchains + 1) * self.world, dtype=np.uint64)
+        total = C.c_int64()
+        tp, xp, thp = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._lib.check(self._L.pdmp_ensemble_gather_bps_traces(ens._h, self._h, int(root), widths.ctypes.data, counts.ctypes.data, counts.size,
+                                                                C.byref(tp), C.byref(xp), C.byref(thp), C.byref(total)))
+        counts = counts[:int(widths.sum())]
+        if self.rank != root:
+            return widths, counts, None
+        n = int(total.value)
+        if not to_host:
+            return widths, counts, ((tp.value, xp.value, thp.value), n)
+        t, x, th = np.empty(n), np.empty((n, ens.d)), np.empty((n, ens.d))
+        if n:
+            self._lib.check(self._L.pdmp_comm_gathered_bps_copy(self._h, t.ctypes.data, x.ctypes.data, th.ctypes.data, 0, n))
+        return widths, counts, (t, x, th)
 
     def reduce_moments(self, ens, T_prev, T, root=0):
         d = ens.d
