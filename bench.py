@@ -260,7 +260,8 @@ def make_workload(pkg, args, rank, local_rank):
         ens.set_target(pkg.LogisticTarget(P["A"], P["y"], P["ny"], P["mu"], P["gamma0"], ksub))
         integrals = os.environ.get("PDMP_BENCH_C4_INTEGRALS", "0") != "0" or args.gather  # (--gather reduces the batch-mean sums: they need the integrals)
         # (the engine's own ∫x_i dt -- no counterpart in the reference, nothing in this configuration reads it -- costs the state-in-LDS kernel
-        # 8 of 32 bytes per coordinate: 8 instead of 12 chains per CU.  PDMP_BENCH_C4_INTEGRALS=1 keeps it.)
+        # 8 of 32 bytes per coordinate: 8 instead of 13 chains per CU.  PDMP_BENCH_C4_INTEGRALS=1 keeps it; the line carries the other variant as
+        # `with_path_integrals`, measured in the same process after the timed region.)
         ens.set_path_integrals(integrals)
         if getattr(args, "tracked", False):
             ens.set_gradient_tracking(True)
@@ -510,6 +511,40 @@ def main():
                  "unhealthy_chains": int(np.count_nonzero(xc1["status"] != pkg._lib.CHAIN_OK)),
                  "note": "kernel time from HIP events of this process, after the timed region; same seeds, step and trace handling"}
 
+    # C4: the same workload with the engine's path integrals kept (8 instead of 13 chains per CU), beside the headline -- figures of different
+    # rounds are comparable through it (rounds 1-2 kept the integrals)
+    with_integrals = None
+    if rank == 0 and args.config == "C4" and not args.gather and os.environ.get("PDMP_BENCH_C4_INTEGRALS", "0") == "0" and args.exact_steps > 0:
+        a2 = argparse.Namespace(**vars(args))
+        a2.gather = True  # (keeps the integrals: see make_workload)
+        W2 = make_workload(pkg, a2, rank, local_rank)
+        e2 = W2["ens"]
+        n2 = args.warmup + min(args.steps, 4)
+        ims, c0 = [], None
+        for k in range(n2):
+            T2 = (k + 1) * args.dt
+            ms2 = 0.0
+            while True:
+                e2.run(T2, pkg._lib.RUN_STOP_BEFORE, sync=False)
+                ms2 += e2.last_run_ms()
+                full = bool(np.any(e2.counters()["status"] == pkg._lib.CHAIN_TRACE_FULL)) if W2["cap"] else False
+                if W2["cap"]:
+                    e2.trace_reset()
+                if not full:
+                    break
+            ims.append(ms2)
+            if k == args.warmup - 1:
+                c0 = e2.counters()
+        c1 = e2.counters()
+        e2.close()
+        secs = float(np.sum(ims[args.warmup:])) * 1e-3
+        base0 = {f: (int(c0[f].sum()) if c0 is not None else 0) for f in ("num", "nacc", "nevents")}
+        w2 = {f: int(c1[f].sum()) - base0[f] for f in ("num", "nacc", "nevents")}
+        ach2 = W2["bytes"](w2) / secs / 1e9
+        with_integrals = {"ms_per_step": 1e3 * secs / (n2 - args.warmup), "value": w2["nevents"] / secs, "unit": W2["unit"],
+                          "roofline_frac": ach2 / HBM_PEAK_GBS, "steps": n2 - args.warmup,
+                          "note": "pdmp_ensemble_set_path_integrals(1): 18.7 instead of 11.9 KB of LDS per chain, 8 instead of 13 chains per CU"}
+
     # ESS/s.  A fresh ensemble of the same shape is started IN STATIONARITY -- x0 ~ N(0, inv(Gamma)) exactly (DCT of the lattice,
     # problems.gmrf_stationary_sample), theta0 uniform on {+-1} -- and run for B batches of length b on the timed kernel; after every batch
     # the device returns the path integrals J_i of every chain at 32 probe coordinates (pdmp_ensemble_path_integrals).  With the exact mean 0
@@ -735,6 +770,8 @@ def main():
             out["ess"] = ess
         if exact is not None:
             out["exact"] = exact
+        if with_integrals is not None:
+            out["with_path_integrals"] = with_integrals
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, G, c) if args.config in ("C3", "C3G") else cpu_baseline_config(pkg, args.config)
         print(json.dumps(out), flush=True)

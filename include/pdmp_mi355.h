@@ -246,7 +246,7 @@ pdmp_status pdmp_ensemble_ess_end(pdmp_ensemble* ens, double* sum_y, double* sum
 /*
  * The engine keeps ∫ x_i dt per chain and coordinate next to the state (what batch_means / ess_* / path_integrals read; the reference has no
  * such thing).  enable = 0 drops it: those calls then return PDMP_ERR_INVALID, and the kernels that hold a chain's state on chip (small d:
- * the subsampled logistic target, pdmp_logistic.hip) fit 10 chains per CU instead of 8.  Default: kept.  Call before set_state.
+ * the subsampled logistic target, pdmp_logistic.hip) fit 13 chains per CU instead of 8 (config C4, d = 442: 11.9 against 18.7 KB of LDS per chain; measured 105 against 133 ms per step).  Default: kept.  Call before set_state.
  */
 pdmp_status pdmp_ensemble_set_path_integrals(pdmp_ensemble* ens, int enable);
 
@@ -381,9 +381,11 @@ pdmp_status pdmp_ensemble_bps_final_state(pdmp_ensemble* ens, int64_t chain_firs
  *   consume_mean(chain_first, n, ...)    mean [n x d] and the last event time T of each chain (the reference's scale 1/(2T));
  *   consume_inclusion(chain_first, n, ...)  inclusion_prob [n x d] (:161-178: time with x_i ≠ 0 before or after an event of i, over T);
  *   consume_discretized(chain, k_first, k_count, out, npoints, grid_dev)
- *                                        rows k_first .. of chain's grid positions [k_count x d]; *npoints = number of grid times the
- *                                        reference would emit so far (those before the chain's last event; at least t0); *grid_dev = the
- *                                        whole device array, for consumers that stay on the device.  Any of the three may be NULL.
+ *                                        rows k_first .. of chain's grid positions [k_count x d] (row k belongs to time t0 + k grid_dt; row 0 is
+ *                                        x0); *npoints = number of grid times the reference would emit so far (those before the chain's last
+ *                                        event; at least t0) -- NOT clamped: a value above grid_points means the grid of consume_begin was too
+ *                                        short and the later rows were dropped; *grid_dev = the whole device array, for consumers that stay on the
+ *                                        device.  Any of the three may be NULL.
  * Time-ordered traces of piecewise-linear paths only: ZigZag flow without refresh clock (spdmp, pdmp, sspdmp).  Values are those of
  * zigzagboomerang.jl_amd/trace.py (discretize: bitwise; mean: the same sums scaled once instead of term by term).
  */

@@ -54,9 +54,9 @@ def test_discretize_and_mean_on_the_device(gpu_pkg, tracked):
             tr = traces[k]
             assert len(tr.events) > 10000 and T[k] == tr.events["t"][-1]
             grid, X = pkg.trace.discretize(tr, dt)
-            got = ens.consume_discretized(k)
+            gt, got = ens.consume_discretized(k)
             assert got.shape == X.shape and len(grid) > 20
-            assert np.array_equal(got, X)                       # bit for bit
+            assert np.array_equal(got, X) and np.array_equal(gt, grid)   # bit for bit (times and positions)
             ref = pkg.trace.mean(tr)
             assert np.allclose(m[k], ref, rtol=1e-12, atol=1e-15)
         # a later slice extends both (the cursors persist; points flushed earlier are re-emitted with the same values)
@@ -69,7 +69,7 @@ def test_discretize_and_mean_on_the_device(gpu_pkg, tracked):
         m, T = ens.consume_mean()
         for k in range(2):
             grid, X = pkg.trace.discretize(traces[k], 0.9)
-            assert np.array_equal(ens.consume_discretized(k), X) and len(grid) > 100
+            assert np.array_equal(ens.consume_discretized(k)[1], X) and len(grid) > 100
             assert np.allclose(m[k], pkg.trace.mean(traces[k]), rtol=1e-12, atol=1e-15)
 
 
@@ -86,7 +86,7 @@ def test_consumers_on_sticky_traces_and_refusals(gpu_pkg):
         for k in range(2):
             assert np.sum(traces[k].events["theta"] == 0.0) > 20  # freezes in the trace
             grid, X = pkg.trace.discretize(traces[k], 0.5)
-            assert np.array_equal(ens.consume_discretized(k), X)
+            assert np.array_equal(ens.consume_discretized(k)[1], X)
             assert np.allclose(m[k], pkg.trace.mean(traces[k]), rtol=1e-12, atol=1e-15)
         p, Tp = ens.consume_inclusion()
         for k in range(2):  # inclusion_prob(Ξ), src/trace.jl:161-178: what a sticky run is for
@@ -109,3 +109,31 @@ def test_consumers_on_sticky_traces_and_refusals(gpu_pkg):
         ens.run(0.5, L.RUN_STOP_BEFORE)
         with pytest.raises(L.PdmpError):
             ens.consume_begin(0.5, 10)  # ... and before the first run
+
+
+def test_discretized_first_row_without_events_and_a_grid_that_is_too_short(gpu_pkg):
+    """collect(discretize(Ξ, dt)) starts with t0 => x0 (src/trace.jl:106-110) also when the chain has produced no event yet; a run that goes past the
+    grid given to consume_begin is reported (the unclamped point count), not silently truncated."""
+    pkg = gpu_pkg
+    G = pkg.problems.gmrf_precision(16)
+    d = 256
+    rng = np.random.default_rng(0)
+    x0 = rng.standard_normal((2, d))
+    th0 = rng.choice([-1.0, 1.0], (2, d))
+    with pkg.Ensemble(2, d, trace_capacity=4000) as ens:
+        ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
+        ens.set_target(pkg.GaussianTarget(G))
+        ens.set_state(0.0, x0, th0, pkg.problems.column_norms(G), np.array([1, 2], dtype=np.uint64))
+        ens.consume_begin(0.25, 8)
+        gt, X = ens.consume_discretized(1)          # nothing has run
+        assert np.array_equal(gt, [0.0]) and np.array_equal(X, x0[1:2])
+        ens.run(1.0, pkg._lib.RUN_STOP_BEFORE)
+        ens.consume()
+        gt, X = ens.consume_discretized(0)
+        assert np.array_equal(gt, [0.0, 0.25, 0.5, 0.75]), gt
+        assert np.array_equal(X[0], x0[0])
+        ens.trace_reset()
+        ens.run(6.0, pkg._lib.RUN_STOP_BEFORE)       # 7 * 0.25 = 1.75 < 6
+        ens.consume()
+        with pytest.raises(ValueError, match="consume_begin was given 8 points"):
+            ens.consume_discretized(0)

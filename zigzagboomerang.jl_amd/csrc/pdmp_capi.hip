@@ -1683,7 +1683,8 @@ pdmp_status pdmp_ensemble_consume_begin(pdmp_ensemble* e, double grid_dt, int64_
         if ((st = e->d_cgrid.alloc((size_t)(n * grid_points * d))) != PDMP_OK) return st;
         HIP_TRY(hipMemsetAsync(e->d_cgrid.p, 0, (size_t)(n * grid_points * d) * sizeof(double), e->stream));
     }
-    int rc = pdmp::launch_consume_init(e->d_rec.p, e->track ? 128 : 64, d, n, e->t0_state, e->d_ccur.p, e->d_cmeta.p, e->stream);
+    int rc = pdmp::launch_consume_init(e->d_rec.p, e->track ? 128 : 64, d, n, e->t0_state, e->d_ccur.p, e->d_cmeta.p,
+                                       grid_points > 0 ? e->d_cgrid.p : nullptr, grid_points, e->stream);
     if (rc != 0) return fail(PDMP_ERR_HIP, "consume_init launch failed: %s", hipGetErrorString((hipError_t)rc));
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->consuming = true;
@@ -1760,8 +1761,10 @@ pdmp_status pdmp_ensemble_consume_discretized(pdmp_ensemble* e, int64_t chain, i
         HIP_TRY(hipMemcpy(mh.data(), e->d_cmeta.p + (size_t)chain * pdmp::consume_meta_bytes(), mh.size(), hipMemcpyDeviceToHost));
         double tl;
         memcpy(&tl, mh.data() + 8, sizeof tl);
-        int64_t np = 0;
-        while (np < e->cons_K && e->t0_state + e->cons_dt * (double)np < tl) ++np;
+        // NOT clamped to the grid: a value above grid_points tells the caller that the grid was too short for the run (rows beyond it do not exist)
+        int64_t np = (int64_t)floor((tl - e->t0_state) / e->cons_dt);
+        np = np > 1 ? np - 1 : 0;
+        while (e->t0_state + e->cons_dt * (double)np < tl) ++np;
         *npoints = np > 0 ? np : 1;
     }
     if (grid_dev) *grid_dev = e->d_cgrid.p;

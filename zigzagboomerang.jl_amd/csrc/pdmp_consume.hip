@@ -53,7 +53,7 @@ struct ConsumeMeta {
 };
 
 __global__ __launch_bounds__(256) void consume_init_kernel(const ZzRec* rec0, int64_t rec_stride, int64_t d, int64_t nchains, double t0,
-                                                           ConsumeCursor* cur, ConsumeMeta* meta) {
+                                                           ConsumeCursor* cur, ConsumeMeta* meta, double* grid, int64_t K) {
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (k < nchains) {
         ConsumeMeta m;
@@ -71,6 +71,8 @@ __global__ __launch_bounds__(256) void consume_init_kernel(const ZzRec* rec0, in
     c.y = 0.0;
     c.z = 0.0;
     cur[k] = c;
+    // the first element of collect(discretize(Ξ, dt)) is t0 => x0 whatever follows (src/trace.jl:106-110): also for a chain without an event
+    if (grid && K > 0) grid[(k / d) * K * d + (k % d)] = r->x;
 }
 
 // grid point k of coordinate i: the closed form from the cursor (events with t <= g applied: src/trace.jl:111-121)
@@ -191,10 +193,11 @@ int launch_consume_inclusion(int64_t d, int64_t chain_first, int64_t n, const vo
 size_t consume_cursor_bytes() { return sizeof(ConsumeCursor); }
 size_t consume_meta_bytes() { return sizeof(ConsumeMeta); }
 
-int launch_consume_init(const ZzRec* rec, int64_t rec_stride, int64_t d, int64_t nchains, double t0, void* cur, void* meta, void* stream) {
+int launch_consume_init(const ZzRec* rec, int64_t rec_stride, int64_t d, int64_t nchains, double t0, void* cur, void* meta, double* grid, int64_t K,
+                        void* stream) {
     const int64_t n = nchains * d;
     hipLaunchKernelGGL(consume_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rec, rec_stride, d, nchains, t0,
-                       static_cast<ConsumeCursor*>(cur), static_cast<ConsumeMeta*>(meta));
+                       static_cast<ConsumeCursor*>(cur), static_cast<ConsumeMeta*>(meta), grid, K);
     return (int)hipGetLastError();
 }
 int launch_consume_events(const pdmp_event* ev, int64_t cap, const DevChain* hdr, int64_t d, int64_t nchains, void* cur, void* meta, double* grid,

@@ -372,7 +372,8 @@ size_t zz_local_lds_bytes(uint32_t nblk_pad, uint32_t blob_w_pad);
 // pdmp_consume.hip
 size_t consume_cursor_bytes();
 size_t consume_meta_bytes();
-int launch_consume_init(const ZzRec* rec, int64_t rec_stride, int64_t d, int64_t nchains, double t0, void* cur, void* meta, void* stream);
+int launch_consume_init(const ZzRec* rec, int64_t rec_stride, int64_t d, int64_t nchains, double t0, void* cur, void* meta, double* grid, int64_t K,
+                        void* stream);
 int launch_consume_events(const pdmp_event* ev, int64_t cap, const DevChain* hdr, int64_t d, int64_t nchains, void* cur, void* meta, double* grid,
                           int64_t K, double t0, double dt, void* stream);
 int launch_consume_flush(int64_t d, int64_t nchains, const void* cur, const void* meta, double* grid, int64_t K, double t0, double dt, void* stream);

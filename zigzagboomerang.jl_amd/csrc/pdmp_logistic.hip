@@ -11,7 +11,7 @@
 //     observation (its <= 6 regressors with their coefficients, y, m−y and the two control-variate constants: scripts/logistic.jl:86-93),
 //     the design's column lists, the flow's (member, entry) tables -- plus the bound (t_old, a, b) of the popped coordinate (one record read
 //     per proposal, requested before the tables are walked) and the fire-and-forget stores of new bounds, accept counts and events.
-// One chain per wavefront, one wavefront per workgroup (no barriers); 8 chains per CU by LDS (18.7 KB each; 10 when the engine's own path
+// One chain per wavefront, one wavefront per workgroup (no barriers); 8 chains per CU by LDS at d = 442 (18.7 KB each; 13 -- 11.9 KB each, and 128 registers -- when the engine's own path
 // integrals ∫x_i dt are switched off, pdmp_ensemble_set_path_integrals).  With so few waves per SIMD nothing hides a wave's own latency, so
 // the iteration is laid out as a short dependent chain:
 //   * all of the iteration's random numbers in ONE lane-parallel Philox evaluation and ONE logarithm, taken while the header load is in

@@ -228,10 +228,12 @@ class Ensemble:
         c = _f64(c).reshape(self.d)
         seeds = np.ascontiguousarray(seeds, dtype=np.uint64).reshape(self.nchains)
         _lib.check(self._L.pdmp_ensemble_set_state(self._h, float(t0), _ptr(x0), _ptr(theta0), _ptr(c), _ptr(seeds)))
+        self.t0 = float(t0)
 
     def set_state_synthetic(self, t0, c, seed0):
         c = _f64(c).reshape(self.d)
         _lib.check(self._L.pdmp_ensemble_set_state_synthetic(self._h, float(t0), _ptr(c), int(seed0)))
+        self.t0 = float(t0)
 
     # ---- running
     def run(self, T, flags=_lib.RUN_REFERENCE_TAIL, stream=None, sync=True):
@@ -298,6 +300,7 @@ class Ensemble:
     # ---- trace consumers on the device (pdmp_ensemble_consume_*)
     def consume_begin(self, grid_dt=0.0, grid_points=0):
         _lib.check(self._L.pdmp_ensemble_consume_begin(self._h, float(grid_dt), int(grid_points)))
+        self._grid = (float(grid_dt), int(grid_points))
 
     def consume(self):
         _lib.check(self._L.pdmp_ensemble_consume(self._h))
@@ -319,14 +322,18 @@ class Ensemble:
         return p, T
 
     def consume_discretized(self, chain, k_first=0, k_count=None):
-        """(grid times, positions [npoints x d]) of collect(discretize(Ξ, dt)) for one chain (src/trace.jl:94-125)."""
+        """(grid times [npoints], positions [npoints x d]) of collect(discretize(Ξ, dt)) for one chain (src/trace.jl:94-125); the first row is
+        t0 => x0.  Raises if the run went past the grid given to consume_begin (the later points were dropped on the device)."""
         npts = C.c_int64()
         _lib.check(self._L.pdmp_ensemble_consume_discretized(self._h, int(chain), 0, 0, None, C.byref(npts), None))
+        dt, K = self._grid
+        if int(npts.value) > K:
+            raise ValueError("consume_discretized: the chain's trace reaches grid point %d, consume_begin was given %d points" % (int(npts.value), K))
         k_count = int(npts.value) - k_first if k_count is None else int(k_count)
         out = np.empty((max(k_count, 0), self.d))
         if k_count > 0:
             _lib.check(self._L.pdmp_ensemble_consume_discretized(self._h, int(chain), int(k_first), k_count, _ptr(out), None, None))
-        return out
+        return self.t0 + dt * (k_first + np.arange(max(k_count, 0))), out
 
     def set_path_integrals(self, enable=True):
         """Keep ∫x_i dt next to the state (default) or not (pdmp_ensemble_set_path_integrals); before set_state."""
