@@ -18,6 +18,7 @@ from __graft_entry__ import load_package  # noqa: E402
 
 pkg = load_package()
 P = pkg.problems
+OUT = HERE  # where the fixtures are written (tests/test_oracle_crosscheck_fixtures.py points it at a scratch directory)
 
 
 def hx(a):
@@ -35,7 +36,7 @@ def main():
     g = np.load(os.path.join(HERE, "golden.npz"))
     for name, G, scale in (("d8", P.maintest_precision(8), 0.9), ("grid8", P.gmrf_precision(8), 1.0)):
         ev = g[f"{name}_events"]
-        with open(os.path.join(HERE, f"crosscheck_spdmp_{name}.txt"), "w") as f:
+        with open(os.path.join(OUT, f"crosscheck_spdmp_{name}.txt"), "w") as f:
             f.write("sampler spdmp\nseed 1234\nT %s\nscale %s\n" % (hx([50.0]), hx([scale])))
             write_matrix(f, "Gamma", G)
             f.write("x0 %s\ntheta0 %s\nc %s\n" % (hx(g[f"{name}_x0"]), hx(g[f"{name}_th0"]), hx(g[f"{name}_c"])))
@@ -49,7 +50,7 @@ def main():
     x0, th0 = rng.standard_normal(8), rng.standard_normal(8)
     r = O.pdmp_bps(G, None, x0, th0, 1.1, 20.0, lambda_ref=0.5, seed=77, ev_cap=5000, mass_L=sp.csc_matrix(Lc))
     assert r["status"] == 0
-    with open(os.path.join(HERE, "crosscheck_bps_d8.txt"), "w") as f:
+    with open(os.path.join(OUT, "crosscheck_bps_d8.txt"), "w") as f:
         f.write("sampler bps\nseed 77\nT %s\nlambda_ref %s\nrho %s\nc %s\n" % (hx([20.0]), hx([0.5]), hx([0.0]), hx([1.1])))
         write_matrix(f, "Gamma", G)
         write_matrix(f, "L", Lc)
@@ -59,7 +60,7 @@ def main():
             f.write("%s %s %s\n" % (hx([r["t_ev"][k]]), hx(r["x_ev"][k]), hx(r["theta_ev"][k])))
     # sticky 1-d, test/sticky.jl:7-36 parameters (golden.npz: sticky1d_events)
     ev = g["sticky1d_events"]
-    with open(os.path.join(HERE, "crosscheck_sspdmp_1d.txt"), "w") as f:
+    with open(os.path.join(OUT, "crosscheck_sspdmp_1d.txt"), "w") as f:
         f.write("sampler sspdmp\nseed 5\nT %s\n" % hx([200.0]))
         f.write("sigma2 %s\nmu %s\nkappa %s\nc %s\nx0 %s\ntheta0 %s\n" % (hx([0.5]), hx([0.9]), hx([1.5]), hx([20.0]), hx([1.0]), hx([0.8])))
         f.write("num %d\nacc %d\nevents %d\n" % (int(g["sticky1d_counts"][0]), int(g["sticky1d_counts"][1]), len(ev)))
@@ -77,7 +78,7 @@ def write_1d():
                                  ("boomerang1d", dict(flow="boomerang", boomerang=(1.1, 1.2, 0.5), noise=0.1), 1.41, 0.5, 10.0)):
         r = O.pdmp_1d(mu, s2, x0, th0, 200.0, c, seed=3, **kw)
         assert r["status"] == 0 and len(r["events"]) > 50
-        with open(os.path.join(HERE, f"crosscheck_{name}.txt"), "w") as f:
+        with open(os.path.join(OUT, f"crosscheck_{name}.txt"), "w") as f:
             f.write("sampler %s\nseed 3\nT %s\nmu %s\nsigma2 %s\nnoise %s\n" % (name, hx([200.0]), hx([mu]), hx([s2]), hx([kw["noise"]])))
             if name == "boomerang1d":
                 b = kw["boomerang"]
@@ -108,7 +109,7 @@ def write_more():
     sigma = 1.0 / np.sqrt(Gf.diagonal())  # FactBoomerang(Γ, μ, λ) sets σ = (Vector(diag(Γ))).^(-0.5), src/types.jl:79
     r = O.spdmp_zigzag(Gf, np.zeros(d), G, x0, th0, c, 30.0, seed=21, lambda_ref=0.3, sigma=sigma, factboomerang=True)
     assert r["status"] == 0 and r["nrefresh"] > 3
-    with open(os.path.join(HERE, "crosscheck_factboomerang_d8.txt"), "w") as f:
+    with open(os.path.join(OUT, "crosscheck_factboomerang_d8.txt"), "w") as f:
         f.write("sampler factboomerang\nseed 21\nT %s\nscale %s\nlambda_ref %s\n" % (hx([30.0]), hx([1.2]), hx([0.3])))
         write_matrix(f, "Gamma", G)
         f.write("x0 %s\ntheta0 %s\nc %s\n" % (hx(x0), hx(th0), hx(c)))
@@ -117,7 +118,7 @@ def write_more():
     x0, th0 = rng.standard_normal(d), rng.choice([-1.0, 1.0], d)
     r = O.spdmp_zigzag(G, np.zeros(d), G, x0, th0, 1.5 * c, 40.0, seed=22, lambda_ref=0.4)
     assert r["status"] == 0 and r["nrefresh"] > 5
-    with open(os.path.join(HERE, "crosscheck_zigzag_refresh_d8.txt"), "w") as f:
+    with open(os.path.join(OUT, "crosscheck_zigzag_refresh_d8.txt"), "w") as f:
         f.write("sampler zigzag_refresh\nseed 22\nT %s\nscale %s\nlambda_ref %s\n" % (hx([40.0]), hx([1.0]), hx([0.4])))
         write_matrix(f, "Gamma", G)
         f.write("x0 %s\ntheta0 %s\nc %s\n" % (hx(x0), hx(th0), hx(1.5 * c)))
@@ -129,7 +130,7 @@ def write_more():
     cl = 0.6 * c
     r = O.spdmp_zigzag(G, np.zeros(d), G, x0, th0, cl, 25.0, seed=23, local_bound=True)
     assert r["status"] == 0 and len(r["events"]) > 50
-    with open(os.path.join(HERE, "crosscheck_localbound_d8.txt"), "w") as f:
+    with open(os.path.join(OUT, "crosscheck_localbound_d8.txt"), "w") as f:
         f.write("sampler localbound\nseed 23\nT %s\nscale %s\n" % (hx([25.0]), hx([1.0])))
         write_matrix(f, "Gamma", G)
         f.write("x0 %s\ntheta0 %s\nc %s\n" % (hx(x0), hx(th0), hx(cl)))
@@ -139,7 +140,7 @@ def write_more():
     Lc = np.tril(np.linalg.cholesky(G.toarray()))
     r = O.pdmp_bps(G, None, x0, th0, 16.0, 15.0, lambda_ref=0.5, seed=24, ev_cap=5000, boomerang_mu=np.zeros(d), mass_L=sp.csc_matrix(Lc))
     assert r["status"] == 0 and r["nevents"] > 5
-    with open(os.path.join(HERE, "crosscheck_boomerang_d8.txt"), "w") as f:
+    with open(os.path.join(OUT, "crosscheck_boomerang_d8.txt"), "w") as f:
         f.write("sampler boomerang\nseed 24\nT %s\nlambda_ref %s\nrho %s\nc %s\n" % (hx([15.0]), hx([0.5]), hx([0.0]), hx([16.0])))
         write_matrix(f, "Gamma", G)
         write_matrix(f, "L", Lc)
@@ -154,7 +155,7 @@ def write_more():
     th0 = Pl["sigma"] * rng.choice([-1.0, 1.0], p_)
     r = O.spdmp_zigzag(Pl["Gdrop"], Pl["mu"], Pl["Gdrop"], Pl["x0"], th0, Pl["c"], 30.0, seed=25, adapt=True, factor=5.0, logistic=lg, sigma=Pl["sigma"])
     assert r["status"] == 0 and len(r["events"]) > 30
-    with open(os.path.join(HERE, "crosscheck_logistic_p%d.txt" % p_), "w") as f:
+    with open(os.path.join(OUT, "crosscheck_logistic_p%d.txt" % p_), "w") as f:
         f.write("sampler logistic\nseed 25\nT %s\ngamma0 %s\nksub 3\nfactor %s\n" % (hx([30.0]), hx([Pl["gamma0"]]), hx([5.0])))
         A = sp.coo_matrix(Pl["A"])
         f.write("A %d %d %d\n" % (A.shape[0], A.shape[1], A.nnz))

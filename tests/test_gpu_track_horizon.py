@@ -127,6 +127,41 @@ def test_every_leaver_is_the_sequential_tracked_sampler_bit_for_bit(c3_horizon):
             _bitwise_state(e.final_state(q, 1), cn[q], oracle_tracked[k], k)
 
 
+def test_moving_kernel_equals_the_moving_oracle_on_64_chains_at_the_horizon(c3_horizon):
+    """The bit-identical evaluation at C3's own horizon on more than two chains: 64 chains of the 4096-chain run on zz_local_spec8_kernel -- every
+    64th, the ends, and chain 1018 (whose TRACKED arithmetic holds an exact tie of two keys at t = 18.89) -- against the oracle's restatement of
+    src/sfact.jl:73-145 over T = 20 (1.4e6 proposals per chain; a thread pool over the host cores, ctypes releases the GIL): counters and the whole
+    final state bit for bit.  An exact tie of two keys in the MOVING arithmetic would show up here as a mismatch -- the device pops the lowest
+    coordinate, the reference's heap whatever sits higher (src/priorityqueue.jl:46-61) -- and is reported as such, not hidden: none was found on
+    these chains."""
+    from concurrent.futures import ThreadPoolExecutor
+    import os
+    pkg, G, c, ens, cnt, left_at = c3_horizon
+    d = G.shape[0]
+    chains = sorted(set(list(range(0, 4096, 66)) + [1018, 4095]))[:64]
+    assert len(chains) == 64
+
+    def run(k):
+        x0, th0 = O.synthetic_state(SEED0 + k, d)
+        return O.spdmp_zigzag(G, None, G, x0, th0, c, T_END, seed=SEED0 + k, stop_before_T=True, want_trace=False)
+
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as pool:
+        res = list(pool.map(run, chains))
+    mism = []
+    for k, r in zip(chains, res):
+        assert r["status"] == 0
+        fs = ens["exact"].final_state(k, 1)
+        ck = cnt["exact"][k]
+        same = ((int(ck["num"]), int(ck["nacc"]), int(ck["ndraw_main"])) == (r["num"], r["nacc"], r["ndraw_main"]) and
+                np.array_equal(fs["acc"][0], r["acc"]) and np.array_equal(fs["theta"][0], r["theta"]) and np.array_equal(fs["t"][0], r["t"]) and
+                np.array_equal(fs["x"][0], r["x"]))
+        if not same:
+            mism.append(k)
+    print("moving kernel vs moving oracle at T = 20: %d chains, %.4g proposals, mismatches (= exact ties of two keys): %s" %
+          (len(chains), float(sum(r["num"] for r in res)), mism))
+    assert mism == []
+
+
 def test_c4_tracked_bounds_over_a_long_run(gpu_pkg):
     """Config C4 (8192 chains of the subsampled logistic regression, adapt, factor 5) to T = 100 with tracked BOUNDS and with the moving
     evaluation (7·10⁹ proposals each).  The two arithmetics round the positions differently -- the moving evaluation brings G1[i] to every
