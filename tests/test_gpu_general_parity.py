@@ -253,7 +253,7 @@ def test_local_bound_exact_ties_are_ordered_by_index_not_by_heap_shape(gpu_pkg):
     assert abs(len(ev) - len(oe)) < 0.1 * len(oe) and np.all(np.isfinite(x)) and np.all(np.abs(th) == 1.0)
 
 
-def test_c4_state_in_lds_equals_state_in_hbm(gpu_pkg):
+def test_c4_state_in_lds_equals_state_in_hbm(gpu_pkg, gpu_pkg_parity):
     """Config C4's kernel keeps a chain's state in LDS for a whole slice (pdmp_logistic.hip); PDMP_DEBUG_KERNEL_SEQ keeps the records in HBM
     (pdmp_general.hip).  Same chains on both, in slices with trace refills (state leaves and re-enters LDS at every launch), with and
     without the engine's path integrals: identical events, counters, final states, adapted bounds, ∫x dt; the integrals' entry points are
@@ -271,11 +271,12 @@ def test_c4_state_in_lds_equals_state_in_hbm(gpu_pkg):
     # DESIGN.md §5a): 6 chains = rows that are full, half full and -- in the last wavefront -- absent
     for name, kernel, integrals, rows in (("lds", "auto", True, 0), ("lds_noI", "auto", False, 0), ("hbm", "seq", True, 0),
                                           ("rows32", "auto", True, 32), ("rows16", "auto", True, 16), ("rows16_noI", "auto", False, 16)):
-        with pkg.Ensemble(nch, d, adapt=True, factor=5.0, trace_capacity=400) as ens:
+        pk = gpu_pkg_parity if rows else pkg  # (zz_logistic_rows_kernel lives in the parity build of the library: conftest.py)
+        with pk.Ensemble(nch, d, adapt=True, factor=5.0, trace_capacity=400) as ens:
             ens.debug_set_kernel(kernel)
             ens.debug_set_logistic_rows(rows)
-            ens.set_flow(pkg.ZigZag(P["Gdrop"], P["mu"], P["sigma"]))
-            ens.set_target(pkg.LogisticTarget(P["A"], P["y"], P["ny"], P["mu"], P["gamma0"], 10))
+            ens.set_flow(pk.ZigZag(P["Gdrop"], P["mu"], P["sigma"]))
+            ens.set_target(pk.LogisticTarget(P["A"], P["y"], P["ny"], P["mu"], P["gamma0"], 10))
             ens.set_path_integrals(integrals)
             ens.set_state(0.0, X0, TH0, P["c"], seeds)
             evs = [[] for _ in range(nch)]
@@ -293,7 +294,7 @@ def test_c4_state_in_lds_equals_state_in_hbm(gpu_pkg):
                 pj = ens.path_integrals(12.0, np.arange(0, d, 7))
             else:
                 bm = pj = None
-                with pytest.raises(L.PdmpError) as ei:
+                with pytest.raises(pk._lib.PdmpError) as ei:
                     ens.batch_means(0.0, 12.0)
                 assert ei.value.code == L.PDMP_ERR_INVALID and "switched off" in str(ei.value)
             runs[name] = (cnt, [np.concatenate(e) for e in evs], ens.final_state(), bm, pj)

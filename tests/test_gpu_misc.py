@@ -188,3 +188,24 @@ def test_engine_rccl_entry_points_world1(gpu_pkg):
                 e0.set_target(pkg.GaussianTarget(G))
                 e0.set_state_synthetic(0.0, c, 1)
                 comm.gather_traces(e0)
+
+
+def test_default_library_carries_one_kernel_per_path(gpu_pkg):
+    """The measured-slower cross-implementations (zz_local_exactp_kernel, zz_logistic_rows_kernel) are not in libpdmp_mi355.so: asking for them by
+    name is refused with a status that says where they live (the parity build, lib/libpdmp_mi355.parity.so), never served by another kernel."""
+    pkg = gpu_pkg
+    L = pkg._lib
+    G = pkg.problems.gmrf_precision(48)
+    d = G.shape[0]
+    with pkg.Ensemble(1, d) as ens:
+        with pytest.raises(L.PdmpError) as ei:
+            ens.debug_set_logistic_rows(32)
+        assert ei.value.code == L.PDMP_ERR_UNSUPPORTED and "parity" in str(ei.value)
+    with pkg.Ensemble(1, d) as ens:
+        ens.debug_set_kernel("exactp")
+        ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
+        ens.set_target(pkg.GaussianTarget(G))
+        ens.set_state_synthetic(0.0, pkg.problems.column_norms(G), 1)
+        with pytest.raises(L.PdmpError) as ei:
+            ens.run(0.1)
+        assert ei.value.code == L.PDMP_ERR_UNSUPPORTED and "parity" in str(ei.value)

@@ -12,6 +12,8 @@ pytestmark = pytest.mark.gpu
 
 MODES = (None, "spec4", "seq", "exactp")  # None: the default dispatch = the 8-event kernel for this workload
 OTHERS = MODES[1:]  # "exactp": the one-proposal-per-lane kernel (pdmp_exactp.hip), opt-in; serves Γ_bound == Γ_target without adaptation
+# (since round 4 zz_local_exactp_kernel is not in the default library: its runs go through the parity build, conftest.py: gpu_pkg_parity --
+# a second instance of the package bound to lib/libpdmp_mi355.parity.so; every other mode runs on the default library)
 BASIC = MODES[:3]
 
 
@@ -44,12 +46,12 @@ def _run_sliced(pkg, monkeypatch, mode, nch, cap, slices, seed0, n=128):
     return G, c, ev, cnt, fs
 
 
-def test_sliced_runs_with_trace_refills_agree_across_kernels_and_with_the_oracle(gpu_pkg, monkeypatch):
+def test_sliced_runs_with_trace_refills_agree_across_kernels_and_with_the_oracle(gpu_pkg, gpu_pkg_parity, monkeypatch):
     pkg = gpu_pkg
     T = 0.3
     slices = ((0.11, pkg._lib.RUN_STOP_BEFORE), (0.2, pkg._lib.RUN_STOP_BEFORE), (T, pkg._lib.RUN_REFERENCE_TAIL))
     nch, seed0 = 6, 0xABC000
-    runs = {m: _run_sliced(pkg, monkeypatch, m, nch, 1500, slices, seed0) for m in MODES}
+    runs = {m: _run_sliced(gpu_pkg_parity if m == "exactp" else pkg, monkeypatch, m, nch, 1500, slices, seed0) for m in MODES}
     G, c, ev8, cnt8, fs8 = runs[None]
     assert np.all(cnt8["status"] == pkg._lib.CHAIN_OK)
     for m in OTHERS:
@@ -124,7 +126,7 @@ def test_bound_violation_stops_the_chain_at_the_same_event_in_all_kernels(gpu_pk
     assert np.array_equal(fs8["x"][k], r["x"]) and np.array_equal(fs8["t"][k], r["t"]) and np.array_equal(fs8["theta"][k], r["theta"])
 
 
-def test_many_chains_longer_run_three_kernels_agree(gpu_pkg, monkeypatch):
+def test_many_chains_longer_run_three_kernels_agree(gpu_pkg, gpu_pkg_parity, monkeypatch):
     """256 chains to T = 1 (1.4e7 proposals per kernel): counters, final states and trace digests of the 8-event, 4-event and
     one-event kernels are identical -- three independent implementations of the event loop, rare paths included."""
     import hashlib
@@ -132,7 +134,7 @@ def test_many_chains_longer_run_three_kernels_agree(gpu_pkg, monkeypatch):
     slices = ((0.37, pkg._lib.RUN_STOP_BEFORE), (1.0, pkg._lib.RUN_STOP_BEFORE))
     dig = {}
     for m in MODES:
-        _, _, ev, cnt, fs = _run_sliced(pkg, monkeypatch, m, 256, 16000, slices, 0x51DE)
+        _, _, ev, cnt, fs = _run_sliced(gpu_pkg_parity if m == "exactp" else pkg, monkeypatch, m, 256, 16000, slices, 0x51DE)
         h = hashlib.sha256()
         for k in range(256):
             h.update(np.ascontiguousarray(ev[k]).tobytes())
@@ -146,12 +148,12 @@ def test_many_chains_longer_run_three_kernels_agree(gpu_pkg, monkeypatch):
 
 
 @pytest.mark.parametrize("n,T", [(46, 1.5), (64, 1.0), (100, 0.5), (127, 0.3)])
-def test_other_lattice_sizes_use_the_same_kernel(gpu_pkg, monkeypatch, n, T):
+def test_other_lattice_sizes_use_the_same_kernel(gpu_pkg, gpu_pkg_parity, monkeypatch, n, T):
     """The 8-event kernel serves every n x n lattice with 2048 <= d <= 16384 (its first level covers ceil(d / 32) blocks, the
     rest stay +Inf): d = 2116 (not a multiple of 32), 4096, 10 000, 16 129 against the other kernels and the oracle."""
     pkg = gpu_pkg
     slices = ((0.4 * T, pkg._lib.RUN_STOP_BEFORE), (T, pkg._lib.RUN_REFERENCE_TAIL))
-    runs = {m: _run_sliced(pkg, monkeypatch, m, 5, 3000, slices, 9000 + n, n=n) for m in MODES}
+    runs = {m: _run_sliced(gpu_pkg_parity if m == "exactp" else pkg, monkeypatch, m, 5, 3000, slices, 9000 + n, n=n) for m in MODES}
     G, c, ev8, cnt8, fs8 = runs[None]
     d = G.shape[0]
     assert np.all(cnt8["status"] == pkg._lib.CHAIN_OK)
@@ -204,7 +206,7 @@ def test_adapt_and_target_mean_on_a_lattice_of_spec8_size(gpu_pkg, monkeypatch, 
     assert grew > 0  # the adaptation did happen
 
 
-def test_rounding_level_violation_with_the_targets_own_matrix(gpu_pkg, monkeypatch):
+def test_rounding_level_violation_with_the_targets_own_matrix(gpu_pkg, gpu_pkg_parity, monkeypatch):
     """Γ_bound == Γ_target and c at rounding level: the affine bound equals the rate up to the last bits, so an accepted proposal
     with l >= l̄ -- error(...) in the reference, src/sfact.jl:124 -- does occur.  This is the only way into the violation path of
     the one-proposal-per-lane kernel (it serves equal matrices only): same stop, counters, trace and state as the other kernels."""
@@ -218,9 +220,10 @@ def test_rounding_level_violation_with_the_targets_own_matrix(gpu_pkg, monkeypat
             monkeypatch.delenv("PDMP_KERNEL", raising=False)
         else:
             monkeypatch.setenv("PDMP_KERNEL", m)
-        with pkg.Ensemble(16, d, trace_capacity=30000) as ens:
-            ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
-            ens.set_target(pkg.GaussianTarget(G))
+        pk = gpu_pkg_parity if m == "exactp" else pkg
+        with pk.Ensemble(16, d, trace_capacity=30000) as ens:
+            ens.set_flow(pk.ZigZag(G, np.zeros(d)))
+            ens.set_target(pk.GaussianTarget(G))
             ens.set_state_synthetic(0.0, c, 0xC0DE)
             ens.run(2.0, pkg._lib.RUN_STOP_BEFORE)
             cnt = ens.counters()

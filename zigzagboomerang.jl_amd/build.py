@@ -15,7 +15,13 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpdmp_mi355.so")
 SOURCES = ["pdmp_capi.hip", "pdmp_kernels.hip", "pdmp_bps.hip", "pdmp_general.hip", "pdmp_partition.hip", "pdmp_trackp.hip",
-           "pdmp_consume.hip", "pdmp_logistic.hip", "pdmp_comm.hip", "pdmp_exactp.hip", "pdmp_1d.hip", "pdmp_logrows.hip"]
+           "pdmp_consume.hip", "pdmp_logistic.hip", "pdmp_comm.hip", "pdmp_1d.hip"]
+# Measured-slower cross-implementations of two event loops (zz_local_exactp_kernel: the moving evaluation with one proposal per lane;
+# zz_logistic_rows_kernel: several chains of config C4 per wavefront).  They are NOT in the default library: `build.py --variant parity`
+# (-DPDMP_EXTRA_KERNELS) makes lib/libpdmp_mi355.parity.so with them, which the parity suite loads beside the default one
+# (tests/conftest.py: gpu_pkg_parity) to hold them to the same oracle.
+EXTRA_SOURCES = ["pdmp_exactp.hip", "pdmp_logrows.hip"]
+PARITY_DEFINES = ("PDMP_EXTRA_KERNELS",)
 HEADERS = [os.path.join(CSRC, "pdmp_engine.hpp"),
            os.path.join(PKG_DIR, "..", "include", "pdmp_mi355.h"),
            os.path.join(PKG_DIR, "..", "include", "pdmp_debug.h"),
@@ -36,7 +42,8 @@ def find_hipcc():
 def needs_build(lib_path=LIB_PATH):
     if not os.path.exists(lib_path):
         return True
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    srcs = SOURCES + (EXTRA_SOURCES if lib_path.endswith(".parity.so") else [])
+    deps = [os.path.join(CSRC, s) for s in srcs] + HEADERS
     return os.path.getmtime(lib_path) < max(os.path.getmtime(p) for p in deps)
 
 
@@ -52,9 +59,13 @@ def build(force=False, verbose=False, variant=None, defines=()):
     if defines and not variant:
         raise ValueError("build(defines=...) needs a variant name: an experimental -D build must not replace the default library "
                          "(needs_build() compares time stamps only and would keep it)")
+    if variant == "parity" and not defines:
+        defines = PARITY_DEFINES
     lib_path = variant_path(variant)
-    if not force and not defines and not needs_build(lib_path):
+    parity = variant == "parity" and tuple(defines) == PARITY_DEFINES
+    if not force and (not defines or parity) and not needs_build(lib_path):
         return lib_path
+    sources = SOURCES + (EXTRA_SOURCES if "PDMP_EXTRA_KERNELS" in defines else [])
     os.makedirs(LIB_DIR, exist_ok=True)
     obj_dir = os.path.join(LIB_DIR, "obj" + ("." + variant if variant else ""))
     os.makedirs(obj_dir, exist_ok=True)
@@ -64,7 +75,7 @@ def build(force=False, verbose=False, variant=None, defines=()):
     with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            if force or defines or needs_build(lib_path):
+            if force or (defines and not parity) or needs_build(lib_path):
                 hipcc = find_hipcc()
                 cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + ["-D" + d for d in defines]
                 hdr_time = max(os.path.getmtime(p) for p in HEADERS)
@@ -85,8 +96,8 @@ def build(force=False, verbose=False, variant=None, defines=()):
                             f.write(flags_txt)
                     return obj
 
-                with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:
-                    objs = list(pool.map(compile_one, SOURCES))
+                with ThreadPoolExecutor(max_workers=len(sources)) as pool:
+                    objs = list(pool.map(compile_one, sources))
                 tmp = lib_path + ".tmp.%d" % os.getpid()
                 # (librccl for pdmp_comm.hip: the post-run gather / reduce links RCCL directly)
                 cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
@@ -137,4 +148,5 @@ if __name__ == "__main__":
     a = ap.parse_args()
     print(build(force=a.force, verbose=True, variant=a.variant, defines=tuple(a.defines)))
     if not a.variant:
+        print(build(force=a.force, verbose=True, variant="parity"))  # the parity suite's library (default + the opt-in cross-implementations)
         print(build_examples(verbose=True))

@@ -372,6 +372,9 @@ pdmp_status pdmp_debug_set_track_groups(pdmp_ensemble* e, int on) {
 }
 pdmp_status pdmp_debug_set_logistic_rows(pdmp_ensemble* e, int w) {
     if (!e || (w != -1 && w != 0 && w != 16 && w != 32)) return fail(PDMP_ERR_INVALID, "row width: -1 (default), 0 (one chain per wavefront), 16 or 32");
+#ifndef PDMP_EXTRA_KERNELS
+    if (w > 0) return fail(PDMP_ERR_UNSUPPORTED, "zz_logistic_rows_kernel is not part of this library: it lives in the parity build (build.py --variant parity, -DPDMP_EXTRA_KERNELS)");
+#endif
     e->dbg_lg_rows = w;
     return PDMP_OK;
 }
@@ -1376,12 +1379,17 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         // ... several chains per wavefront where the draws of a proposal fit a row (pdmp_logrows.hip); pdmp_debug_set_logistic_rows picks the width
         if (e->track_lg && !lds_resident)
             return fail(PDMP_ERR_UNSUPPORTED, "gradient tracking with the logistic target runs on the LDS-resident kernel: d <= 512, k_sub <= 32, rows of <= 6 regressors");
+#ifdef PDMP_EXTRA_KERNELS
         const int rows_w = (!lds_resident || e->track_lg) ? 0 : (e->dbg_lg_rows >= 0 ? e->dbg_lg_rows : PDMP_LG_ROWS_DEFAULT);
         const bool rows = rows_w > 0 && pdmp::zz_logistic_rows_supported(P, Q, LT, rows_w);
         if (lds_resident && e->dbg_lg_rows > 0 && !rows) return fail(PDMP_ERR_UNSUPPORTED, "pdmp_debug_set_logistic_rows: this ensemble does not fit rows of %d lanes", rows_w);
         e->last_kernel = rows ? "zz_logistic_rows_kernel" : lds_resident ? "zz_logistic_lds_kernel" : "zz_general_run_kernel";
         int rcg = rows ? pdmp::launch_zz_logistic_rows(P, Q, LT, e->keep_integrals, rows_w, e->cfg.nchains, s)
                        : lds_resident ? pdmp::launch_zz_logistic_lds(P, Q, LT, e->keep_integrals, e->cfg.nchains, s) : pdmp::launch_zz_general_run(P, Q, e->cfg.nchains, s);
+#else
+        e->last_kernel = lds_resident ? "zz_logistic_lds_kernel" : "zz_general_run_kernel";
+        int rcg = lds_resident ? pdmp::launch_zz_logistic_lds(P, Q, LT, e->keep_integrals, e->cfg.nchains, s) : pdmp::launch_zz_general_run(P, Q, e->cfg.nchains, s);
+#endif
         if (rcg != 0) return fail(PDMP_ERR_HIP, "zz_general_run launch failed: %s", hipGetErrorString((hipError_t)rcg));
         HIP_TRY(hipEventRecord(e->ev1, s));
         e->timed = true;
@@ -1424,6 +1432,7 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         }
         return PDMP_OK;
     }
+#ifdef PDMP_EXTRA_KERNELS
     if (e->exactp && spec_ok) {
         P.lattice_n = e->lattice_n;
         P.lattice_magic = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)e->lattice_n + 1);
@@ -1441,8 +1450,13 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
             return PDMP_OK;
         }
     }
+#endif
     if (e->dbg_kernel == PDMP_DEBUG_KERNEL_EXACTP)  // asked for by name: never another kernel in its place
+#ifndef PDMP_EXTRA_KERNELS
+        return fail(PDMP_ERR_UNSUPPORTED, "PDMP_DEBUG_KERNEL_EXACTP: zz_local_exactp_kernel is not part of this library: it lives in the parity build (build.py --variant parity, -DPDMP_EXTRA_KERNELS)");
+#else
         return fail(PDMP_ERR_UNSUPPORTED, "PDMP_DEBUG_KERNEL_EXACTP: spdmp on a plain lattice (16 <= n <= 128, d >= 2048) with the bounding matrix equal to the target's, no adaptation, and a trace or no trace");
+#endif
     const bool sticky_spec = sticky && e->use_spec && e->blob_mmax <= 16 && dbg_cap == 0;  // the ZigZag speculative kernel's requirements, one zone member per lane
     e->last_kernel = sticky ? (sticky_spec ? "zz_sticky_spec_kernel" : "zz_sticky_run_kernel") : "zz_local_run_kernel";
     int rc = sticky ? (sticky_spec ? pdmp::launch_zz_sticky_spec(P, e->cfg.nchains, s) : pdmp::launch_zz_sticky_run(P, e->cfg.nchains, s))
