@@ -1,7 +1,11 @@
-"""The moving (bit-identical) evaluation OFF the benchmark stencil (-m gpu): zz_local_spec_kernel<.., WIDE> -- four events per iteration with
-two zone members per lane -- serves two-hop neighbourhoods of 17 .. 32 coordinates (the 7-point 3-d lattice: |S| = 25; random symmetric
-patterns with <= 6 entries per column: |S| <= 26).  Every case runs on the speculative kernel and on the one-event kernel (PDMP_KERNEL=seq);
-both must equal the oracle's restatement of src/sfact.jl:73-145 bit for bit (tolerance 0)."""
+"""The moving (bit-identical) evaluation OFF the benchmark stencil (-m gpu), two-hop neighbourhoods of 17 .. 32 coordinates (the 7-point 3-d
+lattice: |S| = 25; random symmetric patterns with <= 6 entries per column: |S| <= 26):
+  * zz_local_spec8g_kernel -- eight events per iteration, per-coordinate tables instead of blob templates, zones compared through a bitmap --
+    the default for the plain configuration at 2048 <= d <= 16384;
+  * zz_local_spec_kernel<.., WIDE> -- four events per iteration with two zone members per lane -- everything else (adaptation, a target mean,
+    small d; PDMP_KERNEL=spec4 selects it where the 8-event kernel would run);
+  * the one-event kernel (PDMP_KERNEL=seq).
+All must equal the oracle's restatement of src/sfact.jl:73-145 bit for bit (tolerance 0)."""
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -13,10 +17,10 @@ from test_gpu_zigzag_parity import run_case
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["spec", "seq"])
+@pytest.fixture(autouse=True, params=["spec", "spec4", "seq"])
 def kernel_mode(request, monkeypatch):
-    if request.param == "seq":
-        monkeypatch.setenv("PDMP_KERNEL", "seq")
+    if request.param != "spec":
+        monkeypatch.setenv("PDMP_KERNEL", request.param)
     else:
         monkeypatch.delenv("PDMP_KERNEL", raising=False)
     return request.param
@@ -32,13 +36,13 @@ def test_wide_zones_match_oracle(gpu_pkg, kernel_mode, which, T):
     assert 16 < mmax <= 32
     rng = np.random.default_rng(3)
     run_case(pkg, G, G, rng.standard_normal((3, d)), rng.choice([-1.0, 1.0], (3, d)), pkg.problems.column_norms(G), T, seed=1300)
-    if kernel_mode == "spec":
+    if kernel_mode != "seq":
         with pkg.Ensemble(1, d) as ens:
             ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
             ens.set_target(pkg.GaussianTarget(G))
             ens.set_state_synthetic(0.0, pkg.problems.column_norms(G), 1)
             ens.run(0.1)
-            assert ens.kernel_name() == "zz_local_spec_kernel<WIDE>"
+            assert ens.kernel_name() == ("zz_local_spec8g_kernel" if kernel_mode == "spec" else "zz_local_spec_kernel<WIDE>")
 
 
 def test_wide_zones_small_d_loose_bound_mean_adapt(gpu_pkg):
@@ -88,3 +92,39 @@ def test_wide_zones_slices_and_trace_refills(gpu_pkg):
             assert np.array_equal(ev[f], r["events"][f]), f
         assert np.array_equal(fs["t"][q], r["t"]) and np.array_equal(fs["x"][q], r["x"]) and np.array_equal(fs["theta"][q], r["theta"])
         assert np.array_equal(fs["acc"][q], r["acc"])
+
+
+def test_eight_event_kernel_at_c3g_width(gpu_pkg, kernel_mode):
+    """Config C3G at its width on the moving evaluation (d = 15625: the 25^3 lattice; d = 16384: the random pattern; 4096 chains to T = 0.25): every
+    chain healthy, the 8-event and the 4-event kernel agree on every chain's counters, first and last chain bit for bit the oracle."""
+    if kernel_mode == "seq":
+        pytest.skip("the one-event kernel at this width takes minutes and is covered at d = 2197")
+    pkg = gpu_pkg
+    for G in (pkg.problems.lattice3d_precision(25), pkg.problems.random_sparse_precision(16384, 6)):
+        d = G.shape[0]
+        c = pkg.problems.column_norms(G)
+        nch, T = 4096, 0.25
+        with pkg.Ensemble(nch, d, trace_capacity=int(1.5 * d * T) + 1024) as ens:
+            ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
+            ens.set_target(pkg.GaussianTarget(G))
+            ens.set_state_synthetic(0.0, c, 0x5EED0000)
+            ens.run(T, pkg._lib.RUN_STOP_BEFORE)
+            assert ens.kernel_name() == ("zz_local_spec8g_kernel" if kernel_mode == "spec" else "zz_local_spec_kernel<WIDE>")
+            cnt = ens.counters()
+            assert np.all(cnt["status"] == pkg._lib.CHAIN_OK)
+            key = (d, int(cnt["num"].sum()), int(cnt["nacc"].sum()), int(cnt["ndraw_main"].sum()))
+            _WIDTH_TOTALS.setdefault(d, set()).add(key)
+            assert len(_WIDTH_TOTALS[d]) == 1, _WIDTH_TOTALS[d]  # (both kernels: the same proposals, reflections and draws over all 4096 chains)
+            for q in (0, nch - 1):
+                x0, th0 = O.synthetic_state(0x5EED0000 + q, d)
+                r = O.spdmp_zigzag(G, None, G, x0, th0, c, T, seed=0x5EED0000 + q, stop_before_T=True)
+                ev = ens.trace(q, counters=cnt)
+                fs = ens.final_state(q, 1)
+                assert len(ev) == len(r["events"]) and int(cnt["num"][q]) == r["num"]
+                for f in ("i", "t", "x", "theta"):
+                    assert np.array_equal(ev[f], r["events"][f]), f
+                assert np.array_equal(fs["t"][0], r["t"]) and np.array_equal(fs["x"][0], r["x"]) and np.array_equal(fs["theta"][0], r["theta"])
+                assert np.array_equal(fs["acc"][0], r["acc"])
+
+
+_WIDTH_TOTALS = {}

@@ -23,6 +23,7 @@ SOURCES = ["pdmp_capi.hip", "pdmp_kernels.hip", "pdmp_bps.hip", "pdmp_general.hi
 EXTRA_SOURCES = ["pdmp_exactp.hip", "pdmp_logrows.hip"]
 PARITY_DEFINES = ("PDMP_EXTRA_KERNELS",)
 HEADERS = [os.path.join(CSRC, "pdmp_engine.hpp"),
+           os.path.join(CSRC, "pdmp_spec8g.inc"),  # (included by pdmp_kernels.hip)
            os.path.join(PKG_DIR, "..", "include", "pdmp_mi355.h"),
            os.path.join(PKG_DIR, "..", "include", "pdmp_debug.h"),
            os.path.join(PKG_DIR, "..", "include", "pdmp_detmath.h")]

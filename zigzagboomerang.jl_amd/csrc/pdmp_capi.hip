@@ -122,6 +122,12 @@ struct pdmp_ensemble {
     bool exactp = false;       // the moving evaluation runs on zz_local_exactp_kernel (plain lattice; decided by set_state)
     bool track_pairs = false;  // the queue's level 0 is (key, time) pairs in d_kp (pdmp_trackp.hip); decided by set_state
     DevBuf<double> d_kp;
+    // zz_local_spec8g_kernel's tables (any graph with |G1| <= 8, |S| <= 32; built with the blob)
+    bool has_g8 = false;
+    DevBuf<uint16_t> d_g8_sid;
+    DevBuf<uint32_t> d_g8_hw;
+    DevBuf<uint64_t> d_g8_posj;
+    DevBuf<double> d_g8_gamt, d_g8_valj;
     bool track_generic = false;  // ... on a graph that is not the plain lattice: G1 ids in the records, Γ values in d_gam8 (|G1| <= 8)
     DevBuf<double> d_gam8;
     DevBuf<uint16_t> d_nb16;
@@ -827,6 +833,37 @@ static pdmp_status build_blob(pdmp_ensemble* e, const double* c) {
     e->blob_kmax = kmax;
     e->blob_mmax = mmax;
     // (pdmp_debug_set_kernel(PDMP_DEBUG_KERNEL_SEQ) forces the one-event-per-iteration kernel: A/B runs, parity tests)
+    // eight events per iteration off the lattice: per-coordinate tables instead of blob templates (pdmp_spec8g.inc)
+    e->has_g8 = false;
+    if (kmax <= 8 && mmax <= 32 && d >= 2048 && d <= 16384 && !(kmax <= 5 && mmax <= 13)) {
+        std::vector<uint16_t> sid((size_t)d * 32, (uint16_t)0xFFFF);
+        std::vector<uint32_t> hwv((size_t)d, 0u);
+        std::vector<uint64_t> posj((size_t)d * 8, 0ull);
+        std::vector<double> gamt((size_t)d * 8, 0.0), valj((size_t)d * 8, 0.0);
+        for (int64_t i = 0; i < d; ++i) {
+            const uint32_t c0 = e->colptr[i], k = e->colptr[i + 1] - c0;
+            const uint32_t s0 = e->h_sptr[i], m = e->h_sptr[i + 1] - s0;
+            hwv[(size_t)i] = k | (m << 8) | ((uint32_t)e->h_selfpos[i] << 16);
+            for (uint32_t w = 0; w < m; ++w) sid[(size_t)i * 32 + (size_t)(w & 7u) * 4 + (w >> 3)] = (uint16_t)e->h_sidx[s0 + w];
+            for (uint32_t jj = 0; jj < k; ++jj) {
+                gamt[(size_t)i * 8 + jj] = e->h_tval[c0 + jj];
+                valj[(size_t)i * 8 + jj] = e->bval[c0 + jj];
+                const uint32_t j = e->rowval[c0 + jj];
+                const uint32_t kj = e->colptr[j + 1] - e->colptr[j];
+                const uint32_t q0 = e->h_qptr[c0 + jj];
+                uint64_t pw = 0;
+                for (uint32_t pp = 0; pp < kj; ++pp) pw |= (uint64_t)e->h_pos[q0 + pp] << (8 * pp);
+                posj[(size_t)i * 8 + jj] = pw;
+            }
+        }
+        pdmp_status sg;
+        if ((sg = e->d_g8_sid.upload(sid)) != PDMP_OK) return sg;
+        if ((sg = e->d_g8_hw.upload(hwv)) != PDMP_OK) return sg;
+        if ((sg = e->d_g8_posj.upload(posj)) != PDMP_OK) return sg;
+        if ((sg = e->d_g8_gamt.upload(gamt)) != PDMP_OK) return sg;
+        if ((sg = e->d_g8_valj.upload(valj)) != PDMP_OK) return sg;
+        e->has_g8 = true;
+    }
     e->use_spec = pdmp::zz_spec_supported(e->nblk, mmax, kmax) && e->dbg_kernel != PDMP_DEBUG_KERNEL_SEQ &&
                   (mmax > 16 ? pdmp::zz_spec_wide_lds_bytes(e->nblk_pad, Wpad) : pdmp::zz_spec_lds_bytes(e->nblk_pad, Wpad)) <= 64 * 1024;
     return e->d_blob.upload(blob);
@@ -1277,6 +1314,13 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
     P.blob = e->d_blob.p;
     P.tix = e->d_tix.p;
     P.common_tix = e->common_tix;
+    if (e->has_g8) {
+        P.g8_sid = e->d_g8_sid.p;
+        P.g8_hw = e->d_g8_hw.p;
+        P.g8_posj = e->d_g8_posj.p;
+        P.g8_gamt = e->d_g8_gamt.p;
+        P.g8_valj = e->d_g8_valj.p;
+    }
     DevBuf<double> dbgbuf;
     const int64_t dbg_cap = e->dbg_dump;
     if (dbg_cap > 0) {

@@ -2668,6 +2668,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     }
 }
 
+#include "pdmp_spec8g.inc"
+
 // ------------------------------------------------------------------------------------------ tracked-gradient loop
 //
 // zz_local_spec8_kernel's scheme (eight event slots per iteration, threshold selection, scalar accept walk, exact validation, commit of
@@ -4045,8 +4047,8 @@ int launch_zz_local_spec(const ZzRunParams& p, int64_t nchains, void* stream, co
     const size_t lds = zz_spec_lds_bytes(p.nblk_pad, p.blob_w_pad);
     const int ne = (int)((p.nblk + 63) / 64);
     dim3 grid((unsigned)nchains), block(64);
-    const bool plain = !p.adapt && p.c_chain == nullptr && p.tb.gmu_t == nullptr && (p.flags & 0x100) && p.blob_sw == 7 &&
-                       p.blob_pw == 1 && p.blob_kmax == 5 && p.blob_w_pad == 58;
+    const bool plain_cfg = !p.adapt && p.c_chain == nullptr && p.tb.gmu_t == nullptr && (p.flags & 0x100);
+    const bool plain = plain_cfg && p.blob_sw == 7 && p.blob_pw == 1 && p.blob_kmax == 5 && p.blob_w_pad == 58;
     // without a refresh clock the last key block holds only the (infinite) refresh slot: when d fills 256 blocks exactly the
     // queue's first level is scanned as 4 entries per lane instead of 5
     const bool plain4 = plain && !p.has_refresh && p.d == 256 * 64 && p.nblk == 257;
@@ -4056,7 +4058,16 @@ int launch_zz_local_spec(const ZzRunParams& p, int64_t nchains, void* stream, co
     const bool spec8 = geom && !p.has_refresh && p.d >= 2048 && p.d <= (int64_t)S8_NBLK * 32 &&
                        !p.force_spec4;  // (pdmp_debug_set_kernel: A/B runs and parity tests of the 4-event kernel)
     const bool wide = p.blob_sw > 8;  // |S[i]| up to 32: two zone members per lane
-    if (kname) *kname = spec8 ? "zz_local_spec8_kernel" : wide ? "zz_local_spec_kernel<WIDE>" : "zz_local_spec_kernel";
+    // eight events per iteration on any graph with |G1| <= 8, |S| <= 32 (tables built by the host when the geometry fits), plain configuration
+    const bool spec8g = !spec8 && p.g8_sid != nullptr && plain_cfg && !p.has_refresh && p.d >= 2048 && p.d <= (int64_t)S8_NBLK * 32 && !p.force_spec4;
+    if (kname) *kname = spec8 ? "zz_local_spec8_kernel" : spec8g ? "zz_local_spec8g_kernel" : wide ? "zz_local_spec_kernel<WIDE>" : "zz_local_spec_kernel";
+    if (spec8g) {
+        ZzRunParams q = p;
+        q.nblk = (uint32_t)((p.d + 31) / 32);
+        if (p.dbg) hipLaunchKernelGGL((zz_local_spec8g_kernel<true>), grid, block, zz_spec8g_lds_bytes(), (hipStream_t)stream, q);
+        else hipLaunchKernelGGL((zz_local_spec8g_kernel<false>), grid, block, zz_spec8g_lds_bytes(), (hipStream_t)stream, q);
+        return (int)hipGetLastError();
+    }
     if (wide) {
         const size_t ldsw = zz_spec_wide_lds_bytes(p.nblk_pad, p.blob_w_pad);
         if (p.dbg) hipLaunchKernelGGL((zz_local_spec_wide_kernel<8, true>), grid, block, ldsw, (hipStream_t)stream, p);
