@@ -36,6 +36,10 @@ def test_wide_zones_match_oracle(gpu_pkg, kernel_mode, which, T):
     assert 16 < mmax <= 32
     rng = np.random.default_rng(3)
     run_case(pkg, G, G, rng.standard_normal((3, d)), rng.choice([-1.0, 1.0], (3, d)), pkg.problems.column_norms(G), T, seed=1300)
+    # a bounding Γ whose VALUES differ from the target's (Z = ZigZag(1.2 Γ, 0), as test/maintest.jl:23 has 0.9 Γ): the 8-event kernel then takes the
+    # gradient's coefficients from their own table
+    run_case(pkg, G, sp.csc_matrix(1.2 * G), rng.standard_normal((2, d)), rng.choice([-1.0, 1.0], (2, d)), 1.2 * pkg.problems.column_norms(G), 0.5 * T,
+             seed=1400)
     if kernel_mode != "seq":
         with pkg.Ensemble(1, d) as ens:
             ens.set_flow(pkg.ZigZag(G, np.zeros(d)))

@@ -123,11 +123,9 @@ struct pdmp_ensemble {
     bool track_pairs = false;  // the queue's level 0 is (key, time) pairs in d_kp (pdmp_trackp.hip); decided by set_state
     DevBuf<double> d_kp;
     // zz_local_spec8g_kernel's tables (any graph with |G1| <= 8, |S| <= 32; built with the blob)
-    bool has_g8 = false;
-    DevBuf<uint16_t> d_g8_sid;
-    DevBuf<uint32_t> d_g8_hw;
-    DevBuf<uint64_t> d_g8_posj;
-    DevBuf<double> d_g8_gamt, d_g8_valj;
+    bool has_g8 = false, g8_same = false;
+    DevBuf<uint64_t> d_g8_line;
+    DevBuf<double> d_g8_member, d_g8_gamt;
     bool track_generic = false;  // ... on a graph that is not the plain lattice: G1 ids in the records, Γ values in d_gam8 (|G1| <= 8)
     DevBuf<double> d_gam8;
     DevBuf<uint16_t> d_nb16;
@@ -835,33 +833,37 @@ static pdmp_status build_blob(pdmp_ensemble* e, const double* c) {
     // (pdmp_debug_set_kernel(PDMP_DEBUG_KERNEL_SEQ) forces the one-event-per-iteration kernel: A/B runs, parity tests)
     // eight events per iteration off the lattice: per-coordinate tables instead of blob templates (pdmp_spec8g.inc)
     e->has_g8 = false;
+    e->g8_same = false;
     if (kmax <= 8 && mmax <= 32 && d >= 2048 && d <= 16384 && !(kmax <= 5 && mmax <= 13)) {
-        std::vector<uint16_t> sid((size_t)d * 32, (uint16_t)0xFFFF);
-        std::vector<uint32_t> hwv((size_t)d, 0u);
-        std::vector<uint64_t> posj((size_t)d * 8, 0ull);
-        std::vector<double> gamt((size_t)d * 8, 0.0), valj((size_t)d * 8, 0.0);
+        std::vector<uint64_t> line((size_t)d * 16, 0ull);
+        std::vector<double> member((size_t)d * 16, 0.0), gamt((size_t)d * 8, 0.0);
+        bool same = true;
         for (int64_t i = 0; i < d; ++i) {
             const uint32_t c0 = e->colptr[i], k = e->colptr[i + 1] - c0;
             const uint32_t s0 = e->h_sptr[i], m = e->h_sptr[i + 1] - s0;
-            hwv[(size_t)i] = k | (m << 8) | ((uint32_t)e->h_selfpos[i] << 16);
-            for (uint32_t w = 0; w < m; ++w) sid[(size_t)i * 32 + (size_t)(w & 7u) * 4 + (w >> 3)] = (uint16_t)e->h_sidx[s0 + w];
+            uint16_t ids[32];
+            for (uint32_t w = 0; w < 32; ++w) ids[w] = (w < m) ? (uint16_t)(e->h_sidx[s0 + w] | (w < k ? 0x8000u : 0u)) : (uint16_t)0x7FFF;
+            for (uint32_t gl = 0; gl < 8; ++gl)
+                line[(size_t)i * 16 + gl] = (uint64_t)ids[gl] | ((uint64_t)ids[gl + 8] << 16) | ((uint64_t)ids[gl + 16] << 32) | ((uint64_t)ids[gl + 24] << 48);
             for (uint32_t jj = 0; jj < k; ++jj) {
                 gamt[(size_t)i * 8 + jj] = e->h_tval[c0 + jj];
-                valj[(size_t)i * 8 + jj] = e->bval[c0 + jj];
+                member[(size_t)i * 16 + jj] = e->bval[c0 + jj];
+                same = same && e->h_tval[c0 + jj] == e->bval[c0 + jj];
                 const uint32_t j = e->rowval[c0 + jj];
                 const uint32_t kj = e->colptr[j + 1] - e->colptr[j];
                 const uint32_t q0 = e->h_qptr[c0 + jj];
                 uint64_t pw = 0;
                 for (uint32_t pp = 0; pp < kj; ++pp) pw |= (uint64_t)e->h_pos[q0 + pp] << (8 * pp);
-                posj[(size_t)i * 8 + jj] = pw;
+                line[(size_t)i * 16 + 8 + jj] = pw;
             }
+            member[(size_t)i * 16 + 8] = c[i];
+            member[(size_t)i * 16 + 9] = e->h_gmu_b[i];
         }
         pdmp_status sg;
-        if ((sg = e->d_g8_sid.upload(sid)) != PDMP_OK) return sg;
-        if ((sg = e->d_g8_hw.upload(hwv)) != PDMP_OK) return sg;
-        if ((sg = e->d_g8_posj.upload(posj)) != PDMP_OK) return sg;
-        if ((sg = e->d_g8_gamt.upload(gamt)) != PDMP_OK) return sg;
-        if ((sg = e->d_g8_valj.upload(valj)) != PDMP_OK) return sg;
+        if ((sg = e->d_g8_line.upload(line)) != PDMP_OK) return sg;
+        if ((sg = e->d_g8_member.upload(member)) != PDMP_OK) return sg;
+        if (!same && (sg = e->d_g8_gamt.upload(gamt)) != PDMP_OK) return sg;
+        e->g8_same = same;
         e->has_g8 = true;
     }
     e->use_spec = pdmp::zz_spec_supported(e->nblk, mmax, kmax) && e->dbg_kernel != PDMP_DEBUG_KERNEL_SEQ &&
@@ -1315,11 +1317,9 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
     P.tix = e->d_tix.p;
     P.common_tix = e->common_tix;
     if (e->has_g8) {
-        P.g8_sid = e->d_g8_sid.p;
-        P.g8_hw = e->d_g8_hw.p;
-        P.g8_posj = e->d_g8_posj.p;
-        P.g8_gamt = e->d_g8_gamt.p;
-        P.g8_valj = e->d_g8_valj.p;
+        P.g8_line = e->d_g8_line.p;
+        P.g8_member = e->d_g8_member.p;
+        P.g8_gamt = e->g8_same ? nullptr : e->d_g8_gamt.p;
     }
     DevBuf<double> dbgbuf;
     const int64_t dbg_cap = e->dbg_dump;

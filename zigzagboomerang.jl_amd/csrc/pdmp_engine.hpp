@@ -172,12 +172,10 @@ struct ZzRunParams {
     int32_t track_two_sums;  // tracked-gradient kernel: the bounding Γ differs from the target's (two pairs of sums per coordinate)
     int32_t lattice_n;       // n if the graph is the n x n 5-point lattice in column-major numbering (i = row + n col), else 0
     uint32_t lattice_magic;  // ceil(2^32 / n): column of i = umulhi(i, magic) for i < 2^16
-    // per-coordinate tables of zz_local_spec8g_kernel (pdmp_spec8g.inc: |G1| <= 8, |S| <= 32), or null
-    const uint16_t* __restrict__ g8_sid;   // [d][8][4] S[i] transposed: lane gl's zone positions gl, gl + 8, gl + 16, gl + 24
-    const uint32_t* __restrict__ g8_hw;    // [d] k | m << 8 | self << 16
-    const uint64_t* __restrict__ g8_posj;  // [d][8] positions inside S[i] of the members of G1[j], j = G1[i][gl]
-    const double* __restrict__ g8_gamt;    // [d][8] Γt[G1[i], i]
-    const double* __restrict__ g8_valj;    // [d][8] Γ[G1[j], j]
+    // per-coordinate tables of zz_local_spec8g_kernel (pdmp_spec8g.inc: |G1| <= 8, |S| <= 32), one 128-byte line per coordinate each, or null
+    const uint64_t* __restrict__ g8_line;    // [d][16]: S[i] transposed (4 x u16 per lane) | positions inside S[i] of the members of G1[j], j = G1[i][gl]
+    const double* __restrict__ g8_member;    // [d][16]: Γ[G1[j], j] (8) | c_j | Γ[:,j]·μ | -
+    const double* __restrict__ g8_gamt;      // [d][8] Γt[G1[i], i] when the target's values differ from the bounding ones, else null
     // sticky ZigZag (src/ss_fact.jl)
     const double* __restrict__ kappa;  // [d] thaw rates
     double* thf;                       // [nchains x d] saved speeds θf
