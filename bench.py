@@ -54,7 +54,7 @@ def cpu_baseline_config(pkg, config, budget_s=12.0):
     """The CPU oracle (kind="port") on the secondary configurations: an ENSEMBLE of independent chains over a pool of host threads, one chain
     per thread (the chains the GPU ensemble starts with: same seeds), after one chain alone on one thread (the reference's own way of running:
     src/sfact.jl:199-208 is a sequential loop).  ctypes releases the GIL for the duration of a call, so a Python thread pool IS one C thread per chain.
-    Bounded sample: the chain length is chosen so that the pool runs for about `budget_s` seconds."""
+    Bounded sample: one chain alone for 1-2 seconds, then the pool with one chain of the same length per thread."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from concurrent.futures import ThreadPoolExecutor
     import oracle_lib as O
@@ -101,7 +101,10 @@ def cpu_baseline_config(pkg, config, budget_s=12.0):
         if s1 >= 1.0:
             break
         Ts *= min(30.0, 2.0 / max(s1, 1e-3))
-    T = float(Ts * budget_s / max(s1, 1e-3))
+    # the pool's chains run to the SAME length as the chain that was timed alone (a chain's cost per unit of process time is not constant --
+    # C5's sticky chains get several times more expensive after their first time unit -- and 16 threads that stream a 131 MB design share
+    # the host's memory bandwidth: extrapolating the length from the single run once made this leg take 20 minutes)
+    T = float(Ts)
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=nthr) as pool:
         evs = list(pool.map(lambda k: one(k, T), range(nthr)))
