@@ -34,6 +34,26 @@ DT_STEP = 1.0
 SEED0 = 0x5EED0000
 
 
+class _banner_to_stderr:
+    """parallel.c_stdout_to_stderr without importing the package first (torch must be imported before the engine library is loaded): RCCL prints its
+    version banner through C stdio on stdout; this line's stdout is ONE JSON line."""
+
+    def __enter__(self):
+        import ctypes
+        self._libc = ctypes.CDLL(None)
+        sys.stdout.flush()
+        self._libc.fflush(None)
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *a):
+        self._libc.fflush(None)
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def algorithmic_bytes(num, nacc):
     """224 B per proposal + 48 B per rejection + 616 B per accepted reflection."""
     return 224.0 * num + 48.0 * (num - nacc) + 616.0 * nacc
@@ -408,10 +428,13 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
-    comm = None  # the engine's own RCCL communicator (pdmp_comm_*): the default for N > 1 and for --gather -- no torch in the process
-    # test hooks (never set by the driver): run several ranks on ONE device with the gloo backend to exercise the N>1 path
-    # (RCCL refuses two ranks on one GPU); PDMP_BENCH_BACKEND=nccl selects torch.distributed over RCCL, the round-2 path
-    backend = os.environ.get("PDMP_BENCH_BACKEND", "engine")
+    comm = None  # the engine's own RCCL communicator (pdmp_comm_*): no torch in the process
+    # Which transport carries the barriers and the reductions of this line.  N = 1 (--gather): the engine's communicator.  N > 1: torch.distributed
+    # over RCCL ("nccl") by default -- neither path has run on more than one GPU yet (one GPU per build box; RCCL refuses two ranks on one device),
+    # and until the engine's has, the transport every ROCm node is exercised with daily carries the driver's scaling run; PDMP_BENCH_BACKEND=engine
+    # selects pdmp_comm_* for N > 1 (all-or-nothing rendezvous: it falls back to "nccl" on EVERY rank or on none), "gloo" is the test hook that
+    # lets several ranks share ONE device (PDMP_BENCH_SINGLE_DEVICE).  The run itself has no collective either way.
+    backend = os.environ.get("PDMP_BENCH_BACKEND", "engine" if world == 1 else "nccl")
     if os.environ.get("PDMP_BENCH_SINGLE_DEVICE"):
         local_rank = 0
     red_dev = "cpu"
@@ -420,7 +443,10 @@ def main():
         import torch.distributed as dist
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+            with _banner_to_stderr():  # (RCCL's version banner would land on this process's stdout, after the JSON line)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+                dist.barrier()  # the communicator is created here at the latest
+                torch.cuda.synchronize()
             red_dev = "cuda"
         else:
             dist.init_process_group(backend)
@@ -433,7 +459,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-            dist1.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+            with _banner_to_stderr():
+                dist1.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+                dist1.barrier()
+                torch.cuda.synchronize()
             red_dev = "cuda"
         else:
             dist1.init_process_group(backend, rank=0, world_size=1)
@@ -455,7 +484,10 @@ def main():
             import torch.distributed as dist
             backend = "nccl"
             torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            with _banner_to_stderr():
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                dist.barrier()
+                torch.cuda.synchronize()
             red_dev = "cuda"
     W = make_workload(pkg, args, rank, local_rank)
     ens, d, cap, nch = W["ens"], W["d"], W["cap"], args.chains

@@ -232,6 +232,30 @@ def exchange_unique_id(rank, world, make_id, addr=None, port=None, timeout=120.0
     raise RuntimeError("exchange_unique_id: rank %d could not reach rank 0 at %s:%s" % (rank, addr, cands))
 
 
+class c_stdout_to_stderr:
+    """RCCL prints a version banner on the C stdout of rank 0 while a communicator initialises (through C stdio: it sits in the buffer until the
+    process exits).  A benchmark's stdout is ONE JSON line, so for the duration of the initialising calls the C-level stdout points at stderr, and the
+    buffer is flushed before it is restored.  Used around pdmp_comm_init and around torch.distributed's first collective alike."""
+
+    def __enter__(self):
+        import ctypes as C
+        import os
+        import sys
+        self._libc = C.CDLL(None)
+        sys.stdout.flush()
+        self._libc.fflush(None)
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *a):
+        import os
+        self._libc.fflush(None)
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 class Comm:
     """pdmp_comm*: one RCCL communicator per (process, device)."""
 
@@ -247,22 +271,10 @@ class Comm:
             _lib.check(self._L.pdmp_comm_unique_id(buf, 128))
             return buf.raw
 
-        # RCCL prints a version banner on the C stdout of rank 0 while it initialises; a benchmark's stdout is one JSON line, so the C-level
-        # stdout points at stderr for the duration of the two calls (and is flushed before it is restored)
-        import os
-        import sys
-        libc = C.CDLL(None)
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
+        with c_stdout_to_stderr():  # (RCCL's banner: see there)
             uid = exchange_unique_id(self.rank, self.world, make_id, addr, port)
             h = C.c_void_p()
             _lib.check(self._L.pdmp_comm_init(uid, self.rank, self.world, self.device, C.byref(h)))
-        finally:
-            libc.fflush(None)
-            os.dup2(saved, 1)
-            os.close(saved)
         self._h = h
 
     def close(self):
