@@ -155,3 +155,55 @@ def test_generic_graph_full_width(gpu_pkg):
                 rt = O.spdmp_zigzag(G, None, G, x0, th0, c, T, seed=0x5EED0000 + q, stop_before_T=True, tracked=True)
                 fa = ens.final_state(q, 1)
                 check_chain_bitwise(ens.trace(q, counters=cnt), fa["t"][0], fa["x"][0], fa["theta"][0], fa["acc"][0], cnt["num"][q], None, rt)
+
+
+def adversarial(pkg, which):
+    """Graphs that stress the zone logic of the speculative kernels: many events of one iteration are neighbours (distance 1) or share a neighbour
+    (distance 2)."""
+    if which == "cliques8":      # d / 8 complete graphs K8: |G1| = |S| = 8, every pair inside a clique conflicts
+        n = 320
+        B = sp.kron(sp.identity(n, format="csc"), sp.csc_matrix(-0.3 * (np.ones((8, 8)) - np.eye(8))), format="csc")
+    elif which == "path":        # tridiagonal: |G1| <= 3, |S| <= 5 (not the 2-d lattice's blob geometry)
+        d = 2400
+        B = sp.diags([-np.ones(d - 1), -np.ones(d - 1)], [-1, 1], format="csc")
+    elif which == "triangular":  # 6 neighbours: the 50 x 50 triangular lattice, |G1| = 7, |S| = 19
+        n = 50
+        idx = np.arange(n * n).reshape(n, n)
+        pairs = [(idx[:, :-1], idx[:, 1:]), (idx[:-1, :], idx[1:, :]), (idx[:-1, :-1], idx[1:, 1:])]
+        a = np.concatenate([p[0].ravel() for p in pairs])
+        b = np.concatenate([p[1].ravel() for p in pairs])
+        W = sp.coo_matrix((-np.ones(a.size), (a, b)), shape=(n * n, n * n))
+        B = sp.csc_matrix(W + W.T)
+    else:
+        raise KeyError(which)
+    G = sp.csc_matrix(B + sp.diags(0.05 - np.asarray(B.sum(axis=0)).ravel()))
+    G.sort_indices()
+    return G
+
+
+@pytest.mark.parametrize("which,T", [("cliques8", 6.0), ("path", 8.0), ("triangular", 5.0)])
+@pytest.mark.parametrize("tracked", [True, False])
+def test_adversarial_graphs_both_evaluations(gpu_pkg, which, T, tracked):
+    """Cliques of 8, a path and the triangular lattice on the one-proposal-per-lane tracked kernel and on the 8-event kernel of the moving evaluation
+    (`zz_local_spec8g_kernel`): bit for bit their oracles."""
+    pkg = gpu_pkg
+    G = adversarial(pkg, which)
+    d = G.shape[0]
+    assert np.diff(G.indptr).max() <= 8 and abs(G - G.T).max() == 0
+    rng = np.random.default_rng(17)
+    nch = 3
+    x0 = rng.standard_normal((nch, d))
+    th0 = rng.choice([-1.0, 1.0], (nch, d))
+    c = pkg.problems.column_norms(G)
+    tr, (t, x, th), (acc, num), _ = pkg.spdmp(pkg.GaussianTarget(G), 0.0, x0, th0, T, c, pkg.ZigZag(G, np.zeros(d)), seed=1700, tracked=tracked)
+    with pkg.Ensemble(1, d) as ens:
+        ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
+        ens.set_target(pkg.GaussianTarget(G))
+        ens.set_gradient_tracking(tracked)
+        ens.set_state_synthetic(0.0, c, 1)
+        ens.run(0.05)
+        assert ens.kernel_name() == ("zz_local_trackp_kernel<LAT=false>" if tracked else "zz_local_spec8g_kernel")
+    for q in range(nch):
+        r = O.spdmp_zigzag(G, None, G, x0[q], th0[q], c, T, seed=1700 + q, tracked=tracked)
+        assert r["status"] == 0 and len(r["events"]) > 1000
+        check_chain_bitwise(tr[q].events, t[q], x[q], th[q], acc[q], num[q], None, r)

@@ -834,7 +834,8 @@ static pdmp_status build_blob(pdmp_ensemble* e, const double* c) {
     // eight events per iteration off the lattice: per-coordinate tables instead of blob templates (pdmp_spec8g.inc)
     e->has_g8 = false;
     e->g8_same = false;
-    if (kmax <= 8 && mmax <= 32 && d >= 2048 && d <= 16384 && !(kmax <= 5 && mmax <= 13)) {
+    // (every graph of that size whose blob geometry is not EXACTLY the 2-d lattice's, which zz_local_spec8_kernel serves from LDS templates)
+    if (kmax <= 8 && mmax <= 32 && d >= 2048 && d <= 16384 && !(SW == 7 && PW == 1 && kmax == 5 && Wpad == 58)) {
         std::vector<uint64_t> line((size_t)d * 16, 0ull);
         std::vector<double> member((size_t)d * 16, 0.0), gamt((size_t)d * 8, 0.0);
         bool same = true;
