@@ -64,6 +64,36 @@ def test_wide_zones_small_d_loose_bound_mean_adapt(gpu_pkg):
     run_case(pkg, G, G, rng.standard_normal((2, d)), rng.choice([-1.0, 1.0], (2, d)), pkg.problems.column_norms(G), 15.0, seed=42)
 
 
+def test_eight_event_kernel_with_adaptation_and_a_target_mean(gpu_pkg, kernel_mode):
+    """zz_local_spec8g_kernel<.., FULL>: `adapt` with bounds that start too small under a bounding Γ = 0.9 Γ (own coefficient table), and a target
+    mean with the bounding Γ equal to the target's (coefficients from the member lines), at d = 2197 / 2500."""
+    pkg = gpu_pkg
+    for which in ("lattice3d", "random6"):
+        G = graphs(pkg, which)
+        d = G.shape[0]
+        rng = np.random.default_rng(21)
+        mu = 0.3 * rng.standard_normal(d)
+        x0, th0 = rng.standard_normal((2, d)), rng.choice([-1.0, 1.0], (2, d))
+        run_case(pkg, G, sp.csc_matrix(0.9 * G), x0, th0, 0.2 * pkg.problems.column_norms(G), 4.0, seed=61, adapt=True, target_mu=mu)
+        Z = pkg.ZigZag(G, mu)
+        c = pkg.problems.column_norms(G)
+        tr, fs, (acc, num), _ = pkg.spdmp(pkg.GaussianTarget(G, mu), 0.0, x0, th0, 3.0, c, Z, seed=62)
+        for k in range(2):
+            r = O.spdmp_zigzag(G, mu, G, x0[k], th0[k], c, 3.0, seed=62 + k, target_mu=mu)
+            ev = tr[k].events
+            assert len(ev) == len(r["events"]) and int(num[k]) == r["num"]
+            for f in ("i", "t", "x", "theta"):
+                assert np.array_equal(ev[f], r["events"][f]), f
+            assert np.array_equal(fs[1][k], r["x"]) and np.array_equal(fs[0][k], r["t"])
+    if kernel_mode == "spec":
+        with pkg.Ensemble(1, d, adapt=True) as ens:
+            ens.set_flow(pkg.ZigZag(sp.csc_matrix(0.9 * G), np.zeros(d)))
+            ens.set_target(pkg.GaussianTarget(G, mu))
+            ens.set_state_synthetic(0.0, pkg.problems.column_norms(G), 1)
+            ens.run(0.1)
+            assert ens.kernel_name() == "zz_local_spec8g_kernel"
+
+
 def test_wide_zones_slices_and_trace_refills(gpu_pkg):
     pkg = gpu_pkg
     L = pkg._lib
