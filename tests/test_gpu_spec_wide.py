@@ -64,6 +64,30 @@ def test_wide_zones_small_d_loose_bound_mean_adapt(gpu_pkg):
     run_case(pkg, G, G, rng.standard_normal((2, d)), rng.choice([-1.0, 1.0], (2, d)), pkg.problems.column_norms(G), 15.0, seed=42)
 
 
+def test_two_hop_sets_up_to_64_four_events_per_iteration(gpu_pkg, kernel_mode):
+    """33 <= |S| <= 64 (a random pattern with up to 8 entries per column: |S| <= 50; cliques of 8 joined in a ring: |S| = 24 .. ): zz_local_spec8g_kernel<GW = 16>,
+    four events per iteration in 16-lane groups, against the oracle bit for bit -- plain, with a bounding Γ of its own, and with adaptation + a target mean."""
+    pkg = gpu_pkg
+    G = graphs(pkg, "random8")
+    d = G.shape[0]
+    B = (abs(G) > 0).astype(np.int64)
+    mmax = int(np.diff((B @ B).tocsc().indptr).max())
+    assert 32 < mmax <= 64
+    rng = np.random.default_rng(33)
+    x0, th0 = rng.standard_normal((3, d)), rng.choice([-1.0, 1.0], (3, d))
+    c = pkg.problems.column_norms(G)
+    run_case(pkg, G, G, x0, th0, c, 4.0, seed=2100)
+    run_case(pkg, G, sp.csc_matrix(1.2 * G), x0[:2], th0[:2], 1.2 * c, 2.0, seed=2200)
+    mu = 0.3 * rng.standard_normal(d)
+    run_case(pkg, G, sp.csc_matrix(0.9 * G), x0[:2], th0[:2], 0.2 * c, 3.0, seed=2300, adapt=True, target_mu=mu)
+    with pkg.Ensemble(1, d) as ens:
+        ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
+        ens.set_target(pkg.GaussianTarget(G))
+        ens.set_state_synthetic(0.0, c, 1)
+        ens.run(0.1)
+        assert ens.kernel_name() == ("zz_local_spec8g_kernel<GW=16>" if kernel_mode == "spec" else "zz_local_run_kernel")
+
+
 def test_eight_event_kernel_with_adaptation_and_a_target_mean(gpu_pkg, kernel_mode):
     """zz_local_spec8g_kernel<.., FULL>: `adapt` with bounds that start too small under a bounding Γ = 0.9 Γ (own coefficient table), and a target
     mean with the bounding Γ equal to the target's (coefficients from the member lines), at d = 2197 / 2500."""
@@ -134,21 +158,24 @@ def test_eight_event_kernel_at_c3g_width(gpu_pkg, kernel_mode):
     if kernel_mode == "seq":
         pytest.skip("the one-event kernel at this width takes minutes and is covered at d = 2197")
     pkg = gpu_pkg
-    for G in (pkg.problems.lattice3d_precision(25), pkg.problems.random_sparse_precision(16384, 6)):
+    for gi, G in enumerate((pkg.problems.lattice3d_precision(25), pkg.problems.random_sparse_precision(16384, 6), pkg.problems.random_sparse_precision(16384, 8))):
         d = G.shape[0]
         c = pkg.problems.column_norms(G)
-        nch, T = 4096, 0.25
+        nch, T = 4096, (0.25 if gi < 2 else 0.1)
         with pkg.Ensemble(nch, d, trace_capacity=int(1.5 * d * T) + 1024) as ens:
             ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
             ens.set_target(pkg.GaussianTarget(G))
             ens.set_state_synthetic(0.0, c, 0x5EED0000)
             ens.run(T, pkg._lib.RUN_STOP_BEFORE)
-            assert ens.kernel_name() == ("zz_local_spec8g_kernel" if kernel_mode == "spec" else "zz_local_spec_kernel<WIDE>")
+            # (|S| <= 50 on the third graph: four events per iteration in 16-lane groups, or -- the only other kernel there -- one event per iteration)
+            want = (("zz_local_spec8g_kernel<GW=16>" if gi == 2 else "zz_local_spec8g_kernel") if kernel_mode == "spec" else
+                    ("zz_local_run_kernel" if gi == 2 else "zz_local_spec_kernel<WIDE>"))
+            assert ens.kernel_name() == want
             cnt = ens.counters()
             assert np.all(cnt["status"] == pkg._lib.CHAIN_OK)
-            key = (d, int(cnt["num"].sum()), int(cnt["nacc"].sum()), int(cnt["ndraw_main"].sum()))
-            _WIDTH_TOTALS.setdefault(d, set()).add(key)
-            assert len(_WIDTH_TOTALS[d]) == 1, _WIDTH_TOTALS[d]  # (both kernels: the same proposals, reflections and draws over all 4096 chains)
+            key = (gi, int(cnt["num"].sum()), int(cnt["nacc"].sum()), int(cnt["ndraw_main"].sum()))
+            _WIDTH_TOTALS.setdefault(gi, set()).add(key)
+            assert len(_WIDTH_TOTALS[gi]) == 1, _WIDTH_TOTALS[gi]  # (both kernels: the same proposals, reflections and draws over all 4096 chains)
             for q in (0, nch - 1):
                 x0, th0 = O.synthetic_state(0x5EED0000 + q, d)
                 r = O.spdmp_zigzag(G, None, G, x0, th0, c, T, seed=0x5EED0000 + q, stop_before_T=True)

@@ -124,6 +124,7 @@ struct pdmp_ensemble {
     DevBuf<double> d_kp;
     // zz_local_spec8g_kernel's tables (any graph with |G1| <= 8, |S| <= 32; built with the blob)
     bool has_g8 = false, g8_same = false;
+    int g8_gw = 8;  // lanes per event of zz_local_spec8g_kernel: 8 (|S| <= 32) or 16 (|S| <= 64)
     DevBuf<uint64_t> d_g8_line;
     DevBuf<double> d_g8_member, d_g8_gamt;
     bool track_generic = false;  // ... on a graph that is not the plain lattice: G1 ids in the records, Γ values in d_gam8 (|G1| <= 8)
@@ -835,17 +836,21 @@ static pdmp_status build_blob(pdmp_ensemble* e, const double* c) {
     e->has_g8 = false;
     e->g8_same = false;
     // (every graph of that size whose blob geometry is not EXACTLY the 2-d lattice's, which zz_local_spec8_kernel serves from LDS templates)
-    if (kmax <= 8 && mmax <= 32 && d >= 2048 && d <= 16384 && !(SW == 7 && PW == 1 && kmax == 5 && Wpad == 58)) {
-        std::vector<uint64_t> line((size_t)d * 16, 0ull);
+    e->g8_gw = 8;
+    if (kmax <= 8 && mmax <= 64 && d >= 2048 && d <= 16384 && !(SW == 7 && PW == 1 && kmax == 5 && Wpad == 58)) {
+        // 8 lanes per event (eight events per iteration) up to |S| = 32, 16 lanes (four events) up to 64: a lane owns zone positions gl + q GW
+        const uint32_t GW = (mmax <= 32) ? 8u : 16u, LSTR = GW + 8u;
+        e->g8_gw = (int)GW;
+        std::vector<uint64_t> line((size_t)d * LSTR, 0ull);
         std::vector<double> member((size_t)d * 16, 0.0), gamt((size_t)d * 8, 0.0);
         bool same = true;
         for (int64_t i = 0; i < d; ++i) {
             const uint32_t c0 = e->colptr[i], k = e->colptr[i + 1] - c0;
             const uint32_t s0 = e->h_sptr[i], m = e->h_sptr[i + 1] - s0;
-            uint16_t ids[32];
-            for (uint32_t w = 0; w < 32; ++w) ids[w] = (w < m) ? (uint16_t)(e->h_sidx[s0 + w] | (w < k ? 0x8000u : 0u)) : (uint16_t)0x7FFF;
-            for (uint32_t gl = 0; gl < 8; ++gl)
-                line[(size_t)i * 16 + gl] = (uint64_t)ids[gl] | ((uint64_t)ids[gl + 8] << 16) | ((uint64_t)ids[gl + 16] << 32) | ((uint64_t)ids[gl + 24] << 48);
+            uint16_t ids[64];
+            for (uint32_t w = 0; w < 4 * GW; ++w) ids[w] = (w < m) ? (uint16_t)(e->h_sidx[s0 + w] | (w < k ? 0x8000u : 0u)) : (uint16_t)0x7FFF;
+            for (uint32_t gl = 0; gl < GW; ++gl)
+                line[(size_t)i * LSTR + gl] = (uint64_t)ids[gl] | ((uint64_t)ids[gl + GW] << 16) | ((uint64_t)ids[gl + 2 * GW] << 32) | ((uint64_t)ids[gl + 3 * GW] << 48);
             for (uint32_t jj = 0; jj < k; ++jj) {
                 gamt[(size_t)i * 8 + jj] = e->h_tval[c0 + jj];
                 member[(size_t)i * 16 + jj] = e->bval[c0 + jj];
@@ -855,7 +860,7 @@ static pdmp_status build_blob(pdmp_ensemble* e, const double* c) {
                 const uint32_t q0 = e->h_qptr[c0 + jj];
                 uint64_t pw = 0;
                 for (uint32_t pp = 0; pp < kj; ++pp) pw |= (uint64_t)e->h_pos[q0 + pp] << (8 * pp);
-                line[(size_t)i * 16 + 8 + jj] = pw;
+                line[(size_t)i * LSTR + GW + jj] = pw;
             }
             member[(size_t)i * 16 + 8] = c[i];
             member[(size_t)i * 16 + 9] = e->h_gmu_b[i];
@@ -1321,6 +1326,7 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         P.g8_line = e->d_g8_line.p;
         P.g8_member = e->d_g8_member.p;
         P.g8_gamt = e->g8_same ? nullptr : e->d_g8_gamt.p;
+        P.g8_gw = e->g8_gw;
     }
     DevBuf<double> dbgbuf;
     const int64_t dbg_cap = e->dbg_dump;
@@ -1360,7 +1366,9 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
     const bool phenv = e->dbg_phase != 0;
     e->dbg_phase_valid = 0;
     DevBuf<double> phbuf;
-    const bool spec_ok = e->use_spec && dbg_cap == 0 && !P.has_refresh && !P.move_all && !sticky;
+    // (33 <= |S| <= 64: no blob kernel takes it, but zz_local_spec8g_kernel<.., GW = 16> does where its own conditions hold)
+    const bool g16_ok = e->has_g8 && e->g8_gw == 16 && e->dbg_kernel == PDMP_DEBUG_KERNEL_AUTO && (P.flags & 0x100) && !phenv;
+    const bool spec_ok = (e->use_spec || g16_ok) && dbg_cap == 0 && !P.has_refresh && !P.move_all && !sticky;
     const bool general_path = e->needs_general || e->target_kind == 1 || e->adaptscale || e->local_bound;
     if (phenv && (spec_ok || general_path)) {
         pdmp_status st3 = phbuf.alloc(16);

@@ -176,6 +176,7 @@ struct ZzRunParams {
     const uint64_t* __restrict__ g8_line;    // [d][16]: S[i] transposed (4 x u16 per lane) | positions inside S[i] of the members of G1[j], j = G1[i][gl]
     const double* __restrict__ g8_member;    // [d][16]: Γ[G1[j], j] (8) | c_j | Γ[:,j]·μ | -
     const double* __restrict__ g8_gamt;      // [d][8] Γt[G1[i], i] when the target's values differ from the bounding ones, else null
+    int32_t g8_gw;                           // lanes per event: 8 (line = 16 words) or 16 (|S| up to 64: line = 24 words)
     // sticky ZigZag (src/ss_fact.jl)
     const double* __restrict__ kappa;  // [d] thaw rates
     double* thf;                       // [nchains x d] saved speeds θf

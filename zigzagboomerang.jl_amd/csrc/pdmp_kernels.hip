@@ -4060,18 +4060,25 @@ int launch_zz_local_spec(const ZzRunParams& p, int64_t nchains, void* stream, co
     const bool wide = p.blob_sw > 8;  // |S[i]| up to 32: two zone members per lane
     // eight events per iteration on any graph with |G1| <= 8, |S| <= 32 (tables built by the host when the geometry fits), plain configuration
     const bool spec8g = !spec8 && p.g8_line != nullptr && (p.flags & 0x100) && !p.has_refresh && p.d >= 2048 && p.d <= (int64_t)S8_NBLK * 32 && !p.force_spec4;
-    if (kname) *kname = spec8 ? "zz_local_spec8_kernel" : spec8g ? "zz_local_spec8g_kernel" : wide ? "zz_local_spec_kernel<WIDE>" : "zz_local_spec_kernel";
+    if (kname) *kname = spec8 ? "zz_local_spec8_kernel" : spec8g ? (p.g8_gw == 16 ? "zz_local_spec8g_kernel<GW=16>" : "zz_local_spec8g_kernel") : wide ? "zz_local_spec_kernel<WIDE>" : "zz_local_spec_kernel";
     if (spec8g) {
         ZzRunParams q = p;
         q.nblk = (uint32_t)((p.d + 31) / 32);
         const bool same = p.g8_gamt == nullptr;  // the target's Γ values are the bounding ones: the gradient's coefficients come from the member lines
-        if (!plain_cfg) {  // adaptation and / or a target mean
-            if (same) hipLaunchKernelGGL((zz_local_spec8g_kernel<false, true, true>), grid, block, zz_spec8g_lds_bytes(), (hipStream_t)stream, q);
-            else hipLaunchKernelGGL((zz_local_spec8g_kernel<false, false, true>), grid, block, zz_spec8g_lds_bytes(), (hipStream_t)stream, q);
-        } else if (p.dbg && same) hipLaunchKernelGGL((zz_local_spec8g_kernel<true, true>), grid, block, zz_spec8g_lds_bytes(), (hipStream_t)stream, q);
-        else if (p.dbg) hipLaunchKernelGGL((zz_local_spec8g_kernel<true, false>), grid, block, zz_spec8g_lds_bytes(), (hipStream_t)stream, q);
-        else if (same) hipLaunchKernelGGL((zz_local_spec8g_kernel<false, true>), grid, block, zz_spec8g_lds_bytes(), (hipStream_t)stream, q);
-        else hipLaunchKernelGGL((zz_local_spec8g_kernel<false, false>), grid, block, zz_spec8g_lds_bytes(), (hipStream_t)stream, q);
+        const size_t l8 = zz_spec8g_lds_bytes();
+        const hipStream_t st_ = (hipStream_t)stream;
+        if (p.g8_gw == 16) {  // four events per iteration, |S| up to 64
+            if (!plain_cfg && same) hipLaunchKernelGGL((zz_local_spec8g_kernel<false, true, true, 16>), grid, block, l8, st_, q);
+            else if (!plain_cfg) hipLaunchKernelGGL((zz_local_spec8g_kernel<false, false, true, 16>), grid, block, l8, st_, q);
+            else if (same) hipLaunchKernelGGL((zz_local_spec8g_kernel<false, true, false, 16>), grid, block, l8, st_, q);
+            else hipLaunchKernelGGL((zz_local_spec8g_kernel<false, false, false, 16>), grid, block, l8, st_, q);
+        } else if (!plain_cfg) {  // adaptation and / or a target mean
+            if (same) hipLaunchKernelGGL((zz_local_spec8g_kernel<false, true, true>), grid, block, l8, st_, q);
+            else hipLaunchKernelGGL((zz_local_spec8g_kernel<false, false, true>), grid, block, l8, st_, q);
+        } else if (p.dbg && same) hipLaunchKernelGGL((zz_local_spec8g_kernel<true, true>), grid, block, l8, st_, q);
+        else if (p.dbg) hipLaunchKernelGGL((zz_local_spec8g_kernel<true, false>), grid, block, l8, st_, q);
+        else if (same) hipLaunchKernelGGL((zz_local_spec8g_kernel<false, true>), grid, block, l8, st_, q);
+        else hipLaunchKernelGGL((zz_local_spec8g_kernel<false, false>), grid, block, l8, st_, q);
         return (int)hipGetLastError();
     }
     if (wide) {
