@@ -21,9 +21,9 @@ MAIN = {"C3": "zz_local_track", "C3X": "zz_local_spec8_kernel", "C2": "bps_run_k
         "C4T": "zz_logistic_lds_kernel", "C5": "zz_general_run_kernel",
         # config C3G (graphs that are not the 2-d lattice): tracked / moving evaluation on the 3-d lattice and on a random pattern
         "C3G": "zz_local_trackp_kernel", "C3GX": "zz_local_spec8g_kernel", "C3G_random6": "zz_local_trackp_kernel",
-        "C3GX_random6": "zz_local_spec8g_kernel", "C3G_random8": "zz_local_trackp_kernel"}
+        "C3GX_random6": "zz_local_spec8g_kernel", "C3G_random8": "zz_local_trackp_kernel", "C3GX_random8": "zz_local_spec8g_kernel"}
 CMD = {"C3X": "C3 --exact", "C4T": "C4 --tracked", "C3G": "C3G", "C3GX": "C3G --exact", "C3G_random6": "C3G --graph random6",
-       "C3GX_random6": "C3G --graph random6 --exact", "C3G_random8": "C3G --graph random8"}
+       "C3GX_random6": "C3G --graph random6 --exact", "C3G_random8": "C3G --graph random8", "C3GX_random8": "C3G --graph random8 --exact"}
 
 
 def rows(path):

@@ -6,14 +6,14 @@
 #   tools/profile_collect.py (run here, copied into profiles/ by the caller).
 set -u
 TAG=$1; shift
-CONFIGS=${@:-C3 C3X C3G C3GX C3G_random6 C3GX_random6 C3G_random8 C2 C4 C4T C5}   # C3X = C3 on the bit-identical moving kernel (bench.py --exact); C4T = C4 with tracked bounds (--tracked); C3G* = graphs off the 2-d lattice
+CONFIGS=${@:-C3 C3X C3G C3GX C3G_random6 C3GX_random6 C3G_random8 C3GX_random8 C2 C4 C4T C5}   # C3X = C3 on the bit-identical moving kernel (bench.py --exact); C4T = C4 with tracked bounds (--tracked); C3G* = graphs off the 2-d lattice
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 for C in $CONFIGS; do
-  case $C in C3|C3X) ST=8;; C3G|C3G_random6|C3G_random8) ST=6;; C3GX|C3GX_random6) ST=3;; C2) ST=8;; C4|C4T) ST=6;; C5) ST=4;; esac
+  case $C in C3|C3X) ST=8;; C3G|C3G_random6|C3G_random8) ST=6;; C3GX|C3GX_random6|C3GX_random8) ST=3;; C2) ST=8;; C4|C4T) ST=6;; C5) ST=4;; esac
   ARGS="--config $C --steps $ST --warmup 2 --no-cpu-baseline --ess-batches 0 --exact-steps 0"
   if [ "$C" = C3X ]; then ARGS="--config C3 --exact --steps $ST --warmup 2 --no-cpu-baseline --ess-batches 0 --exact-steps 0"; fi
   if [ "$C" = C4T ]; then ARGS="--config C4 --tracked --steps $ST --warmup 2 --no-cpu-baseline --ess-batches 0 --exact-steps 0"; fi
@@ -23,6 +23,7 @@ for C in $CONFIGS; do
     C3G_random6) ARGS="--config C3G --graph random6 --steps $ST --warmup 2 --no-cpu-baseline";;
     C3GX_random6) ARGS="--config C3G --graph random6 --exact --steps $ST --warmup 1 --no-cpu-baseline";;
     C3G_random8) ARGS="--config C3G --graph random8 --steps $ST --warmup 2 --no-cpu-baseline";;
+    C3GX_random8) ARGS="--config C3G --graph random8 --exact --steps $ST --warmup 1 --no-cpu-baseline";;
   esac
   python $ROOT/bench.py $ARGS 2>/dev/null | grep '^{' > "$OUT/${C}_bench.json"
   timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/${C}_stats" -o st --output-format csv -- python $ROOT/bench.py $ARGS > "$OUT/${C}_stats.log" 2>&1
