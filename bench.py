@@ -734,7 +734,7 @@ def main():
             nev_g = int(sum(int(c.sum().item()) for c in counts_by_rank))
             assert sum(int(t.shape[0]) for t in gathered) == nev_g
             gather = {"seconds": tg, "events": nev_g, "bytes": 32 * nev_g, "GBps": 32 * nev_g / tg / 1e9,
-                      "chains": int(sum(c.numel() for c in counts_by_rank)), "staging": staging,
+                      "chains": int(sum(c.numel() for c in counts_by_rank)), "staging": staging, "backend": "torch.distributed " + backend,
                       "steps": "all_gather(counts) -> grouped isend/irecv of the trace segments to rank 0 -> reduce(SUM) of 2 x d sums",
                       "first_event_time_rank_last": float(gathered[-1][0, 0].item()) if gathered[-1].shape[0] else None,
                       "mean_of_batch_means": float(np.mean(sy) / (nch * world))}

@@ -222,3 +222,22 @@ def test_bps_gather_returns_every_event_in_chain_order(gpu_pkg):
                 assert np.array_equal(t[at:at + n], tk) and np.array_equal(x[at:at + n], xk) and np.array_equal(th[at:at + n], thk)
                 at += n
             assert at == len(t)
+
+
+def test_bench_over_torch_nccl_launched_by_torchrun(gpu_pkg):
+    """The transport the driver's N > 1 runs use by default (torch.distributed, backend nccl = RCCL), launched the way the driver launches it
+    (torch.distributed.run), at the only world size one GPU allows: barriers, the max-over-ranks reduction and the timed exchange on RCCL;
+    RCCL's version banner must not reach stdout (ONE JSON line)."""
+    env = dict(os.environ)
+    env["PDMP_BENCH_BACKEND"] = "nccl"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--ess-batches", "0",
+           "--chains", "256", "--gather"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["unhealthy_chains"] == 0 and out["value"] > 0
+    g = out["gather"]
+    assert g["events"] > 0 and g["chains"] == 256 and g["bytes"] == 32 * g["events"] and "nccl" in g["backend"]

@@ -12,7 +12,7 @@ from __graft_entry__ import load_package  # noqa: E402
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C4"
 pkg = load_package()
-ap = argparse.Namespace(config=cfg, chains=bench.CONFIG_DEFAULTS[cfg]["chains"], dt=bench.CONFIG_DEFAULTS[cfg]["dt"], grid=128, no_trace=False, exact=False)
+ap = argparse.Namespace(config=cfg, chains=bench.CONFIG_DEFAULTS[cfg]["chains"], dt=bench.CONFIG_DEFAULTS[cfg]["dt"], grid=128, no_trace=False, exact=False, gather=False, tracked=False, graph="lattice3d")
 W = bench.make_workload(pkg, ap, 0, 0)
 ens = W["ens"]
 L = pkg._lib

@@ -944,12 +944,9 @@ extern "C" pdmp_status pdmp_ensemble_set_target_logistic(pdmp_ensemble* e, int64
             c.k = e->colptr[(size_t)j + 1] - c.cp0;
             c.sp0 = e->h_sptr[(size_t)j];
             c.m = e->h_sptr[(size_t)j + 1] - c.sp0;
-            c.self = 0;
-            for (uint32_t q = 0; q < c.k; ++q)
-                if (e->rowval[c.cp0 + q] == (uint32_t)j) c.self = q;
             c.l = (uint32_t)(A_colptr[j + 1] - A_colptr[j]);
             c.r0 = (uint32_t)A_colptr[j];
-            c.pad = 0;
+            c.lk = (double)c.l / (double)(uint32_t)k_sub;
         }
         std::vector<pdmp::LgObs> ho((size_t)n);
         memset(ho.data(), 0, ho.size() * sizeof(pdmp::LgObs));

@@ -176,7 +176,7 @@ pdmp_status agree(pdmp_comm* c, pdmp_status local) {
     C_HIP(hipMemcpyAsync(&any, dv + 1, sizeof any, hipMemcpyDeviceToHost, c->stream));
     C_HIP(hipStreamSynchronize(c->stream));
     if (local != PDMP_OK) return local;  // (this rank's own message stays in pdmp_last_error)
-    if (any) return cfail(PDMP_ERR_INVALID, "the gather was refused on another rank (its output buffers are too small or an allocation failed there); nothing was exchanged");
+    if (any) return cfail(PDMP_ERR_INVALID, "the exchange was refused on another rank (an argument check or an allocation failed there); nothing was exchanged");
     return PDMP_OK;
 }
 
@@ -432,9 +432,11 @@ pdmp_status pdmp_ensemble_reduce_moments(pdmp_ensemble* ens, pdmp_comm* c, int r
     if (st != PDMP_OK) return st;
     if (dev != c->device) return cfail(PDMP_ERR_INVALID, "the ensemble lives on device %d, the communicator on %d", dev, c->device);
     std::vector<double> h((size_t)(2 * d));
-    if ((st = pdmp_ensemble_batch_means(ens, T_prev, T, h.data(), h.data() + d)) != PDMP_OK) return st;
     C_HIP(hipSetDevice(c->device));
-    if ((st = c->red.need((size_t)(2 * d) * sizeof(double))) != PDMP_OK) return st;
+    // (what can fail on ONE rank -- its consumer is not armed, its interval is empty, an allocation -- is voted on before the reduction)
+    pdmp_status local = pdmp_ensemble_batch_means(ens, T_prev, T, h.data(), h.data() + d);
+    if (local == PDMP_OK) local = c->red.need((size_t)(2 * d) * sizeof(double));
+    if ((st = agree(c, local)) != PDMP_OK) return st;
     C_HIP(hipMemcpyAsync(c->red.p, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     C_NCCL(ncclReduce(c->red.p, c->red.p, (size_t)(2 * d), ncclDouble, ncclSum, root, c->comm, c->stream));
     if (c->rank == root) C_HIP(hipMemcpyAsync(h.data(), c->red.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));

@@ -273,8 +273,8 @@ int launch_zz_general_run(const ZzRunParams& p, const ZzGeneralParams& q, int64_
 struct LgCoord {  // everything a proposal needs that depends on the coordinate alone
     uint32_t cp0, k;    // column of the bounding Γ: G1[i] = rowval[cp0 .. cp0 + k)
     uint32_t sp0, m;    // S[i] = sidx[sp0 .. sp0 + m) = G1[i] followed by G2[i]
-    uint32_t self, l;   // position of i inside G1[i]; observations with a non-zero entry in column i of the design A
-    uint32_t r0, pad;   // they are a_row / a_val [r0 .. r0 + l)
+    uint32_t l, r0;     // observations with a non-zero entry in column i of the design A: a_row / a_val [r0 .. r0 + l)
+    double lk;          // l / k_sub, the weight of a sampled observation (scripts/logistic.jl:85: the same IEEE division, done once on the host)
 };
 static_assert(sizeof(LgCoord) == 32, "one sector");
 struct alignas(128) LgObs {  // one observation (a column of A'): scripts/logistic.jl:86-93

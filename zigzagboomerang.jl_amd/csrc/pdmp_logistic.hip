@@ -219,6 +219,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     // s1 += px[z0 .. z1), s2 += pt[z0 .. z1) in order: the LDS reads of 8 terms are issued together, the adds stay sequential
     auto run_sums = [&](uint32_t z0, uint32_t z1, double& s1, double& s2) {
         uint32_t z = z0;
+#pragma unroll 1
         for (; z + 8 <= z1; z += 8) {
             double u[8], w[8];
 #pragma unroll
@@ -249,6 +250,47 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
     };
 
+    // the same sums over px[0 .. n), pt[0 .. n) for a WAVE-UNIFORM n (the proposal's own re-bound: |G1[i]|, 3 at the median): the remainder past the
+    // last full group of 8 is added under scalar branches -- the predicated form above costs 16 adds and 32 selects whatever the remainder is
+    auto run_sums_uniform = [&](uint32_t n, double& s1, double& s2) {
+        const uint32_t n8 = n & ~7u;
+        if (n8) run_sums(0u, n8, s1, s2);
+        const uint32_t rem = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n - n8));
+#define LG_ADD(q)   \
+    do {            \
+        s1 += u[q]; \
+        s2 += w[q]; \
+    } while (0)
+        if (rem) {  // (four at a time: the kernel sits at its register limit)
+            double u[4], w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                u[q] = px[(n8 + q) & (LG_PCH - 1)];
+                w[q] = pt[(n8 + q) & (LG_PCH - 1)];
+            }
+            switch (rem) {
+                case 1: LG_ADD(0); break;
+                case 2: LG_ADD(0); LG_ADD(1); break;
+                case 3: LG_ADD(0); LG_ADD(1); LG_ADD(2); break;
+                default: LG_ADD(0); LG_ADD(1); LG_ADD(2); LG_ADD(3); break;
+            }
+        }
+        if (rem > 4u) {
+            double u[3], w[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                u[q] = px[(n8 + 4 + q) & (LG_PCH - 1)];
+                w[q] = pt[(n8 + 4 + q) & (LG_PCH - 1)];
+            }
+            switch (rem) {
+                case 5: LG_ADD(0); break;
+                case 6: LG_ADD(0); LG_ADD(1); break;
+                default: LG_ADD(0); LG_ADD(1); LG_ADD(2); break;
+            }
+        }
+#undef LG_ADD
+    };
+
     // Random numbers, two blocks of 64 kept in registers: lane r holds draw gbase + r of the global-rng stream (its 64 bits: the sampled
     // observations are pdmp_randint of them) and draw mbase + r of the main stream (the uniform and its logarithm).  A proposal uses k_sub of
     // the first and 2 (rejected) or 1 + k (accepted) of the second, so one Philox pass serves 6 proposals' observations, one Philox + log pass
@@ -260,6 +302,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     double mu = 0.0, mL = 0.0;
     bool running = stop_before || (t_event < T);
     PrioTurn prio;
+    // (every load of the set-up is complete before the loop is entered: with loads pending on the loop's entry edge the compiler puts
+    // s_waitcnt vmcnt(0) at the loop's head, where every iteration then also waits for the stores of the one before it)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     while (running) {
         prio.step();
         if (P.trace_cap > 0 && ntrace >= (uint64_t)P.trace_cap) {
@@ -312,15 +357,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const uint64_t bits = gbits;
         const double ucoin = l_readlane(mu, (int)moff);
         const uint32_t cp0 = H.cp0, k = H.k, sp0 = H.sp0, m = H.m;
-        // [2]: G1[i] and its Γ values, the sampled entries of column i of the design, the members' table entries
+        // [2]: the sampled entries of column i of the design FIRST (the observation records hang on them: the longest chain of look-ups), then
+        // G1[i] and its Γ values -- every lane loads (lanes past k re-read the last entry): a load under a lane mask makes the number of loads
+        // in flight unknown to the compiler, which then waits for ALL of them before the next level is requested (one more round trip)
         const uint32_t rdraw = (uint32_t)(((bits >> 32) * (uint64_t)H.l) >> 32);  // pdmp_randint
         const uint32_t ii = H.r0 + (qa ? rdraw : 0u);
-        const bool gm = (uint32_t)lane < k;
-        // (with tracked bounds only an accepted event, one proposal in seven, looks at G1[i]: its tables are read there, not here)
-        const uint32_t jm = (!TRK && gm) ? P.tb.sidx[sp0 + (uint32_t)lane] : 0u;
-        const double wm = (!TRK && gm) ? P.tb.bval[cp0 + (uint32_t)lane] : 0.0;
         const uint32_t row = LT.a_row[ii];
         const double v = LT.a_val[ii];
+        const bool gm = (uint32_t)lane < k;
+        // (with tracked bounds only an accepted event, one proposal in seven, looks at G1[i]: its tables are read there, not here)
+        const uint32_t lm = gm ? (uint32_t)lane : (k - 1u);  // (k >= 1: the diagonal)
+        const uint32_t jm = TRK ? 0u : P.tb.sidx[sp0 + lm];
+        const double wm = TRK ? 0.0 : P.tb.bval[cp0 + lm];
         uint4 mrec0 = make_uint4(0u, 0u, 0u, 0u);
         uint32_t qs0 = 0, qe0 = 0, g2a = 0xffffffffu;
         // [3]: the sampled observations
@@ -329,8 +377,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const double4 w0 = *reinterpret_cast<const double4*>(&ob->val[0]);
         const double2 w1 = *reinterpret_cast<const double2*>(&ob->val[4]);
         const uint4 ix = *reinterpret_cast<const uint4*>(&ob->idx[0]);     // idx[0..5], ne, pad
-        // ... and what may come from HBM: needed at the thinning test only (c_j, Γ[:,j]·μ of the first 64 members: an accepted event's
-        // re-bound would otherwise begin with an exposed HBM round trip)
+        // ... and what may come from HBM: needed at the thinning test only, and requested AFTER the observation records (a wave's loads return in
+        // order; the compiler would otherwise hoist these requests, which depend on i alone, in front of them)
+        asm volatile("" ::: "memory");
         double cj0 = 0.0, gmu0 = 0.0;
         double4 trk_i = make_double4(0.0, 0.0, 0.0, 0.0);  // (g, gd, tg, -) of i
         if constexpr (TRK) {
@@ -355,7 +404,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 pt[lane] = wm * nx.y;
             }
             L_ORDER();
-            run_sums(0u, (k < 64u) ? k : 64u, s1r, s2r);  // (every lane the same sums: LDS broadcasts)
+            run_sums_uniform((k < 64u) ? k : 64u, s1r, s2r);  // (every lane the same sums: LDS broadcasts)
             for (uint32_t base = 64u; base < k; base += 64u) {  // (columns beyond 64 entries: the intercept's)
                 L_ORDER();
                 const uint32_t pp = base + (uint32_t)lane;
@@ -366,7 +415,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                     pt[lane] = w * nx.y;
                 }
                 L_ORDER();
-                run_sums(0u, (k - base < 64u) ? (k - base) : 64u, s1r, s2r);
+                run_sums_uniform((k - base < 64u) ? (k - base) : 64u, s1r, s2r);
             }
             L_ORDER();
         }
@@ -385,7 +434,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 if (e < ne) u += wv[e] * move1(id[e], tp).x;
                 L_ORDER();
             }
-            const double w = (double)H.l / (double)Q.ksub * v;
+            const double w = H.lk * v;  // l / k * vals[i]
             // the two sigmoids of an observation are evaluated SIDE BY SIDE: its own lane takes sigmoid(-u), the lane 32 further on (idle: at most
             // 32 observations are sampled) takes sigmoid(u) -- one exponential and one division per lane instead of two
             const bool qb = (((uint32_t)lane - 32u - goff) & 63u) < (uint32_t)nq;  // partner of an observation lane
@@ -443,13 +492,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             }
             const double a = c_i + (s1r - gmu_i) * th_i;  // src/fact_samplers.jl:51
             const double b = c_i / 100 + th_i * s2r;      // :52
-            const double key = tp + l_poisson_time_L(a, b, l_readlane(mL, (int)moff + 1));
+            // The new bound goes out BEFORE the event time is worked out (70 instructions): the loop's head waits for every memory operation in
+            // flight (s_waitcnt vmcnt(0): on some path of the control-flow graph a load is still pending, as far as the compiler can tell), these
+            // stores included -- the earlier they leave, the less of their way to the L2 is waited for there.  Every load of this iteration has
+            // been used by now; saying so keeps the compiler from putting a wait of its own between the stores.
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
             if (lane == 0) {
                 ZzRec* r = rec + i;
                 r->t_old = tp;
                 r->a = a;
                 r->b = b;
             }
+            asm volatile("" ::: "memory");
+            const double key = tp + l_poisson_time_L(a, b, l_readlane(mL, (int)moff + 1));
             set_key(i, key);
             nm += 1;
             L_ORDER();

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(64) void zz_logistic_rows_kernel(ZzRunParams P, ZzG
                 if (e < ne) u += wv[e] * move1(id[e], tp).x;
                 R_ORDER();
             }
-            const double w = (double)H.l / (double)Q.ksub * v;
+            const double w = H.lk * v;  // l / k * vals[i]
             const double t1 = w * c0.x * r_sigmoid(-u);    // sigmoidn(u) = sigmoid(-u)
             const double t2 = w * c0.y * (-r_sigmoid(u));  // nsigmoid(u) = -sigmoid(u)
             const double t3 = w * c0.x * c0.z;             // sigmoidn(u0), u0 = idot(At, row, μ): tabulated per observation
