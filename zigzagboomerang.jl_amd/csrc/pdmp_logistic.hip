@@ -153,8 +153,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     uint32_t status = hdr->c.status;
     if (status == PDMP_CHAIN_BOUND_VIOLATED || status == PDMP_CHAIN_STALLED) return;
     const uint64_t seed = hdr->seed;
-    uint64_t nm = hdr->c.ndraw_main, ng = hdr->c.ndraw_global;
-    uint64_t num = hdr->c.num, nacc = hdr->c.nacc, ntrace = hdr->c.ntrace, nevents = hdr->c.nevents;
+    // counters of the launch as 32-bit differences (the wavefront's scalar registers are short: 64-bit running counters were spilled to vector
+    // lanes and reloaded inside the loop); a launch makes far fewer than 2^32 draws
+    const uint64_t nm0 = hdr->c.ndraw_main, ng0 = hdr->c.ndraw_global, ntrace0 = hdr->c.ntrace;
+    uint32_t dnm = 0, dng = 0, dnum = 0, dnacc = 0, dnev = 0;
+    const uint32_t trace_room = (P.trace_cap > 0) ? (uint32_t)(((uint64_t)P.trace_cap > ntrace0) ? ((uint64_t)P.trace_cap - ntrace0) : 0) : 0xffffffffu;
     double t_last = hdr->c.t_last;
     double t_event = hdr->t_event;
     status = PDMP_CHAIN_OK;
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     // ~13 proposals' coins and bounds -- instead of one of each per proposal.  The lanes that WORK on the sampled observations are the ones
     // that hold their draws: [goff, goff + k_sub), goff = ng − gbase.
     constexpr uint32_t LG_MMARGIN = 26;  // members of an accepted event whose draws the block is guaranteed to hold (more: formed on demand)
-    uint64_t gbase = ng - 64u, mbase = nm - 64u;  // (empty blocks: the first iteration fills them)
+    uint32_t gbase = 0u - 64u, mbase = 0u - 64u;  // (as differences too; empty blocks: the first iteration fills them)
     uint64_t gbits = 0;
     double mu = 0.0, mL = 0.0;
     bool running = stop_before || (t_event < T);
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     while (running) {
         prio.step();
-        if (P.trace_cap > 0 && ntrace >= (uint64_t)P.trace_cap) {
+        if (dnev >= trace_room) {
             status = PDMP_CHAIN_TRACE_FULL;
             break;
         }
@@ -343,16 +346,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         // ---------------- every random number of the iteration, one Philox evaluation: lane q < k_sub -> draw ng + q of the global-rng stream
         // (rand(sampler), scripts/logistic.jl:84); lane k_sub -> the thinning coin, draw nm (:121); lane k_sub + 1 + r -> draw nm + 1 + r, the
         // uniform of the r-th re-bound of this proposal (r = 0: the rejected proposal's own, :139; r < k: the members of an accepted one, :134)
-        if ((uint32_t)(ng - gbase) + (uint32_t)nq > 64u) {  // (uniform)
-            gbase = ng;
-            gbits = pdmp_bits64(seed, PDMP_STREAM_GLOBAL, ng + (uint64_t)lane);
+        if ((dng - gbase) + (uint32_t)nq > 64u) {  // (uniform)
+            gbase = dng;
+            gbits = pdmp_bits64(seed, PDMP_STREAM_GLOBAL, ng0 + (uint64_t)dng + (uint64_t)lane);
         }
-        if ((uint32_t)(nm - mbase) + 2u + LG_MMARGIN > 64u) {
-            mbase = nm;
-            mu = pdmp_bits_to_u01(pdmp_bits64(seed, PDMP_STREAM_MAIN, nm + (uint64_t)lane));
+        if ((dnm - mbase) + 2u + LG_MMARGIN > 64u) {
+            mbase = dnm;
+            mu = pdmp_bits_to_u01(pdmp_bits64(seed, PDMP_STREAM_MAIN, nm0 + (uint64_t)dnm + (uint64_t)lane));
             mL = pdmp_log(mu);
         }
-        const uint32_t goff = (uint32_t)(ng - gbase), moff = (uint32_t)(nm - mbase);
+        const uint32_t goff = dng - gbase, moff = dnm - mbase;
         const bool qa = (uint32_t)lane - goff < (uint32_t)nq;
         const uint64_t bits = gbits;
         const double ucoin = l_readlane(mu, (int)moff);
@@ -474,15 +477,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 }
                 L_ORDER();
             }
-            ng += (uint64_t)Q.ksub;
+            dng += (uint32_t)Q.ksub;
             g = prior - s;
         }
         LPHASE(2);
         const double th_i = xt[i].y;
         const double l_rate = l_pos(g * th_i);                   // :119
         const double lbound = l_pos(a_i + b_i * (tp - told_i));  // :119
-        num += 1;
-        nm += 1;  // the coin is draw nm, :121
+        dnum += 1;
+        dnm += 1;  // the coin is draw nm, :121
         const bool accept = (ucoin * lbound < l_rate);
         if (!accept) {
             // ---------------- rejected (:137-139): the bound from the sums taken above
@@ -506,13 +509,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             asm volatile("" ::: "memory");
             const double key = tp + l_poisson_time_L(a, b, l_readlane(mL, (int)moff + 1));
             set_key(i, key);
-            nm += 1;
+            dnm += 1;
             L_ORDER();
             LPHASE(4);
             continue;
         }
         // ---------------- accepted
-        nacc += 1;
+        dnacc += 1;
         double ci_new = c_i;
         if (l_rate >= lbound) {  // :123
             if (!adapt) {
@@ -555,7 +558,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 const uint32_t src = moff + 1u + jj;  // draw nm + jj (nm already counts the coin)
                 double Ldraw = l_shfl(mL, (src < 64u) ? src : 63u);
                 if (__ballot(valid && src >= 64u) != 0) {
-                    const double Lx = pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm + (uint64_t)jj));
+                    const double Lx = pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm0 + (uint64_t)dnm + (uint64_t)jj));
                     Ldraw = (src >= 64u) ? Lx : Ldraw;
                 }
                 if (valid) {
@@ -608,7 +611,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             const uint32_t src = moff + 1u + jj;
             double Ldraw = l_shfl(mL, (src < 64u) ? src : 63u);
             if (__ballot(valid && src >= 64u) != 0) {
-                const double Lx = pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm + (uint64_t)jj));
+                const double Lx = pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm0 + (uint64_t)dnm + (uint64_t)jj));
                 Ldraw = (src >= 64u) ? Lx : Ldraw;
             }
             double s1 = 0.0, s2 = 0.0;
@@ -667,7 +670,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             }
             L_ORDER();
         }
-        nm += (uint64_t)k;
+        dnm += k;
         L_ORDER();
         LPHASE(4);
         if (ev && lane == 0) {
@@ -676,10 +679,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             e.i = (int64_t)i;
             e.x = xt[i].x;
             e.theta = -th_i;
-            ev[ntrace] = e;
+            ev[ntrace0 + dnev] = e;
         }
-        ntrace += 1;
-        nevents += 1;
+        dnev += 1;
         t_event = tp;
         if (!stop_before && !(tp < T)) running = false;
         L_ORDER();
@@ -702,18 +704,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     }
     if (PROF && chain == 0 && lane == 0 && P.dbg) {
         for (int q = 0; q < 8; ++q) P.dbg[q] = (double)ph[q];
-        P.dbg[10] = (double)(num - hdr->c.num);
+        P.dbg[10] = (double)dnum;
     }
 #undef LPHASE
     if (lane == 0) {
         hdr->c.t_last = t_last;
         hdr->t_event = t_event;
-        hdr->c.num = num;
-        hdr->c.nacc = nacc;
-        hdr->c.ntrace = ntrace;
-        hdr->c.nevents = nevents;
-        hdr->c.ndraw_main = nm;
-        hdr->c.ndraw_global = ng;
+        hdr->c.num += dnum;
+        hdr->c.nacc += dnacc;
+        hdr->c.ntrace = ntrace0 + dnev;
+        hdr->c.nevents += dnev;
+        hdr->c.ndraw_main = nm0 + dnm;
+        hdr->c.ndraw_global = ng0 + dng;
         hdr->c.status = status;
     }
 }
