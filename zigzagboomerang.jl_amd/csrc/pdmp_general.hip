@@ -656,18 +656,30 @@ __global__ __launch_bounds__(64) void zz_general_run_kernel(ZzRunParams P_in, Zz
                                         I_[r] = h->I;
                                     }
                                 }
+                                // every row's move is worked out first -- that uses every load of the super-step --, then the stores go out together.
+                                // Written row by row (move, store, next row) the compiler has to assume a load may still be pending when it reaches
+                                // the next row's use (the loads stand under lane masks) and waits with s_waitcnt vmcnt(0) -- behind the stores it
+                                // has just issued: every row, and the loop's head, then waited for a write to reach the L2.
+                                double xe_[G_NR], In_[G_NR];
+                                bool st_[G_NR];
+#pragma unroll
+                                for (int r = 0; r < G_NR; ++r) {
+                                    const double dt = tp - t_[r];
+                                    xe_[r] = x_[r] + th_[r] * dt;
+                                    In_[r] = I_[r] + dt * ((x_[r] + xe_[r]) * 0.5);
+                                    st_[r] = in[r] && dt != 0.0;  // (a coordinate an earlier row -- or the proposal's own move -- brought to t′ already)
+                                }
+                                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing is in flight any more, and the compiler knows
 #pragma unroll
                                 for (int r = 0; r < G_NR; ++r) {
                                     if (in[r]) {  // (a record two rows move gets the same values stored twice)
                                         ZzHot* const h = H(cc[r]);
-                                        const double dt = tp - t_[r];
-                                        const double xe = x_[r] + th_[r] * dt;
-                                        if (dt != 0.0) {  // (a coordinate an earlier row -- or the proposal's own move -- brought to t′ already)
-                                            h->x = xe;
+                                        if (st_[r]) {
+                                            h->x = xe_[r];
                                             h->t = tp;
-                                            h->I = I_[r] + dt * ((x_[r] + xe) * 0.5);
+                                            h->I = In_[r];
                                         }
-                                        prodm[zr[r] * G_PROW + lane] = we[r] * xe;
+                                        prodm[zr[r] * G_PROW + lane] = we[r] * xe_[r];
                                     }
                                     if (has[r]) {
                                         if (lane == zr[r]) {
