@@ -207,3 +207,51 @@ def test_adversarial_graphs_both_evaluations(gpu_pkg, which, T, tracked):
         r = O.spdmp_zigzag(G, None, G, x0[q], th0[q], c, T, seed=1700 + q, tracked=tracked)
         assert r["status"] == 0 and len(r["events"]) > 1000
         check_chain_bitwise(tr[q].events, t[q], x[q], th[q], acc[q], num[q], None, r)
+
+
+def test_c3g_random_graph_at_width_over_a_longer_horizon(gpu_pkg):
+    """Config C3G (random pattern, <= 6 entries per column, d = 16384, 4096 chains) over T = 4 -- 3.3e5 proposals per chain, 1.4e9 in all -- on BOTH
+    evaluations off the stencil (zz_local_trackp_kernel<LAT=false>, zz_local_spec8g_kernel): 32 chains of each run (every 132nd and the last) bit
+    for bit against their oracles -- counters and the whole final state --, and the two evaluations agreeing on the counters of (nearly) every
+    chain: a chain may leave the moving evaluation's index sequence at a rounding flip (tests/test_gpu_track_horizon.py), a handful at most here."""
+    from concurrent.futures import ThreadPoolExecutor
+    import os
+    pkg = gpu_pkg
+    G = pkg.problems.random_sparse_precision(16384, 6)
+    d = G.shape[0]
+    c = pkg.problems.column_norms(G)
+    nch, T, seed0 = 4096, 4.0, 0x5EED0000
+    chains = sorted(set(list(range(0, nch, 132)) + [nch - 1]))[:32]
+    cnts, finals = {}, {}
+    for tracked in (True, False):
+        with pkg.Ensemble(nch, d, trace_capacity=0) as ens:
+            ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
+            ens.set_target(pkg.GaussianTarget(G))
+            ens.set_gradient_tracking(tracked)
+            ens.set_state_synthetic(0.0, c, seed0)
+            for t in (1.0, 2.0, 3.0, T):
+                ens.run(t, pkg._lib.RUN_STOP_BEFORE)
+            cn = ens.counters()
+            assert np.all(cn["status"] == pkg._lib.CHAIN_OK)
+            assert ens.kernel_name().startswith("zz_local_trackp_kernel" if tracked else "zz_local_spec8g_kernel")
+            cnts[tracked] = cn
+            finals[tracked] = {k: ens.final_state(k, 1) for k in chains}
+
+    def run(args):
+        k, tracked = args
+        x0, th0 = O.synthetic_state(seed0 + k, d)
+        return O.spdmp_zigzag(G, None, G, x0, th0, c, T, seed=seed0 + k, stop_before_T=True, want_trace=False, tracked=tracked)
+
+    jobs = [(k, tr) for tr in (True, False) for k in chains]
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as pool:
+        res = dict(zip(jobs, pool.map(run, jobs)))
+    for (k, tracked), r in res.items():
+        assert r["status"] == 0
+        ck, fs = cnts[tracked][k], finals[tracked][k]
+        assert (int(ck["num"]), int(ck["nacc"]), int(ck["ndraw_main"])) == (r["num"], r["nacc"], r["ndraw_main"]), (k, tracked)
+        assert np.array_equal(fs["acc"][0], r["acc"]) and np.array_equal(fs["theta"][0], r["theta"]), (k, tracked)
+        assert np.array_equal(fs["t"][0], r["t"]) and np.array_equal(fs["x"][0], r["x"]), (k, tracked)
+    differ = (cnts[True]["num"] != cnts[False]["num"]) | (cnts[True]["nacc"] != cnts[False]["nacc"]) | (cnts[True]["ndraw_main"] != cnts[False]["ndraw_main"])
+    print("C3G random6 to T = %g: %.4g proposals, chains whose tracked counters differ from the moving evaluation's: %s" %
+          (T, cnts[True]["num"].sum(), np.flatnonzero(differ).tolist()))
+    assert cnts[True]["num"].sum() > 1.0e9 and np.count_nonzero(differ) <= 8
