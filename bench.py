@@ -442,12 +442,19 @@ def main():
         import torch
         import torch.distributed as dist
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            with _banner_to_stderr():  # (RCCL's version banner would land on this process's stdout, after the JSON line)
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
-                dist.barrier()  # the communicator is created here at the latest
-                torch.cuda.synchronize()
-            red_dev = "cuda"
+            try:
+                torch.cuda.set_device(local_rank)
+                with _banner_to_stderr():  # (RCCL's version banner would land on this process's stdout, after the JSON line)
+                    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+                    dist.barrier()  # the communicator is created here at the latest
+                    torch.cuda.synchronize()
+                red_dev = "cuda"
+            except Exception as exc:  # the run has no collective: barriers and four reductions of a few doubles travel as well over gloo
+                print(f"bench.py: rank {rank}: torch.distributed over RCCL failed ({exc}); barriers and reductions over gloo instead", file=sys.stderr, flush=True)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                backend = "gloo"
+                dist.init_process_group("gloo")
         else:
             dist.init_process_group(backend)
 
