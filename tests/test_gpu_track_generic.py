@@ -211,7 +211,7 @@ def test_adversarial_graphs_both_evaluations(gpu_pkg, which, T, tracked):
 
 def test_c3g_random_graph_at_width_over_a_longer_horizon(gpu_pkg):
     """Config C3G (random pattern, <= 6 entries per column, d = 16384, 4096 chains) over T = 4 -- 3.3e5 proposals per chain, 1.4e9 in all -- on BOTH
-    evaluations off the stencil (zz_local_trackp_kernel<LAT=false>, zz_local_spec8g_kernel): 32 chains of each run (every 132nd and the last) bit
+    evaluations off the stencil (zz_local_trackp_kernel<LAT=false>, zz_local_spec8g_kernel): 32 chains of each run (every 132nd and the last) and every chain on which the two evaluations disagree, bit
     for bit against their oracles -- counters and the whole final state --, and the two evaluations agreeing on the counters of (nearly) every
     chain: a chain may leave the moving evaluation's index sequence at a rounding flip (tests/test_gpu_track_horizon.py), a handful at most here."""
     from concurrent.futures import ThreadPoolExecutor
@@ -222,9 +222,10 @@ def test_c3g_random_graph_at_width_over_a_longer_horizon(gpu_pkg):
     c = pkg.problems.column_norms(G)
     nch, T, seed0 = 4096, 4.0, 0x5EED0000
     chains = sorted(set(list(range(0, nch, 132)) + [nch - 1]))[:32]
-    cnts, finals = {}, {}
-    for tracked in (True, False):
-        with pkg.Ensemble(nch, d, trace_capacity=0) as ens:
+    cnts, finals, enss = {}, {}, {}
+    try:
+        for tracked in (True, False):
+            ens = enss[tracked] = pkg.Ensemble(nch, d, trace_capacity=0)
             ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
             ens.set_target(pkg.GaussianTarget(G))
             ens.set_gradient_tracking(tracked)
@@ -235,7 +236,15 @@ def test_c3g_random_graph_at_width_over_a_longer_horizon(gpu_pkg):
             assert np.all(cn["status"] == pkg._lib.CHAIN_OK)
             assert ens.kernel_name().startswith("zz_local_trackp_kernel" if tracked else "zz_local_spec8g_kernel")
             cnts[tracked] = cn
-            finals[tracked] = {k: ens.final_state(k, 1) for k in chains}
+        differ = (cnts[True]["num"] != cnts[False]["num"]) | (cnts[True]["nacc"] != cnts[False]["nacc"]) | (cnts[True]["ndraw_main"] != cnts[False]["ndraw_main"])
+        # every chain that left the moving evaluation's index sequence is checked too: it must still be the sequential tracked sampler bit for bit
+        # (a rounding flip, not a commit of the speculative kernel that the sequential sampler would not make)
+        chains = sorted(set(chains) | set(int(k) for k in np.flatnonzero(differ)[:8]))
+        for tracked in (True, False):
+            finals[tracked] = {k: enss[tracked].final_state(k, 1) for k in chains}
+    finally:
+        for e in enss.values():
+            e.close()
 
     def run(args):
         k, tracked = args
@@ -251,7 +260,6 @@ def test_c3g_random_graph_at_width_over_a_longer_horizon(gpu_pkg):
         assert (int(ck["num"]), int(ck["nacc"]), int(ck["ndraw_main"])) == (r["num"], r["nacc"], r["ndraw_main"]), (k, tracked)
         assert np.array_equal(fs["acc"][0], r["acc"]) and np.array_equal(fs["theta"][0], r["theta"]), (k, tracked)
         assert np.array_equal(fs["t"][0], r["t"]) and np.array_equal(fs["x"][0], r["x"]), (k, tracked)
-    differ = (cnts[True]["num"] != cnts[False]["num"]) | (cnts[True]["nacc"] != cnts[False]["nacc"]) | (cnts[True]["ndraw_main"] != cnts[False]["ndraw_main"])
     print("C3G random6 to T = %g: %.4g proposals, chains whose tracked counters differ from the moving evaluation's: %s" %
           (T, cnts[True]["num"].sum(), np.flatnonzero(differ).tolist()))
     assert cnts[True]["num"].sum() > 1.0e9 and np.count_nonzero(differ) <= 8
