@@ -233,7 +233,7 @@ def make_workload(pkg, args, rank, local_rank):
     with the same JSON schema and its own roofline object) plus what the generic timing loop needs to know about it."""
     L = pkg._lib
     nch, dt = args.chains, args.dt
-    seed0 = SEED0 + rank * nch
+    seed0 = SEED0 + args.chain_first  # (global chain index: a rank's chains are the same chains whatever the number of ranks)
     W = {"config": args.config, "trace_full_retry": True}
     if args.config == "C3":
         G = pkg.problems.gmrf_precision(args.grid)
@@ -292,7 +292,7 @@ def make_workload(pkg, args, rank, local_rank):
         import scipy.sparse as sp
         d = 1024
         cap = 512  # events per chain per launch: 512 x 16 392 B x 4096 chains = 34 GB of HBM (a step of dT = 30 is ~410 events)
-        rng = np.random.default_rng(1000 + rank)
+        rng = np.random.default_rng(1000 + args.chain_first)
         ens = pkg.Ensemble(nch, d, sampler=L.SAMPLER_BPS, factor=2.0, device=local_rank, trace_capacity=cap)
         ens.set_flow_bps(pkg.BouncyParticle(sp.identity(d, format="csc"), np.zeros(d), 1.0))
         ens.set_state_bps(0.0, rng.standard_normal((nch, d)), rng.standard_normal((nch, d)), 1e-3,
@@ -308,7 +308,7 @@ def make_workload(pkg, args, rank, local_rank):
         d = P["p"]
         ksub = 10
         cap = 0 if args.no_trace else int(600 * dt) + 512
-        rng = np.random.default_rng(2000 + rank)
+        rng = np.random.default_rng(2000 + args.chain_first)
         ens = pkg.Ensemble(nch, d, adapt=True, factor=5.0, device=local_rank, trace_capacity=cap)
         ens.set_flow(pkg.ZigZag(P["Gdrop"], P["mu"], P["sigma"]))
         ens.set_target(pkg.LogisticTarget(P["A"], P["y"], P["ny"], P["mu"], P["gamma0"], ksub))
@@ -381,6 +381,175 @@ def make_workload(pkg, args, rank, local_rank):
     return W
 
 
+def c3_ensemble(pkg, G, c, nch, cap, seed0, tracked, device=0):
+    """A C3 / C3G ensemble of `nch` chains with the seeds seed0 + chain on either evaluation."""
+    d = G.shape[0]
+    e = pkg.Ensemble(nch, d, device=device, trace_capacity=cap)
+    e.set_flow(pkg.ZigZag(G, np.zeros(d)))
+    e.set_target(pkg.GaussianTarget(G))
+    if tracked:
+        e.set_gradient_tracking(True)
+    e.set_state_synthetic(0.0, c, seed0)
+    return e
+
+
+def timed_slices(pkg, e, dt, nwarm, nsteps, cap):
+    """nwarm + nsteps slices of dT on ensemble e: (seconds of the kernels of the last nsteps [HIP events], counter differences over them)."""
+    ms, c0 = [], None
+    for k in range(nwarm + nsteps):
+        if k == nwarm:
+            c0 = e.counters()
+        e.run((k + 1) * dt, pkg._lib.RUN_STOP_BEFORE, sync=False)
+        ms.append(e.last_run_ms())
+        if cap:
+            e.trace_reset()
+    c1 = e.counters()
+    secs = float(np.sum(ms[nwarm:])) * 1e-3
+    work = {f: int(c1[f].sum()) - int(c0[f].sum()) for f in ("num", "nacc", "nevents")}
+    return secs, work, int(np.count_nonzero(c1["status"] != pkg._lib.CHAIN_OK))
+
+
+def measure_exact(pkg, args, G, c, cap, local_rank):
+    """The bit-identical (moving) evaluation beside the headline (never inside `value`): same workload, seeds and step on zz_local_spec8_kernel."""
+    ex = c3_ensemble(pkg, G, c, args.chains, cap, SEED0 + args.chain_first, False, local_rank)
+    xs, w, bad = timed_slices(pkg, ex, args.dt, 2, args.exact_steps, cap)
+    kname = ex.kernel_name()
+    ex.close()
+    xach = algorithmic_bytes(w["num"], w["nacc"]) / xs / 1e9
+    return {"kernel": kname, "evaluation": "moving: bit-identical to the oracle (indices, outcomes, times, positions)",
+            "steps": args.exact_steps, "ms_per_step": 1e3 * xs / args.exact_steps, "value": w["nacc"] / xs, "unit": "reflection events/s",
+            "proposals_per_s": w["num"] / xs, "roofline": {"bound": "hbm", "achieved": xach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                           "frac": xach / HBM_PEAK_GBS},
+            "unhealthy_chains": bad,
+            "note": "kernel time from HIP events of this process, after the timed region; same seeds, step and trace handling"}
+
+
+def measure_strong_proxy(pkg, args, G, c, local_rank, value_1gpu, exact_1gpu):
+    """The per-GPU term of the north star's strong-scaling curve, measured on THIS GPU: rank 0's share of the --total-chains ensemble on a job of
+    R = 2, 4, 8 GPUs is chains [0, N/R) -- the run has no collective and the tables are replicated, so one GPU running N/R chains IS what every
+    rank of that job does (SURVEY 8 e1; src/sfact.jl:199-208 is the loop each chain runs).  Projected job rate = R x this GPU's rate at N/R chains;
+    efficiency = that / (R x the 1-GPU rate)."""
+    rows = []
+    d = G.shape[0]
+    for R in (2, 4, 8):
+        n = args.total_chains // R
+        if n < 1:
+            continue
+        row = {"gpus": R, "chains_per_gpu": n, "waves_per_simd": n / 1024.0}
+        for name, tracked, ref in (("tracked", True, value_1gpu), ("exact", False, exact_1gpu)):
+            if ref is None:
+                continue
+            cap = int(2.0 * d * args.dt) + 1024
+            e = c3_ensemble(pkg, G, c, n, cap, SEED0, tracked, local_rank)
+            secs, w, bad = timed_slices(pkg, e, args.dt, 2, max(2, min(args.steps, 6)), cap)
+            kname = e.kernel_name()
+            e.close()
+            ach = algorithmic_bytes(w["num"], w["nacc"]) / secs / 1e9
+            row[name] = {"kernel": kname, "ms_per_step": 1e3 * secs / max(2, min(args.steps, 6)), "events_per_s": w["nacc"] / secs,
+                         "proposals_per_s": w["num"] / secs, "events_per_s_per_chain": w["nacc"] / secs / n,
+                         "roofline_frac": ach / HBM_PEAK_GBS, "projected_job_events_per_s": R * w["nacc"] / secs,
+                         "projected_efficiency": (R * w["nacc"] / secs) / (R * ref), "unhealthy_chains": bad}
+        rows.append(row)
+    return {"what": f"this GPU running the share N/R of the {args.total_chains}-chain ensemble that a rank of an R-GPU job runs (no collective in the run: "
+                    "the per-GPU term of the strong-scaling curve, measured, not modelled); efficiency = rate at N/R chains / rate at N chains",
+            "by_gpus": rows}
+
+
+def measure_with_integrals(pkg, args, rank, local_rank):
+    """C4: the same workload with the engine's path integrals kept (8 instead of 13 chains per CU), beside the headline -- figures of different
+    rounds are comparable through it (rounds 1-2 kept the integrals)."""
+    a2 = argparse.Namespace(**vars(args))
+    a2.gather = True  # (keeps the integrals: see make_workload)
+    W2 = make_workload(pkg, a2, rank, local_rank)
+    e2 = W2["ens"]
+    n2 = args.warmup + min(args.steps, 4)
+    ims, c0 = [], None
+    for k in range(n2):
+        T2 = (k + 1) * args.dt
+        ms2 = 0.0
+        while True:
+            e2.run(T2, pkg._lib.RUN_STOP_BEFORE, sync=False)
+            ms2 += e2.last_run_ms()
+            full = bool(np.any(e2.counters()["status"] == pkg._lib.CHAIN_TRACE_FULL)) if W2["cap"] else False
+            if W2["cap"]:
+                e2.trace_reset()
+            if not full:
+                break
+        ims.append(ms2)
+        if k == args.warmup - 1:
+            c0 = e2.counters()
+    c1 = e2.counters()
+    e2.close()
+    secs = float(np.sum(ims[args.warmup:])) * 1e-3
+    base0 = {f: (int(c0[f].sum()) if c0 is not None else 0) for f in ("num", "nacc", "nevents")}
+    w2 = {f: int(c1[f].sum()) - base0[f] for f in ("num", "nacc", "nevents")}
+    ach2 = W2["bytes"](w2) / secs / 1e9
+    return {"ms_per_step": 1e3 * secs / (n2 - args.warmup), "value": w2["nevents"] / secs, "unit": W2["unit"],
+            "roofline_frac": ach2 / HBM_PEAK_GBS, "steps": n2 - args.warmup,
+            "note": "pdmp_ensemble_set_path_integrals(1): 18.7 instead of 11.9 KB of LDS per chain, 8 instead of 13 chains per CU"}
+
+
+def measure_ess(pkg, args, W, ens, local_rank):
+    """ESS/s.  A fresh ensemble of the same shape is started IN STATIONARITY -- x0 ~ N(0, inv(Gamma)) exactly (DCT of the lattice,
+    problems.gmrf_stationary_sample), theta0 uniform on {+-1} -- and run for B batches of length b on the timed kernel; after every batch
+    the device returns the path integrals J_i of every chain at 32 probe coordinates (pdmp_ensemble_path_integrals).  With the exact mean 0
+    and exact Var_pi = diag(inv(Gamma)), sigma2(s) = s * mean (Y_s)^2 over chains and merged batches at every dyadic batch length
+    s = b .. B*b (ess.multiscale_ess); ESS_i(s) = N*B*b*Var_pi,i / sigma2_i(s) shrinks as s passes the autocorrelation times of the slow
+    lattice modes (eigenvalue 0.01: ~150 time units), so the HEADLINE is the SMALLEST of them -- the largest s, i.e. the spread of the N
+    whole-run means -- and `last_doubling` says how far from its plateau that still is.  Divided by the GPU seconds of that run.
+    Returns (ess object, the ensemble still open or None)."""
+    G, c, d, cap, nch = W["G"], W["c"], W["d"], W["cap"], args.chains
+    B, b = args.ess_batches, args.ess_batch_len
+    probes = np.linspace(0, d - 1, 32).astype(np.int64)
+    if args.no_stationary_start:
+        es, T0, start = ens, (args.warmup + args.steps) * args.dt, "continued from the timed run (x0 ~ N(0, I)): slow modes NOT in equilibrium"
+    else:
+        ens.close()
+        rng = np.random.default_rng(SEED0)
+        es = pkg.Ensemble(nch, d, device=local_rank, trace_capacity=cap)
+        es.set_flow(pkg.ZigZag(G, np.zeros(d)))
+        es.set_target(pkg.GaussianTarget(G))
+        if not args.exact:
+            es.set_gradient_tracking(True)
+        es.set_state(0.0, pkg.problems.gmrf_stationary_sample(args.grid, nch, rng), rng.choice([-1.0, 1.0], (nch, d)), c,
+                     np.arange(nch, dtype=np.uint64) + np.uint64(SEED0 + (1 << 24)))
+        T0, start = 0.0, "stationary: x0 ~ N(0, inv(Gamma)) exactly, theta0 uniform on {+-1}"
+    ess_ms = 0.0
+    J = [es.path_integrals(T0, probes)]
+    nsl = max(1, int(round(b / args.dt)))
+    for kb in range(B):
+        for q in range(nsl):  # slices of dT, so that the trace segments (sized for one step) are recycled as in the timed steps
+            es.run(T0 + kb * b + (q + 1) * (b / nsl), pkg._lib.RUN_STOP_BEFORE, sync=False)
+            ess_ms += es.last_run_ms()
+            if cap:
+                es.trace_reset()
+        J.append(es.path_integrals(T0 + (kb + 1) * b, probes))
+    ebad = int(np.count_nonzero(es.counters()["status"] != pkg._lib.CHAIN_OK))
+    kname = es.kernel_name()
+    if es is not ens:
+        es.close()
+    var_pi = pkg.problems.gmrf_marginal_variances(args.grid)[probes]
+    r = pkg.ess.multiscale_ess(np.stack(J), b, var_pi, mean=0.0)
+    gpu_s = ess_ms * 1e-3
+    ex_ess = r["ess_extrapolated"]
+    return {"definition": f"N={nch} chains, B={B} batches of length b={b} (run length {B * b}), path integrals of every chain at 32 probe "
+                          "coordinates; sigma2(s) = s*mean(Y_s^2) at dyadic batch lengths s=b..B*b with the exact mean 0; ESS_i(s) = "
+                          "N*B*b*Var_pi,i/sigma2_i(s), Var_pi = exact diag(inv(Gamma)); sigma2 grows with s towards sigma2_asym (bias -Gamma/s), "
+                          "so the HEADLINE uses the Richardson value 2*sigma2(B*b) - sigma2(B*b/2) -- the smallest ESS of all listed; per GPU "
+                          "second of the run that produced the path; min / median over the probes",
+            "start": start, "evaluation": "exact" if args.exact else "tracked",
+            "ess_min_per_s": float(ex_ess.min() / gpu_s), "ess_median_per_s": float(np.median(ex_ess) / gpu_s),
+            "ess_per_chain_time_median": float(np.median(var_pi / r["sigma2_extrapolated"])),
+            "ess_per_chain_time_min": float(np.min(var_pi / r["sigma2_extrapolated"])),
+            "iact_median": float(np.median(r["sigma2_extrapolated"] / (2.0 * var_pi))),
+            "last_doubling_median": float(np.median(r["last_doubling"])), "last_doubling_max": float(np.max(r["last_doubling"])),
+            "by_batch_len": {str(float(sc)): {"ess_min_per_s": float(r["ess"][q].min() / gpu_s),
+                                              "ess_median_per_s": float(np.median(r["ess"][q]) / gpu_s)}
+                             for q, sc in enumerate(r["scales"])},
+            "unhealthy_chains": ebad, "gpu_seconds": gpu_s, "batches": B, "batch_len": b, "kernel": kname}
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="C3", choices=sorted(CONFIG_DEFAULTS),
@@ -388,7 +557,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--chains", type=int, default=None, help="chains per GPU (default: the configuration's)")
+    ap.add_argument("--chains", type=int, default=None, help="chains per GPU (weak scaling; default: the configuration's)")
+    ap.add_argument("--scaling", default=None, choices=["strong", "weak"],
+                    help="strong (default for C3 / C3G, the north star's form: ONE ensemble of --total-chains chains, rank r of R runs chains "
+                         "[r N/R, (r+1) N/R), SURVEY 8 e1) or weak (--chains per GPU; default for C2 / C4 / C5, whose widths are one GPU's share)")
+    ap.add_argument("--total-chains", type=int, default=None, help="strong scaling: chains of the whole job (default: the configuration's width)")
+    ap.add_argument("--no-strong-proxy", action="store_true",
+                    help="C3 at N = 1: skip the `strong_proxy` object (this GPU's share of the 2 / 4 / 8-GPU strong-scaling job, timed after the region)")
     ap.add_argument("--grid", type=int, default=GRID)
     ap.add_argument("--dt", type=float, default=None, help="process time per step (default: the configuration's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -412,6 +587,8 @@ def main():
     ap.add_argument("--exact", action="store_true",
                     help="C3: the bit-identical moving evaluation (zz_local_spec8_kernel) instead of the tracked-gradient one")
     args = ap.parse_args()
+    if args.scaling is None:
+        args.scaling = "strong" if args.config in ("C3", "C3G") and args.chains is None else "weak"
     if args.chains is None:
         args.chains = CONFIG_DEFAULTS[args.config]["chains"]
     if args.dt is None:
@@ -427,6 +604,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # which chains are this rank's: weak = its own block of --chains, strong = its share of ONE ensemble (zigzagboomerang.jl_amd/parallel.py)
+    if args.scaling == "strong":
+        if args.total_chains is None:
+            args.total_chains = args.chains
+        base, rem = divmod(args.total_chains, world)  # (= parallel.shard_range; the package is imported later: torch first)
+        args.chains = base + (1 if rank < rem else 0)
+        args.chain_first = rank * base + min(rank, rem)
+        if args.chains < 1:
+            raise SystemExit(f"--scaling strong: {args.total_chains} chains over {world} ranks leaves rank {rank} without one")
+    else:
+        args.total_chains = args.chains * world
+        args.chain_first = rank * args.chains
     dist = None
     comm = None  # the engine's own RCCL communicator (pdmp_comm_*): no torch in the process
     # Which transport carries the barriers and the reductions of this line.  N = 1 (--gather): the engine's communicator.  N > 1: torch.distributed
@@ -556,124 +745,21 @@ def main():
     if args.config == "C5":
         num = work["grads"]
 
-    # The bit-identical evaluation beside the headline (never inside `value`): the same workload, seeds and step on zz_local_spec8_kernel
+    # Beside the headline, never inside `value` (each measured in this process after the timed region)
     exact = None
     if rank == 0 and args.config == "C3" and not args.exact and args.exact_steps > 0:
-        ex = pkg.Ensemble(nch, d, device=local_rank, trace_capacity=cap)
-        ex.set_flow(pkg.ZigZag(G, np.zeros(d)))
-        ex.set_target(pkg.GaussianTarget(G))
-        ex.set_state_synthetic(0.0, c, SEED0 + rank * nch)
-        xms = []
-        for k in range(2 + args.exact_steps):
-            ex.run((k + 1) * args.dt, pkg._lib.RUN_STOP_BEFORE, sync=False)
-            xms.append(ex.last_run_ms())
-            if k == 1:
-                xc0 = ex.counters()
-            if cap:
-                ex.trace_reset()
-        xc1 = ex.counters()
-        ex.close()
-        xnum = int(xc1["num"].sum()) - int(xc0["num"].sum())
-        xacc = int(xc1["nacc"].sum()) - int(xc0["nacc"].sum())
-        xs = float(np.sum(xms[2:])) * 1e-3
-        xach = algorithmic_bytes(xnum, xacc) / xs / 1e9
-        exact = {"kernel": "zz_local_spec8_kernel", "evaluation": "moving: bit-identical to the oracle (indices, outcomes, times, positions)",
-                 "steps": args.exact_steps, "ms_per_step": 1e3 * xs / args.exact_steps, "value": xacc / xs, "unit": "reflection events/s",
-                 "proposals_per_s": xnum / xs, "roofline": {"bound": "hbm", "achieved": xach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                            "frac": xach / HBM_PEAK_GBS},
-                 "unhealthy_chains": int(np.count_nonzero(xc1["status"] != pkg._lib.CHAIN_OK)),
-                 "note": "kernel time from HIP events of this process, after the timed region; same seeds, step and trace handling"}
-
-    # C4: the same workload with the engine's path integrals kept (8 instead of 13 chains per CU), beside the headline -- figures of different
-    # rounds are comparable through it (rounds 1-2 kept the integrals)
+        exact = measure_exact(pkg, args, G, c, cap, local_rank)
+    strong_proxy = None
+    if rank == 0 and world == 1 and args.config == "C3" and not args.no_strong_proxy and not args.gather and not args.no_trace:
+        v1 = nev / max(float(np.sum(kernel_ms)) * 1e-3, 1e-9)  # (this GPU's kernel-time rate at the full width: the same clock as the proxy's)
+        strong_proxy = measure_strong_proxy(pkg, args, G, c, local_rank, v1 if not args.exact else None,
+                                            exact["value"] if exact else (v1 if args.exact else None))
     with_integrals = None
     if rank == 0 and args.config == "C4" and not args.gather and os.environ.get("PDMP_BENCH_C4_INTEGRALS", "0") == "0" and args.exact_steps > 0:
-        a2 = argparse.Namespace(**vars(args))
-        a2.gather = True  # (keeps the integrals: see make_workload)
-        W2 = make_workload(pkg, a2, rank, local_rank)
-        e2 = W2["ens"]
-        n2 = args.warmup + min(args.steps, 4)
-        ims, c0 = [], None
-        for k in range(n2):
-            T2 = (k + 1) * args.dt
-            ms2 = 0.0
-            while True:
-                e2.run(T2, pkg._lib.RUN_STOP_BEFORE, sync=False)
-                ms2 += e2.last_run_ms()
-                full = bool(np.any(e2.counters()["status"] == pkg._lib.CHAIN_TRACE_FULL)) if W2["cap"] else False
-                if W2["cap"]:
-                    e2.trace_reset()
-                if not full:
-                    break
-            ims.append(ms2)
-            if k == args.warmup - 1:
-                c0 = e2.counters()
-        c1 = e2.counters()
-        e2.close()
-        secs = float(np.sum(ims[args.warmup:])) * 1e-3
-        base0 = {f: (int(c0[f].sum()) if c0 is not None else 0) for f in ("num", "nacc", "nevents")}
-        w2 = {f: int(c1[f].sum()) - base0[f] for f in ("num", "nacc", "nevents")}
-        ach2 = W2["bytes"](w2) / secs / 1e9
-        with_integrals = {"ms_per_step": 1e3 * secs / (n2 - args.warmup), "value": w2["nevents"] / secs, "unit": W2["unit"],
-                          "roofline_frac": ach2 / HBM_PEAK_GBS, "steps": n2 - args.warmup,
-                          "note": "pdmp_ensemble_set_path_integrals(1): 18.7 instead of 11.9 KB of LDS per chain, 8 instead of 13 chains per CU"}
-
-    # ESS/s.  A fresh ensemble of the same shape is started IN STATIONARITY -- x0 ~ N(0, inv(Gamma)) exactly (DCT of the lattice,
-    # problems.gmrf_stationary_sample), theta0 uniform on {+-1} -- and run for B batches of length b on the timed kernel; after every batch
-    # the device returns the path integrals J_i of every chain at 32 probe coordinates (pdmp_ensemble_path_integrals).  With the exact mean 0
-    # and exact Var_pi = diag(inv(Gamma)), sigma2(s) = s * mean (Y_s)^2 over chains and merged batches at every dyadic batch length
-    # s = b .. B*b (ess.multiscale_ess); ESS_i(s) = N*B*b*Var_pi,i / sigma2_i(s) shrinks as s passes the autocorrelation times of the slow
-    # lattice modes (eigenvalue 0.01: ~150 time units), so the HEADLINE is the SMALLEST of them -- the largest s, i.e. the spread of the N
-    # whole-run means -- and `last_doubling` says how far from its plateau that still is.  Divided by the GPU seconds of that run.
+        with_integrals = measure_with_integrals(pkg, args, rank, local_rank)
     ess = None
     if rank == 0 and world == 1 and args.config == "C3" and args.ess_batches >= 1 and not args.gather:
-        B, b = args.ess_batches, args.ess_batch_len
-        probes = np.linspace(0, d - 1, 32).astype(np.int64)
-        if args.no_stationary_start:
-            es, T0, start = ens, (args.warmup + args.steps) * args.dt, "continued from the timed run (x0 ~ N(0, I)): slow modes NOT in equilibrium"
-        else:
-            ens.close()
-            rng = np.random.default_rng(SEED0)
-            es = pkg.Ensemble(nch, d, device=local_rank, trace_capacity=cap)
-            es.set_flow(pkg.ZigZag(G, np.zeros(d)))
-            es.set_target(pkg.GaussianTarget(G))
-            if not args.exact:
-                es.set_gradient_tracking(True)
-            es.set_state(0.0, pkg.problems.gmrf_stationary_sample(args.grid, nch, rng), rng.choice([-1.0, 1.0], (nch, d)), c,
-                         np.arange(nch, dtype=np.uint64) + np.uint64(SEED0 + (1 << 24)))
-            T0, start = 0.0, "stationary: x0 ~ N(0, inv(Gamma)) exactly, theta0 uniform on {+-1}"
-        ess_ms = 0.0
-        J = [es.path_integrals(T0, probes)]
-        nsl = max(1, int(round(b / args.dt)))
-        for kb in range(B):
-            for q in range(nsl):  # slices of dT, so that the trace segments (sized for one step) are recycled as in the timed steps
-                es.run(T0 + kb * b + (q + 1) * (b / nsl), pkg._lib.RUN_STOP_BEFORE, sync=False)
-                ess_ms += es.last_run_ms()
-                if cap:
-                    es.trace_reset()
-            J.append(es.path_integrals(T0 + (kb + 1) * b, probes))
-        ebad = int(np.count_nonzero(es.counters()["status"] != pkg._lib.CHAIN_OK))
-        if es is not ens:
-            es.close()
-        var_pi = pkg.problems.gmrf_marginal_variances(args.grid)[probes]
-        r = pkg.ess.multiscale_ess(np.stack(J), b, var_pi, mean=0.0)
-        gpu_s = ess_ms * 1e-3
-        ex_ess = r["ess_extrapolated"]
-        ess = {"definition": f"N={nch} chains, B={B} batches of length b={b} (run length {B * b}), path integrals of every chain at 32 probe "
-                             "coordinates; sigma2(s) = s*mean(Y_s^2) at dyadic batch lengths s=b..B*b with the exact mean 0; ESS_i(s) = "
-                             "N*B*b*Var_pi,i/sigma2_i(s), Var_pi = exact diag(inv(Gamma)); sigma2 grows with s towards sigma2_asym (bias -Gamma/s), "
-                             "so the HEADLINE uses the Richardson value 2*sigma2(B*b) - sigma2(B*b/2) -- the smallest ESS of all listed; per GPU "
-                             "second of the run that produced the path; min / median over the probes",
-               "start": start,
-               "ess_min_per_s": float(ex_ess.min() / gpu_s), "ess_median_per_s": float(np.median(ex_ess) / gpu_s),
-               "ess_per_chain_time_median": float(np.median(var_pi / r["sigma2_extrapolated"])),
-               "ess_per_chain_time_min": float(np.min(var_pi / r["sigma2_extrapolated"])),
-               "iact_median": float(np.median(r["sigma2_extrapolated"] / (2.0 * var_pi))),
-               "last_doubling_median": float(np.median(r["last_doubling"])), "last_doubling_max": float(np.max(r["last_doubling"])),
-               "by_batch_len": {str(float(sc)): {"ess_min_per_s": float(r["ess"][q].min() / gpu_s),
-                                                 "ess_median_per_s": float(np.median(r["ess"][q]) / gpu_s)}
-                                for q, sc in enumerate(r["scales"])},
-               "unhealthy_chains": ebad, "gpu_seconds": gpu_s, "batches": B, "batch_len": b, "kernel": W["kernel"]}
+        ess = measure_ess(pkg, args, W, ens, local_rank)
 
     # post-run exchange (never inside `value`): SURVEY 8e1
     gather = None
@@ -746,35 +832,71 @@ def main():
                       "first_event_time_rank_last": float(gathered[-1][0, 0].item()) if gathered[-1].shape[0] else None,
                       "mean_of_batch_means": float(np.mean(sy) / (nch * world))}
 
-    # aggregate over ranks: max time, summed work
-    if comm is not None and world > 1:
-        elapsed = float(comm.allreduce([elapsed], "max")[0])
-        num_all, nacc_all, nev_all, bad_all = [float(v) for v in comm.allreduce([float(num), float(nacc), float(nev), float(bad)], "sum")]
-    elif dist is not None:
-        import torch
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        ww = torch.tensor([float(num), float(nacc), float(nev), float(bad)], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(ww, op=dist.ReduceOp.SUM)
-        elapsed = float(tt.item())
-        num_all, nacc_all, nev_all, bad_all = [float(v) for v in ww.tolist()]
-    else:
-        num_all, nacc_all, nev_all, bad_all = float(num), float(nacc), float(nev), float(bad)
-
-    per_rank = None
-    if args.per_rank:
-        c0 = cnt[0]
-        mine = {"rank": rank, "seed_first": int(SEED0 + rank * nch), "num": int(num), "nacc": int(nacc), "nevents": int(nev),
-                "chain0": {"num": int(c0["num"]), "nacc": int(c0["nacc"]), "ndraw_main": int(c0["ndraw_main"]), "t_last": float(c0["t_last"])}}
+    def allreduce(values, op):
+        """sum / max over the ranks on whatever transport carries this line (comm: the engine's RCCL communicator; dist: torch.distributed)."""
         if comm is not None and world > 1:
-            vec = np.zeros((world, 8))
-            vec[rank] = [mine["seed_first"], mine["num"], mine["nacc"], mine["nevents"], c0["num"], c0["nacc"], c0["ndraw_main"], c0["t_last"]]
-            vec = comm.allreduce(vec, "sum").reshape(world, 8)
-            per_rank = [{"rank": r, "seed_first": int(v[0]), "num": int(v[1]), "nacc": int(v[2]), "nevents": int(v[3]),
+            return [float(v) for v in comm.allreduce([float(v) for v in values], op)]
+        if dist is not None:
+            import torch
+            tv = torch.tensor([float(v) for v in values], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tv, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+            return [float(v) for v in tv.tolist()]
+        return [float(v) for v in values]
+
+    # aggregate over ranks: max time, summed work
+    elapsed = allreduce([elapsed], "max")[0]
+    num_all, nacc_all, nev_all, bad_all = allreduce([num, nacc, nev, bad], "sum")
+
+    # N > 1, strong scaling: the weak-scaling view of the same job beside it (the configuration's width PER GPU: what rounds 1-4 reported),
+    # so that one driver run yields both curves -- same barriers, max over ranks, never inside `value`
+    weak = None
+    if world > 1 and args.scaling == "strong" and args.config == "C3" and not args.gather:
+        nw = CONFIG_DEFAULTS["C3"]["chains"]
+        ew = c3_ensemble(pkg, G, c, nw, cap, SEED0 + rank * nw, not args.exact, local_rank)
+        nst = max(2, min(args.steps, 6))
+        for k in range(2):
+            ew.run((k + 1) * args.dt, pkg._lib.RUN_STOP_BEFORE, sync=False)
+            ew.last_run_ms()
+            ew.trace_reset()
+        cw0 = ew.counters()
+        barrier()
+        tw0 = time.perf_counter()
+        for k in range(2, 2 + nst):
+            ew.run((k + 1) * args.dt, pkg._lib.RUN_STOP_BEFORE, sync=False)
+            ew.last_run_ms()
+            ew.trace_reset()
+        barrier()
+        tw = allreduce([time.perf_counter() - tw0], "max")[0]
+        nevw = allreduce([int(ew.counters()["nevents"].sum()) - int(cw0["nevents"].sum())], "sum")[0]
+        ew.close()
+        weak = {"scaling": "weak", "chains_per_gpu": nw, "steps": nst, "ms_per_step": 1e3 * tw / nst, "value": nevw / tw, "unit": W["unit"],
+                "note": "the same job with the configuration's width on EVERY GPU, timed after the strong region with the same barriers"}
+
+    ranks_seen = 1
+    if comm is not None and world > 1:
+        ranks_seen = int(round(float(comm.allreduce([1.0], "sum")[0])))
+    elif dist is not None:
+        ranks_seen = int(dist.get_world_size())
+    per_rank = None
+    if args.per_rank or world > 1:
+        c0 = cnt[0]
+        mine = {"rank": rank, "seed_first": int(SEED0 + args.chain_first), "chains": int(nch), "num": int(num), "nacc": int(nacc), "nevents": int(nev),
+                "kernel_ms_per_step": float(np.sum(kernel_ms)) / max(args.steps, 1),
+                "chain0": {"num": int(c0["num"]), "nacc": int(c0["nacc"]), "ndraw_main": int(c0["ndraw_main"]), "t_last": float(c0["t_last"])}}
+        if world > 1:
+            vec = np.zeros((world, 10))
+            vec[rank] = [mine["seed_first"], mine["num"], mine["nacc"], mine["nevents"], c0["num"], c0["nacc"], c0["ndraw_main"], c0["t_last"],
+                         mine["chains"], mine["kernel_ms_per_step"]]
+            if comm is not None:
+                vec = comm.allreduce(vec, "sum").reshape(world, 10)
+            else:  # (a plain all_reduce: the one collective every backend of this script is known to carry)
+                import torch
+                tv = torch.tensor(vec, dtype=torch.float64, device=red_dev)
+                dist.all_reduce(tv, op=dist.ReduceOp.SUM)
+                vec = tv.cpu().numpy()
+            per_rank = [{"rank": r, "seed_first": int(v[0]), "chains": int(v[8]), "kernel_ms_per_step": float(v[9]),
+                         "num": int(v[1]), "nacc": int(v[2]), "nevents": int(v[3]),
                          "chain0": {"num": int(v[4]), "nacc": int(v[5]), "ndraw_main": int(v[6]), "t_last": float(v[7])}} for r, v in enumerate(vec)]
-        elif dist is not None:
-            per_rank = [None] * world
-            dist.all_gather_object(per_rank, mine)
         else:
             per_rank = [mine]
 
@@ -814,13 +936,15 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "evaluation": ("exact" if args.exact else "tracked") if args.config in ("C3", "C3G") else ("tracked" if (args.config == "C4" and args.tracked) else "exact"),
             "config": {"workload": W["workload"] + (f"; evaluation: {W['evaluation']}" if "evaluation" in W else ""),
-                       "chains_per_gpu": nch, "d": d, "dT": args.dt, "parallelism": f"chains sharded x{world}, no collective in the run"
+                       "chains_per_gpu": nch, "total_chains": args.total_chains, "d": d, "dT": args.dt,
+                       "parallelism": (f"ONE ensemble of {args.total_chains} chains, rank r runs chains [r N/R, (r+1) N/R) (strong scaling), no collective in the run"
+                                       if args.scaling == "strong" else f"{nch} chains per GPU x{world} (weak scaling), no collective in the run")
                                       + (" (reductions of this line: " + ("pdmp_comm_allreduce, RCCL linked by the engine" if comm is not None else "torch.distributed " + backend) + ")" if world > 1 else "")},
             "proposals_per_s": num_all / elapsed,
             # (sticky chains reset (acc, num) whenever a bound adapts, src/ss_fact.jl:134: no acceptance ratio can be formed from them)
@@ -836,8 +960,13 @@ def main():
         out["totals"] = {"num": num_all, "nacc": nacc_all, "nevents": nev_all, "T_end": (args.warmup + args.steps) * args.dt}
         if issue is not None:
             out["issue"] = issue
+        out["ranks_seen"] = ranks_seen  # size of the communicator that carried this line's reductions (1: no communicator)
         if per_rank is not None:
             out["per_rank"] = per_rank
+        if strong_proxy is not None:
+            out["strong_proxy"] = strong_proxy
+        if weak is not None:
+            out["weak"] = weak
         if gather is not None:
             out["gather"] = gather
         if ess is not None:
@@ -849,16 +978,19 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, G, c) if args.config in ("C3", "C3G") else cpu_baseline_config(pkg, args.config)
             if ess is not None and "ensemble" in out["cpu_baseline"]:
-                # ESS/s of the CPU ensemble.  The CPU chains ARE the GPU chains (same algorithm, same seeds, bit-identical event sequences), so the
-                # effective sample size per unit of PROCESS time is the same number for both -- measured above on 4096 chains x 1024 time units --
-                # and ESS per second = that x the process time the pool advances per second of wall time (chains x T / seconds)
+                # ESS/s of the CPU ensemble.  The CPU pool runs the reference's (moving) evaluation; the GPU ESS leg above ran the evaluation named in
+                # `ess.evaluation` (tracked by default: the same process law -- the same sampler with sums carried instead of gathered, index-exact
+                # against the moving one until a rounding flip, ~4 % of the chains by T = 1024 -- not the same realisations).  The effective sample
+                # size per unit of PROCESS time is a property of the sampler, estimated once on 4096 chains x 1024 time units; ESS per second = that x
+                # the process time the pool advances per second of wall time (chains x T / seconds)
                 ce = out["cpu_baseline"]["ensemble"]
                 chain_time_per_s = ce["chains"] * ce["T"] / ce["seconds"]
                 out["cpu_baseline"]["ess"] = {"ess_min_per_s": ess["ess_per_chain_time_min"] * chain_time_per_s,
                                               "ess_median_per_s": ess["ess_per_chain_time_median"] * chain_time_per_s,
                                               "chain_time_per_s": chain_time_per_s,
-                                              "definition": "ESS per unit process time of the sampler (the GPU leg's estimate: same process, same seeds) x process time "
-                                                            "advanced per wall second by the CPU pool; same estimator, same probes as `ess`"}
+                                              "definition": "ESS per unit process time of the sampler (the GPU leg's estimate, made on the `ess.evaluation` evaluation: the same "
+                                                            "process law as the CPU pool's moving evaluation, not the same realisations) x process time advanced per "
+                                                            "wall second by the CPU pool; same estimator, same probes as `ess`"}
         print(json.dumps(out), flush=True)
     ens.close()
     if comm is not None:

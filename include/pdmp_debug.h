@@ -36,6 +36,13 @@ pdmp_status pdmp_debug_phase_profile(pdmp_ensemble* ens, double* out16, int* kin
  * floats and commit the same sequence.  The choice fixes the queue's layout: call it BEFORE set_state.  (Rounds 1-2 carried two more
  * variants, key blocks of 32 and of 16 in the record layout; they were superseded and removed.) */
 pdmp_status pdmp_debug_set_track_groups(pdmp_ensemble* ens, int which);
+/* zz_local_trackp_kernel / zz_local_trackp2_kernel: the two-wave form gives every chain a helper wavefront (the chain's uniforms and their
+ * logarithms produced ahead into a ring in LDS, the next windows' lines requested early); same committed sequence and floats.  -1 = chosen by
+ * the ensemble's width (at most 1024 chains: a launch that leaves SIMDs idle), 0 = never, 1 = always.  Before the next run. */
+pdmp_status pdmp_debug_set_helper_wave(pdmp_ensemble* ens, int mode);
+/* ... its tuning (none of it changes a result): the selection threshold grows by `grow` when every candidate committed and shrinks by `shrink`
+ * when more than `slack` did not; the helper requests the lines of the blocks within `ahead` window lengths beyond the current window */
+pdmp_status pdmp_debug_set_helper_steering(pdmp_ensemble* ens, double grow, double shrink, int slack, double ahead);
 /* name of the event-loop kernel the last pdmp_ensemble_run launched (bench.py prints it with every line: no figure without its kernel) */
 pdmp_status pdmp_debug_last_kernel(pdmp_ensemble* ens, char* out, int64_t cap);
 /* chains per wavefront of the LDS-resident logistic kernel (config C4): -1 the library's default, 0 one chain (pdmp_logistic.hip), 16 or 32 =

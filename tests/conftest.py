@@ -35,6 +35,15 @@ def gpu_pkg(pkg):
     return pkg
 
 
+@pytest.fixture(params=["one_wave", "two_waves"])
+def trackp_form(request, monkeypatch):
+    """Both forms of the one-proposal-per-lane tracked kernel on the same test: zz_local_trackp_kernel (one wavefront per chain: what wide
+    ensembles run) and zz_local_trackp2_kernel (a helper wavefront per chain: what ensembles of at most 1024 chains run by default) --
+    include/pdmp_debug.h: pdmp_debug_set_helper_wave, forwarded by engine.Ensemble from PDMP_HELPER_WAVE."""
+    monkeypatch.setenv("PDMP_HELPER_WAVE", "0" if request.param == "one_wave" else "1")
+    return request.param
+
+
 @pytest.fixture(scope="session")
 def gpu_pkg_parity(gpu_pkg):
     """A SECOND instance of the package bound to lib/libpdmp_mi355.parity.so (build.py --variant parity: the default library's sources plus the
@@ -57,5 +66,5 @@ def gpu_pkg_parity(gpu_pkg):
             os.environ.pop("PDMP_MI355_LIB", None)
         else:
             os.environ["PDMP_MI355_LIB"] = old
-    assert mod._lib.lib_path() != path or True
+    assert mod._lib.loaded_path() == path  # (the parity library IS what this instance loaded)
     return mod

@@ -32,7 +32,7 @@ def test_library_loads_and_exports_every_symbol(pkg):
     L = ctypes.CDLL(pkg._lib.lib_path())
     for name in declared_functions() + declared_functions("pdmp_debug.h"):
         assert hasattr(L, name), name
-    assert pkg._lib.load().pdmp_abi_version() == pkg._lib.ABI_VERSION == 2
+    assert pkg._lib.load().pdmp_abi_version() == pkg._lib.ABI_VERSION == 3
 
 
 def test_struct_sizes(pkg):

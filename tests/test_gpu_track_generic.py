@@ -42,7 +42,7 @@ def graphs(pkg, which):
 
 
 @pytest.mark.parametrize("which,T", [("lattice3d", 10.0), ("random6", 6.0), ("random8", 5.0), ("ragged", 5.0)])
-def test_generic_graph_tracked_matches_oracle(gpu_pkg, which, T):
+def test_generic_graph_tracked_matches_oracle(gpu_pkg, which, T, trackp_form):
     pkg = gpu_pkg
     G = graphs(pkg, which)
     d = G.shape[0]
@@ -61,7 +61,7 @@ def test_generic_graph_tracked_matches_oracle(gpu_pkg, which, T):
         check_chain(tr[q].events, t[q], x[q], th[q], acc[q], num[q], None, O.spdmp_zigzag(G, None, G, x0[q], th0[q], c, T, seed=900 + q))
 
 
-def test_generic_graph_slices_refills_start_time_and_violation(gpu_pkg):
+def test_generic_graph_slices_refills_start_time_and_violation(gpu_pkg, trackp_form):
     """Slices with PDMP_RUN_STOP_BEFORE, a trace buffer that fills up several times, t0 != 0, and a bound violation (status, where the oracle stops)."""
     pkg = gpu_pkg
     L = pkg._lib
@@ -112,7 +112,7 @@ def test_generic_graph_slices_refills_start_time_and_violation(gpu_pkg):
             assert np.array_equal(ev["i"], r["events"]["i"]) and np.array_equal(ev["t"], r["events"]["t"])
 
 
-def test_generic_kernel_equals_the_lattice_kernel_on_a_relabelled_lattice(gpu_pkg):
+def test_generic_kernel_equals_the_lattice_kernel_on_a_relabelled_lattice(gpu_pkg, trackp_form):
     """The same process under a permutation of the coordinates: the n x n lattice relabelled at random is 'a random graph' to the engine
     (LAT = false); every chain's proposal / accept counts differ from the plain lattice's only through the tie rule -- so compare through the
     oracle: both runs equal their own tracked oracle bit for bit, and the generic one is what a user with an arbitrary numbering gets."""
@@ -183,7 +183,7 @@ def adversarial(pkg, which):
 
 @pytest.mark.parametrize("which,T", [("cliques8", 6.0), ("path", 8.0), ("triangular", 5.0)])
 @pytest.mark.parametrize("tracked", [True, False])
-def test_adversarial_graphs_both_evaluations(gpu_pkg, which, T, tracked):
+def test_adversarial_graphs_both_evaluations(gpu_pkg, which, T, tracked, trackp_form):
     """Cliques of 8, a path and the triangular lattice on the one-proposal-per-lane tracked kernel and on the 8-event kernel of the moving evaluation
     (`zz_local_spec8g_kernel`): bit for bit their oracles."""
     pkg = gpu_pkg
@@ -202,7 +202,8 @@ def test_adversarial_graphs_both_evaluations(gpu_pkg, which, T, tracked):
         ens.set_gradient_tracking(tracked)
         ens.set_state_synthetic(0.0, c, 1)
         ens.run(0.05)
-        assert ens.kernel_name() == ("zz_local_trackp_kernel<LAT=false>" if tracked else "zz_local_spec8g_kernel")
+        assert ens.kernel_name() == (("zz_local_trackp_kernel<LAT=false>" if trackp_form == "one_wave" else "zz_local_trackp2_kernel<LAT=false>")
+                                     if tracked else "zz_local_spec8g_kernel")
     for q in range(nch):
         r = O.spdmp_zigzag(G, None, G, x0[q], th0[q], c, T, seed=1700 + q, tracked=tracked)
         assert r["status"] == 0 and len(r["events"]) > 1000

@@ -46,7 +46,7 @@ def check_chain_bitwise(ev, fs_t, fs_x, fs_th, acc, num, cout, r):
 
 
 @pytest.mark.parametrize("n,T", [(48, 12.0), (64, 6.0), (47, 5.0)])
-def test_tracked_matches_oracle_on_lattices(gpu_pkg, n, T):
+def test_tracked_matches_oracle_on_lattices(gpu_pkg, n, T, trackp_form):
     """The north-star workload's relatives (n x n grid-Laplace GMRFs; 47 is odd: border templates everywhere), bound Γ == target Γ."""
     pkg = gpu_pkg
     G = pkg.problems.gmrf_precision(n)
@@ -113,7 +113,7 @@ def test_tracked_with_looser_bound_mean_and_adapt(gpu_pkg):
                             O.spdmp_zigzag(0.9 * G, mu, G, x0[k], th0[k], c, T, seed=31 + k, target_mu=mu, adapt=True, factor=1.8, tracked=True))
 
 
-def test_tracked_slices_trace_refills_and_violation(gpu_pkg):
+def test_tracked_slices_trace_refills_and_violation(gpu_pkg, trackp_form):
     """Slices with PDMP_RUN_STOP_BEFORE, a trace buffer that fills up several times, the reference tail (last event at t′ >= T), path
     integrals (batch means) against the host integral of the trace, and a bound violation without adapt (status, not a crash)."""
     pkg = gpu_pkg
@@ -260,7 +260,7 @@ def test_full_size_traces_and_states_against_exact_kernel_and_oracle(c3_tracked)
 
 
 @pytest.mark.parametrize("which", [0, 1])
-def test_tracked_with_a_start_time(gpu_pkg, monkeypatch, which):
+def test_tracked_with_a_start_time(gpu_pkg, monkeypatch, which, trackp_form):
     """t0 != 0: the reference's initial queue carries no t0 (src/sfact.jl:186), so the first proposals lie BEFORE the clocks' start; the
     pair-layout kernel's level-1 base must sit below them, and its t_old is stored (an order of times would not give it)."""
     pkg = gpu_pkg

@@ -11,7 +11,7 @@ import numpy as np
 from . import build as _build
 
 PDMP_OK = 0
-ABI_VERSION = 3  # include/pdmp_mi355.h: PDMP_ABI_VERSION
+ABI_VERSION = 2  # include/pdmp_mi355.h: PDMP_ABI_VERSION
 ERR_NAMES = {0: "PDMP_OK", 1: "PDMP_ERR_INVALID", 2: "PDMP_ERR_NO_DEVICE", 3: "PDMP_ERR_HIP",
              4: "PDMP_ERR_UNSUPPORTED", 5: "PDMP_ERR_NOMEM"}
 
@@ -46,7 +46,7 @@ EXPORTED_SYMBOLS = [
 ]
 # include/pdmp_debug.h: diagnostics, not part of the drop-in boundary
 DEBUG_SYMBOLS = ["pdmp_debug_set_kernel", "pdmp_debug_set_spec_g2", "pdmp_debug_set_phase_profile", "pdmp_debug_phase_profile",
-                 "pdmp_debug_set_proposal_dump", "pdmp_debug_set_track_groups", "pdmp_debug_set_helper_wave", "pdmp_debug_set_helper_steering", "pdmp_debug_last_kernel", "pdmp_debug_set_logistic_rows", "pdmp_debug_math_probe", "pdmp_debug_write_probe", "pdmp_debug_sector_probe"]
+                 "pdmp_debug_set_proposal_dump", "pdmp_debug_set_track_groups", "pdmp_debug_last_kernel", "pdmp_debug_set_logistic_rows", "pdmp_debug_math_probe", "pdmp_debug_write_probe", "pdmp_debug_sector_probe"]
 DEBUG_KERNELS = {"auto": 0, "seq": 1, "spec4": 2, "spec8": 3, "exactp": 4}
 
 
@@ -62,12 +62,6 @@ class PdmpError(RuntimeError):
 
 
 _lib = None
-_loaded_path = None
-
-
-def loaded_path():
-    """Path of the library this module instance actually loaded (None before load())."""
-    return _loaded_path
 
 
 def lib_path():
@@ -77,7 +71,7 @@ def lib_path():
 
 def load():
     """Load libpdmp_mi355.so; raise if it has not been built (no fallback)."""
-    global _lib, _loaded_path
+    global _lib
     if _lib is not None:
         return _lib
     path = lib_path()
@@ -162,8 +156,6 @@ def load():
     L.pdmp_debug_phase_profile.argtypes = [vp, vp, C.POINTER(C.c_int)]
     L.pdmp_debug_set_proposal_dump.argtypes = [vp, i64]
     L.pdmp_debug_set_track_groups.argtypes = [vp, C.c_int]
-    L.pdmp_debug_set_helper_wave.argtypes = [vp, C.c_int]
-    L.pdmp_debug_set_helper_steering.argtypes = [vp, C.c_double, C.c_double, C.c_int, C.c_double]
     L.pdmp_debug_last_kernel.argtypes = [vp, C.c_char_p, i64]
     L.pdmp_debug_set_logistic_rows.argtypes = [vp, C.c_int]
     for name in EXPORTED_SYMBOLS + DEBUG_SYMBOLS:
@@ -171,7 +163,6 @@ def load():
         if name not in ("pdmp_last_error", "pdmp_abi_version", "pdmp_device_count", "pdmp_ensemble_destroy", "pdmp_comm_destroy"):
             fn.restype = C.c_int
     _lib = L
-    _loaded_path = path
     return L
 
 

@@ -70,11 +70,6 @@ struct DevBuf {
 
 }  // namespace
 
-// zz_local_trackp: ensembles of at most this many chains run the two-wave form (pdmp_trackp.hip).  Measured on C3 (profiles/r05_*): the helper
-// wave pays while a SIMD holds at most two waves with it.
-#ifndef HELPER_WAVE_MAX_CHAINS
-#define HELPER_WAVE_MAX_CHAINS 1024
-#endif
 struct pdmp_ensemble {
     pdmp_config cfg{};
     hipStream_t stream = nullptr;
@@ -120,8 +115,6 @@ struct pdmp_ensemble {
     int dbg_phase_valid = 0;
     int64_t dbg_dump = 0;          // dump the first n proposals of chain 0 (one-event kernel) to stderr
     int dbg_track_groups = 0;      // gradient tracking: keep the 8-lane-group kernel where the one-proposal-per-lane kernel would run
-    double dbg_hw_steer[4] = {0, 0, 0, 0};  // pdmp_debug_set_helper_steering: grow, shrink, slack, ahead (0: the kernel's defaults)
-    int dbg_helper_wave = -1;      // zz_local_trackp: -1 = the two-wave form where the launch leaves SIMDs idle (HELPER_WAVE_MAX_CHAINS), 0 = never, 1 = always
     // tracked-gradient kernel (pdmp_ensemble_set_gradient_tracking)
     bool track_requested = false, track = false, track_two_sums = false;
     bool track_lg = false;     // tracked bounds under the logistic target (zz_logistic_lds_kernel<.., TRK>); d_trk holds (g, gd, tg) per coordinate
@@ -380,20 +373,6 @@ pdmp_status pdmp_debug_last_kernel(pdmp_ensemble* e, char* out, int64_t cap) {
 pdmp_status pdmp_debug_set_track_groups(pdmp_ensemble* e, int on) {
     if (!e) return fail(PDMP_ERR_INVALID, "null argument");
     e->dbg_track_groups = (on == 1) ? 1 : 0;
-    return PDMP_OK;
-}
-pdmp_status pdmp_debug_set_helper_wave(pdmp_ensemble* e, int mode) {
-    if (!e || mode < -1 || mode > 1) return fail(PDMP_ERR_INVALID, "helper wave: -1 (by occupancy), 0 (never), 1 (always)");
-    e->dbg_helper_wave = mode;
-    return PDMP_OK;
-}
-pdmp_status pdmp_debug_set_helper_steering(pdmp_ensemble* e, double grow, double shrink, int slack, double ahead) {
-    if (!e || !(grow > 1.0) || !(shrink > 0.0 && shrink < 1.0) || slack < 0 || slack > 64 || !(ahead >= 0.0))
-        return fail(PDMP_ERR_INVALID, "helper steering: grow > 1, 0 < shrink < 1, 0 <= slack <= 64, ahead >= 0");
-    e->dbg_hw_steer[0] = grow;
-    e->dbg_hw_steer[1] = shrink;
-    e->dbg_hw_steer[2] = (double)slack;
-    e->dbg_hw_steer[3] = ahead;
     return PDMP_OK;
 }
 pdmp_status pdmp_debug_set_logistic_rows(pdmp_ensemble* e, int w) {
@@ -1479,22 +1458,7 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         // one proposal per lane where the graph is the plain lattice (pdmp_trackp.hip); elsewhere, and on request, the 8-lane-group kernel
         if (e->track_pairs) {
             P.keys = e->d_kp.p;
-            // the two-wave form (a helper wave per chain) where the ensemble leaves SIMDs idle: at most two resident waves per SIMD with it
-            // (1024 SIMDs, two waves per chain) -- a rank's share of a strong-scaled job; wider ensembles hide a wave's latency with other chains
-            {
-                uint32_t hist[16] = {0}, best = 0;
-                for (int64_t k = 0; k < e->cfg.d; ++k) hist[std::min<uint32_t>(e->colptr[(size_t)k + 1] - e->colptr[(size_t)k], 15u)] += 1;
-                for (uint32_t k = 1; k < 16; ++k)
-                    if (hist[k] > hist[best]) best = k;
-                P.typ_extra = best > 0 ? best - 1u : 0u;
-            }
-            P.hw_grow = e->dbg_hw_steer[0];
-            P.hw_shrink = e->dbg_hw_steer[1];
-            P.hw_slack = (uint32_t)e->dbg_hw_steer[2];
-            P.hw_ahead = e->dbg_hw_steer[3];
-            P.helper_wave = (e->dbg_helper_wave == 1 || (e->dbg_helper_wave == -1 && e->cfg.nchains <= HELPER_WAVE_MAX_CHAINS)) ? 1 : 0;
-            e->last_kernel = P.helper_wave ? (e->lattice_n ? "zz_local_trackp2_kernel" : "zz_local_trackp2_kernel<LAT=false>")
-                                           : (e->lattice_n ? "zz_local_trackp_kernel" : "zz_local_trackp_kernel<LAT=false>");
+            e->last_kernel = e->lattice_n ? "zz_local_trackp_kernel" : "zz_local_trackp_kernel<LAT=false>";
             int rcp = pdmp::launch_zz_local_trackp(P, e->cfg.nchains, s);
             if (rcp != 0) return fail(PDMP_ERR_HIP, "zz_local_trackp launch failed (%d)", rcp);
             HIP_TRY(hipEventRecord(e->ev1, s));

@@ -28,7 +28,6 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
-#include <type_traits>
 
 #include "../../include/pdmp_detmath.h"
 #include "pdmp_engine.hpp"
@@ -82,14 +81,6 @@ __device__ __forceinline__ double w_grp8_min(double v) {
     v = w_min(v, w_dpp<0x141>(v));
     return v;
 }
-__device__ __forceinline__ uint32_t w_grp8_min_u32(uint32_t v) {
-    uint32_t o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);
-    v = (o < v) ? o : v;
-    o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true);
-    v = (o < v) ? o : v;
-    o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xf, 0xf, true);
-    return (o < v) ? o : v;
-}
 __device__ __forceinline__ double w_pos(double x) {
     return (x > 0.0) ? x : ((x != x) ? x : 0.0);
 }
@@ -111,20 +102,6 @@ __device__ __forceinline__ double w_below(double x) {  // the largest double bel
     return __longlong_as_double(b);
 }
 
-__device__ __forceinline__ uint32_t w_wave_min_u32(uint32_t v) {  // (DPP: six steps on the vector unit instead of six ds_bpermute round trips)
-    auto step = [](uint32_t x, auto ctrl) -> uint32_t {
-        const uint32_t o = (uint32_t)__builtin_amdgcn_mov_dpp((int)x, decltype(ctrl)::value, 0xf, 0xf, true);
-        return (o < x) ? o : x;
-    };
-    v = step(v, std::integral_constant<int, 0xB1>{});
-    v = step(v, std::integral_constant<int, 0x4E>{});
-    v = step(v, std::integral_constant<int, 0x141>{});
-    v = step(v, std::integral_constant<int, 0x140>{});
-    // (row_bcast: lanes that receive nothing read 0 and are not used: the result is lane 63's)
-    v = step(v, std::integral_constant<int, 0x142>{});
-    v = step(v, std::integral_constant<int, 0x143>{});
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-}
 // DPP prefix operations over the 64 lanes (row_shr 1, 2, 3 of the input, then row_shr 4 / 8 of the partial result inside the enabled banks,
 // then row_bcast 15 / 31 across the rows): lanes without a source keep the identity.
 template <int CTRL, int ROWM, int BANKM>
@@ -183,40 +160,26 @@ __device__ __forceinline__ double p_dec(uint32_t bits, double tb) {
     return w_below(tb + (double)__uint_as_float(bits & ~7u));  // (one ulp below the rounded sum: never above the exact one)
 }
 constexpr uint32_t P_INFBITS = 0x7f7ffff8u;  // patterns from here on: the block is empty (+Inf)
-__device__ __forceinline__ uint32_t lbf_pos(const unsigned char* smem, uint32_t b) {  // position bits of block b's level-1 entry
-    return reinterpret_cast<const uint32_t*>(smem)[b] & 7u;
-}
 
 }  // namespace
 
-// LDS layout (bytes).  HW = the two-wave form (below): room for 64 candidates, the control words shared with the helper wave and the ring of draws.
-template <bool HW>
-struct WL {
-    static constexpr uint32_t LB = 0;                      // [2048] u32 lower bounds of the block minima (+ argument position), key blocks of 8
-    static constexpr uint32_t EX = 8192;                   // [64] f64 what event e exposes; before that the exact block minima of the candidates
-    static constexpr uint32_t RS = 8704;                   // [CMAX] f64 candidates: block minimum without the argument
-    static constexpr uint32_t TP = HW ? 9216 : 9152;       // [CMAX] f64 candidates: proposal time stored with the argument
-    static constexpr uint32_t PB = HW ? 9728 : 9600;       // [CMAX] u8 candidates: position of the argument | position of the runner-up << 4
-    static constexpr uint32_t SLB = HW ? 9792 : 9664;      // [64] u16 event blocks, rank order
-    static constexpr uint32_t TB = HW ? 9920 : 9792;       // [64] u16 candidate blocks, compaction order
-    static constexpr uint32_t ACL = HW ? 10048 : 9920;     // [8] u16 the accepted events
-    static constexpr uint32_t RO = HW ? 10064 : 9936;      // [64] u8 candidate of each rank
-    static constexpr uint32_t SELDT = HW ? 10128 : 10000;  // f64 selection threshold above the minimum
-    static constexpr uint32_t NB = HW ? 10144 : 10016;     // (LAT = false) [8][8] u16 G1 of the accepted events, in event order
-    static constexpr uint32_t CTL = 10272;                 // (HW) control words shared by the two waves (struct WCtl)
-    static constexpr uint32_t HPF = 10336;                 // (HW) [64] u16 the helper wave's list of coordinates whose lines it requests
-    static constexpr uint32_t RING = 10464;                // (HW) [W_NR] (u, log u): draw n of the launch at slot n % W_NR
-    static constexpr uint32_t EVD = 18656;                 // (HW) [6][64] f64 event slots, by rank: th, g, gd, tg, c, c/100 of the event's coordinate
-    static constexpr uint32_t EVU = 21728;                 // (HW) [64] u32 event slots: block | position bits << 16
-    static constexpr uint32_t EVN = 21984;                 // (HW, LAT = false) [64] 8 x u16 event slots: G1 of the event's coordinate
-    static constexpr int CMAX = HW ? 64 : 56;              // candidates per iteration (block-scan passes of 8)
-    static constexpr uint32_t WIN = HW ? 256u : 128u;      // draws an iteration may consume (single wave: two per lane in registers)
-};
-constexpr uint32_t W_NR = 512;  // (HW) ring slots
+// LDS layout (bytes)
+constexpr uint32_t W_LB = 0;         // [2048] u32 lower bounds of the block minima (+ argument position), key blocks of 8
+constexpr uint32_t W_EX = 8192;      // [64] f64 what event e exposes; before that the exact block minima of the candidates
+constexpr uint32_t W_RS = 8704;      // [56] f64 candidates: block minimum without the argument
+constexpr uint32_t W_TP = 9152;      // [56] f64 candidates: proposal time stored with the argument
+constexpr uint32_t W_PB = 9600;      // [56] u8 candidates: position of the argument | position of the runner-up << 4
+constexpr uint32_t W_SLB = 9664;     // [64] u16 event blocks, rank order
+constexpr uint32_t W_TB = 9792;      // [64] u16 candidate blocks, compaction order
+constexpr uint32_t W_ACL = 9920;     // [8] u16 the accepted events
+constexpr uint32_t W_RO = 9936;      // [64] u8 candidate of each rank
+constexpr uint32_t W_SELDT = 10000;  // f64 selection threshold above the minimum
 constexpr uint32_t W_BYTES = 10008;
-constexpr uint32_t W_BYTES_G = WL<false>::NB + 128;
-constexpr uint32_t W_BYTES_HW = WL<true>::EVN + 64 * 16;  // 23 008 bytes: 6 chains per CU (the two-wave form runs at most 4)
+constexpr uint32_t W_NB = 10016;     // (LAT = false) [8][8] u16 G1 of the accepted events, in event order
+constexpr uint32_t W_BYTES_G = W_NB + 128;
 constexpr uint32_t W_NBLK = 2048;
+constexpr uint32_t W_WIN = 128;      // draws held in registers (two per lane)
+constexpr int W_CMAX = 56;           // candidates per iteration (7 block-scan passes of 8)
 constexpr int W_AMAX = 8;            // accepted events per iteration (one group each)
 // steering of the selection threshold (measured: 1.15 / 0.8 / 3 -- pdmp_trackx.hip's -- is 3.5 % slower here, where every candidate's line is read)
 #ifndef W_GROW
@@ -224,28 +187,7 @@ constexpr int W_AMAX = 8;            // accepted events per iteration (one group
 #define W_SHRINK 0.98
 #define W_SLACK 5u
 #endif
-// ... of the two-wave form, which runs where the SIMDs are under-occupied: a candidate read in vain costs nothing there, a short list does
-#ifndef W_GROW_HW
-#define W_GROW_HW 1.1
-#define W_SHRINK_HW 0.95
-#define W_SLACK_HW 20u
-#endif
-#ifndef W_NHYP
-#define W_NHYP 8     // hypotheses of the accept chain's first guess, two-wave form (a draw is one LDS read)
-#define W_NHYP_1W 4  // ... single-wave form (a draw is two ds_bpermute pairs; A/B at 2048 chains: 4 is 0.6 % faster than none, 8 is 2 % slower)
-#endif
-#ifndef W_PF_AHEAD
-#define W_PF_AHEAD 2.0  // the helper wave requests the lines of every block within this many window lengths beyond the window
-#endif
 static_assert(W_BYTES <= 10240 && W_BYTES_G <= 10240, "16 chains per CU: 160 KB / 16");
-static_assert(WL<true>::EVD == WL<true>::RING + W_NR * 16 && W_BYTES_HW <= 26624, "6 chains per CU: 160 KB / 6");
-struct WCtl {  // (HW) written by one wave, polled by the other: DS operations of a wave execute in order, so data written before a word is visible with it
-    uint32_t filled;    // helper: draws [0, filled) of the launch are in the ring
-    uint32_t consumed;  // main: draws [0, consumed) are used up (their slots may be overwritten)
-    uint32_t exitf;     // main: the launch is over
-    uint32_t pad;
-    double pf_tau, pf_dt, pf_tb;  // main: end and length of the current window, base of the level-1 bounds (what the helper prefetches against)
-};
 
 namespace {
 // is the 16-bit value v (given twice: v | v << 16) one of the eight halves of nb?
@@ -263,96 +205,9 @@ __device__ __forceinline__ uint32_t nb_count(const uint4 nb) {
 }
 }  // namespace
 
-// The helper wave of the two-wave form (HW): wave 1 of the chain's workgroup.  It computes nothing the result depends on beyond the chain's
-// stream of uniforms, which it produces AHEAD of the main wave -- draw n of the launch and its logarithm into slot n % W_NR of a ring in LDS, 64
-// per pass, as far as the main wave's published consumption leaves room -- and it requests the lines the main wave's NEXT windows will read
-// (every block whose level-1 bound lies within W_PF_AHEAD window lengths beyond the current window: its key line, the record its position bits
-// point at and, on the lattice, that coordinate's four neighbours' records), so that they are in the L2 when the main wave asks.  A request is
-// a load whose value is thrown away; what the helper reads of level 1 may be mid-update -- a wrong guess costs a line, never a result.
-template <bool LAT>
-__device__ __forceinline__ void trackp_helper(const ZzRunParams& P, unsigned char* smem, const int lane, const int64_t chain, const uint64_t seed,
-                                           const uint64_t nm0) {
-    using L = WL<true>;
-    volatile WCtl* const ctl = reinterpret_cast<volatile WCtl*>(smem + L::CTL);
-    double2* const ring = reinterpret_cast<double2*>(smem + L::RING);
-    const uint4* const lb4 = reinterpret_cast<const uint4*>(smem + L::LB);
-    const int64_t d = P.d;
-    const uint32_t nlat = (uint32_t)P.lattice_n, nmagic = P.lattice_magic;
-    const char* const recb = reinterpret_cast<const char*>(reinterpret_cast<const TrRecP*>(P.rec) + chain * d);
-    const char* const kpb = reinterpret_cast<const char*>(reinterpret_cast<const double2*>(P.keys) + chain * P.dk);
-    uint16_t* const HPF = reinterpret_cast<uint16_t*>(smem + L::HPF);
-    uint32_t filled = 0, sink = 0;
-    double pf_done = -W_INF;  // blocks with bounds up to here have been requested
-    for (;;) {
-        if (ctl->exitf != 0u) break;
-        bool did = false;
-        const uint32_t cons = ctl->consumed;
-        while (filled + 64u <= cons + W_NR) {  // the ring comes first: as far as the main wave's consumption leaves room
-            const uint32_t n = filled + (uint32_t)lane;
-            const double u = pdmp_u01(seed, PDMP_STREAM_MAIN, nm0 + (uint64_t)n);
-            ring[n & (W_NR - 1u)] = make_double2(u, pdmp_log(u));
-            W_ORDER();
-            filled += 64u;
-            if (lane == 0) ctl->filled = filled;
-            did = true;
-        }
-        const double tau = ctl->pf_tau, dts = ctl->pf_dt, tbs = ctl->pf_tb;
-        const double target = tau + P.hw_ahead * dts;
-        if (target > pf_done) {
-            // every block whose bound lies in (pf_done, target]: compacted into a list, one coordinate per lane, all its lines requested at once
-            const uint32_t lo = (pf_done > tbs) ? p_thr(pf_done, tbs) : 0u, hi = p_thr(target, tbs);
-            uint32_t cm = 0;
-#pragma unroll
-            for (int j = 7; j >= 0; --j) {
-                const uint4 v = lb4[lane + 64 * j];
-                cm = (cm << 4) | ((v.x > lo && v.x <= hi) ? 1u : 0u) | ((v.y > lo && v.y <= hi) ? 2u : 0u) | ((v.z > lo && v.z <= hi) ? 4u : 0u) |
-                     ((v.w > lo && v.w <= hi) ? 8u : 0u);
-            }
-            const uint32_t ncl = (uint32_t)__builtin_popcount(cm);
-            const uint32_t incl = w_scan_add_u32(ncl);
-            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            uint32_t ix = incl - ncl, m_ = cm;
-            while (m_ != 0u) {
-                const uint32_t j = (uint32_t)(__ffs((int)m_) - 1);
-                const uint32_t b = 4u * ((uint32_t)lane + 64u * (j >> 2)) + (j & 3u);
-                if (ix < 64u) HPF[ix] = (uint16_t)(b * 8u + (lbf_pos(smem, b)));
-                ix += 1;
-                m_ &= m_ - 1u;
-            }
-            W_ORDER();
-            if ((uint32_t)lane < tot) {
-                const uint32_t i = (uint32_t)HPF[lane];
-                const char* const kl = kpb + (size_t)(i >> 3) * 128;
-                const char* const rl = recb + (size_t)i * 128;
-                uint32_t a0 = *reinterpret_cast<const uint32_t*>(kl), a1 = *reinterpret_cast<const uint32_t*>(kl + 64);
-                uint32_t a2 = *reinterpret_cast<const uint32_t*>(rl), a3 = *reinterpret_cast<const uint32_t*>(rl + 64);
-                if (LAT) {
-                    const uint32_t col = __umulhi(i, nmagic), row = i - col * nlat;
-                    const uint32_t nbr[4] = {col > 0u ? i - nlat : i, row > 0u ? i - 1u : i, row + 1u < nlat ? i + 1u : i, col + 1u < nlat ? i + nlat : i};
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        const char* const nl = recb + (size_t)nbr[w] * 128;
-                        a0 ^= *reinterpret_cast<const uint32_t*>(nl);
-                        a1 ^= *reinterpret_cast<const uint32_t*>(nl + 64);
-                    }
-                }
-                sink ^= a0 ^ a1 ^ a2 ^ a3;
-            }
-            asm volatile("" ::"v"(sink));
-            pf_done = target;
-            did = true;
-        }
-        if (!did) __builtin_amdgcn_s_sleep(4);
-    }
-    asm volatile("" ::"v"(sink));
-}
-
-template <bool PROF, bool LAT, bool HW>
-__device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
-    using L = WL<HW>;
-    constexpr int W_CMAX = L::CMAX;
-    constexpr uint32_t W_WIN = L::WIN;
-    const int lane = threadIdx.x & 63;
+template <bool PROF, bool LAT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void zz_local_trackp_kernel(ZzRunParams P) {
+    const int lane = threadIdx.x;
     const int g = lane >> 3, gl = lane & 7;
     const int64_t chain = blockIdx.x;
     const int64_t d = P.d;
@@ -360,22 +215,19 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
     const uint32_t nlat = (uint32_t)P.lattice_n, nmagic = P.lattice_magic;
 
     extern __shared__ __align__(16) unsigned char smem[];
-    uint32_t* const lbf = reinterpret_cast<uint32_t*>(smem + L::LB);
-    double* const EX = reinterpret_cast<double*>(smem + L::EX);
+    uint32_t* const lbf = reinterpret_cast<uint32_t*>(smem + W_LB);
+    double* const EX = reinterpret_cast<double*>(smem + W_EX);
     double* const KM = EX;  // (exact block minima of the candidates, until the events are set up)
-    double* const RS = reinterpret_cast<double*>(smem + L::RS);
-    double* const TPR = reinterpret_cast<double*>(smem + L::TP);
-    uint16_t* const SLB = reinterpret_cast<uint16_t*>(smem + L::SLB);
-    uint16_t* const TB = reinterpret_cast<uint16_t*>(smem + L::TB);
-    uint16_t* const ACL = reinterpret_cast<uint16_t*>(smem + L::ACL);
-    uint8_t* const RO = reinterpret_cast<uint8_t*>(smem + L::RO);
-    double* const EVD = reinterpret_cast<double*>(smem + L::EVD);      // (HW only)
-    uint32_t* const EVU = reinterpret_cast<uint32_t*>(smem + L::EVU);  // (HW only)
-    uint4* const EVN = reinterpret_cast<uint4*>(smem + L::EVN);        // (HW, LAT = false only)
-    uint4* const NB4 = reinterpret_cast<uint4*>(smem + L::NB);        // (LAT = false only)
-    uint16_t* const NB16 = reinterpret_cast<uint16_t*>(smem + L::NB);
-    volatile WCtl* const ctl = reinterpret_cast<volatile WCtl*>(smem + L::CTL);                // (HW only)
-    const double2* const ring = reinterpret_cast<const double2*>(smem + L::RING);              // (HW only)
+    double* const RS = reinterpret_cast<double*>(smem + W_RS);
+    double* const TPR = reinterpret_cast<double*>(smem + W_TP);
+    uint8_t* const PB = reinterpret_cast<uint8_t*>(smem + W_PB);
+    uint16_t* const SLB = reinterpret_cast<uint16_t*>(smem + W_SLB);
+    uint16_t* const TB = reinterpret_cast<uint16_t*>(smem + W_TB);
+    uint16_t* const ACL = reinterpret_cast<uint16_t*>(smem + W_ACL);
+    uint8_t* const RO = reinterpret_cast<uint8_t*>(smem + W_RO);
+    double* const SELDT = reinterpret_cast<double*>(smem + W_SELDT);
+    uint4* const NB4 = reinterpret_cast<uint4*>(smem + W_NB);        // (LAT = false only)
+    uint16_t* const NB16 = reinterpret_cast<uint16_t*>(smem + W_NB);
 
     TrRecP* const rec = reinterpret_cast<TrRecP*>(P.rec) + chain * d;
     double2* const kp = reinterpret_cast<double2*>(P.keys) + chain * P.dk;  // (key, t_old) per coordinate
@@ -383,26 +235,9 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
     pdmp_event* const evout = P.ev ? P.ev + chain * P.trace_cap : nullptr;
 
     uint32_t status = hdr->c.status;
-    if (status == PDMP_CHAIN_BOUND_VIOLATED || status == PDMP_CHAIN_STALLED) return;  // (both waves)
+    if (status == PDMP_CHAIN_BOUND_VIOLATED || status == PDMP_CHAIN_STALLED) return;
     const uint64_t seed = hdr->seed;
     const uint64_t nm0 = hdr->c.ndraw_main, ntrace0 = hdr->c.ntrace;
-    if (HW) {
-        // the two waves part here: the control words are set before either polls them (the one barrier of the kernel; the header is read by
-        // both waves above and written by the main wave at the very end)
-        if (threadIdx.x == 0) {
-            ctl->filled = 0u;
-            ctl->consumed = 0u;
-            ctl->exitf = 0u;
-            ctl->pf_tau = -W_INF;
-            ctl->pf_dt = 0.0;
-            ctl->pf_tb = 0.0;
-        }
-        __syncthreads();
-        if (threadIdx.x >= 64) {
-            trackp_helper<LAT>(P, smem, lane, chain, seed, nm0);
-            return;
-        }
-    }
     uint32_t dnm = 0, dnum = 0, dnacc = 0, vnacc = 0;
     // ring of uniforms in registers: ureg[q] holds draw nm0 + uidx[q], the unique index n in [dnm, dnm + 128) with n % 64 == lane and (n / 64) % 2 == q
     double ureg[2] = {0.0, 0.0};
@@ -416,7 +251,7 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
                                     ? (uint32_t)(((uint64_t)P.trace_cap > ntrace0) ? ((uint64_t)P.trace_cap - ntrace0) : 0)
                                     : 0xffffffffu;
 
-    double seldt = 1e-3;  // (wave-uniform) the selection threshold above the queue's minimum
+    if (lane == 0) SELDT[0] = 1e-3;
     // base of the level-1 bounds: below every key (the initial keys of the reference carry no t0, src/sfact.jl:186)
     double tb;  // (wave-uniform; moves up with the front)
     {
@@ -450,7 +285,6 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
 
     uint64_t ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t ph_t0 = PROF ? (uint64_t)__builtin_readcyclecounter() : 0;
-    uint64_t ph_rounds = 0, ph_guess = 0;
     uint64_t ph_iters = 0, ph_raw = 0, ph_zone = 0, ph_eval = 0;  // candidates: selected, after the zone cut, after the window and accept limits
 #define WPHASE(k)                                                         \
     do {                                                                  \
@@ -471,12 +305,8 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
             status = PDMP_CHAIN_TRACE_FULL;
             break;
         }
-        // ---------------- ring of uniforms: draws dnm .. dnm + 127, two per lane (HW: dnm .. dnm + 255 from the helper wave's ring in LDS)
-        if (HW) {
-            if (lane == 0) ctl->consumed = dnm;
-            while (ctl->filled < dnm + W_WIN) __builtin_amdgcn_s_sleep(1);
-            W_ORDER();
-        } else {
+        // ---------------- ring of uniforms: draws dnm .. dnm + 127, two per lane
+        {
             const uint32_t n0 = dnm + (((uint32_t)lane - dnm) & 63u);  // the smallest n >= dnm with n % 64 == lane
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -497,14 +327,9 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
             }
         }
         WPHASE(7);
-        auto draw = [&](uint32_t n) -> double {  // draw nm0 + n for dnm <= n < dnm + W_WIN (every lane calls it: ds_bpermute)
-            if (HW) return ring[n & (W_NR - 1u)].x;
+        auto draw = [&](uint32_t n) -> double {  // draw nm0 + n for dnm <= n < dnm + 128 (every lane calls it: ds_bpermute)
             const double v0 = w_shfl(ureg[0], n & 63u), v1 = w_shfl(ureg[1], n & 63u);
             return ((n >> 6) & 1u) ? v1 : v0;
-        };
-        auto drawlog = [&](uint32_t n) -> double {  // its logarithm (HW: computed once, by the helper wave, with the same pdmp_log)
-            if (HW) return ring[n & (W_NR - 1u)].y;
-            return pdmp_log(draw(n));
         };
         // ---------------- select: every block whose lower bound is within the threshold, at most W_CMAX of them
         int C = 0;
@@ -526,7 +351,11 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
             uint32_t mloc = kk[0];
 #pragma unroll
             for (int j = 1; j < 32; ++j) mloc = (kk[j] < mloc) ? kk[j] : mloc;
-            uint32_t mqb = w_wave_min_u32(mloc);
+            for (int off = 32; off >= 1; off >>= 1) {
+                const uint32_t o = (uint32_t)__shfl_xor((int)mloc, off, 64);
+                mloc = (o < mloc) ? o : mloc;
+            }
+            uint32_t mqb = mloc;
             double mql = p_dec(mqb, tb);  // a lower bound of the next event time
             if (mqb < P_INFBITS && (need_rebase || mql - tb > 0.25)) {
                 // move the base of the bounds up to the front (a float resolves 2^-24 of its distance from the base)
@@ -541,7 +370,11 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
                 mloc = kk[0];
 #pragma unroll
                 for (int j = 1; j < 32; ++j) mloc = (kk[j] < mloc) ? kk[j] : mloc;
-                mqb = w_wave_min_u32(mloc);
+                for (int off = 32; off >= 1; off >>= 1) {
+                    const uint32_t o = (uint32_t)__shfl_xor((int)mloc, off, 64);
+                    mloc = (o < mloc) ? o : mloc;
+                }
+                mqb = mloc;
                 mql = p_dec(mqb, tb);
                 W_ORDER();
             }
@@ -550,7 +383,7 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
             } else if (stop_before && !(mql < T)) {
                 finished = true;
             } else {
-                double dt_sel = seldt;
+                double dt_sel = w_uniform(SELDT[0]);
                 uint32_t cm = 0, ncl = 0, incl = 0;
                 for (int tries = 0;; ++tries) {
                     tau = mql + dt_sel;
@@ -590,25 +423,13 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
             break;
         }
         if (finished) break;
-        if (HW && lane == 0) {  // what the helper wave prefetches against
-            ctl->pf_tau = tau;
-            ctl->pf_dt = dt_used;
-            ctl->pf_tb = tb;
-        }
         W_ORDER();
         WPHASE(8);
         const bool crowded = Cc > (uint32_t)W_CMAX;  // exact ties beyond W_CMAX blocks (keys tied by construction): handled one event at a time
         if (crowded) Cc = (uint32_t)W_CMAX;
-        // ---------------- candidate lane c: its block's line -- the 8 (key, time) pairs, eight 16-byte loads of ITS lane (the lines are distinct, the
-        // request count is that of a group of 8 lanes reading one pair each) -- and the record the position bits point at, requested together
+        // ---------------- candidate lane c: its block, the record the position bits point at (requested now, with the block's line)
         const bool isc = (uint32_t)lane < Cc;
         const uint32_t cblk = isc ? (uint32_t)TB[lane] : 0u;
-        double2 q8[8];
-        {
-            const double2* const bl = kp + (size_t)cblk * 8;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) q8[q] = isc ? bl[q] : make_double2(W_INF, 0.0);
-        }
         const uint32_t cpos = isc ? (lbf[cblk] & 7u) : 0u;
         const uint32_t ci = cblk * 8u + cpos;
         const TrRecP* const rci = rec + ci;
@@ -616,34 +437,43 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
         const double2 c_c2 = *reinterpret_cast<const double2*>(&rci->c);  // (same line: no table in the event loop)
         uint4 c_nb = make_uint4(0u, 0u, 0u, 0u);
         if (!LAT) c_nb = *reinterpret_cast<const uint4*>(&rci->gam0);  // G1[ci]: eight 16-bit ids
-        // the exact minimum of the block, its position (the lowest on ties) and time, the minimum of the rest and its position: in the lane's own
-        // registers, one pass for all candidates instead of one per 8 of them
-        double c_km = W_INF, c_rs = W_INF, c_tp = 0.0;
-        uint32_t c_pb = 0u;
+        // ---------------- the candidates' lines, 8 per pass (one per 8-lane group, one (key, time) pair per lane): exact minimum, its position and
+        // time, the minimum of the rest and its position -- staged in LDS per candidate
         {
-            double m1 = q8[0].x, t1 = q8[0].y;
-            uint32_t p1 = 0u;
+            const int npass = ((int)Cc + 7) >> 3;
+            for (int p0 = 0; p0 < npass; p0 += 4) {
+                double2 k2[4];
 #pragma unroll
-            for (int q = 1; q < 8; ++q) {
-                const bool lt = q8[q].x < m1;
-                m1 = lt ? q8[q].x : m1;
-                t1 = lt ? q8[q].y : t1;
-                p1 = lt ? (uint32_t)q : p1;
-            }
-            double m2 = W_INF;
+                for (int q = 0; q < 4; ++q) {
+                    const int e = 8 * (p0 + q) + g;
+                    k2[q] = make_double2(W_INF, 0.0);
+                    if (e < (int)Cc) k2[q] = kp[(size_t)TB[e] * 8 + gl];
+                }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) m2 = w_min(m2, ((uint32_t)q == p1) ? W_INF : q8[q].x);
-            uint32_t p2 = 0u;
-#pragma unroll
-            for (int q = 7; q >= 0; --q) p2 = ((((uint32_t)q == p1) ? W_INF : q8[q].x) == m2) ? (uint32_t)q : p2;  // (the lowest position that holds it)
-            if (isc) {
-                c_km = m1;
-                c_rs = m2;
-                c_tp = t1;
-                c_pb = p1 | (p2 << 4);
+                for (int q = 0; q < 4; ++q) {
+                    if (8 * (p0 + q) >= (int)Cc) continue;  // (uniform)
+                    const int e = 8 * (p0 + q) + g;
+                    const double kq = k2[q].x;
+                    const double gm = w_grp8_min(kq);
+                    const uint64_t winball = __ballot(kq == gm);
+                    const int wl = __ffs((unsigned)((winball >> (8 * g)) & 0xffu)) - 1;  // (>= 0)
+                    const double kr = (gl == wl) ? W_INF : kq;
+                    const double gr = w_grp8_min(kr);
+                    const uint64_t rball = __ballot(kr == gr);
+                    const int rl = __ffs((unsigned)((rball >> (8 * g)) & 0xffu)) - 1;
+                    if (gl == wl && e < (int)Cc) {
+                        KM[e] = gm;
+                        RS[e] = gr;
+                        TPR[e] = k2[q].y;
+                        PB[e] = (uint8_t)((uint32_t)wl | ((uint32_t)rl << 4));
+                    }
+                }
             }
         }
+        W_ORDER();
         // ---------------- events = candidates whose exact minimum is within the threshold; everybody refreshes its bound
+        const double c_km = isc ? KM[lane] : W_INF;
+        const uint32_t c_pb = isc ? (uint32_t)PB[lane] : 0u;
         if (isc) lbf[cblk] = (c_km < W_INF) ? p_enc(c_km, tb, c_pb & 7u) : P_INFBITS;
         bool isev = isc && c_km <= tau;
         if (crowded) {
@@ -663,44 +493,33 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
         }
         const uint64_t evb = __ballot(isev);
         int nev = __popcll(evb);
-        // exactly equal keys among the events (probability zero unless keys are tied by construction) give equal ranks -- ranks count the strictly
-        // smaller keys, so their sum then falls short of 0 + 1 + .. + (nev − 1): one event this iteration, the tied minimum of the lowest block
-        bool slot = isev;  // this lane's candidate takes event slot `rank`
-        {
-            const uint32_t rsum = (uint32_t)__builtin_amdgcn_readlane((int)w_scan_add_u32(isev ? rank : 0u), 63);
-            if (rsum != (uint32_t)(nev * (nev - 1) / 2)) {
-                const double mn = w_wave_min(own);
-                const uint32_t bsel = w_wave_min_u32((isev && own == mn) ? cblk : 0xffffffffu);
-                slot = isev && cblk == bsel;  // (rank 0: nothing is smaller than the minimum)
-                nev = 1;
+        if (isev) RO[rank] = (uint8_t)lane;
+        W_ORDER();
+        const bool dup = isev && RO[rank] != (uint8_t)lane;
+        if (__ballot(dup) != 0) {
+            // exactly equal keys among the events (probability zero unless keys are tied by construction): one event this iteration, the tied
+            // minimum of the lowest block
+            const double mn = w_wave_min(own);
+            uint32_t bsel = (isev && own == mn) ? cblk : 0xffffffffu;
+            for (int off = 32; off >= 1; off >>= 1) {
+                const uint32_t o = (uint32_t)__shfl_xor((int)bsel, off, 64);
+                bsel = (o < bsel) ? o : bsel;
             }
+            W_ORDER();
+            if (isev && cblk == bsel) RO[0] = (uint8_t)lane;
+            nev = 1;
+            W_ORDER();
         }
         // a candidate whose record was requested at the wrong position ends the list at its rank
         {
             const bool wrongpos = isev && (c_pb & 7u) != cpos;
-            const uint32_t wr = w_wave_min_u32(wrongpos ? rank : 0xffffffffu);
+            uint32_t wr = wrongpos ? rank : 0xffffffffu;
+            for (int off = 32; off >= 1; off >>= 1) {
+                const uint32_t o = (uint32_t)__shfl_xor((int)wr, off, 64);
+                wr = (o < wr) ? o : wr;
+            }
             if (wr < (uint32_t)nev) nev = (int)wr;
         }
-        // ---------------- lane r = event r: everything moves over from its candidate's lane -- written to slot `rank`, read from slot `lane` (HW: the
-        // whole record; else the candidate's lane number, and the record through ds_bpermute)
-        if (slot && rank < (uint32_t)nev) {
-            KM[rank] = c_km;
-            RS[rank] = c_rs;
-            TPR[rank] = c_tp;
-            if (HW) {
-                EVD[0 * 64 + rank] = c_th;
-                EVD[1 * 64 + rank] = c_g;
-                EVD[2 * 64 + rank] = c_gd;
-                EVD[3 * 64 + rank] = c_tg;
-                EVD[4 * 64 + rank] = c_c2.x;
-                EVD[5 * 64 + rank] = c_c2.y;
-                EVU[rank] = cblk | (c_pb << 16);
-                if (!LAT) EVN[rank] = c_nb;
-            } else {
-                RO[rank] = (uint8_t)lane;
-            }
-        }
-        W_ORDER();
         WPHASE(9);
         C = nev;
         if (PROF) ph_iters += 1;
@@ -713,51 +532,29 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
                 status = PDMP_CHAIN_STALLED;  // (more than W_CMAX exactly tied block minima: keys tied by construction)
                 break;
             }
-            seldt = w_uniform(dt_used * 2.0);
+            if (lane == 0) SELDT[0] = dt_used * 2.0;
+            W_ORDER();
             continue;
         }
+        // ---------------- lane r = event r: everything moves over from its candidate's lane
         bool ev = lane < C;
-        const double tp = ev ? KM[lane] : W_INF;  // the event time: the exact block minimum
-        const double rest = ev ? RS[lane] : W_INF;
-        const double tprop_i = ev ? TPR[lane] : 0.0;
-        uint32_t blk, pbe;
-        double th, g_i, gd_i, tg_i;
-        double2 c_i2;
-        uint4 nb_i = make_uint4(~0u, ~0u, ~0u, ~0u);
-        if (HW) {
-            const uint32_t bu = EVU[lane];
-            blk = bu & 0xffffu;
-            pbe = bu >> 16;
-            th = EVD[0 * 64 + lane];
-            g_i = EVD[1 * 64 + lane];
-            gd_i = EVD[2 * 64 + lane];
-            tg_i = EVD[3 * 64 + lane];
-            c_i2 = make_double2(EVD[4 * 64 + lane], EVD[5 * 64 + lane]);
-            if (!LAT) nb_i = EVN[lane];
-        } else {
-            const uint32_t src = ev ? (uint32_t)RO[lane] : 0u;
-            blk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)cblk);
-            pbe = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)c_pb);
-            th = w_shfl(c_th, src);
-            g_i = w_shfl(c_g, src);
-            gd_i = w_shfl(c_gd, src);
-            tg_i = w_shfl(c_tg, src);
-            c_i2 = make_double2(w_shfl(c_c2.x, src), w_shfl(c_c2.y, src));
-            if (!LAT) {
-                nb_i.x = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)c_nb.x);
-                nb_i.y = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)c_nb.y);
-                nb_i.z = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)c_nb.z);
-                nb_i.w = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)c_nb.w);
-            }
-        }
+        const uint32_t src = ev ? (uint32_t)RO[lane] : 0u;
+        const uint32_t blk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)cblk);
+        const uint32_t pbe = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)c_pb);
+        const double tp = ev ? KM[src] : W_INF;  // the event time: the exact block minimum
+        const double rest = ev ? RS[src] : W_INF;
+        const double tprop_i = ev ? TPR[src] : 0.0;
         const uint32_t i = ev ? (blk * 8u + (pbe & 7u)) : 0u;
         const uint32_t rarg = blk * 8u + (pbe >> 4);
+        const double th = w_shfl(c_th, src), g_i = w_shfl(c_g, src), gd_i = w_shfl(c_gd, src), tg_i = w_shfl(c_tg, src);
+        const double2 c_i2 = make_double2(w_shfl(c_c2.x, src), w_shfl(c_c2.y, src));
         const double c_i = c_i2.x;
         W_ORDER();
         if (ev) SLB[lane] = (uint16_t)blk;
         W_ORDER();
         WPHASE(0);
         uint32_t rc_i = 0xffffu, k_i;
+        uint4 nb_i = make_uint4(~0u, ~0u, ~0u, ~0u);
         if (LAT) {
             // lattice coordinates packed for the zone test: byte 0 = row, byte 1 = column
             const uint32_t col_i = __umulhi(i, nmagic);
@@ -767,9 +564,14 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
             k_i = 1u + (col_i > 0u ? 1u : 0u) + (row_i > 0u ? 1u : 0u) + (row_i + 1u < nlat ? 1u : 0u) + (col_i + 1u < nlat ? 1u : 0u);
         } else {
             // G1[i] came with the candidate's line
+            nb_i.x = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)c_nb.x);
+            nb_i.y = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)c_nb.y);
+            nb_i.z = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)c_nb.z);
+            nb_i.w = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)c_nb.w);
             k_i = nb_count(nb_i);
         }
         W_ORDER();
+        WPHASE(1);
         // ---------------- rates from the tracked sums (src/sfact.jl:116-119 with g_i(t′) = g_i + gd_i (t′ − tg_i))
         const double g_now = g_i + gd_i * (tp - tg_i);
         const double l = w_pos(g_now * th);
@@ -779,67 +581,21 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
         const double a_i = c_i + (g_i + gd_i * (told_i - tg_i)) * th;
         const double b_i = c_i2.y + th * gd_i;
         const double lbound = w_pos(a_i + b_i * (tp - told_i));
-        // ---------------- accept chain: offsets and outcomes as a fix-point (every round settles the events up to the next change).  Event r's coin is
-        // draw 2 r + the draws the accepted events before it took beyond two (k − 1 each, k <= 8): three ballots of the accept mask by the bits of
-        // k − 1, counted below the lane (v_mbcnt) -- no prefix scan
-        const uint32_t ex_i = k_i - 1u;
-        uint32_t off = 2u * (uint32_t)lane;
+        // ---------------- accept chain: offsets and outcomes as a fix-point (every round settles the events up to the next change)
+        uint32_t cost = ev ? 2u : 0u;
+        uint32_t off = 0;
         bool acc = false;
-        {
-            // A first guess from W_NHYP hypotheses at once: "j accepted events of the usual size before me" puts my coin at 2 r + j e (e = the graph's
-            // most frequent k − 1: 4 inside the lattice).  The accept masks are walked on the scalar unit -- the first accepted event under
-            // hypothesis 0, the next one after it under hypothesis 1, ... -- until the masks run out or an accepted event of another size ends the
-            // walk.  The fix-point below starts from that guess and is what decides: from ANY start, round t leaves the first t events exact, and
-            // it ends only when a round reproduces its own input, which only the sequential outcome does.
-            const uint32_t etyp = P.typ_extra;
-            const uint64_t pl1 = __ballot(ev && (ex_i & 1u)), pl2 = __ballot(ev && (ex_i & 2u)), pl4 = __ballot(ev && (ex_i & 4u));
-            auto offsets = [&](uint64_t ab) -> uint32_t {  // 2 r + the extra draws of the accepted events before lane r: their k − 1, bit plane by bit plane
-                const uint64_t a1 = ab & pl1, a2 = ab & pl2, a4 = ab & pl4;
-                const uint32_t n1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(a1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)a1, 0u));
-                const uint32_t n2 = __builtin_amdgcn_mbcnt_hi((uint32_t)(a2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)a2, 0u));
-                const uint32_t n4 = __builtin_amdgcn_mbcnt_hi((uint32_t)(a4 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)a4, 0u));
-                return 2u * (uint32_t)lane + n1 + 2u * n2 + 4u * n4;
-            };
-            uint64_t accb = 0;
-            const uint64_t tg0_ = PROF ? (uint64_t)__builtin_readcyclecounter() : 0;
-            constexpr int NHYP = HW ? W_NHYP : W_NHYP_1W;
-            if (NHYP > 0) {
-                uint64_t hb[NHYP > 0 ? NHYP : 1];
-                double uj[NHYP > 0 ? NHYP : 1];
-#pragma unroll
-                for (int j = 0; j < NHYP; ++j) {  // (the reads first, by every lane: one round trip)
-                    const uint32_t oj = off + etyp * (uint32_t)j;
-                    uj[j] = draw(dnm + ((oj < W_WIN - 1u) ? oj : W_WIN - 1u));
-                }
-#pragma unroll
-                for (int j = 0; j < NHYP; ++j) {
-                    const uint32_t oj = off + etyp * (uint32_t)j;
-                    hb[j] = __ballot((int)ev & (int)(oj + 1u + k_i <= W_WIN) & (int)(uj[j] * lbound < l));
-                }
-                const uint64_t odd = __ballot(ev && ex_i != etyp);
-                uint64_t live = ~0ull;  // the lanes after the last accepted event found; 0 once the walk has ended
-#pragma unroll
-                for (int j = 0; j < NHYP; ++j) {
-                    const uint64_t rem = hb[j] & live;
-                    const uint64_t low = rem & (0ull - rem);  // its lowest set bit (0 if none)
-                    accb |= low;
-                    live = (low & ~odd) ? ~(low | (low - 1ull)) : 0ull;
-                }
-                if (accb != 0ull) off = offsets(accb);
-            }
-            if (PROF) ph_guess += (uint64_t)__builtin_readcyclecounter() - tg0_;
-            for (int round = 0; round < 72; ++round) {
-                if (PROF) ph_rounds += 1;
-                const bool inwin = ev && (off + 1u + k_i <= W_WIN);
-                const double u = draw(dnm + ((off < W_WIN - 1u) ? off : W_WIN - 1u));
-                acc = inwin && (u * lbound < l);  // :121
-                const uint64_t nb_ = __ballot(acc);
-                if (nb_ == accb) break;
-                accb = nb_;
-                off = offsets(accb);
-            }
+        for (int round = 0; round < 66; ++round) {
+            const uint32_t incl = w_scan_add_u32(cost);
+            off = incl - cost;
+            const bool inwin = ev && (off + 1u + k_i <= W_WIN);
+            const double u = draw(dnm + ((off < 127u) ? off : 127u));
+            acc = inwin && (u * lbound < l);  // :121
+            const uint32_t nc = ev ? (acc ? (1u + k_i) : 2u) : 0u;
+            const bool changed = nc != cost;
+            cost = nc;
+            if (__ballot(changed) == 0) break;
         }
-        const uint32_t cost = ev ? (acc ? (1u + k_i) : 2u) : 0u;
         // events whose draws would leave the ring wait for the next iteration
         {
             const uint64_t outb = __ballot(ev && !(off + 1u + k_i <= W_WIN));
@@ -848,7 +604,6 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
                 C = (cut < C) ? cut : C;
             }
         }
-        WPHASE(1);  // (the accept chain)
         // at most W_AMAX accepted events per iteration: the candidate list ends before the next one
         {
             uint64_t ab = __ballot(acc) & ((C < 64) ? ((1ull << C) - 1ull) : ~0ull);
@@ -940,20 +695,7 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
         // then free to re-bound their rejected proposals in the same evaluation, see below)
         const int g0 = 8 - nacc_it;
         const bool gact = g >= g0;
-        uint32_t ea = 0u;  // the event of this lane's group: the (g − g0)-th accepted one
-        if (HW) {
-            // (the positions of the accept mask's set bits, walked on the scalar unit: no round trip through LDS)
-            uint64_t m_ = accball;
-            const int want = g - g0;
-#pragma unroll
-            for (int n = 0; n < W_AMAX; ++n) {
-                const uint32_t pos = m_ ? (uint32_t)(__ffsll((unsigned long long)m_) - 1) : 0u;
-                m_ &= m_ - 1ull;
-                ea = (want == n) ? pos : ea;
-            }
-        } else {
-            ea = gact ? (uint32_t)ACL[g - g0] : 0u;
-        }
+        const uint32_t ea = gact ? (uint32_t)ACL[g - g0] : 0u;
         const uint32_t ia_b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ea << 2), (int)i);
         const uint32_t off_b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ea << 2), (int)off);
         const uint32_t ia = gact ? ia_b : 0u;
@@ -1016,7 +758,7 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
         double a2, b2, key2;
         {
             const uint32_t dix = gact ? (offa + 1u + (uint32_t)gl) : (off + 1u);
-            const double L = drawlog(dnm + ((dix < W_WIN - 1u) ? dix : W_WIN - 1u));
+            const double L = pdmp_log(draw(dnm + ((dix < 127u) ? dix : 127u)));
             const double cc = gact ? cjm2.x : c_i, cc100 = gact ? cjm2.y : c_i2.y;
             const double gg = gact ? gj : g_now, tt = gact ? thj : th, gdd = gact ? gdj : gd_i;
             a2 = cc + gg * tt;
@@ -1025,7 +767,7 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
         }
         const double keyj = mem ? key2 : W_INF;
         if (__ballot(ev && !acc && gact) != 0) {
-            const double L = drawlog(dnm + ((off + 1u < W_WIN - 1u) ? off + 1u : W_WIN - 1u));
+            const double L = pdmp_log(draw(dnm + ((off + 1u < 127u) ? off + 1u : 127u)));
             const double a2e = c_i + g_now * th;
             const double b2e = c_i2.y + th * gd_i;
             const double k2e = tp + w_poisson_time_L(a2e, b2e, L);
@@ -1058,9 +800,9 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
         {
             const double kin = (mem && (jm >> 3) == blka) ? keyj : W_INF;
             const double kinmin = w_grp8_min(kin);
-            // position bits of the member that holds it (the lowest lane of the group on ties): a DPP minimum of (lane in group, position)
-            const uint32_t wkey = (gact && kin == kinmin) ? (((uint32_t)gl << 3) | (jm & 7u)) : 0xffu;
-            const uint32_t jwin = w_grp8_min_u32(wkey);  // (no lane of an inactive group is read below)
+            const uint64_t winball = __ballot(gact && kin == kinmin);
+            const int wl = __ffs((unsigned)((winball >> (8 * g)) & 0xffu)) - 1;
+            const uint32_t jwin = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)(lane & ~7) + (uint32_t)(wl < 0 ? 0 : wl)) << 2), (int)jm);
             const bool restwins = resta_b <= kinmin;
             rowmin_a = restwins ? resta_b : kinmin;
             cand_a = restwins ? (rarga_b & 7u) : (jwin & 7u);
@@ -1074,8 +816,9 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
         // ---------------- validate: all earlier events commit, zones disjoint, nothing produced or exposed earlier than t′
         uint32_t Rc;
         {
-            const double prev = (lane > 0 && lane <= C) ? EX[lane - 1] : W_INF;  // what event lane − 1 exposes
-            const double pref = w_scan_min_f64(prev);  // exclusive prefix minimum
+            const double expo = ev ? EX[lane] : W_INF;
+            const double prev = w_shfl(expo, (uint32_t)((lane > 0) ? lane - 1 : 0));
+            const double pref = w_scan_min_f64((lane > 0) ? prev : W_INF);  // exclusive prefix minimum
             const bool okr = ev && (lane == 0 || pref > tp);  // (zone conflicts ended the candidate list already)
             const uint64_t bad = ~__ballot(okr);
             const uint32_t r_ok = bad ? (uint32_t)(__ffsll((unsigned long long)bad) - 1) : 64u;
@@ -1103,8 +846,7 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
             if (stopped) vsel = -1;
         }
         // steer the threshold so that the raw candidate list is just longer than what can commit
-        seldt = w_uniform(dt_used * (((int)Rc >= Craw) ? (HW ? P.hw_grow : W_GROW)
-                                                       : (((int)Rc + (int)(HW ? P.hw_slack : W_SLACK) < Craw) ? (HW ? P.hw_shrink : W_SHRINK) : 1.0)));
+        if (lane == 0) SELDT[0] = dt_used * (((int)Rc >= Craw) ? W_GROW : (((int)Rc + (int)W_SLACK < Craw) ? W_SHRINK : 1.0));
         WPHASE(4);
         // ---------------- commit the valid prefix
         const bool commit = ev && (uint32_t)lane < Rc;
@@ -1181,11 +923,8 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
         P.dbg[11] = (double)ph_raw;
         P.dbg[12] = (double)ph_zone;
         P.dbg[13] = (double)ph_eval;
-        P.dbg[14] = (double)ph_rounds;
-        P.dbg[15] = (double)ph_guess;
     }
 #undef WPHASE
-    if (HW && lane == 0) ctl->exitf = 1u;
     if (lane == 0) {
         hdr->c.t_last = t_last;
         hdr->t_event = t_event;
@@ -1196,20 +935,6 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
         hdr->c.ndraw_main = nm0 + dnm;
         hdr->c.status = status;
     }
-}
-
-template <bool PROF, bool LAT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void zz_local_trackp_kernel(ZzRunParams P) {
-    trackp_body<PROF, LAT, false>(P);
-}
-// The two-wave form: one chain per WORKGROUP of two wavefronts -- the main wave runs the event loop above, the helper wave (trackp_helper)
-// keeps the ring of draws filled and the next windows' lines on their way.  For ensembles that leave SIMDs idle (a rank's share of a
-// strong-scaled job: 2048 / 1024 / 512 chains on 1024 SIMDs), where a chain's rate is set by ONE wave's dependent chain of instructions and
-// round trips and nothing else runs beside it.  Same committed sequence, same floats (same draws, same pdmp_log, same arithmetic in the same
-// lanes): only who computes a uniform and when a line is requested differ.
-template <bool PROF, bool LAT>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 4))) void zz_local_trackp2_kernel(ZzRunParams P) {
-    trackp_body<PROF, LAT, true>(P);
 }
 
 bool zz_trackp_supported(const ZzRunParams& p) {
@@ -1224,23 +949,6 @@ int launch_zz_local_trackp(const ZzRunParams& p, int64_t nchains, void* stream) 
     ZzRunParams q = p;
     q.nblk = (uint32_t)((p.d + 7) / 8);  // (dk is a multiple of 64, the padding keys are +Inf)
     const bool lat = p.lattice_n != 0;
-    if (p.helper_wave) {
-        dim3 block2(128);
-        if (!(q.hw_grow > 1.0)) {  // (not set by pdmp_debug_set_helper_steering: the defaults)
-            q.hw_grow = W_GROW_HW;
-            q.hw_shrink = W_SHRINK_HW;
-            q.hw_slack = W_SLACK_HW;
-            q.hw_ahead = W_PF_AHEAD;
-        }
-        if (lat) {
-            if (p.dbg) hipLaunchKernelGGL((zz_local_trackp2_kernel<true, true>), grid, block2, W_BYTES_HW, (hipStream_t)stream, q);
-            else hipLaunchKernelGGL((zz_local_trackp2_kernel<false, true>), grid, block2, W_BYTES_HW, (hipStream_t)stream, q);
-        } else {
-            if (p.dbg) hipLaunchKernelGGL((zz_local_trackp2_kernel<true, false>), grid, block2, W_BYTES_HW, (hipStream_t)stream, q);
-            else hipLaunchKernelGGL((zz_local_trackp2_kernel<false, false>), grid, block2, W_BYTES_HW, (hipStream_t)stream, q);
-        }
-        return (int)hipGetLastError();
-    }
     if (lat) {
         if (p.dbg) hipLaunchKernelGGL((zz_local_trackp_kernel<true, true>), grid, block, W_BYTES, (hipStream_t)stream, q);
         else hipLaunchKernelGGL((zz_local_trackp_kernel<false, true>), grid, block, W_BYTES, (hipStream_t)stream, q);

@@ -46,11 +46,6 @@ class Ensemble:
             self.debug_set_kernel(k)
         if os.environ.get("PDMP_TRACK_GROUPS"):
             _lib.check(self._L.pdmp_debug_set_track_groups(self._h, int(os.environ["PDMP_TRACK_GROUPS"])))
-        if os.environ.get("PDMP_HELPER_WAVE"):
-            self.debug_set_helper_wave(int(os.environ["PDMP_HELPER_WAVE"]))
-        if os.environ.get("PDMP_HELPER_STEER"):  # "grow,shrink,slack,ahead"
-            g_, s_, k_, a_ = os.environ["PDMP_HELPER_STEER"].split(",")
-            _lib.check(self._L.pdmp_debug_set_helper_steering(self._h, float(g_), float(s_), int(k_), float(a_)))
         if os.environ.get("PDMP_LG_ROWS"):
             _lib.check(self._L.pdmp_debug_set_logistic_rows(self._h, int(os.environ["PDMP_LG_ROWS"])))
         if os.environ.get("PDMP_SPEC_G2"):
@@ -60,10 +55,6 @@ class Ensemble:
     def debug_set_kernel(self, name):
         """'auto' | 'seq' (one event per iteration) | 'spec4' (4-event kernel where the 8-event one would run); before set_flow."""
         _lib.check(self._L.pdmp_debug_set_kernel(self._h, _lib.DEBUG_KERNELS[name]))
-
-    def debug_set_helper_wave(self, mode):
-        """zz_local_trackp: -1 the two-wave form by ensemble width (default), 0 never, 1 always (include/pdmp_debug.h)."""
-        _lib.check(self._L.pdmp_debug_set_helper_wave(self._h, int(mode)))
 
     def kernel_name(self):
         """Event-loop kernel of the last run (include/pdmp_debug.h: pdmp_debug_last_kernel); '' before the first run."""
