@@ -43,6 +43,9 @@ pdmp_status pdmp_debug_set_helper_wave(pdmp_ensemble* ens, int mode);
 /* ... its tuning (none of it changes a result): the selection threshold grows by `grow` when every candidate committed and shrinks by `shrink`
  * when more than `slack` did not; the helper requests the lines of the blocks within `ahead` window lengths beyond the current window */
 pdmp_status pdmp_debug_set_helper_steering(pdmp_ensemble* ens, double grow, double shrink, int slack, double ahead);
+/* PDMP_CHAIN_PAUSED under test: a chain pauses once ONE launch has used n draws of its main stream (the subsampled-logistic kernel: n proposals)
+ * instead of 3 * 2^30; 0 restores the default */
+pdmp_status pdmp_debug_set_launch_count_limit(pdmp_ensemble* ens, uint32_t n);
 /* name of the event-loop kernel the last pdmp_ensemble_run launched (bench.py prints it with every line: no figure without its kernel) */
 pdmp_status pdmp_debug_last_kernel(pdmp_ensemble* ens, char* out, int64_t cap);
 /* chains per wavefront of the LDS-resident logistic kernel (config C4): -1 the library's default, 0 one chain (pdmp_logistic.hip), 16 or 32 =

@@ -62,6 +62,9 @@ typedef enum {
 #define PDMP_CHAIN_BOUND_VIOLATED 1 /* l >= lb with adapt = false (reference: error, src/sfact.jl:124) */
 #define PDMP_CHAIN_STALLED 2        /* queue minimum is +Inf */
 #define PDMP_CHAIN_TRACE_FULL 3     /* trace buffer full: drain with pdmp_ensemble_trace_* and run again */
+#define PDMP_CHAIN_PAUSED 4         /* a launch counts its draws and proposals in 32 bits: a chain that has used 3 * 2^30 of them inside ONE call of
+                                     * pdmp_ensemble_run (~10^9 proposals: only without a trace buffer) stops there, nothing to drain -- run again,
+                                     * the run continues exactly (ABI 3) */
 
 /* run flags */
 #define PDMP_RUN_REFERENCE_TAIL 0 /* `while t′ < T` (src/sfact.jl:199): the last event has t′ >= T        */

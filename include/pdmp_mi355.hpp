@@ -166,7 +166,7 @@ class Ensemble {
                 if (k.status == PDMP_CHAIN_BOUND_VIOLATED) throw std::runtime_error("Tuning parameter `c` too small.");
             sink(cnt);
             bool full = false;
-            for (const auto& k : cnt) full = full || k.status == PDMP_CHAIN_TRACE_FULL;
+            for (const auto& k : cnt) full = full || k.status == PDMP_CHAIN_TRACE_FULL || k.status == PDMP_CHAIN_PAUSED;  // (both resume with the next run)
             if (!full) return cnt;
         }
     }
@@ -429,7 +429,7 @@ inline std::vector<Result1d> run_1d(pdmp_1d_config cfg, const std::vector<double
             out[k].trace.insert(out[k].trace.end(), ev.begin() + (ptrdiff_t)(k * (size_t)cfg.trace_capacity),
                                 ev.begin() + (ptrdiff_t)(k * (size_t)cfg.trace_capacity + (size_t)nev[k]));
             if (st[k].status == PDMP_CHAIN_BOUND_VIOLATED) throw std::runtime_error("Tuning parameter `c` too small.");  // :55
-            again = again || st[k].status == PDMP_CHAIN_TRACE_FULL;
+            again = again || st[k].status == PDMP_CHAIN_TRACE_FULL || st[k].status == PDMP_CHAIN_PAUSED;
         }
         if (!again) break;
     }

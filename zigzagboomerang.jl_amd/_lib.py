@@ -17,7 +17,7 @@ ERR_NAMES = {0: "PDMP_OK", 1: "PDMP_ERR_INVALID", 2: "PDMP_ERR_NO_DEVICE", 3: "P
 
 PDMP_ERR_INVALID, PDMP_ERR_NO_DEVICE, PDMP_ERR_HIP, PDMP_ERR_UNSUPPORTED, PDMP_ERR_NOMEM = 1, 2, 3, 4, 5
 SAMPLER_ZIGZAG_LOCAL, SAMPLER_ZIGZAG_ALL, SAMPLER_BPS, SAMPLER_STICKY_ZIGZAG = 0, 1, 2, 3
-CHAIN_OK, CHAIN_BOUND_VIOLATED, CHAIN_STALLED, CHAIN_TRACE_FULL = 0, 1, 2, 3
+CHAIN_OK, CHAIN_BOUND_VIOLATED, CHAIN_STALLED, CHAIN_TRACE_FULL, CHAIN_PAUSED = 0, 1, 2, 3, 4
 RUN_REFERENCE_TAIL, RUN_STOP_BEFORE = 0, 1
 
 EVENT_DTYPE = np.dtype([("t", "<f8"), ("i", "<i8"), ("x", "<f8"), ("theta", "<f8")])
@@ -46,7 +46,7 @@ EXPORTED_SYMBOLS = [
 ]
 # include/pdmp_debug.h: diagnostics, not part of the drop-in boundary
 DEBUG_SYMBOLS = ["pdmp_debug_set_kernel", "pdmp_debug_set_spec_g2", "pdmp_debug_set_phase_profile", "pdmp_debug_phase_profile",
-                 "pdmp_debug_set_proposal_dump", "pdmp_debug_set_track_groups", "pdmp_debug_set_helper_wave", "pdmp_debug_set_helper_steering", "pdmp_debug_last_kernel", "pdmp_debug_set_logistic_rows", "pdmp_debug_math_probe", "pdmp_debug_write_probe", "pdmp_debug_sector_probe"]
+                 "pdmp_debug_set_proposal_dump", "pdmp_debug_set_track_groups", "pdmp_debug_set_helper_wave", "pdmp_debug_set_helper_steering", "pdmp_debug_set_launch_count_limit", "pdmp_debug_last_kernel", "pdmp_debug_set_logistic_rows", "pdmp_debug_math_probe", "pdmp_debug_write_probe", "pdmp_debug_sector_probe"]
 DEBUG_KERNELS = {"auto": 0, "seq": 1, "spec4": 2, "spec8": 3, "exactp": 4}
 
 
@@ -163,6 +163,7 @@ def load():
     L.pdmp_debug_set_proposal_dump.argtypes = [vp, i64]
     L.pdmp_debug_set_track_groups.argtypes = [vp, C.c_int]
     L.pdmp_debug_set_helper_wave.argtypes = [vp, C.c_int]
+    L.pdmp_debug_set_launch_count_limit.argtypes = [vp, C.c_uint32]
     L.pdmp_debug_set_helper_steering.argtypes = [vp, C.c_double, C.c_double, C.c_int, C.c_double]
     L.pdmp_debug_last_kernel.argtypes = [vp, C.c_char_p, i64]
     L.pdmp_debug_set_logistic_rows.argtypes = [vp, C.c_int]

@@ -121,6 +121,7 @@ struct pdmp_ensemble {
     int64_t dbg_dump = 0;          // dump the first n proposals of chain 0 (one-event kernel) to stderr
     int dbg_track_groups = 0;      // gradient tracking: keep the 8-lane-group kernel where the one-proposal-per-lane kernel would run
     double dbg_hw_steer[4] = {0, 0, 0, 0};  // pdmp_debug_set_helper_steering: grow, shrink, slack, ahead (0: the kernel's defaults)
+    uint32_t dbg_count_limit = 0;  // pdmp_debug_set_launch_count_limit (0: PDMP_LAUNCH_COUNT_LIMIT)
     int dbg_helper_wave = -1;      // zz_local_trackp: -1 = the two-wave form where the launch leaves SIMDs idle (HELPER_WAVE_MAX_CHAINS), 0 = never, 1 = always
     // tracked-gradient kernel (pdmp_ensemble_set_gradient_tracking)
     bool track_requested = false, track = false, track_two_sums = false;
@@ -385,6 +386,11 @@ pdmp_status pdmp_debug_set_track_groups(pdmp_ensemble* e, int on) {
 pdmp_status pdmp_debug_set_helper_wave(pdmp_ensemble* e, int mode) {
     if (!e || mode < -1 || mode > 1) return fail(PDMP_ERR_INVALID, "helper wave: -1 (by occupancy), 0 (never), 1 (always)");
     e->dbg_helper_wave = mode;
+    return PDMP_OK;
+}
+pdmp_status pdmp_debug_set_launch_count_limit(pdmp_ensemble* e, uint32_t n) {
+    if (!e) return fail(PDMP_ERR_INVALID, "null argument");
+    e->dbg_count_limit = n;
     return PDMP_OK;
 }
 pdmp_status pdmp_debug_set_helper_steering(pdmp_ensemble* e, double grow, double shrink, int slack, double ahead) {
@@ -1331,6 +1337,7 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         return PDMP_OK;
     }
     pdmp::ZzRunParams P{};
+    P.count_limit = e->dbg_count_limit ? e->dbg_count_limit : pdmp::PDMP_LAUNCH_COUNT_LIMIT;
     P.tb = e->tables();
     P.rec = e->d_rec.p;
     P.keys = e->d_keys.p;

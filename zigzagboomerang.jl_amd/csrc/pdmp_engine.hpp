@@ -143,6 +143,10 @@ struct ZzTables {
     const uint16_t* __restrict__ nb16;  // [d][8] G1[i] ascending, 0xFFFF past |G1[i]| (d <= 16384)
 };
 
+// A launch keeps its draw / proposal counters as 32-bit differences from the header's 64-bit ones: a chain that reaches this many pauses
+// (PDMP_CHAIN_PAUSED, resumable like TRACE_FULL with nothing to drain) instead of wrapping them
+constexpr uint32_t PDMP_LAUNCH_COUNT_LIMIT = 0xC0000000u;
+
 struct ZzRunParams {
     ZzTables tb;
     ZzRec* rec;
@@ -170,6 +174,7 @@ struct ZzRunParams {
     int32_t move_all;  // G = All(): the `pdmp` driver for ZigZag (src/sfact.jl:236)
     int32_t force_spec4;  // diagnostics (pdmp_debug_set_kernel): keep the 4-event kernel where the 8-event one would run
     int32_t track_two_sums;  // tracked-gradient kernel: the bounding Γ differs from the target's (two pairs of sums per coordinate)
+    uint32_t count_limit;    // a chain whose launch has used this many draws (proposals: the logistic kernel) pauses: PDMP_LAUNCH_COUNT_LIMIT, or a test's
     uint32_t typ_extra;      // zz_local_trackp: the most frequent |G1[i]| − 1 (the accept chain's first guess; any value is correct)
     double hw_grow, hw_shrink, hw_ahead;  // ... its steering of the selection threshold and how far ahead the helper requests lines (window lengths)
     uint32_t hw_slack;

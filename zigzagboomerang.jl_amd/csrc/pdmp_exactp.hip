@@ -285,6 +285,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             status = PDMP_CHAIN_TRACE_FULL;
             break;
         }
+        if (dnm >= P.count_limit) {  // (32-bit counters of the launch: pause, the host runs again)
+            status = PDMP_CHAIN_PAUSED;
+            break;
+        }
         X_PH(8);
         // ---------------- ring of uniforms: draws dnm .. dnm + 127, two per lane
         {

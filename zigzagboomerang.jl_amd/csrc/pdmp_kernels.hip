@@ -1470,6 +1470,10 @@ __device__ __forceinline__ void zz_local_spec_body(const ZzRunParams& P_in) {
             status = PDMP_CHAIN_TRACE_FULL;
             break;
         }
+        if (dnm >= P.count_limit) {  // (32-bit counters of the launch: pause, the host runs again)
+            status = PDMP_CHAIN_PAUSED;
+            break;
+        }
         // ---------------- select up to E candidate events (spec_select)
         bool first_inf;
         const int Esel = spec_select<NE, E, PLAIN && NE == 4>(bk, nblk, lane, stop_before, T, SLT, SLH, SLB, first_inf);
@@ -2097,6 +2101,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         prio.step();
         if (dnacc >= trace_room) {
             status = PDMP_CHAIN_TRACE_FULL;
+            break;
+        }
+        if (dnm >= P.count_limit) {  // (32-bit counters of the launch: pause, the host runs again)
+            status = PDMP_CHAIN_PAUSED;
             break;
         }
         // ---------------- select the (up to) E smallest block minima, in time order, WITHOUT a tournament per candidate: one
@@ -2791,6 +2799,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             status = PDMP_CHAIN_TRACE_FULL;
             break;
         }
+        if (dnm >= P.count_limit) {  // (32-bit counters of the launch: pause, the host runs again)
+            status = PDMP_CHAIN_PAUSED;
+            break;
+        }
         // ---------------- select the (up to) E smallest block minima, in time order, WITHOUT a tournament per candidate: one
         // wave minimum m, then every first-level entry below the threshold m + sel_dt is a candidate -- four compares and four
         // population counts tell how many there are.  The candidates (at most SEL_CAP, else the threshold is halved) are compacted
@@ -3471,6 +3483,10 @@ __global__ __launch_bounds__(64) void zz_sticky_spec_kernel(ZzRunParams P_in) {
         prio.step();
         if (dnev >= trace_room) {
             status = PDMP_CHAIN_TRACE_FULL;
+            break;
+        }
+        if (dnm >= P.count_limit) {  // (32-bit counters of the launch: pause, the host runs again)
+            status = PDMP_CHAIN_PAUSED;
             break;
         }
         // ---------------- select up to E candidate events (spec_select)

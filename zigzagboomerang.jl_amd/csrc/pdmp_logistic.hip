@@ -155,7 +155,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const uint64_t seed = hdr->seed;
     // counters of the launch as 32-bit differences (the wavefront's scalar registers are short: 64-bit running counters were spilled to vector
     // lanes and reloaded inside the loop); a launch makes far fewer than 2^32 draws
-    const uint64_t nm0 = hdr->c.ndraw_main, ng0 = hdr->c.ndraw_global, ntrace0 = hdr->c.ntrace;
+    uint64_t nm0 = hdr->c.ndraw_main, ng0 = hdr->c.ndraw_global;  // (bases of the 32-bit stream positions dnm, dng: advanced at every refill)
+    const uint64_t ntrace0 = hdr->c.ntrace;
     uint32_t dnm = 0, dng = 0, dnum = 0, dnacc = 0, dnev = 0;
     const uint32_t trace_room = (P.trace_cap > 0) ? (uint32_t)(((uint64_t)P.trace_cap > ntrace0) ? ((uint64_t)P.trace_cap - ntrace0) : 0) : 0xffffffffu;
     double t_last = hdr->c.t_last;
@@ -314,6 +315,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             status = PDMP_CHAIN_TRACE_FULL;
             break;
         }
+        if (dnum >= P.count_limit) {  // (32-bit proposal count of the launch: pause, the host runs again)
+            status = PDMP_CHAIN_PAUSED;
+            break;
+        }
         // ---------------- peek(Q), src/sfact.jl:77: the minimum of the key array, lowest coordinate on exact ties
         double tp = kreg[0];
         uint32_t i = (uint32_t)lane;
@@ -347,12 +352,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         // (rand(sampler), scripts/logistic.jl:84); lane k_sub -> the thinning coin, draw nm (:121); lane k_sub + 1 + r -> draw nm + 1 + r, the
         // uniform of the r-th re-bound of this proposal (r = 0: the rejected proposal's own, :139; r < k: the members of an accepted one, :134)
         if ((dng - gbase) + (uint32_t)nq > 64u) {  // (uniform)
-            gbase = dng;
-            gbits = pdmp_bits64(seed, PDMP_STREAM_GLOBAL, ng0 + (uint64_t)dng + (uint64_t)lane);
+            // the stream positions are 32-bit differences from a 64-bit base: folded into the base at every refill (two scalar additions),
+            // so that no run length wraps them -- k_sub draws per proposal pass 2^32 after ~1.3e8 proposals of one chain
+            ng0 += (uint64_t)dng;
+            dng = 0u;
+            gbase = 0u;
+            gbits = pdmp_bits64(seed, PDMP_STREAM_GLOBAL, ng0 + (uint64_t)lane);
         }
         if ((dnm - mbase) + 2u + LG_MMARGIN > 64u) {
-            mbase = dnm;
-            mu = pdmp_bits_to_u01(pdmp_bits64(seed, PDMP_STREAM_MAIN, nm0 + (uint64_t)dnm + (uint64_t)lane));
+            nm0 += (uint64_t)dnm;
+            dnm = 0u;
+            mbase = 0u;
+            mu = pdmp_bits_to_u01(pdmp_bits64(seed, PDMP_STREAM_MAIN, nm0 + (uint64_t)lane));
             mL = pdmp_log(mu);
         }
         const uint32_t goff = dng - gbase, moff = dnm - mbase;

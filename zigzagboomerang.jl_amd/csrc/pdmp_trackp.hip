@@ -471,6 +471,10 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
             status = PDMP_CHAIN_TRACE_FULL;
             break;
         }
+        if (dnm >= P.count_limit) {  // (32-bit counters of the launch: pause, the host runs again)
+            status = PDMP_CHAIN_PAUSED;
+            break;
+        }
         // ---------------- ring of uniforms: draws dnm .. dnm + 127, two per lane (HW: dnm .. dnm + 255 from the helper wave's ring in LDS)
         if (HW) {
             if (lane == 0) ctl->consumed = dnm;

@@ -48,6 +48,8 @@ class Ensemble:
             _lib.check(self._L.pdmp_debug_set_track_groups(self._h, int(os.environ["PDMP_TRACK_GROUPS"])))
         if os.environ.get("PDMP_HELPER_WAVE"):
             self.debug_set_helper_wave(int(os.environ["PDMP_HELPER_WAVE"]))
+        if os.environ.get("PDMP_LAUNCH_COUNT_LIMIT"):
+            _lib.check(self._L.pdmp_debug_set_launch_count_limit(self._h, int(os.environ["PDMP_LAUNCH_COUNT_LIMIT"])))
         if os.environ.get("PDMP_HELPER_STEER"):  # "grow,shrink,slack,ahead"
             g_, s_, k_, a_ = os.environ["PDMP_HELPER_STEER"].split(",")
             _lib.check(self._L.pdmp_debug_set_helper_steering(self._h, float(g_), float(s_), int(k_), float(a_)))

@@ -299,7 +299,7 @@ def _zigzag(sampler, target, t0, x0, θ0, T, c, F, factor, adapt, seed, device, 
                 raise RuntimeError("Tuning parameter `c` too small.")  # src/sfact.jl:124
             if trace:
                 _drain(ens, events)
-            if not np.any(cnt["status"] == _lib.CHAIN_TRACE_FULL):
+            if not np.any((cnt["status"] == _lib.CHAIN_TRACE_FULL) | (cnt["status"] == _lib.CHAIN_PAUSED)):  # (both resume with the next run)
                 break
         fs = ens.final_state()
         cnt = ens.counters()
@@ -365,7 +365,7 @@ def _bps(t0, x0, θ0, T, c, B, factor, adapt, seed, device, trace_capacity, trac
                         xs[k].append(b_)
                         ths[k].append(c_)
                 ens.trace_reset()
-            if not np.any(cnt["status"] == _lib.CHAIN_TRACE_FULL):
+            if not np.any((cnt["status"] == _lib.CHAIN_TRACE_FULL) | (cnt["status"] == _lib.CHAIN_PAUSED)):  # (both resume with the next run)
                 break
         fs = ens.bps_final_state()
         cnt = ens.counters()
