@@ -455,6 +455,73 @@ def measure_strong_proxy(pkg, args, G, c, local_rank, value_1gpu, exact_1gpu):
             "by_gpus": rows}
 
 
+def measure_pipeline(pkg, args, G, c, local_rank, ref_rate):
+    """The measured steps again with their trace CONSUMED (src/sfact.jl:211 returns Ξ; discretize and mean are what callers run over it next:
+    src/trace.jl:106-125,182-200, test/maintest.jl:28-29): after every slice pdmp_ensemble_consume_async applies the slice's events to the
+    per-(chain, coordinate) cursors -- streaming mean(Ξ) and collect(discretize(Ξ, 0.5)) -- on the ensemble's second stream, two trace buffers, no
+    trace_reset.  Both orders are timed: the consumer BETWEEN the slices (the library's choice for an ensemble that fills the device) and BESIDE
+    the next slice.  End-to-end = events / wall time of the loop; beside it the consumer alone and what the host could drain over PCIe instead."""
+    d = G.shape[0]
+    nch, dt = args.chains, args.dt
+    nw, ns = 2, max(2, min(args.steps, 6))
+    grid_dt = 0.5
+    K = int(round((nw + ns + 2) * dt / grid_dt)) + 2
+    cap = int(2.0 * d * dt) + 1024
+    modes = {}
+    alone_ms, alone_ev, drain, chk = [], [], None, None
+    for name, mode in (("between_slices", 0), ("beside_next_slice", 1)):
+        e = c3_ensemble(pkg, G, c, nch, cap, SEED0 + args.chain_first, not args.exact, local_rank)
+        e.debug_set_consumer_overlap(mode)
+        e.consume_begin(grid_dt, K)
+        for k in range(nw):
+            e.run((k + 1) * dt, pkg._lib.RUN_STOP_BEFORE, sync=False)
+            e.consume_async()
+        e.sync()
+        c0 = e.counters()
+        run_ms = []
+        t0 = time.perf_counter()
+        for k in range(nw, nw + ns):
+            e.run((k + 1) * dt, pkg._lib.RUN_STOP_BEFORE, sync=False)
+            e.consume_async()                 # (returns at once)
+            run_ms.append(e.last_run_ms())    # (waits for slice k only)
+        e.sync()
+        wall = time.perf_counter() - t0
+        c1 = e.counters()
+        nev = int(c1["nevents"].sum()) - int(c0["nevents"].sum())
+        modes[name] = {"ms_per_step": 1e3 * wall / ns, "sampler_kernel_ms_per_step": float(np.mean(run_ms)), "end_to_end_events_per_s": nev / wall,
+                       "fraction_of_sampler_alone": (nev / wall) / ref_rate if ref_rate else None,
+                       "unhealthy_chains": int(np.count_nonzero(c1["status"] != pkg._lib.CHAIN_OK))}
+        if mode == 0:
+            # the consumer alone: two more slices, each consumed with nothing beside it
+            for k in range(nw + ns, nw + ns + 2):
+                n0 = int(e.counters()["nevents"].sum())
+                e.run((k + 1) * dt, pkg._lib.RUN_STOP_BEFORE)
+                e.sync()
+                e.consume_async()
+                alone_ms.append(e.last_consume_ms())
+                alone_ev.append(int(e.counters()["nevents"].sum()) - n0)
+            drain = e.debug_host_drain_gbps(1 << 30)
+            m, Tl = e.consume_mean(0, 1)
+            chk = {"chain0_mean_abs_max": float(np.max(np.abs(m[0]))), "chain0_T_last": float(Tl[0])}
+        e.close()
+    cons_bytes = np.mean(alone_ev) * (32 + 2 * 32) + nch * d * (dt / grid_dt) * (32 + 8.0)  # events + cursor read / write; per grid row: cursor read + point
+    cons_s = float(np.mean(alone_ms)) * 1e-3
+    best = max(modes, key=lambda k: modes[k]["end_to_end_events_per_s"])
+    out = {"what": "the timed steps with their trace consumed on the device (streaming mean + discretize at dt = 0.5 over every chain and coordinate) by "
+                   "pdmp_ensemble_consume_async: a second stream, two trace buffers, no trace_reset",
+           "steps": ns, "order": best, "library_default_order": "between_slices" if nch > 2048 else "beside_next_slice",
+           "end_to_end_events_per_s": modes[best]["end_to_end_events_per_s"], "fraction_of_sampler_alone": modes[best]["fraction_of_sampler_alone"],
+           "ms_per_step": modes[best]["ms_per_step"], "by_order": modes,
+           "consumer_alone": {"ms_per_step": float(np.mean(alone_ms)), "events_per_s": float(np.mean(alone_ev)) / cons_s,
+                              "algorithmic_bytes_per_step": cons_bytes, "GBps": cons_bytes / cons_s / 1e9,
+                              "roofline_frac": cons_bytes / cons_s / 1e9 / HBM_PEAK_GBS,
+                              "model": "32 B per event + 32 B cursor read + 32 B cursor written; per grid row (d x chains x dT / 0.5 per step) a cursor read + 8 B"},
+           "trace_GBps_at_this_rate": 32.0 * modes[best]["end_to_end_events_per_s"] / 1e9, "host_drain_GBps": drain,
+           "host_drain_note": "device -> pinned host copy of 1 GiB of the trace buffer: what draining Ξ over PCIe instead would be limited to"}
+    out.update(chk or {})
+    return out
+
+
 def measure_with_integrals(pkg, args, rank, local_rank):
     """C4: the same workload with the engine's path integrals kept (8 instead of 13 chains per CU), beside the headline -- figures of different
     rounds are comparable through it (rounds 1-2 kept the integrals)."""
@@ -562,6 +629,8 @@ def main():
                     help="strong (default for C3 / C3G, the north star's form: ONE ensemble of --total-chains chains, rank r of R runs chains "
                          "[r N/R, (r+1) N/R), SURVEY 8 e1) or weak (--chains per GPU; default for C2 / C4 / C5, whose widths are one GPU's share)")
     ap.add_argument("--total-chains", type=int, default=None, help="strong scaling: chains of the whole job (default: the configuration's width)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="C3 at N = 1: skip the `pipeline` object (the steps again with their trace consumed on the device beside the sampler)")
     ap.add_argument("--no-strong-proxy", action="store_true",
                     help="C3 at N = 1: skip the `strong_proxy` object (this GPU's share of the 2 / 4 / 8-GPU strong-scaling job, timed after the region)")
     ap.add_argument("--grid", type=int, default=GRID)
@@ -754,6 +823,9 @@ def main():
         v1 = nev / max(float(np.sum(kernel_ms)) * 1e-3, 1e-9)  # (this GPU's kernel-time rate at the full width: the same clock as the proxy's)
         strong_proxy = measure_strong_proxy(pkg, args, G, c, local_rank, v1 if not args.exact else None,
                                             exact["value"] if exact else (v1 if args.exact else None))
+    pipeline = None
+    if rank == 0 and world == 1 and args.config == "C3" and not args.no_pipeline and not args.gather and not args.no_trace:
+        pipeline = measure_pipeline(pkg, args, G, c, local_rank, nev / max(float(np.sum(kernel_ms)) * 1e-3, 1e-9))
     with_integrals = None
     if rank == 0 and args.config == "C4" and not args.gather and os.environ.get("PDMP_BENCH_C4_INTEGRALS", "0") == "0" and args.exact_steps > 0:
         with_integrals = measure_with_integrals(pkg, args, rank, local_rank)
@@ -965,6 +1037,8 @@ def main():
             out["per_rank"] = per_rank
         if strong_proxy is not None:
             out["strong_proxy"] = strong_proxy
+        if pipeline is not None:
+            out["pipeline"] = pipeline
         if weak is not None:
             out["weak"] = weak
         if gather is not None:

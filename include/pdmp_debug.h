@@ -46,6 +46,11 @@ pdmp_status pdmp_debug_set_helper_steering(pdmp_ensemble* ens, double grow, doub
 /* PDMP_CHAIN_PAUSED under test: a chain pauses once ONE launch has used n draws of its main stream (the subsampled-logistic kernel: n proposals)
  * instead of 3 * 2^30; 0 restores the default */
 pdmp_status pdmp_debug_set_launch_count_limit(pdmp_ensemble* ens, uint32_t n);
+/* pdmp_ensemble_consume_async: -1 = the consumer runs beside the next slice where the ensemble leaves SIMDs idle (at most 2048 chains) and between
+ * the slices where it fills the device (measured: beside a full-width C3 launch it costs the launch more than its own time), 0 / 1 = always between / beside */
+pdmp_status pdmp_debug_set_consumer_overlap(pdmp_ensemble* ens, int mode);
+/* what the host could drain instead of consuming on the device: `bytes` of the ensemble's trace buffer copied to pinned host memory, GB/s */
+pdmp_status pdmp_debug_host_drain_probe(pdmp_ensemble* ens, int64_t bytes, double* gbps);
 /* name of the event-loop kernel the last pdmp_ensemble_run launched (bench.py prints it with every line: no figure without its kernel) */
 pdmp_status pdmp_debug_last_kernel(pdmp_ensemble* ens, char* out, int64_t cap);
 /* chains per wavefront of the LDS-resident logistic kernel (config C4): -1 the library's default, 0 one chain (pdmp_logistic.hip), 16 or 32 =

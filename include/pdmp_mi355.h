@@ -398,6 +398,14 @@ pdmp_status pdmp_ensemble_bps_final_state(pdmp_ensemble* ens, int64_t chain_firs
  */
 pdmp_status pdmp_ensemble_consume_begin(pdmp_ensemble* ens, double grid_dt, int64_t grid_points);
 pdmp_status pdmp_ensemble_consume(pdmp_ensemble* ens);
+/* The same beside the sampler (ABI 3): what the last pdmp_ensemble_run (on `stream`, 0 = the ensemble's own) wrote is consumed on a second stream of
+ * the ensemble and the trace segments are handed back EMPTY at once -- no pdmp_ensemble_trace_reset; the next run writes the other of two trace
+ * buffers while this slice is consumed, and waits only for the consumer of the slice before it.  The reference returns Ξ (src/sfact.jl:211) and
+ * callers then run discretize / mean over it (src/trace.jl:106-125,182-200): at the sampler's rate (32 B per event) a C3 trace exceeds what PCIe
+ * drains, so this is how a full-rate run is USED.  Returns without waiting; consume_mean / _inclusion / _discretized and every entry point that
+ * reads state wait for the consumers.  pdmp_ensemble_last_consume_ms: kernel time of the last asynchronous consumer (waits for it). */
+pdmp_status pdmp_ensemble_consume_async(pdmp_ensemble* ens, void* stream);
+pdmp_status pdmp_ensemble_last_consume_ms(pdmp_ensemble* ens, float* ms);
 pdmp_status pdmp_ensemble_consume_mean(pdmp_ensemble* ens, int64_t chain_first, int64_t n, double* mean, double* T_last);
 /* inclusion_prob(Ξ) (src/trace.jl:161-178) per chain: the fraction of [t0, T] each coordinate spent away from 0 -- what a sticky run is made for */
 pdmp_status pdmp_ensemble_consume_inclusion(pdmp_ensemble* ens, int64_t chain_first, int64_t n, double* prob, double* T_last);

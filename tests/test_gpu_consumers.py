@@ -137,3 +137,47 @@ def test_discretized_first_row_without_events_and_a_grid_that_is_too_short(gpu_p
         ens.consume()
         with pytest.raises(ValueError, match="consume_begin was given 8 points"):
             ens.consume_discretized(0)
+
+
+@pytest.mark.parametrize("tracked", [False, True])
+def test_asynchronous_consumer_equals_the_synchronous_one(gpu_pkg, tracked):
+    """pdmp_ensemble_consume_async: slices run back to back without trace_reset -- the consumer of slice k runs on the ensemble's second stream
+    while slice k + 1 is sampled into the other trace buffer -- and mean / discretize come out bit for bit as with consume() + trace_reset()
+    after every slice (same seeds, same slices); the trace handed back is empty after every call."""
+    pkg = gpu_pkg
+    L = pkg._lib
+    n = 48
+    G = pkg.problems.gmrf_precision(n)
+    d = n * n
+    c = pkg.problems.column_norms(G)
+    nch, dt, K = 5, 0.5, 32
+    slices = [1.0 + 0.9 * k for k in range(12)]
+    res = []
+    for mode in ("sync", "async"):
+        with pkg.Ensemble(nch, d, trace_capacity=4000) as ens:
+            ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
+            ens.set_target(pkg.GaussianTarget(G))
+            if tracked:
+                ens.set_gradient_tracking(True)
+            ens.set_state_synthetic(0.0, c, 321)
+            ens.consume_begin(dt, K)
+            for Tk in slices:
+                ens.run(Tk, L.RUN_STOP_BEFORE, sync=False)
+                if mode == "sync":
+                    ens.sync()
+                    assert not np.any(ens.counters()["status"] == L.CHAIN_TRACE_FULL)
+                    ens.consume()
+                    ens.trace_reset()
+                else:
+                    ens.consume_async()
+            if mode == "async":
+                assert ens.last_consume_ms() > 0.0
+                cn = ens.counters()
+                assert np.all(cn["ntrace"] == 0) and np.all(cn["status"] == L.CHAIN_OK) and cn["nevents"].min() > 10000
+            m, T = ens.consume_mean()
+            grids = [ens.consume_discretized(k) for k in range(nch)]
+            res.append((m, T, grids, ens.counters()["nevents"].copy()))
+    (m0, T0, g0, n0), (m1, T1, g1, n1) = res
+    assert np.array_equal(n0, n1) and np.array_equal(T0, T1) and np.array_equal(m0, m1)
+    for k in range(nch):
+        assert np.array_equal(g0[k][0], g1[k][0]) and np.array_equal(g0[k][1], g1[k][1]) and g0[k][1].shape[0] > 20

@@ -39,14 +39,14 @@ EXPORTED_SYMBOLS = [
     "pdmp_ensemble_set_mass_cholesky", "pdmp_ensemble_set_bps_options",
     "pdmp_ensemble_ess_begin", "pdmp_ensemble_ess_batch", "pdmp_ensemble_ess_end", "pdmp_ensemble_set_gradient_tracking",
     "pdmp_ensemble_path_integrals", "pdmp_ensemble_set_path_integrals", "pdmp_ensemble_set_neighbourhood", "pdmp_ensemble_info",
-    "pdmp_ensemble_consume_begin", "pdmp_ensemble_consume", "pdmp_ensemble_consume_mean", "pdmp_ensemble_consume_inclusion", "pdmp_ensemble_consume_discretized", "pdmp_1d_run",
+    "pdmp_ensemble_consume_begin", "pdmp_ensemble_consume", "pdmp_ensemble_consume_async", "pdmp_ensemble_last_consume_ms", "pdmp_ensemble_consume_mean", "pdmp_ensemble_consume_inclusion", "pdmp_ensemble_consume_discretized", "pdmp_1d_run",
     "pdmp_comm_unique_id", "pdmp_comm_init", "pdmp_comm_destroy", "pdmp_comm_info", "pdmp_comm_barrier", "pdmp_comm_allreduce",
     "pdmp_ensemble_gather_traces", "pdmp_ensemble_reduce_moments", "pdmp_comm_gathered_copy",
     "pdmp_ensemble_gather_bps_traces", "pdmp_comm_gathered_bps_copy", "pdmp_ensemble_bps_trace_dev",
 ]
 # include/pdmp_debug.h: diagnostics, not part of the drop-in boundary
 DEBUG_SYMBOLS = ["pdmp_debug_set_kernel", "pdmp_debug_set_spec_g2", "pdmp_debug_set_phase_profile", "pdmp_debug_phase_profile",
-                 "pdmp_debug_set_proposal_dump", "pdmp_debug_set_track_groups", "pdmp_debug_set_helper_wave", "pdmp_debug_set_helper_steering", "pdmp_debug_set_launch_count_limit", "pdmp_debug_last_kernel", "pdmp_debug_set_logistic_rows", "pdmp_debug_math_probe", "pdmp_debug_write_probe", "pdmp_debug_sector_probe"]
+                 "pdmp_debug_set_proposal_dump", "pdmp_debug_set_track_groups", "pdmp_debug_set_helper_wave", "pdmp_debug_set_helper_steering", "pdmp_debug_set_launch_count_limit", "pdmp_debug_host_drain_probe", "pdmp_debug_set_consumer_overlap", "pdmp_debug_last_kernel", "pdmp_debug_set_logistic_rows", "pdmp_debug_math_probe", "pdmp_debug_write_probe", "pdmp_debug_sector_probe"]
 DEBUG_KERNELS = {"auto": 0, "seq": 1, "spec4": 2, "spec8": 3, "exactp": 4}
 
 
@@ -117,6 +117,10 @@ def load():
     L.pdmp_ensemble_info.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(C.c_int)]
     L.pdmp_ensemble_consume_begin.argtypes = [vp, f64, i64]
     L.pdmp_ensemble_consume.argtypes = [vp]
+    L.pdmp_ensemble_consume_async.argtypes = [vp, vp]
+    L.pdmp_ensemble_last_consume_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.pdmp_debug_set_consumer_overlap.argtypes = [vp, C.c_int]
+    L.pdmp_debug_host_drain_probe.argtypes = [vp, i64, C.POINTER(C.c_double)]
     L.pdmp_ensemble_consume_mean.argtypes = [vp, i64, i64, vp, vp]
     L.pdmp_ensemble_consume_inclusion.argtypes = [vp, i64, i64, vp, vp]
     L.pdmp_ensemble_consume_discretized.argtypes = [vp, i64, i64, i64, vp, C.POINTER(i64), C.POINTER(vp)]

@@ -5,6 +5,8 @@
 // fallback: without a gfx950 device every entry point that needs one fails with PDMP_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -122,6 +124,7 @@ struct pdmp_ensemble {
     int dbg_track_groups = 0;      // gradient tracking: keep the 8-lane-group kernel where the one-proposal-per-lane kernel would run
     double dbg_hw_steer[4] = {0, 0, 0, 0};  // pdmp_debug_set_helper_steering: grow, shrink, slack, ahead (0: the kernel's defaults)
     uint32_t dbg_count_limit = 0;  // pdmp_debug_set_launch_count_limit (0: PDMP_LAUNCH_COUNT_LIMIT)
+    int dbg_cons_overlap = -1;     // pdmp_debug_set_consumer_overlap: -1 by ensemble width, 0 the consumer runs between slices, 1 beside the next slice
     int dbg_helper_wave = -1;      // zz_local_trackp: -1 = the two-wave form where the launch leaves SIMDs idle (HELPER_WAVE_MAX_CHAINS), 0 = never, 1 = always
     // tracked-gradient kernel (pdmp_ensemble_set_gradient_tracking)
     bool track_requested = false, track = false, track_two_sums = false;
@@ -165,7 +168,20 @@ struct pdmp_ensemble {
     // streaming trace consumers (pdmp_ensemble_consume_*): cursor per (chain, coordinate), per-chain progress, the discretisation grid
     DevBuf<unsigned char> d_ccur, d_cmeta;
     DevBuf<double> d_cgrid;
-    bool consuming = false;
+    bool consuming = false, cons_z = false;
+    // pdmp_ensemble_consume_async: a second trace buffer (the event loop writes one while the consumer reads the other), the consumer's stream,
+    // the (ntrace, nevents) snapshots of the two most recent slices and the events that order the two streams
+    DevBuf<pdmp_event> d_ev2;
+    DevBuf<uint64_t> d_snap[2];
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_run_done = nullptr, ev_cons_done[2] = {nullptr, nullptr}, ev_c0 = nullptr, ev_c1 = nullptr;
+    bool cons_pending[2] = {false, false}, cons_timed = false;
+    int async_k = 0;
+    // the consumer of the last pdmp_ensemble_consume_async is LAUNCHED behind the next event-loop launch (or at the next entry point that waits
+    // for the device): the event loop's workgroups take the device first and the low-priority consumer fills what they leave -- launched first,
+    // its workgroups would hold the slots the event loop's 4096 single-wave workgroups need and push part of them into a second round
+    pdmp_event* deferred_buf = nullptr;
+    int deferred_k = -1;
     double cons_dt = 0.0;
     int64_t cons_K = 0;
     DevBuf<pdmp::LgCoord> lg_coord;
@@ -223,12 +239,28 @@ struct pdmp_ensemble {
     }
 };
 
-#ifndef PDMP_LG_ROWS_DEFAULT
 #define PDMP_LG_ROWS_DEFAULT 0  // chains per wavefront of the LDS-resident logistic kernel by default: 0 = one (pdmp_logistic.hip), 16 / 32 = rows (pdmp_logrows.hip)
-#endif
-#ifndef PDMP_LG_FILL
-#define PDMP_LG_FILL 0.95  // lanes of a 64-entry chunk a range fills on average (ranged sweep of long logistic rows; 0.6 .. 1.1 measured on C5)
-#endif
+#define PDMP_LG_FILL 0.95       // lanes of a 64-entry chunk a range fills on average (ranged sweep of long logistic rows; 0.6 .. 1.1 measured on C5)
+
+static pdmp_status launch_deferred_consumer(pdmp_ensemble* e) {
+    if (e->deferred_k < 0) return PDMP_OK;
+    const int k = e->deferred_k;
+    e->deferred_k = -1;
+    HIP_TRY(hipEventRecord(e->ev_c0, e->stream2));
+    int rc = pdmp::launch_consume_events(e->deferred_buf, e->cfg.trace_capacity, e->d_hdr.p, e->d_snap[k].p, e->cfg.d, e->cfg.nchains, e->d_ccur.p,
+                                         e->cons_z, e->d_cmeta.p, e->d_cgrid.p, e->cons_K, e->t0_state, e->cons_dt, e->stream2);
+    if (rc != 0) return fail(PDMP_ERR_HIP, "consume launch failed: %s", hipGetErrorString((hipError_t)rc));
+    HIP_TRY(hipEventRecord(e->ev_c1, e->stream2));
+    HIP_TRY(hipEventRecord(e->ev_cons_done[k], e->stream2));
+    e->cons_pending[k] = true;
+    e->cons_timed = true;
+    return PDMP_OK;
+}
+// hipDeviceSynchronize for an ensemble: a deferred consumer is launched first (what follows reads its results or the buffers it reads)
+static hipError_t device_sync(pdmp_ensemble* e) {
+    if (e && e->deferred_k >= 0 && launch_deferred_consumer(e) != PDMP_OK) return hipErrorUnknown;
+    return hipDeviceSynchronize();
+}
 
 extern "C" {
 
@@ -388,6 +420,11 @@ pdmp_status pdmp_debug_set_helper_wave(pdmp_ensemble* e, int mode) {
     e->dbg_helper_wave = mode;
     return PDMP_OK;
 }
+pdmp_status pdmp_debug_set_consumer_overlap(pdmp_ensemble* e, int mode) {
+    if (!e || mode < -1 || mode > 1) return fail(PDMP_ERR_INVALID, "consumer overlap: -1 (by width), 0 (between slices), 1 (beside the next slice)");
+    e->dbg_cons_overlap = mode;
+    return PDMP_OK;
+}
 pdmp_status pdmp_debug_set_launch_count_limit(pdmp_ensemble* e, uint32_t n) {
     if (!e) return fail(PDMP_ERR_INVALID, "null argument");
     e->dbg_count_limit = n;
@@ -454,6 +491,9 @@ void pdmp_ensemble_destroy(pdmp_ensemble* e) {
     if (!e) return;
     (void)hipSetDevice(e->cfg.device);
     (void)hipDeviceSynchronize();
+    for (hipEvent_t ev : {e->ev_run_done, e->ev_cons_done[0], e->ev_cons_done[1], e->ev_c0, e->ev_c1})
+        if (ev) (void)hipEventDestroy(ev);
+    if (e->stream2) (void)hipStreamDestroy(e->stream2);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -1296,7 +1336,13 @@ pdmp_status pdmp_ensemble_set_state_synthetic(pdmp_ensemble* e, double t0, const
 
 static void fill_bps_ext(const pdmp_ensemble* e, pdmp::BpsRunParams& B);
 
+static pdmp_status ensemble_run_impl(pdmp_ensemble* e, double T, int flags, void* stream);
 pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* stream) {
+    pdmp_status st = ensemble_run_impl(e, T, flags, stream);
+    if (st == PDMP_OK && e->deferred_k >= 0) st = launch_deferred_consumer(e);  // (behind the event loop's launch: see pdmp_ensemble_consume_async)
+    return st;
+}
+static pdmp_status ensemble_run_impl(pdmp_ensemble* e, double T, int flags, void* stream) {
     if (!e) return fail(PDMP_ERR_INVALID, "null argument");
     if (!e->has_state) return fail(PDMP_ERR_INVALID, "set_state must be called before run");
     if (flags != PDMP_RUN_REFERENCE_TAIL && flags != PDMP_RUN_STOP_BEFORE) return fail(PDMP_ERR_INVALID, "bad flags");
@@ -1472,7 +1518,7 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         HIP_TRY(hipEventRecord(e->ev1, s));
         e->timed = true;
         if (phenv) {
-            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(device_sync(e));
             HIP_TRY(hipMemcpy(e->dbg_phase_out, phbuf.p, sizeof e->dbg_phase_out, hipMemcpyDeviceToHost));
             e->dbg_phase_valid = 2;  // general kernel: [0..6] = select, move G1, gradient, coin + G2, re-bound, re-queue, tail; [10] = proposals
         }
@@ -1507,7 +1553,7 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
             HIP_TRY(hipEventRecord(e->ev1, s));
             e->timed = true;
             if (phenv) {
-                HIP_TRY(hipDeviceSynchronize());
+                HIP_TRY(device_sync(e));
                 HIP_TRY(hipMemcpy(e->dbg_phase_out, phbuf.p, sizeof e->dbg_phase_out, hipMemcpyDeviceToHost));
                 e->dbg_phase_valid = 1;
             }
@@ -1519,7 +1565,7 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
         HIP_TRY(hipEventRecord(e->ev1, s));
         e->timed = true;
         if (phenv) {
-            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(device_sync(e));
             HIP_TRY(hipMemcpy(e->dbg_phase_out, phbuf.p, sizeof e->dbg_phase_out, hipMemcpyDeviceToHost));
             e->dbg_phase_valid = 1;
         }
@@ -1536,7 +1582,7 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
             HIP_TRY(hipEventRecord(e->ev1, s));
             e->timed = true;
             if (phenv) {  // [10] iterations, [11] candidates, [12] left by the zone test, [13] committed, [14] events among the candidates
-                HIP_TRY(hipDeviceSynchronize());
+                HIP_TRY(device_sync(e));
                 HIP_TRY(hipMemcpy(e->dbg_phase_out, phbuf.p, sizeof e->dbg_phase_out, hipMemcpyDeviceToHost));
                 e->dbg_phase_valid = 1;
             }
@@ -1558,12 +1604,12 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
     HIP_TRY(hipEventRecord(e->ev1, s));
     e->timed = true;
     if (phenv && spec_ok) {
-        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(device_sync(e));
         HIP_TRY(hipMemcpy(e->dbg_phase_out, phbuf.p, sizeof e->dbg_phase_out, hipMemcpyDeviceToHost));
         e->dbg_phase_valid = 1;  // speculative kernels: [0..8] = cycles per phase, [10] = iterations
     }
     if (dbg_cap > 0) {
-        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(device_sync(e));
         std::vector<double> hd((size_t)dbg_cap * 16);
         HIP_TRY(hipMemcpy(hd.data(), dbgbuf.p, hd.size() * sizeof(double), hipMemcpyDeviceToHost));
         for (int64_t r = 0; r < dbg_cap; ++r) {
@@ -1578,7 +1624,7 @@ pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* strea
 pdmp_status pdmp_ensemble_sync(pdmp_ensemble* e) {
     if (!e) return fail(PDMP_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(e->cfg.device));
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(device_sync(e));
     return PDMP_OK;
 }
 
@@ -1595,7 +1641,7 @@ pdmp_status pdmp_ensemble_counters(pdmp_ensemble* e, pdmp_chain_counters* out) {
     if (!e || !out) return fail(PDMP_ERR_INVALID, "null argument");
     if (!e->has_state) return fail(PDMP_ERR_INVALID, "no state");
     HIP_TRY(hipSetDevice(e->cfg.device));
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(device_sync(e));
     std::vector<pdmp::DevChain> h((size_t)e->cfg.nchains);
     HIP_TRY(hipMemcpy(h.data(), e->d_hdr.p, h.size() * sizeof(pdmp::DevChain), hipMemcpyDeviceToHost));
     for (size_t k = 0; k < h.size(); ++k) out[k] = h[k].c;
@@ -1626,7 +1672,7 @@ pdmp_status pdmp_ensemble_trace_copy(pdmp_ensemble* e, int64_t chain, int64_t fi
     if (chain < 0 || chain >= e->cfg.nchains || first < 0 || count < 0 || first + count > e->cfg.trace_capacity)
         return fail(PDMP_ERR_INVALID, "trace range out of bounds");
     HIP_TRY(hipSetDevice(e->cfg.device));
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(device_sync(e));
     if (count)
         HIP_TRY(hipMemcpy(out, e->d_ev.p + chain * e->cfg.trace_capacity + first, (size_t)count * sizeof(pdmp_event),
                           hipMemcpyDeviceToHost));
@@ -1637,7 +1683,7 @@ pdmp_status pdmp_ensemble_trace_reset(pdmp_ensemble* e) {
     if (!e) return fail(PDMP_ERR_INVALID, "null argument");
     if (!e->has_state) return fail(PDMP_ERR_INVALID, "no state");
     HIP_TRY(hipSetDevice(e->cfg.device));
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(device_sync(e));
     // ntrace lives at a fixed offset inside each 128-byte header: zero it with a strided 2-D memset
     const size_t off = offsetof(pdmp::DevChain, c) + offsetof(pdmp_chain_counters, ntrace);
     HIP_TRY(hipMemset2DAsync(reinterpret_cast<char*>(e->d_hdr.p) + off, sizeof(pdmp::DevChain), 0, sizeof(uint64_t),
@@ -1655,7 +1701,7 @@ pdmp_status pdmp_ensemble_final_state(pdmp_ensemble* e, int64_t chain_first, int
     if (chain_first < 0 || n < 0 || chain_first + n > e->cfg.nchains) return fail(PDMP_ERR_INVALID, "chain range");
     if (n == 0) return PDMP_OK;
     HIP_TRY(hipSetDevice(e->cfg.device));
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(device_sync(e));
     const int64_t d = e->cfg.d;
     const size_t cnt = (size_t)(n * d);
     DevBuf<double> bt, bx, bth, bc;
@@ -1689,7 +1735,7 @@ pdmp_status pdmp_ensemble_batch_means(pdmp_ensemble* e, double T_prev, double T,
     if (st0 != PDMP_OK) return st0;
     if (!(T > T_prev)) return fail(PDMP_ERR_INVALID, "T must exceed T_prev");
     HIP_TRY(hipSetDevice(e->cfg.device));
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(device_sync(e));
     const int64_t d = e->cfg.d, n = e->cfg.nchains;
     pdmp_status st;
     if (e->d_jprev.n != (size_t)(n * d)) {
@@ -1721,7 +1767,7 @@ pdmp_status pdmp_ensemble_ess_begin(pdmp_ensemble* e, double T0) {
     pdmp_status st = ess_ready(e);
     if (st != PDMP_OK) return st;
     HIP_TRY(hipSetDevice(e->cfg.device));
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(device_sync(e));
     const int64_t d = e->cfg.d, n = e->cfg.nchains;
     if (e->d_jprev.n != (size_t)(n * d) && (st = e->d_jprev.alloc((size_t)(n * d))) != PDMP_OK) return st;
     if (e->d_jstart.n != (size_t)(n * d) && (st = e->d_jstart.alloc((size_t)(n * d))) != PDMP_OK) return st;
@@ -1741,7 +1787,7 @@ pdmp_status pdmp_ensemble_ess_batch(pdmp_ensemble* e, double T) {
     if (e->ess_batches < 0) return fail(PDMP_ERR_INVALID, "pdmp_ensemble_ess_begin first");
     if (!(T > e->ess_Tlast)) return fail(PDMP_ERR_INVALID, "batch end %g does not exceed the previous one %g", T, e->ess_Tlast);
     HIP_TRY(hipSetDevice(e->cfg.device));
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(device_sync(e));
     int rc = pdmp::launch_zz_ess(e->d_rec.p, e->track ? 128 : 64, e->d_jprev.p, e->d_jstart.p, e->cfg.d, e->cfg.nchains, 1, e->ess_Tlast, T,
                                  e->d_essacc.p, e->stream);
     if (rc != 0) return fail(PDMP_ERR_HIP, "ess launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -1783,14 +1829,15 @@ pdmp_status pdmp_ensemble_consume_begin(pdmp_ensemble* e, double grid_dt, int64_
     HIP_TRY(hipSetDevice(e->cfg.device));
     const int64_t d = e->cfg.d, n = e->cfg.nchains;
     pdmp_status st;
-    if ((st = e->d_ccur.alloc((size_t)(n * d) * pdmp::consume_cursor_bytes())) != PDMP_OK) return st;
+    e->cons_z = e->cfg.sampler == PDMP_SAMPLER_STICKY_ZIGZAG;  // (the time away from 0, inclusion_prob: a sum of its own where coordinates can freeze)
+    if ((st = e->d_ccur.alloc((size_t)(n * d) * pdmp::consume_cursor_bytes(e->cons_z))) != PDMP_OK) return st;
     if ((st = e->d_cmeta.alloc((size_t)n * pdmp::consume_meta_bytes())) != PDMP_OK) return st;
     e->d_cgrid.release();
     if (grid_points > 0) {
         if ((st = e->d_cgrid.alloc((size_t)(n * grid_points * d))) != PDMP_OK) return st;
         HIP_TRY(hipMemsetAsync(e->d_cgrid.p, 0, (size_t)(n * grid_points * d) * sizeof(double), e->stream));
     }
-    int rc = pdmp::launch_consume_init(e->d_rec.p, e->track ? 128 : 64, d, n, e->t0_state, e->d_ccur.p, e->d_cmeta.p,
+    int rc = pdmp::launch_consume_init(e->d_rec.p, e->track ? 128 : 64, d, n, e->t0_state, e->d_ccur.p, e->cons_z, e->d_cmeta.p,
                                        grid_points > 0 ? e->d_cgrid.p : nullptr, grid_points, e->stream);
     if (rc != 0) return fail(PDMP_ERR_HIP, "consume_init launch failed: %s", hipGetErrorString((hipError_t)rc));
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1804,11 +1851,87 @@ pdmp_status pdmp_ensemble_consume(pdmp_ensemble* e) {
     if (!e) return fail(PDMP_ERR_INVALID, "null argument");
     if (!e->consuming || !e->has_state) return fail(PDMP_ERR_INVALID, "pdmp_ensemble_consume_begin first");
     HIP_TRY(hipSetDevice(e->cfg.device));
-    HIP_TRY(hipDeviceSynchronize());
-    int rc = pdmp::launch_consume_events(e->d_ev.p, e->cfg.trace_capacity, e->d_hdr.p, e->cfg.d, e->cfg.nchains, e->d_ccur.p, e->d_cmeta.p,
+    HIP_TRY(device_sync(e));
+    int rc = pdmp::launch_consume_events(e->d_ev.p, e->cfg.trace_capacity, e->d_hdr.p, nullptr, e->cfg.d, e->cfg.nchains, e->d_ccur.p, e->cons_z, e->d_cmeta.p,
                                          e->d_cgrid.p, e->cons_K, e->t0_state, e->cons_dt, e->stream);
     if (rc != 0) return fail(PDMP_ERR_HIP, "consume launch failed: %s", hipGetErrorString((hipError_t)rc));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    return PDMP_OK;
+}
+
+// The consumer beside the sampler: what the last launch wrote is handed to the consumers on a SECOND stream, and the segments come back empty at
+// once -- the next pdmp_ensemble_run writes the other of two trace buffers while this slice is consumed (a C3 slice is 1.7 GB of events: at the
+// sampler's rate the host could not drain it over PCIe; src/sfact.jl:211 returns Ξ, and discretize / mean are what every caller does with it next,
+// src/trace.jl:106-125,182-200).  Stream order: [run k] -> snapshot of the per-chain counts + reset (run stream) -> consumer k (second stream,
+// after the snapshot); run k + 1 waits for consumer k − 1, which read the buffer it is about to write.  Returns without waiting.
+pdmp_status pdmp_ensemble_consume_async(pdmp_ensemble* e, void* stream) {
+    if (!e) return fail(PDMP_ERR_INVALID, "null argument");
+    if (!e->consuming || !e->has_state) return fail(PDMP_ERR_INVALID, "pdmp_ensemble_consume_begin first");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    const int64_t n = e->cfg.nchains;
+    pdmp_status st;
+    if ((st = launch_deferred_consumer(e)) != PDMP_OK) return st;  // (two calls without a run between them)
+    if (!e->stream2) {
+        int least = 0, greatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&e->stream2, hipStreamNonBlocking, least));  // (the event loop's launches go first)
+        for (hipEvent_t* ev : {&e->ev_run_done, &e->ev_cons_done[0], &e->ev_cons_done[1], &e->ev_c0, &e->ev_c1}) HIP_TRY(hipEventCreate(ev));
+    }
+    if (e->d_ev2.n != e->d_ev.n && (st = e->d_ev2.alloc(e->d_ev.n)) != PDMP_OK) return st;
+    const int k = e->async_k;
+    if (e->d_snap[k].n != (size_t)(2 * n) && (st = e->d_snap[k].alloc((size_t)(2 * n))) != PDMP_OK) return st;
+    int rc = pdmp::launch_consume_snapshot(e->d_hdr.p, n, e->d_snap[k].p, s);
+    if (rc != 0) return fail(PDMP_ERR_HIP, "consume_snapshot launch failed: %s", hipGetErrorString((hipError_t)rc));
+    HIP_TRY(hipEventRecord(e->ev_run_done, s));
+    pdmp_event* const filled = e->d_ev.p;
+    std::swap(e->d_ev.p, e->d_ev2.p);  // (same sizes) the next launch writes the other buffer ...
+    if (e->cons_pending[k ^ 1]) HIP_TRY(hipStreamWaitEvent(s, e->ev_cons_done[k ^ 1], 0));  // ... once the consumer that read it is done
+    HIP_TRY(hipStreamWaitEvent(e->stream2, e->ev_run_done, 0));
+    e->deferred_buf = filled;
+    e->deferred_k = k;  // (launched behind the next event-loop launch: launch_deferred_consumer)
+    // An ensemble that fills the device is bound by the memory system, and a consumer beside it costs it more than the consumer's own time
+    // (measured on C3, 4096 chains: 39 -> 56 ms per slice beside a 7 ms consumer): there the consumer runs BETWEEN the slices -- the next launch
+    // waits for it -- and the second trace buffer only saves the reset.  Narrower ensembles leave SIMDs idle: the consumer runs beside the next slice.
+    const bool beside = e->dbg_cons_overlap == 1 || (e->dbg_cons_overlap == -1 && e->cfg.nchains <= 2048);
+    if (!beside) {
+        if ((st = launch_deferred_consumer(e)) != PDMP_OK) return st;
+        HIP_TRY(hipStreamWaitEvent(s, e->ev_cons_done[k], 0));
+    }
+    e->async_k = k ^ 1;
+    return PDMP_OK;
+}
+
+// What the host could drain instead: `bytes` of the trace buffer copied to pinned host memory, in GB/s (a measurement for bench.py's pipeline
+// object, not a code path of the engine)
+pdmp_status pdmp_debug_host_drain_probe(pdmp_ensemble* e, int64_t bytes, double* gbps) {
+    if (!e || !gbps || bytes <= 0) return fail(PDMP_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const size_t have = e->d_ev.n * sizeof(pdmp_event);
+    const size_t nb = std::min<size_t>((size_t)bytes, have);
+    if (nb == 0) return fail(PDMP_ERR_INVALID, "ensemble was created with trace_capacity = 0");
+    void* host = nullptr;
+    HIP_TRY(hipHostMalloc(&host, nb, hipHostMallocDefault));
+    HIP_TRY(device_sync(e));
+    hipError_t err = hipMemcpy(host, e->d_ev.p, nb, hipMemcpyDeviceToHost);  // (warm-up: page tables, the copy engine's first touch)
+    const auto t0 = std::chrono::steady_clock::now();
+    if (err == hipSuccess) err = hipMemcpy(host, e->d_ev.p, nb, hipMemcpyDeviceToHost);
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    (void)hipHostFree(host);
+    if (err != hipSuccess) return fail(PDMP_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(err));
+    *gbps = (double)nb / secs / 1e9;
+    return PDMP_OK;
+}
+
+// kernel time of the last asynchronous consumer (waits for it)
+pdmp_status pdmp_ensemble_last_consume_ms(pdmp_ensemble* e, float* ms) {
+    if (!e || !ms) return fail(PDMP_ERR_INVALID, "null argument");
+    if (!e->cons_timed && e->deferred_k < 0) return fail(PDMP_ERR_INVALID, "no asynchronous consumer has run");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    pdmp_status st = launch_deferred_consumer(e);
+    if (st != PDMP_OK) return st;
+    HIP_TRY(hipEventSynchronize(e->ev_c1));
+    HIP_TRY(hipEventElapsedTime(ms, e->ev_c0, e->ev_c1));
     return PDMP_OK;
 }
 
@@ -1817,6 +1940,7 @@ pdmp_status pdmp_ensemble_consume_mean(pdmp_ensemble* e, int64_t chain_first, in
     if (!e->consuming) return fail(PDMP_ERR_INVALID, "pdmp_ensemble_consume_begin first");
     if (chain_first < 0 || n <= 0 || chain_first + n > e->cfg.nchains) return fail(PDMP_ERR_INVALID, "chain range");
     HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(device_sync(e));  // (asynchronous consumers run on a second stream)
     const int64_t d = e->cfg.d;
     DevBuf<double> bm, bt;
     pdmp_status st;
@@ -1835,12 +1959,13 @@ pdmp_status pdmp_ensemble_consume_inclusion(pdmp_ensemble* e, int64_t chain_firs
     if (!e->consuming) return fail(PDMP_ERR_INVALID, "pdmp_ensemble_consume_begin first");
     if (chain_first < 0 || n <= 0 || chain_first + n > e->cfg.nchains) return fail(PDMP_ERR_INVALID, "chain range");
     HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(device_sync(e));  // (asynchronous consumers run on a second stream)
     const int64_t d = e->cfg.d;
     DevBuf<double> bm, bt;
     pdmp_status st;
     if ((st = bm.alloc((size_t)(n * d))) != PDMP_OK) return st;
     if ((st = bt.alloc((size_t)n)) != PDMP_OK) return st;
-    int rc = pdmp::launch_consume_inclusion(d, chain_first, n, e->d_ccur.p, e->d_cmeta.p, bm.p, bt.p, e->stream);
+    int rc = pdmp::launch_consume_inclusion(d, e->cfg.nchains, e->cons_z, e->t0_state, chain_first, n, e->d_ccur.p, e->d_cmeta.p, bm.p, bt.p, e->stream);
     if (rc != 0) return fail(PDMP_ERR_HIP, "consume_inclusion launch failed: %s", hipGetErrorString((hipError_t)rc));
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(prob, bm.p, (size_t)(n * d) * sizeof(double), hipMemcpyDeviceToHost));
@@ -1855,6 +1980,7 @@ pdmp_status pdmp_ensemble_consume_discretized(pdmp_ensemble* e, int64_t chain, i
     if (chain < 0 || chain >= e->cfg.nchains || k_first < 0 || k_count < 0 || k_first + k_count > e->cons_K)
         return fail(PDMP_ERR_INVALID, "chain / grid range");
     HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(device_sync(e));  // (asynchronous consumers run on a second stream)
     const int64_t d = e->cfg.d;
     // the points after every coordinate's last event, up to the chain's last event time (idempotent)
     int rc = pdmp::launch_consume_flush(d, e->cfg.nchains, e->d_ccur.p, e->d_cmeta.p, e->d_cgrid.p, e->cons_K, e->t0_state, e->cons_dt, e->stream);
@@ -1894,7 +2020,7 @@ pdmp_status pdmp_ensemble_path_integrals(pdmp_ensemble* e, double T, int64_t npr
     for (int64_t k = 0; k < nprobe; ++k)
         if (probes[k] < 0 || probes[k] >= d) return fail(PDMP_ERR_INVALID, "probe coordinate %lld out of range", (long long)probes[k]);
     HIP_TRY(hipSetDevice(e->cfg.device));
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(device_sync(e));
     DevBuf<int64_t> dp;
     DevBuf<double> dout;
     if ((st = dp.upload(std::vector<int64_t>(probes, probes + nprobe))) != PDMP_OK) return st;
@@ -2272,7 +2398,7 @@ pdmp_status pdmp_ensemble_bps_trace_copy(pdmp_ensemble* e, int64_t chain, int64_
     if (chain < 0 || chain >= e->cfg.nchains || first < 0 || count < 0 || first + count > cap)
         return fail(PDMP_ERR_INVALID, "trace range out of bounds");
     HIP_TRY(hipSetDevice(e->cfg.device));
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(device_sync(e));
     if (count == 0) return PDMP_OK;
     const int64_t slot = chain * cap + first;
     if (t) HIP_TRY(hipMemcpy(t, e->b_ev_t.p + slot, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
@@ -2288,7 +2414,7 @@ pdmp_status pdmp_ensemble_bps_final_state(pdmp_ensemble* e, int64_t chain_first,
     if (e->cfg.sampler != PDMP_SAMPLER_BPS || !e->has_state) return fail(PDMP_ERR_INVALID, "no BPS state");
     if (chain_first < 0 || n < 0 || chain_first + n > e->cfg.nchains) return fail(PDMP_ERR_INVALID, "chain range");
     HIP_TRY(hipSetDevice(e->cfg.device));
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(device_sync(e));
     const int64_t d = e->cfg.d;
     if (n == 0) return PDMP_OK;
     if (x) HIP_TRY(hipMemcpy(x, e->b_x.p + chain_first * d, (size_t)(n * d) * sizeof(double), hipMemcpyDeviceToHost));

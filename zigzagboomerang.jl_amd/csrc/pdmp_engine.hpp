@@ -77,31 +77,13 @@ static_assert(sizeof(DevChain) == 128, "chain header is 128 bytes");
 // wave, 4 or more per SIMD) the oldest finishes well before the youngest, which then runs out the launch alone.  Every event loop calls
 // prio_turn(iteration) at its top: the waves of a SIMD take turns at the top priority (a turn = PDMP_PRIO_TURN iterations; measured on the
 // headline workload: 6 % faster than without, turns of 1 .. 1024 iterations within 1 % of each other).
-#ifndef PDMP_PRIO_TURN
-#define PDMP_PRIO_TURN 256u
-#endif
-#ifndef PDMP_PRIO_MODE
-#define PDMP_PRIO_MODE 0
-#endif
+constexpr uint32_t PDMP_PRIO_TURN = 256u;
 struct PrioTurn {
     uint32_t slot, it;
-#if PDMP_PRIO_MODE == 1
-    __device__ __forceinline__ PrioTurn() : slot((blockIdx.x >> 10) & 3u), it(0) {}
-#elif PDMP_PRIO_MODE == 2
-    __device__ __forceinline__ PrioTurn() : slot(blockIdx.x * 0x9E3779B9u), it(0) {}
-#else
     __device__ __forceinline__ PrioTurn() : slot((uint32_t)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 3u), it(0) {}  // HW_ID.wave_id
-#endif
     __device__ __forceinline__ void step() {
-        if (PDMP_PRIO_TURN != 0u && (it & (PDMP_PRIO_TURN - 1u)) == 0u) {
-#if PDMP_PRIO_MODE == 2
-            uint32_t h = (slot ^ (it / PDMP_PRIO_TURN)) * 0x85EBCA6Bu;
-            h ^= h >> 13;
-            h *= 0xC2B2AE35u;
-            const uint32_t pr = (uint32_t)__builtin_amdgcn_readfirstlane((int)(h >> 30));
-#else
+        if ((it & (PDMP_PRIO_TURN - 1u)) == 0u) {
             const uint32_t pr = ((it / PDMP_PRIO_TURN) + slot) & 3u;
-#endif
             switch (pr) {
                 case 0: __builtin_amdgcn_s_setprio(0); break;
                 case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -384,15 +366,17 @@ int launch_zz_ess(const ZzRec* rec, int64_t rec_stride, double* jprev, double* j
                   double T, double* acc, void* stream);
 size_t zz_local_lds_bytes(uint32_t nblk_pad, uint32_t blob_w_pad);
 // pdmp_consume.hip
-size_t consume_cursor_bytes();
+size_t consume_cursor_bytes(bool with_z);
 size_t consume_meta_bytes();
-int launch_consume_init(const ZzRec* rec, int64_t rec_stride, int64_t d, int64_t nchains, double t0, void* cur, void* meta, double* grid, int64_t K,
-                        void* stream);
-int launch_consume_events(const pdmp_event* ev, int64_t cap, const DevChain* hdr, int64_t d, int64_t nchains, void* cur, void* meta, double* grid,
-                          int64_t K, double t0, double dt, void* stream);
+int launch_consume_init(const ZzRec* rec, int64_t rec_stride, int64_t d, int64_t nchains, double t0, void* cur, bool with_z, void* meta, double* grid,
+                        int64_t K, void* stream);
+int launch_consume_snapshot(DevChain* hdr, int64_t nchains, uint64_t* snap, void* stream);
+int launch_consume_events(const pdmp_event* ev, int64_t cap, const DevChain* hdr, const uint64_t* snap, int64_t d, int64_t nchains, void* cur,
+                          bool with_z, void* meta, double* grid, int64_t K, double t0, double dt, void* stream);
 int launch_consume_flush(int64_t d, int64_t nchains, const void* cur, const void* meta, double* grid, int64_t K, double t0, double dt, void* stream);
 int launch_consume_mean(int64_t d, int64_t chain_first, int64_t n, const void* cur, const void* meta, double* mean_out, double* T_out, void* stream);
-int launch_consume_inclusion(int64_t d, int64_t chain_first, int64_t n, const void* cur, const void* meta, double* out, double* T_out, void* stream);
+int launch_consume_inclusion(int64_t d, int64_t nchains, bool with_z, double t0, int64_t chain_first, int64_t n, void* cur, const void* meta, double* out,
+                             double* T_out, void* stream);
 int launch_zz_path_integrals(const ZzRec* rec, int64_t rec_stride, int64_t d, int64_t nchains, const int64_t* probes, int64_t nprobe,
                              double T, double* out, void* stream);
 int launch_math_probe(uint64_t seed, int64_t n, double* out, void* stream);

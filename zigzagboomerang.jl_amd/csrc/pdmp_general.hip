@@ -97,9 +97,7 @@ __device__ __forceinline__ double g_sigmoid(double x) {
 
 #define G_PCH 128u  // (member, entry) products staged per chunk by the re-bound step
 #define G_PROW 65u  // doubles between the product lines of two sampled rows (ranged sweep)
-#ifndef G_NR
 #define G_NR 3     // sampled rows whose records are in flight together in the ranged sweep
-#endif
 
 size_t zz_general_lds_bytes(uint32_t nblk_pad, uint32_t mmax_pad, bool boom) {
     return (size_t)nblk_pad * 8 + (size_t)(boom ? 3 : 2) * mmax_pad * 8 + (size_t)nblk_pad * 4 + (size_t)2 * G_PCH * 8;

@@ -2260,14 +2260,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const uint64_t acc_i = ri->acc;
         double kq[4];
         {
-#ifdef PDMP_X_KEYLINES
-            // the block's 256 bytes as TWO whole-line requests: lane gl takes keys 2gl, 2gl+1 of each 128-byte half
-            const double2* kp = reinterpret_cast<const double2*>(keys + (size_t)blk * 32);
-            const double2 k01 = kp[gl], k23 = kp[8 + gl];
-#else
             const double2* kp = reinterpret_cast<const double2*>(keys + (size_t)blk * 32 + gl * 4);
             const double2 k01 = kp[0], k23 = kp[1];
-#endif
             kq[0] = k01.x;
             kq[1] = k01.y;
             kq[2] = k23.x;
@@ -2441,11 +2435,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         LDS_ORDER();
         if (active && (sA >> 5) == blk) {
             const uint32_t e_ = sA & 31u;
-#ifdef PDMP_X_KEYLINES
-            pk[((e_ & 15u) >> 1) * 4u + (((e_ >> 4) ^ pk_t) << 1) + (e_ & 1u)] = key;
-#else
             pk[(e_ & ~3u) + ((((e_ & 3u) >> 1) ^ pk_t) << 1) + (e_ & 1u)] = key;
-#endif
         }
         LDS_ORDER();
         PHASE(5);
@@ -2469,19 +2459,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             PMIN(p23.x, 2);
             PMIN(p23.y, 3);
 #undef PMIN
-#ifdef PDMP_X_KEYLINES
-            cand = blk * 32u + ((li >> 1) << 4) + (uint32_t)gl * 2u + (li & 1u);
-            rowmin = grp8_min_f64(lm);
-            const uint64_t winball = __ballot(gvalid && lm == rowmin);
-            const uint64_t winlo = __ballot(gvalid && lm == rowmin && li < 2u);  // (ties: the lowest coordinate wins)
-            const unsigned wlo = (unsigned)((winlo >> (8 * g)) & 0xffu);
-            wl2 = __ffs(wlo ? wlo : (unsigned)((winball >> (8 * g)) & 0xffu)) - 1;
-#else
             cand = blk * 32u + (uint32_t)gl * 4u + li;
             rowmin = grp8_min_f64(lm);
             const uint64_t winball = __ballot(gvalid && lm == rowmin);
             wl2 = __ffs((unsigned)((winball >> (8 * g)) & 0xffu)) - 1;
-#endif
         }
         const double keymin = grp8_min_f64(key);
         const double expose = min_f64(rowmin, keymin);
@@ -3125,11 +3106,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         LDS_ORDER();
         if (active && (sA >> 5) == blk) {
             const uint32_t e_ = sA & 31u;
-#ifdef PDMP_X_KEYLINES
-            pk[((e_ & 15u) >> 1) * 4u + (((e_ >> 4) ^ pk_t) << 1) + (e_ & 1u)] = key;
-#else
             pk[(e_ & ~3u) + ((((e_ & 3u) >> 1) ^ pk_t) << 1) + (e_ & 1u)] = key;
-#endif
         }
         LDS_ORDER();
         PHASE(5);
@@ -3153,19 +3130,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             PMIN(p23.x, 2);
             PMIN(p23.y, 3);
 #undef PMIN
-#ifdef PDMP_X_KEYLINES
-            cand = blk * 32u + ((li >> 1) << 4) + (uint32_t)gl * 2u + (li & 1u);
-            rowmin = grp8_min_f64(lm);
-            const uint64_t winball = __ballot(gvalid && lm == rowmin);
-            const uint64_t winlo = __ballot(gvalid && lm == rowmin && li < 2u);  // (ties: the lowest coordinate wins)
-            const unsigned wlo = (unsigned)((winlo >> (8 * g)) & 0xffu);
-            wl2 = __ffs(wlo ? wlo : (unsigned)((winball >> (8 * g)) & 0xffu)) - 1;
-#else
             cand = blk * 32u + (uint32_t)gl * 4u + li;
             rowmin = grp8_min_f64(lm);
             const uint64_t winball = __ballot(gvalid && lm == rowmin);
             wl2 = __ffs((unsigned)((winball >> (8 * g)) & 0xffu)) - 1;
-#endif
         }
         const double keymin = grp8_min_f64(key);
         const double expose = min_f64(rowmin, keymin);

@@ -196,12 +196,10 @@ struct WL {
     static constexpr uint32_t EX = 8192;                   // [64] f64 what event e exposes; before that the exact block minima of the candidates
     static constexpr uint32_t RS = 8704;                   // [CMAX] f64 candidates: block minimum without the argument
     static constexpr uint32_t TP = HW ? 9216 : 9152;       // [CMAX] f64 candidates: proposal time stored with the argument
-    static constexpr uint32_t PB = HW ? 9728 : 9600;       // [CMAX] u8 candidates: position of the argument | position of the runner-up << 4
     static constexpr uint32_t SLB = HW ? 9792 : 9664;      // [64] u16 event blocks, rank order
     static constexpr uint32_t TB = HW ? 9920 : 9792;       // [64] u16 candidate blocks, compaction order
     static constexpr uint32_t ACL = HW ? 10048 : 9920;     // [8] u16 the accepted events
     static constexpr uint32_t RO = HW ? 10064 : 9936;      // [64] u8 candidate of each rank
-    static constexpr uint32_t SELDT = HW ? 10128 : 10000;  // f64 selection threshold above the minimum
     static constexpr uint32_t NB = HW ? 10144 : 10016;     // (LAT = false) [8][8] u16 G1 of the accepted events, in event order
     static constexpr uint32_t CTL = 10272;                 // (HW) control words shared by the two waves (struct WCtl)
     static constexpr uint32_t HPF = 10336;                 // (HW) [64] u16 the helper wave's list of coordinates whose lines it requests
@@ -219,24 +217,16 @@ constexpr uint32_t W_BYTES_HW = WL<true>::EVN + 64 * 16;  // 23 008 bytes: 6 cha
 constexpr uint32_t W_NBLK = 2048;
 constexpr int W_AMAX = 8;            // accepted events per iteration (one group each)
 // steering of the selection threshold (measured: 1.15 / 0.8 / 3 -- pdmp_trackx.hip's -- is 3.5 % slower here, where every candidate's line is read)
-#ifndef W_GROW
 #define W_GROW 1.02
 #define W_SHRINK 0.98
 #define W_SLACK 5u
-#endif
 // ... of the two-wave form, which runs where the SIMDs are under-occupied: a candidate read in vain costs nothing there, a short list does
-#ifndef W_GROW_HW
 #define W_GROW_HW 1.1
 #define W_SHRINK_HW 0.95
 #define W_SLACK_HW 20u
-#endif
-#ifndef W_NHYP
 #define W_NHYP 8     // hypotheses of the accept chain's first guess, two-wave form (a draw is one LDS read)
 #define W_NHYP_1W 4  // ... single-wave form (a draw is two ds_bpermute pairs; A/B at 2048 chains: 4 is 0.6 % faster than none, 8 is 2 % slower)
-#endif
-#ifndef W_PF_AHEAD
 #define W_PF_AHEAD 2.0  // the helper wave requests the lines of every block within this many window lengths beyond the window
-#endif
 static_assert(W_BYTES <= 10240 && W_BYTES_G <= 10240, "16 chains per CU: 160 KB / 16");
 static_assert(WL<true>::EVD == WL<true>::RING + W_NR * 16 && W_BYTES_HW <= 26624, "6 chains per CU: 160 KB / 6");
 struct WCtl {  // (HW) written by one wave, polled by the other: DS operations of a wave execute in order, so data written before a word is visible with it

@@ -316,6 +316,26 @@ class Ensemble:
     def consume(self):
         _lib.check(self._L.pdmp_ensemble_consume(self._h))
 
+    def consume_async(self, stream=None):
+        """Consume what the last run wrote on the ensemble's second stream and hand the trace segments back empty -- no trace_reset; the next
+        run overlaps with it (pdmp_ensemble_consume_async)."""
+        _lib.check(self._L.pdmp_ensemble_consume_async(self._h, stream))
+
+    def debug_set_consumer_overlap(self, mode):
+        """-1 by ensemble width (default), 0 the asynchronous consumer runs between slices, 1 beside the next slice (include/pdmp_debug.h)."""
+        _lib.check(self._L.pdmp_debug_set_consumer_overlap(self._h, int(mode)))
+
+    def last_consume_ms(self):
+        ms = C.c_float()
+        _lib.check(self._L.pdmp_ensemble_last_consume_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    def debug_host_drain_gbps(self, nbytes=1 << 30):
+        """GB/s of a device-to-pinned-host copy of `nbytes` of the trace buffer (what draining the trace over PCIe would run at)."""
+        g = C.c_double()
+        _lib.check(self._L.pdmp_debug_host_drain_probe(self._h, int(nbytes), C.byref(g)))
+        return float(g.value)
+
     def consume_mean(self, chain_first=0, n=None):
         """(mean [n x d], T_last [n]): mean(Ξ) of src/trace.jl:182-200 per chain, from the device-side cursors."""
         if n is None:
