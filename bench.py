@@ -696,25 +696,20 @@ def main():
     if os.environ.get("PDMP_BENCH_SINGLE_DEVICE"):
         local_rank = 0
     red_dev = "cpu"
-    if world > 1 and backend != "engine":
-        import torch
-        import torch.distributed as dist
-        if backend == "nccl":
-            try:
-                torch.cuda.set_device(local_rank)
-                with _banner_to_stderr():  # (RCCL's version banner would land on this process's stdout, after the JSON line)
-                    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
-                    dist.barrier()  # the communicator is created here at the latest
-                    torch.cuda.synchronize()
-                red_dev = "cuda"
-            except Exception as exc:  # the run has no collective: barriers and four reductions of a few doubles travel as well over gloo
-                print(f"bench.py: rank {rank}: torch.distributed over RCCL failed ({exc}); barriers and reductions over gloo instead", file=sys.stderr, flush=True)
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                backend = "gloo"
-                dist.init_process_group("gloo")
-        else:
-            dist.init_process_group(backend)
+    nccl_group = None  # the torch.distributed group that carries this line's reductions over RCCL (None: the default group)
+    ctl = None         # N > 1: a gloo group (TCP on MASTER_ADDR) that every rank joins FIRST -- whether RCCL is used is voted on over it
+    transport_log = []
+    if world > 1:
+        import torch  # (before the engine library is loaded: one HIP runtime per process, the one torch ships)
+        import torch.distributed as ctl
+        ctl.init_process_group("gloo")
+
+    def vote(ok):
+        """True iff `ok` on EVERY rank (MIN over the gloo group): a transport is adopted by all ranks or by none -- a rank on which RCCL came up
+        never waits in a collective for ranks that have already fallen back (round 4 decided rank by rank)."""
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64)
+        ctl.all_reduce(t, op=ctl.ReduceOp.MIN)
+        return bool(t.item() == 1.0)
 
     if world == 1 and args.gather and backend != "engine":
         # the exchange written against torch.distributed: a one-rank group makes N = 1 run the very same code
@@ -739,21 +734,45 @@ def main():
         raise SystemExit("bench.py: no gfx950 device visible; the engine has no CPU fallback")
     if backend == "engine" and (world > 1 or args.gather):
         # ncclCommInitRank through the library (the 128-byte id travels over a TCP rendezvous on MASTER_ADDR: parallel.exchange_unique_id)
+        err = None
         try:
             comm = pkg.parallel.Comm(rank, world, local_rank)
-        except Exception as exc:  # e.g. the TCP rendezvous port range is closed on this node: the torch.distributed path still measures
+        except Exception as exc:  # e.g. RCCL refuses the ranks' devices, or the rendezvous port range is closed on this node
             if world == 1:
                 raise
-            print(f"bench.py: rank {rank}: pdmp_comm_init failed ({exc}); falling back to torch.distributed over RCCL", file=sys.stderr, flush=True)
-            import torch
-            import torch.distributed as dist
+            err = exc
+            print(f"bench.py: rank {rank}: pdmp_comm_init failed ({exc})", file=sys.stderr, flush=True)
+        if world > 1 and not vote(err is None):
+            if comm is not None:
+                comm.close()
+                comm = None
+            transport_log.append("engine communicator (pdmp_comm_init) did not come up on every rank")
+            print(f"bench.py: rank {rank}: the engine's communicator did not come up on every rank; falling back to torch.distributed over RCCL", file=sys.stderr, flush=True)
             backend = "nccl"
+    if world > 1 and backend == "nccl":
+        # RCCL through torch.distributed, as a second group beside the gloo one; adopted by the vote
+        g, err = None, None
+        try:
+            import datetime
             torch.cuda.set_device(local_rank)
-            with _banner_to_stderr():
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-                dist.barrier()
+            with _banner_to_stderr():  # (RCCL's version banner would land on this process's stdout, after the JSON line)
+                g = ctl.new_group(backend="nccl", timeout=datetime.timedelta(seconds=300))  # nccl == RCCL on ROCm
+                probe = torch.ones(1, dtype=torch.float64, device="cuda")
+                ctl.all_reduce(probe, group=g)  # the communicator is created here at the latest
                 torch.cuda.synchronize()
-            red_dev = "cuda"
+                if int(round(float(probe.item()))) != world:
+                    raise RuntimeError(f"all_reduce over RCCL returned {probe.item()}, expected {world}")
+        except Exception as exc:  # the run has no collective: barriers and a few small reductions travel as well over gloo
+            err = exc
+            print(f"bench.py: rank {rank}: torch.distributed over RCCL failed ({exc})", file=sys.stderr, flush=True)
+        if vote(err is None):
+            nccl_group, red_dev, dist = g, "cuda", ctl
+        else:
+            transport_log.append("torch.distributed over RCCL did not come up on every rank")
+            print(f"bench.py: rank {rank}: RCCL did not come up on every rank; barriers and reductions over gloo instead", file=sys.stderr, flush=True)
+            backend = "gloo"
+    if world > 1 and backend == "gloo":
+        dist = ctl
     W = make_workload(pkg, args, rank, local_rank)
     ens, d, cap, nch = W["ens"], W["d"], W["cap"], args.chains
     G, c = W.get("G"), W.get("c")
@@ -763,7 +782,7 @@ def main():
         if comm is not None:
             comm.barrier()
         if dist is not None:
-            dist.barrier()
+            dist.barrier(group=nccl_group)
             if red_dev == "cuda":
                 import torch
                 torch.cuda.synchronize()
@@ -886,14 +905,14 @@ def main():
         staging = "device" if red_dev == "cuda" else "host"
         barrier()
         tg0 = time.perf_counter()
-        counts_by_rank, gathered, sy, sy2 = par.gather_ensemble(ens, sy, sy2, staging=staging)
+        counts_by_rank, gathered, sy, sy2 = par.gather_ensemble(ens, sy, sy2, staging=staging, group=nccl_group)
         if red_dev == "cuda" or dist is None:
             torch.cuda.synchronize()
         barrier()
         tg = time.perf_counter() - tg0
         if dist is not None:
             tgt = torch.tensor([tg], dtype=torch.float64, device=red_dev)
-            dist.all_reduce(tgt, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tgt, op=dist.ReduceOp.MAX, group=nccl_group)
             tg = float(tgt.item())
         if rank == 0:
             nev_g = int(sum(int(c.sum().item()) for c in counts_by_rank))
@@ -911,7 +930,7 @@ def main():
         if dist is not None:
             import torch
             tv = torch.tensor([float(v) for v in values], dtype=torch.float64, device=red_dev)
-            dist.all_reduce(tv, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+            dist.all_reduce(tv, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM, group=nccl_group)
             return [float(v) for v in tv.tolist()]
         return [float(v) for v in values]
 
@@ -948,7 +967,7 @@ def main():
     if comm is not None and world > 1:
         ranks_seen = int(round(float(comm.allreduce([1.0], "sum")[0])))
     elif dist is not None:
-        ranks_seen = int(dist.get_world_size())
+        ranks_seen = int(dist.get_world_size(group=nccl_group))
     per_rank = None
     if args.per_rank or world > 1:
         c0 = cnt[0]
@@ -964,7 +983,7 @@ def main():
             else:  # (a plain all_reduce: the one collective every backend of this script is known to carry)
                 import torch
                 tv = torch.tensor(vec, dtype=torch.float64, device=red_dev)
-                dist.all_reduce(tv, op=dist.ReduceOp.SUM)
+                dist.all_reduce(tv, op=dist.ReduceOp.SUM, group=nccl_group)
                 vec = tv.cpu().numpy()
             per_rank = [{"rank": r, "seed_first": int(v[0]), "chains": int(v[8]), "kernel_ms_per_step": float(v[9]),
                          "num": int(v[1]), "nacc": int(v[2]), "nevents": int(v[3]),
@@ -1033,6 +1052,10 @@ def main():
         if issue is not None:
             out["issue"] = issue
         out["ranks_seen"] = ranks_seen  # size of the communicator that carried this line's reductions (1: no communicator)
+        if world > 1:
+            out["transport"] = {"reductions": "pdmp_comm_allreduce (RCCL linked by the engine)" if comm is not None else "torch.distributed " + backend,
+                                "control": "torch.distributed gloo (every rank joins it first; a transport is adopted by a vote over it: all ranks or none)",
+                                "fallbacks": transport_log}
         if per_rank is not None:
             out["per_rank"] = per_rank
         if strong_proxy is not None:
@@ -1070,7 +1093,10 @@ def main():
     if comm is not None:
         comm.barrier()
         comm.close()
-    if dist is not None:
+    if ctl is not None:  # (N > 1: the gloo group, and the RCCL group beside it if it was adopted)
+        ctl.barrier()
+        ctl.destroy_process_group()
+    elif dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -42,7 +42,9 @@ def _run_bench(nranks, extra, env_extra=None, timeout=900):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]  # ONE JSON line, from rank 0
-    return json.loads(lines[0])
+    out = json.loads(lines[0])
+    out["_stderr"] = r.stderr
+    return out
 
 
 def test_bench_two_ranks_on_one_device(gpu_pkg):
@@ -241,3 +243,37 @@ def test_bench_over_torch_nccl_launched_by_torchrun(gpu_pkg):
     assert out["n_gpus"] == 1 and out["unhealthy_chains"] == 0 and out["value"] > 0
     g = out["gather"]
     assert g["events"] > 0 and g["chains"] == 256 and g["bytes"] == 32 * g["events"] and "nccl" in g["backend"]
+
+
+def test_strong_scaling_two_ranks_on_one_device(gpu_pkg):
+    """bench.py --gpus 2 in its DEFAULT form -- the north star's: ONE ensemble of 4096 chains, rank r runs chains [r N/R, (r+1) N/R) --
+    against one rank running all 4096: `scaling` says strong, the communicator saw both ranks, every rank reports its share, the seeds continue
+    across the ranks, the summed counters equal the one-rank run's, and the weak-scaling view is measured beside it."""
+    steps, warm = 2, 1
+    common = ["--steps", str(steps), "--warmup", str(warm), "--no-cpu-baseline", "--ess-batches", "0", "--exact-steps", "0"]
+    two = _run_bench(2, common, {"PDMP_BENCH_SINGLE_DEVICE": "1", "PDMP_BENCH_BACKEND": "gloo"})
+    assert two["scaling"] == "strong" and two["n_gpus"] == 2 and two["ranks_seen"] == 2
+    assert two["config"]["total_chains"] == 4096 and two["config"]["chains_per_gpu"] == 2048
+    pr = two["per_rank"]
+    assert [q["chains"] for q in pr] == [2048, 2048] and [q["seed_first"] for q in pr] == [SEED0, SEED0 + 2048]
+    assert all(q["kernel_ms_per_step"] > 0 for q in pr)
+    assert two["transport"]["reductions"] == "torch.distributed gloo" and two["transport"]["fallbacks"] == []
+    w = two["weak"]
+    assert w["scaling"] == "weak" and w["chains_per_gpu"] == 4096 and w["value"] > 0
+    one = _run_bench(1, common + ["--no-strong-proxy", "--no-pipeline"])
+    assert one["scaling"] == "strong" and one["ranks_seen"] == 1 and one["config"]["chains_per_gpu"] == 4096
+    assert one["totals"] == two["totals"]
+
+
+def test_transport_fallback_is_voted_on_by_every_rank(gpu_pkg):
+    """PDMP_BENCH_BACKEND=engine with two ranks on ONE device: RCCL refuses two ranks of a communicator on one GPU, so pdmp_comm_init fails --
+    and so does torch.distributed's RCCL group -- on every rank; each refusal is voted on over the gloo control group (every rank or none falls
+    back), the line is produced over gloo and says what happened.  This is the path to ncclCommInitRank and back that CAN run on a one-GPU box;
+    two ranks on two GPUs over xGMI remain unexecuted by the build."""
+    out = _run_bench(2, ["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--ess-batches", "0", "--exact-steps", "0", "--chains", "256",
+                         "--scaling", "weak"],
+                     {"PDMP_BENCH_SINGLE_DEVICE": "1", "PDMP_BENCH_BACKEND": "engine"})
+    assert out["ranks_seen"] == 2 and out["n_gpus"] == 2 and out["unhealthy_chains"] == 0 and out["value"] > 0
+    assert out["transport"]["reductions"] == "torch.distributed gloo"
+    assert len(out["transport"]["fallbacks"]) == 2 and "pdmp_comm_init" in out["transport"]["fallbacks"][0] and "RCCL" in out["transport"]["fallbacks"][1]
+    assert "pdmp_comm_init failed" in out["_stderr"] and "over gloo instead" in out["_stderr"]

@@ -1051,7 +1051,7 @@ static void detect_lattice(pdmp_ensemble* e) {
     const int64_t d = e->cfg.d;
     e->lattice_n = 0;
     int64_t nl = (int64_t)std::llround(std::sqrt((double)d));
-    bool lat = nl * nl == d && nl >= 16 && nl <= 128 && !e->colptr.empty();
+    bool lat = nl * nl == d && nl >= 16 && nl <= 256 && !e->colptr.empty();  // (256: pdmp_trackp.hip's 8192 block bounds; other users check their own limit)
     for (int64_t col = 0; lat && col < nl; ++col)
         for (int64_t row = 0; lat && row < nl; ++row) {
             const int64_t ii = row + nl * col;
@@ -1285,8 +1285,9 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
         if (!trackp_ok && (!e->use_spec || !pdmp::zz_spec8_geometry(G))) {
             e->track = false;
             return fail(PDMP_ERR_UNSUPPORTED,
-                        "gradient tracking: 2048 <= d <= 16384 and either a symmetric graph with |G1| <= 8 without adaptation, target mean or a "
-                        "bounding matrix of its own (one proposal per lane), or the 8-event kernel's geometry (|G1| <= 5, |S| <= 13)");
+                        "gradient tracking: without adaptation, target mean or a bounding matrix of its own (one proposal per lane) the n x n lattice "
+                        "with 2048 <= d <= 65536 or a symmetric graph with |G1| <= 8 and 2048 <= d <= 16384; else the 8-event kernel's geometry "
+                        "(|G1| <= 5, |S| <= 13, 2048 <= d <= 16384)");
         }
     }
     P.track = e->track ? 1 : 0;
@@ -1546,7 +1547,8 @@ static pdmp_status ensemble_run_impl(pdmp_ensemble* e, double T, int flags, void
             P.hw_slack = (uint32_t)e->dbg_hw_steer[2];
             P.hw_ahead = e->dbg_hw_steer[3];
             P.helper_wave = (e->dbg_helper_wave == 1 || (e->dbg_helper_wave == -1 && e->cfg.nchains <= HELPER_WAVE_MAX_CHAINS)) ? 1 : 0;
-            e->last_kernel = P.helper_wave ? (e->lattice_n ? "zz_local_trackp2_kernel" : "zz_local_trackp2_kernel<LAT=false>")
+            if (e->cfg.d > 16384) P.helper_wave = 0;  // (8192 block bounds leave no LDS for the ring: zz_local_trackp_big_kernel, one wave per chain)
+            e->last_kernel = e->cfg.d > 16384 ? "zz_local_trackp_big_kernel" : P.helper_wave ? (e->lattice_n ? "zz_local_trackp2_kernel" : "zz_local_trackp2_kernel<LAT=false>")
                                            : (e->lattice_n ? "zz_local_trackp_kernel" : "zz_local_trackp_kernel<LAT=false>");
             int rcp = pdmp::launch_zz_local_trackp(P, e->cfg.nchains, s);
             if (rcp != 0) return fail(PDMP_ERR_HIP, "zz_local_trackp launch failed (%d)", rcp);

@@ -190,17 +190,20 @@ __device__ __forceinline__ uint32_t lbf_pos(const unsigned char* smem, uint32_t 
 }  // namespace
 
 // LDS layout (bytes).  HW = the two-wave form (below): room for 64 candidates, the control words shared with the helper wave and the ring of draws.
-template <bool HW>
+template <bool HW, bool BIG = false>
 struct WL {
-    static constexpr uint32_t LB = 0;                      // [2048] u32 lower bounds of the block minima (+ argument position), key blocks of 8
-    static constexpr uint32_t EX = 8192;                   // [64] f64 what event e exposes; before that the exact block minima of the candidates
-    static constexpr uint32_t RS = 8704;                   // [CMAX] f64 candidates: block minimum without the argument
-    static constexpr uint32_t TP = HW ? 9216 : 9152;       // [CMAX] f64 candidates: proposal time stored with the argument
-    static constexpr uint32_t SLB = HW ? 9792 : 9664;      // [64] u16 event blocks, rank order
-    static constexpr uint32_t TB = HW ? 9920 : 9792;       // [64] u16 candidate blocks, compaction order
-    static constexpr uint32_t ACL = HW ? 10048 : 9920;     // [8] u16 the accepted events
-    static constexpr uint32_t RO = HW ? 10064 : 9936;      // [64] u8 candidate of each rank
-    static constexpr uint32_t NB = HW ? 10144 : 10016;     // (LAT = false) [8][8] u16 G1 of the accepted events, in event order
+    static_assert(!(HW && BIG), "the two-wave form keeps 2048 block bounds");
+    static constexpr uint32_t NBLK = BIG ? 8192 : 2048;    // key blocks of 8 a chain may have: d <= 16384, or (BIG, round 5) d <= 65536
+    static constexpr uint32_t XO = (NBLK - 2048) * 4;      // (everything behind the bounds moves up by what they take more)
+    static constexpr uint32_t LB = 0;                      // [NBLK] u32 lower bounds of the block minima (+ argument position), key blocks of 8
+    static constexpr uint32_t EX = XO + 8192;              // [64] f64 what event e exposes; before that the exact block minima of the candidates
+    static constexpr uint32_t RS = XO + 8704;              // [CMAX] f64 candidates: block minimum without the argument
+    static constexpr uint32_t TP = XO + (HW ? 9216 : 9152);   // [CMAX] f64 candidates: proposal time stored with the argument
+    static constexpr uint32_t SLB = XO + (HW ? 9792 : 9664);  // [64] u16 event blocks, rank order
+    static constexpr uint32_t TB = XO + (HW ? 9920 : 9792);   // [64] u16 candidate blocks, compaction order
+    static constexpr uint32_t ACL = XO + (HW ? 10048 : 9920); // [8] u16 the accepted events
+    static constexpr uint32_t RO = XO + (HW ? 10064 : 9936);  // [64] u8 candidate of each rank
+    static constexpr uint32_t NB = XO + (HW ? 10144 : 10016); // (LAT = false) [8][8] u16 G1 of the accepted events, in event order
     static constexpr uint32_t CTL = 10272;                 // (HW) control words shared by the two waves (struct WCtl)
     static constexpr uint32_t HPF = 10336;                 // (HW) [64] u16 the helper wave's list of coordinates whose lines it requests
     static constexpr uint32_t RING = 10464;                // (HW) [W_NR] (u, log u): draw n of the launch at slot n % W_NR
@@ -209,12 +212,11 @@ struct WL {
     static constexpr uint32_t EVN = 21984;                 // (HW, LAT = false) [64] 8 x u16 event slots: G1 of the event's coordinate
     static constexpr int CMAX = HW ? 64 : 56;              // candidates per iteration (block-scan passes of 8)
     static constexpr uint32_t WIN = HW ? 256u : 128u;      // draws an iteration may consume (single wave: two per lane in registers)
+    static constexpr uint32_t BYTES = HW ? EVN + 64 * 16 : NB + 128;  // dynamic LDS of a chain
 };
 constexpr uint32_t W_NR = 512;  // (HW) ring slots
-constexpr uint32_t W_BYTES = 10008;
-constexpr uint32_t W_BYTES_G = WL<false>::NB + 128;
-constexpr uint32_t W_BYTES_HW = WL<true>::EVN + 64 * 16;  // 23 008 bytes: 6 chains per CU (the two-wave form runs at most 4)
-constexpr uint32_t W_NBLK = 2048;
+constexpr uint32_t W_BYTES_1W = WL<false>::BYTES, W_BYTES_BIG = WL<false, true>::BYTES;
+constexpr uint32_t W_BYTES_HW = WL<true>::BYTES;  // 23 008 bytes: 6 chains per CU (the two-wave form runs at most 4)
 constexpr int W_AMAX = 8;            // accepted events per iteration (one group each)
 // steering of the selection threshold (measured: 1.15 / 0.8 / 3 -- pdmp_trackx.hip's -- is 3.5 % slower here, where every candidate's line is read)
 #define W_GROW 1.02
@@ -227,7 +229,8 @@ constexpr int W_AMAX = 8;            // accepted events per iteration (one group
 #define W_NHYP 8     // hypotheses of the accept chain's first guess, two-wave form (a draw is one LDS read)
 #define W_NHYP_1W 4  // ... single-wave form (a draw is two ds_bpermute pairs; A/B at 2048 chains: 4 is 0.6 % faster than none, 8 is 2 % slower)
 #define W_PF_AHEAD 2.0  // the helper wave requests the lines of every block within this many window lengths beyond the window
-static_assert(W_BYTES <= 10240 && W_BYTES_G <= 10240, "16 chains per CU: 160 KB / 16");
+static_assert(WL<false>::BYTES <= 10240, "16 chains per CU: 160 KB / 16");
+static_assert(WL<false, true>::BYTES <= 40960, "d <= 65536: 4 chains per CU (one per SIMD), 160 KB / 4");
 static_assert(WL<true>::EVD == WL<true>::RING + W_NR * 16 && W_BYTES_HW <= 26624, "6 chains per CU: 160 KB / 6");
 struct WCtl {  // (HW) written by one wave, polled by the other: DS operations of a wave execute in order, so data written before a word is visible with it
     uint32_t filled;    // helper: draws [0, filled) of the launch are in the ring
@@ -262,7 +265,7 @@ __device__ __forceinline__ uint32_t nb_count(const uint4 nb) {
 template <bool LAT>
 __device__ __forceinline__ void trackp_helper(const ZzRunParams& P, unsigned char* smem, const int lane, const int64_t chain, const uint64_t seed,
                                            const uint64_t nm0) {
-    using L = WL<true>;
+    using L = WL<true, false>;
     volatile WCtl* const ctl = reinterpret_cast<volatile WCtl*>(smem + L::CTL);
     double2* const ring = reinterpret_cast<double2*>(smem + L::RING);
     const uint4* const lb4 = reinterpret_cast<const uint4*>(smem + L::LB);
@@ -337,9 +340,11 @@ __device__ __forceinline__ void trackp_helper(const ZzRunParams& P, unsigned cha
     asm volatile("" ::"v"(sink));
 }
 
-template <bool PROF, bool LAT, bool HW>
+template <bool PROF, bool LAT, bool HW, bool BIG>
 __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
-    using L = WL<HW>;
+    using L = WL<HW, BIG>;
+    constexpr uint32_t W_NBLK = L::NBLK;
+    constexpr int NCH = (int)(W_NBLK / 2048u);  // chunks of 2048 block bounds: 32 per lane each
     constexpr int W_CMAX = L::CMAX;
     constexpr uint32_t W_WIN = L::WIN;
     const int lane = threadIdx.x & 63;
@@ -508,33 +513,51 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
         double tau = 0.0;
         bool tau_clipped = false;
         {
+            // lane's entries: in chunk c (2048 block bounds), blocks 2048 c + 4 (lane + 64 j) + 0..3, j < 8 (one 16-byte read each).  One chunk
+            // (d <= 16384): the 32 entries stay in registers through the three passes below; four (d <= 65536): every pass reads them again
             uint32_t kk[32];
+            auto loadc = [&](int c) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {  // lane's 32 entries: blocks 4 (lane + 64 j) + 0..3 (one 16-byte read each)
-                const uint4 v = reinterpret_cast<const uint4*>(lbf)[lane + 64 * j];
-                kk[4 * j + 0] = v.x;
-                kk[4 * j + 1] = v.y;
-                kk[4 * j + 2] = v.z;
-                kk[4 * j + 3] = v.w;
+                for (int j = 0; j < 8; ++j) {
+                    const uint4 v = reinterpret_cast<const uint4*>(lbf)[512 * c + lane + 64 * j];
+                    kk[4 * j + 0] = v.x;
+                    kk[4 * j + 1] = v.y;
+                    kk[4 * j + 2] = v.z;
+                    kk[4 * j + 3] = v.w;
+                }
+            };
+            auto lanemin = [&]() -> uint32_t {
+                uint32_t m_ = kk[0];
+#pragma unroll
+                for (int j = 1; j < 32; ++j) m_ = (kk[j] < m_) ? kk[j] : m_;
+                return m_;
+            };
+            uint32_t mloc = 0xffffffffu;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                loadc(c);
+                const uint32_t m_ = lanemin();
+                mloc = (m_ < mloc) ? m_ : mloc;
             }
-            uint32_t mloc = kk[0];
-#pragma unroll
-            for (int j = 1; j < 32; ++j) mloc = (kk[j] < mloc) ? kk[j] : mloc;
             uint32_t mqb = w_wave_min_u32(mloc);
             double mql = p_dec(mqb, tb);  // a lower bound of the next event time
             if (mqb < P_INFBITS && (need_rebase || mql - tb > 0.25)) {
                 // move the base of the bounds up to the front (a float resolves 2^-24 of its distance from the base)
+                mloc = 0xffffffffu;
 #pragma unroll
-                for (int j = 0; j < 32; ++j)
-                    kk[j] = (kk[j] >= P_INFBITS) ? P_INFBITS : p_enc(p_dec(kk[j], tb), mql, kk[j] & 7u);
+                for (int c = 0; c < NCH; ++c) {
+                    if (NCH > 1) loadc(c);
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    reinterpret_cast<uint4*>(lbf)[lane + 64 * j] = make_uint4(kk[4 * j + 0], kk[4 * j + 1], kk[4 * j + 2], kk[4 * j + 3]);
+                    for (int j = 0; j < 32; ++j)
+                        kk[j] = (kk[j] >= P_INFBITS) ? P_INFBITS : p_enc(p_dec(kk[j], tb), mql, kk[j] & 7u);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        reinterpret_cast<uint4*>(lbf)[512 * c + lane + 64 * j] = make_uint4(kk[4 * j + 0], kk[4 * j + 1], kk[4 * j + 2], kk[4 * j + 3]);
+                    const uint32_t m_ = lanemin();
+                    mloc = (m_ < mloc) ? m_ : mloc;
+                }
                 tb = mql;
                 need_rebase = false;
-                mloc = kk[0];
-#pragma unroll
-                for (int j = 1; j < 32; ++j) mloc = (kk[j] < mloc) ? kk[j] : mloc;
                 mqb = w_wave_min_u32(mloc);
                 mql = p_dec(mqb, tb);
                 W_ORDER();
@@ -545,7 +568,7 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
                 finished = true;
             } else {
                 double dt_sel = seldt;
-                uint32_t cm = 0, ncl = 0, incl = 0;
+                uint32_t cm[NCH], ncl = 0, incl = 0;
                 for (int tries = 0;; ++tries) {
                     tau = mql + dt_sel;
                     tau_clipped = false;
@@ -555,10 +578,16 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
                     }
                     if (tries >= 64) tau = mql;
                     const uint32_t thr = p_thr(tau, tb);
-                    cm = 0;
+                    ncl = 0;
 #pragma unroll
-                    for (int j = 31; j >= 0; --j) cm = cm + cm + ((kk[j] <= thr) ? 1u : 0u);
-                    ncl = (uint32_t)__builtin_popcount(cm);
+                    for (int c = 0; c < NCH; ++c) {
+                        if (NCH > 1) loadc(c);
+                        uint32_t m_ = 0;
+#pragma unroll
+                        for (int j = 31; j >= 0; --j) m_ = m_ + m_ + ((kk[j] <= thr) ? 1u : 0u);
+                        cm[c] = m_;
+                        ncl += (uint32_t)__builtin_popcount(m_);
+                    }
                     incl = w_scan_add_u32(ncl);
                     Cc = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                     if (Cc <= (uint32_t)W_CMAX || tries >= 64) break;
@@ -566,13 +595,17 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
                 }
                 {
                     // (more than W_CMAX blocks inside the narrowest threshold: the first W_CMAX are looked at, see below)
-                    uint32_t ix = incl - ncl, m_ = cm;
-                    while (__ballot(m_ != 0u) != 0) {
-                        if (m_ != 0u) {
-                            const uint32_t j = (uint32_t)(__ffs((int)m_) - 1);
-                            if (ix < 64u) TB[ix] = (uint16_t)(4u * ((uint32_t)lane + 64u * (j >> 2)) + (j & 3u));
-                            ix += 1;
-                            m_ &= m_ - 1u;
+                    uint32_t ix = incl - ncl;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        uint32_t m_ = cm[c];
+                        while (__ballot(m_ != 0u) != 0) {
+                            if (m_ != 0u) {
+                                const uint32_t j = (uint32_t)(__ffs((int)m_) - 1);
+                                if (ix < 64u) TB[ix] = (uint16_t)(2048u * (uint32_t)c + 4u * ((uint32_t)lane + 64u * (j >> 2)) + (j & 3u));
+                                ix += 1;
+                                m_ &= m_ - 1u;
+                            }
                         }
                     }
                 }
@@ -1194,7 +1227,13 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
 
 template <bool PROF, bool LAT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void zz_local_trackp_kernel(ZzRunParams P) {
-    trackp_body<PROF, LAT, false>(P);
+    trackp_body<PROF, LAT, false, false>(P);
+}
+// 16384 < d <= 65536 (the lattice up to 256 x 256; round 5): 8192 block bounds take 32 KB of LDS, so four chains share a CU -- one wave per SIMD,
+// the register file to itself -- and the selection scans four chunks of 2048 bounds.  Same loop, same results.
+template <bool PROF>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void zz_local_trackp_big_kernel(ZzRunParams P) {
+    trackp_body<PROF, true, false, true>(P);
 }
 // The two-wave form: one chain per WORKGROUP of two wavefronts -- the main wave runs the event loop above, the helper wave (trackp_helper)
 // keeps the ring of draws filled and the next windows' lines on their way.  For ensembles that leave SIMDs idle (a rank's share of a
@@ -1203,14 +1242,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 // lanes): only who computes a uniform and when a line is requested differ.
 template <bool PROF, bool LAT>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 4))) void zz_local_trackp2_kernel(ZzRunParams P) {
-    trackp_body<PROF, LAT, true>(P);
+    trackp_body<PROF, LAT, true, false>(P);
 }
 
 bool zz_trackp_supported(const ZzRunParams& p) {
     // the plain lattice (neighbours from the index), or any graph whose ids and values are tabulated (|G1| <= TRACKP_KMAX, checked by the host)
-    const bool graph = (p.lattice_n >= 16 && p.lattice_n <= 128) || (p.tb.nb16 != nullptr && p.tb.gam8 != nullptr);
-    return graph && !p.adapt && p.c_chain == nullptr && p.tb.gmu_t == nullptr && !p.track_two_sums &&
-           !p.has_refresh && p.d >= 2048 && p.d <= (int64_t)W_NBLK * 8;
+    // (the lattice up to 256 x 256: d <= 65536 on 8192 block bounds, four chains per CU; a graph's ids are 16 bits with 0xFFFF for "none" and
+    // compared as halves below 2^15: d <= 16384)
+    const bool lattice = p.lattice_n >= 16 && p.lattice_n <= 256 && p.d <= (int64_t)WL<false, true>::NBLK * 8;
+    const bool graph = p.lattice_n == 0 && p.tb.nb16 != nullptr && p.tb.gam8 != nullptr && p.d <= (int64_t)WL<false>::NBLK * 8;
+    return (lattice || graph) && !p.adapt && p.c_chain == nullptr && p.tb.gmu_t == nullptr && !p.track_two_sums && !p.has_refresh && p.d >= 2048;
 }
 
 int launch_zz_local_trackp(const ZzRunParams& p, int64_t nchains, void* stream) {
@@ -1218,6 +1259,11 @@ int launch_zz_local_trackp(const ZzRunParams& p, int64_t nchains, void* stream) 
     ZzRunParams q = p;
     q.nblk = (uint32_t)((p.d + 7) / 8);  // (dk is a multiple of 64, the padding keys are +Inf)
     const bool lat = p.lattice_n != 0;
+    if (p.d > (int64_t)WL<false>::NBLK * 8) {  // 8192 block bounds in LDS (the lattice only), one wave per chain
+        if (p.dbg) hipLaunchKernelGGL((zz_local_trackp_big_kernel<true>), grid, block, W_BYTES_BIG, (hipStream_t)stream, q);
+        else hipLaunchKernelGGL((zz_local_trackp_big_kernel<false>), grid, block, W_BYTES_BIG, (hipStream_t)stream, q);
+        return (int)hipGetLastError();
+    }
     if (p.helper_wave) {
         dim3 block2(128);
         if (!(q.hw_grow > 1.0)) {  // (not set by pdmp_debug_set_helper_steering: the defaults)
@@ -1236,11 +1282,11 @@ int launch_zz_local_trackp(const ZzRunParams& p, int64_t nchains, void* stream) 
         return (int)hipGetLastError();
     }
     if (lat) {
-        if (p.dbg) hipLaunchKernelGGL((zz_local_trackp_kernel<true, true>), grid, block, W_BYTES, (hipStream_t)stream, q);
-        else hipLaunchKernelGGL((zz_local_trackp_kernel<false, true>), grid, block, W_BYTES, (hipStream_t)stream, q);
+        if (p.dbg) hipLaunchKernelGGL((zz_local_trackp_kernel<true, true>), grid, block, W_BYTES_1W, (hipStream_t)stream, q);
+        else hipLaunchKernelGGL((zz_local_trackp_kernel<false, true>), grid, block, W_BYTES_1W, (hipStream_t)stream, q);
     } else {
-        if (p.dbg) hipLaunchKernelGGL((zz_local_trackp_kernel<true, false>), grid, block, W_BYTES_G, (hipStream_t)stream, q);
-        else hipLaunchKernelGGL((zz_local_trackp_kernel<false, false>), grid, block, W_BYTES_G, (hipStream_t)stream, q);
+        if (p.dbg) hipLaunchKernelGGL((zz_local_trackp_kernel<true, false>), grid, block, W_BYTES_1W, (hipStream_t)stream, q);
+        else hipLaunchKernelGGL((zz_local_trackp_kernel<false, false>), grid, block, W_BYTES_1W, (hipStream_t)stream, q);
     }
     return (int)hipGetLastError();
 }
