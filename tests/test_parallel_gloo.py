@@ -207,3 +207,38 @@ def test_unique_id_rendezvous_is_all_or_nothing_and_ignores_strays():
         p.join(timeout=30)
         assert p.exitcode == 0
     assert got[0] == ("ok", bytes(range(128))) and got[1] == ("ok", bytes(range(128))), got
+
+
+def test_unique_id_rendezvous_passes_a_foreign_listener_on_its_first_port():
+    """Something else listens on the first candidate port and accepts without ever answering (another service, another job's rank 0 that is
+    busy): rank 0 binds the next candidate; the peer gets no acknowledgement on the first port within 5 seconds and moves on to the next one
+    instead of spending the whole deadline there (round 4: it waited `timeout + 10` seconds on whichever port accepted first)."""
+    import multiprocessing as mp
+    import socket
+    import time
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cands = [20000 + (port * 7 + 131 * k + 13) % 20000 for k in range(8)]
+    squatter = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    squatter.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    try:
+        squatter.bind(("127.0.0.1", cands[0]))
+    except OSError:
+        pytest.skip("the first candidate port is taken on this host")
+    squatter.listen(8)  # (the kernel completes the handshakes; nobody ever reads or answers)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    t0 = time.time()
+    ps = [ctx.Process(target=_uid_worker_outcome, args=(r, 2, port, 60.0, q)) for r in (0, 1)]
+    for p in ps:
+        p.start()
+    got = {r: (what, msg) for r, what, msg in (q.get(timeout=90) for _ in range(2))}
+    took = time.time() - t0
+    for p in ps:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    squatter.close()
+    assert got[0] == ("ok", bytes(range(128))) and got[1] == ("ok", bytes(range(128))), got
+    assert took < 45.0, took  # (5 s on the foreign port + start-up, not the 60 s deadline)

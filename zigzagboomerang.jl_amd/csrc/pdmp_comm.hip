@@ -267,10 +267,17 @@ pdmp_status pdmp_ensemble_gather_traces(pdmp_ensemble* ens, pdmp_comm* c, int ro
     C_HIP(hipSetDevice(c->device));
     const int W = c->world;
     c->ngathered = 0;  // (whatever happens below, the previous gather's events are no longer what gathered_copy should serve)
+    // From here on every rank takes part in every collective whatever fails on it alone: a local failure is carried in `local` (it contributes no
+    // events), voted on by agree() before anything is sent, and failures after the vote are recorded and returned once the grouped exchange has
+    // closed -- a rank never leaves its peers waiting in a collective
+    pdmp_status local = PDMP_OK;
     std::vector<pdmp_chain_counters> cnt((size_t)nch);
-    if ((st = pdmp_ensemble_counters(ens, cnt.data())) != PDMP_OK) return st;
+    local = pdmp_ensemble_counters(ens, cnt.data());
+    void* evdev = nullptr;
+    int64_t capdev = 0;
+    if (local == PDMP_OK) local = pdmp_ensemble_trace_dev(ens, &evdev, &capdev);
     std::vector<uint64_t> mine((size_t)nch, 0), all;
-    for (int64_t k = 0; k < nch; ++k) mine[(size_t)k] = cnt[(size_t)k].ntrace;
+    for (int64_t k = 0; local == PDMP_OK && k < nch; ++k) mine[(size_t)k] = cnt[(size_t)k].ntrace;
     std::vector<int64_t> widths;
     int64_t wmax = 0;
     if ((st = exchange_counts(c, nch, mine, widths, all, wmax)) != PDMP_OK) return st;
@@ -285,8 +292,7 @@ pdmp_status pdmp_ensemble_gather_traces(pdmp_ensemble* ens, pdmp_comm* c, int ro
     }
     if (nevents_total) *nevents_total = (int64_t)total;
     // ---- everything that can fail on ONE rank, checked now (wsum and total are known everywhere) and voted on before anything is sent
-    pdmp_status local = PDMP_OK;
-    if (counts && counts_cap < wsum)
+    if (local == PDMP_OK && counts && counts_cap < wsum)
         local = cfail(PDMP_ERR_INVALID, "counts holds %lld entries, the ensemble has %lld chains", (long long)counts_cap, (long long)wsum);
     if (local == PDMP_OK && c->rank == root && events_host && (int64_t)total > events_cap)
         local = cfail(PDMP_ERR_INVALID, "events_host holds %lld events, %llu would be gathered", (long long)events_cap, (unsigned long long)total);
@@ -300,24 +306,27 @@ pdmp_status pdmp_ensemble_gather_traces(pdmp_ensemble* ens, pdmp_comm* c, int ro
         for (int r = 0; r < W; ++r)
             for (int64_t k = 0; k < widths[(size_t)r]; ++k) counts[q++] = all[(size_t)r * (size_t)wmax + (size_t)k];
     }
-    // ---- compact the local segments
-    void* evdev = nullptr;
-    int64_t capdev = 0;
-    if ((st = pdmp_ensemble_trace_dev(ens, &evdev, &capdev)) != PDMP_OK) return st;
+    // ---- compact the local segments (a failure here no longer returns before the exchange: it is reported after it)
+    pdmp_status late = PDMP_OK;
+    auto note = [&](hipError_t e_, const char* what) {
+        if (e_ != hipSuccess && late == PDMP_OK) late = cfail(PDMP_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e_));
+    };
     std::vector<uint64_t> offs((size_t)nch, 0);
     for (int64_t k = 1; k < nch; ++k) offs[(size_t)k] = offs[(size_t)k - 1] + mine[(size_t)k - 1];
     uint64_t* doffs = static_cast<uint64_t*>(c->offs.p);
-    C_HIP(hipMemcpyAsync(doffs, offs.data(), (size_t)nch * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-    C_HIP(hipMemcpyAsync(doffs + nch, mine.data(), (size_t)nch * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-    if (my_total)
+    note(hipMemcpyAsync(doffs, offs.data(), (size_t)nch * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream), "hipMemcpyAsync (offsets)");
+    note(hipMemcpyAsync(doffs + nch, mine.data(), (size_t)nch * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream), "hipMemcpyAsync (counts)");
+    if (my_total && late == PDMP_OK)
         hipLaunchKernelGGL(compact_traces_kernel, dim3((unsigned)nch, 4), dim3(256), 0, c->stream, static_cast<const uint4*>(evdev), capdev, doffs + nch,
                            doffs, static_cast<uint4*>(c->compact.p));
-    C_HIP(hipGetLastError());
+    note(hipGetLastError(), "compact_traces_kernel launch");
     // ---- gatherv to the root
     pdmp_event* gdst = (c->rank == root) ? static_cast<pdmp_event*>(c->gathered.p) : nullptr;
     std::vector<uint64_t> bytes((size_t)W);
     for (int r = 0; r < W; ++r) bytes[(size_t)r] = tot[(size_t)r] * sizeof(pdmp_event);
-    if ((st = gatherv_bytes(c, root, c->compact.p, bytes, reinterpret_cast<char*>(gdst))) != PDMP_OK) return st;
+    st = gatherv_bytes(c, root, c->compact.p, bytes, reinterpret_cast<char*>(gdst));
+    if (late != PDMP_OK) return late;  // (the bytes this rank sent are not its events: the root's caller learns of it from this rank's status)
+    if (st != PDMP_OK) return st;
     if (c->rank == root && events_host && total) {
         C_HIP(hipMemcpyAsync(events_host, gdst, (size_t)total * sizeof(pdmp_event), hipMemcpyDeviceToHost, c->stream));
         C_HIP(hipStreamSynchronize(c->stream));
@@ -343,10 +352,11 @@ pdmp_status pdmp_ensemble_gather_bps_traces(pdmp_ensemble* ens, pdmp_comm* c, in
     C_HIP(hipSetDevice(c->device));
     const int W = c->world;
     c->ngathered_bps = 0;
+    pdmp_status local = PDMP_OK;  // (as in pdmp_ensemble_gather_traces: carried to the vote, never returned on one rank alone past this point)
     std::vector<pdmp_chain_counters> cnt((size_t)nch);
-    if ((st = pdmp_ensemble_counters(ens, cnt.data())) != PDMP_OK) return st;
+    local = pdmp_ensemble_counters(ens, cnt.data());
     std::vector<uint64_t> mine((size_t)nch, 0), all;
-    for (int64_t k = 0; k < nch; ++k) mine[(size_t)k] = cnt[(size_t)k].ntrace;
+    for (int64_t k = 0; local == PDMP_OK && k < nch; ++k) mine[(size_t)k] = cnt[(size_t)k].ntrace;
     std::vector<int64_t> widths;
     int64_t wmax = 0;
     if ((st = exchange_counts(c, nch, mine, widths, all, wmax)) != PDMP_OK) return st;
@@ -361,8 +371,7 @@ pdmp_status pdmp_ensemble_gather_bps_traces(pdmp_ensemble* ens, pdmp_comm* c, in
     }
     if (nevents_total) *nevents_total = (int64_t)total;
     const uint64_t my_total = tot[(size_t)c->rank];
-    pdmp_status local = PDMP_OK;
-    if (counts && counts_cap < wsum)
+    if (local == PDMP_OK && counts && counts_cap < wsum)
         local = cfail(PDMP_ERR_INVALID, "counts holds %lld entries, the ensemble has %lld chains", (long long)counts_cap, (long long)wsum);
     if (local == PDMP_OK) local = c->offs.need((size_t)(2 * nch) * sizeof(uint64_t));
     if (local == PDMP_OK) local = c->compact.need((size_t)(my_total ? my_total : 1) * (size_t)d * sizeof(double));  // (one array at a time)
@@ -380,22 +389,28 @@ pdmp_status pdmp_ensemble_gather_bps_traces(pdmp_ensemble* ens, pdmp_comm* c, in
     std::vector<uint64_t> offs((size_t)nch, 0);
     for (int64_t k = 1; k < nch; ++k) offs[(size_t)k] = offs[(size_t)k - 1] + mine[(size_t)k - 1];
     uint64_t* doffs = static_cast<uint64_t*>(c->offs.p);
-    C_HIP(hipMemcpyAsync(doffs, offs.data(), (size_t)nch * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-    C_HIP(hipMemcpyAsync(doffs + nch, mine.data(), (size_t)nch * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    pdmp_status late = PDMP_OK;  // (after the vote nothing returns before the three grouped exchanges have closed)
+    auto note = [&](hipError_t e_, const char* what) {
+        if (e_ != hipSuccess && late == PDMP_OK) late = cfail(PDMP_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e_));
+    };
+    note(hipMemcpyAsync(doffs, offs.data(), (size_t)nch * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream), "hipMemcpyAsync (offsets)");
+    note(hipMemcpyAsync(doffs + nch, mine.data(), (size_t)nch * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream), "hipMemcpyAsync (counts)");
     struct Piece {
         const void* src;
         int64_t wpe;
         DBuf* dst;
     } pieces[3] = {{tdev, 1, &c->gathered}, {xdev, d, &c->gx}, {thdev, d, &c->gth}};
     for (const Piece& pc : pieces) {
-        if (my_total)
+        if (my_total && late == PDMP_OK)
             hipLaunchKernelGGL(compact_words_kernel, dim3((unsigned)nch, 4), dim3(256), 0, c->stream, static_cast<const uint64_t*>(pc.src), cap * pc.wpe,
                                doffs + nch, doffs, pc.wpe, static_cast<uint64_t*>(c->compact.p));
-        C_HIP(hipGetLastError());
+        note(hipGetLastError(), "compact_words_kernel launch");
         std::vector<uint64_t> bytes((size_t)W);
         for (int r = 0; r < W; ++r) bytes[(size_t)r] = tot[(size_t)r] * (uint64_t)pc.wpe * sizeof(double);
-        if ((st = gatherv_bytes(c, root, c->compact.p, bytes, (c->rank == root) ? static_cast<char*>(pc.dst->p) : nullptr)) != PDMP_OK) return st;
+        const pdmp_status sg = gatherv_bytes(c, root, c->compact.p, bytes, (c->rank == root) ? static_cast<char*>(pc.dst->p) : nullptr);
+        if (sg != PDMP_OK && late == PDMP_OK) late = sg;
     }
+    if (late != PDMP_OK) return late;
     const bool isroot = c->rank == root;
     if (t_dev) *t_dev = isroot ? c->gathered.p : nullptr;
     if (x_dev) *x_dev = isroot ? c->gx.p : nullptr;

@@ -141,7 +141,9 @@ def exchange_unique_id(rank, world, make_id, addr=None, port=None, timeout=120.0
     into the same deadline).  So a caller that falls back to another transport when this raises (bench.py: torch.distributed over RCCL)
     falls back on ALL ranks -- never some peers inside ncclCommInitRank while rank 0 has moved on.  A connection must open with a 16-byte
     job token (MASTER_ADDR, MASTER_PORT, world size, TORCHELASTIC_RUN_ID) and its rank: strays, port scanners and a second job that happens
-    to share MASTER_PORT are dropped after a 5 s read timeout instead of being served (or hanging the accept loop)."""
+    to share MASTER_PORT are dropped after a 5 s read timeout instead of being served (or hanging the accept loop).  Rank 0 acknowledges a
+    valid hello at once (magic + "AK" + token), so a peer that reached some OTHER listener on a candidate port moves on after 5 seconds; a rank
+    that connects twice replaces its first connection."""
     import hashlib
     import os
     import socket
@@ -198,9 +200,16 @@ def exchange_unique_id(rank, world, make_id, addr=None, port=None, timeout=120.0
                 except (socket.timeout, OSError):
                     h = None
                 r = struct.unpack("<i", h[-4:])[0] if h else -1
-                if not h or h[:len(_MAGIC)] != _MAGIC or h[len(_MAGIC):len(_MAGIC) + 16] != token or not (0 < r < world) or r in conns:
+                if not h or h[:len(_MAGIC)] != _MAGIC or h[len(_MAGIC):len(_MAGIC) + 16] != token or not (0 < r < world):
                     conn.close()
                     continue
+                try:
+                    conn.sendall(_MAGIC + b"AK" + token)  # this IS rank 0 of this job: the peer may now wait for the verdict
+                except OSError:
+                    conn.close()
+                    continue
+                if r in conns:  # (rank r connected again: its first socket is dead or timed out -- the new one is the one that gets the verdict)
+                    conns[r].close()
                 conns[r] = conn
             ok = len(conns) == world - 1
             for conn in conns.values():
@@ -220,6 +229,12 @@ def exchange_unique_id(rank, world, make_id, addr=None, port=None, timeout=120.0
             try:
                 with socket.create_connection((addr, p), timeout=2.0) as s:
                     s.sendall(_MAGIC + token + struct.pack("<i", rank))
+                    # rank 0 acknowledges a valid hello at once: a listener on this port that accepts but is not rank 0 of this job (or never
+                    # answers) costs 5 seconds, not the whole deadline -- the next candidate port is tried
+                    s.settimeout(5.0)
+                    ack = read_exact(s, len(_MAGIC) + 2 + 16)
+                    if not ack or ack[:len(_MAGIC)] != _MAGIC or ack[len(_MAGIC):len(_MAGIC) + 2] != b"AK" or ack[len(_MAGIC) + 2:] != token:
+                        continue
                     s.settimeout(max(5.0, deadline - time.time() + 10.0))  # (rank 0 answers once everybody has arrived, or at its deadline)
                     buf = read_exact(s, reply)
                     if buf and buf[:len(_MAGIC)] == _MAGIC:
