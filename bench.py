@@ -629,6 +629,9 @@ def main():
                     help="strong (default for C3 / C3G, the north star's form: ONE ensemble of --total-chains chains, rank r of R runs chains "
                          "[r N/R, (r+1) N/R), SURVEY 8 e1) or weak (--chains per GPU; default for C2 / C4 / C5, whose widths are one GPU's share)")
     ap.add_argument("--total-chains", type=int, default=None, help="strong scaling: chains of the whole job (default: the configuration's width)")
+    ap.add_argument("--late-T", type=float, default=200.0,
+                    help="C4: continue the timed ensemble (untimed) to this process time and time --steps slices again there (`late`: the figure of a "
+                         "long run, where the bounds have adapted; 0: skip)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="C3 at N = 1: skip the `pipeline` object (the steps again with their trace consumed on the device beside the sampler)")
     ap.add_argument("--no-strong-proxy", action="store_true",
@@ -787,6 +790,17 @@ def main():
                 import torch
                 torch.cuda.synchronize()
 
+    def allreduce(values, op):
+        """sum / max over the ranks on whatever transport carries this line (comm: the engine's RCCL communicator; dist: torch.distributed)."""
+        if comm is not None and world > 1:
+            return [float(v) for v in comm.allreduce([float(v) for v in values], op)]
+        if dist is not None:
+            import torch
+            tv = torch.tensor([float(v) for v in values], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tv, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM, group=nccl_group)
+            return [float(v) for v in tv.tolist()]
+        return [float(v) for v in values]
+
     launches = [0]
 
     def step(k):
@@ -848,6 +862,36 @@ def main():
     with_integrals = None
     if rank == 0 and args.config == "C4" and not args.gather and os.environ.get("PDMP_BENCH_C4_INTEGRALS", "0") == "0" and args.exact_steps > 0:
         with_integrals = measure_with_integrals(pkg, args, rank, local_rank)
+    # C4: the timed region sits in the transient of a T = 2000 configuration -- adapt with factor 5 (scripts/logistic.jl:167) keeps raising bounds, the
+    # acceptance falls from 0.8 to 0.04 over the first 200 time units and a slice gets 8 times as expensive (tools/c4_drift.py) -- so the SAME
+    # ensemble is continued (untimed) to --late-T and timed again there: `late` is the figure of a long run, `value` the one of its first slices
+    late = None
+    if args.config == "C4" and args.late_T > (args.warmup + args.steps) * args.dt and not args.gather:
+        k0 = args.warmup + args.steps
+        k1 = int(round(args.late_T / args.dt))
+        for k in range(k0, k1):
+            step(k)
+        barrier()
+        l0 = work_counters()
+        launches_l0 = launches[0]
+        lms = []
+        tl0 = time.perf_counter()
+        for k in range(k1, k1 + args.steps):
+            lms.append(step(k))
+        barrier()
+        tl = allreduce([time.perf_counter() - tl0], "max")[0]
+        l1 = work_counters()
+        lw = {key: l1[key] - l0[key] for key in l0}
+        if rank == 0:
+            nl = max(launches[0] - launches_l0, 1)
+            lk = float(np.sum(lms)) / nl
+            lach = W["bytes"](lw) / nl / (lk * 1e-3) / 1e9
+            late = {"T_range": [k1 * args.dt, (k1 + args.steps) * args.dt], "steps": args.steps, "ms_per_step": 1e3 * tl / args.steps,
+                    "value_this_rank": lw["nevents"] / tl, "unit": W["unit"], "proposals_per_s_this_rank": lw["num"] / tl,
+                    "acceptance": lw["nacc"] / max(lw["num"], 1), "kernel_ms_avg": lk, "launches_per_step": nl / args.steps,
+                    "roofline_frac": lach / HBM_PEAK_GBS, "achieved_GBps": lach,
+                    "note": "the same ensemble continued to T = %g and timed again: the bounds have adapted (the acceptance falls from 0.8 at T = 2 to "
+                            "0.04 at T = 200, still falling slowly), a proposal costs what it costs in a long run" % (k1 * args.dt)}
     ess = None
     if rank == 0 and world == 1 and args.config == "C3" and args.ess_batches >= 1 and not args.gather:
         ess = measure_ess(pkg, args, W, ens, local_rank)
@@ -922,17 +966,6 @@ def main():
                       "steps": "all_gather(counts) -> grouped isend/irecv of the trace segments to rank 0 -> reduce(SUM) of 2 x d sums",
                       "first_event_time_rank_last": float(gathered[-1][0, 0].item()) if gathered[-1].shape[0] else None,
                       "mean_of_batch_means": float(np.mean(sy) / (nch * world))}
-
-    def allreduce(values, op):
-        """sum / max over the ranks on whatever transport carries this line (comm: the engine's RCCL communicator; dist: torch.distributed)."""
-        if comm is not None and world > 1:
-            return [float(v) for v in comm.allreduce([float(v) for v in values], op)]
-        if dist is not None:
-            import torch
-            tv = torch.tensor([float(v) for v in values], dtype=torch.float64, device=red_dev)
-            dist.all_reduce(tv, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM, group=nccl_group)
-            return [float(v) for v in tv.tolist()]
-        return [float(v) for v in values]
 
     # aggregate over ranks: max time, summed work
     elapsed = allreduce([elapsed], "max")[0]
@@ -1064,6 +1097,8 @@ def main():
             out["pipeline"] = pipeline
         if weak is not None:
             out["weak"] = weak
+        if late is not None:
+            out["late"] = late
         if gather is not None:
             out["gather"] = gather
         if ess is not None:
