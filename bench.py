@@ -1041,6 +1041,10 @@ def main():
             tkey = args.config
             if args.config == "C3" and args.exact:
                 tkey = "C3X"
+            if args.config == "C3" and args.grid != GRID:
+                tkey = "C3_g%d" % args.grid
+            elif args.config == "C3" and nch != CONFIG_DEFAULTS["C3"]["chains"]:
+                tkey += "_w%d" % nch  # (a rank's share of the ensemble: its own PMC passes)
             elif args.config == "C4" and args.tracked:
                 tkey = "C4T"
             elif args.config == "C3G":

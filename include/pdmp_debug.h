@@ -40,9 +40,9 @@ pdmp_status pdmp_debug_set_track_groups(pdmp_ensemble* ens, int which);
  * logarithms produced ahead into a ring in LDS, the next windows' lines requested early); same committed sequence and floats.  -1 = chosen by
  * the ensemble's width (at most 1024 chains: a launch that leaves SIMDs idle), 0 = never, 1 = always.  Before the next run. */
 pdmp_status pdmp_debug_set_helper_wave(pdmp_ensemble* ens, int mode);
-/* ... its tuning (none of it changes a result): the selection threshold grows by `grow` when every candidate committed and shrinks by `shrink`
- * when more than `slack` did not; the helper requests the lines of the blocks within `ahead` window lengths beyond the current window */
-pdmp_status pdmp_debug_set_helper_steering(pdmp_ensemble* ens, double grow, double shrink, int slack, double ahead);
+/* ... its tuning (none of it changes a result): the selection threshold moves by `gain` of the way towards `target` raw candidates per iteration;
+ * the helper requests the lines of the blocks within `ahead` window lengths beyond the current window */
+pdmp_status pdmp_debug_set_helper_steering(pdmp_ensemble* ens, double gain, int target, double ahead);
 /* PDMP_CHAIN_PAUSED under test: a chain pauses once ONE launch has used n draws of its main stream (the subsampled-logistic kernel: n proposals)
  * instead of 3 * 2^30; 0 restores the default */
 pdmp_status pdmp_debug_set_launch_count_limit(pdmp_ensemble* ens, uint32_t n);

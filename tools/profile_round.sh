@@ -13,11 +13,17 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 for C in $CONFIGS; do
-  case $C in C3|C3X) ST=8;; C3G|C3G_random6|C3G_random8) ST=6;; C3GX|C3GX_random6|C3GX_random8) ST=3;; C2) ST=8;; C4|C4T) ST=6;; C5) ST=4;; esac
-  ARGS="--config $C --steps $ST --warmup 2 --no-cpu-baseline --ess-batches 0 --exact-steps 0"
-  if [ "$C" = C3X ]; then ARGS="--config C3 --exact --steps $ST --warmup 2 --no-cpu-baseline --ess-batches 0 --exact-steps 0"; fi
-  if [ "$C" = C4T ]; then ARGS="--config C4 --tracked --steps $ST --warmup 2 --no-cpu-baseline --ess-batches 0 --exact-steps 0"; fi
+  case $C in C3|C3X|C3_w2048|C3_w1024|C3_w512|C3X_w1024|C3X_w512) ST=8;; C3_g256) ST=4;; C3G|C3G_random6|C3G_random8) ST=6;; C3GX|C3GX_random6|C3GX_random8) ST=3;; C2) ST=8;; C4|C4T) ST=6;; C5) ST=4;; esac
+  ARGS="--config $C --steps $ST --warmup 2 --no-cpu-baseline --ess-batches 0 --exact-steps 0 --no-strong-proxy --no-pipeline --late-T 0"
+  if [ "$C" = C3X ]; then ARGS="--config C3 --exact --steps $ST --warmup 2 --no-cpu-baseline --ess-batches 0 --exact-steps 0 --no-strong-proxy --no-pipeline"; fi
+  if [ "$C" = C4T ]; then ARGS="--config C4 --tracked --steps $ST --warmup 2 --no-cpu-baseline --ess-batches 0 --exact-steps 0 --late-T 0"; fi
   case $C in
+    C3_w2048|C3_w1024|C3_w512)   # a rank's share of the 4096-chain ensemble on 2 / 4 / 8 GPUs (the strong-scaling proxy), tracked
+      ARGS="--config C3 --chains ${C#C3_w} --steps $ST --warmup 2 --no-cpu-baseline --ess-batches 0 --exact-steps 0 --no-strong-proxy --no-pipeline";;
+    C3X_w1024|C3X_w512)          # ... on the bit-identical moving kernel
+      ARGS="--config C3 --exact --chains ${C#C3X_w} --steps $ST --warmup 2 --no-cpu-baseline --ess-batches 0 --exact-steps 0 --no-strong-proxy --no-pipeline";;
+    C3_g256)                     # d = 65536: the 256 x 256 lattice, 1024 chains (the same 8.6 GB of chain state)
+      ARGS="--config C3 --grid 256 --chains 1024 --steps $ST --warmup 2 --no-cpu-baseline --ess-batches 0 --exact-steps 0 --no-strong-proxy --no-pipeline";;
     C3G) ARGS="--config C3G --steps $ST --warmup 2 --no-cpu-baseline";;
     C3GX) ARGS="--config C3G --exact --steps $ST --warmup 1 --no-cpu-baseline";;
     C3G_random6) ARGS="--config C3G --graph random6 --steps $ST --warmup 2 --no-cpu-baseline";;

@@ -168,7 +168,7 @@ def load():
     L.pdmp_debug_set_track_groups.argtypes = [vp, C.c_int]
     L.pdmp_debug_set_helper_wave.argtypes = [vp, C.c_int]
     L.pdmp_debug_set_launch_count_limit.argtypes = [vp, C.c_uint32]
-    L.pdmp_debug_set_helper_steering.argtypes = [vp, C.c_double, C.c_double, C.c_int, C.c_double]
+    L.pdmp_debug_set_helper_steering.argtypes = [vp, C.c_double, C.c_int, C.c_double]
     L.pdmp_debug_last_kernel.argtypes = [vp, C.c_char_p, i64]
     L.pdmp_debug_set_logistic_rows.argtypes = [vp, C.c_int]
     for name in EXPORTED_SYMBOLS + DEBUG_SYMBOLS:

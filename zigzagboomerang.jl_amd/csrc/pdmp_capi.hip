@@ -122,7 +122,7 @@ struct pdmp_ensemble {
     int dbg_phase_valid = 0;
     int64_t dbg_dump = 0;          // dump the first n proposals of chain 0 (one-event kernel) to stderr
     int dbg_track_groups = 0;      // gradient tracking: keep the 8-lane-group kernel where the one-proposal-per-lane kernel would run
-    double dbg_hw_steer[4] = {0, 0, 0, 0};  // pdmp_debug_set_helper_steering: grow, shrink, slack, ahead (0: the kernel's defaults)
+    double dbg_hw_steer[3] = {0, 0, 0};  // pdmp_debug_set_helper_steering: gain, target, ahead (0: the kernel's defaults)
     uint32_t dbg_count_limit = 0;  // pdmp_debug_set_launch_count_limit (0: PDMP_LAUNCH_COUNT_LIMIT)
     int dbg_cons_overlap = -1;     // pdmp_debug_set_consumer_overlap: -1 by ensemble width, 0 the consumer runs between slices, 1 beside the next slice
     int dbg_helper_wave = -1;      // zz_local_trackp: -1 = the two-wave form where the launch leaves SIMDs idle (HELPER_WAVE_MAX_CHAINS), 0 = never, 1 = always
@@ -430,13 +430,12 @@ pdmp_status pdmp_debug_set_launch_count_limit(pdmp_ensemble* e, uint32_t n) {
     e->dbg_count_limit = n;
     return PDMP_OK;
 }
-pdmp_status pdmp_debug_set_helper_steering(pdmp_ensemble* e, double grow, double shrink, int slack, double ahead) {
-    if (!e || !(grow > 1.0) || !(shrink > 0.0 && shrink < 1.0) || slack < 0 || slack > 64 || !(ahead >= 0.0))
-        return fail(PDMP_ERR_INVALID, "helper steering: grow > 1, 0 < shrink < 1, 0 <= slack <= 64, ahead >= 0");
-    e->dbg_hw_steer[0] = grow;
-    e->dbg_hw_steer[1] = shrink;
-    e->dbg_hw_steer[2] = (double)slack;
-    e->dbg_hw_steer[3] = ahead;
+pdmp_status pdmp_debug_set_helper_steering(pdmp_ensemble* e, double gain, int target, double ahead) {
+    if (!e || !(gain > 0.0 && gain <= 1.0) || target < 1 || target > 64 || !(ahead >= 0.0))
+        return fail(PDMP_ERR_INVALID, "helper steering: 0 < gain <= 1, 1 <= target <= 64, ahead >= 0");
+    e->dbg_hw_steer[0] = gain;
+    e->dbg_hw_steer[1] = (double)target;
+    e->dbg_hw_steer[2] = ahead;
     return PDMP_OK;
 }
 pdmp_status pdmp_debug_set_logistic_rows(pdmp_ensemble* e, int w) {
@@ -1542,10 +1541,9 @@ static pdmp_status ensemble_run_impl(pdmp_ensemble* e, double T, int flags, void
                     if (hist[k] > hist[best]) best = k;
                 P.typ_extra = best > 0 ? best - 1u : 0u;
             }
-            P.hw_grow = e->dbg_hw_steer[0];
-            P.hw_shrink = e->dbg_hw_steer[1];
-            P.hw_slack = (uint32_t)e->dbg_hw_steer[2];
-            P.hw_ahead = e->dbg_hw_steer[3];
+            P.hw_gain = e->dbg_hw_steer[0];
+            P.hw_target = (uint32_t)e->dbg_hw_steer[1];
+            P.hw_ahead = e->dbg_hw_steer[2];
             P.helper_wave = (e->dbg_helper_wave == 1 || (e->dbg_helper_wave == -1 && e->cfg.nchains <= HELPER_WAVE_MAX_CHAINS)) ? 1 : 0;
             if (e->cfg.d > 16384) P.helper_wave = 0;  // (8192 block bounds leave no LDS for the ring: zz_local_trackp_big_kernel, one wave per chain)
             e->last_kernel = e->cfg.d > 16384 ? "zz_local_trackp_big_kernel" : P.helper_wave ? (e->lattice_n ? "zz_local_trackp2_kernel" : "zz_local_trackp2_kernel<LAT=false>")

@@ -158,8 +158,8 @@ struct ZzRunParams {
     int32_t track_two_sums;  // tracked-gradient kernel: the bounding Γ differs from the target's (two pairs of sums per coordinate)
     uint32_t count_limit;    // a chain whose launch has used this many draws (proposals: the logistic kernel) pauses: PDMP_LAUNCH_COUNT_LIMIT, or a test's
     uint32_t typ_extra;      // zz_local_trackp: the most frequent |G1[i]| − 1 (the accept chain's first guess; any value is correct)
-    double hw_grow, hw_shrink, hw_ahead;  // ... its steering of the selection threshold and how far ahead the helper requests lines (window lengths)
-    uint32_t hw_slack;
+    double hw_gain, hw_ahead;  // ... its steering of the selection threshold (gain towards a target count) and how far ahead the helper requests lines
+    uint32_t hw_target;
     int32_t helper_wave;     // zz_local_trackp: the two-wave form (a helper wave per chain: ring of draws + prefetch), for under-occupied launches
     int32_t lattice_n;       // n if the graph is the n x n 5-point lattice in column-major numbering (i = row + n col), else 0
     uint32_t lattice_magic;  // ceil(2^32 / n): column of i = umulhi(i, magic) for i < 2^16

@@ -222,13 +222,13 @@ constexpr int W_AMAX = 8;            // accepted events per iteration (one group
 #define W_GROW 1.02
 #define W_SHRINK 0.98
 #define W_SLACK 5u
-// ... of the two-wave form, which runs where the SIMDs are under-occupied: a candidate read in vain costs nothing there, a short list does
-#define W_GROW_HW 1.1
-#define W_SHRINK_HW 0.95
-#define W_SLACK_HW 20u
+// ... of the two-wave form: the raw candidate count is steered towards a target, by a gain (A/B at 512 / 1024 chains: 48 at 0.3 is 3 % faster than
+// the step rule above with 1.1 / 0.95 / 20, and than a target of 56)
+#define W_TARGET_HW 48u
+#define W_GAIN_HW 0.3
 #define W_NHYP 8     // hypotheses of the accept chain's first guess, two-wave form (a draw is one LDS read)
 #define W_NHYP_1W 4  // ... single-wave form (a draw is two ds_bpermute pairs; A/B at 2048 chains: 4 is 0.6 % faster than none, 8 is 2 % slower)
-#define W_PF_AHEAD 2.0  // the helper wave requests the lines of every block within this many window lengths beyond the window
+#define W_PF_AHEAD 1.0  // the helper wave requests the lines of every block within this many window lengths beyond the window (1, 2, 4 measured: 1)
 static_assert(WL<false>::BYTES <= 10240, "16 chains per CU: 160 KB / 16");
 static_assert(WL<false, true>::BYTES <= 40960, "d <= 65536: 4 chains per CU (one per SIMD), 160 KB / 4");
 static_assert(WL<true>::EVD == WL<true>::RING + W_NR * 16 && W_BYTES_HW <= 26624, "6 chains per CU: 160 KB / 6");
@@ -345,6 +345,8 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
     using L = WL<HW, BIG>;
     constexpr uint32_t W_NBLK = L::NBLK;
     constexpr int NCH = (int)(W_NBLK / 2048u);  // chunks of 2048 block bounds: 32 per lane each
+    constexpr int AMAXT = W_AMAX;  // accepted events per iteration: one pass of 8 groups (a second pass for events 8 .. 15 was built and measured in
+    // round 5 on the two-wave form: the iteration's cost grows with the window as fast as what it commits -- 17.8 against 17.5 ms at 512 chains)
     constexpr int W_CMAX = L::CMAX;
     constexpr uint32_t W_WIN = L::WIN;
     const int lane = threadIdx.x & 63;
@@ -591,7 +593,8 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
                     incl = w_scan_add_u32(ncl);
                     Cc = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                     if (Cc <= (uint32_t)W_CMAX || tries >= 64) break;
-                    dt_sel *= 0.5;
+                    // (HW: shrink to what the count asks for, not by half -- the 64 candidate lanes are the resource the threshold is steered by)
+                    dt_sel *= HW ? (double)(W_CMAX - 6) / (double)Cc : 0.5;
                 }
                 {
                     // (more than W_CMAX blocks inside the narrowest threshold: the first W_CMAX are looked at, see below)
@@ -876,12 +879,12 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
             }
         }
         WPHASE(1);  // (the accept chain)
-        // at most W_AMAX accepted events per iteration: the candidate list ends before the next one
+        // at most AMAXT accepted events per iteration: the candidate list ends before the next one
         {
             uint64_t ab = __ballot(acc) & ((C < 64) ? ((1ull << C) - 1ull) : ~0ull);
-            if (__popcll(ab) > W_AMAX) {
+            if (__popcll(ab) > AMAXT) {
                 uint64_t m_ = ab;
-                for (int q = 0; q < W_AMAX; ++q) m_ &= m_ - 1;
+                for (int q = 0; q < AMAXT; ++q) m_ &= m_ - 1;
                 C = __ffsll((unsigned long long)m_) - 1;
             }
         }
@@ -959,109 +962,156 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
         if (PROF) ph_eval += (uint64_t)C;
         const uint64_t accball = __ballot(acc);
         const int nacc_it = __popcll(accball);
-        if (LAT && acc) ACL[__popcll(accball & ((1ull << lane) - 1ull))] = (uint16_t)lane;  // (LAT = false: written with the zones, same slots)
+        if (LAT && !HW && acc) ACL[__popcll(accball & ((1ull << lane) - 1ull))] = (uint16_t)lane;  // (LAT = false: written with the zones, same slots; HW on the lattice: not read)
         W_ORDER();
         WPHASE(2);
         // ---------------- accepted events, one 8-lane group each: members of G1[i] (ascending, :131-135)
-        // (the groups of the accepted events are the LAST nacc_it groups of the wave, in event order: the low lanes -- lane r = event r -- are
-        // then free to re-bound their rejected proposals in the same evaluation, see below)
-        const int g0 = 8 - nacc_it;
-        const bool gact = g >= g0;
-        uint32_t ea = 0u;  // the event of this lane's group: the (g − g0)-th accepted one
-        if (HW) {
-            // (the positions of the accept mask's set bits, walked on the scalar unit: no round trip through LDS)
-            uint64_t m_ = accball;
-            const int want = g - g0;
+        // (the groups of the accepted events are the LAST groups of the wave, in event order: the low lanes -- lane r = event r -- are then free
+        // to re-bound their rejected proposals in the same evaluation, see below)
+        struct GOut {
+            bool gact, mem, selfl;
+            uint32_t ea, ia, blka, jm, cand_a;
+            double tpa, gj, gdj, keyj, xa, txa, Ia, th_ia, rowmin_a;
+            uint64_t acc_ia;
+        };
+        double key2 = W_INF;  // the new key of this lane's rejected proposal (event lanes)
+        auto group_stage = [&](const int base, const int ng, const bool first) -> GOut {
+            GOut o;
+            const int g0 = 8 - ng;
+            const bool gact = g >= g0;
+            uint32_t ea = 0u;  // the event of this lane's group: the (base + g − g0)-th accepted one
+            if (HW) {
+                // (the positions of the accept mask's set bits, walked on the scalar unit: no round trip through LDS)
+                uint64_t m_ = accball;
+                const int want = base + g - g0;
 #pragma unroll
-            for (int n = 0; n < W_AMAX; ++n) {
-                const uint32_t pos = m_ ? (uint32_t)(__ffsll((unsigned long long)m_) - 1) : 0u;
-                m_ &= m_ - 1ull;
-                ea = (want == n) ? pos : ea;
-            }
-        } else {
-            ea = gact ? (uint32_t)ACL[g - g0] : 0u;
-        }
-        const uint32_t ia_b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ea << 2), (int)i);
-        const uint32_t off_b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ea << 2), (int)off);
-        const uint32_t ia = gact ? ia_b : 0u;
-        const uint32_t blka = gact ? (uint32_t)SLB[ea] : 0u;
-        const double tpa_b = w_shfl(tp, ea);
-        const double tpa = gact ? tpa_b : 0.0;
-        const uint32_t offa = gact ? off_b : 0u;
-        uint32_t ka = 0, jm = ia;
-        bool mem = false;
-        if (LAT) {
-        // G1[ia] on the lattice, ascending: {ia − n, ia − 1, ia, ia + 1, ia + n} inside the grid -- computed, so that the members' records are
-        // requested at once; the CSC tables are read for the VALUES only (Γ[j, i] = Γ[i, j]: symmetric, checked on the host)
-        const uint32_t cola = __umulhi(ia, nmagic), rowa = ia - cola * nlat;
-        const bool hasL = cola > 0u, hasU = rowa > 0u, hasD = rowa + 1u < nlat, hasR = cola + 1u < nlat;
-        ka = gact ? (1u + (hasL ? 1u : 0u) + (hasU ? 1u : 0u) + (hasD ? 1u : 0u) + (hasR ? 1u : 0u)) : 0u;
-        mem = gact && (uint32_t)gl < ka;
-        {
-            // position gl among the present members in the order L, U, self, D, R
-            uint32_t pos = (uint32_t)gl;
-            const uint32_t cand5[5] = {ia - nlat, ia - 1u, ia, ia + 1u, ia + nlat};
-            const bool has5[5] = {hasL, hasU, true, hasD, hasR};
-            uint32_t seen = 0;
-#pragma unroll
-            for (int q = 0; q < 5; ++q) {
-                if (has5[q]) {
-                    if (seen == pos && mem) jm = cand5[q];
-                    seen += 1;
+                for (int n = 0; n < AMAXT; ++n) {
+                    const uint32_t pos = m_ ? (uint32_t)(__ffsll((unsigned long long)m_) - 1) : 0u;
+                    m_ &= m_ - 1ull;
+                    ea = (want == n) ? pos : ea;
                 }
+            } else {
+                ea = gact ? (uint32_t)ACL[g - g0] : 0u;
             }
-        }
-        } else {
-            // member gl of G1[ia]: the ids the event's candidate lane read with its record (LDS slot g − g0), ascending (:131-135)
-            const uint32_t jraw = gact ? (uint32_t)NB16[8 * (g - g0) + gl] : 0xffffu;
-            mem = jraw != 0xffffu;
-            jm = mem ? jraw : ia;
-        }
-        TrRecP* const rj = rec + jm;
-        TrRecP* const ria = rec + ia;
-        double gam = 0.0;  // Γ[jm, ia]: member gl of G1[ia]
-        if (LAT) {
-            if (mem) gam = (gl == 0) ? ria->gam0 : (gl == 1) ? ria->gam1 : (gl == 2) ? ria->gam2 : (gl == 3) ? ria->gam3 : ria->gam4;
-        } else {
-            if (mem) gam = P.tb.gam8[(size_t)ia * 8 + (size_t)gl];  // (shared table, L2: requested next to the members' records)
-        }
-        // (the reflecting coordinate's own fields are read again by its group: the lines are in L2)
-        const double th_ia = ria->th;
-        double xa = ria->x, txa = ria->tx, Ia = ria->I;
-        const uint64_t acc_ia = ria->acc;
-        const double thj0 = rj->th, gj0 = rj->g, gdj0 = rj->gd, tgj = rj->tg;
-        const double2 cjm2 = *reinterpret_cast<const double2*>(&rj->c);
-        const double resta_b = w_shfl(rest, ea);  // the accepted event's block without it, and where that minimum sits
-        const uint32_t rarga_b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ea << 2), (int)rarg);
-        // ---------------- ONE evaluation of the new bound and key per lane (logarithm, two divisions, square root): the re-bound of a rejected
-        // proposal (:137-140) in its event lane, the re-bound of a member of G1 (:131-135) in its group lane.  A lane that is both (more than
-        // 64 − 8 nacc candidates) evaluates its rejected proposal again below.
-        const bool selfl = mem && jm == ia;
-        const double thj = selfl ? -th_ia : thj0;
-        const double gj = gj0 + gdj0 * (tpa - tgj);
-        const double gdj = gdj0 + gam * (-2.0 * th_ia);  // θ_i -> −θ_i
-        double a2, b2, key2;
-        {
-            const uint32_t dix = gact ? (offa + 1u + (uint32_t)gl) : (off + 1u);
-            const double L = drawlog(dnm + ((dix < W_WIN - 1u) ? dix : W_WIN - 1u));
-            const double cc = gact ? cjm2.x : c_i, cc100 = gact ? cjm2.y : c_i2.y;
-            const double gg = gact ? gj : g_now, tt = gact ? thj : th, gdd = gact ? gdj : gd_i;
-            a2 = cc + gg * tt;
-            b2 = cc100 + tt * gdd;
-            key2 = (gact ? tpa : tp) + w_poisson_time_L(a2, b2, L);
-        }
-        const double keyj = mem ? key2 : W_INF;
-        if (__ballot(ev && !acc && gact) != 0) {
-            const double L = drawlog(dnm + ((off + 1u < W_WIN - 1u) ? off + 1u : W_WIN - 1u));
-            const double a2e = c_i + g_now * th;
-            const double b2e = c_i2.y + th * gd_i;
-            const double k2e = tp + w_poisson_time_L(a2e, b2e, L);
-            if (gact) {
-                a2 = a2e;
-                b2 = b2e;
-                key2 = k2e;
+            const uint32_t ia_b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ea << 2), (int)i);
+            const uint32_t off_b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ea << 2), (int)off);
+            const uint32_t ia = gact ? ia_b : 0u;
+            const uint32_t blka = gact ? (uint32_t)SLB[ea] : 0u;
+            const double tpa_b = w_shfl(tp, ea);
+            const double tpa = gact ? tpa_b : 0.0;
+            const uint32_t offa = gact ? off_b : 0u;
+            uint32_t ka = 0, jm = ia;
+            bool mem = false;
+            if (LAT) {
+                // G1[ia] on the lattice, ascending: {ia − n, ia − 1, ia, ia + 1, ia + n} inside the grid -- computed, so that the members' records
+                // are requested at once; the CSC tables are read for the VALUES only (Γ[j, i] = Γ[i, j]: symmetric, checked on the host)
+                const uint32_t cola = __umulhi(ia, nmagic), rowa = ia - cola * nlat;
+                const bool hasL = cola > 0u, hasU = rowa > 0u, hasD = rowa + 1u < nlat, hasR = cola + 1u < nlat;
+                ka = gact ? (1u + (hasL ? 1u : 0u) + (hasU ? 1u : 0u) + (hasD ? 1u : 0u) + (hasR ? 1u : 0u)) : 0u;
+                mem = gact && (uint32_t)gl < ka;
+                // position gl among the present members in the order L, U, self, D, R
+                const uint32_t pos = (uint32_t)gl;
+                const uint32_t cand5[5] = {ia - nlat, ia - 1u, ia, ia + 1u, ia + nlat};
+                const bool has5[5] = {hasL, hasU, true, hasD, hasR};
+                uint32_t seen = 0;
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    if (has5[q]) {
+                        if (seen == pos && mem) jm = cand5[q];
+                        seen += 1;
+                    }
+                }
+            } else {
+                // member gl of G1[ia]: the ids the event's candidate lane read with its record (LDS slot g − g0), ascending (:131-135)
+                const uint32_t jraw = gact ? (uint32_t)NB16[8 * (g - g0) + gl] : 0xffffu;
+                mem = jraw != 0xffffu;
+                jm = mem ? jraw : ia;
             }
-        }
+            TrRecP* const rj = rec + jm;
+            TrRecP* const ria = rec + ia;
+            double gam = 0.0;  // Γ[jm, ia]: member gl of G1[ia]
+            if (LAT) {
+                if (mem) gam = (gl == 0) ? ria->gam0 : (gl == 1) ? ria->gam1 : (gl == 2) ? ria->gam2 : (gl == 3) ? ria->gam3 : ria->gam4;
+            } else {
+                if (mem) gam = P.tb.gam8[(size_t)ia * 8 + (size_t)gl];  // (shared table, L2: requested next to the members' records)
+            }
+            // (the reflecting coordinate's own fields are read again by its group: the lines are in L2)
+            const double th_ia = ria->th;
+            double xa = ria->x, txa = ria->tx, Ia = ria->I;
+            const uint64_t acc_ia = ria->acc;
+            const double thj0 = rj->th, gj0 = rj->g, gdj0 = rj->gd, tgj = rj->tg;
+            const double2 cjm2 = *reinterpret_cast<const double2*>(&rj->c);
+            const double resta_b = w_shfl(rest, ea);  // the accepted event's block without it, and where that minimum sits
+            const uint32_t rarga_b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ea << 2), (int)rarg);
+            // ---------------- ONE evaluation of the new bound and key per lane (logarithm, two divisions, square root): the re-bound of a
+            // rejected proposal (:137-140) in its event lane (first pass), the re-bound of a member of G1 (:131-135) in its group lane.  A lane
+            // that is both (more than 64 − 8 ng candidates) evaluates its rejected proposal again below.
+            const bool selfl = mem && jm == ia;
+            const double thj = selfl ? -th_ia : thj0;
+            const double gj = gj0 + gdj0 * (tpa - tgj);
+            const double gdj = gdj0 + gam * (-2.0 * th_ia);  // θ_i -> −θ_i
+            double a2l, b2l, key2l;
+            {
+                const bool mine = gact || !first;  // (a later pass evaluates for its groups only)
+                const uint32_t dix = mine ? (offa + 1u + (uint32_t)gl) : (off + 1u);
+                const double Lg = drawlog(dnm + ((dix < W_WIN - 1u) ? dix : W_WIN - 1u));
+                const double cc = mine ? cjm2.x : c_i, cc100 = mine ? cjm2.y : c_i2.y;
+                const double gg = mine ? gj : g_now, tt = mine ? thj : th, gdd = mine ? gdj : gd_i;
+                a2l = cc + gg * tt;
+                b2l = cc100 + tt * gdd;
+                key2l = (mine ? tpa : tp) + w_poisson_time_L(a2l, b2l, Lg);
+            }
+            const double keyj = mem ? key2l : W_INF;
+            if (first) {
+                if (__ballot(ev && !acc && gact) != 0) {
+                    const double Le = drawlog(dnm + ((off + 1u < W_WIN - 1u) ? off + 1u : W_WIN - 1u));
+                    const double a2e = c_i + g_now * th;
+                    const double b2e = c_i2.y + th * gd_i;
+                    const double k2e = tp + w_poisson_time_L(a2e, b2e, Le);
+                    if (gact) key2l = k2e;
+                }
+                key2 = key2l;
+            }
+            if (selfl) {  // event(i, t, x, θ, F) (src/sfact.jl:50-52): x_i at t′
+                const double dtx = tpa - txa;
+                const double xn = xa + th_ia * dtx;
+                Ia = Ia + dtx * ((xa + xn) * 0.5);
+                xa = xn;
+                txa = tpa;
+            }
+            // the accepted event's block: a LOWER BOUND of its new minimum is enough (level 1 holds bounds): the smaller of the block without the
+            // event -- which may still count a member's OLD key: then the bound is stale low and costs a look later -- and the members' new keys in it
+            const double kin = (mem && (jm >> 3) == blka) ? keyj : W_INF;
+            const double kinmin = w_grp8_min(kin);
+            // position bits of the member that holds it (the lowest lane of the group on ties): a DPP minimum of (lane in group, position)
+            const uint32_t wkey = (gact && kin == kinmin) ? (((uint32_t)gl << 3) | (jm & 7u)) : 0xffu;
+            const uint32_t jwin = w_grp8_min_u32(wkey);  // (no lane of an inactive group is read below)
+            const bool restwins = resta_b <= kinmin;
+            const double rowmin_a = restwins ? resta_b : kinmin;
+            const uint32_t cand_a = restwins ? (rarga_b & 7u) : (jwin & 7u);
+            const double keymin = w_grp8_min(keyj);
+            if (gact && gl == 0) EX[ea] = w_min(rowmin_a, keymin);
+            o.gact = gact;
+            o.mem = mem;
+            o.selfl = selfl;
+            o.ea = ea;
+            o.ia = ia;
+            o.blka = blka;
+            o.jm = jm;
+            o.cand_a = cand_a;
+            o.tpa = tpa;
+            o.gj = gj;
+            o.gdj = gdj;
+            o.keyj = keyj;
+            o.xa = xa;
+            o.txa = txa;
+            o.Ia = Ia;
+            o.th_ia = th_ia;
+            o.rowmin_a = rowmin_a;
+            o.acc_ia = acc_ia;
+            return o;
+        };
+        const GOut G0 = group_stage(0, nacc_it, true);
         // new minimum of the popped block of a rejected event, and what the event exposes
         double rowmin = W_INF;
         uint32_t cand = i;
@@ -1069,31 +1119,6 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
             const bool mine = key2 < rest || (key2 == rest && i < rarg);
             rowmin = mine ? key2 : rest;
             cand = mine ? i : rarg;
-        }
-        if (selfl) {  // event(i, t, x, θ, F) (src/sfact.jl:50-52): x_i at t′
-            const double dtx = tpa - txa;
-            const double xn = xa + th_ia * dtx;
-            Ia = Ia + dtx * ((xa + xn) * 0.5);
-            xa = xn;
-            txa = tpa;
-        }
-        // the accepted event's block: a LOWER BOUND of its new minimum is enough (level 1 holds bounds): the smaller of the block without the
-        // event -- which may still count a member's OLD key: then the bound is stale low and costs a look later -- and the members' new keys in it
-        double rowmin_a = W_INF;
-        uint32_t cand_a = 0;
-        int wl_a = -1;
-        {
-            const double kin = (mem && (jm >> 3) == blka) ? keyj : W_INF;
-            const double kinmin = w_grp8_min(kin);
-            // position bits of the member that holds it (the lowest lane of the group on ties): a DPP minimum of (lane in group, position)
-            const uint32_t wkey = (gact && kin == kinmin) ? (((uint32_t)gl << 3) | (jm & 7u)) : 0xffu;
-            const uint32_t jwin = w_grp8_min_u32(wkey);  // (no lane of an inactive group is read below)
-            const bool restwins = resta_b <= kinmin;
-            rowmin_a = restwins ? resta_b : kinmin;
-            cand_a = restwins ? (rarga_b & 7u) : (jwin & 7u);
-            wl_a = 0;  // (lane 0 of the group stores the bound)
-            const double keymin = w_grp8_min(keyj);
-            if (gact && gl == 0) EX[ea] = w_min(rowmin_a, keymin);
         }
         if (ev && !acc) EX[lane] = rowmin;  // (rowmin <= key2: the new key is one of its candidates)
         W_ORDER();
@@ -1130,8 +1155,14 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
             if (stopped) vsel = -1;
         }
         // steer the threshold so that the raw candidate list is just longer than what can commit
-        seldt = w_uniform(dt_used * (((int)Rc >= Craw) ? (HW ? P.hw_grow : W_GROW)
-                                                       : (((int)Rc + (int)(HW ? P.hw_slack : W_SLACK) < Craw) ? (HW ? P.hw_shrink : W_SHRINK) : 1.0)));
+        if (HW) {
+            // the two-wave form aims the raw candidate count at a target -- a candidate read in vain costs an under-occupied device nothing, idle
+            // candidate lanes do -- moving a fraction of the way per iteration
+            const double want = (double)P.hw_target / (double)(Craw > 0 ? Craw : 1);
+            seldt = w_uniform(dt_used * (1.0 + P.hw_gain * (((want < 2.0) ? want : 2.0) - 1.0)));
+        } else {
+            seldt = w_uniform(dt_used * (((int)Rc >= Craw) ? W_GROW : (((int)Rc + (int)W_SLACK < Craw) ? W_SHRINK : 1.0)));
+        }
         WPHASE(4);
         // ---------------- commit the valid prefix
         const bool commit = ev && (uint32_t)lane < Rc;
@@ -1139,41 +1170,46 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
             if (!(rekey_by < Rc)) kp[i] = make_double2(key2, tp);  // (else a later accepted neighbour of this iteration re-bounds i: its pair)
             lbf[blk] = (rowmin < W_INF) ? p_enc(rowmin, tb, cand & 7u) : P_INFBITS;
         }
-        const bool gcommit = gact && ea < Rc;
         const uint64_t acc_c = accball & ((Rc < 64u) ? ((1ull << Rc) - 1ull) : ~0ull);
-        if (gcommit) {
-            if (mem) {
-                rj->g = gj;
-                rj->gd = gdj;
-                rj->tg = tpa;
-                kp[jm] = make_double2(keyj, tpa);  // (the bound of every member is computed now)
-            }
-            if (selfl) {
-                ria->x = xa;
-                ria->th = -th_ia;
-                ria->tx = txa;
-                ria->I = Ia;
-                ria->acc = acc_ia + 1;
-                ria->tacc = tpa;
-                if (evout) {
-                    const uint32_t rnk = (uint32_t)__popcll(acc_c & ((1ull << ea) - 1ull));
-                    pdmp_event e;
-                    e.t = tpa;
-                    e.i = (int64_t)ia;
-                    e.x = xa;
-                    e.theta = -th_ia;
-                    evout[ntrace0 + dnacc + rnk] = e;
+        auto commit_groups = [&](const GOut& o) {
+            const bool gcommit = o.gact && o.ea < Rc;
+            if (gcommit) {
+                TrRecP* const rj = rec + o.jm;
+                TrRecP* const ria = rec + o.ia;
+                if (o.mem) {
+                    rj->g = o.gj;
+                    rj->gd = o.gdj;
+                    rj->tg = o.tpa;
+                    kp[o.jm] = make_double2(o.keyj, o.tpa);  // (the bound of every member is computed now)
                 }
+                if (o.selfl) {
+                    ria->x = o.xa;
+                    ria->th = -o.th_ia;
+                    ria->tx = o.txa;
+                    ria->I = o.Ia;
+                    ria->acc = o.acc_ia + 1;
+                    ria->tacc = o.tpa;
+                    if (evout) {
+                        const uint32_t rnk = (uint32_t)__popcll(acc_c & ((1ull << o.ea) - 1ull));
+                        pdmp_event e;
+                        e.t = o.tpa;
+                        e.i = (int64_t)o.ia;
+                        e.x = o.xa;
+                        e.theta = -o.th_ia;
+                        evout[ntrace0 + dnacc + rnk] = e;
+                    }
+                }
+                if (gl == 0) lbf[o.blka] = (o.rowmin_a < W_INF) ? p_enc(o.rowmin_a, tb, o.cand_a) : P_INFBITS;  // (lane 0 of the group stores the bound)
             }
-            if (gl == wl_a) lbf[blka] = (rowmin_a < W_INF) ? p_enc(rowmin_a, tb, cand_a) : P_INFBITS;
-        }
+            return gcommit;
+        };
+        const bool gc0 = commit_groups(G0);
         W_ORDER();
         WPHASE(5);
         // ---------------- bounds of the blocks of re-bounded neighbours: lowered where the new key is below them (an LDS atomic minimum); a key
         // that ROSE leaves its block's bound stale low, which costs a look at the block later and nothing else
         {
-            const bool upd = gcommit && mem && (jm >> 3) != blka;
-            if (upd && keyj < W_INF) atomicMin(&lbf[jm >> 3], p_enc(keyj, tb, jm & 7u));
+            if (gc0 && G0.mem && (G0.jm >> 3) != G0.blka && G0.keyj < W_INF) atomicMin(&lbf[G0.jm >> 3], p_enc(G0.keyj, tb, G0.jm & 7u));
         }
         W_ORDER();
         WPHASE(6);
@@ -1266,10 +1302,9 @@ int launch_zz_local_trackp(const ZzRunParams& p, int64_t nchains, void* stream) 
     }
     if (p.helper_wave) {
         dim3 block2(128);
-        if (!(q.hw_grow > 1.0)) {  // (not set by pdmp_debug_set_helper_steering: the defaults)
-            q.hw_grow = W_GROW_HW;
-            q.hw_shrink = W_SHRINK_HW;
-            q.hw_slack = W_SLACK_HW;
+        if (!(q.hw_gain > 0.0)) {  // (not set by pdmp_debug_set_helper_steering: the defaults)
+            q.hw_gain = W_GAIN_HW;
+            q.hw_target = W_TARGET_HW;
             q.hw_ahead = W_PF_AHEAD;
         }
         if (lat) {

@@ -50,9 +50,9 @@ class Ensemble:
             self.debug_set_helper_wave(int(os.environ["PDMP_HELPER_WAVE"]))
         if os.environ.get("PDMP_LAUNCH_COUNT_LIMIT"):
             _lib.check(self._L.pdmp_debug_set_launch_count_limit(self._h, int(os.environ["PDMP_LAUNCH_COUNT_LIMIT"])))
-        if os.environ.get("PDMP_HELPER_STEER"):  # "grow,shrink,slack,ahead"
-            g_, s_, k_, a_ = os.environ["PDMP_HELPER_STEER"].split(",")
-            _lib.check(self._L.pdmp_debug_set_helper_steering(self._h, float(g_), float(s_), int(k_), float(a_)))
+        if os.environ.get("PDMP_HELPER_STEER"):  # "gain,target,ahead"
+            g_, k_, a_ = os.environ["PDMP_HELPER_STEER"].split(",")
+            _lib.check(self._L.pdmp_debug_set_helper_steering(self._h, float(g_), int(k_), float(a_)))
         if os.environ.get("PDMP_LG_ROWS"):
             _lib.check(self._L.pdmp_debug_set_logistic_rows(self._h, int(os.environ["PDMP_LG_ROWS"])))
         if os.environ.get("PDMP_SPEC_G2"):
