@@ -683,14 +683,19 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
             need_rebase = true;
         }
         const double own = isev ? c_km : W_INF;
+        // rank = the number of events with a smaller key: every lane compares its key with all of them, read from LDS one after the other (one
+        // address for the wave: a broadcast) -- three instructions per candidate where two v_readlane and the scalar moves behind them took five
+        KM[lane] = own;  // (KM is free here: the event slots are written into it only after the ranks are known)
+        W_ORDER();
         uint32_t rank = 0;
-        for (uint32_t m0 = 0; m0 < Cc; m0 += 4) {  // (lanes past the candidates hold +Inf: reading them changes nothing)
+        for (uint32_t m0 = 0; m0 < Cc; m0 += 8) {  // (lanes past the candidates hold +Inf: reading them changes nothing)
+            double km[8];
 #pragma unroll
-            for (uint32_t q = 0; q < 4; ++q) {
-                const double km = w_readlane(own, (int)(m0 + q));
-                rank += (km < own) ? 1u : 0u;
-            }
+            for (uint32_t q = 0; q < 8; ++q) km[q] = KM[m0 + q];
+#pragma unroll
+            for (uint32_t q = 0; q < 8; ++q) rank += (km[q] < own) ? 1u : 0u;
         }
+        W_ORDER();
         const uint64_t evb = __ballot(isev);
         int nev = __popcll(evb);
         // exactly equal keys among the events (probability zero unless keys are tied by construction) give equal ranks -- ranks count the strictly
