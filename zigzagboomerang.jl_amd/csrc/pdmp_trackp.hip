@@ -239,6 +239,13 @@ struct WCtl {  // (HW) written by one wave, polled by the other: DS operations o
     uint32_t pad;
     double pf_tau, pf_dt, pf_tb;  // main: end and length of the current window, base of the level-1 bounds (what the helper prefetches against)
 };
+// The control words are reached through an LDS-qualified pointer: a volatile access through a generic pointer compiles to FLAT loads and stores
+// with system-scope bits, each followed by s_waitcnt vmcnt(0) -- the poll at the head of every iteration then waits for every global store of
+// the commit before it (read off the ISA in round 5).  With the address space stated they are ds_read / ds_write under lgkmcnt alone.
+typedef volatile __attribute__((address_space(3))) WCtl* WCtlPtr;
+__device__ __forceinline__ WCtlPtr w_ctl(unsigned char* smem, uint32_t offset) {
+    return (WCtlPtr)(__attribute__((address_space(3))) unsigned char*)(smem + offset);
+}
 
 namespace {
 // is the 16-bit value v (given twice: v | v << 16) one of the eight halves of nb?
@@ -266,7 +273,7 @@ template <bool LAT>
 __device__ __forceinline__ void trackp_helper(const ZzRunParams& P, unsigned char* smem, const int lane, const int64_t chain, const uint64_t seed,
                                            const uint64_t nm0) {
     using L = WL<true, false>;
-    volatile WCtl* const ctl = reinterpret_cast<volatile WCtl*>(smem + L::CTL);
+    const WCtlPtr ctl = w_ctl(smem, L::CTL);
     double2* const ring = reinterpret_cast<double2*>(smem + L::RING);
     const uint4* const lb4 = reinterpret_cast<const uint4*>(smem + L::LB);
     const int64_t d = P.d;
@@ -371,7 +378,7 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
     uint4* const EVN = reinterpret_cast<uint4*>(smem + L::EVN);        // (HW, LAT = false only)
     uint4* const NB4 = reinterpret_cast<uint4*>(smem + L::NB);        // (LAT = false only)
     uint16_t* const NB16 = reinterpret_cast<uint16_t*>(smem + L::NB);
-    volatile WCtl* const ctl = reinterpret_cast<volatile WCtl*>(smem + L::CTL);                // (HW only)
+    const WCtlPtr ctl = w_ctl(smem, L::CTL);                                                   // (HW only)
     const double2* const ring = reinterpret_cast<const double2*>(smem + L::RING);              // (HW only)
 
     TrRecP* const rec = reinterpret_cast<TrRecP*>(P.rec) + chain * d;
