@@ -456,8 +456,14 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
     uint64_t ph_t0 = PROF ? (uint64_t)__builtin_readcyclecounter() : 0;
     uint64_t ph_rounds = 0, ph_guess = 0;
     uint64_t ph_iters = 0, ph_raw = 0, ph_zone = 0, ph_eval = 0;  // candidates: selected, after the zone cut, after the window and accept limits
+#ifdef PDMP_PHASE_MARKS  // (ISA reading: a comment line per phase boundary in the assembly of the non-profiling instantiations)
+#define WMARK(k) asm volatile("; WPHASE " #k)
+#else
+#define WMARK(k)
+#endif
 #define WPHASE(k)                                                         \
     do {                                                                  \
+        WMARK(k);                                                         \
         if (PROF) {                                                       \
             const uint64_t now_ = (uint64_t)__builtin_readcyclecounter(); \
             ph[k] += now_ - ph_t0;                                        \
@@ -748,6 +754,10 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
         if (PROF) ph_iters += 1;
         if (PROF) ph_raw += (uint64_t)Cc;
         const int Craw = (int)Cc;
+        // (the candidates' record loads are named here, before the first branch that can leave the iteration: hipcc's structured control flow has
+        // edges from the idle path below to the loop's latch that no wave ever takes, and a load still in flight along one of them put
+        // s_waitcnt vmcnt(0) at the loop's head and latch -- where it waits for the COMMIT'S STORES of every iteration: read off the ISA in round 5)
+        asm volatile("" ::"v"(c_th), "v"(c_g), "v"(c_gd), "v"(c_tg), "v"(c_c2.x), "v"(c_c2.y), "v"(c_nb.x));
         if (C == 0) {
             // nothing to do in this window (stale bounds refreshed, a wrong position fixed, or no key before T)
             if (tau_clipped && !crowded && __ballot(isc && c_km <= tau) == 0) break;  // stop_before: every key is at or beyond T
@@ -1052,7 +1062,8 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
             double xa = ria->x, txa = ria->tx, Ia = ria->I;
             const uint64_t acc_ia = ria->acc;
             const double thj0 = rj->th, gj0 = rj->g, gdj0 = rj->gd, tgj = rj->tg;
-            const double2 cjm2 = *reinterpret_cast<const double2*>(&rj->c);
+            double2 cjm2 = *reinterpret_cast<const double2*>(&rj->c);
+            asm volatile("" : "+v"(cjm2.x), "+v"(cjm2.y));  // (one 16-byte load with the others: hipcc sank the second half under the select below, a dependent round trip)
             const double resta_b = w_shfl(rest, ea);  // the accepted event's block without it, and where that minimum sits
             const uint32_t rarga_b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ea << 2), (int)rarg);
             // ---------------- ONE evaluation of the new bound and key per lane (logarithm, two divisions, square root): the re-bound of a
@@ -1103,6 +1114,9 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
             const uint32_t cand_a = restwins ? (rarga_b & 7u) : (jwin & 7u);
             const double keymin = w_grp8_min(keyj);
             if (gact && gl == 0) EX[ea] = w_min(rowmin_a, keymin);
+            // (the reflecting coordinate's fields are used under lane masks only: named here, or the path around the commit carries their loads to
+            // the loop's head, where the wait for them is a wait for the commit's stores)
+            asm volatile("" ::"v"(xa), "v"(txa), "v"(Ia), "v"(acc_ia));
             o.gact = gact;
             o.mem = mem;
             o.selfl = selfl;
