@@ -169,8 +169,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 
     uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t ph_t0 = PROF ? (uint64_t)__builtin_readcyclecounter() : 0;
+#ifdef PDMP_PHASE_MARKS  // (ISA reading: a comment line per phase boundary in the assembly)
+#define LMARK(k) asm volatile("; LPHASE " #k)
+#else
+#define LMARK(k)
+#endif
 #define LPHASE(k)                                                         \
     do {                                                                  \
+        LMARK(k);                                                         \
         if (PROF) {                                                       \
             const uint64_t now_ = (uint64_t)__builtin_readcyclecounter(); \
             ph[k] += now_ - ph_t0;                                        \
@@ -492,6 +498,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             g = prior - s;
         }
         LPHASE(2);
+        // (every load of the iteration is named here, before the first branch that can reach the loop's latch: hipcc's structured control flow has
+        // edges no wave takes, and a load still in flight along one of them puts s_waitcnt vmcnt(0) at the loop's head -- a wait for this iteration's
+        // STORES: round 5, read off the ISA of the tracked lattice kernel first)
+        asm volatile("" ::"v"(c_i), "v"(gmu_i), "v"(told_i), "v"(a_i), "v"(b_i), "v"(acc_i), "v"(jm), "v"(wm), "v"(trk_i.x), "v"(trk_i.y), "v"(trk_i.z));
         const double th_i = xt[i].y;
         const double l_rate = l_pos(g * th_i);                   // :119
         const double lbound = l_pos(a_i + b_i * (tp - told_i));  // :119
@@ -506,11 +516,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             }
             const double a = c_i + (s1r - gmu_i) * th_i;  // src/fact_samplers.jl:51
             const double b = c_i / 100 + th_i * s2r;      // :52
-            // The new bound goes out BEFORE the event time is worked out (70 instructions): the loop's head waits for every memory operation in
-            // flight (s_waitcnt vmcnt(0): on some path of the control-flow graph a load is still pending, as far as the compiler can tell), these
-            // stores included -- the earlier they leave, the less of their way to the L2 is waited for there.  Every load of this iteration has
-            // been used by now; saying so keeps the compiler from putting a wait of its own between the stores.
-            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+            // (the new bound goes out before the event time is worked out: 70 instructions of the stores' way to the L2)
             if (lane == 0) {
                 ZzRec* r = rec + i;
                 r->t_old = tp;
