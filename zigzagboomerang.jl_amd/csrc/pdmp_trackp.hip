@@ -914,7 +914,35 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
         // ---------------- zones.  Only an ACCEPTED event m disturbs a later event r: within lattice distance 1 it changes r's sums (r's outcome
         // above is then garbage), at distance 2 the two share a neighbour, which matters only if r is accepted too.  A rejected event writes its
         // own (key, time) pair and nothing else.  The list ends at the first disturbed event (everything before it is unaffected).
-        if (LAT) {
+        if (LAT && HW) {
+            // every event lane looks at all accepted events at once: they (<= W_AMAX of them inside the list) put (row, column, event) into LDS,
+            // eight words that every lane reads back -- no walk over the accepted events on the scalar unit (a readlane, a ballot and the
+            // scalar moves between them per event: ~300 cycles each for a wave alone on its SIMD)
+            uint32_t* const ZA = reinterpret_cast<uint32_t*>(smem + L::NB);  // (the ids' room of the LAT = false instantiation)
+            const uint64_t ab = __ballot(acc) & ((C < 64) ? ((1ull << C) - 1ull) : ~0ull);
+            if (lane < W_AMAX) ZA[lane] = 0x00fffefeu;  // (an empty slot: event 255 -- behind every lane, so it disturbs none, and a key it claims is stored by its lane all the same)
+            W_ORDER();
+            if (acc && lane < C)
+                ZA[__builtin_amdgcn_mbcnt_hi((uint32_t)(ab >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ab, 0u))] = rc_i | ((uint32_t)lane << 16);
+            W_ORDER();
+            const uint4 z0 = reinterpret_cast<const uint4*>(ZA)[0], z1 = reinterpret_cast<const uint4*>(ZA)[1];
+            const uint32_t zz[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
+            bool conf = false;
+#pragma unroll
+            for (int q = 0; q < W_AMAX; ++q) {
+                const uint32_t m = zz[q] >> 16;
+                const uint32_t sad = __builtin_amdgcn_sad_u8(rc_i, zz[q] & 0xffffu, 0u);
+                conf = conf || (((uint32_t)lane > m) && (sad <= 1u || (sad <= 2u && acc)));
+                // an EARLIER rejected event next to accepted event m: m's group writes that coordinate's new key after it
+                if (sad <= 1u && (uint32_t)lane < m && m < rekey_by) rekey_by = m;
+            }
+            const uint64_t cb = __ballot(conf) & ((C < 64) ? ((1ull << C) - 1ull) : ~0ull);
+            if (cb) {
+                const int c0 = __ffsll((unsigned long long)cb) - 1;
+                C = (c0 < C) ? c0 : C;
+            }
+        } else if (LAT) {
+            // (with several waves on the SIMD the walk over the accepted events costs less than eight tests per lane: A/B at 2048 chains, round 5)
             uint64_t confb = 0;
             uint64_t ab = __ballot(acc) & ((C < 64) ? ((1ull << C) - 1ull) : ~0ull);
             while (ab) {
@@ -1159,26 +1187,22 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
             const uint32_t r_ok = bad ? (uint32_t)(__ffsll((unsigned long long)bad) - 1) : 64u;
             Rc = (r_ok < (uint32_t)C) ? r_ok : (uint32_t)C;
             if (vsel != (int)Rc) vsel = -1;  // the violating proposal counts only once everything before it is committed
-            // the trace's room and the end of the run (`while t′ < T` looks at accepted events only, :199)
+            // the trace's room and the end of the run (`while t′ < T` looks at accepted events only, :199): the first accepted event that fills
+            // the trace or reaches T ends the list behind it -- every event lane tests itself, two ballots (a walk over the accepted events on
+            // the scalar unit cost a lone wave ~100 cycles per event)
             const uint64_t accc = accball & ((Rc < 64u) ? ((1ull << Rc) - 1ull) : ~0ull);
-            uint64_t walk = accc;
-            uint32_t na = 0;
-            bool stopped = false;
-            while (walk && !stopped) {
-                const int r = __ffsll((unsigned long long)walk) - 1;
-                walk &= walk - 1;
-                na += 1;
-                if (P.trace_cap > 0 && dnacc + na >= trace_room) {
-                    status = PDMP_CHAIN_TRACE_FULL;
-                    stopped = true;
-                }
-                if (!stop_before && !(w_readlane(tp, r) < T)) {
-                    running = false;
-                    stopped = true;
-                }
-                if (stopped) Rc = (uint32_t)r + 1u;
+            const bool isacc_c = ((accc >> lane) & 1ull) != 0ull;
+            const uint32_t na_l = __builtin_amdgcn_mbcnt_hi((uint32_t)(accc >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)accc, 0u)) + 1u;  // accepted events up to this one
+            const uint64_t fullb = __ballot(isacc_c && P.trace_cap > 0 && dnacc + na_l >= trace_room);
+            const uint64_t endb = __ballot(isacc_c && !stop_before && !(tp < T));
+            const uint64_t stopb = fullb | endb;
+            if (stopb) {
+                const int r = __ffsll((unsigned long long)stopb) - 1;
+                if ((fullb >> r) & 1ull) status = PDMP_CHAIN_TRACE_FULL;
+                if ((endb >> r) & 1ull) running = false;
+                Rc = (uint32_t)r + 1u;
+                vsel = -1;
             }
-            if (stopped) vsel = -1;
         }
         // steer the threshold so that the raw candidate list is just longer than what can commit
         if (HW) {
