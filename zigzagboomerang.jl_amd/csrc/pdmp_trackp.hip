@@ -226,6 +226,8 @@ constexpr int W_AMAX = 8;            // accepted events per iteration (one group
 // the step rule above with 1.1 / 0.95 / 20, and than a target of 56)
 #define W_TARGET_HW 48u
 #define W_GAIN_HW 0.3
+#define W_TARGET_1W 44u                // ... of the one-wave forms where they use a target (56 candidate lanes, a window of 128 draws)
+#define W_TARGET_1W_MAX_CHAINS 3072    // ... which they do up to three chains per SIMD (256 CUs x 4 SIMDs)
 #define W_NHYP 8     // hypotheses of the accept chain's first guess, two-wave form (a draw is one LDS read)
 #define W_NHYP_1W 4  // ... single-wave form (a draw is two ds_bpermute pairs; A/B at 2048 chains: 4 is 0.6 % faster than none, 8 is 2 % slower)
 #define W_PF_AHEAD 1.0  // the helper wave requests the lines of every block within this many window lengths beyond the window (1, 2, 4 measured: 1)
@@ -1205,8 +1207,8 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
             }
         }
         // steer the threshold so that the raw candidate list is just longer than what can commit
-        if (HW) {
-            // the two-wave form aims the raw candidate count at a target -- a candidate read in vain costs an under-occupied device nothing, idle
+        if (HW || P.hw_target != 0u) {
+            // the two-wave form (and the one-wave forms of an under-occupied launch: hw_target set by the launcher) aims the raw candidate count at a target -- a candidate read in vain costs an under-occupied device nothing, idle
             // candidate lanes do -- moving a fraction of the way per iteration
             const double want = (double)P.hw_target / (double)(Craw > 0 ? Craw : 1);
             seldt = w_uniform(dt_used * (1.0 + P.hw_gain * (((want < 2.0) ? want : 2.0) - 1.0)));
@@ -1345,6 +1347,18 @@ int launch_zz_local_trackp(const ZzRunParams& p, int64_t nchains, void* stream) 
     ZzRunParams q = p;
     q.nblk = (uint32_t)((p.d + 7) / 8);  // (dk is a multiple of 64, the padding keys are +Inf)
     const bool lat = p.lattice_n != 0;
+    if (!p.helper_wave && !(q.hw_gain > 0.0)) {
+        // one-wave forms: the step rule (W_GROW / W_SHRINK / W_SLACK: few candidates read in vain) where the launch fills the device and the memory
+        // system is the other limit; a target count, as in the two-wave form, where it does not (at most three chains per SIMD, and always at
+        // d > 16384, where LDS admits one chain per SIMD): a chain's rate is then set by how much one iteration commits.  A/B in one session,
+        // round 5: 2048 chains 25.8 -> 22.0 ms, d = 65536 at 1024 chains 90.4 -> 80.4 ms; 4096 chains 46.6 -> 48.1 ms (so not there)
+        if (nchains <= W_TARGET_1W_MAX_CHAINS || p.d > (int64_t)WL<false>::NBLK * 8) {
+            q.hw_gain = W_GAIN_HW;
+            q.hw_target = W_TARGET_1W;
+        } else {
+            q.hw_target = 0u;
+        }
+    }
     if (p.d > (int64_t)WL<false>::NBLK * 8) {  // 8192 block bounds in LDS (the lattice only), one wave per chain
         if (p.dbg) hipLaunchKernelGGL((zz_local_trackp_big_kernel<true>), grid, block, W_BYTES_BIG, (hipStream_t)stream, q);
         else hipLaunchKernelGGL((zz_local_trackp_big_kernel<false>), grid, block, W_BYTES_BIG, (hipStream_t)stream, q);
