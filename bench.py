@@ -5,7 +5,10 @@ JSON line for BASELINE.json's other GPU configurations (their own metric, byte m
 Workload (BASELINE.json configs[2], the one `metric` is quoted on):
     Γ = 0.01 I + gridlaplacian(128,128)  (scripts/gridlaplace.jl:4-21, scripts/gaussianrandomfield.jl:15), d = 16384,
     ∇ϕ(x,i) = Γ[:,i]·x, Z = ZigZag(Γ, 0), c[i] = ‖Γ[:,i]‖₂, x0 ~ N(0,I), θ0 ∈ {±1}, t0 = 0, adapt = false,
-    4096 chains PER GPU (weak scaling: chains are independent, no data-path collective), Philox seeds 0x5EED0000 + chain.
+    ONE ensemble of 4096 chains: at N GPUs rank r runs chains [r 4096/N, (r+1) 4096/N) (strong scaling, the north star's form; chains are
+    independent, no data-path collective; `--scaling weak` keeps 4096 chains PER GPU), Philox seeds 0x5EED0000 + chain.  At N = 1 the line also
+    carries `strong_proxy` -- this GPU running the 2048 / 1024 / 512 chains that a rank of a 2 / 4 / 8-GPU job runs: the per-GPU term of the curve,
+    measured -- and `pipeline`: the same steps with their trace consumed on the device (streaming mean + discretize) beside the sampler.
 A "step" advances every chain by ΔT = 1.0 time units through pdmp_ensemble_run (one persistent kernel launch);
 the initial state is generated on the device, so inputs are resident in HBM when the timed region starts.
 Traces ARE written (32 B/event into a per-chain HBM segment, part of the algorithmic bytes) and recycled every step.

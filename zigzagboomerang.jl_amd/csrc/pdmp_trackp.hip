@@ -327,7 +327,13 @@ __device__ __forceinline__ void trackp_helper(const ZzRunParams& P, unsigned cha
                 const char* const kl = kpb + (size_t)(i >> 3) * 128;
                 const char* const rl = recb + (size_t)i * 128;
                 uint32_t a0 = *reinterpret_cast<const uint32_t*>(kl), a1 = *reinterpret_cast<const uint32_t*>(kl + 64);
+#ifdef PDMP_HW_NO_REC_PF
+                uint32_t a2 = 0, a3 = 0;
+                (void)rl;
+#else
                 uint32_t a2 = *reinterpret_cast<const uint32_t*>(rl), a3 = *reinterpret_cast<const uint32_t*>(rl + 64);
+#endif
+#ifndef PDMP_HW_NO_NBR_PF
                 if (LAT) {
                     const uint32_t col = __umulhi(i, nmagic), row = i - col * nlat;
                     const uint32_t nbr[4] = {col > 0u ? i - nlat : i, row > 0u ? i - 1u : i, row + 1u < nlat ? i + 1u : i, col + 1u < nlat ? i + nlat : i};
@@ -338,6 +344,7 @@ __device__ __forceinline__ void trackp_helper(const ZzRunParams& P, unsigned cha
                         a1 ^= *reinterpret_cast<const uint32_t*>(nl + 64);
                     }
                 }
+#endif
                 sink ^= a0 ^ a1 ^ a2 ^ a3;
             }
             asm volatile("" ::"v"(sink));
