@@ -73,9 +73,10 @@ struct DevBuf {
 }  // namespace
 
 // zz_local_trackp: ensembles of at most this many chains run the two-wave form (pdmp_trackp.hip).  Measured on C3 (profiles/r05_*): the helper
-// wave pays while a SIMD holds at most two waves with it.
+// wave pays as long as every chain is resident -- its 23 KB of LDS admit six chains per CU, 1536 on 256 CUs (1280 chains 17.9 against 21.3 ms for
+// one wave, 1536 chains 19.2 against 21.8; beyond, workgroups wait for a slot).
 #ifndef HELPER_WAVE_MAX_CHAINS
-#define HELPER_WAVE_MAX_CHAINS 1024
+#define HELPER_WAVE_MAX_CHAINS 1536
 #endif
 struct pdmp_ensemble {
     pdmp_config cfg{};

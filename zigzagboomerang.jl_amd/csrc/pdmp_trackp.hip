@@ -268,9 +268,11 @@ __device__ __forceinline__ uint32_t nb_count(const uint4 nb) {
 // The helper wave of the two-wave form (HW): wave 1 of the chain's workgroup.  It computes nothing the result depends on beyond the chain's
 // stream of uniforms, which it produces AHEAD of the main wave -- draw n of the launch and its logarithm into slot n % W_NR of a ring in LDS, 64
 // per pass, as far as the main wave's published consumption leaves room -- and it requests the lines the main wave's NEXT windows will read
-// (every block whose level-1 bound lies within W_PF_AHEAD window lengths beyond the current window: its key line, the record its position bits
-// point at and, on the lattice, that coordinate's four neighbours' records), so that they are in the L2 when the main wave asks.  A request is
-// a load whose value is thrown away; what the helper reads of level 1 may be mid-update -- a wrong guess costs a line, never a result.
+// (every block whose level-1 bound lies within W_PF_AHEAD window lengths beyond the current window: its key line and the record its position bits
+// point at), so that they are in the L2 when the main wave asks.  A request is a load whose value is thrown away; what the helper reads of
+// level 1 may be mid-update -- a wrong guess costs a line, never a result.  (Until late in round 5 it also requested the four lattice neighbours'
+// records of every such coordinate -- used by the 18 % that are accepted: 3.5 x the algorithmic bytes, 5.75 TB/s at 1024 chains, where leaving them
+// out is worth 8 % and lets the two-wave form win up to the 1536 chains its LDS admits.)
 template <bool LAT>
 __device__ __forceinline__ void trackp_helper(const ZzRunParams& P, unsigned char* smem, const int lane, const int64_t chain, const uint64_t seed,
                                            const uint64_t nm0) {
@@ -279,7 +281,6 @@ __device__ __forceinline__ void trackp_helper(const ZzRunParams& P, unsigned cha
     double2* const ring = reinterpret_cast<double2*>(smem + L::RING);
     const uint4* const lb4 = reinterpret_cast<const uint4*>(smem + L::LB);
     const int64_t d = P.d;
-    const uint32_t nlat = (uint32_t)P.lattice_n, nmagic = P.lattice_magic;
     const char* const recb = reinterpret_cast<const char*>(reinterpret_cast<const TrRecP*>(P.rec) + chain * d);
     const char* const kpb = reinterpret_cast<const char*>(reinterpret_cast<const double2*>(P.keys) + chain * P.dk);
     uint16_t* const HPF = reinterpret_cast<uint16_t*>(smem + L::HPF);
@@ -327,24 +328,7 @@ __device__ __forceinline__ void trackp_helper(const ZzRunParams& P, unsigned cha
                 const char* const kl = kpb + (size_t)(i >> 3) * 128;
                 const char* const rl = recb + (size_t)i * 128;
                 uint32_t a0 = *reinterpret_cast<const uint32_t*>(kl), a1 = *reinterpret_cast<const uint32_t*>(kl + 64);
-#ifdef PDMP_HW_NO_REC_PF
-                uint32_t a2 = 0, a3 = 0;
-                (void)rl;
-#else
                 uint32_t a2 = *reinterpret_cast<const uint32_t*>(rl), a3 = *reinterpret_cast<const uint32_t*>(rl + 64);
-#endif
-#ifndef PDMP_HW_NO_NBR_PF
-                if (LAT) {
-                    const uint32_t col = __umulhi(i, nmagic), row = i - col * nlat;
-                    const uint32_t nbr[4] = {col > 0u ? i - nlat : i, row > 0u ? i - 1u : i, row + 1u < nlat ? i + 1u : i, col + 1u < nlat ? i + nlat : i};
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        const char* const nl = recb + (size_t)nbr[w] * 128;
-                        a0 ^= *reinterpret_cast<const uint32_t*>(nl);
-                        a1 ^= *reinterpret_cast<const uint32_t*>(nl + 64);
-                    }
-                }
-#endif
                 sink ^= a0 ^ a1 ^ a2 ^ a3;
             }
             asm volatile("" ::"v"(sink));
