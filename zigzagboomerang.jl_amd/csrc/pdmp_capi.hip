@@ -1442,7 +1442,7 @@ static pdmp_status ensemble_run_impl(pdmp_ensemble* e, double T, int flags, void
     const bool g16_ok = e->has_g8 && e->g8_gw == 16 && e->dbg_kernel == PDMP_DEBUG_KERNEL_AUTO && (P.flags & 0x100) && !phenv;
     const bool spec_ok = (e->use_spec || g16_ok) && dbg_cap == 0 && !P.has_refresh && !P.move_all && !sticky;
     const bool general_path = e->needs_general || e->target_kind == 1 || e->adaptscale || e->local_bound;
-    if (phenv && (spec_ok || general_path)) {
+    if (phenv && (spec_ok || general_path || e->track)) {  // (the tracked kernels take every d their layout serves: d = 65536 has no speculative kernel beside it)
         pdmp_status st3 = phbuf.alloc(16);
         if (st3 != PDMP_OK) return st3;
         HIP_TRY(hipMemsetAsync(phbuf.p, 0, 16 * sizeof(double), s));
