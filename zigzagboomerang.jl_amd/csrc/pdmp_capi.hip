@@ -72,11 +72,11 @@ struct DevBuf {
 
 }  // namespace
 
-// zz_local_trackp: ensembles of at most this many chains run the two-wave form (pdmp_trackp.hip).  Measured on C3 (profiles/r05_*): the helper
-// wave pays as long as every chain is resident -- its 23 KB of LDS admit six chains per CU, 1536 on 256 CUs (1280 chains 17.9 against 21.3 ms for
-// one wave, 1536 chains 19.2 against 21.8; beyond, workgroups wait for a slot).
-#ifndef HELPER_WAVE_MAX_CHAINS
-#define HELPER_WAVE_MAX_CHAINS 1536
+// zz_local_trackp: ensembles of at most this many chains PER COMPUTE UNIT run the two-wave form (pdmp_trackp.hip).  Measured on C3 (profiles/r05_*):
+// the helper wave pays as long as every chain is resident -- its 23 KB of LDS admit six chains per CU, 1536 on the MI355X's 256 CUs (1280 chains 17.9
+// against 21.3 ms for one wave, 1536 chains 19.2 against 21.8; beyond, workgroups wait for a slot).
+#ifndef HELPER_WAVE_MAX_CHAINS_PER_CU
+#define HELPER_WAVE_MAX_CHAINS_PER_CU 6
 #endif
 struct pdmp_ensemble {
     pdmp_config cfg{};
@@ -126,7 +126,8 @@ struct pdmp_ensemble {
     double dbg_hw_steer[3] = {0, 0, 0};  // pdmp_debug_set_helper_steering: gain, target, ahead (0: the kernel's defaults)
     uint32_t dbg_count_limit = 0;  // pdmp_debug_set_launch_count_limit (0: PDMP_LAUNCH_COUNT_LIMIT)
     int dbg_cons_overlap = -1;     // pdmp_debug_set_consumer_overlap: -1 by ensemble width, 0 the consumer runs between slices, 1 beside the next slice
-    int dbg_helper_wave = -1;      // zz_local_trackp: -1 = the two-wave form where the launch leaves SIMDs idle (HELPER_WAVE_MAX_CHAINS), 0 = never, 1 = always
+    int n_cu = 0;                  // compute units of the device (hipDeviceProp_t::multiProcessorCount)
+    int dbg_helper_wave = -1;      // zz_local_trackp: -1 = the two-wave form where the launch leaves SIMDs idle (HELPER_WAVE_MAX_CHAINS_PER_CU), 0 = never, 1 = always
     // tracked-gradient kernel (pdmp_ensemble_set_gradient_tracking)
     bool track_requested = false, track = false, track_two_sums = false;
     bool track_lg = false;     // tracked bounds under the logistic target (zz_logistic_lds_kernel<.., TRK>); d_trk holds (g, gd, tg) per coordinate
@@ -478,6 +479,7 @@ pdmp_status pdmp_ensemble_create(const pdmp_config* cfg, pdmp_ensemble** out) {
     HIP_TRY(hipSetDevice(cfg->device));
     pdmp_ensemble* e = new pdmp_ensemble();
     e->cfg = *cfg;
+    e->n_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&e->ev0) != hipSuccess || hipEventCreate(&e->ev1) != hipSuccess) {
         delete e;
@@ -1542,10 +1544,11 @@ static pdmp_status ensemble_run_impl(pdmp_ensemble* e, double T, int flags, void
                     if (hist[k] > hist[best]) best = k;
                 P.typ_extra = best > 0 ? best - 1u : 0u;
             }
+            P.n_cu = e->n_cu;
             P.hw_gain = e->dbg_hw_steer[0];
             P.hw_target = (uint32_t)e->dbg_hw_steer[1];
             P.hw_ahead = e->dbg_hw_steer[2];
-            P.helper_wave = (e->dbg_helper_wave == 1 || (e->dbg_helper_wave == -1 && e->cfg.nchains <= HELPER_WAVE_MAX_CHAINS)) ? 1 : 0;
+            P.helper_wave = (e->dbg_helper_wave == 1 || (e->dbg_helper_wave == -1 && e->cfg.nchains <= (int64_t)HELPER_WAVE_MAX_CHAINS_PER_CU * (e->n_cu > 0 ? e->n_cu : 256))) ? 1 : 0;
             if (e->cfg.d > 16384) P.helper_wave = 0;  // (8192 block bounds leave no LDS for the ring: zz_local_trackp_big_kernel, one wave per chain)
             e->last_kernel = e->cfg.d > 16384 ? "zz_local_trackp_big_kernel" : P.helper_wave ? (e->lattice_n ? "zz_local_trackp2_kernel" : "zz_local_trackp2_kernel<LAT=false>")
                                            : (e->lattice_n ? "zz_local_trackp_kernel" : "zz_local_trackp_kernel<LAT=false>");

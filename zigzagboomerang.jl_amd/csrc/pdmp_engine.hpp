@@ -160,6 +160,7 @@ struct ZzRunParams {
     uint32_t typ_extra;      // zz_local_trackp: the most frequent |G1[i]| − 1 (the accept chain's first guess; any value is correct)
     double hw_gain, hw_ahead;  // ... its steering of the selection threshold (gain towards a target count) and how far ahead the helper requests lines
     uint32_t hw_target;
+    int32_t n_cu;            // (host side) compute units of the device: the launchers' width thresholds are per CU (0: 256)
     int32_t helper_wave;     // zz_local_trackp: the two-wave form (a helper wave per chain: ring of draws + prefetch), for under-occupied launches
     int32_t lattice_n;       // n if the graph is the n x n 5-point lattice in column-major numbering (i = row + n col), else 0
     uint32_t lattice_magic;  // ceil(2^32 / n): column of i = umulhi(i, magic) for i < 2^16

@@ -227,7 +227,7 @@ constexpr int W_AMAX = 8;            // accepted events per iteration (one group
 #define W_TARGET_HW 48u
 #define W_GAIN_HW 0.3
 #define W_TARGET_1W 44u                // ... of the one-wave forms where they use a target (56 candidate lanes, a window of 128 draws)
-#define W_TARGET_1W_MAX_CHAINS 3072    // ... which they do up to three chains per SIMD (256 CUs x 4 SIMDs)
+#define W_TARGET_1W_MAX_PER_CU 12      // ... which they do up to three chains per SIMD (3072 chains on 256 CUs)
 #define W_NHYP 8     // hypotheses of the accept chain's first guess, two-wave form (a draw is one LDS read)
 #define W_NHYP_1W 4  // ... single-wave form (a draw is two ds_bpermute pairs; A/B at 2048 chains: 4 is 0.6 % faster than none, 8 is 2 % slower)
 #define W_PF_AHEAD 1.0  // the helper wave requests the lines of every block within this many window lengths beyond the window (1, 2, 4 measured: 1)
@@ -1343,7 +1343,7 @@ int launch_zz_local_trackp(const ZzRunParams& p, int64_t nchains, void* stream) 
         // system is the other limit; a target count, as in the two-wave form, where it does not (at most three chains per SIMD, and always at
         // d > 16384, where LDS admits one chain per SIMD): a chain's rate is then set by how much one iteration commits.  A/B in one session,
         // round 5: 2048 chains 25.8 -> 22.0 ms, d = 65536 at 1024 chains 90.4 -> 80.4 ms; 4096 chains 46.6 -> 48.1 ms (so not there)
-        if (nchains <= W_TARGET_1W_MAX_CHAINS || p.d > (int64_t)WL<false>::NBLK * 8) {
+        if (nchains <= (int64_t)W_TARGET_1W_MAX_PER_CU * (p.n_cu > 0 ? p.n_cu : 256) || p.d > (int64_t)WL<false>::NBLK * 8) {
             q.hw_gain = W_GAIN_HW;
             q.hw_target = W_TARGET_1W;
         } else {
