@@ -107,7 +107,7 @@ def cpu_baseline_config(pkg, config, budget_s=12.0):
             return r["nacc"]
         T1, what = 60.0, "chains of the subsampled logistic regression (n=8840, p=442)"
     else:
-        P = pkg.problems.spike_slab_logistic_problem(p=10_000, num_rows=2000)
+        P = pkg.problems.spike_slab_logistic_problem(p=10_000, num_rows=args.c5_rows)
         lg = dict(A=P["A"], At=P["At"], y=P["y"], ny=P["ny"], mu=P["mu"], gamma0=P["gamma0"], k=12)
 
         def one(k, T):
@@ -346,7 +346,7 @@ def make_workload(pkg, args, rank, local_rank):
                        f"+48 B per rejection, +{per_acc:.0f} B per accepted reflection (|G2|={g2bar:.1f}): SURVEY 8d3's model with this graph",
                  bytes=lambda w: per_prop * w["num"] + per_rej * (w["num"] - w["nacc"]) + per_acc * w["nacc"])
     elif args.config == "C5":
-        P = pkg.problems.spike_slab_logistic_problem(p=10_000, num_rows=2000)
+        P = pkg.problems.spike_slab_logistic_problem(p=10_000, num_rows=args.c5_rows)
         d = P["p"]
         ksub = 12
         cap = 0 if args.no_trace else int(30000 * dt) + 1024
@@ -376,7 +376,7 @@ def make_workload(pkg, args, rank, local_rank):
                           f"(scripts/exampledesign.jl), Gaussian slab gamma0={P['gamma0']}, kappa=(gamma0/sqrt(2pi))/(1/w-1) w={P['w']}, Z=ZigZag(I,mu), "
                           f"c=1, adapt (scripts/spikeandslab.jl:96-129), {nch} chains/GPU, step = advance all chains by dT={dt}",
                  model=f"per gradient evaluation {per_grad:.0f} B = {distinct:.0f} distinct coordinates moved once (40 B) + {ksub * rbar - distinct:.0f} "
-                       f"re-reads of an already moved coordinate (8 B) + ksub*r = {ksub * rbar:.0f} design entries streamed (12 B: 131 MB table) + 64 B "
+                       f"re-reads of an already moved coordinate (8 B) + ksub*r = {ksub * rbar:.0f} design entries streamed (12 B: {P['At'].nnz * 12 / 1e6:.0f} MB table) + 64 B "
                        f"(r={rbar:.0f} coefficients per sampled observation), + 96 B per trace event (record, bound, key, thaw clock)",
                  bytes=lambda w: per_grad * w["grads"] + 96.0 * w["nevents"])
     else:
@@ -639,6 +639,9 @@ def main():
                     help="C3 at N = 1: skip the `pipeline` object (the steps again with their trace consumed on the device beside the sampler)")
     ap.add_argument("--no-strong-proxy", action="store_true",
                     help="C3 at N = 1: skip the `strong_proxy` object (this GPU's share of the 2 / 4 / 8-GPU strong-scaling job, timed after the region)")
+    ap.add_argument("--c5-rows", type=int, default=2000,
+                    help="C5: rows of the design the gradient subsamples from (the script's 50 000 rows at 10^4 columns would be 2.7e10 stored entries; the work "
+                         "per proposal depends on k_sub and the row length, not on it -- 10000 rows = a 655 MB table, beyond the MALL, checks that: DESIGN 5)")
     ap.add_argument("--grid", type=int, default=GRID)
     ap.add_argument("--dt", type=float, default=None, help="process time per step (default: the configuration's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
