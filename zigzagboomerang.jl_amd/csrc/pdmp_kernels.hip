@@ -3909,7 +3909,7 @@ __global__ __launch_bounds__(256) void zz_track_unpack_kernel(const TrRec* rec0,
     const uint32_t s0 = tb.sptr[i], s1 = tb.sptr[i + 1];
     for (uint32_t p = s0; p < s1; ++p) {  // S[i] = G1[i] followed by G2[i]; the patterns are symmetric: j ∈ S[i] <=> i ∈ S[j]
         const uint32_t j = tb.sidx[p];
-        const double tpj = kp ? kp[j].y : rec[j].tprop, taj = rec[j].tacc;
+        const double tpj = kp ? kp[j].y : rec[j].tprop, taj = kp ? rec[j].tx : rec[j].tacc;  // (pair layout: the last accept's time is the position's clock)
         if (p - s0 < k && tpj > tr) tr = tpj;
         if (taj > tr) tr = taj;
     }

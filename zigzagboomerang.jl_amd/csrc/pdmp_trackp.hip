@@ -1231,7 +1231,8 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
                     ria->tx = o.txa;
                     ria->I = o.Ia;
                     ria->acc = o.acc_ia + 1;
-                    ria->tacc = o.tpa;
+                    // (the time of i's last accept IS its position's clock tx in this layout -- x_i is brought up on i's accepts only --: a store into
+                    // the line's fourth sector, dirty for nothing else, went with it; zz_track_unpack_kernel reads tx)
                     if (evout) {
                         const uint32_t rnk = (uint32_t)__popcll(acc_c & ((1ull << o.ea) - 1ull));
                         pdmp_event e;
