@@ -219,9 +219,11 @@ constexpr uint32_t W_BYTES_1W = WL<false>::BYTES, W_BYTES_BIG = WL<false, true>:
 constexpr uint32_t W_BYTES_HW = WL<true>::BYTES;  // 23 008 bytes: 6 chains per CU (the two-wave form runs at most 4)
 constexpr int W_AMAX = 8;            // accepted events per iteration (one group each)
 // steering of the selection threshold (measured: 1.15 / 0.8 / 3 -- pdmp_trackx.hip's -- is 3.5 % slower here, where every candidate's line is read)
+#ifndef W_GROW
 #define W_GROW 1.02
 #define W_SHRINK 0.98
 #define W_SLACK 5u
+#endif
 // ... of the two-wave form: the raw candidate count is steered towards a target, by a gain (A/B at 512 / 1024 chains: 48 at 0.3 is 3 % faster than
 // the step rule above with 1.1 / 0.95 / 20, and than a target of 56)
 #define W_TARGET_HW 48u
