@@ -520,7 +520,7 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
         bool stalled = false, finished = false;
         double dt_used = 0.0;
         uint32_t Cc = 0;
-        double tau = 0.0;
+        double tau = 0.0, mql_sel = 0.0;  // the window's end and the lower bound of the next event time it starts from
         bool tau_clipped = false;
         {
             // lane's entries: in chunk c (2048 block bounds), blocks 2048 c + 4 (lane + 64 j) + 0..3, j < 8 (one 16-byte read each).  One chunk
@@ -621,6 +621,7 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
                     }
                 }
                 dt_used = dt_sel;
+                mql_sel = mql;
             }
         }
         if (stalled) {
@@ -691,32 +692,67 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
             need_rebase = true;
         }
         const double own = isev ? c_km : W_INF;
-        // rank = the number of events with a smaller key: every lane compares its key with all of them, read from LDS one after the other (one
-        // address for the wave: a broadcast) -- three instructions per candidate where two v_readlane and the scalar moves behind them took five
-        KM[lane] = own;  // (KM is free here: the event slots are written into it only after the ranks are known)
-        W_ORDER();
-        uint32_t rank = 0;
-        for (uint32_t m0 = 0; m0 < Cc; m0 += 8) {  // (lanes past the candidates hold +Inf: reading them changes nothing)
-            double km[8];
-#pragma unroll
-            for (uint32_t q = 0; q < 8; ++q) km[q] = KM[m0 + q];
-#pragma unroll
-            for (uint32_t q = 0; q < 8; ++q) rank += (km[q] < own) ? 1u : 0u;
-        }
-        W_ORDER();
+        // rank = the number of events with a smaller key.  First on 15-bit images of the keys -- (key − front) scaled so that the window maps onto
+        // 0 .. 32766, a monotone map: distinct images order like their keys -- two candidates per packed instruction (a 16-bit difference, its sign
+        // bit, a 16-bit add) from one 128-byte table that every lane reads whole; candidates that are no events hold 32767.  Two events with one
+        // image give equal ranks, the ranks' sum falls short of 0 + 1 + .. + (nev − 1), and the exact comparison below takes over (about one
+        // iteration in fifty at 48 candidates); it is also what tells exactly tied keys.
         const uint64_t evb = __ballot(isev);
         int nev = __popcll(evb);
+        uint32_t rank = 0, rsum = 0xffffffffu;
+        if (tau > mql_sel) {
+            uint16_t* const QK = TB;  // (the candidates' blocks are in registers by now)
+            const double scale = 32766.0 * __builtin_amdgcn_rcp(tau - mql_sel);
+            const double img = (own - mql_sel) * scale;
+            const uint32_t qi = isev ? (uint32_t)w_pos(img) : 32767u;
+            const uint32_t qk = isev ? ((qi < 32766u) ? qi : 32766u) : 32767u;
+            QK[lane] = (uint16_t)qk;
+            W_ORDER();
+            typedef short pk16 __attribute__((ext_vector_type(2)));
+            typedef unsigned short upk16 __attribute__((ext_vector_type(2)));
+            const pk16 own2 = {(short)qk, (short)qk};
+            upk16 cnt = {0, 0};
+            const uint4* const QK4 = reinterpret_cast<const uint4*>(QK);
+#pragma unroll
+            for (uint32_t h = 0; h < 2u; ++h) {
+                if (h == 0u || Cc > 32u) {  // (wave-uniform; 32 candidates per batch of four 16-byte reads issued together: slots past the candidates hold 32767)
+                    const uint4 w0 = QK4[4u * h + 0u], w1 = QK4[4u * h + 1u], w2 = QK4[4u * h + 2u], w3 = QK4[4u * h + 3u];
+                    const uint32_t ww[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const pk16 k2 = __builtin_bit_cast(pk16, ww[q]);
+                        const pk16 df = k2 - own2;  // (< 0 where the candidate's image is smaller: both are below 2^15)
+                        cnt += __builtin_bit_cast(upk16, df) >> (unsigned short)15;
+                    }
+                }
+            }
+            rank = (uint32_t)cnt.x + (uint32_t)cnt.y;
+            W_ORDER();
+            rsum = (uint32_t)__builtin_amdgcn_readlane((int)w_scan_add_u32(isev ? rank : 0u), 63);
+        }
+        if (rsum != (uint32_t)(nev * (nev - 1) / 2)) {
+            // every lane compares its key with all of them, read from LDS one after the other (one address for the wave: a broadcast)
+            KM[lane] = own;  // (KM is free here: the event slots are written into it only after the ranks are known)
+            W_ORDER();
+            rank = 0;
+            for (uint32_t m0 = 0; m0 < Cc; m0 += 8) {  // (lanes past the candidates hold +Inf: reading them changes nothing)
+                double km[8];
+#pragma unroll
+                for (uint32_t q = 0; q < 8; ++q) km[q] = KM[m0 + q];
+#pragma unroll
+                for (uint32_t q = 0; q < 8; ++q) rank += (km[q] < own) ? 1u : 0u;
+            }
+            W_ORDER();
+            rsum = (uint32_t)__builtin_amdgcn_readlane((int)w_scan_add_u32(isev ? rank : 0u), 63);
+        }
         // exactly equal keys among the events (probability zero unless keys are tied by construction) give equal ranks -- ranks count the strictly
         // smaller keys, so their sum then falls short of 0 + 1 + .. + (nev − 1): one event this iteration, the tied minimum of the lowest block
         bool slot = isev;  // this lane's candidate takes event slot `rank`
-        {
-            const uint32_t rsum = (uint32_t)__builtin_amdgcn_readlane((int)w_scan_add_u32(isev ? rank : 0u), 63);
-            if (rsum != (uint32_t)(nev * (nev - 1) / 2)) {
-                const double mn = w_wave_min(own);
-                const uint32_t bsel = w_wave_min_u32((isev && own == mn) ? cblk : 0xffffffffu);
-                slot = isev && cblk == bsel;  // (rank 0: nothing is smaller than the minimum)
-                nev = 1;
-            }
+        if (rsum != (uint32_t)(nev * (nev - 1) / 2)) {
+            const double mn = w_wave_min(own);
+            const uint32_t bsel = w_wave_min_u32((isev && own == mn) ? cblk : 0xffffffffu);
+            slot = isev && cblk == bsel;  // (rank 0: nothing is smaller than the minimum)
+            nev = 1;
         }
         // a candidate whose record was requested at the wrong position ends the list at its rank
         {
