@@ -196,27 +196,22 @@ struct WL {
     static constexpr uint32_t NBLK = BIG ? 8192 : 2048;    // key blocks of 8 a chain may have: d <= 16384, or (BIG, round 5) d <= 65536
     static constexpr uint32_t XO = (NBLK - 2048) * 4;      // (everything behind the bounds moves up by what they take more)
     static constexpr uint32_t LB = 0;                      // [NBLK] u32 lower bounds of the block minima (+ argument position), key blocks of 8
-    static constexpr uint32_t EX = XO + 8192;              // [64] f64 what event e exposes; before that the exact block minima of the candidates
-    static constexpr uint32_t RS = XO + 8704;              // [CMAX] f64 candidates: block minimum without the argument
-    static constexpr uint32_t TP = XO + (HW ? 9216 : 9152);   // [CMAX] f64 candidates: proposal time stored with the argument
+    static constexpr uint32_t EX = XO + 8192;              // [64] f64 what event e exposes; before that the candidates' keys where the ranks need them exactly
+    // (XO + 8704 .. SLB: the candidate / event slots of the forms before the record was pushed from lane to lane: free)
     static constexpr uint32_t SLB = XO + (HW ? 9792 : 9664);  // [64] u16 event blocks, rank order
     static constexpr uint32_t TB = XO + (HW ? 9920 : 9792);   // [64] u16 candidate blocks, compaction order
     static constexpr uint32_t ACL = XO + (HW ? 10048 : 9920); // [8] u16 the accepted events
-    static constexpr uint32_t RO = XO + (HW ? 10064 : 9936);  // [64] u8 candidate of each rank
     static constexpr uint32_t NB = XO + (HW ? 10144 : 10016); // (LAT = false) [8][8] u16 G1 of the accepted events, in event order
     static constexpr uint32_t CTL = 10272;                 // (HW) control words shared by the two waves (struct WCtl)
     static constexpr uint32_t HPF = 10336;                 // (HW) [64] u16 the helper wave's list of coordinates whose lines it requests
     static constexpr uint32_t RING = 10464;                // (HW) [W_NR] (u, log u): draw n of the launch at slot n % W_NR
-    static constexpr uint32_t EVD = 18656;                 // (HW) [6][64] f64 event slots, by rank: th, g, gd, tg, c, c/100 of the event's coordinate
-    static constexpr uint32_t EVU = 21728;                 // (HW) [64] u32 event slots: block | position bits << 16
-    static constexpr uint32_t EVN = 21984;                 // (HW, LAT = false) [64] 8 x u16 event slots: G1 of the event's coordinate
     static constexpr int CMAX = HW ? 64 : 56;              // candidates per iteration (block-scan passes of 8)
     static constexpr uint32_t WIN = HW ? 256u : 128u;      // draws an iteration may consume (single wave: two per lane in registers)
-    static constexpr uint32_t BYTES = HW ? EVN + 64 * 16 : NB + 128;  // dynamic LDS of a chain
+    static constexpr uint32_t BYTES = HW ? RING + 512 * 16 : NB + 128;  // dynamic LDS of a chain
 };
 constexpr uint32_t W_NR = 512;  // (HW) ring slots
 constexpr uint32_t W_BYTES_1W = WL<false>::BYTES, W_BYTES_BIG = WL<false, true>::BYTES;
-constexpr uint32_t W_BYTES_HW = WL<true>::BYTES;  // 23 008 bytes: 6 chains per CU (the two-wave form runs at most 4)
+constexpr uint32_t W_BYTES_HW = WL<true>::BYTES;  // 18 656 bytes: 8 chains per CU
 constexpr int W_AMAX = 8;            // accepted events per iteration (one group each)
 // steering of the selection threshold (measured: 1.15 / 0.8 / 3 -- pdmp_trackx.hip's -- is 3.5 % slower here, where every candidate's line is read)
 #ifndef W_GROW
@@ -235,7 +230,7 @@ constexpr int W_AMAX = 8;            // accepted events per iteration (one group
 #define W_PF_AHEAD 1.0  // the helper wave requests the lines of every block within this many window lengths beyond the window (1, 2, 4 measured: 1)
 static_assert(WL<false>::BYTES <= 10240, "16 chains per CU: 160 KB / 16");
 static_assert(WL<false, true>::BYTES <= 40960, "d <= 65536: 4 chains per CU (one per SIMD), 160 KB / 4");
-static_assert(WL<true>::EVD == WL<true>::RING + W_NR * 16 && W_BYTES_HW <= 26624, "6 chains per CU: 160 KB / 6");
+static_assert(W_BYTES_HW == WL<true>::RING + W_NR * 16 && W_BYTES_HW <= 20480, "8 chains per CU: 160 KB / 8");
 struct WCtl {  // (HW) written by one wave, polled by the other: DS operations of a wave execute in order, so data written before a word is visible with it
     uint32_t filled;    // helper: draws [0, filled) of the launch are in the ring
     uint32_t consumed;  // main: draws [0, consumed) are used up (their slots may be overwritten)
@@ -362,15 +357,9 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
     uint32_t* const lbf = reinterpret_cast<uint32_t*>(smem + L::LB);
     double* const EX = reinterpret_cast<double*>(smem + L::EX);
     double* const KM = EX;  // (exact block minima of the candidates, until the events are set up)
-    double* const RS = reinterpret_cast<double*>(smem + L::RS);
-    double* const TPR = reinterpret_cast<double*>(smem + L::TP);
     uint16_t* const SLB = reinterpret_cast<uint16_t*>(smem + L::SLB);
     uint16_t* const TB = reinterpret_cast<uint16_t*>(smem + L::TB);
     uint16_t* const ACL = reinterpret_cast<uint16_t*>(smem + L::ACL);
-    uint8_t* const RO = reinterpret_cast<uint8_t*>(smem + L::RO);
-    double* const EVD = reinterpret_cast<double*>(smem + L::EVD);      // (HW only)
-    uint32_t* const EVU = reinterpret_cast<uint32_t*>(smem + L::EVU);  // (HW only)
-    uint4* const EVN = reinterpret_cast<uint4*>(smem + L::EVN);        // (HW, LAT = false only)
     uint4* const NB4 = reinterpret_cast<uint4*>(smem + L::NB);        // (LAT = false only)
     uint16_t* const NB16 = reinterpret_cast<uint16_t*>(smem + L::NB);
     const WCtlPtr ctl = w_ctl(smem, L::CTL);                                                   // (HW only)
@@ -760,25 +749,21 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
             const uint32_t wr = w_wave_min_u32(wrongpos ? rank : 0xffffffffu);
             if (wr < (uint32_t)nev) nev = (int)wr;
         }
-        // ---------------- lane r = event r: everything moves over from its candidate's lane -- written to slot `rank`, read from slot `lane` (HW: the
-        // whole record; else the candidate's lane number, and the record through ds_bpermute)
-        if (slot && rank < (uint32_t)nev) {
-            KM[rank] = c_km;
-            RS[rank] = c_rs;
-            TPR[rank] = c_tp;
-            if (HW) {
-                EVD[0 * 64 + rank] = c_th;
-                EVD[1 * 64 + rank] = c_g;
-                EVD[2 * 64 + rank] = c_gd;
-                EVD[3 * 64 + rank] = c_tg;
-                EVD[4 * 64 + rank] = c_c2.x;
-                EVD[5 * 64 + rank] = c_c2.y;
-                EVU[rank] = cblk | (c_pb << 16);
-                if (!LAT) EVN[rank] = c_nb;
-            } else {
-                RO[rank] = (uint8_t)lane;
-            }
-        }
+        // ---------------- lane r = event r: everything moves over from its candidate's lane, PUSHED to lane `rank` (ds_permute: one trip through the
+        // LDS crossbar, no LDS memory; until late in round 5 the record went through slots in LDS -- a write, a wait and a read, two trips -- or,
+        // in the one-wave form, was pulled by 14 ds_bpermute behind a table of source lanes).  A candidate that is no event of this iteration
+        // parks its words on lane 63, which is an event's lane only when all 64 candidates are events -- and then nobody parks.
+        const uint32_t pdst = ((slot && rank < (uint32_t)nev) ? rank : 63u) << 2;
+        auto push32 = [&](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_ds_permute((int)pdst, (int)v); };
+        auto push64 = [&](double v) -> double {
+            const int lo = __builtin_amdgcn_ds_permute((int)pdst, __double2loint(v)), hi = __builtin_amdgcn_ds_permute((int)pdst, __double2hiint(v));
+            return __hiloint2double(hi, lo);
+        };
+        const double e_km = push64(c_km), e_rs = push64(c_rs), e_tp = push64(c_tp);
+        const double e_th = push64(c_th), e_g = push64(c_g), e_gd = push64(c_gd), e_tg = push64(c_tg), e_c = push64(c_c2.x), e_c100 = push64(c_c2.y);
+        const uint32_t e_bu = push32(cblk | (c_pb << 16));
+        uint4 e_nb = make_uint4(~0u, ~0u, ~0u, ~0u);
+        if (!LAT) e_nb = make_uint4(push32(c_nb.x), push32(c_nb.y), push32(c_nb.z), push32(c_nb.w));
         W_ORDER();
         WPHASE(9);
         C = nev;
@@ -800,39 +785,13 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
             continue;
         }
         bool ev = lane < C;
-        const double tp = ev ? KM[lane] : W_INF;  // the event time: the exact block minimum
-        const double rest = ev ? RS[lane] : W_INF;
-        const double tprop_i = ev ? TPR[lane] : 0.0;
-        uint32_t blk, pbe;
-        double th, g_i, gd_i, tg_i;
-        double2 c_i2;
-        uint4 nb_i = make_uint4(~0u, ~0u, ~0u, ~0u);
-        if (HW) {
-            const uint32_t bu = EVU[lane];
-            blk = bu & 0xffffu;
-            pbe = bu >> 16;
-            th = EVD[0 * 64 + lane];
-            g_i = EVD[1 * 64 + lane];
-            gd_i = EVD[2 * 64 + lane];
-            tg_i = EVD[3 * 64 + lane];
-            c_i2 = make_double2(EVD[4 * 64 + lane], EVD[5 * 64 + lane]);
-            if (!LAT) nb_i = EVN[lane];
-        } else {
-            const uint32_t src = ev ? (uint32_t)RO[lane] : 0u;
-            blk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)cblk);
-            pbe = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)c_pb);
-            th = w_shfl(c_th, src);
-            g_i = w_shfl(c_g, src);
-            gd_i = w_shfl(c_gd, src);
-            tg_i = w_shfl(c_tg, src);
-            c_i2 = make_double2(w_shfl(c_c2.x, src), w_shfl(c_c2.y, src));
-            if (!LAT) {
-                nb_i.x = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)c_nb.x);
-                nb_i.y = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)c_nb.y);
-                nb_i.z = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)c_nb.z);
-                nb_i.w = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)c_nb.w);
-            }
-        }
+        const double tp = ev ? e_km : W_INF;  // the event time: the exact block minimum
+        const double rest = ev ? e_rs : W_INF;
+        const double tprop_i = ev ? e_tp : 0.0;
+        const uint32_t blk = e_bu & 0xffffu, pbe = e_bu >> 16;
+        const double th = e_th, g_i = e_g, gd_i = e_gd, tg_i = e_tg;
+        const double2 c_i2 = make_double2(e_c, e_c100);
+        const uint4 nb_i = LAT ? make_uint4(~0u, ~0u, ~0u, ~0u) : e_nb;
         const uint32_t i = ev ? (blk * 8u + (pbe & 7u)) : 0u;
         const uint32_t rarg = blk * 8u + (pbe >> 4);
         const double c_i = c_i2.x;
@@ -1359,7 +1318,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 // round trips and nothing else runs beside it.  Same committed sequence, same floats (same draws, same pdmp_log, same arithmetic in the same
 // lanes): only who computes a uniform and when a line is requested differ.
 template <bool PROF, bool LAT>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 4))) void zz_local_trackp2_kernel(ZzRunParams P) {
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void zz_local_trackp2_kernel(ZzRunParams P) {
     trackp_body<PROF, LAT, true, false>(P);
 }
 
