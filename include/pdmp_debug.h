@@ -38,7 +38,7 @@ pdmp_status pdmp_debug_phase_profile(pdmp_ensemble* ens, double* out16, int* kin
 pdmp_status pdmp_debug_set_track_groups(pdmp_ensemble* ens, int which);
 /* zz_local_trackp_kernel / zz_local_trackp2_kernel: the two-wave form gives every chain a helper wavefront (the chain's uniforms and their
  * logarithms produced ahead into a ring in LDS, the next windows' lines requested early); same committed sequence and floats.  -1 = chosen by
- * the ensemble's width (at most six chains per compute unit, 1536 on an MI355X: what the form's LDS admits), 0 = never, 1 = always.  Before the next run. */
+ * the ensemble's width (at most seven chains per compute unit, 1792 on an MI355X), 0 = never, 1 = always.  Before the next run. */
 pdmp_status pdmp_debug_set_helper_wave(pdmp_ensemble* ens, int mode);
 /* ... its tuning (none of it changes a result): the selection threshold moves by `gain` of the way towards `target` raw candidates per iteration;
  * the helper requests the lines of the blocks within `ahead` window lengths beyond the current window */

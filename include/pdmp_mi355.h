@@ -37,7 +37,7 @@ extern "C" {
  *    (pdmp_ensemble_set_neighbourhood), pdmp_ensemble_set_target_bps and the pdmp_comm_* (RCCL) entry points; Boomerang ensembles
  *    need an explicit mass factor like BouncyParticle ones.
  * 3: pdmp_ensemble_consume_discretized no longer clamps *npoints (it reports the grid points the trace reaches; row 0 is always x0),
- *    pdmp_ensemble_gather_bps_traces / pdmp_comm_gathered_bps_copy / pdmp_ensemble_bps_trace_dev exist, and ensembles of at most six chains per compute unit (1536 on an MI355X)
+ *    pdmp_ensemble_gather_bps_traces / pdmp_comm_gathered_bps_copy / pdmp_ensemble_bps_trace_dev exist, and ensembles of at most seven chains per compute unit (1792 on an MI355X)
  *    run the tracked local ZigZag with a helper wavefront per chain (same results; include/pdmp_debug.h: pdmp_debug_set_helper_wave).
  *    A host binding must check pdmp_abi_version() at load time. */
 #define PDMP_ABI_VERSION 3

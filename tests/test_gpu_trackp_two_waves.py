@@ -1,6 +1,6 @@
 """The two-wave form of the one-proposal-per-lane tracked kernel (-m gpu): zz_local_trackp2_kernel gives every chain a helper wavefront (the chain's
-uniforms and their logarithms produced ahead into a ring in LDS, the next windows' lines requested early) and is what ensembles of at most 1536
-chains run (six chains per CU: what its LDS admits) -- a rank's share of the north star's 4096-chain ensemble on 4 or 8 GPUs (the loop each chain runs:
+uniforms and their logarithms produced ahead into a ring in LDS, the next windows' lines requested early) and is what ensembles of at most 1792
+chains run (seven chains per CU) -- a rank's share of the north star's 4096-chain ensemble on 4 or 8 GPUs (the loop each chain runs:
 src/sfact.jl:199-208).  Held to the same bar as the one-wave form: bit for bit the oracle's tracked evaluation, and -- at the widths it is
 meant for -- every counter of every chain equal to the one-wave form's."""
 import numpy as np
@@ -24,18 +24,18 @@ def _ensemble(pkg, G, c, nch, cap, helper, seed0=SEED0):
 
 
 def test_default_form_follows_the_ensemble_width(gpu_pkg):
-    """<= 1536 chains: two waves per chain; wider: one (pdmp_debug_last_kernel says which ran)."""
+    """<= 1792 chains (seven per CU): two waves per chain; wider: one (pdmp_debug_last_kernel says which ran)."""
     pkg = gpu_pkg
     G = pkg.problems.gmrf_precision(64)
     c = pkg.problems.column_norms(G)
-    for nch, name in ((3, "zz_local_trackp2_kernel"), (1536, "zz_local_trackp2_kernel"), (1537, "zz_local_trackp_kernel")):
+    for nch, name in ((3, "zz_local_trackp2_kernel"), (1792, "zz_local_trackp2_kernel"), (1793, "zz_local_trackp_kernel")):
         with _ensemble(pkg, G, c, nch, 0, -1) as e:
             e.run(0.05, pkg._lib.RUN_STOP_BEFORE)
             assert e.kernel_name() == name, (nch, e.kernel_name())
             assert np.all(e.counters()["status"] == pkg._lib.CHAIN_OK)
 
 
-@pytest.mark.parametrize("nch", [512, 1024, 1536])
+@pytest.mark.parametrize("nch", [512, 1024, 1792])
 def test_strong_scaling_shares_equal_the_one_wave_form_and_the_oracle(gpu_pkg, nch):
     """C3's geometry (d = 16384) at the widths of a rank of the 8- and 4-GPU job, T = 2 in two slices with the trace recycled: every chain's
     proposal count, accepted count and draw count equal the one-wave form's; first and last chain bit for bit the oracle's tracked evaluation

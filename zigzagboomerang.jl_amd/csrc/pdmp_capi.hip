@@ -73,10 +73,11 @@ struct DevBuf {
 }  // namespace
 
 // zz_local_trackp: ensembles of at most this many chains PER COMPUTE UNIT run the two-wave form (pdmp_trackp.hip).  Measured on C3 (profiles/r05_*):
-// the helper wave pays as long as every chain is resident -- its 23 KB of LDS admit six chains per CU, 1536 on the MI355X's 256 CUs (1280 chains 17.9
-// against 21.3 ms for one wave, 1536 chains 19.2 against 21.8; beyond, workgroups wait for a slot).
+// the helper wave pays as long as every chain is resident with room to spare -- 18.7 KB of LDS and 128 registers admit eight chains per CU; up to
+// seven (1792 on the MI355X's 256 CUs) two waves win: 1536 chains 18.7 against 21.2 ms for one wave, 1792 chains 20.6 against 21.7, 1920 chains 23.1
+// against 22.2.
 #ifndef HELPER_WAVE_MAX_CHAINS_PER_CU
-#define HELPER_WAVE_MAX_CHAINS_PER_CU 6
+#define HELPER_WAVE_MAX_CHAINS_PER_CU 7
 #endif
 struct pdmp_ensemble {
     pdmp_config cfg{};

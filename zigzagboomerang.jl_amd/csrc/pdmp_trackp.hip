@@ -269,7 +269,7 @@ __device__ __forceinline__ uint32_t nb_count(const uint4 nb) {
 // point at), so that they are in the L2 when the main wave asks.  A request is a load whose value is thrown away; what the helper reads of
 // level 1 may be mid-update -- a wrong guess costs a line, never a result.  (Until late in round 5 it also requested the four lattice neighbours'
 // records of every such coordinate -- used by the 18 % that are accepted: 3.5 x the algorithmic bytes, 5.75 TB/s at 1024 chains, where leaving them
-// out is worth 8 % and lets the two-wave form win up to the 1536 chains its LDS admits.)
+// out is worth 8 % and lets the two-wave form win up to seven chains per CU (1792: pdmp_capi.hip).)
 template <bool LAT>
 __device__ __forceinline__ void trackp_helper(const ZzRunParams& P, unsigned char* smem, const int lane, const int64_t chain, const uint64_t seed,
                                            const uint64_t nm0) {
