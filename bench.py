@@ -492,7 +492,7 @@ def measure_pipeline(pkg, args, G, c, local_rank, ref_rate):
         c1 = e.counters()
         nev = int(c1["nevents"].sum()) - int(c0["nevents"].sum())
         modes[name] = {"ms_per_step": 1e3 * wall / ns, "sampler_kernel_ms_per_step": float(np.mean(run_ms)), "end_to_end_events_per_s": nev / wall,
-                       "fraction_of_sampler_alone": (nev / wall) / ref_rate if ref_rate else None,
+                       "fraction_of_timed_value": (nev / wall) / ref_rate if ref_rate else None,
                        "unhealthy_chains": int(np.count_nonzero(c1["status"] != pkg._lib.CHAIN_OK))}
         if mode == 0:
             # the consumer alone: two more slices, each consumed with nothing beside it
@@ -509,11 +509,19 @@ def measure_pipeline(pkg, args, G, c, local_rank, ref_rate):
         e.close()
     cons_bytes = np.mean(alone_ev) * (32 + 2 * 32) + nch * d * (dt / grid_dt) * (32 + 8.0)  # events + cursor read / write; per grid row: cursor read + point
     cons_s = float(np.mean(alone_ms)) * 1e-3
+    # The sampler ALONE, measured in the same minutes: its kernel time in the between-slices loop, where no kernel runs beside it (the timed value of
+    # the line may be minutes old, and the full-width launch has two timing modes that come and go: DESIGN.md 5)
+    alone_adjacent_ms = modes["between_slices"]["sampler_kernel_ms_per_step"]
+    for m_ in modes.values():
+        m_["fraction_of_sampler_alone"] = alone_adjacent_ms / m_["ms_per_step"]
     best = max(modes, key=lambda k: modes[k]["end_to_end_events_per_s"])
     out = {"what": "the timed steps with their trace consumed on the device (streaming mean + discretize at dt = 0.5 over every chain and coordinate) by "
                    "pdmp_ensemble_consume_async: a second stream, two trace buffers, no trace_reset",
            "steps": ns, "order": best, "library_default_order": "between_slices" if nch > 2048 else "beside_next_slice",
            "end_to_end_events_per_s": modes[best]["end_to_end_events_per_s"], "fraction_of_sampler_alone": modes[best]["fraction_of_sampler_alone"],
+           "fraction_of_timed_value": modes[best]["fraction_of_timed_value"], "sampler_alone_ms_per_step": alone_adjacent_ms,
+           "fraction_note": "fraction_of_sampler_alone = the sampler's kernel time per step in the between-slices loop (nothing runs beside it there) / this loop's "
+                            "wall time per step; fraction_of_timed_value compares with the line's `value`, measured minutes earlier and possibly in the other timing mode",
            "ms_per_step": modes[best]["ms_per_step"], "by_order": modes,
            "consumer_alone": {"ms_per_step": float(np.mean(alone_ms)), "events_per_s": float(np.mean(alone_ev)) / cons_s,
                               "algorithmic_bytes_per_step": cons_bytes, "GBps": cons_bytes / cons_s / 1e9,
