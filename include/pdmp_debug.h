@@ -40,6 +40,12 @@ pdmp_status pdmp_debug_set_track_groups(pdmp_ensemble* ens, int which);
  * logarithms produced ahead into a ring in LDS, the next windows' lines requested early); same committed sequence and floats.  -1 = chosen by
  * the ensemble's width (at most seven chains per compute unit, 1792 on an MI355X), 0 = never, 1 = always.  Before the next run. */
 pdmp_status pdmp_debug_set_helper_wave(pdmp_ensemble* ens, int mode);
+/* zz_local_trackl_kernel (round 6): the same event loop on the LINE layout -- a coordinate pair's (key, t_old) pairs, sums and constants in one
+ * 128-byte line, nine-bit wheel images of the pair minima in LDS -- which is what ensembles of more than 12 chains per compute unit run on the
+ * plain lattice with an even side (d <= 16384); same committed sequence and floats.  -1 = by the ensemble's width, 0 = never, 1 = wherever the
+ * layout serves.  The choice fixes the state's layout: call it BEFORE set_state.  With this kernel pdmp_debug_set_helper_steering's first two
+ * arguments are the block minima per quantum of the wheel and the events a window aims at (0: the defaults). */
+pdmp_status pdmp_debug_set_track_lines(pdmp_ensemble* ens, int mode);
 /* ... its tuning (none of it changes a result): the selection threshold moves by `gain` of the way towards `target` raw candidates per iteration;
  * the helper requests the lines of the blocks within `ahead` window lengths beyond the current window */
 pdmp_status pdmp_debug_set_helper_steering(pdmp_ensemble* ens, double gain, int target, double ahead);

@@ -35,12 +35,14 @@ def gpu_pkg(pkg):
     return pkg
 
 
-@pytest.fixture(params=["one_wave", "two_waves"])
+@pytest.fixture(params=["one_wave", "two_waves", "lines"])
 def trackp_form(request, monkeypatch):
-    """Both forms of the one-proposal-per-lane tracked kernel on the same test: zz_local_trackp_kernel (one wavefront per chain: what wide
-    ensembles run) and zz_local_trackp2_kernel (a helper wavefront per chain: what ensembles of at most 1024 chains run by default) --
-    include/pdmp_debug.h: pdmp_debug_set_helper_wave, forwarded by engine.Ensemble from PDMP_HELPER_WAVE."""
-    monkeypatch.setenv("PDMP_HELPER_WAVE", "0" if request.param == "one_wave" else "1")
+    """The forms of the one-proposal-per-lane tracked kernel on the same test: zz_local_trackp_kernel (one wavefront per chain), zz_local_trackp2_kernel
+    (a helper wavefront per chain: what ensembles of at most 1792 chains run by default) and zz_local_trackl_kernel (the line layout: what ensembles of
+    more than 3072 chains run on the plain lattice; a graph the layout does not serve keeps the one-wave form) -- include/pdmp_debug.h:
+    pdmp_debug_set_helper_wave / pdmp_debug_set_track_lines, forwarded by engine.Ensemble from PDMP_HELPER_WAVE / PDMP_TRACK_LINES."""
+    monkeypatch.setenv("PDMP_HELPER_WAVE", "1" if request.param == "two_waves" else "0")
+    monkeypatch.setenv("PDMP_TRACK_LINES", "1" if request.param == "lines" else "0")
     return request.param
 
 

@@ -202,7 +202,7 @@ def test_adversarial_graphs_both_evaluations(gpu_pkg, which, T, tracked, trackp_
         ens.set_gradient_tracking(tracked)
         ens.set_state_synthetic(0.0, c, 1)
         ens.run(0.05)
-        assert ens.kernel_name() == (("zz_local_trackp_kernel<LAT=false>" if trackp_form == "one_wave" else "zz_local_trackp2_kernel<LAT=false>")
+        assert ens.kernel_name() == (("zz_local_trackp2_kernel<LAT=false>" if trackp_form == "two_waves" else "zz_local_trackp_kernel<LAT=false>")
                                      if tracked else "zz_local_spec8g_kernel")
     for q in range(nch):
         r = O.spdmp_zigzag(G, None, G, x0[q], th0[q], c, T, seed=1700 + q, tracked=tracked)

@@ -651,7 +651,8 @@ __global__ __launch_bounds__(64) void bps_init_kernel(BpsRunParams P, const uint
         h.seed = seed;
         h.t0 = t0;
         h.t_event = t0;
-        for (int k = 0; k < 4; ++k) h.pad[k] = 0;
+        h.tl_scale = 0.0;
+        for (int k = 0; k < 3; ++k) h.pad[k] = 0;
         P.hdr[chain] = h;
     }
 }

@@ -79,6 +79,11 @@ struct DevBuf {
 #ifndef HELPER_WAVE_MAX_CHAINS_PER_CU
 #define HELPER_WAVE_MAX_CHAINS_PER_CU 7
 #endif
+// zz_local_trackl (pdmp_trackl.hip, the line layout): ensembles of MORE than this many chains per compute unit -- where the one-wave form with the
+// step rule runs today and the memory system is what an iteration waits for; narrower ensembles keep pdmp_trackp.hip's forms (target steering, two waves)
+#ifndef LINES_MIN_CHAINS_PER_CU
+#define LINES_MIN_CHAINS_PER_CU 12
+#endif
 struct pdmp_ensemble {
     pdmp_config cfg{};
     hipStream_t stream = nullptr;
@@ -136,6 +141,12 @@ struct pdmp_ensemble {
     bool exactp = false;       // the moving evaluation runs on zz_local_exactp_kernel (plain lattice; decided by set_state)
     bool track_pairs = false;  // the queue's level 0 is (key, time) pairs in d_kp (pdmp_trackp.hip); decided by set_state
     DevBuf<double> d_kp;
+    // the line layout (pdmp_trackl.hip): full-width launches on the plain lattice run on d_tl_lines / d_tl_cold; d_rec / d_kp are brought up to
+    // date (canon_stale) only when something reads the state -- final_state, the path-integral kernels, consume_begin
+    bool track_lines = false, canon_stale = false;
+    int dbg_track_lines = -1;  // pdmp_debug_set_track_lines: -1 by ensemble width (more than LINES_MIN_CHAINS_PER_CU chains per CU), 0 never, 1 always
+    DevBuf<pdmp::TrLine> d_tl_lines;
+    DevBuf<pdmp::TrCold> d_tl_cold;
     // zz_local_spec8g_kernel's tables (any graph with |G1| <= 8, |S| <= 32; built with the blob)
     bool has_g8 = false, g8_same = false;
     int g8_gw = 8;  // lanes per event of zz_local_spec8g_kernel: 8 (|S| <= 32) or 16 (|S| <= 64)
@@ -263,6 +274,17 @@ static pdmp_status launch_deferred_consumer(pdmp_ensemble* e) {
 static hipError_t device_sync(pdmp_ensemble* e) {
     if (e && e->deferred_k >= 0 && launch_deferred_consumer(e) != PDMP_OK) return hipErrorUnknown;
     return hipDeviceSynchronize();
+}
+
+// the records / pairs of pdmp_trackp.hip's layout from the lines (pdmp_trackl.hip), where a run has left them behind
+static pdmp_status ensure_canon(pdmp_ensemble* e) {
+    if (!e->track_lines || !e->canon_stale) return PDMP_OK;
+    HIP_TRY(device_sync(e));
+    int rc = pdmp::launch_zz_trackl_unpack(e->d_tl_lines.p, e->d_tl_cold.p, e->d_rec.p, e->d_kp.p, e->cfg.d, e->dk, e->cfg.nchains, e->stream);
+    if (rc != 0) return fail(PDMP_ERR_HIP, "trackl_unpack launch failed: %s", hipGetErrorString((hipError_t)rc));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->canon_stale = false;
+    return PDMP_OK;
 }
 
 extern "C" {
@@ -416,6 +438,11 @@ pdmp_status pdmp_debug_last_kernel(pdmp_ensemble* e, char* out, int64_t cap) {
 pdmp_status pdmp_debug_set_track_groups(pdmp_ensemble* e, int on) {
     if (!e) return fail(PDMP_ERR_INVALID, "null argument");
     e->dbg_track_groups = (on == 1) ? 1 : 0;
+    return PDMP_OK;
+}
+pdmp_status pdmp_debug_set_track_lines(pdmp_ensemble* e, int mode) {
+    if (!e || mode < -1 || mode > 1) return fail(PDMP_ERR_INVALID, "track lines: -1 (by ensemble width), 0 (never), 1 (wherever the layout serves)");
+    e->dbg_track_lines = mode;
     return PDMP_OK;
 }
 pdmp_status pdmp_debug_set_helper_wave(pdmp_ensemble* e, int mode) {
@@ -1307,6 +1334,8 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
         if (rct != 0) return fail(PDMP_ERR_HIP, "zz_logistic_track_init launch failed: %s", hipGetErrorString((hipError_t)rct));
     }
     e->track_pairs = false;
+    e->track_lines = false;
+    e->canon_stale = false;
     if (e->track) {
         if (trackp_ok) {
             if (e->d_kp.n != (size_t)(2 * n * e->dk) && (st = e->d_kp.alloc((size_t)(2 * n * e->dk))) != PDMP_OK) return st;
@@ -1315,6 +1344,23 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
             rc = pdmp::launch_zz_trackp_consts(e->d_rec.p, e->d_cc.p, e->track_generic ? e->d_nb16.p : nullptr, d, n, e->stream);
             if (rc != 0) return fail(PDMP_ERR_HIP, "trackp_consts launch failed: %s", hipGetErrorString((hipError_t)rc));
             e->track_pairs = true;
+            // the line layout where the ensemble fills the device (decided here: the layout belongs to the kernel)
+            pdmp::ZzRunParams G{};
+            G.tb = e->tables();
+            G.lattice_n = e->lattice_n;
+            G.adapt = e->cfg.adapt;
+            G.track_two_sums = e->track_two_sums ? 1 : 0;
+            G.has_refresh = e->lambda_ref > 0;
+            G.d = d;
+            const int64_t ncu = e->n_cu > 0 ? e->n_cu : 256;
+            const bool wide = n > (int64_t)LINES_MIN_CHAINS_PER_CU * ncu;
+            if (pdmp::zz_trackl_supported(G) && !e->track_generic && (e->dbg_track_lines == 1 || (e->dbg_track_lines == -1 && wide))) {
+                if (e->d_tl_lines.n != (size_t)(n * e->dk / 2) && (st = e->d_tl_lines.alloc((size_t)(n * e->dk / 2))) != PDMP_OK) return st;
+                if (e->d_tl_cold.n != (size_t)(n * e->dk) && (st = e->d_tl_cold.alloc((size_t)(n * e->dk))) != PDMP_OK) return st;
+                rc = pdmp::launch_zz_trackl_pack(e->d_rec.p, e->d_kp.p, e->d_tl_lines.p, e->d_tl_cold.p, d, e->dk, n, e->stream);
+                if (rc != 0) return fail(PDMP_ERR_HIP, "trackl_pack launch failed: %s", hipGetErrorString((hipError_t)rc));
+                e->track_lines = true;
+            }
         }
     }
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1534,6 +1580,31 @@ static pdmp_status ensemble_run_impl(pdmp_ensemble* e, double T, int flags, void
         P.lattice_n = e->lattice_n;
         P.lattice_magic = e->lattice_n ? (uint32_t)(((uint64_t)1 << 32) / (uint64_t)e->lattice_n + 1) : 0u;
         // one proposal per lane where the graph is the plain lattice (pdmp_trackp.hip); elsewhere, and on request, the 8-lane-group kernel
+        if (e->track_lines) {
+            {
+                uint32_t hist[16] = {0}, best = 0;
+                for (int64_t k = 0; k < e->cfg.d; ++k) hist[std::min<uint32_t>(e->colptr[(size_t)k + 1] - e->colptr[(size_t)k], 15u)] += 1;
+                for (uint32_t k = 1; k < 16; ++k)
+                    if (hist[k] > hist[best]) best = k;
+                P.typ_extra = best > 0 ? best - 1u : 0u;
+            }
+            P.tl_lines = e->d_tl_lines.p;
+            P.tl_cold = e->d_tl_cold.p;
+            P.hw_gain = e->dbg_hw_steer[0];  // (pdmp_debug_set_helper_steering: block minima per quantum, events per window -- A/B; 0: the kernel's)
+            P.hw_target = (uint32_t)e->dbg_hw_steer[1];
+            e->last_kernel = "zz_local_trackl_kernel";
+            e->canon_stale = true;
+            int rcl = pdmp::launch_zz_local_trackl(P, e->cfg.nchains, s);
+            if (rcl != 0) return fail(PDMP_ERR_HIP, "zz_local_trackl launch failed (%d)", rcl);
+            HIP_TRY(hipEventRecord(e->ev1, s));
+            e->timed = true;
+            if (phenv) {
+                HIP_TRY(device_sync(e));
+                HIP_TRY(hipMemcpy(e->dbg_phase_out, phbuf.p, sizeof e->dbg_phase_out, hipMemcpyDeviceToHost));
+                e->dbg_phase_valid = 1;
+            }
+            return PDMP_OK;
+        }
         if (e->track_pairs) {
             P.keys = e->d_kp.p;
             // the two-wave form (a helper wave per chain) where the ensemble leaves SIMDs idle: at most two resident waves per SIMD with it
@@ -1707,6 +1778,7 @@ pdmp_status pdmp_ensemble_final_state(pdmp_ensemble* e, int64_t chain_first, int
     if (n == 0) return PDMP_OK;
     HIP_TRY(hipSetDevice(e->cfg.device));
     HIP_TRY(device_sync(e));
+    { pdmp_status stc = ensure_canon(e); if (stc != PDMP_OK) return stc; }
     const int64_t d = e->cfg.d;
     const size_t cnt = (size_t)(n * d);
     DevBuf<double> bt, bx, bth, bc;
@@ -1748,6 +1820,7 @@ pdmp_status pdmp_ensemble_batch_means(pdmp_ensemble* e, double T_prev, double T,
         HIP_TRY(hipMemsetAsync(e->d_jprev.p, 0, (size_t)(n * d) * sizeof(double), e->stream));  // (same stream as the kernel: the ensemble's stream is non-blocking, the null stream does not order against it)
     }
     if (e->d_sum.n != (size_t)(2 * d) && (st = e->d_sum.alloc((size_t)(2 * d))) != PDMP_OK) return st;
+    if ((st = ensure_canon(e)) != PDMP_OK) return st;
     HIP_TRY(hipMemsetAsync(e->d_sum.p, 0, (size_t)(2 * d) * sizeof(double), e->stream));
     int rc = pdmp::launch_zz_batch_means(e->d_rec.p, e->track ? 128 : 64, e->d_jprev.p, d, n, T_prev, T, e->d_sum.p, e->d_sum.p + d,
                                          e->stream);
@@ -1777,6 +1850,7 @@ pdmp_status pdmp_ensemble_ess_begin(pdmp_ensemble* e, double T0) {
     if (e->d_jprev.n != (size_t)(n * d) && (st = e->d_jprev.alloc((size_t)(n * d))) != PDMP_OK) return st;
     if (e->d_jstart.n != (size_t)(n * d) && (st = e->d_jstart.alloc((size_t)(n * d))) != PDMP_OK) return st;
     if (e->d_essacc.n != (size_t)(4 * d) && (st = e->d_essacc.alloc((size_t)(4 * d))) != PDMP_OK) return st;
+    if ((st = ensure_canon(e)) != PDMP_OK) return st;
     HIP_TRY(hipMemsetAsync(e->d_essacc.p, 0, (size_t)(4 * d) * sizeof(double), e->stream));
     int rc = pdmp::launch_zz_ess(e->d_rec.p, e->track ? 128 : 64, e->d_jprev.p, e->d_jstart.p, d, n, 0, T0, T0, e->d_essacc.p, e->stream);
     if (rc != 0) return fail(PDMP_ERR_HIP, "ess launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -1793,6 +1867,7 @@ pdmp_status pdmp_ensemble_ess_batch(pdmp_ensemble* e, double T) {
     if (!(T > e->ess_Tlast)) return fail(PDMP_ERR_INVALID, "batch end %g does not exceed the previous one %g", T, e->ess_Tlast);
     HIP_TRY(hipSetDevice(e->cfg.device));
     HIP_TRY(device_sync(e));
+    if ((st = ensure_canon(e)) != PDMP_OK) return st;
     int rc = pdmp::launch_zz_ess(e->d_rec.p, e->track ? 128 : 64, e->d_jprev.p, e->d_jstart.p, e->cfg.d, e->cfg.nchains, 1, e->ess_Tlast, T,
                                  e->d_essacc.p, e->stream);
     if (rc != 0) return fail(PDMP_ERR_HIP, "ess launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -1809,6 +1884,7 @@ pdmp_status pdmp_ensemble_ess_end(pdmp_ensemble* e, double* sum_y, double* sum_y
     if (e->ess_batches < 1) return fail(PDMP_ERR_INVALID, "no batch accumulated (ess_begin, then ess_batch)");
     HIP_TRY(hipSetDevice(e->cfg.device));
     const int64_t d = e->cfg.d;
+    if ((st = ensure_canon(e)) != PDMP_OK) return st;
     HIP_TRY(hipMemsetAsync(e->d_essacc.p + 2 * d, 0, (size_t)(2 * d) * sizeof(double), e->stream));
     int rc = pdmp::launch_zz_ess(e->d_rec.p, e->track ? 128 : 64, e->d_jprev.p, e->d_jstart.p, d, e->cfg.nchains, 2, e->ess_T0, e->ess_Tlast,
                                  e->d_essacc.p, e->stream);
@@ -1842,6 +1918,7 @@ pdmp_status pdmp_ensemble_consume_begin(pdmp_ensemble* e, double grid_dt, int64_
         if ((st = e->d_cgrid.alloc((size_t)(n * grid_points * d))) != PDMP_OK) return st;
         HIP_TRY(hipMemsetAsync(e->d_cgrid.p, 0, (size_t)(n * grid_points * d) * sizeof(double), e->stream));
     }
+    if ((st = ensure_canon(e)) != PDMP_OK) return st;
     int rc = pdmp::launch_consume_init(e->d_rec.p, e->track ? 128 : 64, d, n, e->t0_state, e->d_ccur.p, e->cons_z, e->d_cmeta.p,
                                        grid_points > 0 ? e->d_cgrid.p : nullptr, grid_points, e->stream);
     if (rc != 0) return fail(PDMP_ERR_HIP, "consume_init launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -2030,6 +2107,7 @@ pdmp_status pdmp_ensemble_path_integrals(pdmp_ensemble* e, double T, int64_t npr
     DevBuf<double> dout;
     if ((st = dp.upload(std::vector<int64_t>(probes, probes + nprobe))) != PDMP_OK) return st;
     if ((st = dout.alloc((size_t)(n * nprobe))) != PDMP_OK) return st;
+    if ((st = ensure_canon(e)) != PDMP_OK) return st;
     int rc = pdmp::launch_zz_path_integrals(e->d_rec.p, e->track ? 128 : 64, d, n, dp.p, nprobe, T, dout.p, e->stream);
     if (rc != 0) return fail(PDMP_ERR_HIP, "path_integrals launch failed: %s", hipGetErrorString((hipError_t)rc));
     HIP_TRY(hipStreamSynchronize(e->stream));

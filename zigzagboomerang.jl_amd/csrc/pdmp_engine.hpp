@@ -63,12 +63,31 @@ static_assert(sizeof(TrRecP) == 128 && offsetof(TrRecP, tacc) == offsetof(TrRec,
 // can request its members' records at once -- and the values Γ[G1[i], i] come from the shared table ZzTables::gam8 (L2-resident, requested
 // side by side with the members' records).
 
+// The LINE layout of the one-proposal-per-lane tracked kernel at full width (pdmp_trackl.hip, round 6): everything a proposal of coordinate i
+// reads or writes is in ONE 128-byte line that it shares with its pair mate i ^ 1 -- the queue's level 0 IS the record.  Sector 0: the two
+// (key, t_old) pairs (a rejected proposal dirties 16 bytes of it and nothing else); sectors 1, 2: (θ, g, gd, tg) of either coordinate (written
+// on accepts in G1[i]); sector 3: what depends on the coordinate alone (c_i, c_i / 100: no table in the event loop).  What only an ACCEPTED
+// event of i itself touches -- the position at its own clock, ∫ x dt, the reflection count -- is a 32-byte cold record per coordinate.
+struct alignas(128) TrLine {
+    double key0, told0, key1, told1;
+    double th0, g0, gd0, tg0;
+    double th1, g1, gd1, tg1;
+    double c0, c100_0, c1, c100_1;
+};
+static_assert(sizeof(TrLine) == 128, "one line per coordinate pair");
+struct alignas(32) TrCold {
+    double x, tx, I;
+    uint64_t acc;
+};
+static_assert(sizeof(TrCold) == 32, "one sector per coordinate");
+
 struct alignas(128) DevChain {
     pdmp_chain_counters c;  // 72 bytes, copied out verbatim by pdmp_ensemble_counters
     uint64_t seed;
     double t0;
     double t_event;  // t′ of the last RETURNED event: the loop variable of `while t′ < T` (src/sfact.jl:199)
-    uint64_t pad[4];
+    double tl_scale;  // pdmp_trackl.hip: quanta per unit time of the chain's event-time wheel (0: not chosen yet), kept from launch to launch
+    uint64_t pad[3];
 };
 static_assert(sizeof(DevChain) == 128, "chain header is 128 bytes");
 
@@ -162,6 +181,9 @@ struct ZzRunParams {
     uint32_t hw_target;
     int32_t n_cu;            // (host side) compute units of the device: the launchers' width thresholds are per CU (0: 256)
     int32_t helper_wave;     // zz_local_trackp: the two-wave form (a helper wave per chain: ring of draws + prefetch), for under-occupied launches
+    // the line layout (pdmp_trackl.hip): [nchains x dk / 2] TrLine, [nchains x dk] TrCold; null elsewhere
+    void* tl_lines;
+    void* tl_cold;
     int32_t lattice_n;       // n if the graph is the n x n 5-point lattice in column-major numbering (i = row + n col), else 0
     uint32_t lattice_magic;  // ceil(2^32 / n): column of i = umulhi(i, magic) for i < 2^16
     // per-coordinate tables of zz_local_spec8g_kernel (pdmp_spec8g.inc: |G1| <= 8, |S| <= 32), one 128-byte line per coordinate each, or null
@@ -357,6 +379,11 @@ bool zz_trackp_supported(const ZzRunParams& p);
 int launch_zz_local_trackp(const ZzRunParams& p, int64_t nchains, void* stream);
 int launch_zz_keys_to_pairs(const double* keys, void* kp, int64_t n, double t0, void* stream);
 int launch_zz_trackp_consts(void* rec, const CoordConst* cc, const uint16_t* nb16, int64_t d, int64_t nchains, void* stream);
+// pdmp_trackl.hip: the same kernel on the line layout (full-width launches of the plain lattice, d <= 16384)
+bool zz_trackl_supported(const ZzRunParams& p);
+int launch_zz_local_trackl(const ZzRunParams& p, int64_t nchains, void* stream);
+int launch_zz_trackl_pack(const void* rec, const void* kp, void* lines, void* cold, int64_t d, int64_t dk, int64_t nchains, void* stream);
+int launch_zz_trackl_unpack(const void* lines, const void* cold, void* rec, void* kp, int64_t d, int64_t dk, int64_t nchains, void* stream);
 constexpr int TRACKP_KMAX = 8;  // |G1[i]| the generic instantiation takes (one member per lane of an 8-lane group)
 bool zz_spec8_geometry(const ZzRunParams& p);  // the 8-event kernels' requirements on the neighbourhood blob and on d
 // kp != nullptr: the (key, time of the last own proposal) pairs of pdmp_trackp.hip hold tprop instead of the records (chain stride dk pairs)

@@ -266,7 +266,8 @@ __global__ __launch_bounds__(256) void zz_init_kernel(ZzInitParams P) {
         h.seed = seed;
         h.t0 = P.t0;
         h.t_event = P.t0;
-        for (int k = 0; k < 4; ++k) h.pad[k] = 0;
+        h.tl_scale = 0.0;
+        for (int k = 0; k < 3; ++k) h.pad[k] = 0;
         P.hdr[chain] = h;
     }
 }

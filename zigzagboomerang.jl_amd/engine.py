@@ -48,6 +48,8 @@ class Ensemble:
             _lib.check(self._L.pdmp_debug_set_track_groups(self._h, int(os.environ["PDMP_TRACK_GROUPS"])))
         if os.environ.get("PDMP_HELPER_WAVE"):
             self.debug_set_helper_wave(int(os.environ["PDMP_HELPER_WAVE"]))
+        if os.environ.get("PDMP_TRACK_LINES"):
+            self.debug_set_track_lines(int(os.environ["PDMP_TRACK_LINES"]))
         if os.environ.get("PDMP_LAUNCH_COUNT_LIMIT"):
             _lib.check(self._L.pdmp_debug_set_launch_count_limit(self._h, int(os.environ["PDMP_LAUNCH_COUNT_LIMIT"])))
         if os.environ.get("PDMP_HELPER_STEER"):  # "gain,target,ahead"
@@ -66,6 +68,10 @@ class Ensemble:
     def debug_set_helper_wave(self, mode):
         """zz_local_trackp: -1 the two-wave form by ensemble width (default), 0 never, 1 always (include/pdmp_debug.h)."""
         _lib.check(self._L.pdmp_debug_set_helper_wave(self._h, int(mode)))
+
+    def debug_set_track_lines(self, mode):
+        """zz_local_trackl (the line layout): -1 by ensemble width (default), 0 never, 1 wherever it serves; before set_state (include/pdmp_debug.h)."""
+        _lib.check(self._L.pdmp_debug_set_track_lines(self._h, int(mode)))
 
     def kernel_name(self):
         """Event-loop kernel of the last run (include/pdmp_debug.h: pdmp_debug_last_kernel); '' before the first run."""
