@@ -461,8 +461,9 @@ pdmp_status pdmp_debug_set_launch_count_limit(pdmp_ensemble* e, uint32_t n) {
     return PDMP_OK;
 }
 pdmp_status pdmp_debug_set_helper_steering(pdmp_ensemble* e, double gain, int target, double ahead) {
-    if (!e || !(gain > 0.0 && gain <= 1.0) || target < 1 || target > 64 || !(ahead >= 0.0))
-        return fail(PDMP_ERR_INVALID, "helper steering: 0 < gain <= 1, 1 <= target <= 64, ahead >= 0");
+    // (zz_local_trackl reads them as block minima per quantum and events per window: hence the wide range of the first)
+    if (!e || !(gain > 0.0 && gain <= 4096.0) || target < 1 || target > 64 || !(ahead >= 0.0))
+        return fail(PDMP_ERR_INVALID, "helper steering: 0 < gain <= 4096 (<= 1 for the two-wave form), 1 <= target <= 64, ahead >= 0");
     e->dbg_hw_steer[0] = gain;
     e->dbg_hw_steer[1] = (double)target;
     e->dbg_hw_steer[2] = ahead;
@@ -1592,6 +1593,7 @@ static pdmp_status ensemble_run_impl(pdmp_ensemble* e, double T, int flags, void
             P.tl_cold = e->d_tl_cold.p;
             P.hw_gain = e->dbg_hw_steer[0];  // (pdmp_debug_set_helper_steering: block minima per quantum, events per window -- A/B; 0: the kernel's)
             P.hw_target = (uint32_t)e->dbg_hw_steer[1];
+            P.hw_ahead = e->dbg_hw_steer[2];  // (a block to watch: the -DPDMP_TL_CHECK build of pdmp_trackl.hip)
             e->last_kernel = "zz_local_trackl_kernel";
             e->canon_stale = true;
             int rcl = pdmp::launch_zz_local_trackl(P, e->cfg.nchains, s);

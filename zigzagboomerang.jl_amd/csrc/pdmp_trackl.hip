@@ -344,6 +344,9 @@ __device__ __forceinline__ void trackl_body(const ZzRunParams& P) {
         }                                                                 \
     } while (0)
 
+#ifdef PDMP_TL_CHECK
+    int tlc_bad = 0;
+#endif
     PrioTurn prio;
     uint32_t idle = 0;  // consecutive iterations without an event
     bool running = stop_before || (t_event < T);
@@ -392,7 +395,7 @@ __device__ __forceinline__ void trackl_body(const ZzRunParams& P) {
                 const double mk = l_min(s0.x, s0.z);
                 const int64_t R = (int64_t)tl_q(mk, tref, s) - (int64_t)F;
                 const uint32_t r = (img_get(smem, b) - fwc) & 511u;
-                if (R < (int64_t)r) printf("TLCHECK chain %d iter %u block %u r %u R %lld F %d key %.17g tlast %.17g dnum %u\n", (int)chain, (unsigned)prio.it, b, r, (long long)R, F, mk, t_last, dnum);
+                if (R < (int64_t)r && tlc_bad < 3) { tlc_bad += 1; printf("TLCHECK chain %d iter %u block %u r %u R %lld F %d key %.17g tlast %.17g dnum %u\n", (int)chain, (unsigned)prio.it, b, r, (long long)R, F, mk, t_last, dnum); }
             }
         }
 #endif
@@ -515,7 +518,7 @@ __device__ __forceinline__ void trackl_body(const ZzRunParams& P) {
         // ---------------- events = candidates whose exact minimum lies in the window; everybody refreshes its image
         const int32_t c_q = tl_q(c_km, tref, s);
 #ifdef PDMP_TL_CHECK
-        if (isc && chain == 0 && cblk == 688u) printf("W refresh it %u F %d q %d km %.17g\n", (unsigned)prio.it, F, c_q, c_km);
+        if (isc && chain == (int64_t)P.dbg_cap && cblk == (uint32_t)P.hw_ahead) printf("W refresh it %u F %d q %d km %.17g\n", (unsigned)prio.it, F, c_q, c_km);
 #endif
         if (isc) img_set(smem, cblk, (uint32_t)c_q & 511u);
         const bool isev = isc && ((int64_t)c_q - (int64_t)F < (int64_t)meff) && (!stop_before || c_km < T);
@@ -894,7 +897,7 @@ __device__ __forceinline__ void trackl_body(const ZzRunParams& P) {
         if (commit && !acc) {  // a rejected proposal: ONE 16-byte store into the line it read, and the line's new image
             if (!(rekey_by < Rc)) *reinterpret_cast<double2*>(lines + (size_t)blk * 128 + 16 * (pbe & 1u)) = make_double2(key2, tp);
 #ifdef PDMP_TL_CHECK
-            if (chain == 0 && blk == 688u) printf("W reject it %u F %d q %d rowmin %.17g key2 %.17g rest %.17g lane %d\n", (unsigned)prio.it, F, tl_q(rowmin, tref, s), rowmin, key2, rest, lane);
+            if (chain == (int64_t)P.dbg_cap && blk == (uint32_t)P.hw_ahead) printf("W reject it %u F %d q %d rowmin %.17g key2 %.17g rest %.17g lane %d\n", (unsigned)prio.it, F, tl_q(rowmin, tref, s), rowmin, key2, rest, lane);
 #endif
             img_set(smem, blk, img_pos(rowmin));
         }
@@ -921,7 +924,7 @@ __device__ __forceinline__ void trackl_body(const ZzRunParams& P) {
                 }
             }
 #ifdef PDMP_TL_CHECK
-            if (gl == 0 && chain == 0 && blka == 688u) printf("W group it %u F %d q %d rowmin_a %.17g ea %u\n", (unsigned)prio.it, F, tl_q(rowmin_a, tref, s), rowmin_a, ea);
+            if (gl == 0 && chain == (int64_t)P.dbg_cap && blka == (uint32_t)P.hw_ahead) printf("W group it %u F %d q %d rowmin_a %.17g ea %u\n", (unsigned)prio.it, F, tl_q(rowmin_a, tref, s), rowmin_a, ea);
 #endif
             if (gl == 0) img_set(smem, blka, img_pos(rowmin_a));
         }
@@ -944,20 +947,30 @@ __device__ __forceinline__ void trackl_body(const ZzRunParams& P) {
                 const uint32_t rcur = (cur - fw) & 511u;
                 const bool inw = rcur < (uint32_t)meff;
 #ifdef PDMP_TL_CHECK
-                if (want0 && chain == 0 && bj == 688u) printf("W lower it %u F %d rn %u cur %u rcur %u keyj %.17g jm %u\n", (unsigned)prio.it, F, rn, cur, rcur, keyj, jm);
+                if (want0 && chain == (int64_t)P.dbg_cap && bj == (uint32_t)P.hw_ahead) printf("W lower it %u F %d rn %u cur %u rcur %u keyj %.17g jm %u\n", (unsigned)prio.it, F, rn, cur, rcur, keyj, jm);
 #endif
-                if (want0 && (inw || rn < rcur)) img_set(smem, bj, ((inw ? dn : rn) + fw) & 511u);
+                // two lanes aiming at one line (the two coordinates of a pair, re-bounded by two accepted events) would mix their bytes and ninth
+                // bits: every acting lane claims its line in a 64-entry table first (EX is free by now); where a claim is lost -- or two lines
+                // share an entry -- the lanes act one after the other, each on what the one before left
+                const bool act = want0 && (inw || rn < rcur);
+                unsigned char* const CL = smem + LL::EX;
+                if (act) CL[bj & 63u] = (unsigned char)lane;
                 L_ORDER();
-                const uint32_t now = img_get(smem, bj);
-                uint64_t badl = __ballot(want0 && rn < 512u && ((now - fw) & 511u) > rn);
-                while (badl) {
-                    const int L0 = __ffsll((unsigned long long)badl) - 1;
-                    badl &= badl - 1;
-                    if (lane == L0) {
-                        const uint32_t c2 = img_get(smem, bj);
-                        if (rn < ((c2 - fw) & 511u)) img_set(smem, bj, (rn + fw) & 511u);
+                const bool lost = act && CL[bj & 63u] != (unsigned char)lane;
+                if (__ballot(lost) == 0) {
+                    if (act) img_set(smem, bj, ((inw ? dn : rn) + fw) & 511u);
+                } else {
+                    uint64_t todo = __ballot(act);
+                    while (todo) {
+                        const int L0 = __ffsll((unsigned long long)todo) - 1;
+                        todo &= todo - 1;
+                        if (lane == L0) {
+                            const uint32_t rc2 = (img_get(smem, bj) - fw) & 511u;
+                            const bool inw2 = rc2 < (uint32_t)meff;
+                            if (inw2 || rn < rc2) img_set(smem, bj, ((inw2 ? dn : rn) + fw) & 511u);
+                        }
+                        L_ORDER();
                     }
-                    L_ORDER();
                 }
             }
         }
