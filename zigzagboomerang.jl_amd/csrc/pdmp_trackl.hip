@@ -157,8 +157,8 @@ constexpr int L_NHYP = 4;       // hypotheses of the accept chain's first guess
 constexpr int32_t L_MMAX = 128; // quanta a window may span (the SWAR test takes at most 128)
 // block minima per quantum the scale aims at, and the events an iteration's window aims at (pdmp_debug_set_helper_steering overrides both: A/B)
 #ifndef L_TARGETQ
-#define L_TARGETQ 26.0
-#define L_TARGET 30.0
+#define L_TARGETQ 30.0
+#define L_TARGET 56.0
 #endif
 
 // block b's ninth bit: word and mask in the plane.  Lane o = (b >> 4) & 63 scans the 16-byte pieces o + 64 j (j = b >> 10) of the byte array; its
@@ -193,8 +193,8 @@ __device__ __forceinline__ int32_t tl_q(double t, double tref, double s) {
 
 template <bool PROF>
 __device__ __forceinline__ void trackl_body(const ZzRunParams& P) {
-    const int lane = threadIdx.x & 63;
-    const int g = lane >> 3, gl = lane & 7;
+    const int lane0 = threadIdx.x & 63;
+    int lane = lane0;
     const int64_t chain = blockIdx.x;
     const int64_t d = P.d;
     const uint32_t nb2p = (uint32_t)(P.dk / 2);  // lines of a chain (dk is a multiple of 64: whole 16-byte pieces of the byte array)
@@ -231,15 +231,7 @@ __device__ __forceinline__ void trackl_body(const ZzRunParams& P) {
                                     ? (uint32_t)(((uint64_t)P.trace_cap > ntrace0) ? ((uint64_t)P.trace_cap - ntrace0) : 0)
                                     : 0xffffffffu;
     const double targetq = (P.hw_gain > 0.0) ? P.hw_gain : L_TARGETQ;
-    const double target_ev = (P.hw_target != 0u) ? (double)P.hw_target : L_TARGET;
-
-    // validity of the lane's blocks as the packed flags order them (word q covers the 16-byte pieces lane + 64 (2 q) and lane + 64 (2 q + 1))
-    uint32_t VM[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const uint32_t u0 = (uint32_t)lane + 64u * (uint32_t)(2 * q), u1 = u0 + 64u;
-        VM[q] = ((16u * u0 < nb2p) ? 0x0f0f0f0fu : 0u) | ((16u * u1 < nb2p) ? 0xf0f0f0f0u : 0u);
-    }
+    const double raw_target = (P.hw_target != 0u) ? (double)P.hw_target : L_TARGET;
 
     // ---------------- the wheel: scale s (quanta per unit time), reference time, images of every block minimum
     const double tref = t_last;  // (wave-uniform, fixed for the launch)
@@ -322,13 +314,16 @@ __device__ __forceinline__ void trackl_body(const ZzRunParams& P) {
         return;
     }
     int32_t m = 1;              // quanta of the next window
-    double avgq = targetq;      // events per quantum, a running mean
+    double evq = targetq, rqf = 1.5 * targetq;  // events / candidates a NEW quantum brings, running means
+    int32_t prev_base = 0;      // quanta of the current window that the window before it had looked at already
+    double prev_left = 0.0;     // ... and the events in them that it did not commit
+    double inv_s = 1.0 / s;
     uint32_t since_rescale = 0;
 
     uint64_t ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t ph_t0 = PROF ? (uint64_t)__builtin_readcyclecounter() : 0;
     uint64_t ph_rounds = 0, ph_guess = 0;
-    uint64_t ph_iters = 0, ph_raw = 0, ph_zone = 0, ph_eval = 0;
+    uint64_t ph_iters = 0, ph_raw = 0, ph_zone = 0, ph_eval = 0, ph_nev = 0, ph_ties = 0, ph_cut1 = 0, ph_cut2 = 0, ph_alias = 0, ph_near = 0, ph_meff = 0;
 #ifdef PDMP_PHASE_MARKS
 #define LMARK(k) asm volatile("; LPHASE " #k)
 #else
@@ -351,6 +346,11 @@ __device__ __forceinline__ void trackl_body(const ZzRunParams& P) {
     uint32_t idle = 0;  // consecutive iterations without an event
     bool running = stop_before || (t_event < T);
     while (running) {
+        // (the lane index is made opaque once per iteration: LLVM otherwise hoists lane-only arithmetic -- masks, LDS addresses, the validity words
+        // of the scan -- out of this loop, runs out of registers and SPILLS it; the reload inside the loop waits with vmcnt(0) for every store in flight)
+        lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const int g = lane >> 3, gl = lane & 7;
         prio.step();
         if (dnacc >= trace_room) {
             status = PDMP_CHAIN_TRACE_FULL;
@@ -423,6 +423,13 @@ __device__ __forceinline__ void trackl_body(const ZzRunParams& P) {
             if (meff > (int32_t)(256u - lo)) meff = (int32_t)(256u - lo);
             if (meff > L_MMAX) meff = L_MMAX;
             if (stop_before && (int64_t)QT - (int64_t)F + 1 < (int64_t)meff) meff = (int32_t)((int64_t)QT - (int64_t)F + 1);
+            // validity of the lane's blocks as the packed flags order them (word q covers the 16-byte pieces lane + 64 (2 q) and lane + 64 (2 q + 1))
+            uint32_t VM[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t u0 = (uint32_t)lane + 64u * (uint32_t)(2 * q), u1 = u0 + 64u;
+                VM[q] = ((16u * u0 < nb2p) ? 0x0f0f0f0fu : 0u) | ((16u * u1 < nb2p) ? 0xf0f0f0f0u : 0u);
+            }
             uint32_t PK[4];
             for (int tries = 0;; ++tries) {
                 // bytes y = (image − lo) mod 256 < meff, four per word: per-byte subtraction without borrows between the bytes, then y's bit 7 clear
@@ -468,8 +475,7 @@ __device__ __forceinline__ void trackl_body(const ZzRunParams& P) {
                     crowded = true;  // one quantum holds more blocks than the wave has lanes: the scale is too coarse here
                     break;
                 }
-                int32_t mn = (int32_t)(((uint32_t)meff * 48u) / Cc);
-                meff = (mn < 1) ? 1 : ((mn >= meff) ? meff - 1 : mn);
+                meff = (Cc > 96u && meff > 2) ? meff / 2 : meff - 1;  // (windows are a few quanta: one less is the list just shorter)
             }
         }
         if (crowded) {
@@ -478,10 +484,14 @@ __device__ __forceinline__ void trackl_body(const ZzRunParams& P) {
                 break;
             }
             s = l_uniform(s * 2.0);
-            avgq = avgq * 0.5;
+            inv_s = 1.0 / s;
+            evq = evq * 0.5;
+            rqf = rqf * 0.5;
             since_rescale = 0;
             rebuild();
             m = 1;
+            prev_base = 0;
+            prev_left = 0.0;
             if (++idle > 4096u) {
                 status = PDMP_CHAIN_STALLED;
                 break;
@@ -530,7 +540,7 @@ __device__ __forceinline__ void trackl_body(const ZzRunParams& P) {
         uint32_t rank = 0, rsum = 0xffffffffu;
         {
             uint16_t* const QK = TB;  // (the candidates' blocks are in registers by now)
-            const double tlo = tref + (double)F / s;
+            const double tlo = tref + (double)F * inv_s;
             const double scale = 32766.0 * s * __builtin_amdgcn_rcp((double)meff);
             const double img = (own - tlo) * scale;
             const uint32_t qi = isev ? (uint32_t)l_pos(img) : 32767u;
@@ -582,6 +592,7 @@ __device__ __forceinline__ void trackl_body(const ZzRunParams& P) {
             slot = isev && cblk == bsel;
             rank = 0;
             nev = 1;
+            if (PROF) ph_ties += 1;
         }
         // ---------------- lane r = event r: everything moves over from its candidate's lane, pushed to lane `rank` (ds_permute)
         const uint32_t pdst = ((slot && rank < (uint32_t)nev) ? rank : 63u) << 2;
@@ -598,6 +609,10 @@ __device__ __forceinline__ void trackl_body(const ZzRunParams& P) {
         int C = nev;
         if (PROF) ph_iters += 1;
         if (PROF) ph_raw += (uint64_t)Cc;
+        if (PROF) ph_nev += (uint64_t)nev0;
+        if (PROF) ph_alias += (uint64_t)__popcll(__ballot(isc && ((int64_t)c_q - (int64_t)F >= 512)));
+        if (PROF) ph_near += (uint64_t)__popcll(__ballot(isc && !isev && ((int64_t)c_q - (int64_t)F < 512)));
+        if (PROF) ph_meff += (uint64_t)meff;
         asm volatile("" ::"v"(c_th), "v"(c_g), "v"(c_gd), "v"(c_tg), "v"(c_c), "v"(c_c100));
         if (C == 0) {
             // no key in the window (stale or revolved images refreshed): the front moves to its end
@@ -613,10 +628,14 @@ __device__ __forceinline__ void trackl_body(const ZzRunParams& P) {
                     break;
                 }
                 m = 1;
+                prev_base = 0;
+                prev_left = 0.0;
                 continue;
             }
             F += meff;
             m = (2 * meff < L_MMAX) ? 2 * meff : L_MMAX;
+            prev_base = 0;
+            prev_left = 0.0;
             continue;
         }
         bool ev = lane < C;
@@ -709,6 +728,7 @@ __device__ __forceinline__ void trackl_body(const ZzRunParams& P) {
                 C = (cut < C) ? cut : C;
             }
         }
+        if (PROF) ph_cut1 += (uint64_t)C;
         LPHASE(1);
         // at most L_AMAX accepted events per iteration: the candidate list ends before the next one
         {
@@ -719,6 +739,7 @@ __device__ __forceinline__ void trackl_body(const ZzRunParams& P) {
                 C = __ffsll((unsigned long long)m_) - 1;
             }
         }
+        if (PROF) ph_cut2 += (uint64_t)C;
         uint32_t rekey_by = 0xffffffffu;  // the first accepted later event that re-bounds this lane's coordinate (its key is then not this lane's to store)
         // ---------------- zones: an ACCEPTED event m disturbs a later event r within lattice distance 1 (r's sums change), at distance 2 if r is
         // accepted too (they share a neighbour).  The list ends at the first disturbed event.
@@ -806,7 +827,8 @@ __device__ __forceinline__ void trackl_body(const ZzRunParams& P) {
         const double2 sj0 = *reinterpret_cast<const double2*>(lj + 32 + 32 * pj);  // (θ, g)
         double2 sj1 = *reinterpret_cast<const double2*>(lj + 48 + 32 * pj);        // (gd, tg)
         double2 cjm2 = *reinterpret_cast<const double2*>(lj + 96 + 16 * pj);       // (c, c / 100)
-        asm volatile("" : "+v"(cjm2.x), "+v"(cjm2.y), "+v"(sj1.x), "+v"(sj1.y));
+        double kmate = *reinterpret_cast<const double*>(lj + 16 * (pj ^ 1u));      // the member's pair mate's key (same line: the line's new image, exactly)
+        asm volatile("" : "+v"(cjm2.x), "+v"(cjm2.y), "+v"(sj1.x), "+v"(sj1.y), "+v"(kmate));
         const double thj0 = sj0.x, gj0 = sj0.y, gdj0 = sj1.x, tgj = sj1.y;
         const double resta_b = l_shfl(rest, ea);  // the accepted event's pair mate's key
         // ---------------- ONE evaluation of the new bound and key per lane: the re-bound of a rejected proposal (:137-140) in its event lane, the
@@ -946,21 +968,25 @@ __device__ __forceinline__ void trackl_body(const ZzRunParams& P) {
                 const uint32_t cur = img_get(smem, bj);
                 const uint32_t rcur = (cur - fw) & 511u;
                 const bool inw = rcur < (uint32_t)meff;
+                // the pair mate's key as the line held it: beyond this window it is no event of this iteration, hence still the mate's key --
+                // the line's minimum is known exactly and its image is SET (a key that rose leaves nothing stale behind)
+                const bool trust = want0 && ((int64_t)tl_q(kmate, tref, s) - (int64_t)F >= (int64_t)meff);
+                const uint32_t wx = img_pos(l_min(keyj, kmate));
 #ifdef PDMP_TL_CHECK
-                if (want0 && chain == (int64_t)P.dbg_cap && bj == (uint32_t)P.hw_ahead) printf("W lower it %u F %d rn %u cur %u rcur %u keyj %.17g jm %u\n", (unsigned)prio.it, F, rn, cur, rcur, keyj, jm);
+                if (want0 && chain == (int64_t)P.dbg_cap && bj == (uint32_t)P.hw_ahead) printf("W lower it %u F %d rn %u cur %u rcur %u keyj %.17g jm %u kmate %.17g trust %d\n", (unsigned)prio.it, F, rn, cur, rcur, keyj, jm, kmate, (int)trust);
 #endif
                 // two lanes aiming at one line (the two coordinates of a pair, re-bounded by two accepted events) would mix their bytes and ninth
                 // bits: every acting lane claims its line in a 64-entry table first (EX is free by now); where a claim is lost -- or two lines
-                // share an entry -- the lanes act one after the other, each on what the one before left
-                const bool act = want0 && (inw || rn < rcur);
+                // share an entry -- the lanes act one after the other, each on what the one before left (lowering only: the mate's key is void)
+                const bool act = want0 && (trust || inw || rn < rcur);
                 unsigned char* const CL = smem + LL::EX;
                 if (act) CL[bj & 63u] = (unsigned char)lane;
                 L_ORDER();
                 const bool lost = act && CL[bj & 63u] != (unsigned char)lane;
                 if (__ballot(lost) == 0) {
-                    if (act) img_set(smem, bj, ((inw ? dn : rn) + fw) & 511u);
+                    if (act) img_set(smem, bj, trust ? wx : (((inw ? dn : rn) + fw) & 511u));
                 } else {
-                    uint64_t todo = __ballot(act);
+                    uint64_t todo = __ballot(want0);
                     while (todo) {
                         const int L0 = __ffsll((unsigned long long)todo) - 1;
                         todo &= todo - 1;
@@ -998,26 +1024,39 @@ __device__ __forceinline__ void trackl_body(const ZzRunParams& P) {
             status = PDMP_CHAIN_BOUND_VIOLATED;
         }
         if (status != PDMP_CHAIN_OK) break;
-        // ---------------- the next window: from the quantum of the last committed time to the end of this one, and further by as many quanta as
-        // the events still wanted are expected to take
+        // ---------------- the next window: what is left of this one -- from the quantum of the last committed time to its end: `left` events read
+        // and not committed -- and as many new quanta as the candidate lanes have room for, by the running means of what a new quantum brings
         {
             const int32_t Bend = F + meff;
+            const int32_t newq = meff - prev_base;  // new quanta this window took in (fewer than asked for where the list was cut)
+            if (newq >= 1) {
+                const double inv = __builtin_amdgcn_rcp((double)newq);
+                const double rawn = (double)Cc - 1.3 * prev_left, evn = (double)nev0 - prev_left;
+                rqf = l_uniform(rqf + (((rawn > 0.0) ? rawn : 0.0) * inv - rqf) * (1.0 / 16.0));
+                evq = l_uniform(evq + (((evn > 0.0) ? evn : 0.0) * inv - evq) * (1.0 / 16.0));
+            }
             F = Fn;
             const double left = (double)(nev0 - (int)Rc);
-            avgq = avgq + ((double)nev0 / (double)meff - avgq) * (1.0 / 32.0);
-            const double aq = (avgq > 1.0) ? avgq : 1.0;
-            double extra = floor((target_ev - left) / aq + 0.5);
-            extra = (extra > 0.0) ? ((extra < 64.0) ? extra : 64.0) : 0.0;
-            int32_t mn = (Bend - F) + (int32_t)extra;
+            const double room = raw_target - 1.3 * left;
+            double extra = (room > 0.0) ? floor(room * __builtin_amdgcn_rcp((rqf > 1.0) ? rqf : 1.0)) : 0.0;
+            if (extra < 1.0 && left < 12.0) extra = 1.0;
+            extra = (extra < 32.0) ? extra : 32.0;
+            prev_base = Bend - F;
+            prev_left = l_uniform(left);
+            const int32_t mn = prev_base + (int32_t)extra;
             m = (mn < 1) ? 1 : ((mn > L_MMAX) ? L_MMAX : mn);
             // the scale follows the density of events: a quantum should hold about targetq of them
             since_rescale += 1;
-            if (since_rescale >= 512u && (avgq > 1.5 * targetq || avgq < 0.5 * targetq)) {
-                s = l_uniform(s * avgq / targetq);
-                avgq = targetq;
+            if (since_rescale >= 512u && (evq > 1.5 * targetq || evq < 0.6 * targetq)) {
+                s = l_uniform(s * evq / targetq);
+                inv_s = l_uniform(1.0 / s);
+                evq = targetq;
+                rqf = 1.5 * targetq;
                 since_rescale = 0;
                 rebuild();
                 m = 1;
+                prev_base = 0;
+                prev_left = 0.0;
             }
         }
         L_ORDER();
@@ -1031,6 +1070,10 @@ __device__ __forceinline__ void trackl_body(const ZzRunParams& P) {
         P.dbg[13] = (double)ph_eval;
         P.dbg[14] = (double)ph_rounds;
         P.dbg[15] = (double)ph_guess;
+        printf("trackl chain 0: alias %llu near %llu meff %llu rqf %g\n", (unsigned long long)ph_alias, (unsigned long long)ph_near, (unsigned long long)ph_meff, rqf);
+        printf("trackl chain 0: iters %llu raw %llu nev %llu ties %llu after-ring %llu after-amax %llu after-zone %llu commits %u s %g avgq %g\n", (unsigned long long)ph_iters,
+               (unsigned long long)ph_raw, (unsigned long long)ph_nev, (unsigned long long)ph_ties, (unsigned long long)ph_cut1, (unsigned long long)ph_cut2,
+               (unsigned long long)ph_zone, dnum, s, evq);
     }
 #undef LPHASE
     if (lane == 0) {
