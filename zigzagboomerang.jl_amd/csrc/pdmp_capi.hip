@@ -144,7 +144,7 @@ struct pdmp_ensemble {
     // the line layout (pdmp_trackl.hip): full-width launches on the plain lattice run on d_tl_lines / d_tl_cold; d_rec / d_kp are brought up to
     // date (canon_stale) only when something reads the state -- final_state, the path-integral kernels, consume_begin
     bool track_lines = false, canon_stale = false;
-    int dbg_track_lines = -1;  // pdmp_debug_set_track_lines: -1 by ensemble width (more than LINES_MIN_CHAINS_PER_CU chains per CU), 0 never, 1 always
+    int dbg_track_lines = -1;  // pdmp_debug_set_track_lines: 1 = the line layout wherever it serves; -1 / 0 = never (it lost the A/B: DESIGN.md §5)
     DevBuf<pdmp::TrLine> d_tl_lines;
     DevBuf<pdmp::TrCold> d_tl_cold;
     // zz_local_spec8g_kernel's tables (any graph with |G1| <= 8, |S| <= 32; built with the blob)
@@ -1355,7 +1355,10 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
             G.d = d;
             const int64_t ncu = e->n_cu > 0 ? e->n_cu : 256;
             const bool wide = n > (int64_t)LINES_MIN_CHAINS_PER_CU * ncu;
-            if (pdmp::zz_trackl_supported(G) && !e->track_generic && (e->dbg_track_lines == 1 || (e->dbg_track_lines == -1 && wide))) {
+            // (measured, round 6: 2.7 instead of 3.2 lines read per proposal, but 72 instead of 54 vector instructions -- 47.9 ms against 45.4 / 38.8 ms
+            // for pdmp_trackp.hip's form on boxes in the slow / fast timing mode: the layout is kept as an opt-in form, never chosen by width)
+            (void)wide;
+            if (pdmp::zz_trackl_supported(G) && !e->track_generic && e->dbg_track_lines == 1) {
                 if (e->d_tl_lines.n != (size_t)(n * e->dk / 2) && (st = e->d_tl_lines.alloc((size_t)(n * e->dk / 2))) != PDMP_OK) return st;
                 if (e->d_tl_cold.n != (size_t)(n * e->dk) && (st = e->d_tl_cold.alloc((size_t)(n * e->dk))) != PDMP_OK) return st;
                 rc = pdmp::launch_zz_trackl_pack(e->d_rec.p, e->d_kp.p, e->d_tl_lines.p, e->d_tl_cold.p, d, e->dk, n, e->stream);

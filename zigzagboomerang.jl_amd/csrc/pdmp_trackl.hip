@@ -1070,10 +1070,6 @@ __device__ __forceinline__ void trackl_body(const ZzRunParams& P) {
         P.dbg[13] = (double)ph_eval;
         P.dbg[14] = (double)ph_rounds;
         P.dbg[15] = (double)ph_guess;
-        printf("trackl chain 0: alias %llu near %llu meff %llu rqf %g\n", (unsigned long long)ph_alias, (unsigned long long)ph_near, (unsigned long long)ph_meff, rqf);
-        printf("trackl chain 0: iters %llu raw %llu nev %llu ties %llu after-ring %llu after-amax %llu after-zone %llu commits %u s %g avgq %g\n", (unsigned long long)ph_iters,
-               (unsigned long long)ph_raw, (unsigned long long)ph_nev, (unsigned long long)ph_ties, (unsigned long long)ph_cut1, (unsigned long long)ph_cut2,
-               (unsigned long long)ph_zone, dnum, s, evq);
     }
 #undef LPHASE
     if (lane == 0) {
