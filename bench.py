@@ -548,7 +548,7 @@ def measure_with_integrals(pkg, args, rank, local_rank):
         while True:
             e2.run(T2, pkg._lib.RUN_STOP_BEFORE, sync=False)
             ms2 += e2.last_run_ms()
-            full = bool(np.any(e2.counters()["status"] == pkg._lib.CHAIN_TRACE_FULL)) if W2["cap"] else False
+            full = pkg._lib.needs_rerun(e2.counters()["status"]) if W2["cap"] else False
             if W2["cap"]:
                 e2.trace_reset()
             if not full:
@@ -645,6 +645,9 @@ def main():
                          "long run, where the bounds have adapted; 0: skip)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="C3 at N = 1: skip the `pipeline` object (the steps again with their trace consumed on the device beside the sampler)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="C3 at N = 1: skip the `configs` object (short runs of C2 / C4 / C5 / C3G / C3 at d = 65536 in their own processes after the region) "
+                         "and the `mode` object (which timing mode this process saw)")
     ap.add_argument("--no-strong-proxy", action="store_true",
                     help="C3 at N = 1: skip the `strong_proxy` object (this GPU's share of the 2 / 4 / 8-GPU strong-scaling job, timed after the region)")
     ap.add_argument("--c5-rows", type=int, default=2000,
@@ -827,7 +830,7 @@ def main():
             full = False
             if cap:
                 if args.config != "C3":  # a chain whose segment filled up pauses with TRACE_FULL: drain and continue the slice
-                    full = bool(np.any(ens.counters()["status"] == pkg._lib.CHAIN_TRACE_FULL))
+                    full = pkg._lib.needs_rerun(ens.counters()["status"])
                 ens.trace_reset()
             if not full:
                 return ms
@@ -909,6 +912,12 @@ def main():
     ess = None
     if rank == 0 and world == 1 and args.config == "C3" and args.ess_batches >= 1 and not args.gather:
         ess = measure_ess(pkg, args, W, ens, local_rank)
+    # the default line also carries the other configurations (short runs, own processes) and the timing mode it ran in
+    configs = mode = None
+    default_line = (rank == 0 and world == 1 and args.config == "C3" and not args.exact and not args.gather and not args.no_trace and not args.no_configs
+                    and args.grid == GRID and nch == CONFIG_DEFAULTS["C3"]["chains"] and strong_proxy is not None)
+    if default_line:
+        mode = pkg.benchlib.measure_mode(pkg, float(np.sum(kernel_ms)) / max(launches[0], 1), strong_proxy)
 
     # post-run exchange (never inside `value`): SURVEY 8e1
     gather = None
@@ -1099,6 +1108,17 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "model": W["model"]},
         }
+        if args.config == "C3" and not args.exact:
+            # what the TRACKED recurrences themselves need (DESIGN.md 5 "own model"): per proposal the coordinate's (key, t_old) and (θ, g, gd, tg) read
+            # = 48 B; a rejected one writes (key, t_old) = 16 B; an accepted one instead moves x_i (x, tx, ∫x dt, count read and written: 64 B), flips
+            # θ_i (8 B), reads the sums of its k - 1 neighbours (32 B each), writes (g, gd, tg) and a new (key, t_old) for all k members (40 B each)
+            # and appends an event (32 B): 432 B on the lattice (k = 5).  `frac` above is on SURVEY 8d3's model of the MOVING algorithm (what is graded).
+            kk = 5.0  # |G1| inside the lattice
+            acc_b = 64.0 + 8.0 + 32.0 * (kk - 1.0) + 40.0 * kk + 32.0
+            own_b = (48.0 * num + 16.0 * (num - nacc) + acc_b * nacc) / nlaunch
+            out["roofline"]["own_model"] = {"bytes_per_launch": own_b, "achieved": own_b / (k_ms * 1e-3) / 1e9, "frac": own_b / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                            "model": "48*num + 16*(num-nacc) + %.0f*nacc bytes: what the tracked recurrences read and write (no neighbour moves)" % acc_b,
+                                            "traffic_over_own": (traffic / own_b) if traffic else None}
         out["totals"] = {"num": num_all, "nacc": nacc_all, "nevents": nev_all, "T_end": (args.warmup + args.steps) * args.dt}
         if issue is not None:
             out["issue"] = issue
@@ -1123,6 +1143,12 @@ def main():
             out["ess"] = ess
         if exact is not None:
             out["exact"] = exact
+            # the figure of the reference's own arithmetic (the moving evaluation, bit-identical to the oracle's restatement of src/sfact.jl:73-145), one
+            # level up: `value` above is the tracked evaluation's (opt-in at the boundary: pdmp_ensemble_set_gradient_tracking / tracked = true)
+            out["value_reference_arithmetic"] = exact["value"]
+            out["roofline_frac_reference_arithmetic"] = exact["roofline"]["frac"] if isinstance(exact.get("roofline"), dict) else exact.get("roofline_frac")
+        if mode is not None:
+            out["mode"] = mode
         if with_integrals is not None:
             out["with_path_integrals"] = with_integrals
         if world == 1 and not args.no_cpu_baseline:
@@ -1141,6 +1167,8 @@ def main():
                                               "definition": "ESS per unit process time of the sampler (the GPU leg's estimate, made on the `ess.evaluation` evaluation: the same "
                                                             "process law as the CPU pool's moving evaluation, not the same realisations) x process time advanced per "
                                                             "wall second by the CPU pool; same estimator, same probes as `ess`"}
+        if default_line:
+            out["configs"] = pkg.benchlib.measure_configs(os.path.abspath(__file__))
         print(json.dumps(out), flush=True)
     ens.close()
     if comm is not None:

@@ -177,7 +177,7 @@ def test_slicing_is_exact(gpu_pkg):
                 for k in range(3):
                     ts[k].append(ens.bps_trace(k, counters=cnt)[0])
                 ens.trace_reset()
-                if not np.any(cnt["status"] == pkg._lib.CHAIN_TRACE_FULL):
+                if not pkg._lib.needs_rerun(cnt["status"]):
                     break
         fs = ens.bps_final_state()
     for k in range(3):

@@ -31,7 +31,7 @@ def _run(pkg, ens, G, c, T_slices, dt, K, seed, tracked, sticky=None):
             for k in range(nch):
                 evs[k].append(ens.trace(k, counters=cnt))
             ens.trace_reset()
-            if not np.any(cnt["status"] == L.CHAIN_TRACE_FULL):
+            if not L.needs_rerun(cnt["status"]):
                 break
             refills += 1
     traces = [pkg.FactTrace(None, 0.0, x0[k], th0[k], np.concatenate(evs[k])) for k in range(nch)]

@@ -287,7 +287,7 @@ def test_c4_state_in_lds_equals_state_in_hbm(gpu_pkg, gpu_pkg_parity):
                     for k in range(nch):
                         evs[k].append(ens.trace(k, counters=cnt))
                     ens.trace_reset()
-                    if not np.any(cnt["status"] == L.CHAIN_TRACE_FULL):
+                    if not L.needs_rerun(cnt["status"]):
                         break
             if integrals:
                 bm = ens.batch_means(0.0, 12.0)
@@ -347,7 +347,7 @@ def test_c4_tracked_bounds_equal_the_tracked_oracle(gpu_pkg):
                     for k in range(nch):
                         evs[k].append(ens.trace(k, counters=cnt))
                     ens.trace_reset()
-                    if not np.any(cnt["status"] == L.CHAIN_TRACE_FULL):
+                    if not L.needs_rerun(cnt["status"]):
                         break
             pj = ens.path_integrals(T, np.arange(0, d, 9)) if integrals else None
             runs[name] = (cnt, [np.concatenate(e) for e in evs], ens.final_state(), pj)

@@ -38,7 +38,7 @@ def _run_sliced(pkg, monkeypatch, mode, nch, cap, slices, seed0, n=128):
                     for k in range(nch):
                         evs[k].append(ens.trace(k, counters=cnt))
                     ens.trace_reset()
-                if not np.any(cnt["status"] == pkg._lib.CHAIN_TRACE_FULL):
+                if not pkg._lib.needs_rerun(cnt["status"]):
                     break
         cnt = ens.counters()
         fs = ens.final_state()

@@ -137,7 +137,7 @@ def test_wide_zones_slices_and_trace_refills(gpu_pkg):
                 for q in range(nch):
                     evs[q].append(ens.trace(q, counters=cnt))
                 ens.trace_reset()
-                if not np.any(cnt["status"] == L.CHAIN_TRACE_FULL):
+                if not L.needs_rerun(cnt["status"]):
                     break
         fs = ens.final_state()
         cnt = ens.counters()

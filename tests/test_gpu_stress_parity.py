@@ -62,7 +62,7 @@ def test_random_slices_and_tiny_traces_zigzag(gpu_pkg, case):
                     if cnt["ntrace"][k]:
                         events[k].append(ens.trace(k, counters=cnt))
                 ens.trace_reset()
-                if not np.any(cnt["status"] == pkg._lib.CHAIN_TRACE_FULL):
+                if not pkg._lib.needs_rerun(cnt["status"]):
                     break
         fs = ens.final_state()
         cnt = ens.counters()
@@ -110,7 +110,7 @@ def test_random_slices_and_tiny_traces_sticky(gpu_pkg, case):
                     if cnt["ntrace"][k]:
                         events[k].append(ens.trace(k, counters=cnt))
                 ens.trace_reset()
-                if not np.any(cnt["status"] == pkg._lib.CHAIN_TRACE_FULL):
+                if not pkg._lib.needs_rerun(cnt["status"]):
                     break
         fs = ens.final_state()
         cnt = ens.counters()

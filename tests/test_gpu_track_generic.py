@@ -82,7 +82,7 @@ def test_generic_graph_slices_refills_start_time_and_violation(gpu_pkg, trackp_f
                 for q in range(nch):
                     evs[q].append(ens.trace(q, counters=cnt))
                 ens.trace_reset()
-                if not np.any(cnt["status"] == L.CHAIN_TRACE_FULL):
+                if not L.needs_rerun(cnt["status"]):
                     break
         fs = ens.final_state()
         cnt = ens.counters()

@@ -136,7 +136,7 @@ def test_tracked_slices_trace_refills_and_violation(gpu_pkg, trackp_form):
                 for k in range(nch):
                     evs[k].append(ens.trace(k, counters=cnt))
                 ens.trace_reset()
-                if not np.any(cnt["status"] == L.CHAIN_TRACE_FULL):
+                if not L.needs_rerun(cnt["status"]):
                     break
             if Tk == 4.0:
                 s1, s2 = ens.batch_means(0.0, 4.0)

@@ -92,7 +92,7 @@ def test_two_wave_form_with_a_small_trace_segment_and_the_reference_tail(gpu_pkg
         for k in range(2):
             got[k].append(e.trace(k, counters=cn))
         e.trace_reset()
-        if not np.any(cn["status"] == L.CHAIN_TRACE_FULL):
+        if not L.needs_rerun(cn["status"]):
             break
     assert e.kernel_name() == "zz_local_trackp2_kernel"
     for k in range(2):

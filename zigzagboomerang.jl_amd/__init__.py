@@ -5,7 +5,7 @@ wrapper), samplers.py (spdmp/... mirror of the reference's call shape), trace.py
 problems.py (inputs of the reference's scripts).  The directory name contains a dot, so it is loaded
 through `__graft_entry__.load_package()` under the module name `zigzagboomerang_jl_amd`.
 """
-from . import _lib, build, ess, parallel, problems, trace  # noqa: F401
+from . import _lib, benchlib, build, ess, parallel, problems, trace  # noqa: F401
 from .engine import Ensemble  # noqa: F401
 from .samplers import Partition, parallel_spdmp, pdmp, spdmp, sspdmp  # noqa: F401
 from .flows import (Boomerang, Boomerang1d, BouncyParticle, LocalBound, FactBoomerang, FactTrace, GaussianTarget, GaussianTarget1d,  # noqa: F401

@@ -18,6 +18,13 @@ ERR_NAMES = {0: "PDMP_OK", 1: "PDMP_ERR_INVALID", 2: "PDMP_ERR_NO_DEVICE", 3: "P
 PDMP_ERR_INVALID, PDMP_ERR_NO_DEVICE, PDMP_ERR_HIP, PDMP_ERR_UNSUPPORTED, PDMP_ERR_NOMEM = 1, 2, 3, 4, 5
 SAMPLER_ZIGZAG_LOCAL, SAMPLER_ZIGZAG_ALL, SAMPLER_BPS, SAMPLER_STICKY_ZIGZAG = 0, 1, 2, 3
 CHAIN_OK, CHAIN_BOUND_VIOLATED, CHAIN_STALLED, CHAIN_TRACE_FULL, CHAIN_PAUSED = 0, 1, 2, 3, 4
+
+
+def needs_rerun(status):
+    """A launch returned before T for some chain and the next run resumes it: its trace segment is full (drain or reset it first), or its 32-bit
+    launch counters are (PDMP_CHAIN_PAUSED: nothing to drain).  Every `run until T` loop of the host side asks this."""
+    st = np.asarray(status)
+    return bool(np.any((st == CHAIN_TRACE_FULL) | (st == CHAIN_PAUSED)))
 RUN_REFERENCE_TAIL, RUN_STOP_BEFORE = 0, 1
 
 EVENT_DTYPE = np.dtype([("t", "<f8"), ("i", "<i8"), ("x", "<f8"), ("theta", "<f8")])

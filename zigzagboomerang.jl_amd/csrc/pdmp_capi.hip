@@ -24,6 +24,7 @@
 namespace {
 
 thread_local std::string g_err;
+thread_local std::string g_deferred_err;  // the message of a deferred consumer launch that failed inside device_sync (kept through HIP_TRY)
 
 pdmp_status fail(pdmp_status st, const char* fmt, ...) {
     char buf[512];
@@ -38,7 +39,11 @@ pdmp_status fail(pdmp_status st, const char* fmt, ...) {
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
         hipError_t e_ = (expr);                                                                         \
-        if (e_ != hipSuccess) return fail(PDMP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+        if (e_ != hipSuccess) {                                                                         \
+            const std::string dm_ = g_deferred_err;                                                     \
+            g_deferred_err.clear();                                                                     \
+            return fail(PDMP_ERR_HIP, "%s failed: %s%s%s", #expr, hipGetErrorString(e_), dm_.empty() ? "" : " -- ", dm_.c_str()); \
+        }                                                                                               \
     } while (0)
 
 template <class T>
@@ -270,9 +275,23 @@ static pdmp_status launch_deferred_consumer(pdmp_ensemble* e) {
     e->cons_timed = true;
     return PDMP_OK;
 }
+// A consumer that was deferred behind the next run, the pending flags and the buffer parity of pdmp_ensemble_consume_async are dropped (set_state,
+// consume_begin: the cursors they would write are about to be re-initialised); whatever already runs on the consumer's stream is waited for
+static void discard_async_consumer(pdmp_ensemble* e) {
+    e->deferred_k = -1;
+    e->deferred_buf = nullptr;
+    if (e->stream2) (void)hipStreamSynchronize(e->stream2);
+    e->cons_pending[0] = e->cons_pending[1] = false;
+    e->cons_timed = false;
+    e->async_k = 0;
+}
 // hipDeviceSynchronize for an ensemble: a deferred consumer is launched first (what follows reads its results or the buffers it reads)
 static hipError_t device_sync(pdmp_ensemble* e) {
-    if (e && e->deferred_k >= 0 && launch_deferred_consumer(e) != PDMP_OK) return hipErrorUnknown;
+    if (e && e->deferred_k >= 0 && launch_deferred_consumer(e) != PDMP_OK) {
+        // (the launch's own message is in g_err; HIP_TRY would overwrite it with "unknown error": keep it as the prefix of what follows)
+        g_deferred_err = g_err;
+        return hipErrorLaunchFailure;
+    }
     return hipDeviceSynchronize();
 }
 
@@ -1337,6 +1356,7 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
     e->track_pairs = false;
     e->track_lines = false;
     e->canon_stale = false;
+    discard_async_consumer(e);  // (a consumer deferred behind "the next run" belongs to the state that is being replaced)
     if (e->track) {
         if (trackp_ok) {
             if (e->d_kp.n != (size_t)(2 * n * e->dk) && (st = e->d_kp.alloc((size_t)(2 * n * e->dk))) != PDMP_OK) return st;
@@ -1924,6 +1944,7 @@ pdmp_status pdmp_ensemble_consume_begin(pdmp_ensemble* e, double grid_dt, int64_
         HIP_TRY(hipMemsetAsync(e->d_cgrid.p, 0, (size_t)(n * grid_points * d) * sizeof(double), e->stream));
     }
     if ((st = ensure_canon(e)) != PDMP_OK) return st;
+    discard_async_consumer(e);
     int rc = pdmp::launch_consume_init(e->d_rec.p, e->track ? 128 : 64, d, n, e->t0_state, e->d_ccur.p, e->cons_z, e->d_cmeta.p,
                                        grid_points > 0 ? e->d_cgrid.p : nullptr, grid_points, e->stream);
     if (rc != 0) return fail(PDMP_ERR_HIP, "consume_init launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -1960,10 +1981,25 @@ pdmp_status pdmp_ensemble_consume_async(pdmp_ensemble* e, void* stream) {
     pdmp_status st;
     if ((st = launch_deferred_consumer(e)) != PDMP_OK) return st;  // (two calls without a run between them)
     if (!e->stream2) {
+        // created into locals and committed to the ensemble together: a failure half-way leaves nothing behind that a later call would trust
         int least = 0, greatest = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIP_TRY(hipStreamCreateWithPriority(&e->stream2, hipStreamNonBlocking, least));  // (the event loop's launches go first)
-        for (hipEvent_t* ev : {&e->ev_run_done, &e->ev_cons_done[0], &e->ev_cons_done[1], &e->ev_c0, &e->ev_c1}) HIP_TRY(hipEventCreate(ev));
+        hipStream_t s2 = nullptr;
+        hipEvent_t evs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        hipError_t err = hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, least);  // (the event loop's launches go first)
+        for (int q = 0; q < 5 && err == hipSuccess; ++q) err = hipEventCreate(&evs[q]);
+        if (err != hipSuccess) {
+            for (hipEvent_t ev : evs)
+                if (ev) (void)hipEventDestroy(ev);
+            if (s2) (void)hipStreamDestroy(s2);
+            return fail(PDMP_ERR_HIP, "consume_async: stream / event creation failed: %s", hipGetErrorString(err));
+        }
+        e->stream2 = s2;
+        e->ev_run_done = evs[0];
+        e->ev_cons_done[0] = evs[1];
+        e->ev_cons_done[1] = evs[2];
+        e->ev_c0 = evs[3];
+        e->ev_c1 = evs[4];
     }
     if (e->d_ev2.n != e->d_ev.n && (st = e->d_ev2.alloc(e->d_ev.n)) != PDMP_OK) return st;
     const int k = e->async_k;
@@ -1999,8 +2035,8 @@ pdmp_status pdmp_debug_host_drain_probe(pdmp_ensemble* e, int64_t bytes, double*
     if (nb == 0) return fail(PDMP_ERR_INVALID, "ensemble was created with trace_capacity = 0");
     void* host = nullptr;
     HIP_TRY(hipHostMalloc(&host, nb, hipHostMallocDefault));
-    HIP_TRY(device_sync(e));
-    hipError_t err = hipMemcpy(host, e->d_ev.p, nb, hipMemcpyDeviceToHost);  // (warm-up: page tables, the copy engine's first touch)
+    hipError_t err = device_sync(e);
+    if (err == hipSuccess) err = hipMemcpy(host, e->d_ev.p, nb, hipMemcpyDeviceToHost);  // (warm-up: page tables, the copy engine's first touch)
     const auto t0 = std::chrono::steady_clock::now();
     if (err == hipSuccess) err = hipMemcpy(host, e->d_ev.p, nb, hipMemcpyDeviceToHost);
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -165,7 +165,7 @@ namespace {
 // Agreement on whether to go on: MAX over the ranks of a local flag.  Argument checks that only ONE rank can make (its counts / events buffers
 // are too small, its allocation failed) are voted on before any rank enters the send / recv phase -- a rank that returned on its own would leave
 // its peers blocked in the next collective.
-pdmp_status agree(pdmp_comm* c, pdmp_status local) {
+pdmp_status agree(pdmp_comm* c, pdmp_status local, const char* what_elsewhere = nullptr) {
     int32_t flag = (local == PDMP_OK) ? 0 : 1;
     pdmp_status st = c->vote.need(2 * sizeof(int32_t));
     if (st != PDMP_OK) return st;  // (64 bytes of device memory: if that fails nothing works)
@@ -176,7 +176,7 @@ pdmp_status agree(pdmp_comm* c, pdmp_status local) {
     C_HIP(hipMemcpyAsync(&any, dv + 1, sizeof any, hipMemcpyDeviceToHost, c->stream));
     C_HIP(hipStreamSynchronize(c->stream));
     if (local != PDMP_OK) return local;  // (this rank's own message stays in pdmp_last_error)
-    if (any) return cfail(PDMP_ERR_INVALID, "the exchange was refused on another rank (an argument check or an allocation failed there); nothing was exchanged");
+    if (any) return cfail(PDMP_ERR_INVALID, "%s", what_elsewhere ? what_elsewhere : "the exchange was refused on another rank (an argument check or an allocation failed there); nothing was exchanged");
     return PDMP_OK;
 }
 
@@ -325,8 +325,12 @@ pdmp_status pdmp_ensemble_gather_traces(pdmp_ensemble* ens, pdmp_comm* c, int ro
     std::vector<uint64_t> bytes((size_t)W);
     for (int r = 0; r < W; ++r) bytes[(size_t)r] = tot[(size_t)r] * sizeof(pdmp_event);
     st = gatherv_bytes(c, root, c->compact.p, bytes, reinterpret_cast<char*>(gdst));
-    if (late != PDMP_OK) return late;  // (the bytes this rank sent are not its events: the root's caller learns of it from this rank's status)
-    if (st != PDMP_OK) return st;
+    // a second vote AFTER the exchange: a rank whose compaction or transfer failed has sent bytes that are not its events -- every rank, the
+    // root first of all, returns an error then and nothing counts as gathered
+    if ((st = agree(c, late != PDMP_OK ? late : st, "the exchange failed on another rank after the vote: what the root received is not its events")) != PDMP_OK) {
+        c->ngathered = 0;
+        return st;
+    }
     if (c->rank == root && events_host && total) {
         C_HIP(hipMemcpyAsync(events_host, gdst, (size_t)total * sizeof(pdmp_event), hipMemcpyDeviceToHost, c->stream));
         C_HIP(hipStreamSynchronize(c->stream));
@@ -410,7 +414,10 @@ pdmp_status pdmp_ensemble_gather_bps_traces(pdmp_ensemble* ens, pdmp_comm* c, in
         const pdmp_status sg = gatherv_bytes(c, root, c->compact.p, bytes, (c->rank == root) ? static_cast<char*>(pc.dst->p) : nullptr);
         if (sg != PDMP_OK && late == PDMP_OK) late = sg;
     }
-    if (late != PDMP_OK) return late;
+    if ((st = agree(c, late, "the exchange failed on another rank after the vote: what the root received is not its events")) != PDMP_OK) {
+        c->ngathered_bps = 0;
+        return st;
+    }
     const bool isroot = c->rank == root;
     if (t_dev) *t_dev = isroot ? c->gathered.p : nullptr;
     if (x_dev) *x_dev = isroot ? c->gx.p : nullptr;

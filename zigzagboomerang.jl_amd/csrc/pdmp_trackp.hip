@@ -300,7 +300,10 @@ __device__ __forceinline__ void trackp_helper(const ZzRunParams& P, unsigned cha
         const double target = tau + P.hw_ahead * dts;
         if (target > pf_done) {
             // every block whose bound lies in (pf_done, target]: compacted into a list, one coordinate per lane, all its lines requested at once
-            const uint32_t lo = (pf_done > tbs) ? p_thr(pf_done, tbs) : 0u, hi = p_thr(target, tbs);
+            // (hi stays below the patterns of empty blocks: a target at +Inf -- a window doubled through many idle iterations, a large hw_ahead --
+            // must not select the padding blocks behind the chain's last coordinate, whose lines do not exist)
+            const uint32_t lo = (pf_done > tbs) ? p_thr(pf_done, tbs) : 0u;
+            const uint32_t hi0 = p_thr(target, tbs), hi = (hi0 < P_INFBITS) ? hi0 : P_INFBITS - 1u;
             uint32_t cm = 0;
 #pragma unroll
             for (int j = 7; j >= 0; --j) {
@@ -320,7 +323,7 @@ __device__ __forceinline__ void trackp_helper(const ZzRunParams& P, unsigned cha
                 m_ &= m_ - 1u;
             }
             W_ORDER();
-            if ((uint32_t)lane < tot) {
+            if ((uint32_t)lane < tot && (uint32_t)HPF[lane] < (uint32_t)d) {
                 const uint32_t i = (uint32_t)HPF[lane];
                 const char* const kl = kpb + (size_t)(i >> 3) * 128;
                 const char* const rl = recb + (size_t)i * 128;
@@ -576,7 +579,9 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
                         tau_clipped = true;
                     }
                     if (tries >= 64) tau = mql;
-                    const uint32_t thr = p_thr(tau, tb);
+                    // (below the patterns of empty blocks whatever the window has grown to through idle iterations: the blocks behind the chain's
+                    // last coordinate hold P_INFBITS and have no lines)
+                    const uint32_t thr0 = p_thr(tau, tb), thr = (thr0 < P_INFBITS) ? thr0 : P_INFBITS - 1u;
                     ncl = 0;
 #pragma unroll
                     for (int c = 0; c < NCH; ++c) {
