@@ -224,6 +224,60 @@ def test_refresh_clock_matches_oracle(gpu_pkg):
             assert np.array_equal(acc[k], r["acc"])
 
 
+@pytest.mark.parametrize("n,T,lam", [(48, 3.0, 2.0), (128, 1.0, 3.0)])
+def test_refresh_clock_on_the_speculative_kernel(gpu_pkg, monkeypatch, n, T, lam):
+    """λref > 0 at d = 2304 and d = 16384 (round 6): the 4-event kernel takes the run -- the clock's events are processed by themselves between its
+    speculative iterations (src/sfact.jl:78-114) -- and commits, bit for bit, what the one-event kernel and the oracle do: events (reflections and
+    refreshes, in order), counters, both random streams' positions, final state; with slices and a trace that refills."""
+    pkg = gpu_pkg
+    L = pkg._lib
+    G = pkg.problems.gmrf_precision(n)
+    d = n * n
+    rng = np.random.default_rng(n)
+    sig = 0.5 + rng.random(d)
+    nch = 3
+    x0 = rng.standard_normal((nch, d))
+    th0 = sig * rng.choice([-1.0, 1.0], (nch, d))
+    c = 1.5 * pkg.problems.column_norms(G)
+    seeds = [977 + k for k in range(nch)]
+    res = {}
+    for kern in ("auto", "seq"):
+        with pkg.Ensemble(nch, d, trace_capacity=4000) as ens:
+            ens.debug_set_kernel(kern)
+            ens.set_flow(pkg.ZigZag(G, np.zeros(d), sig, λref=lam))
+            ens.set_target(pkg.GaussianTarget(G))
+            ens.set_state(0.0, x0, th0, c, seeds)
+            evs = [[] for _ in range(nch)]
+            for Tk, flag in ((0.4 * T, L.RUN_STOP_BEFORE), (T, L.RUN_REFERENCE_TAIL)):
+                while True:
+                    ens.run(Tk, flag)
+                    cnt = ens.counters()
+                    for k in range(nch):
+                        evs[k].append(ens.trace(k, counters=cnt))
+                    ens.trace_reset()
+                    if not L.needs_rerun(cnt["status"]):
+                        break
+            assert ens.kernel_name() == ("zz_local_run_kernel" if kern == "seq" else "zz_local_spec_kernel"), ens.kernel_name()
+            res[kern] = ([np.concatenate(e) for e in evs], cnt, ens.final_state())
+    for f in ("num", "nacc", "nevents", "nrefresh", "ndraw_main", "ndraw_global", "status"):
+        assert np.array_equal(res["auto"][1][f], res["seq"][1][f]), f
+    for k in range(nch):
+        for f in ("i", "t", "x", "theta"):
+            assert np.array_equal(res["auto"][0][k][f], res["seq"][0][k][f]), (k, f)
+        for f in ("t", "x", "theta", "acc"):
+            assert np.array_equal(res["auto"][2][f][k], res["seq"][2][f][k]), (k, f)
+    # the oracle: the reference-tail run to T in one piece (slices only cut the launches)
+    for k in (0, nch - 1):
+        r = O.spdmp_zigzag(G, None, G, x0[k], th0[k], c, T, seed=seeds[k], lambda_ref=lam, sigma=sig)
+        assert r["status"] == 0 and r["nrefresh"] >= 2
+        ev = res["auto"][0][k]
+        assert len(ev) == len(r["events"]), (len(ev), len(r["events"]))
+        for f in ("i", "t", "x", "theta"):
+            assert np.array_equal(ev[f], r["events"][f]), (k, f)
+        assert int(res["auto"][1]["num"][k]) == r["num"] and int(res["auto"][1]["nrefresh"][k]) == r["nrefresh"]
+        assert np.array_equal(res["auto"][2]["x"][k], r["x"]) and np.array_equal(res["auto"][2]["theta"][k], r["theta"])
+
+
 def test_pdmp_all_matches_oracle(gpu_pkg):
     """pdmp = spdmp with G = All() (src/sfact.jl:236): all coordinates move at every proposal."""
     pkg = gpu_pkg

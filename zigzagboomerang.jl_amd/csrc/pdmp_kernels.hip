@@ -1421,6 +1421,8 @@ __device__ __forceinline__ void zz_local_spec_body(const ZzRunParams& P_in) {
     const uint64_t seed = hdr->seed;
     const uint64_t nm0 = hdr->c.ndraw_main, ntrace0 = hdr->c.ntrace;
     uint32_t dnm = 0, dnum = 0, dnacc = 0;  // 32-bit deltas of this launch (a launch advances a chain by far < 2^32 draws)
+    uint32_t dnref = 0;                     // refresh events of this launch (recorded in the trace like reflections, src/sfact.jl:143)
+    uint64_t ng = hdr->c.ndraw_global;      // the "global rng" stream of the refresh clock (:80,:84,:108)
     uint32_t vnacc = 0;                     // 1 if the launch ends on a bound violation (acc is bumped before the check)
     double t_last = hdr->c.t_last;
     double t_event = hdr->t_event;
@@ -1467,7 +1469,7 @@ __device__ __forceinline__ void zz_local_spec_body(const ZzRunParams& P_in) {
     PrioTurn prio;
     while (running) {
         prio.step();
-        if (dnacc >= trace_room) {
+        if (dnacc + dnref >= trace_room) {
             status = PDMP_CHAIN_TRACE_FULL;
             break;
         }
@@ -1477,12 +1479,151 @@ __device__ __forceinline__ void zz_local_spec_body(const ZzRunParams& P_in) {
         }
         // ---------------- select up to E candidate events (spec_select)
         bool first_inf;
-        const int Esel = spec_select<NE, E, PLAIN && NE == 4>(bk, nblk, lane, stop_before, T, SLT, SLH, SLB, first_inf);
+        int Esel = spec_select<NE, E, PLAIN && NE == 4>(bk, nblk, lane, stop_before, T, SLT, SLH, SLB, first_inf);
         if (Esel == 0) {
             if (first_inf) status = PDMP_CHAIN_STALLED;
             break;
         }
         LDS_ORDER();
+        if (P.has_refresh) {
+            // ---------------- the refresh clock (key d, src/sfact.jl:78-114) among the candidates: the events before it go through the speculative
+            // iteration as usual; once it is the chain's NEXT event it is processed by itself, the whole wave on one event, exactly as
+            // zz_local_run_kernel does (a refresh moves the neighbourhood of one random coordinate and re-bounds that of another: no zone
+            // test covers it, and at rate λref against thousands of proposals per unit time it need not be fast)
+            const uint64_t rfb = __ballot(g < Esel && gl == 0 && bi[SLB[g]] == (uint32_t)d);
+            if (rfb) {
+                const int rg = (__ffsll((unsigned long long)rfb) - 1) >> 4;
+                if (rg > 0) {
+                    Esel = rg;
+                } else {
+                    const double tp = uniform_f64(SLT[0]);
+                    uint64_t* const lb0 = reinterpret_cast<uint64_t*>(smem + O_LB);
+                    double* const sx0 = reinterpret_cast<double*>(smem + O_SX);
+                    double* const sth0 = reinterpret_cast<double*>(smem + O_STH);
+                    const uint64_t nm = nm0 + (uint64_t)dnm;
+                    t_last = tp;
+                    const uint32_t i1 = pdmp_randint(seed, PDMP_STREAM_GLOBAL, ng, (uint32_t)d);  // :80
+                    ng += 1;
+                    {
+                        const uint64_t* bsrc = P.blob + (size_t)P.tix[i1] * P.blob_w_pad;
+                        for (uint32_t w = lane; w < P.blob_w; w += 64) lb0[w] = bsrc[w];
+                        LDS_ORDER();
+                        const int k1 = (int)uniform_u32((uint32_t)(lb0[0] & 0xff));
+                        if (lane < k1) {  // smove_forward!(G, i1, ...), :82
+                            const uint64_t sw = lb0[1 + (lane >> 1)];
+                            const uint32_t s1 = i1 + ((lane & 1) ? (uint32_t)(sw >> 32) : (uint32_t)sw);
+                            ZzRec* r1 = rec + s1;
+                            const double x0 = r1->x, th0 = r1->th, t0 = r1->t, I0 = r1->I;
+                            const double dt = tp - t0;
+                            const double xn = x0 + th0 * dt;
+                            r1->x = xn;
+                            r1->t = tp;
+                            r1->I = I0 + dt * ((x0 + xn) * 0.5);
+                        }
+                        LDS_ORDER();
+                    }
+                    const uint32_t i2 = pdmp_randint(seed, PDMP_STREAM_GLOBAL, ng, (uint32_t)d);  // :84
+                    ng += 1;
+                    {
+                        const uint64_t* bsrc = P.blob + (size_t)P.tix[i2] * P.blob_w_pad;
+                        for (uint32_t w = lane; w < P.blob_w; w += 64) lb0[w] = bsrc[w];
+                    }
+                    LDS_ORDER();
+                    const uint64_t hw = lb0[0];
+                    const int k = (int)uniform_u32((uint32_t)(hw & 0xff));
+                    const int m = (int)uniform_u32((uint32_t)((hw >> 8) & 0xff));
+                    const int self = (int)uniform_u32((uint32_t)((hw >> 16) & 0xff));
+                    const int kjmax = (int)uniform_u32((uint32_t)((hw >> 24) & 0xff));
+                    uint32_t s = i2;
+                    if (lane < m) {
+                        const uint64_t sw = lb0[1 + (lane >> 1)];
+                        s = i2 + ((lane & 1) ? (uint32_t)(sw >> 32) : (uint32_t)sw);
+                    }
+                    ZzRec* rs = rec + s;
+                    double x = 0.0, th = 0.0, t = 0.0, I = 0.0;
+                    if (lane < m) {
+                        x = rs->x;
+                        th = rs->th;
+                        t = rs->t;
+                        I = rs->I;
+                    }
+                    if (lane >= k && lane < m) {  // smove_forward!(G2, i, ...), :85
+                        const double dt = tp - t;
+                        const double xn = x + th * dt;
+                        I = I + dt * ((x + xn) * 0.5);
+                        x = xn;
+                        t = tp;
+                    }
+                    const double usign = pdmp_u01(seed, PDMP_STREAM_MAIN, nm);  // θ[i] = σ[i]*rand(rng, (-1,1)), :100-101
+                    if (lane == self) th = P.tb.sigma[i2] * ((usign < 0.5) ? -1.0 : 1.0);
+                    // Q[n+1] = t′ + waiting_time_ref(F) = t′ + randexp()/λref from the global rng, :108
+                    const double newref = tp + (-pdmp_log(pdmp_u01(seed, PDMP_STREAM_GLOBAL, ng))) / P.lambda_ref;
+                    ng += 1;
+                    if (lane < m) {
+                        sx0[lane] = x;
+                        sth0[lane] = th;
+                    }
+                    LDS_ORDER();
+                    const uint32_t sub0 = 1 + SW + (uint32_t)lane * R_;
+                    double key = PDMP_INF;
+                    if (lane < k) {  // :110-114 (at the coordinates' OWN, possibly stale, clocks: the reference's behaviour)
+                        const double gmu = __longlong_as_double((long long)lb0[sub0 + 1]);
+                        const double cj = cmut ? cmut[s] : __longlong_as_double((long long)lb0[sub0 + 2]);
+                        const int kj = (int)(lb0[sub0 + 3] & 0xff);
+                        double gx = 0.0, gt = 0.0;
+                        for (int base = 0; base < kjmax; base += 8) {
+                            const uint64_t pw = lb0[sub0 + 4 + (base >> 3)];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                const int pp = base + q;
+                                if (pp < kj) {
+                                    const double v = __longlong_as_double((long long)lb0[sub0 + 4 + PW + pp]);
+                                    const int ps = (int)((pw >> (8 * q)) & 0xff);
+                                    gx += v * sx0[ps];
+                                    gt += v * sth0[ps];
+                                }
+                            }
+                        }
+                        const double a = cj + (gx - gmu) * th;
+                        const double b = cj / 100 + th * gt;
+                        const double L = pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm + 1 + (uint64_t)lane));
+                        key = t + dev_poisson_time_L(a, b, L);
+                        rs->t_old = t;
+                        rs->a = a;
+                        rs->b = b;
+                        keys[s] = key;
+                    }
+                    dnm += 1u + (uint32_t)k;
+                    if (lane < m) {
+                        rs->x = x;
+                        rs->th = th;
+                        rs->t = t;
+                        rs->I = I;
+                    }
+                    if (lane == 0) keys[d] = newref;
+                    for (int jj = 0; jj <= k; ++jj) {
+                        const uint32_t j = (jj < k) ? readlane_u32(s, jj) : (uint32_t)d;
+                        const double kjv = (jj < k) ? readlane_f64(key, jj < k ? jj : 0) : newref;
+                        level1_update(bk, bi, keys, lane, j, kjv);
+                        LDS_ORDER();
+                    }
+                    const double t_i = readlane_f64(t, self), x_i = readlane_f64(x, self), th_i2 = readlane_f64(th, self);
+                    if (ev && lane == 0) {  // event(i, t, x, θ, F) = (t[i], i, x[i], θ[i]), :143
+                        pdmp_event e;
+                        e.t = t_i;
+                        e.i = (int64_t)i2;
+                        e.x = x_i;
+                        e.theta = th_i2;
+                        ev[ntrace0 + dnacc + dnref] = e;
+                    }
+                    dnref += 1;
+                    t_event = tp;
+                    if (!stop_before && !(tp < T)) running = false;
+                    LDS_ORDER();
+                    continue;
+                }
+            }
+        }
         PHASE(0);
         if (PROF) ph_iters += 1;
         const bool gvalid = g < Esel;
@@ -1761,7 +1902,7 @@ __device__ __forceinline__ void zz_local_spec_body(const ZzRunParams& P_in) {
             bool stopped = false;
             // the usual case needs no walk: the slice mode stops on time alone, and the trace has room for every accepted slot
             const uint32_t acc_run = accb & ((1u << r_ok) - 1u);
-            const bool plainrun = stop_before && !(P.trace_cap > 0 && dnacc + (uint32_t)__popc(acc_run) >= trace_room);
+            const bool plainrun = stop_before && !(P.trace_cap > 0 && dnacc + dnref + (uint32_t)__popc(acc_run) >= trace_room);
             if (plainrun) {
                 Rc = r_ok;
                 nacc_c = (uint32_t)__popc(acc_run);
@@ -1770,7 +1911,7 @@ __device__ __forceinline__ void zz_local_spec_body(const ZzRunParams& P_in) {
                 Rc = r + 1;
                 if ((accb >> r) & 1u) {
                     nacc_c += 1;
-                    if (dnacc + nacc_c >= trace_room && P.trace_cap > 0) {
+                    if (dnacc + dnref + nacc_c >= trace_room && P.trace_cap > 0) {
                         status = PDMP_CHAIN_TRACE_FULL;
                         stopped = true;
                     }
@@ -1823,7 +1964,7 @@ __device__ __forceinline__ void zz_local_spec_body(const ZzRunParams& P_in) {
                 e.i = (int64_t)i;
                 e.x = x;
                 e.theta = th;
-                ev[ntrace0 + dnacc + rank] = e;
+                ev[ntrace0 + dnacc + dnref + rank] = e;
             }
         }
         LDS_ORDER();
@@ -1899,8 +2040,10 @@ __device__ __forceinline__ void zz_local_spec_body(const ZzRunParams& P_in) {
         hdr->t_event = t_event;
         hdr->c.num += dnum;
         hdr->c.nacc += dnacc + vnacc;
-        hdr->c.ntrace = ntrace0 + dnacc;
-        hdr->c.nevents += dnacc;
+        hdr->c.ntrace = ntrace0 + dnacc + dnref;
+        hdr->c.nevents += dnacc + dnref;
+        hdr->c.nrefresh += dnref;
+        hdr->c.ndraw_global = ng;
         hdr->c.ndraw_main = nm0 + dnm;
         hdr->c.status = status;
     }
