@@ -245,7 +245,13 @@ def make_workload(pkg, args, rank, local_rank):
         # events per chain per unit time ~0.8 d; 2x head-room, recycled every step
         cap = 0 if args.no_trace else int(2.0 * d * dt) + 1024
         ens = pkg.Ensemble(nch, d, device=local_rank, trace_capacity=cap)
-        ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
+        if args.lambda_ref > 0.0:
+            # C3R: the same workload with the flow's refresh clock on (src/sfact.jl:78-114; ZigZag(Γ, μ, σ = 1; λref), `test/staticarrays.jl:45` uses one):
+            # the reference's own arithmetic only (the tracked evaluation has no refresh), on the 4-event speculative kernel since round 6
+            args.exact = True
+            ens.set_flow(pkg.ZigZag(G, np.zeros(d), np.ones(d), λref=args.lambda_ref))
+        else:
+            ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
         ens.set_target(pkg.GaussianTarget(G))
         if not args.exact:
             ens.set_gradient_tracking(True)
@@ -654,6 +660,8 @@ def main():
                     help="C5: rows of the design the gradient subsamples from (the script's 50 000 rows at 10^4 columns would be 2.7e10 stored entries; the work "
                          "per proposal depends on k_sub and the row length, not on it -- 10000 rows = a 655 MB table, beyond the MALL, checks that: DESIGN 5)")
     ap.add_argument("--grid", type=int, default=GRID)
+    ap.add_argument("--lambda-ref", type=float, default=0.0,
+                    help="C3: rate of the flow's refresh clock (C3R; > 0 implies --exact: the tracked evaluation has no refresh)")
     ap.add_argument("--dt", type=float, default=None, help="process time per step (default: the configuration's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ess-batches", type=int, default=16, help="B: batches per chain of the ESS run after the timed region (0: skip; a power of two)")
@@ -869,12 +877,12 @@ def main():
     if rank == 0 and args.config == "C3" and not args.exact and args.exact_steps > 0:
         exact = measure_exact(pkg, args, G, c, cap, local_rank)
     strong_proxy = None
-    if rank == 0 and world == 1 and args.config == "C3" and not args.no_strong_proxy and not args.gather and not args.no_trace:
+    if rank == 0 and world == 1 and args.config == "C3" and args.lambda_ref == 0.0 and not args.no_strong_proxy and not args.gather and not args.no_trace:
         v1 = nev / max(float(np.sum(kernel_ms)) * 1e-3, 1e-9)  # (this GPU's kernel-time rate at the full width: the same clock as the proxy's)
         strong_proxy = measure_strong_proxy(pkg, args, G, c, local_rank, v1 if not args.exact else None,
                                             exact["value"] if exact else (v1 if args.exact else None))
     pipeline = None
-    if rank == 0 and world == 1 and args.config == "C3" and not args.no_pipeline and not args.gather and not args.no_trace:
+    if rank == 0 and world == 1 and args.config == "C3" and args.lambda_ref == 0.0 and not args.no_pipeline and not args.gather and not args.no_trace:
         pipeline = measure_pipeline(pkg, args, G, c, local_rank, nev / max(float(np.sum(kernel_ms)) * 1e-3, 1e-9))
     with_integrals = None
     if rank == 0 and args.config == "C4" and not args.gather and os.environ.get("PDMP_BENCH_C4_INTEGRALS", "0") == "0" and args.exact_steps > 0:

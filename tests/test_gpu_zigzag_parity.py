@@ -224,7 +224,7 @@ def test_refresh_clock_matches_oracle(gpu_pkg):
             assert np.array_equal(acc[k], r["acc"])
 
 
-@pytest.mark.parametrize("n,T,lam", [(48, 3.0, 2.0), (128, 1.0, 3.0)])
+@pytest.mark.parametrize("n,T,lam", [(48, 3.0, 2.0), (128, 1.0, 8.0)])
 def test_refresh_clock_on_the_speculative_kernel(gpu_pkg, monkeypatch, n, T, lam):
     """λref > 0 at d = 2304 and d = 16384 (round 6): the 4-event kernel takes the run -- the clock's events are processed by themselves between its
     speculative iterations (src/sfact.jl:78-114) -- and commits, bit for bit, what the one-event kernel and the oracle do: events (reflections and
@@ -238,7 +238,7 @@ def test_refresh_clock_on_the_speculative_kernel(gpu_pkg, monkeypatch, n, T, lam
     nch = 3
     x0 = rng.standard_normal((nch, d))
     th0 = sig * rng.choice([-1.0, 1.0], (nch, d))
-    c = 1.5 * pkg.problems.column_norms(G)
+    c = 4.0 * pkg.problems.column_norms(G)  # (|θ_i| = σ_i up to 1.5: bounds with room, no violation over the horizon)
     seeds = [977 + k for k in range(nch)]
     res = {}
     for kern in ("auto", "seq"):
@@ -269,7 +269,7 @@ def test_refresh_clock_on_the_speculative_kernel(gpu_pkg, monkeypatch, n, T, lam
     # the oracle: the reference-tail run to T in one piece (slices only cut the launches)
     for k in (0, nch - 1):
         r = O.spdmp_zigzag(G, None, G, x0[k], th0[k], c, T, seed=seeds[k], lambda_ref=lam, sigma=sig)
-        assert r["status"] == 0 and r["nrefresh"] >= 2
+        assert r["status"] == 0 and r["nrefresh"] >= 2, (r["status"], r["nrefresh"])
         ev = res["auto"][0][k]
         assert len(ev) == len(r["events"]), (len(ev), len(r["events"]))
         for f in ("i", "t", "x", "theta"):
