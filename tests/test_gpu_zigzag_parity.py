@@ -226,9 +226,10 @@ def test_refresh_clock_matches_oracle(gpu_pkg):
 
 @pytest.mark.parametrize("n,T,lam", [(48, 3.0, 2.0), (128, 1.0, 8.0)])
 def test_refresh_clock_on_the_speculative_kernel(gpu_pkg, monkeypatch, n, T, lam):
-    """λref > 0 at d = 2304 and d = 16384 (round 6): the 4-event kernel takes the run -- the clock's events are processed by themselves between its
-    speculative iterations (src/sfact.jl:78-114) -- and commits, bit for bit, what the one-event kernel and the oracle do: events (reflections and
-    refreshes, in order), counters, both random streams' positions, final state; with slices and a trace that refills."""
+    """λref > 0 at d = 2304 and d = 16384 (round 6): the 8-event lattice kernel (the default there) and the 4-event kernel take the run -- the
+    clock's events are processed by themselves between their speculative iterations (src/sfact.jl:78-114) -- and commit, bit for bit, what the
+    one-event kernel and the oracle do: events (reflections and refreshes, in order), counters, both random streams' positions, final state;
+    with slices and a trace that refills."""
     pkg = gpu_pkg
     L = pkg._lib
     G = pkg.problems.gmrf_precision(n)
@@ -241,7 +242,8 @@ def test_refresh_clock_on_the_speculative_kernel(gpu_pkg, monkeypatch, n, T, lam
     c = 4.0 * pkg.problems.column_norms(G)  # (|θ_i| = σ_i up to 1.5: bounds with room, no violation over the horizon)
     seeds = [977 + k for k in range(nch)]
     res = {}
-    for kern in ("auto", "seq"):
+    names = {"auto": "zz_local_spec8_kernel", "spec4": "zz_local_spec_kernel", "seq": "zz_local_run_kernel"}
+    for kern in ("auto", "spec4", "seq"):
         with pkg.Ensemble(nch, d, trace_capacity=4000) as ens:
             ens.debug_set_kernel(kern)
             ens.set_flow(pkg.ZigZag(G, np.zeros(d), sig, λref=lam))
@@ -257,15 +259,16 @@ def test_refresh_clock_on_the_speculative_kernel(gpu_pkg, monkeypatch, n, T, lam
                     ens.trace_reset()
                     if not L.needs_rerun(cnt["status"]):
                         break
-            assert ens.kernel_name() == ("zz_local_run_kernel" if kern == "seq" else "zz_local_spec_kernel"), ens.kernel_name()
+            assert ens.kernel_name() == names[kern], (kern, ens.kernel_name())
             res[kern] = ([np.concatenate(e) for e in evs], cnt, ens.final_state())
-    for f in ("num", "nacc", "nevents", "nrefresh", "ndraw_main", "ndraw_global", "status"):
-        assert np.array_equal(res["auto"][1][f], res["seq"][1][f]), f
-    for k in range(nch):
-        for f in ("i", "t", "x", "theta"):
-            assert np.array_equal(res["auto"][0][k][f], res["seq"][0][k][f]), (k, f)
-        for f in ("t", "x", "theta", "acc"):
-            assert np.array_equal(res["auto"][2][f][k], res["seq"][2][f][k]), (k, f)
+    for kern in ("auto", "spec4"):
+        for f in ("num", "nacc", "nevents", "nrefresh", "ndraw_main", "ndraw_global", "status"):
+            assert np.array_equal(res[kern][1][f], res["seq"][1][f]), (kern, f)
+        for k in range(nch):
+            for f in ("i", "t", "x", "theta"):
+                assert np.array_equal(res[kern][0][k][f], res["seq"][0][k][f]), (kern, k, f)
+            for f in ("t", "x", "theta", "acc"):
+                assert np.array_equal(res[kern][2][f][k], res["seq"][2][f][k]), (kern, k, f)
     # the oracle: the reference-tail run to T in one piece (slices only cut the launches)
     for k in (0, nch - 1):
         r = O.spdmp_zigzag(G, None, G, x0[k], th0[k], c, T, seed=seeds[k], lambda_ref=lam, sigma=sig)

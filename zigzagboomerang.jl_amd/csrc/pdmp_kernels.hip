@@ -2188,6 +2188,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const uint64_t nm0 = hdr->c.ndraw_main, ntrace0 = hdr->c.ntrace;
     uint32_t dnm = 0, dnum = 0, dnacc = 0;
     uint32_t vnacc = 0;  // 1 if the launch ends on a bound violation (acc is bumped before the check)
+    // the flow's refresh clock (src/sfact.jl:78-114, round 6): its time is a wave-uniform scalar here, not a queue entry (key d lies behind the
+    // first level's 512 blocks); its events are processed by themselves between the speculative iterations, as zz_local_run_kernel does
+    const bool has_refresh = P.has_refresh != 0;
+    double t_ref = has_refresh ? keys[d] : PDMP_INF;
+    uint32_t dnref = 0;                 // refresh events of this launch (recorded in the trace like reflections, :143)
+    uint64_t ng = hdr->c.ndraw_global;  // the "global rng" stream of the clock (:80,:84,:108)
     double t_last = hdr->c.t_last;
     double t_event = hdr->t_event;
     status = PDMP_CHAIN_OK;
@@ -2243,7 +2249,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     PrioTurn prio;
     while (running) {
         prio.step();
-        if (dnacc >= trace_room) {
+        if (dnacc + dnref >= trace_room) {
             status = PDMP_CHAIN_TRACE_FULL;
             break;
         }
@@ -2258,7 +2264,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         // the event slots.  Whatever sel_dt is, the slots hold exactly the smallest entries of the queue, so the committed
         // sequence does not depend on it; it is steered towards ~12 candidates per iteration.
         int Esel = 0;
-        bool first_inf = false;
+        bool first_inf = false, do_ref = false;
         {
             double kk[8];
 #pragma unroll
@@ -2266,7 +2272,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             const double mloc = min_f64(min_f64(min_f64(kk[0], kk[1]), min_f64(kk[2], kk[3])),
                                         min_f64(min_f64(kk[4], kk[5]), min_f64(kk[6], kk[7])));
             const double mq = wave_min_f64(mloc);
-            if (!(mq < PDMP_INF)) {
+            do_ref = has_refresh && t_ref < mq && !(stop_before && !(t_ref < T));  // (a coordinate's event at the clock's very time goes first)
+            if (do_ref) {
+            } else if (!(mq < PDMP_INF)) {
                 first_inf = true;
             } else if (!(stop_before && !(mq < T))) {
                 if (lane < (int)SEL_CAP) TK[lane] = PDMP_INF;
@@ -2284,6 +2292,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 for (int tries = 0;; ++tries) {
                     tau = mq + dt_sel;  // (>= mq: the minimum itself always qualifies)
                     if (stop_before && !(tau < T)) tau = pdmp_below(T);
+                    if (!(tau < t_ref)) tau = (t_ref > mq) ? pdmp_below(t_ref) : mq;  // nothing at or beyond the refresh clock's time (but the minimum itself)
                     const bool pile = tries > 64;  // more than SEL_CAP entries EQUAL to the minimum: one (lowest block) per iteration
                     if (tries >= 64) tau = mq;     // a pile of exactly equal keys: the entries equal to the minimum only
                     uint32_t base = 0;
@@ -2338,8 +2347,155 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 if (lane == 0) SELDT[0] = dt_sel * f;
             }
         }
+        if (do_ref) {
+            // ---------------- the refresh clock is the chain's next event: src/sfact.jl:78-114, restated with its quirks exactly as
+            // zz_local_run_kernel does (two independent coordinate draws from the global stream -- the neighbourhood that is moved, :80, and the
+            // coordinate that is refreshed, :84 --, G1[i] re-bounded at the coordinates' own, possibly stale, clocks); the whole wave on one event
+            const double tp = t_ref;
+            uint64_t* const lb0 = LB + WPAD;  // (blob slot 1: free between iterations)
+            double* const sx0 = reinterpret_cast<double*>(smem + S8_SX);
+            double* const sth0 = reinterpret_cast<double*>(smem + S8_STH);
+            const uint64_t nm = nm0 + (uint64_t)dnm;
+            t_last = tp;
+            const uint32_t i1 = pdmp_randint(seed, PDMP_STREAM_GLOBAL, ng, (uint32_t)d);
+            ng += 1;
+            {
+                const uint64_t* bsrc = P.blob + (size_t)P.tix[i1] * WPAD;
+                if (lane < (int)WPAD) lb0[lane] = bsrc[lane];
+                LDS_ORDER();
+                const int k1 = (int)uniform_u32((uint32_t)(lb0[0] & 0xff));
+                if (lane < k1) {  // smove_forward!(G, i1, ...), :82
+                    const uint64_t sw = lb0[1 + (lane >> 1)];
+                    const uint32_t s1 = i1 + ((lane & 1) ? (uint32_t)(sw >> 32) : (uint32_t)sw);
+                    ZzRec* r1 = rec + s1;
+                    const double x0 = r1->x, th0 = r1->th, t0 = r1->t, I0 = r1->I;
+                    const double dt = tp - t0;
+                    const double xn = x0 + th0 * dt;
+                    r1->x = xn;
+                    r1->t = tp;
+                    r1->I = I0 + dt * ((x0 + xn) * 0.5);
+                }
+                LDS_ORDER();
+            }
+            const uint32_t i2 = pdmp_randint(seed, PDMP_STREAM_GLOBAL, ng, (uint32_t)d);
+            ng += 1;
+            {
+                const uint64_t* bsrc = P.blob + (size_t)P.tix[i2] * WPAD;
+                if (lane < (int)WPAD) lb0[lane] = bsrc[lane];
+            }
+            LDS_ORDER();
+            const uint64_t hw = lb0[0];
+            const int k = (int)uniform_u32((uint32_t)(hw & 0xff));
+            const int m = (int)uniform_u32((uint32_t)((hw >> 8) & 0xff));
+            const int self = (int)uniform_u32((uint32_t)((hw >> 16) & 0xff));
+            uint32_t s = i2;
+            if (lane < m) {
+                const uint64_t sw = lb0[1 + (lane >> 1)];
+                s = i2 + ((lane & 1) ? (uint32_t)(sw >> 32) : (uint32_t)sw);
+            }
+            ZzRec* rs = rec + s;
+            double x = 0.0, th = 0.0, t = 0.0, I = 0.0;
+            if (lane < m) {
+                x = rs->x;
+                th = rs->th;
+                t = rs->t;
+                I = rs->I;
+            }
+            if (lane >= k && lane < m) {  // smove_forward!(G2, i, ...), :85
+                const double dt = tp - t;
+                const double xn = x + th * dt;
+                I = I + dt * ((x + xn) * 0.5);
+                x = xn;
+                t = tp;
+            }
+            const double usign = pdmp_u01(seed, PDMP_STREAM_MAIN, nm);  // θ[i] = σ[i]*rand(rng, (-1,1)), :100-101
+            if (lane == self) th = P.tb.sigma[i2] * ((usign < 0.5) ? -1.0 : 1.0);
+            const double newref = tp + (-pdmp_log(pdmp_u01(seed, PDMP_STREAM_GLOBAL, ng))) / P.lambda_ref;  // :108
+            ng += 1;
+            if (lane < m) {
+                sx0[lane] = x;
+                sth0[lane] = th;
+            }
+            LDS_ORDER();
+            const uint32_t sub0 = 1 + SW + (uint32_t)lane * R_;
+            double key = PDMP_INF;
+            if (lane < k) {  // :110-114
+                const double gmu = __longlong_as_double((long long)lb0[sub0 + 1]);
+                const double cj = cmut ? cmut[s] : __longlong_as_double((long long)lb0[sub0 + 2]);
+                const int kj = (int)(lb0[sub0 + 3] & 0xff);
+                const uint64_t pw = lb0[sub0 + 4];
+                double gx = 0.0, gt = 0.0;
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    if (q < kj) {
+                        const double v = __longlong_as_double((long long)lb0[sub0 + 4 + PW + q]);
+                        const int ps = (int)((pw >> (8 * q)) & 0xff);
+                        gx += v * sx0[ps];
+                        gt += v * sth0[ps];
+                    }
+                }
+                const double a = cj + (gx - gmu) * th;
+                const double b = cj / 100 + th * gt;
+                const double L = pdmp_log(pdmp_u01(seed, PDMP_STREAM_MAIN, nm + 1 + (uint64_t)lane));
+                key = t + dev_poisson_time_L(a, b, L);
+                rs->t_old = t;
+                rs->a = a;
+                rs->b = b;
+                keys[s] = key;
+            }
+            dnm += 1u + (uint32_t)k;
+            if (lane < m) {
+                rs->x = x;
+                rs->th = th;
+                rs->t = t;
+                rs->I = I;
+            }
+            if (lane == 0) keys[d] = newref;
+            t_ref = newref;
+            for (int jj = 0; jj < k; ++jj) {  // first level: blocks of 32 keys
+                const uint32_t j = readlane_u32(s, jj);
+                const double kjv = readlane_f64(key, jj);
+                const uint32_t bj = j >> 5;
+                LDS_ORDER();
+                const double cur = bk[bj];
+                const uint32_t ci = bi[bj];
+                if (kjv < cur || (kjv == cur && j < ci)) {
+                    if (lane == 0) {
+                        bk[bj] = kjv;
+                        bi[bj] = (uint16_t)j;
+                    }
+                } else if (ci == j) {
+                    const double kv = (lane < 32) ? __hip_atomic_load(keys + (size_t)bj * 32 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : PDMP_INF;
+                    const double mn = wave_min_f64(kv);
+                    const uint64_t bl = __ballot(kv == mn);
+                    const int arg = bl ? (__ffsll((unsigned long long)bl) - 1) : 0;
+                    if (lane == 0) {
+                        bk[bj] = mn;
+                        bi[bj] = (uint16_t)(bj * 32 + (uint32_t)arg);
+                    }
+                }
+                LDS_ORDER();
+            }
+            const double t_i = readlane_f64(t, self), x_i = readlane_f64(x, self), th_i2 = readlane_f64(th, self);
+            if (ev && lane == 0) {  // event(i, t, x, θ, F) = (t[i], i, x[i], θ[i]), :143
+                pdmp_event e;
+                e.t = t_i;
+                e.i = (int64_t)i2;
+                e.x = x_i;
+                e.theta = th_i2;
+                ev[ntrace0 + dnacc + dnref] = e;
+            }
+            dnref += 1;
+            t_event = tp;
+            if (!stop_before && !(tp < T)) running = false;
+            LDS_ORDER();
+            continue;
+        }
         if (Esel == 0) {
-            if (first_inf) status = PDMP_CHAIN_STALLED;
+            if (first_inf && !(t_ref < PDMP_INF)) status = PDMP_CHAIN_STALLED;
+            if (first_inf && t_ref < PDMP_INF && !(stop_before && !(t_ref < T))) {  // (no coordinate has a finite key, the clock does: its event is next)
+                continue;
+            }
             break;
         }
         LDS_ORDER();
@@ -2638,7 +2794,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             bool stopped = false;
             // the usual case needs no walk: the slice mode stops on time alone, and the trace has room for every accepted slot
             const uint32_t nacc_all = (uint32_t)__popcll(accball & ((r_ok < 8u) ? ((1ull << (8 * r_ok)) - 1ull) : ~0ull));
-            const bool plainrun = stop_before && !(P.trace_cap > 0 && dnacc + nacc_all >= trace_room);
+            const bool plainrun = stop_before && !(P.trace_cap > 0 && dnacc + dnref + nacc_all >= trace_room);
             if (plainrun) {
                 Rc = r_ok;
                 nacc_c = nacc_all;
@@ -2647,7 +2803,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 Rc = r + 1;
                 if ((accball >> (8 * r)) & 1ull) {
                     nacc_c += 1;
-                    if (dnacc + nacc_c >= trace_room && P.trace_cap > 0) {
+                    if (dnacc + dnref + nacc_c >= trace_room && P.trace_cap > 0) {
                         status = PDMP_CHAIN_TRACE_FULL;
                         stopped = true;
                     }
@@ -2699,7 +2855,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 e.i = (int64_t)i;
                 e.x = x;
                 e.theta = th;
-                ev[ntrace0 + dnacc + rank] = e;
+                ev[ntrace0 + dnacc + dnref + rank] = e;
             }
         }
         LDS_ORDER();
@@ -2794,8 +2950,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         hdr->t_event = t_event;
         hdr->c.num += dnum;
         hdr->c.nacc += dnacc + vnacc;
-        hdr->c.ntrace = ntrace0 + dnacc;
-        hdr->c.nevents += dnacc;
+        hdr->c.ntrace = ntrace0 + dnacc + dnref;
+        hdr->c.nevents += dnacc + dnref;
+        hdr->c.nrefresh += dnref;
+        hdr->c.ndraw_global = ng;
         hdr->c.ndraw_main = nm0 + dnm;
         hdr->c.status = status;
     }
@@ -4183,7 +4341,7 @@ int launch_zz_local_spec(const ZzRunParams& p, int64_t nchains, void* stream, co
     // the 8-event kernel: the lattice blob geometry, no refresh clock, 2048 <= d <= 16384 (its first level has 512 entries over
     // 32-key blocks; below 64 blocks there are too few candidates for eight slots)
     const bool geom = (p.flags & 0x100) && p.blob_sw == 7 && p.blob_pw == 1 && p.blob_kmax == 5 && p.blob_w_pad == 58;
-    const bool spec8 = geom && !p.has_refresh && p.d >= 2048 && p.d <= (int64_t)S8_NBLK * 32 &&
+    const bool spec8 = geom && p.d >= 2048 && p.d <= (int64_t)S8_NBLK * 32 &&
                        !p.force_spec4;  // (pdmp_debug_set_kernel: A/B runs and parity tests of the 4-event kernel)
     const bool wide = p.blob_sw > 8;  // |S[i]| up to 32: two zone members per lane
     // eight events per iteration on any graph with |G1| <= 8, |S| <= 32 (tables built by the host when the geometry fits), plain configuration
