@@ -1070,7 +1070,11 @@ def main():
         if os.path.exists(tpath):
             tp = json.load(open(tpath))
             tkey = args.config
-            if args.config == "C3" and args.exact:
+            if args.config == "C3" and args.lambda_ref > 0.0:
+                tkey = "C3R"
+            elif args.config == "C3" and W.get("kernel") == "zz_local_trackl_kernel":
+                tkey = "C3L"
+            elif args.config == "C3" and args.exact:
                 tkey = "C3X"
             if args.config == "C3" and args.grid != GRID:
                 tkey = "C3_g%d" % args.grid

@@ -24,11 +24,13 @@ MAIN = {"C3": "zz_local_track", "C3X": "zz_local_spec8_kernel", "C2": "bps_run_k
         "C3GX_random6": "zz_local_spec8g_kernel", "C3G_random8": "zz_local_trackp_kernel", "C3GX_random8": "zz_local_spec8g_kernel",
         # round 5: a rank's share of the 4096-chain ensemble on 2 / 4 / 8 GPUs (the strong-scaling proxy) and the 256 x 256 lattice
         "C3_w2048": "zz_local_trackp_kernel", "C3_w1024": "zz_local_trackp2_kernel", "C3_w512": "zz_local_trackp2_kernel",
-        "C3X_w1024": "zz_local_spec8_kernel", "C3X_w512": "zz_local_spec8_kernel", "C3_g256": "zz_local_trackp_big_kernel"}
+        "C3X_w1024": "zz_local_spec8_kernel", "C3X_w512": "zz_local_spec8_kernel", "C3_g256": "zz_local_trackp_big_kernel",
+        # round 6: the line layout (opt-in form, PDMP_TRACK_LINES=1) and the lattice with the flow's refresh clock on (bench.py --lambda-ref 1)
+        "C3L": "zz_local_trackl_kernel", "C3R": "zz_local_spec8_kernel"}
 CMD = {"C3X": "C3 --exact", "C4T": "C4 --tracked", "C3G": "C3G", "C3GX": "C3G --exact", "C3G_random6": "C3G --graph random6",
        "C3GX_random6": "C3G --graph random6 --exact", "C3G_random8": "C3G --graph random8", "C3GX_random8": "C3G --graph random8 --exact",
        "C3_w2048": "C3 --chains 2048", "C3_w1024": "C3 --chains 1024", "C3_w512": "C3 --chains 512", "C3X_w1024": "C3 --exact --chains 1024",
-       "C3X_w512": "C3 --exact --chains 512", "C3_g256": "C3 --grid 256 --chains 1024"}
+       "C3X_w512": "C3 --exact --chains 512", "C3_g256": "C3 --grid 256 --chains 1024", "C3L": "C3 (PDMP_TRACK_LINES=1)", "C3R": "C3 --lambda-ref 1.0"}
 
 
 def rows(path):
