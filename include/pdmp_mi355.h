@@ -411,6 +411,16 @@ pdmp_status pdmp_ensemble_consume_mean(pdmp_ensemble* ens, int64_t chain_first, 
 pdmp_status pdmp_ensemble_consume_inclusion(pdmp_ensemble* ens, int64_t chain_first, int64_t n, double* prob, double* T_last);
 pdmp_status pdmp_ensemble_consume_discretized(pdmp_ensemble* ens, int64_t chain, int64_t k_first, int64_t k_count, double* out,
                                               int64_t* npoints, void** grid_dev);
+/* cummean(Ξ) (src/trace.jl:203-226) on the device (round 6): once enabled (after consume_begin; the synchronous consumer), pdmp_ensemble_consume also leaves,
+ * for every event of the segment it consumes, the running pair (t_i, Σ (x_prev + x_k)(t_k − t_prev) / (2 t_i)) of the event's coordinate -- the sums are
+ * carried from segment to segment, so the pairs are those of the whole run's trace (bit for bit the reference's order of operations per coordinate).
+ * _copy: the pairs of slots [first, first + count) of a chain's segment, the slots pdmp_ensemble_trace_copy returns the events of. */
+pdmp_status pdmp_ensemble_consume_cummean(pdmp_ensemble* ens, int enable);
+pdmp_status pdmp_ensemble_consume_cummean_copy(pdmp_ensemble* ens, int64_t chain, int64_t first, int64_t count, double* t, double* y);
+/* subtrace(Ξ, J) (src/trace.jl:275-290) on the device (round 6): the events of a chain's current trace segment whose coordinate lies in the ascending
+ * 0-based index set J, renumbered by their position in J, compacted on the device; n_out = how many there are (at most out_cap are written to `out`). */
+pdmp_status pdmp_ensemble_subtrace_copy(pdmp_ensemble* ens, int64_t chain, const int64_t* J, int64_t nJ, pdmp_event* out, int64_t out_cap,
+                                        int64_t* n_out);
 
 /* what the ensemble was created with (any pointer may be NULL) */
 pdmp_status pdmp_ensemble_info(pdmp_ensemble* ens, int64_t* nchains, int64_t* d, int64_t* trace_capacity, int* device);

@@ -21,7 +21,7 @@ EVENT1D_DTYPE = np.dtype([("t", "<f8"), ("x", "<f8"), ("theta", "<f8")])
 
 def build_oracle(force=False):
     src = os.path.join(_ORACLE_DIR, "pdmp_oracle.c")
-    hdrs = [os.path.join(_ORACLE_DIR, "pdmp_oracle.h"),
+    hdrs = [os.path.join(_ORACLE_DIR, "pdmp_oracle.h"), os.path.join(_ORACLE_DIR, "trace_oracle.c"),
             os.path.join(os.path.dirname(_ORACLE_DIR), "include", "pdmp_detmath.h")]
     if not force and os.path.exists(_LIB_PATH):
         newest = max(os.path.getmtime(p) for p in [src] + hdrs)
@@ -461,3 +461,74 @@ class PQ:
 
     def check(self):
         return bool(lib().orc_pq_check(self.h))
+
+
+# ---- what callers do next with a FactTrace: oracle/trace_oracle.c (src/trace.jl restated event by event)
+def _ev_arrays(events):
+    return (np.ascontiguousarray(events["t"], dtype=np.float64), np.ascontiguousarray(events["i"], dtype=np.int64),
+            np.ascontiguousarray(events["x"], dtype=np.float64), np.ascontiguousarray(events["theta"], dtype=np.float64))
+
+
+def trace_mean(t0, x0, events):
+    """Statistics.mean(trace), src/trace.jl:182-200"""
+    et, ei, ex, _ = _ev_arrays(events)
+    x0 = _f64(x0)
+    y = np.empty(x0.size)
+    L = lib()
+    L.orc_trace_mean.restype = None
+    L.orc_trace_mean.argtypes = [C.c_int64, C.c_double, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_trace_mean(x0.size, float(t0), x0.ctypes.data, et.size, et.ctypes.data, ei.ctypes.data, ex.ctypes.data, y.ctypes.data)
+    return y
+
+
+def trace_inclusion_prob(t0, x0, events):
+    """inclusion_prob(trace), src/trace.jl:161-178"""
+    et, ei, ex, _ = _ev_arrays(events)
+    x0 = _f64(x0)
+    y = np.empty(x0.size)
+    L = lib()
+    L.orc_trace_inclusion_prob.restype = None
+    L.orc_trace_inclusion_prob.argtypes = [C.c_int64, C.c_double, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_trace_inclusion_prob(x0.size, float(t0), x0.ctypes.data, et.size, et.ctypes.data, ei.ctypes.data, ex.ctypes.data, y.ctypes.data)
+    return y
+
+
+def trace_cummean(t0, x0, events):
+    """cummean(trace::FactTrace), src/trace.jl:203-226: (t, y) after every event, in event order (entry k belongs to coordinate events["i"][k])"""
+    et, ei, ex, _ = _ev_arrays(events)
+    x0 = _f64(x0)
+    ot, oy = np.empty(et.size), np.empty(et.size)
+    L = lib()
+    L.orc_trace_cummean.restype = None
+    L.orc_trace_cummean.argtypes = [C.c_int64, C.c_double, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_trace_cummean(x0.size, float(t0), x0.ctypes.data, et.size, et.ctypes.data, ei.ctypes.data, ex.ctypes.data, ot.ctypes.data, oy.ctypes.data)
+    return ot, oy
+
+
+def trace_discretize(t0, x0, th0, events, dt):
+    """collect(discretize(trace, dt)) for a ZigZag FactTrace, src/trace.jl:100-125"""
+    et, ei, ex, eth = _ev_arrays(events)
+    x0, th0 = _f64(x0), _f64(th0)
+    span = (et[-1] - t0) if et.size else 0.0
+    cap = int(span / dt) + 8
+    ts, xs = np.empty(cap), np.empty((cap, x0.size))
+    L = lib()
+    L.orc_trace_discretize.restype = C.c_int64
+    L.orc_trace_discretize.argtypes = [C.c_int64, C.c_double, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_double, C.c_int64, C.c_void_p, C.c_void_p]
+    q = L.orc_trace_discretize(x0.size, float(t0), x0.ctypes.data, th0.ctypes.data, et.size, et.ctypes.data, ei.ctypes.data, ex.ctypes.data,
+                               eth.ctypes.data, float(dt), cap, ts.ctypes.data, xs.ctypes.data)
+    assert q <= cap
+    return ts[:q], xs[:q]
+
+
+def trace_subtrace(J, events):
+    """subtrace(tr, J), src/trace.jl:275-290: (indices of the kept events, their new 0-based coordinates)"""
+    _, ei, _, _ = _ev_arrays(events)
+    J = np.ascontiguousarray(J, dtype=np.int64)
+    ok, oi = np.empty(ei.size, dtype=np.int64), np.empty(ei.size, dtype=np.int64)
+    L = lib()
+    L.orc_trace_subtrace.restype = C.c_int64
+    L.orc_trace_subtrace.argtypes = [C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    m = L.orc_trace_subtrace(J.size, J.ctypes.data, ei.size, ei.ctypes.data, ok.ctypes.data, oi.ctypes.data)
+    return ok[:m], oi[:m]

@@ -4,6 +4,8 @@ term by term) -- with a trace buffer far smaller than the trace, recycled after 
 import numpy as np
 import pytest
 
+import oracle_lib as O
+
 pytestmark = pytest.mark.gpu
 
 
@@ -59,6 +61,10 @@ def test_discretize_and_mean_on_the_device(gpu_pkg, tracked):
             assert np.array_equal(got, X) and np.array_equal(gt, grid)   # bit for bit (times and positions)
             ref = pkg.trace.mean(tr)
             assert np.allclose(m[k], ref, rtol=1e-12, atol=1e-15)
+            # ... and against the oracle's restatement of src/trace.jl (oracle/trace_oracle.c): the device consumers one hop from the reference
+            ts, xs = O.trace_discretize(0.0, tr.x0, tr.θ0, tr.events, dt)
+            assert len(ts) == len(gt) and np.allclose(gt, ts, rtol=0, atol=1e-10) and np.allclose(got, xs, rtol=0, atol=1e-9)
+            assert np.allclose(m[k], O.trace_mean(0.0, tr.x0, tr.events), rtol=1e-12, atol=1e-15)
         # a later slice extends both (the cursors persist; points flushed earlier are re-emitted with the same values)
         ens.run(11.0, pkg._lib.RUN_STOP_BEFORE)
     # dense duplicates inside a chunk: d = 8 coordinates, every chunk of 256 events holds each of them ~32 times
@@ -92,6 +98,7 @@ def test_consumers_on_sticky_traces_and_refusals(gpu_pkg):
         for k in range(2):  # inclusion_prob(Ξ), src/trace.jl:161-178: what a sticky run is for
             ref = pkg.trace.inclusion_prob(traces[k])
             assert np.allclose(p[k], ref, rtol=1e-12, atol=1e-15) and Tp[k] == traces[k].events["t"][-1]
+            assert np.allclose(p[k], O.trace_inclusion_prob(0.0, traces[k].x0, traces[k].events), rtol=1e-12, atol=1e-15)  # (oracle/trace_oracle.c)
             assert 0.05 < ref.mean() < 0.95 and ref.min() < 0.9  # coordinates do spend time at 0
     with pkg.Ensemble(1, d, trace_capacity=100) as ens:
         ens.set_flow(pkg.ZigZag(G, np.zeros(d), λref=0.2))
@@ -181,3 +188,55 @@ def test_asynchronous_consumer_equals_the_synchronous_one(gpu_pkg, tracked):
     assert np.array_equal(n0, n1) and np.array_equal(T0, T1) and np.array_equal(m0, m1)
     for k in range(nch):
         assert np.array_equal(g0[k][0], g1[k][0]) and np.array_equal(g0[k][1], g1[k][1]) and g0[k][1].shape[0] > 20
+
+
+def test_subtrace_and_cummean_on_the_device(gpu_pkg):
+    """subtrace(Ξ, J) and cummean(Ξ) on the device (round 6: src/trace.jl:203-226,275-290) against oracle/trace_oracle.c: the device's subtrace of every
+    segment concatenated equals the oracle's subtrace of the whole trace, event for event; the running pairs the consumer leaves beside the events are,
+    BIT FOR BIT, the oracle's (t, y / (2 t)) list -- over a trace that reaches the consumer in pieces."""
+    pkg = gpu_pkg
+    L = pkg._lib
+    n = 48
+    G = pkg.problems.gmrf_precision(n)
+    d = n * n
+    c = pkg.problems.column_norms(G)
+    nch = 2
+    J = np.array([0, 5, 47, 48, 1000, 1001, 2303])
+    with pkg.Ensemble(nch, d, trace_capacity=1200) as ens:
+        ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
+        ens.set_target(pkg.GaussianTarget(G))
+        rng = np.random.default_rng(9)
+        x0, th0 = rng.standard_normal((nch, d)), rng.choice([-1.0, 1.0], (nch, d))
+        ens.set_state(0.0, x0, th0, c, np.arange(nch, dtype=np.uint64) + 90)
+        ens.consume_begin(0.5, 8)
+        ens.consume_cummean(True)
+        evs, subs, cmt, cmy = [[] for _ in range(nch)], [[] for _ in range(nch)], [[] for _ in range(nch)], [[] for _ in range(nch)]
+        refills = 0
+        for Tk in (1.5, 4.0):
+            while True:
+                ens.run(Tk, L.RUN_STOP_BEFORE)
+                cnt = ens.counters()
+                ens.consume()
+                for k in range(nch):
+                    e = ens.trace(k, counters=cnt)
+                    evs[k].append(e)
+                    subs[k].append(ens.subtrace(k, J))
+                    t, y = ens.consume_cummean_pairs(k, len(e))
+                    cmt[k].append(t)
+                    cmy[k].append(y)
+                ens.trace_reset()
+                if not L.needs_rerun(cnt["status"]):
+                    break
+                refills += 1
+        assert refills >= 3
+    for k in range(nch):
+        ev = np.concatenate(evs[k])
+        assert len(ev) > 4000
+        ok, oi = O.trace_subtrace(J, ev)
+        sub = np.concatenate(subs[k])
+        assert len(sub) == len(ok) > 5
+        assert np.array_equal(sub["i"], oi)
+        for f in ("t", "x", "theta"):
+            assert np.array_equal(sub[f], ev[f][ok]), f
+        ot, oy = O.trace_cummean(0.0, x0[k], ev)
+        assert np.array_equal(np.concatenate(cmt[k]), ot) and np.array_equal(np.concatenate(cmy[k]), oy)

@@ -153,3 +153,29 @@ def test_vectorised_consumers_equal_the_reference_loops(pkg):
     td, xd = pkg.trace.discretize(trb, 0.25)
     td0, xd0 = _sequential_discretize(trb, 0.25, True)
     assert len(td) == len(td0) and np.allclose(xd, xd0, rtol=0, atol=1e-9)
+
+
+def test_host_consumers_equal_the_oracle_restatement_of_trace_jl(pkg):
+    """zigzagboomerang.jl_amd/trace.py against oracle/trace_oracle.c -- the event-by-event loops of src/trace.jl:100-125,161-226,275-290 in C, one
+    hop from the reference -- on an oracle-made ZigZag trace: mean, inclusion_prob, cummean, collect(discretize), subtrace."""
+    tr = _fact_trace(pkg, T=600.0)
+    ev = tr.events
+    assert len(ev) > 2000
+    assert np.allclose(pkg.trace.mean(tr), O.trace_mean(tr.t0, tr.x0, ev), rtol=1e-13, atol=0)
+    assert np.allclose(pkg.trace.inclusion_prob(tr), O.trace_inclusion_prob(tr.t0, tr.x0, ev), rtol=1e-13, atol=0)
+    ot, oy = O.trace_cummean(tr.t0, tr.x0, ev)
+    cm = pkg.trace.cummean(tr)
+    for j in range(tr.x0.size):
+        own = np.nonzero(ev["i"] == j)[0]
+        t, y = cm[j]
+        assert t[0] == tr.t0 and y[0] == tr.x0[j]
+        assert np.array_equal(t[1:], ot[own]) and np.allclose(y[1:], oy[own], rtol=1e-12, atol=1e-15)
+    for dt in (0.37, 1.0):
+        td, xd = pkg.trace.discretize(tr, dt)
+        ts, xs = O.trace_discretize(tr.t0, tr.x0, tr.θ0, ev, dt)
+        assert len(td) == len(ts) and np.allclose(td, ts, rtol=0, atol=1e-10) and np.allclose(xd, xs, rtol=0, atol=1e-9)
+    J = np.array([0, 3, 4, 7])
+    sub = pkg.trace.subtrace(tr, J)
+    ok, oi = O.trace_subtrace(J, ev)
+    assert np.array_equal(sub.events["i"], oi) and np.array_equal(sub.events["t"], ev["t"][ok]) and np.array_equal(sub.events["x"], ev["x"][ok])
+    assert np.array_equal(sub.x0, tr.x0[J]) and np.array_equal(sub.θ0, tr.θ0[J])

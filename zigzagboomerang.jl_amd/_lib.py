@@ -46,7 +46,7 @@ EXPORTED_SYMBOLS = [
     "pdmp_ensemble_set_mass_cholesky", "pdmp_ensemble_set_bps_options",
     "pdmp_ensemble_ess_begin", "pdmp_ensemble_ess_batch", "pdmp_ensemble_ess_end", "pdmp_ensemble_set_gradient_tracking",
     "pdmp_ensemble_path_integrals", "pdmp_ensemble_set_path_integrals", "pdmp_ensemble_set_neighbourhood", "pdmp_ensemble_info",
-    "pdmp_ensemble_consume_begin", "pdmp_ensemble_consume", "pdmp_ensemble_consume_async", "pdmp_ensemble_last_consume_ms", "pdmp_ensemble_consume_mean", "pdmp_ensemble_consume_inclusion", "pdmp_ensemble_consume_discretized", "pdmp_1d_run",
+    "pdmp_ensemble_consume_begin", "pdmp_ensemble_consume", "pdmp_ensemble_consume_async", "pdmp_ensemble_last_consume_ms", "pdmp_ensemble_consume_mean", "pdmp_ensemble_consume_inclusion", "pdmp_ensemble_consume_discretized", "pdmp_ensemble_consume_cummean", "pdmp_ensemble_consume_cummean_copy", "pdmp_ensemble_subtrace_copy", "pdmp_1d_run",
     "pdmp_comm_unique_id", "pdmp_comm_init", "pdmp_comm_destroy", "pdmp_comm_info", "pdmp_comm_barrier", "pdmp_comm_allreduce",
     "pdmp_ensemble_gather_traces", "pdmp_ensemble_reduce_moments", "pdmp_comm_gathered_copy",
     "pdmp_ensemble_gather_bps_traces", "pdmp_comm_gathered_bps_copy", "pdmp_ensemble_bps_trace_dev",
@@ -130,6 +130,9 @@ def load():
     L.pdmp_debug_host_drain_probe.argtypes = [vp, i64, C.POINTER(C.c_double)]
     L.pdmp_ensemble_consume_mean.argtypes = [vp, i64, i64, vp, vp]
     L.pdmp_ensemble_consume_inclusion.argtypes = [vp, i64, i64, vp, vp]
+    L.pdmp_ensemble_consume_cummean.argtypes = [vp, C.c_int]
+    L.pdmp_ensemble_consume_cummean_copy.argtypes = [vp, i64, i64, i64, vp, vp]
+    L.pdmp_ensemble_subtrace_copy.argtypes = [vp, i64, vp, i64, vp, i64, vp]
     L.pdmp_ensemble_consume_discretized.argtypes = [vp, i64, i64, i64, vp, C.POINTER(i64), C.POINTER(vp)]
     L.pdmp_1d_run.argtypes = [C.POINTER(Config1d), vp, vp, C.c_double, vp, vp]
     L.pdmp_1d_run.restype = C.c_int

@@ -187,6 +187,8 @@ struct pdmp_ensemble {
     // streaming trace consumers (pdmp_ensemble_consume_*): cursor per (chain, coordinate), per-chain progress, the discretisation grid
     DevBuf<unsigned char> d_ccur, d_cmeta;
     DevBuf<double> d_cgrid;
+    DevBuf<double> d_ccm;      // pdmp_ensemble_consume_cummean: (t, y / (2 t)) per event slot of the last consumed segment [nchains x cap x 2], or empty
+    bool cons_cummean = false;
     bool consuming = false, cons_z = false;
     // pdmp_ensemble_consume_async: a second trace buffer (the event loop writes one while the consumer reads the other), the consumer's stream,
     // the (ntrace, nevents) snapshots of the two most recent slices and the events that order the two streams
@@ -1947,6 +1949,7 @@ pdmp_status pdmp_ensemble_consume_begin(pdmp_ensemble* e, double grid_dt, int64_
     }
     if ((st = ensure_canon(e)) != PDMP_OK) return st;
     discard_async_consumer(e);
+    e->cons_cummean = false;
     int rc = pdmp::launch_consume_init(e->d_rec.p, e->track ? 128 : 64, d, n, e->t0_state, e->d_ccur.p, e->cons_z, e->d_cmeta.p,
                                        grid_points > 0 ? e->d_cgrid.p : nullptr, grid_points, e->stream);
     if (rc != 0) return fail(PDMP_ERR_HIP, "consume_init launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -1963,9 +1966,76 @@ pdmp_status pdmp_ensemble_consume(pdmp_ensemble* e) {
     HIP_TRY(hipSetDevice(e->cfg.device));
     HIP_TRY(device_sync(e));
     int rc = pdmp::launch_consume_events(e->d_ev.p, e->cfg.trace_capacity, e->d_hdr.p, nullptr, e->cfg.d, e->cfg.nchains, e->d_ccur.p, e->cons_z, e->d_cmeta.p,
-                                         e->d_cgrid.p, e->cons_K, e->t0_state, e->cons_dt, e->stream);
+                                         e->d_cgrid.p, e->cons_K, e->t0_state, e->cons_dt, e->stream, e->cons_cummean ? e->d_ccm.p : nullptr);
     if (rc != 0) return fail(PDMP_ERR_HIP, "consume launch failed: %s", hipGetErrorString((hipError_t)rc));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    return PDMP_OK;
+}
+
+// cummean(Ξ) on the device (src/trace.jl:203-226): with it enabled, pdmp_ensemble_consume also leaves, for every event of the segment it consumes, the
+// running pair (t_i, Σ (x_prev + x_k)(t_k − t_prev) / (2 t_i)) of the event's coordinate -- the cursors carry the sums from segment to segment, so the
+// pairs are those of the whole run's trace.  Enable after consume_begin (the synchronous consumer only).
+pdmp_status pdmp_ensemble_consume_cummean(pdmp_ensemble* e, int enable) {
+    if (!e) return fail(PDMP_ERR_INVALID, "null argument");
+    if (!e->consuming) return fail(PDMP_ERR_INVALID, "pdmp_ensemble_consume_begin first");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    if (enable) {
+        const size_t n = (size_t)e->cfg.nchains * (size_t)e->cfg.trace_capacity * 2;
+        pdmp_status st;
+        if (e->d_ccm.n != n && (st = e->d_ccm.alloc(n)) != PDMP_OK) return st;
+    }
+    e->cons_cummean = enable != 0;
+    return PDMP_OK;
+}
+// ... the pairs of slots [first, first + count) of `chain`'s segment (the same slots pdmp_ensemble_trace_copy returns the events of)
+pdmp_status pdmp_ensemble_consume_cummean_copy(pdmp_ensemble* e, int64_t chain, int64_t first, int64_t count, double* t_out, double* y_out) {
+    if (!e || !t_out || !y_out) return fail(PDMP_ERR_INVALID, "null argument");
+    if (!e->cons_cummean) return fail(PDMP_ERR_INVALID, "pdmp_ensemble_consume_cummean(ens, 1) first");
+    if (chain < 0 || chain >= e->cfg.nchains || first < 0 || count < 0 || first + count > e->cfg.trace_capacity) return fail(PDMP_ERR_INVALID, "range out of bounds");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(device_sync(e));
+    std::vector<double> pairs((size_t)count * 2);
+    if (count) HIP_TRY(hipMemcpy(pairs.data(), e->d_ccm.p + 2 * (chain * e->cfg.trace_capacity + first), (size_t)count * 2 * sizeof(double), hipMemcpyDeviceToHost));
+    for (int64_t k = 0; k < count; ++k) {
+        t_out[k] = pairs[(size_t)(2 * k)];
+        y_out[k] = pairs[(size_t)(2 * k + 1)];
+    }
+    return PDMP_OK;
+}
+
+// subtrace(Ξ, J) on the device (src/trace.jl:275-290): the events of `chain`'s current segment whose coordinate lies in the ascending index set J,
+// renumbered by their position in J, compacted by a kernel and copied out (n_out: how many there are; at most out_cap are written)
+pdmp_status pdmp_ensemble_subtrace_copy(pdmp_ensemble* e, int64_t chain, const int64_t* J, int64_t nJ, pdmp_event* out, int64_t out_cap, int64_t* n_out) {
+    if (!e || !J || !n_out || (out_cap > 0 && !out)) return fail(PDMP_ERR_INVALID, "null argument");
+    NEED_FACTORISED(e);
+    if (e->cfg.trace_capacity <= 0) return fail(PDMP_ERR_INVALID, "ensemble was created with trace_capacity = 0");
+    if (chain < 0 || chain >= e->cfg.nchains || nJ < 0 || out_cap < 0) return fail(PDMP_ERR_INVALID, "bad argument");
+    const int64_t d = e->cfg.d;
+    std::vector<int32_t> loc((size_t)d, -1);
+    for (int64_t k = 0; k < nJ; ++k) {
+        if (J[k] < 0 || J[k] >= d || (k > 0 && J[k] <= J[k - 1])) return fail(PDMP_ERR_INVALID, "J must be ascending coordinates in [0, d) (@assert issorted(J), src/trace.jl:276)");
+        loc[(size_t)J[k]] = (int32_t)k;
+    }
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(device_sync(e));
+    pdmp::DevChain h;
+    HIP_TRY(hipMemcpy(&h, e->d_hdr.p + chain, sizeof h, hipMemcpyDeviceToHost));
+    const int64_t n = (int64_t)std::min<uint64_t>(h.c.ntrace, (uint64_t)e->cfg.trace_capacity);
+    DevBuf<int32_t> dloc;
+    DevBuf<pdmp_event> dout;
+    DevBuf<unsigned long long> dn;
+    pdmp_status st;
+    if ((st = dloc.upload(loc)) != PDMP_OK) return st;
+    if ((st = dout.alloc((size_t)std::max<int64_t>(out_cap, 1))) != PDMP_OK) return st;
+    if ((st = dn.alloc(1)) != PDMP_OK) return st;
+    int rc = pdmp::launch_trace_subtrace(e->d_ev.p + chain * e->cfg.trace_capacity, n, dloc.p, dout.p, out_cap, dn.p, e->stream);
+    if (rc != 0) return fail(PDMP_ERR_HIP, "trace_subtrace launch failed: %s", hipGetErrorString((hipError_t)rc));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    unsigned long long cnt = 0;
+    HIP_TRY(hipMemcpy(&cnt, dn.p, sizeof cnt, hipMemcpyDeviceToHost));
+    *n_out = (int64_t)cnt;
+    const int64_t ncopy = std::min<int64_t>((int64_t)cnt, out_cap);
+    if (ncopy > 0) HIP_TRY(hipMemcpy(out, dout.p, (size_t)ncopy * sizeof(pdmp_event), hipMemcpyDeviceToHost));
     return PDMP_OK;
 }
 

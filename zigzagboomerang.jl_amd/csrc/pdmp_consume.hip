@@ -102,7 +102,7 @@ __device__ __forceinline__ void consume_emit(double* grid_chain, int64_t d, int6
 constexpr int CONSUME_HASH = 4096;  // slots of the per-chunk table that finds two events of one coordinate
 __global__ __launch_bounds__(256) void consume_events_kernel(const pdmp_event* ev0, int64_t cap, const DevChain* hdr, const uint64_t* __restrict__ snap,
                                                              int64_t d, ConsumeCursor* cur0, double* zs0, ConsumeMeta* meta, double* grid0, int64_t K,
-                                                             double t0, double dt) {
+                                                             double t0, double dt, double2* cm0) {
     const int64_t chain = blockIdx.x;
     const int tid = threadIdx.x;
     __shared__ uint32_t s_i[256];
@@ -178,6 +178,9 @@ __global__ __launch_bounds__(256) void consume_events_kernel(const pdmp_event* e
                     c.x = evt.x;
                     c.th = evt.theta;
                     cur[i] = c;
+                    // cummean(Ξ), src/trace.jl:203-226: after each event of coordinate i the pair (t[i], y[i] / (2 t[i])) -- the same sum, the same
+                    // order of operations per coordinate; written beside the event's slot (round 6)
+                    if (cm0) cm0[chain * cap + (int64_t)e] = make_double2(c.t, c.y / (2.0 * c.t));
                     __threadfence_block();
                     s_done[tid] = 1;
                     mine_done = true;
@@ -261,9 +264,54 @@ int launch_consume_init(const ZzRec* rec, int64_t rec_stride, int64_t d, int64_t
     return (int)hipGetLastError();
 }
 int launch_consume_events(const pdmp_event* ev, int64_t cap, const DevChain* hdr, const uint64_t* snap, int64_t d, int64_t nchains, void* cur,
-                          bool with_z, void* meta, double* grid, int64_t K, double t0, double dt, void* stream) {
+                          bool with_z, void* meta, double* grid, int64_t K, double t0, double dt, void* stream, double* cummean_pairs) {
     hipLaunchKernelGGL(consume_events_kernel, dim3((unsigned)nchains), dim3(256), 0, (hipStream_t)stream, ev, cap, hdr, snap, d,
-                       static_cast<ConsumeCursor*>(cur), z_of(cur, d, nchains, with_z), static_cast<ConsumeMeta*>(meta), grid, K, t0, dt);
+                       static_cast<ConsumeCursor*>(cur), z_of(cur, d, nchains, with_z), static_cast<ConsumeMeta*>(meta), grid, K, t0, dt,
+                       reinterpret_cast<double2*>(cummean_pairs));
+    return (int)hipGetLastError();
+}
+
+// subtrace(tr, J), src/trace.jl:275-290, on a chain's trace segment: the events whose coordinate lies in J, renumbered by their position in J (loc[i] =
+// position of i in J, or -1), in their order; one workgroup, chunks of 256 events compacted by a block-wide prefix count
+__global__ __launch_bounds__(256) void trace_subtrace_kernel(const pdmp_event* __restrict__ ev, int64_t n, const int32_t* __restrict__ loc, pdmp_event* __restrict__ out,
+                                                            int64_t out_cap, unsigned long long* n_out) {
+    __shared__ uint32_t s_cnt[256];
+    __shared__ unsigned long long s_base;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_base = 0ull;
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += 256) {
+        const int64_t k = base + tid;
+        pdmp_event e;
+        e.t = 0.0;
+        e.i = 0;
+        e.x = e.theta = 0.0;
+        int32_t l = -1;
+        if (k < n) {
+            e = ev[k];
+            l = loc[e.i];
+        }
+        s_cnt[tid] = (l >= 0) ? 1u : 0u;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {  // inclusive prefix sum
+            const uint32_t v = (tid >= off) ? s_cnt[tid - off] : 0u;
+            __syncthreads();
+            s_cnt[tid] += v;
+            __syncthreads();
+        }
+        const unsigned long long at = s_base + (unsigned long long)s_cnt[tid] - 1ull;
+        if (l >= 0 && (int64_t)at < out_cap) {
+            e.i = (int64_t)l;
+            out[at] = e;
+        }
+        __syncthreads();
+        if (tid == 255) s_base += (unsigned long long)s_cnt[255];
+        __syncthreads();
+    }
+    if (tid == 0) *n_out = s_base;
+}
+int launch_trace_subtrace(const pdmp_event* ev, int64_t n, const int32_t* loc, pdmp_event* out, int64_t out_cap, unsigned long long* n_out, void* stream) {
+    hipLaunchKernelGGL(trace_subtrace_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ev, n, loc, out, out_cap, n_out);
     return (int)hipGetLastError();
 }
 // what a finished launch left in its trace segments, per chain, and the segments handed back empty (the event loop's next launch writes the OTHER

@@ -400,7 +400,8 @@ int launch_consume_init(const ZzRec* rec, int64_t rec_stride, int64_t d, int64_t
                         int64_t K, void* stream);
 int launch_consume_snapshot(DevChain* hdr, int64_t nchains, uint64_t* snap, void* stream);
 int launch_consume_events(const pdmp_event* ev, int64_t cap, const DevChain* hdr, const uint64_t* snap, int64_t d, int64_t nchains, void* cur,
-                          bool with_z, void* meta, double* grid, int64_t K, double t0, double dt, void* stream);
+                          bool with_z, void* meta, double* grid, int64_t K, double t0, double dt, void* stream, double* cummean_pairs = nullptr);
+int launch_trace_subtrace(const pdmp_event* ev, int64_t n, const int32_t* loc, pdmp_event* out, int64_t out_cap, unsigned long long* n_out, void* stream);
 int launch_consume_flush(int64_t d, int64_t nchains, const void* cur, const void* meta, double* grid, int64_t K, double t0, double dt, void* stream);
 int launch_consume_mean(int64_t d, int64_t chain_first, int64_t n, const void* cur, const void* meta, double* mean_out, double* T_out, void* stream);
 int launch_consume_inclusion(int64_t d, int64_t nchains, bool with_z, double t0, int64_t chain_first, int64_t n, void* cur, const void* meta, double* out,

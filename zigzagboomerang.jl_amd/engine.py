@@ -350,6 +350,25 @@ class Ensemble:
         _lib.check(self._L.pdmp_ensemble_consume_mean(self._h, int(chain_first), int(n), _ptr(m), _ptr(T)))
         return m, T
 
+    def consume_cummean(self, enable=True):
+        """cummean(Ξ) on the device (src/trace.jl:203-226): with it on, consume() also leaves the running (t, y / (2 t)) pair of every event's coordinate."""
+        _lib.check(self._L.pdmp_ensemble_consume_cummean(self._h, int(bool(enable))))
+
+    def consume_cummean_pairs(self, chain, count, first=0):
+        """The pairs of slots [first, first + count) of `chain`'s last consumed segment: (t, y) arrays aligned with trace(chain)."""
+        t, y = np.empty(int(count)), np.empty(int(count))
+        _lib.check(self._L.pdmp_ensemble_consume_cummean_copy(self._h, int(chain), int(first), int(count), _ptr(t), _ptr(y)))
+        return t, y
+
+    def subtrace(self, chain, J):
+        """subtrace(Ξ, J) of `chain`'s current trace segment, compacted on the device (src/trace.jl:275-290): EVENT_DTYPE array with renumbered i."""
+        import ctypes
+        J = np.ascontiguousarray(J, dtype=np.int64)
+        out = np.empty(max(self.trace_capacity, 1), dtype=_lib.EVENT_DTYPE)
+        n = ctypes.c_int64(0)
+        _lib.check(self._L.pdmp_ensemble_subtrace_copy(self._h, int(chain), J.ctypes.data, int(J.size), out.ctypes.data, int(out.size), ctypes.byref(n)))
+        return out[:n.value].copy()
+
     def consume_inclusion(self, chain_first=0, n=None):
         """(inclusion_prob [n x d], T_last [n]): inclusion_prob(Ξ) of src/trace.jl:161-178 per chain, from the device-side cursors."""
         if n is None:
