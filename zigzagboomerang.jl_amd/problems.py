@@ -223,6 +223,23 @@ def spike_slab_logistic_problem(p=10_000, num_rows=2000, gamma0=0.25, w=0.5, see
     At.sort_indices()
     Ad = A.toarray()
     x = np.zeros(p)
+    if n > p:
+        # the script's own population (scripts/exampledesign.jl:2: 50 000 rows) has more rows than columns: the Newton step in its primal form,
+        # (γ0 I + A'WA) δ = g, a p x p system (bench.py --c5-rows 50000: a one-off measurement, minutes of host time)
+        for _ in range(12):
+            u = Ad @ x
+            g = gamma0 * x - Ad.T @ (y * sig(-u)) + Ad.T @ (ny * sig(u))
+            wgt = sig(u) * sig(-u)
+            H = Ad.T @ (wgt[:, None] * Ad)
+            H[np.diag_indices(p)] += gamma0
+            step = np.linalg.solve(H, g)
+            x = x - step
+            if np.linalg.norm(step) <= 1e-12 * (1.0 + np.linalg.norm(x)):
+                break
+        mu = x
+        kappa = np.full(p, (gamma0 / np.sqrt(2 * np.pi)) / (1 / w - 1))
+        return dict(A=A, At=At, y=y, ny=ny, mu=mu, gamma0=gamma0, kappa=kappa, G=sp.identity(p, format="csc"), sigma=np.ones(p),
+                    c=np.ones(p), xtrue=xtrue, n=n, p=p, w=w)
     for _ in range(12):  # Newton on the slab posterior; (γ0 I + B'B)⁻¹ g = (g − B'(γ0 I + B B')⁻¹ B g)/γ0 with B = W^½ A (n < p)
         u = Ad @ x
         g = gamma0 * x - Ad.T @ (y * sig(-u)) + Ad.T @ (ny * sig(u))
