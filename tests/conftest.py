@@ -12,6 +12,10 @@ for p in (HERE, ROOT):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950) device; run with -m gpu on the GPU box")
+    # a kernel that never returns must not take the whole run with it (pytest-timeout is in the image; a test's own budget is minutes at most):
+    # per-test timeout unless the command line gave one
+    if config.pluginmanager.hasplugin("timeout") and not getattr(config.option, "timeout", None):
+        config.option.timeout = 900
 
 
 @pytest.fixture(scope="session")

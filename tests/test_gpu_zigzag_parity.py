@@ -224,7 +224,7 @@ def test_refresh_clock_matches_oracle(gpu_pkg):
             assert np.array_equal(acc[k], r["acc"])
 
 
-@pytest.mark.parametrize("n,T,lam", [(48, 3.0, 2.0), (128, 1.0, 8.0)])
+@pytest.mark.parametrize("n,T,lam", [(48, 3.0, 2.0), (50, 3.0, 2.0), (128, 1.0, 8.0)])  # (50: d = 2500 is no multiple of 32 -- the clock's slot shares a key block with coordinates)
 def test_refresh_clock_on_the_speculative_kernel(gpu_pkg, monkeypatch, n, T, lam):
     """λref > 0 at d = 2304 and d = 16384 (round 6): the 8-event lattice kernel (the default there) and the 4-event kernel take the run -- the
     clock's events are processed by themselves between their speculative iterations (src/sfact.jl:78-114) -- and commit, bit for bit, what the
@@ -279,6 +279,56 @@ def test_refresh_clock_on_the_speculative_kernel(gpu_pkg, monkeypatch, n, T, lam
             assert np.array_equal(ev[f], r["events"][f]), (k, f)
         assert int(res["auto"][1]["num"][k]) == r["num"] and int(res["auto"][1]["nrefresh"][k]) == r["nrefresh"]
         assert np.array_equal(res["auto"][2]["x"][k], r["x"]) and np.array_equal(res["auto"][2]["theta"][k], r["theta"])
+
+
+@pytest.mark.parametrize("which", ["random6", "lattice3d"])
+def test_refresh_clock_off_the_lattice(gpu_pkg, which):
+    """λref > 0 on graphs that are not the 2-d lattice (round 6): zz_local_spec8g_kernel (the default there) and the 4-event kernel against the one-event
+    kernel -- events, counters, both streams, final state bit for bit -- and the oracle."""
+    pkg = gpu_pkg
+    L = pkg._lib
+    G = pkg.problems.random_sparse_precision(2500, 6, seed=5) if which == "random6" else pkg.problems.lattice3d_precision(14)
+    d = G.shape[0]
+    rng = np.random.default_rng(d)
+    sig = 0.5 + rng.random(d)
+    nch, T, lam = 2, 2.0, 3.0
+    x0 = rng.standard_normal((nch, d))
+    th0 = sig * rng.choice([-1.0, 1.0], (nch, d))
+    c = 4.0 * pkg.problems.column_norms(G)
+    seeds = [1177 + k for k in range(nch)]
+    res = {}
+    for kern in ("auto", "spec4", "seq"):
+        with pkg.Ensemble(nch, d, trace_capacity=3000) as ens:
+            ens.debug_set_kernel(kern)
+            ens.set_flow(pkg.ZigZag(G, np.zeros(d), sig, λref=lam))
+            ens.set_target(pkg.GaussianTarget(G))
+            ens.set_state(0.0, x0, th0, c, seeds)
+            evs = [[] for _ in range(nch)]
+            while True:
+                ens.run(T, L.RUN_REFERENCE_TAIL)
+                cnt = ens.counters()
+                for k in range(nch):
+                    evs[k].append(ens.trace(k, counters=cnt))
+                ens.trace_reset()
+                if not L.needs_rerun(cnt["status"]):
+                    break
+            res[kern] = ([np.concatenate(e) for e in evs], cnt, ens.final_state(), ens.kernel_name())
+    assert res["auto"][3].startswith("zz_local_spec8g_kernel") and res["seq"][3] == "zz_local_run_kernel", (res["auto"][3], res["spec4"][3])
+    assert res["spec4"][3].startswith("zz_local_spec_kernel"), res["spec4"][3]
+    for kern in ("auto", "spec4"):
+        for f in ("num", "nacc", "nevents", "nrefresh", "ndraw_main", "ndraw_global", "status"):
+            assert np.array_equal(res[kern][1][f], res["seq"][1][f]), (kern, f)
+        for k in range(nch):
+            for f in ("i", "t", "x", "theta"):
+                assert np.array_equal(res[kern][0][k][f], res["seq"][0][k][f]), (kern, k, f)
+            for f in ("t", "x", "theta", "acc"):
+                assert np.array_equal(res[kern][2][f][k], res["seq"][2][f][k]), (kern, k, f)
+    r = O.spdmp_zigzag(G, None, G, x0[0], th0[0], c, T, seed=seeds[0], lambda_ref=lam, sigma=sig)
+    assert r["status"] == 0 and r["nrefresh"] >= 2, (r["status"], r["nrefresh"])
+    ev = res["auto"][0][0]
+    assert len(ev) == len(r["events"])
+    for f in ("i", "t", "x", "theta"):
+        assert np.array_equal(ev[f], r["events"][f]), f
 
 
 def test_pdmp_all_matches_oracle(gpu_pkg):

@@ -1515,9 +1515,8 @@ static pdmp_status ensemble_run_impl(pdmp_ensemble* e, double T, int flags, void
     DevBuf<double> phbuf;
     // (33 <= |S| <= 64: no blob kernel takes it, but zz_local_spec8g_kernel<.., GW = 16> does where its own conditions hold)
     const bool g16_ok = e->has_g8 && e->g8_gw == 16 && e->dbg_kernel == PDMP_DEBUG_KERNEL_AUTO && (P.flags & 0x100) && !phenv;
-    // (a refresh clock, src/sfact.jl:78-114: the 4-event kernel processes the clock's events by themselves between its speculative iterations --
-    // round 6; the 8-event kernels have no such step and are not chosen then: launch_zz_local_spec)
-    const bool spec_ok = (e->use_spec || (g16_ok && !P.has_refresh)) && dbg_cap == 0 && !P.move_all && !sticky;
+    // (a refresh clock, src/sfact.jl:78-114: the speculative kernels process the clock's events by themselves between their iterations -- round 6)
+    const bool spec_ok = (e->use_spec || g16_ok) && dbg_cap == 0 && !P.move_all && !sticky;
     const bool general_path = e->needs_general || e->target_kind == 1 || e->adaptscale || e->local_bound;
     if (phenv && (spec_ok || general_path || e->track)) {  // (the tracked kernels take every d their layout serves: d = 65536 has no speculative kernel beside it)
         pdmp_status st3 = phbuf.alloc(16);

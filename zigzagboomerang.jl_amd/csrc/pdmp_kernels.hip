@@ -2212,11 +2212,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     }
     for (uint32_t b = lane; b < nblk; b += 64) {
         const double* kp = keys + (size_t)b * 32;
-        double mk = kp[0];
+        // (the refresh clock's slot, key d, sits inside the last block when d is no multiple of 32: it is no coordinate -- its time lives in t_ref,
+        // and the slot holds +Inf in memory for as long as this launch runs, so that the rescans of its block do not see it either)
+        double mk = (has_refresh && b * 32 == (uint32_t)d) ? PDMP_INF : kp[0];
         uint32_t mi = 0;
 #pragma unroll 8
         for (int q = 1; q < 32; ++q) {
-            const double v = kp[q];
+            const double v = (has_refresh && b * 32 + (uint32_t)q == (uint32_t)d) ? PDMP_INF : kp[q];
             if (v < mk) {
                 mk = v;
                 mi = q;
@@ -2230,6 +2232,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         bi[b] = 0;
     }
     LDS_ORDER();
+    if (has_refresh && lane == 0) __hip_atomic_store(keys + d, PDMP_INF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     uint32_t rng_base = 0xffffffffu;
     double ureg = 0.0;  // draw rng_base + lane of the chain's stream
@@ -2450,8 +2453,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 rs->t = t;
                 rs->I = I;
             }
-            if (lane == 0) keys[d] = newref;
-            t_ref = newref;
+            t_ref = newref;  // (stored into keys[d] when the launch ends)
             for (int jj = 0; jj < k; ++jj) {  // first level: blocks of 32 keys
                 const uint32_t j = readlane_u32(s, jj);
                 const double kjv = readlane_f64(key, jj);
@@ -2954,6 +2956,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         hdr->c.nevents += dnacc + dnref;
         hdr->c.nrefresh += dnref;
         hdr->c.ndraw_global = ng;
+        if (has_refresh) keys[d] = t_ref;
         hdr->c.ndraw_main = nm0 + dnm;
         hdr->c.status = status;
     }
@@ -4345,7 +4348,7 @@ int launch_zz_local_spec(const ZzRunParams& p, int64_t nchains, void* stream, co
                        !p.force_spec4;  // (pdmp_debug_set_kernel: A/B runs and parity tests of the 4-event kernel)
     const bool wide = p.blob_sw > 8;  // |S[i]| up to 32: two zone members per lane
     // eight events per iteration on any graph with |G1| <= 8, |S| <= 32 (tables built by the host when the geometry fits), plain configuration
-    const bool spec8g = !spec8 && p.g8_line != nullptr && (p.flags & 0x100) && !p.has_refresh && p.d >= 2048 && p.d <= (int64_t)S8_NBLK * 32 && !p.force_spec4;
+    const bool spec8g = !spec8 && p.g8_line != nullptr && (p.flags & 0x100) && p.d >= 2048 && p.d <= (int64_t)S8_NBLK * 32 && !p.force_spec4;
     if (kname) *kname = spec8 ? "zz_local_spec8_kernel" : spec8g ? (p.g8_gw == 16 ? "zz_local_spec8g_kernel<GW=16>" : "zz_local_spec8g_kernel") : wide ? "zz_local_spec_kernel<WIDE>" : "zz_local_spec_kernel";
     if (spec8g) {
         ZzRunParams q = p;
