@@ -113,6 +113,41 @@ def test_tracked_with_looser_bound_mean_and_adapt(gpu_pkg):
                             O.spdmp_zigzag(0.9 * G, mu, G, x0[k], th0[k], c, T, seed=31 + k, target_mu=mu, adapt=True, factor=1.8, tracked=True))
 
 
+@pytest.mark.parametrize("n", [48, 64])
+def test_tracked_adapt_on_the_one_proposal_per_lane_kernel(gpu_pkg, n, trackp_form):
+    """adapt = true on the one-proposal-per-lane tracked kernel (round 6; before, adaptation dropped to the 8-lane-group kernel): bounds that start far too
+    small are multiplied by `factor` where a proposal violates them (src/sfact.jl:123-128, src/fact_samplers.jl:67-70) and the run goes on -- events,
+    counters, final state AND the adapted bounds bit for bit the tracked oracle's; events and counters those of the moving oracle."""
+    pkg = gpu_pkg
+    G = pkg.problems.gmrf_precision(n)
+    d = n * n
+    rng = np.random.default_rng(n + 1)
+    nch, T = 3, 4.0
+    x0 = rng.standard_normal((nch, d))
+    th0 = rng.choice([-1.0, 1.0], (nch, d))
+    # (with the bounding Γ equal to the target's the bound exceeds the rate by exactly c_i (1 + Δt / 100): only where c_i is at rounding level can a
+    # proposal violate it -- every eleventh coordinate starts there and adapts upwards until rounding no longer reaches it)
+    c = pkg.problems.column_norms(G)
+    c[::11] = 1e-300
+    tr, (t, x, th), (acc, num), cout = pkg.spdmp(pkg.GaussianTarget(G), 0.0, x0, th0, T, c, pkg.ZigZag(G, np.zeros(d)), seed=911, adapt=True, factor=1.8,
+                                                 tracked=True)
+    with pkg.Ensemble(1, d, adapt=True, factor=1.8) as ens:  # (the line layout does not adapt: that form keeps the pair layout's one-wave kernel here)
+        ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
+        ens.set_target(pkg.GaussianTarget(G))
+        ens.set_gradient_tracking(True)
+        ens.set_state_synthetic(0.0, c, 1)
+        ens.run(0.05)
+        assert ens.kernel_name() == ("zz_local_trackp2_kernel" if trackp_form == "two_waves" else "zz_local_trackp_kernel"), ens.kernel_name()
+    for k in range(nch):
+        rt = O.spdmp_zigzag(G, None, G, x0[k], th0[k], c, T, seed=911 + k, adapt=True, factor=1.8, tracked=True)
+        assert rt["status"] == 0 and np.count_nonzero(rt["c"] > c) > 5 and len(rt["events"]) > 1000  # (bounds did adapt)
+        check_chain_bitwise(tr[k].events, t[k], x[k], th[k], acc[k], num[k], cout[k], rt)
+        # (which proposals violate a vanishing bound is decided by the last bits of the rate: the MOVING evaluation adapts other coordinates at other
+        # times -- its events still agree, its bounds need not: the tracked oracle is the bar here)
+        r = O.spdmp_zigzag(G, None, G, x0[k], th0[k], c, T, seed=911 + k, adapt=True, factor=1.8)
+        check_chain(tr[k].events, t[k], x[k], th[k], acc[k], num[k], None, r)
+
+
 def test_tracked_slices_trace_refills_and_violation(gpu_pkg, trackp_form):
     """Slices with PDMP_RUN_STOP_BEFORE, a trace buffer that fills up several times, the reference tail (last event at t′ >= T), path
     integrals (batch means) against the host integral of the trace, and a bound violation without adapt (status, not a crash)."""

@@ -1819,6 +1819,10 @@ pdmp_status pdmp_ensemble_final_state(pdmp_ensemble* e, int64_t chain_first, int
     if (c && (st = bc.alloc(cnt)) != PDMP_OK) return st;
     const double* c_src = e->cfg.adapt ? e->d_c_chain.p : e->d_c.p;
     const int64_t c_stride = e->cfg.adapt ? d : 0;
+    if (e->track_pairs && e->cfg.adapt) {  // (the one-proposal-per-lane kernel keeps the adapted bounds in its record lines)
+        int rcc = pdmp::launch_zz_trackp_c_out(e->d_rec.p, e->d_c_chain.p, e->cfg.nchains * d, e->stream);
+        if (rcc != 0) return fail(PDMP_ERR_HIP, "trackp_c_out launch failed: %s", hipGetErrorString((hipError_t)rcc));
+    }
     int rc = e->track ? pdmp::launch_zz_track_unpack(reinterpret_cast<const pdmp::TrRec*>(e->d_rec.p), e->tables(), c_src, c_stride, d,
                                                      chain_first, n, e->t0_state, bt.p, bx.p, bth.p, bacc.p, bc.p, e->track_pairs ? e->d_kp.p : nullptr, e->dk, e->stream)
                        : pdmp::launch_zz_unpack(e->d_rec.p, c_src, c_stride, d, chain_first, n, bt.p, bx.p, bth.p, bacc.p, bc.p,

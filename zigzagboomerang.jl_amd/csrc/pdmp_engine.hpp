@@ -378,6 +378,7 @@ int launch_zz_local_exactp(const ZzRunParams& p, int64_t nchains, void* stream);
 bool zz_trackp_supported(const ZzRunParams& p);
 int launch_zz_local_trackp(const ZzRunParams& p, int64_t nchains, void* stream);
 int launch_zz_keys_to_pairs(const double* keys, void* kp, int64_t n, double t0, void* stream);
+int launch_zz_trackp_c_out(const void* rec, double* c_chain, int64_t n, void* stream);
 int launch_zz_trackp_consts(void* rec, const CoordConst* cc, const uint16_t* nb16, int64_t d, int64_t nchains, void* stream);
 // pdmp_trackl.hip: the same kernel on the line layout (full-width launches of the plain lattice, d <= 16384)
 bool zz_trackl_supported(const ZzRunParams& p);

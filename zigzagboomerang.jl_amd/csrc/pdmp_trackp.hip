@@ -995,11 +995,16 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
         // a proposal that violates its bound ends the run (adapt = false: error(...), :124): nothing after it is looked at
         const bool violated0 = acc && (l >= lbound);
         int vsel = -1;
+        uint64_t vb_adapt = 0;  // adapt = true (round 6): the accepted events that multiply their bound by `factor` and go on (adapt!(c, i, factor), :127, src/fact_samplers.jl:67-70)
         {
             const uint64_t vb = __ballot(violated0) & ((C < 64) ? ((1ull << C) - 1ull) : ~0ull);
             if (vb) {
-                vsel = __ffsll((unsigned long long)vb) - 1;
-                C = vsel;  // the violating event itself is not committed
+                if (P.adapt) {
+                    vb_adapt = vb;
+                } else {
+                    vsel = __ffsll((unsigned long long)vb) - 1;
+                    C = vsel;  // the violating event itself is not committed
+                }
             }
         }
         ev = lane < C;
@@ -1014,7 +1019,8 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
         // (the groups of the accepted events are the LAST groups of the wave, in event order: the low lanes -- lane r = event r -- are then free
         // to re-bound their rejected proposals in the same evaluation, see below)
         struct GOut {
-            bool gact, mem, selfl;
+            bool gact, mem, selfl, adapted;
+            double c_new, c100_new;
             uint32_t ea, ia, blka, jm, cand_a;
             double tpa, gj, gdj, keyj, xa, txa, Ia, th_ia, rowmin_a;
             uint64_t acc_ia;
@@ -1093,6 +1099,12 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
             // rejected proposal (:137-140) in its event lane (first pass), the re-bound of a member of G1 (:131-135) in its group lane.  A lane
             // that is both (more than 64 − 8 ng candidates) evaluates its rejected proposal again below.
             const bool selfl = mem && jm == ia;
+            // a violated bound under adapt: c_i <- factor c_i before G1[i] is re-bounded (only i's own bound reads c_i)
+            const bool adapted = selfl && ((vb_adapt >> ea) & 1ull) != 0ull;
+            if (adapted) {
+                cjm2.x = cjm2.x * P.factor;
+                cjm2.y = cjm2.x / 100;
+            }
             const double thj = selfl ? -th_ia : thj0;
             const double gj = gj0 + gdj0 * (tpa - tgj);
             const double gdj = gdj0 + gam * (-2.0 * th_ia);  // θ_i -> −θ_i
@@ -1143,6 +1155,9 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
             o.gact = gact;
             o.mem = mem;
             o.selfl = selfl;
+            o.adapted = adapted;
+            o.c_new = cjm2.x;
+            o.c100_new = cjm2.y;
             o.ea = ea;
             o.ia = ia;
             o.blka = blka;
@@ -1233,6 +1248,7 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
                     ria->tx = o.txa;
                     ria->I = o.Ia;
                     ria->acc = o.acc_ia + 1;
+                    if (o.adapted) *reinterpret_cast<double2*>(&ria->c) = make_double2(o.c_new, o.c100_new);
                     // (the time of i's last accept IS its position's clock tx in this layout -- x_i is brought up on i's accepts only --: a store into
                     // the line's fourth sector, dirty for nothing else, went with it; zz_track_unpack_kernel reads tx)
                     if (evout) {
@@ -1333,7 +1349,8 @@ bool zz_trackp_supported(const ZzRunParams& p) {
     // compared as halves below 2^15: d <= 16384)
     const bool lattice = p.lattice_n >= 16 && p.lattice_n <= 256 && p.d <= (int64_t)WL<false, true>::NBLK * 8;
     const bool graph = p.lattice_n == 0 && p.tb.nb16 != nullptr && p.tb.gam8 != nullptr && p.d <= (int64_t)WL<false>::NBLK * 8;
-    return (lattice || graph) && !p.adapt && p.c_chain == nullptr && p.tb.gmu_t == nullptr && !p.track_two_sums && !p.has_refresh && p.d >= 2048;
+    // (adapt: the per-chain bounds are the c / c100 words of the record lines -- round 6)
+    return (lattice || graph) && p.tb.gmu_t == nullptr && !p.track_two_sums && !p.has_refresh && p.d >= 2048;
 }
 
 int launch_zz_local_trackp(const ZzRunParams& p, int64_t nchains, void* stream) {
@@ -1411,6 +1428,16 @@ int launch_zz_trackp_consts(void* rec, const CoordConst* cc, const uint16_t* nb1
     const unsigned gy = (unsigned)((nchains < 1024) ? nchains : 1024);
     hipLaunchKernelGGL(zz_trackp_consts_kernel, dim3((unsigned)((d + 255) / 256), gy), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<TrRecP*>(rec), cc, nb16, d, nchains);
+    return (int)hipGetLastError();
+}
+
+// adapt: the per-chain bounds live in the record lines; final_state reads them from the engine's c_chain array -- copied there on demand
+__global__ __launch_bounds__(256) void zz_trackp_c_out_kernel(const TrRecP* __restrict__ rec, double* __restrict__ c_chain, int64_t n) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k < n) c_chain[k] = rec[k].c;
+}
+int launch_zz_trackp_c_out(const void* rec, double* c_chain, int64_t n, void* stream) {
+    hipLaunchKernelGGL(zz_trackp_c_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const TrRecP*>(rec), c_chain, n);
     return (int)hipGetLastError();
 }
 
