@@ -148,6 +148,40 @@ def test_tracked_adapt_on_the_one_proposal_per_lane_kernel(gpu_pkg, n, trackp_fo
         check_chain(tr[k].events, t[k], x[k], th[k], acc[k], num[k], None, r)
 
 
+@pytest.mark.parametrize("case", ["flow_mean_only", "same_mean", "different_means"])
+def test_tracked_with_a_flow_mean(gpu_pkg, case, trackp_form):
+    """Z = ZigZag(Γ, μ) with μ ≠ 0 under gradient tracking (round 6).  The flow's Γ[:,i]·μ enters every bound (src/fact_samplers.jl:51); until round 6 the
+    one-proposal-per-lane kernel ignored it (found by this test's first case: a flow mean WITHOUT a target mean diverged from the oracle after five
+    events).  Now the constant rides in the record line: served with no target mean and with a target whose Γμ equals the flow's (the rate subtracts it
+    too); a target mean of its own keeps the 8-lane-group kernel.  Bit for bit the tracked oracle in all three."""
+    pkg = gpu_pkg
+    n = 48
+    G = pkg.problems.gmrf_precision(n)
+    d = n * n
+    rng = np.random.default_rng(3)
+    mu = 0.3 * rng.standard_normal(d)
+    tmu = {"flow_mean_only": None, "same_mean": mu, "different_means": 0.5 * mu}[case]
+    nch, T = 2, 3.0
+    x0 = rng.standard_normal((nch, d))
+    th0 = rng.choice([-1.0, 1.0], (nch, d))
+    c = 3.0 * pkg.problems.column_norms(G)
+    tgt = pkg.GaussianTarget(G) if tmu is None else pkg.GaussianTarget(G, tmu)
+    tr, (t, x, th), (acc, num), _ = pkg.spdmp(tgt, 0.0, x0, th0, T, c, pkg.ZigZag(G, mu), seed=77, tracked=True)
+    with pkg.Ensemble(1, d) as ens:
+        ens.set_flow(pkg.ZigZag(G, mu))
+        ens.set_target(tgt)
+        ens.set_gradient_tracking(True)
+        ens.set_state_synthetic(0.0, c, 1)
+        ens.run(0.05)
+        want = "zz_local_track_kernel" if case == "different_means" else ("zz_local_trackp2_kernel" if trackp_form == "two_waves" else "zz_local_trackp_kernel")
+        assert ens.kernel_name() == want, (case, ens.kernel_name())
+    for k in range(nch):
+        r = O.spdmp_zigzag(G, mu, G, x0[k], th0[k], c, T, seed=77 + k, target_mu=tmu, tracked=True)
+        assert r["status"] == 0 and len(r["events"]) > 1000
+        check_chain_bitwise(tr[k].events, t[k], x[k], th[k], acc[k], num[k], None, r)
+        check_chain(tr[k].events, t[k], x[k], th[k], acc[k], num[k], None, O.spdmp_zigzag(G, mu, G, x0[k], th0[k], c, T, seed=77 + k, target_mu=tmu))
+
+
 def test_tracked_slices_trace_refills_and_violation(gpu_pkg, trackp_form):
     """Slices with PDMP_RUN_STOP_BEFORE, a trace buffer that fills up several times, the reference tail (last event at t′ >= T), path
     integrals (batch means) against the host integral of the trace, and a bound violation without adapt (status, not a crash)."""

@@ -107,7 +107,8 @@ struct pdmp_ensemble {
     bool has_tmu = false;
 
     // host copies of the derived tables (inputs of the per-coordinate blob)
-    std::vector<double> h_gmu_b, h_tval;
+    std::vector<double> h_gmu_b, h_gmu_t, h_tval;
+    int track_mean = 0;  // zz_local_trackp: 0 no mean, 1 the flow's Γμ in the bounds, 2 also in the rate (the target's Γμ equals it); decided by set_state
     std::vector<uint32_t> h_sptr, h_sidx, h_qptr;
     std::vector<uint8_t> h_pos, h_selfpos;
     uint32_t blob_w = 0, blob_w_pad = 0, blob_sw = 0, blob_pw = 0, blob_kmax = 0, blob_mmax = 0;
@@ -849,6 +850,7 @@ pdmp_status pdmp_ensemble_set_target_gaussian_csc(pdmp_ensemble* e, const int64_
         gmu_t[i] = s;
     }
     e->has_tmu = (mu != nullptr);
+    e->h_gmu_t = gmu_t;
     e->target_kind = 0;
     e->h_tval = tval;
     pdmp_status st;
@@ -1327,6 +1329,20 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
         G.track_two_sums = e->track_two_sums ? 1 : 0;
         G.has_refresh = e->lambda_ref > 0;
         G.d = d;
+        // the means (round 6): the one-proposal-per-lane kernel keeps ONE constant Γ[:,i]·μ per coordinate -- the flow's, which enters every bound
+        // (src/fact_samplers.jl:51); a target mean is served where its Γμ is the same numbers (the usual Z = ZigZag(Γ, μ) on ∇ϕ = Γ(x − μ))
+        {
+            bool flow_mean = false;
+            for (double v : e->h_gmu_b) flow_mean = flow_mean || v != 0.0;
+            e->track_mean = flow_mean ? 1 : 0;
+            if (e->has_tmu) {
+                const bool same = e->h_gmu_t.size() == e->h_gmu_b.size() && std::equal(e->h_gmu_t.begin(), e->h_gmu_t.end(), e->h_gmu_b.begin());
+                if (same && !e->track_two_sums) {
+                    e->track_mean = 2;
+                    G.tb.gmu_t = nullptr;  // (served: the support test below need not refuse it)
+                }
+            }
+        }
         trackp_ok = pdmp::zz_trackp_supported(G) && e->dbg_track_groups == 0;
         if (!trackp_ok) e->track_generic = false;
         G.blob_sw = e->blob_sw;
@@ -1364,7 +1380,7 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
             if (e->d_kp.n != (size_t)(2 * n * e->dk) && (st = e->d_kp.alloc((size_t)(2 * n * e->dk))) != PDMP_OK) return st;
             rc = pdmp::launch_zz_keys_to_pairs(e->d_keys.p, e->d_kp.p, n * e->dk, t0, e->stream);
             if (rc != 0) return fail(PDMP_ERR_HIP, "keys_to_pairs launch failed: %s", hipGetErrorString((hipError_t)rc));
-            rc = pdmp::launch_zz_trackp_consts(e->d_rec.p, e->d_cc.p, e->track_generic ? e->d_nb16.p : nullptr, d, n, e->stream);
+            rc = pdmp::launch_zz_trackp_consts(e->d_rec.p, e->d_cc.p, e->track_generic ? e->d_nb16.p : nullptr, e->track_mean ? e->d_gmu_b.p : nullptr, d, n, e->stream);
             if (rc != 0) return fail(PDMP_ERR_HIP, "trackp_consts launch failed: %s", hipGetErrorString((hipError_t)rc));
             e->track_pairs = true;
             // the line layout where the ensemble fills the device (decided here: the layout belongs to the kernel)
@@ -1380,7 +1396,7 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
             // (measured, round 6: 2.7 instead of 3.2 lines read per proposal, but 72 instead of 54 vector instructions -- 47.9 ms against 45.4 / 38.8 ms
             // for pdmp_trackp.hip's form on boxes in the slow / fast timing mode: the layout is kept as an opt-in form, never chosen by width)
             (void)wide;
-            if (pdmp::zz_trackl_supported(G) && !e->track_generic && e->dbg_track_lines == 1) {
+            if (pdmp::zz_trackl_supported(G) && !e->track_generic && e->track_mean == 0 && e->dbg_track_lines == 1) {
                 if (e->d_tl_lines.n != (size_t)(n * e->dk / 2) && (st = e->d_tl_lines.alloc((size_t)(n * e->dk / 2))) != PDMP_OK) return st;
                 if (e->d_tl_cold.n != (size_t)(n * e->dk) && (st = e->d_tl_cold.alloc((size_t)(n * e->dk))) != PDMP_OK) return st;
                 rc = pdmp::launch_zz_trackl_pack(e->d_rec.p, e->d_kp.p, e->d_tl_lines.p, e->d_tl_cold.p, d, e->dk, n, e->stream);
@@ -1635,6 +1651,8 @@ static pdmp_status ensemble_run_impl(pdmp_ensemble* e, double T, int flags, void
         }
         if (e->track_pairs) {
             P.keys = e->d_kp.p;
+            P.track_mean = e->track_mean;
+            if (e->track_mean == 2) P.tb.gmu_t = nullptr;  // (the rate's mean rides in the record lines)
             // the two-wave form (a helper wave per chain) where the ensemble leaves SIMDs idle: at most two resident waves per SIMD with it
             // (1024 SIMDs, two waves per chain) -- a rank's share of a strong-scaled job; wider ensembles hide a wave's latency with other chains
             {

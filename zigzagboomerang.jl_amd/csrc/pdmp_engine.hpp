@@ -175,6 +175,7 @@ struct ZzRunParams {
     int32_t move_all;  // G = All(): the `pdmp` driver for ZigZag (src/sfact.jl:236)
     int32_t force_spec4;  // diagnostics (pdmp_debug_set_kernel): keep the 4-event kernel where the 8-event one would run
     int32_t track_two_sums;  // tracked-gradient kernel: the bounding Γ differs from the target's (two pairs of sums per coordinate)
+    int32_t track_mean;      // zz_local_trackp: 0 no mean, 1 the flow's Γμ in the bounds only, 2 also in the rate (the target has the same Γμ); host-set
     uint32_t count_limit;    // a chain whose launch has used this many draws (proposals: the logistic kernel) pauses: PDMP_LAUNCH_COUNT_LIMIT, or a test's
     uint32_t typ_extra;      // zz_local_trackp: the most frequent |G1[i]| − 1 (the accept chain's first guess; any value is correct)
     double hw_gain, hw_ahead;  // ... its steering of the selection threshold (gain towards a target count) and how far ahead the helper requests lines
@@ -379,7 +380,7 @@ bool zz_trackp_supported(const ZzRunParams& p);
 int launch_zz_local_trackp(const ZzRunParams& p, int64_t nchains, void* stream);
 int launch_zz_keys_to_pairs(const double* keys, void* kp, int64_t n, double t0, void* stream);
 int launch_zz_trackp_c_out(const void* rec, double* c_chain, int64_t n, void* stream);
-int launch_zz_trackp_consts(void* rec, const CoordConst* cc, const uint16_t* nb16, int64_t d, int64_t nchains, void* stream);
+int launch_zz_trackp_consts(void* rec, const CoordConst* cc, const uint16_t* nb16, const double* gmu, int64_t d, int64_t nchains, void* stream);
 // pdmp_trackl.hip: the same kernel on the line layout (full-width launches of the plain lattice, d <= 16384)
 bool zz_trackl_supported(const ZzRunParams& p);
 int launch_zz_local_trackl(const ZzRunParams& p, int64_t nchains, void* stream);

@@ -647,6 +647,12 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
         const TrRecP* const rci = rec + ci;
         const double c_th = rci->th, c_g = rci->g, c_gd = rci->gd, c_tg = rci->tg;
         const double2 c_c2 = *reinterpret_cast<const double2*>(&rci->c);  // (same line: no table in the event loop)
+        // Γ[:,i]·μ of the flow (src/fact_samplers.jl:51: a = c + (Γ[:,i]·x − Γ[:,i]·μ) θ_i), kept in the record line's spare word where a mean is set
+        // (round 6: until then a flow mean without a target mean was silently ignored here); track_mean = 2: the target has the same mean and the
+        // rate subtracts it too (∇ϕ_i = Γ[:,i]·x − (Γμ)_i)
+        const int tmean = P.track_mean;  // (wave-uniform)
+        double c_gmu = 0.0;
+        if (tmean) c_gmu = rci->tacc;
         uint4 c_nb = make_uint4(0u, 0u, 0u, 0u);
         if (!LAT) c_nb = *reinterpret_cast<const uint4*>(&rci->gam0);  // G1[ci]: eight 16-bit ids
         // the exact minimum of the block, its position (the lowest on ties) and time, the minimum of the rest and its position: in the lane's own
@@ -766,6 +772,8 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
         };
         const double e_km = push64(c_km), e_rs = push64(c_rs), e_tp = push64(c_tp);
         const double e_th = push64(c_th), e_g = push64(c_g), e_gd = push64(c_gd), e_tg = push64(c_tg), e_c = push64(c_c2.x), e_c100 = push64(c_c2.y);
+        double e_gmu = 0.0;
+        if (tmean) e_gmu = push64(c_gmu);
         const uint32_t e_bu = push32(cblk | (c_pb << 16));
         uint4 e_nb = make_uint4(~0u, ~0u, ~0u, ~0u);
         if (!LAT) e_nb = make_uint4(push32(c_nb.x), push32(c_nb.y), push32(c_nb.z), push32(c_nb.w));
@@ -778,7 +786,7 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
         // (the candidates' record loads are named here, before the first branch that can leave the iteration: hipcc's structured control flow has
         // edges from the idle path below to the loop's latch that no wave ever takes, and a load still in flight along one of them put
         // s_waitcnt vmcnt(0) at the loop's head and latch -- where it waits for the COMMIT'S STORES of every iteration: read off the ISA in round 5)
-        asm volatile("" ::"v"(c_th), "v"(c_g), "v"(c_gd), "v"(c_tg), "v"(c_c2.x), "v"(c_c2.y), "v"(c_nb.x));
+        asm volatile("" ::"v"(c_th), "v"(c_g), "v"(c_gd), "v"(c_tg), "v"(c_c2.x), "v"(c_c2.y), "v"(c_nb.x), "v"(c_gmu));
         if (C == 0) {
             // nothing to do in this window (stale bounds refreshed, a wrong position fixed, or no key before T)
             if (tau_clipped && !crowded && __ballot(isc && c_km <= tau) == 0) break;  // stop_before: every key is at or beyond T
@@ -819,11 +827,13 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
         W_ORDER();
         // ---------------- rates from the tracked sums (src/sfact.jl:116-119 with g_i(t′) = g_i + gd_i (t′ − tg_i))
         const double g_now = g_i + gd_i * (tp - tg_i);
-        const double l = w_pos(g_now * th);
+        const double gmu_i = e_gmu;
+        const double l = w_pos(((tmean == 2) ? g_now - gmu_i : g_now) * th);
         // the bound in force (src/fact_samplers.jl:50-54), re-derived: it was computed at t_old (the coordinate's last proposal or the last
         // re-basing of its sums, whichever came later: stored with the key) from exactly these operands
         const double told_i = tprop_i;
-        const double a_i = c_i + (g_i + gd_i * (told_i - tg_i)) * th;
+        const double g_told = g_i + gd_i * (told_i - tg_i);
+        const double a_i = c_i + (tmean ? g_told - gmu_i : g_told) * th;
         const double b_i = c_i2.y + th * gd_i;
         const double lbound = w_pos(a_i + b_i * (tp - told_i));
         // ---------------- accept chain: offsets and outcomes as a fix-point (every round settles the events up to the next change).  Event r's coin is
@@ -1091,6 +1101,8 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
             double xa = ria->x, txa = ria->tx, Ia = ria->I;
             const uint64_t acc_ia = ria->acc;
             const double thj0 = rj->th, gj0 = rj->g, gdj0 = rj->gd, tgj = rj->tg;
+            double gmu_j = 0.0;
+            if (tmean) gmu_j = rj->tacc;
             double2 cjm2 = *reinterpret_cast<const double2*>(&rj->c);
             asm volatile("" : "+v"(cjm2.x), "+v"(cjm2.y));  // (one 16-byte load with the others: hipcc sank the second half under the select below, a dependent round trip)
             const double resta_b = w_shfl(rest, ea);  // the accepted event's block without it, and where that minimum sits
@@ -1114,7 +1126,8 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
                 const uint32_t dix = mine ? (offa + 1u + (uint32_t)gl) : (off + 1u);
                 const double Lg = drawlog(dnm + ((dix < W_WIN - 1u) ? dix : W_WIN - 1u));
                 const double cc = mine ? cjm2.x : c_i, cc100 = mine ? cjm2.y : c_i2.y;
-                const double gg = mine ? gj : g_now, tt = mine ? thj : th, gdd = mine ? gdj : gd_i;
+                const double gg0 = mine ? gj : g_now, tt = mine ? thj : th, gdd = mine ? gdj : gd_i;
+                const double gg = tmean ? gg0 - (mine ? gmu_j : gmu_i) : gg0;
                 a2l = cc + gg * tt;
                 b2l = cc100 + tt * gdd;
                 key2l = (mine ? tpa : tp) + w_poisson_time_L(a2l, b2l, Lg);
@@ -1123,7 +1136,7 @@ __device__ __forceinline__ void trackp_body(const ZzRunParams& P) {
             if (first) {
                 if (__ballot(ev && !acc && gact) != 0) {
                     const double Le = drawlog(dnm + ((off + 1u < W_WIN - 1u) ? off + 1u : W_WIN - 1u));
-                    const double a2e = c_i + g_now * th;
+                    const double a2e = c_i + (tmean ? g_now - gmu_i : g_now) * th;
                     const double b2e = c_i2.y + th * gd_i;
                     const double k2e = tp + w_poisson_time_L(a2e, b2e, Le);
                     if (gact) key2l = k2e;
@@ -1350,6 +1363,8 @@ bool zz_trackp_supported(const ZzRunParams& p) {
     const bool lattice = p.lattice_n >= 16 && p.lattice_n <= 256 && p.d <= (int64_t)WL<false, true>::NBLK * 8;
     const bool graph = p.lattice_n == 0 && p.tb.nb16 != nullptr && p.tb.gam8 != nullptr && p.d <= (int64_t)WL<false>::NBLK * 8;
     // (adapt: the per-chain bounds are the c / c100 words of the record lines -- round 6)
+    // (means: track_mean is set by the host -- 0 none, 1 the flow's only, 2 flow and target with the same Γμ; a target mean that differs from the flow's
+    // keeps the 8-lane-group kernel: the host passes gmu_t then)
     return (lattice || graph) && p.tb.gmu_t == nullptr && !p.track_two_sums && !p.has_refresh && p.d >= 2048;
 }
 
@@ -1403,7 +1418,7 @@ int launch_zz_local_trackp(const ZzRunParams& p, int64_t nchains, void* stream) 
 
 // the per-coordinate constants into the two free sectors of every record (after the init kernel)
 __global__ __launch_bounds__(256) void zz_trackp_consts_kernel(TrRecP* __restrict__ rec, const CoordConst* __restrict__ cc,
-                                                              const uint16_t* __restrict__ nb16, int64_t d, int64_t nchains) {
+                                                              const uint16_t* __restrict__ nb16, const double* __restrict__ gmu, int64_t d, int64_t nchains) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= d) return;
     const CoordConst e = cc[i];
@@ -1422,12 +1437,13 @@ __global__ __launch_bounds__(256) void zz_trackp_consts_kernel(TrRecP* __restric
         r->gam2 = e.gam[2];
         r->gam3 = e.gam[3];
         r->gam4 = e.gam[4];
+        r->tacc = gmu ? gmu[i] : 0.0;  // (the spare word: Γ[:,i]·μ of the flow where a mean is set)
     }
 }
-int launch_zz_trackp_consts(void* rec, const CoordConst* cc, const uint16_t* nb16, int64_t d, int64_t nchains, void* stream) {
+int launch_zz_trackp_consts(void* rec, const CoordConst* cc, const uint16_t* nb16, const double* gmu, int64_t d, int64_t nchains, void* stream) {
     const unsigned gy = (unsigned)((nchains < 1024) ? nchains : 1024);
     hipLaunchKernelGGL(zz_trackp_consts_kernel, dim3((unsigned)((d + 255) / 256), gy), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<TrRecP*>(rec), cc, nb16, d, nchains);
+                       reinterpret_cast<TrRecP*>(rec), cc, nb16, gmu, d, nchains);
     return (int)hipGetLastError();
 }
 
