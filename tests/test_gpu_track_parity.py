@@ -182,6 +182,26 @@ def test_tracked_with_a_flow_mean(gpu_pkg, case, trackp_form):
         check_chain(tr[k].events, t[k], x[k], th[k], acc[k], num[k], None, O.spdmp_zigzag(G, mu, G, x0[k], th0[k], c, T, seed=77 + k, target_mu=tmu))
 
 
+def test_tracked_with_speeds_that_are_not_one(gpu_pkg, trackp_form):
+    """θ0 = ±σ_i with σ_i in [0.5, 1.5] (scripts/logistic.jl:158 starts its chains that way): the reflections keep |θ_i|, the tracked sums move by
+    −2 θ_i Γ[:,i] -- nothing in the one-proposal-per-lane kernel may assume unit speeds."""
+    pkg = gpu_pkg
+    n = 50
+    G = pkg.problems.gmrf_precision(n)
+    d = n * n
+    rng = np.random.default_rng(12)
+    sig = 0.5 + rng.random(d)
+    nch, T = 2, 3.0
+    x0 = rng.standard_normal((nch, d))
+    th0 = sig * rng.choice([-1.0, 1.0], (nch, d))
+    c = 3.0 * pkg.problems.column_norms(G)
+    tr, (t, x, th), (acc, num), _ = pkg.spdmp(pkg.GaussianTarget(G), 0.0, x0, th0, T, c, pkg.ZigZag(G, np.zeros(d), sig), seed=313, tracked=True)
+    for k in range(nch):
+        r = O.spdmp_zigzag(G, None, G, x0[k], th0[k], c, T, seed=313 + k, sigma=sig, tracked=True)
+        assert r["status"] == 0 and len(r["events"]) > 1000
+        check_chain_bitwise(tr[k].events, t[k], x[k], th[k], acc[k], num[k], None, r)
+
+
 def test_tracked_slices_trace_refills_and_violation(gpu_pkg, trackp_form):
     """Slices with PDMP_RUN_STOP_BEFORE, a trace buffer that fills up several times, the reference tail (last event at t′ >= T), path
     integrals (batch means) against the host integral of the trace, and a bound violation without adapt (status, not a crash)."""
