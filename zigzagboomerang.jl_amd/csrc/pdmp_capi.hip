@@ -84,11 +84,6 @@ struct DevBuf {
 #ifndef HELPER_WAVE_MAX_CHAINS_PER_CU
 #define HELPER_WAVE_MAX_CHAINS_PER_CU 7
 #endif
-// zz_local_trackl (pdmp_trackl.hip, the line layout): ensembles of MORE than this many chains per compute unit -- where the one-wave form with the
-// step rule runs today and the memory system is what an iteration waits for; narrower ensembles keep pdmp_trackp.hip's forms (target steering, two waves)
-#ifndef LINES_MIN_CHAINS_PER_CU
-#define LINES_MIN_CHAINS_PER_CU 12
-#endif
 struct pdmp_ensemble {
     pdmp_config cfg{};
     hipStream_t stream = nullptr;
@@ -1391,11 +1386,8 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
             G.track_two_sums = e->track_two_sums ? 1 : 0;
             G.has_refresh = e->lambda_ref > 0;
             G.d = d;
-            const int64_t ncu = e->n_cu > 0 ? e->n_cu : 256;
-            const bool wide = n > (int64_t)LINES_MIN_CHAINS_PER_CU * ncu;
             // (measured, round 6: 2.7 instead of 3.2 lines read per proposal, but 72 instead of 54 vector instructions -- 47.9 ms against 45.4 / 38.8 ms
             // for pdmp_trackp.hip's form on boxes in the slow / fast timing mode: the layout is kept as an opt-in form, never chosen by width)
-            (void)wide;
             if (pdmp::zz_trackl_supported(G) && !e->track_generic && e->track_mean == 0 && e->dbg_track_lines == 1) {
                 if (e->d_tl_lines.n != (size_t)(n * e->dk / 2) && (st = e->d_tl_lines.alloc((size_t)(n * e->dk / 2))) != PDMP_OK) return st;
                 if (e->d_tl_cold.n != (size_t)(n * e->dk) && (st = e->d_tl_cold.alloc((size_t)(n * e->dk))) != PDMP_OK) return st;
