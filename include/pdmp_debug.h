@@ -46,6 +46,15 @@ pdmp_status pdmp_debug_set_helper_wave(pdmp_ensemble* ens, int mode);
  * layout serves.  The choice fixes the state's layout: call it BEFORE set_state.  With this kernel pdmp_debug_set_helper_steering's first two
  * arguments are the block minima per quantum of the wheel and the events a window aims at (0: the defaults). */
 pdmp_status pdmp_debug_set_track_lines(pdmp_ensemble* ens, int mode);
+/* Device addresses of the ensemble's large arrays (tracked records, (key, t_old) pairs, trace slots, chain headers, canonical records, keys,
+ * per-coordinate constants, tables): tools/mode_alloc.py relates the full-width slice's timing mode to where they landed. */
+pdmp_status pdmp_debug_buffer_addresses(pdmp_ensemble* ens, uint64_t* out8);
+/* How the arrays of several GB were laid over the device's three memory classes (csrc/pdmp_place.hip), as text: per array the class of every 1 GB
+ * chunk in address order, the chunks created while looking for the classes and the seconds that took -- or "hipMalloc" where the array was not placed. */
+pdmp_status pdmp_debug_placement(pdmp_ensemble* ens, char* buf, size_t nbuf);
+/* Copies one array (0 records, 1 pairs, 2 trace, 3 headers, 4 constants, 5 keys) into newly allocated memory and continues on the copy; the old
+ * allocation stays reserved until the process ends (so that the copy lands on other pages).  For tools/mode_alloc.py only. */
+pdmp_status pdmp_debug_move_buffer(pdmp_ensemble* ens, int which);
 /* ... its tuning (none of it changes a result): the selection threshold moves by `gain` of the way towards `target` raw candidates per iteration;
  * the helper requests the lines of the blocks within `ahead` window lengths beyond the current window */
 pdmp_status pdmp_debug_set_helper_steering(pdmp_ensemble* ens, double gain, int target, double ahead);

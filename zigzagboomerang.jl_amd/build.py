@@ -15,7 +15,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpdmp_mi355.so")
 SOURCES = ["pdmp_capi.hip", "pdmp_kernels.hip", "pdmp_bps.hip", "pdmp_general.hip", "pdmp_partition.hip", "pdmp_trackp.hip", "pdmp_trackl.hip",
-           "pdmp_consume.hip", "pdmp_logistic.hip", "pdmp_comm.hip", "pdmp_1d.hip"]
+           "pdmp_consume.hip", "pdmp_logistic.hip", "pdmp_comm.hip", "pdmp_1d.hip", "pdmp_place.hip"]
 # Measured-slower cross-implementations of two event loops (zz_local_exactp_kernel: the moving evaluation with one proposal per lane;
 # zz_logistic_rows_kernel: several chains of config C4 per wavefront).  They are NOT in the default library: `build.py --variant parity`
 # (-DPDMP_EXTRA_KERNELS) makes lib/libpdmp_mi355.parity.so with them, which the parity suite loads beside the default one

@@ -50,9 +50,15 @@ template <class T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
-    pdmp_status alloc(size_t count) {
+    pdmp::Placement placed;  // arrays of several GB: chunks of the three memory classes in turn (pdmp_place.hip); otherwise empty, and p is a hipMalloc
+    pdmp_status alloc(size_t count, const char* tag = nullptr) {
         release();
         if (count == 0) return PDMP_OK;
+        if (pdmp::placed_alloc(count * sizeof(T), placed, tag)) {
+            p = static_cast<T*>(placed.va);
+            n = count;
+            return PDMP_OK;
+        }
         hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
         if (e != hipSuccess) {
             p = nullptr;
@@ -68,7 +74,8 @@ struct DevBuf {
         return PDMP_OK;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (placed.va) pdmp::placed_free(placed);
+        else if (p) (void)hipFree(p);
         p = nullptr;
         n = 0;
     }
@@ -460,6 +467,64 @@ pdmp_status pdmp_debug_set_track_groups(pdmp_ensemble* e, int on) {
 pdmp_status pdmp_debug_set_track_lines(pdmp_ensemble* e, int mode) {
     if (!e || mode < -1 || mode > 1) return fail(PDMP_ERR_INVALID, "track lines: -1 (by ensemble width), 0 (never), 1 (wherever the layout serves)");
     e->dbg_track_lines = mode;
+    return PDMP_OK;
+}
+pdmp_status pdmp_debug_buffer_addresses(pdmp_ensemble* e, uint64_t* out8) {
+    // where the state lives: tracked records, (key, t_old) pairs, trace slots, chain headers, canonical records, keys, the consts, the blob
+    if (!e || !out8) return fail(PDMP_ERR_INVALID, "null argument");
+    out8[0] = (uint64_t)(uintptr_t)e->d_trk.p;
+    out8[1] = (uint64_t)(uintptr_t)e->d_kp.p;
+    out8[2] = (uint64_t)(uintptr_t)e->d_ev.p;
+    out8[3] = (uint64_t)(uintptr_t)e->d_hdr.p;
+    out8[4] = (uint64_t)(uintptr_t)e->d_rec.p;
+    out8[5] = (uint64_t)(uintptr_t)e->d_keys.p;
+    out8[6] = (uint64_t)(uintptr_t)e->d_cc.p;
+    out8[7] = (uint64_t)(uintptr_t)e->d_blob.p;
+    return PDMP_OK;
+}
+pdmp_status pdmp_debug_placement(pdmp_ensemble* e, char* buf, size_t nbuf) {
+    // how the large arrays were laid over the device's memory classes (pdmp_place.hip): "records 012012012 (31 chunks walked, 0.92 s); ..."
+    if (!e || !buf || nbuf == 0) return fail(PDMP_ERR_INVALID, "null argument");
+    std::string r;
+    auto add = [&](const char* name, const pdmp::Placement& p, size_t bytes) {
+        if (bytes < ((size_t)256 << 20)) return;
+        char t[160];
+        if (p.va) snprintf(t, sizeof t, "%s%s %s (%zu chunks walked, %.2f s)", r.empty() ? "" : "; ", name, p.classes.c_str(), p.walked, p.seconds);
+        else snprintf(t, sizeof t, "%s%s hipMalloc (%.1f GB)", r.empty() ? "" : "; ", name, bytes / 1073741824.0);
+        r += t;
+    };
+    add("records", e->d_rec.placed, e->d_rec.n * sizeof(pdmp::ZzRec));
+    add("pairs", e->d_kp.placed, e->d_kp.n * sizeof(double));
+    add("keys", e->d_keys.placed, e->d_keys.n * sizeof(double));
+    add("trace", e->d_ev.placed, e->d_ev.n * sizeof(pdmp_event));
+    add("lines", e->d_tl_lines.placed, e->d_tl_lines.n * sizeof(pdmp::TrLine));
+    snprintf(buf, nbuf, "%s", r.c_str());
+    return PDMP_OK;
+}
+pdmp_status pdmp_debug_move_buffer(pdmp_ensemble* e, int which) {
+    if (!e || !e->has_state) return fail(PDMP_ERR_INVALID, "move buffer: an ensemble with a state");
+    HIP_TRY(device_sync(e));
+    // a copy of the array in newly allocated memory; the old allocation is KEPT (so the copy cannot land on the same pages) until the process ends
+    auto move_buf = [](auto& b) -> hipError_t {
+        if (!b.p || b.n == 0) return hipSuccess;
+        void* np = nullptr;
+        const size_t bytes = b.n * sizeof(*b.p);
+        hipError_t r = hipMalloc(&np, bytes);
+        if (r != hipSuccess) return r;
+        r = hipMemcpy(np, b.p, bytes, hipMemcpyDeviceToDevice);
+        if (r != hipSuccess) return r;
+        b.p = static_cast<decltype(b.p)>(np);
+        return hipSuccess;
+    };
+    switch (which) {
+        case 0: HIP_TRY(move_buf(e->d_rec)); break;
+        case 1: HIP_TRY(move_buf(e->d_kp)); break;
+        case 2: HIP_TRY(move_buf(e->d_ev)); break;
+        case 3: HIP_TRY(move_buf(e->d_hdr)); break;
+        case 4: HIP_TRY(move_buf(e->d_cc)); break;
+        case 5: HIP_TRY(move_buf(e->d_keys)); break;
+        default: return fail(PDMP_ERR_INVALID, "move buffer: 0 records, 1 pairs, 2 trace, 3 headers, 4 constants, 5 keys");
+    }
     return PDMP_OK;
 }
 pdmp_status pdmp_debug_set_helper_wave(pdmp_ensemble* e, int mode) {
@@ -1125,13 +1190,13 @@ static pdmp_status alloc_state(pdmp_ensemble* e) {
     const int64_t d = e->cfg.d, n = e->cfg.nchains;
     pdmp_status st;
     const size_t nrec = (size_t)(n * d) * (e->track ? 2 : 1);  // TrRec is two ZzRec long
-    if (e->d_rec.n != nrec && (st = e->d_rec.alloc(nrec)) != PDMP_OK) return st;
-    if (e->d_keys.n != (size_t)(n * e->dk) && (st = e->d_keys.alloc((size_t)(n * e->dk))) != PDMP_OK) return st;
+    if (e->d_rec.n != nrec && (st = e->d_rec.alloc(nrec, "rec")) != PDMP_OK) return st;
+    if (e->d_keys.n != (size_t)(n * e->dk) && (st = e->d_keys.alloc((size_t)(n * e->dk), "keys")) != PDMP_OK) return st;
     if (e->d_hdr.n != (size_t)n && (st = e->d_hdr.alloc((size_t)n)) != PDMP_OK) return st;
     if (e->cfg.adapt && e->d_c_chain.n != (size_t)(n * d) && (st = e->d_c_chain.alloc((size_t)(n * d))) != PDMP_OK)
         return st;
     if (e->cfg.trace_capacity > 0 && e->d_ev.n != (size_t)(n * e->cfg.trace_capacity) &&
-        (st = e->d_ev.alloc((size_t)(n * e->cfg.trace_capacity))) != PDMP_OK)
+        (st = e->d_ev.alloc((size_t)(n * e->cfg.trace_capacity), "ev")) != PDMP_OK)
         return st;
     e->d_jprev.release();
     return PDMP_OK;
@@ -1372,7 +1437,7 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
     discard_async_consumer(e);  // (a consumer deferred behind "the next run" belongs to the state that is being replaced)
     if (e->track) {
         if (trackp_ok) {
-            if (e->d_kp.n != (size_t)(2 * n * e->dk) && (st = e->d_kp.alloc((size_t)(2 * n * e->dk))) != PDMP_OK) return st;
+            if (e->d_kp.n != (size_t)(2 * n * e->dk) && (st = e->d_kp.alloc((size_t)(2 * n * e->dk), "kp")) != PDMP_OK) return st;
             rc = pdmp::launch_zz_keys_to_pairs(e->d_keys.p, e->d_kp.p, n * e->dk, t0, e->stream);
             if (rc != 0) return fail(PDMP_ERR_HIP, "keys_to_pairs launch failed: %s", hipGetErrorString((hipError_t)rc));
             rc = pdmp::launch_zz_trackp_consts(e->d_rec.p, e->d_cc.p, e->track_generic ? e->d_nb16.p : nullptr, e->track_mean ? e->d_gmu_b.p : nullptr, d, n, e->stream);

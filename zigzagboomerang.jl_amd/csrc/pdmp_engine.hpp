@@ -21,6 +21,8 @@
 //   plus a 64-slot (x,θ) scratch for the neighbourhood being re-bounded.
 #pragma once
 #include <cstdint>
+#include <string>
+#include <vector>
 
 #include "../../include/pdmp_mi355.h"
 
@@ -403,6 +405,16 @@ int launch_consume_init(const ZzRec* rec, int64_t rec_stride, int64_t d, int64_t
 int launch_consume_snapshot(DevChain* hdr, int64_t nchains, uint64_t* snap, void* stream);
 int launch_consume_events(const pdmp_event* ev, int64_t cap, const DevChain* hdr, const uint64_t* snap, int64_t d, int64_t nchains, void* cur,
                           bool with_z, void* meta, double* grid, int64_t K, double t0, double dt, void* stream, double* cummean_pairs = nullptr);
+// pdmp_place.hip: an array of several GB built from chunks of the device's three memory classes in turn (one contiguous address range)
+struct Placement {
+    void* va = nullptr;
+    size_t va_bytes = 0, chunk = 0, walked = 0;  // walked: chunks created while looking for the classes
+    double seconds = 0.0;
+    std::vector<void*> handles;
+    std::string classes;  // one digit per chunk in address order, e.g. "012012012"
+};
+bool placed_alloc(size_t bytes, Placement& out, const char* tag = nullptr);  // false: nothing is held, the caller allocates some other way
+void placed_free(Placement& p);
 int launch_trace_subtrace(const pdmp_event* ev, int64_t n, const int32_t* loc, pdmp_event* out, int64_t out_cap, unsigned long long* n_out, void* stream);
 int launch_consume_flush(int64_t d, int64_t nchains, const void* cur, const void* meta, double* grid, int64_t K, double t0, double dt, void* stream);
 int launch_consume_mean(int64_t d, int64_t chain_first, int64_t n, const void* cur, const void* meta, double* mean_out, double* T_out, void* stream);

@@ -73,6 +73,24 @@ class Ensemble:
         """zz_local_trackl (the line layout): -1 by ensemble width (default), 0 never, 1 wherever it serves; before set_state (include/pdmp_debug.h)."""
         _lib.check(self._L.pdmp_debug_set_track_lines(self._h, int(mode)))
 
+    def debug_buffer_addresses(self):
+        """Device addresses of the large arrays (pdmp_debug.h): records, pairs, trace, headers, canonical records, keys, consts, tables."""
+        import ctypes as C
+        out = (C.c_uint64 * 8)()
+        _lib.check(self._L.pdmp_debug_buffer_addresses(self._h, out))
+        return dict(zip(("trk", "kp", "ev", "hdr", "rec", "keys", "cc", "blob"), [int(v) for v in out]))
+
+    def debug_placement(self):
+        """How the arrays of several GB lie over the device's memory classes (pdmp_debug.h: pdmp_debug_placement), as text."""
+        import ctypes
+        buf = ctypes.create_string_buffer(1024)
+        _lib.check(self._L.pdmp_debug_placement(self._h, buf, 1024))
+        return buf.value.decode()
+
+    def debug_move_buffer(self, which):
+        """Continue on a copy of one array in newly allocated memory (pdmp_debug.h): 0 records, 1 pairs, 2 trace, 3 headers, 4 constants, 5 keys."""
+        _lib.check(self._L.pdmp_debug_move_buffer(self._h, int(which)))
+
     def kernel_name(self):
         """Event-loop kernel of the last run (include/pdmp_debug.h: pdmp_debug_last_kernel); '' before the first run."""
         import ctypes
