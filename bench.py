@@ -701,6 +701,7 @@ def main():
         return {"num": int(cn["num"].sum()), "nacc": int(cn["nacc"].sum()), "nevents": int(cn["nevents"].sum()),
                 "grads": int(cn["ndraw_global"].sum()) // W.get("ksub", 1)}
 
+    placement_log = ens.debug_placement() if hasattr(ens, "debug_placement") else None  # (what set_state's placement probes saw and kept)
     for k in range(args.warmup):
         step(k)
     barrier()
@@ -776,7 +777,7 @@ def main():
     default_line = (rank == 0 and world == 1 and args.config == "C3" and not args.exact and not args.gather and not args.no_trace and not args.no_configs
                     and args.grid == GRID and nch == CONFIG_DEFAULTS["C3"]["chains"] and strong_proxy is not None)
     if default_line:
-        mode = pkg.benchlib.measure_mode(pkg, float(np.sum(kernel_ms)) / max(launches[0], 1), strong_proxy)
+        mode = pkg.benchlib.measure_mode(pkg, float(np.sum(kernel_ms)) / max(launches[0], 1), strong_proxy, placement_log)
 
     # post-run exchange (never inside `value`): SURVEY 8e1
     gather = None

@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--steps", type=int, default=6)
 ap.add_argument("--chains", type=int, default=4096)
+ap.add_argument("--exact", action="store_true", help="the moving (bit-identical) evaluation instead of the tracked one")
 ap.add_argument("--caps", default="33792", help="trace capacities (events per chain) to try in turn, in the keep-all phase")
 args = ap.parse_args()
 pkg = load_package()
@@ -29,14 +30,19 @@ def one(keep, cap=2 * d + 1024):
     ens = pkg.Ensemble(args.chains, d, trace_capacity=cap)
     ens.set_flow(pkg.ZigZag(G, np.zeros(d)))
     ens.set_target(pkg.GaussianTarget(G))
-    ens.set_gradient_tracking(True)
+    if not args.exact:
+        ens.set_gradient_tracking(True)
     ens.set_state_synthetic(0.0, c, 0x5EED0000)
     ms = []
+    global last_addr, last_ev
+    last_ev = []
     for k in range(2 + args.steps):
+        n0 = int(ens.counters()["nacc"].sum())
         ens.run(float(k + 1), pkg._lib.RUN_STOP_BEFORE, sync=False)
         ms.append(ens.last_run_ms())
+        cn = ens.counters()
+        last_ev.append((round((int(cn["nacc"].sum()) - n0) / 1e6, 2), int(np.count_nonzero(cn["status"] != pkg._lib.CHAIN_OK)), round(float(cn["t_last"].min()), 3)))
         ens.trace_reset()
-    global last_addr
     last_addr = {k: hex(v) for k, v in ens.debug_buffer_addresses().items()}
     last_addr["placement"] = ens.debug_placement()
     if keep is None:
@@ -49,7 +55,7 @@ def one(keep, cap=2 * d + 1024):
 for phase, keep, cap in [("close_each", None, 2 * d + 1024)] + [("keep_all", [], int(v)) for v in args.caps.split(",")]:
     for r in range(args.rounds):
         m, all_ms = one(keep, cap)
-        print(json.dumps({"phase": phase, "cap": cap, "round": r, "ms": round(m, 2), "ev": last_addr["ev"], "kp": last_addr["kp"], "placement": last_addr["placement"]}), flush=True)
+        print(json.dumps({"phase": phase, "cap": cap, "round": r, "ms": round(m, 2), "ev": last_addr["ev"], "kp": last_addr["kp"], "placement": last_addr["placement"], "slices": all_ms, "Mevents": last_ev[2:]}), flush=True)
     if keep:
         # the kept ensembles again, in order: is the mode a property of the allocation?
         for j, ens in enumerate(keep if args.steps > 100 else []):

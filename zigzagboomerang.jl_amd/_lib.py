@@ -53,7 +53,7 @@ EXPORTED_SYMBOLS = [
 ]
 # include/pdmp_debug.h: diagnostics, not part of the drop-in boundary
 DEBUG_SYMBOLS = ["pdmp_debug_set_kernel", "pdmp_debug_set_spec_g2", "pdmp_debug_set_phase_profile", "pdmp_debug_phase_profile",
-                 "pdmp_debug_set_proposal_dump", "pdmp_debug_set_track_groups", "pdmp_debug_set_helper_wave", "pdmp_debug_set_track_lines", "pdmp_debug_buffer_addresses", "pdmp_debug_placement", "pdmp_debug_move_buffer", "pdmp_debug_set_helper_steering", "pdmp_debug_set_launch_count_limit", "pdmp_debug_host_drain_probe", "pdmp_debug_set_consumer_overlap", "pdmp_debug_last_kernel", "pdmp_debug_set_logistic_rows", "pdmp_debug_math_probe", "pdmp_debug_write_probe", "pdmp_debug_sector_probe"]
+                 "pdmp_debug_set_proposal_dump", "pdmp_debug_set_track_groups", "pdmp_debug_set_helper_wave", "pdmp_debug_set_track_lines", "pdmp_debug_buffer_addresses", "pdmp_debug_placement", "pdmp_debug_set_placement", "pdmp_debug_move_buffer", "pdmp_debug_set_helper_steering", "pdmp_debug_set_launch_count_limit", "pdmp_debug_host_drain_probe", "pdmp_debug_set_consumer_overlap", "pdmp_debug_last_kernel", "pdmp_debug_set_logistic_rows", "pdmp_debug_math_probe", "pdmp_debug_write_probe", "pdmp_debug_sector_probe"]
 DEBUG_KERNELS = {"auto": 0, "seq": 1, "spec4": 2, "spec8": 3, "exactp": 4}
 
 
@@ -181,6 +181,7 @@ def load():
     L.pdmp_debug_buffer_addresses.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.pdmp_debug_move_buffer.argtypes = [vp, C.c_int]
     L.pdmp_debug_placement.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.pdmp_debug_set_placement.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p]
     L.pdmp_debug_set_launch_count_limit.argtypes = [vp, C.c_uint32]
     L.pdmp_debug_set_helper_steering.argtypes = [vp, C.c_double, C.c_int, C.c_double]
     L.pdmp_debug_last_kernel.argtypes = [vp, C.c_char_p, i64]

@@ -58,10 +58,11 @@ def measure_configs(bench_path, budget_s=115.0, per_run_s=60.0):
     return out
 
 
-def measure_mode(pkg, full_width_kernel_ms, strong_proxy):
-    """Which timing mode did this process run in (the same binary runs the full-width C3 slice in ~38.5 or in ~45.5 ms, by box and by
-    the minute, while 2048 chains and the memory probes do not move)?  The full-width kernel time, this GPU's 2048-chain slice from the strong
-    proxy and the random-line probes (128-byte lines read, and read + written back, by 4096 x 64 lanes), all from this process."""
+def measure_mode(pkg, full_width_kernel_ms, strong_proxy, placement=None):
+    """Which timing mode did this process run in (the same binary runs the full-width C3 slice in ~38.5 or in ~45.5 ms -- by the
+    ALLOCATION that backs the records and the pairs, round 6 -- while 2048 chains and the memory probes do not move)?  The full-width kernel time,
+    this GPU's 2048-chain slice from the strong proxy, the random-line probes (128-byte lines read, and read + written back, by 4096 x 64 lanes),
+    and what set_state's placement probes saw and kept (`placement`: pdmp_debug_placement), all from this process."""
     r = {}
     for write, name in ((0, "read"), (1, "read_write")):
         ms = min(pkg._lib.sector_probe(4096, 16384, 400, write) for _ in range(2))
@@ -73,9 +74,11 @@ def measure_mode(pkg, full_width_kernel_ms, strong_proxy):
             if e.get("chains_per_gpu") == 2048 and e.get("tracked"):
                 w2048 = e["tracked"]["ms_per_step"]
     label = "fast" if full_width_kernel_ms < 41.0 else ("slow" if full_width_kernel_ms > 43.5 else "between")
-    return {"full_width_kernel_ms": full_width_kernel_ms, "label": label, "chains_2048_ms": w2048, "random_lines": r,
-            "rule": "zz_local_trackp_kernel at 4096 chains x d = 16384: < 41 ms fast, > 43.5 ms slow (observed: 38.2-39.0 and 44.7-46.5); the 2048-chain slice "
-                    "(21.3-22.8 ms) and the line probes (7.7 / 5.5 TB/s) are the same in both modes -- if THEY move, it is not the mode"}
+    return {"full_width_kernel_ms": full_width_kernel_ms, "label": label, "chains_2048_ms": w2048, "random_lines": r, "placement": placement,
+            "rule": "zz_local_trackp_kernel at 4096 chains x d = 16384: < 41 ms fast, > 43.5 ms slow (observed: 38.2-39.0 and 44.7-46.5); the mode belongs to the "
+                    "allocations behind the records and the pairs: set_state times a short launch, re-allocates and keeps the fastest (placement: the probes in "
+                    "ms and what was kept; PDMP_PLACE_TUNE=0 turns it off and the mode is the driver's coin again); the 2048-chain slice (21.3-22.8 ms) and the "
+                    "line probes (7.7 / 5.5 TB/s) do not see it"}
 
 # ---- the C3 side measurements of bench.py (moved here in round 6: bench.py keeps the contract, the workloads and the timed loop)
 def algorithmic_bytes(num, nacc):

@@ -51,10 +51,10 @@ struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
     pdmp::Placement placed;  // arrays of several GB: chunks of the three memory classes in turn (pdmp_place.hip); otherwise empty, and p is a hipMalloc
-    pdmp_status alloc(size_t count, const char* tag = nullptr) {
+    pdmp_status alloc(size_t count, const pdmp::PlaceConfig* pc = nullptr, const std::string* pattern = nullptr) {
         release();
         if (count == 0) return PDMP_OK;
-        if (pdmp::placed_alloc(count * sizeof(T), placed, tag)) {
+        if (pc && pdmp::placed_alloc(count * sizeof(T), placed, pc, pattern)) {
             p = static_cast<T*>(placed.va);
             n = count;
             return PDMP_OK;
@@ -152,6 +152,9 @@ struct pdmp_ensemble {
     // the line layout (pdmp_trackl.hip): full-width launches on the plain lattice run on d_tl_lines / d_tl_cold; d_rec / d_kp are brought up to
     // date (canon_stale) only when something reads the state -- final_state, the path-integral kernels, consume_begin
     bool track_lines = false, canon_stale = false;
+    pdmp::PlaceConfig place_cfg;  // pdmp_debug_set_placement
+    int place_tune = 1;          // init_state_tuned: 1 (default) probe and re-allocate, 0 take what hipMalloc gives
+    std::string tune_log;  // init_state_tuned: the placement probes of the last set_state (pdmp_debug_placement)
     int dbg_track_lines = -1;  // pdmp_debug_set_track_lines: 1 = the line layout wherever it serves; -1 / 0 = never (it lost the A/B: DESIGN.md §5)
     DevBuf<pdmp::TrLine> d_tl_lines;
     DevBuf<pdmp::TrCold> d_tl_cold;
@@ -482,6 +485,18 @@ pdmp_status pdmp_debug_buffer_addresses(pdmp_ensemble* e, uint64_t* out8) {
     out8[7] = (uint64_t)(uintptr_t)e->d_blob.p;
     return PDMP_OK;
 }
+pdmp_status pdmp_debug_set_placement(pdmp_ensemble* e, int tune, int place, const char* rec, const char* kp, const char* ev) {
+    if (!e || tune < -1 || tune > 1 || place < 0 || place > 1) return fail(PDMP_ERR_INVALID, "placement: tune -1 (keep) / 0 / 1, place 0 / 1");
+    for (const char* ptn : {rec, kp, ev})
+        for (const char* q = ptn; q && *q; ++q)
+            if (*q < '0' || *q > '2') return fail(PDMP_ERR_INVALID, "placement: a class pattern is a string of the digits 0, 1, 2");
+    if (tune >= 0) e->place_tune = tune;
+    e->place_cfg.enabled = place;
+    e->place_cfg.rec = rec ? rec : "";
+    e->place_cfg.kp = kp ? kp : "";
+    e->place_cfg.ev = ev ? ev : "";
+    return PDMP_OK;
+}
 pdmp_status pdmp_debug_placement(pdmp_ensemble* e, char* buf, size_t nbuf) {
     // how the large arrays were laid over the device's memory classes (pdmp_place.hip): "records 012012012 (31 chunks walked, 0.92 s); ..."
     if (!e || !buf || nbuf == 0) return fail(PDMP_ERR_INVALID, "null argument");
@@ -498,6 +513,7 @@ pdmp_status pdmp_debug_placement(pdmp_ensemble* e, char* buf, size_t nbuf) {
     add("keys", e->d_keys.placed, e->d_keys.n * sizeof(double));
     add("trace", e->d_ev.placed, e->d_ev.n * sizeof(pdmp_event));
     add("lines", e->d_tl_lines.placed, e->d_tl_lines.n * sizeof(pdmp::TrLine));
+    if (!e->tune_log.empty()) r += (r.empty() ? "" : "; ") + e->tune_log;
     snprintf(buf, nbuf, "%s", r.c_str());
     return PDMP_OK;
 }
@@ -1190,13 +1206,13 @@ static pdmp_status alloc_state(pdmp_ensemble* e) {
     const int64_t d = e->cfg.d, n = e->cfg.nchains;
     pdmp_status st;
     const size_t nrec = (size_t)(n * d) * (e->track ? 2 : 1);  // TrRec is two ZzRec long
-    if (e->d_rec.n != nrec && (st = e->d_rec.alloc(nrec, "rec")) != PDMP_OK) return st;
-    if (e->d_keys.n != (size_t)(n * e->dk) && (st = e->d_keys.alloc((size_t)(n * e->dk), "keys")) != PDMP_OK) return st;
+    if (e->d_rec.n != nrec && (st = e->d_rec.alloc(nrec, &e->place_cfg, &e->place_cfg.rec)) != PDMP_OK) return st;
+    if (e->d_keys.n != (size_t)(n * e->dk) && (st = e->d_keys.alloc((size_t)(n * e->dk))) != PDMP_OK) return st;
     if (e->d_hdr.n != (size_t)n && (st = e->d_hdr.alloc((size_t)n)) != PDMP_OK) return st;
     if (e->cfg.adapt && e->d_c_chain.n != (size_t)(n * d) && (st = e->d_c_chain.alloc((size_t)(n * d))) != PDMP_OK)
         return st;
     if (e->cfg.trace_capacity > 0 && e->d_ev.n != (size_t)(n * e->cfg.trace_capacity) &&
-        (st = e->d_ev.alloc((size_t)(n * e->cfg.trace_capacity), "ev")) != PDMP_OK)
+        (st = e->d_ev.alloc((size_t)(n * e->cfg.trace_capacity), &e->place_cfg, &e->place_cfg.ev)) != PDMP_OK)
         return st;
     e->d_jprev.release();
     return PDMP_OK;
@@ -1437,7 +1453,7 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
     discard_async_consumer(e);  // (a consumer deferred behind "the next run" belongs to the state that is being replaced)
     if (e->track) {
         if (trackp_ok) {
-            if (e->d_kp.n != (size_t)(2 * n * e->dk) && (st = e->d_kp.alloc((size_t)(2 * n * e->dk), "kp")) != PDMP_OK) return st;
+            if (e->d_kp.n != (size_t)(2 * n * e->dk) && (st = e->d_kp.alloc((size_t)(2 * n * e->dk), &e->place_cfg, &e->place_cfg.kp)) != PDMP_OK) return st;
             rc = pdmp::launch_zz_keys_to_pairs(e->d_keys.p, e->d_kp.p, n * e->dk, t0, e->stream);
             if (rc != 0) return fail(PDMP_ERR_HIP, "keys_to_pairs launch failed: %s", hipGetErrorString((hipError_t)rc));
             rc = pdmp::launch_zz_trackp_consts(e->d_rec.p, e->d_cc.p, e->track_generic ? e->d_nb16.p : nullptr, e->track_mean ? e->d_gmu_b.p : nullptr, d, n, e->stream);
@@ -1470,22 +1486,119 @@ static pdmp_status init_state(pdmp_ensemble* e, double t0, const double* x0, con
     return PDMP_OK;
 }
 
+static pdmp_status ensemble_run_impl(pdmp_ensemble* e, double T, int flags, void* stream);
+
+// WHERE the records and the pairs of a full-width tracked ensemble lie decides whether its slices take 38 or 45 ms (DESIGN.md 5 "The timing modes are a
+// property of the allocation": the same binary, the same process, by the hipMalloc that backs either array).  No API shows the property, a few
+// milliseconds of the event loop do: after the state is set, a short launch (every chain pauses after PLACE_PROBE_DRAWS draws) is timed, the pairs --
+// then the records -- are given new allocations (the old ones stay reserved, so the new ones are other memory), the state is set again and the launch
+// repeated; the fastest combination is kept, the rest freed, and the state set one last time.  Every probe does identical work, so the times compare
+// directly; the ensemble the caller gets is bit for bit the one set_state alone would have made.  pdmp_debug_set_placement(ens, 0, ...) turns it off.
+#define PLACE_PROBE_DRAWS 12000u
+#define PLACE_TUNE_MIN_CHAINS 3072  // (only launches that fill the device show the two modes)
+static pdmp_status init_state_tuned(pdmp_ensemble* e, double t0, const double* x0, const double* th0, const double* c, const uint64_t* seeds,
+                                    uint64_t seed0) {
+    e->tune_log.clear();
+    pdmp_status st = init_state(e, t0, x0, th0, c, seeds, seed0);
+    if (st != PDMP_OK) return st;
+    // the two arrays the event loop scatters over: the records, and level 0 of the queue -- (key, time) pairs under tracking, plain keys otherwise.
+    // Kernels of pdmp_kernels.hip / pdmp_trackp.hip only (they pause on the draw count; the general-degree, logistic and sticky paths are not probed)
+    DevBuf<double>& keybuf = e->track_pairs ? e->d_kp : e->d_keys;
+    const size_t rec_bytes = e->d_rec.n * sizeof(*e->d_rec.p), kp_bytes = keybuf.n * sizeof(double);
+    const bool probed_kernel = e->cfg.sampler == PDMP_SAMPLER_ZIGZAG_LOCAL && (e->track_pairs || !e->track) && !e->track_lines && !e->needs_general &&
+                               e->target_kind == 0 && !e->adaptscale && !e->local_bound && e->dbg_dump == 0;
+    if (e->place_tune == 0 || !probed_kernel || e->cfg.nchains < PLACE_TUNE_MIN_CHAINS || rec_bytes < ((size_t)2 << 30) || e->d_rec.placed.va ||
+        keybuf.placed.va || e->dbg_count_limit != 0)
+        return PDMP_OK;
+    size_t freeb = 0, totb = 0;
+    if (hipMemGetInfo(&freeb, &totb) != hipSuccess || freeb < 3 * (rec_bytes + kp_bytes) + ((size_t)8 << 30)) {
+        (void)hipGetLastError();
+        return PDMP_OK;
+    }
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto probe = [&](float& ms) -> pdmp_status {
+        e->dbg_count_limit = PLACE_PROBE_DRAWS;
+        pdmp_status r = ensemble_run_impl(e, t0 + 1.0e3, PDMP_RUN_STOP_BEFORE, nullptr);
+        e->dbg_count_limit = 0;
+        if (r != PDMP_OK) return r;
+        HIP_TRY(hipEventSynchronize(e->ev1));
+        HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+        return PDMP_OK;
+    };
+    // candidates: (records, pairs) pointers; index 0 is what set_state allocated
+    std::vector<void*> recs{(void*)e->d_rec.p}, kps{(void*)keybuf.p};
+    struct Trial { size_t r, k; float ms; };
+    std::vector<Trial> trials;
+    auto measure = [&](size_t r, size_t k) -> pdmp_status {
+        const bool moved = (void*)e->d_rec.p != recs[r] || (void*)keybuf.p != kps[k];
+        e->d_rec.p = static_cast<decltype(e->d_rec.p)>(recs[r]);
+        keybuf.p = static_cast<double*>(kps[k]);
+        pdmp_status r2 = PDMP_OK;
+        if (moved || !trials.empty()) r2 = init_state(e, t0, x0, th0, c, seeds, seed0);
+        if (r2 != PDMP_OK) return r2;
+        float ms = 0;
+        if ((r2 = probe(ms)) != PDMP_OK) return r2;
+        trials.push_back({r, k, ms});
+        return PDMP_OK;
+    };
+    auto best = [&]() { return *std::min_element(trials.begin(), trials.end(), [](const Trial& a, const Trial& b) { return a.ms < b.ms; }); };
+    auto worst = [&]() { return *std::max_element(trials.begin(), trials.end(), [](const Trial& a, const Trial& b) { return a.ms < b.ms; }); };
+    // both levels seen and the fast one in hand: done (the modes are 17 % apart; probes repeat to 1-2 %)
+    auto settled = [&]() { return trials.size() >= 2 && worst().ms > 1.08f * best().ms; };
+    st = measure(0, 0);
+    for (int step = 0; st == PDMP_OK && step < 5 && !settled(); ++step) {
+        // new pairs three times (1 GB), then new records twice (8 GB), each beside the best partner so far
+        void* np = nullptr;
+        const bool pairs_turn = step < 3;
+        if (hipMalloc(&np, pairs_turn ? kp_bytes : rec_bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+        }
+        if (pairs_turn) {
+            kps.push_back(np);
+            st = measure(best().r, kps.size() - 1);
+        } else {
+            recs.push_back(np);
+            st = measure(recs.size() - 1, best().k);
+        }
+    }
+    // keep the best pair, free the rest, and leave the state as set_state makes it
+    const Trial b = trials.empty() ? Trial{0, 0, 0.f} : best();
+    e->d_rec.p = static_cast<decltype(e->d_rec.p)>(recs[b.r]);
+    keybuf.p = static_cast<double*>(kps[b.k]);
+    HIP_TRY(hipDeviceSynchronize());
+    for (size_t k = 0; k < recs.size(); ++k)
+        if (k != b.r) (void)hipFree(recs[k]);
+    for (size_t k = 0; k < kps.size(); ++k)
+        if (k != b.k) (void)hipFree(kps[k]);
+    pdmp_status st2 = init_state(e, t0, x0, th0, c, seeds, seed0);
+    char t[96];
+    snprintf(t, sizeof t, "placement probes (ms, %u draws per chain):", PLACE_PROBE_DRAWS);
+    e->tune_log = t;
+    for (const Trial& q : trials) {
+        snprintf(t, sizeof t, " %.2f[r%zu p%zu]", q.ms, q.r, q.k);
+        e->tune_log += t;
+    }
+    snprintf(t, sizeof t, "; kept r%zu p%zu; %.2f s", b.r, b.k, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
+    e->tune_log += t;
+    return st != PDMP_OK ? st : st2;
+}
+
 pdmp_status pdmp_ensemble_set_state(pdmp_ensemble* e, double t0, const double* x0, const double* theta0,
                                     const double* c, const uint64_t* seeds) {
     if (!e || !x0 || !theta0 || !seeds) return fail(PDMP_ERR_INVALID, "null argument");
     NEED_FACTORISED(e);
-    return init_state(e, t0, x0, theta0, c, seeds, 0);
+    return init_state_tuned(e, t0, x0, theta0, c, seeds, 0);
 }
 
 pdmp_status pdmp_ensemble_set_state_synthetic(pdmp_ensemble* e, double t0, const double* c, uint64_t seed0) {
     if (!e) return fail(PDMP_ERR_INVALID, "null argument");
     NEED_FACTORISED(e);
-    return init_state(e, t0, nullptr, nullptr, c, nullptr, seed0);
+    return init_state_tuned(e, t0, nullptr, nullptr, c, nullptr, seed0);
 }
 
 static void fill_bps_ext(const pdmp_ensemble* e, pdmp::BpsRunParams& B);
 
-static pdmp_status ensemble_run_impl(pdmp_ensemble* e, double T, int flags, void* stream);
 pdmp_status pdmp_ensemble_run(pdmp_ensemble* e, double T, int flags, void* stream) {
     pdmp_status st = ensemble_run_impl(e, T, flags, stream);
     if (st == PDMP_OK && e->deferred_k >= 0) st = launch_deferred_consumer(e);  // (behind the event loop's launch: see pdmp_ensemble_consume_async)

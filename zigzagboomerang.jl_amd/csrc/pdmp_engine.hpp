@@ -413,7 +413,12 @@ struct Placement {
     std::vector<void*> handles;
     std::string classes;  // one digit per chunk in address order, e.g. "012012012"
 };
-bool placed_alloc(size_t bytes, Placement& out, const char* tag = nullptr);  // false: nothing is held, the caller allocates some other way
+struct PlaceConfig {
+    int enabled = 0;  // experimental (pdmp_place.hip's header says why): off unless pdmp_debug_set_placement turns it on
+    size_t chunk_mb = 1024, min_mb = 3072, max_walk = 192;
+    std::string rec, kp, ev;  // class patterns of the records / the pairs / the trace ("" = "012" for arrays of at least min_mb, nothing below)
+};
+bool placed_alloc(size_t bytes, Placement& out, const PlaceConfig* cfg, const std::string* forced_pattern);  // false: nothing is held
 void placed_free(Placement& p);
 int launch_trace_subtrace(const pdmp_event* ev, int64_t n, const int32_t* loc, pdmp_event* out, int64_t out_cap, unsigned long long* n_out, void* stream);
 int launch_consume_flush(int64_t d, int64_t nchains, const void* cur, const void* meta, double* grid, int64_t K, double t0, double dt, void* stream);

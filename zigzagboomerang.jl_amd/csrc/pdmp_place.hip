@@ -7,12 +7,15 @@
 // the full-width launch (38 / 45 ms per slice of C3, the same binary, by the allocation).  The classes are not visible through any API, but they are
 // measurable in milliseconds: two chunks of one class run a short two-chunk scatter ~20 % slower than two chunks of different classes.
 //
-// So an array of several GB is built from 1 GB chunks (hipMemCreate), each classified against one reference chunk per class found so far, and mapped
-// into one contiguous address range in round-robin order of the classes; chunks the round robin has no use for are held until the walk ends (the
-// allocator would hand them out again) and then released.  Kernels see an ordinary pointer.  Any failure on the way gives the memory back and reports
-// "not placed": the caller falls back to hipMalloc.
-//   PDMP_PLACE=0            plain hipMalloc everywhere                     PDMP_PLACE_MIN_MB   arrays at least this large are placed (default 3072)
-//   PDMP_PLACE_CHUNK_MB     chunk size (default 1024)                      PDMP_PLACE_MAX_WALK chunks created at most while looking for the classes (192)
+// EXPERIMENTAL, OFF BY DEFAULT.  An array of several GB is built from 1 GB chunks (hipMemCreate), each classified against one
+// reference chunk per class found so far, and mapped into one contiguous address range in a chosen order of the classes ("012" cycled, or a pattern per
+// array); chunks the pattern has no use for are held until the walk ends (the allocator would hand them out again) and then
+// released.  Kernels see an ordinary pointer.  What it showed (tools/probes/place_matrix.sh): records striped over the three classes run the
+// full-width C3 slice in 39.5-39.9 ms whatever else happens -- neither the 38.3 nor the 45.5 ms of a plain hipMalloc.  Why it is not the default: on this
+// ROCm (7.2) memory that went through hipMemCreate / hipMemMap / hipMemUnmap / hipMemRelease in quick succession was seen to LOSE WRITES (chains of a freshly
+// set state dead at t = 0) and, with many ensembles alive, to raise GPU memory access faults.  The shipped answer to the timing modes is therefore the
+// probe-and-reallocate loop of pdmp_capi.hip (init_state_tuned), which uses hipMalloc only.
+// Switched on per ensemble: pdmp_debug_set_placement (include/pdmp_debug.h; the Python wrapper forwards PDMP_PLACE, PDMP_PLACE_rec / _kp / _ev).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -43,11 +46,6 @@ __global__ __launch_bounds__(64) void place_pair_scatter_kernel(uint4* a, uint4*
         const uint32_t j = ((s >> 9) * 2654435761u >> 7) & mask;
         slab[(size_t)j * 8 + ((threadIdx.x + 3) & 7)] = v;
     }
-}
-
-size_t env_num(const char* name, size_t dflt) {
-    const char* v = getenv(name);
-    return v && *v ? (size_t)strtoull(v, nullptr, 10) : dflt;
 }
 
 struct Walked {
@@ -82,24 +80,17 @@ void placed_free(Placement& p) {
     p.va_bytes = 0;
 }
 
-bool placed_alloc(size_t bytes, Placement& out, const char* tag) {
+bool placed_alloc(size_t bytes, Placement& out, const PlaceConfig* cfg, const std::string* forced_pattern) {
     out = Placement{};
-    if (env_num("PDMP_PLACE", 1) == 0) return false;
-    const size_t chunk = env_num("PDMP_PLACE_CHUNK_MB", 1024) << 20;
-    // the classes of the array's chunks in address order, cycled: "012" by default; PDMP_PLACE_<tag> overrides per array (experiments)
-    std::string pattern = "012";
-    bool forced = false;
-    if (tag) {
-        const char* v = getenv((std::string("PDMP_PLACE_") + tag).c_str());
-        if (v && *v) {
-            pattern = v;
-            forced = true;
-        }
-    }
+    if (!cfg || !cfg->enabled) return false;  // EXPERIMENTAL, off by default: see the header
+    const size_t chunk = cfg->chunk_mb << 20;
+    // the classes of the array's chunks in address order, cycled: "012" by default; a pattern of its own per array for experiments
+    const bool forced = forced_pattern && !forced_pattern->empty();
+    const std::string pattern = forced ? *forced_pattern : std::string("012");
     for (char ch : pattern)
         if (ch < '0' || ch > '2') return false;
-    if (chunk < ((size_t)64 << 20) || (chunk & (chunk - 1)) != 0 || (!forced && bytes < (env_num("PDMP_PLACE_MIN_MB", 3072) << 20))) return false;
-    const size_t need = (bytes + chunk - 1) / chunk, max_walk = std::max<size_t>(env_num("PDMP_PLACE_MAX_WALK", 192), need);
+    if (chunk < ((size_t)64 << 20) || (chunk & (chunk - 1)) != 0 || (!forced && bytes < (cfg->min_mb << 20))) return false;
+    const size_t need = (bytes + chunk - 1) / chunk, max_walk = std::max<size_t>(cfg->max_walk, need);
     if (need < 3 && !forced) return false;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;

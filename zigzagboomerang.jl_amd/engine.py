@@ -50,6 +50,9 @@ class Ensemble:
             self.debug_set_helper_wave(int(os.environ["PDMP_HELPER_WAVE"]))
         if os.environ.get("PDMP_TRACK_LINES"):
             self.debug_set_track_lines(int(os.environ["PDMP_TRACK_LINES"]))
+        if any(os.environ.get(v) for v in ("PDMP_PLACE_TUNE", "PDMP_PLACE", "PDMP_PLACE_rec", "PDMP_PLACE_kp", "PDMP_PLACE_ev")):
+            pat = [os.environ.get("PDMP_PLACE_" + a, "").encode() or None for a in ("rec", "kp", "ev")]
+            self.debug_set_placement(int(os.environ.get("PDMP_PLACE_TUNE", "-1")), int(os.environ.get("PDMP_PLACE", "1" if any(pat) else "0")), *pat)
         if os.environ.get("PDMP_LAUNCH_COUNT_LIMIT"):
             _lib.check(self._L.pdmp_debug_set_launch_count_limit(self._h, int(os.environ["PDMP_LAUNCH_COUNT_LIMIT"])))
         if os.environ.get("PDMP_HELPER_STEER"):  # "gain,target,ahead"
@@ -79,6 +82,11 @@ class Ensemble:
         out = (C.c_uint64 * 8)()
         _lib.check(self._L.pdmp_debug_buffer_addresses(self._h, out))
         return dict(zip(("trk", "kp", "ev", "hdr", "rec", "keys", "cc", "blob"), [int(v) for v in out]))
+
+    def debug_set_placement(self, tune=-1, place=0, rec=None, kp=None, ev=None):
+        """Placement of the large arrays (pdmp_debug.h: pdmp_debug_set_placement): tune 1 / 0 = set_state's probe-and-reallocate loop on / off (-1: as it
+        is, on by default); place 1 = the experimental chunk-wise placement with optional class patterns (bytes) for records / pairs / trace."""
+        _lib.check(self._L.pdmp_debug_set_placement(self._h, int(tune), int(place), rec, kp, ev))
 
     def debug_placement(self):
         """How the arrays of several GB lie over the device's memory classes (pdmp_debug.h: pdmp_debug_placement), as text."""
