@@ -110,6 +110,10 @@ def main():
             # timed launches only: the last steps x launches_per_step dispatches of the main kernel
             d = [(float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e6 for r in kt if kern in r["Kernel_Name"]]
             nl = int(round(B["steps"] * B["roofline"]["launches_per_step"]))
+            if d and min(d) < 0.5 * max(d):
+                small = [v for v in d if v < 0.5 * max(d)]
+                f.write(f"\n# {kern}: the row above includes {len(small)} short launches ({min(small):.2f}-{max(small):.2f} ms): set_state's placement probes "
+                        "(every chain pauses after 12 000 draws; csrc/pdmp_capi.hip init_state_tuned) -- not slices")
             if d:
                 f.write(f"\n# {kern}: average over the {min(nl, len(d))} timed launches {sum(d[-nl:]) / len(d[-nl:]):.4f} ms "
                         f"(all {len(d)} launches incl. warm-up: {sum(d) / len(d):.4f} ms)\n")

@@ -1495,7 +1495,7 @@ static pdmp_status ensemble_run_impl(pdmp_ensemble* e, double T, int flags, void
 // repeated; the fastest combination is kept, the rest freed, and the state set one last time.  Every probe does identical work, so the times compare
 // directly; the ensemble the caller gets is bit for bit the one set_state alone would have made.  pdmp_debug_set_placement(ens, 0, ...) turns it off.
 #define PLACE_PROBE_DRAWS 12000u
-#define PLACE_TUNE_MIN_CHAINS 3072  // (only launches that fill the device show the two modes)
+#define PLACE_TUNE_MIN_CHAINS 1024  // (the two modes were seen on launches that fill the device: 4096 chains; narrower ones are probed as well, it costs milliseconds)
 static pdmp_status init_state_tuned(pdmp_ensemble* e, double t0, const double* x0, const double* th0, const double* c, const uint64_t* seeds,
                                     uint64_t seed0) {
     e->tune_log.clear();

@@ -197,6 +197,7 @@ __device__ __forceinline__ void trackl_body(const ZzRunParams& P) {
     int lane = lane0;
     const int64_t chain = blockIdx.x;
     const int64_t d = P.d;
+    (void)d;  // (the invariant check of -DPDMP_TL_CHECK reads it)
     const uint32_t nb2p = (uint32_t)(P.dk / 2);  // lines of a chain (dk is a multiple of 64: whole 16-byte pieces of the byte array)
     const uint32_t nlat = (uint32_t)P.lattice_n, nmagic = P.lattice_magic;
 
