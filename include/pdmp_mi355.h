@@ -170,6 +170,9 @@ pdmp_status pdmp_ensemble_set_target_logistic(pdmp_ensemble* ens, int64_t n, con
  * unlike src/fact_samplers.jl:68); seeds is [nchains].  Computes b[i] = ab(...) and the initial queue
  * Q[i] = poisson_time(b[i], rand(rng)) ON THE DEVICE, drawing the first d uniforms of each chain in
  * order i = 0..d-1 (:184-187; like the reference, t0 is not added to the initial keys).
+ * For a ZigZag ensemble that fills the device (>= 1024 chains, >= 2 GB of records) the call also chooses WHERE the records and the queue's level 0
+ * lie: it times a short launch, re-allocates the two arrays a few times and keeps the fastest placement (0.03-0.1 s; the state handed back is
+ * the one described above, bit for bit: DESIGN.md 5 "The timing modes are a property of the allocation"; pdmp_debug_set_placement turns it off).
  */
 pdmp_status pdmp_ensemble_set_state(pdmp_ensemble* ens, double t0, const double* x0, const double* theta0,
                                     const double* c, const uint64_t* seeds);
