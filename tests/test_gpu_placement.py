@@ -67,3 +67,34 @@ def test_placement_arguments_are_checked(gpu_pkg):
         with pytest.raises(pkg._lib.PdmpError):
             ens.debug_set_placement(place=1, rec=b"013")
         ens.debug_set_placement(tune=0, place=0)
+
+
+def _run_bps(pkg, tune):
+    import scipy.sparse as sp
+    nch, d, cap = 1024, 1024, 256  # 2 GB per event array: from there set_state_bps probes
+    rng = np.random.default_rng(9)
+    with pkg.Ensemble(nch, d, sampler=pkg._lib.SAMPLER_BPS, factor=2.0, trace_capacity=cap) as ens:
+        ens.set_flow_bps(pkg.BouncyParticle(sp.identity(d, format="csc"), np.zeros(d), 1.0))
+        ens.debug_set_placement(tune=tune)
+        ens.set_state_bps(0.0, rng.standard_normal((nch, d)), rng.standard_normal((nch, d)), 1e-3, np.arange(nch, dtype=np.uint64) + 5)
+        log = ens.debug_placement()
+        cnt0 = ens.counters()
+        assert int(cnt0["nevents"].sum()) <= nch and np.all(cnt0["status"] == pkg._lib.CHAIN_OK)
+        ens.run(3.0, pkg._lib.RUN_STOP_BEFORE)
+        cnt = ens.counters()
+        t, x, th = ens.bps_trace(7, counters=cnt) if hasattr(ens, "bps_trace") else (None, None, None)
+        return log, cnt, (t, x, th)
+
+
+def test_bps_placement_probes_leave_the_ensemble_as_set_state_makes_it(gpu_pkg):
+    pkg = gpu_pkg
+    log1, cnt1, tr1 = _run_bps(pkg, 1)
+    log0, cnt0, tr0 = _run_bps(pkg, 0)
+    assert "placement probes" in log1 and "kept x" in log1, log1
+    assert "placement probes" not in log0
+    for f in ("num", "nacc", "nevents", "ntrace", "status", "t_last"):
+        assert np.array_equal(cnt1[f], cnt0[f]), f
+    assert int(cnt1["nevents"].sum()) > 5 * 1024
+    for a, b in zip(tr1, tr0):
+        if a is not None:
+            assert np.array_equal(a, b)

@@ -519,6 +519,7 @@ pdmp_status pdmp_debug_placement(pdmp_ensemble* e, char* buf, size_t nbuf) {
 }
 pdmp_status pdmp_debug_move_buffer(pdmp_ensemble* e, int which) {
     if (!e || !e->has_state) return fail(PDMP_ERR_INVALID, "move buffer: an ensemble with a state");
+    if ((which >= 6) != (e->cfg.sampler == PDMP_SAMPLER_BPS)) return fail(PDMP_ERR_INVALID, "move buffer: 6-10 are the Bouncy Particle's arrays, 0-5 the ZigZag's");
     HIP_TRY(device_sync(e));
     // a copy of the array in newly allocated memory; the old allocation is KEPT (so the copy cannot land on the same pages) until the process ends
     auto move_buf = [](auto& b) -> hipError_t {
@@ -539,7 +540,12 @@ pdmp_status pdmp_debug_move_buffer(pdmp_ensemble* e, int which) {
         case 3: HIP_TRY(move_buf(e->d_hdr)); break;
         case 4: HIP_TRY(move_buf(e->d_cc)); break;
         case 5: HIP_TRY(move_buf(e->d_keys)); break;
-        default: return fail(PDMP_ERR_INVALID, "move buffer: 0 records, 1 pairs, 2 trace, 3 headers, 4 constants, 5 keys");
+        case 6: HIP_TRY(move_buf(e->b_ev_x)); break;
+        case 7: HIP_TRY(move_buf(e->b_ev_th)); break;
+        case 8: HIP_TRY(move_buf(e->b_x)); break;
+        case 9: HIP_TRY(move_buf(e->b_th)); break;
+        case 10: HIP_TRY(move_buf(e->b_ev_t)); break;
+        default: return fail(PDMP_ERR_INVALID, "move buffer: 0 records, 1 pairs, 2 trace, 3 headers, 4 constants, 5 keys; BPS: 6 / 7 event x / theta, 8 / 9 x / theta, 10 event t");
     }
     return PDMP_OK;
 }
@@ -2723,8 +2729,7 @@ pdmp_status pdmp_ensemble_set_bps_options(pdmp_ensemble* e, int local_bound, int
     return PDMP_OK;
 }
 
-pdmp_status pdmp_ensemble_set_state_bps(pdmp_ensemble* e, double t0, const double* x0, const double* theta0, double c,
-                                        const uint64_t* seeds) {
+static pdmp_status init_state_bps(pdmp_ensemble* e, double t0, const double* x0, const double* theta0, double c, const uint64_t* seeds) {
     if (!e || !x0 || !theta0 || !seeds) return fail(PDMP_ERR_INVALID, "null argument");
     if (e->cfg.sampler != PDMP_SAMPLER_BPS || !e->has_flow) return fail(PDMP_ERR_INVALID, "set_flow_bps first");
     if (e->bps_flow_kind == 0 && !e->bps_gamma_is_I && !e->bps_has_mass)
@@ -2738,14 +2743,15 @@ pdmp_status pdmp_ensemble_set_state_bps(pdmp_ensemble* e, double t0, const doubl
     HIP_TRY(hipSetDevice(e->cfg.device));
     const int64_t d = e->cfg.d, n = e->cfg.nchains, cap = e->cfg.trace_capacity;
     pdmp_status st;
-    if ((st = e->b_x.alloc((size_t)(n * d))) != PDMP_OK) return st;
-    if ((st = e->b_th.alloc((size_t)(n * d))) != PDMP_OK) return st;
-    if ((st = e->b_scal.alloc((size_t)(n * 8))) != PDMP_OK) return st;
-    if ((st = e->d_hdr.alloc((size_t)n)) != PDMP_OK) return st;
+    // (arrays of the right size are kept: a second set_state -- set_state_bps's placement probes among them -- writes into the same memory)
+    if (e->b_x.n != (size_t)(n * d) && (st = e->b_x.alloc((size_t)(n * d))) != PDMP_OK) return st;
+    if (e->b_th.n != (size_t)(n * d) && (st = e->b_th.alloc((size_t)(n * d))) != PDMP_OK) return st;
+    if (e->b_scal.n != (size_t)(n * 8) && (st = e->b_scal.alloc((size_t)(n * 8))) != PDMP_OK) return st;
+    if (e->d_hdr.n != (size_t)n && (st = e->d_hdr.alloc((size_t)n)) != PDMP_OK) return st;
     if (cap > 0) {
-        if ((st = e->b_ev_t.alloc((size_t)(n * cap))) != PDMP_OK) return st;
-        if ((st = e->b_ev_x.alloc((size_t)(n * cap * d))) != PDMP_OK) return st;
-        if ((st = e->b_ev_th.alloc((size_t)(n * cap * d))) != PDMP_OK) return st;
+        if (e->b_ev_t.n != (size_t)(n * cap) && (st = e->b_ev_t.alloc((size_t)(n * cap))) != PDMP_OK) return st;
+        if (e->b_ev_x.n != (size_t)(n * cap * d) && (st = e->b_ev_x.alloc((size_t)(n * cap * d))) != PDMP_OK) return st;
+        if (e->b_ev_th.n != (size_t)(n * cap * d) && (st = e->b_ev_th.alloc((size_t)(n * cap * d))) != PDMP_OK) return st;
     }
     HIP_TRY(hipMemcpy(e->b_x.p, x0, (size_t)(n * d) * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->b_th.p, theta0, (size_t)(n * d) * sizeof(double), hipMemcpyHostToDevice));
@@ -2775,6 +2781,77 @@ pdmp_status pdmp_ensemble_set_state_bps(pdmp_ensemble* e, double t0, const doubl
     e->ran = false;
     e->timed = false;
     return PDMP_OK;
+}
+
+// The Bouncy Particle streams every event's (x, θ) into two large arrays; whether those two allocations get along decides 4.5 or 5.3 ms per step of config
+// C2 (tools/mode_move_bps.py: moving either flips it; x, θ and the event times do not matter) -- the same property of the memory as init_state_tuned's.
+// With a trace of at least 2 GB per array: fill it once (every chain pauses when its segment is full), time that, give the θ array (then the x array) new hipMallocs,
+// keep the fastest pair, set the state again.
+pdmp_status pdmp_ensemble_set_state_bps(pdmp_ensemble* e, double t0, const double* x0, const double* theta0, double c,
+                                        const uint64_t* seeds) {
+    if (e) e->tune_log.clear();
+    pdmp_status st = init_state_bps(e, t0, x0, theta0, c, seeds);
+    if (st != PDMP_OK) return st;
+    const size_t ev_bytes = e->b_ev_th.n * sizeof(double);
+    size_t freeb = 0, totb = 0;
+    if (e->place_tune == 0 || e->cfg.trace_capacity <= 0 || ev_bytes < ((size_t)2 << 30) || e->b_ev_th.placed.va) return PDMP_OK;
+    if (hipMemGetInfo(&freeb, &totb) != hipSuccess || freeb < 6 * ev_bytes + ((size_t)8 << 30)) {
+        (void)hipGetLastError();
+        return PDMP_OK;
+    }
+    const auto t_begin = std::chrono::steady_clock::now();
+    std::vector<void*> ths{(void*)e->b_ev_th.p}, xs{(void*)e->b_ev_x.p};
+    struct Trial { size_t x, th; float ms; };
+    std::vector<Trial> trials;
+    auto measure = [&](size_t kx, size_t kth) -> pdmp_status {
+        e->b_ev_x.p = static_cast<double*>(xs[kx]);
+        e->b_ev_th.p = static_cast<double*>(ths[kth]);
+        pdmp_status r = trials.empty() ? PDMP_OK : init_state_bps(e, t0, x0, theta0, c, seeds);
+        if (r != PDMP_OK) return r;
+        if ((r = ensemble_run_impl(e, t0 + 1.0e30, PDMP_RUN_STOP_BEFORE, nullptr)) != PDMP_OK) return r;
+        float t = 0;
+        HIP_TRY(hipEventSynchronize(e->ev1));
+        HIP_TRY(hipEventElapsedTime(&t, e->ev0, e->ev1));
+        trials.push_back({kx, kth, t});
+        return PDMP_OK;
+    };
+    auto best = [&]() { return *std::min_element(trials.begin(), trials.end(), [](const Trial& a, const Trial& b) { return a.ms < b.ms; }); };
+    auto worst = [&]() { return *std::max_element(trials.begin(), trials.end(), [](const Trial& a, const Trial& b) { return a.ms < b.ms; }); };
+    // (three levels here: the trace filled in 5.9-6.1, 6.3 or 6.9-7.3 ms -- steps of 4.6, 4.9, 5.4 ms; done once the whole spread has been seen)
+    auto settled = [&]() { return trials.size() >= 2 && worst().ms > 1.15f * best().ms; };
+    st = measure(0, 0);
+    for (int step = 0; st == PDMP_OK && step < 5 && !settled(); ++step) {  // new θ arrays three times, then new x arrays twice
+        void* np = nullptr;
+        if (hipMalloc(&np, ev_bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+        }
+        if (step < 3) {
+            ths.push_back(np);
+            st = measure(best().x, ths.size() - 1);
+        } else {
+            xs.push_back(np);
+            st = measure(xs.size() - 1, best().th);
+        }
+    }
+    const Trial b = trials.empty() ? Trial{0, 0, 0.f} : best();
+    e->b_ev_x.p = static_cast<double*>(xs[b.x]);
+    e->b_ev_th.p = static_cast<double*>(ths[b.th]);
+    HIP_TRY(hipDeviceSynchronize());
+    for (size_t k = 0; k < ths.size(); ++k)
+        if (k != b.th) (void)hipFree(ths[k]);
+    for (size_t k = 0; k < xs.size(); ++k)
+        if (k != b.x) (void)hipFree(xs[k]);
+    pdmp_status st2 = init_state_bps(e, t0, x0, theta0, c, seeds);
+    char t[96];
+    e->tune_log = "placement probes (ms, the trace filled once):";
+    for (const Trial& q : trials) {
+        snprintf(t, sizeof t, " %.2f[x%zu th%zu]", q.ms, q.x, q.th);
+        e->tune_log += t;
+    }
+    snprintf(t, sizeof t, "; kept x%zu th%zu; %.2f s", b.x, b.th, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
+    e->tune_log += t;
+    return st != PDMP_OK ? st : st2;
 }
 
 pdmp_status pdmp_ensemble_bps_trace_copy(pdmp_ensemble* e, int64_t chain, int64_t first, int64_t count, double* t, double* x,
