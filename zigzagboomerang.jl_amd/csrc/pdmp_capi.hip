@@ -1498,7 +1498,8 @@ static pdmp_status ensemble_run_impl(pdmp_ensemble* e, double T, int flags, void
 // property of the allocation": the same binary, the same process, by the hipMalloc that backs either array).  No API shows the property, a few
 // milliseconds of the event loop do: after the state is set, a short launch (every chain pauses after PLACE_PROBE_DRAWS draws) is timed, the pairs --
 // then the records -- are given new allocations (the old ones stay reserved, so the new ones are other memory), the state is set again and the launch
-// repeated; the fastest combination is kept, the rest freed, and the state set one last time.  Every probe does identical work, so the times compare
+// repeated (pairs and records in turn, a spacer allocation before each so that it lands elsewhere); the fastest combination is kept, the rest freed, and
+// the state set one last time.  Every probe does identical work, so the times compare
 // directly; the ensemble the caller gets is bit for bit the one set_state alone would have made.  pdmp_debug_set_placement(ens, 0, ...) turns it off.
 #define PLACE_PROBE_DRAWS 12000u
 #define PLACE_TUNE_MIN_CHAINS 1024  // (the two modes were seen on launches that fill the device: 4096 chains; narrower ones are probed as well, it costs milliseconds)
@@ -1552,11 +1553,21 @@ static pdmp_status init_state_tuned(pdmp_ensemble* e, double t0, const double* x
     // both levels seen and the fast one in hand: done (the modes are 17 % apart; probes repeat to 1-2 %)
     auto settled = [&]() { return trials.size() >= 2 && worst().ms > 1.08f * best().ms; };
     st = measure(0, 0);
-    for (int step = 0; st == PDMP_OK && step < 5 && !settled(); ++step) {
-        // new pairs three times (1 GB), then new records twice (8 GB), each beside the best partner so far
-        void* np = nullptr;
-        const bool pairs_turn = step < 3;
-        if (hipMalloc(&np, pairs_turn ? kp_bytes : rec_bytes) != hipSuccess) {
+    // new pairs and new records in turn, at most four of each.  What matters is which REGIONS of the memory the two arrays lie in, and consecutive
+    // hipMallocs are neighbours: a spacer allocation (held to the end) goes before every candidate so that it lands somewhere else
+    std::vector<void*> spacers;
+    const size_t spacer_bytes = (size_t)6 << 30;
+    for (int step = 0; st == PDMP_OK && step < 8 && !settled(); ++step) {
+        const bool pairs_turn = (step & 1) == 0;
+        const size_t want = pairs_turn ? kp_bytes : rec_bytes;
+        if (hipMemGetInfo(&freeb, &totb) != hipSuccess || freeb < want + spacer_bytes + rec_bytes + kp_bytes + ((size_t)8 << 30)) {
+            (void)hipGetLastError();
+            break;
+        }
+        void *sp = nullptr, *np = nullptr;
+        if (hipMalloc(&sp, spacer_bytes) == hipSuccess) spacers.push_back(sp);
+        else (void)hipGetLastError();
+        if (hipMalloc(&np, want) != hipSuccess) {
             (void)hipGetLastError();
             break;
         }
@@ -1577,6 +1588,7 @@ static pdmp_status init_state_tuned(pdmp_ensemble* e, double t0, const double* x
         if (k != b.r) (void)hipFree(recs[k]);
     for (size_t k = 0; k < kps.size(); ++k)
         if (k != b.k) (void)hipFree(kps[k]);
+    for (void* sp : spacers) (void)hipFree(sp);
     pdmp_status st2 = init_state(e, t0, x0, th0, c, seeds, seed0);
     char t[96];
     snprintf(t, sizeof t, "placement probes (ms, %u draws per chain):", PLACE_PROBE_DRAWS);
