@@ -25,6 +25,7 @@ def _run(pkg, tracked, tune, nch, n, T, explicit_state):
         else:
             ens.set_state_synthetic(0.0, c, 0xABCD)
         log = ens.debug_placement()
+        assert ens.kernel_name() == ""  # (the probes' launches are not the caller's)
         cnt0 = ens.counters()
         assert int(cnt0["num"].sum()) == 0 and int(cnt0["ntrace"].sum()) == 0 and np.all(cnt0["status"] == pkg._lib.CHAIN_OK)
         while True:

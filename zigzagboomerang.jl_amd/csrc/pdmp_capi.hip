@@ -1590,6 +1590,7 @@ static pdmp_status init_state_tuned(pdmp_ensemble* e, double t0, const double* x
         if (k != b.k) (void)hipFree(kps[k]);
     for (void* sp : spacers) (void)hipFree(sp);
     pdmp_status st2 = init_state(e, t0, x0, th0, c, seeds, seed0);
+    e->last_kernel = "";  // (pdmp_debug_last_kernel: '' before the caller's first run)
     char t[96];
     snprintf(t, sizeof t, "placement probes (ms, %u draws per chain):", PLACE_PROBE_DRAWS);
     e->tune_log = t;
@@ -2855,6 +2856,7 @@ pdmp_status pdmp_ensemble_set_state_bps(pdmp_ensemble* e, double t0, const doubl
     for (size_t k = 0; k < xs.size(); ++k)
         if (k != b.x) (void)hipFree(xs[k]);
     pdmp_status st2 = init_state_bps(e, t0, x0, theta0, c, seeds);
+    e->last_kernel = "";
     char t[96];
     e->tune_log = "placement probes (ms, the trace filled once):";
     for (const Trial& q : trials) {
